@@ -1,0 +1,254 @@
+/* swp.h — C ABI of libswp.so, the MI355X-native batch task-placement engine.
+ *
+ * Drop-in boundary for swarmkit's manager/scheduler hot path. The reference has no FFI: the seam
+ * is Go-internal (Scheduler.nodeSet / Scheduler.pipeline, scheduler.go:32-51). Each entry point
+ * below names the reference interface it replaces (paths under /root/reference/). A thin cgo shim
+ *  keeps nodeSet's Go map as the source of truth for the non-numeric fields and
+ * mirrors every mutator call into the engine.
+ *
+ * Conventions
+ *   - returns 0 (SWP_OK) or a negative SWP_E*; no C++ exception crosses this boundary;
+ *   - every buffer is caller-allocated, caller-owned and only read/written during the call
+ *     (cgo pointer rules: the engine retains no caller pointer);
+ *   - the engine owns all device memory; one engine per Scheduler; NOT thread-safe: the caller
+ *     (the single scheduler goroutine, scheduler.go:175-237) serialises calls;
+ *   - strings never reach the device: they are interned to dense uint32 ids (0 = "" / absent);
+ *   - all structs are little-endian PODs with natural alignment; sizes are asserted in swp_abi_check().
+ *   - There is NO CPU implementation behind this ABI: without a gfx950 device swp_create()
+ *     fails with SWP_ENODEVICE and nothing else is usable.
+ */
+#ifndef SWP_H
+#define SWP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWP_ABI_VERSION 1
+
+enum {
+    SWP_OK = 0,
+    SWP_EINVAL = -1,       /* bad argument / unknown id */
+    SWP_ENOTFOUND = -2,    /* errNodeNotFound, nodeset.go:12 */
+    SWP_ENOMEM = -3,
+    SWP_EHIP = -4,         /* HIP runtime error; swp_last_error() has the text */
+    SWP_EUNSUPPORTED = -5, /* feature kept on the Go path (generic resources, CSI volumes, ...) */
+    SWP_ERANGE = -6,       /* value outside the engine's documented limits */
+    SWP_ENODEVICE = -7     /* no gfx950 device: the engine has no CPU fallback */
+};
+
+typedef struct swp_engine swp_engine;
+
+/* ------------------------------------------------------------------------------------------ */
+/* configuration                                                                               */
+typedef struct {
+    int32_t  device;        /* HIP device ordinal */
+    uint32_t window;        /* tasks per scan window; 0 = auto (about N/2, clamped) */
+    uint32_t resolver_threads; /* 0 = auto (256 or 1024 by node count) */
+    uint32_t flags;         /* SWP_CFG_* */
+    /* node-range shard owned by this engine for the sharded scan; [0,0) = all */
+    uint32_t shard_rank, shard_count;
+    uint32_t reserved[2];
+} swp_config;
+
+#define SWP_CFG_PROFILE 1u   /* record hipEvent timings per kernel class into swp_stats_t */
+
+/* ------------------------------------------------------------------------------------------ */
+/* interning — replaces every string compare on the path (constraint.go:90,109-203 EqualFold;   */
+/* filter.go:283-306 platform strings; filter.go:179-202 plugin names; nodeinfo.go map keys)    */
+enum {
+    SWP_SPACE_NODE_ID = 0,   /* api.Node.ID → dense node index (also the canonical scan order) */
+    SWP_SPACE_SERVICE = 1,   /* api.Task.ServiceID */
+    SWP_SPACE_LABEL_KEY = 2, /* label names, case-sensitive (constraint.go:180-182,195-196) */
+    SWP_SPACE_FOLDED = 3,    /* values compared with strings.EqualFold: label values, node.id,
+                                node.hostname, node.platform.os/arch constraint operands */
+    SWP_SPACE_OS = 4,        /* Platform.OS, case-sensitive (filter.go:302) */
+    SWP_SPACE_ARCH = 5,      /* Platform.Architecture after x86_64→amd64, aarch64→arm64 (filter.go:285-299) */
+    SWP_SPACE_PLUGIN = 6,    /* "<Type>\0<Name>" (filter.go:179-202) */
+    SWP_SPACE_COUNT = 7
+};
+/* id 0 is reserved for the empty string in every space except NODE_ID (node index 0 is a node). */
+int swp_intern(swp_engine*, int space, const char* utf8, size_t len, uint32_t* id_out);
+/* reverse lookup, for tests / debugging: copies up to cap bytes, returns the full length or <0 */
+int swp_intern_lookup(swp_engine*, int space, uint32_t id, char* out, size_t cap);
+
+/* ------------------------------------------------------------------------------------------ */
+/* node rows — NodeInfo numeric mirror (nodeinfo.go:28-44) plus the api.Node fields the filters */
+/* read                                                                  */
+#define SWP_NODE_READY        0x001u  /* Status.State==READY && Spec.Availability==ACTIVE (filter.go:41-44) */
+#define SWP_NODE_HAS_DESC     0x002u  /* Description != nil */
+#define SWP_NODE_HAS_PLATFORM 0x004u  /* Description.Platform != nil */
+#define SWP_NODE_HAS_ENGINE   0x008u  /* Description.Engine != nil */
+#define SWP_NODE_HAS_LABELS   0x010u  /* Spec.Annotations.Labels != nil */
+#define SWP_NODE_HAS_ELABELS  0x020u  /* Description.Engine.Labels != nil */
+#define SWP_NODE_MANAGER      0x040u  /* Role == MANAGER (constraint.go:148 compares Role.String()) */
+#define SWP_NODE_HAS_LOGPLUG  0x080u  /* Engine.Plugins lists at least one Type=="Log" (filter.go:169-175) */
+#define SWP_NODE_IP_VALID     0x100u  /* net.ParseIP(Status.Addr) != nil */
+#define SWP_NODE_IP_V4        0x200u  /* address is IPv4 (or IPv4-mapped) */
+
+typedef struct {
+    uint32_t node;        /* NODE_ID id */
+    uint32_t flags;       /* SWP_NODE_* */
+    int64_t  cpu;         /* AvailableResources.NanoCPUs   (may be negative, scheduler.go:378-379) */
+    int64_t  mem;         /* AvailableResources.MemoryBytes */
+    uint32_t total;       /* ActiveTasksCount */
+    uint32_t os;          /* SWP_SPACE_OS id   (platform filter) */
+    uint32_t arch;        /* SWP_SPACE_ARCH id (platform filter) */
+    uint32_t os_fold;     /* SWP_SPACE_FOLDED id of Platform.OS            (node.platform.os constraint) */
+    uint32_t arch_fold;   /* SWP_SPACE_FOLDED id of Platform.Architecture  (node.platform.arch) */
+    uint32_t hostname_fold; /* SWP_SPACE_FOLDED id of Description.Hostname (node.hostname) */
+    uint32_t id_fold;     /* SWP_SPACE_FOLDED id of Node.ID                (node.id) */
+    uint32_t reserved;
+    uint8_t  ip[16];      /* Status.Addr as 16-byte address (v4 as ::ffff:a.b.c.d) */
+    uint64_t version;     /* Meta.Version.Index — echoed by swp_node_get for the stale check, scheduler.go:540 */
+} swp_node_row;           /* 80 bytes */
+
+typedef struct { uint32_t key; uint32_t value; } swp_kv;   /* (LABEL_KEY id, FOLDED id) */
+
+/* nodeSet.alloc, nodeset.go:18-20: drop every node row and all derived state */
+int swp_reset(swp_engine*, uint32_t n_nodes_hint);
+/* nodeSet.addOrUpdateNode / updateNode (nodeset.go:33-44) as called from createOrUpdateNode
+ * (scheduler.go:368-396) and buildNodeSet (:973-990). Labels/plugins replace the previous ones. */
+int swp_node_upsert(swp_engine*, const swp_node_row* row,
+                    const swp_kv* node_labels, uint32_t n_node_labels,
+                    const swp_kv* engine_labels, uint32_t n_engine_labels,
+                    const uint32_t* plugins, uint32_t n_plugins);
+/* numeric-only fast path of swp_node_upsert: update flags/cpu/mem/total of an existing node
+ * (availability flips, resource reconciliation) without touching labels/plugins */
+int swp_node_update_dynamic(swp_engine*, uint32_t node, uint32_t flags, int64_t cpu, int64_t mem, uint32_t total);
+/* nodeSet.remove, nodeset.go:46-48 */
+int swp_node_remove(swp_engine*, uint32_t node);
+/* nodeSet.nodeInfo, nodeset.go:23-29: SWP_ENOTFOUND <-> errNodeNotFound */
+int swp_node_get(swp_engine*, uint32_t node, swp_node_row* out);
+/* NodeInfo.ActiveTasksCountByService[service] = count (nodeinfo.go:32) */
+int swp_node_set_svc_count(swp_engine*, uint32_t node, uint32_t service, uint32_t count);
+int swp_node_get_svc_count(swp_engine*, uint32_t node, uint32_t service, uint32_t* count_out);
+/* countRecentFailures(now, t) for (service, specVersion) on this node (nodeinfo.go:206-221), as
+ * evaluated by the shim at the `now` of the coming batch (scheduler.go:706). spec_version is 0
+ * for tasks without one (the zero api.Version). */
+int swp_node_set_failures(swp_engine*, uint32_t node, uint32_t service, uint64_t spec_version, uint32_t count);
+/* usedHostPorts insert/delete (nodeinfo.go:78-84,139-145). protocol: TCP 0 / UDP 1 / SCTP 2 */
+int swp_node_port(swp_engine*, uint32_t node, uint32_t protocol, uint32_t port, int set);
+
+/* ------------------------------------------------------------------------------------------ */
+/* task-side predicate sets (what Filter.SetTask extracts from a task, filter.go)               */
+enum {   /* constraint kinds, constraint.go:109-203 */
+    SWP_CK_NODE_ID = 0, SWP_CK_HOSTNAME = 1, SWP_CK_IP = 2, SWP_CK_ROLE = 3,
+    SWP_CK_PLATFORM_OS = 4, SWP_CK_PLATFORM_ARCH = 5, SWP_CK_NODE_LABEL = 6, SWP_CK_ENGINE_LABEL = 7,
+    SWP_CK_INVALID = 8   /* unknown key: false for both operators (constraint.go:200-203) */
+};
+enum { SWP_OP_EQ = 0, SWP_OP_NE = 1 };
+enum { SWP_IP_SINGLE = 0, SWP_IP_CIDR = 1, SWP_IP_MALFORMED = 2 };
+
+typedef struct {
+    uint32_t kind;       /* SWP_CK_* */
+    uint32_t op;         /* SWP_OP_* */
+    uint32_t key;        /* LABEL_KEY id for the two label kinds */
+    uint32_t value;      /* FOLDED id of the expression; for SWP_CK_ROLE: FOLDED id as well */
+    uint8_t  ip[16];     /* SWP_CK_IP: address / network (already masked) */
+    uint32_t ip_kind;    /* SWP_IP_* */
+    uint32_t prefix_len; /* bits, counted in the 128-bit form (v4 /24 → 120) */
+    uint32_t ip_is_v4;   /* the expression was written as IPv4 */
+    uint32_t reserved;
+} swp_constraint;        /* 48 bytes */
+
+typedef struct { uint32_t os; uint32_t arch; } swp_platform;   /* ids in OS / ARCH space; 0 = wildcard */
+typedef struct { uint32_t protocol; uint32_t port; } swp_port;
+
+/* ConstraintFilter.SetTask (filter.go:218-232): returns the id of the de-duplicated set */
+int swp_constraint_set(swp_engine*, const swp_constraint* cs, uint32_t n, uint32_t* id_out);
+/* PlatformFilter.SetTask (filter.go:253-263) */
+int swp_platform_set(swp_engine*, const swp_platform* ps, uint32_t n, uint32_t* id_out);
+/* PluginFilter.SetTask (filter.go:119-131): `required` = Volume/Network plugins that must exist;
+ * log_plugin = Log plugin id or 0 (filter.go:165-175) */
+int swp_plugin_set(swp_engine*, const uint32_t* required, uint32_t n, uint32_t log_plugin, uint32_t* id_out);
+/* HostPortFilter.SetTask (filter.go:322-333): host-mode published ports of the task */
+int swp_port_set(swp_engine*, const swp_port* ports, uint32_t n, uint32_t* id_out);
+
+#define SWP_TASK_RES_ENABLED 0x1u   /* ResourceFilter.SetTask returned true (filter.go:61-74) */
+
+typedef struct {
+    uint32_t service;        /* SERVICE id */
+    uint32_t flags;          /* SWP_TASK_* */
+    int64_t  cpu;            /* Reservations.NanoCPUs */
+    int64_t  mem;            /* Reservations.MemoryBytes */
+    uint32_t constraint_set; /* 0 = ConstraintFilter disabled */
+    uint32_t platform_set;   /* 0 = PlatformFilter disabled */
+    uint32_t plugin_set;     /* 0 = PluginFilter disabled */
+    uint32_t port_set;       /* 0 = HostPortFilter disabled */
+    uint64_t max_replicas;   /* 0 = MaxReplicasFilter disabled (filter.go:363-370) */
+    uint64_t spec_version;   /* SpecVersion.Index (0 when nil) — selects the failure bucket */
+    uint32_t reserved[2];
+} swp_task_desc;             /* 64 bytes */
+
+/* ------------------------------------------------------------------------------------------ */
+/* the hot path                                                                                */
+#define SWP_NFILTERS 8   /* Ready, Resource, Plugin, Constraint, Platform, HostPort, MaxReplicas, Volumes */
+
+/* Whole-tick batch for singleton groups == tick() over one-off tasks (scheduler.go:429-488 with
+ * scheduleTaskGroup :694-748 on a group of one, nodeSet.tree nodeset.go:50-124, Pipeline.Process
+ * pipeline.go:56-68, nodeLess :708-735) INCLUDING the residual update (nodeinfo.go:108-154).
+ * Tasks are placed in array order; each placement is visible to the next task.
+ *   out_node[i]      node index or -1 ("no suitable node")
+ *   out_fail_hist[i] per-filter first-failure counts over all nodes at the moment task i was
+ *                    tried (what Pipeline.Explain reads, pipeline.go:84-103); only written for
+ *                    tasks with out_node[i] == -1; may be NULL. */
+int swp_schedule_batch(swp_engine*, const swp_task_desc* tasks, uint32_t n_tasks,
+                       int32_t* out_node, uint32_t* out_fail_hist /* [n_tasks][SWP_NFILTERS] */);
+
+/* The same in three steps so that a caller (bench.py) can time the device pass alone:
+ *   prepare: de-duplicate predicate sets, upload descriptors and per-service state
+ *   run:     kernels only (class bitmaps → scan → resolve/commit → explain); asynchronous
+ *   fetch:   wait, copy results back, fold the placements into the host-side node mirror */
+typedef struct swp_batch swp_batch;
+int swp_batch_prepare(swp_engine*, const swp_task_desc* tasks, uint32_t n_tasks, swp_batch** out);
+int swp_batch_run(swp_engine*, swp_batch*);
+int swp_batch_fetch(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fail_hist);
+void swp_batch_free(swp_engine*, swp_batch*);
+/* Device-side snapshot / restore of all mutable node state (cpu, mem, total, per-service counts,
+ * host ports) so that a benchmark can replay the same batch from the same state. */
+int swp_state_save(swp_engine*);
+int swp_state_restore(swp_engine*);
+
+/* NodeInfo.addTask / removeTask for tasks the engine did not place itself (event handlers
+ * scheduler.go:254-366; rollback :472-487). add_or_remove: 1 = add, 0 = remove. */
+typedef struct {
+    uint32_t node;
+    uint32_t service;
+    int64_t  cpu, mem;
+    uint32_t port_set;     /* 0 = none */
+    uint32_t counted;      /* DesiredState <= COMPLETED: counts toward ActiveTasksCount* (nodeinfo.go:148) */
+} swp_placement;           /* 32 bytes */
+int swp_commit(swp_engine*, const swp_placement* p, uint32_t n, int add_or_remove);
+
+/* Pipeline.Process on ONE (task, node) pair == taskFitNode's check (scheduler.go:646-654).
+ * *first_fail = -1 on pass, else the index of the first failing filter. */
+int swp_check_node(swp_engine*, const swp_task_desc* task, uint32_t node, int32_t* first_fail);
+
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t batches, tasks, placed, infeasible;
+    uint64_t pair_evals;        /* Σ tasks × present nodes */
+    uint64_t verify_retries;    /* resolver candidates rejected by the freshness re-check */
+    uint64_t slow_path_tasks;   /* tasks resolved through the per-service exception list */
+    uint64_t rebase_events;
+    uint32_t n_nodes, n_words, last_windows, last_static_classes;
+    float    ms_classes, ms_scan, ms_resolve, ms_explain, ms_total;   /* last batch, SWP_CFG_PROFILE */
+    uint32_t scan_launches, resolve_launches;
+} swp_stats_t;
+
+int swp_create(const swp_config*, swp_engine** out);
+void swp_destroy(swp_engine*);
+int swp_stats(swp_engine*, swp_stats_t* out);
+const char* swp_strerror(int code);
+const char* swp_last_error(swp_engine*);   /* engine may be NULL: last swp_create failure */
+/* sizeof() of every ABI struct, so that a binding can assert its own layout */
+int swp_abi_check(uint32_t* sizes, uint32_t n);   /* order: config,node_row,kv,constraint,platform,port,task_desc,placement,stats */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWP_H */

@@ -1,0 +1,320 @@
+"""ctypes binding of include/swp.h (libswp.so). Mirrors the header 1:1; no placement logic here."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "swarmkit_amd", "csrc")
+LIB_PATH = os.path.join(ROOT, "swarmkit_amd", "lib", "libswp.so")
+
+SWP_OK, SWP_EINVAL, SWP_ENOTFOUND, SWP_ENOMEM, SWP_EHIP, SWP_EUNSUPPORTED, SWP_ERANGE, SWP_ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7
+(SPACE_NODE_ID, SPACE_SERVICE, SPACE_LABEL_KEY, SPACE_FOLDED, SPACE_OS, SPACE_ARCH, SPACE_PLUGIN) = range(7)
+NODE_READY, NODE_HAS_DESC, NODE_HAS_PLATFORM, NODE_HAS_ENGINE = 0x1, 0x2, 0x4, 0x8
+NODE_HAS_LABELS, NODE_HAS_ELABELS, NODE_MANAGER, NODE_HAS_LOGPLUG, NODE_IP_VALID, NODE_IP_V4 = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
+(CK_NODE_ID, CK_HOSTNAME, CK_IP, CK_ROLE, CK_PLATFORM_OS, CK_PLATFORM_ARCH, CK_NODE_LABEL, CK_ENGINE_LABEL, CK_INVALID) = range(9)
+OP_EQ, OP_NE = 0, 1
+IP_SINGLE, IP_CIDR, IP_MALFORMED = 0, 1, 2
+TASK_RES_ENABLED, TASK_UNCOUNTED = 0x1, 0x2
+CFG_PROFILE = 1
+NFILTERS = 8
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("window", C.c_uint32), ("resolver_threads", C.c_uint32), ("flags", C.c_uint32),
+                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+class NodeRow(C.Structure):
+    _fields_ = [("node", C.c_uint32), ("flags", C.c_uint32), ("cpu", C.c_int64), ("mem", C.c_int64), ("total", C.c_uint32),
+                ("os", C.c_uint32), ("arch", C.c_uint32), ("os_fold", C.c_uint32), ("arch_fold", C.c_uint32),
+                ("hostname_fold", C.c_uint32), ("id_fold", C.c_uint32), ("reserved", C.c_uint32), ("ip", C.c_uint8 * 16),
+                ("version", C.c_uint64)]
+
+
+class KV(C.Structure):
+    _fields_ = [("key", C.c_uint32), ("value", C.c_uint32)]
+
+
+class Constraint(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("op", C.c_uint32), ("key", C.c_uint32), ("value", C.c_uint32), ("ip", C.c_uint8 * 16),
+                ("ip_kind", C.c_uint32), ("prefix_len", C.c_uint32), ("ip_is_v4", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Platform(C.Structure):
+    _fields_ = [("os", C.c_uint32), ("arch", C.c_uint32)]
+
+
+class Port(C.Structure):
+    _fields_ = [("protocol", C.c_uint32), ("port", C.c_uint32)]
+
+
+class TaskDesc(C.Structure):
+    _fields_ = [("service", C.c_uint32), ("flags", C.c_uint32), ("cpu", C.c_int64), ("mem", C.c_int64),
+                ("constraint_set", C.c_uint32), ("platform_set", C.c_uint32), ("plugin_set", C.c_uint32), ("port_set", C.c_uint32),
+                ("max_replicas", C.c_uint64), ("spec_version", C.c_uint64), ("reserved", C.c_uint32 * 2)]
+
+
+class Placement(C.Structure):
+    _fields_ = [("node", C.c_uint32), ("service", C.c_uint32), ("cpu", C.c_int64), ("mem", C.c_int64), ("port_set", C.c_uint32),
+                ("counted", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("tasks", C.c_uint64), ("placed", C.c_uint64), ("infeasible", C.c_uint64),
+                ("pair_evals", C.c_uint64), ("verify_retries", C.c_uint64), ("slow_path_tasks", C.c_uint64), ("rebase_events", C.c_uint64),
+                ("n_nodes", C.c_uint32), ("n_words", C.c_uint32), ("last_windows", C.c_uint32), ("last_static_classes", C.c_uint32),
+                ("ms_classes", C.c_float), ("ms_scan", C.c_float), ("ms_resolve", C.c_float), ("ms_explain", C.c_float), ("ms_total", C.c_float),
+                ("scan_launches", C.c_uint32), ("resolve_launches", C.c_uint32)]
+
+
+# numpy views of the POD structs, for bulk construction
+TASK_DTYPE = np.dtype([("service", "<u4"), ("flags", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("constraint_set", "<u4"),
+                       ("platform_set", "<u4"), ("plugin_set", "<u4"), ("port_set", "<u4"), ("max_replicas", "<u8"),
+                       ("spec_version", "<u8"), ("reserved", "<u4", (2,))])
+PLACEMENT_DTYPE = np.dtype([("node", "<u4"), ("service", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("port_set", "<u4"), ("counted", "<u4")])
+assert TASK_DTYPE.itemsize == C.sizeof(TaskDesc) == 64
+assert PLACEMENT_DTYPE.itemsize == C.sizeof(Placement) == 32
+
+EXPORTS = [
+    "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
+    "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
+    "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_schedule_batch", "swp_batch_prepare",
+    "swp_batch_run", "swp_batch_fetch", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node",
+    "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check",
+]
+
+
+class SwpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"swp error {code}: {msg}")
+        self.code = code
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). In-tree output: swarmkit_amd/lib/libswp.so."""
+    srcs = [os.path.join(CSRC, f) for f in ("swp_engine.hip", "swp_device.hpp", "Makefile")] + [os.path.join(ROOT, "include", "swp.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        if os.path.exists(LIB_PATH):
+            return LIB_PATH
+        raise RuntimeError("hipcc not found and no prebuilt libswp.so")
+    r = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("libswp.so build failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build_library()
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, i64, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64, C.c_char_p
+    P = C.POINTER
+    sig = {
+        "swp_create": ([P(Config), P(vp)], C.c_int),
+        "swp_destroy": ([vp], None),
+        "swp_reset": ([vp, u32], C.c_int),
+        "swp_intern": ([vp, C.c_int, cp, C.c_size_t, P(u32)], C.c_int),
+        "swp_intern_lookup": ([vp, C.c_int, u32, cp, C.c_size_t], C.c_int),
+        "swp_node_upsert": ([vp, P(NodeRow), P(KV), u32, P(KV), u32, P(u32), u32], C.c_int),
+        "swp_node_update_dynamic": ([vp, u32, u32, i64, i64, u32], C.c_int),
+        "swp_node_remove": ([vp, u32], C.c_int),
+        "swp_node_get": ([vp, u32, P(NodeRow)], C.c_int),
+        "swp_node_set_svc_count": ([vp, u32, u32, u32], C.c_int),
+        "swp_node_get_svc_count": ([vp, u32, u32, P(u32)], C.c_int),
+        "swp_node_set_failures": ([vp, u32, u32, u64, u32], C.c_int),
+        "swp_node_port": ([vp, u32, u32, u32, C.c_int], C.c_int),
+        "swp_constraint_set": ([vp, P(Constraint), u32, P(u32)], C.c_int),
+        "swp_platform_set": ([vp, P(Platform), u32, P(u32)], C.c_int),
+        "swp_plugin_set": ([vp, P(u32), u32, u32, P(u32)], C.c_int),
+        "swp_port_set": ([vp, P(Port), u32, P(u32)], C.c_int),
+        "swp_schedule_batch": ([vp, vp, u32, vp, vp], C.c_int),
+        "swp_batch_prepare": ([vp, vp, u32, P(vp)], C.c_int),
+        "swp_batch_run": ([vp, vp], C.c_int),
+        "swp_batch_fetch": ([vp, vp, vp, vp], C.c_int),
+        "swp_batch_free": ([vp, vp], None),
+        "swp_state_save": ([vp], C.c_int),
+        "swp_state_restore": ([vp], C.c_int),
+        "swp_commit": ([vp, vp, u32, C.c_int], C.c_int),
+        "swp_check_node": ([vp, P(TaskDesc), u32, P(i32)], C.c_int),
+        "swp_stats": ([vp, P(Stats)], C.c_int),
+        "swp_strerror": ([C.c_int], cp),
+        "swp_last_error": ([vp], cp),
+        "swp_abi_check": ([P(u32), u32], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = res
+    sizes = (u32 * 16)()
+    n = L.swp_abi_check(sizes, 16)
+    want = [C.sizeof(x) for x in (Config, NodeRow, KV, Constraint, Platform, Port, TaskDesc, Placement, Stats)]
+    if list(sizes[:n]) != want:
+        raise RuntimeError(f"ABI struct size mismatch: lib {list(sizes[:n])} vs binding {want}")
+    _lib = L
+    return L
+
+
+class Batch:
+    def __init__(self, eng, handle, n):
+        self.eng, self.h, self.n = eng, handle, n
+
+    def run(self):
+        self.eng._ck(self.eng.L.swp_batch_run(self.eng.h, self.h))
+
+    def fetch(self, want_hist=True):
+        out = np.empty(self.n, dtype=np.int32)
+        hist = np.zeros((self.n, NFILTERS), dtype=np.uint32) if want_hist else None
+        self.eng._ck(self.eng.L.swp_batch_fetch(self.eng.h, self.h, out.ctypes.data, hist.ctypes.data if want_hist else None))
+        return out, hist
+
+    def free(self):
+        if self.h:
+            self.eng.L.swp_batch_free(self.eng.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One swp_engine handle. Raises SwpError(SWP_ENODEVICE) when no gfx950 is present: there is no CPU path."""
+
+    def __init__(self, device=0, window=0, resolver_threads=0, profile=False):
+        self.L = load_library()
+        cfg = Config(device=device, window=window, resolver_threads=resolver_threads, flags=CFG_PROFILE if profile else 0)
+        h = C.c_void_p()
+        rc = self.L.swp_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise SwpError(rc, self.L.swp_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.swp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise SwpError(rc, self.L.swp_strerror(rc).decode() + ": " + self.L.swp_last_error(self.h).decode())
+
+    def reset(self, hint=0):
+        self._ck(self.L.swp_reset(self.h, hint))
+
+    def intern(self, space, s):
+        b = s.encode() if isinstance(s, str) else s
+        out = C.c_uint32()
+        self._ck(self.L.swp_intern(self.h, space, b, len(b), C.byref(out)))
+        return out.value
+
+    def node_upsert(self, row, labels=(), engine_labels=(), plugins=()):
+        la = (KV * max(1, len(labels)))(*[KV(k, v) for k, v in labels])
+        ea = (KV * max(1, len(engine_labels)))(*[KV(k, v) for k, v in engine_labels])
+        pa = (C.c_uint32 * max(1, len(plugins)))(*plugins)
+        self._ck(self.L.swp_node_upsert(self.h, C.byref(row), la, len(labels), ea, len(engine_labels), pa, len(plugins)))
+
+    def node_update_dynamic(self, node, flags, cpu, mem, total):
+        self._ck(self.L.swp_node_update_dynamic(self.h, node, flags, cpu, mem, total))
+
+    def node_remove(self, node):
+        self._ck(self.L.swp_node_remove(self.h, node))
+
+    def node_get(self, node):
+        row = NodeRow()
+        rc = self.L.swp_node_get(self.h, node, C.byref(row))
+        if rc == SWP_ENOTFOUND:
+            return None
+        self._ck(rc)
+        return row
+
+    def node_set_svc_count(self, node, service, count):
+        self._ck(self.L.swp_node_set_svc_count(self.h, node, service, count))
+
+    def node_get_svc_count(self, node, service):
+        out = C.c_uint32()
+        self._ck(self.L.swp_node_get_svc_count(self.h, node, service, C.byref(out)))
+        return out.value
+
+    def node_set_failures(self, node, service, spec_version, count):
+        self._ck(self.L.swp_node_set_failures(self.h, node, service, spec_version, count))
+
+    def node_port(self, node, protocol, port, set_=True):
+        self._ck(self.L.swp_node_port(self.h, node, protocol, port, 1 if set_ else 0))
+
+    def constraint_set(self, cs):
+        arr = (Constraint * max(1, len(cs)))(*cs)
+        out = C.c_uint32()
+        self._ck(self.L.swp_constraint_set(self.h, arr, len(cs), C.byref(out)))
+        return out.value
+
+    def platform_set(self, ps):
+        arr = (Platform * max(1, len(ps)))(*[Platform(o, a) for o, a in ps])
+        out = C.c_uint32()
+        self._ck(self.L.swp_platform_set(self.h, arr, len(ps), C.byref(out)))
+        return out.value
+
+    def plugin_set(self, required, log_plugin=0):
+        arr = (C.c_uint32 * max(1, len(required)))(*required)
+        out = C.c_uint32()
+        self._ck(self.L.swp_plugin_set(self.h, arr, len(required), log_plugin, C.byref(out)))
+        return out.value
+
+    def port_set(self, ports):
+        arr = (Port * max(1, len(ports)))(*[Port(p, q) for p, q in ports])
+        out = C.c_uint32()
+        self._ck(self.L.swp_port_set(self.h, arr, len(ports), C.byref(out)))
+        return out.value
+
+    def schedule_batch(self, tasks, want_hist=True):
+        """tasks: numpy array of TASK_DTYPE. Returns (out_node int32[T], hist uint32[T,8] or None)."""
+        tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
+        n = len(tasks)
+        out = np.empty(n, dtype=np.int32)
+        hist = np.zeros((n, NFILTERS), dtype=np.uint32) if want_hist else None
+        self._ck(self.L.swp_schedule_batch(self.h, tasks.ctypes.data, n, out.ctypes.data, hist.ctypes.data if want_hist else None))
+        return out, hist
+
+    def batch_prepare(self, tasks):
+        tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
+        h = C.c_void_p()
+        self._ck(self.L.swp_batch_prepare(self.h, tasks.ctypes.data, len(tasks), C.byref(h)))
+        return Batch(self, h, len(tasks))
+
+    def state_save(self):
+        self._ck(self.L.swp_state_save(self.h))
+
+    def state_restore(self):
+        self._ck(self.L.swp_state_restore(self.h))
+
+    def commit(self, placements, add=True):
+        p = np.ascontiguousarray(placements, dtype=PLACEMENT_DTYPE)
+        self._ck(self.L.swp_commit(self.h, p.ctypes.data, len(p), 1 if add else 0))
+
+    def check_node(self, task, node):
+        t = np.ascontiguousarray(task, dtype=TASK_DTYPE).reshape(1)
+        ff = C.c_int32()
+        self._ck(self.L.swp_check_node(self.h, C.cast(t.ctypes.data, C.POINTER(TaskDesc)), node, C.byref(ff)))
+        return ff.value
+
+    def stats(self):
+        s = Stats()
+        self._ck(self.L.swp_stats(self.h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}

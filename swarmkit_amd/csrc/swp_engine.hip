@@ -1,0 +1,1233 @@
+// swp_engine.hip — host runtime behind include/swp.h (libswp.so).
+//
+// Owns: string interning, the host mirror of the nodeSet's numeric state, predicate-set
+// de-duplication, device memory, kernel sequencing. There is NO CPU placement path in here:
+// every placement decision is taken by the kernels in swp_device.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/swp.h"
+#include "swp_device.hpp"
+
+using namespace swpdev;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        release();
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Interner {
+    std::unordered_map<std::string, uint32_t> map;
+    std::vector<std::string> strs;
+    bool zero_is_empty = true;
+    void init(bool zero_empty) {
+        zero_is_empty = zero_empty;
+        map.clear();
+        strs.clear();
+        if (zero_empty) {
+            strs.emplace_back();
+            map.emplace(std::string(), 0u);
+        }
+    }
+    uint32_t get(const std::string& s) {
+        auto it = map.find(s);
+        if (it != map.end()) return it->second;
+        uint32_t id = (uint32_t)strs.size();
+        strs.push_back(s);
+        map.emplace(s, id);
+        return id;
+    }
+};
+
+// strings.EqualFold canonicalisation for the FOLDED space. Expressions are limited by the value
+// regexp (constraint.go:23-26) to ASCII plus the two runes RE2 folds onto ASCII letters
+// (U+212A KELVIN SIGN, U+017F LONG S), so mapping exactly those orbits onto lower-case ASCII and
+// leaving every other byte alone decides EqualFold(exp, value) by byte equality.
+std::string fold_canon(const char* s, size_t len) {
+    std::string out;
+    out.reserve(len);
+    for (size_t i = 0; i < len;) {
+        unsigned char c = (unsigned char)s[i];
+        if (c < 0x80) {
+            out.push_back((c >= 'A' && c <= 'Z') ? char(c + 32) : char(c));
+            ++i;
+        } else if (c == 0xE2 && i + 2 < len && (unsigned char)s[i + 1] == 0x84 && (unsigned char)s[i + 2] == 0xAA) {
+            out.push_back('k');
+            i += 3;
+        } else if (c == 0xC5 && i + 1 < len && (unsigned char)s[i + 1] == 0xBF) {
+            out.push_back('s');
+            i += 2;
+        } else {
+            out.push_back(char(c));
+            ++i;
+        }
+    }
+    return out;
+}
+
+struct HostNode {
+    bool present = false;
+    swp_node_row row{};
+    std::vector<swp_kv> labels, elabels;
+    std::vector<uint32_t> plugins;
+    std::map<uint32_t, uint32_t> svc;                             // service -> ActiveTasksCountByService
+    std::map<std::pair<uint32_t, uint64_t>, uint32_t> fails;      // (service, specVersion) -> recent failures
+    std::set<uint64_t> ports;                                     // protocol<<32 | port
+};
+
+inline uint64_t port_key(uint32_t proto, uint32_t port) { return ((uint64_t)proto << 32) | port; }
+inline uint64_t svcver_key(uint32_t svc, uint64_t ver) { return ((uint64_t)svc << 40) ^ ver * 0x9E3779B97F4A7C15ull; }
+
+}  // namespace
+
+struct swp_batch {
+    uint32_t T = 0;
+    std::vector<swp_task_desc> tasks;
+    std::vector<RTask> rt;
+    std::vector<uint32_t> svc_global;      // batch-local service -> SERVICE id
+    std::vector<uint32_t> list_off;        // [n_svc+1]
+    std::vector<uint32_t> list_node0, list_svc0, list_fail0;   // pristine lists
+    std::vector<uint32_t> xrow, xnode;     // scatter sources for X
+    std::vector<uint32_t> prow, pnode;     // scatter sources for portmap
+    std::vector<uint64_t> port_keys;       // batch-local port -> (proto,port)
+    std::vector<uint32_t> pset_off, pset_ids;
+    std::vector<uint32_t> con_off, plat_off, plug_off, plug_req;
+    std::vector<DevConstraint> cons;
+    std::vector<uint2> plats;
+    std::vector<uint4> triples;
+    uint32_t n_con = 0, n_plat = 0, n_plug = 0, n_sc = 0, n_svc = 0, n_ports = 0;
+    uint32_t window = 0, n_windows = 0;
+    bool ran = false;
+
+    DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
+    DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
+    DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
+    DevBuf d_con, d_plat, d_plug, d_sc, d_F, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
+};
+
+struct swp_engine {
+    swp_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    Interner spaces[SWP_SPACE_COUNT];
+    uint32_t role_worker = 0, role_manager = 0;
+
+    std::vector<HostNode> nodes;
+    uint32_t n_nodes = 0;   // highest node index in use + 1
+    uint32_t n_present = 0;
+    std::unordered_map<uint32_t, std::unordered_map<uint32_t, uint32_t>> svc_nodes;   // service -> node -> count (>0)
+    std::unordered_map<uint32_t, std::unordered_set<uint32_t>> fail_nodes;            // service -> nodes with failure records
+    std::unordered_map<uint64_t, std::unordered_set<uint32_t>> port_nodes;            // (proto,port) -> nodes
+
+    // predicate sets, de-duplicated by content
+    std::vector<std::vector<swp_constraint>> con_sets{1};
+    std::vector<std::vector<swp_platform>> plat_sets{1};
+    struct PlugSet { std::vector<uint32_t> required; uint32_t log = 0; };
+    std::vector<PlugSet> plug_sets{1};
+    std::vector<std::vector<swp_port>> port_sets{1};
+    std::map<std::string, uint32_t> con_index, plat_index, plug_index, port_index;
+
+    // label columns of attr[][]: 0 id, 1 hostname, 2 os, 3 arch, 4.. labels
+    std::map<uint32_t, uint32_t> node_label_col, engine_label_col;
+    uint32_t n_cols = 4;
+
+    // device node arrays
+    uint32_t ncap = 0;
+    DevBuf d_flags, d_cpu, d_mem, d_total, d_os, d_arch, d_attr, d_ip, d_plug_off, d_plug_ids, d_ready, d_valid;
+    DevBuf d_save_cpu, d_save_mem, d_save_total;
+    bool dev_static_dirty = true;    // flags/os/arch/attr/ip/plugins need a re-upload
+    bool dev_dynamic_dirty = true;   // cpu/mem/total need a re-upload
+    uint32_t dev_cols = 0;
+
+    // saved host state for swp_state_restore
+    struct Saved {
+        bool valid = false;
+        std::vector<HostNode> nodes;
+        decltype(svc_nodes) svc_nodes_;
+        decltype(port_nodes) port_nodes_;
+    } saved;
+
+    swp_stats_t stats{};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        last_error = buf;
+        return code;
+    }
+};
+
+#define HIPCHECK(e, call)                                                                             \
+    do {                                                                                              \
+        hipError_t _r = (call);                                                                       \
+        if (_r != hipSuccess) return (e)->fail(SWP_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+
+uint32_t n_words_of(uint32_t n) { return (n + 63) / 64; }
+
+template <class T>
+int upload(swp_engine* e, DevBuf& b, const std::vector<T>& v, size_t min_elems = 1) {
+    size_t bytes = std::max(v.size(), min_elems) * sizeof(T);
+    HIPCHECK(e, b.reserve(bytes));
+    if (!v.empty()) HIPCHECK(e, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    return SWP_OK;
+}
+
+void engine_reset_nodes(swp_engine* e) {
+    e->nodes.clear();
+    e->n_nodes = 0;
+    e->n_present = 0;
+    e->svc_nodes.clear();
+    e->fail_nodes.clear();
+    e->port_nodes.clear();
+    e->dev_static_dirty = true;
+    e->dev_dynamic_dirty = true;
+    e->saved.valid = false;
+}
+
+uint32_t label_value(const std::vector<swp_kv>& kv, uint32_t key) {
+    for (const swp_kv& x : kv)
+        if (x.key == key) return x.value;
+    return 0;
+}
+
+// Push the host mirror of the node rows to the device (bulk; node counts are ≤ ~1e5 and a tick
+// is preceded by few mutations, so whole-array uploads of the dirty group are the simple choice).
+int flush_nodes(swp_engine* e) {
+    uint32_t N = e->n_nodes;
+    uint32_t need_cap = std::max<uint32_t>(64, ((N + 63) / 64) * 64);
+    bool grow = need_cap > e->ncap || e->dev_cols != e->n_cols;
+    if (grow) {
+        e->ncap = std::max(need_cap, e->ncap);
+        e->dev_static_dirty = e->dev_dynamic_dirty = true;
+    }
+    uint32_t cap = e->ncap;
+    if (e->dev_static_dirty) {
+        std::vector<uint32_t> flags(cap, 0), os(cap, 0), arch(cap, 0), attr((size_t)e->n_cols * cap, 0), ip((size_t)cap * 4, 0);
+        std::vector<uint32_t> poff(cap + 1, 0), pids;
+        for (uint32_t n = 0; n < N; ++n) {
+            const HostNode& h = e->nodes[n];
+            poff[n] = (uint32_t)pids.size();
+            if (!h.present) continue;
+            flags[n] = (h.row.flags & 0x7FFFFFFFu) | DEV_VALID;
+            os[n] = h.row.os;
+            arch[n] = h.row.arch;
+            attr[0 * (size_t)cap + n] = h.row.id_fold;
+            attr[1 * (size_t)cap + n] = h.row.hostname_fold;
+            attr[2 * (size_t)cap + n] = h.row.os_fold;
+            attr[3 * (size_t)cap + n] = h.row.arch_fold;
+            for (auto& kc : e->node_label_col) attr[(size_t)kc.second * cap + n] = label_value(h.labels, kc.first);
+            for (auto& kc : e->engine_label_col) attr[(size_t)kc.second * cap + n] = label_value(h.elabels, kc.first);
+            for (int q = 0; q < 4; ++q)
+                ip[(size_t)n * 4 + q] = ((uint32_t)h.row.ip[4 * q] << 24) | ((uint32_t)h.row.ip[4 * q + 1] << 16) | ((uint32_t)h.row.ip[4 * q + 2] << 8) | h.row.ip[4 * q + 3];
+            pids.insert(pids.end(), h.plugins.begin(), h.plugins.end());
+        }
+        for (uint32_t n = N; n <= cap; ++n) poff[n] = (uint32_t)pids.size();
+        int rc;
+        if ((rc = upload(e, e->d_flags, flags))) return rc;
+        if ((rc = upload(e, e->d_os, os))) return rc;
+        if ((rc = upload(e, e->d_arch, arch))) return rc;
+        if ((rc = upload(e, e->d_attr, attr))) return rc;
+        if ((rc = upload(e, e->d_ip, ip))) return rc;
+        if ((rc = upload(e, e->d_plug_off, poff))) return rc;
+        if ((rc = upload(e, e->d_plug_ids, pids))) return rc;
+        HIPCHECK(e, e->d_ready.reserve((size_t)(cap / 64) * 8));
+        HIPCHECK(e, e->d_valid.reserve((size_t)(cap / 64) * 8));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));   // host vectors die at scope exit
+        e->dev_cols = e->n_cols;
+        e->dev_static_dirty = false;
+    }
+    if (e->dev_dynamic_dirty) {
+        std::vector<int64_t> cpu(cap, 0), mem(cap, 0);
+        std::vector<uint32_t> total(cap, 0);
+        for (uint32_t n = 0; n < N; ++n) {
+            const HostNode& h = e->nodes[n];
+            if (!h.present) continue;
+            cpu[n] = h.row.cpu;
+            mem[n] = h.row.mem;
+            total[n] = h.row.total;
+        }
+        int rc;
+        if ((rc = upload(e, e->d_cpu, cpu))) return rc;
+        if ((rc = upload(e, e->d_mem, mem))) return rc;
+        if ((rc = upload(e, e->d_total, total))) return rc;
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        e->dev_dynamic_dirty = false;
+    }
+    return SWP_OK;
+}
+
+NodeView node_view(swp_engine* e) {
+    NodeView nv{};
+    nv.n_nodes = e->n_nodes;
+    nv.n_words = n_words_of(e->n_nodes);
+    nv.ncap = e->ncap;
+    nv.flags = e->d_flags.as<uint32_t>();
+    nv.cpu = e->d_cpu.as<long long>();
+    nv.mem = e->d_mem.as<long long>();
+    nv.total = e->d_total.as<uint32_t>();
+    nv.os = e->d_os.as<uint32_t>();
+    nv.arch = e->d_arch.as<uint32_t>();
+    nv.attr = e->d_attr.as<uint32_t>();
+    nv.ip = e->d_ip.as<uint32_t>();
+    nv.plug_off = e->d_plug_off.as<uint32_t>();
+    nv.plug_ids = e->d_plug_ids.as<uint32_t>();
+    nv.role_worker = e->role_worker;
+    nv.role_manager = e->role_manager;
+    return nv;
+}
+
+template <class T>
+std::string bytes_of(const T* p, size_t n) { return std::string(reinterpret_cast<const char*>(p), n * sizeof(T)); }
+
+// ---- batch construction -------------------------------------------------------------------------
+int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch* b) {
+    b->T = T;
+    b->tasks.assign(tasks, tasks + T);
+    b->rt.resize(T);
+    std::unordered_map<uint32_t, uint32_t> con_local, plat_local, plug_local, pset_local, svc_local;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> sc_local;
+    std::vector<uint32_t> con_ids{0}, plat_ids{0}, plug_ids{0}, pset_ids_global;
+    std::vector<uint64_t> svc_ver;          // per local service: spec version used for failure lookup
+    std::vector<uint32_t> svc_ntasks;
+    std::vector<uint32_t> task_rank(T);
+    std::unordered_map<uint64_t, uint32_t> port_local;
+
+    for (uint32_t i = 0; i < T; ++i) {
+        const swp_task_desc& d = tasks[i];
+        if (d.constraint_set >= e->con_sets.size() || d.platform_set >= e->plat_sets.size() || d.plugin_set >= e->plug_sets.size() ||
+            d.port_set >= e->port_sets.size())
+            return e->fail(SWP_EINVAL, "task %u references an unknown predicate set", i);
+        if (d.service >= e->spaces[SWP_SPACE_SERVICE].strs.size()) return e->fail(SWP_EINVAL, "task %u: unknown service id %u", i, d.service);
+        RTask& r = b->rt[i];
+        std::memset(&r, 0, sizeof r);
+        r.cpu = d.cpu;
+        r.mem = d.mem;
+        r.flags = (d.flags & SWP_TASK_RES_ENABLED) ? RT_RES : 0u;
+        if (d.flags & 0x2u) r.flags |= RT_UNCOUNTED;
+        auto local = [](std::unordered_map<uint32_t, uint32_t>& m, std::vector<uint32_t>& ids, uint32_t g) -> uint32_t {
+            if (g == 0) return 0u;
+            auto it = m.find(g);
+            if (it != m.end()) return it->second;
+            uint32_t l = (uint32_t)ids.size();
+            ids.push_back(g);
+            m.emplace(g, l);
+            return l;
+        };
+        r.cls_con = local(con_local, con_ids, d.constraint_set);
+        r.cls_plat = local(plat_local, plat_ids, d.platform_set);
+        r.cls_plug = local(plug_local, plug_ids, d.plugin_set);
+        auto key = std::make_tuple(r.cls_con, r.cls_plat, r.cls_plug);
+        auto sit = sc_local.find(key);
+        if (sit == sc_local.end()) {
+            sit = sc_local.emplace(key, (uint32_t)b->triples.size()).first;
+            b->triples.push_back(uint4{r.cls_con, r.cls_plat, r.cls_plug, 0u});
+        }
+        r.sc = sit->second;
+        if (d.port_set) {
+            r.flags |= RT_PORTS;
+            auto pit = pset_local.find(d.port_set);
+            if (pit == pset_local.end()) {
+                pit = pset_local.emplace(d.port_set, (uint32_t)pset_ids_global.size()).first;
+                pset_ids_global.push_back(d.port_set);
+            }
+            r.pset = pit->second;
+        }
+        if (d.max_replicas) {
+            r.flags |= RT_MAXREP;
+            r.maxrep = d.max_replicas;
+        }
+        auto vit = svc_local.find(d.service);
+        if (vit == svc_local.end()) {
+            vit = svc_local.emplace(d.service, (uint32_t)b->svc_global.size()).first;
+            b->svc_global.push_back(d.service);
+            svc_ver.push_back(d.spec_version);
+            svc_ntasks.push_back(0);
+        } else if (svc_ver[vit->second] != d.spec_version) {
+            return e->fail(SWP_EUNSUPPORTED, "one batch mixes spec versions of service %u (one-off tasks have none)", d.service);
+        }
+        r.svc = vit->second;
+        task_rank[i] = svc_ntasks[r.svc]++;
+    }
+    b->n_svc = (uint32_t)b->svc_global.size();
+    b->n_sc = (uint32_t)b->triples.size();
+    b->n_con = (uint32_t)con_ids.size();
+    b->n_plat = (uint32_t)plat_ids.size();
+    b->n_plug = (uint32_t)plug_ids.size();
+
+    // per-service exception lists: nodes with svcCount>0 or ≥ maxFailures recent failures
+    b->list_off.assign(b->n_svc + 1, 0);
+    std::vector<uint32_t> init_cnt(b->n_svc, 0);
+    for (uint32_t s = 0; s < b->n_svc; ++s) {
+        uint32_t g = b->svc_global[s];
+        b->list_off[s] = (uint32_t)b->list_node0.size();
+        std::map<uint32_t, std::pair<uint32_t, uint32_t>> ent;   // node -> (svc, fail), node-ordered
+        auto sn = e->svc_nodes.find(g);
+        if (sn != e->svc_nodes.end())
+            for (auto& kv : sn->second)
+                if (kv.second > 0 && e->nodes[kv.first].present) ent[kv.first].first = kv.second;
+        auto fn = e->fail_nodes.find(g);
+        if (fn != e->fail_nodes.end())
+            for (uint32_t n : fn->second) {
+                if (!e->nodes[n].present) continue;
+                auto fit = e->nodes[n].fails.find({g, svc_ver[s]});
+                if (fit != e->nodes[n].fails.end() && fit->second >= MAX_FAILURES) ent[n].second = fit->second;
+            }
+        for (auto& kv : ent) {
+            if (kv.second.first == 0 && kv.second.second == 0) continue;
+            b->xrow.push_back(s);
+            b->xnode.push_back(kv.first);
+            b->list_node0.push_back(kv.first);
+            b->list_svc0.push_back(kv.second.first);
+            b->list_fail0.push_back(kv.second.second);
+        }
+        init_cnt[s] = (uint32_t)b->list_node0.size() - b->list_off[s];
+        for (uint32_t k = 0; k < svc_ntasks[s]; ++k) {
+            b->list_node0.push_back(LIST_EMPTY);
+            b->list_svc0.push_back(0);
+            b->list_fail0.push_back(0);
+        }
+    }
+    b->list_off[b->n_svc] = (uint32_t)b->list_node0.size();
+    for (uint32_t i = 0; i < T; ++i) b->rt[i].slot = b->list_off[b->rt[i].svc] + init_cnt[b->rt[i].svc] + task_rank[i];
+
+    // host ports
+    b->pset_off.assign(1, 0);
+    for (uint32_t gs : pset_ids_global) {
+        for (const swp_port& p : e->port_sets[gs]) {
+            uint64_t k = port_key(p.protocol, p.port);
+            auto it = port_local.find(k);
+            if (it == port_local.end()) {
+                it = port_local.emplace(k, (uint32_t)b->port_keys.size()).first;
+                b->port_keys.push_back(k);
+                auto pn = e->port_nodes.find(k);
+                if (pn != e->port_nodes.end())
+                    for (uint32_t n : pn->second)
+                        if (e->nodes[n].present) {
+                            b->prow.push_back(it->second);
+                            b->pnode.push_back(n);
+                        }
+            }
+            b->pset_ids.push_back(it->second);
+        }
+        b->pset_off.push_back((uint32_t)b->pset_ids.size());
+    }
+    b->n_ports = (uint32_t)b->port_keys.size();
+
+    // class tables (row 0 = "filter disabled")
+    b->con_off.assign(2, 0);   // row 0 ("filter disabled") is the empty range [0,0)
+    for (uint32_t l = 1; l < con_ids.size(); ++l) {
+        for (const swp_constraint& c : e->con_sets[con_ids[l]]) {
+            DevConstraint dc{};
+            dc.kind = c.kind;
+            dc.op = c.op;
+            dc.value = c.value;
+            dc.col = 0;
+            if (c.kind == SWP_CK_NODE_LABEL) {
+                auto it = e->node_label_col.find(c.key);
+                if (it == e->node_label_col.end()) return e->fail(SWP_EINVAL, "label column missing (internal)");
+                dc.col = it->second;
+            } else if (c.kind == SWP_CK_ENGINE_LABEL) {
+                auto it = e->engine_label_col.find(c.key);
+                if (it == e->engine_label_col.end()) return e->fail(SWP_EINVAL, "engine label column missing (internal)");
+                dc.col = it->second;
+            }
+            for (int q = 0; q < 4; ++q)
+                dc.ip[q] = ((uint32_t)c.ip[4 * q] << 24) | ((uint32_t)c.ip[4 * q + 1] << 16) | ((uint32_t)c.ip[4 * q + 2] << 8) | c.ip[4 * q + 3];
+            dc.ip_kind = c.ip_kind;
+            dc.prefix_len = c.prefix_len;
+            dc.ip_is_v4 = c.ip_is_v4;
+            b->cons.push_back(dc);
+        }
+        b->con_off.push_back((uint32_t)b->cons.size());
+    }
+    b->plat_off.assign(2, 0);
+    for (uint32_t l = 1; l < plat_ids.size(); ++l) {
+        for (const swp_platform& p : e->plat_sets[plat_ids[l]]) b->plats.push_back(uint2{p.os, p.arch});
+        b->plat_off.push_back((uint32_t)b->plats.size());
+    }
+    b->plug_off.assign(2, 0);
+    for (uint32_t l = 1; l < plug_ids.size(); ++l) {
+        const swp_engine::PlugSet& ps = e->plug_sets[plug_ids[l]];
+        b->plug_req.push_back(ps.log);
+        b->plug_req.insert(b->plug_req.end(), ps.required.begin(), ps.required.end());
+        b->plug_off.push_back((uint32_t)b->plug_req.size());
+    }
+    return SWP_OK;
+}
+
+int upload_batch(swp_engine* e, swp_batch* b) {
+    const uint32_t Wn = n_words_of(e->n_nodes);
+    const uint32_t T = b->T;
+    int rc;
+    if ((rc = upload(e, b->d_rt, b->rt))) return rc;
+    if ((rc = upload(e, b->d_list_node0, b->list_node0))) return rc;
+    if ((rc = upload(e, b->d_list_svc0, b->list_svc0))) return rc;
+    if ((rc = upload(e, b->d_list_fail0, b->list_fail0))) return rc;
+    if ((rc = upload(e, b->d_list_off, b->list_off))) return rc;
+    if ((rc = upload(e, b->d_xrow, b->xrow))) return rc;
+    if ((rc = upload(e, b->d_xnode, b->xnode))) return rc;
+    if ((rc = upload(e, b->d_prow, b->prow))) return rc;
+    if ((rc = upload(e, b->d_pnode, b->pnode))) return rc;
+    if ((rc = upload(e, b->d_pset_off, b->pset_off))) return rc;
+    if ((rc = upload(e, b->d_pset_ids, b->pset_ids))) return rc;
+    if ((rc = upload(e, b->d_con_off, b->con_off))) return rc;
+    if ((rc = upload(e, b->d_cons, b->cons))) return rc;
+    if ((rc = upload(e, b->d_plat_off, b->plat_off))) return rc;
+    if ((rc = upload(e, b->d_plats, b->plats))) return rc;
+    if ((rc = upload(e, b->d_plug_off, b->plug_off))) return rc;
+    if ((rc = upload(e, b->d_plug_req, b->plug_req))) return rc;
+    if ((rc = upload(e, b->d_triples, b->triples))) return rc;
+    size_t L = std::max<size_t>(b->list_node0.size(), 1);
+    HIPCHECK(e, b->d_list_node.reserve(L * 4));
+    HIPCHECK(e, b->d_list_svc.reserve(L * 4));
+    HIPCHECK(e, b->d_list_fail.reserve(L * 4));
+    HIPCHECK(e, b->d_out.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_hist.reserve((size_t)T * 8 * 4));
+    HIPCHECK(e, b->d_X.reserve((size_t)std::max<uint32_t>(b->n_svc, 1) * Wn * 8));
+    HIPCHECK(e, b->d_portmap.reserve((size_t)std::max<uint32_t>(b->n_ports, 1) * Wn * 8));
+    HIPCHECK(e, b->d_con.reserve((size_t)b->n_con * Wn * 8));
+    HIPCHECK(e, b->d_plat.reserve((size_t)b->n_plat * Wn * 8));
+    HIPCHECK(e, b->d_plug.reserve((size_t)b->n_plug * Wn * 8));
+    HIPCHECK(e, b->d_sc.reserve((size_t)b->n_sc * Wn * 8));
+    uint32_t W = e->cfg.window;
+    if (W == 0) {
+        W = std::max<uint32_t>(e->n_nodes / 2, 1024);
+        W = std::min<uint32_t>(W, 65536);
+    }
+    W = ((W + 63) / 64) * 64;
+    W = std::min<uint32_t>(W, ((T + 63) / 64) * 64);
+    b->window = W;
+    b->n_windows = (T + W - 1) / W;
+    HIPCHECK(e, b->d_F.reserve((size_t)W * Wn * 8));
+    HIPCHECK(e, b->d_log_node.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_log_task.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_log_prev.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_last.reserve((size_t)std::max<uint32_t>(e->n_nodes, 1) * 4));
+    HIPCHECK(e, b->d_inf_task.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_inf_pos.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_ctl.reserve(sizeof(Ctl)));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return SWP_OK;
+}
+
+template <int K>
+hipError_t launch_resolve(const ResolveArgs& ra, uint32_t threads, size_t lds, hipStream_t s) {
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (r != hipSuccess) return r;
+    hipLaunchKernelGGL(k_resolve<K>, dim3(1), dim3(threads), lds, s, ra);
+    return hipGetLastError();
+}
+
+int run_classes(swp_engine* e, swp_batch* b) {
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N);
+    NodeView nv = node_view(e);
+    dim3 blk(256);
+    uint32_t gx = (N + 255) / 256;
+    hipLaunchKernelGGL(k_ready, dim3(gx), blk, 0, e->stream, nv, e->d_ready.as<u64>(), e->d_valid.as<u64>());
+    if (b->n_con > 1)
+        hipLaunchKernelGGL(k_constraint_classes, dim3(gx, b->n_con - 1), blk, 0, e->stream, nv, b->d_con_off.as<uint32_t>(),
+                           b->d_cons.as<DevConstraint>(), b->d_con.as<u64>());
+    if (b->n_plat > 1)
+        hipLaunchKernelGGL(k_platform_classes, dim3(gx, b->n_plat - 1), blk, 0, e->stream, nv, b->d_plat_off.as<uint32_t>(),
+                           b->d_plats.as<uint2>(), b->d_plat.as<u64>());
+    if (b->n_plug > 1)
+        hipLaunchKernelGGL(k_plugin_classes, dim3(gx, b->n_plug - 1), blk, 0, e->stream, nv, b->d_plug_off.as<uint32_t>(),
+                           b->d_plug_req.as<uint32_t>(), b->d_plug.as<u64>());
+    hipLaunchKernelGGL(k_static_combine, dim3((Wn + 255) / 256, b->n_sc), blk, 0, e->stream, Wn, b->n_sc, b->d_triples.as<uint4>(),
+                       e->d_ready.as<u64>(), b->d_con.as<u64>(), b->d_plat.as<u64>(), b->d_plug.as<u64>(), b->d_sc.as<u64>());
+    HIPCHECK(e, hipGetLastError());
+    return SWP_OK;
+}
+
+int batch_run(swp_engine* e, swp_batch* b) {
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N), T = b->T;
+    if (N == 0 || T == 0) { b->ran = true; return SWP_OK; }
+    const bool prof = (e->cfg.flags & SWP_CFG_PROFILE) != 0;
+    hipStream_t st = e->stream;
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[0], st));
+
+    // per-batch device state back to pristine
+    size_t L = b->list_node0.size();
+    if (L) {
+        HIPCHECK(e, hipMemcpyAsync(b->d_list_node.p, b->d_list_node0.p, L * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(e, hipMemcpyAsync(b->d_list_svc.p, b->d_list_svc0.p, L * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(e, hipMemcpyAsync(b->d_list_fail.p, b->d_list_fail0.p, L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHECK(e, hipMemsetAsync(b->d_X.p, 0, (size_t)std::max<uint32_t>(b->n_svc, 1) * Wn * 8, st));
+    HIPCHECK(e, hipMemsetAsync(b->d_portmap.p, 0, (size_t)std::max<uint32_t>(b->n_ports, 1) * Wn * 8, st));
+    HIPCHECK(e, hipMemsetAsync(b->d_last.p, 0xFF, (size_t)N * 4, st));
+    HIPCHECK(e, hipMemsetAsync(b->d_ctl.p, 0, sizeof(Ctl), st));
+    HIPCHECK(e, hipMemsetAsync(b->d_hist.p, 0, (size_t)T * 8 * 4, st));
+    if (!b->xrow.empty())
+        hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b->xrow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b->xrow.size(),
+                           b->d_xrow.as<uint32_t>(), b->d_xnode.as<uint32_t>(), Wn, b->d_X.as<u64>());
+    if (!b->prow.empty())
+        hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b->prow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b->prow.size(),
+                           b->d_prow.as<uint32_t>(), b->d_pnode.as<uint32_t>(), Wn, b->d_portmap.as<u64>());
+    int rc = run_classes(e, b);
+    if (rc) return rc;
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[1], st));
+
+    // resolver geometry
+    uint32_t threads = e->cfg.resolver_threads;
+    if (threads == 0) threads = Wn <= 256 ? 256 : 1024;
+    threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, (threads / 64) * 64));
+    uint32_t K = (Wn + threads - 1) / threads;
+    if (K > 16) return e->fail(SWP_ERANGE, "node count %u exceeds the single-GPU resolver (shard the node set)", N);
+    const size_t lds_budget = 160 * 1024 - 512;
+    const size_t fixed = (size_t)Wn * 8 + 2 * 16 * 8 + 64;
+    if (fixed + (size_t)Wn * 8 * 2 > lds_budget) return e->fail(SWP_ERANGE, "node count %u: level planes do not fit LDS (shard the node set)", N);
+    uint32_t nb_alloc = (uint32_t)std::min<size_t>(16, (lds_budget - fixed) / ((size_t)Wn * 8));
+    size_t lds = fixed + (size_t)nb_alloc * Wn * 8;
+
+    float ms_scan = 0, ms_res = 0;
+    (void)ms_scan;
+    (void)ms_res;
+    for (uint32_t wi = 0; wi < b->n_windows; ++wi) {
+        uint32_t j0 = wi * b->window, cnt = std::min(b->window, T - j0);
+        ScanArgs sa{};
+        sa.n_nodes = N;
+        sa.n_words = Wn;
+        sa.j0 = j0;
+        sa.count = cnt;
+        sa.cpu = e->d_cpu.as<long long>();
+        sa.mem = e->d_mem.as<long long>();
+        sa.rt = b->d_rt.as<RTask>();
+        sa.sc = b->d_sc.as<u64>();
+        sa.portmap = b->d_portmap.as<u64>();
+        sa.pset_off = b->d_pset_off.as<uint32_t>();
+        sa.pset_ids = b->d_pset_ids.as<uint32_t>();
+        sa.F = b->d_F.as<u64>();
+        dim3 sgrid((Wn + SCAN_WPW - 1) / SCAN_WPW, (cnt + SCAN_TCH - 1) / SCAN_TCH);
+        hipLaunchKernelGGL(k_scan, sgrid, dim3(64), 0, st, sa);
+
+        ResolveArgs ra{};
+        ra.n_nodes = N;
+        ra.n_words = Wn;
+        ra.j0 = j0;
+        ra.count = cnt;
+        ra.nb_alloc = nb_alloc;
+        ra.F = b->d_F.as<u64>();
+        ra.valid = e->d_valid.as<u64>();
+        ra.X = b->d_X.as<u64>();
+        ra.rt = b->d_rt.as<RTask>();
+        ra.cpu = e->d_cpu.as<long long>();
+        ra.mem = e->d_mem.as<long long>();
+        ra.total = e->d_total.as<uint32_t>();
+        ra.list_node = b->d_list_node.as<uint32_t>();
+        ra.list_svc = b->d_list_svc.as<uint32_t>();
+        ra.list_fail = b->d_list_fail.as<uint32_t>();
+        ra.list_off = b->d_list_off.as<uint32_t>();
+        ra.portmap = b->d_portmap.as<u64>();
+        ra.pset_off = b->d_pset_off.as<uint32_t>();
+        ra.pset_ids = b->d_pset_ids.as<uint32_t>();
+        ra.out_node = b->d_out.as<int32_t>();
+        ra.log_node = b->d_log_node.as<uint32_t>();
+        ra.log_task = b->d_log_task.as<uint32_t>();
+        ra.log_prev = b->d_log_prev.as<int32_t>();
+        ra.last = b->d_last.as<int32_t>();
+        ra.inf_task = b->d_inf_task.as<uint32_t>();
+        ra.inf_pos = b->d_inf_pos.as<uint32_t>();
+        ra.ctl = b->d_ctl.as<Ctl>();
+        hipError_t r;
+        switch (K) {
+        case 1: r = launch_resolve<1>(ra, threads, lds, st); break;
+        case 2: r = launch_resolve<2>(ra, threads, lds, st); break;
+        case 3: case 4: r = launch_resolve<4>(ra, threads, lds, st); break;
+        case 5: case 6: case 7: case 8: r = launch_resolve<8>(ra, threads, lds, st); break;
+        default: r = launch_resolve<16>(ra, threads, lds, st); break;
+        }
+        if (r != hipSuccess) return e->fail(SWP_EHIP, "k_resolve launch: %s", hipGetErrorString(r));
+    }
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
+
+    // explain pass: needs the number of unplaceable tasks (one small D2H, once per batch)
+    Ctl ctl{};
+    HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
+    HIPCHECK(e, hipStreamSynchronize(st));
+    if (ctl.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the level planes that fit in LDS");
+    if (ctl.ninf) {
+        ExplainArgs xa{};
+        xa.n_nodes = N;
+        xa.n_words = Wn;
+        xa.n_inf = ctl.ninf;
+        xa.inf_task = b->d_inf_task.as<uint32_t>();
+        xa.inf_pos = b->d_inf_pos.as<uint32_t>();
+        xa.rt = b->d_rt.as<RTask>();
+        xa.valid = e->d_valid.as<u64>();
+        xa.ready = e->d_ready.as<u64>();
+        xa.con = b->d_con.as<u64>();
+        xa.plat = b->d_plat.as<u64>();
+        xa.plug = b->d_plug.as<u64>();
+        xa.cpu = e->d_cpu.as<long long>();
+        xa.mem = e->d_mem.as<long long>();
+        xa.portmap = b->d_portmap.as<u64>();
+        xa.pset_off = b->d_pset_off.as<uint32_t>();
+        xa.pset_ids = b->d_pset_ids.as<uint32_t>();
+        xa.list_node = b->d_list_node.as<uint32_t>();
+        xa.list_svc = b->d_list_svc.as<uint32_t>();
+        xa.list_off = b->d_list_off.as<uint32_t>();
+        xa.log_task = b->d_log_task.as<uint32_t>();
+        xa.log_prev = b->d_log_prev.as<int32_t>();
+        xa.last = b->d_last.as<int32_t>();
+        xa.hist = b->d_hist.as<uint32_t>();
+        uint32_t done = 0;
+        while (done < ctl.ninf) {   // grid.y ≤ 65535
+            uint32_t chunk = std::min<uint32_t>(ctl.ninf - done, 32768);
+            ExplainArgs xc = xa;
+            xc.inf_task += done;
+            xc.inf_pos += done;
+            hipLaunchKernelGGL(k_explain, dim3((N + 255) / 256, chunk), dim3(256), 0, st, xc);
+            done += chunk;
+        }
+        HIPCHECK(e, hipGetLastError());
+    }
+    if (prof) {
+        HIPCHECK(e, hipEventRecord(e->ev[3], st));
+        HIPCHECK(e, hipEventSynchronize(e->ev[3]));
+        float a = 0, c = 0, d = 0, t = 0;
+        (void)hipEventElapsedTime(&a, e->ev[0], e->ev[1]);
+        (void)hipEventElapsedTime(&c, e->ev[1], e->ev[2]);
+        (void)hipEventElapsedTime(&d, e->ev[2], e->ev[3]);
+        (void)hipEventElapsedTime(&t, e->ev[0], e->ev[3]);
+        e->stats.ms_classes = a;
+        e->stats.ms_scan = 0;
+        e->stats.ms_resolve = c;   // scan+resolve interleaved per window
+        e->stats.ms_explain = d;
+        e->stats.ms_total = t;
+    }
+    e->stats.verify_retries += ctl.verify_retries;
+    e->stats.slow_path_tasks += ctl.slow_tasks;
+    e->stats.rebase_events += ctl.rebases;
+    e->stats.last_windows = b->n_windows;
+    e->stats.last_static_classes = b->n_sc;
+    e->stats.scan_launches += b->n_windows;
+    e->stats.resolve_launches += b->n_windows;
+    b->ran = true;
+    return SWP_OK;
+}
+
+void host_apply_placement(swp_engine* e, uint32_t node, uint32_t service, int64_t cpu, int64_t mem, uint32_t port_set, bool counted, bool add) {
+    HostNode& h = e->nodes[node];
+    if (add) {
+        h.row.cpu -= cpu;
+        h.row.mem -= mem;
+    } else {
+        h.row.cpu += cpu;
+        h.row.mem += mem;
+    }
+    if (counted) {
+        if (add) {
+            h.row.total += 1;
+            uint32_t c = ++h.svc[service];
+            e->svc_nodes[service][node] = c;
+        } else {
+            h.row.total -= 1;
+            uint32_t& c = h.svc[service];
+            c -= 1;   // may wrap like Go's int going negative would not; counts are never negative on this path
+            if (c == 0) {
+                h.svc.erase(service);
+                e->svc_nodes[service].erase(node);
+            } else {
+                e->svc_nodes[service][node] = c;
+            }
+        }
+    }
+    if (port_set)
+        for (const swp_port& p : e->port_sets[port_set]) {
+            uint64_t k = port_key(p.protocol, p.port);
+            if (add) {
+                h.ports.insert(k);
+                e->port_nodes[k].insert(node);
+            } else {
+                h.ports.erase(k);   // removeTask deletes unconditionally (nodeinfo.go:78-84)
+                e->port_nodes[k].erase(node);
+            }
+        }
+}
+
+template <class Set, class Index, class Vec>
+int register_set(Index& index, Vec& sets, const std::string& key, Set&& value, uint32_t* id_out) {
+    auto it = index.find(key);
+    if (it != index.end()) {
+        *id_out = it->second;
+        return SWP_OK;
+    }
+    uint32_t id = (uint32_t)sets.size();
+    sets.push_back(std::forward<Set>(value));
+    index.emplace(key, id);
+    *id_out = id;
+    return SWP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* swp_strerror(int code) {
+    switch (code) {
+    case SWP_OK: return "ok";
+    case SWP_EINVAL: return "invalid argument";
+    case SWP_ENOTFOUND: return "node not found in scheduler dataset";   // errNodeNotFound, nodeset.go:12
+    case SWP_ENOMEM: return "out of memory";
+    case SWP_EHIP: return "HIP runtime error";
+    case SWP_EUNSUPPORTED: return "unsupported on the device path";
+    case SWP_ERANGE: return "value outside engine limits";
+    case SWP_ENODEVICE: return "no gfx950 device (the engine has no CPU fallback)";
+    }
+    return "unknown error";
+}
+
+const char* swp_last_error(swp_engine* e) { return e ? e->last_error.c_str() : g_create_error.c_str(); }
+
+int swp_abi_check(uint32_t* sizes, uint32_t n) {
+    const uint32_t s[] = {sizeof(swp_config), sizeof(swp_node_row), sizeof(swp_kv), sizeof(swp_constraint), sizeof(swp_platform),
+                          sizeof(swp_port), sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t)};
+    uint32_t m = sizeof s / sizeof s[0];
+    for (uint32_t i = 0; i < n && i < m; ++i) sizes[i] = s[i];
+    return (int)m;
+}
+
+int swp_create(const swp_config* cfg, swp_engine** out) {
+    if (!out) return SWP_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t r = hipGetDeviceCount(&count);
+    if (r != hipSuccess || count == 0) {
+        g_create_error = std::string("no HIP device: ") + (r == hipSuccess ? "device count is 0" : hipGetErrorString(r));
+        return SWP_ENODEVICE;
+    }
+    int dev = cfg ? cfg->device : 0;
+    if (dev < 0 || dev >= count) {
+        g_create_error = "device ordinal out of range";
+        return SWP_EINVAL;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is not gfx950: ") + prop.gcnArchName;
+        return SWP_ENODEVICE;
+    }
+    auto e = std::make_unique<swp_engine>();
+    if (cfg) e->cfg = *cfg;
+    e->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_error = "hipStreamCreate failed";
+        return SWP_EHIP;
+    }
+    for (auto& ev : e->ev)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            g_create_error = "hipEventCreate failed";
+            return SWP_EHIP;
+        }
+    for (int s = 0; s < SWP_SPACE_COUNT; ++s) e->spaces[s].init(s != SWP_SPACE_NODE_ID);
+    e->role_worker = e->spaces[SWP_SPACE_FOLDED].get("worker");
+    e->role_manager = e->spaces[SWP_SPACE_FOLDED].get("manager");
+    *out = e.release();
+    return SWP_OK;
+}
+
+void swp_destroy(swp_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int swp_reset(swp_engine* e, uint32_t n_nodes_hint) {
+    if (!e) return SWP_EINVAL;
+    engine_reset_nodes(e);
+    e->spaces[SWP_SPACE_NODE_ID].init(false);
+    e->nodes.reserve(n_nodes_hint);
+    return SWP_OK;
+}
+
+int swp_intern(swp_engine* e, int space, const char* utf8, size_t len, uint32_t* id_out) {
+    if (!e || space < 0 || space >= SWP_SPACE_COUNT || !id_out || (!utf8 && len)) return SWP_EINVAL;
+    std::string s = space == SWP_SPACE_FOLDED ? fold_canon(utf8, len) : std::string(utf8 ? utf8 : "", len);
+    if (space == SWP_SPACE_ARCH) {   // filter.go:285-299
+        if (s == "x86_64") s = "amd64";
+        else if (s == "aarch64") s = "arm64";
+    }
+    *id_out = e->spaces[space].get(s);
+    return SWP_OK;
+}
+
+int swp_intern_lookup(swp_engine* e, int space, uint32_t id, char* out, size_t cap) {
+    if (!e || space < 0 || space >= SWP_SPACE_COUNT) return SWP_EINVAL;
+    const auto& strs = e->spaces[space].strs;
+    if (id >= strs.size()) return SWP_ENOTFOUND;
+    const std::string& s = strs[id];
+    if (out && cap) std::memcpy(out, s.data(), std::min(cap, s.size()));
+    return (int)s.size();
+}
+
+int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* node_labels, uint32_t n_node_labels, const swp_kv* engine_labels,
+                    uint32_t n_engine_labels, const uint32_t* plugins, uint32_t n_plugins) {
+    if (!e || !row) return SWP_EINVAL;
+    if (row->node >= e->spaces[SWP_SPACE_NODE_ID].strs.size()) return e->fail(SWP_EINVAL, "node id %u was never interned", row->node);
+    if (row->total >= (1u << 30)) return e->fail(SWP_ERANGE, "ActiveTasksCount out of range");
+    if (row->node >= e->nodes.size()) e->nodes.resize(row->node + 1);
+    HostNode& h = e->nodes[row->node];
+    if (!h.present) e->n_present++;
+    h.present = true;
+    h.row = *row;
+    h.labels.assign(node_labels, node_labels + n_node_labels);
+    h.elabels.assign(engine_labels, engine_labels + n_engine_labels);
+    h.plugins.assign(plugins, plugins + n_plugins);
+    e->n_nodes = std::max(e->n_nodes, row->node + 1);
+    e->dev_static_dirty = e->dev_dynamic_dirty = true;
+    return SWP_OK;
+}
+
+int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_t cpu, int64_t mem, uint32_t total) {
+    if (!e) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    HostNode& h = e->nodes[node];
+    if (h.row.flags != flags) e->dev_static_dirty = true;
+    h.row.flags = flags;
+    h.row.cpu = cpu;
+    h.row.mem = mem;
+    h.row.total = total;
+    e->dev_dynamic_dirty = true;
+    return SWP_OK;
+}
+
+int swp_node_remove(swp_engine* e, uint32_t node) {
+    if (!e) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_OK;   // delete of an absent key is a no-op
+    HostNode& h = e->nodes[node];
+    for (auto& kv : h.svc) e->svc_nodes[kv.first].erase(node);
+    for (auto& kv : h.fails) e->fail_nodes[kv.first.first].erase(node);
+    for (uint64_t k : h.ports) e->port_nodes[k].erase(node);
+    h = HostNode();
+    e->n_present--;
+    e->dev_static_dirty = e->dev_dynamic_dirty = true;
+    return SWP_OK;
+}
+
+int swp_node_get(swp_engine* e, uint32_t node, swp_node_row* out) {
+    if (!e || !out) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    *out = e->nodes[node].row;
+    return SWP_OK;
+}
+
+int swp_node_set_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint32_t count) {
+    if (!e) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    if (count >= (1u << 30)) return e->fail(SWP_ERANGE, "service task count out of range");
+    HostNode& h = e->nodes[node];
+    if (count) {
+        h.svc[service] = count;
+        e->svc_nodes[service][node] = count;
+    } else {
+        h.svc.erase(service);
+        e->svc_nodes[service].erase(node);
+    }
+    return SWP_OK;
+}
+
+int swp_node_get_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint32_t* count_out) {
+    if (!e || !count_out) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    auto it = e->nodes[node].svc.find(service);
+    *count_out = it == e->nodes[node].svc.end() ? 0 : it->second;
+    return SWP_OK;
+}
+
+int swp_node_set_failures(swp_engine* e, uint32_t node, uint32_t service, uint64_t spec_version, uint32_t count) {
+    if (!e) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    if (count >= (1u << 30)) return e->fail(SWP_ERANGE, "failure count out of range");
+    HostNode& h = e->nodes[node];
+    if (count) {
+        h.fails[{service, spec_version}] = count;
+        e->fail_nodes[service].insert(node);
+    } else {
+        h.fails.erase({service, spec_version});
+    }
+    return SWP_OK;
+}
+
+int swp_node_port(swp_engine* e, uint32_t node, uint32_t protocol, uint32_t port, int set) {
+    if (!e) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    uint64_t k = port_key(protocol, port);
+    if (set) {
+        e->nodes[node].ports.insert(k);
+        e->port_nodes[k].insert(node);
+    } else {
+        e->nodes[node].ports.erase(k);
+        e->port_nodes[k].erase(node);
+    }
+    return SWP_OK;
+}
+
+int swp_constraint_set(swp_engine* e, const swp_constraint* cs, uint32_t n, uint32_t* id_out) {
+    if (!e || !id_out || (!cs && n)) return SWP_EINVAL;
+    if (n == 0) { *id_out = 0; return SWP_OK; }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (cs[i].kind > SWP_CK_INVALID || cs[i].op > SWP_OP_NE) return e->fail(SWP_EINVAL, "bad constraint kind/op");
+        if (cs[i].kind == SWP_CK_NODE_LABEL && !e->node_label_col.count(cs[i].key)) {
+            e->node_label_col[cs[i].key] = e->n_cols++;
+            e->dev_static_dirty = true;
+        }
+        if (cs[i].kind == SWP_CK_ENGINE_LABEL && !e->engine_label_col.count(cs[i].key)) {
+            e->engine_label_col[cs[i].key] = e->n_cols++;
+            e->dev_static_dirty = true;
+        }
+    }
+    return register_set(e->con_index, e->con_sets, bytes_of(cs, n), std::vector<swp_constraint>(cs, cs + n), id_out);
+}
+
+int swp_platform_set(swp_engine* e, const swp_platform* ps, uint32_t n, uint32_t* id_out) {
+    if (!e || !id_out || (!ps && n)) return SWP_EINVAL;
+    if (n == 0) { *id_out = 0; return SWP_OK; }
+    return register_set(e->plat_index, e->plat_sets, bytes_of(ps, n), std::vector<swp_platform>(ps, ps + n), id_out);
+}
+
+int swp_plugin_set(swp_engine* e, const uint32_t* required, uint32_t n, uint32_t log_plugin, uint32_t* id_out) {
+    if (!e || !id_out || (!required && n)) return SWP_EINVAL;
+    swp_engine::PlugSet ps;
+    ps.required.assign(required, required + n);
+    ps.log = log_plugin;
+    std::string key = bytes_of(&log_plugin, 1) + bytes_of(required, n);
+    return register_set(e->plug_index, e->plug_sets, key, std::move(ps), id_out);
+}
+
+int swp_port_set(swp_engine* e, const swp_port* ports, uint32_t n, uint32_t* id_out) {
+    if (!e || !id_out || (!ports && n)) return SWP_EINVAL;
+    if (n == 0) { *id_out = 0; return SWP_OK; }
+    return register_set(e->port_index, e->port_sets, bytes_of(ports, n), std::vector<swp_port>(ports, ports + n), id_out);
+}
+
+int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_tasks, swp_batch** out) {
+    if (!e || !out || (!tasks && n_tasks)) return SWP_EINVAL;
+    *out = nullptr;
+    (void)hipSetDevice(e->device);
+    int rc = flush_nodes(e);
+    if (rc) return rc;
+    auto b = std::make_unique<swp_batch>();
+    if ((rc = build_batch(e, tasks, n_tasks, b.get()))) return rc;
+    if (e->dev_static_dirty && (rc = flush_nodes(e))) return rc;
+    if (n_tasks && e->n_nodes && (rc = upload_batch(e, b.get()))) return rc;
+    *out = b.release();
+    return SWP_OK;
+}
+
+int swp_batch_run(swp_engine* e, swp_batch* b) {
+    if (!e || !b) return SWP_EINVAL;
+    (void)hipSetDevice(e->device);
+    return batch_run(e, b);
+}
+
+int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* out_fail_hist) {
+    if (!e || !b || (!out_node && b->T)) return SWP_EINVAL;
+    if (!b->ran) return e->fail(SWP_EINVAL, "swp_batch_fetch before swp_batch_run");
+    (void)hipSetDevice(e->device);
+    const uint32_t T = b->T;
+    if (T == 0) return SWP_OK;
+    if (e->n_nodes == 0) {
+        // nodeSet is empty: every task is "no suitable node" with an empty explanation
+        for (uint32_t i = 0; i < T; ++i) out_node[i] = -1;
+        if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
+        e->stats.batches++;
+        e->stats.tasks += T;
+        e->stats.infeasible += T;
+        b->ran = false;
+        return SWP_OK;
+    }
+    HIPCHECK(e, hipMemcpyAsync(out_node, b->d_out.p, (size_t)T * 4, hipMemcpyDeviceToHost, e->stream));
+    if (out_fail_hist) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, b->d_hist.p, (size_t)T * 8 * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    uint64_t placed = 0;
+    for (uint32_t i = 0; i < T; ++i) {
+        int32_t n = out_node[i];
+        if (n < 0) continue;
+        if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return e->fail(SWP_EHIP, "device returned an invalid node index %d for task %u", n, i);
+        const swp_task_desc& d = b->tasks[i];
+        host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+        ++placed;
+    }
+    e->stats.batches++;
+    e->stats.tasks += T;
+    e->stats.placed += placed;
+    e->stats.infeasible += T - placed;
+    e->stats.pair_evals += (uint64_t)T * e->n_present;
+    b->ran = false;
+    return SWP_OK;
+}
+
+void swp_batch_free(swp_engine* e, swp_batch* b) {
+    if (e) {
+        (void)hipSetDevice(e->device);
+        if (e->stream) (void)hipStreamSynchronize(e->stream);
+    }
+    delete b;
+}
+
+int swp_schedule_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t n_tasks, int32_t* out_node, uint32_t* out_fail_hist) {
+    swp_batch* b = nullptr;
+    int rc = swp_batch_prepare(e, tasks, n_tasks, &b);
+    if (rc) return rc;
+    rc = swp_batch_run(e, b);
+    if (!rc) rc = swp_batch_fetch(e, b, out_node, out_fail_hist);
+    swp_batch_free(e, b);
+    return rc;
+}
+
+int swp_state_save(swp_engine* e) {
+    if (!e) return SWP_EINVAL;
+    (void)hipSetDevice(e->device);
+    int rc = flush_nodes(e);
+    if (rc) return rc;
+    size_t cap = e->ncap;
+    HIPCHECK(e, e->d_save_cpu.reserve(cap * 8));
+    HIPCHECK(e, e->d_save_mem.reserve(cap * 8));
+    HIPCHECK(e, e->d_save_total.reserve(cap * 4));
+    HIPCHECK(e, hipMemcpyAsync(e->d_save_cpu.p, e->d_cpu.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHECK(e, hipMemcpyAsync(e->d_save_mem.p, e->d_mem.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHECK(e, hipMemcpyAsync(e->d_save_total.p, e->d_total.p, cap * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    e->saved.nodes = e->nodes;
+    e->saved.svc_nodes_ = e->svc_nodes;
+    e->saved.port_nodes_ = e->port_nodes;
+    e->saved.valid = true;
+    return SWP_OK;
+}
+
+int swp_state_restore(swp_engine* e) {
+    if (!e) return SWP_EINVAL;
+    if (!e->saved.valid) return e->fail(SWP_EINVAL, "swp_state_restore without swp_state_save");
+    (void)hipSetDevice(e->device);
+    if (e->saved.nodes.size() != e->nodes.size() || e->dev_static_dirty) return e->fail(SWP_EINVAL, "node set changed since swp_state_save");
+    size_t cap = e->ncap;
+    HIPCHECK(e, hipMemcpyAsync(e->d_cpu.p, e->d_save_cpu.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHECK(e, hipMemcpyAsync(e->d_mem.p, e->d_save_mem.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHECK(e, hipMemcpyAsync(e->d_total.p, e->d_save_total.p, cap * 4, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    e->nodes = e->saved.nodes;
+    e->svc_nodes = e->saved.svc_nodes_;
+    e->port_nodes = e->saved.port_nodes_;
+    e->dev_dynamic_dirty = false;
+    return SWP_OK;
+}
+
+int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add_or_remove) {
+    if (!e || (!p && n)) return SWP_EINVAL;
+    if (n == 0) return SWP_OK;
+    (void)hipSetDevice(e->device);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (p[i].node >= e->nodes.size() || !e->nodes[p[i].node].present) return SWP_ENOTFOUND;
+        if (p[i].port_set >= e->port_sets.size()) return SWP_EINVAL;
+    }
+    int rc = flush_nodes(e);   // device rows must be current before the residual kernel touches them
+    if (rc) return rc;
+    std::vector<DevPlacement> dp(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        dp[i].node = p[i].node;
+        dp[i].counted = p[i].counted;
+        dp[i].cpu = p[i].cpu;
+        dp[i].mem = p[i].mem;
+        host_apply_placement(e, p[i].node, p[i].service, p[i].cpu, p[i].mem, p[i].port_set, p[i].counted != 0, add_or_remove != 0);
+    }
+    DevBuf d;
+    HIPCHECK(e, d.reserve((size_t)n * sizeof(DevPlacement)));
+    HIPCHECK(e, hipMemcpyAsync(d.p, dp.data(), (size_t)n * sizeof(DevPlacement), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_commit, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, d.as<DevPlacement>(), add_or_remove, e->d_cpu.as<long long>(),
+                       e->d_mem.as<long long>(), e->d_total.as<uint32_t>());
+    HIPCHECK(e, hipGetLastError());
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return SWP_OK;
+}
+
+int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int32_t* first_fail) {
+    if (!e || !task || !first_fail) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    (void)hipSetDevice(e->device);
+    swp_batch* b = nullptr;
+    int rc = swp_batch_prepare(e, task, 1, &b);
+    if (rc) return rc;
+    std::unique_ptr<swp_batch, void (*)(swp_batch*)> guard(b, [](swp_batch* x) { delete x; });
+    if ((rc = run_classes(e, b))) return rc;
+    CheckArgs ca{};
+    ca.node = node;
+    ca.n_words = n_words_of(e->n_nodes);
+    ca.rt = b->rt[0];
+    ca.valid = e->d_valid.as<u64>();
+    ca.ready = e->d_ready.as<u64>();
+    ca.con = b->d_con.as<u64>();
+    ca.plat = b->d_plat.as<u64>();
+    ca.plug = b->d_plug.as<u64>();
+    ca.cpu = e->d_cpu.as<long long>();
+    ca.mem = e->d_mem.as<long long>();
+    const HostNode& h = e->nodes[node];
+    ca.port_busy = 0;
+    if (task->port_set)
+        for (const swp_port& p : e->port_sets[task->port_set])
+            if (h.ports.count(port_key(p.protocol, p.port))) ca.port_busy = 1;
+    auto it = h.svc.find(task->service);
+    ca.svc_count = it == h.svc.end() ? 0 : it->second;
+    DevBuf out;
+    HIPCHECK(e, out.reserve(4));
+    ca.out = out.as<int32_t>();
+    hipLaunchKernelGGL(k_check_pair, dim3(1), dim3(64), 0, e->stream, ca);
+    HIPCHECK(e, hipGetLastError());
+    int32_t ff = 0;
+    HIPCHECK(e, hipMemcpyAsync(&ff, out.p, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    *first_fail = ff;
+    return SWP_OK;
+}
+
+int swp_stats(swp_engine* e, swp_stats_t* out) {
+    if (!e || !out) return SWP_EINVAL;
+    e->stats.n_nodes = e->n_present;
+    e->stats.n_words = n_words_of(e->n_nodes);
+    *out = e->stats;
+    return SWP_OK;
+}
+
+}  // extern "C"

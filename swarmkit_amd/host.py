@@ -1,0 +1,590 @@
+"""Host-side mirror of manager/scheduler.Scheduler ABOVE the C ABI (include/swp.h).
+
+What a cgo shim would do inside swarmkit, written in Python for the test bed:
+it keeps the string-typed half of the nodeSet (api.Node docs, NodeInfo.Tasks, failure timestamps),
+turns every mutator of nodeSet / NodeInfo into ABI calls, translates Filter.SetTask into
+predicate-set registrations, and turns the engine's numeric answers back into scheduling decisions
+(NodeID, Status.Err strings). It contains NO placement logic: which node a task lands on is decided
+by the kernels behind swp_schedule_batch.
+
+Mirrors (paths under /root/reference/manager/scheduler/):
+  scheduler.go:254-396  createTask / updateTask / deleteTask / createOrUpdateNode
+  scheduler.go:429-488  tick            (one-off tasks → swp_schedule_batch)
+  scheduler.go:646-690  taskFitNode     (swp_check_node)
+  scheduler.go:928-971  noSuitableNode  (Status.Err from the failure histogram, pipeline.go:84-103)
+  nodeinfo.go:66-221    addTask / removeTask / taskFailed / countRecentFailures
+"""
+import ipaddress
+import re
+
+import numpy as np
+
+from . import abi
+
+# api/types.proto:510-539
+NEW, PENDING, ASSIGNED, RUNNING, COMPLETE, SHUTDOWN, FAILED, REJECTED = 0, 64, 192, 512, 576, 640, 704, 768
+NODE_READY, AVAIL_ACTIVE = 2, 0
+MOUNT_VOLUME, MOUNT_CLUSTER = 1, 4
+PUBLISH_HOST = 1
+
+MONITOR_FAILURES = 5 * 60 * 1_000_000_000   # scheduler.go:19
+MAX_FAILURES = 5                            # scheduler.go:23
+
+_TASK_STATES = {"NEW": 0, "PENDING": 64, "ASSIGNED": 192, "ACCEPTED": 256, "PREPARING": 320, "READY": 384, "STARTING": 448,
+                "RUNNING": 512, "COMPLETE": 576, "SHUTDOWN": 640, "FAILED": 704, "REJECTED": 768, "REMOVE": 800, "ORPHANED": 832}
+
+
+class Unsupported(NotImplementedError):
+    """The task/feature stays on the reference's own Go path (SWP_EUNSUPPORTED)."""
+
+
+def _get(d, *path, default=None):
+    for p in path:
+        if d is None:
+            return default
+        d = d.get(p)
+    return default if d is None else d
+
+
+def _state(v, table=_TASK_STATES):
+    if v is None:
+        return 0
+    return table[v] if isinstance(v, str) else int(v)
+
+
+# ---- constraint.Parse (constraint.go:40-81) ---------------------------------------------------------
+# key `^(?i)[a-z_][a-z0-9\-_.]+$`, value pattern constraint.go:23-26; under (?i) RE2 also folds
+# U+212A (KELVIN SIGN) and U+017F (LONG S) onto k / s.
+_KEY_RE = re.compile("[a-zA-Z_\u212a\u017f][a-zA-Z0-9\\-_.\u212a\u017f]+")
+_VAL_RE = re.compile("[a-zA-Z0-9:\\-_\t\n\f\r .*()?+\\[\\]\\\\^$|/\u212a\u017f]+")
+# strings.TrimSpace: Unicode White_Space
+_GO_SPACE = "\t\n\v\f\r \x85\xa0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u2028\u2029\u202f\u205f\u3000"
+
+
+def parse_constraints(exprs):
+    """Returns [(key, op, exp)] or None when constraint.Parse would return an error."""
+    out = []
+    for e in exprs:
+        found = False
+        for i, op in enumerate(("==", "!=")):
+            at = e.find(op)
+            if at < 0:
+                continue
+            key, val = e[:at].strip(_GO_SPACE), e[at + 2:].strip(_GO_SPACE)
+            if not _KEY_RE.fullmatch(key) or not _VAL_RE.fullmatch(val):
+                return None
+            out.append((key, i, val))
+            found = True
+            break
+        if not found:
+            return None
+    return out
+
+
+def _fold_eq(a, b):
+    """strings.EqualFold restricted to what a constraint KEY can contain (ASCII + K-sign + long-s)."""
+    def canon(s):
+        return s.replace("K", "k").replace("ſ", "s").lower()
+    return canon(a) == canon(b)
+
+
+def _parse_ip(s):
+    """net.ParseIP → (16 bytes, is_v4) or None."""
+    if "%" in s:
+        return None
+    try:
+        ip = ipaddress.ip_address(s)
+    except ValueError:
+        return None
+    if ip.version == 4:
+        return b"\x00" * 10 + b"\xff\xff" + ip.packed, True
+    return ip.packed, ip.ipv4_mapped is not None
+
+
+class HostScheduler:
+    """Scheduler surface: create_node/update_node/delete_node/create_task/update_task/delete_task/tick."""
+
+    SECOND = 1_000_000_000
+
+    def __init__(self, engine=None, **engine_kw):
+        self.e = engine or abi.Engine(**engine_kw)
+        self.e.reset(0)
+        self.now = 1_000_000_000_000
+        self.nodes = {}            # id -> {"doc", "idx", "tasks": {task id: task doc}, "failures": {(svc, ver): [ts]}, "last_cleanup"}
+        self.idx_to_id = {}
+        self.services = {}         # id -> spec version index or None
+        self.unassigned = {}       # insertion-ordered: id -> task doc
+        self.pending_preassigned = {}
+        self.preassigned = set()
+        self.all_tasks = {}
+        self._desc_cache = {}
+
+    # ------------------------------------------------------------------------------ interning helpers
+    def _folded(self, s):
+        return self.e.intern(abi.SPACE_FOLDED, s or "")
+
+    def _node_row(self, doc, idx, cpu, mem, total):
+        flags = 0
+        st = _get(doc, "Status", "State", default=0)
+        st = {"UNKNOWN": 0, "DOWN": 1, "READY": 2, "DISCONNECTED": 3}.get(st, st)
+        av = _get(doc, "Spec", "Availability", default=0)
+        av = {"ACTIVE": 0, "PAUSE": 1, "DRAIN": 2}.get(av, av)
+        if st == NODE_READY and av == AVAIL_ACTIVE:
+            flags |= abi.NODE_READY
+        role = doc.get("Role", 0)
+        if role in (1, "MANAGER"):
+            flags |= abi.NODE_MANAGER
+        row = abi.NodeRow(node=idx, cpu=cpu, mem=mem, total=total)
+        row.id_fold = self._folded(doc.get("ID", ""))
+        labels = _get(doc, "Spec", "Annotations", "Labels")
+        lab = []
+        if labels is not None:
+            flags |= abi.NODE_HAS_LABELS
+            lab = [(self.e.intern(abi.SPACE_LABEL_KEY, k), self._folded(v)) for k, v in labels.items()]
+        elab, plugins = [], []
+        desc = doc.get("Description")
+        if desc is not None:
+            flags |= abi.NODE_HAS_DESC
+            row.hostname_fold = self._folded(desc.get("Hostname", ""))
+            plat = desc.get("Platform")
+            if plat is not None:
+                flags |= abi.NODE_HAS_PLATFORM
+                row.os = self.e.intern(abi.SPACE_OS, plat.get("OS", "") or "")
+                row.arch = self.e.intern(abi.SPACE_ARCH, plat.get("Architecture", "") or "")
+                row.os_fold = self._folded(plat.get("OS", ""))
+                row.arch_fold = self._folded(plat.get("Architecture", ""))
+            eng = desc.get("Engine")
+            if eng is not None:
+                flags |= abi.NODE_HAS_ENGINE
+                el = eng.get("Labels")
+                if el is not None:
+                    flags |= abi.NODE_HAS_ELABELS
+                    elab = [(self.e.intern(abi.SPACE_LABEL_KEY, k), self._folded(v)) for k, v in el.items()]
+                for p in eng.get("Plugins") or []:
+                    typ, name = p.get("Type", ""), p.get("Name", "")
+                    if typ == "Log":
+                        flags |= abi.NODE_HAS_LOGPLUG
+                    plugins.append(self.e.intern(abi.SPACE_PLUGIN, typ + "\0" + name))
+                    if name.endswith(":latest"):   # filter.go:189-199: "name" also matches "name:latest"
+                        plugins.append(self.e.intern(abi.SPACE_PLUGIN, typ + "\0" + name[:-7]))
+        ip = _parse_ip(_get(doc, "Status", "Addr", default="") or "")
+        if ip is not None:
+            flags |= abi.NODE_IP_VALID | (abi.NODE_IP_V4 if ip[1] else 0)
+            row.ip = (abi.C.c_uint8 * 16)(*ip[0])
+        row.flags = flags
+        row.version = _get(doc, "Meta", "Version", "Index", default=0)
+        return row, lab, elab, plugins
+
+    # ------------------------------------------------------------------------------ nodeSet mutators
+    @staticmethod
+    def _reservations(task):
+        r = _get(task, "Spec", "Resources", "Reservations")
+        if r is None:
+            return 0, 0
+        return int(r.get("NanoCPUs", 0) or 0), int(r.get("MemoryBytes", 0) or 0)
+
+    def create_node(self, doc):
+        """createOrUpdateNode, scheduler.go:368-396."""
+        nid = doc["ID"]
+        ent = self.nodes.get(nid)
+        res = _get(doc, "Description", "Resources")
+        cpu = mem = 0
+        if res is not None:
+            if res.get("Generic"):
+                raise Unsupported("generic resources stay on the Go path")
+            cpu, mem = int(res.get("NanoCPUs", 0) or 0), int(res.get("MemoryBytes", 0) or 0)
+            if ent is not None:
+                for t in ent["tasks"].values():
+                    c, m = self._reservations(t)
+                    cpu -= c
+                    mem -= m
+        idx = self.e.intern(abi.SPACE_NODE_ID, nid)
+        total = 0
+        if ent is not None:
+            cur = self.e.node_get(idx)
+            total = cur.total if cur is not None else 0
+        else:
+            ent = {"doc": doc, "idx": idx, "tasks": {}, "failures": {}, "last_cleanup": self.now}
+            self.nodes[nid] = ent
+            self.idx_to_id[idx] = nid
+        ent["doc"] = doc
+        row, lab, elab, plugins = self._node_row(doc, idx, cpu, mem, total)
+        self.e.node_upsert(row, lab, elab, plugins)
+
+    update_node = create_node
+
+    def delete_node(self, nid):
+        """nodeSet.remove, nodeset.go:46-48."""
+        ent = self.nodes.pop(nid, None)
+        if ent is not None:
+            self.e.node_remove(ent["idx"])
+
+    def node_info(self, nid):
+        ent = self.nodes.get(nid)
+        if ent is None:
+            return None   # errNodeNotFound
+        row = self.e.node_get(ent["idx"])
+        by_service = {}
+        for t in ent["tasks"].values():
+            sid = t.get("ServiceID", "")
+            c = self.e.node_get_svc_count(ent["idx"], self.e.intern(abi.SPACE_SERVICE, sid))
+            if c:
+                by_service[sid] = c
+        return {"ID": nid, "ActiveTasksCount": row.total, "ActiveTasksCountByService": by_service,
+                "AvailableResources": {"NanoCPUs": row.cpu, "MemoryBytes": row.mem, "Generic": []},
+                "Tasks": sorted(ent["tasks"])}
+
+    # ------------------------------------------------------------------------------ NodeInfo.addTask/removeTask
+    def _port_set(self, task):
+        ports = [(int(p.get("Protocol", 0) if not isinstance(p.get("Protocol", 0), str) else {"TCP": 0, "UDP": 1, "SCTP": 2}[p["Protocol"]]),
+                  int(p.get("PublishedPort", 0)))
+                 for p in (_get(task, "Endpoint", "Ports") or [])
+                 if p.get("PublishMode", 0) in (PUBLISH_HOST, "HOST") and int(p.get("PublishedPort", 0)) != 0]
+        return self.e.port_set(ports) if ports else 0
+
+    def _placement(self, ent, task, counted, with_resources=True):
+        cpu, mem = self._reservations(task) if with_resources else (0, 0)
+        p = np.zeros(1, dtype=abi.PLACEMENT_DTYPE)
+        p["node"] = ent["idx"]
+        p["service"] = self.e.intern(abi.SPACE_SERVICE, task.get("ServiceID", ""))
+        p["cpu"], p["mem"] = cpu, mem
+        p["port_set"] = self._port_set(task) if with_resources else 0
+        p["counted"] = 1 if counted else 0
+        return p
+
+    def _add_task(self, ent, t):
+        """nodeinfo.go:108-154; returns True when nodeInfo was modified."""
+        old = ent["tasks"].get(t["ID"])
+        ds = _state(t.get("DesiredState"))
+        if old is not None:
+            ods = _state(old.get("DesiredState"))
+            if ds <= COMPLETE < ods:
+                ent["tasks"][t["ID"]] = t
+                self.e.commit(self._placement(ent, t, True, with_resources=False), add=True)
+                return True
+            if ods <= COMPLETE < ds:
+                ent["tasks"][t["ID"]] = t
+                self.e.commit(self._placement(ent, t, True, with_resources=False), add=False)
+                return True
+            return False
+        ent["tasks"][t["ID"]] = t
+        self.e.commit(self._placement(ent, t, ds <= COMPLETE), add=True)
+        return True
+
+    def _remove_task(self, ent, t):
+        """nodeinfo.go:66-104."""
+        old = ent["tasks"].pop(t["ID"], None)
+        if old is None:
+            return False
+        self.e.commit(self._placement(ent, t, _state(old.get("DesiredState")) <= COMPLETE), add=False)
+        return True
+
+    def _task_failed(self, ent, t):
+        """nodeinfo.go:177-202."""
+        if self.now - ent["last_cleanup"] >= MONITOR_FAILURES:
+            for k in [k for k, ts in ent["failures"].items() if not any(self.now - x < MONITOR_FAILURES for x in ts)]:
+                del ent["failures"][k]
+            ent["last_cleanup"] = self.now
+        key = (t.get("ServiceID", ""), _get(t, "SpecVersion", "Index", default=0))
+        lst = ent["failures"].get(key, [])
+        expired = 0
+        for ts in lst:
+            if self.now - ts < MONITOR_FAILURES:
+                break
+            expired += 1
+        ent["failures"][key] = lst[expired:] + [self.now]
+
+    def _count_recent_failures(self, ent, key):
+        """nodeinfo.go:206-221."""
+        lst = ent["failures"].get(key, [])
+        count = len(lst)
+        for i in range(count - 1, -1, -1):
+            if self.now - lst[i] > MONITOR_FAILURES:
+                count -= i + 1
+                break
+        return count
+
+    # ------------------------------------------------------------------------------ task event handlers
+    def set_service(self, sid, spec_version=None):
+        self.services[sid] = spec_version
+
+    def delete_service(self, sid):
+        self.services.pop(sid, None)
+
+    def advance(self, seconds):
+        self.now += int(seconds * self.SECOND)
+
+    def create_task(self, t):
+        """scheduler.go:254-283."""
+        st = _state(_get(t, "Status", "State"))
+        if st < PENDING or st > RUNNING:
+            return False
+        self.all_tasks[t["ID"]] = t
+        if not t.get("NodeID"):
+            self.unassigned[t["ID"]] = t
+            return True
+        if st == PENDING:
+            self.preassigned.add(t["ID"])
+            self.pending_preassigned[t["ID"]] = t
+            return False
+        ent = self.nodes.get(t["NodeID"])
+        if ent is not None:
+            self._add_task(ent, t)
+        return False
+
+    def update_task(self, t):
+        """scheduler.go:285-349."""
+        st = _state(_get(t, "Status", "State"))
+        if st < PENDING:
+            return False
+        old = self.all_tasks.get(t["ID"])
+        if st > RUNNING:
+            if old is None:
+                return False
+            if st != _state(_get(old, "Status", "State")) and st in (FAILED, REJECTED):
+                if t["ID"] not in self.preassigned:
+                    ent = self.nodes.get(t.get("NodeID", ""))
+                    if ent is not None:
+                        self._task_failed(ent, t)
+            self._delete_task(old)
+            return True
+        if not t.get("NodeID"):
+            if old is not None:
+                self._delete_task(old)
+            self.all_tasks[t["ID"]] = t
+            self.unassigned[t["ID"]] = t
+            return True
+        if st == PENDING:
+            if old is not None:
+                self._delete_task(old)
+            self.preassigned.add(t["ID"])
+            self.all_tasks[t["ID"]] = t
+            self.pending_preassigned[t["ID"]] = t
+            return False
+        self.all_tasks[t["ID"]] = t
+        ent = self.nodes.get(t["NodeID"])
+        if ent is not None:
+            self._add_task(ent, t)
+        return False
+
+    def _delete_task(self, t):
+        """scheduler.go:351-366."""
+        self.all_tasks.pop(t["ID"], None)
+        self.preassigned.discard(t["ID"])
+        self.pending_preassigned.pop(t["ID"], None)
+        ent = self.nodes.get(t.get("NodeID", ""))
+        if ent is not None and self._remove_task(ent, t):
+            return True
+        return False
+
+    def delete_task(self, t):
+        return self._delete_task(t)
+
+    # ------------------------------------------------------------------------------ Filter.SetTask → predicate sets
+    def _constraint_structs(self, parsed):
+        out = []
+        for key, op, exp in parsed:
+            c = abi.Constraint(kind=abi.CK_INVALID, op=op)
+            c.value = self._folded(exp)
+            if _fold_eq(key, "node.id"):
+                c.kind = abi.CK_NODE_ID
+            elif _fold_eq(key, "node.hostname"):
+                c.kind = abi.CK_HOSTNAME
+            elif _fold_eq(key, "node.ip"):
+                c.kind = abi.CK_IP
+                ip = _parse_ip(exp)
+                if ip is not None:
+                    c.ip_kind, c.ip_is_v4 = abi.IP_SINGLE, 1 if ip[1] else 0
+                    c.ip = (abi.C.c_uint8 * 16)(*ip[0])
+                else:
+                    net = None
+                    if "/" in exp:
+                        addr, _, plen = exp.partition("/")
+                        a = _parse_ip(addr)
+                        if a is not None and plen.isdigit() and len(plen) <= 3:
+                            syntactic_v4 = ":" not in addr
+                            bits = 32 if syntactic_v4 else 128
+                            if int(plen) <= bits:
+                                net = (a[0], syntactic_v4, int(plen) + (96 if syntactic_v4 else 0))
+                    if net is None:
+                        c.ip_kind = abi.IP_MALFORMED
+                    else:
+                        c.ip_kind, c.ip_is_v4, c.prefix_len = abi.IP_CIDR, 1 if net[1] else 0, net[2]
+                        c.ip = (abi.C.c_uint8 * 16)(*net[0])
+            elif _fold_eq(key, "node.role"):
+                c.kind = abi.CK_ROLE
+            elif _fold_eq(key, "node.platform.os"):
+                c.kind = abi.CK_PLATFORM_OS
+            elif _fold_eq(key, "node.platform.arch"):
+                c.kind = abi.CK_PLATFORM_ARCH
+            elif len(key) > len("node.labels.") and _fold_eq(key[:len("node.labels.")], "node.labels."):
+                c.kind = abi.CK_NODE_LABEL
+                c.key = self.e.intern(abi.SPACE_LABEL_KEY, key[len("node.labels."):])
+            elif len(key) > len("engine.labels.") and _fold_eq(key[:len("engine.labels.")], "engine.labels."):
+                c.kind = abi.CK_ENGINE_LABEL
+                c.key = self.e.intern(abi.SPACE_LABEL_KEY, key[len("engine.labels."):])
+            out.append(c)
+        return out
+
+    def task_desc(self, t):
+        """One swp_task_desc (numpy record) from an api.Task doc == Pipeline.SetTask (pipeline.go:76-81)."""
+        d = np.zeros(1, dtype=abi.TASK_DTYPE)
+        d["service"] = self.e.intern(abi.SPACE_SERVICE, t.get("ServiceID", ""))
+        res = _get(t, "Spec", "Resources", "Reservations")
+        if res is not None:
+            if res.get("Generic"):
+                raise Unsupported("generic resources stay on the Go path")
+            cpu, mem = int(res.get("NanoCPUs", 0) or 0), int(res.get("MemoryBytes", 0) or 0)
+            d["cpu"], d["mem"] = cpu, mem
+            if cpu != 0 or mem != 0:   # ResourceFilter.SetTask, filter.go:61-74
+                d["flags"] |= abi.TASK_RES_ENABLED
+        if _state(t.get("DesiredState")) > COMPLETE:
+            d["flags"] |= abi.TASK_UNCOUNTED
+        pl = _get(t, "Spec", "Placement")
+        if pl is not None:
+            cons = pl.get("Constraints") or []
+            if cons:
+                parsed = parse_constraints(cons)
+                if parsed is not None:   # parse error ⇒ filter disabled (filter.go:223-229)
+                    d["constraint_set"] = self.e.constraint_set(self._constraint_structs(parsed))
+            plats = pl.get("Platforms") or []
+            if plats:
+                d["platform_set"] = self.e.platform_set(
+                    [(self.e.intern(abi.SPACE_OS, p.get("OS", "") or ""), self.e.intern(abi.SPACE_ARCH, p.get("Architecture", "") or "")) for p in plats])
+            d["max_replicas"] = int(pl.get("MaxReplicas", 0) or 0)
+            for pref in pl.get("Preferences") or []:
+                if pref.get("Spread") is not None:
+                    raise Unsupported("spread preferences: decision-tree scan is not on the device yet")
+        # PluginFilter.SetTask, filter.go:119-131
+        mounts = _get(t, "Spec", "Container", "Mounts") or []
+        for m in mounts:
+            if m.get("Type") in (MOUNT_CLUSTER, "CLUSTER"):
+                raise Unsupported("CSI cluster volumes stay on the Go path")
+        vol = [_get(m, "VolumeOptions", "DriverConfig", "Name") for m in mounts
+               if m.get("Type") in (MOUNT_VOLUME, "VOLUME") and _get(m, "VolumeOptions", "DriverConfig") is not None
+               and _get(m, "VolumeOptions", "DriverConfig", "Name") not in (None, "", "local")]
+        nets = t.get("Networks") or []
+        logd = _get(t, "Spec", "LogDriver")
+        if nets or logd is not None or vol:
+            req = [self.e.intern(abi.SPACE_PLUGIN, "Volume\0" + v) for v in vol]
+            for na in nets:
+                name = _get(na, "Network", "DriverState", "Name")
+                if name:
+                    req.append(self.e.intern(abi.SPACE_PLUGIN, "Network\0" + name))
+            log = 0
+            if logd is not None and logd.get("Name") not in (None, "", "none"):
+                log = self.e.intern(abi.SPACE_PLUGIN, "Log\0" + logd["Name"])
+            if req or log:
+                d["plugin_set"] = self.e.plugin_set(req, log)
+        d["port_set"] = self._port_set(t)
+        d["spec_version"] = _get(t, "SpecVersion", "Index", default=0)
+        return d
+
+    # ------------------------------------------------------------------------------ Explain
+    _EXPLAIN = [("1 node not available for new tasks", "%d nodes not available for new tasks"),
+                ("insufficient resources on 1 node", "insufficient resources on %d nodes"),
+                ("missing plugin on 1 node", "missing plugin on %d nodes"),
+                ("scheduling constraints not satisfied on 1 node", "scheduling constraints not satisfied on %d nodes"),
+                ("unsupported platform on 1 node", "unsupported platform on %d nodes"),
+                ("host-mode port already in use on 1 node", "host-mode port already in use on %d nodes"),
+                ("max replicas per node limit exceed", "max replicas per node limit exceed"),
+                ("cannot fulfill requested CSI volume mounts on 1 node", "cannot fulfill requested CSI volume mounts on %d nodes")]
+
+    @classmethod
+    def explain(cls, hist):
+        """Pipeline.Explain, pipeline.go:84-103: stable sort by failure count, descending."""
+        order = sorted(range(len(hist)), key=lambda i: -int(hist[i]))
+        parts = []
+        for i in order:
+            n = int(hist[i])
+            if n > 0:
+                one, many = cls._EXPLAIN[i]
+                parts.append(one if n == 1 else (many % n if "%d" in many else many))
+        return "; ".join(parts)
+
+    # ------------------------------------------------------------------------------ tick
+    def _push_failures(self, service_ids):
+        for ent in self.nodes.values():
+            for (sid, ver) in list(ent["failures"]):
+                if sid in service_ids:
+                    self.e.node_set_failures(ent["idx"], self.e.intern(abi.SPACE_SERVICE, sid), ver, self._count_recent_failures(ent, (sid, ver)))
+
+    def process_preassigned(self):
+        """processPreassignedTasks + taskFitNode, scheduler.go:398-426, 646-690."""
+        decisions = []
+        for tid, t in list(self.pending_preassigned.items()):
+            ent = self.nodes.get(t.get("NodeID", ""))
+            if ent is None:
+                continue
+            new_t = dict(t)
+            ff = self.e.check_node(self.task_desc(t), ent["idx"])
+            if ff >= 0:
+                hist = [0] * abi.NFILTERS
+                hist[ff] = 1
+                new_t["Status"] = dict(t.get("Status", {}), Err=self.explain(hist))
+                self.all_tasks[tid] = new_t
+            else:
+                new_t["Status"] = {"State": ASSIGNED, "Message": "scheduler confirmed task can run on preassigned node"}
+                self.all_tasks[tid] = new_t
+                self._add_task(ent, new_t)
+                del self.pending_preassigned[tid]
+            decisions.append(self._decision(t, new_t))
+        return decisions
+
+    @staticmethod
+    def _decision(old, new):
+        return {"ID": new["ID"], "ServiceID": new.get("ServiceID", ""), "NodeID": new.get("NodeID", ""),
+                "State": _state(_get(new, "Status", "State")), "Message": _get(new, "Status", "Message", default=""),
+                "Err": _get(new, "Status", "Err", default=""), "OldState": _state(_get(old, "Status", "State"))}
+
+    def tick(self):
+        """scheduler.go:429-488 for one-off tasks (SpecVersion == nil)."""
+        queue = [(tid, t) for tid, t in self.unassigned.items() if t is not None and not t.get("NodeID")]
+        self.unassigned.clear()
+        if any(t.get("SpecVersion") is not None for _, t in queue):
+            raise Unsupported("grouped tasks (SpecVersion set): top-k group scan is not on the device yet")
+        decisions = []
+        if not queue:
+            return decisions
+        self._push_failures({t.get("ServiceID", "") for _, t in queue})
+        descs = np.concatenate([self.task_desc(t) for _, t in queue])
+        out, hist = self.e.schedule_batch(descs)
+        for (tid, t), n, h in zip(queue, out, hist):
+            if n >= 0:
+                nid = self.idx_to_id[int(n)]
+                new_t = dict(t)
+                new_t["NodeID"] = nid
+                new_t["Status"] = {"State": ASSIGNED, "Message": "scheduler assigned task to node"}
+                self.all_tasks[tid] = new_t
+                self.nodes[nid]["tasks"][tid] = new_t   # numeric addTask already happened on the device
+                decisions.append(self._decision(t, new_t))
+                continue
+            # noSuitableNode, scheduler.go:928-971
+            sid = t.get("ServiceID", "")
+            if sid not in self.services:
+                continue
+            new_t = dict(t)
+            sv, tv = self.services[sid], _get(t, "SpecVersion", "Index")
+            if sv is not None and tv is not None and sv > tv:
+                if _state(_get(t, "Status", "State")) == PENDING and _state(t.get("DesiredState")) >= SHUTDOWN:
+                    new_t["Status"] = dict(t.get("Status", {}), State=SHUTDOWN, Err="")
+            else:
+                ex = self.explain(h)
+                new_t["Status"] = dict(t.get("Status", {}), Err="no suitable node (" + ex + ")" if ex else "no suitable node")
+                self.unassigned[tid] = new_t
+            self.all_tasks[tid] = new_t
+            decisions.append(self._decision(t, new_t))
+        return decisions
+
+
+def load_workload(sched, wl):
+    """Bulk path used by bench.py / large parity tests: nodes through create_node, tasks as one
+    descriptor array (per-service spec translated once, then tiled)."""
+    for i in range(wl.N):
+        sched.create_node(wl.node_doc(i))
+    for k in range(wl.S):
+        sched.set_service(wl.service_id(k))
+    per_service = np.concatenate([sched.task_desc(dict(wl.service_spec(k), ID="x", ServiceID=wl.service_id(k), DesiredState=RUNNING))
+                                  for k in range(wl.S)])
+    svc_of_task = np.arange(wl.T) % wl.S
+    return per_service[svc_of_task]
