@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — placements/s of the batch task-placement hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+A "step" = one full pass of the hot path over one batch of synthetic pending tasks
+(BASELINE.json configs[2]: 100k one-off tasks x 10k nodes, Resource + Constraint + Platform
+filters, spread strategy), starting from the same cluster state every step, with the node rows and
+task descriptors already resident in HBM. Inside the timed region, per step:
+    device state restore (3 small D2D copies) -> class bitmaps -> [scan -> resolve/commit] per window
+    -> explain pass -> placements copied back to the host (400 KB).
+Host-side descriptor building / interning (what the Go shim does while it enqueues tasks) is
+outside the timed region; its cost and the PCIe-inclusive rate are reported in DESIGN.md.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); see DESIGN.md "Multi-GPU".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ROW_B = {"cfg2": 32, "cfg3": 48, "cfg4": 64}   # algorithmic node-row bytes per (task,node) pair, SURVEY.md §8a
+TASK_B = 64 + 8                # descriptor + result per task, SURVEY.md §8d
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """The CPU oracle (single thread, like the reference's single scheduling goroutine) on a bounded
+    sample of the SAME workload: the full node set, the first `sample` tasks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    o = orc.Oracle()
+    for i in range(wl.N):
+        o.create_node(wl.node_doc(i))
+    for k in range(wl.S):
+        o.set_service(wl.service_id(k))
+    # calibrate on a small slice, then size the sample for ~budget_s of scheduling work
+    probe = min(wl.T, max(50, 2_000_000 // max(wl.N, 1)))
+    for j in range(probe):
+        o.create_task(wl.task_doc(j))
+    t0 = time.perf_counter()
+    o.tick()
+    dt = time.perf_counter() - t0
+    rate = probe / max(dt, 1e-9)
+    sample = int(min(wl.T - probe, max(0, rate * budget_s)))
+    done, total_dt = probe, dt
+    if sample > 0:
+        for j in range(probe, probe + sample):
+            o.create_task(wl.task_doc(j))
+        t0 = time.perf_counter()
+        o.tick()
+        d2 = time.perf_counter() - t0
+        done, total_dt = sample, d2   # steady-state slice (cluster already partly filled, like the GPU pass on average)
+    return {"value": done / total_dt, "unit": "placements/s", "cores": 1, "kind": "port",
+            "pair_evals_per_s": done * wl.N / total_dt,
+            "sample": f"{done} consecutive one-off tasks of the same workload against all {wl.N} nodes "
+                      f"(oracle tick() wall time {total_dt:.2f} s, after a {probe}-task warm-in)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--tasks", type=int, default=None)
+    ap.add_argument("--nodes", type=int, default=None)
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also verify the placements against the oracle sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from swarmkit_amd import abi, host, synth
+
+    # Multi-GPU (round 1): independent replicas — every rank schedules its own cluster of the same shape
+    # (seed offset by rank); no data-path collective. The node-sharded scan with an RCCL exchange is the
+    # next row of SURVEY.md §8e.
+    wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=None if rank == 0 else 0x5EED0000 + 1000 * rank + 3)
+    eng = abi.Engine(device=local_rank, window=args.window, profile=True)
+    sched = host.HostScheduler(engine=eng)
+    t0 = time.perf_counter()
+    descs = host.load_workload(sched, wl)
+    t_host_prep = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    batch = eng.batch_prepare(descs)
+    t_prepare = time.perf_counter() - t0
+    eng.state_save()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        eng.state_restore()
+        batch.run()
+        return batch.results(want_hist=False)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ms_scan = ms_resolve = ms_explain = ms_classes = ms_dev = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, _ = step()
+        st = eng.stats()
+        ms_scan += st["ms_scan"]
+        ms_resolve += st["ms_resolve"]
+        ms_explain += st["ms_explain"]
+        ms_classes += st["ms_classes"]
+        ms_dev += st["ms_total"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    st = eng.stats()
+    K = max(args.steps, 1)
+    windows = st["last_windows"]
+    placed = int((out >= 0).sum())
+    pairs = wl.T * wl.N
+    row_b = ROW_B.get(args.workload, 48)
+    alg_bytes_step = pairs * row_b + wl.T * TASK_B
+    t_step = elapsed / K
+    # dominant kernel = k_resolve (sequential argmin + residual-update commit): one launch per window
+    res_launch_ms = ms_resolve / K / max(windows, 1)
+    alg_bytes_launch = alg_bytes_step / max(windows, 1)
+    achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get("k_resolve_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "task placements/sec (100k one-off tasks x 10k nodes, Resource+Constraint+Platform filters, spread)",
+        "value": world * wl.T / t_step,
+        "unit": "placements/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": t_step * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": dict(wl.describe(), parallelism="replicas" if world > 1 else "single", window=int(st["last_windows"] and -(-wl.T // st["last_windows"])),
+                       static_classes=st["last_static_classes"]),
+        "pair_evals_per_s": world * pairs / t_step,
+        "placed": placed,
+        "unplaceable": wl.T - placed,
+        "roofline": {"bound": "hbm", "kernel": "k_resolve", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows},
+        "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_scan": ms_scan / K, "k_resolve": ms_resolve / K,
+                                "k_explain": ms_explain / K, "device_total": ms_dev / K},
+        "whole_job_algorithmic_GBs": alg_bytes_step / t_step / 1e9,
+        "k_scan_algorithmic_GBs": (alg_bytes_step / (ms_scan / K * 1e-3) / 1e9) if ms_scan > 0 else None,
+        "host_prep_s": {"intern+descriptors": t_host_prep, "swp_batch_prepare": t_prepare},
+        "resolver_raw": {k: st[k] for k in ("generic_tasks", "resolver_spins", "verify_retries", "slow_path_tasks", "rebase_events", "batches")},
+        "resolver": {"verify_retries": st["verify_retries"] // max(st["resolve_launches"] // max(windows, 1), 1),
+                     "slow_path_tasks": st["slow_path_tasks"] // max(st["resolve_launches"] // max(windows, 1), 1)},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl)
+    if args.check and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import parity_util as pu
+        n = min(wl.T, 3000)
+        op, oe, _ = pu.oracle_run(wl, count=n)
+        bad = sum(1 for j in range(n) if (op[wl.task_id(j)] or None) != (sched.idx_to_id[int(out[j])] if out[j] >= 0 else None))
+        result["check"] = {"tasks": n, "mismatches": bad}
+    if rank == 0:
+        print(json.dumps(result))
+    batch.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

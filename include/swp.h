@@ -207,6 +207,9 @@ typedef struct swp_batch swp_batch;
 int swp_batch_prepare(swp_engine*, const swp_task_desc* tasks, uint32_t n_tasks, swp_batch** out);
 int swp_batch_run(swp_engine*, swp_batch*);
 int swp_batch_fetch(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fail_hist);
+/* copy the device results of the last run back WITHOUT folding them into the host mirror (replay
+ * benchmarking: run → results → swp_state_restore → run …) */
+int swp_batch_results(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fail_hist);
 void swp_batch_free(swp_engine*, swp_batch*);
 /* Device-side snapshot / restore of all mutable node state (cpu, mem, total, per-service counts,
  * host ports) so that a benchmark can replay the same batch from the same state. */
@@ -235,6 +238,8 @@ typedef struct {
     uint64_t verify_retries;    /* resolver candidates rejected by the freshness re-check */
     uint64_t slow_path_tasks;   /* tasks resolved through the per-service exception list */
     uint64_t rebase_events;
+    uint64_t generic_tasks;     /* tasks that left the resolver's hot-level fast path */
+    uint64_t resolver_spins;    /* resolver wave polls while waiting for staged rows */
     uint32_t n_nodes, n_words, last_windows, last_static_classes;
     float    ms_classes, ms_scan, ms_resolve, ms_explain, ms_total;   /* last batch, SWP_CFG_PROFILE */
     uint32_t scan_launches, resolve_launches;

@@ -552,7 +552,7 @@ NodeInfo new_node_info(const NodePtr& n, const std::vector<TaskPtr>& tasks, cons
     NodeInfo ni;
     ni.node = n;
     ni.tasks = std::make_shared<std::map<std::string, TaskPtr>>();
-    ni.by_service = std::make_shared<std::map<std::string, int64_t>>();
+    ni.by_service = std::make_shared<std::unordered_map<std::string, int64_t>>();
     ni.available = std::make_shared<Resources>(avail);
     ni.used_ports = std::make_shared<std::map<HostPortSpec, int>>();
     ni.recent_failures = std::make_shared<std::map<VersionedService, std::vector<int64_t>>>();
@@ -649,8 +649,11 @@ void NodeInfo::task_failed(int64_t now, const Task& t) {
 
 // countRecentFailures, nodeinfo.go:206-221
 int64_t NodeInfo::count_recent_failures(int64_t now, const Task& t) const {
-    if (!recent_failures) return 0;
-    VersionedService vs{t.service_id, t.has_spec_version ? t.spec_version : 0};
+    if (!recent_failures || recent_failures->empty()) return 0;
+    return count_recent_failures_key(now, VersionedService{t.service_id, t.has_spec_version ? t.spec_version : 0});
+}
+int64_t NodeInfo::count_recent_failures_key(int64_t now, const VersionedService& vs) const {
+    if (!recent_failures || recent_failures->empty()) return 0;   // Go: lookups in an empty map return at once
     auto it = recent_failures->find(vs);
     if (it == recent_failures->end()) return 0;
     const std::vector<int64_t>& list = it->second;
@@ -956,7 +959,7 @@ DecisionTree Scheduler::tree(const std::string& service_id, const std::vector<Pr
     if (max_assignments == 0) return root;
     for (const Slot& slot : slots_) {
         if (!slot.present) continue;
-        NodeInfo node = slot.info;   // range copies the value
+        const NodeInfo& node = slot.info;   // Go copies the struct (plain memcpy); a reference is the cost-fair equivalent
         DecisionTree* tree = &root;
         for (const Preference& pref : prefs) {
             if (!pref.is_spread) continue;
@@ -1221,10 +1224,11 @@ void Scheduler::schedule_task_group(OrderedTasks& group, std::vector<Decision>& 
     pipeline.set_task(t.get());
     int64_t now_captured = now;
     const Task* tp = t.get();
-    NodeLess node_less = [this, now_captured, tp](const NodeInfo& a, const NodeInfo& b) {
+    const VersionedService vs_key{tp->service_id, tp->has_spec_version ? tp->spec_version : 0};
+    NodeLess node_less = [this, now_captured, tp, vs_key](const NodeInfo& a, const NodeInfo& b) {
         ++nodeless_calls;
-        int64_t fa = a.count_recent_failures(now_captured, *tp);
-        int64_t fb = b.count_recent_failures(now_captured, *tp);
+        int64_t fa = a.count_recent_failures_key(now_captured, vs_key);
+        int64_t fb = b.count_recent_failures_key(now_captured, vs_key);
         if (fa >= kMaxFailures || fb >= kMaxFailures) {
             if (fa > fb) return false;
             if (fb > fa) return true;

@@ -172,7 +172,7 @@ struct NodeInfo {
     NodePtr node;
     std::shared_ptr<std::map<std::string, TaskPtr>> tasks;
     int64_t active_tasks_count = 0;
-    std::shared_ptr<std::map<std::string, int64_t>> by_service;
+    std::shared_ptr<std::unordered_map<std::string, int64_t>> by_service;   // Go map: hashed
     std::shared_ptr<Resources> available;
     std::shared_ptr<std::map<HostPortSpec, int>> used_ports;
     std::shared_ptr<std::map<VersionedService, std::vector<int64_t>>> recent_failures;
@@ -184,6 +184,7 @@ struct NodeInfo {
     bool remove_task(const Task& t);
     void task_failed(int64_t now, const Task& t);
     int64_t count_recent_failures(int64_t now, const Task& t) const;
+    int64_t count_recent_failures_key(int64_t now, const VersionedService& vs) const;
     void cleanup_failures(int64_t now);
 };
 NodeInfo new_node_info(const NodePtr& n, const std::vector<TaskPtr>& tasks, const Resources& avail, int64_t now);

@@ -64,6 +64,7 @@ class Placement(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("batches", C.c_uint64), ("tasks", C.c_uint64), ("placed", C.c_uint64), ("infeasible", C.c_uint64),
                 ("pair_evals", C.c_uint64), ("verify_retries", C.c_uint64), ("slow_path_tasks", C.c_uint64), ("rebase_events", C.c_uint64),
+                ("generic_tasks", C.c_uint64), ("resolver_spins", C.c_uint64),
                 ("n_nodes", C.c_uint32), ("n_words", C.c_uint32), ("last_windows", C.c_uint32), ("last_static_classes", C.c_uint32),
                 ("ms_classes", C.c_float), ("ms_scan", C.c_float), ("ms_resolve", C.c_float), ("ms_explain", C.c_float), ("ms_total", C.c_float),
                 ("scan_launches", C.c_uint32), ("resolve_launches", C.c_uint32)]
@@ -81,7 +82,7 @@ EXPORTS = [
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_schedule_batch", "swp_batch_prepare",
-    "swp_batch_run", "swp_batch_fetch", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node",
+    "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node",
     "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check",
 ]
 
@@ -141,6 +142,7 @@ def load_library():
         "swp_batch_prepare": ([vp, vp, u32, P(vp)], C.c_int),
         "swp_batch_run": ([vp, vp], C.c_int),
         "swp_batch_fetch": ([vp, vp, vp, vp], C.c_int),
+        "swp_batch_results": ([vp, vp, vp, vp], C.c_int),
         "swp_batch_free": ([vp, vp], None),
         "swp_state_save": ([vp], C.c_int),
         "swp_state_restore": ([vp], C.c_int),
@@ -175,6 +177,12 @@ class Batch:
         out = np.empty(self.n, dtype=np.int32)
         hist = np.zeros((self.n, NFILTERS), dtype=np.uint32) if want_hist else None
         self.eng._ck(self.eng.L.swp_batch_fetch(self.eng.h, self.h, out.ctypes.data, hist.ctypes.data if want_hist else None))
+        return out, hist
+
+    def results(self, want_hist=True):
+        out = np.empty(self.n, dtype=np.int32)
+        hist = np.zeros((self.n, NFILTERS), dtype=np.uint32) if want_hist else None
+        self.eng._ck(self.eng.L.swp_batch_results(self.eng.h, self.h, out.ctypes.data, hist.ctypes.data if want_hist else None))
         return out, hist
 
     def free(self):

@@ -73,7 +73,8 @@ struct DevConstraint {   // 48 B
 
 struct Ctl {
     u32 ncommit, ninf, error, pad0;
-    u64 verify_retries, slow_tasks, rebases, pad1;
+    u64 verify_retries, slow_tasks, rebases, generic_tasks, spin_waits, pad1;
+    u64 cyc[8];   // dbg&16: cycles spent in resolver sections
 };
 
 enum { ERR_NONE = 0, ERR_LEVEL_RANGE = 1 };
@@ -335,6 +336,9 @@ struct ResolveArgs {
     u32 n_nodes, n_words;
     u32 j0, count;
     u32 nb_alloc;            // planes that fit in LDS
+    u32 dbg;                 // timing experiments only (env SWP_DBG); 0 in production
+    u32 xs;                  // row stride of X in words
+    u32 tb;                  // k_resolve2: tasks per staged block
     const u64* F;            // [count][n_words] for this window
     const u64* valid;        // [n_words]
     u64* X;                  // [n_svc][n_words]
@@ -710,6 +714,966 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
         a.ctl->verify_retries += st_retries;
         a.ctl->slow_tasks += st_slow;
         a.ctl->rebases += st_rebase;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_resolve1 — the same sequential pass as k_resolve for node sets that fit ONE wavefront
+// (n_words ≤ 64*K): no workgroup barrier anywhere, so nothing ever forces vmcnt(0) and the global
+// loads of the next tasks' rows stay in flight under the current task's work.
+//   * lane l owns words {l + 64k}; F/X rows are prefetched D tasks ahead into a register ring
+//     (static indexing: the task loop is unrolled by D);
+//   * argmin key = (level << idx_bits) | node packed in 32 bits and reduced with 6 DPP steps;
+//   * the commit is fire-and-forget: ds_xor on exactly the planes whose bit flips in level+1,
+//     no-return global atomics for cpu/mem/total, plain stores for X / list / log; the one value that
+//     must come back (the node's previous commit, for the explain chain) is consumed one commit later.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ u32 dpp_u32(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// min over the 64 lanes of a wave; every lane returns the result
+__device__ __forceinline__ u32 wave_min_u32_dpp(u32 v) {
+    v = min(v, dpp_u32<0x111>(v));        // row_shr:1
+    v = min(v, dpp_u32<0x112>(v));        // row_shr:2
+    v = min(v, dpp_u32<0x114>(v));        // row_shr:4
+    v = min(v, dpp_u32<0x118>(v));        // row_shr:8   → lane 15 of every row holds the row minimum
+    v = min(v, dpp_u32<0x142, 0xa>(v));   // row_bcast:15 into rows 1,3
+    v = min(v, dpp_u32<0x143, 0xc>(v));   // row_bcast:31 into rows 2,3 → lane 63 holds the wave minimum
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// NBR = level planes held in registers per owned word (levels 0 .. 2^NBR-1 above `base`).
+#define R1_NBR 8
+
+template <int K, int D>
+__global__ __launch_bounds__(64) void k_resolve1(ResolveArgs a) {
+    const u32 lane = threadIdx.x;
+    const u32 Wn = a.n_words;
+    if (a.ctl->error != ERR_NONE) return;
+    u32 ncommit = a.ctl->ncommit, ninf = a.ctl->ninf;
+    u32 st_retries = 0, st_slow = 0, st_rebase = 0;
+    // last commit per node (head of the explain pass's per-node chain) lives in LDS for the whole
+    // window: the hot loop must never consume a VMEM result younger than the D-deep prefetch ring —
+    // vmcnt retires in order, so waiting on one recent load/atomic would drain the whole ring.
+    extern __shared__ int32_t last_lds[];
+    for (u32 n = lane; n < a.n_nodes; n += 64) last_lds[n] = a.last[n];
+
+    const u32 idx_bits = 32 - __clz((Wn * 64) | 1u);   // node indices < 64*64*K
+    const u32 idx_mask = (1u << idx_bits) - 1u;
+    u32 NB = 1, base = 0;
+
+    // Per-lane state, all in registers: lane l owns words {l + 64k}.
+    u64 pl[R1_NBR][K];   // level bit-planes of the owned words
+    u64 tch[K];          // nodes committed to since the scan (their F bits may be stale)
+#pragma unroll
+    for (int k = 0; k < K; ++k) tch[k] = 0;
+
+    // (re)build the level planes from total[]; false when the level span needs more than R1_NBR planes.
+    // The bit loop is the dynamic one; k and b stay fully unrolled so that pl[][] never leaves registers.
+    auto build_planes = [&]() __attribute__((always_inline)) -> bool {
+        u64 vm[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) vm[k] = (lane + 64 * k) < Wn ? a.valid[lane + 64 * k] : 0ull;
+        u32 lo = 0xFFFFFFFFu, hi = 0;
+        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if ((vm[k] >> i) & 1ull) {
+                    u32 t = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lo = min(lo, t);
+                    hi = max(hi, t);
+                }
+            }
+        }
+        lo = wave_min_u32(lo);
+        hi = wave_max_u32(hi);
+        if (lo == 0xFFFFFFFFu) { lo = 0; hi = 0; }
+        u32 span = hi - lo;
+        u32 need = 32 - __clz(span | 1u);
+        u32 cap = min((u32)R1_NBR, 32u - idx_bits);   // the packed (level, node) key must fit 32 bits
+        if (need > cap) return false;
+        base = lo;
+        NB = min(cap, need + 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int b = 0; b < R1_NBR; ++b) pl[b][k] = 0;
+        }
+        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                u32 lvl = 0;
+                if ((vm[k] >> i) & 1ull)
+                    lvl = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+#pragma unroll
+                for (int b = 0; b < R1_NBR; ++b) pl[b][k] |= (u64)((lvl >> b) & 1u) << i;
+            }
+        }
+        return true;
+    };
+    if (!build_planes()) {
+        if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+        return;
+    }
+
+    // bit-sliced argmin(level, index) over the candidate words; 0xFFFFFFFF when there is none
+    auto search = [&](const u64 (&mk)[K]) __attribute__((always_inline)) -> u32 {
+        u64 m[K];
+        u32 lv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { m[k] = mk[k]; lv[k] = 0; }
+#pragma unroll
+        for (int b = R1_NBR - 1; b >= 0; --b) {
+            if ((u32)b < NB) {   // uniform
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    u64 t = m[k] & ~pl[b][k];
+                    bool nz = t != 0;
+                    m[k] = nz ? t : m[k];
+                    lv[k] |= nz ? 0u : (1u << b);
+                }
+            }
+        }
+        u32 best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u32 w = lane + 64 * k;
+            u32 cand = (lv[k] << idx_bits) | (w * 64 + (u32)(__ffsll((long long)m[k]) - 1));
+            best = min(best, m[k] ? cand : 0xFFFFFFFFu);
+        }
+        return wave_min_u32_dpp(best);
+    };
+
+    // level+1 for node (owner lane, word slot ko): flip exactly the planes whose bit changes
+    auto bump = [&](bool owner, u32 ko, u64 bit, u32 lvl) __attribute__((always_inline)) {
+        const u32 flip = lvl ^ (lvl + 1);
+        const u64 xb = owner ? bit : 0ull;
+#pragma unroll
+        for (int b = 0; b < R1_NBR; ++b) {
+            if (flip >> b & 1u) {   // uniform
+#pragma unroll
+                for (int k = 0; k < K; ++k) pl[b][k] ^= ((u32)k == ko) ? xb : 0ull;   // value select keeps pl[][] in registers
+            }
+        }
+    };
+
+    // register ring: slot u holds the rows of the task with (index ≡ u mod D)
+    u64 Fr[D][K], Xr[D][K];
+    u32 sv[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        bool have = (u32)u < a.count;
+        sv[u] = have ? cload(&a.rt[a.j0 + u].svc) : 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u32 w = lane + 64 * k;
+            bool in = have && w < Wn;
+            Fr[u][k] = in ? a.F[(size_t)u * Wn + w] : 0;
+            Xr[u][k] = in ? __hip_atomic_load(&a.X[(size_t)sv[u] * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+    }
+    // service / flags of upcoming tasks are fetched one iteration before they are needed
+    u32 sv_ahead = (u32)D < a.count ? cload(&a.rt[a.j0 + D].svc) : 0u;
+    u32 fl_next = cload(&a.rt[a.j0].flags);
+
+    u32 j = 0;          // next task (window-relative); its rows sit in ring slot j % D
+    int ustart = 0;     // == j % D
+    bool fatal = false;
+    u64 gk[K], gXc[K];  // candidate / X words of a task handed to the generic path
+#pragma unroll
+    for (int k = 0; k < K; ++k) { gk[k] = 0; gXc[k] = 0; }
+    u32 g_svc = 0;
+
+    while (j < a.count && !fatal) {
+        bool generic = false, want_rebase = false;
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (u < ustart) continue;                               // uniform
+            if (j >= a.count || generic || want_rebase) continue;   // uniform
+            const u32 gj = a.j0 + j;
+            const RTask* r = a.rt + gj;
+            u64 mk[K], Xc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                Xc[k] = Xr[u][k];
+                mk[k] = Fr[u][k] & ~Xr[u][k];
+            }
+            const u32 rsvc = sv[u];
+            const u32 rflags = fl_next;
+            // refill this ring slot with task j+D; fetch flags of task j+1
+            {
+                const u32 jn = j + D;
+                const bool have = jn < a.count;
+                const u32 sn = sv_ahead;
+                sv_ahead = (jn + 1 < a.count) ? cload(&a.rt[a.j0 + jn + 1].svc) : 0u;
+                fl_next = (j + 1 < a.count) ? cload(&a.rt[gj + 1].flags) : 0u;
+                sv[u] = sn;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    u32 w = lane + 64 * k;
+                    const bool inw = have && w < Wn;
+                    const bool in = inw && !(a.dbg & 4u);
+                    Fr[u][k] = in ? a.F[(size_t)jn * Wn + w] : ((inw && w + 1 < Wn) ? ~0ull >> (w * 7 % 13) : 0);
+                    Xr[u][k] = in ? __hip_atomic_load(&a.X[(size_t)sn * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                }
+            }
+            const i64 rcpu = cload(&r->cpu), rmem = cload(&r->mem);
+            const u32 rslot = cload(&r->slot);
+
+            u32 g = 0xFFFFFFFFu;
+            bool fast = !(rflags & (RT_PORTS | RT_UNCOUNTED));
+            u32 n = 0, lvl = 0, w = 0, ko = 0;
+            u64 bit = 0;
+            bool owner = false;
+            if (fast) {
+                g = search(mk);
+                fast = g != 0xFFFFFFFFu;
+            }
+            if (fast) {
+                n = g & idx_mask;
+                lvl = g >> idx_bits;
+                w = n >> 6;
+                ko = w >> 6;
+                bit = 1ull << (n & 63);
+                owner = (w & 63) == lane;
+                u64 tsel = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? tch[k] : tsel;
+                // stale-F hazard or level overflow → generic path
+                if (ballot64(owner && (tsel & bit)) != 0 || lvl == (1u << NB) - 1u) fast = false;
+            }
+            if (!fast) {   // hand the task to the generic path below (one copy of the heavy code)
+#pragma unroll
+                for (int k = 0; k < K; ++k) { gk[k] = mk[k]; gXc[k] = Xc[k]; }
+                g_svc = rsvc;
+                generic = true;
+                ustart = u;
+                continue;
+            }
+
+            // ------------- lean commit == NodeInfo.addTask (nodeinfo.go:108-154), counted task, no host ports -------------
+            bump(owner, ko, bit, lvl);
+#pragma unroll
+            for (int k = 0; k < K; ++k) tch[k] |= (owner && (u32)k == ko) ? bit : 0ull;
+            if (owner) {
+                if (!(a.dbg & 1u)) {
+                    if (rcpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rcpu));
+                    if (rmem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rmem));
+                    atomicAdd(a.total + n, 1u);
+                }
+                u64 nx = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) nx = ((u32)k == ko) ? (Xc[k] | bit) : nx;
+                if (!(a.dbg & 2u)) {
+                    __hip_atomic_store(&a.X[(size_t)rsvc * Wn + w], nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.list_node[rslot] = n;
+                    a.list_svc[rslot] = 1;
+                    a.list_fail[rslot] = 0;
+                    a.log_node[ncommit] = n;
+                    a.log_task[ncommit] = gj;
+                    a.log_prev[ncommit] = last_lds[n];
+                }
+                last_lds[n] = (int32_t)ncommit;
+                a.out_node[gj] = (int32_t)n;
+            }
+            // a prefetched X row of the same service must see this node as taken
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const u32 held = j - (u32)u + (u32)d + ((u32)d <= (u32)u ? (u32)D : 0u);   // task whose rows sit in slot d now
+                if (sv[d] == rsvc && held < a.count && !(a.dbg & 8u)) {   // uniform, rare
+#pragma unroll
+                    for (int k = 0; k < K; ++k) Xr[d][k] |= (owner && (u32)k == ko) ? bit : 0ull;
+                }
+            }
+            ++ncommit;
+            ++j;
+        }
+        if (!generic && !want_rebase) { ustart = 0; continue; }   // a full round of D tasks went through the fast path
+
+        // =========================== generic path: one task, every feature ===========================
+        {
+            const u32 gj = a.j0 + j;
+            const RTask* r = a.rt + gj;
+            const u32 rflags = r->flags, rsvc = g_svc, rslot = r->slot, rpset = r->pset;
+            const i64 rcpu = r->cpu, rmem = r->mem;
+            const bool counted = !(rflags & RT_UNCOUNTED);
+            bool placed = false, via_list = false;
+            u32 n = 0, lvl = 0, entry = 0;
+            for (;;) {   // plain candidates, re-checking nodes committed to since the scan
+                u32 g = search(gk);
+                if (g == 0xFFFFFFFFu) break;
+                n = g & idx_mask;
+                lvl = g >> idx_bits;
+                const u32 w = n >> 6, ko = w >> 6;
+                const u64 bit = 1ull << (n & 63);
+                const bool owner = (w & 63) == lane;
+                u64 tsel = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? tch[k] : tsel;
+                bool ok = true;
+                if (ballot64(owner && (tsel & bit)) != 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    if (rflags & RT_RES) {
+                        i64 c = __hip_atomic_load(&a.cpu[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        i64 m = __hip_atomic_load(&a.mem[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (rcpu <= c) && (rmem <= m);
+                    }
+                    if (ok && (rflags & RT_PORTS)) {
+                        for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
+                            if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) ok = false;
+                    }
+                }
+                if (ok) { placed = true; break; }
+#pragma unroll
+                for (int k = 0; k < K; ++k) gk[k] &= ~((owner && (u32)k == ko) ? bit : 0ull);
+                ++st_retries;
+            }
+            if (!placed) {
+                // exception list of the service: nodes with svcCount>0 or ≥5 recent failures
+                const u64 maxrep = r->maxrep;
+                const u32 e0 = a.list_off[rsvc], e1 = a.list_off[rsvc + 1];
+                u64 bhi = KEY_NONE, blo = KEY_NONE;
+                u32 be = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                for (u32 e = e0 + lane; e < e1; e += 64) {
+                    u32 nn = __hip_atomic_load(&a.list_node[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (nn == LIST_EMPTY) continue;
+                    u32 w = nn >> 6;
+                    u64 bit = 1ull << (nn & 63);
+                    if (!(a.F[(size_t)j * Wn + w] & bit)) continue;
+                    if (rflags & RT_RES) {
+                        i64 c = __hip_atomic_load(&a.cpu[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        i64 m = __hip_atomic_load(&a.mem[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!(rcpu <= c && rmem <= m)) continue;
+                    }
+                    if (rflags & RT_PORTS) {
+                        bool used = false;
+                        for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
+                            if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) used = true;
+                        if (used) continue;
+                    }
+                    u32 svn = __hip_atomic_load(&a.list_svc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    u32 fl = __hip_atomic_load(&a.list_fail[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((rflags & RT_MAXREP) && !((u64)svn < maxrep)) continue;   // filter.go:373-375
+                    u32 fcl = fl >= MAX_FAILURES ? fl - (MAX_FAILURES - 1) : 0u;    // nodeLess, scheduler.go:708-735
+                    u32 tot = __hip_atomic_load(&a.total[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    u64 hi = ((u64)fcl << 32) | svn, lo = ((u64)tot << 32) | nn;
+                    if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; be = e; }
+                }
+                u64 ghi = wave_min_u64(bhi);
+                if (ghi != KEY_NONE) {
+                    u64 glo = wave_min_u64(bhi == ghi ? blo : KEY_NONE);
+                    u64 who = ballot64(bhi == ghi && blo == glo);
+                    entry = (u32)__builtin_amdgcn_readlane((int)be, __ffsll((long long)who) - 1);
+                    n = (u32)glo;
+                    lvl = (u32)(glo >> 32) - base;
+                    placed = true;
+                    via_list = true;
+                    ++st_slow;
+                }
+            }
+            if (placed) {
+                const u32 w = n >> 6, ko = w >> 6;
+                const u64 bit = 1ull << (n & 63);
+                const bool owner = (w & 63) == lane;
+                if (counted) {
+                    if (lvl == (1u << NB) - 1u) want_rebase = true;   // level+1 leaves the planes: rebuild from total[]
+                    else bump(owner, ko, bit, lvl);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) tch[k] |= (owner && (u32)k == ko) ? bit : 0ull;
+                if (owner) {
+                    if (rcpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rcpu));
+                    if (rmem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rmem));
+                    if (rflags & RT_PORTS)
+                        for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p) atomicOr(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], bit);
+                    if (counted) {
+                        atomicAdd(a.total + n, 1u);
+                        if (via_list) atomicAdd(a.list_svc + entry, 1u);
+                        else {
+                            u64 nx = 0;
+#pragma unroll
+                            for (int k = 0; k < K; ++k) nx = ((u32)k == ko) ? (gXc[k] | bit) : nx;
+                            __hip_atomic_store(&a.X[(size_t)rsvc * Wn + w], nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            a.list_node[rslot] = n;
+                            a.list_svc[rslot] = 1;
+                            a.list_fail[rslot] = 0;
+                        }
+                    }
+                    a.log_node[ncommit] = n;
+                    a.log_task[ncommit] = gj;
+                    a.log_prev[ncommit] = last_lds[n];
+                    last_lds[n] = (int32_t)ncommit;
+                    a.out_node[gj] = (int32_t)n;
+                }
+                if (counted && !via_list) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        // slot d holds task j - ustart + d (+D when it was already consumed and refilled this round)
+                        const u32 held = j - (u32)ustart + (u32)d + ((int)d <= ustart ? (u32)D : 0u);
+                        if (sv[d] == rsvc && held < a.count) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) Xr[d][k] |= (owner && (u32)k == ko) ? bit : 0ull;
+                        }
+                    }
+                }
+                ++ncommit;
+            } else {
+                if (lane == 0) {
+                    a.out_node[gj] = -1;
+                    a.inf_task[ninf] = gj;
+                    a.inf_pos[ninf] = ncommit;
+                }
+                ++ninf;
+            }
+            ++j;
+            ustart = ustart + 1;
+        }
+        if (want_rebase) {
+            ++st_rebase;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            if (!build_planes()) {
+                if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+                fatal = true;
+            }
+        }
+        if (ustart >= D) ustart = 0;
+    }
+    for (u32 n = lane; n < a.n_nodes; n += 64) a.last[n] = last_lds[n];
+    if (lane == 0) {
+        a.ctl->ncommit = ncommit;
+        a.ctl->ninf = ninf;
+        a.ctl->verify_retries += st_retries;
+        a.ctl->slow_tasks += st_slow;
+        a.ctl->rebases += st_rebase;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_resolve2 — two cooperating wavefronts in one workgroup.
+//   wave 1 (LOADER)   streams, one block of R2_TB tasks ahead, the tasks' F rows, their services' X rows
+//                     and a compact task record from HBM into an LDS double buffer;
+//   wave 0 (RESOLVER) runs the sequential argmin/commit loop touching LDS and registers only: it never
+//                     consumes a VMEM or SMEM result, so no memory latency sits on the critical path and
+//                     its stores/atomics are fire-and-forget.
+// A lone wave issues roughly one dependent instruction per 4-5 cycles, so the resolver is built for a
+// SHORT instruction stream: a small non-unrolled loop (I-cache resident) and "hot level" masks —
+//   BELOW = nodes with level < h, LA = level == h, LB = level == h+1 (h = the level most picks come from) —
+// which turn the common-case argmin into ANDs plus wave ballots (no reduction at all: the lowest node index
+// is the lowest (k, lane, bit)). The bit-planes stay the ground truth; anything unusual (no candidate at
+// h/h+1, a candidate below h, host ports, a node already committed to in this window, level overflow)
+// takes the generic path = the full bit-sliced search + re-check + exception list.
+// X freshness: an X row staged in LDS may miss the commits of the last ≤2 blocks; the resolver keeps the
+// last 64 commits (service, node), one per lane, and ORs the matching ones in at consumption.
+// ---------------------------------------------------------------------------------------------
+#define R2_TB_MAX 16
+struct R2Rec {   // 32 B, staged per task
+    i64 cpu, mem;
+    u32 flags, svc, slot, pset;
+};
+
+template <int K, bool PROF>
+__global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
+    extern __shared__ unsigned char r2_lds[];
+    const u32 Wn = a.n_words, XS = a.xs, R2_TB = a.tb;
+    // LDS carve-up (all 16-byte aligned)
+    int32_t* last_lds = reinterpret_cast<int32_t*>(r2_lds);                                   // [n_nodes]
+    const size_t off_f = (((size_t)a.n_nodes * 4 + 15) / 16) * 16;
+    const size_t fblk = (size_t)R2_TB * Wn * 8, xblk = (size_t)R2_TB * XS * 8;
+    u64* Fb = reinterpret_cast<u64*>(r2_lds + off_f);                                          // [2][TB][Wn]
+    u64* Xb = reinterpret_cast<u64*>(r2_lds + off_f + 2 * fblk);                               // [2][TB][XS]
+    R2Rec* Tb = reinterpret_cast<R2Rec*>(r2_lds + off_f + 2 * fblk + 2 * xblk);                // [2][TB]
+    u32* flags_lds = reinterpret_cast<u32*>(r2_lds + off_f + 2 * fblk + 2 * xblk + 2 * R2_TB * sizeof(R2Rec));
+    // flags_lds[0..1] = ready[buf] (block index + 1), [2] = done (blocks finished by the resolver), [3] = abort
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 nblk = (a.count + R2_TB - 1) / R2_TB;
+    if (a.ctl->error != ERR_NONE) return;
+    if (tid < 4) flags_lds[tid] = 0;
+    for (u32 n = tid; n < a.n_nodes; n += 128) last_lds[n] = a.last[n];
+    __syncthreads();
+
+    if (wave == 1) {
+        // =============================== LOADER ===============================
+        for (u32 b = 0; b < nblk; ++b) {
+            const u32 buf = b & 1;
+            if (b >= 2) {   // buffer is free (and every commit of blocks ≤ b-2 is visible) once block b-2 is done
+                u32 spins = 0;
+                while (__hip_atomic_load(&flags_lds[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < b - 1) {
+                    if (__hip_atomic_load(&flags_lds[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 26)) return;   // bounded: never hang the GPU
+                }
+            }
+            const u32 t0 = b * R2_TB, nt = min((u32)R2_TB, a.count - t0);
+            // task records
+            if (lane < nt) {
+                const RTask* r = a.rt + a.j0 + t0 + lane;
+                R2Rec rec;
+                rec.cpu = r->cpu;
+                rec.mem = r->mem;
+                rec.flags = r->flags;
+                rec.svc = r->svc;
+                rec.slot = r->slot;
+                rec.pset = r->pset;
+                Tb[buf * R2_TB + lane] = rec;
+            }
+            // F rows: one contiguous run of nt*Wn words; 8 loads in flight per lane
+            {
+                const u64* src = a.F + (size_t)t0 * Wn;
+                u64* dst = Fb + (size_t)buf * R2_TB * Wn;
+                const u32 nw = nt * Wn;
+                for (u32 i0 = 0; i0 < nw; i0 += 64 * 8) {
+                    u64 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        u32 i = i0 + 64 * q + lane;
+                        v[q] = i < nw ? src[i] : 0ull;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        u32 i = i0 + 64 * q + lane;
+                        if (i < nw) dst[i] = v[q];
+                    }
+                }
+            }
+            // X rows (mutable: read past the L1); 4 rows = 4*K loads in flight per lane
+            for (u32 t = 0; t < nt; t += 4) {
+                u64 v[4][K];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ht = t + q < nt;
+                    const u32 svc = ht ? cload(&a.rt[a.j0 + t0 + t + q].svc) : 0u;
+                    const u64* src = a.X + (size_t)svc * XS;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const u32 i = lane + 64 * k;
+                        v[q][k] = (ht && i < Wn) ? __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (t + q < nt) {
+                        u64* dst = Xb + ((size_t)buf * R2_TB + t + q) * XS;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const u32 i = lane + 64 * k;
+                            if (i < Wn) dst[i] = v[q][k];
+                        }
+                    }
+                }
+            }
+            __hip_atomic_store(&flags_lds[buf], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+
+    // =============================== RESOLVER ===============================
+    u32 ncommit = a.ctl->ncommit, ninf = a.ctl->ninf;
+    u32 st_retries = 0, st_slow = 0, st_rebase = 0, st_generic = 0, st_spins = 0;
+    const u32 idx_bits = 32 - __clz((Wn * 64) | 1u);
+    const u32 idx_mask = (1u << idx_bits) - 1u;
+    u32 NB = 1, base = 0, h = 0;
+    u64 pl[R1_NBR][K];   // level bit-planes of the owned words {lane + 64k}
+    u64 tch[K];          // nodes committed to since the scan
+    u64 BELOW[K], LA[K], LB[K], VAL[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        tch[k] = 0;
+        VAL[k] = (lane + 64 * k) < Wn ? a.valid[lane + 64 * k] : 0ull;
+    }
+    u32 ring_svc = 0xFFFFFFFFu, ring_node = 0;   // lane e: the commit with (index mod 64) == e
+
+    auto build_planes = [&]() __attribute__((always_inline)) -> bool {
+        u32 lo = 0xFFFFFFFFu, hi = 0;
+        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if ((VAL[k] >> i) & 1ull) {
+                    u32 t = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lo = min(lo, t);
+                    hi = max(hi, t);
+                }
+            }
+        }
+        lo = wave_min_u32(lo);
+        hi = wave_max_u32(hi);
+        if (lo == 0xFFFFFFFFu) { lo = 0; hi = 0; }
+        u32 need = 32 - __clz((hi - lo) | 1u);
+        u32 cap = min((u32)R1_NBR, 32u - idx_bits);
+        if (need > cap) return false;
+        base = lo;
+        NB = min(cap, need + 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int b = 0; b < R1_NBR; ++b) pl[b][k] = 0;
+        }
+        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                u32 lvl = 0;
+                if ((VAL[k] >> i) & 1ull)
+                    lvl = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+#pragma unroll
+                for (int b = 0; b < R1_NBR; ++b) pl[b][k] |= (u64)((lvl >> b) & 1u) << i;
+            }
+        }
+        return true;
+    };
+    // hot masks from the planes for level hh: BELOW = level < hh, LA = level == hh, LB = level == hh+1
+    auto derive_masks = [&](u32 hh) __attribute__((always_inline)) {
+        h = hh;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u64 lt = 0, eq = VAL[k], eq1 = VAL[k];
+            const u32 h1 = hh + 1;
+#pragma unroll
+            for (int b = R1_NBR - 1; b >= 0; --b) {
+                const u64 p = pl[b][k];
+                if (hh >> b & 1u) { lt |= eq & ~p; eq &= p; } else { eq &= ~p; }
+                if (h1 >> b & 1u) eq1 &= p; else eq1 &= ~p;
+            }
+            BELOW[k] = lt;
+            LA[k] = eq;
+            LB[k] = eq1;
+        }
+    };
+    // most populated level among {levels of valid nodes}: cheap proxy = level of the first node of the fullest LA
+    auto search = [&](const u64 (&mk)[K]) __attribute__((always_inline)) -> u32 {
+        u64 m[K];
+        u32 lv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { m[k] = mk[k]; lv[k] = 0; }
+#pragma unroll
+        for (int b = R1_NBR - 1; b >= 0; --b) {
+            if ((u32)b < NB) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    u64 t = m[k] & ~pl[b][k];
+                    bool nz = t != 0;
+                    m[k] = nz ? t : m[k];
+                    lv[k] |= nz ? 0u : (1u << b);
+                }
+            }
+        }
+        u32 best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u32 w = lane + 64 * k;
+            u32 cand = (lv[k] << idx_bits) | (w * 64 + (u32)(__ffsll((long long)m[k]) - 1));
+            best = min(best, m[k] ? cand : 0xFFFFFFFFu);
+        }
+        return wave_min_u32_dpp(best);
+    };
+    auto bump = [&](bool owner, u32 ko, u64 bit, u32 lvl) __attribute__((always_inline)) {
+        const u32 flip = lvl ^ (lvl + 1);   // always a run of low bits: planes 0..ctz(~lvl) flip
+        u64 xk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) xk[k] = (owner && (u32)k == ko) ? bit : 0ull;
+#pragma unroll
+        for (int b = 0; b < R1_NBR; ++b) {
+            if (__builtin_expect(!(flip >> b & 1u), b > 0)) break;
+#pragma unroll
+            for (int k = 0; k < K; ++k) pl[b][k] ^= xk[k];
+        }
+    };
+    // lowest node of a per-lane candidate set: lowest k, then lowest lane, then lowest bit
+    auto first_node = [&](const u64 (&c)[K], u32* node) __attribute__((always_inline)) -> bool {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u64 any = ballot64(c[k] != 0);
+            if (any) {
+                int l = __ffsll((long long)any) - 1;
+                u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)c[k], l);
+                u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(c[k] >> 32), l);
+                u64 word = ((u64)hi << 32) | lo;
+                *node = ((u32)l + 64u * (u32)k) * 64u + (u32)(__ffsll((long long)word) - 1);
+                return true;
+            }
+        }
+        return false;
+    };
+
+    if (!build_planes()) {
+        if (lane == 0) {
+            a.ctl->error = ERR_LEVEL_RANGE;
+            __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    derive_masks(0);
+    bool fatal = false;
+    constexpr bool prof = PROF;
+    u64 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tk = prof ? wall_clock64() : 0;
+    const u64 c_start = prof ? clock64() : 0, w_start = tk;
+#define R2_TICK(slot) do { if constexpr (PROF) { u64 _n = wall_clock64(); cyc[slot] += _n - tk; tk = _n; } } while (0)
+
+    for (u32 b = 0; b < nblk && !fatal; ++b) {
+        const u32 buf = b & 1;
+        {
+            u32 spins = 0;
+            while (__hip_atomic_load(&flags_lds[buf], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != b + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 26)) { fatal = true; break; }
+            }
+            st_spins += spins;
+            if (fatal) break;
+        }
+        R2_TICK(0);
+        const u32 t0 = b * R2_TB, nt = min((u32)R2_TB, a.count - t0);
+        for (u32 t = 0; t < nt && !fatal; ++t) {
+            const u32 j = t0 + t, gj = a.j0 + j;
+            const R2Rec rec = Tb[buf * R2_TB + t];
+            const u32 rflags = (u32)__builtin_amdgcn_readfirstlane((int)rec.flags);
+            const u32 rsvc = (u32)__builtin_amdgcn_readfirstlane((int)rec.svc);
+            const u64* frow = Fb + ((size_t)buf * R2_TB + t) * Wn;
+            const u64* xrow = Xb + ((size_t)buf * R2_TB + t) * XS;
+            u64 mk[K], Xc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const u32 w = lane + 64 * k;
+                const bool in = w < Wn;
+                Xc[k] = in ? xrow[w] : 0ull;
+                mk[k] = in ? frow[w] : 0ull;
+            }
+            // commits younger than the staged X row
+            {
+                u64 match = ballot64(ring_svc == rsvc);
+                while (__builtin_expect(match != 0, 0)) {
+                    int e = __ffsll((long long)match) - 1;
+                    match &= match - 1;
+                    u32 nn = (u32)__builtin_amdgcn_readlane((int)ring_node, e);
+                    u32 ww = nn >> 6;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) Xc[k] |= (lane + 64u * k == ww) ? (1ull << (nn & 63)) : 0ull;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) mk[k] &= ~Xc[k];
+            R2_TICK(1);
+
+            // ---------------- fast path: winner at the hot level h (LA) or h+1 (LB), nothing below ----------------
+            bool fast = !(rflags & (RT_PORTS | RT_UNCOUNTED));
+            u32 n = 0, lvl = 0;
+            if (fast) {
+                u64 cb[K], ca[K];
+                bool anyb = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    cb[k] = mk[k] & BELOW[k];
+                    ca[k] = mk[k] & LA[k];
+                    anyb = anyb || (cb[k] != 0);
+                }
+                if (__builtin_expect(ballot64(anyb) != 0, 0)) fast = false;
+                else if (first_node(ca, &n)) lvl = h;
+                else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) ca[k] = mk[k] & LB[k];
+                    if (first_node(ca, &n)) lvl = h + 1;
+                    else fast = false;
+                }
+            }
+            u32 w = n >> 6, ko = w >> 6;
+            u64 bit = 1ull << (n & 63);
+            bool owner = (w & 63) == lane;
+            if (fast) {
+                u64 tsel = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? tch[k] : tsel;
+                if (ballot64(owner && (tsel & bit)) != 0 || lvl >= (1u << NB) - 1u) fast = false;
+            }
+            bool placed = fast, via_list = false;
+            u32 entry = 0;
+            bool want_rebase = false;
+            R2_TICK(2);
+            if (__builtin_expect(!fast, 0)) {
+                // ---------------- generic path: every feature, full bit-sliced search ----------------
+                ++st_generic;
+                const i64 rcpu = rec.cpu, rmem = rec.mem;
+                const u32 rpset = rec.pset;
+                u64 gk[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) gk[k] = mk[k];
+                placed = false;
+                for (;;) {
+                    u32 g = search(gk);
+                    if (g == 0xFFFFFFFFu) break;
+                    n = g & idx_mask;
+                    lvl = g >> idx_bits;
+                    w = n >> 6;
+                    ko = w >> 6;
+                    bit = 1ull << (n & 63);
+                    owner = (w & 63) == lane;
+                    u64 tsel = 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? tch[k] : tsel;
+                    bool ok = true;
+                    if (ballot64(owner && (tsel & bit)) != 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                        if (rflags & RT_RES) {
+                            i64 c = __hip_atomic_load(&a.cpu[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            i64 m = __hip_atomic_load(&a.mem[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = (rcpu <= c) && (rmem <= m);
+                        }
+                        if (ok && (rflags & RT_PORTS)) {
+                            for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
+                                if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) ok = false;
+                        }
+                    }
+                    if (ok) { placed = true; break; }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) gk[k] &= ~((owner && (u32)k == ko) ? bit : 0ull);
+                    ++st_retries;
+                }
+                if (!placed) {
+                    const u64 maxrep = a.rt[gj].maxrep;
+                    const u32 e0 = a.list_off[rsvc], e1 = a.list_off[rsvc + 1];
+                    u64 bhi = KEY_NONE, blo = KEY_NONE;
+                    u32 be = 0;
+                    // (no fence: every load below is an agent-scope atomic served by the L2 that also executed
+                    //  this wave's own atomics/stores to the same words)
+                    for (u32 e = e0 + lane; e < e1; e += 64) {
+                        u32 nn = __hip_atomic_load(&a.list_node[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (nn == LIST_EMPTY) continue;
+                        u32 ww = nn >> 6;
+                        u64 bb = 1ull << (nn & 63);
+                        if (!(a.F[(size_t)j * Wn + ww] & bb)) continue;
+                        if (rflags & RT_RES) {
+                            i64 c = __hip_atomic_load(&a.cpu[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            i64 m = __hip_atomic_load(&a.mem[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (!(rcpu <= c && rmem <= m)) continue;
+                        }
+                        if (rflags & RT_PORTS) {
+                            bool used = false;
+                            for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
+                                if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + ww], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bb) used = true;
+                            if (used) continue;
+                        }
+                        u32 svn = __hip_atomic_load(&a.list_svc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u32 fl = __hip_atomic_load(&a.list_fail[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((rflags & RT_MAXREP) && !((u64)svn < maxrep)) continue;
+                        u32 fcl = fl >= MAX_FAILURES ? fl - (MAX_FAILURES - 1) : 0u;
+                        u32 tot = __hip_atomic_load(&a.total[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u64 hi = ((u64)fcl << 32) | svn, lo = ((u64)tot << 32) | nn;
+                        if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; be = e; }
+                    }
+                    u64 ghi = wave_min_u64(bhi);
+                    if (ghi != KEY_NONE) {
+                        u64 glo = wave_min_u64(bhi == ghi ? blo : KEY_NONE);
+                        u64 who = ballot64(bhi == ghi && blo == glo);
+                        entry = (u32)__builtin_amdgcn_readlane((int)be, __ffsll((long long)who) - 1);
+                        n = (u32)glo;
+                        lvl = (u32)(glo >> 32) - base;
+                        w = n >> 6;
+                        ko = w >> 6;
+                        bit = 1ull << (n & 63);
+                        owner = (w & 63) == lane;
+                        placed = true;
+                        via_list = true;
+                        ++st_slow;
+                    }
+                }
+            }
+
+            R2_TICK(3);
+            if (placed) {
+                // ---------------- commit == NodeInfo.addTask (nodeinfo.go:108-154) ----------------
+                const bool counted = !(rflags & RT_UNCOUNTED);
+                if (counted) {
+                    if (lvl >= (1u << NB) - 1u) want_rebase = true;
+                    else {
+                        bump(owner, ko, bit, lvl);
+                        if (fast) {   // node moves h→h+1 (LA→LB) or h+1→h+2 (leaves LB)
+                            const u64 ob = owner ? bit : 0ull;
+                            const bool from_a = lvl == h;
+#pragma unroll
+                            for (int k = 0; k < K; ++k) {
+                                const u64 x = ((u32)k == ko) ? ob : 0ull;
+                                LA[k] &= ~x;
+                                LB[k] = from_a ? (LB[k] | x) : (LB[k] & ~x);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) tch[k] |= (owner && (u32)k == ko) ? bit : 0ull;
+                if (owner) {
+                    if (rec.cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rec.cpu));
+                    if (rec.mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rec.mem));
+                    if (rflags & RT_PORTS)
+                        for (u32 p = a.pset_off[rec.pset]; p < a.pset_off[rec.pset + 1]; ++p) atomicOr(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], bit);
+                    if (counted) {
+                        atomicAdd(a.total + n, 1u);
+                        if (via_list) atomicAdd(a.list_svc + entry, 1u);
+                        else {
+                            atomicOr(&a.X[(size_t)rsvc * XS + w], bit);
+                            a.list_node[rec.slot] = n;
+                            a.list_svc[rec.slot] = 1;
+                            a.list_fail[rec.slot] = 0;
+                        }
+                    }
+                    a.log_node[ncommit] = n;
+                    a.log_task[ncommit] = gj;
+                    a.log_prev[ncommit] = last_lds[n];
+                    last_lds[n] = (int32_t)ncommit;
+                    a.out_node[gj] = (int32_t)n;
+                }
+                if (counted && !via_list) {   // remember the commit for rows staged before it
+                    const bool me = lane == (ncommit & 63u);
+                    ring_svc = me ? rsvc : ring_svc;
+                    ring_node = me ? n : ring_node;
+                }
+                ++ncommit;
+                if (!fast && !want_rebase && counted) {
+                    // a generic commit may have moved a node across the hot levels; a plain pick at another level
+                    // re-centres the hot level there (nodes below it are handled exactly through BELOW)
+                    derive_masks((!via_list && lvl + 2 < (1u << NB)) ? lvl : h);
+                }
+                if (fast && lvl == h + 1) {
+                    // picks come from h+1: if level h is exhausted for everybody, advance the hot level
+                    bool anya = false;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) anya = anya || (LA[k] != 0);
+                    if (!ballot64(anya) && h + 2 < (1u << NB) - 1u) derive_masks(h + 1);
+                }
+            } else {
+                if (lane == 0) {
+                    a.out_node[gj] = -1;
+                    a.inf_task[ninf] = gj;
+                    a.inf_pos[ninf] = ncommit;
+                }
+                ++ninf;
+            }
+            if (__builtin_expect(want_rebase, 0)) {
+                ++st_rebase;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                if (!build_planes()) {
+                    if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+                    fatal = true;
+                } else derive_masks(0);
+            }
+            R2_TICK(4);
+        }
+        // every store/atomic of this block is in L2 before the loader may restage rows that depend on it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&flags_lds[2], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        R2_TICK(5);
+    }
+    if (fatal) __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (u32 n = lane; n < a.n_nodes; n += 64) a.last[n] = last_lds[n];
+    if (lane == 0) {
+        a.ctl->ncommit = ncommit;
+        a.ctl->ninf = ninf;
+        a.ctl->verify_retries += st_retries;
+        a.ctl->slow_tasks += st_slow;
+        a.ctl->rebases += st_rebase;
+        a.ctl->generic_tasks += st_generic;
+        a.ctl->spin_waits += st_spins;
+        if (prof) { cyc[6] = clock64() - c_start; cyc[7] = wall_clock64() - w_start; }
+        for (int q = 0; q < 8; ++q) a.ctl->cyc[q] += cyc[q];
     }
 }
 

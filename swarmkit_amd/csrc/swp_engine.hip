@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <set>
@@ -180,6 +181,8 @@ struct swp_engine {
 
     swp_stats_t stats{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_pool;   // per-launch kernel timing (SWP_CFG_PROFILE)
+    bool host_dirty_since_save = true;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -548,6 +551,36 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     return SWP_OK;
 }
 
+template <int K, int D>
+hipError_t launch_resolve1(const ResolveArgs& ra, size_t lds, hipStream_t s) {
+    (void)lds;
+    size_t need = (size_t)ra.n_nodes * 4 + 64;   // last commit per node
+    static size_t attr_bytes = 0;
+    if (need > 64 * 1024 && need > attr_bytes) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve1<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (r != hipSuccess) return r;
+        attr_bytes = 160 * 1024 - 512;
+    }
+    hipLaunchKernelGGL((k_resolve1<K, D>), dim3(1), dim3(64), need, s, ra);
+    return hipGetLastError();
+}
+
+template <int K, bool PROF>
+hipError_t launch_resolve2p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve2<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (r != hipSuccess) return r;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_resolve2<K, PROF>), dim3(1), dim3(128), lds, s, ra);
+    return hipGetLastError();
+}
+template <int K>
+hipError_t launch_resolve2(const ResolveArgs& ra, size_t lds, hipStream_t s) {
+    return (ra.dbg & 16u) ? launch_resolve2p<K, true>(ra, lds, s) : launch_resolve2p<K, false>(ra, lds, s);
+}
+
 template <int K>
 hipError_t launch_resolve(const ResolveArgs& ra, uint32_t threads, size_t lds, hipStream_t s) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -606,8 +639,10 @@ int batch_run(swp_engine* e, swp_batch* b) {
     if (rc) return rc;
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[1], st));
 
-    // resolver geometry
+    // resolver geometry: one wavefront (barrier-free) when the node words fit 64 lanes x 8, else one workgroup
+    const bool one_wave = (e->cfg.resolver_threads == 0 ? Wn <= 512 : e->cfg.resolver_threads == 64) && (size_t)N * 4 + 64 <= 160 * 1024 - 512;
     uint32_t threads = e->cfg.resolver_threads;
+    if (one_wave) threads = 64;
     if (threads == 0) threads = Wn <= 256 ? 256 : 1024;
     threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, (threads / 64) * 64));
     uint32_t K = (Wn + threads - 1) / threads;
@@ -618,9 +653,27 @@ int batch_run(swp_engine* e, swp_batch* b) {
     uint32_t nb_alloc = (uint32_t)std::min<size_t>(16, (lds_budget - fixed) / ((size_t)Wn * 8));
     size_t lds = fixed + (size_t)nb_alloc * Wn * 8;
 
-    float ms_scan = 0, ms_res = 0;
-    (void)ms_scan;
-    (void)ms_res;
+    // resolver variant: 2 = two-wave LDS-staged (default when it fits), 1 = one wave + register ring, 0 = one workgroup
+    int variant = getenv("SWP_RESOLVER") ? atoi(getenv("SWP_RESOLVER")) : 2;
+    uint32_t r2_tb = 0;
+    size_t r2_lds = 0;
+    if (variant == 2) {
+        const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
+        const size_t fixed2 = off_f + 2 * R2_TB_MAX * 32 + 64;
+        size_t per_task = (size_t)4 * Wn * 8;   // two buffers x (F row + X row)
+        if (fixed2 + 4 * per_task <= lds_budget && Wn <= 512) {
+            r2_tb = (uint32_t)std::min<size_t>(R2_TB_MAX, (lds_budget - fixed2) / per_task);
+            r2_lds = fixed2 + (size_t)r2_tb * per_task;
+        } else variant = one_wave ? 1 : 0;
+    }
+    if (variant == 1 && !one_wave) variant = 0;
+    if (prof) {
+        while (e->ev_pool.size() < (size_t)4 * b->n_windows) {
+            hipEvent_t x;
+            HIPCHECK(e, hipEventCreate(&x));
+            e->ev_pool.push_back(x);
+        }
+    }
     for (uint32_t wi = 0; wi < b->n_windows; ++wi) {
         uint32_t j0 = wi * b->window, cnt = std::min(b->window, T - j0);
         ScanArgs sa{};
@@ -637,7 +690,9 @@ int batch_run(swp_engine* e, swp_batch* b) {
         sa.pset_ids = b->d_pset_ids.as<uint32_t>();
         sa.F = b->d_F.as<u64>();
         dim3 sgrid((Wn + SCAN_WPW - 1) / SCAN_WPW, (cnt + SCAN_TCH - 1) / SCAN_TCH);
+        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 0], st));
         hipLaunchKernelGGL(k_scan, sgrid, dim3(64), 0, st, sa);
+        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 1], st));
 
         ResolveArgs ra{};
         ra.n_nodes = N;
@@ -645,6 +700,9 @@ int batch_run(swp_engine* e, swp_batch* b) {
         ra.j0 = j0;
         ra.count = cnt;
         ra.nb_alloc = nb_alloc;
+        ra.dbg = getenv("SWP_DBG") ? (uint32_t)atoi(getenv("SWP_DBG")) : 0u;
+        ra.xs = Wn;
+        ra.tb = r2_tb;
         ra.F = b->d_F.as<u64>();
         ra.valid = e->d_valid.as<u64>();
         ra.X = b->d_X.as<u64>();
@@ -668,6 +726,25 @@ int batch_run(swp_engine* e, swp_batch* b) {
         ra.inf_pos = b->d_inf_pos.as<uint32_t>();
         ra.ctl = b->d_ctl.as<Ctl>();
         hipError_t r;
+        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
+        if (variant == 2) {
+            const uint32_t K2 = (Wn + 63) / 64;
+            switch (K2) {
+            case 1: r = launch_resolve2<1>(ra, r2_lds, st); break;
+            case 2: r = launch_resolve2<2>(ra, r2_lds, st); break;
+            case 3: r = launch_resolve2<3>(ra, r2_lds, st); break;
+            case 4: r = launch_resolve2<4>(ra, r2_lds, st); break;
+            default: r = launch_resolve2<8>(ra, r2_lds, st); break;
+            }
+        } else if (variant == 1) {
+            switch (K) {
+            case 1: r = launch_resolve1<1, 8>(ra, lds, st); break;
+            case 2: r = launch_resolve1<2, 8>(ra, lds, st); break;
+            case 3: r = launch_resolve1<3, 8>(ra, lds, st); break;
+            case 4: r = launch_resolve1<4, 8>(ra, lds, st); break;
+            default: r = launch_resolve1<8, 4>(ra, lds, st); break;
+            }
+        } else
         switch (K) {
         case 1: r = launch_resolve<1>(ra, threads, lds, st); break;
         case 2: r = launch_resolve<2>(ra, threads, lds, st); break;
@@ -676,6 +753,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         default: r = launch_resolve<16>(ra, threads, lds, st); break;
         }
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_resolve launch: %s", hipGetErrorString(r));
+        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
     }
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
 
@@ -728,15 +806,31 @@ int batch_run(swp_engine* e, swp_batch* b) {
         (void)hipEventElapsedTime(&c, e->ev[1], e->ev[2]);
         (void)hipEventElapsedTime(&d, e->ev[2], e->ev[3]);
         (void)hipEventElapsedTime(&t, e->ev[0], e->ev[3]);
+        float scan_sum = 0, res_sum = 0;
+        for (uint32_t wi = 0; wi < b->n_windows; ++wi) {
+            float x = 0, y = 0;
+            (void)hipEventElapsedTime(&x, e->ev_pool[4 * wi + 0], e->ev_pool[4 * wi + 1]);
+            (void)hipEventElapsedTime(&y, e->ev_pool[4 * wi + 2], e->ev_pool[4 * wi + 3]);
+            scan_sum += x;
+            res_sum += y;
+        }
+        (void)c;
         e->stats.ms_classes = a;
-        e->stats.ms_scan = 0;
-        e->stats.ms_resolve = c;   // scan+resolve interleaved per window
+        e->stats.ms_scan = scan_sum;      // Σ over windows of k_scan launch durations
+        e->stats.ms_resolve = res_sum;    // Σ over windows of k_resolve launch durations
         e->stats.ms_explain = d;
         e->stats.ms_total = t;
     }
     e->stats.verify_retries += ctl.verify_retries;
     e->stats.slow_path_tasks += ctl.slow_tasks;
     e->stats.rebase_events += ctl.rebases;
+    e->stats.generic_tasks += ctl.generic_tasks;
+    e->stats.resolver_spins += ctl.spin_waits;
+    if (getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16))
+        fprintf(stderr, "[swp] resolver cycles (100MHz ticks): wait %llu prep %llu pick %llu generic %llu commit %llu blockend %llu | commits %u inf %u generic %llu\n",
+                ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.cyc[4], ctl.cyc[5], ctl.ncommit, ctl.ninf, ctl.generic_tasks);
+    if (getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16) && ctl.cyc[7])
+        fprintf(stderr, "[swp] shader clock: %llu cycles / %llu x10ns => %.0f MHz\n", ctl.cyc[6], ctl.cyc[7], (double)ctl.cyc[6] / ((double)ctl.cyc[7] * 0.01));
     e->stats.last_windows = b->n_windows;
     e->stats.last_static_classes = b->n_sc;
     e->stats.scan_launches += b->n_windows;
@@ -746,6 +840,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
 }
 
 void host_apply_placement(swp_engine* e, uint32_t node, uint32_t service, int64_t cpu, int64_t mem, uint32_t port_set, bool counted, bool add) {
+    e->host_dirty_since_save = true;
     HostNode& h = e->nodes[node];
     if (add) {
         h.row.cpu -= cpu;
@@ -871,6 +966,7 @@ void swp_destroy(swp_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -906,6 +1002,7 @@ int swp_intern_lookup(swp_engine* e, int space, uint32_t id, char* out, size_t c
 int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* node_labels, uint32_t n_node_labels, const swp_kv* engine_labels,
                     uint32_t n_engine_labels, const uint32_t* plugins, uint32_t n_plugins) {
     if (!e || !row) return SWP_EINVAL;
+    e->host_dirty_since_save = true;
     if (row->node >= e->spaces[SWP_SPACE_NODE_ID].strs.size()) return e->fail(SWP_EINVAL, "node id %u was never interned", row->node);
     if (row->total >= (1u << 30)) return e->fail(SWP_ERANGE, "ActiveTasksCount out of range");
     if (row->node >= e->nodes.size()) e->nodes.resize(row->node + 1);
@@ -923,6 +1020,7 @@ int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* node_l
 
 int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_t cpu, int64_t mem, uint32_t total) {
     if (!e) return SWP_EINVAL;
+    e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     HostNode& h = e->nodes[node];
     if (h.row.flags != flags) e->dev_static_dirty = true;
@@ -936,6 +1034,7 @@ int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_
 
 int swp_node_remove(swp_engine* e, uint32_t node) {
     if (!e) return SWP_EINVAL;
+    e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_OK;   // delete of an absent key is a no-op
     HostNode& h = e->nodes[node];
     for (auto& kv : h.svc) e->svc_nodes[kv.first].erase(node);
@@ -956,6 +1055,7 @@ int swp_node_get(swp_engine* e, uint32_t node, swp_node_row* out) {
 
 int swp_node_set_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint32_t count) {
     if (!e) return SWP_EINVAL;
+    e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     if (count >= (1u << 30)) return e->fail(SWP_ERANGE, "service task count out of range");
     HostNode& h = e->nodes[node];
@@ -979,6 +1079,7 @@ int swp_node_get_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint3
 
 int swp_node_set_failures(swp_engine* e, uint32_t node, uint32_t service, uint64_t spec_version, uint32_t count) {
     if (!e) return SWP_EINVAL;
+    e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     if (count >= (1u << 30)) return e->fail(SWP_ERANGE, "failure count out of range");
     HostNode& h = e->nodes[node];
@@ -993,6 +1094,7 @@ int swp_node_set_failures(swp_engine* e, uint32_t node, uint32_t service, uint64
 
 int swp_node_port(swp_engine* e, uint32_t node, uint32_t protocol, uint32_t port, int set) {
     if (!e) return SWP_EINVAL;
+    e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     uint64_t k = port_key(protocol, port);
     if (set) {
@@ -1100,6 +1202,17 @@ int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* ou
     return SWP_OK;
 }
 
+int swp_batch_results(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* out_fail_hist) {
+    if (!e || !b || (!out_node && b->T)) return SWP_EINVAL;
+    if (!b->ran) return e->fail(SWP_EINVAL, "swp_batch_results before swp_batch_run");
+    (void)hipSetDevice(e->device);
+    if (b->T == 0 || e->n_nodes == 0) return SWP_OK;
+    HIPCHECK(e, hipMemcpyAsync(out_node, b->d_out.p, (size_t)b->T * 4, hipMemcpyDeviceToHost, e->stream));
+    if (out_fail_hist) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, b->d_hist.p, (size_t)b->T * 8 * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return SWP_OK;
+}
+
 void swp_batch_free(swp_engine* e, swp_batch* b) {
     if (e) {
         (void)hipSetDevice(e->device);
@@ -1135,6 +1248,7 @@ int swp_state_save(swp_engine* e) {
     e->saved.svc_nodes_ = e->svc_nodes;
     e->saved.port_nodes_ = e->port_nodes;
     e->saved.valid = true;
+    e->host_dirty_since_save = false;
     return SWP_OK;
 }
 
@@ -1147,10 +1261,13 @@ int swp_state_restore(swp_engine* e) {
     HIPCHECK(e, hipMemcpyAsync(e->d_cpu.p, e->d_save_cpu.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHECK(e, hipMemcpyAsync(e->d_mem.p, e->d_save_mem.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHECK(e, hipMemcpyAsync(e->d_total.p, e->d_save_total.p, cap * 4, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHECK(e, hipStreamSynchronize(e->stream));
-    e->nodes = e->saved.nodes;
-    e->svc_nodes = e->saved.svc_nodes_;
-    e->port_nodes = e->saved.port_nodes_;
+    if (e->host_dirty_since_save) {   // the host mirror only moves in swp_batch_fetch / swp_commit / node mutators
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        e->nodes = e->saved.nodes;
+        e->svc_nodes = e->saved.svc_nodes_;
+        e->port_nodes = e->saved.port_nodes_;
+        e->host_dirty_since_save = false;
+    }
     e->dev_dynamic_dirty = false;
     return SWP_OK;
 }
