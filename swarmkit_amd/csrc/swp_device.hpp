@@ -1270,6 +1270,7 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
 
     // =============================== RESOLVER ===============================
     u32 ncommit = a.ctl->ncommit, ninf = a.ctl->ninf;
+    u32 applied = ncommit;   // commits [applied, ncommit) still live only in the lane ring
     u32 st_retries = 0, st_slow = 0, st_rebase = 0, st_generic = 0, st_spins = 0;
     const u32 idx_bits = 32 - __clz((Wn * 64) | 1u);
     const u32 idx_mask = (1u << idx_bits) - 1u;
@@ -1282,7 +1283,10 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
         tch[k] = 0;
         VAL[k] = (lane + 64 * k) < Wn ? a.valid[lane + 64 * k] : 0ull;
     }
-    u32 ring_svc = 0xFFFFFFFFu, ring_node = 0;   // lane e: the commit with (index mod 64) == e
+    // commit ring: lane e holds the commit whose index ≡ e (mod 64). It serves (1) X freshness for rows
+    // staged before the commit and (2) the deferred, lane-parallel application of the side effects.
+    u32 rg_svc = 0xFFFFFFFFu, rg_node = 0, rg_task = 0, rg_slot = 0, rg_flags = 0;
+    i64 rg_cpu = 0, rg_mem = 0;
 
     auto build_planes = [&]() __attribute__((always_inline)) -> bool {
         u32 lo = 0xFFFFFFFFu, hi = 0;
@@ -1339,7 +1343,6 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
             LB[k] = eq1;
         }
     };
-    // most populated level among {levels of valid nodes}: cheap proxy = level of the first node of the fullest LA
     auto search = [&](const u64 (&mk)[K]) __attribute__((always_inline)) -> u32 {
         u64 m[K];
         u32 lv[K];
@@ -1366,11 +1369,9 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
         }
         return wave_min_u32_dpp(best);
     };
-    auto bump = [&](bool owner, u32 ko, u64 bit, u32 lvl) __attribute__((always_inline)) {
-        const u32 flip = lvl ^ (lvl + 1);   // always a run of low bits: planes 0..ctz(~lvl) flip
-        u64 xk[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) xk[k] = (owner && (u32)k == ko) ? bit : 0ull;
+    // level+1 for one node: planes 0..ctz(~lvl) flip (always a run of low bits → early-exit chain)
+    auto bump = [&](const u64 (&xk)[K], u32 lvl) __attribute__((always_inline)) {
+        const u32 flip = lvl ^ (lvl + 1);
 #pragma unroll
         for (int b = 0; b < R1_NBR; ++b) {
             if (__builtin_expect(!(flip >> b & 1u), b > 0)) break;
@@ -1378,21 +1379,32 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
             for (int k = 0; k < K; ++k) pl[b][k] ^= xk[k];
         }
     };
-    // lowest node of a per-lane candidate set: lowest k, then lowest lane, then lowest bit
-    auto first_node = [&](const u64 (&c)[K], u32* node) __attribute__((always_inline)) -> bool {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            u64 any = ballot64(c[k] != 0);
-            if (any) {
-                int l = __ffsll((long long)any) - 1;
-                u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)c[k], l);
-                u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(c[k] >> 32), l);
-                u64 word = ((u64)hi << 32) | lo;
-                *node = ((u32)l + 64u * (u32)k) * 64u + (u32)(__ffsll((long long)word) - 1);
-                return true;
+    // Apply the side effects of commits [applied, ncommit) — one commit per lane: residual update of the
+    // node row (NodeInfo.addTask, nodeinfo.go:108-154), exception-list entry, commit log + per-node chain.
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (ncommit != applied) {
+            const u32 last_c = ncommit - 1;
+            const u32 ce = last_c - ((last_c - lane) & 63u);   // this lane's newest commit index
+            if (ce >= applied && ce <= last_c) {
+                const u32 n = rg_node;
+                if (rg_cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rg_cpu));
+                if (rg_mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rg_mem));
+                if (rg_flags & 1u) {   // counted
+                    atomicAdd(a.total + n, 1u);
+                    if (rg_flags & 2u) atomicAdd(a.list_svc + rg_slot, 1u);   // placed through the exception list
+                    else {
+                        a.list_node[rg_slot] = n;
+                        a.list_svc[rg_slot] = 1;
+                        a.list_fail[rg_slot] = 0;
+                    }
+                }
+                a.log_node[ce] = n;
+                a.log_task[ce] = rg_task;
+                a.log_prev[ce] = (int32_t)atomicExch(reinterpret_cast<u32*>(&last_lds[n]), ce);   // chain order within a flush is arbitrary
+                a.out_node[rg_task] = (int32_t)n;
             }
+            applied = ncommit;
         }
-        return false;
     };
 
     if (!build_planes()) {
@@ -1410,93 +1422,133 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
     const u64 c_start = prof ? clock64() : 0, w_start = tk;
 #define R2_TICK(slot) do { if constexpr (PROF) { u64 _n = wall_clock64(); cyc[slot] += _n - tk; tk = _n; } } while (0)
 
-    for (u32 b = 0; b < nblk && !fatal; ++b) {
-        const u32 buf = b & 1;
-        {
-            u32 spins = 0;
-            while (__hip_atomic_load(&flags_lds[buf], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != b + 1) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 26)) { fatal = true; break; }
-            }
-            st_spins += spins;
-            if (fatal) break;
+    auto wait_block = [&](u32 bi) __attribute__((always_inline)) {
+        u32 spins = 0;
+        while (__hip_atomic_load(&flags_lds[bi & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != bi + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) { fatal = true; break; }
         }
-        R2_TICK(0);
-        const u32 t0 = b * R2_TB, nt = min((u32)R2_TB, a.count - t0);
-        for (u32 t = 0; t < nt && !fatal; ++t) {
-            const u32 j = t0 + t, gj = a.j0 + j;
-            const R2Rec rec = Tb[buf * R2_TB + t];
-            const u32 rflags = (u32)__builtin_amdgcn_readfirstlane((int)rec.flags);
-            const u32 rsvc = (u32)__builtin_amdgcn_readfirstlane((int)rec.svc);
-            const u64* frow = Fb + ((size_t)buf * R2_TB + t) * Wn;
-            const u64* xrow = Xb + ((size_t)buf * R2_TB + t) * XS;
-            u64 mk[K], Xc[K];
+        st_spins += spins;
+    };
+    // rows + record of the task about to be processed (read one task ahead)
+    u64 cF[K], cX[K];
+    R2Rec crec;
+    auto read_task = [&](u32 jj) __attribute__((always_inline)) {
+        const u32 bi = jj / R2_TB, tt = jj % R2_TB, bf = bi & 1;
+        crec = Tb[bf * R2_TB + tt];
+        const u64* frow = Fb + ((size_t)bf * R2_TB + tt) * Wn;
+        const u64* xrow = Xb + ((size_t)bf * R2_TB + tt) * XS;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const u32 w = lane + 64 * k;
-                const bool in = w < Wn;
-                Xc[k] = in ? xrow[w] : 0ull;
-                mk[k] = in ? frow[w] : 0ull;
-            }
-            // commits younger than the staged X row
-            {
-                u64 match = ballot64(ring_svc == rsvc);
-                while (__builtin_expect(match != 0, 0)) {
-                    int e = __ffsll((long long)match) - 1;
-                    match &= match - 1;
-                    u32 nn = (u32)__builtin_amdgcn_readlane((int)ring_node, e);
-                    u32 ww = nn >> 6;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) Xc[k] |= (lane + 64u * k == ww) ? (1ull << (nn & 63)) : 0ull;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) mk[k] &= ~Xc[k];
-            R2_TICK(1);
+        for (int k = 0; k < K; ++k) {
+            const u32 w = lane + 64 * k;
+            const bool in = w < Wn;
+            cF[k] = in ? frow[w] : 0ull;
+            cX[k] = in ? xrow[w] : 0ull;
+        }
+    };
+    wait_block(0);
+    if (!fatal) read_task(0);
+    R2_TICK(0);
 
-            // ---------------- fast path: winner at the hot level h (LA) or h+1 (LB), nothing below ----------------
-            bool fast = !(rflags & (RT_PORTS | RT_UNCOUNTED));
-            u32 n = 0, lvl = 0;
-            if (fast) {
-                u64 cb[K], ca[K];
-                bool anyb = false;
+    for (u32 j = 0; j < a.count && !fatal; ++j) {
+        const u32 gj = a.j0 + j;
+        const R2Rec rec = crec;
+        const u32 rflags = (u32)__builtin_amdgcn_readfirstlane((int)rec.flags);
+        const u32 rsvc = (u32)__builtin_amdgcn_readfirstlane((int)rec.svc);
+        u64 mk[K];
+        {
+            u64 Xc[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    cb[k] = mk[k] & BELOW[k];
-                    ca[k] = mk[k] & LA[k];
-                    anyb = anyb || (cb[k] != 0);
-                }
-                if (__builtin_expect(ballot64(anyb) != 0, 0)) fast = false;
-                else if (first_node(ca, &n)) lvl = h;
-                else {
+            for (int k = 0; k < K; ++k) Xc[k] = cX[k];
+            // commits younger than the staged X row
+            u64 match = ballot64(rg_svc == rsvc);
+            while (__builtin_expect(match != 0, 0)) {
+                int e = __ffsll((long long)match) - 1;
+                match &= match - 1;
+                u32 nn = (u32)__builtin_amdgcn_readlane((int)rg_node, e);
+                u32 ww = nn >> 6;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) ca[k] = mk[k] & LB[k];
-                    if (first_node(ca, &n)) lvl = h + 1;
-                    else fast = false;
-                }
+                for (int k = 0; k < K; ++k) Xc[k] |= (lane + 64u * k == ww) ? (1ull << (nn & 63)) : 0ull;
             }
-            u32 w = n >> 6, ko = w >> 6;
-            u64 bit = 1ull << (n & 63);
-            bool owner = (w & 63) == lane;
-            if (fast) {
-                u64 tsel = 0;
 #pragma unroll
-                for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? tch[k] : tsel;
-                if (ballot64(owner && (tsel & bit)) != 0 || lvl >= (1u << NB) - 1u) fast = false;
-            }
-            bool placed = fast, via_list = false;
-            u32 entry = 0;
-            bool want_rebase = false;
-            R2_TICK(2);
-            if (__builtin_expect(!fast, 0)) {
-                // ---------------- generic path: every feature, full bit-sliced search ----------------
-                ++st_generic;
+            for (int k = 0; k < K; ++k) mk[k] = cF[k] & ~Xc[k];
+        }
+        R2_TICK(1);
+
+        // ---------------- fast pick: lowest node at the hot level h (LA), else at h+1 (LB); nothing below h ----------------
+        // preference order of the 2K candidate words: A0..A(K-1), L0..L(K-1); inside a word: lowest lane, lowest bit
+        u64 cw[2 * K];
+        u64 bal[2 * K];
+        bool anyb = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            anyb = anyb || ((mk[k] & BELOW[k]) != 0);
+            cw[k] = mk[k] & LA[k];
+            cw[K + k] = mk[k] & LB[k];
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * K; ++q) bal[q] = ballot64(cw[q] != 0);
+        const u64 below = ballot64(anyb);
+        int qsel = -1;
+        u64 bsel = 0;
+#pragma unroll
+        for (int q = 2 * K - 1; q >= 0; --q) {
+            const bool nz = bal[q] != 0;
+            qsel = nz ? q : qsel;
+            bsel = nz ? bal[q] : bsel;
+        }
+        bool fast = !(rflags & (RT_PORTS | RT_UNCOUNTED)) && below == 0 && qsel >= 0;
+        u32 n = 0, lvl = 0, w = 0, ko = 0;
+        u64 bit = 0;
+        bool owner = false;
+        if (__builtin_expect(fast, 1)) {
+            const int l = __ffsll((long long)bsel) - 1;
+            u64 wsel = cw[0];
+#pragma unroll
+            for (int q = 1; q < 2 * K; ++q) wsel = (q == qsel) ? cw[q] : wsel;
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)wsel, l);
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(wsel >> 32), l);
+            const u64 word = ((u64)hi << 32) | lo;
+            ko = (u32)qsel % (u32)K;
+            lvl = h + ((u32)qsel >= (u32)K ? 1u : 0u);
+            w = (u32)l + 64u * ko;
+            const u32 bpos = (u32)(__ffsll((long long)word) - 1);
+            n = w * 64u + bpos;
+            bit = 1ull << bpos;
+            owner = (u32)l == lane;
+            u64 tsel = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? tch[k] : tsel;
+            // node already committed to in this window (its F bit may be stale) or level overflow → generic path
+            if (ballot64(owner && (tsel & bit)) != 0 || lvl >= (1u << NB) - 1u) fast = false;
+        }
+        R2_TICK(2);
+
+        // ---------------- read the next task's rows now: their LDS latency hides under the commit ----------------
+        if (j + 1 < a.count) {
+            if (__builtin_expect((j + 1) % R2_TB == 0, 0)) wait_block((j + 1) / R2_TB);
+            if (!fatal) read_task(j + 1);
+        }
+
+        bool placed = fast, via_list = false;
+        u32 entry = 0;
+        bool want_rebase = false;
+        if (__builtin_expect(!fast, 0)) {
+            // ---------------- generic path: every feature, full bit-sliced search ----------------
+            ++st_generic;
+            bool anym = false;
+#pragma unroll
+            for (int k = 0; k < K; ++k) anym = anym || (mk[k] != 0);
+            const u32 e0 = a.list_off[rsvc], e1 = a.list_off[rsvc + 1];
+            placed = false;
+            if (ballot64(anym) != 0 || e1 > e0) {
                 const i64 rcpu = rec.cpu, rmem = rec.mem;
                 const u32 rpset = rec.pset;
+                flush();   // the re-checks below read cpu/mem/total/lists: bring them up to date
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 u64 gk[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) gk[k] = mk[k];
-                placed = false;
                 for (;;) {
                     u32 g = search(gk);
                     if (g == 0xFFFFFFFFu) break;
@@ -1511,7 +1563,6 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
                     for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? tch[k] : tsel;
                     bool ok = true;
                     if (ballot64(owner && (tsel & bit)) != 0) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
                         if (rflags & RT_RES) {
                             i64 c = __hip_atomic_load(&a.cpu[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             i64 m = __hip_atomic_load(&a.mem[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1527,13 +1578,11 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
                     for (int k = 0; k < K; ++k) gk[k] &= ~((owner && (u32)k == ko) ? bit : 0ull);
                     ++st_retries;
                 }
-                if (!placed) {
+                if (!placed && e1 > e0) {
+                    // exception list of the service: nodes with svcCount>0 or ≥5 recent failures
                     const u64 maxrep = a.rt[gj].maxrep;
-                    const u32 e0 = a.list_off[rsvc], e1 = a.list_off[rsvc + 1];
                     u64 bhi = KEY_NONE, blo = KEY_NONE;
                     u32 be = 0;
-                    // (no fence: every load below is an agent-scope atomic served by the L2 that also executed
-                    //  this wave's own atomics/stores to the same words)
                     for (u32 e = e0 + lane; e < e1; e += 64) {
                         u32 nn = __hip_atomic_load(&a.list_node[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (nn == LIST_EMPTY) continue;
@@ -1553,8 +1602,8 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
                         }
                         u32 svn = __hip_atomic_load(&a.list_svc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         u32 fl = __hip_atomic_load(&a.list_fail[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((rflags & RT_MAXREP) && !((u64)svn < maxrep)) continue;
-                        u32 fcl = fl >= MAX_FAILURES ? fl - (MAX_FAILURES - 1) : 0u;
+                        if ((rflags & RT_MAXREP) && !((u64)svn < maxrep)) continue;   // filter.go:373-375
+                        u32 fcl = fl >= MAX_FAILURES ? fl - (MAX_FAILURES - 1) : 0u;    // nodeLess, scheduler.go:708-735
                         u32 tot = __hip_atomic_load(&a.total[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         u64 hi = ((u64)fcl << 32) | svn, lo = ((u64)tot << 32) | nn;
                         if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; be = e; }
@@ -1576,92 +1625,88 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
                     }
                 }
             }
-
-            R2_TICK(3);
-            if (placed) {
-                // ---------------- commit == NodeInfo.addTask (nodeinfo.go:108-154) ----------------
-                const bool counted = !(rflags & RT_UNCOUNTED);
-                if (counted) {
-                    if (lvl >= (1u << NB) - 1u) want_rebase = true;
-                    else {
-                        bump(owner, ko, bit, lvl);
-                        if (fast) {   // node moves h→h+1 (LA→LB) or h+1→h+2 (leaves LB)
-                            const u64 ob = owner ? bit : 0ull;
-                            const bool from_a = lvl == h;
-#pragma unroll
-                            for (int k = 0; k < K; ++k) {
-                                const u64 x = ((u32)k == ko) ? ob : 0ull;
-                                LA[k] &= ~x;
-                                LB[k] = from_a ? (LB[k] | x) : (LB[k] & ~x);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k) tch[k] |= (owner && (u32)k == ko) ? bit : 0ull;
-                if (owner) {
-                    if (rec.cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rec.cpu));
-                    if (rec.mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rec.mem));
-                    if (rflags & RT_PORTS)
-                        for (u32 p = a.pset_off[rec.pset]; p < a.pset_off[rec.pset + 1]; ++p) atomicOr(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], bit);
-                    if (counted) {
-                        atomicAdd(a.total + n, 1u);
-                        if (via_list) atomicAdd(a.list_svc + entry, 1u);
-                        else {
-                            atomicOr(&a.X[(size_t)rsvc * XS + w], bit);
-                            a.list_node[rec.slot] = n;
-                            a.list_svc[rec.slot] = 1;
-                            a.list_fail[rec.slot] = 0;
-                        }
-                    }
-                    a.log_node[ncommit] = n;
-                    a.log_task[ncommit] = gj;
-                    a.log_prev[ncommit] = last_lds[n];
-                    last_lds[n] = (int32_t)ncommit;
-                    a.out_node[gj] = (int32_t)n;
-                }
-                if (counted && !via_list) {   // remember the commit for rows staged before it
-                    const bool me = lane == (ncommit & 63u);
-                    ring_svc = me ? rsvc : ring_svc;
-                    ring_node = me ? n : ring_node;
-                }
-                ++ncommit;
-                if (!fast && !want_rebase && counted) {
-                    // a generic commit may have moved a node across the hot levels; a plain pick at another level
-                    // re-centres the hot level there (nodes below it are handled exactly through BELOW)
-                    derive_masks((!via_list && lvl + 2 < (1u << NB)) ? lvl : h);
-                }
-                if (fast && lvl == h + 1) {
-                    // picks come from h+1: if level h is exhausted for everybody, advance the hot level
-                    bool anya = false;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) anya = anya || (LA[k] != 0);
-                    if (!ballot64(anya) && h + 2 < (1u << NB) - 1u) derive_masks(h + 1);
-                }
-            } else {
-                if (lane == 0) {
-                    a.out_node[gj] = -1;
-                    a.inf_task[ninf] = gj;
-                    a.inf_pos[ninf] = ncommit;
-                }
-                ++ninf;
-            }
-            if (__builtin_expect(want_rebase, 0)) {
-                ++st_rebase;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                if (!build_planes()) {
-                    if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
-                    fatal = true;
-                } else derive_masks(0);
-            }
-            R2_TICK(4);
         }
-        // every store/atomic of this block is in L2 before the loader may restage rows that depend on it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&flags_lds[2], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        R2_TICK(5);
+        R2_TICK(3);
+
+        if (__builtin_expect(placed, 1)) {
+            // ---------------- commit: registers now, memory side effects at the next flush ----------------
+            const bool counted = !(rflags & RT_UNCOUNTED);
+            u64 xk[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) xk[k] = (owner && (u32)k == ko) ? bit : 0ull;
+            if (counted) {
+                if (__builtin_expect(lvl >= (1u << NB) - 1u, 0)) want_rebase = true;
+                else {
+                    bump(xk, lvl);
+                    if (fast) {   // node moves h→h+1 (LA→LB) or h+1→h+2 (leaves LB)
+                        const bool from_a = lvl == h;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            LA[k] &= ~xk[k];
+                            LB[k] = (LB[k] & ~xk[k]) | (from_a ? xk[k] : 0ull);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) tch[k] |= xk[k];
+            if (__builtin_expect((rflags & RT_PORTS) != 0, 0)) {
+                if (owner)
+                    for (u32 p = a.pset_off[rec.pset]; p < a.pset_off[rec.pset + 1]; ++p) atomicOr(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], bit);
+            }
+            if (counted && !via_list) {
+                if (owner) atomicOr(&a.X[(size_t)rsvc * XS + w], bit);   // the loader restages X rows from memory
+            }
+            {   // remember the commit: X freshness + deferred side effects
+                const bool me = lane == (ncommit & 63u);
+                rg_svc = me ? ((counted && !via_list) ? rsvc : 0xFFFFFFFFu) : rg_svc;
+                rg_node = me ? n : rg_node;
+                rg_task = me ? gj : rg_task;
+                rg_slot = me ? (via_list ? entry : rec.slot) : rg_slot;
+                rg_flags = me ? ((counted ? 1u : 0u) | (via_list ? 2u : 0u)) : rg_flags;
+                rg_cpu = me ? rec.cpu : rg_cpu;
+                rg_mem = me ? rec.mem : rg_mem;
+            }
+            ++ncommit;
+            if (__builtin_expect((ncommit & 63u) == 0, 0)) flush();
+            if (__builtin_expect(!fast && !want_rebase && counted, 0)) {
+                // a generic commit may have moved a node across the hot levels; a plain pick at another level
+                // re-centres the hot level there (nodes below it stay exact through BELOW)
+                derive_masks((!via_list && lvl + 2 < (1u << NB)) ? lvl : h);
+            }
+            if (__builtin_expect(fast && lvl == h + 1, 0)) {
+                // picks come from h+1: if level h is exhausted for everybody, advance the hot level
+                bool anya = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) anya = anya || (LA[k] != 0);
+                if (!ballot64(anya) && h + 2 < (1u << NB) - 1u) derive_masks(h + 1);
+            }
+        } else {
+            if (lane == 0) {
+                a.inf_task[ninf] = gj;
+                a.inf_pos[ninf] = ncommit;
+            }
+            ++ninf;
+        }
+        if (__builtin_expect(want_rebase, 0)) {
+            ++st_rebase;
+            flush();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!build_planes()) {
+                if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+                fatal = true;
+            } else derive_masks(0);
+        }
+        R2_TICK(4);
+        if (__builtin_expect((j + 1) % R2_TB == 0 || j + 1 == a.count, 0)) {
+            // every X atomic of this block is in L2 before the loader may restage rows that depend on it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&flags_lds[2], j / R2_TB + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            R2_TICK(5);
+        }
     }
     if (fatal) __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    flush();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     for (u32 n = lane; n < a.n_nodes; n += 64) a.last[n] = last_lds[n];
     if (lane == 0) {
@@ -1723,7 +1768,8 @@ __global__ __launch_bounds__(256) void k_explain(ExplainArgs a) {
         u32 port_later = 0;   // bit q: the q-th port of this task's set was taken on n by a LATER commit
         u32 pp0 = 0, pp1 = 0;
         if (rt.flags & RT_PORTS) { pp0 = a.pset_off[rt.pset]; pp1 = a.pset_off[rt.pset + 1]; }
-        for (int32_t ci = a.last[n]; ci >= pos; ci = a.log_prev[ci]) {
+        for (int32_t ci = a.last[n]; ci >= 0; ci = a.log_prev[ci]) {   // chain order is arbitrary: filter, don't stop early
+            if (ci < pos) continue;
             const RTask* tk = a.rt + a.log_task[ci];
             c += tk->cpu;
             m += tk->mem;

@@ -629,6 +629,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
     HIPCHECK(e, hipMemsetAsync(b->d_last.p, 0xFF, (size_t)N * 4, st));
     HIPCHECK(e, hipMemsetAsync(b->d_ctl.p, 0, sizeof(Ctl), st));
     HIPCHECK(e, hipMemsetAsync(b->d_hist.p, 0, (size_t)T * 8 * 4, st));
+    HIPCHECK(e, hipMemsetAsync(b->d_out.p, 0xFF, (size_t)T * 4, st));   // -1 = no suitable node unless a commit says otherwise
     if (!b->xrow.empty())
         hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b->xrow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b->xrow.size(),
                            b->d_xrow.as<uint32_t>(), b->d_xnode.as<uint32_t>(), Wn, b->d_X.as<u64>());
