@@ -190,3 +190,101 @@ def scenario_resource_constraint(factory, with_generic=True):
     s.create_node(node("bignode", Description={"Resources": _res(4e9, 8e9, g(named("orange", "blue", "red", "green"), discrete("apple", 4)))}))
     a = assignments(s.tick())
     assert [d["NodeID"] for d in a] == ["bignode"]
+
+
+def _plat(arch, os_):
+    return {"Architecture": arch, "OS": os_}
+
+
+def scenario_platform(factory):
+    """TestSchedulerCompatiblePlatform, scheduler_test.go:2109-2340."""
+    s = factory()
+    s.set_service("serviceID1")
+    s.create_node(node("node1", Description={"Platform": _plat("x86_64", "linux")}))
+    s.create_node(node("node2", Description={"Platform": _plat("amd64", "windows")}))
+    s.create_node(node("node3", Description={}))   # nil platform: cannot take anything with a platform constraint
+    s.create_task(pending("id1", "serviceID1", Spec={"Placement": {"Platforms": [_plat("amd64", "linux")]}}))
+    a = assignments(s.tick())
+    assert [d["NodeID"] for d in a] == ["node1"]   # x86_64 == amd64 after normalisation
+    s.create_task(pending("id2", "serviceID1", Spec={"Placement": {"Platforms": [_plat("arm", "linux")]}}))
+    f = failures(s.tick())
+    assert f[0]["Err"] == "no suitable node (unsupported platform on 3 nodes)"   # :2311
+    s.create_task(pending("id3", "serviceID1"))
+    a = assignments(s.tick())
+    assert a[0]["ID"] == "id3" and a[0]["NodeID"] in ("node2", "node3")
+    s.create_task(pending("id4", "serviceID1", Spec={"Placement": {"Platforms": [_plat("", "linux")]}}))
+    a = [d for d in assignments(s.tick()) if d["ID"] == "id4"]
+    assert a[0]["NodeID"] == "node1"
+    s.create_task(pending("id5", "serviceID1", Spec={"Placement": {"Platforms": [_plat("amd64", "linux"), _plat("x86_64", "windows")]}}))
+    a = [d for d in assignments(s.tick()) if d["ID"] == "id5"]
+    assert a[0]["NodeID"] in ("node1", "node2")
+
+
+def _port(proto, port=58):
+    return {"PublishMode": 1, "PublishedPort": port, "Protocol": proto}
+
+
+def scenario_host_port(factory):
+    """TestSchedulerHostPort, scheduler_test.go:3467-3626."""
+    s = factory()
+    s.set_service("serviceID1")
+    s.create_task(pending("id1", "serviceID1", Endpoint={"Ports": [_port(0)]}))
+    s.create_task(pending("id2", "serviceID1", Endpoint={"Ports": [_port(1)]}))
+    assert len(failures(s.tick())) == 2
+    s.create_node(node("nodeid1"))
+    s.create_node(node("nodeid2"))
+    a = assignments(s.tick())
+    assert len(a) == 2 and a[0]["NodeID"] != a[1]["NodeID"]
+    s.create_task(pending("id3", "serviceID1", Endpoint={"Ports": [_port(1), _port(0)]}))
+    f = failures(s.tick())
+    assert f[0]["Err"] == "no suitable node (host-mode port already in use on 2 nodes)"   # :3625
+
+
+def scenario_max_replicas(factory):
+    """TestSchedulerMaxReplicas, scheduler_test.go:3628-3879."""
+    s = factory()
+    s.set_service("serviceID1")
+    mr1 = {"Placement": {"MaxReplicas": 1}}
+    s.create_task(pending("id1", "serviceID1", Spec=mr1))
+    s.create_task(pending("id2", "serviceID1", Spec=mr1))
+    assert len(failures(s.tick())) == 2
+    s.create_node(node("nodeid1"))
+    s.create_node(node("nodeid2"))
+    a = assignments(s.tick())
+    assert len(a) == 2 and a[0]["NodeID"] != a[1]["NodeID"]
+    s.create_task(pending("id3", "serviceID1", Spec=mr1))
+    f = failures(s.tick())
+    assert f[0]["Err"] == "no suitable node (max replicas per node limit exceed)"   # :3761
+    s.create_node(node("nodeid3"))
+    # id3 is still queued: it now fits on the new node
+    a = assignments(s.tick())
+    assert [d["NodeID"] for d in a] == ["nodeid3"]
+    spec = {"Placement": {"Constraints": ["node.hostname==node1"], "MaxReplicas": 3}}
+    for i in (4, 5, 6):
+        s.create_task(pending(f"id{i}", "serviceID1", Spec=spec))
+    s.tick()
+    s.create_task(pending("id7", "serviceID1", Spec=spec))
+    f = [d for d in failures(s.tick()) if d["ID"] == "id7"]
+    assert f[0]["Err"] == "no suitable node (scheduling constraints not satisfied on 3 nodes)"   # :3878
+
+
+def scenario_faulty_node(factory):
+    """TestSchedulerFaultyNode, scheduler_test.go:1325-1476: ≥5 recent failures down-weight a node;
+    pre-assigned tasks neither count nor care."""
+    s = factory()
+    s.create_node(node("id1"))
+    s.create_node(node("id2"))
+    s.create_task({"ID": "id1", "ServiceID": "service1", "NodeID": "id1", "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING}})
+    s.create_task({"ID": "id2", "ServiceID": "service2", "NodeID": "id1", "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING}})
+    for i in range(8):
+        t = pending(f"r{i}", "service1")
+        s.create_task(t)
+        a = assignments(s.tick())
+        assert len(a) == 1 and a[0]["ID"] == t["ID"]
+        assert a[0]["NodeID"] == ("id2" if i < 5 else "id1"), (i, a)   # :1426-1430
+        p = {"ID": f"p{i}", "ServiceID": "service2", "NodeID": "id1", "DesiredState": orc.RUNNING, "Status": {"State": orc.PENDING}}
+        s.create_task(p)
+        pa = assignments(s.process_preassigned())
+        assert len(pa) == 1 and pa[0]["NodeID"] == "id1"
+        s.update_task(dict(t, NodeID=a[0]["NodeID"], Status={"State": orc.FAILED}))
+        s.update_task(dict(p, Status={"State": orc.FAILED}))

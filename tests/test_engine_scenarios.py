@@ -1,0 +1,74 @@
+"""GPU: the reference's scheduler scenarios and filter truth tables through the HIP engine (C ABI +
+host mirror). Same scenario code as tests/test_oracle_scheduler.py."""
+import pytest
+
+import kat_tables as kt
+import scenarios as sc
+from swarmkit_amd import host as swhost
+
+pytestmark = pytest.mark.gpu
+
+
+def factory():
+    return swhost.HostScheduler()
+
+
+def test_basic():
+    sc.scenario_basic(factory)
+
+
+def test_ha_one_off():
+    sc.scenario_ha(factory, False)
+
+
+def test_no_ready_nodes():
+    sc.scenario_no_ready_nodes(factory)
+
+
+def test_resource_constraint():
+    sc.scenario_resource_constraint(factory, with_generic=False)
+
+
+def test_platform():
+    sc.scenario_platform(factory)
+
+
+def test_host_port():
+    sc.scenario_host_port(factory)
+
+
+def test_max_replicas():
+    sc.scenario_max_replicas(factory)
+
+
+def test_faulty_node():
+    sc.scenario_faulty_node(factory)
+
+
+def test_unsupported_features_are_refused_not_faked():
+    s = factory()
+    s.create_node(sc.node("n1"))
+    s.create_task(sc.pending("t1", "svc", 1))   # grouped (SpecVersion set)
+    with pytest.raises(swhost.Unsupported):
+        s.tick()
+    s = factory()
+    s.create_node(sc.node("n1"))
+    s.create_task(sc.pending("t1", "svc", Spec={"Placement": {"Preferences": [{"Spread": {"SpreadDescriptor": "node.labels.az"}}]}}))
+    with pytest.raises(swhost.Unsupported):
+        s.tick()
+
+
+def test_constraint_truth_tables_on_device():
+    """constraint_test.go:62-350 through k_constraint_classes (swp_check_node)."""
+    for cons, node, want in kt.constraint_cases():
+        s = factory()
+        s.create_node(node)
+        t = sc.pending("t", "svc", Spec={"Placement": {"Constraints": cons}})
+        d = s.task_desc(t)
+        if want is None:
+            assert int(d["constraint_set"][0]) == 0, cons
+            continue
+        assert int(d["constraint_set"][0]) != 0, cons
+        ff = s.e.check_node(d, s.nodes[node["ID"]]["idx"])
+        assert (ff == -1) == want, (cons, node, ff)
+        assert ff in (-1, 3), (cons, ff)

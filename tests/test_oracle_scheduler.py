@@ -30,3 +30,19 @@ def test_no_ready_nodes():
 @pytest.mark.parametrize("with_generic", [False, True])
 def test_resource_constraint(with_generic):
     sc.scenario_resource_constraint(factory, with_generic)
+
+
+def test_platform():
+    sc.scenario_platform(factory)
+
+
+def test_host_port():
+    sc.scenario_host_port(factory)
+
+
+def test_max_replicas():
+    sc.scenario_max_replicas(factory)
+
+
+def test_faulty_node():
+    sc.scenario_faulty_node(factory)
