@@ -68,7 +68,8 @@ enum {
     SWP_SPACE_OS = 4,        /* Platform.OS, case-sensitive (filter.go:302) */
     SWP_SPACE_ARCH = 5,      /* Platform.Architecture after x86_64→amd64, aarch64→arm64 (filter.go:285-299) */
     SWP_SPACE_PLUGIN = 6,    /* "<Type>\0<Name>" (filter.go:179-202) */
-    SWP_SPACE_COUNT = 7
+    SWP_SPACE_RAW = 7,       /* label values as written, case-sensitive: decision-tree branches (nodeset.go:84-101) */
+    SWP_SPACE_COUNT = 8
 };
 /* id 0 is reserved for the empty string in every space except NODE_ID (node index 0 is a node). */
 int swp_intern(swp_engine*, int space, const char* utf8, size_t len, uint32_t* id_out);
@@ -106,7 +107,7 @@ typedef struct {
     uint64_t version;     /* Meta.Version.Index — echoed by swp_node_get for the stale check, scheduler.go:540 */
 } swp_node_row;           /* 80 bytes */
 
-typedef struct { uint32_t key; uint32_t value; } swp_kv;   /* (LABEL_KEY id, FOLDED id) */
+typedef struct { uint32_t key; uint32_t value; uint32_t raw; } swp_kv;   /* (LABEL_KEY id, FOLDED id, RAW id) */
 
 /* nodeSet.alloc, nodeset.go:18-20: drop every node row and all derived state */
 int swp_reset(swp_engine*, uint32_t n_nodes_hint);
@@ -167,6 +168,11 @@ int swp_platform_set(swp_engine*, const swp_platform* ps, uint32_t n, uint32_t* 
 int swp_plugin_set(swp_engine*, const uint32_t* required, uint32_t n, uint32_t log_plugin, uint32_t* id_out);
 /* HostPortFilter.SetTask (filter.go:322-333): host-mode published ports of the task */
 int swp_port_set(swp_engine*, const swp_port* ports, uint32_t n, uint32_t* id_out);
+/* Spread preferences that create a decision-tree level (nodeset.go:59-82): kind is SWP_CK_NODE_LABEL or
+ * SWP_CK_ENGINE_LABEL, key the LABEL_KEY id of the part after the prefix; other descriptors are skipped by
+ * the caller exactly as the reference skips them. */
+typedef struct { uint32_t kind; uint32_t key; } swp_spread;
+int swp_spread_set(swp_engine*, const swp_spread* levels, uint32_t n, uint32_t* id_out);
 
 #define SWP_TASK_RES_ENABLED 0x1u   /* ResourceFilter.SetTask returned true (filter.go:61-74) */
 
@@ -181,7 +187,8 @@ typedef struct {
     uint32_t port_set;       /* 0 = HostPortFilter disabled */
     uint64_t max_replicas;   /* 0 = MaxReplicasFilter disabled (filter.go:363-370) */
     uint64_t spec_version;   /* SpecVersion.Index (0 when nil) — selects the failure bucket */
-    uint32_t reserved[2];
+    uint32_t spread_set;     /* 0 = no spread preferences (Placement.Preferences, nodeset.go:59-82) */
+    uint32_t reserved;
 } swp_task_desc;             /* 64 bytes */
 
 /* ------------------------------------------------------------------------------------------ */
@@ -198,6 +205,18 @@ typedef struct {
  *                    tasks with out_node[i] == -1; may be NULL. */
 int swp_schedule_batch(swp_engine*, const swp_task_desc* tasks, uint32_t n_tasks,
                        int32_t* out_node, uint32_t* out_fail_hist /* [n_tasks][SWP_NFILTERS] */);
+
+/* tick() over task GROUPS (tasks sharing ServiceID + SpecVersion, scheduler.go:438-466): for each group, in
+ * array order, scheduleTaskGroup with k = sizes[g] (scheduler.go:694-748): nodeSet.tree with a max-heap of k
+ * per leaf (nodeset.go:50-124, container/heap order reproduced), scheduleNTasksOnSubtree (:772-825), the fill
+ * loop scheduleNTasksOnNodes (:844-924) incl. the residual update. One descriptor per group (all tasks of a
+ * group are identical for the filters, scheduler.go:696-702). Also the path of one-off tasks that carry spread
+ * preferences (a group of one).
+ *   out_node       Σ sizes entries, group after group, tasks in canonical (enqueue) order; -1 = left over
+ *   out_fail_hist  [n_groups][SWP_NFILTERS]: Pipeline counters as noSuitableNode would read them
+ *                  (scheduler.go:929), written for groups with left-over tasks */
+int swp_schedule_groups(swp_engine*, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups,
+                        int32_t* out_node, uint32_t* out_fail_hist);
 
 /* The same in three steps so that a caller (bench.py) can time the device pass alone:
  *   prepare: de-duplicate predicate sets, upload descriptors and per-service state
@@ -251,7 +270,7 @@ int swp_stats(swp_engine*, swp_stats_t* out);
 const char* swp_strerror(int code);
 const char* swp_last_error(swp_engine*);   /* engine may be NULL: last swp_create failure */
 /* sizeof() of every ABI struct, so that a binding can assert its own layout */
-int swp_abi_check(uint32_t* sizes, uint32_t n);   /* order: config,node_row,kv,constraint,platform,port,task_desc,placement,stats */
+int swp_abi_check(uint32_t* sizes, uint32_t n);   /* order: config,node_row,kv,constraint,platform,port,task_desc,placement,stats,spread */
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ CSRC = os.path.join(ROOT, "swarmkit_amd", "csrc")
 LIB_PATH = os.path.join(ROOT, "swarmkit_amd", "lib", "libswp.so")
 
 SWP_OK, SWP_EINVAL, SWP_ENOTFOUND, SWP_ENOMEM, SWP_EHIP, SWP_EUNSUPPORTED, SWP_ERANGE, SWP_ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7
-(SPACE_NODE_ID, SPACE_SERVICE, SPACE_LABEL_KEY, SPACE_FOLDED, SPACE_OS, SPACE_ARCH, SPACE_PLUGIN) = range(7)
+(SPACE_NODE_ID, SPACE_SERVICE, SPACE_LABEL_KEY, SPACE_FOLDED, SPACE_OS, SPACE_ARCH, SPACE_PLUGIN, SPACE_RAW) = range(8)
 NODE_READY, NODE_HAS_DESC, NODE_HAS_PLATFORM, NODE_HAS_ENGINE = 0x1, 0x2, 0x4, 0x8
 NODE_HAS_LABELS, NODE_HAS_ELABELS, NODE_MANAGER, NODE_HAS_LOGPLUG, NODE_IP_VALID, NODE_IP_V4 = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 (CK_NODE_ID, CK_HOSTNAME, CK_IP, CK_ROLE, CK_PLATFORM_OS, CK_PLATFORM_ARCH, CK_NODE_LABEL, CK_ENGINE_LABEL, CK_INVALID) = range(9)
@@ -34,7 +34,7 @@ class NodeRow(C.Structure):
 
 
 class KV(C.Structure):
-    _fields_ = [("key", C.c_uint32), ("value", C.c_uint32)]
+    _fields_ = [("key", C.c_uint32), ("value", C.c_uint32), ("raw", C.c_uint32)]
 
 
 class Constraint(C.Structure):
@@ -50,10 +50,14 @@ class Port(C.Structure):
     _fields_ = [("protocol", C.c_uint32), ("port", C.c_uint32)]
 
 
+class Spread(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("key", C.c_uint32)]
+
+
 class TaskDesc(C.Structure):
     _fields_ = [("service", C.c_uint32), ("flags", C.c_uint32), ("cpu", C.c_int64), ("mem", C.c_int64),
                 ("constraint_set", C.c_uint32), ("platform_set", C.c_uint32), ("plugin_set", C.c_uint32), ("port_set", C.c_uint32),
-                ("max_replicas", C.c_uint64), ("spec_version", C.c_uint64), ("reserved", C.c_uint32 * 2)]
+                ("max_replicas", C.c_uint64), ("spec_version", C.c_uint64), ("spread_set", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Placement(C.Structure):
@@ -73,7 +77,7 @@ class Stats(C.Structure):
 # numpy views of the POD structs, for bulk construction
 TASK_DTYPE = np.dtype([("service", "<u4"), ("flags", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("constraint_set", "<u4"),
                        ("platform_set", "<u4"), ("plugin_set", "<u4"), ("port_set", "<u4"), ("max_replicas", "<u8"),
-                       ("spec_version", "<u8"), ("reserved", "<u4", (2,))])
+                       ("spec_version", "<u8"), ("spread_set", "<u4"), ("reserved", "<u4")])
 PLACEMENT_DTYPE = np.dtype([("node", "<u4"), ("service", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("port_set", "<u4"), ("counted", "<u4")])
 assert TASK_DTYPE.itemsize == C.sizeof(TaskDesc) == 64
 assert PLACEMENT_DTYPE.itemsize == C.sizeof(Placement) == 32
@@ -81,7 +85,7 @@ assert PLACEMENT_DTYPE.itemsize == C.sizeof(Placement) == 32
 EXPORTS = [
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
-    "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_schedule_batch", "swp_batch_prepare",
+    "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
     "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node",
     "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check",
 ]
@@ -138,6 +142,8 @@ def load_library():
         "swp_platform_set": ([vp, P(Platform), u32, P(u32)], C.c_int),
         "swp_plugin_set": ([vp, P(u32), u32, u32, P(u32)], C.c_int),
         "swp_port_set": ([vp, P(Port), u32, P(u32)], C.c_int),
+        "swp_spread_set": ([vp, P(Spread), u32, P(u32)], C.c_int),
+        "swp_schedule_groups": ([vp, vp, vp, u32, vp, vp], C.c_int),
         "swp_schedule_batch": ([vp, vp, u32, vp, vp], C.c_int),
         "swp_batch_prepare": ([vp, vp, u32, P(vp)], C.c_int),
         "swp_batch_run": ([vp, vp], C.c_int),
@@ -159,7 +165,7 @@ def load_library():
         fn.restype = res
     sizes = (u32 * 16)()
     n = L.swp_abi_check(sizes, 16)
-    want = [C.sizeof(x) for x in (Config, NodeRow, KV, Constraint, Platform, Port, TaskDesc, Placement, Stats)]
+    want = [C.sizeof(x) for x in (Config, NodeRow, KV, Constraint, Platform, Port, TaskDesc, Placement, Stats, Spread)]
     if list(sizes[:n]) != want:
         raise RuntimeError(f"ABI struct size mismatch: lib {list(sizes[:n])} vs binding {want}")
     _lib = L
@@ -234,8 +240,8 @@ class Engine:
         return out.value
 
     def node_upsert(self, row, labels=(), engine_labels=(), plugins=()):
-        la = (KV * max(1, len(labels)))(*[KV(k, v) for k, v in labels])
-        ea = (KV * max(1, len(engine_labels)))(*[KV(k, v) for k, v in engine_labels])
+        la = (KV * max(1, len(labels)))(*[KV(*kv) for kv in labels])
+        ea = (KV * max(1, len(engine_labels)))(*[KV(*kv) for kv in engine_labels])
         pa = (C.c_uint32 * max(1, len(plugins)))(*plugins)
         self._ck(self.L.swp_node_upsert(self.h, C.byref(row), la, len(labels), ea, len(engine_labels), pa, len(plugins)))
 
@@ -290,6 +296,22 @@ class Engine:
         out = C.c_uint32()
         self._ck(self.L.swp_port_set(self.h, arr, len(ports), C.byref(out)))
         return out.value
+
+    def spread_set(self, levels):
+        arr = (Spread * max(1, len(levels)))(*[Spread(k, key) for k, key in levels])
+        out = C.c_uint32()
+        self._ck(self.L.swp_spread_set(self.h, arr, len(levels), C.byref(out)))
+        return out.value
+
+    def schedule_groups(self, groups, sizes):
+        """groups: TASK_DTYPE array (one descriptor per group), sizes: tasks per group.
+        Returns (out_node int32[sum sizes], hist uint32[n_groups, 8])."""
+        groups = np.ascontiguousarray(groups, dtype=TASK_DTYPE)
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        out = np.empty(int(sizes.sum()), dtype=np.int32)
+        hist = np.zeros((len(groups), NFILTERS), dtype=np.uint32)
+        self._ck(self.L.swp_schedule_groups(self.h, groups.ctypes.data, sizes.ctypes.data, len(groups), out.ctypes.data, hist.ctypes.data))
+        return out, hist
 
     def schedule_batch(self, tasks, want_hist=True):
         """tasks: numpy array of TASK_DTYPE. Returns (out_node int32[T], hist uint32[T,8] or None)."""

@@ -157,7 +157,8 @@ struct swp_engine {
     struct PlugSet { std::vector<uint32_t> required; uint32_t log = 0; };
     std::vector<PlugSet> plug_sets{1};
     std::vector<std::vector<swp_port>> port_sets{1};
-    std::map<std::string, uint32_t> con_index, plat_index, plug_index, port_index;
+    std::vector<std::vector<swp_spread>> spread_sets{1};
+    std::map<std::string, uint32_t> con_index, plat_index, plug_index, port_index, spread_index;
 
     // label columns of attr[][]: 0 id, 1 hostname, 2 os, 3 arch, 4.. labels
     std::map<uint32_t, uint32_t> node_label_col, engine_label_col;
@@ -321,7 +322,7 @@ template <class T>
 std::string bytes_of(const T* p, size_t n) { return std::string(reinterpret_cast<const char*>(p), n * sizeof(T)); }
 
 // ---- batch construction -------------------------------------------------------------------------
-int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch* b) {
+int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch* b, const uint32_t* weights = nullptr) {
     b->T = T;
     b->tasks.assign(tasks, tasks + T);
     b->rt.resize(T);
@@ -339,6 +340,8 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             d.port_set >= e->port_sets.size())
             return e->fail(SWP_EINVAL, "task %u references an unknown predicate set", i);
         if (d.service >= e->spaces[SWP_SPACE_SERVICE].strs.size()) return e->fail(SWP_EINVAL, "task %u: unknown service id %u", i, d.service);
+        if (d.spread_set >= e->spread_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown spread set", i);
+        if (d.spread_set && !weights) return e->fail(SWP_EUNSUPPORTED, "task %u has spread preferences: schedule it through swp_schedule_groups", i);
         RTask& r = b->rt[i];
         std::memset(&r, 0, sizeof r);
         r.cpu = d.cpu;
@@ -387,7 +390,8 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             return e->fail(SWP_EUNSUPPORTED, "one batch mixes spec versions of service %u (one-off tasks have none)", d.service);
         }
         r.svc = vit->second;
-        task_rank[i] = svc_ntasks[r.svc]++;
+        task_rank[i] = svc_ntasks[r.svc];
+        svc_ntasks[r.svc] += weights ? weights[i] : 1u;
     }
     b->n_svc = (uint32_t)b->svc_global.size();
     b->n_sc = (uint32_t)b->triples.size();
@@ -917,7 +921,7 @@ const char* swp_last_error(swp_engine* e) { return e ? e->last_error.c_str() : g
 
 int swp_abi_check(uint32_t* sizes, uint32_t n) {
     const uint32_t s[] = {sizeof(swp_config), sizeof(swp_node_row), sizeof(swp_kv), sizeof(swp_constraint), sizeof(swp_platform),
-                          sizeof(swp_port), sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t)};
+                          sizeof(swp_port), sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t), sizeof(swp_spread)};
     uint32_t m = sizeof s / sizeof s[0];
     for (uint32_t i = 0; i < n && i < m; ++i) sizes[i] = s[i];
     return (int)m;
@@ -1144,6 +1148,183 @@ int swp_port_set(swp_engine* e, const swp_port* ports, uint32_t n, uint32_t* id_
     if (!e || !id_out || (!ports && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
     return register_set(e->port_index, e->port_sets, bytes_of(ports, n), std::vector<swp_port>(ports, ports + n), id_out);
+}
+
+int swp_spread_set(swp_engine* e, const swp_spread* levels, uint32_t n, uint32_t* id_out) {
+    if (!e || !id_out || (!levels && n)) return SWP_EINVAL;
+    if (n == 0) { *id_out = 0; return SWP_OK; }
+    for (uint32_t i = 0; i < n; ++i)
+        if (levels[i].kind != SWP_CK_NODE_LABEL && levels[i].kind != SWP_CK_ENGINE_LABEL) return e->fail(SWP_EINVAL, "spread level kind must be a label kind");
+    return register_set(e->spread_index, e->spread_sets, bytes_of(levels, n), std::vector<swp_spread>(levels, levels + n), id_out);
+}
+
+int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node,
+                        uint32_t* out_fail_hist) {
+    if (!e || (!groups && n_groups) || (!sizes && n_groups)) return SWP_EINVAL;
+    if (n_groups == 0) return SWP_OK;
+    (void)hipSetDevice(e->device);
+    uint64_t total = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        if (sizes[g] == 0) return e->fail(SWP_EINVAL, "group %u is empty", g);
+        total += sizes[g];
+    }
+    if (total >= (1ull << 31) || !out_node) return SWP_EINVAL;
+    if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)n_groups * SWP_NFILTERS * 4);
+    int rc = flush_nodes(e);
+    if (rc) return rc;
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N);
+    if (N == 0) {   // empty nodeSet: every task is left over, empty explanation
+        for (uint64_t i = 0; i < total; ++i) out_node[i] = -1;
+        return SWP_OK;
+    }
+    swp_batch b;
+    if ((rc = build_batch(e, groups, n_groups, &b, sizes))) return rc;
+    if ((rc = flush_nodes(e))) return rc;
+    if ((rc = upload_batch(e, &b))) return rc;
+    hipStream_t st = e->stream;
+
+    // decision-tree topology per spread set: branch creation order = node index order (nodeset.go:57-101)
+    std::map<uint32_t, uint32_t> tree_local;   // spread set -> local tree
+    std::vector<uint32_t> tree_sets;
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (!tree_local.count(groups[g].spread_set)) {
+            tree_local[groups[g].spread_set] = (uint32_t)tree_sets.size();
+            tree_sets.push_back(groups[g].spread_set);
+        }
+    std::vector<uint32_t> tree_off{0}, tn_parent, tn_first, tn_next, tn_nchild, leaf_of((size_t)tree_sets.size() * N, 0xFFFFFFFFu);
+    for (size_t t = 0; t < tree_sets.size(); ++t) {
+        const auto& levels = e->spread_sets[tree_sets[t]];
+        const uint32_t base = (uint32_t)tn_parent.size();
+        std::vector<uint32_t> last_child;   // per tnode: last child created (for sibling chaining)
+        auto new_node = [&](uint32_t parent) -> uint32_t {
+            uint32_t id = (uint32_t)tn_parent.size() - base;
+            tn_parent.push_back(parent);
+            tn_first.push_back(0xFFFFFFFFu);
+            tn_next.push_back(0xFFFFFFFFu);
+            tn_nchild.push_back(0);
+            last_child.push_back(0xFFFFFFFFu);
+            return id;
+        };
+        new_node(0xFFFFFFFFu);
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> child_of;   // (tnode, raw value id) -> child
+        for (uint32_t n = 0; n < N; ++n) {
+            const HostNode& h = e->nodes[n];
+            if (!h.present) continue;
+            uint32_t tn = 0;
+            for (const swp_spread& lv : levels) {
+                uint32_t value = 0;
+                if (lv.kind == SWP_CK_NODE_LABEL) {
+                    if (h.row.flags & SWP_NODE_HAS_LABELS)
+                        for (const swp_kv& kv : h.labels)
+                            if (kv.key == lv.key) value = kv.raw;
+                } else if ((h.row.flags & SWP_NODE_HAS_DESC) && (h.row.flags & SWP_NODE_HAS_ENGINE) && (h.row.flags & SWP_NODE_HAS_ELABELS)) {
+                    for (const swp_kv& kv : h.elabels)
+                        if (kv.key == lv.key) value = kv.raw;
+                }
+                auto it = child_of.find({tn, value});
+                if (it == child_of.end()) {
+                    uint32_t c = new_node(tn);
+                    if (last_child[tn] == 0xFFFFFFFFu) tn_first[base + tn] = c;
+                    else tn_next[base + last_child[tn]] = c;
+                    last_child[tn] = c;
+                    tn_nchild[base + tn]++;
+                    it = child_of.emplace(std::make_pair(tn, value), c).first;
+                }
+                tn = it->second;
+            }
+            leaf_of[t * N + n] = tn;
+        }
+        tree_off.push_back((uint32_t)tn_parent.size());
+        if (tn_parent.size() - base > G_MAXT) return e->fail(SWP_ERANGE, "spread tree with %zu branches exceeds the device limit %d", tn_parent.size() - base, G_MAXT);
+    }
+    std::vector<GroupRec> recs(n_groups);
+    uint32_t off = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const RTask& r = b.rt[g];
+        GroupRec& q = recs[g];
+        std::memset(&q, 0, sizeof q);
+        q.cpu = r.cpu; q.mem = r.mem; q.flags = r.flags; q.k = sizes[g]; q.svc = r.svc; q.out_off = off; q.pset = r.pset;
+        q.cls_con = r.cls_con; q.cls_plat = r.cls_plat; q.cls_plug = r.cls_plug; q.maxrep = r.maxrep;
+        q.tree = tree_local[groups[g].spread_set];
+        if ((uint64_t)sizes[g] > G_HCAP) return e->fail(SWP_ERANGE, "group of %u tasks exceeds the device heap capacity %d", sizes[g], G_HCAP);
+        off += sizes[g];
+    }
+    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_leaf, d_ff, d_svcd, d_faild, d_out, d_hist;
+    if ((rc = upload(e, d_recs, recs))) return rc;
+    if ((rc = upload(e, d_tree_off, tree_off))) return rc;
+    if ((rc = upload(e, d_par, tn_parent))) return rc;
+    if ((rc = upload(e, d_first, tn_first))) return rc;
+    if ((rc = upload(e, d_next, tn_next))) return rc;
+    if ((rc = upload(e, d_nch, tn_nchild))) return rc;
+    if ((rc = upload(e, d_leaf, leaf_of))) return rc;
+    HIPCHECK(e, d_ff.reserve(N));
+    HIPCHECK(e, d_svcd.reserve((size_t)N * 4));
+    HIPCHECK(e, d_faild.reserve((size_t)N * 4));
+    HIPCHECK(e, d_out.reserve((size_t)total * 4));
+    HIPCHECK(e, d_hist.reserve((size_t)n_groups * 8 * 4));
+    HIPCHECK(e, hipMemsetAsync(d_hist.p, 0, (size_t)n_groups * 8 * 4, st));
+    HIPCHECK(e, hipMemsetAsync(d_out.p, 0xFF, (size_t)total * 4, st));
+    size_t L = b.list_node0.size();
+    if (L) {
+        HIPCHECK(e, hipMemcpyAsync(b.d_list_node.p, b.d_list_node0.p, L * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(e, hipMemcpyAsync(b.d_list_svc.p, b.d_list_svc0.p, L * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHECK(e, hipMemcpyAsync(b.d_list_fail.p, b.d_list_fail0.p, L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHECK(e, hipMemsetAsync(b.d_portmap.p, 0, (size_t)std::max<uint32_t>(b.n_ports, 1) * Wn * 8, st));
+    HIPCHECK(e, hipMemsetAsync(b.d_ctl.p, 0, sizeof(Ctl), st));
+    if (!b.prow.empty())
+        hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b.prow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b.prow.size(),
+                           b.d_prow.as<uint32_t>(), b.d_pnode.as<uint32_t>(), Wn, b.d_portmap.as<u64>());
+    if ((rc = run_classes(e, &b))) return rc;
+    GroupArgs ga{};
+    ga.n_nodes = N; ga.n_words = Wn; ga.n_groups = n_groups; ga.n_trees = (uint32_t)tree_sets.size();
+    ga.g = d_recs.as<GroupRec>();
+    ga.valid = e->d_valid.as<u64>(); ga.ready = e->d_ready.as<u64>();
+    ga.con = b.d_con.as<u64>(); ga.plat = b.d_plat.as<u64>(); ga.plug = b.d_plug.as<u64>();
+    ga.cpu = e->d_cpu.as<long long>(); ga.mem = e->d_mem.as<long long>(); ga.total = e->d_total.as<uint32_t>();
+    ga.portmap = b.d_portmap.as<u64>(); ga.pset_off = b.d_pset_off.as<uint32_t>(); ga.pset_ids = b.d_pset_ids.as<uint32_t>();
+    ga.list_node = b.d_list_node.as<uint32_t>(); ga.list_svc = b.d_list_svc.as<uint32_t>(); ga.list_fail = b.d_list_fail.as<uint32_t>();
+    ga.list_off = b.d_list_off.as<uint32_t>();
+    ga.tree_off = d_tree_off.as<uint32_t>(); ga.tn_parent = d_par.as<uint32_t>(); ga.tn_first = d_first.as<uint32_t>();
+    ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
+    ga.ff = d_ff.as<unsigned char>(); ga.svc_dense = d_svcd.as<uint32_t>(); ga.fail_dense = d_faild.as<uint32_t>();
+    ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
+    const size_t lds = (size_t)G_HCAP * (8 * 2 + 4 * 8) + (size_t)G_MAXT * (8 + 4 * 4) + 256 * (8 * 2 + 4 * 6) + (8 + 16 + 8) * 4 + G_LOG + 256;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHECK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_groups), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_groups, dim3(1), dim3(256), lds, st, ga);
+    HIPCHECK(e, hipGetLastError());
+    Ctl ctl{};
+    HIPCHECK(e, hipMemcpyAsync(&ctl, b.d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
+    HIPCHECK(e, hipMemcpyAsync(out_node, d_out.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+    if (out_fail_hist) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, d_hist.p, (size_t)n_groups * 8 * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(e, hipStreamSynchronize(st));
+    if (ctl.error != ERR_NONE) {
+        e->dev_dynamic_dirty = true;   // device rows may be half-updated: the host mirror (untouched) is re-uploaded
+        return e->fail(SWP_ERANGE, "a group or its spread tree exceeds the device limits (heap slots %d, branches %d)", G_HCAP, G_MAXT);
+    }
+    uint64_t placed = 0;
+    off = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const swp_task_desc& d = groups[g];
+        for (uint32_t i = 0; i < sizes[g]; ++i) {
+            int32_t n = out_node[off + i];
+            if (n < 0) continue;
+            if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return e->fail(SWP_EHIP, "device returned an invalid node index %d", n);
+            host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+            ++placed;
+        }
+        off += sizes[g];
+    }
+    e->stats.batches++;
+    e->stats.tasks += total;
+    e->stats.placed += placed;
+    e->stats.infeasible += total - placed;
+    e->stats.pair_evals += (uint64_t)n_groups * e->n_present;
+    return SWP_OK;
 }
 
 int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_tasks, swp_batch** out) {

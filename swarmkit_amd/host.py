@@ -140,7 +140,7 @@ class HostScheduler:
         lab = []
         if labels is not None:
             flags |= abi.NODE_HAS_LABELS
-            lab = [(self.e.intern(abi.SPACE_LABEL_KEY, k), self._folded(v)) for k, v in labels.items()]
+            lab = [(self.e.intern(abi.SPACE_LABEL_KEY, k), self._folded(v), self.e.intern(abi.SPACE_RAW, v or "")) for k, v in labels.items()]
         elab, plugins = [], []
         desc = doc.get("Description")
         if desc is not None:
@@ -159,7 +159,7 @@ class HostScheduler:
                 el = eng.get("Labels")
                 if el is not None:
                     flags |= abi.NODE_HAS_ELABELS
-                    elab = [(self.e.intern(abi.SPACE_LABEL_KEY, k), self._folded(v)) for k, v in el.items()]
+                    elab = [(self.e.intern(abi.SPACE_LABEL_KEY, k), self._folded(v), self.e.intern(abi.SPACE_RAW, v or "")) for k, v in el.items()]
                 for p in eng.get("Plugins") or []:
                     typ, name = p.get("Type", ""), p.get("Name", "")
                     if typ == "Log":
@@ -452,9 +452,18 @@ class HostScheduler:
                 d["platform_set"] = self.e.platform_set(
                     [(self.e.intern(abi.SPACE_OS, p.get("OS", "") or ""), self.e.intern(abi.SPACE_ARCH, p.get("Architecture", "") or "")) for p in plats])
             d["max_replicas"] = int(pl.get("MaxReplicas", 0) or 0)
-            for pref in pl.get("Preferences") or []:
-                if pref.get("Spread") is not None:
-                    raise Unsupported("spread preferences: decision-tree scan is not on the device yet")
+            levels = []
+            for pref in pl.get("Preferences") or []:   # nodeset.go:59-82: only label spreads create a tree level
+                sp = pref.get("Spread")
+                if sp is None:
+                    continue
+                sd = sp.get("SpreadDescriptor", "") or ""
+                if len(sd) > len("node.labels.") and _fold_eq(sd[:len("node.labels.")], "node.labels."):
+                    levels.append((abi.CK_NODE_LABEL, self.e.intern(abi.SPACE_LABEL_KEY, sd[len("node.labels."):])))
+                elif len(sd) > len("engine.labels.") and _fold_eq(sd[:len("engine.labels.")], "engine.labels."):
+                    levels.append((abi.CK_ENGINE_LABEL, self.e.intern(abi.SPACE_LABEL_KEY, sd[len("engine.labels."):])))
+            if levels:
+                d["spread_set"] = self.e.spread_set(levels)
         # PluginFilter.SetTask, filter.go:119-131
         mounts = _get(t, "Spec", "Container", "Mounts") or []
         for m in mounts:
@@ -537,43 +546,86 @@ class HostScheduler:
                 "State": _state(_get(new, "Status", "State")), "Message": _get(new, "Status", "Message", default=""),
                 "Err": _get(new, "Status", "Err", default=""), "OldState": _state(_get(old, "Status", "State"))}
 
+    def _place(self, tid, t, n, decisions):
+        nid = self.idx_to_id[int(n)]
+        new_t = dict(t)
+        new_t["NodeID"] = nid
+        new_t["Status"] = {"State": ASSIGNED, "Message": "scheduler assigned task to node"}
+        self.all_tasks[tid] = new_t
+        self.nodes[nid]["tasks"][tid] = new_t   # numeric addTask already happened on the device
+        decisions.append(self._decision(t, new_t))
+
+    def _no_suitable_node(self, tid, t, hist, decisions):
+        """noSuitableNode, scheduler.go:928-971."""
+        sid = t.get("ServiceID", "")
+        if sid not in self.services:
+            return
+        new_t = dict(t)
+        sv, tv = self.services[sid], _get(t, "SpecVersion", "Index")
+        if sv is not None and tv is not None and sv > tv:
+            if _state(_get(t, "Status", "State")) == PENDING and _state(t.get("DesiredState")) >= SHUTDOWN:
+                new_t["Status"] = dict(t.get("Status", {}), State=SHUTDOWN, Err="")
+        else:
+            ex = self.explain(hist)
+            new_t["Status"] = dict(t.get("Status", {}), Err="no suitable node (" + ex + ")" if ex else "no suitable node")
+            self.unassigned[tid] = new_t
+        self.all_tasks[tid] = new_t
+        decisions.append(self._decision(t, new_t))
+
+    def _run_groups(self, groups, decisions):
+        """groups: list of [(tid, task)...] sharing a spec; one swp_schedule_groups call, groups in order."""
+        if not groups:
+            return
+        descs = np.concatenate([self.task_desc(g[0][1]) for g in groups])
+        sizes = np.array([len(g) for g in groups], dtype=np.uint32)
+        out, hist = self.e.schedule_groups(descs, sizes)
+        off = 0
+        for gi, g in enumerate(groups):
+            for i, (tid, t) in enumerate(g):
+                n = out[off + i]
+                if n >= 0:
+                    self._place(tid, t, n, decisions)
+                else:
+                    self._no_suitable_node(tid, t, hist[gi], decisions)
+            off += len(g)
+
+    def _run_one_offs(self, run, decisions):
+        if not run:
+            return
+        descs = np.concatenate([self.task_desc(t) for _, t in run])
+        out, hist = self.e.schedule_batch(descs)
+        for (tid, t), n, h in zip(run, out, hist):
+            if n >= 0:
+                self._place(tid, t, n, decisions)
+            else:
+                self._no_suitable_node(tid, t, h, decisions)
+
     def tick(self):
-        """scheduler.go:429-488 for one-off tasks (SpecVersion == nil)."""
+        """scheduler.go:429-488: groups (ServiceID, SpecVersion) in first-seen order, then the one-off tasks in
+        queue order; every scheduling step is a device call (swp_schedule_groups / swp_schedule_batch)."""
         queue = [(tid, t) for tid, t in self.unassigned.items() if t is not None and not t.get("NodeID")]
         self.unassigned.clear()
-        if any(t.get("SpecVersion") is not None for _, t in queue):
-            raise Unsupported("grouped tasks (SpecVersion set): top-k group scan is not on the device yet")
         decisions = []
         if not queue:
             return decisions
         self._push_failures({t.get("ServiceID", "") for _, t in queue})
-        descs = np.concatenate([self.task_desc(t) for _, t in queue])
-        out, hist = self.e.schedule_batch(descs)
-        for (tid, t), n, h in zip(queue, out, hist):
-            if n >= 0:
-                nid = self.idx_to_id[int(n)]
-                new_t = dict(t)
-                new_t["NodeID"] = nid
-                new_t["Status"] = {"State": ASSIGNED, "Message": "scheduler assigned task to node"}
-                self.all_tasks[tid] = new_t
-                self.nodes[nid]["tasks"][tid] = new_t   # numeric addTask already happened on the device
-                decisions.append(self._decision(t, new_t))
-                continue
-            # noSuitableNode, scheduler.go:928-971
-            sid = t.get("ServiceID", "")
-            if sid not in self.services:
-                continue
-            new_t = dict(t)
-            sv, tv = self.services[sid], _get(t, "SpecVersion", "Index")
-            if sv is not None and tv is not None and sv > tv:
-                if _state(_get(t, "Status", "State")) == PENDING and _state(t.get("DesiredState")) >= SHUTDOWN:
-                    new_t["Status"] = dict(t.get("Status", {}), State=SHUTDOWN, Err="")
+        grouped, one_off = {}, []
+        for tid, t in queue:
+            if t.get("SpecVersion") is not None:
+                grouped.setdefault((t.get("ServiceID", ""), _get(t, "SpecVersion", "Index", default=0)), []).append((tid, t))
             else:
-                ex = self.explain(h)
-                new_t["Status"] = dict(t.get("Status", {}), Err="no suitable node (" + ex + ")" if ex else "no suitable node")
-                self.unassigned[tid] = new_t
-            self.all_tasks[tid] = new_t
-            decisions.append(self._decision(t, new_t))
+                one_off.append((tid, t))
+        self._run_groups(list(grouped.values()), decisions)
+        # one-off tasks: a task with spread preferences is a group of one and must keep its place in the order
+        run = []
+        for tid, t in one_off:
+            if int(self.task_desc(t)["spread_set"][0]):
+                self._run_one_offs(run, decisions)
+                run = []
+                self._run_groups([[(tid, t)]], decisions)
+            else:
+                run.append((tid, t))
+        self._run_one_offs(run, decisions)
         return decisions
 
 

@@ -288,3 +288,40 @@ def scenario_faulty_node(factory):
         assert len(pa) == 1 and pa[0]["NodeID"] == "id1"
         s.update_task(dict(t, NodeID=a[0]["NodeID"], Status={"State": orc.FAILED}))
         s.update_task(dict(p, Status={"State": orc.FAILED}))
+
+
+def scenario_multiple_preferences(factory, use_spec_version, with_generic=True):
+    """testMultiplePreferences, scheduler_test.go:808-1106: two spread levels + resources."""
+    s = factory()
+    sv = 1 if use_spec_version else None
+
+    def n(i, az, rack, mem, apples):
+        res = {"NanoCPUs": int(1e9), "MemoryBytes": int(mem)}
+        if with_generic:
+            res["Generic"] = discrete("apple", apples)
+        return node(f"id{i}", Spec={"Annotations": {"Labels": {"az": az, "rack": rack}}}, Description={"Resources": res})
+    s.create_node(n(0, "az1", "rack1", 1e8, 1))
+    s.create_node(n(1, "az1", "rack1", 1e9, 10))
+    for i in (2, 3, 4):
+        s.create_node(n(i, "az2", "rack1", 1e9, 6))
+    for i in (5, 6):
+        s.create_node(n(i, "az2", "rack2", 1e9, 6))
+    reservations = {"MemoryBytes": int(2e8)}
+    if with_generic:
+        reservations["Generic"] = discrete("apple", 2)
+    spec = {"Placement": {"Preferences": [{"Spread": {"SpreadDescriptor": "node.labels.az"}},
+                                          {"Spread": {"SpreadDescriptor": "node.labels.rack"}}]},
+            "Resources": {"Reservations": reservations}}
+    for i in range(12):
+        s.create_task(pending(f"t1id{i}", "service1", sv, Spec=spec))
+    t1 = Counter(d["NodeID"] for d in assignments(s.tick()))
+    assert len(t1) == 6
+    assert t1["id0"] == 0 and t1["id1"] == 5   # :1063-1068
+    rack1 = t1["id2"] + t1["id3"] + t1["id4"]
+    rack2 = t1["id5"] + t1["id6"]
+    assert sorted((rack1, rack2)) == [3, 4]    # :1070-1105
+    if rack1 == 4:
+        assert sorted((t1["id2"], t1["id3"], t1["id4"])) == [1, 1, 2] and sorted((t1["id5"], t1["id6"])) == [1, 2]
+    else:
+        assert (t1["id2"], t1["id3"], t1["id4"]) == (1, 1, 1) and (t1["id5"], t1["id6"]) == (2, 2)
+    return t1

@@ -1,0 +1,94 @@
+"""GPU: grouped tasks (SpecVersion set) and spread preferences — k_groups vs the oracle, decision for decision."""
+import pytest
+
+import orc
+import parity_util as pu
+import scenarios as sc
+from swarmkit_amd import host as swhost
+from swarmkit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def factory():
+    return swhost.HostScheduler()
+
+
+def both(events):
+    """Drive the oracle and the engine with the same event script; compare every tick's decisions."""
+    o, e = orc.Oracle(), swhost.HostScheduler()
+    for ev in events:
+        kind = ev[0]
+        if kind == "tick":
+            do = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in o.tick())
+            de = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in e.tick())
+            assert do == de, [(a, b) for a, b in zip(do, de) if a != b][:5]
+        else:
+            for s in (o, e):
+                getattr(s, kind)(*ev[1:])
+    return o, e
+
+
+def test_ha_grouped():
+    sc.scenario_ha(factory, True)
+
+
+@pytest.mark.parametrize("use_spec_version", [False, True])
+def test_preferences(use_spec_version):
+    sc.scenario_preferences(factory, use_spec_version)
+
+
+@pytest.mark.parametrize("use_spec_version", [False, True])
+def test_multiple_preferences(use_spec_version):
+    sc.scenario_multiple_preferences(factory, use_spec_version, with_generic=False)
+
+
+@pytest.mark.parametrize("name,T,N", [("cfg2", 3000, 150), ("cfg3", 4000, 500), ("cfg4", 4000, 600), ("cfg1", 600, 10)])
+def test_grouped_parity(name, T, N):
+    """S groups of ~100 identical tasks (SURVEY §8d 'grouped' mode): heap order, fill loop, leftovers, explanations."""
+    wl = synth.Workload(name, T=T, N=N, grouped=True)
+    ev = [("create_node", wl.node_doc(i)) for i in range(wl.N)]
+    ev += [("set_service", wl.service_id(k)) for k in range(wl.S)]
+    ev += [("create_task", wl.task_doc(j)) for j in range(wl.T)]
+    ev += [("tick",)]
+    both(ev)
+
+
+def test_grouped_then_one_off_in_one_tick():
+    wl_g = synth.Workload("cfg3", T=1500, N=300, grouped=True)
+    wl_o = synth.Workload("cfg3", T=1500, N=300, grouped=False)
+    ev = [("create_node", wl_g.node_doc(i)) for i in range(wl_g.N)]
+    ev += [("set_service", wl_g.service_id(k)) for k in range(wl_g.S)]
+    for j in range(1500):
+        ev.append(("create_task", wl_g.task_doc(j) if j % 3 else dict(wl_o.task_doc(j), ID="o%05d" % j)))
+    ev += [("tick",), ("tick",)]
+    both(ev)
+
+
+def test_spread_with_constraints_and_leftovers():
+    """Two spread levels, a constraint, tight memory: some groups are only partly placed → Explain replay."""
+    ev = []
+    for i in range(40):
+        ev.append(("create_node", sc.node(f"n{i:02d}", Spec={"Annotations": {"Labels": {"az": f"az{i % 3}", "rack": f"r{i % 5}", "tier": "a" if i % 4 else "b"}}},
+                                          Description={"Resources": {"NanoCPUs": int(4e9), "MemoryBytes": int((1 + i % 3) * 1e9)}})))
+    for sname in ("svcA", "svcB", "svcC"):
+        ev.append(("set_service", sname))
+    prefs = [{"Spread": {"SpreadDescriptor": "node.labels.az"}}, {"Spread": {"SpreadDescriptor": "node.labels.rack"}}]
+    for i in range(70):
+        ev.append(("create_task", sc.pending(f"a{i:03d}", "svcA", 1, Spec={"Placement": {"Preferences": prefs, "Constraints": ["node.labels.tier==a"]},
+                                                                         "Resources": {"Reservations": {"MemoryBytes": int(6e8)}}})))
+    for i in range(50):
+        ev.append(("create_task", sc.pending(f"b{i:03d}", "svcB", 2, Spec={"Placement": {"Preferences": prefs[:1], "MaxReplicas": 2},
+                                                                         "Resources": {"Reservations": {"MemoryBytes": int(3e8)}}})))
+    for i in range(30):
+        ev.append(("create_task", sc.pending(f"c{i:03d}", "svcC", Spec={"Placement": {"Preferences": prefs[1:]}})))   # one-off with preferences
+    ev += [("tick",), ("tick",)]
+    both(ev)
+
+
+def test_generic_resources_are_refused_not_faked():
+    s = factory()
+    s.create_node(sc.node("n1"))
+    s.create_task(sc.pending("t1", "svc", Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))
+    with pytest.raises(swhost.Unsupported):
+        s.tick()

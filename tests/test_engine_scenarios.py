@@ -45,19 +45,6 @@ def test_faulty_node():
     sc.scenario_faulty_node(factory)
 
 
-def test_unsupported_features_are_refused_not_faked():
-    s = factory()
-    s.create_node(sc.node("n1"))
-    s.create_task(sc.pending("t1", "svc", 1))   # grouped (SpecVersion set)
-    with pytest.raises(swhost.Unsupported):
-        s.tick()
-    s = factory()
-    s.create_node(sc.node("n1"))
-    s.create_task(sc.pending("t1", "svc", Spec={"Placement": {"Preferences": [{"Spread": {"SpreadDescriptor": "node.labels.az"}}]}}))
-    with pytest.raises(swhost.Unsupported):
-        s.tick()
-
-
 def test_constraint_truth_tables_on_device():
     """constraint_test.go:62-350 through k_constraint_classes (swp_check_node)."""
     for cons, node, want in kt.constraint_cases():

@@ -46,3 +46,9 @@ def test_max_replicas():
 
 def test_faulty_node():
     sc.scenario_faulty_node(factory)
+
+
+@pytest.mark.parametrize("use_spec_version", [False, True])
+@pytest.mark.parametrize("with_generic", [False, True])
+def test_multiple_preferences(use_spec_version, with_generic):
+    sc.scenario_multiple_preferences(factory, use_spec_version, with_generic)
