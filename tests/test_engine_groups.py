@@ -92,3 +92,55 @@ def test_generic_resources_are_refused_not_faked():
     s.create_task(sc.pending("t1", "svc", Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))
     with pytest.raises(swhost.Unsupported):
         s.tick()
+
+
+def test_churn_rounds():
+    """BASELINE configs[4] in miniature: place, then rounds of {drain 10 % of the nodes, delete their tasks,
+    reactivate the previous set, add as many new tasks} — exercises swp_node_upsert, swp_commit(remove) and the
+    batch path against the oracle, decision for decision."""
+    wl = synth.Workload("cfg3", T=1200, N=200)
+    ev = [("create_node", wl.node_doc(i)) for i in range(wl.N)]
+    ev += [("set_service", wl.service_id(k)) for k in range(wl.S)]
+    ev += [("create_task", wl.task_doc(j)) for j in range(600)]
+    o, e = both(ev + [("tick",)])
+    placed = {}   # task id -> (task doc, node id)
+    docs = {wl.task_id(j): wl.task_doc(j) for j in range(wl.T)}
+
+    def tick_both():
+        do = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in o.tick())
+        de = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in e.tick())
+        assert do == de, [(a, b) for a, b in zip(do, de) if a != b][:5]
+        return do
+    # recover first-tick placements from the oracle's node infos
+    for i in range(wl.N):
+        info = o.node_info(wl.node_id(i))
+        for tid in info["Tasks"]:
+            placed[tid] = wl.node_id(i)
+    nxt, prev_drained = 600, []
+    for rnd in range(6):
+        drained = [wl.node_id(i) for i in range(wl.N) if (i * 7 + rnd * 13) % 10 == 0]
+        for s in (o, e):
+            for nid in prev_drained:
+                s.update_node(wl.node_doc(int(nid[1:])))
+            for nid in drained:
+                s.update_node(dict(wl.node_doc(int(nid[1:])), Spec=dict(wl.node_doc(int(nid[1:]))["Spec"], Availability=2)))
+        gone = [tid for tid, nid in placed.items() if nid in drained]
+        for tid in gone:
+            t = dict(docs[tid], NodeID=placed[tid], Status={"State": orc.RUNNING})
+            for s in (o, e):
+                s.delete_task(t)
+            del placed[tid]
+        for _ in range(len(gone)):
+            if nxt >= wl.T:
+                break
+            for s in (o, e):
+                s.create_task(wl.task_doc(nxt))
+            nxt += 1
+        for tid, nid, err, st in tick_both():
+            if nid and st >= orc.ASSIGNED:
+                placed[tid] = nid
+        prev_drained = drained
+    for i in (0, 7, 50, 199):
+        a, b = o.node_info(wl.node_id(i)), e.node_info(wl.node_id(i))
+        assert a["ActiveTasksCount"] == b["ActiveTasksCount"] and a["AvailableResources"]["NanoCPUs"] == b["AvailableResources"]["NanoCPUs"]
+        assert a["AvailableResources"]["MemoryBytes"] == b["AvailableResources"]["MemoryBytes"]
