@@ -1393,6 +1393,7 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
                     atomicAdd(a.total + n, 1u);
                     if (rg_flags & 2u) atomicAdd(a.list_svc + rg_slot, 1u);   // placed through the exception list
                     else {
+                        atomicOr(&a.X[(size_t)rg_svc * XS + (n >> 6)], 1ull << (n & 63));   // the loader restages X rows from memory
                         a.list_node[rg_slot] = n;
                         a.list_svc[rg_slot] = 1;
                         a.list_fail[rg_slot] = 0;
@@ -1433,8 +1434,8 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
     // rows + record of the task about to be processed (read one task ahead)
     u64 cF[K], cX[K];
     R2Rec crec;
-    auto read_task = [&](u32 jj) __attribute__((always_inline)) {
-        const u32 bi = jj / R2_TB, tt = jj % R2_TB, bf = bi & 1;
+    auto read_task_at = [&](u32 bi, u32 tt) __attribute__((always_inline)) {
+        const u32 bf = bi & 1;
         crec = Tb[bf * R2_TB + tt];
         const u64* frow = Fb + ((size_t)bf * R2_TB + tt) * Wn;
         const u64* xrow = Xb + ((size_t)bf * R2_TB + tt) * XS;
@@ -1447,9 +1448,10 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
         }
     };
     wait_block(0);
-    if (!fatal) read_task(0);
+    if (!fatal) read_task_at(0, 0);
     R2_TICK(0);
 
+    u32 tin = 0, bdone = 0;   // task index inside the block, blocks finished
     for (u32 j = 0; j < a.count && !fatal; ++j) {
         const u32 gj = a.j0 + j;
         const R2Rec rec = crec;
@@ -1526,8 +1528,8 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
 
         // ---------------- read the next task's rows now: their LDS latency hides under the commit ----------------
         if (j + 1 < a.count) {
-            if (__builtin_expect((j + 1) % R2_TB == 0, 0)) wait_block((j + 1) / R2_TB);
-            if (!fatal) read_task(j + 1);
+            if (__builtin_expect(tin + 1 == R2_TB, 0)) wait_block(bdone + 1);
+            if (!fatal) read_task_at(tin + 1 == R2_TB ? bdone + 1 : bdone, tin + 1 == R2_TB ? 0u : tin + 1);
         }
 
         bool placed = fast, via_list = false;
@@ -1654,9 +1656,6 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
                 if (owner)
                     for (u32 p = a.pset_off[rec.pset]; p < a.pset_off[rec.pset + 1]; ++p) atomicOr(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], bit);
             }
-            if (counted && !via_list) {
-                if (owner) atomicOr(&a.X[(size_t)rsvc * XS + w], bit);   // the loader restages X rows from memory
-            }
             {   // remember the commit: X freshness + deferred side effects
                 const bool me = lane == (ncommit & 63u);
                 rg_svc = me ? ((counted && !via_list) ? rsvc : 0xFFFFFFFFu) : rg_svc;
@@ -1668,7 +1667,6 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
                 rg_mem = me ? rec.mem : rg_mem;
             }
             ++ncommit;
-            if (__builtin_expect((ncommit & 63u) == 0, 0)) flush();
             if (__builtin_expect(!fast && !want_rebase && counted, 0)) {
                 // a generic commit may have moved a node across the hot levels; a plain pick at another level
                 // re-centres the hot level there (nodes below it stay exact through BELOW)
@@ -1698,10 +1696,13 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
             } else derive_masks(0);
         }
         R2_TICK(4);
-        if (__builtin_expect((j + 1) % R2_TB == 0 || j + 1 == a.count, 0)) {
-            // every X atomic of this block is in L2 before the loader may restage rows that depend on it
+        if (__builtin_expect(++tin == R2_TB || j + 1 == a.count, 0)) {
+            // block end: apply the (≤ R2_TB) pending commits lane-parallel; every X atomic of this block must be in
+            // L2 before the loader may restage rows that depend on it
+            flush();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&flags_lds[2], j / R2_TB + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&flags_lds[2], ++bdone, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tin = 0;
             R2_TICK(5);
         }
     }
