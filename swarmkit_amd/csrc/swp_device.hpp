@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace swpdev {
 
@@ -1719,6 +1720,631 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
         a.ctl->generic_tasks += st_generic;
         a.ctl->spin_waits += st_spins;
         if (prof) { cyc[6] = clock64() - c_start; cyc[7] = wall_clock64() - w_start; }
+        for (int q = 0; q < 8; ++q) a.ctl->cyc[q] += cyc[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_resolve3 — k_resolve2's two-wave scheme with the resolver's common case cut down to the instructions
+// the algorithm needs (a lone wave issues ~1 instruction per 4 ns, so the task rate IS the instruction count):
+//   * F and X rows are staged interleaved ({F,X} = one 16-byte LDS read per owned word) in rows padded to
+//     64*K words, so the reads are unconditional and one task ahead in the SAME registers (no copies);
+//   * the pick is specialised per owned-word slot k (a scalar branch), so nothing is selected through
+//     v_cndmask chains: one s_ff1 on the slot's ballot, readlanes of that slot's candidate / touched word;
+//   * a fast commit touches only the owner lane of slot k: LA/LB/tch/D with scalar bit operands;
+//   * level bit-planes are updated LAZILY: fast commits only collect the node in D (a node takes at most one
+//     fast commit per window); the bit-sliced "+1 on D" runs when the generic path or a hot-level change
+//     needs exact planes;
+//   * level-range and hot-level-exhausted checks are scalars maintained at derive time, not per task.
+// Semantics (pick order, exception lists, commit log, counters) are those of k_resolve2.
+// ---------------------------------------------------------------------------------------------
+template <int K, bool PROF>
+__global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
+    extern __shared__ unsigned char r3_lds[];
+    const u32 Wn = a.n_words, XS = a.xs, TB = a.tb;
+    constexpr u32 RS = K * 64;   // staged row stride in words
+    int32_t* last_lds = reinterpret_cast<int32_t*>(r3_lds);                                    // [n_nodes]
+    const size_t off_f = (((size_t)a.n_nodes * 4 + 15) / 16) * 16;
+    ulonglong2* FX = reinterpret_cast<ulonglong2*>(r3_lds + off_f);                            // [2*TB + 1][RS] {F, X}
+    R2Rec* Tb = reinterpret_cast<R2Rec*>(r3_lds + off_f + (size_t)(2 * TB + 1) * RS * 16);     // [2*TB + 1]
+    u32* flags_lds = reinterpret_cast<u32*>(r3_lds + off_f + (size_t)(2 * TB + 1) * RS * 16 + (size_t)(2 * TB + 1) * sizeof(R2Rec));
+    // flags_lds[0..1] = ready[buf] (block index + 1), [2] = done (blocks finished by the resolver), [3] = abort
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 nblk = (a.count + TB - 1) / TB;
+    if (a.ctl->error != ERR_NONE) return;
+    if (tid < 4) flags_lds[tid] = 0;
+    for (u32 n = tid; n < a.n_nodes; n += 128) last_lds[n] = a.last[n];
+    __syncthreads();
+
+    if (wave == 1) {
+        // =============================== LOADER ===============================
+        for (u32 b = 0; b < nblk; ++b) {
+            const u32 buf = b & 1;
+            if (b >= 2) {   // buffer is free (and every commit of blocks ≤ b-2 is visible) once block b-2 is done
+                u32 spins = 0;
+                while (__hip_atomic_load(&flags_lds[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < b - 1) {
+                    if (__hip_atomic_load(&flags_lds[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 26)) return;   // bounded: never hang the GPU
+                }
+            }
+            const u32 t0 = b * TB, nt = min(TB, a.count - t0);
+            if (lane < nt) {
+                const RTask* r = a.rt + a.j0 + t0 + lane;
+                R2Rec rec;
+                rec.cpu = r->cpu;
+                rec.mem = r->mem;
+                rec.flags = r->flags;
+                rec.svc = r->svc;
+                rec.slot = r->slot;
+                rec.pset = r->pset;
+                Tb[buf * TB + lane] = rec;
+            }
+            for (u32 t = 0; t < nt; t += 4) {   // 4 rows = 8*K loads in flight per lane
+                u64 f[4][K], x[4][K];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ht = t + q < nt;
+                    const u32 svc = ht ? cload(&a.rt[a.j0 + t0 + t + q].svc) : 0u;
+                    const u64* fs = a.F + (size_t)(t0 + t + q) * Wn;
+                    const u64* xs = a.X + (size_t)svc * XS;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const u32 i = lane + 64 * k;
+                        const bool ok = ht && i < Wn;
+                        f[q][k] = ok ? fs[i] : 0ull;
+                        x[q][k] = ok ? __hip_atomic_load(&xs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;   // mutable: past the L1
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (t + q < nt) {
+                        ulonglong2* dst = FX + ((size_t)buf * TB + t + q) * RS + lane;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) dst[64 * k] = make_ulonglong2(f[q][k], x[q][k]);
+                    }
+                }
+            }
+            __hip_atomic_store(&flags_lds[buf], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+
+    // =============================== RESOLVER ===============================
+    u32 ncommit = a.ctl->ncommit, ninf = a.ctl->ninf;
+    u32 applied = ncommit;   // commits [applied, ncommit) still live only in the lane ring
+    u32 st_retries = 0, st_slow = 0, st_rebase = 0, st_generic = 0, st_spins = 0;
+    const u32 idx_bits = 32 - __clz((Wn * 64) | 1u);
+    const u32 idx_mask = (1u << idx_bits) - 1u;
+    u32 NB = 1, base = 0, h = 0;
+    u32 la_count = 0;    // nodes left at the hot level (scalar)
+    // Exact state = (planes, LA0, LB0, T0) as of the last fold, plus D = nodes fast-committed since then:
+    //   level(n) = planes(n) + [n in D];  LA = LA0 & ~D;  LB = LB0 ^ D;  touched = T0 | D.
+    // A node takes at most one fast commit per window (a touched pick goes generic), so one bit per node suffices
+    // and a fast commit changes D only.
+    u64 pl[R1_NBR][K];   // level bit-planes of the owned words {lane + 64k}
+    u64 D[K];
+    u64 T0[K];           // nodes committed to since the scan (their F bits may be stale)
+    u64 BELOW[K], LA0[K], LB0[K], VAL[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        T0[k] = 0;
+        D[k] = 0;
+        VAL[k] = (lane + 64 * k) < Wn ? a.valid[lane + 64 * k] : 0ull;
+    }
+    // commit ring: lane e holds the commit whose index ≡ e (mod 64): X freshness for rows staged before the
+    // commit, and the deferred lane-parallel application of the side effects (≤ TB pending at any time)
+    u32 rg_svc = 0xFFFFFFFFu, rg_node = 0, rg_meta = 0, rg_slot = 0;   // meta = task-in-block | counted<<8 | via_list<<9
+
+    auto build_planes = [&]() __attribute__((always_inline)) -> bool {
+        u32 lo = 0xFFFFFFFFu, hi = 0;
+        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if ((VAL[k] >> i) & 1ull) {
+                    u32 t = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lo = min(lo, t);
+                    hi = max(hi, t);
+                }
+            }
+        }
+        lo = wave_min_u32(lo);
+        hi = wave_max_u32(hi);
+        if (lo == 0xFFFFFFFFu) { lo = 0; hi = 0; }
+        u32 need = 32 - __clz((hi - lo) | 1u);
+        u32 cap = min((u32)R1_NBR, 32u - idx_bits);
+        if (need > cap) return false;
+        base = lo;
+        NB = min(cap, need + 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            T0[k] |= D[k];
+            D[k] = 0;
+#pragma unroll
+            for (int b = 0; b < R1_NBR; ++b) pl[b][k] = 0;
+        }
+        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                u32 lvl = 0;
+                if ((VAL[k] >> i) & 1ull)
+                    lvl = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+#pragma unroll
+                for (int b = 0; b < R1_NBR; ++b) pl[b][k] |= (u64)((lvl >> b) & 1u) << i;
+            }
+        }
+        return true;
+    };
+    // fold D into the exact state: planes += 1 on D (bit-sliced ripple carry), masks, touched; D = 0
+    auto fold = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u64 c = D[k];
+            LA0[k] &= ~c;
+            LB0[k] ^= c;
+            T0[k] |= c;
+#pragma unroll
+            for (int b = 0; b < R1_NBR; ++b) {
+                const u64 t = pl[b][k] & c;
+                pl[b][k] ^= c;
+                c = t;
+            }
+            D[k] = 0;
+        }
+    };
+    // hot masks from the planes (D must be empty) for level hh: BELOW = level < hh, LA = level == hh, LB = level == hh+1.
+    // When hh+1 cannot be bumped inside the planes every candidate is routed to the generic path (BELOW = all).
+    auto derive_masks = [&](u32 hh) __attribute__((always_inline)) {
+        h = hh;
+        const bool ok = hh + 2u <= (1u << NB) - 1u;
+        u32 cnt = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u64 lt = 0, eq = VAL[k], eq1 = VAL[k];
+            const u32 h1 = hh + 1;
+#pragma unroll
+            for (int b = R1_NBR - 1; b >= 0; --b) {
+                const u64 p = pl[b][k];
+                if (hh >> b & 1u) { lt |= eq & ~p; eq &= p; } else { eq &= ~p; }
+                if (h1 >> b & 1u) eq1 &= p; else eq1 &= ~p;
+            }
+            BELOW[k] = ok ? lt : VAL[k];
+            LA0[k] = ok ? eq : 0ull;
+            LB0[k] = ok ? eq1 : 0ull;
+            cnt += (u32)__popcll(LA0[k]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += (u32)__shfl_xor((int)cnt, off, 64);
+        la_count = (u32)__builtin_amdgcn_readfirstlane((int)cnt);
+    };
+    auto search = [&](const u64 (&mk)[K]) __attribute__((always_inline)) -> u32 {
+        u64 m[K];
+        u32 lv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { m[k] = mk[k]; lv[k] = 0; }
+#pragma unroll
+        for (int b = R1_NBR - 1; b >= 0; --b) {
+            if ((u32)b < NB) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    u64 t = m[k] & ~pl[b][k];
+                    bool nz = t != 0;
+                    m[k] = nz ? t : m[k];
+                    lv[k] |= nz ? 0u : (1u << b);
+                }
+            }
+        }
+        u32 best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u32 w = lane + 64 * k;
+            u32 cand = (lv[k] << idx_bits) | (w * 64 + (u32)(__ffsll((long long)m[k]) - 1));
+            best = min(best, m[k] ? cand : 0xFFFFFFFFu);
+        }
+        return wave_min_u32_dpp(best);
+    };
+    u32 tin = 0, bdone = 0;   // task index inside the block, blocks finished
+    // Apply the side effects of commits [applied, ncommit) — one commit per lane: residual update of the
+    // node row (NodeInfo.addTask, nodeinfo.go:108-154), exception-list entry, commit log + per-node chain.
+    // All pending commits belong to the current block (flushed at every block end).
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (ncommit != applied) {
+            const u32 last_c = ncommit - 1;
+            const u32 ce = last_c - ((last_c - lane) & 63u);   // this lane's newest commit index
+            if (ce >= applied && ce <= last_c) {
+                const u32 n = rg_node, tt = rg_meta & 0xFFu;
+                const R2Rec r = Tb[(bdone & 1u) * TB + tt];
+                const u32 gj = a.j0 + bdone * TB + tt;
+                if (r.cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-r.cpu));
+                if (r.mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-r.mem));
+                if (rg_meta & 0x100u) {   // counted
+                    atomicAdd(a.total + n, 1u);
+                    if (rg_meta & 0x200u) atomicAdd(a.list_svc + rg_slot, 1u);   // placed through the exception list
+                    else {
+                        atomicOr(&a.X[(size_t)r.svc * XS + (n >> 6)], 1ull << (n & 63));   // the loader restages X rows from memory
+                        a.list_node[r.slot] = n;
+                        a.list_svc[r.slot] = 1;
+                        a.list_fail[r.slot] = 0;
+                    }
+                }
+                a.log_node[ce] = n;
+                a.log_task[ce] = gj;
+                a.log_prev[ce] = (int32_t)atomicExch(reinterpret_cast<u32*>(&last_lds[n]), ce);   // chain order within a flush is arbitrary
+                a.out_node[gj] = (int32_t)n;
+            }
+            applied = ncommit;
+        }
+    };
+
+    if (!build_planes()) {
+        if (lane == 0) {
+            a.ctl->error = ERR_LEVEL_RANGE;
+            __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    derive_masks(0);
+    bool fatal = false;
+    u64 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tk = PROF ? wall_clock64() : 0;
+    const u64 c_start = PROF ? clock64() : 0, w_start = tk;
+
+    auto wait_block = [&](u32 bi) __attribute__((always_inline)) {
+        u32 spins = 0;
+        while (__hip_atomic_load(&flags_lds[bi & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != bi + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) { fatal = true; break; }
+        }
+        st_spins += spins;
+    };
+    // rows + record of the task about to be processed (read one task ahead, into the same registers)
+    ulonglong2 cfx[K];
+    uint2 cr;   // {flags, svc}
+    auto read_slot = [&](u32 slot) __attribute__((always_inline)) {   // slot = buf*TB + task-in-block (slot 2*TB = padding)
+        cr = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(&Tb[slot]) + 16);
+        const ulonglong2* row = FX + (size_t)slot * RS + lane;
+#pragma unroll
+        for (int k = 0; k < K; ++k) cfx[k] = row[64 * k];
+    };
+    wait_block(0);
+    if (!fatal) read_slot(0);
+    R2_TICK(0);
+
+    for (u32 j = 0; j < a.count && !fatal; ++j) {
+        const u32 rflags = (u32)__builtin_amdgcn_readfirstlane((int)cr.x);
+        const u32 rsvc = (u32)__builtin_amdgcn_readfirstlane((int)cr.y);
+        u64 mk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) mk[k] = cfx[k].x & ~cfx[k].y;
+        // next task's rows: issued now, consumed next iteration (at a block end this reads a stale/padding slot
+        // that the block-end code re-reads properly)
+        read_slot((bdone & 1u) * TB + tin + 1);
+        {   // commits younger than the staged X row (the ring spans the last 64 commits ≥ 3 blocks)
+            u64 match = ballot64(rg_svc == rsvc);
+            while (__builtin_expect(match != 0, 0)) {
+                const int e = __ffsll((long long)match) - 1;
+                match &= match - 1;
+                const u32 nn = (u32)__builtin_amdgcn_readlane((int)rg_node, e);
+                const u32 ww = nn >> 6;
+#pragma unroll
+                for (int k = 0; k < K; ++k) mk[k] &= ~((lane + 64u * k == ww) ? (1ull << (nn & 63)) : 0ull);
+            }
+        }
+        R2_TICK(1);
+
+        // ---------------- fast pick: lowest node at the hot level h (LA), else at h+1 (LB); nothing below h ----------------
+        u64 sb = 0;
+        u64 ca[K], ba[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            sb |= mk[k] & BELOW[k];
+            ca[k] = mk[k] & LA0[k] & ~D[k];
+        }
+        const u64 sp = ballot64(sb != 0);
+        u64 anya = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ba[k] = ballot64(ca[k] != 0);
+            anya |= ba[k];
+        }
+        bool generic = (rflags & (RT_PORTS | RT_UNCOUNTED)) != 0 || sp != 0;
+        bool placed = false;
+        u32 n = 0;
+
+        // one specialised copy per (class, slot): scalar pick, then D gains the node's bit on its owner lane
+#define R3_TAKE(kk, ISB, BAL, CW)                                                                                  \
+    {                                                                                                              \
+        const int l_ = __builtin_ctzll(BAL);                                                                       \
+        const u64 tv_ = T0[kk] | D[kk];                                                                            \
+        const u32 wlo_ = (u32)__builtin_amdgcn_readlane((int)(u32)(CW), l_);                                       \
+        const u32 whi_ = (u32)__builtin_amdgcn_readlane((int)(u32)((CW) >> 32), l_);                               \
+        const u32 tlo_ = (u32)__builtin_amdgcn_readlane((int)(u32)tv_, l_);                                        \
+        const u32 thi_ = (u32)__builtin_amdgcn_readlane((int)(u32)(tv_ >> 32), l_);                                \
+        const u64 word_ = ((u64)whi_ << 32) | wlo_, tw_ = ((u64)thi_ << 32) | tlo_;                                \
+        const u32 bpos_ = (u32)__builtin_ctzll(word_);                                                             \
+        const u64 bit_ = 1ull << bpos_;                                                                            \
+        if (__builtin_expect((tw_ & bit_) != 0, 0)) generic = true; /* committed to in this window: F may be stale */ \
+        else {                                                                                                     \
+            n = (((u32)l_ + 64u * kk) << 6) + bpos_;                                                               \
+            D[kk] |= (lane == (u32)l_) ? bit_ : 0ull;                                                              \
+            if (!ISB) --la_count;                                                                                  \
+            placed = true;                                                                                         \
+        }                                                                                                          \
+    }
+        if (__builtin_expect(!generic, 1)) {
+            if (anya != 0) {
+            if (K == 1 || ba[0] != 0) { R3_TAKE(0, false, ba[0], ca[0]) }
+            else if constexpr (K > 1) {
+                if (K == 2 || ba[1] != 0) { R3_TAKE(1, false, ba[1], ca[1]) }
+                else if constexpr (K > 2) {
+                    if (K == 3 || ba[2] != 0) { R3_TAKE(2, false, ba[2], ca[2]) }
+                    else if constexpr (K > 3) {
+                        if (K == 4 || ba[3] != 0) { R3_TAKE(3, false, ba[3], ca[3]) }
+                        else if constexpr (K > 4) {
+                            if (K == 5 || ba[4] != 0) { R3_TAKE(4, false, ba[4], ca[4]) }
+                            else if constexpr (K > 5) {
+                                if (K == 6 || ba[5] != 0) { R3_TAKE(5, false, ba[5], ca[5]) }
+                                else if constexpr (K > 6) {
+                                    if (K == 7 || ba[6] != 0) { R3_TAKE(6, false, ba[6], ca[6]) }
+                                    else if constexpr (K > 7) {
+                                        if (K == 8 || ba[7] != 0) { R3_TAKE(7, false, ba[7], ca[7]) }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            } else {
+                u64 cb[K], bb[K];
+                u64 anyb = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    cb[k] = mk[k] & (LB0[k] ^ D[k]);
+                    bb[k] = ballot64(cb[k] != 0);
+                    anyb |= bb[k];
+                }
+                if (anyb == 0) generic = true;
+                else {
+                    if (K == 1 || bb[0] != 0) { R3_TAKE(0, true, bb[0], cb[0]) }
+                    else if constexpr (K > 1) {
+                        if (K == 2 || bb[1] != 0) { R3_TAKE(1, true, bb[1], cb[1]) }
+                        else if constexpr (K > 2) {
+                            if (K == 3 || bb[2] != 0) { R3_TAKE(2, true, bb[2], cb[2]) }
+                            else if constexpr (K > 3) {
+                                if (K == 4 || bb[3] != 0) { R3_TAKE(3, true, bb[3], cb[3]) }
+                                else if constexpr (K > 4) {
+                                    if (K == 5 || bb[4] != 0) { R3_TAKE(4, true, bb[4], cb[4]) }
+                                    else if constexpr (K > 5) {
+                                        if (K == 6 || bb[5] != 0) { R3_TAKE(5, true, bb[5], cb[5]) }
+                                        else if constexpr (K > 6) {
+                                            if (K == 7 || bb[6] != 0) { R3_TAKE(6, true, bb[6], cb[6]) }
+                                            else if constexpr (K > 7) {
+                                                if (K == 8 || bb[7] != 0) { R3_TAKE(7, true, bb[7], cb[7]) }
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    // picks come from h+1: once level h is exhausted for everybody, advance the hot level
+                    if (__builtin_expect(placed && la_count == 0 && h + 3u <= (1u << NB) - 1u, 0)) {
+                        fold();
+                        derive_masks(h + 1);
+                    }
+                }
+            }
+        }
+#undef R3_TAKE
+        R2_TICK(2);
+
+        bool recorded = false;   // the generic path records its own commit
+        if (__builtin_expect(!placed && generic, 0)) {
+            // ---------------- generic path: every feature, full bit-sliced search on exact planes ----------------
+            ++st_generic;
+            // staged rows of this task again (the read-ahead has overwritten the registers): the exception list can
+            // only matter if a feasible node is an exception node of the service (list nodes ⊆ X) or a commit of
+            // the service is still in flight
+            bool anym = false, anyfx = false;
+            {
+                const ulonglong2* row = FX + (size_t)((bdone & 1u) * TB + tin) * RS + lane;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const ulonglong2 v = row[64 * k];
+                    anym = anym || (mk[k] != 0);
+                    anyfx = anyfx || ((v.x & v.y) != 0);
+                }
+            }
+            const bool listp = ballot64(anyfx) != 0 || ballot64(rg_svc == rsvc) != 0;
+            if (ballot64(anym) != 0 || listp) {
+                const R2Rec rec = Tb[(bdone & 1u) * TB + tin];
+                const i64 rcpu = rec.cpu, rmem = rec.mem;
+                const u32 rpset = rec.pset;
+                const u32 gj = a.j0 + j;
+                fold();
+                flush();   // the re-checks below read cpu/mem/total/lists: bring them up to date
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                u32 lvl = 0, w = 0, ko = 0;
+                u64 bit = 0;
+                bool owner = false, via_list = false;
+                u32 entry = 0;
+                u64 gk[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) gk[k] = mk[k];
+                for (;;) {
+                    u32 g = search(gk);
+                    if (g == 0xFFFFFFFFu) break;
+                    n = g & idx_mask;
+                    lvl = g >> idx_bits;
+                    w = n >> 6;
+                    ko = w >> 6;
+                    bit = 1ull << (n & 63);
+                    owner = (w & 63) == lane;
+                    u64 tsel = 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? T0[k] : tsel;
+                    bool ok = true;
+                    if (ballot64(owner && (tsel & bit)) != 0) {
+                        if (rflags & RT_RES) {
+                            i64 c = __hip_atomic_load(&a.cpu[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            i64 m = __hip_atomic_load(&a.mem[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = (rcpu <= c) && (rmem <= m);
+                        }
+                        if (ok && (rflags & RT_PORTS)) {
+                            for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
+                                if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) ok = false;
+                        }
+                    }
+                    if (ok) { placed = true; break; }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) gk[k] &= ~((owner && (u32)k == ko) ? bit : 0ull);
+                    ++st_retries;
+                }
+                if (!placed && listp) {
+                    // exception list of the service: nodes with svcCount>0 or ≥5 recent failures
+                    const u32 e0 = a.list_off[rsvc], e1 = a.list_off[rsvc + 1];
+                    const u64 maxrep = a.rt[gj].maxrep;
+                    u64 bhi = KEY_NONE, blo = KEY_NONE;
+                    u32 be = 0;
+                    for (u32 e = e0 + lane; e < e1; e += 64) {
+                        u32 nn = __hip_atomic_load(&a.list_node[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (nn == LIST_EMPTY) continue;
+                        u32 ww = nn >> 6;
+                        u64 bb2 = 1ull << (nn & 63);
+                        if (!(a.F[(size_t)j * Wn + ww] & bb2)) continue;
+                        if (rflags & RT_RES) {
+                            i64 c = __hip_atomic_load(&a.cpu[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            i64 m = __hip_atomic_load(&a.mem[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (!(rcpu <= c && rmem <= m)) continue;
+                        }
+                        if (rflags & RT_PORTS) {
+                            bool used = false;
+                            for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
+                                if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + ww], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bb2) used = true;
+                            if (used) continue;
+                        }
+                        u32 svn = __hip_atomic_load(&a.list_svc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u32 fl = __hip_atomic_load(&a.list_fail[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((rflags & RT_MAXREP) && !((u64)svn < maxrep)) continue;   // filter.go:373-375
+                        u32 fcl = fl >= MAX_FAILURES ? fl - (MAX_FAILURES - 1) : 0u;    // nodeLess, scheduler.go:708-735
+                        u32 tot = __hip_atomic_load(&a.total[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u64 hi = ((u64)fcl << 32) | svn, lo = ((u64)tot << 32) | nn;
+                        if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; be = e; }
+                    }
+                    u64 ghi = wave_min_u64(bhi);
+                    if (ghi != KEY_NONE) {
+                        u64 glo = wave_min_u64(bhi == ghi ? blo : KEY_NONE);
+                        u64 who = ballot64(bhi == ghi && blo == glo);
+                        entry = (u32)__builtin_amdgcn_readlane((int)be, __ffsll((long long)who) - 1);
+                        n = (u32)glo;
+                        lvl = (u32)(glo >> 32) - base;
+                        w = n >> 6;
+                        ko = w >> 6;
+                        bit = 1ull << (n & 63);
+                        owner = (w & 63) == lane;
+                        placed = true;
+                        via_list = true;
+                        ++st_slow;
+                    }
+                }
+                if (placed) {
+                    // generic commit: exact planes bumped in place, hot masks re-derived
+                    const bool counted = !(rflags & RT_UNCOUNTED);
+                    bool want_rebase = false;
+                    u64 xk[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        xk[k] = (owner && (u32)k == ko) ? bit : 0ull;
+                        T0[k] |= xk[k];
+                    }
+                    if (counted) {
+                        if (lvl >= (1u << NB) - 1u) want_rebase = true;
+                        else {
+                            const u32 flip = lvl ^ (lvl + 1);
+#pragma unroll
+                            for (int b = 0; b < R1_NBR; ++b) {
+                                if (flip >> b & 1u) {
+#pragma unroll
+                                    for (int k = 0; k < K; ++k) pl[b][k] ^= xk[k];
+                                }
+                            }
+                        }
+                    }
+                    if (rflags & RT_PORTS) {
+                        if (owner)
+                            for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p) atomicOr(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], bit);
+                    }
+                    {
+                        const bool me = lane == (ncommit & 63u);
+                        rg_svc = me ? ((counted && !via_list) ? rsvc : 0xFFFFFFFFu) : rg_svc;
+                        rg_node = me ? n : rg_node;
+                        rg_meta = me ? (tin | (counted ? 0x100u : 0u) | (via_list ? 0x200u : 0u)) : rg_meta;
+                        rg_slot = me ? entry : rg_slot;
+                        ++ncommit;
+                        recorded = true;
+                    }
+                    if (want_rebase) {
+                        // the commit is applied to memory first (total[n] + 1), then the planes are rebuilt
+                        ++st_rebase;
+                        flush();
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (!build_planes()) {
+                            if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+                            fatal = true;
+                        } else derive_masks(0);
+                    } else if (counted) {
+                        // a plain pick at another level re-centres the hot level there (nodes below stay exact through BELOW)
+                        derive_masks((!via_list && lvl + 2 < (1u << NB)) ? lvl : h);
+                    }
+                }
+            }
+        }
+        R2_TICK(3);
+
+        if (__builtin_expect(placed && !recorded, 1)) {
+            // remember the fast commit: X freshness + deferred side effects (list slot comes from the task record)
+            const bool me = lane == (ncommit & 63u);
+            rg_svc = me ? rsvc : rg_svc;
+            rg_node = me ? n : rg_node;
+            rg_meta = me ? (tin | 0x100u) : rg_meta;
+            ++ncommit;
+        } else if (!placed) {
+            if (lane == 0) {
+                a.inf_task[ninf] = a.j0 + j;
+                a.inf_pos[ninf] = ncommit;
+            }
+            ++ninf;
+        }
+        R2_TICK(4);
+        if (__builtin_expect(++tin == TB || j + 1 == a.count, 0)) {
+            // block end. Everything flushed at earlier block ends has long completed: wait for it (free), so that the
+            // loader — released below — restages X rows that are exact up to the PREVIOUS block; this block's and the
+            // next two blocks' commits (≤ 3*TB ≤ 48) are covered by the 64-entry ring. Then fire this block's side effects.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flush();
+            __hip_atomic_store(&flags_lds[2], ++bdone, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tin = 0;
+            if (j + 1 < a.count) {
+                wait_block(bdone);
+                if (!fatal) read_slot((bdone & 1u) * TB);
+            }
+            R2_TICK(5);
+        }
+    }
+    if (fatal) __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    flush();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (u32 n2 = lane; n2 < a.n_nodes; n2 += 64) a.last[n2] = last_lds[n2];
+    if (lane == 0) {
+        a.ctl->ncommit = ncommit;
+        a.ctl->ninf = ninf;
+        a.ctl->verify_retries += st_retries;
+        a.ctl->slow_tasks += st_slow;
+        a.ctl->rebases += st_rebase;
+        a.ctl->generic_tasks += st_generic;
+        a.ctl->spin_waits += st_spins;
+        if (PROF) { cyc[6] = clock64() - c_start; cyc[7] = wall_clock64() - w_start; }
         for (int q = 0; q < 8; ++q) a.ctl->cyc[q] += cyc[q];
     }
 }

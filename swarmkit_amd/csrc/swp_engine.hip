@@ -585,6 +585,22 @@ hipError_t launch_resolve2(const ResolveArgs& ra, size_t lds, hipStream_t s) {
     return (ra.dbg & 16u) ? launch_resolve2p<K, true>(ra, lds, s) : launch_resolve2p<K, false>(ra, lds, s);
 }
 
+template <int K, bool PROF>
+hipError_t launch_resolve3p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve3<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (r != hipSuccess) return r;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(128), lds, s, ra);
+    return hipGetLastError();
+}
+template <int K>
+hipError_t launch_resolve3(const ResolveArgs& ra, size_t lds, hipStream_t s) {
+    return (ra.dbg & 16u) ? launch_resolve3p<K, true>(ra, lds, s) : launch_resolve3p<K, false>(ra, lds, s);
+}
+
 template <int K>
 hipError_t launch_resolve(const ResolveArgs& ra, uint32_t threads, size_t lds, hipStream_t s) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -659,9 +675,21 @@ int batch_run(swp_engine* e, swp_batch* b) {
     size_t lds = fixed + (size_t)nb_alloc * Wn * 8;
 
     // resolver variant: 2 = two-wave LDS-staged (default when it fits), 1 = one wave + register ring, 0 = one workgroup
-    int variant = getenv("SWP_RESOLVER") ? atoi(getenv("SWP_RESOLVER")) : 2;
+    int variant = getenv("SWP_RESOLVER") ? atoi(getenv("SWP_RESOLVER")) : 3;
     uint32_t r2_tb = 0;
     size_t r2_lds = 0;
+    if (variant == 3) {
+        // k_resolve3: rows padded to 64*K words, {F,X} interleaved, 2*TB+1 staged slots
+        const uint32_t K3 = (Wn + 63) / 64;
+        const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
+        const size_t per_slot = (size_t)K3 * 64 * 16 + 32;
+        const size_t avail = lds_budget > off_f + 64 ? lds_budget - off_f - 64 : 0;
+        const size_t slots = avail / per_slot;
+        if (K3 <= 8 && slots >= 2 * 4 + 1) {
+            r2_tb = (uint32_t)std::min<size_t>(R2_TB_MAX, (slots - 1) / 2);
+            r2_lds = off_f + (size_t)(2 * r2_tb + 1) * per_slot + 64;
+        } else variant = 2;
+    }
     if (variant == 2) {
         const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
         const size_t fixed2 = off_f + 2 * R2_TB_MAX * 32 + 64;
@@ -732,7 +760,18 @@ int batch_run(swp_engine* e, swp_batch* b) {
         ra.ctl = b->d_ctl.as<Ctl>();
         hipError_t r;
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
-        if (variant == 2) {
+        if (variant == 3) {
+            switch ((Wn + 63) / 64) {
+            case 1: r = launch_resolve3<1>(ra, r2_lds, st); break;
+            case 2: r = launch_resolve3<2>(ra, r2_lds, st); break;
+            case 3: r = launch_resolve3<3>(ra, r2_lds, st); break;
+            case 4: r = launch_resolve3<4>(ra, r2_lds, st); break;
+            case 5: r = launch_resolve3<5>(ra, r2_lds, st); break;
+            case 6: r = launch_resolve3<6>(ra, r2_lds, st); break;
+            case 7: r = launch_resolve3<7>(ra, r2_lds, st); break;
+            default: r = launch_resolve3<8>(ra, r2_lds, st); break;
+            }
+        } else if (variant == 2) {
             const uint32_t K2 = (Wn + 63) / 64;
             switch (K2) {
             case 1: r = launch_resolve2<1>(ra, r2_lds, st); break;
