@@ -1724,6 +1724,17 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
     }
 }
 
+// three-input bit operations on 64-bit words as two v_bitop3_b32 (gfx950); imm bit index = a*4 + b*2 + c
+template <int IMM>
+__device__ __forceinline__ u64 bitop3_u64(u64 a, u64 b, u64 c) {
+    const u32 lo = (u32)__builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, IMM);
+    const u32 hi = (u32)__builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), IMM);
+    return ((u64)hi << 32) | lo;
+}
+#define BITOP_A_AND_B_ANDN_C 0x40   // a & b & ~c
+#define BITOP_A_AND_BXORC 0x60      // a & (b ^ c)
+#define BITOP_AB_OR_C 0xEA          // (a & b) | c
+
 // ---------------------------------------------------------------------------------------------
 // k_resolve3 — k_resolve2's two-wave scheme with the resolver's common case cut down to the instructions
 // the algorithm needs (a lone wave issues ~1 instruction per 4 ns, so the task rate IS the instruction count):
@@ -1778,6 +1789,8 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                 rec.svc = r->svc;
                 rec.slot = r->slot;
                 rec.pset = r->pset;
+                // bit 31 of the staged flags word: this task must take the generic path (host ports, uncounted)
+                if (rec.flags & (RT_PORTS | RT_UNCOUNTED)) rec.flags |= 0x80000000u;
                 Tb[buf * TB + lane] = rec;
             }
             for (u32 t = 0; t < nt; t += 4) {   // 4 rows = 8*K loads in flight per lane
@@ -1811,7 +1824,7 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
     }
 
     // =============================== RESOLVER ===============================
-    u32 ncommit = a.ctl->ncommit, ninf = a.ctl->ninf;
+    u32 ncommit = (u32)__builtin_amdgcn_readfirstlane((int)a.ctl->ncommit), ninf = (u32)__builtin_amdgcn_readfirstlane((int)a.ctl->ninf);
     u32 applied = ncommit;   // commits [applied, ncommit) still live only in the lane ring
     u32 st_retries = 0, st_slow = 0, st_rebase = 0, st_generic = 0, st_spins = 0;
     const u32 idx_bits = 32 - __clz((Wn * 64) | 1u);
@@ -1848,8 +1861,8 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                 }
             }
         }
-        lo = wave_min_u32(lo);
-        hi = wave_max_u32(hi);
+        lo = (u32)__builtin_amdgcn_readfirstlane((int)wave_min_u32(lo));
+        hi = (u32)__builtin_amdgcn_readfirstlane((int)wave_max_u32(hi));
         if (lo == 0xFFFFFFFFu) { lo = 0; hi = 0; }
         u32 need = 32 - __clz((hi - lo) | 1u);
         u32 cap = min((u32)R1_NBR, 32u - idx_bits);
@@ -1991,7 +2004,7 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
 
     auto wait_block = [&](u32 bi) __attribute__((always_inline)) {
         u32 spins = 0;
-        while (__hip_atomic_load(&flags_lds[bi & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != bi + 1) {
+        while ((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags_lds[bi & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != bi + 1) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 26)) { fatal = true; break; }
         }
@@ -2008,17 +2021,19 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
     };
     wait_block(0);
     if (!fatal) read_slot(0);
+    u32 nslot = 1;   // staged slot of the NEXT task
     R2_TICK(0);
 
     for (u32 j = 0; j < a.count && !fatal; ++j) {
-        const u32 rflags = (u32)__builtin_amdgcn_readfirstlane((int)cr.x);
+        const u32 spec = (u32)((int)cr.x >> 31);   // all ones: generic path forced (per-lane copy of a uniform value)
         const u32 rsvc = (u32)__builtin_amdgcn_readfirstlane((int)cr.y);
         u64 mk[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) mk[k] = cfx[k].x & ~cfx[k].y;
         // next task's rows: issued now, consumed next iteration (at a block end this reads a stale/padding slot
         // that the block-end code re-reads properly)
-        read_slot((bdone & 1u) * TB + tin + 1);
+        read_slot(nslot);
+        ++nslot;
         {   // commits younger than the staged X row (the ring spans the last 64 commits ≥ 3 blocks)
             u64 match = ballot64(rg_svc == rsvc);
             while (__builtin_expect(match != 0, 0)) {
@@ -2037,17 +2052,12 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
         u64 ca[K], ba[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            sb |= mk[k] & BELOW[k];
-            ca[k] = mk[k] & LA0[k] & ~D[k];
+            sb = bitop3_u64<BITOP_AB_OR_C>(mk[k], BELOW[k], sb);
+            ca[k] = bitop3_u64<BITOP_A_AND_B_ANDN_C>(mk[k], LA0[k], D[k]);
         }
-        const u64 sp = ballot64(sb != 0);
-        u64 anya = 0;
+        bool generic = ballot64(((u32)sb | (u32)(sb >> 32) | spec) != 0) != 0;   // a candidate below h, or a forced task
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            ba[k] = ballot64(ca[k] != 0);
-            anya |= ba[k];
-        }
-        bool generic = (rflags & (RT_PORTS | RT_UNCOUNTED)) != 0 || sp != 0;
+        for (int k = 0; k < K; ++k) ba[k] = ballot64(ca[k] != 0);
         bool placed = false;
         u32 n = 0;
 
@@ -2072,35 +2082,43 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
         }                                                                                                          \
     }
         if (__builtin_expect(!generic, 1)) {
-            if (anya != 0) {
-            if (K == 1 || ba[0] != 0) { R3_TAKE(0, false, ba[0], ca[0]) }
+            bool tryb = false;
+            if (ba[0] != 0) { R3_TAKE(0, false, ba[0], ca[0]) }
             else if constexpr (K > 1) {
-                if (K == 2 || ba[1] != 0) { R3_TAKE(1, false, ba[1], ca[1]) }
+                if (ba[1] != 0) { R3_TAKE(1, false, ba[1], ca[1]) }
                 else if constexpr (K > 2) {
-                    if (K == 3 || ba[2] != 0) { R3_TAKE(2, false, ba[2], ca[2]) }
+                    if (ba[2] != 0) { R3_TAKE(2, false, ba[2], ca[2]) }
                     else if constexpr (K > 3) {
-                        if (K == 4 || ba[3] != 0) { R3_TAKE(3, false, ba[3], ca[3]) }
+                        if (ba[3] != 0) { R3_TAKE(3, false, ba[3], ca[3]) }
                         else if constexpr (K > 4) {
-                            if (K == 5 || ba[4] != 0) { R3_TAKE(4, false, ba[4], ca[4]) }
+                            if (ba[4] != 0) { R3_TAKE(4, false, ba[4], ca[4]) }
                             else if constexpr (K > 5) {
-                                if (K == 6 || ba[5] != 0) { R3_TAKE(5, false, ba[5], ca[5]) }
+                                if (ba[5] != 0) { R3_TAKE(5, false, ba[5], ca[5]) }
                                 else if constexpr (K > 6) {
-                                    if (K == 7 || ba[6] != 0) { R3_TAKE(6, false, ba[6], ca[6]) }
+                                    if (ba[6] != 0) { R3_TAKE(6, false, ba[6], ca[6]) }
                                     else if constexpr (K > 7) {
-                                        if (K == 8 || ba[7] != 0) { R3_TAKE(7, false, ba[7], ca[7]) }
+                                        if (ba[7] != 0) { R3_TAKE(7, false, ba[7], ca[7]) }
+                                        else tryb = true;
                                     }
+                                    else tryb = true;
                                 }
+                                else tryb = true;
                             }
+                            else tryb = true;
                         }
+                        else tryb = true;
                     }
+                    else tryb = true;
                 }
+                else tryb = true;
             }
-            } else {
+            else tryb = true;
+            if (tryb) {
                 u64 cb[K], bb[K];
                 u64 anyb = 0;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    cb[k] = mk[k] & (LB0[k] ^ D[k]);
+                    cb[k] = bitop3_u64<BITOP_A_AND_BXORC>(mk[k], LB0[k], D[k]);
                     bb[k] = ballot64(cb[k] != 0);
                     anyb |= bb[k];
                 }
@@ -2159,6 +2177,7 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
             const bool listp = ballot64(anyfx) != 0 || ballot64(rg_svc == rsvc) != 0;
             if (ballot64(anym) != 0 || listp) {
                 const R2Rec rec = Tb[(bdone & 1u) * TB + tin];
+                const u32 rflags = (u32)__builtin_amdgcn_readfirstlane((int)rec.flags);
                 const i64 rcpu = rec.cpu, rmem = rec.mem;
                 const u32 rpset = rec.pset;
                 const u32 gj = a.j0 + j;
@@ -2196,6 +2215,7 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                                 if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) ok = false;
                         }
                     }
+                    ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;   // uniform (same address in every lane)
                     if (ok) { placed = true; break; }
 #pragma unroll
                     for (int k = 0; k < K; ++k) gk[k] &= ~((owner && (u32)k == ko) ? bit : 0ull);
@@ -2233,12 +2253,12 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                         if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; be = e; }
                     }
                     u64 ghi = wave_min_u64(bhi);
-                    if (ghi != KEY_NONE) {
+                    if (__builtin_amdgcn_readfirstlane((int)(ghi != KEY_NONE))) {
                         u64 glo = wave_min_u64(bhi == ghi ? blo : KEY_NONE);
                         u64 who = ballot64(bhi == ghi && blo == glo);
                         entry = (u32)__builtin_amdgcn_readlane((int)be, __ffsll((long long)who) - 1);
-                        n = (u32)glo;
-                        lvl = (u32)(glo >> 32) - base;
+                        n = (u32)__builtin_amdgcn_readfirstlane((int)(u32)glo);
+                        lvl = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(glo >> 32)) - base;
                         w = n >> 6;
                         ko = w >> 6;
                         bit = 1ull << (n & 63);
@@ -2299,6 +2319,9 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                     }
                 }
             }
+            // leave no VMEM result pending into the common path: the waitcnt pass would otherwise guard the loop
+            // top with a vmcnt(0) that also drains the fire-and-forget side effects of every flush
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         }
         R2_TICK(3);
 
@@ -2327,7 +2350,9 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
             tin = 0;
             if (j + 1 < a.count) {
                 wait_block(bdone);
-                if (!fatal) read_slot((bdone & 1u) * TB);
+                nslot = (bdone & 1u) * TB;
+                if (!fatal) read_slot(nslot);
+                ++nslot;
             }
             R2_TICK(5);
         }
