@@ -638,5 +638,5 @@ def load_workload(sched, wl):
         sched.set_service(wl.service_id(k))
     per_service = np.concatenate([sched.task_desc(dict(wl.service_spec(k), ID="x", ServiceID=wl.service_id(k), DesiredState=RUNNING))
                                   for k in range(wl.S)])
-    svc_of_task = np.arange(wl.T) % wl.S
+    svc_of_task = np.array([wl.task_service(j) for j in range(wl.T)], dtype=np.int64) if getattr(wl, "order", "rr") != "rr" else np.arange(wl.T) % wl.S
     return per_service[svc_of_task]

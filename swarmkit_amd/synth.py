@@ -56,13 +56,14 @@ CONFIGS = {
 class Workload:
     """A cluster (node docs) plus one batch of pending one-off tasks (task docs)."""
 
-    def __init__(self, name="cfg3", T=None, N=None, seed=None, grouped=False):
+    def __init__(self, name="cfg3", T=None, N=None, seed=None, grouped=False, services=None, order="rr"):
         c = dict(CONFIGS[name])
         self.name = name
         self.T = int(T if T is not None else c["T"])
         self.N = int(N if N is not None else c["N"])
         self.seed = int(seed if seed is not None else 0x5EED0000 + c["cfg"])
-        self.S = c["services"] or max(1, self.T // 100)
+        self.S = int(services) if services else (c["services"] or max(1, self.T // 100))
+        self.order = order   # "rr": task j belongs to service j % S; "major": tasks of one service are consecutive
         self.features = c
         self.grouped = grouped
         self._gen_nodes()
@@ -159,6 +160,8 @@ class Workload:
 
     # ------------------------------------------------------------------ tasks
     def task_service(self, j):
+        if self.order == "major":
+            return min(j // -(-self.T // self.S), self.S - 1)
         return j % self.S
 
     def task_id(self, j):
@@ -177,4 +180,4 @@ class Workload:
 
     def describe(self):
         return {"workload": self.name, "tasks": self.T, "nodes": self.N, "services": self.S, "seed": hex(self.seed),
-                "mode": "grouped" if self.grouped else "one-off"}
+                "mode": "grouped" if self.grouped else "one-off", "order": self.order}

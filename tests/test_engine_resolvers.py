@@ -1,0 +1,64 @@
+"""GPU parity across the resolver kernels and their geometries: every variant (workgroup, one-wave, two-wave,
+two-wave specialised) and every owned-words-per-lane count K must reproduce the oracle bit for bit."""
+import os
+
+import pytest
+
+import parity_util as pu
+from swarmkit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def resolver_env():
+    old = os.environ.get("SWP_RESOLVER")
+    yield
+    if old is None:
+        os.environ.pop("SWP_RESOLVER", None)
+    else:
+        os.environ["SWP_RESOLVER"] = old
+
+
+CASES = [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg1", 500, 40, {}), ("cfg2", 3000, 50, {})]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("name,T,N,kw", CASES)
+def test_variants_agree_with_oracle(resolver_env, variant, name, T, N, kw):
+    wl = synth.Workload(name, T=T, N=N, **kw)
+    op, oe, _ = pu.oracle_run(wl)
+    os.environ["SWP_RESOLVER"] = str(variant)
+    ep, ee, *_ = pu.engine_run(wl)
+    pu.assert_same(op, oe, ep, ee)
+
+
+# node counts that land on K = 1..6 words per lane (64 nodes per word, 64 lanes), incl. word-boundary sizes
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 4096, 4100, 8200, 12400, 16500, 20500])
+def test_words_per_lane(N):
+    T = 1200 if N > 5000 else 2500
+    wl = synth.Workload("cfg3", T=T, N=N)
+    op, oe, _ = pu.oracle_run(wl)
+    ep, ee, *_ = pu.engine_run(wl)
+    pu.assert_same(op, oe, ep, ee)
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("services,order", [(1, "rr"), (2, "rr"), (3, "major"), (40, "major"), (7, "rr")])
+def test_same_service_runs(resolver_env, variant, services, order):
+    """Consecutive tasks of one service: every commit must be visible to the next task of that service although
+    its staged exception row is older (the resolver's commit ring)."""
+    wl = synth.Workload("cfg3", T=2000, N=700, services=services, order=order)
+    op, oe, _ = pu.oracle_run(wl)
+    os.environ["SWP_RESOLVER"] = str(variant)
+    ep, ee, *_ = pu.engine_run(wl)
+    pu.assert_same(op, oe, ep, ee)
+
+
+@pytest.mark.parametrize("window", [16, 17, 100])
+def test_small_windows_block_edges(window):
+    """Windows that are not a multiple of the staged block (16 tasks) and blocks with a single task."""
+    wl = synth.Workload("cfg4", T=1500, N=400)
+    op, oe, _ = pu.oracle_run(wl)
+    ep, ee, *_ = pu.engine_run(wl, window=window)
+    pu.assert_same(op, oe, ep, ee)
