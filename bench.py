@@ -69,31 +69,26 @@ def main():
     ap.add_argument("--tasks", type=int, default=None)
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--order", default="rr", choices=["rr", "major"], help="task order: round-robin over services (SURVEY 8d) or service-major")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also verify the placements against the oracle sample")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus and world_env == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from swarmkit_amd import dist as swdist
+    ranks = swdist.Ranks(backend="nccl" if world_env > 1 else None)   # nccl == RCCL on ROCm
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
 
     from swarmkit_amd import abi, host, synth
 
     # Multi-GPU (round 1): independent replicas — every rank schedules its own cluster of the same shape
     # (seed offset by rank); no data-path collective. The node-sharded scan with an RCCL exchange is the
     # next row of SURVEY.md §8e.
-    wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=None if rank == 0 else 0x5EED0000 + 1000 * rank + 3)
+    wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=ranks.replica_seed(0x5EED0000), order=args.order)
     eng = abi.Engine(device=local_rank, window=args.window, profile=True)
     sched = host.HostScheduler(engine=eng)
     t0 = time.perf_counter()
@@ -106,9 +101,8 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        ranks.barrier()
+        torch.cuda.synchronize()
 
     def step():
         eng.state_restore()
@@ -130,10 +124,7 @@ def main():
         ms_dev += st["ms_total"]
     sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = ranks.max_over_ranks(elapsed)
 
     st = eng.stats()
     K = max(args.steps, 1)
@@ -143,7 +134,7 @@ def main():
     row_b = ROW_B.get(args.workload, 48)
     alg_bytes_step = pairs * row_b + wl.T * TASK_B
     t_step = elapsed / K
-    # dominant kernel = k_resolve (sequential argmin + residual-update commit): one launch per window
+    # dominant kernel = k_resolve3 (sequential argmin + residual-update commit): one launch per window
     res_launch_ms = ms_resolve / K / max(windows, 1)
     alg_bytes_launch = alg_bytes_step / max(windows, 1)
     achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0
@@ -173,7 +164,7 @@ def main():
         "pair_evals_per_s": world * pairs / t_step,
         "placed": placed,
         "unplaceable": wl.T - placed,
-        "roofline": {"bound": "hbm", "kernel": "k_resolve", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_resolve3", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows},
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_scan": ms_scan / K, "k_resolve": ms_resolve / K,
@@ -197,8 +188,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     batch.free()
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
