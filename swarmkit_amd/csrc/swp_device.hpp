@@ -1750,28 +1750,39 @@ __device__ __forceinline__ u64 bitop3_u64(u64 a, u64 b, u64 c) {
 // Semantics (pick order, exception lists, commit log, counters) are those of k_resolve2.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool PROF>
-__global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
+__global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
     extern __shared__ unsigned char r3_lds[];
     const u32 Wn = a.n_words, XS = a.xs, TB = a.tb;
     constexpr u32 RS = K * 64;   // staged row stride in words
     int32_t* last_lds = reinterpret_cast<int32_t*>(r3_lds);                                    // [n_nodes]
     const size_t off_f = (((size_t)a.n_nodes * 4 + 15) / 16) * 16;
-    ulonglong2* FX = reinterpret_cast<ulonglong2*>(r3_lds + off_f);                            // [2*TB + 1][RS] {F, X}
-    R2Rec* Tb = reinterpret_cast<R2Rec*>(r3_lds + off_f + (size_t)(2 * TB + 1) * RS * 16);     // [2*TB + 1]
-    u32* flags_lds = reinterpret_cast<u32*>(r3_lds + off_f + (size_t)(2 * TB + 1) * RS * 16 + (size_t)(2 * TB + 1) * sizeof(R2Rec));
-    // flags_lds[0..1] = ready[buf] (block index + 1), [2] = done (blocks finished by the resolver), [3] = abort
+    u64* MK = reinterpret_cast<u64*>(r3_lds + off_f);                                          // [2*TB + 1][RS]  F & ~X
+    u64* below_lds = MK + (size_t)(2 * TB + 1) * RS;                                           // [RS] published BELOW
+    R2Rec* Tb = reinterpret_cast<R2Rec*>(below_lds + RS);                                      // [2*TB + 1]
+    u32* flags_lds = reinterpret_cast<u32*>(Tb + (2 * TB + 1));
+    // flags_lds[0..1] = ready[buf]: +1 per loader wave and staged block (block b is ready at 2*(b/2 + 1)),
+    // [2] = done (blocks finished by the resolver), [3] = abort, [4] = BELOW epoch (odd while being rewritten),
+    // [5 + 2*buf + loader] = epoch that loader's below-flags of the staged block were computed with
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 nblk = (a.count + TB - 1) / TB;
     if (a.ctl->error != ERR_NONE) return;
-    if (tid < 4) flags_lds[tid] = 0;
-    for (u32 n = tid; n < a.n_nodes; n += 128) last_lds[n] = a.last[n];
+    if (tid < 16) flags_lds[tid] = 0;
+    for (u32 n = tid; n < a.n_nodes; n += 192) last_lds[n] = a.last[n];
     __syncthreads();
 
-    if (wave == 1) {
-        // =============================== LOADER ===============================
+    if (wave != 0) {
+        // =============================== LOADERS (two waves, half a block each) ===============================
+        // Stage, one block ahead: mk = F & ~X per task (rows padded to RS words), the task record, and three
+        // per-task bits in the record's flags word so that the resolver's common case does no mask arithmetic:
+        //   bit 31  the task must take the generic path: host ports / uncounted, or a candidate BELOW the hot level
+        //   bit 30  a feasible node is an exception node of the service (F & X != 0): the exception list may matter
+        //   bit 29  host ports / uncounted alone (used when the BELOW snapshot of the block is stale)
+        const u32 lw = wave - 1;
+        const u32 half = (a.dbg & 32u) ? TB : (TB + 1) / 2;   // dbg 32: loader wave 1 stages whole blocks
+        constexpr int LB = K <= 4 ? 8 : 4;   // rows in flight per loader wave (2*K*LB loads per lane)
         for (u32 b = 0; b < nblk; ++b) {
             const u32 buf = b & 1;
-            if (b >= 2) {   // buffer is free (and every commit of blocks ≤ b-2 is visible) once block b-2 is done
+            if (b >= 2) {   // buffer is free (and every commit of blocks ≤ b-3 is visible) once block b-2 is done
                 u32 spins = 0;
                 while (__hip_atomic_load(&flags_lds[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < b - 1) {
                     if (__hip_atomic_load(&flags_lds[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
@@ -1780,24 +1791,42 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                 }
             }
             const u32 t0 = b * TB, nt = min(TB, a.count - t0);
-            if (lane < nt) {
-                const RTask* r = a.rt + a.j0 + t0 + lane;
-                R2Rec rec;
+            const u32 tb0 = min(nt, lw * half), tb1 = min(nt, (lw + 1) * half);   // this wave's tasks of the block
+            // task records first: their latency hides under the row loads
+            R2Rec rec;
+            const bool hasrec = tb0 + lane < tb1;
+            if (hasrec) {
+                const RTask* r = a.rt + a.j0 + t0 + tb0 + lane;
                 rec.cpu = r->cpu;
                 rec.mem = r->mem;
                 rec.flags = r->flags;
                 rec.svc = r->svc;
                 rec.slot = r->slot;
                 rec.pset = r->pset;
-                // bit 31 of the staged flags word: this task must take the generic path (host ports, uncounted)
-                if (rec.flags & (RT_PORTS | RT_UNCOUNTED)) rec.flags |= 0x80000000u;
-                Tb[buf * TB + lane] = rec;
             }
-            for (u32 t = 0; t < nt; t += 4) {   // 4 rows = 8*K loads in flight per lane
-                u64 f[4][K], x[4][K];
+            // BELOW snapshot under a sequence lock
+            u64 BL[K];
+            u32 ep = 0;
+            {
+                u32 spins = 0;
+                for (;;) {
+                    ep = __hip_atomic_load(&flags_lds[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!(ep & 1u)) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool ht = t + q < nt;
+                        for (int k = 0; k < K; ++k) BL[k] = __hip_atomic_load(&below_lds[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (__hip_atomic_load(&flags_lds[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == ep) break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) return;
+                }
+            }
+            u32 extra = 0;
+            for (u32 t = tb0; t < tb1; t += LB) {
+                u64 f[LB][K], x[LB][K];
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    const bool ht = t + q < tb1;
                     const u32 svc = ht ? cload(&a.rt[a.j0 + t0 + t + q].svc) : 0u;
                     const u64* fs = a.F + (size_t)(t0 + t + q) * Wn;
                     const u64* xs = a.X + (size_t)svc * XS;
@@ -1810,15 +1839,29 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (t + q < nt) {
-                        ulonglong2* dst = FX + ((size_t)buf * TB + t + q) * RS + lane;
+                for (int q = 0; q < LB; ++q) {
+                    if (t + q < tb1) {
+                        u64* dst = MK + ((size_t)buf * TB + t + q) * RS + lane;
+                        u64 sbv = 0, fxv = 0;
 #pragma unroll
-                        for (int k = 0; k < K; ++k) dst[64 * k] = make_ulonglong2(f[q][k], x[q][k]);
+                        for (int k = 0; k < K; ++k) {
+                            const u64 m = f[q][k] & ~x[q][k];
+                            dst[64 * k] = m;
+                            sbv |= m & BL[k];
+                            fxv |= f[q][k] & x[q][k];
+                        }
+                        const u32 bits = (ballot64(sbv != 0) ? 0x80000000u : 0u) | (ballot64(fxv != 0) ? 0x40000000u : 0u);
+                        extra = (tb0 + lane == t + q) ? bits : extra;
                     }
                 }
             }
-            __hip_atomic_store(&flags_lds[buf], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (hasrec) {
+                rec.flags |= extra | ((rec.flags & (RT_PORTS | RT_UNCOUNTED)) ? 0xA0000000u : 0u);
+                Tb[buf * TB + tb0 + lane] = rec;
+            }
+            if (lane == 0) flags_lds[5 + 2 * buf + lw] = ep;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // rows + record of every lane before the count
+            if (lane == 0) __hip_atomic_fetch_add(&flags_lds[buf], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // ONE increment per wave
         }
         return;
     }
@@ -1831,6 +1874,7 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
     const u32 idx_mask = (1u << idx_bits) - 1u;
     u32 NB = 1, base = 0, h = 0;
     u32 la_count = 0;    // nodes left at the hot level (scalar)
+    u32 epoch = 0;       // BELOW epoch (even), bumped by 2 at every publish
     // Exact state = (planes, LA0, LB0, T0) as of the last fold, plus D = nodes fast-committed since then:
     //   level(n) = planes(n) + [n in D];  LA = LA0 & ~D;  LB = LB0 ^ D;  touched = T0 | D.
     // A node takes at most one fast commit per window (a touched pick goes generic), so one bit per node suffices
@@ -1929,6 +1973,13 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cnt += (u32)__shfl_xor((int)cnt, off, 64);
         la_count = (u32)__builtin_amdgcn_readfirstlane((int)cnt);
+        // publish BELOW for the loader (sequence lock: odd epoch while the words are rewritten)
+        __hip_atomic_store(&flags_lds[4], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+        for (int k = 0; k < K; ++k) __hip_atomic_store(&below_lds[lane + 64 * k], BELOW[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        epoch += 2u;
+        __hip_atomic_store(&flags_lds[4], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto search = [&](const u64 (&mk)[K]) __attribute__((always_inline)) -> u32 {
         u64 m[K];
@@ -2004,36 +2055,37 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
 
     auto wait_block = [&](u32 bi) __attribute__((always_inline)) {
         u32 spins = 0;
-        while ((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags_lds[bi & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != bi + 1) {
+        while ((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags_lds[bi & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < 2u * ((bi >> 1) + 1u)) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 26)) { fatal = true; break; }
         }
         st_spins += spins;
     };
-    // rows + record of the task about to be processed (read one task ahead, into the same registers)
-    ulonglong2 cfx[K];
-    uint2 cr;   // {flags, svc}
+    // rows + record of the task about to be processed: read at the END of the previous iteration into the same
+    // registers the pick works on (no copies)
+    u64 mk[K];
+    uint2 cr;   // {flags word, svc}
+    u32 blk_ep = 0;   // BELOW epoch the current block's bit 31 was computed with
     auto read_slot = [&](u32 slot) __attribute__((always_inline)) {   // slot = buf*TB + task-in-block (slot 2*TB = padding)
         cr = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(&Tb[slot]) + 16);
-        const ulonglong2* row = FX + (size_t)slot * RS + lane;
+        const u64* row = MK + (size_t)slot * RS + lane;
 #pragma unroll
-        for (int k = 0; k < K; ++k) cfx[k] = row[64 * k];
+        for (int k = 0; k < K; ++k) mk[k] = row[64 * k];
     };
     wait_block(0);
     if (!fatal) read_slot(0);
+    auto block_epoch = [&](u32 bf) __attribute__((always_inline)) -> u32 {
+        const u32 e0 = (u32)__builtin_amdgcn_readfirstlane((int)flags_lds[5 + 2 * bf]);
+        const u32 e1 = (u32)__builtin_amdgcn_readfirstlane((int)flags_lds[6 + 2 * bf]);
+        return e0 == e1 ? e0 : 0xFFFFFFFFu;   // odd: never equals the (even) current epoch
+    };
+    blk_ep = block_epoch(0);
     u32 nslot = 1;   // staged slot of the NEXT task
     R2_TICK(0);
 
     for (u32 j = 0; j < a.count && !fatal; ++j) {
-        const u32 spec = (u32)((int)cr.x >> 31);   // all ones: generic path forced (per-lane copy of a uniform value)
+        const u32 flagw = cr.x;   // per-lane copy of a uniform word
         const u32 rsvc = (u32)__builtin_amdgcn_readfirstlane((int)cr.y);
-        u64 mk[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) mk[k] = cfx[k].x & ~cfx[k].y;
-        // next task's rows: issued now, consumed next iteration (at a block end this reads a stale/padding slot
-        // that the block-end code re-reads properly)
-        read_slot(nslot);
-        ++nslot;
         {   // commits younger than the staged X row (the ring spans the last 64 commits ≥ 3 blocks)
             u64 match = ballot64(rg_svc == rsvc);
             while (__builtin_expect(match != 0, 0)) {
@@ -2048,16 +2100,20 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
         R2_TICK(1);
 
         // ---------------- fast pick: lowest node at the hot level h (LA), else at h+1 (LB); nothing below h ----------------
-        u64 sb = 0;
+        bool generic;
+        if (__builtin_expect(blk_ep == epoch, 1)) generic = ballot64((int)flagw < 0) != 0;   // staged: forced or a candidate below h
+        else {
+            u64 sb = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) sb = bitop3_u64<BITOP_AB_OR_C>(mk[k], BELOW[k], sb);
+            generic = ballot64(((u32)sb | (u32)(sb >> 32) | (flagw & 0x20000000u)) != 0) != 0;
+        }
         u64 ca[K], ba[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            sb = bitop3_u64<BITOP_AB_OR_C>(mk[k], BELOW[k], sb);
             ca[k] = bitop3_u64<BITOP_A_AND_B_ANDN_C>(mk[k], LA0[k], D[k]);
+            ba[k] = ballot64(ca[k] != 0);
         }
-        bool generic = ballot64(((u32)sb | (u32)(sb >> 32) | spec) != 0) != 0;   // a candidate below h, or a forced task
-#pragma unroll
-        for (int k = 0; k < K; ++k) ba[k] = ballot64(ca[k] != 0);
         bool placed = false;
         u32 n = 0;
 
@@ -2161,20 +2217,12 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
         if (__builtin_expect(!placed && generic, 0)) {
             // ---------------- generic path: every feature, full bit-sliced search on exact planes ----------------
             ++st_generic;
-            // staged rows of this task again (the read-ahead has overwritten the registers): the exception list can
-            // only matter if a feasible node is an exception node of the service (list nodes ⊆ X) or a commit of
-            // the service is still in flight
-            bool anym = false, anyfx = false;
-            {
-                const ulonglong2* row = FX + (size_t)((bdone & 1u) * TB + tin) * RS + lane;
+            // the exception list can only matter if a feasible node is an exception node of the service (list nodes ⊆ X:
+            // staged bit 30) or a commit of the service is still in flight
+            bool anym = false;
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const ulonglong2 v = row[64 * k];
-                    anym = anym || (mk[k] != 0);
-                    anyfx = anyfx || ((v.x & v.y) != 0);
-                }
-            }
-            const bool listp = ballot64(anyfx) != 0 || ballot64(rg_svc == rsvc) != 0;
+            for (int k = 0; k < K; ++k) anym = anym || (mk[k] != 0);
+            const bool listp = ballot64((flagw & 0x40000000u) != 0) != 0 || ballot64(rg_svc == rsvc) != 0;
             if (ballot64(anym) != 0 || listp) {
                 const R2Rec rec = Tb[(bdone & 1u) * TB + tin];
                 const u32 rflags = (u32)__builtin_amdgcn_readfirstlane((int)rec.flags);
@@ -2340,6 +2388,9 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
             ++ninf;
         }
         R2_TICK(4);
+        // next task's rows and record (at a block end this reads a stale/padding slot that the block-end code re-reads)
+        read_slot(nslot);
+        ++nslot;
         if (__builtin_expect(++tin == TB || j + 1 == a.count, 0)) {
             // block end. Everything flushed at earlier block ends has long completed: wait for it (free), so that the
             // loader — released below — restages X rows that are exact up to the PREVIOUS block; this block's and the
@@ -2353,6 +2404,7 @@ __global__ __launch_bounds__(128) void k_resolve3(ResolveArgs a) {
                 nslot = (bdone & 1u) * TB;
                 if (!fatal) read_slot(nslot);
                 ++nslot;
+                blk_ep = block_epoch(bdone & 1u);
             }
             R2_TICK(5);
         }

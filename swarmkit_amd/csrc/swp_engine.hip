@@ -593,7 +593,7 @@ hipError_t launch_resolve3p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
         if (r != hipSuccess) return r;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(128), lds, s, ra);
+    hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(192), lds, s, ra);
     return hipGetLastError();
 }
 template <int K>
@@ -679,15 +679,16 @@ int batch_run(swp_engine* e, swp_batch* b) {
     uint32_t r2_tb = 0;
     size_t r2_lds = 0;
     if (variant == 3) {
-        // k_resolve3: rows padded to 64*K words, {F,X} interleaved, 2*TB+1 staged slots
+        // k_resolve3: staged mk rows padded to 64*K words, 2*TB+1 slots (+ records), one published BELOW row, flags
         const uint32_t K3 = (Wn + 63) / 64;
         const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
-        const size_t per_slot = (size_t)K3 * 64 * 16 + 32;
-        const size_t avail = lds_budget > off_f + 64 ? lds_budget - off_f - 64 : 0;
+        const size_t per_slot = (size_t)K3 * 64 * 8 + 32;
+        const size_t fixed3 = off_f + (size_t)K3 * 64 * 8 + 128;
+        const size_t avail = lds_budget > fixed3 ? lds_budget - fixed3 : 0;
         const size_t slots = avail / per_slot;
         if (K3 <= 8 && slots >= 2 * 4 + 1) {
             r2_tb = (uint32_t)std::min<size_t>(R2_TB_MAX, (slots - 1) / 2);
-            r2_lds = off_f + (size_t)(2 * r2_tb + 1) * per_slot + 64;
+            r2_lds = fixed3 + (size_t)(2 * r2_tb + 1) * per_slot;
         } else variant = 2;
     }
     if (variant == 2) {
