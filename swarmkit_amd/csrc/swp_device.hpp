@@ -1758,7 +1758,8 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
     const size_t off_f = (((size_t)a.n_nodes * 4 + 15) / 16) * 16;
     u64* MK = reinterpret_cast<u64*>(r3_lds + off_f);                                          // [2*TB + 1][RS]  F & ~X
     u64* below_lds = MK + (size_t)(2 * TB + 1) * RS;                                           // [RS] published BELOW
-    R2Rec* Tb = reinterpret_cast<R2Rec*>(below_lds + RS);                                      // [2*TB + 1]
+    u64* xfix_lds = below_lds + RS;                                                            // [RS] scratch, all zero between uses
+    R2Rec* Tb = reinterpret_cast<R2Rec*>(xfix_lds + RS);                                       // [2*TB + 1]
     u32* flags_lds = reinterpret_cast<u32*>(Tb + (2 * TB + 1));
     // flags_lds[0..1] = ready[buf]: +1 per loader wave and staged block (block b is ready at 2*(b/2 + 1)),
     // [2] = done (blocks finished by the resolver), [3] = abort, [4] = BELOW epoch (odd while being rewritten),
@@ -1768,6 +1769,7 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
     if (a.ctl->error != ERR_NONE) return;
     if (tid < 16) flags_lds[tid] = 0;
     for (u32 n = tid; n < a.n_nodes; n += 192) last_lds[n] = a.last[n];
+    for (u32 w = tid; w < RS; w += 192) xfix_lds[w] = 0;
     __syncthreads();
 
     if (wave != 0) {
@@ -2086,15 +2088,18 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
     for (u32 j = 0; j < a.count && !fatal; ++j) {
         const u32 flagw = cr.x;   // per-lane copy of a uniform word
         const u32 rsvc = (u32)__builtin_amdgcn_readfirstlane((int)cr.y);
-        {   // commits younger than the staged X row (the ring spans the last 64 commits ≥ 3 blocks)
-            u64 match = ballot64(rg_svc == rsvc);
-            while (__builtin_expect(match != 0, 0)) {
-                const int e = __ffsll((long long)match) - 1;
-                match &= match - 1;
-                const u32 nn = (u32)__builtin_amdgcn_readlane((int)rg_node, e);
-                const u32 ww = nn >> 6;
+        {   // commits younger than the staged X row (the ring spans the last 64 commits ≥ 3 blocks): every matching
+            // ring lane ORs its node's bit into a zeroed LDS row, all lanes subtract their words, the row is zeroed
+            // again — constant cost however many commits match (service-major task order: all of them)
+            const bool hit = rg_svc == rsvc;
+            if (__builtin_expect(ballot64(hit) != 0, 0)) {
+                u64* cell = xfix_lds + (rg_node >> 6);
+                if (hit) __hip_atomic_fetch_or(cell, 1ull << (rg_node & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // one wave: LDS executes in issue order
 #pragma unroll
-                for (int k = 0; k < K; ++k) mk[k] &= ~((lane + 64u * k == ww) ? (1ull << (nn & 63)) : 0ull);
+                for (int k = 0; k < K; ++k) mk[k] &= ~__hip_atomic_load(&xfix_lds[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                if (hit) __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         R2_TICK(1);

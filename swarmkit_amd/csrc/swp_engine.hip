@@ -683,7 +683,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         const uint32_t K3 = (Wn + 63) / 64;
         const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
         const size_t per_slot = (size_t)K3 * 64 * 8 + 32;
-        const size_t fixed3 = off_f + (size_t)K3 * 64 * 8 + 128;
+        const size_t fixed3 = off_f + (size_t)2 * K3 * 64 * 8 + 128;   // + published BELOW row, ring-fix scratch row, flags
         const size_t avail = lds_budget > fixed3 ? lds_budget - fixed3 : 0;
         const size_t slots = avail / per_slot;
         if (K3 <= 8 && slots >= 2 * 4 + 1) {
