@@ -2459,59 +2459,159 @@ struct ExplainArgs {
     const int32_t* log_prev;
     const int32_t* last;
     u32* hist;   // [T][8]
+    // per-node commit segments, ascending commit index, with suffix sums of the reservations (k_chain_segments)
+    const u32* seg_off;   // [n_nodes]
+    const u32* seg_len;   // [n_nodes]
+    const u32* ent_ci;    // [ncommit]
+    const i64* ent_scpu;  // [ncommit] sum of cpu over this entry and every later one of the node
+    const i64* ent_smem;
 };
 
+// One thread per node: the node's chain of commits (arbitrary order) → a contiguous segment sorted by commit index
+// with suffix sums, so that the explain pass finds "residuals at the task's moment" with a short contiguous scan
+// instead of three dependent loads per chain step.
+struct SegArgs {
+    u32 n_nodes;
+    const RTask* rt;
+    const u32* log_task;
+    const int32_t* log_prev;
+    const int32_t* last;
+    u32* alloc;   // one counter
+    u32* seg_off;
+    u32* seg_len;
+    u32* ent_ci;
+    i64* ent_scpu;
+    i64* ent_smem;
+};
+__global__ __launch_bounds__(256) void k_chain_segments(SegArgs a) {
+    const u32 n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.n_nodes) return;
+    u32 len = 0;
+    for (int32_t ci = a.last[n]; ci >= 0; ci = a.log_prev[ci]) ++len;
+    const u32 off = len ? atomicAdd(a.alloc, len) : 0u;
+    a.seg_off[n] = off;
+    a.seg_len[n] = len;
+    if (!len) return;
+    // insertion sort by commit index while copying (chains are short and nearly descending already)
+    u32 k = 0;
+    for (int32_t ci = a.last[n]; ci >= 0; ci = a.log_prev[ci], ++k) {
+        const RTask* tk = a.rt + a.log_task[ci];
+        const i64 tc = tk->cpu, tm = tk->mem;
+        u32 p = k;
+        while (p > 0 && a.ent_ci[off + p - 1] > (u32)ci) {
+            a.ent_ci[off + p] = a.ent_ci[off + p - 1];
+            a.ent_scpu[off + p] = a.ent_scpu[off + p - 1];
+            a.ent_smem[off + p] = a.ent_smem[off + p - 1];
+            --p;
+        }
+        a.ent_ci[off + p] = (u32)ci;
+        a.ent_scpu[off + p] = tc;
+        a.ent_smem[off + p] = tm;
+    }
+    i64 sc = 0, sm = 0;
+    for (u32 p = len; p-- > 0;) {
+        sc += a.ent_scpu[off + p];
+        sm += a.ent_smem[off + p];
+        a.ent_scpu[off + p] = sc;
+        a.ent_smem[off + p] = sm;
+    }
+}
+
+#define EX_TCH 32   // unplaceable tasks per block: the node row is loaded once and stays in registers
 __global__ __launch_bounds__(256) void k_explain(ExplainArgs a) {
-    u32 e = blockIdx.y;
-    u32 n = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 gj = cload(a.inf_task + e);
-    int32_t pos = (int32_t)cload(a.inf_pos + e);
-    const RTask rt = a.rt[gj];
-    u32 w = n >> 6;
-    u64 bit = 1ull << (n & 63);
-    bool present = n < a.n_nodes && (a.valid[w] & bit);
-    int ff = -1;
-    if (present) {
-        i64 c = a.cpu[n], m = a.mem[n];
-        u32 svc_later = 0;
-        u32 port_later = 0;   // bit q: the q-th port of this task's set was taken on n by a LATER commit
-        u32 pp0 = 0, pp1 = 0;
-        if (rt.flags & RT_PORTS) { pp0 = a.pset_off[rt.pset]; pp1 = a.pset_off[rt.pset + 1]; }
-        for (int32_t ci = a.last[n]; ci >= 0; ci = a.log_prev[ci]) {   // chain order is arbitrary: filter, don't stop early
-            if (ci < pos) continue;
-            const RTask* tk = a.rt + a.log_task[ci];
-            c += tk->cpu;
-            m += tk->mem;
-            if (tk->svc == rt.svc && !(tk->flags & RT_UNCOUNTED)) ++svc_later;
-            if ((rt.flags & RT_PORTS) && (tk->flags & RT_PORTS)) {
-                for (u32 q = pp0; q < pp1 && q - pp0 < 32; ++q)
-                    for (u32 z = a.pset_off[tk->pset]; z < a.pset_off[tk->pset + 1]; ++z)
-                        if (a.pset_ids[z] == a.pset_ids[q]) port_later |= 1u << (q - pp0);
+    const u32 e0 = blockIdx.y * EX_TCH, e1 = min(a.n_inf, e0 + EX_TCH);
+    const u32 n = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 w = n >> 6;   // one word per wave
+    const u64 bit = 1ull << (n & 63);
+    const bool inw = w < a.n_words;
+    const bool present = n < a.n_nodes && inw && (cload(a.valid + (inw ? w : 0)) & bit);
+    const bool is_ready = inw && (cload(a.ready + (inw ? w : 0)) & bit);
+    const i64 c_end = present ? a.cpu[n] : 0, m_end = present ? a.mem[n] : 0;   // end-of-batch residuals
+    __shared__ u32 cnt[EX_TCH][8];
+    for (u32 q = threadIdx.x; q < EX_TCH * 8; q += blockDim.x) (&cnt[0][0])[q] = 0;
+    __syncthreads();
+    for (u32 e = e0; e < e1; ++e) {
+        const u32 gj = cload(a.inf_task + e);
+        const int32_t pos = (int32_t)cload(a.inf_pos + e);
+        const RTask* rp = a.rt + gj;
+        const u32 rflags = cload(&rp->flags), rsvc = cload(&rp->svc), rpset = cload(&rp->pset);
+        const u32 cls_con = cload(&rp->cls_con), cls_plat = cload(&rp->cls_plat), cls_plug = cload(&rp->cls_plug);
+        const i64 rcpu = cload(&rp->cpu), rmem = cload(&rp->mem);
+        const u64 rmaxrep = cload(&rp->maxrep);
+        int ff = -1;
+        if (present) {
+            // state of node n at the task's moment = end-of-batch state minus the commits with index >= pos; the chain
+            // is only walked when a filter's verdict can depend on those commits (resources only shrink inside a
+            // batch: a node that still fits at the end fitted at the task's moment)
+            i64 c = c_end, m = m_end;
+            u32 svc_later = 0;
+            u32 port_later = 0;   // bit q: the q-th port of this task's set was taken on n by a LATER commit
+            u32 pp0 = 0, pp1 = 0;
+            if (rflags & RT_PORTS) { pp0 = a.pset_off[rpset]; pp1 = a.pset_off[rpset + 1]; }
+            bool walked = false;
+            auto walk = [&]() {
+                if (walked) return;
+                walked = true;
+                for (int32_t ci = a.last[n]; ci >= 0; ci = a.log_prev[ci]) {   // chain order is arbitrary: filter, don't stop early
+                    if (ci < pos) continue;
+                    const RTask* tk = a.rt + a.log_task[ci];
+                    c += tk->cpu;
+                    m += tk->mem;
+                    if (tk->svc == rsvc && !(tk->flags & RT_UNCOUNTED)) ++svc_later;
+                    if ((rflags & RT_PORTS) && (tk->flags & RT_PORTS)) {
+                        for (u32 q = pp0; q < pp1 && q - pp0 < 32; ++q)
+                            for (u32 z = a.pset_off[tk->pset]; z < a.pset_off[tk->pset + 1]; ++z)
+                                if (a.pset_ids[z] == a.pset_ids[q]) port_later |= 1u << (q - pp0);
+                    }
+                }
+            };
+            bool res_fail = false;
+            if ((rflags & RT_RES) && is_ready && !(rcpu <= c_end && rmem <= m_end)) {
+                // residuals at the task's moment = end state + reservations of the node's commits with index >= pos
+                const u32 off = a.seg_off[n], len = a.seg_len[n];
+                u32 p = 0;
+                while (p < len && a.ent_ci[off + p] < (u32)pos) ++p;
+                const i64 cc = c_end + (p < len ? a.ent_scpu[off + p] : 0), mm = m_end + (p < len ? a.ent_smem[off + p] : 0);
+                res_fail = !(rcpu <= cc && rmem <= mm);
+            }
+            if (!is_ready) ff = 0;
+            else if (res_fail) ff = 1;
+            else if (cls_plug && !(cload(a.plug + (size_t)cls_plug * a.n_words + w) & bit)) ff = 2;
+            else if (cls_con && !(cload(a.con + (size_t)cls_con * a.n_words + w) & bit)) ff = 3;
+            else if (cls_plat && !(cload(a.plat + (size_t)cls_plat * a.n_words + w) & bit)) ff = 4;
+            else {
+                bool port_busy = false;
+                if (rflags & RT_PORTS) {
+                    bool any = false;
+                    for (u32 q = pp0; q < pp1; ++q) any = any || (a.portmap[(size_t)a.pset_ids[q] * a.n_words + w] & bit);
+                    if (any) {
+                        walk();
+                        for (u32 q = pp0; q < pp1; ++q)
+                            if ((a.portmap[(size_t)a.pset_ids[q] * a.n_words + w] & bit) && !((q - pp0 < 32) && (port_later >> (q - pp0) & 1u))) port_busy = true;
+                    }
+                }
+                if (port_busy) ff = 5;
+                else if (rflags & RT_MAXREP) {
+                    u32 sv = 0;
+                    for (u32 z = a.list_off[rsvc]; z < a.list_off[rsvc + 1]; ++z)
+                        if (a.list_node[z] == n) { sv = a.list_svc[z]; break; }
+                    if (!((u64)sv < rmaxrep)) {   // fails at the end of the batch: it may have passed at the task's moment
+                        walk();
+                        u32 at = sv - svc_later;
+                        if (!((u64)at < rmaxrep)) ff = 6;
+                    }
+                }
             }
         }
-        if (!(a.ready[w] & bit)) ff = 0;
-        else if ((rt.flags & RT_RES) && !(rt.cpu <= c && rt.mem <= m)) ff = 1;
-        else if (rt.cls_plug && !(a.plug[(size_t)rt.cls_plug * a.n_words + w] & bit)) ff = 2;
-        else if (rt.cls_con && !(a.con[(size_t)rt.cls_con * a.n_words + w] & bit)) ff = 3;
-        else if (rt.cls_plat && !(a.plat[(size_t)rt.cls_plat * a.n_words + w] & bit)) ff = 4;
-        else {
-            bool port_busy = false;
-            if (rt.flags & RT_PORTS)
-                for (u32 q = pp0; q < pp1; ++q)
-                    if ((a.portmap[(size_t)a.pset_ids[q] * a.n_words + w] & bit) && !((q - pp0 < 32) && (port_later >> (q - pp0) & 1u))) port_busy = true;
-            if (port_busy) ff = 5;
-            else if (rt.flags & RT_MAXREP) {
-                u32 sv = 0;
-                for (u32 z = a.list_off[rt.svc]; z < a.list_off[rt.svc + 1]; ++z)
-                    if (a.list_node[z] == n) { sv = a.list_svc[z]; break; }
-                u32 at = sv - svc_later;
-                if (!((u64)at < rt.maxrep)) ff = 6;
-            }
+        for (int f = 0; f < 7; ++f) {
+            u64 bm = ballot64(ff == f);
+            if (bm && (threadIdx.x & 63) == 0) atomicAdd(&cnt[e - e0][f], (u32)__popcll(bm));
         }
     }
-    for (int f = 0; f < 7; ++f) {
-        u64 bm = ballot64(ff == f);
-        if (bm && (threadIdx.x & 63) == 0) atomicAdd(&a.hist[(size_t)gj * 8 + f], (u32)__popcll(bm));
+    __syncthreads();
+    for (u32 q = threadIdx.x; q < (e1 - e0) * 8; q += blockDim.x) {
+        const u32 v = (&cnt[0][0])[q];
+        if (v) atomicAdd(&a.hist[(size_t)cload(a.inf_task + e0 + (q >> 3)) * 8 + (q & 7)], v);
     }
 }
 

@@ -134,6 +134,7 @@ struct swp_batch {
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
     DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
     DevBuf d_con, d_plat, d_plug, d_sc, d_F, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
+    DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
 };
 
 struct swp_engine {
@@ -342,6 +343,9 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         if (d.service >= e->spaces[SWP_SPACE_SERVICE].strs.size()) return e->fail(SWP_EINVAL, "task %u: unknown service id %u", i, d.service);
         if (d.spread_set >= e->spread_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown spread set", i);
         if (d.spread_set && !weights) return e->fail(SWP_EUNSUPPORTED, "task %u has spread preferences: schedule it through swp_schedule_groups", i);
+        // the exactness argument (feasibility only shrinks inside a batch) needs non-negative reservations; the API layer
+        // rejects negative ones (manager/controlapi validateResources), a task that carries them stays on the Go path
+        if (d.cpu < 0 || d.mem < 0) return e->fail(SWP_EUNSUPPORTED, "task %u has a negative resource reservation", i);
         RTask& r = b->rt[i];
         std::memset(&r, 0, sizeof r);
         r.cpu = d.cpu;
@@ -547,6 +551,10 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     HIPCHECK(e, b->d_log_node.reserve((size_t)T * 4));
     HIPCHECK(e, b->d_log_task.reserve((size_t)T * 4));
     HIPCHECK(e, b->d_log_prev.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_ent_ci.reserve((size_t)T * 4));
+    HIPCHECK(e, b->d_ent_scpu.reserve((size_t)T * 8));
+    HIPCHECK(e, b->d_ent_smem.reserve((size_t)T * 8));
+    HIPCHECK(e, b->d_seg_alloc.reserve(64));
     HIPCHECK(e, b->d_last.reserve((size_t)std::max<uint32_t>(e->n_nodes, 1) * 4));
     HIPCHECK(e, b->d_inf_task.reserve((size_t)T * 4));
     HIPCHECK(e, b->d_inf_pos.reserve((size_t)T * 4));
@@ -832,13 +840,36 @@ int batch_run(swp_engine* e, swp_batch* b) {
         xa.log_prev = b->d_log_prev.as<int32_t>();
         xa.last = b->d_last.as<int32_t>();
         xa.hist = b->d_hist.as<uint32_t>();
+        // per-node commit segments (sorted, suffix sums) for the residual-at-the-moment lookups
+        HIPCHECK(e, b->d_seg_off.reserve((size_t)N * 4));
+        HIPCHECK(e, b->d_seg_len.reserve((size_t)N * 4));
+        HIPCHECK(e, hipMemsetAsync(b->d_seg_alloc.p, 0, 4, st));
+        SegArgs sg{};
+        sg.n_nodes = N;
+        sg.rt = b->d_rt.as<RTask>();
+        sg.log_task = b->d_log_task.as<uint32_t>();
+        sg.log_prev = b->d_log_prev.as<int32_t>();
+        sg.last = b->d_last.as<int32_t>();
+        sg.alloc = b->d_seg_alloc.as<uint32_t>();
+        sg.seg_off = b->d_seg_off.as<uint32_t>();
+        sg.seg_len = b->d_seg_len.as<uint32_t>();
+        sg.ent_ci = b->d_ent_ci.as<uint32_t>();
+        sg.ent_scpu = b->d_ent_scpu.as<long long>();
+        sg.ent_smem = b->d_ent_smem.as<long long>();
+        hipLaunchKernelGGL(k_chain_segments, dim3((N + 255) / 256), dim3(256), 0, st, sg);
+        xa.seg_off = sg.seg_off;
+        xa.seg_len = sg.seg_len;
+        xa.ent_ci = sg.ent_ci;
+        xa.ent_scpu = sg.ent_scpu;
+        xa.ent_smem = sg.ent_smem;
         uint32_t done = 0;
-        while (done < ctl.ninf) {   // grid.y ≤ 65535
-            uint32_t chunk = std::min<uint32_t>(ctl.ninf - done, 32768);
+        while (done < ctl.ninf) {   // grid.y ≤ 65535 blocks of EX_TCH tasks
+            uint32_t chunk = std::min<uint32_t>(ctl.ninf - done, 32768u * EX_TCH);
             ExplainArgs xc = xa;
             xc.inf_task += done;
             xc.inf_pos += done;
-            hipLaunchKernelGGL(k_explain, dim3((N + 255) / 256, chunk), dim3(256), 0, st, xc);
+            xc.n_inf = chunk;
+            hipLaunchKernelGGL(k_explain, dim3((N + 255) / 256, (chunk + EX_TCH - 1) / EX_TCH), dim3(256), 0, st, xc);
             done += chunk;
         }
         HIPCHECK(e, hipGetLastError());
