@@ -1750,7 +1750,7 @@ __device__ __forceinline__ u64 bitop3_u64(u64 a, u64 b, u64 c) {
 // Semantics (pick order, exception lists, commit log, counters) are those of k_resolve2.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool PROF>
-__global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
+__global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
     extern __shared__ unsigned char r3_lds[];
     const u32 Wn = a.n_words, XS = a.xs, TB = a.tb;
     constexpr u32 RS = K * 64;   // staged row stride in words
@@ -1760,17 +1760,68 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
     u64* below_lds = MK + (size_t)(2 * TB + 1) * RS;                                           // [RS] published BELOW
     u64* xfix_lds = below_lds + RS;                                                            // [RS] scratch, all zero between uses
     R2Rec* Tb = reinterpret_cast<R2Rec*>(xfix_lds + RS);                                       // [2*TB + 1]
-    u32* flags_lds = reinterpret_cast<u32*>(Tb + (2 * TB + 1));
+    uint4* dump_lds = reinterpret_cast<uint4*>(Tb + (2 * TB + 2));                             // [2][R2_TB_MAX] commits handed to the committer
+    u32* flags_lds = reinterpret_cast<u32*>(dump_lds + 2 * R2_TB_MAX);
     // flags_lds[0..1] = ready[buf]: +1 per loader wave and staged block (block b is ready at 2*(b/2 + 1)),
     // [2] = done (blocks finished by the resolver), [3] = abort, [4] = BELOW epoch (odd while being rewritten),
-    // [5 + 2*buf + loader] = epoch that loader's below-flags of the staged block were computed with
+    // [5 + 2*buf + loader] = epoch that loader's below-flags of the staged block were computed with,
+    // [9] = issued (blocks whose side effects the committer has issued), [10] = completed (… and that are visible
+    // in memory), [11 + buf] = number of commits in dump_lds[buf]
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 nblk = (a.count + TB - 1) / TB;
     if (a.ctl->error != ERR_NONE) return;
     if (tid < 16) flags_lds[tid] = 0;
-    for (u32 n = tid; n < a.n_nodes; n += 192) last_lds[n] = a.last[n];
-    for (u32 w = tid; w < RS; w += 192) xfix_lds[w] = 0;
+    for (u32 n = tid; n < a.n_nodes; n += 256) last_lds[n] = a.last[n];
+    for (u32 w = tid; w < RS; w += 256) xfix_lds[w] = 0;
     __syncthreads();
+
+    // Side effects of one commit: residual update of the node row (NodeInfo.addTask, nodeinfo.go:108-154),
+    // exception bitmap + list entry, commit log + per-node chain, placement. blk = the block the task belongs to.
+    auto apply_commit = [&](u32 n, u32 meta, u32 list_entry, u32 ce, u32 blk) __attribute__((always_inline)) {
+        const u32 tt = meta & 0xFFu;
+        const R2Rec r = Tb[(blk & 1u) * TB + tt];
+        const u32 gj = a.j0 + blk * TB + tt;
+        if (r.cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-r.cpu));
+        if (r.mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-r.mem));
+        if (meta & 0x100u) {   // counted
+            atomicAdd(a.total + n, 1u);
+            if (meta & 0x200u) atomicAdd(a.list_svc + list_entry, 1u);   // placed through the exception list
+            else {
+                atomicOr(&a.X[(size_t)r.svc * XS + (n >> 6)], 1ull << (n & 63));   // the loaders restage X rows from memory
+                a.list_node[r.slot] = n;
+                a.list_svc[r.slot] = 1;
+                a.list_fail[r.slot] = 0;
+            }
+        }
+        a.log_node[ce] = n;
+        a.log_task[ce] = gj;
+        a.log_prev[ce] = (int32_t)atomicExch(reinterpret_cast<u32*>(&last_lds[n]), ce);   // chain order is arbitrary
+        a.out_node[gj] = (int32_t)n;
+    };
+
+    if (wave == 3) {
+        // =============================== COMMITTER ===============================
+        // Applies the memory side effects of every finished block (handed over through dump_lds) so that the
+        // resolver never issues or waits for VMEM on its common path.
+        for (u32 b = 0; b < nblk; ++b) {
+            u32 spins = 0;
+            while (__hip_atomic_load(&flags_lds[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < b + 1) {
+                if (__hip_atomic_load(&flags_lds[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 26)) return;   // bounded: never hang the GPU
+            }
+            const u32 cnt = flags_lds[11 + (b & 1u)];
+            if (lane < cnt) {
+                const uint4 e = dump_lds[(b & 1u) * R2_TB_MAX + lane];
+                apply_commit(e.x, e.y, e.z, e.w, b);
+            }
+            // the dump and the task records of this block have been read: the loaders may restage the buffer
+            __hip_atomic_store(&flags_lds[9], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&flags_lds[10], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
 
     if (wave != 0) {
         // =============================== LOADERS (two waves, half a block each) ===============================
@@ -1784,9 +1835,9 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
         constexpr int LB = K <= 4 ? 8 : 4;   // rows in flight per loader wave (2*K*LB loads per lane)
         for (u32 b = 0; b < nblk; ++b) {
             const u32 buf = b & 1;
-            if (b >= 2) {   // buffer is free (and every commit of blocks ≤ b-3 is visible) once block b-2 is done
+            if (b >= 2) {   // buffer is free once the committer has read block b-2's records; commits of blocks ≤ b-3 are visible
                 u32 spins = 0;
-                while (__hip_atomic_load(&flags_lds[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < b - 1) {
+                while (__hip_atomic_load(&flags_lds[9], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < b - 1) {
                     if (__hip_atomic_load(&flags_lds[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 26)) return;   // bounded: never hang the GPU
@@ -2010,35 +2061,20 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
         return wave_min_u32_dpp(best);
     };
     u32 tin = 0, bdone = 0;   // task index inside the block, blocks finished
-    // Apply the side effects of commits [applied, ncommit) — one commit per lane: residual update of the
-    // node row (NodeInfo.addTask, nodeinfo.go:108-154), exception-list entry, commit log + per-node chain.
-    // All pending commits belong to the current block (flushed at every block end).
+    // Generic path / rebase only: memory must reflect every commit so far. The pending commits of the current block
+    // are applied here (one per lane); the finished blocks are the committer's — wait until it reports them visible.
+    bool fatal = false;
     auto flush = [&]() __attribute__((always_inline)) {
         if (ncommit != applied) {
             const u32 last_c = ncommit - 1;
             const u32 ce = last_c - ((last_c - lane) & 63u);   // this lane's newest commit index
-            if (ce >= applied && ce <= last_c) {
-                const u32 n = rg_node, tt = rg_meta & 0xFFu;
-                const R2Rec r = Tb[(bdone & 1u) * TB + tt];
-                const u32 gj = a.j0 + bdone * TB + tt;
-                if (r.cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-r.cpu));
-                if (r.mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-r.mem));
-                if (rg_meta & 0x100u) {   // counted
-                    atomicAdd(a.total + n, 1u);
-                    if (rg_meta & 0x200u) atomicAdd(a.list_svc + rg_slot, 1u);   // placed through the exception list
-                    else {
-                        atomicOr(&a.X[(size_t)r.svc * XS + (n >> 6)], 1ull << (n & 63));   // the loader restages X rows from memory
-                        a.list_node[r.slot] = n;
-                        a.list_svc[r.slot] = 1;
-                        a.list_fail[r.slot] = 0;
-                    }
-                }
-                a.log_node[ce] = n;
-                a.log_task[ce] = gj;
-                a.log_prev[ce] = (int32_t)atomicExch(reinterpret_cast<u32*>(&last_lds[n]), ce);   // chain order within a flush is arbitrary
-                a.out_node[gj] = (int32_t)n;
-            }
+            if (ce >= applied && ce <= last_c) apply_commit(rg_node, rg_meta, rg_slot, ce, bdone);
             applied = ncommit;
+        }
+        u32 spins = 0;
+        while ((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags_lds[10], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < bdone) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) { fatal = true; break; }
         }
     };
 
@@ -2050,7 +2086,6 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
         return;
     }
     derive_masks(0);
-    bool fatal = false;
     u64 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tk = PROF ? wall_clock64() : 0;
     const u64 c_start = PROF ? clock64() : 0, w_start = tk;
@@ -2371,10 +2406,11 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
                         derive_masks((!via_list && lvl + 2 < (1u << NB)) ? lvl : h);
                     }
                 }
+                // leave no VMEM result pending into the common path: the waitcnt pass would otherwise guard the loop
+                // top with a vmcnt(0) that also drains every fire-and-forget store. (Only here: the quick exit above —
+                // a task without any candidate — issues no load, and must not wait for the stores in flight.)
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             }
-            // leave no VMEM result pending into the common path: the waitcnt pass would otherwise guard the loop
-            // top with a vmcnt(0) that also drains the fire-and-forget side effects of every flush
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         }
         R2_TICK(3);
 
@@ -2397,11 +2433,26 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
         read_slot(nslot);
         ++nslot;
         if (__builtin_expect(++tin == TB || j + 1 == a.count, 0)) {
-            // block end. Everything flushed at earlier block ends has long completed: wait for it (free), so that the
-            // loader — released below — restages X rows that are exact up to the PREVIOUS block; this block's and the
-            // next two blocks' commits (≤ 3*TB ≤ 48) are covered by the 64-entry ring. Then fire this block's side effects.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            flush();
+            // block end: hand the (≤ TB) pending commits to the committer wave through LDS. No VMEM here. The dump slot
+            // was last used two blocks ago; the committer has normally long consumed it.
+            {
+                u32 spins = 0;
+                while (bdone >= 2 && (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&flags_lds[9], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < bdone - 1) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 26)) { fatal = true; break; }
+                }
+                st_spins += spins;
+            }
+            {
+                const u32 pend = ncommit - applied;
+                if (pend) {
+                    const u32 last_c = ncommit - 1;
+                    const u32 ce = last_c - ((last_c - lane) & 63u);
+                    if (ce >= applied && ce <= last_c) dump_lds[(bdone & 1u) * R2_TB_MAX + (ce - applied)] = make_uint4(rg_node, rg_meta, rg_slot, ce);
+                }
+                if (lane == 0) flags_lds[11 + (bdone & 1u)] = pend;
+                applied = ncommit;
+            }
             __hip_atomic_store(&flags_lds[2], ++bdone, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             tin = 0;
             if (j + 1 < a.count) {
@@ -2415,7 +2466,7 @@ __global__ __launch_bounds__(192) void k_resolve3(ResolveArgs a) {
         }
     }
     if (fatal) __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    flush();
+    if (!fatal) flush();   // nothing pending after the last block end; waits for the committer's last block
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     for (u32 n2 = lane; n2 < a.n_nodes; n2 += 64) a.last[n2] = last_lds[n2];
     if (lane == 0) {

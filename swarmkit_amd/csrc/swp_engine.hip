@@ -601,7 +601,7 @@ hipError_t launch_resolve3p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
         if (r != hipSuccess) return r;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(192), lds, s, ra);
+    hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(256), lds, s, ra);
     return hipGetLastError();
 }
 template <int K>
@@ -691,7 +691,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         const uint32_t K3 = (Wn + 63) / 64;
         const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
         const size_t per_slot = (size_t)K3 * 64 * 8 + 32;
-        const size_t fixed3 = off_f + (size_t)2 * K3 * 64 * 8 + 128;   // + published BELOW row, ring-fix scratch row, flags
+        const size_t fixed3 = off_f + (size_t)2 * K3 * 64 * 8 + 32 + 2 * R2_TB_MAX * 16 + 256;   // + BELOW row, ring-fix row, pad record, commit dump, flags
         const size_t avail = lds_budget > fixed3 ? lds_budget - fixed3 : 0;
         const size_t slots = avail / per_slot;
         if (K3 <= 8 && slots >= 2 * 4 + 1) {
