@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--order", default="rr", choices=["rr", "major"], help="task order: round-robin over services (SURVEY 8d) or service-major")
+    ap.add_argument("--mode", default="one-off", choices=["one-off", "grouped"],
+                    help="one-off (headline, SURVEY 8d primary mode) or grouped: S groups of T/S tasks through swp_schedule_groups (secondary mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also verify the placements against the oracle sample")
     args = ap.parse_args()
@@ -94,6 +96,31 @@ def main():
     t0 = time.perf_counter()
     descs = host.load_workload(sched, wl)
     t_host_prep = time.perf_counter() - t0
+    if args.mode == "grouped":
+        # secondary mode: every service is ONE group of T/S identical tasks -> S scans instead of T.
+        # Timed end to end around swp_schedule_groups (descriptor upload, k_groups, results back).
+        import numpy as np
+        per_service = descs[:wl.S] if wl.order == "rr" else descs[::max(wl.T // wl.S, 1)][:wl.S]
+        sizes = np.bincount(np.array([wl.task_service(j) for j in range(wl.T)]), minlength=wl.S).astype(np.uint32)
+        eng.state_save()
+        for _ in range(args.warmup):
+            eng.state_restore()
+            eng.schedule_groups(per_service, sizes)
+        torch.cuda.synchronize(); ranks.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.state_restore()
+            out, _h = eng.schedule_groups(per_service, sizes)
+        torch.cuda.synchronize(); ranks.barrier()
+        t_step = ranks.max_over_ranks(time.perf_counter() - t0) / max(args.steps, 1)
+        if rank == 0:
+            print(json.dumps({"metric": "task placements/sec, grouped mode (S groups of T/S tasks, end to end through swp_schedule_groups)",
+                              "value": world * wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+                              "data": "synthetic", "config": dict(wl.describe(), mode="grouped", groups=int(wl.S)),
+                              "pair_evals_per_s": world * wl.S * wl.N / t_step, "placed": int((out >= 0).sum())}))
+        ranks.close()
+        return
     t0 = time.perf_counter()
     batch = eng.batch_prepare(descs)
     t_prepare = time.perf_counter() - t0

@@ -1,0 +1,68 @@
+"""BASELINE-size parity on the GPU: the engine's full placement vector and every explanation string against the
+SHA-256 digests the CPU oracle produced offline (tests/golden/make_golden_full.py), plus size-independent
+properties (window independence, run-to-run determinism, feasibility of every placement)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import parity_util as pu
+from swarmkit_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_digests.json")
+
+
+def _digests(wl, out, errs):
+    idx = np.asarray(out, dtype=np.int32)
+    h1 = hashlib.sha256(idx.tobytes()).hexdigest()
+    h2 = hashlib.sha256("\n".join(f"{k}={errs[k]}" for k in sorted(errs)).encode()).hexdigest()
+    return h1, h2
+
+
+@pytest.mark.parametrize("key", ["cfg2_full", "cfg3_full", "cfg3_full_major"])
+def test_full_size_matches_oracle_digest(key):
+    doc = json.load(open(GOLD))[key]
+    wl = synth.Workload(**doc["workload"])
+    assert (wl.T, wl.N, hex(wl.seed)) == (doc["T"], doc["N"], doc["seed"])
+    ep, ee, s, out, hist = pu.engine_run(wl)
+    assert [int(v) for v in out[:16]] == doc["first16"]
+    assert int((np.asarray(out) >= 0).sum()) == doc["placed"]
+    h1, h2 = _digests(wl, out, ee)
+    assert h1 == doc["sha256_node_index_i32"]
+    assert h2 == doc["sha256_errors"]
+
+
+def test_full_size_window_independence_and_determinism():
+    wl = synth.Workload("cfg3")
+    _, e1, _, out1, _ = pu.engine_run(wl)
+    _, e2, _, out2, _ = pu.engine_run(wl, window=1024)
+    _, e3, _, out3, _ = pu.engine_run(wl)
+    assert np.array_equal(out1, out2) and e1 == e2      # the scan window (snapshot freshness) must not matter
+    assert np.array_equal(out1, out3) and e1 == e3      # run-to-run
+
+
+def test_full_size_every_placement_is_feasible():
+    """Independent of the oracle: replay the placements on the host in task order and check every filter of the
+    synthetic cfg3 spec (resources with residual update, zone/disk constraints, platform)."""
+    wl = synth.Workload("cfg3")
+    _, _, _, out, _ = pu.engine_run(wl)
+    out = np.asarray(out)
+    cpu, mem = wl.node_cpu.astype(np.int64).copy(), wl.node_mem.astype(np.int64).copy()
+    arch = np.where(np.isin(wl.node_arch, ["x86_64", "amd64"]), "amd64", "arm64")
+    for j in np.nonzero(out >= 0)[0]:
+        k, n = wl.task_service(int(j)), int(out[j])
+        assert wl.svc_cpu[k] <= cpu[n] and wl.svc_mem[k] <= mem[n], (j, n)
+        cpu[n] -= wl.svc_cpu[k]
+        mem[n] -= wl.svc_mem[k]
+        if wl.svc_zone[k] >= 0:
+            assert wl.node_zone[n] == wl.svc_zone[k]
+        if wl.svc_nohdd[k]:
+            assert wl.node_ssd[n]
+        if wl.svc_plat[k] == 1:
+            assert wl.node_os[n] == "linux" and arch[n] == "amd64"
+        elif wl.svc_plat[k] == 2:
+            assert wl.node_os[n] == "linux"
+    assert (cpu >= 0).all() and (mem >= 0).all()
