@@ -2743,30 +2743,23 @@ __device__ __forceinline__ bool g_less_vals(u32 fa, u32 sa, u32 ta, u32 fb, u32 
     return ta < tb;
 }
 
-struct GHeap {   // heap slots of the real decision tree: node state travels with the slot
-    u32 *node, *total, *svc, *fail, *placed;
+// nodeLess as ONE integer compare: key = (failures if >= 5 else 0, svcCount, total) packed 8 | 24 | 32 bits
+// (both sides below 5 failures skip the failure compare, scheduler.go:713-722; a side at >= 5 beats any side below).
+__device__ __forceinline__ u64 g_key(u32 fail, u32 svc, u32 total) {
+    const u32 fc = fail >= MAX_FAILURES ? fail : 0u;
+    return ((u64)fc << 56) | ((u64)svc << 32) | total;
+}
+__device__ __forceinline__ bool g_key_ok(u32 fail, u32 svc) { return fail < 256u && svc < (1u << 24); }
+
+struct GHeap {   // heap positions hold (key, state id); the node state itself never moves
+    u64* key;
+    u32* pay;
+    u32 *node, *total, *svc, *fail, *placed;   // state, indexed by state id
     i64 *cpu, *mem;
-    __device__ __forceinline__ bool less(u32 a, u32 b) const { return g_less_vals(fail[a], svc[a], total[a], fail[b], svc[b], total[b]); }
+    __device__ __forceinline__ bool less(u32 a, u32 b) const { return key[a] < key[b]; }
     __device__ __forceinline__ void swap(u32 a, u32 b) {
-        u32 t;
-        t = node[a]; node[a] = node[b]; node[b] = t;
-        t = total[a]; total[a] = total[b]; total[b] = t;
-        t = svc[a]; svc[a] = svc[b]; svc[b] = t;
-        t = fail[a]; fail[a] = fail[b]; fail[b] = t;
-        t = placed[a]; placed[a] = placed[b]; placed[b] = t;
-        i64 x;
-        x = cpu[a]; cpu[a] = cpu[b]; cpu[b] = x;
-        x = mem[a]; mem[a] = mem[b]; mem[b] = x;
-    }
-};
-struct GHeap2 {  // replay heap: keys only
-    u32 *total, *svc, *fail;
-    __device__ __forceinline__ bool less(u32 a, u32 b) const { return g_less_vals(fail[a], svc[a], total[a], fail[b], svc[b], total[b]); }
-    __device__ __forceinline__ void swap(u32 a, u32 b) {
-        u32 t;
-        t = total[a]; total[a] = total[b]; total[b] = t;
-        t = svc[a]; svc[a] = svc[b]; svc[b] = t;
-        t = fail[a]; fail[a] = fail[b]; fail[b] = t;
+        const u64 k = key[a]; key[a] = key[b]; key[b] = k;
+        const u32 t = pay[a]; pay[a] = pay[b]; pay[b] = t;
     }
 };
 // container/heap (go stdlib) over nodeMaxHeap: Less(i,j) = lessFunc(nodes[j], nodes[i]) (nodeheap.go:17-20)
@@ -2793,63 +2786,68 @@ template <class HP> __device__ inline bool g_down(HP& h, u32 base, int i0, int n
     return i > i0;
 }
 
-__global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
+#define G_THREADS 1024   // one workgroup; every N-long loop strides by it
+__global__ __launch_bounds__(G_THREADS) void k_groups(GroupArgs a) {
     extern __shared__ unsigned char g_lds[];
     GHeap H;
-    GHeap2 H2;
     unsigned char* p = g_lds;
+    H.key = reinterpret_cast<u64*>(p); p += G_HCAP * 8;
     H.cpu = reinterpret_cast<i64*>(p); p += G_HCAP * 8;
     H.mem = reinterpret_cast<i64*>(p); p += G_HCAP * 8;
     i64* tsum = reinterpret_cast<i64*>(p); p += G_MAXT * 8;              // decisionTree.tasks
-    i64* e_cpu = reinterpret_cast<i64*>(p); p += 256 * 8;
-    i64* e_mem = reinterpret_cast<i64*>(p); p += 256 * 8;
+    i64* e_cpu = reinterpret_cast<i64*>(p); p += G_THREADS * 8;
+    i64* e_mem = reinterpret_cast<i64*>(p); p += G_THREADS * 8;
     H.node = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
     H.total = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
     H.svc = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
     H.fail = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
     H.placed = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H2.total = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H2.svc = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H2.fail = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
+    H.pay = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
     u32* h_off = reinterpret_cast<u32*>(p); p += G_MAXT * 4;              // first heap slot of a leaf
     int32_t* h_len = reinterpret_cast<int32_t*>(p); p += G_MAXT * 4;      // nodeMaxHeap.length
     int32_t* h_cnt = reinterpret_cast<int32_t*>(p); p += G_MAXT * 4;      // len(nodeMaxHeap.nodes)
     int32_t* h_adm = reinterpret_cast<int32_t*>(p); p += G_MAXT * 4;      // slots ever filled (write-back range)
-    u32* e_node = reinterpret_cast<u32*>(p); p += 256 * 4;
-    u32* e_total = reinterpret_cast<u32*>(p); p += 256 * 4;
-    u32* e_svc = reinterpret_cast<u32*>(p); p += 256 * 4;
-    u32* e_fail = reinterpret_cast<u32*>(p); p += 256 * 4;
-    u32* e_leaf = reinterpret_cast<u32*>(p); p += 256 * 4;
-    u32* e_ff = reinterpret_cast<u32*>(p); p += 256 * 4;
-    u32* wcnt = reinterpret_cast<u32*>(p); p += 8 * 4;
+    u32* e_node = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
+    u32* e_total = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
+    u32* e_svc = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
+    u32* e_fail = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
+    u32* e_leaf = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
+    p += G_THREADS * 4;   // (spare staging column)
+    u32* wcnt = reinterpret_cast<u32*>(p); p += 16 * 4;
     u32* shv = reinterpret_cast<u32*>(p); p += 16 * 4;
     u32* cntx = reinterpret_cast<u32*>(p); p += 8 * 4;                    // Explain counters
+    u64* failed = reinterpret_cast<u64*>(p); p += (G_HCAP / 64) * 8;     // fill loop: slots that failed Process
+    u64* rootkey = reinterpret_cast<u64*>(p); p += G_MAXT * 8;             // per leaf: heap root key after tree()
     unsigned char* plog = p; p += G_LOG;
-    enum { S_NENT = 0, S_ERR = 1, S_LEFT = 2, S_NLOG = 3, S_LISTPOS = 4 };
+    enum { S_NENT = 0, S_ERR = 1, S_LEFT = 2, S_NLOG = 3, S_LISTPOS = 4, S_LASTPASS = 5 };
 
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 N = a.n_nodes, Wn = a.n_words;
     if (a.ctl->error != ERR_NONE) return;
 
+    u64 gt[6] = {0, 0, 0, 0, 0, 0};
+    u64 gtk = wall_clock64();
+#define G_TICK(q) do { u64 _n = wall_clock64(); gt[q] += _n - gtk; gtk = _n; } while (0)
     for (u32 gi = 0; gi < a.n_groups; ++gi) {
         const GroupRec G = a.g[gi];
         const u32 tbase = a.tree_off[G.tree], ntn = a.tree_off[G.tree + 1] - tbase;
         const u32* leaf_of = a.leaf_of_node + (size_t)G.tree * N;
         const u32 k = G.k;
         // ---------- per-group reset ----------
-        for (u32 i = tid; i < ntn; i += 256) { tsum[i] = 0; h_off[i] = 0; h_len[i] = 0; h_cnt[i] = 0; h_adm[i] = 0; }
-        for (u32 n = tid; n < N; n += 256) { a.svc_dense[n] = 0; a.fail_dense[n] = 0; }
-        if (tid == 0) { shv[S_ERR] = 0; shv[S_NLOG] = 0; shv[S_LEFT] = 0; }
+        for (u32 i = tid; i < ntn; i += G_THREADS) { tsum[i] = 0; h_off[i] = 0; h_len[i] = 0; h_cnt[i] = 0; h_adm[i] = 0; }
+        for (u32 n = tid; n < N; n += G_THREADS) { a.svc_dense[n] = 0; a.fail_dense[n] = 0; }
+        if (tid == 0) { shv[S_ERR] = 0; shv[S_NLOG] = 0; shv[S_LEFT] = 0; shv[S_LASTPASS] = 0; }
         __syncthreads();
         // the service's (node, svcCount, failures) list → dense per-node columns
-        for (u32 e = a.list_off[G.svc] + tid; e < a.list_off[G.svc + 1]; e += 256) {
+        for (u32 e = a.list_off[G.svc] + tid; e < a.list_off[G.svc + 1]; e += G_THREADS) {
             u32 n = a.list_node[e];
             if (n != LIST_EMPTY) { a.svc_dense[n] = a.list_svc[e]; a.fail_dense[n] = a.list_fail[e]; }
         }
         __syncthreads();
 
+        G_TICK(0);
         // ---------- (A) Pipeline.Process on every node: first failing filter or FF_PASS ----------
-        for (u32 n0 = 0; n0 < N; n0 += 256) {
+        for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
             const u32 n = n0 + tid;
             if (n < N) {
                 const u32 w = n >> 6;
@@ -2891,8 +2889,9 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
             return;
         }
 
-        // ---------- (B) heap admission in node order, 256 nodes at a time (nodeset.go:107-120) ----------
-        for (u32 n0 = 0; n0 < N; n0 += 256) {
+        G_TICK(1);
+        // ---------- (B) heap admission in node order, G_THREADS nodes at a time (nodeset.go:107-120) ----------
+        for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
             const u32 n = n0 + tid;
             bool cand = false;
             u32 leaf = 0, sv = 0, fl = 0, tot = 0;
@@ -2901,11 +2900,9 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
                 sv = a.svc_dense[n];
                 fl = a.fail_dense[n];
                 tot = a.total[n];
+                if (!g_key_ok(fl, sv)) shv[S_ERR] = 1;
                 if (h_len[leaf] < (int)k) cand = true;
-                else {
-                    const u32 r = h_off[leaf];
-                    cand = g_less_vals(fl, sv, tot, H.fail[r], H.svc[r], H.total[r]);
-                }
+                else cand = g_key(fl, sv, tot) < H.key[h_off[leaf]];
             }
             const u64 bal = ballot64(cand);
             if (lane == 0) wcnt[wave] = (u32)__popcll(bal);
@@ -2917,22 +2914,27 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
                 e_node[pos] = n; e_leaf[pos] = leaf; e_svc[pos] = sv; e_fail[pos] = fl; e_total[pos] = tot;
                 e_cpu[pos] = a.cpu[n]; e_mem[pos] = a.mem[n];
             }
-            if (tid == 255) shv[S_NENT] = before + (u32)__popcll(bal);
+            if (tid == G_THREADS - 1) shv[S_NENT] = before + (u32)__popcll(bal);
             __syncthreads();
             if (tid == 0) {
                 const u32 ne = shv[S_NENT];
                 for (u32 i = 0; i < ne; ++i) {
                     const u32 lf = e_leaf[i], base = h_off[lf];
                     const int len = h_len[lf];
-                    if (len < (int)k) {   // heap.Push
-                        const u32 sl = base + (u32)len;
-                        H.node[sl] = e_node[i]; H.total[sl] = e_total[i]; H.svc[sl] = e_svc[i]; H.fail[sl] = e_fail[i];
-                        H.cpu[sl] = e_cpu[i]; H.mem[sl] = e_mem[i]; H.placed[sl] = 0;
+                    const u64 ek = g_key(e_fail[i], e_svc[i], e_total[i]);
+                    u32 sid;
+                    if (len < (int)k) sid = base + (u32)len;          // heap.Push: a fresh state slot
+                    else if (ek < H.key[base]) sid = H.pay[base];      // replaces the root: the evicted node's state slot is reused
+                    else continue;
+                    shv[S_LASTPASS] = e_node[i] + 1;   // the last Process that returned true inside tree()
+                    H.node[sid] = e_node[i]; H.total[sid] = e_total[i]; H.svc[sid] = e_svc[i]; H.fail[sid] = e_fail[i];
+                    H.cpu[sid] = e_cpu[i]; H.mem[sid] = e_mem[i]; H.placed[sid] = 0;
+                    if (len < (int)k) {
+                        H.key[sid] = ek; H.pay[sid] = sid;
                         h_len[lf] = len + 1; h_cnt[lf] = len + 1; h_adm[lf] = len + 1;
                         g_up(H, base, len);
-                    } else if (g_less_vals(e_fail[i], e_svc[i], e_total[i], H.fail[base], H.svc[base], H.total[base])) {
-                        H.node[base] = e_node[i]; H.total[base] = e_total[i]; H.svc[base] = e_svc[i]; H.fail[base] = e_fail[i];
-                        H.cpu[base] = e_cpu[i]; H.mem[base] = e_mem[i]; H.placed[base] = 0;
+                    } else {
+                        H.key[base] = ek;
                         if (!g_down(H, base, 0, len)) g_up(H, base, 0);   // heap.Fix(0)
                     }
                 }
@@ -2940,12 +2942,21 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
             __syncthreads();
         }
 
+        G_TICK(2);
+        // heap roots and lengths as tree() left them: the Explain pass needs them after (C) has spent the heaps
+        for (u32 i = tid; i < ntn; i += G_THREADS) {
+            rootkey[i] = H.key[h_off[i]];
+            h_adm[i] = h_len[i];   // == slots ever filled (pushes only grow the heap)
+        }
+        __syncthreads();
         // ---------- (C) tree walk + fill loops: thread 0, on LDS state only ----------
         if (tid == 0) {
             u32 next_task = 0, nlog = 0;
+            bool bad_key = false;
             const bool has_ports = (G.flags & RT_PORTS) != 0;
             // Pipeline.Process on a heap slot: the static filters passed at admission and cannot change
-            auto process = [&](u32 sl) -> bool {
+            auto process = [&](u32 pos) -> bool {
+                const u32 sl = H.pay[pos];
                 u32 ff = FF_PASS;
                 if ((G.flags & RT_RES) && !(G.cpu <= H.cpu[sl] && G.mem <= H.mem[sl])) ff = 1;
                 else if (has_ports && H.placed[sl] > 0) ff = 5;
@@ -2957,20 +2968,24 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
             // scheduleNTasksOnNodes, scheduler.go:844-924, on the leaf's slots [base, base+cnt)
             auto fill = [&](int want, u32 base, int cnt) -> int {
                 int scheduled = 0, iter = 0;
-                u64 failed[G_HCAP / 64];
-                for (int q = 0; q < G_HCAP / 64; ++q) failed[q] = 0;
+                for (int q = 0; q <= (cnt >> 6); ++q) failed[q] = 0;
                 while (next_task < k) {
-                    const u32 sl = base + (u32)(iter % cnt);
+                    const u32 pos = base + (u32)(iter % cnt);
+                    const u32 sl = H.pay[pos];
                     a.out_node[G.out_off + next_task] = (int32_t)H.node[sl];
                     ++next_task;
                     H.cpu[sl] -= G.cpu;   // NodeInfo.addTask (nodeinfo.go:108-154)
                     H.mem[sl] -= G.mem;
                     H.placed[sl] += 1;
-                    if (!(G.flags & RT_UNCOUNTED)) { H.total[sl] += 1; H.svc[sl] += 1; }
+                    if (!(G.flags & RT_UNCOUNTED)) {
+                        H.total[sl] += 1; H.svc[sl] += 1;
+                        if (!g_key_ok(H.fail[sl], H.svc[sl])) bad_key = true;
+                        H.key[pos] = g_key(H.fail[sl], H.svc[sl], H.total[sl]);
+                    }
                     ++scheduled;
                     if (scheduled == want) return scheduled;
                     if (iter + 1 < cnt) {
-                        if (H.less(base + (u32)((iter + 1) % cnt), sl)) ++iter;   // first pass
+                        if (H.less(base + (u32)((iter + 1) % cnt), pos)) ++iter;   // first pass
                     } else ++iter;                                                 // later passes: round robin
                     const int orig = iter;
                     for (;;) {
@@ -3077,7 +3092,7 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
                 }
                 if (!called && !bad) f.phase = 1;
             }
-            if (bad) shv[S_ERR] = 1;
+            if (bad || bad_key) shv[S_ERR] = 1;
             shv[S_LEFT] = k - next_task;
             shv[S_NLOG] = nlog;
             for (u32 i = next_task; i < k; ++i) a.out_node[G.out_off + i] = -1;
@@ -3088,42 +3103,33 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
             return;
         }
 
+        G_TICK(3);
         // ---------- Explain counters for a group with leftovers (pipeline.go:56-68 call sequence) ----------
         if (shv[S_LEFT] > 0) {
+            // Every passing Process zeroes the counters (pipeline.go:64-66), so only the calls AFTER the last passing one
+            // count. Inside tree() the heaps stop changing after that call: a later node was "called" (nodeset.go:108-116)
+            // iff its leaf's heap was not full or the node is less than the final root — evaluated in parallel.
             if (tid < 8) cntx[tid] = 0;
-            for (u32 i = tid; i < ntn; i += 256) h_len[i] = 0;   // replay heap lengths (the real ones are spent)
             __syncthreads();
-            for (u32 n0 = 0; n0 < N; n0 += 256) {
+            const u32 lastp = shv[S_LASTPASS];   // node index + 1 of the last passing call (0: none)
+            for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
                 const u32 n = n0 + tid;
-                const bool present = n < N && ((a.valid[n >> 6] >> (n & 63)) & 1ull);
-                e_ff[tid] = present ? (u32)a.ff[n] : 0xFFFFu;   // 0xFFFF = no such node
-                if (present) { e_leaf[tid] = leaf_of[n]; e_svc[tid] = a.svc_dense[n]; e_fail[tid] = a.fail_dense[n]; e_total[tid] = a.total[n]; }
-                __syncthreads();
-                if (tid == 0) {
-                    const u32 lim = min(256u, N - n0);
-                    for (u32 i = 0; i < lim; ++i) {
-                        if (e_ff[i] == 0xFFFFu) continue;
-                        const u32 lf = e_leaf[i], base = h_off[lf];
-                        const int len = h_len[lf];
-                        bool called = false, replace = false;
-                        if (len < (int)k) called = true;
-                        else if (g_less_vals(e_fail[i], e_svc[i], e_total[i], H2.fail[base], H2.svc[base], H2.total[base])) { called = true; replace = true; }
-                        if (!called) continue;
-                        if (e_ff[i] != FF_PASS) { cntx[e_ff[i]]++; continue; }
-                        for (int q = 0; q < 8; ++q) cntx[q] = 0;   // a passing Process zeroes every counter
-                        if (!replace) {
-                            const u32 sl = base + (u32)len;
-                            H2.total[sl] = e_total[i]; H2.svc[sl] = e_svc[i]; H2.fail[sl] = e_fail[i];
-                            h_len[lf] = len + 1;
-                            g_up(H2, base, len);
-                        } else {
-                            H2.total[base] = e_total[i]; H2.svc[base] = e_svc[i]; H2.fail[base] = e_fail[i];
-                            if (!g_down(H2, base, 0, len)) g_up(H2, base, 0);
-                        }
+                u32 f = 0xFFu;
+                if (n < N && n >= lastp && ((a.valid[n >> 6] >> (n & 63)) & 1ull)) {
+                    const u32 ffn = a.ff[n];
+                    if (ffn != FF_PASS) {
+                        const u32 lf = leaf_of[n];
+                        const bool called = h_adm[lf] < (int)k ||
+                                            g_key(a.fail_dense[n], a.svc_dense[n], a.total[n]) < rootkey[lf];   // (D) has not run yet: tree()-time values
+                        if (called) f = ffn;
                     }
                 }
-                __syncthreads();
+                for (u32 q = 0; q < 7; ++q) {
+                    const u64 bm = ballot64(f == q);
+                    if (bm && lane == 0) atomicAdd(&cntx[q], (u32)__popcll(bm));
+                }
             }
+            __syncthreads();
             if (tid == 0) {
                 const u32 nl = min(shv[S_NLOG], (u32)G_LOG);
                 for (u32 i = 0; i < nl; ++i) {
@@ -3137,7 +3143,7 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
         }
 
         // ---------- (D) write-back: node rows, host ports, the service's (node, count) list ----------
-        for (u32 i = tid; i < ntn; i += 256) {
+        for (u32 i = tid; i < ntn; i += G_THREADS) {
             if (a.tn_nchild[tbase + i] != 0) continue;
             const u32 base = h_off[i];
             for (int q = 0; q < h_adm[i]; ++q) {
@@ -3156,7 +3162,7 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
         if (tid == 0) shv[S_LISTPOS] = a.list_off[G.svc];
         __syncthreads();
         const u32 lend = a.list_off[G.svc + 1];
-        for (u32 n0 = 0; n0 < N; n0 += 256) {
+        for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
             const u32 n = n0 + tid;
             const bool keep = n < N && (a.svc_dense[n] > 0 || a.fail_dense[n] >= MAX_FAILURES);
             const u64 bal = ballot64(keep);
@@ -3167,12 +3173,14 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
             const u32 pos = before + (u32)__popcll(bal & ((1ull << lane) - 1ull));
             if (keep && pos < lend) { a.list_node[pos] = n; a.list_svc[pos] = a.svc_dense[n]; a.list_fail[pos] = a.fail_dense[n]; }
             __syncthreads();
-            if (tid == 0) shv[S_LISTPOS] += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            if (tid == 0) { u32 t_ = 0; for (u32 q = 0; q < G_THREADS / 64; ++q) t_ += wcnt[q]; shv[S_LISTPOS] += t_; }
             __syncthreads();
         }
-        for (u32 e = shv[S_LISTPOS] + tid; e < lend; e += 256) a.list_node[e] = LIST_EMPTY;
+        for (u32 e = shv[S_LISTPOS] + tid; e < lend; e += G_THREADS) a.list_node[e] = LIST_EMPTY;
         __syncthreads();
+        G_TICK(5);
     }
+    if (tid == 0) for (int q = 0; q < 6; ++q) a.ctl->cyc[q] = gt[q];
 }
 
 // ---------------------------------------------------------------------------------------------

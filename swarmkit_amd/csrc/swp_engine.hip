@@ -1360,14 +1360,28 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
     ga.ff = d_ff.as<unsigned char>(); ga.svc_dense = d_svcd.as<uint32_t>(); ga.fail_dense = d_faild.as<uint32_t>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
-    const size_t lds = (size_t)G_HCAP * (8 * 2 + 4 * 8) + (size_t)G_MAXT * (8 + 4 * 4) + 256 * (8 * 2 + 4 * 6) + (8 + 16 + 8) * 4 + G_LOG + 256;
+    const size_t lds = (size_t)G_HCAP * (8 * 3 + 4 * 6) + (size_t)G_MAXT * (8 + 4 * 4 + 8) + (size_t)G_THREADS * (8 * 2 + 4 * 6) + (16 + 16 + 8) * 4 + (G_HCAP / 64) * 8 + G_LOG + 256;
     static bool attr = false;
     if (!attr) {
         HIPCHECK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_groups), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
         attr = true;
     }
-    hipLaunchKernelGGL(k_groups, dim3(1), dim3(256), lds, st, ga);
+    const bool gdbg = getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16);
+    hipEvent_t gev0 = nullptr, gev1 = nullptr;
+    if (gdbg) { (void)hipEventCreate(&gev0); (void)hipEventCreate(&gev1); (void)hipEventRecord(gev0, st); }
+    hipLaunchKernelGGL(k_groups, dim3(1), dim3(G_THREADS), lds, st, ga);
     HIPCHECK(e, hipGetLastError());
+    if (gdbg) {
+        (void)hipEventRecord(gev1, st);
+        (void)hipEventSynchronize(gev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, gev0, gev1);
+        Ctl c2{};
+        (void)hipMemcpy(&c2, b.d_ctl.p, sizeof c2, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[swp] k_groups %.3f ms for %u groups | ticks(10ns): reset %llu scan %llu admit %llu walk %llu explain %llu writeback %llu\n", ms, n_groups,
+                c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5]);
+        (void)hipEventDestroy(gev0); (void)hipEventDestroy(gev1);
+    }
     Ctl ctl{};
     HIPCHECK(e, hipMemcpyAsync(&ctl, b.d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
     HIPCHECK(e, hipMemcpyAsync(out_node, d_out.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
