@@ -174,7 +174,9 @@ def main():
             traffic = None
 
     result = {
-        "metric": "task placements/sec (100k one-off tasks x 10k nodes, Resource+Constraint+Platform filters, spread)",
+        "metric": f"task placements/sec ({wl.T // 1000}k one-off tasks x {wl.N // 1000}k nodes, "
+                  + {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filters", "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}.get(args.workload, args.workload)
+                  + ", spread)",
         "value": world * wl.T / t_step,
         "unit": "placements/s",
         "n_gpus": world,
@@ -191,7 +193,7 @@ def main():
         "pair_evals_per_s": world * pairs / t_step,
         "placed": placed,
         "unplaceable": wl.T - placed,
-        "roofline": {"bound": "hbm", "kernel": "k_resolve3", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": {3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}.get(int(st.get("last_resolver", 3)), "k_resolve"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows},
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_scan": ms_scan / K, "k_resolve": ms_resolve / K,

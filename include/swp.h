@@ -262,6 +262,7 @@ typedef struct {
     uint32_t n_nodes, n_words, last_windows, last_static_classes;
     float    ms_classes, ms_scan, ms_resolve, ms_explain, ms_total;   /* last batch, SWP_CFG_PROFILE */
     uint32_t scan_launches, resolve_launches;
+    uint32_t last_resolver;     /* resolver kernel of the last batch: 3 = k_resolve3, 2 = k_resolve2, 1 = k_resolve1, 0 = k_resolve */
 } swp_stats_t;
 
 int swp_create(const swp_config*, swp_engine** out);

@@ -911,6 +911,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
     e->stats.last_static_classes = b->n_sc;
     e->stats.scan_launches += b->n_windows;
     e->stats.resolve_launches += b->n_windows;
+    e->stats.last_resolver = (uint32_t)variant;
     b->ran = true;
     return SWP_OK;
 }
