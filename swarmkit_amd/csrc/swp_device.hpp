@@ -2723,6 +2723,7 @@ struct GroupArgs {
     const u32* tn_first;     // first child or 0xFFFFFFFF
     const u32* tn_next;      // next sibling or 0xFFFFFFFF
     const u32* tn_nchild;
+    const u32* tn_nodes;     // nodes whose leaf this tnode is
     const u32* leaf_of_node; // [n_trees][n_nodes] tnode of the node's leaf
     unsigned char* ff;       // scratch [n_nodes]
     u32* svc_dense;          // scratch [n_nodes]
@@ -2880,7 +2881,7 @@ __global__ __launch_bounds__(G_THREADS) void k_groups(GroupArgs a) {
             for (int i = (int)ntn - 1; i > 0; --i) tsum[a.tn_parent[tbase + i]] += tsum[i];   // children follow their parent
             u32 off = 0;
             for (u32 i = 0; i < ntn; ++i)
-                if (a.tn_nchild[tbase + i] == 0) { h_off[i] = off; off += k; }
+                if (a.tn_nchild[tbase + i] == 0) { h_off[i] = off; off += min(k, a.tn_nodes[tbase + i]); }   // a leaf's heap holds ≤ its node count
             if (off > G_HCAP || ntn > G_MAXT) shv[S_ERR] = 1;
         }
         __syncthreads();

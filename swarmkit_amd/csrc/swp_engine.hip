@@ -1263,7 +1263,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
             tree_local[groups[g].spread_set] = (uint32_t)tree_sets.size();
             tree_sets.push_back(groups[g].spread_set);
         }
-    std::vector<uint32_t> tree_off{0}, tn_parent, tn_first, tn_next, tn_nchild, leaf_of((size_t)tree_sets.size() * N, 0xFFFFFFFFu);
+    std::vector<uint32_t> tree_off{0}, tn_parent, tn_first, tn_next, tn_nchild, tn_nodes, leaf_of((size_t)tree_sets.size() * N, 0xFFFFFFFFu);
     for (size_t t = 0; t < tree_sets.size(); ++t) {
         const auto& levels = e->spread_sets[tree_sets[t]];
         const uint32_t base = (uint32_t)tn_parent.size();
@@ -1274,6 +1274,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
             tn_first.push_back(0xFFFFFFFFu);
             tn_next.push_back(0xFFFFFFFFu);
             tn_nchild.push_back(0);
+            tn_nodes.push_back(0);
             last_child.push_back(0xFFFFFFFFu);
             return id;
         };
@@ -1305,6 +1306,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
                 tn = it->second;
             }
             leaf_of[t * N + n] = tn;
+            tn_nodes[base + tn]++;   // nodes of this leaf: its heap never holds more (nodeset.go:107-120)
         }
         tree_off.push_back((uint32_t)tn_parent.size());
         if (tn_parent.size() - base > G_MAXT) return e->fail(SWP_ERANGE, "spread tree with %zu branches exceeds the device limit %d", tn_parent.size() - base, G_MAXT);
@@ -1318,16 +1320,23 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
         q.cpu = r.cpu; q.mem = r.mem; q.flags = r.flags; q.k = sizes[g]; q.svc = r.svc; q.out_off = off; q.pset = r.pset;
         q.cls_con = r.cls_con; q.cls_plat = r.cls_plat; q.cls_plug = r.cls_plug; q.maxrep = r.maxrep;
         q.tree = tree_local[groups[g].spread_set];
-        if ((uint64_t)sizes[g] > G_HCAP) return e->fail(SWP_ERANGE, "group of %u tasks exceeds the device heap capacity %d", sizes[g], G_HCAP);
+        {   // heap slots the group needs: per leaf min(k, nodes of the leaf)
+            const uint32_t t = q.tree;
+            uint64_t need = 0;
+            for (uint32_t i = tree_off[t]; i < tree_off[t + 1]; ++i)
+                if (tn_nchild[i] == 0) need += std::min<uint32_t>(sizes[g], tn_nodes[i]);
+            if (need > G_HCAP) return e->fail(SWP_ERANGE, "group of %u tasks needs %llu heap slots over its spread tree, the device holds %d", sizes[g], (unsigned long long)need, G_HCAP);
+        }
         off += sizes[g];
     }
-    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_leaf, d_ff, d_svcd, d_faild, d_out, d_hist;
+    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_tnn, d_leaf, d_ff, d_svcd, d_faild, d_out, d_hist;
     if ((rc = upload(e, d_recs, recs))) return rc;
     if ((rc = upload(e, d_tree_off, tree_off))) return rc;
     if ((rc = upload(e, d_par, tn_parent))) return rc;
     if ((rc = upload(e, d_first, tn_first))) return rc;
     if ((rc = upload(e, d_next, tn_next))) return rc;
     if ((rc = upload(e, d_nch, tn_nchild))) return rc;
+    if ((rc = upload(e, d_tnn, tn_nodes))) return rc;
     if ((rc = upload(e, d_leaf, leaf_of))) return rc;
     HIPCHECK(e, d_ff.reserve(N));
     HIPCHECK(e, d_svcd.reserve((size_t)N * 4));
@@ -1358,7 +1367,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     ga.list_node = b.d_list_node.as<uint32_t>(); ga.list_svc = b.d_list_svc.as<uint32_t>(); ga.list_fail = b.d_list_fail.as<uint32_t>();
     ga.list_off = b.d_list_off.as<uint32_t>();
     ga.tree_off = d_tree_off.as<uint32_t>(); ga.tn_parent = d_par.as<uint32_t>(); ga.tn_first = d_first.as<uint32_t>();
-    ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
+    ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.tn_nodes = d_tnn.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
     ga.ff = d_ff.as<unsigned char>(); ga.svc_dense = d_svcd.as<uint32_t>(); ga.fail_dense = d_faild.as<uint32_t>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
     const size_t lds = (size_t)G_HCAP * (8 * 3 + 4 * 6) + (size_t)G_MAXT * (8 + 4 * 4 + 8) + (size_t)G_THREADS * (8 * 2 + 4 * 6) + (16 + 16 + 8) * 4 + (G_HCAP / 64) * 8 + G_LOG + 256;
