@@ -2058,7 +2058,7 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
             u32 cand = (lv[k] << idx_bits) | (w * 64 + (u32)(__ffsll((long long)m[k]) - 1));
             best = min(best, m[k] ? cand : 0xFFFFFFFFu);
         }
-        return wave_min_u32_dpp(best);
+        return best;   // per lane: (level << idx_bits) | node of its best candidate, or 0xFFFFFFFF
     };
     u32 tin = 0, bdone = 0;   // task index inside the block, blocks finished
     // Generic path / rebase only: memory must reflect every commit so far. The pending commits of the current block
@@ -2280,34 +2280,50 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) gk[k] = mk[k];
                 for (;;) {
-                    u32 g = search(gk);
+                    // Every lane proposes the best candidate of its own words; the wave's minimum is THE candidate of the
+                    // reference (lowest level, lowest index). Lanes whose proposal sits at that same level re-check it
+                    // against memory in the same round trip (a node committed to in this window may no longer fit: its F
+                    // bit is stale) and drop it if it fails — so a storm of stale candidates costs one memory latency per
+                    // 64 of them, not one each. Dropping is safe: resources only shrink inside a batch.
+                    const u32 mine = search(gk);
+                    const u32 g = wave_min_u32_dpp(mine);
                     if (g == 0xFFFFFFFFu) break;
-                    n = g & idx_mask;
-                    lvl = g >> idx_bits;
-                    w = n >> 6;
-                    ko = w >> 6;
-                    bit = 1ull << (n & 63);
-                    owner = (w & 63) == lane;
-                    u64 tsel = 0;
+                    const u32 glvl = g >> idx_bits;
+                    const bool act = mine != 0xFFFFFFFFu && (mine >> idx_bits) == glvl;
+                    const u32 mn = mine & idx_mask, mw = mn >> 6, mko = mw >> 6;
+                    const u64 mbit = 1ull << (mn & 63);
+                    bool mine_ok = true;
+                    if (act) {
+                        u64 tsel = 0;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) tsel = ((u32)k == ko) ? T0[k] : tsel;
-                    bool ok = true;
-                    if (ballot64(owner && (tsel & bit)) != 0) {
-                        if (rflags & RT_RES) {
-                            i64 c = __hip_atomic_load(&a.cpu[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            i64 m = __hip_atomic_load(&a.mem[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = (rcpu <= c) && (rmem <= m);
+                        for (int k = 0; k < K; ++k) tsel = ((u32)k == mko) ? T0[k] : tsel;
+                        if (tsel & mbit) {
+                            if (rflags & RT_RES) {
+                                i64 c = __hip_atomic_load(&a.cpu[mn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                i64 m = __hip_atomic_load(&a.mem[mn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                mine_ok = (rcpu <= c) && (rmem <= m);
+                            }
+                            if (mine_ok && (rflags & RT_PORTS)) {
+                                for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
+                                    if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + mw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mbit) mine_ok = false;
+                            }
                         }
-                        if (ok && (rflags & RT_PORTS)) {
-                            for (u32 p = a.pset_off[rpset]; p < a.pset_off[rpset + 1]; ++p)
-                                if (__hip_atomic_load(&a.portmap[(size_t)a.pset_ids[p] * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) ok = false;
+                        if (!mine_ok) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) gk[k] &= ~(((u32)k == mko) ? mbit : 0ull);
                         }
                     }
-                    ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;   // uniform (same address in every lane)
-                    if (ok) { placed = true; break; }
-#pragma unroll
-                    for (int k = 0; k < K; ++k) gk[k] &= ~((owner && (u32)k == ko) ? bit : 0ull);
-                    ++st_retries;
+                    st_retries += (u32)__popcll(ballot64(act && !mine_ok));
+                    if (ballot64(act && mine == g && mine_ok) != 0) {
+                        n = g & idx_mask;
+                        lvl = glvl;
+                        w = n >> 6;
+                        ko = w >> 6;
+                        bit = 1ull << (n & 63);
+                        owner = (w & 63) == lane;
+                        placed = true;
+                        break;
+                    }
                 }
                 if (!placed && listp) {
                     // exception list of the service: nodes with svcCount>0 or ≥5 recent failures
