@@ -1946,16 +1946,26 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
     // commit, and the deferred lane-parallel application of the side effects (≤ TB pending at any time)
     u32 rg_svc = 0xFFFFFFFFu, rg_node = 0, rg_meta = 0, rg_slot = 0;   // meta = task-in-block | counted<<8 | via_list<<9
 
+    // (Re)build the level planes from total[]. Each lane owns 64 consecutive counters per word: all 64 loads of a word
+    // are issued before the first use (one memory round trip per word instead of one per node: the serialised version
+    // cost ~0.25 ms per launch). The loads bypass the L1: a rebase re-reads counters this kernel has just updated.
+    auto load_word_totals = [&](int k, u32 (&v)[64]) __attribute__((always_inline)) {
+        const u32 w = lane + 64 * k;
+        const u32* src = a.total + (size_t)(w < Wn ? w : 0) * 64;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     auto build_planes = [&]() __attribute__((always_inline)) -> bool {
         u32 lo = 0xFFFFFFFFu, hi = 0;
-        for (int i = 0; i < 64; ++i) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if ((VAL[k] >> i) & 1ull) {
-                    u32 t = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lo = min(lo, t);
-                    hi = max(hi, t);
-                }
+        for (int k = 0; k < K; ++k) {
+            u32 v[64];
+            load_word_totals(k, v);
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const bool on = (VAL[k] >> i) & 1ull;
+                lo = min(lo, on ? v[i] : 0xFFFFFFFFu);
+                hi = max(hi, on ? v[i] : 0u);
             }
         }
         lo = (u32)__builtin_amdgcn_readfirstlane((int)wave_min_u32(lo));
@@ -1970,18 +1980,19 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
         for (int k = 0; k < K; ++k) {
             T0[k] |= D[k];
             D[k] = 0;
+            u32 v[64];
+            load_word_totals(k, v);
+            u64 p[R1_NBR];
 #pragma unroll
-            for (int b = 0; b < R1_NBR; ++b) pl[b][k] = 0;
-        }
-        for (int i = 0; i < 64; ++i) {
+            for (int b = 0; b < R1_NBR; ++b) p[b] = 0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                u32 lvl = 0;
-                if ((VAL[k] >> i) & 1ull)
-                    lvl = __hip_atomic_load(&a.total[(lane + 64 * k) * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+            for (int i = 0; i < 64; ++i) {
+                const u32 lvl = ((VAL[k] >> i) & 1ull) ? v[i] - base : 0u;
 #pragma unroll
-                for (int b = 0; b < R1_NBR; ++b) pl[b][k] |= (u64)((lvl >> b) & 1u) << i;
+                for (int b = 0; b < R1_NBR; ++b) p[b] |= (u64)((lvl >> b) & 1u) << i;
             }
+#pragma unroll
+            for (int b = 0; b < R1_NBR; ++b) pl[b][k] = p[b];
         }
         return true;
     };
