@@ -1359,4 +1359,73 @@ void Scheduler::no_suitable_node(OrderedTasks& group, std::vector<Decision>& dec
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// api/genericresource/validate.go:54-85 — HasResource
+// ---------------------------------------------------------------------------------------------
+bool generic_has_resource(const GenericResource& res, const GenericList& resources) {
+    for (const GenericResource& r : resources) {
+        if (res.kind != r.kind) continue;                       // :56-58
+        if (!r.named) {                                         // DiscreteResourceSpec, :61-70
+            if (res.named) return false;
+            if (res.ivalue > r.ivalue) return false;
+            return true;
+        }
+        if (!res.named) return false;                           // NamedResourceSpec, :71-80
+        if (res.svalue != r.svalue) continue;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// manager/orchestrator/constraintenforcer/constraint_enforcer.go:65-196 — rejectNoncompliantTasks
+// ---------------------------------------------------------------------------------------------
+std::vector<std::string> enforce_node(const Node& node, const std::vector<TaskPtr>& tasks,
+                                      const std::map<std::string, ServicePlacement>& service_placement) {
+    std::vector<std::string> removed;
+    if (node.availability != NodeAvailabilityActive) return removed;   // :70-72: drain = orchestrator's job, pause = hands off
+    Resources available;                                               // :101-106
+    if (node.has_description && node.has_resources) available = node.resources;
+    GenericList fake_store;
+    for (const TaskPtr& tp : tasks) {
+        const Task& t = *tp;
+        if (t.desired_state < TaskStateAssigned || t.desired_state > TaskStateCompleted) continue;   // :118-120
+        if (t.state >= TaskStateCompleted) continue;                                                  // :124-126
+        // placement: the service's CURRENT spec if the service exists, else the task's own (:152-161)
+        bool has_placement = t.has_placement;
+        const std::vector<std::string>* cons = &t.constraints;
+        auto it = service_placement.find(t.service_id);
+        if (it != service_placement.end()) {
+            has_placement = it->second.has_placement;
+            cons = &it->second.constraints;
+        }
+        if (has_placement && !cons->empty()) {                                                        // :162-168
+            std::vector<Constraint> cs;
+            if (!constraint_parse(*cons, &cs, nullptr)) cs.clear();   // `constraints, _ := constraint.Parse(...)`: nil on error
+            if (!node_matches(cs, node)) {
+                removed.push_back(t.id);
+                continue;
+            }
+        }
+        if (t.has_reservations) {                                                                     // :172-184
+            if (t.reservations.memory_bytes > available.memory_bytes) { removed.push_back(t.id); continue; }
+            if (t.reservations.nano_cpus > available.nano_cpus) { removed.push_back(t.id); continue; }
+            available.memory_bytes -= t.reservations.memory_bytes;
+            available.nano_cpus -= t.reservations.nano_cpus;
+        }
+        if (!t.assigned_generic.empty()) {                                                            // :188-199
+            bool gone = false;
+            for (const GenericResource& ta : t.assigned_generic)
+                if (!generic_has_resource(ta, available.generic)) { gone = true; break; }
+            if (gone) {
+                removed.push_back(t.id);
+                break;   // `break loop`: the whole task loop ends here (:193)
+            }
+            fake_store.insert(fake_store.end(), t.assigned_generic.begin(), t.assigned_generic.end());   // ClaimResources,
+            generic_consume(&available.generic, t.assigned_generic);                                    // resource_management.go:36-40
+        }
+    }
+    return removed;
+}
+
 }  // namespace orc

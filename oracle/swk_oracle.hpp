@@ -139,6 +139,16 @@ struct Task {              // the api.Task field subset the path reads
 using TaskPtr = std::shared_ptr<Task>;
 using NodePtr = std::shared_ptr<Node>;
 
+// ---- manager/orchestrator/constraintenforcer/constraint_enforcer.go ---------------------------
+// rejectNoncompliantTasks (constraint_enforcer.go:65-196) for ONE node: the ids of the tasks the enforcer would set to
+// REJECTED. `tasks` = store.FindTasks(ByNodeID) in the order given (canonical: ascending task id; the reference itself
+// calls the order nondeterministic, :104-109). `service_placement` maps a ServiceID to the CURRENT service spec's
+// placement constraints (services[t.ServiceID] != nil, :152-161); a task of an unknown service uses its own spec.
+struct ServicePlacement { bool has_placement = false; std::vector<std::string> constraints; };
+std::vector<std::string> enforce_node(const Node& node, const std::vector<TaskPtr>& tasks,
+                                      const std::map<std::string, ServicePlacement>& service_placement);
+bool generic_has_resource(const GenericResource& res, const GenericList& resources);   // validate.go:54-85
+
 // ---- manager/constraint/constraint.go -------------------------------------
 struct Constraint { std::string key; int op = 0; std::string exp; };   // op: 0 ==, 1 !=
 bool constraint_parse(const std::vector<std::string>& env, std::vector<Constraint>* out, std::string* err);

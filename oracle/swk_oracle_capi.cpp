@@ -516,4 +516,36 @@ int orc_tree(const char* doc_json) {
     });
 }
 
+// rejectNoncompliantTasks for one node. doc = {"Node": api.Node, "Tasks": [api.Task, ...], "Services": {id: {"Spec":
+// {"Task": {"Placement": {"Constraints": [...]}}}}}}; result (orc_result) = JSON array of rejected task ids.
+int orc_enforce(const char* doc_json) {
+    return guarded([&] {
+        auto d = orcjson::parse(doc_json);
+        NodePtr n = decode_node(*d->get("Node"));
+        std::vector<TaskPtr> tasks;
+        if (const Value* ts = d->obj_or_null("Tasks"))
+            for (auto& t : ts->arr) tasks.push_back(decode_task(*t));
+        std::map<std::string, ServicePlacement> sp;
+        if (const Value* sv = d->obj_or_null("Services"))
+            for (auto& kv : sv->obj) {
+                ServicePlacement p;
+                if (const Value* spec = kv.second->obj_or_null("Spec"))
+                    if (const Value* tk = spec->obj_or_null("Task"))
+                        if (const Value* pl = tk->obj_or_null("Placement")) {
+                            p.has_placement = true;
+                            if (const Value* cs = pl->obj_or_null("Constraints"))
+                                for (auto& c : cs->arr) p.constraints.push_back(c->s);
+                        }
+                sp[kv.first] = p;
+            }
+        std::vector<std::string> out = enforce_node(*n, tasks, sp);
+        g_out = "[";
+        for (size_t i = 0; i < out.size(); ++i) {
+            if (i) g_out += ",";
+            g_out += "\"" + out[i] + "\"";
+        }
+        g_out += "]";
+    });
+}
+
 }  // extern "C"

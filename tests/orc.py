@@ -58,6 +58,7 @@ def lib():
         L.orc_constraint_match.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         L.orc_equal_fold.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         L.orc_pipeline_process.argtypes = [ctypes.c_char_p]
+        L.orc_enforce.argtypes = [ctypes.c_char_p]
         L.orc_nodeinfo_ops.argtypes = [ctypes.c_char_p]
         L.orc_tree.argtypes = [ctypes.c_char_p]
         _lib = L
@@ -166,6 +167,13 @@ def constraint_match(expr, what):
 
 def equal_fold(a, b):
     return bool(lib().orc_equal_fold(a.encode(), b.encode()))
+
+
+def enforce(node, tasks, services=None):
+    """constraintenforcer.rejectNoncompliantTasks for one node: ids of the tasks that would be REJECTED.
+    tasks: api.Task docs in store order (canonical: ascending ID); services: {ServiceID: api.Service doc}."""
+    _check(lib().orc_enforce(_j({"Node": node, "Tasks": list(tasks), "Services": services or {}})))
+    return json.loads(lib().orc_result().decode())
 
 
 def pipeline_process(task, node, available=None, by_service=None, used_ports=None):
