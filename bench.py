@@ -70,8 +70,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--order", default="rr", choices=["rr", "major"], help="task order: round-robin over services (SURVEY 8d) or service-major")
-    ap.add_argument("--mode", default="one-off", choices=["one-off", "grouped"],
-                    help="one-off (headline, SURVEY 8d primary mode) or grouped: S groups of T/S tasks through swp_schedule_groups (secondary mode)")
+    ap.add_argument("--mode", default="one-off", choices=["one-off", "grouped", "enforce"],
+                    help="one-off (headline, SURVEY 8d primary mode); grouped: S groups of T/S tasks through swp_schedule_groups (secondary mode); "
+                         "enforce: the constraint enforcer's start-up sweep (SURVEY 8f-1) over the cluster the placement produced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also verify the placements against the oracle sample")
     args = ap.parse_args()
@@ -96,6 +97,56 @@ def main():
     t0 = time.perf_counter()
     descs = host.load_workload(sched, wl)
     t_host_prep = time.perf_counter() - t0
+    if args.mode == "enforce":
+        # constraintenforcer.rejectNoncompliantTasks for EVERY node (the enforcer's start-up sweep,
+        # constraint_enforcer.go:45-52) after the batch has been placed: tasks-on-node x (current service constraints +
+        # reservations against Description.Resources). Timed end to end around swp_enforce.
+        import numpy as np
+        out, _h = eng.schedule_batch(descs, want_hist=False)
+        placed = np.nonzero(out >= 0)[0]
+        order = placed[np.lexsort((placed, out[placed]))]          # by node, then task id (= canonical store order)
+        node_of = out[order]
+        svc_of = np.array([wl.task_service(int(j)) for j in order])
+        cset = descs["constraint_set"][order]
+        trec = np.zeros(len(order), dtype=abi.ENF_TASK_DTYPE)
+        trec["cpu"], trec["mem"], trec["constraint_set"] = wl.svc_cpu[svc_of], wl.svc_mem[svc_of], cset
+        trec["flags"], trec["desired_state"], trec["state"] = abi.ENF_RESERVATIONS, 512, 512
+        firsts = np.searchsorted(node_of, np.arange(wl.N), side="left")
+        counts = np.searchsorted(node_of, np.arange(wl.N), side="right") - firsts
+        nrec = np.zeros(wl.N, dtype=abi.ENF_NODE_DTYPE)
+        nrec["node"], nrec["first_task"], nrec["n_tasks"] = np.arange(wl.N), firsts, counts
+        nrec["cpu"], nrec["mem"] = wl.node_cpu, wl.node_mem
+        for _ in range(args.warmup):
+            rej = eng.enforce(nrec, trec)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rej = eng.enforce(nrec, trec)
+        t_step = (time.perf_counter() - t0) / max(args.steps, 1)
+        res = {"metric": "constraint-enforcer sweep: (task, node) compliance checks/sec, end to end through swp_enforce",
+               "value": len(order) / t_step, "unit": "task checks/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+               "data": "synthetic", "config": dict(wl.describe(), mode="enforce", tasks_checked=int(len(order)), nodes_swept=int(wl.N)),
+               "rejected": int(rej.sum())}
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc
+            sample = min(wl.N, 400)
+            docs = {}
+            for idx, j in enumerate(order):
+                n = int(node_of[idx])
+                if n < sample:
+                    docs.setdefault(n, []).append(dict(wl.task_doc(int(j)), NodeID=wl.node_id(n), DesiredState=512, Status={"State": 512}))
+            t0 = time.perf_counter()
+            nt = 0
+            for n in range(sample):
+                nt += len(docs.get(n, ()))
+                orc.enforce(wl.node_doc(n), docs.get(n, []), {})
+            dt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": nt / dt, "unit": "task checks/s", "cores": 1, "kind": "port",
+                                   "sample": f"oracle enforce_node on the first {sample} nodes ({nt} tasks, {dt:.2f} s incl. JSON marshalling)"}
+        print(json.dumps(res))
+        ranks.close()
+        return
     if args.mode == "grouped":
         # secondary mode: every service is ONE group of T/S identical tasks -> S scans instead of T.
         # Timed end to end around swp_schedule_groups (descriptor upload, k_groups, results back).

@@ -250,6 +250,33 @@ int swp_commit(swp_engine*, const swp_placement* p, uint32_t n, int add_or_remov
  * *first_fail = -1 on pass, else the index of the first failing filter. */
 int swp_check_node(swp_engine*, const swp_task_desc* task, uint32_t node, int32_t* first_fail);
 
+/* constraintenforcer.rejectNoncompliantTasks (manager/orchestrator/constraintenforcer/constraint_enforcer.go:65-196)
+ * over MANY nodes in one call: the enforcer's start-up sweep (Run, :45-52) or a burst of EventUpdateNode. Per node the
+ * reference walks the node's tasks in store order: skip by desired / observed state (:118-126), reject when the node
+ * no longer matches the placement constraints of the task's CURRENT service spec (or of the task itself when the service
+ * is gone, :152-168), else account the reservation against Description.Resources in that order and reject what no
+ * longer fits (:172-184). The caller lists only ACTIVE nodes (:70-72) and resolves which constraint list applies;
+ * an unparsable list is passed as constraint_set 0 (`constraints, _ := constraint.Parse`, :163). Tasks that carry
+ * AssignedGenericResources (:188-199) stay on the Go path: do not pass their node.
+ *   out_reject[i] = 1 when task i would be set to REJECTED, else 0. */
+typedef struct {
+    uint32_t node;          /* NODE_ID id; must be present in the engine's nodeSet mirror */
+    uint32_t first_task;    /* index of the node's first task in `tasks` */
+    uint32_t n_tasks;
+    uint32_t reserved;
+    int64_t  cpu, mem;      /* node.Description.Resources (0,0 when nil, :101-106) */
+} swp_enforce_node;         /* 32 bytes */
+#define SWP_ENF_RESERVATIONS 0x1u   /* t.Spec.Resources != nil && Reservations != nil (:172) */
+typedef struct {
+    int64_t  cpu, mem;          /* Reservations */
+    uint32_t constraint_set;    /* swp_constraint_set id, 0 = no (parsable) constraints */
+    uint32_t flags;             /* SWP_ENF_* */
+    uint32_t desired_state;     /* api.TaskState numeric values (NEW=0 … ASSIGNED=192 … COMPLETE=576 …) */
+    uint32_t state;             /* Status.State */
+} swp_enforce_task;             /* 32 bytes */
+int swp_enforce(swp_engine*, const swp_enforce_node* nodes, uint32_t n_nodes, const swp_enforce_task* tasks, uint32_t n_tasks,
+                uint8_t* out_reject);
+
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
     uint64_t batches, tasks, placed, infeasible;

@@ -79,6 +79,10 @@ TASK_DTYPE = np.dtype([("service", "<u4"), ("flags", "<u4"), ("cpu", "<i8"), ("m
                        ("platform_set", "<u4"), ("plugin_set", "<u4"), ("port_set", "<u4"), ("max_replicas", "<u8"),
                        ("spec_version", "<u8"), ("spread_set", "<u4"), ("reserved", "<u4")])
 PLACEMENT_DTYPE = np.dtype([("node", "<u4"), ("service", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("port_set", "<u4"), ("counted", "<u4")])
+ENF_NODE_DTYPE = np.dtype([("node", "<u4"), ("first_task", "<u4"), ("n_tasks", "<u4"), ("reserved", "<u4"), ("cpu", "<i8"), ("mem", "<i8")])
+ENF_TASK_DTYPE = np.dtype([("cpu", "<i8"), ("mem", "<i8"), ("constraint_set", "<u4"), ("flags", "<u4"), ("desired_state", "<u4"), ("state", "<u4")])
+ENF_RESERVATIONS = 1
+assert ENF_NODE_DTYPE.itemsize == 32 and ENF_TASK_DTYPE.itemsize == 32
 assert TASK_DTYPE.itemsize == C.sizeof(TaskDesc) == 64
 assert PLACEMENT_DTYPE.itemsize == C.sizeof(Placement) == 32
 
@@ -86,7 +90,7 @@ EXPORTS = [
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
-    "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node",
+    "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce",
     "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check",
 ]
 
@@ -154,6 +158,7 @@ def load_library():
         "swp_state_restore": ([vp], C.c_int),
         "swp_commit": ([vp, vp, u32, C.c_int], C.c_int),
         "swp_check_node": ([vp, P(TaskDesc), u32, P(i32)], C.c_int),
+        "swp_enforce": ([vp, vp, u32, vp, u32, vp], C.c_int),
         "swp_stats": ([vp, P(Stats)], C.c_int),
         "swp_strerror": ([C.c_int], cp),
         "swp_last_error": ([vp], cp),
@@ -312,6 +317,15 @@ class Engine:
         hist = np.zeros((len(groups), NFILTERS), dtype=np.uint32)
         self._ck(self.L.swp_schedule_groups(self.h, groups.ctypes.data, sizes.ctypes.data, len(groups), out.ctypes.data, hist.ctypes.data))
         return out, hist
+
+    def enforce(self, nodes, tasks):
+        """constraintenforcer.rejectNoncompliantTasks over many nodes. nodes: ENF_NODE_DTYPE, tasks: ENF_TASK_DTYPE
+        (grouped by node, store order). Returns uint8[len(tasks)]: 1 = the task would be REJECTED."""
+        nodes = np.ascontiguousarray(nodes, dtype=ENF_NODE_DTYPE)
+        tasks = np.ascontiguousarray(tasks, dtype=ENF_TASK_DTYPE)
+        out = np.zeros(len(tasks), dtype=np.uint8)
+        self._ck(self.L.swp_enforce(self.h, nodes.ctypes.data, len(nodes), tasks.ctypes.data, len(tasks), out.ctypes.data))
+        return out
 
     def schedule_batch(self, tasks, want_hist=True):
         """tasks: numpy array of TASK_DTYPE. Returns (out_node int32[T], hist uint32[T,8] or None)."""

@@ -3228,6 +3228,40 @@ __global__ void k_commit(u32 n, const DevPlacement* __restrict__ p, int add, i64
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_enforce — constraintenforcer.rejectNoncompliantTasks (constraint_enforcer.go:65-196), one thread per node:
+// the node's tasks in store order, constraint verdicts from the class bitmaps (the same k_constraint_classes the
+// scheduler's ConstraintFilter uses), reservations accounted sequentially against Description.Resources.
+// ---------------------------------------------------------------------------------------------
+struct EnfNode { u32 node, first, count, pad; i64 cpu, mem; };
+struct EnfTask { i64 cpu, mem; u32 cls_con, flags, desired, state; };
+static_assert(sizeof(EnfNode) == 32 && sizeof(EnfTask) == 32, "enforcer record layout");
+#define TASK_STATE_ASSIGNED 192u
+#define TASK_STATE_COMPLETE 576u
+
+__global__ __launch_bounds__(256) void k_enforce(u32 n_enf, u32 n_words, const EnfNode* __restrict__ nodes, const EnfTask* __restrict__ tasks,
+                                                 const u64* __restrict__ con, unsigned char* __restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_enf) return;
+    const EnfNode nd = nodes[i];
+    const u32 w = nd.node >> 6;
+    const u64 bit = 1ull << (nd.node & 63);
+    i64 cpu = nd.cpu, mem = nd.mem;
+    for (u32 t = nd.first; t < nd.first + nd.count; ++t) {
+        const EnfTask tk = tasks[t];
+        unsigned char rej = 0;
+        if (tk.desired < TASK_STATE_ASSIGNED || tk.desired > TASK_STATE_COMPLETE) { out[t] = 0; continue; }   // :118-120
+        if (tk.state >= TASK_STATE_COMPLETE) { out[t] = 0; continue; }                                       // :124-126
+        if (tk.cls_con && !(con[(size_t)tk.cls_con * n_words + w] & bit)) rej = 1;                            // :162-168
+        else if (tk.flags & 1u) {                                                                            // :172-184
+            if (tk.mem > mem) rej = 1;
+            else if (tk.cpu > cpu) rej = 1;
+            else { mem -= tk.mem; cpu -= tk.cpu; }
+        }
+        out[t] = rej;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_check_pair — Pipeline.Process on one (task,node) pair (taskFitNode, scheduler.go:646-654)
 // ---------------------------------------------------------------------------------------------
 struct CheckArgs {

@@ -1616,6 +1616,58 @@ int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int3
     return SWP_OK;
 }
 
+int swp_enforce(swp_engine* e, const swp_enforce_node* nodes, uint32_t n_nodes, const swp_enforce_task* tasks, uint32_t n_tasks,
+                uint8_t* out_reject) {
+    if (!e || (!nodes && n_nodes) || (!tasks && n_tasks) || (!out_reject && n_tasks)) return SWP_EINVAL;
+    if (n_tasks == 0 || n_nodes == 0) {
+        if (n_tasks) std::memset(out_reject, 0, n_tasks);
+        return SWP_OK;
+    }
+    (void)hipSetDevice(e->device);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        if (nodes[i].node >= e->nodes.size() || !e->nodes[nodes[i].node].present) return e->fail(SWP_ENOTFOUND, "enforce: node %u is not in the nodeSet mirror", nodes[i].node);
+        if ((uint64_t)nodes[i].first_task + nodes[i].n_tasks > n_tasks) return e->fail(SWP_EINVAL, "enforce: node %u lists tasks beyond the task array", i);
+    }
+    // the constraint sets in play become classes exactly as for a scheduling batch (one pseudo task per enforce task)
+    uint32_t svc = 0;
+    {
+        static const char kDummy[] = "\0swp-enforce";
+        int rc = swp_intern(e, SWP_SPACE_SERVICE, kDummy, sizeof kDummy - 1, &svc);
+        if (rc) return rc;
+    }
+    std::vector<swp_task_desc> descs(n_tasks);
+    std::memset(descs.data(), 0, descs.size() * sizeof(swp_task_desc));
+    for (uint32_t i = 0; i < n_tasks; ++i) {
+        descs[i].service = svc;
+        descs[i].constraint_set = tasks[i].constraint_set;
+    }
+    int rc = flush_nodes(e);
+    if (rc) return rc;
+    swp_batch b;
+    if ((rc = build_batch(e, descs.data(), n_tasks, &b, nullptr))) return rc;
+    if ((rc = flush_nodes(e))) return rc;
+    if ((rc = upload_batch(e, &b))) return rc;
+    if ((rc = run_classes(e, &b))) return rc;
+    const uint32_t Wn = n_words_of(e->n_nodes);
+    std::vector<EnfNode> en(n_nodes);
+    std::vector<EnfTask> et(n_tasks);
+    for (uint32_t i = 0; i < n_nodes; ++i) en[i] = EnfNode{nodes[i].node, nodes[i].first_task, nodes[i].n_tasks, 0u, nodes[i].cpu, nodes[i].mem};
+    for (uint32_t i = 0; i < n_tasks; ++i)
+        et[i] = EnfTask{tasks[i].cpu, tasks[i].mem, b.rt[i].cls_con, tasks[i].flags & SWP_ENF_RESERVATIONS, tasks[i].desired_state, tasks[i].state};
+    DevBuf d_en, d_et, d_out;
+    if ((rc = upload(e, d_en, en))) return rc;
+    if ((rc = upload(e, d_et, et))) return rc;
+    HIPCHECK(e, d_out.reserve(n_tasks));
+    hipStream_t st = e->stream;
+    HIPCHECK(e, hipMemsetAsync(d_out.p, 0, n_tasks, st));
+    hipLaunchKernelGGL(k_enforce, dim3((n_nodes + 255) / 256), dim3(256), 0, st, n_nodes, Wn, d_en.as<EnfNode>(), d_et.as<EnfTask>(),
+                       b.d_con.as<u64>(), d_out.as<unsigned char>());
+    HIPCHECK(e, hipGetLastError());
+    HIPCHECK(e, hipMemcpyAsync(out_reject, d_out.p, n_tasks, hipMemcpyDeviceToHost, st));
+    HIPCHECK(e, hipStreamSynchronize(st));
+    return SWP_OK;
+}
+
 int swp_stats(swp_engine* e, swp_stats_t* out) {
     if (!e || !out) return SWP_EINVAL;
     e->stats.n_nodes = e->n_present;

@@ -629,6 +629,47 @@ class HostScheduler:
         return decisions
 
 
+def enforce(sched, node_docs, tasks_by_node, services=None):
+    """constraintenforcer.rejectNoncompliantTasks (constraint_enforcer.go:65-196) for many nodes through swp_enforce.
+    node_docs: api.Node docs already known to `sched` (create_node); tasks_by_node: {node id: [api.Task docs]} (sorted here
+    by task ID = the canonical store order); services: {ServiceID: api.Service doc} — the CURRENT specs.
+    Returns {node id: [rejected task ids]} for the ACTIVE nodes (others are skipped, :70-72)."""
+    services = services or {}
+    nrec, trec, owners = [], [], []
+    for nd in node_docs:
+        avail = _get(nd, "Spec", "Availability")
+        if avail not in (None, 0, "ACTIVE"):
+            continue
+        nid = nd["ID"]
+        tasks = sorted(tasks_by_node.get(nid, ()), key=lambda t: t["ID"])
+        res = _get(nd, "Description", "Resources") or {}
+        if res.get("Generic") or any(t.get("AssignedGenericResources") for t in tasks):
+            raise Unsupported("generic resources stay on the Go path")
+        first = len(trec)
+        for t in tasks:
+            svc = services.get(t.get("ServiceID", ""))
+            pl = _get(svc, "Spec", "Task", "Placement") if svc is not None else _get(t, "Spec", "Placement")
+            cset = 0
+            cons = (pl or {}).get("Constraints") or []
+            if cons:
+                parsed = parse_constraints(cons)
+                if parsed is not None:   # `constraints, _ := constraint.Parse(...)`: an error leaves no constraints (:163)
+                    cset = sched.e.constraint_set(sched._constraint_structs(parsed))
+            r = _get(t, "Spec", "Resources", "Reservations")
+            trec.append((int((r or {}).get("NanoCPUs", 0) or 0), int((r or {}).get("MemoryBytes", 0) or 0), cset,
+                         abi.ENF_RESERVATIONS if r is not None else 0, _state(t.get("DesiredState")), _state(_get(t, "Status", "State"))))
+            owners.append((nid, t["ID"]))
+        nrec.append((sched.nodes[nid]["idx"], first, len(trec) - first, 0, int(res.get("NanoCPUs", 0) or 0), int(res.get("MemoryBytes", 0) or 0)))
+    out = {nd["ID"]: [] for nd in node_docs if _get(nd, "Spec", "Availability") in (None, 0, "ACTIVE")}
+    if not trec:
+        return out
+    rej = sched.e.enforce(np.array(nrec, dtype=abi.ENF_NODE_DTYPE), np.array(trec, dtype=abi.ENF_TASK_DTYPE))
+    for (nid, tid), r in zip(owners, rej):
+        if r:
+            out[nid].append(tid)
+    return out
+
+
 def load_workload(sched, wl):
     """Bulk path used by bench.py / large parity tests: nodes through create_node, tasks as one
     descriptor array (per-service spec translated once, then tiled)."""
