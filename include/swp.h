@@ -277,6 +277,12 @@ typedef struct {
 int swp_enforce(swp_engine*, const swp_enforce_node* nodes, uint32_t n_nodes, const swp_enforce_task* tasks, uint32_t n_tasks,
                 uint8_t* out_reject);
 
+/* constraint.NodeMatches(service.constraints, node) for EVERY (constraint set, node) pair: the global orchestrator's
+ * reconciliation sweeps (manager/orchestrator/global/global.go:306, :440, :513 — one NodeMatches per global service
+ * and node). out_bitmaps is [n_sets][n_words] with n_words = ceil(node slots / 64) as reported by swp_stats; bit i of
+ * word w = node index 64w+i. Set 0 (no constraints) matches every present node (NodeMatches(nil) == true). */
+int swp_node_matches(swp_engine*, const uint32_t* constraint_sets, uint32_t n_sets, uint64_t* out_bitmaps, uint32_t n_words);
+
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
     uint64_t batches, tasks, placed, infeasible;

@@ -90,7 +90,7 @@ EXPORTS = [
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
-    "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce",
+    "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce", "swp_node_matches",
     "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check",
 ]
 
@@ -159,6 +159,7 @@ def load_library():
         "swp_commit": ([vp, vp, u32, C.c_int], C.c_int),
         "swp_check_node": ([vp, P(TaskDesc), u32, P(i32)], C.c_int),
         "swp_enforce": ([vp, vp, u32, vp, u32, vp], C.c_int),
+        "swp_node_matches": ([vp, vp, u32, vp, u32], C.c_int),
         "swp_stats": ([vp, P(Stats)], C.c_int),
         "swp_strerror": ([C.c_int], cp),
         "swp_last_error": ([vp], cp),
@@ -325,6 +326,15 @@ class Engine:
         tasks = np.ascontiguousarray(tasks, dtype=ENF_TASK_DTYPE)
         out = np.zeros(len(tasks), dtype=np.uint8)
         self._ck(self.L.swp_enforce(self.h, nodes.ctypes.data, len(nodes), tasks.ctypes.data, len(tasks), out.ctypes.data))
+        return out
+
+    def node_matches(self, constraint_sets):
+        """constraint.NodeMatches for every (set, node) pair: uint64[len(sets), n_words] bitmaps (bit i of word w = node 64w+i)."""
+        sets = np.ascontiguousarray(constraint_sets, dtype=np.uint32)
+        nw = int(self.stats()["n_words"])
+        out = np.zeros((len(sets), nw), dtype=np.uint64)
+        if len(sets):
+            self._ck(self.L.swp_node_matches(self.h, sets.ctypes.data, len(sets), out.ctypes.data, nw))
         return out
 
     def schedule_batch(self, tasks, want_hist=True):

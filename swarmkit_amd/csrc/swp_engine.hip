@@ -1668,6 +1668,41 @@ int swp_enforce(swp_engine* e, const swp_enforce_node* nodes, uint32_t n_nodes, 
     return SWP_OK;
 }
 
+int swp_node_matches(swp_engine* e, const uint32_t* constraint_sets, uint32_t n_sets, uint64_t* out_bitmaps, uint32_t n_words) {
+    if (!e || (!constraint_sets && n_sets) || (!out_bitmaps && n_sets)) return SWP_EINVAL;
+    if (n_sets == 0) return SWP_OK;
+    (void)hipSetDevice(e->device);
+    int rc = flush_nodes(e);
+    if (rc) return rc;
+    const uint32_t Wn = n_words_of(e->n_nodes);
+    if (n_words != Wn) return e->fail(SWP_EINVAL, "node_matches: caller passes %u words per row, the nodeSet has %u", n_words, Wn);
+    if (e->n_nodes == 0) return SWP_OK;
+    uint32_t svc = 0;
+    {
+        static const char kDummy[] = "\0swp-enforce";
+        if ((rc = swp_intern(e, SWP_SPACE_SERVICE, kDummy, sizeof kDummy - 1, &svc))) return rc;
+    }
+    std::vector<swp_task_desc> descs(n_sets);
+    std::memset(descs.data(), 0, descs.size() * sizeof(swp_task_desc));
+    for (uint32_t i = 0; i < n_sets; ++i) {
+        descs[i].service = svc;
+        descs[i].constraint_set = constraint_sets[i];
+    }
+    swp_batch b;
+    if ((rc = build_batch(e, descs.data(), n_sets, &b, nullptr))) return rc;
+    if ((rc = flush_nodes(e))) return rc;
+    if ((rc = upload_batch(e, &b))) return rc;
+    if ((rc = run_classes(e, &b))) return rc;
+    hipStream_t st = e->stream;
+    for (uint32_t i = 0; i < n_sets; ++i) {
+        const uint32_t cls = b.rt[i].cls_con;
+        const void* src = cls ? (const void*)(b.d_con.as<u64>() + (size_t)cls * Wn) : (const void*)e->d_valid.p;   // no constraints: every present node
+        HIPCHECK(e, hipMemcpyAsync(out_bitmaps + (size_t)i * Wn, src, (size_t)Wn * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHECK(e, hipStreamSynchronize(st));
+    return SWP_OK;
+}
+
 int swp_stats(swp_engine* e, swp_stats_t* out) {
     if (!e || !out) return SWP_EINVAL;
     e->stats.n_nodes = e->n_present;

@@ -100,3 +100,40 @@ def test_random_clusters(seed):
         tasks.append(t)
     tasks = list({t["ID"]: t for t in tasks}.values())
     assert engine_enforce(nodes, tasks, services) == oracle_enforce(nodes, tasks, services)
+
+
+def test_node_matches_matrix_equals_per_pair_oracle():
+    """Global orchestrator sweep (global.go:306,440,513): the (constraint set x node) NodeMatches matrix in one call,
+    every cell against the oracle's ConstraintFilter on the same node doc; also the reference's constraint truth tables."""
+    import numpy as np
+    import kat_tables as kt
+    rng = random.Random(77)
+    s = swhost.HostScheduler()
+    nodes = []
+    for i in range(150):
+        labels = {"zone": rng.choice("abc")} if rng.random() < 0.8 else {}
+        d = {"ID": "n%05d" % i, "Role": rng.choice(["WORKER", "MANAGER"]), "Spec": {"Annotations": {"Name": "x", "Labels": labels}},
+             "Status": {"State": orc.READY, "Addr": "10.0.%d.%d" % (rng.randrange(2), i)},
+             "Description": {"Hostname": "h%d" % i, "Platform": {"Architecture": "amd64", "OS": rng.choice(["linux", "windows"])},
+                             "Engine": {"Labels": {"tier": rng.choice(["gold", "tin"])}}}}
+        nodes.append(d)
+        s.create_node(d)
+    lists = [[c] for c in CONS if c != "bogus expr"] + [["node.labels.zone==a", "node.role==manager"], ["node.labels.zone != a", "engine.labels.tier == GOLD"]]
+    sets = [s.e.constraint_set(s._constraint_structs(swhost.parse_constraints(l))) for l in lists] + [0]
+    bm = s.e.node_matches(sets)
+    for r, l in enumerate(lists + [[]]):
+        for i, nd in enumerate(nodes):
+            idx = s.nodes[nd["ID"]]["idx"]
+            got = bool((int(bm[r, idx >> 6]) >> (idx & 63)) & 1)
+            want = True if not l else orc.constraint_filter(l, nd)
+            assert got == want, (l, nd["ID"])
+    # constraint_test.go truth tables, one node at a time
+    for cons, node, want in kt.constraint_cases():
+        if want is None:
+            continue
+        s2 = swhost.HostScheduler()
+        s2.create_node(node)
+        parsed = swhost.parse_constraints(cons)
+        assert parsed is not None
+        row = s2.e.node_matches([s2.e.constraint_set(s2._constraint_structs(parsed))])
+        assert bool(int(row[0, 0]) & 1) == want, (cons, node)
