@@ -383,6 +383,10 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS only: the waves' outstanding global loads (the next task's prefetched rows) and
+// fire-and-forget stores/atomics stay in flight. __syncthreads() would drain them (vmcnt(0)) — ~2 us per task.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int KMAX>
 struct Resolver {
     const ResolveArgs& a;
@@ -414,7 +418,7 @@ struct Resolver {
     __device__ u64 block_min(u64 v) {
         u64 wv = wave_min_u64(v);
         if (lane == 0) red[par * 16 + wave] = wv;
-        __syncthreads();
+        lds_barrier();
         u64 g = red[par * 16];
         for (u32 i = 1; i < nw; ++i) {
             u64 o = red[par * 16 + i];
@@ -435,7 +439,7 @@ struct Resolver {
             while (vm) {
                 int i = __ffsll((long long)vm) - 1;
                 vm &= vm - 1;
-                u32 t = a.total[w * 64 + i];
+                u32 t = __hip_atomic_load(&a.total[w * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 lo = min(lo, t);
                 hi = max(hi, t);
             }
@@ -469,7 +473,7 @@ struct Resolver {
             while (vm) {
                 int i = __ffsll((long long)vm) - 1;
                 vm &= vm - 1;
-                u32 lvl = a.total[w * 64 + i] - base;
+                u32 lvl = __hip_atomic_load(&a.total[w * 64 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
 #pragma unroll
                 for (int b = 0; b < 16; ++b) pl[b] |= (u64)((lvl >> b) & 1u) << i;
             }
@@ -523,6 +527,8 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
         return;
     }
 
+    u32 pend_idx = 0xFFFFFFFFu;   // this thread's last commit whose chain link (log_prev) is still in flight
+    int32_t pend_prev = -1;
     // software prefetch of the next task's rows
     RTask rt_next = a.rt[a.j0];
     u64 Fnx[KMAX], Xnx[KMAX];
@@ -580,22 +586,24 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
             if (owner) {
                 bool ok = true;
                 if (R.touched[w] & bit) {   // F may be stale for this node: re-check the dynamic filters
-                    if (rt.flags & RT_RES) ok = (rt.cpu <= a.cpu[n]) && (rt.mem <= a.mem[n]);
+                    if (rt.flags & RT_RES)
+                        ok = (rt.cpu <= __hip_atomic_load(&a.cpu[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &&
+                             (rt.mem <= __hip_atomic_load(&a.mem[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     if (ok && (rt.flags & RT_PORTS)) {
                         for (u32 p = a.pset_off[rt.pset]; p < a.pset_off[rt.pset + 1]; ++p)
                             if (a.portmap[(size_t)a.pset_ids[p] * a.n_words + w] & bit) ok = false;
                     }
                 }
                 if (ok) {
-                    // residual update == NodeInfo.addTask (nodeinfo.go:108-154)
-                    a.cpu[n] -= rt.cpu;
-                    a.mem[n] -= rt.mem;
+                    // residual update == NodeInfo.addTask (nodeinfo.go:108-154); no-return atomics: nothing to wait for
+                    if (rt.cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rt.cpu));
+                    if (rt.mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rt.mem));
                     R.touched[w] |= bit;
                     if (rt.flags & RT_PORTS)
                         for (u32 p = a.pset_off[rt.pset]; p < a.pset_off[rt.pset + 1]; ++p)
                             a.portmap[(size_t)a.pset_ids[p] * a.n_words + w] |= bit;
                     if (counted) {
-                        a.total[n] += 1;
+                        atomicAdd(a.total + n, 1u);
                         if (!R.bump_level(w, bit)) sh[RS::SH_REBASE] = 1;
                         u64 nx = 0;
                         for (int k = 0; k < KMAX; ++k)
@@ -610,13 +618,16 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
                     }
                     a.log_node[ncommit] = n;
                     a.log_task[ncommit] = gj;
-                    a.log_prev[ncommit] = a.last[n];
-                    a.last[n] = (int32_t)ncommit;
+                    // chain link: the exchange's result is stored when this thread commits next (or at the end), so that
+                    // its latency never sits between two barriers
+                    if (pend_idx != 0xFFFFFFFFu) a.log_prev[pend_idx] = pend_prev;
+                    pend_prev = (int32_t)atomicExch(reinterpret_cast<u32*>(&a.last[n]), ncommit);
+                    pend_idx = ncommit;
                     a.out_node[gj] = (int32_t)n;
                 }
                 sh[RS::SH_OK] = ok ? 1u : 0u;
             }
-            __syncthreads();
+            lds_barrier();
             bool ok = sh[RS::SH_OK] != 0;
             if (ok) { placed = true; break; }
             if (owner)
@@ -665,22 +676,23 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
                 u32 n = (u32)glo, w = n >> 6;
                 u64 bit = 1ull << (n & 63);
                 if ((w % B) == tid) {
-                    a.cpu[n] -= rt.cpu;
-                    a.mem[n] -= rt.mem;
+                    if (rt.cpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rt.cpu));
+                    if (rt.mem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rt.mem));
                     R.touched[w] |= bit;
                     if (rt.flags & RT_PORTS)
                         for (u32 p = a.pset_off[rt.pset]; p < a.pset_off[rt.pset + 1]; ++p)
                             a.portmap[(size_t)a.pset_ids[p] * a.n_words + w] |= bit;
                     if (counted) {
-                        a.total[n] += 1;
+                        atomicAdd(a.total + n, 1u);
                         if (!R.bump_level(w, bit)) sh[RS::SH_REBASE] = 1;
                         u32 sv = __hip_atomic_load(&a.list_svc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&a.list_svc[e], sv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     a.log_node[ncommit] = n;
                     a.log_task[ncommit] = gj;
-                    a.log_prev[ncommit] = a.last[n];
-                    a.last[n] = (int32_t)ncommit;
+                    if (pend_idx != 0xFFFFFFFFu) a.log_prev[pend_idx] = pend_prev;
+                    pend_prev = (int32_t)atomicExch(reinterpret_cast<u32*>(&a.last[n]), ncommit);
+                    pend_idx = ncommit;
                     a.out_node[gj] = (int32_t)n;
                 }
                 placed = true;
@@ -709,6 +721,7 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
             ++ninf;
         }
     }
+    if (pend_idx != 0xFFFFFFFFu) a.log_prev[pend_idx] = pend_prev;
     if (tid == 0) {
         a.ctl->ncommit = ncommit;
         a.ctl->ninf = ninf;
