@@ -387,6 +387,8 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 // fire-and-forget stores/atomics stay in flight. __syncthreads() would drain them (vmcnt(0)) — ~2 us per task.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+__device__ __forceinline__ u32 wave_min_u32_dpp(u32 v);
+
 template <int KMAX>
 struct Resolver {
     const ResolveArgs& a;
@@ -428,6 +430,17 @@ struct Resolver {
         return g;
     }
 
+    // the same for a 32-bit key: six DPP steps instead of twelve ds_bpermute round trips
+    __device__ u32 block_min32(u32 v) {
+        u32 wv = wave_min_u32_dpp(v);
+        if (lane == 0) reinterpret_cast<u32*>(red)[par * 32 + wave] = wv;
+        lds_barrier();
+        u32 g = reinterpret_cast<u32*>(red)[par * 32];
+        for (u32 i = 1; i < nw; ++i) g = min(g, reinterpret_cast<u32*>(red)[par * 32 + i]);
+        par ^= 1;
+        return g;
+    }
+
     // (re)build the level planes from total[] — called at window start and on level overflow.
     // Returns false (uniformly) when the level span does not fit nb_alloc planes.
     __device__ bool build_planes() {
@@ -460,9 +473,11 @@ struct Resolver {
         if (lo == 0xFFFFFFFFu) { lo = 0; hi = 0; }   // no valid node at all
         u32 span = hi - lo;
         u32 need = 32 - __clz(span | 1u);            // bits to hold span (≥1)
-        if (need > a.nb_alloc) return false;
+        const u32 idx_bits = 32 - __clz((a.n_words * 64) | 1u);
+        const u32 capb = min(a.nb_alloc, 32u - idx_bits);   // (level << idx_bits | node) must fit 32 bits (block_min32)
+        if (need > capb) return false;
         base = lo;
-        NB = min(a.nb_alloc, need + 1);              // one spare bit: room to double before the next rebase
+        NB = min(capb, need + 1);                    // one spare bit: room to double before the next rebase
         for (int k = 0; k < KMAX; ++k) {
             u32 w = tid + k * B;
             if (w >= a.n_words) break;
@@ -527,6 +542,7 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
         return;
     }
 
+    const u32 idx_bits = 32 - __clz((a.n_words * 64) | 1u), idx_mask = (1u << idx_bits) - 1u;
     u32 pend_idx = 0xFFFFFFFFu;   // this thread's last commit whose chain link (log_prev) is still in flight
     int32_t pend_prev = -1;
     // software prefetch of the next task's rows
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
 
         // ---------------- plain path: nodes with svcCount == 0 and < MAX_FAILURES failures ----------------
         for (;;) {
-            u64 best = KEY_NONE;
+            u32 best = 0xFFFFFFFFu;
             for (int k = 0; k < KMAX; ++k) {
                 u64 m = mk[k];
                 if (m) {
@@ -573,13 +589,13 @@ __global__ __launch_bounds__(1024) void k_resolve(ResolveArgs a) {
                         if (t) m = t;
                         else lvl |= 1u << b;
                     }
-                    u64 cand = ((u64)lvl << 32) | (u64)(w * 64 + (u32)(__ffsll((long long)m) - 1));
-                    best = cand < best ? cand : best;
+                    u32 cand = (lvl << idx_bits) | (w * 64 + (u32)(__ffsll((long long)m) - 1));
+                    best = min(best, cand);
                 }
             }
-            u64 g = R.block_min(best);
-            if (g == KEY_NONE) break;
-            u32 n = (u32)g, w = n >> 6;
+            u32 g = R.block_min32(best);
+            if (g == 0xFFFFFFFFu) break;
+            u32 n = g & idx_mask, w = n >> 6;
             u64 bit = 1ull << (n & 63);
             bool owner = (w % B) == tid;
             int ko = (int)(w / B);
