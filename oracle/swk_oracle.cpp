@@ -1048,6 +1048,27 @@ bool Scheduler::create_task(const TaskPtr& t) {
     return false;
 }
 
+// setupTasksList, scheduler.go:88-124: what Run() does with every task found in the store when it starts. Unlike the
+// createTask event it also ignores tasks that are still PENDING although their desired state is already past
+// COMPLETED (:98-103). Assigned tasks end up in the node's NodeInfo (buildNodeSet -> newNodeInfo == addTask).
+bool Scheduler::setup_task(const TaskPtr& t) {
+    if (t->state < TaskStatePending || t->state > TaskStateRunning) return false;
+    if (t->state == TaskStatePending && t->desired_state > TaskStateCompleted) return false;
+    all_tasks_[t->id] = t;
+    if (t->node_id.empty()) {
+        enqueue(t);
+        return true;
+    }
+    if (t->state == TaskStatePending) {
+        preassigned_[t->id] = true;
+        pending_preassigned_.put(t->id, t);
+        return false;
+    }
+    NodeInfo ni;
+    if (node_info(t->node_id, &ni) && ni.add_task(t)) ns_update(ni);
+    return false;
+}
+
 // updateTask, scheduler.go:285-349
 bool Scheduler::update_task(const TaskPtr& t) {
     if (t->state < TaskStatePending) return false;

@@ -247,6 +247,7 @@ class Scheduler {
     void create_or_update_node(const NodePtr& n);
     void delete_node(const std::string& id);
     bool create_task(const TaskPtr& t);
+    bool setup_task(const TaskPtr& t);   // setupTasksList, scheduler.go:88-124: a task of the store at scheduler start
     bool update_task(const TaskPtr& t);
     bool delete_task_event(const TaskPtr& t);
     void set_service(const std::string& id, const ServiceRec& rec) { services_[id] = rec; }

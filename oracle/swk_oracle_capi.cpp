@@ -279,7 +279,17 @@ std::string encode_node_info(const NodeInfo& ni) {
             first = false;
             o += "[" + std::to_string(kv.first.protocol) + "," + std::to_string(kv.first.port) + "]";
         }
-    o += "]}";
+    // len(recentFailures[versionedService]) per bucket, as the reference's tests read it (scheduler_test.go:1593-1596)
+    o += "],\"RecentFailures\":{";
+    first = true;
+    if (ni.recent_failures)
+        for (auto& kv : *ni.recent_failures) {
+            if (!first) o += ",";
+            first = false;
+            orcjson::escape_into(o, kv.first.service_id + "@" + std::to_string(kv.first.spec_version));
+            o += ":" + std::to_string(kv.second.size());
+        }
+    o += "}}";
     return o;
 }
 
@@ -340,6 +350,11 @@ int orc_create_task(void* s, const char* task_json) {
     int r = 0;
     int rc = guarded([&] { r = static_cast<Scheduler*>(s)->create_task(decode_task(*orcjson::parse(task_json))); });
     return rc ? rc : r;
+}
+int orc_setup_task(void* s, const char* task_json) {
+    bool r = false;
+    int rc = guarded([&] { r = static_cast<Scheduler*>(s)->setup_task(decode_task(*orcjson::parse(task_json))); });
+    return rc ? rc : (r ? 1 : 0);
 }
 int orc_update_task(void* s, const char* task_json) {
     int r = 0;

@@ -232,7 +232,8 @@ class HostScheduler:
                 by_service[sid] = c
         return {"ID": nid, "ActiveTasksCount": row.total, "ActiveTasksCountByService": by_service,
                 "AvailableResources": {"NanoCPUs": row.cpu, "MemoryBytes": row.mem, "Generic": []},
-                "Tasks": sorted(ent["tasks"])}
+                "Tasks": sorted(ent["tasks"]),
+                "RecentFailures": {"%s@%d" % (sid, ver): len(ts) for (sid, ver), ts in ent["failures"].items()}}
 
     # ------------------------------------------------------------------------------ NodeInfo.addTask/removeTask
     def _port_set(self, task):
@@ -331,6 +332,13 @@ class HostScheduler:
         if ent is not None:
             self._add_task(ent, t)
         return False
+
+    def setup_task(self, t):
+        """setupTasksList, scheduler.go:88-124: a task found in the store when the scheduler starts. Differs from the
+        createTask event in one rule: a task still PENDING whose desired state is already past COMPLETED is ignored."""
+        if _state(_get(t, "Status", "State")) == PENDING and _state(t.get("DesiredState")) > COMPLETE:
+            return False
+        return self.create_task(t)
 
     def update_task(self, t):
         """scheduler.go:285-349."""
@@ -575,6 +583,19 @@ class HostScheduler:
     def _run_groups(self, groups, decisions):
         """groups: list of [(tid, task)...] sharing a spec; one swp_schedule_groups call, groups in order."""
         if not groups:
+            return
+        # one device call must not mix spec versions of one service (the failure buckets are per (service, version)):
+        # split the ordered group list into consecutive runs that respect this, keeping the order
+        seen, cut = {}, None
+        for i, g in enumerate(groups):
+            sid, ver = g[0][1].get("ServiceID", ""), _get(g[0][1], "SpecVersion", "Index", default=0)
+            if seen.setdefault(sid, ver) != ver:
+                cut = i
+                break
+        if cut is not None:
+            self._run_groups(groups[:cut], decisions)
+            self._push_failures({g[0][1].get("ServiceID", "") for g in groups[cut:]})
+            self._run_groups(groups[cut:], decisions)
             return
         descs = np.concatenate([self.task_desc(g[0][1]) for g in groups])
         sizes = np.array([len(g) for g in groups], dtype=np.uint32)

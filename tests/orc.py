@@ -43,7 +43,7 @@ def lib():
         L.orc_set_now.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         L.orc_get_now.argtypes = [ctypes.c_void_p]
         L.orc_get_now.restype = ctypes.c_int64
-        for name in ("orc_create_or_update_node", "orc_delete_node", "orc_create_task", "orc_update_task",
+        for name in ("orc_create_or_update_node", "orc_delete_node", "orc_create_task", "orc_setup_task", "orc_update_task",
                      "orc_delete_task", "orc_delete_service", "orc_node_info"):
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         L.orc_set_service.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint64]
@@ -105,6 +105,10 @@ class Oracle:
 
     def create_task(self, task):
         return bool(_check(self.L.orc_create_task(self.h, _j(task))))
+
+    def setup_task(self, task):
+        """A task that is already in the store when the scheduler starts (setupTasksList, scheduler.go:88-124)."""
+        return bool(_check(self.L.orc_setup_task(self.h, _j(task))))
 
     def update_task(self, task):
         return bool(_check(self.L.orc_update_task(self.h, _j(task))))

@@ -144,3 +144,7 @@ def test_churn_rounds():
         a, b = o.node_info(wl.node_id(i)), e.node_info(wl.node_id(i))
         assert a["ActiveTasksCount"] == b["ActiveTasksCount"] and a["AvailableResources"]["NanoCPUs"] == b["AvailableResources"]["NanoCPUs"]
         assert a["AvailableResources"]["MemoryBytes"] == b["AvailableResources"]["MemoryBytes"]
+
+
+def test_multiple_preferences_scale_up():
+    sc.scenario_multiple_preferences_scale_up(factory)

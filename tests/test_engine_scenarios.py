@@ -59,3 +59,40 @@ def test_constraint_truth_tables_on_device():
         ff = s.e.check_node(d, s.nodes[node["ID"]]["idx"])
         assert (ff == -1) == want, (cons, node, ff)
         assert ff in (-1, 3), (cons, ff)
+
+
+# ---- the remaining scheduler_test.go scenarios (same code as tests/test_oracle_scheduler.py) -------------
+def test_faulty_node_spec_version():
+    sc.scenario_faulty_node_spec_version(factory)
+
+
+def test_resource_constraint_ha():
+    sc.scenario_resource_constraint_ha(factory, with_generic=False)
+
+
+def test_resource_constraint_dead_task():
+    sc.scenario_resource_constraint_dead_task(factory, with_generic=False)
+
+
+def test_preexisting_dead_task():
+    sc.scenario_preexisting_dead_task(factory, with_generic=False)
+
+
+def test_unassigned_map():
+    sc.scenario_unassigned_map(factory)
+
+
+def test_preassigned_tasks():
+    sc.scenario_preassigned_tasks(factory)
+
+
+def test_ignore_tasks():
+    sc.scenario_ignore_tasks(factory)
+
+
+def test_unscheduleable_task():
+    sc.scenario_unscheduleable_task(factory)
+
+
+def test_plugin_constraint():
+    sc.scenario_plugin_constraint(factory)
