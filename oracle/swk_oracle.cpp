@@ -497,8 +497,8 @@ static bool sanitize_resource(const GenericList& node_res, const GenericResource
     return false;   // removed
 }
 
-// Reclaim = reclaimResources + sanitize, resource_management.go:75-153
-void generic_reclaim(GenericList* node_avail, const GenericList& task_assigned, const GenericList& node_res) {
+// reclaimResources, resource_management.go:87-117
+void generic_reclaim_resources(GenericList* node_avail, const GenericList& task_assigned) {
     for (const GenericResource& res : task_assigned) {
         if (!res.named) {
             auto nrs = get_resource_idx(res.kind, *node_avail);
@@ -511,6 +511,10 @@ void generic_reclaim(GenericList* node_avail, const GenericList& task_assigned, 
             node_avail->push_back(res);
         }
     }
+}
+
+// sanitize, resource_management.go:119-153
+void generic_sanitize(const GenericList& node_res, GenericList* node_avail) {
     GenericList sanitized;
     std::map<std::string, bool> kind_sanitized;
     size_t w = 0;
@@ -527,6 +531,12 @@ void generic_reclaim(GenericList* node_avail, const GenericList& task_assigned, 
     }
     node_avail->resize(w);
     node_avail->insert(node_avail->end(), sanitized.begin(), sanitized.end());
+}
+
+// Reclaim = reclaimResources + sanitize, resource_management.go:75-85
+void generic_reclaim(GenericList* node_avail, const GenericList& task_assigned, const GenericList& node_res) {
+    generic_reclaim_resources(node_avail, task_assigned);
+    generic_sanitize(node_res, node_avail);
 }
 
 // ============================================================================

@@ -161,6 +161,8 @@ bool generic_has_enough(const Resources& node_avail, const GenericResource& task
 void generic_claim(GenericList* node_avail, GenericList* task_assigned, const GenericList& reservations);
 void generic_consume(GenericList* node_avail, const GenericList& res);
 void generic_reclaim(GenericList* node_avail, const GenericList& task_assigned, const GenericList& node_res);
+void generic_reclaim_resources(GenericList* node_avail, const GenericList& task_assigned);   // resource_management.go:87-117
+void generic_sanitize(const GenericList& node_res, GenericList* node_avail);                  // resource_management.go:119-153
 
 // ---- manager/scheduler/nodeinfo.go -------------------------------------------
 struct HostPortSpec {

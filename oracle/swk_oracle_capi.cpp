@@ -563,4 +563,37 @@ int orc_enforce(const char* doc_json) {
     });
 }
 
+// api/genericresource as pure functions (resource_management_test.go / helpers_test.go / validate_test.go).
+// doc = {"op": ..., "node": [...], "assigned": [...], "res": [...], "nodeRes": [...]}; result = {"node": [...], "assigned": [...], "ok": bool}
+int orc_generic(const char* doc_json) {
+    return guarded([&] {
+        auto d = orcjson::parse(doc_json);
+        bool nil = false;
+        const std::string op = d->str_or("op", "");
+        GenericList node = decode_generic(d->obj_or_null("node"), &nil);
+        GenericList assigned = decode_generic(d->obj_or_null("assigned"), &nil);
+        GenericList res = decode_generic(d->obj_or_null("res"), &nil);
+        GenericList node_res = decode_generic(d->obj_or_null("nodeRes"), &nil);
+        bool ok = true;
+        if (op == "consume") generic_consume(&node, res);                               // helpers.go:58-84
+        else if (op == "claim") generic_claim(&node, &assigned, res);                   // resource_management.go:11-33
+        else if (op == "reclaim_resources") generic_reclaim_resources(&node, assigned); // :87-117
+        else if (op == "sanitize") generic_sanitize(node_res, &node);                   // :119-153
+        else if (op == "reclaim") generic_reclaim(&node, assigned, node_res);           // :75-85
+        else if (op == "has_resource") ok = !res.empty() && generic_has_resource(res[0], node);   // validate.go:54-85
+        else if (op == "has_enough") {                                                  // validate.go:24-52
+            Resources r;
+            r.generic = node;
+            r.generic_nil = false;
+            bool err = false;
+            ok = !res.empty() && generic_has_enough(r, res[0], &err) && !err;
+        } else throw std::runtime_error("unknown generic op " + op);
+        g_out = "{\"node\":";
+        encode_generic(g_out, node);
+        g_out += ",\"assigned\":";
+        encode_generic(g_out, assigned);
+        g_out += std::string(",\"ok\":") + (ok ? "true" : "false") + "}";
+    });
+}
+
 }  // extern "C"

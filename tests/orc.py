@@ -59,6 +59,7 @@ def lib():
         L.orc_equal_fold.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         L.orc_pipeline_process.argtypes = [ctypes.c_char_p]
         L.orc_enforce.argtypes = [ctypes.c_char_p]
+        L.orc_generic.argtypes = [ctypes.c_char_p]
         L.orc_nodeinfo_ops.argtypes = [ctypes.c_char_p]
         L.orc_tree.argtypes = [ctypes.c_char_p]
         _lib = L
@@ -171,6 +172,12 @@ def constraint_match(expr, what):
 
 def equal_fold(a, b):
     return bool(lib().orc_equal_fold(a.encode(), b.encode()))
+
+
+def generic(op, node=(), assigned=(), res=(), node_res=()):
+    """api/genericresource pure functions. Returns {"node": [...], "assigned": [...], "ok": bool}."""
+    _check(lib().orc_generic(_j({"op": op, "node": list(node), "assigned": list(assigned), "res": list(res), "nodeRes": list(node_res)})))
+    return json.loads(lib().orc_result().decode())
 
 
 def enforce(node, tasks, services=None):
