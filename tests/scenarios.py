@@ -85,12 +85,18 @@ def scenario_basic(factory):
     a = assignments(s.tick())
     assert [d["NodeID"] for d in a] == ["id5"]
 
-    # :264-331 — deleted node never gets tasks
+    # :333-368 — a node created READY and immediately taken DOWN never gets the next task
     s.create_node(node("id6"))
-    s.delete_node("id6")
+    s.update_node({"ID": "id6", "Status": {"State": orc.DOWN}})
     s.create_task(pending("id8"))
     a = assignments(s.tick())
-    assert a[0]["NodeID"] != "id6"
+    assert len(a) == 1 and a[0]["NodeID"] != "id6"
+    # (extra) a deleted node never gets tasks either
+    s.create_node(node("id7"))
+    s.delete_node("id7")
+    s.create_task(pending("id9"))
+    a = assignments(s.tick())
+    assert len(a) == 1 and a[0]["NodeID"] not in ("id6", "id7")
 
 
 def scenario_ha(factory, use_spec_version):
