@@ -70,7 +70,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--order", default="rr", choices=["rr", "major"], help="task order: round-robin over services (SURVEY 8d) or service-major")
-    ap.add_argument("--mode", default="one-off", choices=["one-off", "grouped", "enforce"],
+    ap.add_argument("--rounds", type=int, default=20, help="churn rounds (--mode churn; BASELINE configs[4] uses 100)")
+    ap.add_argument("--mode", default="one-off", choices=["one-off", "grouped", "enforce", "churn"],
                     help="one-off (headline, SURVEY 8d primary mode); grouped: S groups of T/S tasks through swp_schedule_groups (secondary mode); "
                          "enforce: the constraint enforcer's start-up sweep (SURVEY 8f-1) over the cluster the placement produced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,6 +98,47 @@ def main():
     t0 = time.perf_counter()
     descs = host.load_workload(sched, wl)
     t_host_prep = time.perf_counter() - t0
+    if args.mode == "churn":
+        # BASELINE configs[4] / SURVEY 8d cfg5: place the batch once, then rounds of {reactivate the previous round's
+        # drained nodes, drain a seeded random 10 % of the nodes, remove the tasks on them, re-place as many new tasks}.
+        # Exercises the incremental path (swp_node_update_dynamic, swp_commit(remove), swp_schedule_batch), timed end to end.
+        import numpy as np
+        out, _h = eng.schedule_batch(descs, want_hist=False)
+        assign = out.astype(np.int64).copy()          # task -> node (or -1)
+        svc_of = np.array([wl.task_service(j) for j in range(wl.T)])
+        rng = np.random.default_rng(wl.seed)
+        prev = np.zeros(0, dtype=np.int64)
+        replaced = 0
+        t_rounds = []
+        for rnd in range(args.rounds):
+            t0 = time.perf_counter()
+            for n in prev:                             # reactivate
+                row = eng.node_get(int(n))
+                eng.node_update_dynamic(int(n), row.flags | abi.NODE_READY, row.cpu, row.mem, row.total)
+            drained = rng.choice(wl.N, size=max(wl.N // 10, 1), replace=False)
+            for n in drained:                          # Availability = DRAIN
+                row = eng.node_get(int(n))
+                eng.node_update_dynamic(int(n), row.flags & ~abi.NODE_READY, row.cpu, row.mem, row.total)
+            gone = np.nonzero(np.isin(assign, drained))[0]
+            if len(gone):
+                pl = np.zeros(len(gone), dtype=abi.PLACEMENT_DTYPE)
+                pl["node"], pl["service"] = assign[gone], descs["service"][gone]
+                pl["cpu"], pl["mem"], pl["counted"] = descs["cpu"][gone], descs["mem"][gone], 1
+                eng.commit(pl, add=False)              # NodeInfo.removeTask for every task on a drained node
+                new_out, _h = eng.schedule_batch(descs[gone], want_hist=False)   # as many new tasks of the same services
+                assign[gone] = new_out
+                replaced += len(gone)
+            prev = drained
+            t_rounds.append(time.perf_counter() - t0)
+        tt = sum(t_rounds)
+        print(json.dumps({"metric": "reschedule churn: placements/sec over rounds of {drain 10 % of the nodes, remove their tasks, re-place} (end to end)",
+                          "value": replaced / tt if tt else 0.0, "unit": "placements/s", "n_gpus": 1, "steps": args.rounds, "warmup": 0,
+                          "ms_per_step": 1e3 * tt / max(args.rounds, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "int64", "data": "synthetic",
+                          "config": dict(wl.describe(), mode="churn", rounds=args.rounds, replaced=int(replaced)),
+                          "still_placed": int((assign >= 0).sum())}))
+        ranks.close()
+        return
     if args.mode == "enforce":
         # constraintenforcer.rejectNoncompliantTasks for EVERY node (the enforcer's start-up sweep,
         # constraint_enforcer.go:45-52) after the batch has been placed: tasks-on-node x (current service constraints +
