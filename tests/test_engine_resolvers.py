@@ -34,9 +34,9 @@ def test_variants_agree_with_oracle(resolver_env, variant, name, T, N, kw):
 
 
 # node counts that land on K = 1..6 words per lane (64 nodes per word, 64 lanes), incl. word-boundary sizes
-@pytest.mark.parametrize("N", [1, 63, 64, 65, 4096, 4100, 8200, 12400, 16500, 20500])
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 4096, 4100, 8200, 12400, 16500, 20500, 26000, 30000, 40000])
 def test_words_per_lane(N):
-    T = 1200 if N > 5000 else 2500
+    T = 2500 if N <= 5000 else (1200 if N <= 21000 else 700)
     wl = synth.Workload("cfg3", T=T, N=N)
     op, oe, _ = pu.oracle_run(wl)
     ep, ee, *_ = pu.engine_run(wl)
