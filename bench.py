@@ -298,7 +298,7 @@ def main():
         "resolver": {"verify_retries": st["verify_retries"] // max(st["resolve_launches"] // max(windows, 1), 1),
                      "slow_path_tasks": st["slow_path_tasks"] // max(st["resolve_launches"] // max(windows, 1), 1)},
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bounded sample, ~15 s of one host core)
         result["cpu_baseline"] = cpu_baseline(wl)
     if args.check and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
