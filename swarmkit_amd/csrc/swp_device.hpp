@@ -73,7 +73,7 @@ struct DevConstraint {   // 48 B
 };
 
 struct Ctl {
-    u32 ncommit, ninf, error, pad0;
+    u32 ncommit, ninf, error, resume;   // resume: first task NOT processed when `error` stopped a resolver (host continues from there)
     u64 verify_retries, slow_tasks, rebases, generic_tasks, spin_waits, pad1;
     u64 cyc[8];   // dbg&16: cycles spent in resolver sections
 };
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(64) void k_resolve1(ResolveArgs a) {
         return true;
     };
     if (!build_planes()) {
-        if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+        if (lane == 0) { a.ctl->error = ERR_LEVEL_RANGE; a.ctl->resume = a.j0; }
         return;
     }
 
@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(64) void k_resolve1(ResolveArgs a) {
             ++st_rebase;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
             if (!build_planes()) {
-                if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+                if (lane == 0) { a.ctl->error = ERR_LEVEL_RANGE; a.ctl->resume = a.j0 + j; }   // j tasks are done
                 fatal = true;
             }
         }
@@ -1441,6 +1441,7 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
     if (!build_planes()) {
         if (lane == 0) {
             a.ctl->error = ERR_LEVEL_RANGE;
+            a.ctl->resume = a.j0;   // nothing of this window was touched
             __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
@@ -1721,7 +1722,7 @@ __global__ __launch_bounds__(128) void k_resolve2(ResolveArgs a) {
             flush();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!build_planes()) {
-                if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+                if (lane == 0) { a.ctl->error = ERR_LEVEL_RANGE; a.ctl->resume = a.j0 + j + 1; }   // this task is committed
                 fatal = true;
             } else derive_masks(0);
         }
@@ -2103,7 +2104,7 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
     u32 tin = 0, bdone = 0;   // task index inside the block, blocks finished
     // Generic path / rebase only: memory must reflect every commit so far. The pending commits of the current block
     // are applied here (one per lane); the finished blocks are the committer's — wait until it reports them visible.
-    bool fatal = false;
+    bool fatal = false, soft_stop = false;
     auto flush = [&]() __attribute__((always_inline)) {
         if (ncommit != applied) {
             const u32 last_c = ncommit - 1;
@@ -2121,6 +2122,7 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
     if (!build_planes()) {
         if (lane == 0) {
             a.ctl->error = ERR_LEVEL_RANGE;
+            a.ctl->resume = a.j0;   // nothing of this window was touched
             __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
@@ -2454,8 +2456,11 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
                         flush();
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         if (!build_planes()) {
-                            if (lane == 0) a.ctl->error = ERR_LEVEL_RANGE;
+                            // the spread outgrew the register planes: stop after this (committed) task; the host
+                            // continues from `resume` with the 16-plane workgroup resolver
+                            if (lane == 0) { a.ctl->error = ERR_LEVEL_RANGE; a.ctl->resume = a.j0 + j + 1; }
                             fatal = true;
+                            soft_stop = true;
                         } else derive_masks(0);
                     } else if (counted) {
                         // a plain pick at another level re-centres the hot level there (nodes below stay exact through BELOW)
@@ -2521,8 +2526,10 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
             R2_TICK(5);
         }
     }
+    // pending commits of a partial block + the committer's finished blocks (after a soft stop the helper waves are
+    // still alive: release them only afterwards)
+    if (!fatal || soft_stop) { fatal = false; flush(); fatal = fatal || soft_stop; }
     if (fatal) __hip_atomic_store(&flags_lds[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (!fatal) flush();   // nothing pending after the last block end; waits for the committer's last block
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     for (u32 n2 = lane; n2 < a.n_nodes; n2 += 64) a.last[n2] = last_lds[n2];
     if (lane == 0) {

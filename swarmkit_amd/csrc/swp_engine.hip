@@ -710,14 +710,16 @@ int batch_run(swp_engine* e, swp_batch* b) {
     }
     if (variant == 1 && !one_wave) variant = 0;
     if (prof) {
-        while (e->ev_pool.size() < (size_t)4 * b->n_windows) {
+        while (e->ev_pool.size() < (size_t)4 * (2 * b->n_windows + 2)) {   // + the windows of a fall-back pass
             hipEvent_t x;
             HIPCHECK(e, hipEventCreate(&x));
             e->ev_pool.push_back(x);
         }
     }
-    for (uint32_t wi = 0; wi < b->n_windows; ++wi) {
-        uint32_t j0 = wi * b->window, cnt = std::min(b->window, T - j0);
+    uint32_t wi = 0;   // windows launched so far (profiling slots)
+    auto run_windows = [&](uint32_t start, int variant) -> int {
+    for (uint32_t j0 = start; j0 < T; j0 += b->window, ++wi) {
+        const uint32_t cnt = std::min(b->window, T - j0);
         ScanArgs sa{};
         sa.n_nodes = N;
         sa.n_words = Wn;
@@ -808,12 +810,28 @@ int batch_run(swp_engine* e, swp_batch* b) {
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_resolve launch: %s", hipGetErrorString(r));
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
     }
-    if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
+    return SWP_OK;
+    };
+    rc = run_windows(0, variant);
+    if (rc) return rc;
 
     // explain pass: needs the number of unplaceable tasks (one small D2H, once per batch)
     Ctl ctl{};
     HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
     HIPCHECK(e, hipStreamSynchronize(st));
+    if (ctl.error == ERR_LEVEL_RANGE && variant != 0 && ctl.resume < T) {
+        // The per-node task-count spread outgrew the 8 register planes of the wave resolvers (255 levels). The kernel
+        // stopped cleanly after task `resume` - 1 and every later window returned at once: carry on from there with the
+        // workgroup resolver (16 planes in LDS).
+        const uint32_t zero = 0;
+        HIPCHECK(e, hipMemcpyAsync((char*)b->d_ctl.p + offsetof(Ctl, error), &zero, 4, hipMemcpyHostToDevice, st));
+        variant = 0;
+        rc = run_windows(ctl.resume, 0);
+        if (rc) return rc;
+        HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
+        HIPCHECK(e, hipStreamSynchronize(st));
+    }
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
     if (ctl.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the level planes that fit in LDS");
     if (ctl.ninf) {
         ExplainArgs xa{};
@@ -883,10 +901,10 @@ int batch_run(swp_engine* e, swp_batch* b) {
         (void)hipEventElapsedTime(&d, e->ev[2], e->ev[3]);
         (void)hipEventElapsedTime(&t, e->ev[0], e->ev[3]);
         float scan_sum = 0, res_sum = 0;
-        for (uint32_t wi = 0; wi < b->n_windows; ++wi) {
+        for (uint32_t q = 0; q < wi; ++q) {
             float x = 0, y = 0;
-            (void)hipEventElapsedTime(&x, e->ev_pool[4 * wi + 0], e->ev_pool[4 * wi + 1]);
-            (void)hipEventElapsedTime(&y, e->ev_pool[4 * wi + 2], e->ev_pool[4 * wi + 3]);
+            (void)hipEventElapsedTime(&x, e->ev_pool[4 * q + 0], e->ev_pool[4 * q + 1]);
+            (void)hipEventElapsedTime(&y, e->ev_pool[4 * q + 2], e->ev_pool[4 * q + 3]);
             scan_sum += x;
             res_sum += y;
         }

@@ -1,5 +1,6 @@
 """GPU: swp_enforce (k_enforce) vs the oracle's rejectNoncompliantTasks — the reference's enforcer tests through the
 engine, and seeded random clusters (labels, roles, constraints from current service specs, reservations, task states)."""
+import os
 import random
 
 import pytest
@@ -66,7 +67,7 @@ CONS = ["node.labels.zone==a", "node.labels.zone!=b", "node.role==manager", "nod
         "bogus expr", "node.labels.zone==a"]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
 def test_random_clusters(seed):
     rng = random.Random(0xE4F0 + seed)
     nodes = []

@@ -1,6 +1,7 @@
 """GPU: seeded random event scripts through the oracle and the engine — mixed grouped / one-off services with
 random filters and spread preferences, several ticks, node drains / removals / re-adds and task deletions in
 between. Every tick's decisions (node, error string, state) must agree."""
+import os
 import random
 
 import pytest
@@ -80,7 +81,7 @@ def service_spec(rng):
     return t
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "64"))))   # SWP_FUZZ_SEEDS=1000 for a soak
 def test_random_event_scripts(seed):
     rng = random.Random(0xC0FFEE + seed)
     o, e = orc.Oracle(), swhost.HostScheduler(window=rng.choice([0, 0, 7, 64, 300]))

@@ -62,3 +62,27 @@ def test_small_windows_block_edges(window):
     op, oe, _ = pu.oracle_run(wl)
     ep, ee, *_ = pu.engine_run(wl, window=window)
     pu.assert_same(op, oe, ep, ee)
+
+
+@pytest.mark.parametrize("window", [0, 64, 300])
+def test_level_spread_beyond_the_register_planes(window):
+    """One node keeps its count (it is DOWN) while the others take hundreds of tasks: the per-node spread outgrows the
+    255 levels of the wave resolvers in the middle of a window. The engine must carry on with the 16-plane workgroup
+    resolver from the task where the wave resolver stopped — same placements as the oracle, no error."""
+    import orc
+    from swarmkit_amd import host as swhost
+    o, e = orc.Oracle(), swhost.HostScheduler(window=window)
+    docs = [{"ID": "n0", "Status": {"State": orc.READY}}, {"ID": "n1", "Status": {"State": orc.DOWN}}, {"ID": "n2", "Status": {"State": orc.READY}}]
+    for s in (o, e):
+        for d in docs:
+            s.create_node(d)
+        s.set_service("svc")
+    for rnd, cnt in enumerate((350, 400, 250)):
+        for j in range(cnt):
+            t = {"ID": "t%d_%04d" % (rnd, j), "ServiceID": "svc", "DesiredState": orc.RUNNING, "Status": {"State": orc.PENDING}}
+            for s in (o, e):
+                s.create_task(t)
+        do = sorted((d["ID"], d["NodeID"], d["Err"]) for d in o.tick())
+        de = sorted((d["ID"], d["NodeID"], d["Err"]) for d in e.tick())
+        assert do == de
+    assert e.node_info("n0")["ActiveTasksCount"] == o.node_info("n0")["ActiveTasksCount"] == 500
