@@ -166,7 +166,7 @@ int swp_platform_set(swp_engine*, const swp_platform* ps, uint32_t n, uint32_t* 
 /* PluginFilter.SetTask (filter.go:119-131): `required` = Volume/Network plugins that must exist;
  * log_plugin = Log plugin id or 0 (filter.go:165-175) */
 int swp_plugin_set(swp_engine*, const uint32_t* required, uint32_t n, uint32_t log_plugin, uint32_t* id_out);
-/* HostPortFilter.SetTask (filter.go:322-333): host-mode published ports of the task */
+/* HostPortFilter.SetTask (filter.go:322-333): host-mode published ports of the task (at most 32 per task: SWP_ERANGE) */
 int swp_port_set(swp_engine*, const swp_port* ports, uint32_t n, uint32_t* id_out);
 /* Spread preferences that create a decision-tree level (nodeset.go:59-82): kind is SWP_CK_NODE_LABEL or
  * SWP_CK_ENGINE_LABEL, key the LABEL_KEY id of the part after the prefix; other descriptors are skipped by

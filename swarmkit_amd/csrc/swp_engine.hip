@@ -1237,6 +1237,8 @@ int swp_plugin_set(swp_engine* e, const uint32_t* required, uint32_t n, uint32_t
 int swp_port_set(swp_engine* e, const swp_port* ports, uint32_t n, uint32_t* id_out) {
     if (!e || !id_out || (!ports && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
+    // the Explain pass tracks "this port was taken on the node by a LATER commit" in a 32-bit mask per task
+    if (n > 32) return e->fail(SWP_ERANGE, "a task with %u host-mode ports exceeds the device limit of 32 (keep it on the Go path)", n);
     return register_set(e->port_index, e->port_sets, bytes_of(ports, n), std::vector<swp_port>(ports, ports + n), id_out);
 }
 
