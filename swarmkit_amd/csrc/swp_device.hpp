@@ -1766,17 +1766,22 @@ __device__ __forceinline__ u64 bitop3_u64(u64 a, u64 b, u64 c) {
 #define BITOP_AB_OR_C 0xEA          // (a & b) | c
 
 // ---------------------------------------------------------------------------------------------
-// k_resolve3 — k_resolve2's two-wave scheme with the resolver's common case cut down to the instructions
-// the algorithm needs (a lone wave issues ~1 instruction per 4 ns, so the task rate IS the instruction count):
-//   * F and X rows are staged interleaved ({F,X} = one 16-byte LDS read per owned word) in rows padded to
-//     64*K words, so the reads are unconditional and one task ahead in the SAME registers (no copies);
-//   * the pick is specialised per owned-word slot k (a scalar branch), so nothing is selected through
-//     v_cndmask chains: one s_ff1 on the slot's ballot, readlanes of that slot's candidate / touched word;
-//   * a fast commit touches only the owner lane of slot k: LA/LB/tch/D with scalar bit operands;
-//   * level bit-planes are updated LAZILY: fast commits only collect the node in D (a node takes at most one
-//     fast commit per window); the bit-sliced "+1 on D" runs when the generic path or a hot-level change
-//     needs exact planes;
-//   * level-range and hot-level-exhausted checks are scalars maintained at derive time, not per task.
+// k_resolve3 — the sequential argmin + commit pass as ONE workgroup of four wavefronts. A lone wave issues roughly one
+// instruction per 4 ns, so the task rate IS the resolver wave's instruction count per task; everything that is not the
+// decision itself lives on the three helper waves:
+//   * waves 1,2 (LOADERS) stage, one block of TB tasks ahead, mk = F & ~X per task (rows padded to 64*K words so that the
+//     resolver's reads are unconditional), the task record, and per-task bits: "must take the generic path" (host ports /
+//     uncounted / a candidate below the hot level — computed against the BELOW mask the resolver publishes under a
+//     sequence lock; a block staged under an older epoch is recomputed by the resolver) and "the exception list may matter";
+//   * wave 3 (COMMITTER) applies the memory side effects of every finished block from an LDS hand-over, so the resolver's
+//     common path issues no VMEM and never waits for one;
+//   * wave 0 (RESOLVER): level bit-planes, hot-level masks and the touched set in registers over the words {lane + 64k}.
+//     The pick is specialised per slot k (a scalar branch): one s_ff1 on the slot's ballot, readlanes of that slot's
+//     candidate / touched word — nothing goes through v_cndmask chains. A fast commit changes ONE register pair (D, the
+//     nodes fast-committed since the last fold: LA = LA0 & ~D, LB = LB0 ^ D, touched = T0 | D; a node takes at most one fast
+//     commit per window); the bit-sliced "+1 on D" brings the planes up to date when the generic path or a hot-level
+//     change needs them. Level-range and hot-level-exhausted checks are scalars maintained at derive time.
+//   * X rows staged before a commit are repaired from a 64-entry commit ring through a zeroed LDS row (constant cost).
 // Semantics (pick order, exception lists, commit log, counters) are those of k_resolve2.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool PROF>
