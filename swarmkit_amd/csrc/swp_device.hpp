@@ -942,9 +942,8 @@ __global__ __launch_bounds__(64) void k_resolve1(ResolveArgs a) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     u32 w = lane + 64 * k;
-                    const bool inw = have && w < Wn;
-                    const bool in = inw && !(a.dbg & 4u);
-                    Fr[u][k] = in ? a.F[(size_t)jn * Wn + w] : ((inw && w + 1 < Wn) ? ~0ull >> (w * 7 % 13) : 0);
+                    const bool in = have && w < Wn;
+                    Fr[u][k] = in ? a.F[(size_t)jn * Wn + w] : 0;
                     Xr[u][k] = in ? __hip_atomic_load(&a.X[(size_t)sn * Wn + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 }
             }
@@ -987,23 +986,19 @@ __global__ __launch_bounds__(64) void k_resolve1(ResolveArgs a) {
 #pragma unroll
             for (int k = 0; k < K; ++k) tch[k] |= (owner && (u32)k == ko) ? bit : 0ull;
             if (owner) {
-                if (!(a.dbg & 1u)) {
-                    if (rcpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rcpu));
-                    if (rmem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rmem));
-                    atomicAdd(a.total + n, 1u);
-                }
+                if (rcpu) atomicAdd(reinterpret_cast<u64*>(a.cpu + n), (u64)(-rcpu));
+                if (rmem) atomicAdd(reinterpret_cast<u64*>(a.mem + n), (u64)(-rmem));
+                atomicAdd(a.total + n, 1u);
                 u64 nx = 0;
 #pragma unroll
                 for (int k = 0; k < K; ++k) nx = ((u32)k == ko) ? (Xc[k] | bit) : nx;
-                if (!(a.dbg & 2u)) {
-                    __hip_atomic_store(&a.X[(size_t)rsvc * Wn + w], nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.list_node[rslot] = n;
-                    a.list_svc[rslot] = 1;
-                    a.list_fail[rslot] = 0;
-                    a.log_node[ncommit] = n;
-                    a.log_task[ncommit] = gj;
-                    a.log_prev[ncommit] = last_lds[n];
-                }
+                __hip_atomic_store(&a.X[(size_t)rsvc * Wn + w], nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.list_node[rslot] = n;
+                a.list_svc[rslot] = 1;
+                a.list_fail[rslot] = 0;
+                a.log_node[ncommit] = n;
+                a.log_task[ncommit] = gj;
+                a.log_prev[ncommit] = last_lds[n];
                 last_lds[n] = (int32_t)ncommit;
                 a.out_node[gj] = (int32_t)n;
             }
@@ -1011,7 +1006,7 @@ __global__ __launch_bounds__(64) void k_resolve1(ResolveArgs a) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const u32 held = j - (u32)u + (u32)d + ((u32)d <= (u32)u ? (u32)D : 0u);   // task whose rows sit in slot d now
-                if (sv[d] == rsvc && held < a.count && !(a.dbg & 8u)) {   // uniform, rare
+                if (sv[d] == rsvc && held < a.count) {   // uniform, rare
 #pragma unroll
                     for (int k = 0; k < K; ++k) Xr[d][k] |= (owner && (u32)k == ko) ? bit : 0ull;
                 }
@@ -1866,7 +1861,7 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
         //   bit 30  a feasible node is an exception node of the service (F & X != 0): the exception list may matter
         //   bit 29  host ports / uncounted alone (used when the BELOW snapshot of the block is stale)
         const u32 lw = wave - 1;
-        const u32 half = (a.dbg & 32u) ? TB : (TB + 1) / 2;   // dbg 32: loader wave 1 stages whole blocks
+        const u32 half = (TB + 1) / 2;
         constexpr int LB = K <= 4 ? 8 : 4;   // rows in flight per loader wave (2*K*LB loads per lane)
         for (u32 b = 0; b < nblk; ++b) {
             const u32 buf = b & 1;
