@@ -683,7 +683,12 @@ int batch_run(swp_engine* e, swp_batch* b) {
     size_t lds = fixed + (size_t)nb_alloc * Wn * 8;
 
     // resolver variant: 2 = two-wave LDS-staged (default when it fits), 1 = one wave + register ring, 0 = one workgroup
-    int variant = getenv("SWP_RESOLVER") ? atoi(getenv("SWP_RESOLVER")) : 3;
+    // test / debugging knobs, read once per batch: SWP_RESOLVER forces a resolver generation (tests/test_engine_resolvers.py),
+    // SWP_DBG bit 16 switches the in-kernel section timers on
+    const char* env_res = getenv("SWP_RESOLVER");
+    const char* env_dbg = getenv("SWP_DBG");
+    const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
+    int variant = env_res ? atoi(env_res) : 3;
     uint32_t r2_tb = 0;
     size_t r2_lds = 0;
     if (variant == 3) {
@@ -744,7 +749,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         ra.j0 = j0;
         ra.count = cnt;
         ra.nb_alloc = nb_alloc;
-        ra.dbg = getenv("SWP_DBG") ? (uint32_t)atoi(getenv("SWP_DBG")) : 0u;
+        ra.dbg = dbg_bits;
         ra.xs = Wn;
         ra.tb = r2_tb;
         ra.F = b->d_F.as<u64>();
@@ -920,10 +925,10 @@ int batch_run(swp_engine* e, swp_batch* b) {
     e->stats.rebase_events += ctl.rebases;
     e->stats.generic_tasks += ctl.generic_tasks;
     e->stats.resolver_spins += ctl.spin_waits;
-    if (getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16))
+    if (dbg_bits & 16)
         fprintf(stderr, "[swp] resolver cycles (100MHz ticks): wait %llu prep %llu pick %llu generic %llu commit %llu blockend %llu | commits %u inf %u generic %llu\n",
                 ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.cyc[4], ctl.cyc[5], ctl.ncommit, ctl.ninf, ctl.generic_tasks);
-    if (getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16) && ctl.cyc[7])
+    if ((dbg_bits & 16) && ctl.cyc[7])
         fprintf(stderr, "[swp] shader clock: %llu cycles / %llu x10ns => %.0f MHz\n", ctl.cyc[6], ctl.cyc[7], (double)ctl.cyc[6] / ((double)ctl.cyc[7] * 0.01));
     e->stats.last_windows = b->n_windows;
     e->stats.last_static_classes = b->n_sc;
