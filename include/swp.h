@@ -211,7 +211,8 @@ int swp_schedule_batch(swp_engine*, const swp_task_desc* tasks, uint32_t n_tasks
  * per leaf (nodeset.go:50-124, container/heap order reproduced), scheduleNTasksOnSubtree (:772-825), the fill
  * loop scheduleNTasksOnNodes (:844-924) incl. the residual update. One descriptor per group (all tasks of a
  * group are identical for the filters, scheduler.go:696-702). Also the path of one-off tasks that carry spread
- * preferences (a group of one).
+ * preferences (a group of one). (SURVEY.md 8b sketched this entry as swp_scan_groups — candidates out, tree walk and
+ * fill loop on the host; they run on the device as well, so the call returns placements.)
  *   out_node       Σ sizes entries, group after group, tasks in canonical (enqueue) order; -1 = left over
  *   out_fail_hist  [n_groups][SWP_NFILTERS]: Pipeline counters as noSuitableNode would read them
  *                  (scheduler.go:929), written for groups with left-over tasks */
