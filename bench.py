@@ -281,7 +281,7 @@ def main():
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
-        "config": dict(wl.describe(), parallelism="replicas" if world > 1 else "single", window=int(st["last_windows"] and -(-wl.T // st["last_windows"])),
+        "config": dict(wl.describe(), parallelism="replicas" if world > 1 else "single", control_backend=ranks.backend, window=int(st["last_windows"] and -(-wl.T // st["last_windows"])),
                        static_classes=st["last_static_classes"]),
         "pair_evals_per_s": world * pairs / t_step,
         "placed": placed,

@@ -13,6 +13,7 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
+        self.backend = None
         self.device = device
         if self.world > 1:
             import torch
@@ -28,7 +29,23 @@ class Ranks:
                 kw["device_id"] = self.device
             else:
                 self.device = torch.device("cpu")
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+            import datetime
+            kw["timeout"] = datetime.timedelta(minutes=10)
+            try:
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+                if backend == "nccl":      # connect now, so that a broken RCCL set-up shows here and not inside the timed region
+                    dist.barrier()
+            except Exception as e:         # measurement protocol only (no data-path collective): keep the run alive over gloo
+                if backend != "nccl":
+                    raise
+                import sys
+                print(f"swarmkit_amd.dist: RCCL process group failed ({e!r}); using gloo for the timing protocol", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                self.device = torch.device("cpu")
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world, timeout=kw["timeout"])
+            self.backend = backend
             self.dist = dist
 
     def replica_seed(self, base):
