@@ -1,0 +1,94 @@
+/* swp_sched.h — the host side ABOVE swp.h: manager/scheduler.Scheduler's event handlers and tick, restated in C++
+ * over the engine (swarmkit_amd/csrc/swp_sched.cpp, part of libswp.so).
+ *
+ * Inside swarmkit this layer is the cgo shim of INTEGRATION.md, written in Go against the real api.* structs. Go is
+ * not available where this repository is built, so the same logic lives here in C++ with the reference's names
+ * (swp::Scheduler::createTask / updateTask / deleteTask / createOrUpdateNode / tick / processPreassignedTasks /
+ * noSuitableNode, swp::NodeInfo::addTask / removeTask / taskFailed / countRecentFailures) and is driven through the
+ * C entry points below. Documents cross this boundary as JSON with the Go field names (api.Node, api.Task), so a
+ * test reads like the reference's struct literals. The layer holds NO placement logic: which node a task lands on is
+ * decided by the kernels behind swp_schedule_batch / swp_schedule_groups; it keeps the string-typed half of the
+ * nodeSet (node documents, NodeInfo.Tasks, failure timestamps), mirrors every mutator into the engine, translates
+ * Filter.SetTask into predicate sets, and turns the engine's numeric answers back into scheduling decisions
+ * (NodeID, Status.State, Status.Err strings).
+ *
+ * Conventions: as swp.h (0 or negative SWP_E*, no exception crosses, not thread-safe). `const char**` results point
+ * into storage owned by the scheduler handle and stay valid until the next call on that handle.
+ * Paths below are under /root/reference/manager/scheduler/ unless stated otherwise.
+ */
+#ifndef SWP_SCHED_H
+#define SWP_SCHED_H
+#include "swp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct swp_sched swp_sched;
+
+/* scheduler.New (scheduler.go:54-66) + nodeSet.alloc: the engine is borrowed (one engine per Scheduler) and reset. */
+int swp_sched_create(swp_engine* engine, swp_sched** out);
+void swp_sched_destroy(swp_sched*);
+const char* swp_sched_last_error(swp_sched*);
+
+/* createOrUpdateNode (scheduler.go:368-396), reached from EventCreateNode / EventUpdateNode (:214-217) and
+ * buildNodeSet (:973-990). node_json = api.Node. Generic resources → SWP_EUNSUPPORTED (node stays on the Go path). */
+int swp_sched_create_or_update_node(swp_sched*, const char* node_json, size_t len);
+/* EventDeleteNode → nodeSet.remove (scheduler.go:218-219, nodeset.go:46-48) */
+int swp_sched_delete_node(swp_sched*, const char* node_id, size_t len);
+/* nodeSet.nodeInfo (nodeset.go:23-29) as JSON {ID, ActiveTasksCount, ActiveTasksCountByService, AvailableResources,
+ * Tasks, RecentFailures}; SWP_ENOTFOUND <-> errNodeNotFound */
+int swp_sched_node_info(swp_sched*, const char* node_id, size_t len, const char** json_out);
+
+/* What noSuitableNode reads from the store about a service (scheduler.go:934-953): does it exist, and its
+ * SpecVersion (has_version = 0: nil). */
+int swp_sched_set_service(swp_sched*, const char* service_id, size_t len, int has_version, uint64_t version);
+int swp_sched_delete_service(swp_sched*, const char* service_id, size_t len);
+/* Test clock: time.Now() of taskFailed / countRecentFailures (nodeinfo.go:177-221) advances by `ns`. */
+int swp_sched_advance(swp_sched*, int64_t ns);
+
+/* Task event handlers. task_json = api.Task. *tick_needed = the handler's bool result (scheduler.go:196-212:
+ * a true result arms the commit debouncer). */
+int swp_sched_create_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* createTask :254-283 */
+int swp_sched_setup_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);    /* setupTasksList :88-124 */
+int swp_sched_update_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* updateTask :285-349 */
+int swp_sched_delete_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* deleteTask :351-366 */
+
+/* tick (scheduler.go:429-488): task groups (ServiceID, SpecVersion) in first-seen order through swp_schedule_groups,
+ * then the one-off tasks in queue order through swp_schedule_batch; left-overs through noSuitableNode (:928-971).
+ * *decisions_json = JSON array of {ID, ServiceID, NodeID, State, Message, Err, OldState} — what
+ * applySchedulingDecisions (:490-643) would write to the store. */
+int swp_sched_tick(swp_sched*, const char** decisions_json);
+/* processPreassignedTasks + taskFitNode (scheduler.go:398-426, 646-690) through swp_check_node */
+int swp_sched_process_preassigned(swp_sched*, const char** decisions_json);
+
+/* Pipeline.SetTask (pipeline.go:76-81) for one task: every Filter.SetTask (filter.go) translated into predicate-set
+ * registrations; the descriptor is what swp_schedule_batch consumes. CSI cluster volumes / generic resources →
+ * SWP_EUNSUPPORTED. */
+int swp_sched_task_desc(swp_sched*, const char* task_json, size_t len, swp_task_desc* out);
+/* ConstraintFilter.SetTask alone (filter.go:218-232): Placement.Constraints (JSON array of strings) → set id;
+ * *set_out = 0 when the list is empty or constraint.Parse fails (the filter is then disabled, :223-229). */
+int swp_sched_constraint_set(swp_sched*, const char* exprs_json, size_t len, uint32_t* set_out);
+
+/* constraintenforcer.rejectNoncompliantTasks for many nodes (manager/orchestrator/constraintenforcer/
+ * constraint_enforcer.go:65-196) through swp_enforce. request_json = {"nodes": [api.Node...] (already known to the
+ * scheduler), "tasks_by_node": {node id: [api.Task...]}, "services": {service id: api.Service}}; the tasks of a node
+ * are taken in task-ID order (the canonical store order). *rejected_json = {node id: [rejected task ids]} for the
+ * ACTIVE nodes (:70-72). */
+int swp_sched_enforce(swp_sched*, const char* request_json, size_t len, const char** rejected_json);
+
+/* ---- pure string helpers of the path (no engine needed; exercised on CPU against the oracle) ---- */
+/* constraint.Parse (manager/constraint/constraint.go:40-81): exprs_json = JSON array of strings →
+ * *parsed_json = [[key, op (0 "==", 1 "!="), value]...]; SWP_EINVAL when Parse would return an error.
+ * The result lives in a thread-local buffer until the next call. */
+int swp_constraint_parse(const char* exprs_json, size_t len, const char** parsed_json);
+/* strings.EqualFold as the path uses it on constraint KEYS / spread descriptors (ASCII + U+212A + U+017F): 1 / 0 */
+int swp_key_equal_fold(const char* a, size_t la, const char* b, size_t lb);
+/* Pipeline.Explain (pipeline.go:84-103) from a per-filter failure histogram; returns the length, text in `out` */
+int swp_explain(const uint32_t* hist /* [SWP_NFILTERS] */, char* out, size_t cap);
+/* net.ParseIP as constraint.go:128-146 uses it: 1 and the 16-byte form (+ *is_v4) or 0 */
+int swp_parse_ip(const char* s, size_t len, uint8_t out16[16], int* is_v4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWP_SCHED_H */

@@ -7,7 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "swarmkit_amd", "csrc")
-LIB_PATH = os.path.join(ROOT, "swarmkit_amd", "lib", "libswp.so")
+LIB_PATH = os.environ.get("SWP_LIB_PATH") or os.path.join(ROOT, "swarmkit_amd", "lib", "libswp.so")
 
 SWP_OK, SWP_EINVAL, SWP_ENOTFOUND, SWP_ENOMEM, SWP_EHIP, SWP_EUNSUPPORTED, SWP_ERANGE, SWP_ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7
 (SPACE_NODE_ID, SPACE_SERVICE, SPACE_LABEL_KEY, SPACE_FOLDED, SPACE_OS, SPACE_ARCH, SPACE_PLUGIN, SPACE_RAW) = range(8)
@@ -92,7 +92,16 @@ EXPORTS = [
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
     "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce", "swp_node_matches",
     "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check",
+    # include/swp_sched.h — the host layer above the engine
+    "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
+    "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
+    "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce",
+    "swp_constraint_parse", "swp_key_equal_fold", "swp_explain", "swp_parse_ip",
 ]
+
+
+class Unsupported(NotImplementedError):
+    """The task/feature stays on the reference's own Go path (SWP_EUNSUPPORTED)."""
 
 
 class SwpError(RuntimeError):
@@ -103,7 +112,8 @@ class SwpError(RuntimeError):
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). In-tree output: swarmkit_amd/lib/libswp.so."""
-    srcs = [os.path.join(CSRC, f) for f in ("swp_engine.hip", "swp_device.hpp", "Makefile")] + [os.path.join(ROOT, "include", "swp.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("swp_engine.hip", "swp_device.hpp", "swp_sched.cpp", "swp_json.hpp", "Makefile")] \
+        + [os.path.join(ROOT, "include", h) for h in ("swp.h", "swp_sched.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     if not os.path.exists("/opt/rocm/bin/hipcc"):
@@ -116,16 +126,17 @@ def build_library(force=False):
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(path=None):
+    """libswp.so (default) or another library with the same exports (tests/_build/libswpfake.so: the host layer's CPU test double)."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if path == LIB_PATH and not os.path.exists(LIB_PATH):
         build_library()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, u32, u64, i32, i64, cp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64, C.c_char_p
     P = C.POINTER
     sig = {
@@ -165,6 +176,32 @@ def load_library():
         "swp_last_error": ([vp], cp),
         "swp_abi_check": ([P(u32), u32], C.c_int),
     }
+    sz = C.c_size_t
+    PP = P(cp)
+    sig.update({   # include/swp_sched.h — the host layer above the engine ABI
+        "swp_sched_create": ([vp, P(vp)], C.c_int),
+        "swp_sched_destroy": ([vp], None),
+        "swp_sched_last_error": ([vp], cp),
+        "swp_sched_create_or_update_node": ([vp, cp, sz], C.c_int),
+        "swp_sched_delete_node": ([vp, cp, sz], C.c_int),
+        "swp_sched_node_info": ([vp, cp, sz, PP], C.c_int),
+        "swp_sched_set_service": ([vp, cp, sz, C.c_int, u64], C.c_int),
+        "swp_sched_delete_service": ([vp, cp, sz], C.c_int),
+        "swp_sched_advance": ([vp, i64], C.c_int),
+        "swp_sched_create_task": ([vp, cp, sz, P(C.c_int)], C.c_int),
+        "swp_sched_setup_task": ([vp, cp, sz, P(C.c_int)], C.c_int),
+        "swp_sched_update_task": ([vp, cp, sz, P(C.c_int)], C.c_int),
+        "swp_sched_delete_task": ([vp, cp, sz, P(C.c_int)], C.c_int),
+        "swp_sched_tick": ([vp, PP], C.c_int),
+        "swp_sched_process_preassigned": ([vp, PP], C.c_int),
+        "swp_sched_task_desc": ([vp, cp, sz, P(TaskDesc)], C.c_int),
+        "swp_sched_constraint_set": ([vp, cp, sz, P(u32)], C.c_int),
+        "swp_sched_enforce": ([vp, cp, sz, PP], C.c_int),
+        "swp_constraint_parse": ([cp, sz, PP], C.c_int),
+        "swp_key_equal_fold": ([cp, sz, cp, sz], C.c_int),
+        "swp_explain": ([P(u32), cp, sz], C.c_int),
+        "swp_parse_ip": ([cp, sz, P(C.c_uint8), P(C.c_int)], C.c_int),
+    })
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -174,7 +211,7 @@ def load_library():
     want = [C.sizeof(x) for x in (Config, NodeRow, KV, Constraint, Platform, Port, TaskDesc, Placement, Stats, Spread)]
     if list(sizes[:n]) != want:
         raise RuntimeError(f"ABI struct size mismatch: lib {list(sizes[:n])} vs binding {want}")
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -212,8 +249,8 @@ class Batch:
 class Engine:
     """One swp_engine handle. Raises SwpError(SWP_ENODEVICE) when no gfx950 is present: there is no CPU path."""
 
-    def __init__(self, device=0, window=0, resolver_threads=0, profile=False):
-        self.L = load_library()
+    def __init__(self, device=0, window=0, resolver_threads=0, profile=False, lib_path=None):
+        self.L = load_library(lib_path)
         cfg = Config(device=device, window=window, resolver_threads=resolver_threads, flags=CFG_PROFILE if profile else 0)
         h = C.c_void_p()
         rc = self.L.swp_create(C.byref(cfg), C.byref(h))

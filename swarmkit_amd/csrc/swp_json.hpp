@@ -1,0 +1,339 @@
+// swp_json.hpp — the small JSON document model the host-side scheduler mirror (swp_sched.cpp) uses for api.Node /
+// api.Task / api.Service documents. In swarmkit these are protobuf-generated Go structs; across the test-bed boundary
+// they travel as JSON with the Go field names, so that the parity tests read like the reference's struct literals.
+// Objects keep insertion order (a Go struct's field order / Python dict order); sub-documents are shared by reference
+// (immutable once parsed), so copying a task document to change its Status costs one small vector.
+#pragma once
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <initializer_list>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace swp {
+namespace json {
+
+struct Value;
+using Member = std::pair<std::string, Value>;
+
+struct Value {
+    enum Kind : uint8_t { Null, Bool, Int, Real, Str, Arr, Obj };
+    Kind kind = Null;
+    bool b = false;
+    int64_t i = 0;
+    double d = 0.0;
+    std::string s;
+    std::shared_ptr<std::vector<Value>> a;
+    std::shared_ptr<std::vector<Member>> o;
+
+    Value() = default;
+    static Value boolean(bool v) { Value x; x.kind = Bool; x.b = v; return x; }
+    static Value integer(int64_t v) { Value x; x.kind = Int; x.i = v; return x; }
+    static Value real(double v) { Value x; x.kind = Real; x.d = v; return x; }
+    static Value str(std::string v) { Value x; x.kind = Str; x.s = std::move(v); return x; }
+    static Value array() { Value x; x.kind = Arr; x.a = std::make_shared<std::vector<Value>>(); return x; }
+    static Value object() { Value x; x.kind = Obj; x.o = std::make_shared<std::vector<Member>>(); return x; }
+
+    bool is_null() const { return kind == Null; }
+    bool is_obj() const { return kind == Obj; }
+    bool is_arr() const { return kind == Arr; }
+    bool is_str() const { return kind == Str; }
+    bool is_num() const { return kind == Int || kind == Real; }
+
+    // member lookup; nullptr when this is not an object, the key is absent, or the member is null
+    // (a nil pointer / absent field and JSON null are the same thing for every reader on this path)
+    const Value* get(const char* key) const {
+        if (kind != Obj) return nullptr;
+        for (const Member& m : *o)
+            if (m.first == key) return m.second.kind == Null ? nullptr : &m.second;
+        return nullptr;
+    }
+    bool has(const char* key) const {   // present at all, even as null
+        if (kind != Obj) return false;
+        for (const Member& m : *o)
+            if (m.first == key) return true;
+        return false;
+    }
+    // a copy whose member vector is private (sub-documents stay shared): `dict(t)` in the Python twin
+    Value shallow_copy() const {
+        Value x = *this;
+        if (kind == Obj) x.o = std::make_shared<std::vector<Member>>(*o);
+        if (kind == Arr) x.a = std::make_shared<std::vector<Value>>(*a);
+        return x;
+    }
+    void set(const std::string& key, Value v) {   // only on objects this code has just created / shallow-copied
+        for (Member& m : *o)
+            if (m.first == key) { m.second = std::move(v); return; }
+        o->emplace_back(key, std::move(v));
+    }
+    void push(Value v) { a->push_back(std::move(v)); }
+    size_t size() const { return kind == Arr ? a->size() : kind == Obj ? o->size() : 0; }
+};
+
+// nested lookup: at(doc, {"Spec", "Resources", "Reservations"}) — nullptr as soon as a level is nil
+inline const Value* at(const Value* d, std::initializer_list<const char*> path) {
+    for (const char* p : path) {
+        if (d == nullptr) return nullptr;
+        d = d->get(p);
+    }
+    return d;
+}
+inline int64_t as_i64(const Value* v, int64_t def = 0) {
+    if (v == nullptr) return def;
+    switch (v->kind) {
+        case Value::Int: return v->i;
+        case Value::Real: return (int64_t)v->d;
+        case Value::Bool: return v->b ? 1 : 0;
+        default: return def;
+    }
+}
+inline const std::string& as_str(const Value* v) {
+    static const std::string empty;
+    return (v != nullptr && v->kind == Value::Str) ? v->s : empty;
+}
+// Python truthiness of `d.get(key)`: absent / null / "" / 0 / [] / {} are false
+inline bool truthy(const Value* v) {
+    if (v == nullptr) return false;
+    switch (v->kind) {
+        case Value::Null: return false;
+        case Value::Bool: return v->b;
+        case Value::Int: return v->i != 0;
+        case Value::Real: return v->d != 0.0;
+        case Value::Str: return !v->s.empty();
+        case Value::Arr: return !v->a->empty();
+        case Value::Obj: return !v->o->empty();
+    }
+    return false;
+}
+
+struct ParseError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+class Parser {
+  public:
+    Parser(const char* p, size_t n) : p_(p), e_(p + n) {}
+    Value parse_document() {
+        Value v = value(0);
+        ws();
+        if (p_ != e_) fail("trailing characters");
+        return v;
+    }
+
+  private:
+    const char* p_;
+    const char* e_;
+    [[noreturn]] void fail(const char* what) { throw ParseError(std::string("json: ") + what); }
+    void ws() {
+        while (p_ != e_ && (*p_ == ' ' || *p_ == '\t' || *p_ == '\n' || *p_ == '\r')) ++p_;
+    }
+    bool lit(const char* w) {
+        size_t n = std::strlen(w);
+        if ((size_t)(e_ - p_) >= n && std::memcmp(p_, w, n) == 0) { p_ += n; return true; }
+        return false;
+    }
+    static void utf8(std::string& out, uint32_t cp) {
+        if (cp < 0x80) out.push_back((char)cp);
+        else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+        else if (cp < 0x10000) {
+            out.push_back((char)(0xE0 | (cp >> 12)));
+            out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+            out.push_back((char)(0x80 | (cp & 0x3F)));
+        } else {
+            out.push_back((char)(0xF0 | (cp >> 18)));
+            out.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+            out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+            out.push_back((char)(0x80 | (cp & 0x3F)));
+        }
+    }
+    uint32_t hex4() {
+        if (e_ - p_ < 4) fail("short \\u escape");
+        uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) {
+            char c = *p_++;
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= (uint32_t)(c - '0');
+            else if (c >= 'a' && c <= 'f') v |= (uint32_t)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') v |= (uint32_t)(c - 'A' + 10);
+            else fail("bad \\u escape");
+        }
+        return v;
+    }
+    std::string string() {
+        std::string out;
+        ++p_;   // opening quote
+        for (;;) {
+            if (p_ == e_) fail("unterminated string");
+            char c = *p_++;
+            if (c == '"') return out;
+            if (c != '\\') { out.push_back(c); continue; }
+            if (p_ == e_) fail("unterminated escape");
+            char x = *p_++;
+            switch (x) {
+                case '"': out.push_back('"'); break;
+                case '\\': out.push_back('\\'); break;
+                case '/': out.push_back('/'); break;
+                case 'b': out.push_back('\b'); break;
+                case 'f': out.push_back('\f'); break;
+                case 'n': out.push_back('\n'); break;
+                case 'r': out.push_back('\r'); break;
+                case 't': out.push_back('\t'); break;
+                case 'u': {
+                    uint32_t cp = hex4();
+                    if (cp >= 0xD800 && cp < 0xDC00 && e_ - p_ >= 6 && p_[0] == '\\' && p_[1] == 'u') {
+                        const char* save = p_;
+                        p_ += 2;
+                        uint32_t lo = hex4();
+                        if (lo >= 0xDC00 && lo < 0xE000) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                        else p_ = save;
+                    }
+                    utf8(out, cp);
+                    break;
+                }
+                default: fail("bad escape");
+            }
+        }
+    }
+    Value number() {
+        const char* s = p_;
+        bool real = false;
+        if (p_ != e_ && (*p_ == '-' || *p_ == '+')) ++p_;
+        while (p_ != e_ && ((*p_ >= '0' && *p_ <= '9') || *p_ == '.' || *p_ == 'e' || *p_ == 'E' || *p_ == '-' || *p_ == '+')) {
+            if (*p_ == '.' || *p_ == 'e' || *p_ == 'E') real = true;
+            ++p_;
+        }
+        std::string t(s, p_);
+        if (t.empty() || t == "-") fail("bad number");
+        if (!real) {
+            errno = 0;
+            char* end = nullptr;
+            long long v = std::strtoll(t.c_str(), &end, 10);
+            if (errno == 0 && end != nullptr && *end == 0) return Value::integer((int64_t)v);
+            // uint64 values above INT64_MAX (MaxReplicas is a uint64): keep the bit pattern
+            errno = 0;
+            unsigned long long u = std::strtoull(t.c_str(), &end, 10);
+            if (errno == 0 && end != nullptr && *end == 0) return Value::integer((int64_t)u);
+        }
+        return Value::real(std::strtod(t.c_str(), nullptr));
+    }
+    Value value(int depth) {
+        if (depth > 64) fail("nesting too deep");
+        ws();
+        if (p_ == e_) fail("unexpected end");
+        char c = *p_;
+        if (c == '{') {
+            ++p_;
+            Value v = Value::object();
+            ws();
+            if (p_ != e_ && *p_ == '}') { ++p_; return v; }
+            for (;;) {
+                ws();
+                if (p_ == e_ || *p_ != '"') fail("expected a member name");
+                std::string k = string();
+                ws();
+                if (p_ == e_ || *p_ != ':') fail("expected ':'");
+                ++p_;
+                Value m = value(depth + 1);
+                v.set(k, std::move(m));   // a repeated key keeps its first position, last value (Python dict)
+                ws();
+                if (p_ != e_ && *p_ == ',') { ++p_; continue; }
+                if (p_ != e_ && *p_ == '}') { ++p_; return v; }
+                fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            ++p_;
+            Value v = Value::array();
+            ws();
+            if (p_ != e_ && *p_ == ']') { ++p_; return v; }
+            for (;;) {
+                v.push(value(depth + 1));
+                ws();
+                if (p_ != e_ && *p_ == ',') { ++p_; continue; }
+                if (p_ != e_ && *p_ == ']') { ++p_; return v; }
+                fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') return Value::str(string());
+        if (lit("true")) return Value::boolean(true);
+        if (lit("false")) return Value::boolean(false);
+        if (lit("null")) return Value();
+        if (c == '-' || (c >= '0' && c <= '9')) return number();
+        fail("unexpected character");
+    }
+};
+
+inline Value parse(const char* text, size_t len) { return Parser(text, len).parse_document(); }
+inline Value parse(const std::string& text) { return parse(text.data(), text.size()); }
+
+inline void dump_string(std::string& out, const std::string& s) {
+    out.push_back('"');
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': out += "\\\""; break;
+            case '\\': out += "\\\\"; break;
+            case '\n': out += "\\n"; break;
+            case '\r': out += "\\r"; break;
+            case '\t': out += "\\t"; break;
+            default:
+                if (c < 0x20) {
+                    char buf[8];
+                    std::snprintf(buf, sizeof buf, "\\u%04x", c);
+                    out += buf;
+                } else out.push_back((char)c);   // UTF-8 passes through
+        }
+    }
+    out.push_back('"');
+}
+inline void dump(std::string& out, const Value& v) {
+    switch (v.kind) {
+        case Value::Null: out += "null"; break;
+        case Value::Bool: out += v.b ? "true" : "false"; break;
+        case Value::Int: out += std::to_string(v.i); break;
+        case Value::Real: {
+            char buf[40];
+            std::snprintf(buf, sizeof buf, "%.17g", v.d);
+            out += buf;
+            break;
+        }
+        case Value::Str: dump_string(out, v.s); break;
+        case Value::Arr: {
+            out.push_back('[');
+            bool first = true;
+            for (const Value& x : *v.a) {
+                if (!first) out.push_back(',');
+                first = false;
+                dump(out, x);
+            }
+            out.push_back(']');
+            break;
+        }
+        case Value::Obj: {
+            out.push_back('{');
+            bool first = true;
+            for (const Member& m : *v.o) {
+                if (!first) out.push_back(',');
+                first = false;
+                dump_string(out, m.first);
+                out.push_back(':');
+                dump(out, m.second);
+            }
+            out.push_back('}');
+            break;
+        }
+    }
+}
+inline std::string dump(const Value& v) {
+    std::string out;
+    dump(out, v);
+    return out;
+}
+
+}   // namespace json
+}   // namespace swp

@@ -1,0 +1,1283 @@
+// swp_sched.cpp — host side above the C ABI (include/swp_sched.h): manager/scheduler.Scheduler's event handlers and
+// tick over the engine, in C++ with the reference's names. In swarmkit itself this layer is a cgo shim in Go
+// (INTEGRATION.md); Go is not available in this build environment, so it is restated here.
+//
+// NO placement logic lives in this file: every "which node" decision is made by the kernels behind
+// swp_schedule_batch / swp_schedule_groups / swp_check_node / swp_enforce. This layer keeps what a nodeSet keeps
+// beside the numeric columns (node documents, NodeInfo.Tasks, failure timestamps), mirrors the mutators into the
+// engine and converts numeric answers into decisions and Status.Err strings.
+//
+// Mirrors (paths under /root/reference/manager/scheduler/):
+//   scheduler.go:254-366  createTask / updateTask / deleteTask          scheduler.go:368-396  createOrUpdateNode
+//   scheduler.go:398-426  processPreassignedTasks   :646-690 taskFitNode     :429-488 tick     :928-971 noSuitableNode
+//   nodeinfo.go:66-221    removeTask / addTask / taskFailed / countRecentFailures
+//   pipeline.go:76-103    SetTask / Explain          filter.go  every Filter.SetTask
+//   manager/constraint/constraint.go:40-81 Parse;   :109-203 the key dispatch of Match
+#include <arpa/inet.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iterator>
+#include <list>
+#include <map>
+#include <optional>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/swp_sched.h"
+#include "swp_json.hpp"
+
+namespace swp {
+
+using json::Value;
+using json::as_i64;
+using json::as_str;
+using json::at;
+using json::truthy;
+
+// api/types.proto:510-539 (TaskState), :190-207 (NodeStatus.State), specs.proto (Availability, Role, Mount.Type, PublishMode)
+enum : int64_t { NEW = 0, PENDING = 64, ASSIGNED = 192, RUNNING = 512, COMPLETE = 576, SHUTDOWN = 640, FAILED = 704, REJECTED = 768 };
+static constexpr int64_t NODE_STATE_READY = 2, AVAILABILITY_ACTIVE = 0;
+static constexpr int64_t MOUNT_VOLUME = 1, MOUNT_CLUSTER = 4, PUBLISH_HOST = 1;
+static constexpr int64_t MONITOR_FAILURES = 5LL * 60 * 1000000000LL;   // scheduler.go:19
+
+struct Fail {   // carries an SWP_E* code to the C boundary
+    int code;
+    std::string msg;
+};
+[[noreturn]] static void fail(int code, std::string msg) { throw Fail{code, std::move(msg)}; }
+[[noreturn]] static void unsupported(const char* what) { fail(SWP_EUNSUPPORTED, what); }
+
+// ------------------------------------------------------------------------------------------------ small helpers
+// protobuf enums travel either as their number or as their name; an unknown name is an error for the enums whose
+// value is ordered (task states, protocols) and simply "none of the values tested" (-1) for the others
+static int64_t enum_value(const Value* v, std::initializer_list<std::pair<const char*, int64_t>> names, int64_t def = 0, bool strict = false) {
+    if (v == nullptr) return def;
+    if (v->is_str()) {
+        for (const auto& n : names)
+            if (v->s == n.first) return n.second;
+        if (strict) fail(SWP_EINVAL, "unknown enum name '" + v->s + "'");
+        return -1;
+    }
+    return as_i64(v, def);
+}
+static int64_t task_state(const Value* v) {
+    return enum_value(v, {{"NEW", 0}, {"PENDING", 64}, {"ASSIGNED", 192}, {"ACCEPTED", 256}, {"PREPARING", 320}, {"READY", 384}, {"STARTING", 448},
+                          {"RUNNING", 512}, {"COMPLETE", 576}, {"SHUTDOWN", 640}, {"FAILED", 704}, {"REJECTED", 768}, {"REMOVE", 800}, {"ORPHANED", 832}}, 0, true);
+}
+static const std::string& task_id(const Value& t) {
+    const Value* id = t.get("ID");
+    if (id == nullptr || !id->is_str()) fail(SWP_EINVAL, "document without ID");
+    return id->s;
+}
+
+// UTF-8 ⇄ code points (documents are valid UTF-8: they come from a JSON parser)
+static std::u32string decode(const std::string& s) {
+    std::u32string out;
+    size_t i = 0;
+    while (i < s.size()) {
+        unsigned char c = (unsigned char)s[i];
+        uint32_t cp = c;
+        int extra = 0;
+        if (c >= 0xF0) { cp = c & 0x07; extra = 3; }
+        else if (c >= 0xE0) { cp = c & 0x0F; extra = 2; }
+        else if (c >= 0xC0) { cp = c & 0x1F; extra = 1; }
+        ++i;
+        for (int k = 0; k < extra && i < s.size(); ++k, ++i) cp = (cp << 6) | ((unsigned char)s[i] & 0x3F);
+        out.push_back((char32_t)cp);
+    }
+    return out;
+}
+static std::string encode(const std::u32string& s, size_t from = 0, size_t to = std::string::npos) {
+    std::string out;
+    to = std::min(to, s.size());
+    for (size_t i = from; i < to; ++i) {
+        uint32_t cp = s[i];
+        if (cp < 0x80) out.push_back((char)cp);
+        else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+        else if (cp < 0x10000) {
+            out.push_back((char)(0xE0 | (cp >> 12)));
+            out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+            out.push_back((char)(0x80 | (cp & 0x3F)));
+        } else {
+            out.push_back((char)(0xF0 | (cp >> 18)));
+            out.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+            out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+            out.push_back((char)(0x80 | (cp & 0x3F)));
+        }
+    }
+    return out;
+}
+
+// strings.EqualFold restricted to what it is applied to on this path: one side is always an ASCII literal
+// ("node.id", "node.labels." …), so only code points that fold ONTO ASCII matter: A-Z, U+212A KELVIN SIGN → k and
+// U+017F LATIN SMALL LETTER LONG S → s (Unicode simple case folding, constraint.go:110-188).
+static char32_t fold_cp(char32_t c) {
+    if (c >= U'A' && c <= U'Z') return c + 32;
+    if (c == 0x212A) return U'k';
+    if (c == 0x017F) return U's';
+    return c;
+}
+static bool equal_fold(const std::u32string& a, size_t a_len, const char* lit) {
+    size_t n = std::strlen(lit);
+    if (a_len != n) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (fold_cp(a[i]) != (char32_t)(unsigned char)lit[i]) return false;
+    return true;
+}
+static bool equal_fold(const std::u32string& a, const std::u32string& b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i)
+        if (fold_cp(a[i]) != fold_cp(b[i])) return false;
+    return true;
+}
+
+// ---- constraint.Parse (manager/constraint/constraint.go:40-81) ----------------------------------------------------
+// key   `^(?i)[a-z_][a-z0-9\-_.]+$`   value `^(?i)[a-z0-9:\-_\s\.\*\(\)\?\+\[\]\\\^\$\|\/]+$`  (constraint.go:23-26);
+// under (?i) RE2 also lets U+212A and U+017F match k / s. strings.TrimSpace trims Unicode White_Space.
+static bool is_go_space(char32_t c) {
+    switch (c) {
+        case 0x09: case 0x0A: case 0x0B: case 0x0C: case 0x0D: case 0x20: case 0x85: case 0xA0: case 0x1680:
+        case 0x2028: case 0x2029: case 0x202F: case 0x205F: case 0x3000:
+            return true;
+        default:
+            return c >= 0x2000 && c <= 0x200A;
+    }
+}
+static bool is_alpha_i(char32_t c) { return (c >= U'a' && c <= U'z') || (c >= U'A' && c <= U'Z') || c == 0x212A || c == 0x017F; }
+static bool is_digit(char32_t c) { return c >= U'0' && c <= U'9'; }
+static bool key_ok(const std::u32string& k) {
+    if (k.size() < 2) return false;
+    if (!(is_alpha_i(k[0]) || k[0] == U'_')) return false;
+    for (size_t i = 1; i < k.size(); ++i) {
+        char32_t c = k[i];
+        if (!(is_alpha_i(c) || is_digit(c) || c == U'-' || c == U'_' || c == U'.')) return false;
+    }
+    return true;
+}
+static bool value_ok(const std::u32string& v) {
+    if (v.empty()) return false;
+    for (char32_t c : v) {
+        if (is_alpha_i(c) || is_digit(c)) continue;
+        switch (c) {
+            case U':': case U'-': case U'_': case U'\t': case U'\n': case U'\f': case U'\r': case U' ': case U'.': case U'*':
+            case U'(': case U')': case U'?': case U'+': case U'[': case U']': case U'\\': case U'^': case U'$': case U'|': case U'/':
+                continue;
+            default:
+                return false;
+        }
+    }
+    return true;
+}
+struct Expr {
+    std::u32string key;
+    int op;   // 0 "==", 1 "!="
+    std::u32string exp;
+};
+static std::u32string trim(const std::u32string& s, size_t from, size_t to) {
+    while (from < to && is_go_space(s[from])) ++from;
+    while (to > from && is_go_space(s[to - 1])) --to;
+    return s.substr(from, to - from);
+}
+static bool parse_constraints(const std::vector<std::string>& exprs, std::vector<Expr>& out) {
+    out.clear();
+    for (const std::string& raw : exprs) {
+        const std::u32string e = decode(raw);
+        bool found = false;
+        for (int op = 0; op < 2 && !found; ++op) {   // eq first, then noteq (constraint.go:51-68: first operator that splits)
+            const char32_t c0 = op == 0 ? U'=' : U'!';
+            size_t pos = std::u32string::npos;
+            for (size_t i = 0; i + 1 < e.size(); ++i)
+                if (e[i] == c0 && e[i + 1] == U'=') { pos = i; break; }
+            if (pos == std::u32string::npos) continue;
+            Expr x;
+            x.key = trim(e, 0, pos);
+            x.op = op;
+            x.exp = trim(e, pos + 2, e.size());
+            if (!key_ok(x.key) || !value_ok(x.exp)) return false;
+            out.push_back(std::move(x));
+            found = true;
+        }
+        if (!found) return false;
+    }
+    return true;
+}
+
+// net.ParseIP (constraint.go:128-146): dotted decimal without leading zeros, or RFC 4291 text; no zone.
+static bool parse_ip(const std::string& s, uint8_t out[16], bool* is_v4) {
+    if (s.empty() || s.find('%') != std::string::npos || std::strlen(s.c_str()) != s.size()) return false;
+    unsigned char b4[4];
+    if (s.find(':') == std::string::npos) {
+        if (inet_pton(AF_INET, s.c_str(), b4) != 1) return false;
+        std::memset(out, 0, 10);
+        out[10] = out[11] = 0xFF;
+        std::memcpy(out + 12, b4, 4);
+        *is_v4 = true;
+        return true;
+    }
+    if (inet_pton(AF_INET6, s.c_str(), out) != 1) return false;
+    bool mapped = out[10] == 0xFF && out[11] == 0xFF;
+    for (int i = 0; i < 10; ++i) mapped = mapped && out[i] == 0;
+    *is_v4 = mapped;
+    return true;
+}
+
+// Pipeline.Explain (pipeline.go:84-103): entries sorted by failure count, descending, stable for ≤ 12 elements
+// (insertion sort inside sort.Sort), zero counts skipped; each filter's Explain(nodes) text (filter.go).
+static std::string explain(const uint32_t* hist) {
+    static const char* one[SWP_NFILTERS] = {"1 node not available for new tasks", "insufficient resources on 1 node", "missing plugin on 1 node",
+                                            "scheduling constraints not satisfied on 1 node", "unsupported platform on 1 node",
+                                            "host-mode port already in use on 1 node", "max replicas per node limit exceed",
+                                            "cannot fulfill requested CSI volume mounts on 1 node"};
+    static const char* many[SWP_NFILTERS] = {"%u nodes not available for new tasks", "insufficient resources on %u nodes", "missing plugin on %u nodes",
+                                             "scheduling constraints not satisfied on %u nodes", "unsupported platform on %u nodes",
+                                             "host-mode port already in use on %u nodes", "max replicas per node limit exceed",
+                                             "cannot fulfill requested CSI volume mounts on %u nodes"};
+    int order[SWP_NFILTERS];
+    for (int i = 0; i < SWP_NFILTERS; ++i) order[i] = i;
+    std::stable_sort(order, order + SWP_NFILTERS, [&](int a, int b) { return hist[a] > hist[b]; });
+    std::string out;
+    for (int k = 0; k < SWP_NFILTERS; ++k) {
+        const int i = order[k];
+        const uint32_t n = hist[i];
+        if (n == 0) continue;
+        if (!out.empty()) out += "; ";
+        if (n == 1) out += one[i];
+        else {
+            char buf[96];
+            std::snprintf(buf, sizeof buf, many[i], n);
+            out += buf;
+        }
+    }
+    return out;
+}
+
+// An insertion-ordered map (Go code ranges over maps in random order; the canonical order of this implementation is
+// first-insertion order, the same as the oracle's): assigning an existing key keeps its position.
+class OrderedTasks {
+  public:
+    void put(const std::string& id, Value t) {
+        auto it = index_.find(id);
+        if (it != index_.end()) { it->second->second = std::move(t); return; }
+        items_.emplace_back(id, std::move(t));
+        index_[id] = std::prev(items_.end());
+    }
+    void erase(const std::string& id) {
+        auto it = index_.find(id);
+        if (it == index_.end()) return;
+        items_.erase(it->second);
+        index_.erase(it);
+    }
+    void clear() { items_.clear(); index_.clear(); }
+    std::vector<std::pair<std::string, Value>> snapshot() const { return {items_.begin(), items_.end()}; }
+    bool empty() const { return items_.empty(); }
+
+  private:
+    std::list<std::pair<std::string, Value>> items_;
+    std::unordered_map<std::string, std::list<std::pair<std::string, Value>>::iterator> index_;
+};
+
+using FailureKey = std::pair<std::string, int64_t>;   // versionedService: (ServiceID, SpecVersion.Index) — nodeinfo.go:18-26
+
+// The non-numeric half of scheduler.NodeInfo (nodeinfo.go:28-44); the numeric half lives in the engine's node row.
+struct NodeInfo {
+    Value node;                                           // *api.Node
+    uint32_t idx = 0;                                     // engine node index
+    std::map<std::string, Value> Tasks;                   // NodeInfo.Tasks
+    std::map<FailureKey, std::vector<int64_t>> recentFailures;
+    int64_t lastCleanup = 0;
+};
+
+class Scheduler {
+  public:
+    explicit Scheduler(swp_engine* e) : e_(e) { ck(swp_reset(e_, 0), "swp_reset"); }
+
+    std::string scratch;   // result storage handed out through const char**
+    std::string last_error;
+
+    // ---------------------------------------------------------------------------------------------- nodes
+    // createOrUpdateNode, scheduler.go:368-396
+    void createOrUpdateNode(const Value& n) {
+        const std::string& nid = task_id(n);
+        auto it = nodes_.find(nid);
+        NodeInfo* ni = it == nodes_.end() ? nullptr : &it->second;
+        const Value* res = at(&n, {"Description", "Resources"});
+        int64_t cpu = 0, mem = 0;
+        if (res != nullptr) {
+            if (truthy(res->get("Generic"))) unsupported("generic resources stay on the Go path");
+            cpu = as_i64(res->get("NanoCPUs"));
+            mem = as_i64(res->get("MemoryBytes"));
+            if (ni != nullptr) {   // :376-381: subtract the reservations of the tasks already on the node
+                for (const auto& kv : ni->Tasks) {
+                    int64_t c, m;
+                    taskReservations(kv.second, c, m);
+                    cpu -= c;
+                    mem -= m;
+                }
+            }
+        }
+        const uint32_t idx = intern(SWP_SPACE_NODE_ID, nid);
+        uint32_t total = 0;
+        if (ni != nullptr) {
+            swp_node_row cur;
+            int rc = swp_node_get(e_, idx, &cur);
+            if (rc == SWP_OK) total = cur.total;
+            else if (rc != SWP_ENOTFOUND) ck(rc, "swp_node_get");
+        } else {
+            NodeInfo fresh;
+            fresh.idx = idx;
+            fresh.lastCleanup = now_;
+            ni = &nodes_.emplace(nid, std::move(fresh)).first->second;
+            if (idx_to_id_.size() <= idx) idx_to_id_.resize(idx + 1);
+            idx_to_id_[idx] = nid;
+        }
+        ni->node = n;
+        upsertRow(n, idx, cpu, mem, total);
+    }
+    // nodeSet.remove, nodeset.go:46-48
+    void deleteNode(const std::string& nid) {
+        auto it = nodes_.find(nid);
+        if (it == nodes_.end()) return;
+        const uint32_t idx = it->second.idx;
+        nodes_.erase(it);
+        ck(swp_node_remove(e_, idx), "swp_node_remove");
+    }
+    // nodeSet.nodeInfo, nodeset.go:23-29
+    bool nodeInfo(const std::string& nid, std::string& out) {
+        auto it = nodes_.find(nid);
+        if (it == nodes_.end()) return false;
+        NodeInfo& ni = it->second;
+        swp_node_row row;
+        ck(swp_node_get(e_, ni.idx, &row), "swp_node_get");
+        Value by_service = Value::object(), tasks = Value::array(), fails = Value::object();
+        for (const auto& kv : ni.Tasks) {
+            const std::string& sid = as_str(kv.second.get("ServiceID"));
+            uint32_t c = 0;
+            ck(swp_node_get_svc_count(e_, ni.idx, intern(SWP_SPACE_SERVICE, sid), &c), "swp_node_get_svc_count");
+            if (c) by_service.set(sid, Value::integer(c));
+            tasks.push(Value::str(kv.first));
+        }
+        for (const auto& kv : ni.recentFailures) fails.set(kv.first.first + "@" + std::to_string(kv.first.second), Value::integer((int64_t)kv.second.size()));
+        Value avail = Value::object();
+        avail.set("NanoCPUs", Value::integer(row.cpu));
+        avail.set("MemoryBytes", Value::integer(row.mem));
+        avail.set("Generic", Value::array());
+        Value info = Value::object();
+        info.set("ID", Value::str(nid));
+        info.set("ActiveTasksCount", Value::integer(row.total));
+        info.set("ActiveTasksCountByService", by_service);
+        info.set("AvailableResources", avail);
+        info.set("Tasks", tasks);
+        info.set("RecentFailures", fails);
+        out = json::dump(info);
+        return true;
+    }
+
+    // ---------------------------------------------------------------------------------------------- services / clock
+    void setService(const std::string& sid, bool has_version, uint64_t version) {
+        services_[sid] = has_version ? std::optional<uint64_t>(version) : std::nullopt;
+    }
+    void deleteService(const std::string& sid) { services_.erase(sid); }
+    void advance(int64_t ns) { now_ += ns; }
+
+    // ---------------------------------------------------------------------------------------------- task events
+    // Tasks the engine cannot judge (generic resources, CSI cluster volumes) are refused at the event boundary — the shim
+    // leaves them to the Go scheduler's own path — so that a tick never meets one half-way through a batch.
+    static void requireSupported(const Value& t) {
+        if (truthy(at(&t, {"Spec", "Resources", "Reservations", "Generic"}))) unsupported("generic resources stay on the Go path");
+        const Value* mounts = at(&t, {"Spec", "Container", "Mounts"});
+        if (mounts != nullptr && mounts->is_arr())
+            for (const Value& m : *mounts->a)
+                if (enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) == MOUNT_CLUSTER)
+                    unsupported("CSI cluster volumes stay on the Go path");
+    }
+    // createTask, scheduler.go:254-283
+    bool createTask(const Value& t) {
+        const int64_t st = task_state(at(&t, {"Status", "State"}));
+        if (st < PENDING || st > RUNNING) return false;
+        requireSupported(t);
+        const std::string& id = task_id(t);
+        allTasks_[id] = t;
+        if (!truthy(t.get("NodeID"))) {
+            unassignedTasks_.put(id, t);   // enqueue, :250-252
+            return true;
+        }
+        if (st == PENDING) {
+            preassignedTasks_.insert(id);
+            pendingPreassignedTasks_.put(id, t);
+            return false;   // preassigned tasks are processed by processPreassignedTasks, not tick
+        }
+        auto it = nodes_.find(as_str(t.get("NodeID")));
+        if (it != nodes_.end()) addTask(it->second, t);
+        return false;
+    }
+    // setupTasksList, scheduler.go:68-126: a task found in the store at start-up. One rule differs from the createTask
+    // event: a task still PENDING whose desired state is already past COMPLETED is ignored (:93-101).
+    bool setupTask(const Value& t) {
+        if (task_state(at(&t, {"Status", "State"})) == PENDING && task_state(t.get("DesiredState")) > COMPLETE) return false;
+        return createTask(t);
+    }
+    // updateTask, scheduler.go:283-348
+    bool updateTask(const Value& t) {
+        const int64_t st = task_state(at(&t, {"Status", "State"}));
+        if (st < PENDING) return false;
+        const std::string& id = task_id(t);
+        auto old_it = allTasks_.find(id);
+        const bool has_old = old_it != allTasks_.end();
+        if (st > RUNNING) {
+            if (!has_old) return false;
+            const Value old = old_it->second;
+            if (st != task_state(at(&old, {"Status", "State"})) && (st == FAILED || st == REJECTED)) {
+                if (preassignedTasks_.count(id) == 0) {   // preassigned tasks do not count against the node, :303-310
+                    auto n = nodes_.find(as_str(t.get("NodeID")));
+                    if (n != nodes_.end()) taskFailed(n->second, t);
+                }
+            }
+            deleteTask(old);
+            return true;
+        }
+        requireSupported(t);
+        if (!truthy(t.get("NodeID"))) {
+            if (has_old) {
+                const Value old = old_it->second;
+                deleteTask(old);
+            }
+            allTasks_[id] = t;
+            unassignedTasks_.put(id, t);
+            return true;
+        }
+        if (st == PENDING) {
+            if (has_old) {
+                const Value old = old_it->second;
+                deleteTask(old);
+            }
+            preassignedTasks_.insert(id);
+            allTasks_[id] = t;
+            pendingPreassignedTasks_.put(id, t);
+            return false;
+        }
+        allTasks_[id] = t;
+        auto n = nodes_.find(as_str(t.get("NodeID")));
+        if (n != nodes_.end()) addTask(n->second, t);
+        return false;
+    }
+    // deleteTask, scheduler.go:350-366
+    bool deleteTask(const Value& t) {
+        const std::string id = task_id(t);
+        allTasks_.erase(id);
+        preassignedTasks_.erase(id);
+        pendingPreassignedTasks_.erase(id);
+        auto n = nodes_.find(as_str(t.get("NodeID")));
+        if (n != nodes_.end() && removeTask(n->second, t)) return true;
+        return false;
+    }
+
+    // ---------------------------------------------------------------------------------------------- Pipeline.SetTask
+    // One swp_task_desc from an api.Task: every Filter.SetTask of the pipeline (pipeline.go:76-81, filter.go).
+    swp_task_desc taskDesc(const Value& t) {
+        swp_task_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.service = intern(SWP_SPACE_SERVICE, as_str(t.get("ServiceID")));
+        if (const Value* res = at(&t, {"Spec", "Resources", "Reservations"})) {   // ResourceFilter.SetTask, filter.go:61-74
+            if (truthy(res->get("Generic"))) unsupported("generic resources stay on the Go path");
+            d.cpu = as_i64(res->get("NanoCPUs"));
+            d.mem = as_i64(res->get("MemoryBytes"));
+            if (d.cpu != 0 || d.mem != 0) d.flags |= SWP_TASK_RES_ENABLED;
+        }
+        if (task_state(t.get("DesiredState")) > COMPLETE) d.flags |= 0x2u;   // SWP_TASK_UNCOUNTED: nodeinfo.go:148
+        if (const Value* pl = at(&t, {"Spec", "Placement"})) {
+            d.constraint_set = constraintSet(pl->get("Constraints"));          // ConstraintFilter.SetTask, filter.go:218-232
+            if (const Value* plats = pl->get("Platforms")) {                    // PlatformFilter.SetTask, filter.go:253-263
+                if (plats->is_arr() && plats->size() > 0) {
+                    std::vector<swp_platform> ps;
+                    for (const Value& p : *plats->a) ps.push_back({intern(SWP_SPACE_OS, as_str(p.get("OS"))), intern(SWP_SPACE_ARCH, as_str(p.get("Architecture")))});
+                    ck(swp_platform_set(e_, ps.data(), (uint32_t)ps.size(), &d.platform_set), "swp_platform_set");
+                }
+            }
+            d.max_replicas = (uint64_t)as_i64(pl->get("MaxReplicas"));          // MaxReplicasFilter.SetTask, filter.go:363-370
+            if (const Value* prefs = pl->get("Preferences")) {                  // nodeset.go:59-82: only label spreads make a level
+                std::vector<swp_spread> levels;
+                if (prefs->is_arr())
+                    for (const Value& pref : *prefs->a) {
+                        const Value* sp = pref.get("Spread");
+                        if (sp == nullptr) continue;
+                        const std::u32string sd = decode(as_str(sp->get("SpreadDescriptor")));
+                        uint32_t kind, key;
+                        if (labelKey(sd, kind, key)) levels.push_back({kind, key});
+                    }
+                if (!levels.empty()) ck(swp_spread_set(e_, levels.data(), (uint32_t)levels.size(), &d.spread_set), "swp_spread_set");
+            }
+        }
+        // PluginFilter.SetTask, filter.go:119-131 (+ Check :133-177 decides what counts as a requirement)
+        std::vector<std::string> vol;
+        if (const Value* mounts = at(&t, {"Spec", "Container", "Mounts"})) {
+            if (mounts->is_arr()) {
+                for (const Value& m : *mounts->a)
+                    if (enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) == MOUNT_CLUSTER)
+                        unsupported("CSI cluster volumes stay on the Go path");
+                for (const Value& m : *mounts->a) {
+                    if (enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) != MOUNT_VOLUME) continue;
+                    const Value* dc = at(&m, {"VolumeOptions", "DriverConfig"});
+                    if (dc == nullptr) continue;
+                    const Value* name = dc->get("Name");
+                    if (name == nullptr || !name->is_str() || name->s.empty() || name->s == "local") continue;
+                    vol.push_back(name->s);
+                }
+            }
+        }
+        const Value* nets = t.get("Networks");
+        const bool has_nets = truthy(nets) && nets->is_arr();
+        const Value* logd = at(&t, {"Spec", "LogDriver"});
+        if (has_nets || logd != nullptr || !vol.empty()) {
+            std::vector<uint32_t> req;
+            for (const std::string& v : vol) req.push_back(intern(SWP_SPACE_PLUGIN, std::string("Volume") + '\0' + v));
+            if (has_nets)
+                for (const Value& na : *nets->a) {
+                    const std::string& name = as_str(at(&na, {"Network", "DriverState", "Name"}));
+                    if (!name.empty()) req.push_back(intern(SWP_SPACE_PLUGIN, std::string("Network") + '\0' + name));
+                }
+            uint32_t log = 0;
+            if (logd != nullptr) {
+                const Value* name = logd->get("Name");
+                if (name != nullptr && name->is_str() && !name->s.empty() && name->s != "none") log = intern(SWP_SPACE_PLUGIN, std::string("Log") + '\0' + name->s);
+            }
+            if (!req.empty() || log != 0) ck(swp_plugin_set(e_, req.empty() ? &log : req.data(), (uint32_t)req.size(), log, &d.plugin_set), "swp_plugin_set");
+        }
+        d.port_set = portSet(t);                                                 // HostPortFilter.SetTask, filter.go:322-333
+        d.spec_version = (uint64_t)as_i64(at(&t, {"SpecVersion", "Index"}));
+        return d;
+    }
+    // Placement.Constraints → predicate set id; 0 = filter disabled (empty list, or constraint.Parse failed: filter.go:223-229)
+    uint32_t constraintSet(const Value* cons) {
+        if (cons == nullptr || !cons->is_arr() || cons->size() == 0) return 0;
+        std::vector<std::string> exprs;
+        for (const Value& c : *cons->a) exprs.push_back(as_str(&c));
+        std::vector<Expr> parsed;
+        if (!parse_constraints(exprs, parsed)) return 0;
+        std::vector<swp_constraint> cs;
+        for (const Expr& x : parsed) cs.push_back(constraintStruct(x));
+        uint32_t id = 0;
+        ck(swp_constraint_set(e_, cs.data(), (uint32_t)cs.size(), &id), "swp_constraint_set");
+        return id;
+    }
+
+    // ---------------------------------------------------------------------------------------------- preassigned
+    // processPreassignedTasks + taskFitNode, scheduler.go:398-426, 646-690
+    Value processPreassignedTasks() {
+        Value decisions = Value::array();
+        for (auto& kv : pendingPreassignedTasks_.snapshot()) {
+            const std::string& tid = kv.first;
+            const Value& t = kv.second;
+            auto n = nodes_.find(as_str(t.get("NodeID")));
+            if (n == nodes_.end()) continue;   // node not (yet) known: the task stays pending, :651-656
+            Value newT = t.shallow_copy();
+            const swp_task_desc d = taskDesc(t);
+            int32_t ff = -1;
+            ck(swp_check_node(e_, &d, n->second.idx, &ff), "swp_check_node");
+            if (ff >= 0) {
+                uint32_t hist[SWP_NFILTERS] = {0};
+                hist[ff] = 1;
+                Value status = statusCopy(t);
+                status.set("Err", Value::str(explain(hist)));   // newT.Status.Err = s.pipeline.Explain(), :660
+                newT.set("Status", status);
+                allTasks_[tid] = newT;
+            } else {
+                Value status = Value::object();
+                status.set("State", Value::integer(ASSIGNED));
+                status.set("Message", Value::str("scheduler confirmed task can run on preassigned node"));
+                newT.set("Status", status);
+                allTasks_[tid] = newT;
+                addTask(n->second, newT);
+                pendingPreassignedTasks_.erase(tid);
+            }
+            decisions.push(decision(t, newT));
+        }
+        return decisions;
+    }
+
+    // ---------------------------------------------------------------------------------------------- tick
+    // tick, scheduler.go:429-488: task groups (ServiceID, SpecVersion) in first-seen order, then the one-off tasks in
+    // queue order; every scheduling step is a device call.
+    Value tick() {
+        using Item = std::pair<std::string, Value>;
+        std::vector<Item> queue;
+        for (auto& kv : unassignedTasks_.snapshot())
+            if (!truthy(kv.second.get("NodeID"))) queue.push_back(std::move(kv));
+        unassignedTasks_.clear();
+        Value decisions = Value::array();
+        if (queue.empty()) return decisions;
+        std::set<std::string> sids;
+        for (const Item& it : queue) sids.insert(as_str(it.second.get("ServiceID")));
+        pushFailures(sids);
+        std::vector<std::vector<Item>> groups;
+        std::map<FailureKey, size_t> group_of;
+        std::vector<Item> one_off;
+        for (Item& it : queue) {
+            if (it.second.get("SpecVersion") != nullptr) {   // :442-459: tasks with a spec version are grouped
+                FailureKey k{as_str(it.second.get("ServiceID")), as_i64(at(&it.second, {"SpecVersion", "Index"}))};
+                auto g = group_of.find(k);
+                if (g == group_of.end()) {
+                    group_of[k] = groups.size();
+                    groups.emplace_back();
+                    groups.back().push_back(std::move(it));
+                } else groups[g->second].push_back(std::move(it));
+            } else one_off.push_back(std::move(it));
+        }
+        runGroups(groups, 0, groups.size(), decisions);
+        // one-off tasks (:460-466): a task with spread preferences is a group of one and keeps its place in the order
+        std::vector<Item> run;
+        for (Item& it : one_off) {
+            if (taskDesc(it.second).spread_set != 0) {
+                runOneOffs(run, decisions);
+                run.clear();
+                std::vector<std::vector<Item>> single(1);
+                single[0].push_back(std::move(it));
+                runGroups(single, 0, 1, decisions);
+            } else run.push_back(std::move(it));
+        }
+        runOneOffs(run, decisions);
+        return decisions;
+    }
+
+    // ---------------------------------------------------------------------------------------------- constraint enforcer
+    // constraintenforcer.rejectNoncompliantTasks for many nodes (constraint_enforcer.go:65-196) through swp_enforce.
+    Value enforce(const Value& req) {
+        const Value* node_docs = req.get("nodes");
+        const Value* tbn = req.get("tasks_by_node");
+        const Value* services = req.get("services");
+        std::vector<swp_enforce_node> nrec;
+        std::vector<swp_enforce_task> trec;
+        std::vector<std::pair<std::string, std::string>> owners;
+        Value out = Value::object();
+        if (node_docs == nullptr || !node_docs->is_arr()) return out;
+        for (const Value& nd : *node_docs->a) {
+            if (enum_value(at(&nd, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) != AVAILABILITY_ACTIVE) continue;   // :70-72
+            const std::string& nid = task_id(nd);
+            std::vector<const Value*> tasks;
+            if (const Value* lst = tbn != nullptr ? tbn->get(nid.c_str()) : nullptr)
+                if (lst->is_arr())
+                    for (const Value& t : *lst->a) tasks.push_back(&t);
+            std::stable_sort(tasks.begin(), tasks.end(), [](const Value* a, const Value* b) { return task_id(*a) < task_id(*b); });
+            const Value* res = at(&nd, {"Description", "Resources"});
+            bool generic = res != nullptr && truthy(res->get("Generic"));
+            for (const Value* t : tasks) generic = generic || truthy(t->get("AssignedGenericResources"));
+            if (generic) unsupported("generic resources stay on the Go path");
+            auto ni = nodes_.find(nid);
+            if (ni == nodes_.end()) fail(SWP_ENOTFOUND, "enforce: node " + nid + " is not in the nodeSet");
+            const uint32_t first = (uint32_t)trec.size();
+            for (const Value* t : tasks) {
+                const Value* svc = services != nullptr ? services->get(as_str(t->get("ServiceID")).c_str()) : nullptr;
+                // :152-168: the CURRENT service spec decides; the task's own placement only when the service is gone
+                const Value* pl = svc != nullptr ? at(svc, {"Spec", "Task", "Placement"}) : at(t, {"Spec", "Placement"});
+                swp_enforce_task r;
+                std::memset(&r, 0, sizeof r);
+                r.constraint_set = constraintSet(pl != nullptr ? pl->get("Constraints") : nullptr);
+                const Value* rsv = at(t, {"Spec", "Resources", "Reservations"});
+                if (rsv != nullptr) {
+                    r.cpu = as_i64(rsv->get("NanoCPUs"));
+                    r.mem = as_i64(rsv->get("MemoryBytes"));
+                    r.flags = SWP_ENF_RESERVATIONS;
+                }
+                r.desired_state = (uint32_t)task_state(t->get("DesiredState"));
+                r.state = (uint32_t)task_state(at(t, {"Status", "State"}));
+                trec.push_back(r);
+                owners.emplace_back(nid, task_id(*t));
+            }
+            swp_enforce_node n;
+            std::memset(&n, 0, sizeof n);
+            n.node = ni->second.idx;
+            n.first_task = first;
+            n.n_tasks = (uint32_t)trec.size() - first;
+            n.cpu = res != nullptr ? as_i64(res->get("NanoCPUs")) : 0;
+            n.mem = res != nullptr ? as_i64(res->get("MemoryBytes")) : 0;
+            nrec.push_back(n);
+            out.set(nid, Value::array());
+        }
+        if (trec.empty()) return out;
+        std::vector<uint8_t> rej(trec.size(), 0);
+        ck(swp_enforce(e_, nrec.data(), (uint32_t)nrec.size(), trec.data(), (uint32_t)trec.size(), rej.data()), "swp_enforce");
+        for (size_t i = 0; i < rej.size(); ++i)
+            if (rej[i])
+                for (json::Member& m : *out.o)
+                    if (m.first == owners[i].first) { m.second.push(Value::str(owners[i].second)); break; }
+        return out;
+    }
+
+  private:
+    using Item = std::pair<std::string, Value>;
+    swp_engine* e_;
+    int64_t now_ = 1000000000000LL;
+    std::map<std::string, NodeInfo> nodes_;                               // nodeSet.nodes (ordered: deterministic call order)
+    std::vector<std::string> idx_to_id_;
+    std::unordered_map<std::string, std::optional<uint64_t>> services_;   // store.GetService: existence + SpecVersion
+    OrderedTasks unassignedTasks_;                                         // Scheduler.unassignedTasks
+    OrderedTasks pendingPreassignedTasks_;                                 // Scheduler.pendingPreassignedTasks
+    std::set<std::string> preassignedTasks_;                               // Scheduler.preassignedTasks
+    std::unordered_map<std::string, Value> allTasks_;                      // Scheduler.allTasks
+
+    void ck(int rc, const char* what) {
+        if (rc != SWP_OK) fail(rc, std::string(what) + ": " + swp_strerror(rc) + ": " + swp_last_error(e_));
+    }
+    uint32_t intern(int space, const std::string& s) {
+        uint32_t id = 0;
+        ck(swp_intern(e_, space, s.data(), s.size(), &id), "swp_intern");
+        return id;
+    }
+    uint32_t folded(const Value* v) { return intern(SWP_SPACE_FOLDED, as_str(v)); }
+
+    // "node.labels.<name>" / "engine.labels.<name>" (prefix compared with EqualFold, the name is case-sensitive:
+    // constraint.go:177-199, nodeset.go:69-81)
+    bool labelKey(const std::u32string& key, uint32_t& kind, uint32_t& id) {
+        static const size_t nl = std::strlen("node.labels."), el = std::strlen("engine.labels.");
+        if (key.size() > nl && equal_fold(key, nl, "node.labels.")) {
+            kind = SWP_CK_NODE_LABEL;
+            id = intern(SWP_SPACE_LABEL_KEY, encode(key, nl));
+            return true;
+        }
+        if (key.size() > el && equal_fold(key, el, "engine.labels.")) {
+            kind = SWP_CK_ENGINE_LABEL;
+            id = intern(SWP_SPACE_LABEL_KEY, encode(key, el));
+            return true;
+        }
+        return false;
+    }
+    // the key dispatch of Constraint.Match, constraint.go:109-203
+    swp_constraint constraintStruct(const Expr& x) {
+        swp_constraint c;
+        std::memset(&c, 0, sizeof c);
+        c.kind = SWP_CK_INVALID;
+        c.op = (uint32_t)x.op;
+        const std::string exp = encode(x.exp);
+        c.value = intern(SWP_SPACE_FOLDED, exp);
+        const size_t n = x.key.size();
+        if (equal_fold(x.key, n, "node.id")) c.kind = SWP_CK_NODE_ID;
+        else if (equal_fold(x.key, n, "node.hostname")) c.kind = SWP_CK_HOSTNAME;
+        else if (equal_fold(x.key, n, "node.ip")) {
+            c.kind = SWP_CK_IP;
+            bool v4 = false;
+            if (parse_ip(exp, c.ip, &v4)) {
+                c.ip_kind = SWP_IP_SINGLE;
+                c.ip_is_v4 = v4 ? 1 : 0;
+            } else {
+                // net.ParseCIDR: "<address>/<decimal prefix length>", the length bounded by the address family as written
+                c.ip_kind = SWP_IP_MALFORMED;
+                std::memset(c.ip, 0, sizeof c.ip);
+                const size_t slash = exp.find('/');
+                if (slash != std::string::npos) {
+                    const std::string addr = exp.substr(0, slash), plen = exp.substr(slash + 1);
+                    uint8_t a[16];
+                    bool dummy = false;
+                    const bool digits = !plen.empty() && plen.size() <= 3 && std::all_of(plen.begin(), plen.end(), [](char ch) { return ch >= '0' && ch <= '9'; });
+                    if (digits && parse_ip(addr, a, &dummy)) {
+                        const bool syntactic_v4 = addr.find(':') == std::string::npos;
+                        const int bits = syntactic_v4 ? 32 : 128, len = std::atoi(plen.c_str());
+                        if (len <= bits) {
+                            c.ip_kind = SWP_IP_CIDR;
+                            c.ip_is_v4 = syntactic_v4 ? 1 : 0;
+                            c.prefix_len = (uint32_t)(len + (syntactic_v4 ? 96 : 0));
+                            std::memcpy(c.ip, a, 16);
+                        }
+                    }
+                }
+            }
+        } else if (equal_fold(x.key, n, "node.role")) c.kind = SWP_CK_ROLE;
+        else if (equal_fold(x.key, n, "node.platform.os")) c.kind = SWP_CK_PLATFORM_OS;
+        else if (equal_fold(x.key, n, "node.platform.arch")) c.kind = SWP_CK_PLATFORM_ARCH;
+        else {
+            uint32_t kind, key;
+            if (labelKey(x.key, kind, key)) {
+                c.kind = kind;
+                c.key = key;
+            }
+        }
+        return c;
+    }
+
+    // node document → numeric row + interned labels / plugins (every field the path reads)
+    void upsertRow(const Value& doc, uint32_t idx, int64_t cpu, int64_t mem, uint32_t total) {
+        swp_node_row row;
+        std::memset(&row, 0, sizeof row);
+        row.node = idx;
+        row.cpu = cpu;
+        row.mem = mem;
+        row.total = total;
+        uint32_t flags = 0;
+        const int64_t st = enum_value(at(&doc, {"Status", "State"}), {{"UNKNOWN", 0}, {"DOWN", 1}, {"READY", 2}, {"DISCONNECTED", 3}});
+        const int64_t av = enum_value(at(&doc, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}});
+        if (st == NODE_STATE_READY && av == AVAILABILITY_ACTIVE) flags |= SWP_NODE_READY;   // ReadyFilter, filter.go:41-44
+        if (enum_value(doc.get("Role"), {{"WORKER", 0}, {"MANAGER", 1}}) == 1) flags |= SWP_NODE_MANAGER;
+        row.id_fold = folded(doc.get("ID"));
+        std::vector<swp_kv> lab, elab;
+        std::vector<uint32_t> plugins;
+        auto kvs = [&](const Value* labels, std::vector<swp_kv>& out) {
+            if (!labels->is_obj()) return;
+            for (const json::Member& m : *labels->o)
+                out.push_back({intern(SWP_SPACE_LABEL_KEY, m.first), folded(&m.second), intern(SWP_SPACE_RAW, as_str(&m.second))});
+        };
+        if (const Value* labels = at(&doc, {"Spec", "Annotations", "Labels"})) {
+            flags |= SWP_NODE_HAS_LABELS;
+            kvs(labels, lab);
+        }
+        if (const Value* desc = doc.get("Description")) {
+            flags |= SWP_NODE_HAS_DESC;
+            row.hostname_fold = folded(desc->get("Hostname"));
+            if (const Value* plat = desc->get("Platform")) {
+                flags |= SWP_NODE_HAS_PLATFORM;
+                row.os = intern(SWP_SPACE_OS, as_str(plat->get("OS")));
+                row.arch = intern(SWP_SPACE_ARCH, as_str(plat->get("Architecture")));
+                row.os_fold = folded(plat->get("OS"));
+                row.arch_fold = folded(plat->get("Architecture"));
+            }
+            if (const Value* eng = desc->get("Engine")) {
+                flags |= SWP_NODE_HAS_ENGINE;
+                if (const Value* el = eng->get("Labels")) {
+                    flags |= SWP_NODE_HAS_ELABELS;
+                    kvs(el, elab);
+                }
+                const Value* pl = eng->get("Plugins");
+                if (pl != nullptr && pl->is_arr())
+                    for (const Value& p : *pl->a) {
+                        const std::string &typ = as_str(p.get("Type")), &name = as_str(p.get("Name"));
+                        if (typ == "Log") flags |= SWP_NODE_HAS_LOGPLUG;
+                        plugins.push_back(intern(SWP_SPACE_PLUGIN, typ + '\0' + name));
+                        static const std::string latest = ":latest";   // filter.go:189-199: "name" also matches "name:latest"
+                        if (name.size() >= latest.size() && name.compare(name.size() - latest.size(), latest.size(), latest) == 0)
+                            plugins.push_back(intern(SWP_SPACE_PLUGIN, typ + '\0' + name.substr(0, name.size() - latest.size())));
+                    }
+            }
+        }
+        bool v4 = false;
+        if (parse_ip(as_str(at(&doc, {"Status", "Addr"})), row.ip, &v4)) flags |= SWP_NODE_IP_VALID | (v4 ? SWP_NODE_IP_V4 : 0u);
+        else std::memset(row.ip, 0, sizeof row.ip);
+        row.flags = flags;
+        row.version = (uint64_t)as_i64(at(&doc, {"Meta", "Version", "Index"}));
+        static const swp_kv no_kv = {0, 0, 0};
+        static const uint32_t no_plugin = 0;
+        ck(swp_node_upsert(e_, &row, lab.empty() ? &no_kv : lab.data(), (uint32_t)lab.size(), elab.empty() ? &no_kv : elab.data(), (uint32_t)elab.size(),
+                           plugins.empty() ? &no_plugin : plugins.data(), (uint32_t)plugins.size()),
+           "swp_node_upsert");
+    }
+
+    // taskReservations, nodeinfo.go:156-161
+    static void taskReservations(const Value& t, int64_t& cpu, int64_t& mem) {
+        const Value* r = at(&t, {"Spec", "Resources", "Reservations"});
+        cpu = r != nullptr ? as_i64(r->get("NanoCPUs")) : 0;
+        mem = r != nullptr ? as_i64(r->get("MemoryBytes")) : 0;
+    }
+    // host-mode published ports of the task (filter.go:322-333, nodeinfo.go:78-84,139-145) → port-set id, 0 = none
+    uint32_t portSet(const Value& t) {
+        const Value* ports = at(&t, {"Endpoint", "Ports"});
+        if (ports == nullptr || !ports->is_arr()) return 0;
+        std::vector<swp_port> ps;
+        for (const Value& p : *ports->a) {
+            if (enum_value(p.get("PublishMode"), {{"INGRESS", 0}, {"HOST", 1}}) != PUBLISH_HOST) continue;
+            const int64_t port = as_i64(p.get("PublishedPort"));
+            if (port == 0) continue;
+            ps.push_back({(uint32_t)enum_value(p.get("Protocol"), {{"TCP", 0}, {"UDP", 1}, {"SCTP", 2}}, 0, true), (uint32_t)port});
+        }
+        if (ps.empty()) return 0;
+        uint32_t id = 0;
+        ck(swp_port_set(e_, ps.data(), (uint32_t)ps.size(), &id), "swp_port_set");
+        return id;
+    }
+    void commit(const NodeInfo& ni, const Value& t, bool counted, bool with_resources, bool add) {
+        swp_placement p;
+        std::memset(&p, 0, sizeof p);
+        p.node = ni.idx;
+        p.service = intern(SWP_SPACE_SERVICE, as_str(t.get("ServiceID")));
+        if (with_resources) {
+            taskReservations(t, p.cpu, p.mem);
+            p.port_set = portSet(t);
+        }
+        p.counted = counted ? 1 : 0;
+        ck(swp_commit(e_, &p, 1, add ? 1 : 0), "swp_commit");
+    }
+    // NodeInfo.addTask, nodeinfo.go:108-154; true when nodeInfo was modified
+    bool addTask(NodeInfo& ni, const Value& t) {
+        const std::string& id = task_id(t);
+        const int64_t ds = task_state(t.get("DesiredState"));
+        auto old = ni.Tasks.find(id);
+        if (old != ni.Tasks.end()) {
+            const int64_t ods = task_state(old->second.get("DesiredState"));
+            if (ds <= COMPLETE && ods > COMPLETE) {          // :113-119: the task counts again
+                old->second = t;
+                commit(ni, t, true, false, true);
+                return true;
+            }
+            if (ods <= COMPLETE && ds > COMPLETE) {          // :120-126: the task stops counting
+                old->second = t;
+                commit(ni, t, true, false, false);
+                return true;
+            }
+            return false;
+        }
+        ni.Tasks[id] = t;
+        commit(ni, t, ds <= COMPLETE, true, true);
+        return true;
+    }
+    // NodeInfo.removeTask, nodeinfo.go:66-104
+    bool removeTask(NodeInfo& ni, const Value& t) {
+        auto old = ni.Tasks.find(task_id(t));
+        if (old == ni.Tasks.end()) return false;
+        const bool counted = task_state(old->second.get("DesiredState")) <= COMPLETE;
+        ni.Tasks.erase(old);
+        commit(ni, t, counted, true, false);
+        return true;
+    }
+    // NodeInfo.taskFailed (+ cleanupFailures), nodeinfo.go:163-202
+    void taskFailed(NodeInfo& ni, const Value& t) {
+        if (now_ - ni.lastCleanup >= MONITOR_FAILURES) {
+            for (auto it = ni.recentFailures.begin(); it != ni.recentFailures.end();) {
+                bool recent = false;
+                for (int64_t ts : it->second) recent = recent || (now_ - ts < MONITOR_FAILURES);
+                if (!recent) it = ni.recentFailures.erase(it);
+                else ++it;
+            }
+            ni.lastCleanup = now_;
+        }
+        FailureKey k{as_str(t.get("ServiceID")), as_i64(at(&t, {"SpecVersion", "Index"}))};
+        std::vector<int64_t>& lst = ni.recentFailures[k];
+        size_t expired = 0;
+        for (int64_t ts : lst) {
+            if (now_ - ts < MONITOR_FAILURES) break;
+            ++expired;
+        }
+        lst.erase(lst.begin(), lst.begin() + (std::ptrdiff_t)expired);
+        lst.push_back(now_);
+    }
+    // NodeInfo.countRecentFailures, nodeinfo.go:206-221
+    uint32_t countRecentFailures(const NodeInfo& ni, const FailureKey& k) const {
+        auto it = ni.recentFailures.find(k);
+        if (it == ni.recentFailures.end()) return 0;
+        const std::vector<int64_t>& lst = it->second;
+        int64_t count = (int64_t)lst.size();
+        for (int64_t i = count - 1; i >= 0; --i)
+            if (now_ - lst[(size_t)i] > MONITOR_FAILURES) {
+                count -= i + 1;
+                break;
+            }
+        return (uint32_t)count;
+    }
+    // the failure counts nodeLess reads (scheduler.go:706-735) for the services of the coming batch, at its `now`
+    void pushFailures(const std::set<std::string>& sids) {
+        for (auto& kv : nodes_)
+            for (auto& f : kv.second.recentFailures)
+                if (sids.count(f.first.first))
+                    ck(swp_node_set_failures(e_, kv.second.idx, intern(SWP_SPACE_SERVICE, f.first.first), (uint64_t)f.first.second, countRecentFailures(kv.second, f.first)),
+                       "swp_node_set_failures");
+    }
+
+    static Value statusCopy(const Value& t) {
+        const Value* s = t.get("Status");
+        return (s != nullptr && s->is_obj()) ? s->shallow_copy() : Value::object();
+    }
+    // what applySchedulingDecisions (scheduler.go:490-643) would write
+    static Value decision(const Value& old, const Value& neu) {
+        Value d = Value::object();
+        d.set("ID", Value::str(task_id(neu)));
+        d.set("ServiceID", Value::str(as_str(neu.get("ServiceID"))));
+        d.set("NodeID", Value::str(as_str(neu.get("NodeID"))));
+        d.set("State", Value::integer(task_state(at(&neu, {"Status", "State"}))));
+        d.set("Message", Value::str(as_str(at(&neu, {"Status", "Message"}))));
+        d.set("Err", Value::str(as_str(at(&neu, {"Status", "Err"}))));
+        d.set("OldState", Value::integer(task_state(at(&old, {"Status", "State"}))));
+        return d;
+    }
+    // scheduleNTasksOnNodes' bookkeeping for one placed task (scheduler.go:868-897); the numeric addTask already
+    // happened on the device
+    void place(const std::string& tid, const Value& t, int32_t n, Value& decisions) {
+        if ((size_t)n >= idx_to_id_.size()) fail(SWP_EINVAL, "engine returned an unknown node index");
+        const std::string& nid = idx_to_id_[(size_t)n];
+        Value newT = t.shallow_copy();
+        newT.set("NodeID", Value::str(nid));
+        Value status = Value::object();
+        status.set("State", Value::integer(ASSIGNED));
+        status.set("Message", Value::str("scheduler assigned task to node"));
+        newT.set("Status", status);
+        allTasks_[tid] = newT;
+        auto ni = nodes_.find(nid);
+        if (ni == nodes_.end()) fail(SWP_EINVAL, "engine placed a task on a node the nodeSet does not hold");
+        ni->second.Tasks[tid] = newT;
+        decisions.push(decision(t, newT));
+    }
+    // noSuitableNode, scheduler.go:928-971
+    void noSuitableNode(const std::string& tid, const Value& t, const uint32_t* hist, Value& decisions) {
+        auto svc = services_.find(as_str(t.get("ServiceID")));
+        if (svc == services_.end()) return;   // :935-939: the service is gone, the task is dropped
+        Value newT = t.shallow_copy();
+        const Value* tv = at(&t, {"SpecVersion", "Index"});
+        if (svc->second.has_value() && tv != nullptr && *svc->second > (uint64_t)as_i64(tv)) {
+            // :940-953: a task of an old revision that is meant to shut down anyway is moved to SHUTDOWN instead of retried
+            if (task_state(at(&t, {"Status", "State"})) == PENDING && task_state(t.get("DesiredState")) >= SHUTDOWN) {
+                Value status = statusCopy(t);
+                status.set("State", Value::integer(SHUTDOWN));
+                status.set("Err", Value::str(""));
+                newT.set("Status", status);
+            }
+        } else {
+            const std::string ex = explain(hist);
+            Value status = statusCopy(t);
+            status.set("Err", Value::str(ex.empty() ? "no suitable node" : "no suitable node (" + ex + ")"));
+            newT.set("Status", status);
+            unassignedTasks_.put(tid, newT);   // enqueue again, :968
+        }
+        allTasks_[tid] = newT;
+        decisions.push(decision(t, newT));
+    }
+    // groups[from, to): one swp_schedule_groups call, groups in order. One device call must not mix spec versions of one
+    // service (the failure buckets are per (service, version)): cut the ordered list where that would happen.
+    void runGroups(std::vector<std::vector<Item>>& groups, size_t from, size_t to, Value& decisions) {
+        if (from >= to) return;
+        std::map<std::string, int64_t> seen;
+        size_t cut = to;
+        for (size_t i = from; i < to; ++i) {
+            const Value& t0 = groups[i][0].second;
+            const std::string& sid = as_str(t0.get("ServiceID"));
+            const int64_t ver = as_i64(at(&t0, {"SpecVersion", "Index"}));
+            auto ins = seen.emplace(sid, ver);
+            if (!ins.second && ins.first->second != ver) { cut = i; break; }
+        }
+        if (cut != to) {
+            runGroups(groups, from, cut, decisions);
+            std::set<std::string> sids;
+            for (size_t i = cut; i < to; ++i) sids.insert(as_str(groups[i][0].second.get("ServiceID")));
+            pushFailures(sids);
+            runGroups(groups, cut, to, decisions);
+            return;
+        }
+        std::vector<swp_task_desc> descs;
+        std::vector<uint32_t> sizes;
+        size_t total = 0;
+        for (size_t i = from; i < to; ++i) {
+            descs.push_back(taskDesc(groups[i][0].second));
+            sizes.push_back((uint32_t)groups[i].size());
+            total += groups[i].size();
+        }
+        std::vector<int32_t> out(total, -1);
+        std::vector<uint32_t> hist(descs.size() * SWP_NFILTERS, 0);
+        ck(swp_schedule_groups(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_groups");
+        size_t off = 0;
+        for (size_t g = from; g < to; ++g) {
+            for (size_t i = 0; i < groups[g].size(); ++i) {
+                const int32_t n = out[off + i];
+                if (n >= 0) place(groups[g][i].first, groups[g][i].second, n, decisions);
+                else noSuitableNode(groups[g][i].first, groups[g][i].second, &hist[(g - from) * SWP_NFILTERS], decisions);
+            }
+            off += groups[g].size();
+        }
+    }
+    void runOneOffs(const std::vector<Item>& run, Value& decisions) {
+        if (run.empty()) return;
+        std::vector<swp_task_desc> descs;
+        for (const Item& it : run) descs.push_back(taskDesc(it.second));
+        std::vector<int32_t> out(run.size(), -1);
+        std::vector<uint32_t> hist(run.size() * SWP_NFILTERS, 0);
+        ck(swp_schedule_batch(e_, descs.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_batch");
+        for (size_t i = 0; i < run.size(); ++i) {
+            if (out[i] >= 0) place(run[i].first, run[i].second, out[i], decisions);
+            else noSuitableNode(run[i].first, run[i].second, &hist[i * SWP_NFILTERS], decisions);
+        }
+    }
+};
+
+}   // namespace swp
+
+// ===================================================================================================== C boundary
+struct swp_sched {
+    swp::Scheduler impl;
+    explicit swp_sched(swp_engine* e) : impl(e) {}
+};
+
+namespace {
+thread_local std::string g_create_error;
+thread_local std::string g_parse_buffer;
+
+template <class F>
+int guarded(swp_sched* s, F&& body) {
+    if (s == nullptr) return SWP_EINVAL;
+    try {
+        return body(s->impl);
+    } catch (const swp::Fail& f) {
+        s->impl.last_error = f.msg;
+        return f.code;
+    } catch (const swp::json::ParseError& e) {
+        s->impl.last_error = e.what();
+        return SWP_EINVAL;
+    } catch (const std::bad_alloc&) {
+        s->impl.last_error = "out of memory";
+        return SWP_ENOMEM;
+    } catch (const std::exception& e) {
+        s->impl.last_error = e.what();
+        return SWP_EINVAL;
+    }
+}
+int task_event(swp_sched* s, const char* doc, size_t len, int* flag, bool (swp::Scheduler::*handler)(const swp::json::Value&)) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (doc == nullptr) return (int)SWP_EINVAL;
+        const swp::json::Value t = swp::json::parse(doc, len);
+        const bool r = (impl.*handler)(t);
+        if (flag != nullptr) *flag = r ? 1 : 0;
+        return (int)SWP_OK;
+    });
+}
+}   // namespace
+
+extern "C" {
+
+int swp_sched_create(swp_engine* engine, swp_sched** out) {
+    if (engine == nullptr || out == nullptr) return SWP_EINVAL;
+    try {
+        *out = new swp_sched(engine);
+        return SWP_OK;
+    } catch (const swp::Fail& f) {
+        g_create_error = f.msg;
+        return f.code;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return SWP_ENOMEM;
+    }
+}
+void swp_sched_destroy(swp_sched* s) { delete s; }
+const char* swp_sched_last_error(swp_sched* s) { return s != nullptr ? s->impl.last_error.c_str() : g_create_error.c_str(); }
+
+int swp_sched_create_or_update_node(swp_sched* s, const char* node_json, size_t len) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (node_json == nullptr) return (int)SWP_EINVAL;
+        impl.createOrUpdateNode(swp::json::parse(node_json, len));
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_delete_node(swp_sched* s, const char* node_id, size_t len) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        impl.deleteNode(std::string(node_id != nullptr ? node_id : "", node_id != nullptr ? len : 0));
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_node_info(swp_sched* s, const char* node_id, size_t len, const char** json_out) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (node_id == nullptr || json_out == nullptr) return (int)SWP_EINVAL;
+        if (!impl.nodeInfo(std::string(node_id, len), impl.scratch)) return (int)SWP_ENOTFOUND;
+        *json_out = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_set_service(swp_sched* s, const char* service_id, size_t len, int has_version, uint64_t version) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (service_id == nullptr) return (int)SWP_EINVAL;
+        impl.setService(std::string(service_id, len), has_version != 0, version);
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_delete_service(swp_sched* s, const char* service_id, size_t len) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (service_id == nullptr) return (int)SWP_EINVAL;
+        impl.deleteService(std::string(service_id, len));
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_advance(swp_sched* s, int64_t ns) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        impl.advance(ns);
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_create_task(swp_sched* s, const char* j, size_t n, int* f) { return task_event(s, j, n, f, &swp::Scheduler::createTask); }
+int swp_sched_setup_task(swp_sched* s, const char* j, size_t n, int* f) { return task_event(s, j, n, f, &swp::Scheduler::setupTask); }
+int swp_sched_update_task(swp_sched* s, const char* j, size_t n, int* f) { return task_event(s, j, n, f, &swp::Scheduler::updateTask); }
+int swp_sched_delete_task(swp_sched* s, const char* j, size_t n, int* f) { return task_event(s, j, n, f, &swp::Scheduler::deleteTask); }
+
+int swp_sched_tick(swp_sched* s, const char** decisions_json) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (decisions_json == nullptr) return (int)SWP_EINVAL;
+        const swp::json::Value d = impl.tick();
+        impl.scratch = swp::json::dump(d);
+        *decisions_json = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_process_preassigned(swp_sched* s, const char** decisions_json) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (decisions_json == nullptr) return (int)SWP_EINVAL;
+        const swp::json::Value d = impl.processPreassignedTasks();
+        impl.scratch = swp::json::dump(d);
+        *decisions_json = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_task_desc(swp_sched* s, const char* task_json, size_t len, swp_task_desc* out) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (task_json == nullptr || out == nullptr) return (int)SWP_EINVAL;
+        *out = impl.taskDesc(swp::json::parse(task_json, len));
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_constraint_set(swp_sched* s, const char* exprs_json, size_t len, uint32_t* set_out) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (exprs_json == nullptr || set_out == nullptr) return (int)SWP_EINVAL;
+        const swp::json::Value v = swp::json::parse(exprs_json, len);
+        *set_out = impl.constraintSet(&v);
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_enforce(swp_sched* s, const char* request_json, size_t len, const char** rejected_json) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (request_json == nullptr || rejected_json == nullptr) return (int)SWP_EINVAL;
+        const swp::json::Value out = impl.enforce(swp::json::parse(request_json, len));
+        impl.scratch = swp::json::dump(out);
+        *rejected_json = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+
+int swp_constraint_parse(const char* exprs_json, size_t len, const char** parsed_json) {
+    if (exprs_json == nullptr || parsed_json == nullptr) return SWP_EINVAL;
+    try {
+        const swp::json::Value v = swp::json::parse(exprs_json, len);
+        if (!v.is_arr()) return SWP_EINVAL;
+        std::vector<std::string> exprs;
+        for (const swp::json::Value& e : *v.a) exprs.push_back(swp::json::as_str(&e));
+        std::vector<swp::Expr> parsed;
+        if (!swp::parse_constraints(exprs, parsed)) return SWP_EINVAL;
+        swp::json::Value out = swp::json::Value::array();
+        for (const swp::Expr& x : parsed) {
+            swp::json::Value triple = swp::json::Value::array();
+            triple.push(swp::json::Value::str(swp::encode(x.key)));
+            triple.push(swp::json::Value::integer(x.op));
+            triple.push(swp::json::Value::str(swp::encode(x.exp)));
+            out.push(triple);
+        }
+        g_parse_buffer = swp::json::dump(out);
+        *parsed_json = g_parse_buffer.c_str();
+        return SWP_OK;
+    } catch (const std::exception&) {
+        return SWP_EINVAL;
+    }
+}
+int swp_key_equal_fold(const char* a, size_t la, const char* b, size_t lb) {
+    if ((a == nullptr && la) || (b == nullptr && lb)) return 0;
+    return swp::equal_fold(swp::decode(std::string(a ? a : "", la)), swp::decode(std::string(b ? b : "", lb))) ? 1 : 0;
+}
+int swp_explain(const uint32_t* hist, char* out, size_t cap) {
+    if (hist == nullptr) return SWP_EINVAL;
+    const std::string s = swp::explain(hist);
+    if (out != nullptr && cap > 0) {
+        const size_t n = std::min(cap - 1, s.size());
+        std::memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return (int)s.size();
+}
+int swp_parse_ip(const char* s, size_t len, uint8_t out16[16], int* is_v4) {
+    if (s == nullptr || out16 == nullptr) return 0;
+    bool v4 = false;
+    if (!swp::parse_ip(std::string(s, len), out16, &v4)) return 0;
+    if (is_v4 != nullptr) *is_v4 = v4 ? 1 : 0;
+    return 1;
+}
+
+}   // extern "C"

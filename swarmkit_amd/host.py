@@ -15,11 +15,14 @@ Mirrors (paths under /root/reference/manager/scheduler/):
   nodeinfo.go:66-221    addTask / removeTask / taskFailed / countRecentFailures
 """
 import ipaddress
+import os
 import re
 
 import numpy as np
 
 from . import abi
+
+DEFAULT_HOST = "cxx"   # "cxx" = swp::Scheduler inside libswp.so; "py" = the Python twin below (SWP_HOST overrides)
 
 # api/types.proto:510-539
 NEW, PENDING, ASSIGNED, RUNNING, COMPLETE, SHUTDOWN, FAILED, REJECTED = 0, 64, 192, 512, 576, 640, 704, 768
@@ -34,8 +37,7 @@ _TASK_STATES = {"NEW": 0, "PENDING": 64, "ASSIGNED": 192, "ACCEPTED": 256, "PREP
                 "RUNNING": 512, "COMPLETE": 576, "SHUTDOWN": 640, "FAILED": 704, "REJECTED": 768, "REMOVE": 800, "ORPHANED": 832}
 
 
-class Unsupported(NotImplementedError):
-    """The task/feature stays on the reference's own Go path (SWP_EUNSUPPORTED)."""
+Unsupported = abi.Unsupported   # the task/feature stays on the reference's own Go path (SWP_EUNSUPPORTED)
 
 
 def _get(d, *path, default=None):
@@ -101,8 +103,10 @@ def _parse_ip(s):
     return ip.packed, ip.ipv4_mapped is not None
 
 
-class HostScheduler:
-    """Scheduler surface: create_node/update_node/delete_node/create_task/update_task/delete_task/tick."""
+class PyHostScheduler:
+    """The Python twin of swp::Scheduler (csrc/swp_sched.cpp): the same event handlers, kept as an independent second
+    implementation of the host layer — tests/test_sched_cpu.py runs both against the same scripted engine and compares
+    every ABI call. Surface: create_node/update_node/delete_node/create_task/update_task/delete_task/tick."""
 
     SECOND = 1_000_000_000
 
@@ -315,11 +319,22 @@ class HostScheduler:
     def advance(self, seconds):
         self.now += int(seconds * self.SECOND)
 
+    @staticmethod
+    def _require_supported(t):
+        """Tasks the engine cannot judge (generic resources, CSI cluster volumes) are refused at the event boundary —
+        the shim leaves them to the Go scheduler's own path — so that a tick never meets one half-way through a batch."""
+        if _get(t, "Spec", "Resources", "Reservations", "Generic"):
+            raise Unsupported("generic resources stay on the Go path")
+        for m in _get(t, "Spec", "Container", "Mounts") or []:
+            if m.get("Type") in (MOUNT_CLUSTER, "CLUSTER"):
+                raise Unsupported("CSI cluster volumes stay on the Go path")
+
     def create_task(self, t):
         """scheduler.go:254-283."""
         st = _state(_get(t, "Status", "State"))
         if st < PENDING or st > RUNNING:
             return False
+        self._require_supported(t)
         self.all_tasks[t["ID"]] = t
         if not t.get("NodeID"):
             self.unassigned[t["ID"]] = t
@@ -356,6 +371,7 @@ class HostScheduler:
                         self._task_failed(ent, t)
             self._delete_task(old)
             return True
+        self._require_supported(t)
         if not t.get("NodeID"):
             if old is not None:
                 self._delete_task(old)
@@ -389,6 +405,11 @@ class HostScheduler:
         return self._delete_task(t)
 
     # ------------------------------------------------------------------------------ Filter.SetTask → predicate sets
+    def constraint_set(self, exprs):
+        """ConstraintFilter.SetTask for a list of expressions: predicate-set id, 0 when empty / unparsable."""
+        parsed = parse_constraints(list(exprs)) if exprs else None
+        return self.e.constraint_set(self._constraint_structs(parsed)) if parsed else 0
+
     def _constraint_structs(self, parsed):
         out = []
         for key, op, exp in parsed:
@@ -521,8 +542,8 @@ class HostScheduler:
 
     # ------------------------------------------------------------------------------ tick
     def _push_failures(self, service_ids):
-        for ent in self.nodes.values():
-            for (sid, ver) in list(ent["failures"]):
+        for _nid, ent in sorted(self.nodes.items()):
+            for (sid, ver) in sorted(ent["failures"]):
                 if sid in service_ids:
                     self.e.node_set_failures(ent["idx"], self.e.intern(abi.SPACE_SERVICE, sid), ver, self._count_recent_failures(ent, (sid, ver)))
 
@@ -650,7 +671,22 @@ class HostScheduler:
         return decisions
 
 
+def HostScheduler(engine=None, **engine_kw):
+    """The host layer the tests and bench.py drive: the C++ one inside libswp.so (default), or its Python twin with
+    SWP_HOST=py."""
+    if os.environ.get("SWP_HOST", DEFAULT_HOST) == "py":
+        return PyHostScheduler(engine, **engine_kw)
+    from . import sched
+    return sched.Scheduler(engine, **engine_kw)
+
+
 def enforce(sched, node_docs, tasks_by_node, services=None):
+    if not isinstance(sched, PyHostScheduler):
+        return sched.enforce(node_docs, tasks_by_node, services)
+    return _py_enforce(sched, node_docs, tasks_by_node, services)
+
+
+def _py_enforce(sched, node_docs, tasks_by_node, services=None):
     """constraintenforcer.rejectNoncompliantTasks (constraint_enforcer.go:65-196) for many nodes through swp_enforce.
     node_docs: api.Node docs already known to `sched` (create_node); tasks_by_node: {node id: [api.Task docs]} (sorted here
     by task ID = the canonical store order); services: {ServiceID: api.Service doc} — the CURRENT specs.

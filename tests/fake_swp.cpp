@@ -1,0 +1,334 @@
+// fake_swp.cpp — TEST DOUBLE of the engine half of include/swp.h, for CPU-only tests of the host layer above the ABI
+// (swarmkit_amd/csrc/swp_sched.cpp and its Python twin swarmkit_amd/host.py).
+//
+// This is NOT a placement implementation and never ships: it lives under tests/, is linked only into
+// tests/_build/libswpfake.so, and its "placements" are a scripted pseudo-random function of a call counter — no
+// feasibility, no scoring. What it does do faithfully is the bookkeeping a host layer can observe (intern tables,
+// node rows, per-service counts, commit arithmetic) and a LOG of every call with ids resolved back to strings, so that
+// two host layers driven by the same event script can be compared call by call (tests/test_sched_cpu.py).
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../include/swp.h"
+
+struct FakeNode {
+    bool present = false;
+    swp_node_row row{};
+    std::map<uint32_t, uint32_t> svc;   // service id -> count
+};
+
+struct swp_engine {
+    std::vector<std::vector<std::string>> names = std::vector<std::vector<std::string>>(SWP_SPACE_COUNT);
+    std::vector<std::map<std::string, uint32_t>> ids = std::vector<std::map<std::string, uint32_t>>(SWP_SPACE_COUNT);
+    std::vector<FakeNode> nodes;
+    std::vector<std::string> sets[5];   // textual form of every registered predicate set: constraint, platform, plugin, port, spread
+    std::vector<std::vector<swp_port>> port_sets;
+    std::string log;
+    std::string err;
+    uint64_t counter = 0;
+
+    swp_engine() {
+        for (int sp = 0; sp < SWP_SPACE_COUNT; ++sp)
+            if (sp != SWP_SPACE_NODE_ID) {   // id 0 = "" everywhere but in the node space
+                names[sp].push_back("");
+                ids[sp][""] = 0;
+            }
+        for (auto& s : sets) s.push_back("-");
+        port_sets.emplace_back();
+    }
+    const std::string& name(int space, uint32_t id) const {
+        static const std::string unknown = "?";
+        return id < names[space].size() ? names[space][id] : unknown;
+    }
+    std::string printable(const std::string& s) const {
+        std::string out;
+        for (unsigned char c : s) out.push_back(c == 0 ? '|' : (char)c);
+        return out;
+    }
+    void say(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        std::vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        log += buf;
+        log.push_back('\n');
+    }
+    uint32_t next() {   // the scripted "decision": a hash of the call counter
+        uint64_t z = (counter++ + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 29;
+        return (uint32_t)(z >> 16);
+    }
+    std::vector<uint32_t> present() const {
+        std::vector<uint32_t> p;
+        for (uint32_t i = 0; i < nodes.size(); ++i)
+            if (nodes[i].present) p.push_back(i);
+        return p;
+    }
+    std::string desc(const swp_task_desc& d) const {
+        char buf[512];
+        std::snprintf(buf, sizeof buf, "svc=%s flags=%u cpu=%lld mem=%lld con=%s plat=%s plug=%s port=%s maxrep=%llu ver=%llu spread=%s",
+                      printable(name(SWP_SPACE_SERVICE, d.service)).c_str(), d.flags, (long long)d.cpu, (long long)d.mem,
+                      d.constraint_set < sets[0].size() ? sets[0][d.constraint_set].c_str() : "?", d.platform_set < sets[1].size() ? sets[1][d.platform_set].c_str() : "?",
+                      d.plugin_set < sets[2].size() ? sets[2][d.plugin_set].c_str() : "?", d.port_set < sets[3].size() ? sets[3][d.port_set].c_str() : "?",
+                      (unsigned long long)d.max_replicas, (unsigned long long)d.spec_version, d.spread_set < sets[4].size() ? sets[4][d.spread_set].c_str() : "?");
+        return buf;
+    }
+    void apply(uint32_t n, uint32_t service, int64_t cpu, int64_t mem, bool counted, bool add) {
+        FakeNode& nd = nodes[n];
+        nd.row.cpu += add ? -cpu : cpu;
+        nd.row.mem += add ? -mem : mem;
+        if (counted) {
+            nd.row.total += add ? 1u : (uint32_t)-1;
+            nd.svc[service] += add ? 1u : (uint32_t)-1;
+        }
+    }
+    // one scripted answer for one task: a present node, or -1 with a scripted histogram
+    int32_t answer(const swp_task_desc& d, uint32_t* hist) {
+        const std::vector<uint32_t> p = present();
+        const uint32_t r = next();
+        if (p.empty() || r % 5u == 0u) {
+            if (hist != nullptr) {
+                for (int k = 0; k < SWP_NFILTERS; ++k) hist[k] = 0;
+                if (!p.empty()) {
+                    hist[(r >> 4) % SWP_NFILTERS] = 1 + (r >> 8) % 3;
+                    hist[(r >> 12) % SWP_NFILTERS] += (r >> 16) % 2;
+                }
+            }
+            return -1;
+        }
+        const uint32_t n = p[(r >> 3) % p.size()];
+        apply(n, d.service, d.cpu, d.mem, !(d.flags & 0x2u), true);
+        return (int32_t)n;
+    }
+    uint32_t add_set(int which, const std::string& text) {
+        for (uint32_t i = 1; i < sets[which].size(); ++i)
+            if (sets[which][i] == text) return i;
+        sets[which].push_back(text);
+        return (uint32_t)sets[which].size() - 1;
+    }
+};
+
+static std::string g_create_err;
+
+extern "C" {
+
+int swp_create(const swp_config*, swp_engine** out) {
+    *out = new swp_engine();
+    return SWP_OK;
+}
+void swp_destroy(swp_engine* e) { delete e; }
+int swp_reset(swp_engine* e, uint32_t) {
+    e->nodes.clear();
+    e->say("reset");
+    return SWP_OK;
+}
+int swp_intern(swp_engine* e, int space, const char* s, size_t len, uint32_t* id_out) {
+    if (space < 0 || space >= SWP_SPACE_COUNT) return SWP_EINVAL;
+    std::string k(s ? s : "", s ? len : 0);
+    auto it = e->ids[space].find(k);
+    if (it == e->ids[space].end()) {
+        it = e->ids[space].emplace(k, (uint32_t)e->names[space].size()).first;
+        e->names[space].push_back(k);
+    }
+    *id_out = it->second;
+    return SWP_OK;
+}
+int swp_intern_lookup(swp_engine* e, int space, uint32_t id, char* out, size_t cap) {
+    if (space < 0 || space >= SWP_SPACE_COUNT || id >= e->names[space].size()) return SWP_EINVAL;
+    const std::string& s = e->names[space][id];
+    if (cap) {
+        size_t n = std::min(cap - 1, s.size());
+        std::memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return (int)s.size();
+}
+int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* nl, uint32_t n_nl, const swp_kv* el, uint32_t n_el, const uint32_t* pl, uint32_t n_pl) {
+    if (row->node >= e->nodes.size()) e->nodes.resize(row->node + 1);
+    FakeNode& nd = e->nodes[row->node];
+    nd.present = true;
+    nd.row = *row;
+    std::string t;
+    char ip[40] = "";
+    for (int i = 0; i < 16; ++i) std::snprintf(ip + 2 * i, 3, "%02x", row->ip[i]);
+    for (uint32_t i = 0; i < n_nl; ++i) t += " L:" + e->name(SWP_SPACE_LABEL_KEY, nl[i].key) + "=" + e->name(SWP_SPACE_FOLDED, nl[i].value) + "/" + e->name(SWP_SPACE_RAW, nl[i].raw);
+    for (uint32_t i = 0; i < n_el; ++i) t += " E:" + e->name(SWP_SPACE_LABEL_KEY, el[i].key) + "=" + e->name(SWP_SPACE_FOLDED, el[i].value) + "/" + e->name(SWP_SPACE_RAW, el[i].raw);
+    for (uint32_t i = 0; i < n_pl; ++i) t += " P:" + e->printable(e->name(SWP_SPACE_PLUGIN, pl[i]));
+    e->say("upsert %s flags=%#x cpu=%lld mem=%lld total=%u os=%s arch=%s osf=%s archf=%s host=%s idf=%s ip=%s ver=%llu%s", e->name(SWP_SPACE_NODE_ID, row->node).c_str(), row->flags,
+           (long long)row->cpu, (long long)row->mem, row->total, e->name(SWP_SPACE_OS, row->os).c_str(), e->name(SWP_SPACE_ARCH, row->arch).c_str(),
+           e->name(SWP_SPACE_FOLDED, row->os_fold).c_str(), e->name(SWP_SPACE_FOLDED, row->arch_fold).c_str(), e->name(SWP_SPACE_FOLDED, row->hostname_fold).c_str(),
+           e->name(SWP_SPACE_FOLDED, row->id_fold).c_str(), ip, (unsigned long long)row->version, t.c_str());
+    return SWP_OK;
+}
+int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_t cpu, int64_t mem, uint32_t total) {
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    swp_node_row& r = e->nodes[node].row;
+    r.flags = flags; r.cpu = cpu; r.mem = mem; r.total = total;
+    e->say("update_dynamic %s", e->name(SWP_SPACE_NODE_ID, node).c_str());
+    return SWP_OK;
+}
+int swp_node_remove(swp_engine* e, uint32_t node) {
+    if (node < e->nodes.size()) e->nodes[node] = FakeNode();
+    e->say("remove %s", e->name(SWP_SPACE_NODE_ID, node).c_str());
+    return SWP_OK;
+}
+int swp_node_get(swp_engine* e, uint32_t node, swp_node_row* out) {
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    *out = e->nodes[node].row;
+    return SWP_OK;
+}
+int swp_node_set_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint32_t count) {
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    e->nodes[node].svc[service] = count;
+    return SWP_OK;
+}
+int swp_node_get_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint32_t* out) {
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    auto it = e->nodes[node].svc.find(service);
+    *out = it == e->nodes[node].svc.end() ? 0 : it->second;
+    return SWP_OK;
+}
+int swp_node_set_failures(swp_engine* e, uint32_t node, uint32_t service, uint64_t ver, uint32_t count) {
+    e->say("failures %s %s@%llu = %u", e->name(SWP_SPACE_NODE_ID, node).c_str(), e->name(SWP_SPACE_SERVICE, service).c_str(), (unsigned long long)ver, count);
+    return SWP_OK;
+}
+int swp_node_port(swp_engine* e, uint32_t node, uint32_t proto, uint32_t port, int set) {
+    e->say("node_port %s %u/%u %d", e->name(SWP_SPACE_NODE_ID, node).c_str(), proto, port, set);
+    return SWP_OK;
+}
+int swp_constraint_set(swp_engine* e, const swp_constraint* cs, uint32_t n, uint32_t* id_out) {
+    std::string t;
+    for (uint32_t i = 0; i < n; ++i) {
+        char buf[160], ip[40] = "";
+        for (int k = 0; k < 16; ++k) std::snprintf(ip + 2 * k, 3, "%02x", cs[i].ip[k]);
+        std::snprintf(buf, sizeof buf, "[k%u o%u key=%s val=%s ip=%s/%u kind%u v4=%u]", cs[i].kind, cs[i].op, e->name(SWP_SPACE_LABEL_KEY, cs[i].key).c_str(),
+                      e->name(SWP_SPACE_FOLDED, cs[i].value).c_str(), ip, cs[i].prefix_len, cs[i].ip_kind, cs[i].ip_is_v4);
+        t += buf;
+    }
+    *id_out = n ? e->add_set(0, t) : 0;
+    return SWP_OK;
+}
+int swp_platform_set(swp_engine* e, const swp_platform* ps, uint32_t n, uint32_t* id_out) {
+    std::string t;
+    for (uint32_t i = 0; i < n; ++i) t += "[" + e->name(SWP_SPACE_OS, ps[i].os) + "/" + e->name(SWP_SPACE_ARCH, ps[i].arch) + "]";
+    *id_out = n ? e->add_set(1, t) : 0;
+    return SWP_OK;
+}
+int swp_plugin_set(swp_engine* e, const uint32_t* req, uint32_t n, uint32_t log_plugin, uint32_t* id_out) {
+    std::string t;
+    for (uint32_t i = 0; i < n; ++i) t += "[" + e->printable(e->name(SWP_SPACE_PLUGIN, req[i])) + "]";
+    t += "log=" + e->printable(e->name(SWP_SPACE_PLUGIN, log_plugin));
+    *id_out = (n || log_plugin) ? e->add_set(2, t) : 0;
+    return SWP_OK;
+}
+int swp_port_set(swp_engine* e, const swp_port* ports, uint32_t n, uint32_t* id_out) {
+    if (n > 32) return SWP_ERANGE;
+    std::string t;
+    for (uint32_t i = 0; i < n; ++i) t += "[" + std::to_string(ports[i].protocol) + "/" + std::to_string(ports[i].port) + "]";
+    *id_out = n ? e->add_set(3, t) : 0;
+    return SWP_OK;
+}
+int swp_spread_set(swp_engine* e, const swp_spread* lv, uint32_t n, uint32_t* id_out) {
+    std::string t;
+    for (uint32_t i = 0; i < n; ++i) t += "[" + std::to_string(lv[i].kind) + ":" + e->name(SWP_SPACE_LABEL_KEY, lv[i].key) + "]";
+    *id_out = n ? e->add_set(4, t) : 0;
+    return SWP_OK;
+}
+int swp_schedule_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t n, int32_t* out_node, uint32_t* hist) {
+    e->say("schedule_batch n=%u", n);
+    for (uint32_t i = 0; i < n; ++i) {
+        out_node[i] = e->answer(tasks[i], hist ? hist + (size_t)i * SWP_NFILTERS : nullptr);
+        e->say("  task %s -> %d", e->desc(tasks[i]).c_str(), out_node[i]);
+    }
+    return SWP_OK;
+}
+int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node, uint32_t* hist) {
+    e->say("schedule_groups n=%u", n_groups);
+    size_t off = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        e->say("  group k=%u %s", sizes[g], e->desc(groups[g]).c_str());
+        uint32_t scratch[SWP_NFILTERS];
+        for (uint32_t i = 0; i < sizes[g]; ++i) {
+            out_node[off + i] = e->answer(groups[g], scratch);
+            if (out_node[off + i] < 0 && hist) std::memcpy(hist + (size_t)g * SWP_NFILTERS, scratch, sizeof scratch);
+        }
+        off += sizes[g];
+    }
+    return SWP_OK;
+}
+int swp_batch_prepare(swp_engine*, const swp_task_desc*, uint32_t, swp_batch**) { return SWP_EUNSUPPORTED; }
+int swp_batch_run(swp_engine*, swp_batch*) { return SWP_EUNSUPPORTED; }
+int swp_batch_fetch(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
+int swp_batch_results(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
+void swp_batch_free(swp_engine*, swp_batch*) {}
+int swp_state_save(swp_engine*) { return SWP_EUNSUPPORTED; }
+int swp_state_restore(swp_engine*) { return SWP_EUNSUPPORTED; }
+int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (p[i].node >= e->nodes.size() || !e->nodes[p[i].node].present) return SWP_ENOTFOUND;
+        e->apply(p[i].node, p[i].service, p[i].cpu, p[i].mem, p[i].counted != 0, add != 0);
+        e->say("commit %s %s svc=%s cpu=%lld mem=%lld port=%s counted=%u", add ? "add" : "remove", e->name(SWP_SPACE_NODE_ID, p[i].node).c_str(),
+               e->name(SWP_SPACE_SERVICE, p[i].service).c_str(), (long long)p[i].cpu, (long long)p[i].mem,
+               p[i].port_set < e->sets[3].size() ? e->sets[3][p[i].port_set].c_str() : "?", p[i].counted);
+    }
+    return SWP_OK;
+}
+int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int32_t* first_fail) {
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    const uint32_t r = e->next();
+    *first_fail = (r % 3u == 0u) ? (int32_t)((r >> 4) % SWP_NFILTERS) : -1;
+    e->say("check_node %s %s -> %d", e->name(SWP_SPACE_NODE_ID, node).c_str(), e->desc(*task).c_str(), *first_fail);
+    return SWP_OK;
+}
+int swp_enforce(swp_engine* e, const swp_enforce_node* nodes, uint32_t n_nodes, const swp_enforce_task* tasks, uint32_t n_tasks, uint8_t* out) {
+    e->say("enforce nodes=%u tasks=%u", n_nodes, n_tasks);
+    for (uint32_t i = 0; i < n_nodes; ++i)
+        e->say("  node %s first=%u n=%u cpu=%lld mem=%lld", e->name(SWP_SPACE_NODE_ID, nodes[i].node).c_str(), nodes[i].first_task, nodes[i].n_tasks, (long long)nodes[i].cpu, (long long)nodes[i].mem);
+    for (uint32_t i = 0; i < n_tasks; ++i) {
+        out[i] = (uint8_t)(e->next() % 3u == 0u);
+        e->say("  task cpu=%lld mem=%lld con=%s flags=%u ds=%u st=%u -> %u", (long long)tasks[i].cpu, (long long)tasks[i].mem,
+               tasks[i].constraint_set < e->sets[0].size() ? e->sets[0][tasks[i].constraint_set].c_str() : "?", tasks[i].flags, tasks[i].desired_state, tasks[i].state, out[i]);
+    }
+    return SWP_OK;
+}
+int swp_node_matches(swp_engine*, const uint32_t*, uint32_t, uint64_t*, uint32_t) { return SWP_EUNSUPPORTED; }
+int swp_stats(swp_engine* e, swp_stats_t* out) {
+    std::memset(out, 0, sizeof *out);
+    out->n_nodes = (uint32_t)e->present().size();
+    out->n_words = (uint32_t)((e->nodes.size() + 63) / 64);
+    return SWP_OK;
+}
+const char* swp_strerror(int code) {
+    switch (code) {
+        case SWP_OK: return "ok";
+        case SWP_EINVAL: return "invalid argument";
+        case SWP_ENOTFOUND: return "node not found";
+        case SWP_EUNSUPPORTED: return "unsupported";
+        case SWP_ERANGE: return "out of range";
+        default: return "error";
+    }
+}
+const char* swp_last_error(swp_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+int swp_abi_check(uint32_t* sizes, uint32_t n) {
+    const uint32_t s[] = {sizeof(swp_config), sizeof(swp_node_row), sizeof(swp_kv), sizeof(swp_constraint), sizeof(swp_platform), sizeof(swp_port),
+                          sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t), sizeof(swp_spread)};
+    uint32_t k = 0;
+    for (; k < n && k < 10; ++k) sizes[k] = s[k];
+    return (int)k;
+}
+// test-only: the call log so far (and clear it)
+const char* swp_fake_take_log(swp_engine* e) {
+    static thread_local std::string out;
+    out.swap(e->log);
+    e->log.clear();
+    return out.c_str();
+}
+
+}   // extern "C"

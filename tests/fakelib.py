@@ -1,0 +1,29 @@
+"""Builds tests/_build/libswpfake.so: the C++ host layer (swarmkit_amd/csrc/swp_sched.cpp, the product source) linked
+against tests/fake_swp.cpp, a scripted TEST DOUBLE of the engine ABI. CPU-only tests of the host layer use it; it is
+never loaded by the product (swarmkit_amd/ does not know it exists)."""
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "_build", "libswpfake.so")
+SRCS = [os.path.join(ROOT, "tests", "fake_swp.cpp"), os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_sched.cpp")]
+DEPS = SRCS + [os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_json.hpp"), os.path.join(ROOT, "include", "swp.h"), os.path.join(ROOT, "include", "swp_sched.h")]
+
+
+def build():
+    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-fPIC", "-shared", "-o", OUT] + SRCS, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("libswpfake.so build failed:\n" + r.stdout + r.stderr)
+    return OUT
+
+
+def take_log(engine):
+    """The fake engine's call log since the last take (ids resolved to strings)."""
+    fn = engine.L.swp_fake_take_log
+    fn.argtypes = [ctypes.c_void_p]
+    fn.restype = ctypes.c_char_p
+    return fn(engine.h).decode().splitlines()

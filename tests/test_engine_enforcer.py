@@ -120,11 +120,11 @@ def test_node_matches_matrix_equals_per_pair_oracle():
         nodes.append(d)
         s.create_node(d)
     lists = [[c] for c in CONS if c != "bogus expr"] + [["node.labels.zone==a", "node.role==manager"], ["node.labels.zone != a", "engine.labels.tier == GOLD"]]
-    sets = [s.e.constraint_set(s._constraint_structs(swhost.parse_constraints(l))) for l in lists] + [0]
+    sets = [s.constraint_set(l) for l in lists] + [0]
     bm = s.e.node_matches(sets)
     for r, l in enumerate(lists + [[]]):
         for i, nd in enumerate(nodes):
-            idx = s.nodes[nd["ID"]]["idx"]
+            idx = s.e.intern(0, nd["ID"])   # SWP_SPACE_NODE_ID
             got = bool((int(bm[r, idx >> 6]) >> (idx & 63)) & 1)
             want = True if not l else orc.constraint_filter(l, nd)
             assert got == want, (l, nd["ID"])
@@ -136,5 +136,5 @@ def test_node_matches_matrix_equals_per_pair_oracle():
         s2.create_node(node)
         parsed = swhost.parse_constraints(cons)
         assert parsed is not None
-        row = s2.e.node_matches([s2.e.constraint_set(s2._constraint_structs(parsed))])
+        row = s2.e.node_matches([s2.constraint_set(cons)])
         assert bool(int(row[0, 0]) & 1) == want, (cons, node)

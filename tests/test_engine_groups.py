@@ -89,9 +89,11 @@ def test_spread_with_constraints_and_leftovers():
 def test_generic_resources_are_refused_not_faked():
     s = factory()
     s.create_node(sc.node("n1"))
-    s.create_task(sc.pending("t1", "svc", Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))
+    with pytest.raises(swhost.Unsupported):   # refused at the event boundary: the task never enters a batch
+        s.create_task(sc.pending("t1", "svc", Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))
+    assert s.tick() == []
     with pytest.raises(swhost.Unsupported):
-        s.tick()
+        s.task_desc(sc.pending("t2", "svc", Spec={"Container": {"Mounts": [{"Type": 4, "Source": "vol"}]}}))
 
 
 def test_churn_rounds():

@@ -9,6 +9,12 @@ from swarmkit_amd import host as swhost
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["cxx", "py"])
+def host_kind(request, monkeypatch):
+    """Every scenario runs through both host layers: swp::Scheduler inside libswp.so and its Python twin."""
+    monkeypatch.setenv("SWP_HOST", request.param)
+
+
 def factory():
     return swhost.HostScheduler()
 
@@ -56,7 +62,7 @@ def test_constraint_truth_tables_on_device():
             assert int(d["constraint_set"][0]) == 0, cons
             continue
         assert int(d["constraint_set"][0]) != 0, cons
-        ff = s.e.check_node(d, s.nodes[node["ID"]]["idx"])
+        ff = s.e.check_node(d, s.e.intern(0, node["ID"]))   # SWP_SPACE_NODE_ID
         assert (ff == -1) == want, (cons, node, ff)
         assert ff in (-1, 3), (cons, ff)
 

@@ -18,7 +18,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def test_library_exports_every_declared_symbol():
     L = abi.load_library()
-    header = open(os.path.join(ROOT, "include", "swp.h")).read()
+    header = open(os.path.join(ROOT, "include", "swp.h")).read() + open(os.path.join(ROOT, "include", "swp_sched.h")).read()
     declared = set(re.findall(r"\b(swp_[a-z_]+)\s*\(", header))
     assert declared, "no declarations found"
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
@@ -58,8 +58,9 @@ def test_host_constraint_parse(expr, ok, key, exp):
         assert p[0][0] == key and p[0][2] == exp
 
 
-def test_host_explain_strings():
-    e = host.HostScheduler.explain
+@pytest.mark.parametrize("explain_fn", [host.PyHostScheduler.explain, __import__("swarmkit_amd.sched", fromlist=["explain"]).explain], ids=["py", "cxx"])
+def test_host_explain_strings(explain_fn):
+    e = explain_fn
     assert e([2, 1, 0, 0, 0, 0, 0, 0]) == "2 nodes not available for new tasks; insufficient resources on 1 node"
     assert e([0, 0, 0, 0, 3, 0, 0, 0]) == "unsupported platform on 3 nodes"
     assert e([0, 0, 0, 0, 0, 0, 2, 0]) == "max replicas per node limit exceed"

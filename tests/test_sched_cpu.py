@@ -1,0 +1,268 @@
+"""CPU: the C++ host layer (csrc/swp_sched.cpp, include/swp_sched.h).
+
+1. Its pure string helpers (constraint.Parse, key folding, net.ParseIP, Pipeline.Explain) against the oracle's
+   restatement of the Go behaviour — called in the PRODUCT library (libswp.so loads without a GPU; only swp_create needs one).
+2. The scheduler logic itself, event by event, against its independent Python twin (swarmkit_amd/host.py, the
+   implementation the GPU parity suite has validated against the oracle): both drive the same scripted test double of
+   the engine (tests/fake_swp.cpp — no placement logic, pseudo-random answers) and must issue the same ABI calls with
+   the same arguments and report the same decisions."""
+import random
+
+import pytest
+
+import fakelib
+import orc
+import test_engine_fuzz as fz
+from swarmkit_amd import abi, host as swhost, sched as swsched
+
+
+# ------------------------------------------------------------------------------------------------ helpers vs the oracle
+@pytest.mark.parametrize("seed", range(8))
+def test_cxx_parse_constraints_matches_the_oracle(seed):
+    import test_host_fuzz_cpu as hf
+    rng = random.Random(0xFADE + seed)
+    for _ in range(400):
+        exprs = [hf.rand_expr(rng) for _ in range(rng.randrange(1, 4))]
+        want, err = orc.constraint_parse(exprs)
+        got = swsched.parse_constraints(exprs)
+        if want is None:
+            assert got is None, (exprs, err, got)
+        else:
+            assert got is not None, (exprs, want)
+            assert [(k, o, v) for k, o, v in got] == [(k, o, v) for k, o, v in want], exprs
+
+
+@pytest.mark.parametrize("expr,ok,key,exp", __import__("kat_tables").PARSE_CASES)
+def test_cxx_constraint_parse_kat(expr, ok, key, exp):
+    p = swsched.parse_constraints([expr])
+    assert (p is not None) == ok
+    if ok:
+        assert p[0][0] == key and p[0][2] == exp
+
+
+def test_cxx_key_fold_matches_equal_fold():
+    rng = random.Random(5)
+    chars = list("abkKsS.-_09") + ["K", "ſ"]
+    for _ in range(3000):
+        a = "".join(rng.choice(chars) for _ in range(rng.randrange(0, 6)))
+        b = "".join(rng.choice(chars) for _ in range(rng.randrange(0, 6)))
+        if rng.random() < 0.5:
+            b = "".join(rng.choice([c, c.upper(), c.lower()]) for c in a)
+        assert swsched.key_equal_fold(a, b) == orc.equal_fold(a, b), (a, b)
+
+
+def test_cxx_parse_ip_matches_the_python_twin():
+    rng = random.Random(11)
+    fixed = ["10.0.0.1", "255.255.255.255", "256.1.1.1", "1.2.3", "1.2.3.4.5", "01.2.3.4", "1.2.3.04", " 1.2.3.4", "1.2.3.4 ", "", "::", "::1", "fe80::1%eth0",
+             "::ffff:1.2.3.4", "::1.2.3.4", "2001:db8::8a2e:370:7334", "2001:db8:0:0:0:0:2:1", "1:2:3:4:5:6:7:8", "1:2:3:4:5:6:7", "1::2::3", "12345::1", "g::1",
+             "1:2:3:4:5:6:1.2.3.4", "::ffff:01.2.3.4", "1.2.3.4/24", "a.b.c.d", "0.0.0.0", "::ffff:0:0", "FE80::ABCD"]
+    corpus = list(fixed)
+    for _ in range(2000):
+        if rng.random() < 0.5:
+            corpus.append(".".join(str(rng.choice([0, 1, 9, 10, 99, 100, 255, 256, 300])) for _ in range(rng.choice([3, 4, 4, 4, 5]))))
+        else:
+            groups = ["%x" % rng.randrange(0, 1 << rng.choice([4, 8, 16])) for _ in range(rng.choice([2, 4, 7, 8, 8, 9]))]
+            s = ":".join(groups)
+            if rng.random() < 0.4:
+                cut = rng.randrange(0, len(groups))
+                s = ":".join(groups[:cut]) + "::" + ":".join(groups[cut + 1:])
+            corpus.append(s)
+    for s in corpus:
+        assert swsched.parse_ip(s) == swhost._parse_ip(s), s
+
+
+# ------------------------------------------------------------------------------------------------ twin test
+class Pair:
+    """The two host layers over two instances of the scripted engine."""
+
+    def __init__(self):
+        lib = fakelib.build()
+        self.py = swhost.PyHostScheduler(engine=abi.Engine(lib_path=lib))
+        self.cx = swsched.Scheduler(engine=abi.Engine(lib_path=lib))
+        self.steps = 0
+
+    def both(self, name, *args):
+        self.steps += 1
+        res = []
+        for s in (self.py, self.cx):
+            try:
+                res.append(("ok", getattr(s, name)(*args)))
+            except abi.Unsupported:
+                res.append(("unsupported", None))
+        assert res[0] == res[1], (self.steps, name, args[:1], res)
+        lp, lc = fakelib.take_log(self.py.e), fakelib.take_log(self.cx.e)
+        assert lp == lc, (self.steps, name, [(a, b) for a, b in zip(lp, lc) if a != b][:3], len(lp), len(lc))
+        return res[0][1]
+
+    def enforce(self, node_docs, tbn, services):
+        self.steps += 1
+        res = []
+        for s in (self.py, self.cx):
+            try:
+                res.append(swhost.enforce(s, node_docs, tbn, services))
+            except abi.Unsupported:
+                res.append("unsupported")
+        a, b = res
+        assert a == b, (self.steps, a, b)
+        lp, lc = fakelib.take_log(self.py.e), fakelib.take_log(self.cx.e)
+        assert lp == lc, (self.steps, [(x, y) for x, y in zip(lp, lc) if x != y][:3])
+        return a
+
+
+def odd_task_bits(rng, t):
+    """Fields the GPU fuzz does not draw: string enums, mounts, log drivers, IP constraints, odd preferences."""
+    r = rng.random()
+    spec = dict(t.get("Spec") or {})
+    if r < 0.10:
+        spec["LogDriver"] = {"Name": rng.choice(["syslog", "none", "", "json-file"])}
+    elif r < 0.18:
+        spec["Container"] = {"Mounts": [{"Type": rng.choice([1, "VOLUME", 0, "BIND"]), "VolumeOptions": {"DriverConfig": {"Name": rng.choice(["nfs", "local", "", "ceph"])}}},
+                                        {"Type": 1, "VolumeOptions": {}}]}
+    elif r < 0.22:
+        spec["Container"] = {"Mounts": [{"Type": rng.choice([4, "CLUSTER"])}]}          # CSI: unsupported
+    elif r < 0.25:
+        spec["Resources"] = {"Reservations": {"NanoCPUs": 10**9, "Generic": [{"DiscreteResourceSpec": {"Kind": "gpu", "Value": 1}}]}}   # unsupported
+    pl = dict(spec.get("Placement") or {})
+    r = rng.random()
+    if r < 0.12:
+        pl["Constraints"] = [rng.choice(["node.ip==10.0.0.0/24", "node.ip!=10.0.0.7", "node.ip==fe80::/10", "node.ip==10.0.0.0/33", "NODE.ID==n00001", "node.hostname!=H3",
+                                         "node.role==manager", "node.platform.arch==AMD64", "Node.Labels.Zone == a", "bogus", "node.labels.zone=a", "engine.labels.tier!=gold ",
+                                         "node.labelsſ==x", "node.ip==::ffff:10.0.0.1", "node.labels.==x"])]
+        if rng.random() < 0.3:
+            pl["Constraints"].append("node.labels.disk != hdd")
+    if r > 0.9:
+        pl["Preferences"] = [{"Spread": {"SpreadDescriptor": rng.choice(["NODE.LABELS.zone", "engine.labels.tier", "node.labels.", "node.id", "", "Node.Labelſ.rack"])}}, {"Other": 1}]
+    if rng.random() < 0.05:
+        pl["MaxReplicas"] = rng.choice([0, 1, 2**63, 2**64 - 1])
+    if pl:
+        spec["Placement"] = pl
+    if spec:
+        t["Spec"] = spec
+    if rng.random() < 0.08:
+        t["Endpoint"] = {"Ports": [{"Protocol": rng.choice([0, 1, "TCP", "UDP", "SCTP"]), "PublishedPort": rng.choice([0, 80, 8080]), "PublishMode": rng.choice([0, 1, "HOST", "INGRESS"])}
+                                   for _ in range(rng.randrange(1, 4))]}
+    if rng.random() < 0.08:
+        t["Networks"] = [{"Network": {"DriverState": {"Name": rng.choice(["overlay", "", "weave"])}}}, {"Network": {}}]
+    return t
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SWP_TWIN_SEEDS", "24"))))
+def test_cxx_host_is_the_twin_of_the_python_host(seed):
+    rng = random.Random(0xBEE5 + seed)
+    p = Pair()
+    n_nodes = rng.choice([1, 3, 17, 40])
+    nodes = {}
+    for i in range(n_nodes):
+        d = fz.node_doc(rng, i)
+        if rng.random() < 0.3:   # string enums, roles, versions, IPv6 / broken addresses
+            d["Status"] = {"State": rng.choice(["READY", "DOWN", "UNKNOWN", 2]), "Addr": rng.choice(["fe80::%d" % i, "10.1.2.%d" % i, "not-an-ip", "::ffff:10.0.0.%d" % i, ""])}
+            d["Spec"] = dict(d["Spec"], Availability=rng.choice(["ACTIVE", "DRAIN", "PAUSE", 0]))
+            d["Role"] = rng.choice(["MANAGER", "WORKER", 1, 0])
+            d["Meta"] = {"Version": {"Index": rng.randrange(1, 1000)}}
+        if rng.random() < 0.1:
+            d["Description"]["Engine"]["Plugins"] = [{"Type": "Log", "Name": "syslog"}, {"Type": "Volume", "Name": "ceph:latest"}]
+        if rng.random() < 0.05:
+            del d["Description"]
+        if rng.random() < 0.05:
+            d["Description"] = dict(d.get("Description") or {}, Resources={"NanoCPUs": 4 * 10**9, "Generic": [{"DiscreteResourceSpec": {"Kind": "gpu", "Value": 2}}]})   # unsupported
+        nodes[i] = d
+        p.both("create_node", d)
+    n_svc = rng.randrange(1, 8)
+    specs = [fz.service_spec(rng) for _ in range(n_svc)]
+    grouped = [rng.random() < 0.5 for _ in range(n_svc)]
+    version = [1] * n_svc
+    for k in range(n_svc):
+        p.both("set_service", "svc%02d" % k, version[k] if grouped[k] and rng.random() < 0.7 else None)
+    docs, placed, tid = {}, {}, 0
+
+    def note(decisions):
+        for d in decisions:
+            if d["NodeID"] and d["State"] >= orc.ASSIGNED:
+                placed[d["ID"]] = d["NodeID"]
+
+    for rnd in range(rng.randrange(2, 6)):
+        for _ in range(rng.randrange(1, 5)):
+            k = rng.randrange(n_svc)
+            if grouped[k] and rng.random() < 0.2:   # service update: a newer spec version (old tasks of the service may still be queued)
+                version[k] += 1
+                p.both("set_service", "svc%02d" % k, version[k])
+            for _ in range(rng.choice([1, 2, 5, 20])):
+                t = {"ID": "t%06d" % tid, "ServiceID": "svc%02d" % k, "DesiredState": rng.choice([orc.RUNNING, orc.RUNNING, "RUNNING", orc.SHUTDOWN]),
+                     "Status": {"State": rng.choice([orc.PENDING, orc.PENDING, "PENDING", orc.NEW, orc.RUNNING])}}
+                if grouped[k]:
+                    t["SpecVersion"] = {"Index": rng.choice([version[k], version[k], max(1, version[k] - 1)])}
+                t.update(specs[k])
+                t = odd_task_bits(rng, t)
+                r = rng.random()
+                if r < 0.15 and nodes:   # preassigned (global-service style) task
+                    t["NodeID"] = rng.choice(sorted(d["ID"] for d in nodes.values()))
+                elif r < 0.18:
+                    t["NodeID"] = "n-unknown"
+                docs[t["ID"]] = t
+                p.both(rng.choice(["create_task", "create_task", "create_task", "setup_task", "update_task"]), t)
+                tid += 1
+        if rng.random() < 0.6:
+            note(p.both("process_preassigned"))
+        note(p.both("tick"))
+        for _ in range(rng.randrange(0, 5)):   # churn between ticks
+            act = rng.random()
+            i = rng.randrange(n_nodes)
+            if act < 0.25 and i in nodes:
+                d = dict(nodes[i], Spec=dict(nodes[i]["Spec"], Availability=rng.choice([0, 1, 2])))
+                nodes[i] = d
+                p.both("update_node", d)
+            elif act < 0.35 and i in nodes:
+                p.both("delete_node", nodes[i]["ID"])
+                for t in [t for t, nid in placed.items() if nid == nodes[i]["ID"]]:
+                    del placed[t]
+                del nodes[i]
+            elif act < 0.45 and i not in nodes:
+                nodes[i] = fz.node_doc(rng, i)
+                p.both("create_node", nodes[i])
+            elif act < 0.70 and placed:   # the task fails on its node: failure bookkeeping + re-queue by the orchestrator
+                t = rng.choice(sorted(placed))
+                d = dict(docs[t], NodeID=placed[t], Status={"State": rng.choice([orc.FAILED, orc.REJECTED, "FAILED", orc.COMPLETE, orc.RUNNING])})
+                p.both("update_task", d)
+                if orc_state(d["Status"]["State"]) > orc.RUNNING:
+                    del placed[t]
+            elif act < 0.8:
+                p.both("advance", rng.choice([1, 30, 200, 400]))
+            elif act < 0.9 and placed:
+                t = rng.choice(sorted(placed))
+                p.both("delete_task", dict(docs[t], NodeID=placed[t], Status={"State": orc.RUNNING}))
+                del placed[t]
+            elif placed:   # desired state flips past COMPLETE and back: the task stops / resumes counting
+                t = rng.choice(sorted(placed))
+                p.both("update_task", dict(docs[t], NodeID=placed[t], DesiredState=rng.choice([orc.SHUTDOWN, orc.RUNNING]), Status={"State": orc.RUNNING}))
+        if rng.random() < 0.5 and nodes:   # constraint-enforcer sweep over the current cluster
+            tbn = {}
+            for t, nid in placed.items():
+                tbn.setdefault(nid, []).append(dict(docs[t], NodeID=nid, Status={"State": orc.RUNNING}))
+            services = {"svc%02d" % k: {"Spec": {"Task": {"Placement": (specs[k].get("Spec") or {}).get("Placement")}}} for k in range(n_svc) if rng.random() < 0.7}
+            live = [d for d in nodes.values() if not ((d.get("Description") or {}).get("Resources") or {}).get("Generic")]
+            if live:
+                p.enforce(live, tbn, services)
+    note(p.both("tick"))
+    for i in list(nodes)[:6]:
+        p.both("node_info", nodes[i]["ID"])
+    p.both("node_info", "n-unknown")
+
+
+def orc_state(v):
+    return {"FAILED": orc.FAILED, "REJECTED": orc.REJECTED}.get(v, v) if isinstance(v, str) else v
+
+
+def test_cxx_wrapper_has_the_twins_surface(monkeypatch):
+    """Everything the parity tests and bench.py call on a host scheduler exists on both implementations, and the bulk
+    workload path (host.load_workload / parity_util.engine_run) runs through the C++ layer (scripted engine: the
+    placements themselves mean nothing here)."""
+    public = {n for n in dir(swhost.PyHostScheduler) if not n.startswith("_") and callable(getattr(swhost.PyHostScheduler, n))}
+    missing = sorted(n for n in public if not hasattr(swsched.Scheduler, n))
+    assert not missing, missing
+    import parity_util as pu
+    from swarmkit_amd import synth
+    monkeypatch.setenv("SWP_HOST", "cxx")
+    wl = synth.Workload("cfg4", T=300, N=40)
+    placed, errs, s, out, hist = pu.engine_run(wl, lib_path=fakelib.build())
+    assert isinstance(s, swsched.Scheduler) and len(placed) == wl.T
+    assert all(e.startswith("no suitable node") for e in errs.values())
