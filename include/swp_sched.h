@@ -30,10 +30,10 @@ int swp_sched_create(swp_engine* engine, swp_sched** out);
 void swp_sched_destroy(swp_sched*);
 const char* swp_sched_last_error(swp_sched*);
 
-/* createOrUpdateNode (scheduler.go:368-396), reached from EventCreateNode / EventUpdateNode (:214-217) and
+/* createOrUpdateNode (scheduler.go:368-396), reached from EventCreateNode / EventUpdateNode (:191-196) and
  * buildNodeSet (:973-990). node_json = api.Node. Generic resources → SWP_EUNSUPPORTED (node stays on the Go path). */
 int swp_sched_create_or_update_node(swp_sched*, const char* node_json, size_t len);
-/* EventDeleteNode → nodeSet.remove (scheduler.go:218-219, nodeset.go:46-48) */
+/* EventDeleteNode → nodeSet.remove (scheduler.go:197-198, nodeset.go:46-48) */
 int swp_sched_delete_node(swp_sched*, const char* node_id, size_t len);
 /* nodeSet.nodeInfo (nodeset.go:23-29) as JSON {ID, ActiveTasksCount, ActiveTasksCountByService, AvailableResources,
  * Tasks, RecentFailures}; SWP_ENOTFOUND <-> errNodeNotFound */
@@ -46,12 +46,12 @@ int swp_sched_delete_service(swp_sched*, const char* service_id, size_t len);
 /* Test clock: time.Now() of taskFailed / countRecentFailures (nodeinfo.go:177-221) advances by `ns`. */
 int swp_sched_advance(swp_sched*, int64_t ns);
 
-/* Task event handlers. task_json = api.Task. *tick_needed = the handler's bool result (scheduler.go:196-212:
- * a true result arms the commit debouncer). */
+/* Task event handlers. task_json = api.Task. *tick_needed = the handler's bool result (scheduler.go:178-190:
+ * a true result sets tickRequired). */
 int swp_sched_create_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* createTask :254-283 */
-int swp_sched_setup_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);    /* setupTasksList :88-124 */
-int swp_sched_update_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* updateTask :285-349 */
-int swp_sched_delete_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* deleteTask :351-366 */
+int swp_sched_setup_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);    /* setupTasksList :68-126 */
+int swp_sched_update_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* updateTask :283-348 */
+int swp_sched_delete_task(swp_sched*, const char* task_json, size_t len, int* tick_needed);   /* deleteTask :350-366 */
 
 /* tick (scheduler.go:429-488): task groups (ServiceID, SpecVersion) in first-seen order through swp_schedule_groups,
  * then the one-off tasks in queue order through swp_schedule_batch; left-overs through noSuitableNode (:928-971).
