@@ -631,16 +631,22 @@ class Scheduler {
         runGroups(groups, 0, groups.size(), decisions);
         // one-off tasks (:460-466): a task with spread preferences is a group of one and keeps its place in the order
         std::vector<Item> run;
+        std::vector<swp_task_desc> run_descs;   // Pipeline.SetTask once per task
         for (Item& it : one_off) {
-            if (taskDesc(it.second).spread_set != 0) {
-                runOneOffs(run, decisions);
+            const swp_task_desc d = taskDesc(it.second);
+            if (d.spread_set != 0) {
+                runOneOffs(run, run_descs, decisions);
                 run.clear();
+                run_descs.clear();
                 std::vector<std::vector<Item>> single(1);
                 single[0].push_back(std::move(it));
                 runGroups(single, 0, 1, decisions);
-            } else run.push_back(std::move(it));
+            } else {
+                run.push_back(std::move(it));
+                run_descs.push_back(d);
+            }
         }
-        runOneOffs(run, decisions);
+        runOneOffs(run, run_descs, decisions);
         return decisions;
     }
 
@@ -1071,10 +1077,8 @@ class Scheduler {
             off += groups[g].size();
         }
     }
-    void runOneOffs(const std::vector<Item>& run, Value& decisions) {
+    void runOneOffs(const std::vector<Item>& run, const std::vector<swp_task_desc>& descs, Value& decisions) {
         if (run.empty()) return;
-        std::vector<swp_task_desc> descs;
-        for (const Item& it : run) descs.push_back(taskDesc(it.second));
         std::vector<int32_t> out(run.size(), -1);
         std::vector<uint32_t> hist(run.size() * SWP_NFILTERS, 0);
         ck(swp_schedule_batch(e_, descs.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_batch");

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -52,6 +53,7 @@ struct swp_engine {
         return out;
     }
     void say(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+        if (quiet) return;
         char buf[1024];
         va_list ap;
         va_start(ap, fmt);
@@ -65,11 +67,17 @@ struct swp_engine {
         z ^= z >> 29;
         return (uint32_t)(z >> 16);
     }
-    std::vector<uint32_t> present() const {
-        std::vector<uint32_t> p;
-        for (uint32_t i = 0; i < nodes.size(); ++i)
-            if (nodes[i].present) p.push_back(i);
-        return p;
+    std::vector<uint32_t> present_cache;
+    bool present_dirty = true;
+    bool quiet = std::getenv("SWP_FAKE_QUIET") != nullptr;   // host-layer timing runs: no log
+    const std::vector<uint32_t>& present() {
+        if (present_dirty) {
+            present_cache.clear();
+            for (uint32_t i = 0; i < nodes.size(); ++i)
+                if (nodes[i].present) present_cache.push_back(i);
+            present_dirty = false;
+        }
+        return present_cache;
     }
     std::string desc(const swp_task_desc& d) const {
         char buf[512];
@@ -91,7 +99,7 @@ struct swp_engine {
     }
     // one scripted answer for one task: a present node, or -1 with a scripted histogram
     int32_t answer(const swp_task_desc& d, uint32_t* hist) {
-        const std::vector<uint32_t> p = present();
+        const std::vector<uint32_t>& p = present();
         const uint32_t r = next();
         if (p.empty() || r % 5u == 0u) {
             if (hist != nullptr) {
@@ -126,6 +134,7 @@ int swp_create(const swp_config*, swp_engine** out) {
 void swp_destroy(swp_engine* e) { delete e; }
 int swp_reset(swp_engine* e, uint32_t) {
     e->nodes.clear();
+    e->present_dirty = true;
     e->say("reset");
     return SWP_OK;
 }
@@ -154,6 +163,7 @@ int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* nl, ui
     if (row->node >= e->nodes.size()) e->nodes.resize(row->node + 1);
     FakeNode& nd = e->nodes[row->node];
     nd.present = true;
+    e->present_dirty = true;
     nd.row = *row;
     std::string t;
     char ip[40] = "";
@@ -176,6 +186,7 @@ int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_
 }
 int swp_node_remove(swp_engine* e, uint32_t node) {
     if (node < e->nodes.size()) e->nodes[node] = FakeNode();
+    e->present_dirty = true;
     e->say("remove %s", e->name(SWP_SPACE_NODE_ID, node).c_str());
     return SWP_OK;
 }
@@ -245,7 +256,7 @@ int swp_schedule_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t n, in
     e->say("schedule_batch n=%u", n);
     for (uint32_t i = 0; i < n; ++i) {
         out_node[i] = e->answer(tasks[i], hist ? hist + (size_t)i * SWP_NFILTERS : nullptr);
-        e->say("  task %s -> %d", e->desc(tasks[i]).c_str(), out_node[i]);
+        if (!e->quiet) e->say("  task %s -> %d", e->desc(tasks[i]).c_str(), out_node[i]);
     }
     return SWP_OK;
 }
@@ -253,7 +264,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     e->say("schedule_groups n=%u", n_groups);
     size_t off = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {
-        e->say("  group k=%u %s", sizes[g], e->desc(groups[g]).c_str());
+        if (!e->quiet) e->say("  group k=%u %s", sizes[g], e->desc(groups[g]).c_str());
         uint32_t scratch[SWP_NFILTERS];
         for (uint32_t i = 0; i < sizes[g]; ++i) {
             out_node[off + i] = e->answer(groups[g], scratch);

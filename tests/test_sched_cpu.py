@@ -266,3 +266,38 @@ def test_cxx_wrapper_has_the_twins_surface(monkeypatch):
     placed, errs, s, out, hist = pu.engine_run(wl, lib_path=fakelib.build())
     assert isinstance(s, swsched.Scheduler) and len(placed) == wl.T
     assert all(e.startswith("no suitable node") for e in errs.values())
+
+
+def test_cxx_host_error_behaviour():
+    """No exception crosses the C boundary: malformed input comes back as a negative SWP_E* with a message, and the
+    scheduler stays usable."""
+    import ctypes as C
+    lib = fakelib.build()
+    s = swsched.Scheduler(engine=abi.Engine(lib_path=lib))
+    L, flag, out = s.L, C.c_int(7), C.c_char_p()
+    bad = b'{"ID": "t1", "Status": {"State": '
+    assert L.swp_sched_create_task(s.h, bad, len(bad), C.byref(flag)) == abi.SWP_EINVAL and b"json" in L.swp_sched_last_error(s.h)
+    no_id = b'{"Status": {"State": 64}}'
+    assert L.swp_sched_create_task(s.h, no_id, len(no_id), C.byref(flag)) == abi.SWP_EINVAL and b"ID" in L.swp_sched_last_error(s.h)
+    odd = b'{"ID": "t1", "Status": {"State": "SLEEPING"}}'
+    assert L.swp_sched_create_task(s.h, odd, len(odd), C.byref(flag)) == abi.SWP_EINVAL and b"SLEEPING" in L.swp_sched_last_error(s.h)
+    assert L.swp_sched_create_task(None, no_id, len(no_id), C.byref(flag)) == abi.SWP_EINVAL
+    assert L.swp_sched_create_task(s.h, None, 0, C.byref(flag)) == abi.SWP_EINVAL
+    assert L.swp_sched_node_info(s.h, b"nope", 4, C.byref(out)) == abi.SWP_ENOTFOUND      # errNodeNotFound
+    generic = {"ID": "n1", "Description": {"Resources": {"NanoCPUs": 1, "Generic": [{"DiscreteResourceSpec": {"Kind": "gpu", "Value": 1}}]}}}
+    with pytest.raises(abi.Unsupported):
+        s.create_node(generic)
+    assert s.node_info("n1") is None                                                      # refused, not half-created
+    with pytest.raises(abi.SwpError) as ei:                                               # enforcer on a node the nodeSet does not hold
+        s.enforce([{"ID": "ghost", "Spec": {"Availability": 0}}], {"ghost": [{"ID": "t", "DesiredState": 512, "Status": {"State": 512}}]})
+    assert ei.value.code == abi.SWP_ENOTFOUND
+    # still usable afterwards
+    s.create_node({"ID": "n2", "Status": {"State": 2}, "Spec": {"Availability": 0}})
+    s.set_service("svc")
+    assert s.create_task({"ID": "t9", "ServiceID": "svc", "DesiredState": 512, "Status": {"State": 64}}) is True
+    d = s.tick()
+    assert [x["ID"] for x in d] == ["t9"]
+    # the pure helpers
+    assert swsched.explain([0, 2, 0, 0, 0, 0, 0, 1]) == "insufficient resources on 2 nodes; cannot fulfill requested CSI volume mounts on 1 node"
+    assert swsched.parse_constraints(["node.labels.a==b", "oops"]) is None
+    assert swsched.parse_constraints([" Node.ID  !=  x y "]) == [("Node.ID", 1, "x y")]
