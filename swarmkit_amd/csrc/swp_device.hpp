@@ -2545,6 +2545,8 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
     }
 }
 
+#include "swp_resolve4.hpp"   // k_resolve4: G replicated resolver waves, speculative rounds (experimental, SWP_RESOLVER=4)
+
 // ---------------------------------------------------------------------------------------------
 // k_explain — per-filter first-failure histogram for every task that found no node, evaluated
 // against the node state AT THE MOMENT that task was tried (Pipeline.Process counters,

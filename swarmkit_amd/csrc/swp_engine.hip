@@ -609,6 +609,19 @@ hipError_t launch_resolve3(const ResolveArgs& ra, size_t lds, hipStream_t s) {
     return (ra.dbg & 16u) ? launch_resolve3p<K, true>(ra, lds, s) : launch_resolve3p<K, false>(ra, lds, s);
 }
 
+constexpr int R4_G = 4;   // resolver replicas of k_resolve4
+template <int K>
+hipError_t launch_resolve4(const ResolveArgs& ra, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve4<K, R4_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (r != hipSuccess) return r;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_resolve4<K, R4_G>), dim3(1), dim3(64 * (R4_G + 3)), lds, s, ra);
+    return hipGetLastError();
+}
+
 template <int K>
 hipError_t launch_resolve(const ResolveArgs& ra, uint32_t threads, size_t lds, hipStream_t s) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -691,6 +704,20 @@ int batch_run(swp_engine* e, swp_batch* b) {
     int variant = env_res ? atoi(env_res) : 3;
     uint32_t r2_tb = 0;
     size_t r2_lds = 0;
+    if (variant == 4) {
+        // k_resolve4 (experimental, only on request): as k_resolve3 plus per-replica D / ring-fix rows, commit rings and records
+        const uint32_t K4 = (Wn + 63) / 64;
+        const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
+        const size_t row = (size_t)K4 * 64 * 8;
+        const size_t per_slot = row + 32;
+        const size_t fixed4 = off_f + row * (1 + 2 * R4_G) + (size_t)R4_G * 64 * 16 + 4 * R4_G * 8 + 32 + 128 + 64;
+        const size_t avail = lds_budget > fixed4 ? lds_budget - fixed4 : 0;
+        const size_t slots = avail / per_slot;
+        if (K4 <= 4 && slots >= 2 * 4) {
+            r2_tb = (uint32_t)std::min<size_t>(R2_TB_MAX, slots / 2);
+            r2_lds = fixed4 + (size_t)(2 * r2_tb) * per_slot;
+        } else variant = 3;
+    }
     if (variant == 3) {
         // k_resolve3: staged mk rows padded to 64*K words, 2*TB+1 slots (+ records), one published BELOW row, flags
         const uint32_t K3 = (Wn + 63) / 64;
@@ -776,7 +803,14 @@ int batch_run(swp_engine* e, swp_batch* b) {
         ra.ctl = b->d_ctl.as<Ctl>();
         hipError_t r;
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
-        if (variant == 3) {
+        if (variant == 4) {
+            switch ((Wn + 63) / 64) {
+            case 1: r = launch_resolve4<1>(ra, r2_lds, st); break;
+            case 2: r = launch_resolve4<2>(ra, r2_lds, st); break;
+            case 3: r = launch_resolve4<3>(ra, r2_lds, st); break;
+            default: r = launch_resolve4<4>(ra, r2_lds, st); break;
+            }
+        } else if (variant == 3) {
             switch ((Wn + 63) / 64) {
             case 1: r = launch_resolve3<1>(ra, r2_lds, st); break;
             case 2: r = launch_resolve3<2>(ra, r2_lds, st); break;
@@ -837,6 +871,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         HIPCHECK(e, hipStreamSynchronize(st));
     }
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
+    if (ctl.error == ERR_PROTOCOL) return e->fail(SWP_EHIP, "k_resolve4: a hand-shake between the resolver replicas timed out");
     if (ctl.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the level planes that fit in LDS");
     if (ctl.ninf) {
         ExplainArgs xa{};
