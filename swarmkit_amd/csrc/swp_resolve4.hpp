@@ -1,6 +1,10 @@
 // swp_resolve4.hpp — k_resolve4: the sequential argmin + commit pass with G REPLICATED resolver wavefronts that pick
-// speculatively for the G tasks of a round. EXPERIMENTAL (SWP_RESOLVER=4): written at the end of round 1 without GPU
-// time left to validate it; the default resolver is k_resolve3. Included from swp_device.hpp after k_resolve3.
+// speculatively for the G tasks of a round. EXPERIMENTAL, opt-in (SWP_RESOLVER=4); the default resolver is k_resolve3.
+// Status at the end of round 1 (one GPU run, the round's last): bit-exact against the oracle on the nine parity cases
+// of tests/test_engine_resolvers.py (SWP_TEST_R4=1), but SLOWER than k_resolve3 on the headline workload (77.9 ms vs
+// 40.8 ms per 100k x 10k batch) — the protocol is right, its constant factors are not yet (docs/NOTES_r01.md §5 lists
+// what the ISA shows: two dependent LDS round trips before the pick, an abort-flag read in every poll iteration, SGPR
+// spill traffic in the round loop). Included from swp_device.hpp after k_resolve3.
 //
 // Why: a lone wave issues one instruction per ≈ 4 ns, k_resolve3 needs ≈ 85 per task; the only way past that is to work
 // on several tasks at once although task i+1 must see task i's placement. Here every resolver wave holds the SAME

@@ -21,8 +21,9 @@ def resolver_env():
 
 
 CASES = [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg1", 500, 40, {}), ("cfg2", 3000, 50, {})]
-# k_resolve4 (speculative rounds over replicated resolver waves) was written after the round's GPU budget was spent: it
-# is opt-in (SWP_RESOLVER=4) and its parity cases run only with SWP_TEST_R4=1 until it has been validated on hardware.
+# k_resolve4 (speculative rounds over replicated resolver waves) is opt-in (SWP_RESOLVER=4): its parity cases passed on an
+# MI355X in the one run the round had left for it, but the kernel is not the default (slower than k_resolve3 so far) and
+# one run says little about a lock-free LDS protocol, so the cases stay out of the default suite: SWP_TEST_R4=1 adds them.
 R4 = [4] if os.environ.get("SWP_TEST_R4") else []
 BASE = [] if os.environ.get("SWP_TEST_R4") == "only" else None   # SWP_TEST_R4=only: just the k_resolve4 cases
 
