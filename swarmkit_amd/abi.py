@@ -112,7 +112,7 @@ class SwpError(RuntimeError):
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). In-tree output: swarmkit_amd/lib/libswp.so."""
-    srcs = [os.path.join(CSRC, f) for f in ("swp_engine.hip", "swp_device.hpp", "swp_sched.cpp", "swp_json.hpp", "Makefile")] \
+    srcs = [os.path.join(CSRC, f) for f in ("swp_engine.hip", "swp_device.hpp", "swp_resolve4.hpp", "swp_sched.cpp", "swp_json.hpp", "Makefile")] \
         + [os.path.join(ROOT, "include", h) for h in ("swp.h", "swp_sched.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
