@@ -1264,24 +1264,36 @@ int swp_constraint_parse(const char* exprs_json, size_t len, const char** parsed
 }
 int swp_key_equal_fold(const char* a, size_t la, const char* b, size_t lb) {
     if ((a == nullptr && la) || (b == nullptr && lb)) return 0;
-    return swp::equal_fold(swp::decode(std::string(a ? a : "", la)), swp::decode(std::string(b ? b : "", lb))) ? 1 : 0;
+    try {
+        return swp::equal_fold(swp::decode(std::string(a ? a : "", la)), swp::decode(std::string(b ? b : "", lb))) ? 1 : 0;
+    } catch (const std::exception&) {
+        return 0;
+    }
 }
 int swp_explain(const uint32_t* hist, char* out, size_t cap) {
     if (hist == nullptr) return SWP_EINVAL;
-    const std::string s = swp::explain(hist);
-    if (out != nullptr && cap > 0) {
-        const size_t n = std::min(cap - 1, s.size());
-        std::memcpy(out, s.data(), n);
-        out[n] = 0;
+    try {
+        const std::string s = swp::explain(hist);
+        if (out != nullptr && cap > 0) {
+            const size_t n = std::min(cap - 1, s.size());
+            std::memcpy(out, s.data(), n);
+            out[n] = 0;
+        }
+        return (int)s.size();
+    } catch (const std::exception&) {
+        return SWP_ENOMEM;
     }
-    return (int)s.size();
 }
 int swp_parse_ip(const char* s, size_t len, uint8_t out16[16], int* is_v4) {
     if (s == nullptr || out16 == nullptr) return 0;
-    bool v4 = false;
-    if (!swp::parse_ip(std::string(s, len), out16, &v4)) return 0;
-    if (is_v4 != nullptr) *is_v4 = v4 ? 1 : 0;
-    return 1;
+    try {
+        bool v4 = false;
+        if (!swp::parse_ip(std::string(s, len), out16, &v4)) return 0;
+        if (is_v4 != nullptr) *is_v4 = v4 ? 1 : 0;
+        return 1;
+    } catch (const std::exception&) {
+        return 0;
+    }
 }
 
 }   // extern "C"
