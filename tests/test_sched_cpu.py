@@ -301,3 +301,29 @@ def test_cxx_host_error_behaviour():
     assert swsched.explain([0, 2, 0, 0, 0, 0, 0, 1]) == "insufficient resources on 2 nodes; cannot fulfill requested CSI volume mounts on 1 node"
     assert swsched.parse_constraints(["node.labels.a==b", "oops"]) is None
     assert swsched.parse_constraints([" Node.ID  !=  x y "]) == [("Node.ID", 1, "x y")]
+
+
+def test_cxx_json_boundary_round_trips_strings_and_numbers():
+    """Documents cross the host boundary as JSON: strings (escapes, surrogate pairs, control characters, raw UTF-8) and
+    64-bit integers must survive parser and writer unchanged."""
+    import ctypes as C
+    import json
+    s = swsched.Scheduler(engine=abi.Engine(lib_path=fakelib.build()))
+    ids = ["plain", "quote\"back\\slash/", "tab\tnl\ncr\r", "ctl\x01\x1f", "é-ſ-K", "astral-\U0001F680-\U00010348", "mixed     end", ""]
+    for i, nid in enumerate(ids):
+        doc = {"ID": nid, "Status": {"State": 2}, "Spec": {"Availability": 0},
+               "Description": {"Resources": {"NanoCPUs": 2**62 + i, "MemoryBytes": 2**53 + 1}}}
+        for text in (json.dumps(doc), json.dumps(doc, ensure_ascii=False)):   # \\uXXXX escapes and raw UTF-8
+            b = text.encode()
+            assert s.L.swp_sched_create_or_update_node(s.h, b, len(b)) == 0, nid
+            info = s.node_info(nid)
+            assert info["ID"] == nid
+            assert info["AvailableResources"] == {"NanoCPUs": 2**62 + i, "MemoryBytes": 2**53 + 1, "Generic": []}
+    # numbers: negative, uint64 above int64 (MaxReplicas), exponent form; unknown members are ignored
+    t = {"ID": "t", "ServiceID": "svc", "DesiredState": 512, "Status": {"State": 64}, "Unknown": [1, {"x": None}, 2.5e3, True],
+         "Spec": {"Placement": {"MaxReplicas": 2**64 - 1}, "Resources": {"Reservations": {"NanoCPUs": -5, "MemoryBytes": 1e3}}}}
+    d = s.task_desc(t)
+    assert int(d["max_replicas"][0]) == 2**64 - 1 and int(d["cpu"][0]) == -5 and int(d["mem"][0]) == 1000
+    for bad in [b"", b"{", b'{"ID": "x",}', b'{"ID": "\\ud800"} trailing', b'[1, 2', b'{"a": tru}', b'"\\x"', b"{" * 100 + b"}" * 100]:
+        flag = C.c_int()
+        assert s.L.swp_sched_create_task(s.h, bad, len(bad), C.byref(flag)) == abi.SWP_EINVAL, bad
