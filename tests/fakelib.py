@@ -15,9 +15,11 @@ def build():
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-fPIC", "-shared", "-o", OUT] + SRCS, capture_output=True, text=True)
+    tmp = "%s.%d.tmp" % (OUT, os.getpid())   # parallel test workers: build privately, publish atomically
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-fPIC", "-shared", "-o", tmp] + SRCS, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("libswpfake.so build failed:\n" + r.stdout + r.stderr)
+    os.replace(tmp, OUT)
     return OUT
 
 
