@@ -75,7 +75,6 @@ def main():
                     help="one-off (headline, SURVEY 8d primary mode); grouped: S groups of T/S tasks through swp_schedule_groups (secondary mode); "
                          "enforce: the constraint enforcer's start-up sweep (SURVEY 8f-1) over the cluster the placement produced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="also verify the placements against the oracle sample")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -300,13 +299,6 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bounded sample, ~15 s of one host core)
         result["cpu_baseline"] = cpu_baseline(wl)
-    if args.check and rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import parity_util as pu
-        n = min(wl.T, 3000)
-        op, oe, _ = pu.oracle_run(wl, count=n)
-        bad = sum(1 for j in range(n) if (op[wl.task_id(j)] or None) != (sched.idx_to_id[int(out[j])] if out[j] >= 0 else None))
-        result["check"] = {"tasks": n, "mismatches": bad}
     if rank == 0:
         print(json.dumps(result))
     batch.free()
