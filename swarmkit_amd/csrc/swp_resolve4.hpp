@@ -31,6 +31,23 @@
 
 #define ERR_PROTOCOL 3   // k_resolve4: an LDS hand-shake between the resolver replicas timed out
 
+// Tuning candidates for the next round, each behind one bit of R4_OPT (make CXXFLAGS+=-DR4_OPT=n; default 0 = the code
+// that passed the parity cases on the GPU). NONE of them has run on hardware yet:
+//   1  issue the D-row reads before they are needed (today: three dependent LDS round trips inside the pick)
+//   2  {flags, svc} of the whole block in registers (lane t = task t), read once per block: the pick no longer starts
+//      with a dependent LDS read of the round's task records
+//   4  test the abort flag every 256 polls instead of in every poll iteration
+//   8  publish which kept candidates are touched instead of giving the round up when ANY of them is: a round then ends
+//      only if the candidate a task actually takes is touched (what the sequential order does)
+#ifndef R4_OPT
+#define R4_OPT 0
+#endif
+#if R4_OPT & 8
+#define R4_POS(mh) (((mh) >> 4) & 0x3FFu)   // bits 16.. of the meta word carry the touched flags
+#else
+#define R4_POS(mh) ((mh) >> 4)
+#endif
+
 __device__ __forceinline__ u32 lds_addr(const void* p) { return (u32)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 // two LDS accesses by the same lanes, guaranteed to execute in this order (one wave's DS instructions are in order)
 __device__ __forceinline__ void lds_write_pair_ordered(u32 a0, u64 v0, u32 a1, u64 v1) {
@@ -435,22 +452,45 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
     u32 blk_ep = 0, round = 0, j = 0;
     wait_block(0);
     if (!fatal) blk_ep = block_epoch(0);
+#if R4_OPT & 2
+    // lane t holds {flags, svc} of task t of the current block (TB <= 16 tasks)
+    auto load_block_records = [&](u32 bf, u32 ntasks) __attribute__((always_inline)) -> uint2 {
+        return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(&Tb[bf * TB + min(lane, ntasks - 1u)]) + 16);
+    };
+    uint2 blk_rec = make_uint2(0u, 0u);
+    if (!fatal) blk_rec = load_block_records(0u, min(TB, a.count));
+#endif
 
     while (j < a.count && !fatal) {
         const u32 base_slot = (bdone & 1u) * TB;
         const u32 nt = min(TB, a.count - bdone * TB);   // tasks of this block
         const u32 g = min((u32)G, nt - tin);            // tasks of this round (a round never crosses a block)
         ++round;
+#if R4_OPT & 2
+        // lane v gets {flags, svc} of task v of the round from the block's register copy (no LDS access on the way to the pick)
+        const uint2 crv = make_uint2((u32)__builtin_amdgcn_ds_bpermute((int)((tin + min(lane, g - 1u)) << 2), (int)blk_rec.x),
+                                     (u32)__builtin_amdgcn_ds_bpermute((int)((tin + min(lane, g - 1u)) << 2), (int)blk_rec.y));
+#else
         // lane v holds {flags, svc} of task v of the round
         const uint2 crv = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(&Tb[base_slot + tin + min(lane, g - 1u)]) + 16);
+#endif
 
         // ---------------- 1. this replica's speculative pick ----------------
         u32 meta_hi = 0;
         u64 keep = 0;
         if (w < g) {
+#if R4_OPT & 2
+            const u32 flagw = rl32(blk_rec.x, tin + w), rsvc = rl32(blk_rec.y, tin + w);
+#else
             const u32 flagw = rl32(crv.x, w), rsvc = rl32(crv.y, w);
+#endif
             u64 mk[K];
             bool ring_hit;
+#if R4_OPT & 1
+            u64 dk_[K];   // issued together with the row reads
+#pragma unroll
+            for (int k = 0; k < K; ++k) dk_[k] = __hip_atomic_load(&my_drow[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
             load_row(base_slot + tin + w, rsvc, mk, ring_hit);
             bool generic;
             if (__builtin_expect(blk_ep == epoch, 1)) generic = (int)flagw < 0;   // staged: forced, or a candidate below h
@@ -465,11 +505,32 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
                 u64 ca[K], ba[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
+#if R4_OPT & 1
+                    const u64 dk = dk_[k];
+#else
                     const u64 dk = __hip_atomic_load(&my_drow[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                     ca[k] = bitop3_u64<BITOP_A_AND_B_ANDN_C>(mk[k], LA0[k], dk);
                     ba[k] = ballot64(ca[k] != 0);
                 }
                 // first slot with a hot-level candidate; keep the lowest w+1 candidates of its first word
+#if R4_OPT & 8
+#define R4_PICK(kk)                                                                                    \
+    {                                                                                                  \
+        const u32 l_ = (u32)__builtin_ctzll(ba[kk]);                                                   \
+        const u64 word_ = rl64(ca[kk], l_), tw_ = rl64(T0[kk], l_);                                    \
+        u64 kp_ = 0, rem_ = word_;                                                                     \
+        u32 tf_ = 0; /* bit c: the c-th kept candidate was committed to in this window (F may be stale) */ \
+        for (u32 c_ = 0; c_ <= w; ++c_) {                                                              \
+            const u64 low_ = rem_ & (0ull - rem_);                                                     \
+            kp_ |= low_;                                                                               \
+            tf_ |= ((low_ & tw_) != 0 ? 1u : 0u) << c_;                                                \
+            rem_ ^= low_;                                                                              \
+        }                                                                                              \
+        keep = kp_;                                                                                    \
+        meta_hi = 3u | ((u32)(kk) << 4) | (l_ << 8) | (tf_ << 16);                                     \
+    }
+#else
 #define R4_PICK(kk)                                                                                    \
     {                                                                                                  \
         const u32 l_ = (u32)__builtin_ctzll(ba[kk]);                                                   \
@@ -485,6 +546,7 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
             meta_hi = 3u | ((u32)(kk) << 4) | (l_ << 8);                                               \
         }                                                                                              \
     }
+#endif
                 if (ba[0] != 0) { R4_PICK(0) }
                 else if constexpr (K > 1) {
                     if (ba[1] != 0) { R4_PICK(1) }
@@ -521,7 +583,11 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
             for (;;) {
                 lds_read_pair_ordered(aM, aW, M, Wd);   // meta first: a current round number implies a current word
                 if (ballot64(lane < (u32)G && (u32)M != round) == 0) break;
+#if R4_OPT & 4
+                if ((++spins & 255u) == 0 && (spins > (1u << 22) || aborted())) { fatal = true; break; }
+#else
                 if (++spins > (1u << 22) || aborted()) { fatal = true; break; }
+#endif
             }
             st_spins += spins;
         }
@@ -538,10 +604,17 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
                 const u64 wd = rl64(Wd, (u32)v);
                 u64 tk = 0;   // bits of the same word taken by earlier tasks of the round
 #pragma unroll
-                for (int u = 0; u < v; ++u) tk |= (cpos[u] == (mh >> 4)) ? cbit[u] : 0ull;
+                for (int u = 0; u < v; ++u) tk |= (cpos[u] == R4_POS(mh)) ? cbit[u] : 0ull;
                 const u64 avail = wd & ~tk;
+#if R4_OPT & 8
+                const u64 low = avail & (0ull - avail);
+                const u32 rank = (u32)__popcll(wd & (low - 1ull));            // how many kept candidates sit below the one taken
+                const bool stale = ((mh >> (16u + rank)) & 1u) != 0;          // … and is that one touched (its F bit may be stale)
+                const bool ok = !ended && (mh & 3u) == 3u && avail != 0 && !stale;
+#else
                 const bool ok = !ended && (mh & 3u) == 3u && avail != 0;
-                cpos[v] = mh >> 4;
+#endif
+                cpos[v] = R4_POS(mh);
                 cbit[v] = ok ? (avail & (0ull - avail)) : 0ull;
                 if (ok) n_round = (u32)v + 1u;
                 else ended = true;
@@ -551,7 +624,11 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
 
         if (__builtin_expect(n_round != 0, 1)) {
             // ---------------- 4. apply the round to this replica ----------------
+#if R4_OPT & 8
+            const u32 mypos = R4_POS((u32)(M >> 32));   // slot | lane << 4 of task `lane`'s word
+#else
             const u32 mypos = (u32)(M >> 36);   // slot | lane << 4 of task `lane`'s word
+#endif
             const u32 mywi = (mypos >> 4) + 64u * (mypos & 15u);
             u64 mybit = 0;
 #pragma unroll
@@ -568,7 +645,11 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
         } else {
             // ---------------- task j is not simple: k_resolve3's full iteration, redundantly on every replica ----------------
             const u32 slot0 = base_slot + tin;
+#if R4_OPT & 2
+            const u32 flag0 = rl32(blk_rec.x, tin), rsvc = rl32(blk_rec.y, tin);
+#else
             const u32 flag0 = rl32(crv.x, 0u), rsvc = rl32(crv.y, 0u);
+#endif
             u64 mk[K], d[K];
             bool ring_hit;
             load_row(slot0, rsvc, mk, ring_hit);
@@ -843,6 +924,9 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
             if (j < a.count && !fatal) {
                 wait_block(bdone);
                 if (!fatal) blk_ep = block_epoch(bdone & 1u);
+#if R4_OPT & 2
+                if (!fatal) blk_rec = load_block_records(bdone & 1u, min(TB, a.count - bdone * TB));
+#endif
             }
         }
     }
