@@ -563,30 +563,15 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     return SWP_OK;
 }
 
-// hipFuncSetAttribute is a per-DEVICE setting: remember, per kernel, which device ordinals have been configured (a
-// process may hold engines on several GPUs; the entry points have made the engine's device current).
-struct AttrOnce {
-    uint64_t done = 0;
-    template <class F>
-    hipError_t ensure(F&& set) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const uint64_t bit = 1ull << (dev & 63);
-        if (done & bit) return hipSuccess;
-        hipError_t r = set();
-        if (r == hipSuccess) done |= bit;
-        return r;
-    }
-};
-
 template <int K, int D>
 hipError_t launch_resolve1(const ResolveArgs& ra, size_t lds, hipStream_t s) {
     (void)lds;
     size_t need = (size_t)ra.n_nodes * 4 + 64;   // last commit per node
-    if (need > 64 * 1024) {
-        static AttrOnce attr;
-        hipError_t r = attr.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve1<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); });
+    static size_t attr_bytes = 0;
+    if (need > 64 * 1024 && need > attr_bytes) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve1<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (r != hipSuccess) return r;
+        attr_bytes = 160 * 1024 - 512;
     }
     hipLaunchKernelGGL((k_resolve1<K, D>), dim3(1), dim3(64), need, s, ra);
     return hipGetLastError();
@@ -594,9 +579,12 @@ hipError_t launch_resolve1(const ResolveArgs& ra, size_t lds, hipStream_t s) {
 
 template <int K, bool PROF>
 hipError_t launch_resolve2p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    static AttrOnce attr;
-    hipError_t r = attr.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve2<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); });
-    if (r != hipSuccess) return r;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve2<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (r != hipSuccess) return r;
+        attr_set = true;
+    }
     hipLaunchKernelGGL((k_resolve2<K, PROF>), dim3(1), dim3(128), lds, s, ra);
     return hipGetLastError();
 }
@@ -607,9 +595,12 @@ hipError_t launch_resolve2(const ResolveArgs& ra, size_t lds, hipStream_t s) {
 
 template <int K, bool PROF>
 hipError_t launch_resolve3p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    static AttrOnce attr;
-    hipError_t r = attr.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve3<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); });
-    if (r != hipSuccess) return r;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve3<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (r != hipSuccess) return r;
+        attr_set = true;
+    }
     hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(256), lds, s, ra);
     return hipGetLastError();
 }
@@ -621,9 +612,12 @@ hipError_t launch_resolve3(const ResolveArgs& ra, size_t lds, hipStream_t s) {
 constexpr int R4_G = 4;   // resolver replicas of k_resolve4
 template <int K>
 hipError_t launch_resolve4(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    static AttrOnce attr;
-    hipError_t r = attr.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve4<K, R4_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); });
-    if (r != hipSuccess) return r;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve4<K, R4_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (r != hipSuccess) return r;
+        attr_set = true;
+    }
     hipLaunchKernelGGL((k_resolve4<K, R4_G>), dim3(1), dim3(64 * (R4_G + 3)), lds, s, ra);
     return hipGetLastError();
 }
@@ -1437,8 +1431,11 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     ga.ff = d_ff.as<unsigned char>(); ga.svc_dense = d_svcd.as<uint32_t>(); ga.fail_dense = d_faild.as<uint32_t>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
     const size_t lds = (size_t)G_HCAP * (8 * 3 + 4 * 6) + (size_t)G_MAXT * (8 + 4 * 4 + 8) + (size_t)G_THREADS * (8 * 2 + 4 * 6) + (16 + 16 + 8) * 4 + (G_HCAP / 64) * 8 + G_LOG + 256;
-    static AttrOnce attr;
-    HIPCHECK(e, attr.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_groups), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); }));
+    static bool attr = false;
+    if (!attr) {
+        HIPCHECK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_groups), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        attr = true;
+    }
     const bool gdbg = getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16);
     hipEvent_t gev0 = nullptr, gev1 = nullptr;
     if (gdbg) { (void)hipEventCreate(&gev0); (void)hipEventCreate(&gev1); (void)hipEventRecord(gev0, st); }
