@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_native_c_consumer_matches_oracle(tmp_path):
     from swarmkit_amd import abi
-    abi.build_library()
+    if not os.path.exists(abi.LIB_PATH):
+        abi.build_library()
     exe = str(tmp_path / "place_demo")
     libdir = os.path.join(ROOT, "swarmkit_amd", "lib")
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "place_demo.c"),
