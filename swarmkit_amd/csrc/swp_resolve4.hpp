@@ -2,9 +2,10 @@
 // speculatively for the G tasks of a round. EXPERIMENTAL, opt-in (SWP_RESOLVER=4); the default resolver is k_resolve3.
 // Status at the end of round 1 (one GPU run, the round's last): bit-exact against the oracle on the nine parity cases
 // of tests/test_engine_resolvers.py (SWP_TEST_R4=1), but SLOWER than k_resolve3 on the headline workload (77.9 ms vs
-// 40.8 ms per 100k x 10k batch) — the protocol is right, its constant factors are not yet (docs/NOTES_r01.md §5 lists
-// what the ISA shows: two dependent LDS round trips before the pick, an abort-flag read in every poll iteration, SGPR
-// spill traffic in the round loop). Included from swp_device.hpp after k_resolve3.
+// 40.8 ms per 100k x 10k batch): 60 % of that workload's tasks are h+1 picks, which today's rounds do not accept, so a
+// round commits 0.4 tasks on average (tools/sim_rounds.py; R4_OPT bit 16 below lets them in). docs/NOTES_r01.md §5 also
+// lists what the ISA shows: dependent LDS round trips before the pick, an abort-flag read in every poll iteration, SGPR
+// spill traffic in the round loop. Included from swp_device.hpp after k_resolve3.
 //
 // Why: a lone wave issues one instruction per ≈ 4 ns, k_resolve3 needs ≈ 85 per task; the only way past that is to work
 // on several tasks at once although task i+1 must see task i's placement. Here every resolver wave holds the SAME
@@ -31,7 +32,7 @@
 
 #define ERR_PROTOCOL 3   // k_resolve4: an LDS hand-shake between the resolver replicas timed out
 
-// Tuning candidates for the next round, each behind one bit of R4_OPT (make CXXFLAGS+=-DR4_OPT=n; default 0 = the code
+// Tuning candidates for the next round, each behind one bit of R4_OPT (make -C swarmkit_amd/csrc EXTRA=-DR4_OPT=n; default 0 = the code
 // that passed the parity cases on the GPU). NONE of them has run on hardware yet:
 //   1  issue the D-row reads before they are needed (today: three dependent LDS round trips inside the pick)
 //   2  {flags, svc} of the whole block in registers (lane t = task t), read once per block: the pick no longer starts
@@ -39,6 +40,16 @@
 //   4  test the abort flag every 256 polls instead of in every poll iteration
 //   8  publish which kept candidates are touched instead of giving the round up when ANY of them is: a round then ends
 //      only if the candidate a task actually takes is touched (what the sequential order does)
+//  16  tasks WITHOUT a hot-level candidate take part in the round with their h+1 candidates (k_resolve3's "B" pick).
+//      tools/sim_rounds.py: on the headline workload 60 % of the tasks are B picks, 30 % A picks — the cluster sits on two
+//      levels at once — so today's rounds commit 0.4 tasks on average (hence 77.9 ms), with B picks 2.4. Exact because a
+//      node taken at level h inside the round was a hot-level node of the snapshot, so it is in no mask that had no
+//      hot-level candidate; B picks of the round only compete with each other (same "skip the taken bits" rule), and a
+//      B candidate that is in D (raised earlier in the window) is touched and ends the round as before.
+//  32  a task with no feasible node at all (k_resolve3's quick exit: mk == 0, no exception-list hint, no commit of its
+//      service in the ring) passes through the round as a no-op instead of ending it: on the headline workload 9.6 % of
+//      the tasks are such (two zone values that no node carries), and with bits 16 + 32 the model commits 3.8 of 4 tasks
+//      per round (6.6 of 8 at G = 8).
 #ifndef R4_OPT
 #define R4_OPT 0
 #endif
@@ -501,6 +512,14 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
                 generic = ballot64(((u32)sb | (u32)(sb >> 32)) != 0) != 0 || (flagw & 0x20000000u) != 0;
             }
             meta_hi = 1u;   // active
+#if R4_OPT & 32
+            bool anym_ = false;
+#pragma unroll
+            for (int k = 0; k < K; ++k) anym_ = anym_ || (mk[k] != 0);
+            const bool none_ = ballot64(anym_) == 0 && (flagw & 0x40000000u) == 0 && !ring_hit;   // k_resolve3's quick exit
+            if (none_) meta_hi = 3u | 8u;   // bit 3: nothing to place, nothing changes
+            else
+#endif
             if (!generic) {
                 u64 ca[K], ba[K];
 #pragma unroll
@@ -570,6 +589,47 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
                     }
                 }
 #undef R4_PICK
+#if R4_OPT & 16
+                {
+                    u64 anya = 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) anya |= ba[k];
+                    if (anya == 0) {   // no hot-level candidate at all: the lowest w+1 candidates at h+1 (LB = LB0 ^ D; D nodes are touched)
+                        u64 cb[K], bb[K];
+                        bool found_ = false;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+#if R4_OPT & 1
+                            const u64 dkb = dk_[k];
+#else
+                            const u64 dkb = __hip_atomic_load(&my_drow[lane + 64 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                            cb[k] = bitop3_u64<BITOP_A_AND_BXORC>(mk[k], LB0[k], dkb);
+                            bb[k] = ballot64(cb[k] != 0);
+                            if (!found_ && bb[k] != 0) {
+                                found_ = true;
+                                const u32 l_ = (u32)__builtin_ctzll(bb[k]);
+                                const u64 word_ = rl64(cb[k], l_), tw_ = rl64(T0[k] | dkb, l_);
+                                u64 kp_ = 0, rem_ = word_;
+                                u32 tf_ = 0;
+                                for (u32 c_ = 0; c_ <= w; ++c_) {
+                                    const u64 low_ = rem_ & (0ull - rem_);
+                                    kp_ |= low_;
+                                    tf_ |= ((low_ & tw_) != 0 ? 1u : 0u) << c_;
+                                    rem_ ^= low_;
+                                }
+                                if ((R4_OPT & 8) != 0) {
+                                    keep = kp_;
+                                    meta_hi = 3u | 4u | ((u32)k << 4) | (l_ << 8) | (tf_ << 16);   // bit 2: an h+1 pick
+                                } else if ((kp_ & tw_) == 0) {
+                                    keep = kp_;
+                                    meta_hi = 3u | 4u | ((u32)k << 4) | (l_ << 8);
+                                }
+                            }
+                        }
+                    }
+                }
+#endif
             }
         }
         // ---------------- 2. exchange ----------------
@@ -592,8 +652,87 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
             st_spins += spins;
         }
         if (fatal) break;
+#if R4_OPT & 32
+        // ---------------- 3'. resolution (same scalar code on every replica); no-candidate tasks pass through ----------------
+        u32 n_round = 0, n_commits = 0, n_none = 0, n_round_a = 0;
+        u32 cpos[G], crank[G], nrank[G];
+        u64 cbit[G];
+        {
+            bool ended = false;
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+                const u32 mh = rl32((u32)(M >> 32), (u32)v);
+                const u64 wd = rl64(Wd, (u32)v);
+                u64 tk = 0;   // bits of the same word taken by earlier tasks of the round
+#pragma unroll
+                for (int u = 0; u < v; ++u) tk |= (cpos[u] == R4_POS(mh)) ? cbit[u] : 0ull;
+                const u64 avail = wd & ~tk;
+                const bool none_v = (mh & 8u) != 0;
+#if R4_OPT & 8
+                const u64 low = avail & (0ull - avail);
+                const u32 rank = (u32)__popcll(wd & (low - 1ull));
+                const bool stale = ((mh >> (16u + rank)) & 1u) != 0;
+                const bool cand_ok = avail != 0 && !stale;
+#else
+                const bool cand_ok = avail != 0;
+#endif
+                const bool ok = !ended && (mh & 3u) == 3u && (none_v || cand_ok);
+                cpos[v] = R4_POS(mh);
+                cbit[v] = (ok && !none_v) ? (avail & (0ull - avail)) : 0ull;
+                crank[v] = n_commits;   // commits / no-ops of the round before task v
+                nrank[v] = n_none;
+                if (ok) {
+                    n_round = (u32)v + 1u;
+                    if (none_v) ++n_none;
+                    else {
+                        ++n_commits;
+                        if ((mh & 4u) == 0) ++n_round_a;
+                    }
+                } else ended = true;
+            }
+        }
+        if (leader) { ++st_rounds; st_round_tasks += n_round; }
+
+        if (__builtin_expect(n_round != 0, 1)) {
+            // ---------------- 4'. apply the round to this replica ----------------
+            const u32 mypos = R4_POS((u32)(M >> 32));   // slot | lane << 4 of task `lane`'s word
+            const u32 mywi = (mypos >> 4) + 64u * (mypos & 15u);
+            u64 mybit = 0;
+            u32 myrank = 0, mynr = 0;
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+                mybit = (lane == (u32)v) ? cbit[v] : mybit;
+                myrank = (lane == (u32)v) ? crank[v] : myrank;
+                mynr = (lane == (u32)v) ? nrank[v] : mynr;
+            }
+            if (lane < n_round && mybit != 0) {
+                __hip_atomic_fetch_or(&my_drow[mywi], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u32 node = (mywi << 6) + (u32)__builtin_ctzll(mybit);
+                my_ring[(ncommit + myrank) & 63u] = make_uint4(crv.y, node, (tin + lane) | 0x100u, 0u);
+            }
+            if (leader && lane < n_round && mybit == 0) {   // "no suitable node": remembered for the explain pass with its moment
+                a.inf_task[ninf + mynr] = a.j0 + j + lane;
+                a.inf_pos[ninf + mynr] = ncommit + myrank;
+            }
+            ncommit += n_commits;
+            ninf += n_none;
+#if R4_OPT & 16
+            la_count -= n_round_a;
+            if (n_commits != n_round_a && la_count == 0 && h + 3u <= (1u << NB) - 1u) {   // h+1 picks and level h is exhausted
+                fold();
+                derive_masks(h + 1);
+            }
+#else
+            la_count -= n_commits;
+#endif
+            tin += n_round;
+            j += n_round;
+#else
         // ---------------- 3. resolution: the same scalar code on every replica ----------------
         u32 n_round = 0;
+#if R4_OPT & 16
+        u32 n_round_a = 0;   // hot-level picks among them
+#endif
         u32 cpos[G];
         u64 cbit[G];
         {
@@ -618,6 +757,9 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
                 cbit[v] = ok ? (avail & (0ull - avail)) : 0ull;
                 if (ok) n_round = (u32)v + 1u;
                 else ended = true;
+#if R4_OPT & 16
+                if (ok && (mh & 4u) == 0) ++n_round_a;
+#endif
             }
         }
         if (leader) { ++st_rounds; st_round_tasks += n_round; }
@@ -639,9 +781,19 @@ __global__ __launch_bounds__(64 * (G + 3)) void k_resolve4(ResolveArgs a) {
                 my_ring[(ncommit + lane) & 63u] = make_uint4(crv.y, node, (tin + lane) | 0x100u, 0u);
             }
             ncommit += n_round;
+#if R4_OPT & 16
+            la_count -= n_round_a;
+            // picks came from h+1: once level h is exhausted for everybody, advance the hot level (as k_resolve3 does on a B pick)
+            if (n_round_a != n_round && la_count == 0 && h + 3u <= (1u << NB) - 1u) {
+                fold();
+                derive_masks(h + 1);
+            }
+#else
             la_count -= n_round;
+#endif
             tin += n_round;
             j += n_round;
+#endif
         } else {
             // ---------------- task j is not simple: k_resolve3's full iteration, redundantly on every replica ----------------
             const u32 slot0 = base_slot + tin;

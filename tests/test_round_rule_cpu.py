@@ -117,3 +117,23 @@ def test_round_rule_is_conservative_not_lossy():
     masks = [1 << 3, (1 << 3) | (1 << 70)]
     assert sequential_prefix(hot2, 0, masks) == [3, 70]
     assert round_rule(hot2, 0, masks, 2) == [3]
+
+
+@pytest.mark.parametrize("drive", ["today", "opt8", "b", "b8"])
+def test_workload_model_agrees_with_every_round_rule(drive):
+    """tools/sim_rounds.py drives a whole synthetic batch (levels, hot-level tracking, windows, touched set, freshness
+    re-checks as in k_resolve3) round by round and asserts that every task a round commits is the plain pick the
+    sequential order makes — for today's rule, with touched flags in the record (R4_OPT=8), with h+1 picks inside rounds
+    (R4_OPT=16) and with both."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sim_rounds
+    from swarmkit_amd import synth
+    for name, T, N, order in (("cfg3", 6000, 600, "rr"), ("cfg3", 4000, 300, "major"), ("cfg2", 5000, 200, "rr")):
+        wl = synth.Workload(name, T=T, N=N, order=order)
+        m = sim_rounds.Model(wl, 0, 4, opt8=drive in ("opt8", "b8"), with_b=drive in ("b", "b8"))
+        m.with_none = drive == "b8"   # R4_OPT=32 on top: tasks without any feasible node pass through the round
+        st = m.run()   # asserts inside
+        assert st["A"] + st["B"] + st["generic"] >= T - st["unplaced"] - 5
+        assert st["round_tasks"] <= T
