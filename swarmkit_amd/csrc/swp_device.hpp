@@ -23,62 +23,9 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "swp_types.hpp"
+
 namespace swpdev {
-
-typedef unsigned long long u64;
-typedef long long i64;
-typedef uint32_t u32;
-
-#define DEV_VALID 0x80000000u   // node slot is present in the nodeSet
-
-// mirror of SWP_NODE_* (include/swp.h)
-#define NF_READY 0x001u
-#define NF_HAS_DESC 0x002u
-#define NF_HAS_PLATFORM 0x004u
-#define NF_HAS_ENGINE 0x008u
-#define NF_HAS_LABELS 0x010u
-#define NF_HAS_ELABELS 0x020u
-#define NF_MANAGER 0x040u
-#define NF_HAS_LOGPLUG 0x080u
-#define NF_IP_VALID 0x100u
-#define NF_IP_V4 0x200u
-
-// RTask.flags
-#define RT_RES 0x1u        // resource filter enabled
-#define RT_PORTS 0x2u      // host-port filter enabled
-#define RT_MAXREP 0x4u     // max-replicas filter enabled
-#define RT_UNCOUNTED 0x8u  // DesiredState > COMPLETED: placement does not bump the task counts
-
-#define LIST_EMPTY 0xFFFFFFFFu
-#define KEY_NONE 0xFFFFFFFFFFFFFFFFull
-#define MAX_FAILURES 5u   // scheduler.go:23
-
-struct RTask {   // 64 B per task, batch order
-    i64 cpu, mem;
-    u32 flags;
-    u32 sc;        // static class (ready & plugin & constraint & platform bitmap row)
-    u32 svc;       // batch-local service index
-    u32 slot;      // absolute index of this task's own entry in the per-service exception list
-    u32 pset;      // batch-local port set
-    u32 cls_con, cls_plat, cls_plug;   // batch-local class rows (0 = filter disabled) — explain pass
-    u64 maxrep;
-    u32 pad[2];
-};
-static_assert(sizeof(RTask) == 64, "RTask layout");
-
-struct DevConstraint {   // 48 B
-    u32 kind, op, col, value;
-    u32 ip[4];
-    u32 ip_kind, prefix_len, ip_is_v4, pad;
-};
-
-struct Ctl {
-    u32 ncommit, ninf, error, resume;   // resume: first task NOT processed when `error` stopped a resolver (host continues from there)
-    u64 verify_retries, slow_tasks, rebases, generic_tasks, spin_waits, pad1;
-    u64 cyc[8];   // dbg&16: cycles spent in resolver sections
-};
-
-enum { ERR_NONE = 0, ERR_LEVEL_RANGE = 1, ERR_GROUP_RANGE = 2 };
 
 // Uniform (wave-invariant) read-only loads go through the constant address space so that the
 // backend emits s_load (scalar cache) instead of 64 identical vector loads.
@@ -333,36 +280,6 @@ __global__ __launch_bounds__(64) void k_scan(ScanArgs a) {
 //   touched-since-scan bitmap. argmin(level, index) over a candidate word is the classic
 //   bit-sliced minimum: NB AND/ANDN steps, no data-dependent loop.
 // ---------------------------------------------------------------------------------------------
-struct ResolveArgs {
-    u32 n_nodes, n_words;
-    u32 j0, count;
-    u32 nb_alloc;            // planes that fit in LDS
-    u32 dbg;                 // timing experiments only (env SWP_DBG); 0 in production
-    u32 xs;                  // row stride of X in words
-    u32 tb;                  // k_resolve2: tasks per staged block
-    const u64* F;            // [count][n_words] for this window
-    const u64* valid;        // [n_words]
-    u64* X;                  // [n_svc][n_words]
-    const RTask* rt;
-    i64* cpu;
-    i64* mem;
-    u32* total;
-    u32* list_node;
-    u32* list_svc;
-    u32* list_fail;
-    const u32* list_off;     // [n_svc+1]
-    u64* portmap;
-    const u32* pset_off;
-    const u32* pset_ids;
-    int32_t* out_node;       // [T]
-    u32* log_node;
-    u32* log_task;
-    int32_t* log_prev;
-    int32_t* last;           // [n_nodes]
-    u32* inf_task;
-    u32* inf_pos;
-    Ctl* ctl;
-};
 
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
 #pragma unroll
@@ -2545,7 +2462,6 @@ __global__ __launch_bounds__(256) void k_resolve3(ResolveArgs a) {
     }
 }
 
-#include "swp_resolve4.hpp"   // k_resolve4: G replicated resolver waves, speculative rounds (experimental, SWP_RESOLVER=4)
 
 // ---------------------------------------------------------------------------------------------
 // k_explain — per-filter first-failure histogram for every task that found no node, evaluated
@@ -3253,6 +3169,20 @@ __global__ __launch_bounds__(G_THREADS) void k_groups(GroupArgs a) {
 // k_commit — NodeInfo.addTask / removeTask arithmetic for placements decided outside the engine
 // (nodeinfo.go:66-154). Several placements may hit one node: integer atomics commute.
 // ---------------------------------------------------------------------------------------------
+// Residuals in the batch's resource units for k_resolve5: floor division, so that need <= residual <=> need/unit <= q for
+// every need that is a multiple of the unit (a negative residual fits nothing, not even a zero reservation: filter.go:78-84).
+__global__ void k_units(u32 n, const i64* __restrict__ cpu, const i64* __restrict__ mem, i64 uc, i64 um, int32_t* __restrict__ q) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto fd = [](i64 a, i64 b) {
+        i64 d = a / b;
+        if (a % b != 0 && a < 0) --d;
+        return d < -(1ll << 30) ? -(1ll << 30) : d > (1ll << 30) ? (1ll << 30) : d;   // present nodes are range-checked by the host
+    };
+    q[2 * i] = (int32_t)fd(cpu[i], uc);
+    q[2 * i + 1] = (int32_t)fd(mem[i], um);
+}
+
 struct DevPlacement { u32 node; u32 counted; i64 cpu, mem; };
 
 __global__ void k_commit(u32 n, const DevPlacement* __restrict__ p, int add, i64* cpu, i64* mem, u32* total) {

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <numeric>
 #include <memory>
 #include <set>
 #include <string>
@@ -20,8 +22,20 @@
 
 #include "../../include/swp.h"
 #include "swp_device.hpp"
+#include "swp_launch.hpp"
 
 using namespace swpdev;
+
+hipError_t swpdev::ensure_big_lds(const void* fn, int device) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, device})) return hipSuccess;
+    hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (r == hipSuccess) done.insert({fn, device});
+    return r;
+}
+
 
 namespace {
 
@@ -129,12 +143,15 @@ struct swp_batch {
     uint32_t n_con = 0, n_plat = 0, n_plug = 0, n_sc = 0, n_svc = 0, n_ports = 0;
     uint32_t window = 0, n_windows = 0;
     bool ran = false;
+    int64_t unit_cpu = 1, unit_mem = 1;   // k_resolve5: gcd of the batch's reservations (RTask.kc / km count these units)
+    bool units_ok = false;                // every reservation fits 2^30 units
 
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
     DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
     DevBuf d_con, d_plat, d_plug, d_sc, d_F, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
+    DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
 };
 
 struct swp_engine {
@@ -397,6 +414,24 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         task_rank[i] = svc_ntasks[r.svc];
         svc_ntasks[r.svc] += weights ? weights[i] : 1u;
     }
+    // resource units of the round resolver: residual fits(need) <=> need/unit <= floor(residual/unit) when every need is a
+    // multiple of the unit, so the kernel can keep exact residuals as 32-bit counts in LDS
+    {
+        int64_t gc = 0, gm = 0;
+        for (uint32_t i = 0; i < T; ++i) {
+            gc = std::gcd(gc, b->rt[i].cpu);
+            gm = std::gcd(gm, b->rt[i].mem);
+        }
+        b->unit_cpu = gc ? gc : 1;
+        b->unit_mem = gm ? gm : 1;
+        b->units_ok = true;
+        for (uint32_t i = 0; i < T; ++i) {
+            const int64_t kc = b->rt[i].cpu / b->unit_cpu, km = b->rt[i].mem / b->unit_mem;
+            if (kc >= R5_QLIM_HOST || km >= R5_QLIM_HOST) { b->units_ok = false; break; }
+            b->rt[i].kc = (uint32_t)kc;
+            b->rt[i].km = (uint32_t)km;
+        }
+    }
     b->n_svc = (uint32_t)b->svc_global.size();
     b->n_sc = (uint32_t)b->triples.size();
     b->n_con = (uint32_t)con_ids.size();
@@ -564,67 +599,44 @@ int upload_batch(swp_engine* e, swp_batch* b) {
 }
 
 template <int K, int D>
-hipError_t launch_resolve1(const ResolveArgs& ra, size_t lds, hipStream_t s) {
+hipError_t launch_resolve1(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
     (void)lds;
     size_t need = (size_t)ra.n_nodes * 4 + 64;   // last commit per node
-    static size_t attr_bytes = 0;
-    if (need > 64 * 1024 && need > attr_bytes) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve1<K, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (need > 64 * 1024) {
+        hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve1<K, D>), dev);
         if (r != hipSuccess) return r;
-        attr_bytes = 160 * 1024 - 512;
     }
     hipLaunchKernelGGL((k_resolve1<K, D>), dim3(1), dim3(64), need, s, ra);
     return hipGetLastError();
 }
 
 template <int K, bool PROF>
-hipError_t launch_resolve2p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve2<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        if (r != hipSuccess) return r;
-        attr_set = true;
-    }
+hipError_t launch_resolve2p(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
+    hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve2<K, PROF>), dev);
+    if (r != hipSuccess) return r;
     hipLaunchKernelGGL((k_resolve2<K, PROF>), dim3(1), dim3(128), lds, s, ra);
     return hipGetLastError();
 }
 template <int K>
-hipError_t launch_resolve2(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    return (ra.dbg & 16u) ? launch_resolve2p<K, true>(ra, lds, s) : launch_resolve2p<K, false>(ra, lds, s);
+hipError_t launch_resolve2(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
+    return (ra.dbg & 16u) ? launch_resolve2p<K, true>(ra, lds, s, dev) : launch_resolve2p<K, false>(ra, lds, s, dev);
 }
 
 template <int K, bool PROF>
-hipError_t launch_resolve3p(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve3<K, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        if (r != hipSuccess) return r;
-        attr_set = true;
-    }
+hipError_t launch_resolve3p(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
+    hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve3<K, PROF>), dev);
+    if (r != hipSuccess) return r;
     hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(256), lds, s, ra);
     return hipGetLastError();
 }
 template <int K>
-hipError_t launch_resolve3(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    return (ra.dbg & 16u) ? launch_resolve3p<K, true>(ra, lds, s) : launch_resolve3p<K, false>(ra, lds, s);
-}
-
-constexpr int R4_G = 4;   // resolver replicas of k_resolve4
-template <int K>
-hipError_t launch_resolve4(const ResolveArgs& ra, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve4<K, R4_G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        if (r != hipSuccess) return r;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_resolve4<K, R4_G>), dim3(1), dim3(64 * (R4_G + 3)), lds, s, ra);
-    return hipGetLastError();
+hipError_t launch_resolve3(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
+    return (ra.dbg & 16u) ? launch_resolve3p<K, true>(ra, lds, s, dev) : launch_resolve3p<K, false>(ra, lds, s, dev);
 }
 
 template <int K>
-hipError_t launch_resolve(const ResolveArgs& ra, uint32_t threads, size_t lds, hipStream_t s) {
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_resolve(const ResolveArgs& ra, uint32_t threads, size_t lds, hipStream_t s, int dev) {
+    hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve<K>), dev);
     if (r != hipSuccess) return r;
     hipLaunchKernelGGL(k_resolve<K>, dim3(1), dim3(threads), lds, s, ra);
     return hipGetLastError();
@@ -701,22 +713,26 @@ int batch_run(swp_engine* e, swp_batch* b) {
     const char* env_res = getenv("SWP_RESOLVER");
     const char* env_dbg = getenv("SWP_DBG");
     const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
-    int variant = env_res ? atoi(env_res) : 3;
+    int variant = env_res ? atoi(env_res) : 5;
     uint32_t r2_tb = 0;
     size_t r2_lds = 0;
-    if (variant == 4) {
-        // k_resolve4 (experimental, only on request): as k_resolve3 plus per-replica D / ring-fix rows, commit rings and records
-        const uint32_t K4 = (Wn + 63) / 64;
-        const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
-        const size_t row = (size_t)K4 * 64 * 8;
-        const size_t per_slot = row + 32;
-        const size_t fixed4 = off_f + row * (1 + 2 * R4_G) + (size_t)R4_G * 64 * 16 + 4 * R4_G * 8 + 32 + 128 + 64;
-        const size_t avail = lds_budget > fixed4 ? lds_budget - fixed4 : 0;
-        const size_t slots = avail / per_slot;
-        if (K4 <= 4 && slots >= 2 * 4) {
-            r2_tb = (uint32_t)std::min<size_t>(R2_TB_MAX, slots / 2);
-            r2_lds = fixed4 + (size_t)(2 * r2_tb) * per_slot;
-        } else variant = 3;
+    // k_resolve5 (round resolver, default): needs <= 64 * R5_KMAX node words, its LDS layout (planes, lists, exact residuals as
+    // 32-bit counts of the batch's resource units) and every residual / reservation below 2^30 units; else k_resolve3 and down
+    const size_t r5_lds = r5_lds_size(N, Wn);
+    if (variant == 5) {
+        bool ok = b->units_ok && r5_supports(Wn) && r5_lds <= lds_budget;
+        for (uint32_t n = 0; ok && n < N; ++n) {
+            const HostNode& h = e->nodes[n];
+            if (!h.present) continue;
+            const int64_t qc = h.row.cpu / b->unit_cpu, qm = h.row.mem / b->unit_mem;
+            if (qc >= R5_QLIM_HOST || qc <= -R5_QLIM_HOST || qm >= R5_QLIM_HOST || qm <= -R5_QLIM_HOST) ok = false;
+        }
+        if (!ok) variant = 3;
+    }
+    if (variant == 5) {
+        HIPCHECK(e, b->d_qres.reserve((size_t)N * 8));
+        hipLaunchKernelGGL(k_units, dim3((N + 255) / 256), dim3(256), 0, st, N, e->d_cpu.as<long long>(), e->d_mem.as<long long>(), (long long)b->unit_cpu,
+                           (long long)b->unit_mem, b->d_qres.as<int32_t>());
     }
     if (variant == 3) {
         // k_resolve3: staged mk rows padded to 64*K words, 2*TB+1 slots (+ records), one published BELOW row, flags
@@ -803,48 +819,44 @@ int batch_run(swp_engine* e, swp_batch* b) {
         ra.ctl = b->d_ctl.as<Ctl>();
         hipError_t r;
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
-        if (variant == 4) {
-            switch ((Wn + 63) / 64) {
-            case 1: r = launch_resolve4<1>(ra, r2_lds, st); break;
-            case 2: r = launch_resolve4<2>(ra, r2_lds, st); break;
-            case 3: r = launch_resolve4<3>(ra, r2_lds, st); break;
-            default: r = launch_resolve4<4>(ra, r2_lds, st); break;
-            }
+        if (variant == 5) {
+            ra.qres = b->d_qres.as<int32_t>();
+            r = launch_resolve5(ra, r5_lds, st, e->device);
         } else if (variant == 3) {
             switch ((Wn + 63) / 64) {
-            case 1: r = launch_resolve3<1>(ra, r2_lds, st); break;
-            case 2: r = launch_resolve3<2>(ra, r2_lds, st); break;
-            case 3: r = launch_resolve3<3>(ra, r2_lds, st); break;
-            case 4: r = launch_resolve3<4>(ra, r2_lds, st); break;
-            case 5: r = launch_resolve3<5>(ra, r2_lds, st); break;
-            case 6: r = launch_resolve3<6>(ra, r2_lds, st); break;
-            case 7: r = launch_resolve3<7>(ra, r2_lds, st); break;
-            default: r = launch_resolve3<8>(ra, r2_lds, st); break;
+            case 1: r = launch_resolve3<1>(ra, r2_lds, st, e->device); break;
+            case 2: r = launch_resolve3<2>(ra, r2_lds, st, e->device); break;
+            case 3: r = launch_resolve3<3>(ra, r2_lds, st, e->device); break;
+            case 4: r = launch_resolve3<4>(ra, r2_lds, st, e->device); break;
+            case 5: r = launch_resolve3<5>(ra, r2_lds, st, e->device); break;
+            case 6: r = launch_resolve3<6>(ra, r2_lds, st, e->device); break;
+            case 7: r = launch_resolve3<7>(ra, r2_lds, st, e->device); break;
+            default: r = launch_resolve3<8>(ra, r2_lds, st, e->device); break;
             }
         } else if (variant == 2) {
             const uint32_t K2 = (Wn + 63) / 64;
             switch (K2) {
-            case 1: r = launch_resolve2<1>(ra, r2_lds, st); break;
-            case 2: r = launch_resolve2<2>(ra, r2_lds, st); break;
-            case 3: r = launch_resolve2<3>(ra, r2_lds, st); break;
-            case 4: r = launch_resolve2<4>(ra, r2_lds, st); break;
-            default: r = launch_resolve2<8>(ra, r2_lds, st); break;
+            case 1: r = launch_resolve2<1>(ra, r2_lds, st, e->device); break;
+            case 2: r = launch_resolve2<2>(ra, r2_lds, st, e->device); break;
+            case 3: r = launch_resolve2<3>(ra, r2_lds, st, e->device); break;
+            case 4: r = launch_resolve2<4>(ra, r2_lds, st, e->device); break;
+            default: r = launch_resolve2<8>(ra, r2_lds, st, e->device); break;
             }
         } else if (variant == 1) {
             switch (K) {
-            case 1: r = launch_resolve1<1, 8>(ra, lds, st); break;
-            case 2: r = launch_resolve1<2, 8>(ra, lds, st); break;
-            case 3: r = launch_resolve1<3, 8>(ra, lds, st); break;
-            case 4: r = launch_resolve1<4, 8>(ra, lds, st); break;
-            default: r = launch_resolve1<8, 4>(ra, lds, st); break;
+            case 1: r = launch_resolve1<1, 8>(ra, lds, st, e->device); break;
+            case 2: r = launch_resolve1<2, 8>(ra, lds, st, e->device); break;
+            case 3: r = launch_resolve1<3, 8>(ra, lds, st, e->device); break;
+            case 4: r = launch_resolve1<4, 8>(ra, lds, st, e->device); break;
+            default: r = launch_resolve1<8, 4>(ra, lds, st, e->device); break;
             }
         } else
         switch (K) {
-        case 1: r = launch_resolve<1>(ra, threads, lds, st); break;
-        case 2: r = launch_resolve<2>(ra, threads, lds, st); break;
-        case 3: case 4: r = launch_resolve<4>(ra, threads, lds, st); break;
-        case 5: case 6: case 7: case 8: r = launch_resolve<8>(ra, threads, lds, st); break;
-        default: r = launch_resolve<16>(ra, threads, lds, st); break;
+        case 1: r = launch_resolve<1>(ra, threads, lds, st, e->device); break;
+        case 2: r = launch_resolve<2>(ra, threads, lds, st, e->device); break;
+        case 3: case 4: r = launch_resolve<4>(ra, threads, lds, st, e->device); break;
+        case 5: case 6: case 7: case 8: r = launch_resolve<8>(ra, threads, lds, st, e->device); break;
+        default: r = launch_resolve<16>(ra, threads, lds, st, e->device); break;
         }
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_resolve launch: %s", hipGetErrorString(r));
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
@@ -871,7 +883,6 @@ int batch_run(swp_engine* e, swp_batch* b) {
         HIPCHECK(e, hipStreamSynchronize(st));
     }
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
-    if (ctl.error == ERR_PROTOCOL) return e->fail(SWP_EHIP, "k_resolve4: a hand-shake between the resolver replicas timed out");
     if (ctl.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the level planes that fit in LDS");
     if (ctl.ninf) {
         ExplainArgs xa{};
@@ -960,7 +971,10 @@ int batch_run(swp_engine* e, swp_batch* b) {
     e->stats.rebase_events += ctl.rebases;
     e->stats.generic_tasks += ctl.generic_tasks;
     e->stats.resolver_spins += ctl.spin_waits;
-    if (dbg_bits & 16)
+    if ((dbg_bits & 16) && variant == 5)
+        fprintf(stderr, "[swp] k_resolve5: rounds %llu (full %llu, cut by class %llu, cut by an exhausted list %llu) | commits %u inf %u generic-path tasks %llu retries %llu\n",
+                ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.ncommit, ctl.ninf, ctl.generic_tasks, ctl.verify_retries);
+    else if (dbg_bits & 16)
         fprintf(stderr, "[swp] resolver cycles (100MHz ticks): wait %llu prep %llu pick %llu generic %llu commit %llu blockend %llu | commits %u inf %u generic %llu\n",
                 ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.cyc[4], ctl.cyc[5], ctl.ncommit, ctl.ninf, ctl.generic_tasks);
     if ((dbg_bits & 16) && ctl.cyc[7])
@@ -1431,11 +1445,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     ga.ff = d_ff.as<unsigned char>(); ga.svc_dense = d_svcd.as<uint32_t>(); ga.fail_dense = d_faild.as<uint32_t>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
     const size_t lds = (size_t)G_HCAP * (8 * 3 + 4 * 6) + (size_t)G_MAXT * (8 + 4 * 4 + 8) + (size_t)G_THREADS * (8 * 2 + 4 * 6) + (16 + 16 + 8) * 4 + (G_HCAP / 64) * 8 + G_LOG + 256;
-    static bool attr = false;
-    if (!attr) {
-        HIPCHECK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_groups), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-        attr = true;
-    }
+    HIPCHECK(e, ensure_big_lds(reinterpret_cast<const void*>(&k_groups), e->device));
     const bool gdbg = getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16);
     hipEvent_t gev0 = nullptr, gev1 = nullptr;
     if (gdbg) { (void)hipEventCreate(&gev0); (void)hipEventCreate(&gev1); (void)hipEventRecord(gev0, st); }

@@ -1,0 +1,20 @@
+// swp_launch.hpp — what the engine runtime (swp_engine.hip) and the resolver translation units share on the host side.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "swp_types.hpp"
+
+namespace swpdev {
+
+#define R5_QLIM_HOST (1ll << 30)   // residuals / reservations in resource units must stay below this (== R5_QLIM)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remembered per (kernel, device ordinal), so
+// that a process holding engines on several GPUs (a manager sharding over the node's 8 devices) raises the limit on each.
+hipError_t ensure_big_lds(const void* fn, int device);
+
+// k_resolve5 (swp_resolve5.hip)
+size_t r5_lds_size(uint32_t n_nodes, uint32_t n_words);
+bool r5_supports(uint32_t n_words);
+hipError_t launch_resolve5(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev);
+
+}  // namespace swpdev

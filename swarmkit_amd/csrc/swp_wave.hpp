@@ -1,0 +1,91 @@
+// swp_wave.hpp — the wave64 / workgroup primitives the round resolver (swp_resolve5.hpp) is written against, gfx950 build.
+//
+// The kernel source uses ONLY these wrappers for everything that is not plain C++ on registers and pointers
+// (cross-lane traffic, LDS / global atomics, barriers, uniform loads). tests/emu/wv_emu.hpp implements the same
+// interface on CPU fibers, so the kernel's control flow, indexing and protocol can be run against a sequential model
+// without a GPU (tests/test_emu_resolve5.py). That harness is test infrastructure: the product only ever builds this
+// header. Rule the kernel follows so that both agree: collectives (ballot, readlane, min, barrier) are only called
+// from wave-uniform control flow.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "swp_types.hpp"
+
+#define WV_DEV __device__ __forceinline__
+#define WV_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+
+namespace wv {
+using swpdev::i64;
+using swpdev::u32;
+using swpdev::u64;
+
+WV_DEV u32 tid() { return threadIdx.x; }
+WV_DEV u32 nthreads() { return blockDim.x; }
+WV_DEV u32 lane() { return threadIdx.x & 63u; }
+// wave index as a scalar (threadIdx.x >> 6 is uniform, the compiler does not always know)
+WV_DEV u32 wave() { return (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+WV_DEV u64* lds() {
+    extern __shared__ u64 wv_lds_[];
+    return wv_lds_;
+}
+
+WV_DEV u64 ballot(bool p) { return __ballot(p); }
+WV_DEV u32 readfirstlane(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+WV_DEV u32 readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+WV_DEV u64 readlane64(u64 v, u32 l) {
+    u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, (int)l);
+    u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), (int)l);
+    return ((u64)hi << 32) | lo;
+}
+// v with lane l replaced by the uniform value s
+WV_DEV u32 writelane(u32 v, u32 s, u32 l) { return (threadIdx.x & 63u) == l ? s : v; }   // v_cmp + v_cndmask (no builtin for v_writelane here)
+// number of set bits of `mask` that belong to lanes below this one
+WV_DEV u32 mbcnt(u64 mask) { return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u)); }
+
+template <int CTRL, int ROW_MASK = 0xf>
+WV_DEV u32 dpp_(u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false); }
+// min over the 64 lanes; every lane returns it (six DPP steps + one readlane)
+WV_DEV u32 min_u32(u32 v) {
+    v = min(v, dpp_<0x111>(v));
+    v = min(v, dpp_<0x112>(v));
+    v = min(v, dpp_<0x114>(v));
+    v = min(v, dpp_<0x118>(v));
+    v = min(v, dpp_<0x142, 0xa>(v));
+    v = min(v, dpp_<0x143, 0xc>(v));
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// workgroup barrier that orders LDS only: outstanding global loads / fire-and-forget atomics stay in flight
+WV_DEV void barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the wave's LDS operations issued so far are done before any lane goes on: what one lane wrote (or or-ed) is what another
+// lane of the same wave reads next. The hardware executes one wave's LDS instructions in order; this pins the compiler too.
+WV_DEV void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// this wave's global stores / atomics / loads have completed (what a later wave behind a barrier may rely on)
+WV_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- LDS atomics (no return value: nothing to wait for) ----
+WV_DEV void lds_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void lds_xor64(u64* p, u64 v) { __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void lds_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// ---- global memory ----
+WV_DEV void g_add64(i64* p, i64 v) { __hip_atomic_fetch_add(reinterpret_cast<u64*>(p), (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV void g_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV void g_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV u32 g_exch32(u32* p, u32 v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// loads that must see what other waves of this workgroup wrote through L2 (bypass the CU's vector L1)
+WV_DEV u64 g_fresh64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV u32 g_fresh32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV i64 g_fresh64s(const i64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV void g_store32_fresh(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// wave-uniform read-only load: constant address space → s_load through the scalar cache
+template <class T>
+WV_DEV T uload(const T* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+
+WV_DEV int ffs64(u64 v) { return __ffsll((long long)v) - 1; }   // index of the lowest set bit (v != 0)
+WV_DEV int popc64(u64 v) { return __popcll(v); }
+
+}  // namespace wv

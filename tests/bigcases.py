@@ -1,0 +1,133 @@
+"""BASELINE-size event scripts shared by the offline digest generator (tests/golden/make_golden_big.py, CPU oracle)
+and the GPU parity tests (tests/test_engine_bigcases.py, HIP engine behind the host scheduler layer).
+
+Every script drives a scheduler object through the reference's event-handler names (create_node / update_node /
+set_service / create_task / delete_task / tick — orc.Oracle and swarmkit_amd.host.HostScheduler expose the same
+methods) and folds every tick's decisions into SHA-256 digests, so both sides run EXACTLY the same protocol.
+
+  cfg4_full     BASELINE.json configs[3]: 1M one-off tasks x 100k nodes, every filter (synth cfg4)
+  cfg5_churn    BASELINE.json configs[4]: 100k tasks x 10k nodes placed, then 100 rounds of {reactivate the previous
+                round's drained nodes, drain 10 % of the nodes, delete the tasks on them, create as many new tasks, tick}
+  refbench_*    the reference's own benchmark shape, benchScheduler (manager/scheduler/scheduler_test.go:3375-3465,
+                sizes :3335-3373): tasks WITHOUT ServiceID / SpecVersion (one service "" for every task), nodes with an
+                empty Engine description, every third node advertising the Network plugin "network", optionally every
+                task attached to a network with that driver
+"""
+import hashlib
+
+from swarmkit_amd import synth
+
+READY, RUNNING, PENDING, ASSIGNED = 2, 512, 64, 192
+
+
+def tick_digest(decisions):
+    """(sha256 over the sorted decision lines, number of assigned tasks)."""
+    lines = sorted("%s|%s|%s|%d" % (d["ID"], d["NodeID"], d["Err"], d["State"]) for d in decisions)
+    h = hashlib.sha256("\n".join(lines).encode()).hexdigest()
+    return h, sum(1 for d in decisions if d["NodeID"] and d["State"] >= ASSIGNED)
+
+
+# ------------------------------------------------------------------------------------------------ cfg4
+def run_cfg4(s, T=None, N=None):
+    wl = synth.Workload("cfg4", T=T, N=N)
+    for i in range(wl.N):
+        s.create_node(wl.node_doc(i))
+    for k in range(wl.S):
+        s.set_service(wl.service_id(k))
+    for j in range(wl.T):
+        s.create_task(wl.task_doc(j))
+    h, placed = tick_digest(s.tick())
+    return {"case": "cfg4", "T": wl.T, "N": wl.N, "seed": hex(wl.seed), "ticks": [h], "placed": [placed]}
+
+
+# ------------------------------------------------------------------------------------------------ cfg5
+def churn_drained(N, rnd):
+    """10 % of the nodes, a different residue class every round (deterministic, no PRNG state to carry)."""
+    return [i for i in range(N) if (i * 7 + rnd * 13) % 10 == 0]
+
+
+def run_churn(s, T0=100_000, N=10_000, rounds=100, services=1000):
+    total = T0 + rounds * (N // 10) * 12   # upper bound on the tasks ever created
+    wl = synth.Workload("cfg3", T=total, N=N, services=services)
+    for i in range(N):
+        s.create_node(wl.node_doc(i))
+    for k in range(wl.S):
+        s.set_service(wl.service_id(k))
+    for j in range(T0):
+        s.create_task(wl.task_doc(j))
+    placed = {}          # task index -> node index
+    by_node = [[] for _ in range(N)]
+    ticks, counts = [], []
+
+    def do_tick():
+        dec = s.tick()
+        h, c = tick_digest(dec)
+        ticks.append(h)
+        counts.append(c)
+        for d in dec:
+            if d["NodeID"] and d["State"] >= ASSIGNED:
+                j, n = int(d["ID"][1:]), int(d["NodeID"][1:])
+                placed[j] = n
+                by_node[n].append(j)
+
+    do_tick()
+    nxt, prev = T0, []
+    for rnd in range(rounds):
+        drained = churn_drained(N, rnd)
+        for i in prev:
+            s.update_node(wl.node_doc(i))
+        for i in drained:
+            doc = wl.node_doc(i)
+            doc["Spec"] = dict(doc["Spec"], Availability=2)   # DRAIN
+            s.update_node(doc)
+        gone = []
+        for i in drained:
+            gone.extend(by_node[i])
+            by_node[i] = []
+        gone.sort()
+        for j in gone:
+            s.delete_task(dict(wl.task_doc(j), NodeID=wl.node_id(placed[j]), Status={"State": RUNNING}))
+            del placed[j]
+        for _ in range(len(gone)):
+            s.create_task(wl.task_doc(nxt))
+            nxt += 1
+        do_tick()
+        prev = drained
+    return {"case": "cfg5_churn", "T0": T0, "N": N, "rounds": rounds, "services": services, "seed": hex(wl.seed), "created": nxt,
+            "ticks": ticks, "placed": counts, "still_placed": len(placed)}
+
+
+# ------------------------------------------------------------------------------------------------ benchScheduler
+def ref_node(i):
+    eng = {"Plugins": [{"Name": "network", "Type": "Network"}]} if i % 3 == 0 else {}
+    return {"ID": "n%08d" % i, "Spec": {"Annotations": {"Name": "name%d" % i, "Labels": {}}}, "Status": {"State": READY},
+            "Description": {"Engine": eng}}
+
+
+def ref_task(i, net):
+    t = {"ID": "task%d" % i, "DesiredState": RUNNING, "ServiceAnnotations": {"Name": "task%d" % i}, "Status": {"State": PENDING}}
+    if net:
+        t["Networks"] = [{"Network": {"DriverState": {"Name": "network"}}}]
+    return t
+
+
+def run_refbench(s, nodes, tasks, net):
+    for i in range(nodes):
+        s.create_node(ref_node(i))
+    s.set_service("")   # the harness' stand-in for "the task's service lookup succeeds"; never consulted: every task is placed
+    for i in range(tasks):
+        s.create_task(ref_task(i, net))
+    h, placed = tick_digest(s.tick())
+    return {"case": "refbench", "nodes": nodes, "tasks": tasks, "net": bool(net), "ticks": [h], "placed": [placed]}
+
+
+CASES = {
+    "cfg4_full": lambda s: run_cfg4(s),
+    "cfg4_mid": lambda s: run_cfg4(s, T=200_000, N=40_000),
+    "cfg5_churn": lambda s: run_churn(s),
+    "cfg5_churn_small": lambda s: run_churn(s, T0=5_000, N=500, rounds=12, services=50),
+    "refbench_1k_100k": lambda s: run_refbench(s, 1_000, 100_000, False),
+    "refbench_net_5k_100k": lambda s: run_refbench(s, 5_000, 100_000, True),
+    "refbench_100k_100k": lambda s: run_refbench(s, 100_000, 100_000, False),
+    "refbench_small": lambda s: run_refbench(s, 100, 3_000, True),
+}

@@ -1,0 +1,249 @@
+// wv_emu.hpp — CPU implementation of the wave / workgroup primitives of swarmkit_amd/csrc/swp_wave.hpp.
+//
+// TEST INFRASTRUCTURE. One workgroup is run as cooperative fibers (ucontext), one per thread; a collective (ballot,
+// readlane, min, wave_sync, barrier) parks the calling fiber until all 64 lanes of its wave (all threads of the
+// workgroup for a barrier) have arrived at the SAME collective, then the last arriver computes the result and releases
+// the others. That is enough to run the round resolver's source (swp_resolve5.hpp) unchanged and check its control
+// flow, indexing and hand-shakes against a sequential model — not its timing, and not memory-ordering hazards between
+// waves (fibers switch only at collectives). The product never includes this file.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+
+#include <algorithm>
+#include <deque>
+#include <functional>
+#include <vector>
+
+#define __host__
+#define __device__
+#define WV_DEV inline
+#define WV_KERNEL(bounds)
+
+#include "../../swarmkit_amd/csrc/swp_types.hpp"
+
+using std::max;
+using std::min;
+
+namespace emu {
+using swpdev::u32;
+using swpdev::u64;
+
+enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_READFIRST, OP_MIN, OP_SYNC, OP_BARRIER };
+
+// Minimal x86-64 System V context switch (callee-saved registers + stack pointer). glibc's swapcontext makes a
+// sigprocmask system call per switch, and a run makes tens of millions of switches.
+struct Ctx { void* sp = nullptr; };
+extern "C" void emu_switch(Ctx* from, Ctx* to);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
+
+struct Fiber {
+    Ctx ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+struct WaveSync {
+    int arrived = 0;
+    int op = OP_NONE;
+    u64 vals[64];
+    u64 aux = 0;
+    u64 result[64];
+};
+
+struct Block {
+    u32 nthreads = 0;
+    std::vector<Fiber> fib;
+    std::vector<WaveSync> waves;
+    int bar_arrived = 0;
+    std::deque<u32> runq;
+    std::vector<u64> lds;
+    std::function<void()> body;
+    Ctx sched;
+    u32 cur = 0;
+    u64 switches = 0;
+};
+inline Block*& B() {
+    static Block* b = nullptr;
+    return b;
+}
+
+inline void yield_blocked() {   // park the current fiber; somebody else re-queues it
+    Block* b = B();
+    b->switches++;
+    emu_switch(&b->fib[b->cur].ctx, &b->sched);
+}
+
+inline void fiber_main() {
+    Block* b = B();
+    b->body();
+    b->fib[b->cur].done = true;
+    emu_switch(&b->fib[b->cur].ctx, &b->sched);
+    abort();   // a finished fiber is never resumed
+}
+
+// run one workgroup of `nthreads` threads with `lds_bytes` of dynamic LDS
+inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
+    Block blk;
+    B() = &blk;
+    blk.nthreads = nthreads;
+    blk.fib.resize(nthreads);
+    blk.waves.resize((nthreads + 63) / 64);
+    blk.lds.assign((lds_bytes + 7) / 8 + 8, 0xCDCDCDCDCDCDCDCDull);   // LDS is NOT zero-initialised on the device either
+    blk.body = body;
+    const size_t STK = 256 * 1024;
+    char* stacks = (char*)mmap(nullptr, STK * nthreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == MAP_FAILED) { perror("mmap"); abort(); }
+    for (u32 t = 0; t < nthreads; ++t) {
+        Fiber& f = blk.fib[t];
+        f.stack = stacks + STK * t;
+        // initial frame: six zeroed callee-saved registers, then the entry point as the return address; the stack is
+        // 16-byte aligned + 8 at function entry, as after a call
+        void** sp = reinterpret_cast<void**>(f.stack + STK - 64);
+        *--sp = nullptr;                       // fake return address of fiber_main (never used)
+        *--sp = (void*)fiber_main;
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        f.ctx.sp = sp;
+        blk.runq.push_back(t);
+    }
+    u32 alive = nthreads;
+    while (alive) {
+        if (blk.runq.empty()) {
+            fprintf(stderr, "emu: DEADLOCK — %u threads alive, none runnable\n", alive);
+            for (size_t w = 0; w < blk.waves.size(); ++w)
+                fprintf(stderr, "  wave %zu: %d lanes waiting in op %d\n", w, blk.waves[w].arrived, blk.waves[w].op);
+            fprintf(stderr, "  barrier: %d arrived\n", blk.bar_arrived);
+            abort();
+        }
+        blk.cur = blk.runq.front();
+        blk.runq.pop_front();
+        emu_switch(&blk.sched, &blk.fib[blk.cur].ctx);
+        if (blk.fib[blk.cur].done) --alive;
+    }
+    munmap(stacks, STK * nthreads);
+    B() = nullptr;
+}
+
+// wave collective: every lane contributes `v` (and the uniform `aux`); returns this lane's result
+inline u64 collective(int op, u64 v, u64 aux) {
+    Block* b = B();
+    const u32 t = b->cur, lane = t & 63, wave = t >> 6;
+    WaveSync& ws = b->waves[wave];
+    const u32 lanes = std::min<u32>(64, b->nthreads - wave * 64);
+    if (ws.arrived == 0) { ws.op = op; ws.aux = aux; }
+    if (ws.op != op || ws.aux != aux) {
+        fprintf(stderr, "emu: wave %u diverged at a collective: lane %u calls op %d (aux %llu) while others wait in op %d (aux %llu)\n", wave, lane, op,
+                (unsigned long long)aux, ws.op, (unsigned long long)ws.aux);
+        abort();
+    }
+    ws.vals[lane] = v;
+    if (++ws.arrived < (int)lanes) {
+        yield_blocked();
+        return ws.result[lane];
+    }
+    // last arriver computes
+    switch (op) {
+    case OP_BALLOT: {
+        u64 m = 0;
+        for (u32 l = 0; l < lanes; ++l)
+            if (ws.vals[l]) m |= 1ull << l;
+        for (u32 l = 0; l < lanes; ++l) ws.result[l] = m;
+        break;
+    }
+    case OP_READLANE:
+        for (u32 l = 0; l < lanes; ++l) ws.result[l] = ws.vals[aux & 63];
+        break;
+    case OP_READFIRST:
+        for (u32 l = 0; l < lanes; ++l) ws.result[l] = ws.vals[0];
+        break;
+    case OP_MIN: {
+        u64 m = ~0ull;
+        for (u32 l = 0; l < lanes; ++l) m = std::min(m, ws.vals[l]);
+        for (u32 l = 0; l < lanes; ++l) ws.result[l] = m;
+        break;
+    }
+    default:
+        break;
+    }
+    ws.arrived = 0;
+    ws.op = OP_NONE;
+    for (u32 l = 0; l < lanes; ++l)
+        if (wave * 64 + l != t) b->runq.push_back(wave * 64 + l);
+    return ws.result[lane];
+}
+
+inline void block_barrier() {
+    Block* b = B();
+    if (++b->bar_arrived < (int)b->nthreads) {
+        yield_blocked();
+        return;
+    }
+    b->bar_arrived = 0;
+    for (u32 t = 0; t < b->nthreads; ++t)
+        if (t != b->cur) b->runq.push_back(t);
+}
+}  // namespace emu
+
+namespace wv {
+using swpdev::i64;
+using swpdev::u32;
+using swpdev::u64;
+
+inline u32 tid() { return emu::B()->cur; }
+inline u32 nthreads() { return emu::B()->nthreads; }
+inline u32 lane() { return emu::B()->cur & 63u; }
+inline u32 wave() { return emu::B()->cur >> 6; }
+inline u64* lds() { return emu::B()->lds.data(); }
+
+inline u64 ballot(bool p) { return emu::collective(emu::OP_BALLOT, p ? 1 : 0, 0); }
+inline u32 readfirstlane(u32 v) { return (u32)emu::collective(emu::OP_READFIRST, v, 0); }
+inline u32 readlane(u32 v, u32 l) { return (u32)emu::collective(emu::OP_READLANE, v, l); }
+inline u64 readlane64(u64 v, u32 l) { return emu::collective(emu::OP_READLANE, v, l); }
+inline u32 writelane(u32 v, u32 s, u32 l) { return lane() == l ? s : v; }
+inline u32 mbcnt(u64 mask) { return (u32)__builtin_popcountll(mask & ((1ull << lane()) - 1ull)); }
+inline u32 min_u32(u32 v) { return (u32)emu::collective(emu::OP_MIN, v, 0); }
+inline void barrier() { emu::block_barrier(); }
+inline void wave_sync() { (void)emu::collective(emu::OP_SYNC, 0, 0); }
+inline void wait_vm() {}
+
+inline void lds_or64(u64* p, u64 v) { *p |= v; }
+inline void lds_xor64(u64* p, u64 v) { *p ^= v; }
+inline void lds_andn64(u64* p, u64 v) { *p &= ~v; }
+
+inline void g_add64(i64* p, i64 v) { *p += v; }
+inline void g_add32(u32* p, u32 v) { *p += v; }
+inline void g_or64(u64* p, u64 v) { *p |= v; }
+inline u32 g_exch32(u32* p, u32 v) { u32 o = *p; *p = v; return o; }
+inline u64 g_fresh64(const u64* p) { return *p; }
+inline u32 g_fresh32(const u32* p) { return *p; }
+inline i64 g_fresh64s(const i64* p) { return *p; }
+inline void g_store32_fresh(u32* p, u32 v) { *p = v; }
+template <class T>
+inline T uload(const T* p) { return *p; }
+
+inline int ffs64(u64 v) { return __builtin_ffsll((long long)v) - 1; }
+inline int popc64(u64 v) { return __builtin_popcountll(v); }
+}  // namespace wv

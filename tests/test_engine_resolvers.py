@@ -1,5 +1,6 @@
-"""GPU parity across the resolver kernels and their geometries: every variant (workgroup, one-wave, two-wave,
-two-wave specialised) and every owned-words-per-lane count K must reproduce the oracle bit for bit."""
+"""GPU parity across the resolver kernels and their geometries: every variant (0 workgroup, 1 one-wave, 2 two-wave,
+3 two-wave specialised, 5 round resolver = the default) and every owned-words-per-lane count K must reproduce the oracle
+bit for bit."""
 import os
 
 import pytest
@@ -21,14 +22,7 @@ def resolver_env():
 
 
 CASES = [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg1", 500, 40, {}), ("cfg2", 3000, 50, {})]
-# k_resolve4 (speculative rounds over replicated resolver waves) is opt-in (SWP_RESOLVER=4): its parity cases passed on an
-# MI355X in the one run the round had left for it, but the kernel is not the default (slower than k_resolve3 so far) and
-# one run says little about a lock-free LDS protocol, so the cases stay out of the default suite: SWP_TEST_R4=1 adds them.
-R4 = [4] if os.environ.get("SWP_TEST_R4") else []
-BASE = [] if os.environ.get("SWP_TEST_R4") == "only" else None   # SWP_TEST_R4=only: just the k_resolve4 cases
-
-
-@pytest.mark.parametrize("variant", ([0, 1, 2, 3] if BASE is None else BASE) + R4)
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
 @pytest.mark.parametrize("name,T,N,kw", CASES)
 def test_variants_agree_with_oracle(resolver_env, variant, name, T, N, kw):
     wl = synth.Workload(name, T=T, N=N, **kw)
@@ -48,7 +42,7 @@ def test_words_per_lane(N):
     pu.assert_same(op, oe, ep, ee)
 
 
-@pytest.mark.parametrize("variant", ([2, 3] if BASE is None else BASE) + R4)
+@pytest.mark.parametrize("variant", [2, 3, 5])
 @pytest.mark.parametrize("services,order", [(1, "rr"), (2, "rr"), (3, "major"), (40, "major"), (7, "rr")])
 def test_same_service_runs(resolver_env, variant, services, order):
     """Consecutive tasks of one service: every commit must be visible to the next task of that service although
