@@ -821,6 +821,8 @@ int batch_run(swp_engine* e, swp_batch* b) {
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
         if (variant == 5) {
             ra.qres = b->d_qres.as<int32_t>();
+            ra.unit_cpu = b->unit_cpu;
+            ra.unit_mem = b->unit_mem;
             r = launch_resolve5(ra, r5_lds, st, e->device);
         } else if (variant == 3) {
             switch ((Wn + 63) / 64) {
@@ -974,6 +976,21 @@ int batch_run(swp_engine* e, swp_batch* b) {
     if ((dbg_bits & 16) && variant == 5)
         fprintf(stderr, "[swp] k_resolve5: rounds %llu (full %llu, cut by class %llu, cut by an exhausted list %llu) | commits %u inf %u generic-path tasks %llu retries %llu\n",
                 ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.ncommit, ctl.ninf, ctl.generic_tasks, ctl.verify_retries);
+    if ((dbg_bits & 16) && variant == 5) {
+        auto lo = [](unsigned long long v) { return (double)(v & 0xFFFFFFFFull) * 64.0; };
+        auto hi = [](unsigned long long v) { return (double)(v >> 32) * 64.0; };
+        const double r = ctl.cyc[0] ? (double)ctl.cyc[0] : 1.0;
+        fprintf(stderr, "[swp] k_resolve5 shader cycles per round: wave0 match %.0f barrier1 %.0f commit %.0f barrier2 %.0f | wave1 list %.0f barrier1 %.0f idle %.0f barrier2 %.0f | cut/refill/generic %.0f\n",
+                lo(ctl.cyc[4]) / r, hi(ctl.cyc[4]) / r, lo(ctl.cyc[5]) / r, hi(ctl.cyc[5]) / r, lo(ctl.cyc[6]) / r, hi(ctl.cyc[6]) / r, lo(ctl.cyc[7]) / r,
+                hi(ctl.cyc[7]) / r, (double)ctl.pad1 * 64.0 / r);
+        fprintf(stderr, "[swp] k_resolve5 matcher per round (cycles): list load %.0f, matching loop %.0f of which inside the scalar loop %.0f over %.1f entries\n", (double)ctl.m_cyc[0] * 64.0 / r, (double)ctl.m_cyc[1] * 64.0 / r,
+                (double)ctl.m_cyc[2] * 64.0 / r, (double)ctl.m_cyc[3] / r);
+        fprintf(stderr, "[swp] k_resolve5 lister wave 1 per round (cycles): prologue %.0f | per 4 tasks: row wait %.0f, level search %.0f, entries %.0f, validation %.0f\n",
+                (double)ctl.l_cyc[0] * 64.0 / r, (double)ctl.l_cyc[1] * 64.0 / r, (double)ctl.l_cyc[2] * 64.0 / r, (double)ctl.l_cyc[3] * 64.0 / r, (double)ctl.l_cyc[4] * 64.0 / r);
+        fprintf(stderr, "[swp] k_resolve5 phase-1 work per wave and round (cycles):");
+        for (int w = 0; w < 16; ++w) fprintf(stderr, " %.0f", (double)ctl.wave_cyc[w] * 64.0 / r);
+        fprintf(stderr, "\n");
+    }
     else if (dbg_bits & 16)
         fprintf(stderr, "[swp] resolver cycles (100MHz ticks): wait %llu prep %llu pick %llu generic %llu commit %llu blockend %llu | commits %u inf %u generic %llu\n",
                 ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.cyc[4], ctl.cyc[5], ctl.ncommit, ctl.ninf, ctl.generic_tasks);

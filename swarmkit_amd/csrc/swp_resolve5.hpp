@@ -4,26 +4,31 @@
 //
 // Why rounds. A lone wavefront retires one instruction per ≈ 4 ns; k_resolve3 needs ≈ 85 per task and is the whole batch
 // time (0.38 µs per task). The work per task that is really sequential is tiny — "take the first candidate nobody before
-// you took" — while finding the candidates (157 words of F & ~X against the level planes at 10k nodes) is wide and
+// you took" — while finding the candidates (157 words of F & ~X against the node levels at 10k nodes) is wide and
 // independent of the other tasks of the round as long as every node is taken at most once per round. So:
 //
-//   lister waves 1..15  build, for each task of the NEXT round, a candidate list: the first R5_Q non-empty words of
+//   lister waves 1..14  build, for each task of the NEXT round, a candidate list: the first R5_Q non-empty words of
 //                       F & ~X restricted to the task's minimum level, in node order, each word validated against the
 //                       exact residuals (kept in LDS in the batch's resource units). One wave per task, 4 tasks per
-//                       wave and round; everything is word-parallel over the lanes {lane + 64k}.
+//                       wave and round; everything is word-parallel over the lanes {lane + 64k}. Levels come from a
+//                       ring of R5_J per-level node masks in LDS (the levels where the picks happen) and, for anything
+//                       below or above the ring, from the bit-planes of all levels.
 //   wave 0 (matcher)    walks the CURRENT round's tasks in order on the scalar unit: task i takes the lowest candidate
-//                       bit of its current word and the bit is struck from every lane that sits on the same word
-//                       (one v_cmp + two v_cndmask per task) — 12 instructions per task instead of 85. Then commits the
-//                       round lane-parallel (planes, residuals, X, exception list, commit log: fire-and-forget).
+//                       bit of its current word and the bit is struck from every lane that sits on the same word.
+//                       Then it applies the round to the LDS state (planes, ring, residuals) and leaves a hand-over record.
+//   wave 15 (committer) applies the memory side effects of the PREVIOUS round from that record while the next round is
+//                       matched: residual update of the node row, task count, X row, exception list, commit log and its
+//                       per-node chain, placement. Nothing on the matcher's path ever waits for memory.
 //
 // Exactness (the list rule). Inside a batch a node's level only grows and feasibility only shrinks. A task's list holds
 // ALL its feasible plain nodes of its minimum level L in node order up to the last listed word; a node taken since the
 // list's snapshot (by the previous round, whose picks are in the TK rows, or by an earlier task of this round) moves to
 // level L+1 > L, so "first listed bit nobody took" is exactly the sequential argmin(level, index) — as long as the list
-// is not exhausted. An exhausted list, a task that must look at its service's exception list (no plain candidate, but
-// F & X ≠ 0), host ports, uncounted tasks: the round is CUT there, the tasks before it are committed, and that one task
-// runs the generic workgroup path (r5_generic: k_resolve's algorithm on this kernel's state). A task with F == 0 and no
-// exception candidate ("no suitable node") passes through the round as a no-op.
+// is not exhausted. When it is, the round is CUT there: the tasks before it are committed and the next round starts at
+// that task with fresh lists (its own list cannot be exhausted at position 0). A task that must look at its service's
+// exception list (no plain candidate, but F & X ≠ 0), whose listed nodes all filled up since the scan, with host ports or
+// uncounted: cut, and that one task runs the generic workgroup path (r5_generic: k_resolve's algorithm on this kernel's
+// state). A task with F == 0 and no exception candidate ("no suitable node") passes through the round as a no-op.
 //
 // Pipeline: while the matcher works on round r, the listers build round r+1 against the state after round r-1; the
 // picks of round r are removed from those lists when the matcher loads them (TK row of the previous round).
@@ -35,53 +40,67 @@
 namespace swpdev {
 
 #define R5_Q 4                    // candidate words per task
-#define R5_LW 15                  // lister waves (waves 1..15)
+#define R5_LW 14                  // lister waves (waves 1..14); wave 0 matches, wave 15 commits to memory
 #define R5_TPW 4                  // task slots per lister wave and round
 #define R5_B (R5_LW * R5_TPW)     // tasks per round
+#define R5_CW 15                  // the committer wave
 #define R5_NBMAX 8                // level planes (255 levels above the lowest valid node)
+#define R5_J 4                    // levels in the mask ring
 #define R5_THREADS 1024
 #define R5_KMAX 4                 // node words per lane: n_words <= 256 (16 384 nodes)
 #define R5_QLIM (1 << 30)         // residuals in resource units must stay below this (host checks)
 
 enum { R5_NONE = 0, R5_FAST = 1, R5_INFEASIBLE = 2, R5_COMPLEX = 3 };
+enum { R5_CUT_NOT = 0, R5_CUT_RELIST = 1, R5_CUT_GENERIC = 2 };
 enum {   // u32 scalars in LDS
-    R5S_NCOMMIT = 0, R5S_NINF, R5S_BASE, R5S_NB, R5S_HOT, R5S_REBUILD, R5S_ERR, R5S_OK, R5S_ENTRY, R5S_PLACED,
+    R5S_NCOMMIT = 0, R5S_NINF, R5S_BASE, R5S_NB, R5S_LB, R5S_REBUILD, R5S_OK, R5S_QUIET, R5S_ADVANCE,
     R5S_CUT0, R5S_CUT1,           // cut position of the round, by round parity
-    R5S_RETRIES, R5S_SLOW, R5S_GENERIC, R5S_REBASES, R5S_ROUNDS, R5S_FULL, R5S_CUT_CLASS, R5S_CUT_EMPTY,
+    R5S_WHY0, R5S_WHY1,           // why it was cut
+    R5S_HJ0, R5S_HJ1,             // hand-over: window-local first task of the round, by round parity
+    R5S_HV0, R5S_HV1,             // hand-over record is pending
+    R5S_BELANY, R5S_RETRIES, R5S_SLOW, R5S_GENERIC, R5S_REBASES, R5S_ROUNDS, R5S_FULL, R5S_CUT_CLASS, R5S_CUT_EMPTY, R5S_RINGADV, R5S_DEEP,
     R5S_COUNT = 32
 };
-#define R5_LIST_U32 ((1 + R5_Q) * 4)   // header + entries, 16 B each
+#define R5_HDR_U32 8                            // list header: class, entries, level, service, kc, km, list slot, -
+#define R5_LIST_U32 (R5_HDR_U32 + R5_Q * 4)     // + entries {word index, -, bits lo, bits hi}; the matcher walks them as 32-node half-words
+#define R5_HAND_U32 8                           // hand-over record: kind, node, commit / inf index, commits before, slot, service, kc, km
+enum { R5H_NONE = 0, R5H_COMMIT = 1, R5H_INF = 2 };
 
 struct R5Lds {
-    u64* planes;     // [R5_NBMAX][rs]
-    u64* tk;         // [2][rs]      picks of the previous / the current round
-    u64* scratch;    // [R5_LW][rs]  per lister wave: same-service commits of the last round as a row
-    u64* red;        // [64]         block reductions
+    u64* planes;     // [R5_NBMAX][rs]  bit b of (level - base) per node
+    u64* lv;         // [R5_J][rs]      nodes at level lb .. lb+J-1 (slot = level % J)
+    u64* below;      // [rs]            nodes below the ring
+    u64* tk;         // [2][rs]         picks of the previous / the current round
+    u64* scratch;    // [R5_LW][rs]     per lister wave: same-service commits of the last round as a row
+    u64* red;        // [64]            block reductions
     u32* lists;      // [2][R5_B][R5_LIST_U32]
-    u32* ring;       // [R5_B][2]    (service, node) of the last round's commits
+    u32* ring;       // [2][R5_B][2]    (service, node) of the last two rounds' commits, by round parity
+    u32* hand;       // [2][R5_B][R5_HAND_U32]  hand-over to the committer, by round parity
     u32* sh;         // [R5S_COUNT]
-    int32_t* q;      // [n_nodes][2] residual cpu / mem in resource units
+    int32_t* q;      // [n_nodes][2]    residual cpu / mem in resource units
     u32 rs;          // row stride in words
 };
 
 inline __host__ __device__ u32 r5_row_stride(u32 n_words) { return (n_words + 7u) & ~7u; }
 inline __host__ __device__ size_t r5_lds_bytes(u32 n_nodes, u32 n_words) {
     const size_t rs = r5_row_stride(n_words);
-    return (size_t)(R5_NBMAX + 2 + R5_LW) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)R5_B * 2 * 4 + R5S_COUNT * 4 +
-           (size_t)n_nodes * 8;
+    return (size_t)(R5_NBMAX + R5_J + 1 + 2 + R5_LW) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
+           (size_t)2 * R5_B * R5_HAND_U32 * 4 + R5S_COUNT * 4 + (size_t)n_nodes * 8;
 }
-WV_DEV R5Lds r5_layout(u64* lds, u32 n_nodes, u32 n_words) {
+WV_DEV R5Lds r5_layout(u64* lds, u32 n_words) {
     R5Lds L;
     L.rs = r5_row_stride(n_words);
     L.planes = lds;
-    L.tk = L.planes + (size_t)R5_NBMAX * L.rs;
+    L.lv = L.planes + (size_t)R5_NBMAX * L.rs;
+    L.below = L.lv + (size_t)R5_J * L.rs;
+    L.tk = L.below + L.rs;
     L.scratch = L.tk + 2 * L.rs;
     L.red = L.scratch + (size_t)R5_LW * L.rs;
     L.lists = reinterpret_cast<u32*>(L.red + 64);
     L.ring = L.lists + 2 * R5_B * R5_LIST_U32;
-    L.sh = L.ring + R5_B * 2;
+    L.hand = L.ring + 2 * R5_B * 2;
+    L.sh = L.hand + 2 * R5_B * R5_HAND_U32;
     L.q = reinterpret_cast<int32_t*>(L.sh + R5S_COUNT);
-    (void)n_nodes;
     return L;
 }
 
@@ -109,8 +128,36 @@ WV_DEV u64 r5_block_min64(u64 v, const R5Lds& L, u32& par) {
     return g;
 }
 
+// ---- the level-mask ring from the planes: LV[l % J] = {level == l} for l in [lb, lb+J), BELOW = {level < lb} --------
+// One thread per node word (rs <= 256 < 1024). Three barriers; ends with one.
+WV_DEV void r5_ring_build(const R5Lds& L, u32 lb) {
+    const u32 w = wv::tid(), NB = L.sh[R5S_NB];
+    if (w < L.rs) {
+        u64 eq[R5_J], lt = 0, e0 = ~0ull;
+        for (int j = 0; j < R5_J; ++j) eq[j] = ((lb + j) >> NB) ? 0ull : ~0ull;   // a level the planes cannot express has no node
+        for (int b = (int)NB - 1; b >= 0; --b) {
+            const u64 p = L.planes[(size_t)b * L.rs + w];
+            for (int j = 0; j < R5_J; ++j) eq[j] &= (((lb + j) >> b) & 1u) ? p : ~p;
+            if ((lb >> b) & 1u) { lt |= e0 & ~p; e0 &= p; } else e0 &= ~p;
+        }
+        for (int j = 0; j < R5_J; ++j) L.lv[(size_t)((lb + j) % R5_J) * L.rs + w] = eq[j];
+        L.below[w] = lt;
+    }
+    const bool some_below = w < L.rs && L.below[w] != 0;
+    wv::barrier();   // every thread has read the flags that sent it here before they are reset
+    if (wv::tid() == 0) L.sh[R5S_BELANY] = 0;
+    wv::barrier();
+    if (some_below) L.sh[R5S_BELANY] = 1;   // many writers, one value
+    if (wv::tid() == 0) {
+        L.sh[R5S_LB] = lb;
+        L.sh[R5S_QUIET] = 0;
+        L.sh[R5S_ADVANCE] = 0;
+    }
+    wv::barrier();
+}
+
 // ---- level planes from total[] (window start, level overflow). One wave per node word: a ballot IS a plane word. ----
-// Returns false (uniformly) when the level span of the valid nodes does not fit R5_NBMAX planes.
+// Returns false (uniformly) when the level span of the valid nodes does not fit R5_NBMAX planes. Ends with a barrier.
 WV_DEV bool r5_build_planes(const ResolveArgs& a, const R5Lds& L, u32& par) {
     const u32 lane = wv::lane(), wave = wv::wave();
     u32 lo = 0xFFFFFFFFu, hi = 0;
@@ -147,10 +194,10 @@ WV_DEV bool r5_build_planes(const ResolveArgs& a, const R5Lds& L, u32& par) {
     if (wv::tid() == 0) {
         L.sh[R5S_BASE] = lo;
         L.sh[R5S_NB] = NB;
-        L.sh[R5S_HOT] = 0;
         L.sh[R5S_REBUILD] = 0;
     }
     wv::barrier();
+    r5_ring_build(L, 0);
     return true;
 }
 
@@ -162,96 +209,145 @@ WV_DEV u32 r5_level_of(const R5Lds& L, u32 NB, u32 w, u64 bit) {
     return lvl;
 }
 
+// one node moves from level rl to rl + 1 in the LDS level structures; true when rl + 1 does not fit the planes
+WV_DEV bool r5_bump_level(const R5Lds& L, u32 NB, u32 lb, u32 w, u64 bit, u32 rl) {
+    const u32 nl = rl + 1, xm = rl ^ nl;
+    for (u32 b = 0; b < NB; ++b)
+        if ((xm >> b) & 1u) wv::lds_xor64(L.planes + (size_t)b * L.rs + w, bit);
+    if (rl < lb) {
+        if (nl >= lb) wv::lds_andn64(L.below + w, bit);
+    } else if (rl < lb + R5_J)
+        wv::lds_andn64(L.lv + (size_t)(rl % R5_J) * L.rs + w, bit);
+    if (nl >= lb && nl < lb + R5_J) wv::lds_or64(L.lv + (size_t)(nl % R5_J) * L.rs + w, bit);
+    return (nl >> NB) != 0;
+}
+
 // ---- lister: candidate lists of the round that starts at window-local task jbase, into list buffer `buf` ------------
+// F and X rows are requested one task ahead. (F was written by the scan on other XCDs — an L2 miss here, ~1 µs — so the
+// committer wave touches the rows of the round after next while it has nothing else to do: r5_touch_rows.)
 template <int K>
-WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u32 lw) {
+WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u32 lw, u64* lt) {
     const u32 lane = wv::lane();
-    const u32 NB = L.sh[R5S_NB], hot = L.sh[R5S_HOT];
-    // hot-level masks of this wave's words from the planes: LA level == hot, LB level == hot + 1, LO level < hot
-    u64 LA[K], LB[K], LO[K];
-    {
-        const u32 hb = hot + 1;
-        const bool hb_ok = (hb >> NB) == 0;
-        for (int k = 0; k < K; ++k) {
-            const u32 w = lane + 64 * k;
-            u64 ea = ~0ull, eb = hb_ok ? ~0ull : 0ull, lt = 0, eq = ~0ull;
-            if (w < L.rs) {
-                for (int b = (int)NB - 1; b >= 0; --b) {
-                    const u64 p = L.planes[(size_t)b * L.rs + w];
-                    ea &= ((hot >> b) & 1u) ? p : ~p;
-                    eb &= ((hb >> b) & 1u) ? p : ~p;
-                    if ((hot >> b) & 1u) { lt |= eq & ~p; eq &= p; } else eq &= ~p;
-                }
-            } else { ea = 0; eb = 0; }
-            LA[k] = ea;
-            LB[k] = eb;
-            LO[k] = lt;
+    u64 lmark = lt ? wv::clock64() : 0;
+#define R5_LT(slot) do { if (lt) { const u64 n_ = wv::clock64(); lt[slot] += n_ - lmark; lmark = n_; } } while (0)
+    const u32 NB = L.sh[R5S_NB], lb = L.sh[R5S_LB];
+    const bool bel_any = L.sh[R5S_BELANY] != 0;
+    u32 fl_[R5_TPW], sv_[R5_TPW];
+    for (u32 t = 0; t < R5_TPW; ++t) {
+        const u32 jj = jbase + lw + R5_LW * t;
+        fl_[t] = 0;
+        sv_[t] = 0;
+        if (jj < a.count) {   // uniform
+            const RTask* rt = a.rt + a.j0 + jj;
+            fl_[t] = wv::uload(&rt->flags);
+            sv_[t] = wv::uload(&rt->svc);
         }
     }
-    const u32 ring_svc = lane < R5_B ? L.ring[2 * lane] : 0xFFFFFFFFu;
-    const u32 ring_node = lane < R5_B ? L.ring[2 * lane + 1] : 0u;
+    u64 Fn[K], Xn[K];
+    for (int k = 0; k < K; ++k) {
+        const u32 w = lane + 64 * k;
+        const bool in = jbase + lw < a.count && w < a.n_words;
+        Fn[k] = in ? a.F[(size_t)(jbase + lw) * a.n_words + w] : 0ull;
+        Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[0] * a.xs + w) : 0ull;
+    }
+    // the lowest ring level and BELOW of this wave's words stay in registers for the round
+    u64 LV0[K], BEL[K];
+    for (int k = 0; k < K; ++k) {
+        const u32 w = lane + 64 * k;
+        const bool in = w < L.rs;
+        LV0[k] = in ? L.lv[(size_t)(lb % R5_J) * L.rs + w] : 0ull;
+        BEL[k] = in ? L.below[w] : 0ull;
+    }
+    // (service, node) of the last two rounds' commits: lanes 0..B-1 hold one round, lanes ... the other needs a second pair
+    const u32 r0_svc = lane < R5_B ? L.ring[2 * lane] : 0xFFFFFFFFu, r0_node = lane < R5_B ? L.ring[2 * lane + 1] : 0u;
+    const u32 r1_svc = lane < R5_B ? L.ring[2 * (R5_B + lane)] : 0xFFFFFFFFu, r1_node = lane < R5_B ? L.ring[2 * (R5_B + lane) + 1] : 0u;
     u64* sr = L.scratch + (size_t)lw * L.rs;
+    R5_LT(0);   // prologue: task records, first row requests, ring masks
 
     for (u32 t = 0; t < R5_TPW; ++t) {
         const u32 s = lw + R5_LW * t;   // task slot of the round == lane of the matcher
         const u32 jj = jbase + s;
         u32* out = L.lists + ((size_t)buf * R5_B + s) * R5_LIST_U32;
+        u64 F[K], X[K];
+        for (int k = 0; k < K; ++k) {
+            F[k] = Fn[k];
+            X[k] = Xn[k];
+        }
+        if (t + 1 < R5_TPW) {
+            const u32 jn = jj + R5_LW;
+            for (int k = 0; k < K; ++k) {
+                const u32 w = lane + 64 * k;
+                const bool in = jn < a.count && w < a.n_words;
+                Fn[k] = in ? a.F[(size_t)jn * a.n_words + w] : 0ull;
+                Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[t + 1] * a.xs + w) : 0ull;
+            }
+        }
         if (jj >= a.count) {   // uniform
-            if (lane == 0) { out[0] = R5_NONE; out[1] = 0; out[2] = 0; }
+            if (lane == 0) { out[0] = R5_NONE; out[1] = 0; }
             continue;
         }
         const RTask* rt = a.rt + a.j0 + jj;
-        const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc);
+        const u32 flags = fl_[t], svc = sv_[t];
         if (flags & (RT_PORTS | RT_UNCOUNTED)) {
-            if (lane == 0) { out[0] = R5_COMPLEX; out[1] = 0; out[2] = 0; }
+            if (lane == 0) { out[0] = R5_COMPLEX; out[1] = 0; }
             continue;
         }
-        u64 F[K], X[K];
-        for (int k = 0; k < K; ++k) {
-            const u32 w = lane + 64 * k;
-            const bool in = w < a.n_words;
-            F[k] = in ? a.F[(size_t)jj * a.n_words + w] : 0ull;
-            X[k] = in ? wv::g_fresh64(a.X + (size_t)svc * a.xs + w) : 0ull;
-        }
-        // commits of the last round may still be on their way to X in memory: patch them in from the ring
-        const u64 match = wv::ballot(ring_svc == svc);
+        u64 mk[K];
+        // commits of the last two rounds may still be on their way to X in memory: patch them in from the ring
+        const u64 match = wv::ballot(r0_svc == svc || r1_svc == svc);
+        R5_LT(1);   // rows have arrived
         if (match) {
-            if (ring_svc == svc) wv::lds_or64(sr + (ring_node >> 6), 1ull << (ring_node & 63));
+            if (r0_svc == svc) wv::lds_or64(sr + (r0_node >> 6), 1ull << (r0_node & 63));
+            if (r1_svc == svc) wv::lds_or64(sr + (r1_node >> 6), 1ull << (r1_node & 63));
             wv::wave_sync();
             for (int k = 0; k < K; ++k) {
                 const u32 w = lane + 64 * k;
                 if (w < L.rs) X[k] |= sr[w];
             }
             wv::wave_sync();
-            if (ring_svc == svc) sr[ring_node >> 6] = 0;
+            if (r0_svc == svc) sr[r0_node >> 6] = 0;
+            if (r1_svc == svc) sr[r1_node >> 6] = 0;
         }
-        u64 mk[K];
-        u64 any_mk = 0, any_fx = 0, in_lo = 0, in_a = 0, in_b = 0;
+        u64 any_mk = 0;
         for (int k = 0; k < K; ++k) {
             mk[k] = F[k] & ~X[k];
             any_mk |= mk[k];
-            any_fx |= F[k] & X[k];
-            in_lo |= mk[k] & LO[k];
-            in_a |= mk[k] & LA[k];
-            in_b |= mk[k] & LB[k];
         }
         if (!wv::ballot(any_mk != 0)) {
             // no plain candidate: "no suitable node" unless a node of the service's exception list is feasible
+            u64 any_fx = 0;
+            for (int k = 0; k < K; ++k) any_fx |= F[k] & X[k];
             const u32 cls = wv::ballot(any_fx != 0) ? R5_COMPLEX : R5_INFEASIBLE;
-            if (lane == 0) { out[0] = cls; out[1] = 0; out[2] = 0; }
+            if (lane == 0) { out[0] = cls; out[1] = 0; }
             continue;
         }
         u64 c[K];
-        u32 lvl;
-        const bool below = wv::ballot(in_lo != 0) != 0;
-        if (!below && wv::ballot(in_a != 0)) {
-            lvl = hot;
-            for (int k = 0; k < K; ++k) c[k] = mk[k] & LA[k];
-        } else if (!below && wv::ballot(in_b != 0)) {
-            lvl = hot + 1;
-            for (int k = 0; k < K; ++k) c[k] = mk[k] & LB[k];
-        } else {
-            // generic: bit-sliced minimum per word, then the wave minimum of the levels
+        u32 lvl = 0xFFFFFFFFu;
+        bool below = false;
+        if (bel_any) {   // uniform; the ring seldom has anything below it
+            u64 in_bel = 0;
+            for (int k = 0; k < K; ++k) in_bel |= mk[k] & BEL[k];
+            below = wv::ballot(in_bel != 0) != 0;
+        }
+        if (!below) {
+            u64 in_0 = 0;
+            for (int k = 0; k < K; ++k) {
+                c[k] = mk[k] & LV0[k];
+                in_0 |= c[k];
+            }
+            if (wv::ballot(in_0 != 0)) lvl = lb;
+            for (u32 jl = 1; jl < R5_J && lvl == 0xFFFFFFFFu; ++jl) {
+                u64 any = 0;
+                for (int k = 0; k < K; ++k) {
+                    const u32 w = lane + 64 * k;
+                    c[k] = w < L.rs ? mk[k] & L.lv[(size_t)((lb + jl) % R5_J) * L.rs + w] : 0ull;
+                    any |= c[k];
+                }
+                if (wv::ballot(any != 0)) lvl = lb + jl;
+            }
+        }
+        if (lvl == 0xFFFFFFFFu) {
+            // below or above the ring: bit-sliced minimum per word over the planes, then the wave minimum of the levels
             u32 lv[K], lmin = 0xFFFFFFFFu;
             for (int k = 0; k < K; ++k) {
                 const u32 w = lane + 64 * k;
@@ -272,45 +368,121 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             lvl = wv::min_u32(lmin);
             for (int k = 0; k < K; ++k)
                 if (lv[k] != lvl) c[k] = 0;
+            if (lane == 0) L.sh[R5S_DEEP] += 1;   // statistics only (several waves may race: the count is approximate)
         }
-        // the first R5_Q non-empty words in node order; entry q is parked in lane q
-        u32 my_w = 0, cnt = 0;
-        u64 my_bits = 0;
+        R5_LT(2);   // level search
+        // the first R5_Q non-empty words in node order: the lane that holds the r-th one writes entry r itself
+        // (entry = {word index, -, bits lo, bits hi}; the matcher reads it as two 32-node half-words)
+        u32 cnt = 0;
         for (int k = 0; k < K; ++k) {
-            u64 bal = wv::ballot(c[k] != 0);
-            while (bal && cnt < R5_Q) {   // uniform
-                const u32 l = (u32)wv::ffs64(bal);
-                bal &= bal - 1;
-                const u64 word = wv::readlane64(c[k], l);
-                if (lane == cnt) { my_w = l + 64 * k; my_bits = word; }
-                ++cnt;
-            }
-        }
-        // ResourceFilter against the exact residuals (filter.go:77-84 in resource units): lane b checks node 64w + b
-        if (flags & RT_RES) {
-            const int32_t kc = (int32_t)wv::uload(&rt->kc), km = (int32_t)wv::uload(&rt->km);
-            for (u32 q = 0; q < R5_Q; ++q) {
-                if (q < cnt) {   // uniform
-                    const u32 sw = wv::readlane(my_w, q);
-                    const u64 sb = wv::readlane64(my_bits, q);
-                    const u32 n = sw * 64 + lane;
-                    bool ok = (sb >> lane) & 1;
-                    if (ok) ok = L.q[2 * n] >= kc && L.q[2 * n + 1] >= km;
-                    const u64 v = wv::ballot(ok);
-                    if (lane == q) my_bits = v;
+            const u64 bal = wv::ballot(c[k] != 0);
+            if (c[k] != 0) {
+                const u32 r = cnt + wv::mbcnt(bal);
+                if (r < R5_Q) {
+                    out[R5_HDR_U32 + 4 * r] = lane + 64 * k;
+                    *reinterpret_cast<u64*>(out + R5_HDR_U32 + 4 * r + 2) = c[k];
                 }
             }
+            cnt += (u32)wv::popc64(bal);
         }
-        const bool some = wv::ballot(lane < cnt && my_bits != 0) != 0;
-        if (lane < cnt) {
-            out[4 + 4 * lane] = my_w;
-            *reinterpret_cast<u64*>(out + 4 + 4 * lane + 2) = my_bits;
+        cnt = min(cnt, (u32)R5_Q);
+        R5_LT(3);   // entries
+        // ResourceFilter against the exact residuals (filter.go:77-84 in resource units): lane b checks node 64w + b
+        const int32_t kc = (int32_t)wv::uload(&rt->kc), km = (int32_t)wv::uload(&rt->km);
+        u32 some = 1;
+        if (flags & RT_RES) {
+            wv::wave_sync();
+            // all four entries are read back first (same address in every lane: broadcast reads), then the residuals of the
+            // four words, then the verdicts: two LDS latencies instead of eight
+            u32 sw[R5_Q];
+            u64 sb[R5_Q];
+            for (u32 q = 0; q < R5_Q; ++q) {
+                sw[q] = out[R5_HDR_U32 + 4 * q];
+                sb[q] = *reinterpret_cast<const u64*>(out + R5_HDR_U32 + 4 * q + 2);
+            }
+            int32_t qc[R5_Q], qm[R5_Q];
+            for (u32 q = 0; q < R5_Q; ++q) {
+                const u32 n = q < cnt ? sw[q] * 64 + lane : 0u;   // entries beyond cnt hold leftovers: read node 0, ignore
+                qc[q] = L.q[2 * n];
+                qm[q] = L.q[2 * n + 1];
+            }
+            wv::lockstep();   // every lane has read the entries before lane 0 rewrites them
+            some = 0;
+            for (u32 q = 0; q < R5_Q; ++q) {
+                const bool ok = q < cnt && ((sb[q] >> lane) & 1) && qc[q] >= kc && qm[q] >= km;
+                const u64 v = wv::ballot(ok);
+                if (v) some = 1;
+                if (lane == 0 && q < cnt) *reinterpret_cast<u64*>(out + R5_HDR_U32 + 4 * q + 2) = v;
+            }
         }
         if (lane == 0) {
             out[0] = some ? R5_FAST : R5_COMPLEX;   // every listed node is full by now: let the generic path look further
-            out[1] = cnt;
+            out[1] = 2 * cnt;
             out[2] = lvl;
+            out[3] = svc;
+            out[4] = (u32)kc;
+            out[5] = (u32)km;
+            out[6] = wv::uload(&rt->slot);
         }
+        R5_LT(4);   // validation + header
+    }
+#undef R5_LT
+}
+
+// the F rows of window-local tasks [j0, j0 + R5_B) into this XCD's L2: one 128-byte line per lane and step
+WV_DEV void r5_touch_rows(const ResolveArgs& a, u32 j0) {
+    if (j0 >= a.count) return;
+    const u32 j1 = min(j0 + (u32)R5_B, a.count);
+    const char* p0 = reinterpret_cast<const char*>(a.F + (size_t)j0 * a.n_words);
+    const size_t bytes = (size_t)(j1 - j0) * a.n_words * 8;
+    for (size_t off = (size_t)wv::lane() * 128; off < bytes; off += 64 * 128) wv::prefetch_l2(p0 + off);
+}
+
+// ---- committer: the memory side effects of one finished round, from its hand-over record ---------------------------
+// Nothing is waited for inside a round: the per-node chain link (the exchange's result) is stored by the NEXT call, and
+// the X / list updates of a round become visible to the listers through the two-round ring until they have landed.
+// drain = true: wait for everything and store the links now (cut, plane rebuild, end of the window).
+struct R5Pend { u32 ci; int32_t prev; };
+WV_DEV void r5_commit_memory(const ResolveArgs& a, const R5Lds& L, u32 hp, R5Pend& pend, bool drain) {
+    const u32 lane = wv::lane();
+    const u32 pending = L.sh[R5S_HV0 + hp], hj = L.sh[R5S_HJ0 + hp];
+    wv::wave_sync();   // every lane has read the flag before lane 0 clears it below
+    wv::wait_vm();     // the previous call's operations (issued a round ago) have landed, its exchange results are here
+    if (pend.ci != 0xFFFFFFFFu) a.log_prev[pend.ci] = pend.prev;
+    pend.ci = 0xFFFFFFFFu;
+    if (pending) {   // uniform
+        if (lane < R5_B) {
+            const u32* h = L.hand + ((size_t)hp * R5_B + lane) * R5_HAND_U32;
+            const u32 kind = h[0], gj = a.j0 + hj + lane;
+            if (kind == R5H_COMMIT) {
+                const u32 n = h[1], ci = h[2], slot = h[4], svc = h[5], w = n >> 6;
+                const u64 bit = 1ull << (n & 63);
+                const i64 rcpu = (i64)h[6] * a.unit_cpu, rmem = (i64)h[7] * a.unit_mem;
+                if (rcpu) wv::g_add64(a.cpu + n, -rcpu);
+                if (rmem) wv::g_add64(a.mem + n, -rmem);
+                wv::g_add32(a.total + n, 1u);
+                wv::g_or64(a.X + (size_t)svc * a.xs + w, bit);
+                a.list_node[slot] = n;
+                a.list_svc[slot] = 1;
+                a.list_fail[slot] = 0;
+                a.log_node[ci] = n;
+                a.log_task[ci] = gj;
+                pend.prev = (int32_t)wv::g_exch32(reinterpret_cast<u32*>(a.last + n), ci);
+                pend.ci = ci;
+                a.out_node[gj] = (int32_t)n;
+            } else if (kind == R5H_INF) {
+                a.inf_task[h[2]] = gj;
+                a.inf_pos[h[2]] = h[3];
+            }
+        }
+        wv::wave_sync();
+        if (lane == 0) L.sh[R5S_HV0 + hp] = 0;
+    }
+    if (drain) {
+        wv::wait_vm();
+        if (pend.ci != 0xFFFFFFFFu) a.log_prev[pend.ci] = pend.prev;
+        pend.ci = 0xFFFFFFFFu;
+        wv::wait_vm();
     }
 }
 
@@ -345,10 +517,7 @@ WV_DEV void r5_commit_one(const ResolveArgs& a, const R5Lds& L, const R5Rt& r, u
         for (u32 p = a.pset_off[r.pset]; p < a.pset_off[r.pset + 1]; ++p) wv::g_or64(a.portmap + (size_t)a.pset_ids[p] * a.n_words + w, bit);
     if (!(r.flags & RT_UNCOUNTED)) {
         wv::g_add32(a.total + n, 1u);
-        const u32 rl = r5_level_of(L, NB, w, bit), nl = rl + 1, xm = rl ^ nl;
-        for (u32 b = 0; b < NB; ++b)
-            if ((xm >> b) & 1u) wv::lds_xor64(L.planes + (size_t)b * L.rs + w, bit);
-        if (nl >> NB) L.sh[R5S_REBUILD] = 1;
+        if (r5_bump_level(L, NB, L.sh[R5S_LB], w, bit, r5_level_of(L, NB, w, bit))) L.sh[R5S_REBUILD] = 1;
         if (e == LIST_EMPTY) {
             wv::g_or64(a.X + (size_t)r.svc * a.xs + w, bit);
             a.list_node[r.slot] = n;
@@ -368,8 +537,6 @@ WV_DEV void r5_commit_one(const ResolveArgs& a, const R5Lds& L, const R5Rt& r, u
 
 WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
     const u32 tid = wv::tid();
-    if (wv::wave() == 0) wv::wait_vm();   // the matcher's fire-and-forget updates of X / lists / portmap have landed
-    wv::barrier();
     const u32 gj = a.j0 + jj;
     const R5Rt r = r5_load_rt(a.rt + gj);
     const u32 NB = L.sh[R5S_NB];
@@ -461,12 +628,12 @@ template <int K>
 WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
     const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave();
     if (wv::uload(&a.ctl->error) != ERR_NONE) return;   // an earlier window stopped: the host carries on from ctl->resume
-    const R5Lds L = r5_layout(wv::lds(), a.n_nodes, a.n_words);
+    const R5Lds L = r5_layout(wv::lds(), a.n_words);
     u32 par = 0;   // parity of the reduction scratch
 
     for (u32 i = tid; i < (2 + R5_LW) * L.rs; i += R5_THREADS) L.tk[i] = 0;   // TK rows and scratch rows are contiguous
     for (u32 i = tid; i < a.n_nodes * 2; i += R5_THREADS) L.q[i] = a.qres[i];
-    for (u32 i = tid; i < R5_B * 2; i += R5_THREADS) L.ring[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
+    for (u32 i = tid; i < 2 * R5_B * 2; i += R5_THREADS) L.ring[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
     if (tid < R5S_COUNT) L.sh[tid] = 0;
     wv::barrier();
     if (tid == 0) {
@@ -478,88 +645,111 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
     u32 j = 0;           // next window-local task
     u32 buf = 0;         // list buffer of the current round
     u32 tkp = 0;         // TK row that holds the previous round's picks
-    u32 rpar = 0;        // round parity (cut flag slot)
+    u32 rpar = 0;        // round parity (cut flag / hand-over / ring slot)
     bool have_lists = false;
-    // matcher state that lives across phases (wave 0 only)
-    u32 m_cls = R5_NONE, m_lvl = 0, m_pick = 0xFFFFFFFFu;
-    u32 pend_ci = 0xFFFFFFFFu;
-    int32_t pend_prev = -1;
+    // matcher state that lives from the match to the LDS commit (wave 0 only)
+    u32 m_cls = R5_NONE, m_lvl = 0, m_pick = 0xFFFFFFFFu, m_svc = 0, m_slot = 0, m_kc = 0, m_km = 0;
+    // committer state (wave 15 only): the chain link whose exchange is still in flight
+    R5Pend pend{0xFFFFFFFFu, -1};
+    // section timers (a.dbg & 16): shader cycles spent by wave 0 in match / barrier 1 / LDS commit / barrier 2 and by wave 1
+    // in list / barrier 1 / - / barrier 2; cyc[4..7] of the control block, pad1 = between the rounds (cuts, refills, generic)
+    const bool prof = (a.dbg & 16u) != 0;
+    u64 lcy[5] = {0, 0, 0, 0, 0};
+    u64 tc[5] = {0, 0, 0, 0, 0}, tm[3] = {0, 0, 0}, nadv = 0, tmark = prof ? wv::clock64() : 0;
+#define R5_TICK(slot) do { if (prof) { const u64 n_ = wv::clock64(); tc[slot] += n_ - tmark; tmark = n_; } } while (0)
 
     while (!fatal && j < a.count) {
         const u32 nb = min((u32)R5_B, a.count - j);
         if (!have_lists) {
             // (re)fill: lists of [j, j+nb) against the state as it is; no earlier picks to strike
-            if (wave != 0) r5_list<K>(a, L, j, buf, wave - 1);
-            else
+            if (wave >= 1 && wave <= R5_LW) r5_list<K>(a, L, j, buf, wave - 1, nullptr);
+            else if (wave == 0)
                 for (u32 i = lane; i < 2 * L.rs; i += 64) L.tk[i] = 0;
             wv::barrier();
             have_lists = true;
+            R5_TICK(4);
         }
-        // ---------------- phase 1: match round [j, j+nb) || list round [j+nb, ...) ----------------
-        u32 cut = nb;
-        if (wave != 0) {
-            r5_list<K>(a, L, j + nb, buf ^ 1, wave - 1);
+        // ---------------- phase 1: match round [j, j+nb) || list round [j+nb, ...) || memory side of the last round ----------
+        if (wave >= 1 && wave <= R5_LW) {
+            r5_list<K>(a, L, j + nb, buf ^ 1, wave - 1, (prof && wave == 1) ? lcy : nullptr);
+        } else if (wave == R5_CW) {
+            r5_commit_memory(a, L, rpar ^ 1, pend, false);
+            r5_touch_rows(a, j + nb + R5_B);   // what the listers will read in the next round
         } else {
             const u32* li = L.lists + ((size_t)buf * R5_B + lane) * R5_LIST_U32;
-            const u64* tkprev = L.tk + (size_t)tkp * L.rs;
-            u64* tkcur = L.tk + (size_t)(tkp ^ 1) * L.rs;
-            u32 cnt = 0, e = 0, w = 0;
-            u64 bits = 0;
+            const u32* tkprev = reinterpret_cast<const u32*>(L.tk + (size_t)tkp * L.rs);
+            u32* tkcur = reinterpret_cast<u32*>(L.tk + (size_t)(tkp ^ 1) * L.rs);
+            u32 cnt = 0, e = 0, w = 0, bits = 0;
             m_cls = R5_NONE;
             m_pick = 0xFFFFFFFFu;
             if (lane < nb) {
                 m_cls = li[0];
                 cnt = li[1];
-                m_lvl = li[2];
             }
             const bool fast = m_cls == R5_FAST;
             if (fast) {
-                w = li[4];
-                bits = *reinterpret_cast<const u64*>(li + 6) & ~tkprev[w];
+                m_lvl = li[2];
+                m_svc = li[3];
+                m_kc = li[4];
+                m_km = li[5];
+                m_slot = li[6];
+                w = 2 * li[R5_HDR_U32];
+                bits = li[R5_HDR_U32 + 2] & ~tkprev[w];
             }
+            const u64 fastmask = wv::ballot(fast), infmask = wv::ballot(m_cls == R5_INFEASIBLE);
+            u64 tq = prof ? wv::clock64() : 0;
+            if (prof) tm[0] += tq - tmark;
+            // the round ends in front of the first task that is neither fast nor a no-op
+            const u64 lanes = (1ull << nb) - 1ull;   // nb <= R5_B < 64
+            const u64 stop = ~(fastmask | infmask) & lanes;
+            u32 cut = stop ? (u32)wv::ffs64(stop) : nb;
+            u32 why = stop ? (u32)R5_CUT_GENERIC : (u32)R5_CUT_NOT;
+            const u64 todo64 = fastmask & ((1ull << cut) - 1ull);
             u32 flushed = 0;   // picks of lanes < flushed are in tkcur
-            // a lane whose current word ran empty moves to its next listed word (minus everything taken since the snapshot)
-#define R5_ADVANCE(upto)                                                                                    \
-    for (;;) {                                                                                              \
-        const u64 need_ = wv::ballot(fast && bits == 0 && e + 1 < cnt);                                    \
-        if (!need_) break;                                                                                  \
-        if (flushed < (upto)) {                                                                             \
-            if (lane >= flushed && lane < (upto) && m_pick != 0xFFFFFFFFu) wv::lds_or64(tkcur + (m_pick >> 6), 1ull << (m_pick & 63)); \
-            flushed = (upto);                                                                               \
-            wv::wave_sync();                                                                                \
-        }                                                                                                   \
-        if (fast && bits == 0 && e + 1 < cnt) {                                                             \
-            ++e;                                                                                            \
-            w = li[4 + 4 * e];                                                                              \
-            bits = *reinterpret_cast<const u64*>(li + 6 + 4 * e) & ~tkprev[w] & ~tkcur[w];                 \
-        }                                                                                                   \
-    }
-            R5_ADVANCE(0u)
-            for (u32 i = 0; i < nb; ++i) {
-                const u32 s_cls = wv::readlane(m_cls, i);
-                if (s_cls == R5_INFEASIBLE) continue;
-                if (s_cls != R5_FAST) { cut = i; if (lane == 0) L.sh[R5S_CUT_CLASS] += 1; break; }
-                const u32 s_w = wv::readlane(w, i);
-                const u64 s_bits = wv::readlane64(bits, i);
-                if (s_bits == 0) { cut = i; if (lane == 0) L.sh[R5S_CUT_EMPTY] += 1; break; }   // list exhausted: the generic path looks further
-                const u32 b = (u32)wv::ffs64(s_bits);
-                m_pick = wv::writelane(m_pick, s_w * 64 + b, i);
-                if (w == s_w) bits &= ~(1ull << b);
-                R5_ADVANCE(i + 1)
+            for (u32 half = 0; half < 2 && why != R5_CUT_RELIST; ++half) {
+                u32 todo = half ? (u32)(todo64 >> 32) : (u32)todo64;
+                while (todo) {
+                    const u64 ta_ = prof ? wv::clock64() : 0;
+                    const u32 at = wv::match_run32(todo, 32 * half, bits, w, m_pick);
+                    if (prof) { tm[2] += wv::clock64() - ta_; ++nadv; }
+                    if (at == 0xFFFFFFFFu) break;
+                    // task `at` (and maybe others) ran out of its current half-word: every such lane moves on through its list,
+                    // minus everything taken since the list's snapshot (previous round: tkprev; this round so far: tkcur)
+                    if (flushed < at) {
+                        if (lane >= flushed && lane < at && m_pick != 0xFFFFFFFFu) wv::lds_or32(tkcur + (m_pick >> 5), 1u << (m_pick & 31));
+                        flushed = at;
+                        wv::wave_sync();
+                    }
+                    for (;;) {
+                        const bool mv = fast && bits == 0 && e + 1 < cnt;
+                        if (!wv::ballot(mv)) break;
+                        if (mv) {
+                            ++e;   // half-word e of the list = half (e & 1) of its 64-node entry e / 2
+                            w = 2 * li[R5_HDR_U32 + 4 * (e >> 1)] + (e & 1);
+                            bits = li[R5_HDR_U32 + 4 * (e >> 1) + 2 + (e & 1)] & ~tkprev[w] & ~tkcur[w];
+                        }
+                    }
+                    if (wv::readlane(bits, at) == 0) {   // list exhausted: the next round starts here with a fresh list
+                        cut = at;
+                        why = R5_CUT_RELIST;
+                        break;
+                    }
+                }
             }
-#undef R5_ADVANCE
-            if (lane >= flushed && lane < cut && m_pick != 0xFFFFFFFFu) wv::lds_or64(tkcur + (m_pick >> 6), 1ull << (m_pick & 63));
-            if (lane == 0) L.sh[R5S_CUT0 + rpar] = cut;
+            if (prof) { const u64 n_ = wv::clock64(); tm[1] += n_ - tq; tq = n_; }
+            if (lane >= flushed && lane < cut && m_pick != 0xFFFFFFFFu) wv::lds_or32(tkcur + (m_pick >> 5), 1u << (m_pick & 31));
+            if (lane == 0) {
+                L.sh[R5S_CUT0 + rpar] = cut;
+                L.sh[R5S_WHY0 + rpar] = why;
+            }
         }
+        R5_TICK(0);
         wv::barrier();
-        // ---------------- phase 2: commit the round's prefix ----------------
+        R5_TICK(1);
+        // ---------------- phase 2: the round's prefix into the LDS state + hand-over record ----------------
         if (wave == 0) {
-            cut = L.sh[R5S_CUT0 + rpar];
-            wv::wait_vm();   // the previous round's fire-and-forget updates have landed (the ring only covers one round)
-            if (pend_ci != 0xFFFFFFFFu) a.log_prev[pend_ci] = pend_prev;
-            pend_ci = 0xFFFFFFFFu;
-            const u32 NB = L.sh[R5S_NB];
-            const u32 gj = a.j0 + j + lane;
+            const u32 cut = L.sh[R5S_CUT0 + rpar];
+            const u32 NB = L.sh[R5S_NB], lb = L.sh[R5S_LB];
             const bool act = lane < cut;
             const bool com = act && m_cls == R5_FAST, inf = act && m_cls == R5_INFEASIBLE;
             const u64 mc = wv::ballot(com), mi = wv::ballot(inf);
@@ -567,87 +757,124 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
             const u32 ci = nc0 + wv::mbcnt(mc);
             u32 rsvc = 0xFFFFFFFFu, rnode = 0;
             bool over = false;
+            u32* h = L.hand + ((size_t)rpar * R5_B + lane) * R5_HAND_U32;
             if (com) {
-                const RTask* rt = a.rt + gj;
-                const i64 rcpu = rt->cpu, rmem = rt->mem;
-                const u32 svc = rt->svc, slot = rt->slot;
-                const int32_t kc = (int32_t)rt->kc, km = (int32_t)rt->km;
                 const u32 n = m_pick, w = n >> 6;
                 const u64 bit = 1ull << (n & 63);
-                const u32 nl = m_lvl + 1, xm = m_lvl ^ nl;
-                for (u32 b = 0; b < NB; ++b)
-                    if ((xm >> b) & 1u) wv::lds_xor64(L.planes + (size_t)b * L.rs + w, bit);
-                over = (nl >> NB) != 0;
-                L.q[2 * n] -= kc;
-                L.q[2 * n + 1] -= km;
-                rsvc = svc;
+                over = r5_bump_level(L, NB, lb, w, bit, m_lvl);
+                L.q[2 * n] -= (int32_t)m_kc;
+                L.q[2 * n + 1] -= (int32_t)m_km;
+                rsvc = m_svc;
                 rnode = n;
-                if (rcpu) wv::g_add64(a.cpu + n, -rcpu);
-                if (rmem) wv::g_add64(a.mem + n, -rmem);
-                wv::g_add32(a.total + n, 1u);
-                wv::g_or64(a.X + (size_t)svc * a.xs + w, bit);
-                a.list_node[slot] = n;
-                a.list_svc[slot] = 1;
-                a.list_fail[slot] = 0;
-                a.log_node[ci] = n;
-                a.log_task[ci] = gj;
-                pend_prev = (int32_t)wv::g_exch32(reinterpret_cast<u32*>(a.last + n), ci);
-                pend_ci = ci;
-                a.out_node[gj] = (int32_t)n;
-            }
-            if (inf) {
-                const u32 ii = ni0 + wv::mbcnt(mi);
-                a.inf_task[ii] = gj;
-                a.inf_pos[ii] = ci;   // commits before this task
-            }
+                h[0] = R5H_COMMIT;
+                h[1] = n;
+                h[2] = ci;
+                h[4] = m_slot;
+                h[5] = m_svc;
+                h[6] = m_kc;
+                h[7] = m_km;
+            } else if (inf) {
+                h[0] = R5H_INF;
+                h[2] = ni0 + wv::mbcnt(mi);
+                h[3] = ci;   // commits before this task
+            } else if (lane < R5_B)
+                h[0] = R5H_NONE;
             if (lane < R5_B) {
-                L.ring[2 * lane] = rsvc;
-                L.ring[2 * lane + 1] = rnode;
+                L.ring[2 * (rpar * R5_B + lane)] = rsvc;
+                L.ring[2 * (rpar * R5_B + lane) + 1] = rnode;
             }
-            const u32 newhot = wv::min_u32(com ? m_lvl : 0xFFFFFFFFu);
+            const bool low_pick = wv::ballot(com && m_lvl <= lb) != 0;
             const bool any_over = wv::ballot(over) != 0;
-            for (u32 i = lane; i < L.rs; i += 64) L.tk[(size_t)tkp * L.rs + i] = 0;   // the previous round's picks are history
             if (lane == 0) {
                 L.sh[R5S_NCOMMIT] = nc0 + (u32)wv::popc64(mc);
                 L.sh[R5S_NINF] = ni0 + (u32)wv::popc64(mi);
-                if (newhot != 0xFFFFFFFFu) L.sh[R5S_HOT] = newhot;
+                L.sh[R5S_HJ0 + rpar] = j;
+                L.sh[R5S_HV0 + rpar] = 1;
                 if (any_over) L.sh[R5S_REBUILD] = 1;
+                // ring policy: two rounds in a row without a pick at the ring's lowest level → the ring moves up one level
+                if (mc) {
+                    if (!low_pick) {
+                        const u32 qn = L.sh[R5S_QUIET] + 1;
+                        L.sh[R5S_QUIET] = qn;
+                        if (qn >= 2) L.sh[R5S_ADVANCE] = 1;
+                    } else
+                        L.sh[R5S_QUIET] = 0;
+                }
                 L.sh[R5S_ROUNDS] += 1;
                 if (cut == nb) L.sh[R5S_FULL] += 1;
+                else if (L.sh[R5S_WHY0 + rpar] == R5_CUT_GENERIC) L.sh[R5S_CUT_CLASS] += 1;
+                else L.sh[R5S_CUT_EMPTY] += 1;
             }
+        } else if (wave == R5_CW) {
+            for (u32 i = lane; i < L.rs; i += 64) L.tk[(size_t)tkp * L.rs + i] = 0;   // the previous round's picks are history
         }
+        R5_TICK(2);
         wv::barrier();
-        cut = L.sh[R5S_CUT0 + rpar];
-        rpar ^= 1;
+        R5_TICK(3);
+        const u32 cut = L.sh[R5S_CUT0 + rpar], why = L.sh[R5S_WHY0 + rpar];
+        const bool rebuild = L.sh[R5S_REBUILD] != 0, advance = L.sh[R5S_ADVANCE] != 0;
         j += cut;
         bool flush = false;
-        if (L.sh[R5S_REBUILD]) {   // a node outgrew the planes: rebuild them around the current minimum
-            if (tid == 0) L.sh[R5S_REBASES] += 1;
-            if (wave == 0) wv::wait_vm();
+        if (cut < nb || rebuild) {
+            // off the pipeline: the memory side of both outstanding rounds lands now (the generic path, the plane rebuild and
+            // the fresh lists read it back)
+            if (wave == R5_CW) {
+                r5_commit_memory(a, L, rpar ^ 1, pend, false);
+                r5_commit_memory(a, L, rpar, pend, true);
+            }
             wv::barrier();
-            if (!r5_build_planes(a, L, par)) { fatal = true; break; }
             flush = true;
         }
-        if (cut < nb) {
+        if (rebuild) {   // a node outgrew the planes: rebuild them around the current minimum
+            if (tid == 0) L.sh[R5S_REBASES] += 1;
+            if (!r5_build_planes(a, L, par)) { fatal = true; break; }
+        } else if (advance) {
+            if (tid == 0) L.sh[R5S_RINGADV] += 1;
+            r5_ring_build(L, L.sh[R5S_LB] + 1);   // lists carry absolute levels: the pipeline goes on
+        }
+        if (cut < nb && why == R5_CUT_GENERIC) {
             r5_generic(a, L, j, par);   // ends with a barrier
             j += 1;
-            flush = true;
             if (L.sh[R5S_REBUILD]) {
                 if (tid == 0) L.sh[R5S_REBASES] += 1;
                 wv::barrier();
                 if (!r5_build_planes(a, L, par)) { fatal = true; break; }
             }
         }
+        rpar ^= 1;
         if (flush) {
             have_lists = false;   // the prefetched lists are for the wrong tasks (or the wrong base)
-            if (wave == 0 && lane < R5_B) L.ring[2 * lane] = 0xFFFFFFFFu;   // everything has landed (wait_vm above)
+            if (wave == 0 && lane < R5_B) {   // everything has landed
+                L.ring[2 * lane] = 0xFFFFFFFFu;
+                L.ring[2 * (R5_B + lane)] = 0xFFFFFFFFu;
+            }
             tkp = 0;
         } else {
             buf ^= 1;
             tkp ^= 1;
         }
+        R5_TICK(4);
     }
-    if (wave == 0 && pend_ci != 0xFFFFFFFFu) a.log_prev[pend_ci] = pend_prev;
+#undef R5_TICK
+    wv::barrier();
+    if (wave == R5_CW) {   // the last rounds' memory side
+        r5_commit_memory(a, L, 0, pend, false);
+        r5_commit_memory(a, L, 1, pend, true);
+    }
+    if (prof && lane == 0) a.ctl->wave_cyc[wave] += tc[0] >> 6;
+    if (prof && lane == 0 && wave == 1)
+        for (int q = 0; q < 5; ++q) a.ctl->l_cyc[q] += lcy[q] >> 6;
+    if (prof && tid == 0)
+    {
+        for (int q = 0; q < 3; ++q) a.ctl->m_cyc[q] += tm[q] >> 6;
+        a.ctl->m_cyc[3] += nadv;
+    }
+    if (prof && lane == 0 && wave < 2) {
+        u64* c = a.ctl->cyc + 4;   // 32-bit halves, units of 64 cycles
+        c[2 * wave] += (tc[0] >> 6) | ((tc[1] >> 6) << 32);
+        c[2 * wave + 1] += (tc[2] >> 6) | ((tc[3] >> 6) << 32);
+        if (wave == 0) a.ctl->pad1 += tc[4] >> 6;
+    }
     wv::barrier();
     for (u32 i = tid; i < a.n_nodes * 2; i += R5_THREADS) a.qres[i] = L.q[i];
     if (tid == 0) {
@@ -661,6 +888,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         a.ctl->cyc[1] += L.sh[R5S_FULL];
         a.ctl->cyc[2] += L.sh[R5S_CUT_CLASS];
         a.ctl->cyc[3] += L.sh[R5S_CUT_EMPTY];
+        a.ctl->spin_waits += L.sh[R5S_DEEP];
         if (fatal) {
             a.ctl->error = ERR_LEVEL_RANGE;
             a.ctl->resume = a.j0 + j;

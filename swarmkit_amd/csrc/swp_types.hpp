@@ -56,6 +56,9 @@ struct Ctl {
     u32 ncommit, ninf, error, resume;   // resume: first task NOT processed when `error` stopped a resolver (host continues from there)
     u64 verify_retries, slow_tasks, rebases, generic_tasks, spin_waits, pad1;
     u64 cyc[8];   // dbg&16: cycles spent in resolver sections
+    u64 m_cyc[4];       // dbg&16, k_resolve5 matcher: list load / matching loop / flush, units of 64 cycles
+    u64 l_cyc[8];       // dbg&16, k_resolve5 lister wave 1: sections of r5_list, units of 64 cycles
+    u64 wave_cyc[16];   // dbg&16, k_resolve5: per wave, cycles of work in phase 1 (match / list / memory commit), units of 64
 };
 
 enum { ERR_NONE = 0, ERR_LEVEL_RANGE = 1, ERR_GROUP_RANGE = 2 };
@@ -91,6 +94,7 @@ struct ResolveArgs {
     u32* inf_pos;
     Ctl* ctl;
     int32_t* qres;           // k_resolve5: [n_nodes][2] residual cpu / mem in the batch's resource units (floor division)
+    i64 unit_cpu, unit_mem;  // k_resolve5: the units (RTask.cpu == kc * unit_cpu, RTask.mem == km * unit_mem)
 };
 
 }  // namespace swpdev

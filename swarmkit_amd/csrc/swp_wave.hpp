@@ -61,29 +61,101 @@ WV_DEV void barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "me
 // the wave's LDS operations issued so far are done before any lane goes on: what one lane wrote (or or-ed) is what another
 // lane of the same wave reads next. The hardware executes one wave's LDS instructions in order; this pins the compiler too.
 WV_DEV void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// a point every lane of the wave passes together. The hardware runs a wave in lockstep, so this is only a compiler fence here;
+// the CPU emulation, whose lanes are separate fibers, rendezvous at it (e.g. all lanes have READ a word before one lane rewrites it).
+WV_DEV void lockstep() { asm volatile("" ::: "memory"); }
 // this wave's global stores / atomics / loads have completed (what a later wave behind a barrier may rely on)
 WV_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- LDS atomics (no return value: nothing to wait for) ----
 WV_DEV void lds_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_xor64(u64* p, u64 v) { __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void lds_or32(u32* p, u32 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ---- global memory ----
-WV_DEV void g_add64(i64* p, i64 v) { __hip_atomic_fetch_add(reinterpret_cast<u64*>(p), (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-WV_DEV void g_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-WV_DEV void g_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-WV_DEV u32 g_exch32(u32* p, u32 v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Everything the kernel exchanges through memory is exchanged between waves of ONE workgroup, so workgroup scope is all the
+// coherence it needs: the operations stay in this XCD's L2 (device scope would send every load past it, ~1 µs each).
+// What other kernels wrote is visible from the launch on, what this one writes at its end.
+WV_DEV void g_add64(i64* p, i64 v) { __hip_atomic_fetch_add(reinterpret_cast<u64*>(p), (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void g_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void g_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV u32 g_exch32(u32* p, u32 v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // loads that must see what other waves of this workgroup wrote through L2 (bypass the CU's vector L1)
-WV_DEV u64 g_fresh64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-WV_DEV u32 g_fresh32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-WV_DEV i64 g_fresh64s(const i64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-WV_DEV void g_store32_fresh(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV u64 g_fresh64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV u32 g_fresh32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV i64 g_fresh64s(const i64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void g_store32_fresh(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// pull the cache line at p into this XCD's L2 (the value is dropped; a later vmcnt wait of the wave covers it)
+WV_DEV void prefetch_l2(const void* p) {
+    u32 dummy;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(p) : "memory");
+}
 // wave-uniform read-only load: constant address space → s_load through the scalar cache
 template <class T>
 WV_DEV T uload(const T* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
 }
+
+// The matcher's inner loop (swp_resolve5.hpp), hand-scheduled: the serial chain of the whole engine.
+//   `todo`  scalar mask of the 32 lanes base..base+31 still to be served, in lane order
+//   `bits`  per lane: candidate bits of its current 32-node half-word `w`;  `pick` per lane: node taken (output)
+// while todo: i = lowest lane of todo; if lane i's bits are empty: stop and return i (todo keeps bit i);
+//             else lane i takes its lowest bit (pick[i] = w[i] * 32 + bit), the bit is struck from EVERY lane that sits on
+//             the same half-word, and i leaves todo.            Returns 0xFFFFFFFF when todo ran empty.
+// 19 instructions per task; the dependent chain is v_and → v_readlane → s_ff1 → s_bitset0 → v_and. All 64 lanes must be
+// active (the loop sets exec itself and restores it). SALU-written lane selects need no wait states on gfx9 (only VALU-
+// written ones do), which is why the lane index is computed on the scalar unit.
+WV_DEV u32 match_run32(u32& todo_io, u32 base_in, u32& bits, u32 w, u32& pick) {
+    // uniform values the compiler may keep in vector registers: the asm needs them on the scalar side
+    u32 todo = (u32)__builtin_amdgcn_readfirstlane((int)todo_io);
+    const u32 base = (u32)__builtin_amdgcn_readfirstlane((int)base_in);
+    u32 stop = 0xFFFFFFFFu, si, sl, sb, sw, sp, sn, sm, m0save;
+    u64 save;
+    asm volatile(
+        "s_setprio 3\n\t"
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b32 %[m0save], m0\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_cmp_eq_u32 %[todo], 0\n\t"
+        "s_cbranch_scc1 3f\n"
+        "1:\n\t"
+        "s_ff1_i32_b32 %[si], %[todo]\n\t"
+        "s_add_i32 %[sl], %[si], %[base]\n\t"
+        "v_readlane_b32 %[sb], %[bits], %[sl]\n\t"
+        "v_readlane_b32 %[sw], %[w], %[sl]\n\t"
+        "s_cmp_eq_u32 %[sb], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_bitset0_b32 %[todo], %[si]\n\t"
+        "s_ff1_i32_b32 %[sp], %[sb]\n\t"
+        "s_lshl_b32 %[sn], %[sw], 5\n\t"
+        "s_or_b32 %[sn], %[sn], %[sp]\n\t"
+        "s_mov_b32 m0, %[sl]\n\t"
+        "s_mov_b32 %[sm], -1\n\t"
+        "s_bitset0_b32 %[sm], %[sp]\n\t"
+        "v_writelane_b32 %[pick], %[sn], m0\n\t"
+        "v_cmpx_eq_u32_e32 vcc, %[sw], %[w]\n\t"
+        "v_and_b32_e32 %[bits], %[sm], %[bits]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_cmp_lg_u32 %[todo], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_branch 3f\n"
+        "2:\n\t"
+        "s_mov_b32 %[stop], %[sl]\n"
+        "3:\n\t"
+        "s_mov_b32 m0, %[m0save]\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "s_setprio 0\n\t"
+        : [todo] "+s"(todo), [bits] "+v"(bits), [pick] "+v"(pick), [stop] "+s"(stop), [si] "=&s"(si), [sl] "=&s"(sl), [sb] "=&s"(sb), [sw] "=&s"(sw),
+          [sp] "=&s"(sp), [sn] "=&s"(sn), [sm] "=&s"(sm), [save] "=&s"(save), [m0save] "=&s"(m0save)
+        : [base] "s"(base), [w] "v"(w)
+        : "vcc", "scc", "memory");
+    todo_io = todo;
+    return stop;
+}
+
+// shader clock (s_memtime); used by the kernel's section timers when ResolveArgs.dbg & 16
+WV_DEV u64 clock64() { return __builtin_amdgcn_s_memtime(); }
 
 WV_DEV int ffs64(u64 v) { return __ffsll((long long)v) - 1; }   // index of the lowest set bit (v != 0)
 WV_DEV int popc64(u64 v) { return __popcll(v); }

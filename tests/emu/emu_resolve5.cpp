@@ -293,6 +293,8 @@ static void emu_window(const Problem& p, State& s, u32 j0, u32 cnt, const std::v
     a.inf_pos = s.inf_pos.data();
     a.ctl = &s.ctl;
     a.qres = qres.data();
+    a.unit_cpu = p.UC;
+    a.unit_mem = p.UM;
     (void)Xpad;
     switch ((p.Wn + 63) / 64) {
     case 1: run_k<1>(a); break;

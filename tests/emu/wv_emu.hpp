@@ -28,6 +28,14 @@
 using std::max;
 using std::min;
 
+// deadlock reports name each thread's last collective: the caller's caller with -DEMU_DEEP_SITE (needs -O0 -fno-omit-frame-pointer;
+// resolve with addr2line), else the wrapper itself
+#ifdef EMU_DEEP_SITE
+#define EMU_SITE() __builtin_return_address(1)
+#else
+#define EMU_SITE() __builtin_return_address(0)
+#endif
+
 namespace emu {
 using swpdev::u32;
 using swpdev::u64;
@@ -85,6 +93,8 @@ struct Block {
     Ctx sched;
     u32 cur = 0;
     u64 switches = 0;
+    std::vector<void*> last_site;   // per thread: return address of its last collective / barrier call (deadlock report)
+    std::vector<u64> ncoll;
 };
 inline Block*& B() {
     static Block* b = nullptr;
@@ -112,6 +122,8 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
     blk.nthreads = nthreads;
     blk.fib.resize(nthreads);
     blk.waves.resize((nthreads + 63) / 64);
+    blk.last_site.assign(nthreads, nullptr);
+    blk.ncoll.assign(nthreads, 0);
     blk.lds.assign((lds_bytes + 7) / 8 + 8, 0xCDCDCDCDCDCDCDCDull);   // LDS is NOT zero-initialised on the device either
     blk.body = body;
     const size_t STK = 256 * 1024;
@@ -136,6 +148,9 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
             for (size_t w = 0; w < blk.waves.size(); ++w)
                 fprintf(stderr, "  wave %zu: %d lanes waiting in op %d\n", w, blk.waves[w].arrived, blk.waves[w].op);
             fprintf(stderr, "  barrier: %d arrived\n", blk.bar_arrived);
+            for (u32 t = 0; t < nthreads; ++t)
+                if ((t & 63) < 2 || (t & 63) > 61 || blk.last_site[t] != blk.last_site[t & ~63u])
+                    fprintf(stderr, "  thread %u: %llu collectives, last at %p\n", t, (unsigned long long)blk.ncoll[t], blk.last_site[t]);
             abort();
         }
         blk.cur = blk.runq.front();
@@ -148,8 +163,10 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
 }
 
 // wave collective: every lane contributes `v` (and the uniform `aux`); returns this lane's result
-inline u64 collective(int op, u64 v, u64 aux) {
+__attribute__((noinline)) inline u64 collective(int op, u64 v, u64 aux) {
     Block* b = B();
+    b->last_site[b->cur] = EMU_SITE();
+    b->ncoll[b->cur]++;
     const u32 t = b->cur, lane = t & 63, wave = t >> 6;
     WaveSync& ws = b->waves[wave];
     const u32 lanes = std::min<u32>(64, b->nthreads - wave * 64);
@@ -195,8 +212,15 @@ inline u64 collective(int op, u64 v, u64 aux) {
     return ws.result[lane];
 }
 
-inline void block_barrier() {
+__attribute__((noinline)) inline void block_barrier() {
     Block* b = B();
+    b->last_site[b->cur] = EMU_SITE();
+    b->ncoll[b->cur]++;
+    if (b->waves[b->cur >> 6].arrived) {
+        fprintf(stderr, "emu: thread %u (wave %u lane %u) reaches a barrier while %d lanes of its wave wait in collective op %d (aux %llu)\n", b->cur, b->cur >> 6,
+                b->cur & 63, b->waves[b->cur >> 6].arrived, b->waves[b->cur >> 6].op, (unsigned long long)b->waves[b->cur >> 6].aux);
+        abort();
+    }
     if (++b->bar_arrived < (int)b->nthreads) {
         yield_blocked();
         return;
@@ -227,10 +251,12 @@ inline u32 mbcnt(u64 mask) { return (u32)__builtin_popcountll(mask & ((1ull << l
 inline u32 min_u32(u32 v) { return (u32)emu::collective(emu::OP_MIN, v, 0); }
 inline void barrier() { emu::block_barrier(); }
 inline void wave_sync() { (void)emu::collective(emu::OP_SYNC, 0, 0); }
+inline void lockstep() { (void)emu::collective(emu::OP_SYNC, 1, 1); }
 inline void wait_vm() {}
 
 inline void lds_or64(u64* p, u64 v) { *p |= v; }
 inline void lds_xor64(u64* p, u64 v) { *p ^= v; }
+inline void lds_or32(u32* p, u32 v) { *p |= v; }
 inline void lds_andn64(u64* p, u64 v) { *p &= ~v; }
 
 inline void g_add64(i64* p, i64 v) { *p += v; }
@@ -241,8 +267,25 @@ inline u64 g_fresh64(const u64* p) { return *p; }
 inline u32 g_fresh32(const u32* p) { return *p; }
 inline i64 g_fresh64s(const i64* p) { return *p; }
 inline void g_store32_fresh(u32* p, u32 v) { *p = v; }
+inline void prefetch_l2(const void*) {}
 template <class T>
 inline T uload(const T* p) { return *p; }
+
+// reference semantics of the hand-scheduled matcher loop of swp_wave.hpp, on the collectives above
+inline u32 match_run32(u32& todo, u32 base, u32& bits, u32 w, u32& pick) {
+    while (todo) {
+        const u32 i = (u32)__builtin_ctz(todo), l = i + base;
+        const u32 sb = readlane(bits, l), sw = readlane(w, l);
+        if (sb == 0) return l;
+        todo &= todo - 1;
+        const u32 p = (u32)__builtin_ctz(sb);
+        if (lane() == l) pick = sw * 32 + p;
+        if (w == sw) bits &= ~(1u << p);
+    }
+    return 0xFFFFFFFFu;
+}
+
+inline u64 clock64() { return 0; }
 
 inline int ffs64(u64 v) { return __builtin_ffsll((long long)v) - 1; }
 inline int popc64(u64 v) { return __builtin_popcountll(v); }
