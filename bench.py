@@ -285,7 +285,7 @@ def main():
         "pair_evals_per_s": world * pairs / t_step,
         "placed": placed,
         "unplaceable": wl.T - placed,
-        "roofline": {"bound": "hbm", "kernel": {4: "k_resolve4", 3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}.get(int(st.get("last_resolver", 3)), "k_resolve"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": {105: "k_resolve5<exact>", 5: "k_resolve5<scan>", 3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}.get(int(st.get("last_resolver", 3)), "k_resolve"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows},
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_scan": ms_scan / K, "k_resolve": ms_resolve / K,

@@ -145,6 +145,11 @@ struct swp_batch {
     bool ran = false;
     int64_t unit_cpu = 1, unit_mem = 1;   // k_resolve5: gcd of the batch's reservations (RTask.kc / km count these units)
     bool units_ok = false;                // every reservation fits 2^30 units
+    // k_resolve5 exact mode: the distinct cpu / memory reservations of the batch as demand classes (RTask.flags carries the
+    // class indices); usable when they fit R5's row budget
+    std::vector<int32_t> thr;
+    uint32_t n_dc = 0, n_dm = 0;
+    bool exact_ok = false;
 
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
@@ -152,6 +157,7 @@ struct swp_batch {
     DevBuf d_con, d_plat, d_plug, d_sc, d_F, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
     DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
+    DevBuf d_thr;                          // k_resolve5 exact mode: thresholds of the demand-class rows
 };
 
 struct swp_engine {
@@ -431,6 +437,28 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             b->rt[i].kc = (uint32_t)kc;
             b->rt[i].km = (uint32_t)km;
         }
+        // demand classes of the exact mode: ResourceFilter (filter.go:77-84) becomes membership in two LDS rows per task
+        b->exact_ok = false;
+        b->thr.clear();
+        b->n_dc = b->n_dm = 0;
+        if (b->units_ok) {
+            std::set<uint32_t> sc_, sm_;
+            for (uint32_t i = 0; i < T; ++i)
+                if (b->rt[i].flags & RT_RES) {
+                    sc_.insert(b->rt[i].kc);
+                    sm_.insert(b->rt[i].km);
+                }
+            if (sc_.size() + sm_.size() <= r5_max_rows() && sc_.size() <= RT_DCLS_MASK && sm_.size() <= RT_DCLS_MASK) {
+                std::unordered_map<uint32_t, uint32_t> ic, im;
+                for (uint32_t v : sc_) { ic[v] = (uint32_t)b->thr.size(); b->thr.push_back((int32_t)v); }
+                b->n_dc = (uint32_t)sc_.size();
+                for (uint32_t v : sm_) { im[v] = (uint32_t)b->thr.size() - b->n_dc; b->thr.push_back((int32_t)v); }
+                b->n_dm = (uint32_t)sm_.size();
+                for (uint32_t i = 0; i < T; ++i)
+                    if (b->rt[i].flags & RT_RES) b->rt[i].flags |= (ic[b->rt[i].kc] << RT_DC_SHIFT) | (im[b->rt[i].km] << RT_DM_SHIFT);
+                b->exact_ok = true;
+            }
+        }
     }
     b->n_svc = (uint32_t)b->svc_global.size();
     b->n_sc = (uint32_t)b->triples.size();
@@ -544,6 +572,7 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     const uint32_t T = b->T;
     int rc;
     if ((rc = upload(e, b->d_rt, b->rt))) return rc;
+    if ((rc = upload(e, b->d_thr, b->thr))) return rc;
     if ((rc = upload(e, b->d_list_node0, b->list_node0))) return rc;
     if ((rc = upload(e, b->d_list_svc0, b->list_svc0))) return rc;
     if ((rc = upload(e, b->d_list_fail0, b->list_fail0))) return rc;
@@ -582,7 +611,7 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     W = std::min<uint32_t>(W, ((T + 63) / 64) * 64);
     b->window = W;
     b->n_windows = (T + W - 1) / W;
-    HIPCHECK(e, b->d_F.reserve((size_t)W * Wn * 8));
+    // d_F (the scan's window of feasibility rows) is reserved at run time: the exact mode of k_resolve5 does not use it
     HIPCHECK(e, b->d_log_node.reserve((size_t)T * 4));
     HIPCHECK(e, b->d_log_task.reserve((size_t)T * 4));
     HIPCHECK(e, b->d_log_prev.reserve((size_t)T * 4));
@@ -718,7 +747,10 @@ int batch_run(swp_engine* e, swp_batch* b) {
     size_t r2_lds = 0;
     // k_resolve5 (round resolver, default): needs <= 64 * R5_KMAX node words, its LDS layout (planes, lists, exact residuals as
     // 32-bit counts of the batch's resource units) and every residual / reservation below 2^30 units; else k_resolve3 and down
-    const size_t r5_lds = r5_lds_size(N, Wn);
+    // exact mode (default when the batch's demand classes fit): no scan, no F, the whole batch in one launch
+    const char* env_exact = getenv("SWP_R5_EXACT");
+    bool r5_exact = variant == 5 && b->exact_ok && !(env_exact && atoi(env_exact) == 0) && r5_lds_size(N, Wn, b->n_dc + b->n_dm) <= lds_budget;
+    const size_t r5_lds = r5_lds_size(N, Wn, r5_exact ? b->n_dc + b->n_dm : 0u);
     if (variant == 5) {
         bool ok = b->units_ok && r5_supports(Wn) && r5_lds <= lds_budget;
         for (uint32_t n = 0; ok && n < N; ++n) {
@@ -729,6 +761,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         }
         if (!ok) variant = 3;
     }
+    if (variant != 5) r5_exact = false;
     if (variant == 5) {
         HIPCHECK(e, b->d_qres.reserve((size_t)N * 8));
         hipLaunchKernelGGL(k_units, dim3((N + 255) / 256), dim3(256), 0, st, N, e->d_cpu.as<long long>(), e->d_mem.as<long long>(), (long long)b->unit_cpu,
@@ -766,8 +799,11 @@ int batch_run(swp_engine* e, swp_batch* b) {
     }
     uint32_t wi = 0;   // windows launched so far (profiling slots)
     auto run_windows = [&](uint32_t start, int variant) -> int {
-    for (uint32_t j0 = start; j0 < T; j0 += b->window, ++wi) {
-        const uint32_t cnt = std::min(b->window, T - j0);
+    const bool exact = r5_exact && variant == 5;
+    const uint32_t win = exact ? T : b->window;
+    if (!exact) HIPCHECK(e, b->d_F.reserve((size_t)b->window * Wn * 8));
+    for (uint32_t j0 = start; j0 < T; j0 += win, ++wi) {
+        const uint32_t cnt = std::min(win, T - j0);
         ScanArgs sa{};
         sa.n_nodes = N;
         sa.n_words = Wn;
@@ -783,7 +819,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         sa.F = b->d_F.as<u64>();
         dim3 sgrid((Wn + SCAN_WPW - 1) / SCAN_WPW, (cnt + SCAN_TCH - 1) / SCAN_TCH);
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 0], st));
-        hipLaunchKernelGGL(k_scan, sgrid, dim3(64), 0, st, sa);
+        if (!exact) hipLaunchKernelGGL(k_scan, sgrid, dim3(64), 0, st, sa);
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 1], st));
 
         ResolveArgs ra{};
@@ -823,6 +859,11 @@ int batch_run(swp_engine* e, swp_batch* b) {
             ra.qres = b->d_qres.as<int32_t>();
             ra.unit_cpu = b->unit_cpu;
             ra.unit_mem = b->unit_mem;
+            ra.sc = b->d_sc.as<u64>();
+            ra.thr = b->d_thr.as<int32_t>();
+            ra.n_dc = exact ? b->n_dc : 0u;
+            ra.n_dm = exact ? b->n_dm : 0u;
+            ra.exact = exact ? 1u : 0u;
             r = launch_resolve5(ra, r5_lds, st, e->device);
         } else if (variant == 3) {
             switch ((Wn + 63) / 64) {
@@ -985,7 +1026,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
                 hi(ctl.cyc[7]) / r, (double)ctl.pad1 * 64.0 / r);
         fprintf(stderr, "[swp] k_resolve5 matcher per round (cycles): list load %.0f, matching loop %.0f of which inside the scalar loop %.0f over %.1f entries\n", (double)ctl.m_cyc[0] * 64.0 / r, (double)ctl.m_cyc[1] * 64.0 / r,
                 (double)ctl.m_cyc[2] * 64.0 / r, (double)ctl.m_cyc[3] / r);
-        fprintf(stderr, "[swp] k_resolve5 lister wave 1 per round (cycles): prologue %.0f | per 4 tasks: row wait %.0f, level search %.0f, entries %.0f, validation %.0f\n",
+fprintf(stderr, "[swp] k_resolve5 lister wave 1 per round (cycles): prologue %.0f | per 4 tasks: row wait %.0f, level search %.0f, entries %.0f, validation %.0f\n",
                 (double)ctl.l_cyc[0] * 64.0 / r, (double)ctl.l_cyc[1] * 64.0 / r, (double)ctl.l_cyc[2] * 64.0 / r, (double)ctl.l_cyc[3] * 64.0 / r, (double)ctl.l_cyc[4] * 64.0 / r);
         fprintf(stderr, "[swp] k_resolve5 phase-1 work per wave and round (cycles):");
         for (int w = 0; w < 16; ++w) fprintf(stderr, " %.0f", (double)ctl.wave_cyc[w] * 64.0 / r);
@@ -996,11 +1037,11 @@ int batch_run(swp_engine* e, swp_batch* b) {
                 ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.cyc[4], ctl.cyc[5], ctl.ncommit, ctl.ninf, ctl.generic_tasks);
     if ((dbg_bits & 16) && ctl.cyc[7])
         fprintf(stderr, "[swp] shader clock: %llu cycles / %llu x10ns => %.0f MHz\n", ctl.cyc[6], ctl.cyc[7], (double)ctl.cyc[6] / ((double)ctl.cyc[7] * 0.01));
-    e->stats.last_windows = b->n_windows;
+    e->stats.last_windows = wi;   // resolver launches of this batch (1 in k_resolve5's exact mode: no scan windows)
     e->stats.last_static_classes = b->n_sc;
-    e->stats.scan_launches += b->n_windows;
-    e->stats.resolve_launches += b->n_windows;
-    e->stats.last_resolver = (uint32_t)variant;
+    e->stats.scan_launches += r5_exact ? 0u : wi;
+    e->stats.resolve_launches += wi;
+    e->stats.last_resolver = (uint32_t)variant + (r5_exact ? 100u : 0u);   // 105 = k_resolve5, exact mode
     b->ran = true;
     return SWP_OK;
 }

@@ -49,6 +49,7 @@ namespace swpdev {
 #define R5_THREADS 1024
 #define R5_KMAX 4                 // node words per lane: n_words <= 256 (16 384 nodes)
 #define R5_QLIM (1 << 30)         // residuals in resource units must stay below this (host checks)
+#define R5_RRMAX 64               // exact mode: demand-class rows (distinct cpu reservations + distinct memory reservations)
 
 enum { R5_NONE = 0, R5_FAST = 1, R5_INFEASIBLE = 2, R5_COMPLEX = 3 };
 enum { R5_CUT_NOT = 0, R5_CUT_RELIST = 1, R5_CUT_GENERIC = 2 };
@@ -72,6 +73,8 @@ struct R5Lds {
     u64* below;      // [rs]            nodes below the ring
     u64* tk;         // [2][rs]         picks of the previous / the current round
     u64* scratch;    // [R5_LW][rs]     per lister wave: same-service commits of the last round as a row
+    u64* rr;         // [n_rr][rs]      exact mode: nodes whose residual cpu (rows 0..n_dc-1) / memory (rows n_dc..) is >= the row's threshold
+    int32_t* thr;    // [R5_RRMAX]      the thresholds, resource units
     u64* red;        // [64]            block reductions
     u32* lists;      // [2][R5_B][R5_LIST_U32]
     u32* ring;       // [2][R5_B][2]    (service, node) of the last two rounds' commits, by round parity
@@ -82,12 +85,12 @@ struct R5Lds {
 };
 
 inline __host__ __device__ u32 r5_row_stride(u32 n_words) { return (n_words + 7u) & ~7u; }
-inline __host__ __device__ size_t r5_lds_bytes(u32 n_nodes, u32 n_words) {
+inline __host__ __device__ size_t r5_lds_bytes(u32 n_nodes, u32 n_words, u32 n_rr) {
     const size_t rs = r5_row_stride(n_words);
-    return (size_t)(R5_NBMAX + R5_J + 1 + 2 + R5_LW) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
-           (size_t)2 * R5_B * R5_HAND_U32 * 4 + R5S_COUNT * 4 + (size_t)n_nodes * 8;
+    return (size_t)(R5_NBMAX + R5_J + 1 + 2 + R5_LW + n_rr) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
+           (size_t)2 * R5_B * R5_HAND_U32 * 4 + R5S_COUNT * 4 + R5_RRMAX * 4 + (size_t)n_nodes * 8;
 }
-WV_DEV R5Lds r5_layout(u64* lds, u32 n_words) {
+WV_DEV R5Lds r5_layout(u64* lds, u32 n_words, u32 n_rr) {
     R5Lds L;
     L.rs = r5_row_stride(n_words);
     L.planes = lds;
@@ -95,12 +98,14 @@ WV_DEV R5Lds r5_layout(u64* lds, u32 n_words) {
     L.below = L.lv + (size_t)R5_J * L.rs;
     L.tk = L.below + L.rs;
     L.scratch = L.tk + 2 * L.rs;
-    L.red = L.scratch + (size_t)R5_LW * L.rs;
+    L.rr = L.scratch + (size_t)R5_LW * L.rs;
+    L.red = L.rr + (size_t)n_rr * L.rs;
     L.lists = reinterpret_cast<u32*>(L.red + 64);
     L.ring = L.lists + 2 * R5_B * R5_LIST_U32;
     L.hand = L.ring + 2 * R5_B * 2;
     L.sh = L.hand + 2 * R5_B * R5_HAND_U32;
-    L.q = reinterpret_cast<int32_t*>(L.sh + R5S_COUNT);
+    L.thr = reinterpret_cast<int32_t*>(L.sh + R5S_COUNT);
+    L.q = L.thr + R5_RRMAX;
     return L;
 }
 
@@ -222,32 +227,64 @@ WV_DEV bool r5_bump_level(const R5Lds& L, u32 NB, u32 lb, u32 w, u64 bit, u32 rl
     return (nl >> NB) != 0;
 }
 
+// ---- exact mode: the demand-class rows ------------------------------------------------------------------------------
+// ResourceFilter.Check (filter.go:77-84) as set membership: node n passes a task with reservations (kc, km) <=> n is in
+// RC[class of kc] & RM[class of km], RC[c] = {q_cpu >= thr[c]}, RM[c] = {q_mem >= thr[n_dc + c]}. Residuals only shrink inside a
+// batch, so a commit can only take bits away. One wave per node word: a ballot IS a row word. Needs q and thr in LDS.
+WV_DEV void r5_rr_build(const ResolveArgs& a, const R5Lds& L) {
+    const u32 lane = wv::lane(), n_rr = a.n_dc + a.n_dm;
+    for (u32 w = wv::wave(); w < L.rs; w += R5_THREADS / 64) {
+        const u32 n = w * 64 + lane;
+        const bool in = n < a.n_nodes;
+        const int32_t qc = in ? L.q[2 * n] : 0, qm = in ? L.q[2 * n + 1] : 0;
+        for (u32 c = 0; c < n_rr; ++c) {
+            const u64 word = wv::ballot(in && (c < a.n_dc ? qc : qm) >= L.thr[c]);
+            if (lane == 0) L.rr[(size_t)c * L.rs + w] = word;
+        }
+    }
+}
+// after a commit left node (w, bit) with residuals (qc, qm): the node leaves every row whose threshold it no longer meets.
+// Thresholds ascend within each group, so the largest one decides whether there is anything to do (the common case: not).
+WV_DEV void r5_rr_update(const R5Lds& L, u32 n_dc, u32 n_dm, u32 w, u64 bit, int32_t qc, int32_t qm) {
+    if (n_dc && qc < L.thr[n_dc - 1])
+        for (u32 c = 0; c < n_dc; ++c)
+            if (qc < L.thr[c]) wv::lds_andn64(L.rr + (size_t)c * L.rs + w, bit);
+    if (n_dm && qm < L.thr[n_dc + n_dm - 1])
+        for (u32 c = 0; c < n_dm; ++c)
+            if (qm < L.thr[n_dc + c]) wv::lds_andn64(L.rr + (size_t)(n_dc + c) * L.rs + w, bit);
+}
+
 // ---- lister: candidate lists of the round that starts at window-local task jbase, into list buffer `buf` ------------
 // F and X rows are requested one task ahead. (F was written by the scan on other XCDs — an L2 miss here, ~1 µs — so the
 // committer wave touches the rows of the round after next while it has nothing else to do: r5_touch_rows.)
-template <int K>
+// EXACT: the rows are sc[static class] & RC & RM (exact at the list's snapshot) instead of the scan's F row (a stale superset
+// that needs the validation step at the end).
+template <int K, bool EXACT>
 WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u32 lw, u64* lt) {
     const u32 lane = wv::lane();
     u64 lmark = lt ? wv::clock64() : 0;
 #define R5_LT(slot) do { if (lt) { const u64 n_ = wv::clock64(); lt[slot] += n_ - lmark; lmark = n_; } } while (0)
     const u32 NB = L.sh[R5S_NB], lb = L.sh[R5S_LB];
     const bool bel_any = L.sh[R5S_BELANY] != 0;
-    u32 fl_[R5_TPW], sv_[R5_TPW];
+    u32 fl_[R5_TPW], sv_[R5_TPW], sc_[R5_TPW];
     for (u32 t = 0; t < R5_TPW; ++t) {
         const u32 jj = jbase + lw + R5_LW * t;
         fl_[t] = 0;
         sv_[t] = 0;
+        sc_[t] = 0;
         if (jj < a.count) {   // uniform
             const RTask* rt = a.rt + a.j0 + jj;
             fl_[t] = wv::uload(&rt->flags);
             sv_[t] = wv::uload(&rt->svc);
+            if (EXACT) sc_[t] = wv::uload(&rt->sc);
         }
     }
     u64 Fn[K], Xn[K];
     for (int k = 0; k < K; ++k) {
         const u32 w = lane + 64 * k;
         const bool in = jbase + lw < a.count && w < a.n_words;
-        Fn[k] = in ? a.F[(size_t)(jbase + lw) * a.n_words + w] : 0ull;
+        if (EXACT) Fn[k] = in ? a.sc[(size_t)sc_[0] * a.n_words + w] : 0ull;
+        else Fn[k] = in ? a.F[(size_t)(jbase + lw) * a.n_words + w] : 0ull;
         Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[0] * a.xs + w) : 0ull;
     }
     // the lowest ring level and BELOW of this wave's words stay in registers for the round
@@ -278,7 +315,8 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             for (int k = 0; k < K; ++k) {
                 const u32 w = lane + 64 * k;
                 const bool in = jn < a.count && w < a.n_words;
-                Fn[k] = in ? a.F[(size_t)jn * a.n_words + w] : 0ull;
+                if (EXACT) Fn[k] = in ? a.sc[(size_t)sc_[t + 1] * a.n_words + w] : 0ull;
+                else Fn[k] = in ? a.F[(size_t)jn * a.n_words + w] : 0ull;
                 Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[t + 1] * a.xs + w) : 0ull;
             }
         }
@@ -291,6 +329,14 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
         if (flags & (RT_PORTS | RT_UNCOUNTED)) {
             if (lane == 0) { out[0] = R5_COMPLEX; out[1] = 0; }
             continue;
+        }
+        if (EXACT && (flags & RT_RES)) {   // uniform
+            const u64* rc = L.rr + (size_t)((flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * L.rs;
+            const u64* rm = L.rr + (size_t)(a.n_dc + ((flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * L.rs;
+            for (int k = 0; k < K; ++k) {
+                const u32 w = lane + 64 * k;
+                if (w < L.rs) F[k] &= rc[w] & rm[w];
+            }
         }
         u64 mk[K];
         // commits of the last two rounds may still be on their way to X in memory: patch them in from the ring
@@ -390,7 +436,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
         // ResourceFilter against the exact residuals (filter.go:77-84 in resource units): lane b checks node 64w + b
         const int32_t kc = (int32_t)wv::uload(&rt->kc), km = (int32_t)wv::uload(&rt->km);
         u32 some = 1;
-        if (flags & RT_RES) {
+        if (!EXACT && (flags & RT_RES)) {
             wv::wave_sync();
             // all four entries are read back first (same address in every lane: broadcast reads), then the residuals of the
             // four words, then the verdicts: two LDS latencies instead of eight
@@ -489,7 +535,7 @@ WV_DEV void r5_commit_memory(const ResolveArgs& a, const R5Lds& L, u32 hp, R5Pen
 // ---- one task through the generic workgroup path: k_resolve's algorithm on this kernel's state ----------------------
 // (plain nodes by bit-sliced minimum with re-check, then the service's exception list; scheduler.go:708-735.)
 // All 1024 threads; thread t owns node word t. Ends with a barrier; counters and flags are in L.sh.
-struct R5Rt { i64 cpu, mem; u32 flags, svc, slot, pset; u64 maxrep; int32_t kc, km; };
+struct R5Rt { i64 cpu, mem; u32 flags, svc, slot, pset, sc; u64 maxrep; int32_t kc, km; };
 WV_DEV R5Rt r5_load_rt(const RTask* rt) {
     R5Rt r;
     r.cpu = wv::uload(&rt->cpu);
@@ -498,6 +544,7 @@ WV_DEV R5Rt r5_load_rt(const RTask* rt) {
     r.svc = wv::uload(&rt->svc);
     r.slot = wv::uload(&rt->slot);
     r.pset = wv::uload(&rt->pset);
+    r.sc = wv::uload(&rt->sc);
     r.maxrep = wv::uload(&rt->maxrep);
     r.kc = (int32_t)wv::uload(&rt->kc);
     r.km = (int32_t)wv::uload(&rt->km);
@@ -513,6 +560,7 @@ WV_DEV void r5_commit_one(const ResolveArgs& a, const R5Lds& L, const R5Rt& r, u
     if (r.mem) wv::g_add64(a.mem + n, -r.mem);
     L.q[2 * n] -= r.kc;
     L.q[2 * n + 1] -= r.km;
+    if (a.exact && (r.kc | r.km)) r5_rr_update(L, a.n_dc, a.n_dm, w, bit, L.q[2 * n], L.q[2 * n + 1]);
     if (r.flags & RT_PORTS)
         for (u32 p = a.pset_off[r.pset]; p < a.pset_off[r.pset + 1]; ++p) wv::g_or64(a.portmap + (size_t)a.pset_ids[p] * a.n_words + w, bit);
     if (!(r.flags & RT_UNCOUNTED)) {
@@ -535,13 +583,24 @@ WV_DEV void r5_commit_one(const ResolveArgs& a, const R5Lds& L, const R5Rt& r, u
     wv::wait_vm();   // the listers read X / the lists through L2 right after the next barrier
 }
 
+template <bool EXACT>
 WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
     const u32 tid = wv::tid();
     const u32 gj = a.j0 + jj;
     const R5Rt r = r5_load_rt(a.rt + gj);
     const u32 NB = L.sh[R5S_NB];
     const bool mine = tid < a.n_words;
-    const u64 f = mine ? a.F[(size_t)jj * a.n_words + tid] : 0ull;
+    u64 f = 0;
+    if (mine) {
+        if (EXACT) {   // what the scan would have written for this task, against the state as it is now
+            f = a.sc[(size_t)r.sc * a.n_words + tid];
+            if (r.flags & RT_RES)
+                f &= L.rr[(size_t)((r.flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * L.rs + tid] & L.rr[(size_t)(a.n_dc + ((r.flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * L.rs + tid];
+            if (r.flags & RT_PORTS)
+                for (u32 p = a.pset_off[r.pset]; p < a.pset_off[r.pset + 1]; ++p) f &= ~wv::g_fresh64(a.portmap + (size_t)a.pset_ids[p] * a.n_words + tid);
+        } else
+            f = a.F[(size_t)jj * a.n_words + tid];
+    }
     u64 mk = mine ? f & ~wv::g_fresh64(a.X + (size_t)r.svc * a.xs + tid) : 0ull;
     const u32 idx_bits = 14, idx_mask = (1u << idx_bits) - 1u;   // n_nodes <= 16 384, levels < 256
     bool placed = false;
@@ -588,7 +647,7 @@ WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
             if (n == LIST_EMPTY) continue;
             const u32 w = n >> 6;
             const u64 bit = 1ull << (n & 63);
-            if (!(a.F[(size_t)jj * a.n_words + w] & bit)) continue;
+            if (!((EXACT ? a.sc[(size_t)r.sc * a.n_words + w] : a.F[(size_t)jj * a.n_words + w]) & bit)) continue;
             if ((r.flags & RT_RES) && !(L.q[2 * n] >= r.kc && L.q[2 * n + 1] >= r.km)) continue;
             if (r.flags & RT_PORTS) {
                 bool used = false;
@@ -624,22 +683,24 @@ WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool EXACT>
 WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
     const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave();
     if (wv::uload(&a.ctl->error) != ERR_NONE) return;   // an earlier window stopped: the host carries on from ctl->resume
-    const R5Lds L = r5_layout(wv::lds(), a.n_words);
+    const R5Lds L = r5_layout(wv::lds(), a.n_words, EXACT ? a.n_dc + a.n_dm : 0u);
     u32 par = 0;   // parity of the reduction scratch
 
     for (u32 i = tid; i < (2 + R5_LW) * L.rs; i += R5_THREADS) L.tk[i] = 0;   // TK rows and scratch rows are contiguous
     for (u32 i = tid; i < a.n_nodes * 2; i += R5_THREADS) L.q[i] = a.qres[i];
     for (u32 i = tid; i < 2 * R5_B * 2; i += R5_THREADS) L.ring[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
     if (tid < R5S_COUNT) L.sh[tid] = 0;
+    if (EXACT && tid < a.n_dc + a.n_dm) L.thr[tid] = a.thr[tid];
     wv::barrier();
     if (tid == 0) {
         L.sh[R5S_NCOMMIT] = a.ctl->ncommit;
         L.sh[R5S_NINF] = a.ctl->ninf;
     }
+    if (EXACT) r5_rr_build(a, L);   // the barriers of r5_build_planes order it before the first lister
     bool fatal = !r5_build_planes(a, L, par);   // ends with a barrier
 
     u32 j = 0;           // next window-local task
@@ -662,7 +723,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         const u32 nb = min((u32)R5_B, a.count - j);
         if (!have_lists) {
             // (re)fill: lists of [j, j+nb) against the state as it is; no earlier picks to strike
-            if (wave >= 1 && wave <= R5_LW) r5_list<K>(a, L, j, buf, wave - 1, nullptr);
+            if (wave >= 1 && wave <= R5_LW) r5_list<K, EXACT>(a, L, j, buf, wave - 1, nullptr);
             else if (wave == 0)
                 for (u32 i = lane; i < 2 * L.rs; i += 64) L.tk[i] = 0;
             wv::barrier();
@@ -671,15 +732,17 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         }
         // ---------------- phase 1: match round [j, j+nb) || list round [j+nb, ...) || memory side of the last round ----------
         if (wave >= 1 && wave <= R5_LW) {
-            r5_list<K>(a, L, j + nb, buf ^ 1, wave - 1, (prof && wave == 1) ? lcy : nullptr);
+            r5_list<K, EXACT>(a, L, j + nb, buf ^ 1, wave - 1, (prof && wave == 1) ? lcy : nullptr);
         } else if (wave == R5_CW) {
             r5_commit_memory(a, L, rpar ^ 1, pend, false);
-            r5_touch_rows(a, j + nb + R5_B);   // what the listers will read in the next round
+            if (!EXACT) r5_touch_rows(a, j + nb + R5_B);   // what the listers will read in the next round
         } else {
             const u32* li = L.lists + ((size_t)buf * R5_B + lane) * R5_LIST_U32;
             const u32* tkprev = reinterpret_cast<const u32*>(L.tk + (size_t)tkp * L.rs);
             u32* tkcur = reinterpret_cast<u32*>(L.tk + (size_t)(tkp ^ 1) * L.rs);
-            u32 cnt = 0, e = 0, w = 0, bits = 0;
+            u32 cnt = 0;
+            u32 eb[2 * R5_Q], ew[2 * R5_Q];   // the list as 32-node half-words (registers): candidate bits, half-word index
+            for (int k = 0; k < 2 * R5_Q; ++k) eb[k] = ew[k] = 0;
             m_cls = R5_NONE;
             m_pick = 0xFFFFFFFFu;
             if (lane < nb) {
@@ -693,9 +756,17 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 m_kc = li[4];
                 m_km = li[5];
                 m_slot = li[6];
-                w = 2 * li[R5_HDR_U32];
-                bits = li[R5_HDR_U32 + 2] & ~tkprev[w];
+                // half-word k of the list = half (k & 1) of its 64-node entry k / 2, minus the previous round's picks
+                for (int k = 0; k < 2 * R5_Q; ++k)
+                    if ((u32)k < cnt) {
+                        ew[k] = 2 * li[R5_HDR_U32 + 4 * (k >> 1)] + (k & 1);
+                        eb[k] = li[R5_HDR_U32 + 4 * (k >> 1) + 2 + (k & 1)] & ~tkprev[ew[k]];
+                    }
             }
+            // current half-word of every lane: the first one of its list that still has a candidate
+            u32 bits = 0, w = 0;
+            for (int k = 2 * R5_Q - 1; k >= 0; --k)
+                if (eb[k]) { bits = eb[k]; w = ew[k]; }
             const u64 fastmask = wv::ballot(fast), infmask = wv::ballot(m_cls == R5_INFEASIBLE);
             u64 tq = prof ? wv::clock64() : 0;
             if (prof) tm[0] += tq - tmark;
@@ -704,36 +775,31 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
             const u64 stop = ~(fastmask | infmask) & lanes;
             u32 cut = stop ? (u32)wv::ffs64(stop) : nb;
             u32 why = stop ? (u32)R5_CUT_GENERIC : (u32)R5_CUT_NOT;
-            const u64 todo64 = fastmask & ((1ull << cut) - 1ull);
+            u64 todo = fastmask & ((1ull << cut) - 1ull);
             u32 flushed = 0;   // picks of lanes < flushed are in tkcur
-            for (u32 half = 0; half < 2 && why != R5_CUT_RELIST; ++half) {
-                u32 todo = half ? (u32)(todo64 >> 32) : (u32)todo64;
-                while (todo) {
-                    const u64 ta_ = prof ? wv::clock64() : 0;
-                    const u32 at = wv::match_run32(todo, 32 * half, bits, w, m_pick);
-                    if (prof) { tm[2] += wv::clock64() - ta_; ++nadv; }
-                    if (at == 0xFFFFFFFFu) break;
-                    // task `at` (and maybe others) ran out of its current half-word: every such lane moves on through its list,
-                    // minus everything taken since the list's snapshot (previous round: tkprev; this round so far: tkcur)
-                    if (flushed < at) {
-                        if (lane >= flushed && lane < at && m_pick != 0xFFFFFFFFu) wv::lds_or32(tkcur + (m_pick >> 5), 1u << (m_pick & 31));
-                        flushed = at;
-                        wv::wave_sync();
-                    }
-                    for (;;) {
-                        const bool mv = fast && bits == 0 && e + 1 < cnt;
-                        if (!wv::ballot(mv)) break;
-                        if (mv) {
-                            ++e;   // half-word e of the list = half (e & 1) of its 64-node entry e / 2
-                            w = 2 * li[R5_HDR_U32 + 4 * (e >> 1)] + (e & 1);
-                            bits = li[R5_HDR_U32 + 4 * (e >> 1) + 2 + (e & 1)] & ~tkprev[w] & ~tkcur[w];
-                        }
-                    }
-                    if (wv::readlane(bits, at) == 0) {   // list exhausted: the next round starts here with a fresh list
-                        cut = at;
-                        why = R5_CUT_RELIST;
-                        break;
-                    }
+            for (;;) {
+                const u64 ta_ = prof ? wv::clock64() : 0;
+                const u32 at = wv::match_run64(todo, bits, w, m_pick);
+                if (prof) { tm[2] += wv::clock64() - ta_; ++nadv; }
+                if (at == 0xFFFFFFFFu) break;
+                // Task `at` ran out of its current half-word — and so, usually, did others that sat on it. Every such lane moves
+                // on in one go: this round's picks so far go to the TK row, each lane cleans all its half-words of them (the
+                // gathers are in flight together) and takes the first one that still has a candidate. Straight-line code, no
+                // loop: a lane's earlier half-words stay empty once they are (picks only accumulate), so recomputing from the
+                // registers is idempotent.
+                if (lane >= flushed && lane < at && m_pick != 0xFFFFFFFFu) wv::lds_or32(tkcur + (m_pick >> 5), 1u << (m_pick & 31));
+                flushed = at;
+                wv::wave_sync();
+                if (fast && bits == 0) {
+                    u32 t[2 * R5_Q];
+                    for (int k = 0; k < 2 * R5_Q; ++k) t[k] = eb[k] & ~tkcur[ew[k]];
+                    for (int k = 2 * R5_Q - 1; k >= 0; --k)
+                        if (t[k]) { bits = t[k]; w = ew[k]; }
+                }
+                if (wv::readlane(bits, at) == 0) {   // list exhausted: the next round starts here with a fresh list
+                    cut = at;
+                    why = R5_CUT_RELIST;
+                    break;
                 }
             }
             if (prof) { const u64 n_ = wv::clock64(); tm[1] += n_ - tq; tq = n_; }
@@ -782,6 +848,20 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
             if (lane < R5_B) {
                 L.ring[2 * (rpar * R5_B + lane)] = rsvc;
                 L.ring[2 * (rpar * R5_B + lane) + 1] = rnode;
+            }
+            if (EXACT) {
+                // demand-class rows: a committed node leaves every row whose threshold its residual no longer meets. The
+                // thresholds come through the scalar cache in a wave-uniform loop (ascending within each group: the largest
+                // one tells whether any lane has anything to do — mostly not)
+                const u32 n = com ? m_pick : 0u;
+                const int32_t qc = com ? L.q[2 * n] : R5_QLIM, qm = com ? L.q[2 * n + 1] : R5_QLIM;
+                const u32 ndc = a.n_dc, ndm = a.n_dm;
+                if (ndc && wv::ballot(qc < wv::uload(a.thr + ndc - 1)))
+                    for (u32 c = 0; c < ndc; ++c)
+                        if (qc < wv::uload(a.thr + c)) wv::lds_andn64(L.rr + (size_t)c * L.rs + (n >> 6), 1ull << (n & 63));
+                if (ndm && wv::ballot(qm < wv::uload(a.thr + ndc + ndm - 1)))
+                    for (u32 c = 0; c < ndm; ++c)
+                        if (qm < wv::uload(a.thr + ndc + c)) wv::lds_andn64(L.rr + (size_t)(ndc + c) * L.rs + (n >> 6), 1ull << (n & 63));
             }
             const bool low_pick = wv::ballot(com && m_lvl <= lb) != 0;
             const bool any_over = wv::ballot(over) != 0;
@@ -833,7 +913,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
             r5_ring_build(L, L.sh[R5S_LB] + 1);   // lists carry absolute levels: the pipeline goes on
         }
         if (cut < nb && why == R5_CUT_GENERIC) {
-            r5_generic(a, L, j, par);   // ends with a barrier
+            r5_generic<EXACT>(a, L, j, par);   // ends with a barrier
             j += 1;
             if (L.sh[R5S_REBUILD]) {
                 if (tid == 0) L.sh[R5S_REBASES] += 1;

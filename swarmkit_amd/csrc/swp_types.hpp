@@ -28,6 +28,11 @@ typedef uint32_t u32;
 #define RT_PORTS 0x2u      // host-port filter enabled
 #define RT_MAXREP 0x4u     // max-replicas filter enabled
 #define RT_UNCOUNTED 0x8u  // DesiredState > COMPLETED: placement does not bump the task counts
+// k_resolve5, exact mode: the task's demand classes (index into the batch's sorted distinct cpu / memory reservations,
+// ResolveArgs.thr) ride in the flag word. Meaningful only with RT_RES.
+#define RT_DC_SHIFT 8
+#define RT_DM_SHIFT 16
+#define RT_DCLS_MASK 0xFFu
 
 #define LIST_EMPTY 0xFFFFFFFFu
 #define KEY_NONE 0xFFFFFFFFFFFFFFFFull
@@ -95,6 +100,13 @@ struct ResolveArgs {
     Ctl* ctl;
     int32_t* qres;           // k_resolve5: [n_nodes][2] residual cpu / mem in the batch's resource units (floor division)
     i64 unit_cpu, unit_mem;  // k_resolve5: the units (RTask.cpu == kc * unit_cpu, RTask.mem == km * unit_mem)
+    // k_resolve5, exact mode (n_dc + n_dm > 0 or exact != 0): F is not used. Feasibility of a plain task is
+    // sc[task's static class] & RC[its cpu class] & RM[its memory class], where the demand-class rows live in LDS and are
+    // kept exact by every commit (a node's bit leaves a row when its residual drops below the row's threshold).
+    const u64* sc;           // [n_sc][n_words] static class rows (ready & constraint & platform & plugin)
+    const int32_t* thr;      // [n_dc + n_dm] thresholds in resource units: the distinct cpu reservations, then the memory ones
+    u32 n_dc, n_dm;
+    u32 exact;
 };
 
 }  // namespace swpdev

@@ -98,60 +98,49 @@ WV_DEV T uload(const T* p) {
 }
 
 // The matcher's inner loop (swp_resolve5.hpp), hand-scheduled: the serial chain of the whole engine.
-//   `todo`  scalar mask of the 32 lanes base..base+31 still to be served, in lane order
+//   `todo`  scalar mask of the lanes still to be served, in lane order
 //   `bits`  per lane: candidate bits of its current 32-node half-word `w`;  `pick` per lane: node taken (output)
 // while todo: i = lowest lane of todo; if lane i's bits are empty: stop and return i (todo keeps bit i);
 //             else lane i takes its lowest bit (pick[i] = w[i] * 32 + bit), the bit is struck from EVERY lane that sits on
 //             the same half-word, and i leaves todo.            Returns 0xFFFFFFFF when todo ran empty.
-// 19 instructions per task; the dependent chain is v_and → v_readlane → s_ff1 → s_bitset0 → v_and. All 64 lanes must be
-// active (the loop sets exec itself and restores it). SALU-written lane selects need no wait states on gfx9 (only VALU-
-// written ones do), which is why the lane index is computed on the scalar unit.
-WV_DEV u32 match_run32(u32& todo_io, u32 base_in, u32& bits, u32 w, u32& pick) {
+// 17 instructions per task; the dependent chain is v_bfi → v_readlane → s_ff1 → s_lshl → v_bfi. The wave must enter with all
+// 64 lanes active (exec is all ones afterwards). SALU-written lane selects need no wait states on gfx9 (only VALU-written
+// ones do), which is why the lane index is computed on the scalar unit.
+WV_DEV u32 match_run64(u64& todo_io, u32& bits, u32 w, u32& pick) {
     // uniform values the compiler may keep in vector registers: the asm needs them on the scalar side
-    u32 todo = (u32)__builtin_amdgcn_readfirstlane((int)todo_io);
-    const u32 base = (u32)__builtin_amdgcn_readfirstlane((int)base_in);
-    u32 stop = 0xFFFFFFFFu, si, sl, sb, sw, sp, sn, sm, m0save;
-    u64 save;
+    u64 todo = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(todo_io >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)todo_io);
+    u32 si, sb, sw, sp, sn, sm;
     asm volatile(
         "s_setprio 3\n\t"
-        "s_mov_b64 %[save], exec\n\t"
-        "s_mov_b32 %[m0save], m0\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_cmp_eq_u32 %[todo], 0\n\t"
+        "s_cmp_eq_u64 %[todo], 0\n\t"
         "s_cbranch_scc1 3f\n"
         "1:\n\t"
-        "s_ff1_i32_b32 %[si], %[todo]\n\t"
-        "s_add_i32 %[sl], %[si], %[base]\n\t"
-        "v_readlane_b32 %[sb], %[bits], %[sl]\n\t"
-        "v_readlane_b32 %[sw], %[w], %[sl]\n\t"
+        "s_ff1_i32_b64 %[si], %[todo]\n\t"
+        "v_readlane_b32 %[sb], %[bits], %[si]\n\t"
+        "v_readlane_b32 %[sw], %[w], %[si]\n\t"
         "s_cmp_eq_u32 %[sb], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_bitset0_b32 %[todo], %[si]\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_bitset0_b64 %[todo], %[si]\n\t"
         "s_ff1_i32_b32 %[sp], %[sb]\n\t"
         "s_lshl_b32 %[sn], %[sw], 5\n\t"
+        "s_lshl_b32 %[sm], 1, %[sp]\n\t"
         "s_or_b32 %[sn], %[sn], %[sp]\n\t"
-        "s_mov_b32 m0, %[sl]\n\t"
-        "s_mov_b32 %[sm], -1\n\t"
-        "s_bitset0_b32 %[sm], %[sp]\n\t"
-        "v_writelane_b32 %[pick], %[sn], m0\n\t"
         "v_cmpx_eq_u32_e32 vcc, %[sw], %[w]\n\t"
-        "v_and_b32_e32 %[bits], %[sm], %[bits]\n\t"
+        "v_bfi_b32 %[bits], %[sm], 0, %[bits]\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_cmp_lg_u32 %[todo], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_branch 3f\n"
-        "2:\n\t"
-        "s_mov_b32 %[stop], %[sl]\n"
+        "s_mov_b32 m0, %[si]\n\t"
+        "v_writelane_b32 %[pick], %[sn], m0\n\t"
+        "s_cmp_lg_u64 %[todo], 0\n\t"
+        "s_cbranch_scc1 1b\n"
         "3:\n\t"
-        "s_mov_b32 m0, %[m0save]\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
         "s_setprio 0\n\t"
-        : [todo] "+s"(todo), [bits] "+v"(bits), [pick] "+v"(pick), [stop] "+s"(stop), [si] "=&s"(si), [sl] "=&s"(sl), [sb] "=&s"(sb), [sw] "=&s"(sw),
-          [sp] "=&s"(sp), [sn] "=&s"(sn), [sm] "=&s"(sm), [save] "=&s"(save), [m0save] "=&s"(m0save)
-        : [base] "s"(base), [w] "v"(w)
-        : "vcc", "scc", "memory");
+        : [todo] "+s"(todo), [bits] "+v"(bits), [pick] "+v"(pick), [si] "=&s"(si), [sb] "=&s"(sb), [sw] "=&s"(sw), [sp] "=&s"(sp), [sn] "=&s"(sn),
+          [sm] "=&s"(sm)
+        : [w] "v"(w)
+        : "vcc", "scc", "m0", "memory");
     todo_io = todo;
-    return stop;
+    return todo ? (u32)__builtin_ctzll(todo) : 0xFFFFFFFFu;
 }
 
 // shader clock (s_memtime); used by the kernel's section timers when ResolveArgs.dbg & 16

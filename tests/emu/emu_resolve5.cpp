@@ -260,17 +260,42 @@ static void ref_window(const Problem& p, State& s, u32 j0, u32 cnt, const std::v
 
 template <int K>
 static void run_k(ResolveArgs a) {
-    emu::launch(R5_THREADS, r5_lds_bytes(a.n_nodes, a.n_words), [a]() { k_resolve5<K>(a); });
+    if (a.exact) emu::launch(R5_THREADS, r5_lds_bytes(a.n_nodes, a.n_words, a.n_dc + a.n_dm), [a]() { k_resolve5<K, true>(a); });
+    else emu::launch(R5_THREADS, r5_lds_bytes(a.n_nodes, a.n_words, 0), [a]() { k_resolve5<K, false>(a); });
 }
 
-static void emu_window(const Problem& p, State& s, u32 j0, u32 cnt, const std::vector<u64>& F, std::vector<int32_t>& qres, std::vector<u64>& Xpad) {
+// exact mode (what the engine's batch preparation does): the distinct reservations of the RT_RES tasks become demand classes
+struct Exact { bool on = false; std::vector<int32_t> thr; u32 n_dc = 0, n_dm = 0; };
+static Exact make_exact(Problem& p) {
+    Exact x;
+    std::set<u32> sc, sm;
+    for (const RTask& r : p.rt)
+        if (r.flags & RT_RES) { sc.insert(r.kc); sm.insert(r.km); }
+    if (sc.size() + sm.size() > R5_RRMAX || sc.size() > 255 || sm.size() > 255) return x;
+    x.on = true;
+    std::map<u32, u32> ic, im;
+    for (u32 v : sc) { ic[v] = (u32)x.thr.size(); x.thr.push_back((int32_t)v); }
+    x.n_dc = (u32)sc.size();
+    for (u32 v : sm) { im[v] = (u32)x.thr.size() - x.n_dc; x.thr.push_back((int32_t)v); }
+    x.n_dm = (u32)sm.size();
+    for (RTask& r : p.rt)
+        if (r.flags & RT_RES) r.flags |= (ic[r.kc] << RT_DC_SHIFT) | (im[r.km] << RT_DM_SHIFT);
+    return x;
+}
+
+static void emu_window(const Problem& p, State& s, u32 j0, u32 cnt, const std::vector<u64>& F, std::vector<int32_t>& qres, std::vector<u64>& Xpad, const Exact& ex) {
     ResolveArgs a{};
     a.n_nodes = p.N;
     a.n_words = p.Wn;
     a.j0 = j0;
     a.count = cnt;
     a.xs = p.Wn;
-    a.F = F.data();
+    a.F = ex.on ? nullptr : F.data();
+    a.sc = p.sc.data();
+    a.thr = ex.thr.data();
+    a.n_dc = ex.n_dc;
+    a.n_dm = ex.n_dm;
+    a.exact = ex.on ? 1u : 0u;
     a.valid = p.valid.data();
     a.X = s.X.data();
     a.rt = p.rt.data();
@@ -315,12 +340,18 @@ static bool same(const char* what, const V& a, const V& b, size_t n) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 8) { fprintf(stderr, "usage: %s seed N T S window order features(0..2) [verbose]\n", argv[0]); return 2; }
+    if (argc < 8) { fprintf(stderr, "usage: %s seed N T S window order features(0..2) [v|x ...]  (x: exact mode when the demand classes fit)\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), W = atoi(argv[5]);
     const int order = atoi(argv[6]);
     const int feat = atoi(argv[7]);
-    const bool verbose = argc > 8;
+    bool verbose = false, want_exact = false;
+    for (int i = 8; i < argc; ++i) {
+        if (argv[i][0] == 'v') verbose = true;
+        if (argv[i][0] == 'x') want_exact = true;
+    }
     Problem p = make_problem(seed, N, T, S, order, feat);
+    Exact ex;
+    if (want_exact) ex = make_exact(p);
     State ref = initial_state(p), em = initial_state(p);
     std::vector<int32_t> qres((size_t)N * 2);
     for (u32 n = 0; n < N; ++n) {
@@ -336,7 +367,7 @@ int main(int argc, char** argv) {
         std::vector<u64> F2;
         scan_window(p, em, j0, cnt, F2);
         if (F2 != F) { fprintf(stderr, "scan diverged before window %u\n", j0); return 1; }
-        emu_window(p, em, j0, cnt, F2, qres, Xpad);
+        emu_window(p, em, j0, cnt, F2, qres, Xpad, ex);
         if (em.ctl.error) { fprintf(stderr, "kernel reported error %u resume %u\n", em.ctl.error, em.ctl.resume); return 3; }
         ok = ok && same("out", em.out, ref.out, T) && same("cpu", em.cpu, ref.cpu, N) && same("mem", em.mem, ref.mem, N) &&
              same("total", em.total, ref.total, N) && same("X", em.X, ref.X, em.X.size()) && same("portmap", em.portmap, ref.portmap, em.portmap.size()) &&
@@ -354,8 +385,8 @@ int main(int argc, char** argv) {
             }
     }
     if (verbose || !ok)
-        fprintf(stderr, "seed %u N %u T %u S %u W %u order %d: placed %u inf %u | rounds %llu full %llu cut(class %llu, empty %llu) generic %llu retries %llu slow %llu rebases %llu -> %s\n", seed, N,
-                T, S, W, order, em.ctl.ncommit, em.ctl.ninf, em.ctl.cyc[0], em.ctl.cyc[1], em.ctl.cyc[2], em.ctl.cyc[3], em.ctl.generic_tasks, em.ctl.verify_retries, em.ctl.slow_tasks,
+        fprintf(stderr, "seed %u N %u T %u S %u W %u order %d exact %d: placed %u inf %u | rounds %llu full %llu cut(class %llu, empty %llu) generic %llu retries %llu slow %llu rebases %llu -> %s\n", seed, N,
+                T, S, W, order, (int)ex.on, em.ctl.ncommit, em.ctl.ninf, em.ctl.cyc[0], em.ctl.cyc[1], em.ctl.cyc[2], em.ctl.cyc[3], em.ctl.generic_tasks, em.ctl.verify_retries, em.ctl.slow_tasks,
                 em.ctl.rebases, ok ? "OK" : "FAIL");
     return ok ? 0 : 1;
 }

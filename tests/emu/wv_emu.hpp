@@ -272,9 +272,9 @@ template <class T>
 inline T uload(const T* p) { return *p; }
 
 // reference semantics of the hand-scheduled matcher loop of swp_wave.hpp, on the collectives above
-inline u32 match_run32(u32& todo, u32 base, u32& bits, u32 w, u32& pick) {
+inline u32 match_run64(u64& todo, u32& bits, u32 w, u32& pick) {
     while (todo) {
-        const u32 i = (u32)__builtin_ctz(todo), l = i + base;
+        const u32 l = (u32)__builtin_ctzll(todo);
         const u32 sb = readlane(bits, l), sw = readlane(w, l);
         if (sb == 0) return l;
         todo &= todo - 1;

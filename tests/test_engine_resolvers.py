@@ -1,6 +1,6 @@
 """GPU parity across the resolver kernels and their geometries: every variant (0 workgroup, 1 one-wave, 2 two-wave,
-3 two-wave specialised, 5 round resolver = the default) and every owned-words-per-lane count K must reproduce the oracle
-bit for bit."""
+3 two-wave specialised, 5 round resolver = the default, in its exact mode — demand-class rows, no scan — and "5s", the
+same kernel over the scan's F rows) and every owned-words-per-lane count K must reproduce the oracle bit for bit."""
 import os
 
 import pytest
@@ -13,21 +13,31 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def resolver_env():
-    old = os.environ.get("SWP_RESOLVER")
+    old = {k: os.environ.get(k) for k in ("SWP_RESOLVER", "SWP_R5_EXACT")}
     yield
-    if old is None:
-        os.environ.pop("SWP_RESOLVER", None)
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def pick_variant(variant):
+    os.environ.pop("SWP_R5_EXACT", None)
+    if variant == "5s":
+        os.environ["SWP_RESOLVER"] = "5"
+        os.environ["SWP_R5_EXACT"] = "0"
     else:
-        os.environ["SWP_RESOLVER"] = old
+        os.environ["SWP_RESOLVER"] = str(variant)
 
 
 CASES = [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg1", 500, 40, {}), ("cfg2", 3000, 50, {})]
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, "5s"])
 @pytest.mark.parametrize("name,T,N,kw", CASES)
 def test_variants_agree_with_oracle(resolver_env, variant, name, T, N, kw):
     wl = synth.Workload(name, T=T, N=N, **kw)
     op, oe, _ = pu.oracle_run(wl)
-    os.environ["SWP_RESOLVER"] = str(variant)
+    pick_variant(variant)
     ep, ee, *_ = pu.engine_run(wl)
     pu.assert_same(op, oe, ep, ee)
 
@@ -42,14 +52,14 @@ def test_words_per_lane(N):
     pu.assert_same(op, oe, ep, ee)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 5])
+@pytest.mark.parametrize("variant", [2, 3, 5, "5s"])
 @pytest.mark.parametrize("services,order", [(1, "rr"), (2, "rr"), (3, "major"), (40, "major"), (7, "rr")])
 def test_same_service_runs(resolver_env, variant, services, order):
     """Consecutive tasks of one service: every commit must be visible to the next task of that service although
     its staged exception row is older (the resolver's commit ring)."""
     wl = synth.Workload("cfg3", T=2000, N=700, services=services, order=order)
     op, oe, _ = pu.oracle_run(wl)
-    os.environ["SWP_RESOLVER"] = str(variant)
+    pick_variant(variant)
     ep, ee, *_ = pu.engine_run(wl)
     pu.assert_same(op, oe, ep, ee)
 

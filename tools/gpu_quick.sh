@@ -11,3 +11,8 @@ d = json.load(open("$O/bench.json"))
 print("ms_per_step", d["ms_per_step"], d["kernels_ms_per_step"])
 PY
 tail -4 $O/bench.err
+timeout 200 python bench.py --no-cpu-baseline --steps 5 --warmup 1 "$@" > $O/bench_nodbg.json 2> $O/bench_nodbg.err; python - <<PY
+import json
+d = json.load(open("$O/bench_nodbg.json"))
+print("nodbg ms_per_step", d["ms_per_step"], d["kernels_ms_per_step"])
+PY
