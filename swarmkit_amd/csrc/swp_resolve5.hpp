@@ -702,6 +702,16 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
     }
     if (EXACT) r5_rr_build(a, L);   // the barriers of r5_build_planes order it before the first lister
     bool fatal = !r5_build_planes(a, L, par);   // ends with a barrier
+    // exact mode, matcher wave: the demand-class thresholds it compares every commit with. Up to 8 + 8 of them live in
+    // registers (padding = a residual no node can have: never "below"); more than that are re-read through the scalar cache.
+    int32_t thr_c[8], thr_m[8], thr_cmax = -R5_QLIM, thr_mmax = -R5_QLIM;
+    const bool small_rr = EXACT && a.n_dc <= 8 && a.n_dm <= 8;
+    for (u32 c = 0; c < 8; ++c) {
+        thr_c[c] = (EXACT && c < a.n_dc && small_rr) ? wv::uload(a.thr + c) : -R5_QLIM;
+        thr_m[c] = (EXACT && c < a.n_dm && small_rr) ? wv::uload(a.thr + a.n_dc + c) : -R5_QLIM;
+    }
+    if (EXACT && a.n_dc) thr_cmax = wv::uload(a.thr + a.n_dc - 1);
+    if (EXACT && a.n_dm) thr_mmax = wv::uload(a.thr + a.n_dc + a.n_dm - 1);
 
     u32 j = 0;           // next window-local task
     u32 buf = 0;         // list buffer of the current round
@@ -856,12 +866,23 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 const u32 n = com ? m_pick : 0u;
                 const int32_t qc = com ? L.q[2 * n] : R5_QLIM, qm = com ? L.q[2 * n + 1] : R5_QLIM;
                 const u32 ndc = a.n_dc, ndm = a.n_dm;
-                if (ndc && wv::ballot(qc < wv::uload(a.thr + ndc - 1)))
-                    for (u32 c = 0; c < ndc; ++c)
-                        if (qc < wv::uload(a.thr + c)) wv::lds_andn64(L.rr + (size_t)c * L.rs + (n >> 6), 1ull << (n & 63));
-                if (ndm && wv::ballot(qm < wv::uload(a.thr + ndc + ndm - 1)))
-                    for (u32 c = 0; c < ndm; ++c)
-                        if (qm < wv::uload(a.thr + ndc + c)) wv::lds_andn64(L.rr + (size_t)(ndc + c) * L.rs + (n >> 6), 1ull << (n & 63));
+                u64* const rw = L.rr + (n >> 6);
+                const u64 rbit = 1ull << (n & 63);
+                if (small_rr) {   // thresholds in registers: no load on this path
+                    if (wv::ballot(qc < thr_cmax))
+                        for (u32 c = 0; c < 8; ++c)
+                            if (c < ndc && qc < thr_c[c]) wv::lds_andn64(rw + (size_t)c * L.rs, rbit);
+                    if (wv::ballot(qm < thr_mmax))
+                        for (u32 c = 0; c < 8; ++c)
+                            if (c < ndm && qm < thr_m[c]) wv::lds_andn64(rw + (size_t)(ndc + c) * L.rs, rbit);
+                } else {
+                    if (ndc && wv::ballot(qc < thr_cmax))
+                        for (u32 c = 0; c < ndc; ++c)
+                            if (qc < wv::uload(a.thr + c)) wv::lds_andn64(rw + (size_t)c * L.rs, rbit);
+                    if (ndm && wv::ballot(qm < thr_mmax))
+                        for (u32 c = 0; c < ndm; ++c)
+                            if (qm < wv::uload(a.thr + ndc + c)) wv::lds_andn64(rw + (size_t)(ndc + c) * L.rs, rbit);
+                }
             }
             const bool low_pick = wv::ballot(com && m_lvl <= lb) != 0;
             const bool any_over = wv::ballot(over) != 0;
