@@ -27,6 +27,44 @@ ROW_B = {"cfg2": 32, "cfg3": 48, "cfg4": 64}   # algorithmic node-row bytes per 
 TASK_B = 64 + 8                # descriptor + result per task, SURVEY.md §8d
 
 
+RESOLVER_NAMES = {105: "k_resolve5<exact>", 5: "k_resolve5<scan>", 3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}
+FILTERS = {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filters",
+           "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}
+
+
+def profile_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary of this round (profiles/r02_pmc_summary.json,
+    produced by tools/profile_round.sh on the GPU box) — a separate rocprofv3 --pmc pass cannot run inside the timed bench.
+    Returns (bytes or None, provenance string)."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
+        if not os.path.exists(path):
+            continue
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        per = doc.get("hbm_bytes_per_launch", {})
+        base = kernel.split("<")[0]
+        if base in per:
+            return per[base], "profiles/%s_pmc_summary.json (%s)" % (tag, doc.get("source", "rocprofv3 --pmc"))
+        if tag == "r01" and "k_resolve_hbm_bytes_per_launch" in doc and base == "k_resolve3":
+            return doc["k_resolve_hbm_bytes_per_launch"], "profiles/r01_pmc_summary.json (k_resolve3, round 1)"
+    return None, "no PMC summary for %s under profiles/" % kernel
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
 def cpu_baseline(wl, budget_s=12.0):
     """The CPU oracle (single thread, like the reference's single scheduling goroutine) on a bounded
     sample of the SAME workload: the full node set, the first `sample` tasks."""
@@ -54,10 +92,99 @@ def cpu_baseline(wl, budget_s=12.0):
         o.tick()
         d2 = time.perf_counter() - t0
         done, total_dt = sample, d2   # steady-state slice (cluster already partly filled, like the GPU pass on average)
-    return {"value": done / total_dt, "unit": "placements/s", "cores": 1, "kind": "port",
+    model, nproc = host_cpu()
+    return {"value": done / total_dt, "unit": "placements/s", "cores": 1, "kind": "port", "cpu_model": model, "nproc": nproc,
             "pair_evals_per_s": done * wl.N / total_dt,
             "sample": f"{done} consecutive one-off tasks of the same workload against all {wl.N} nodes "
                       f"(oracle tick() wall time {total_dt:.2f} s, after a {probe}-task warm-in)"}
+
+
+def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
+    """Node-range shards: the SAME 100k x 10k (or --workload / --tasks / --nodes) job, the node set split over the
+    ranks. Per step: device state restore, then rounds of {k_propose over a block of tasks on every shard, all-gather of the
+    proposal records (RCCL between ranks), the same merge on every rank, k_shard_apply on the owners} until the batch is
+    placed, then the explain pass. Strong scaling: the job is fixed, the node rows per GPU shrink with N."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from swarmkit_amd import abi, host, shard as swshard
+    rank, world = ranks.rank, ranks.world
+    firsts = [r[0] for r in ranges]
+    engines, batches = [eng], [eng.batch_prepare(descs)]
+    if world == 1:   # --shards G: the other engines live on this GPU too
+        for g in range(1, len(ranges)):
+            e2 = abi.Engine(device=ranks.local_rank, profile=True, shard_rank=g, shard_count=len(ranges))
+            s2 = host.HostScheduler(engine=e2)
+            engines.append(e2)
+            batches.append(e2.batch_prepare(host.load_workload(s2, wl, *ranges[g])))
+            batches[-1]._sched = s2
+    for e in engines:
+        e.state_save()
+
+    def make_driver():
+        if world > 1:
+            return swshard.RankShard(batches[0], rank, world, firsts, dist, ranks.device)   # cuda:<local rank> under RCCL, cpu if it fell back to gloo
+        return swshard.ShardGroup(batches, firsts)
+
+    def sync():
+        torch.cuda.synchronize()
+        ranks.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        for e in engines:
+            e.state_restore()
+        drv = make_driver()
+        out, _ = drv.run(want_hist=False)
+        return out, drv.rounds
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ms_prop = ms_apply = 0.0
+    n_launch = n_ptasks = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, rounds = step()
+        st = engines[0].stats()
+        ms_prop += st["ms_propose"]
+        ms_apply += st["ms_apply"]
+        n_launch += st["propose_launches"]
+        n_ptasks += st["propose_tasks"]
+    sync()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    K = max(args.steps, 1)
+    t_step = elapsed / K
+    placed = int((out >= 0).sum())
+    row_b = ROW_B.get(args.workload, 48)
+    n_local = ranges[rank if world > 1 else 0][1]
+    # dominant kernel of this path = k_propose (this rank's launches): tasks proposed x this shard's nodes x row bytes
+    alg_launch = (n_ptasks / max(n_launch, 1)) * n_local * row_b + (n_ptasks / max(n_launch, 1)) * TASK_B
+    launch_ms = ms_prop / max(n_launch, 1)
+    achieved = alg_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    traffic, traffic_src = profile_traffic("k_propose")
+    result = {
+        "metric": f"task placements/sec ({wl.T // 1000}k one-off tasks x {wl.N // 1000}k nodes, " + FILTERS.get(args.workload, args.workload) + ", spread)",
+        "value": wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": dict(wl.describe(), parallelism="node-shard", shards=len(ranges), engines_per_gpu=1 if world > 1 else len(ranges),
+                       exchange="all_gather of %d-byte proposal records per task and shard (%s)" % (abi.PROPOSAL_DTYPE.itemsize, "RCCL" if world > 1 else "host arrays, one process"),
+                       control_backend=ranks.backend, block=swshard.BLOCK, rounds_per_step=rounds, tasks_decided_per_round=wl.T / max(rounds, 1)),
+        "pair_evals_per_s": wl.T * wl.N / t_step, "placed": placed, "unplaceable": wl.T - placed,
+        "roofline": {"bound": "hbm", "kernel": "k_propose", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": launch_ms,
+                     "launches_per_step": n_launch / K,
+                     "note": "rank 0's shard; a task cut off a block is proposed again, so the tasks proposed per step exceed the batch (%.2fx)" % (n_ptasks / K / max(wl.T, 1))},
+        "kernels_ms_per_step": {"k_propose": ms_prop / K, "k_shard_apply": ms_apply / K},
+        "host_prep_s": {"intern+descriptors": t_host_prep},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl)
+    if rank == 0:
+        print(json.dumps(result))
+    for b in batches:
+        b.free()
+    ranks.close()
 
 
 def main():
@@ -75,6 +202,10 @@ def main():
                     help="one-off (headline, SURVEY 8d primary mode); grouped: S groups of T/S tasks through swp_schedule_groups (secondary mode); "
                          "enforce: the constraint enforcer's start-up sweep (SURVEY 8f-1) over the cluster the placement produced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "replicas", "node-shard"],
+                    help="auto: one engine at N=1; at N>1 the node set is sharded over the ranks (SURVEY 8e: contiguous node ranges, RCCL "
+                         "all-gather of the block's proposals, same merge on every rank). replicas: N independent clusters (no collective).")
+    ap.add_argument("--shards", type=int, default=0, help="N=1 only: run the node-shard protocol over this many engines on the one GPU")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,15 +219,31 @@ def main():
 
     from swarmkit_amd import abi, host, synth
 
-    # Multi-GPU (round 1): independent replicas — every rank schedules its own cluster of the same shape
-    # (seed offset by rank); no data-path collective. The node-sharded scan with an RCCL exchange is the
-    # next row of SURVEY.md §8e.
-    wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=ranks.replica_seed(0x5EED0000), order=args.order)
-    eng = abi.Engine(device=local_rank, window=args.window, profile=True)
-    sched = host.HostScheduler(engine=eng)
-    t0 = time.perf_counter()
-    descs = host.load_workload(sched, wl)
-    t_host_prep = time.perf_counter() - t0
+    par = args.parallelism
+    if par == "auto":
+        par = "node-shard" if (world > 1 or args.shards > 1) else "single"
+    shard_mode = par == "node-shard" and args.mode == "one-off"
+    if shard_mode:
+        # every rank sees the SAME cluster and task list and owns one contiguous range of the canonical node order
+        from swarmkit_amd import shard as swshard
+        wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, order=args.order)
+        n_shards = world if world > 1 else max(args.shards, 1)
+        shard_ranges_ = swshard.shard_ranges(wl.N, n_shards)
+        my = rank if world > 1 else 0
+        eng = abi.Engine(device=local_rank, window=args.window, profile=True, shard_rank=my, shard_count=n_shards)
+        sched = host.HostScheduler(engine=eng)
+        t0 = time.perf_counter()
+        descs = host.load_workload(sched, wl, *shard_ranges_[my])
+        t_host_prep = time.perf_counter() - t0
+    else:
+        # replicas: every rank schedules its own cluster of the same shape (seed offset by rank); no data-path collective
+        shard_ranges_ = None
+        wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=ranks.replica_seed(0x5EED0000), order=args.order)
+        eng = abi.Engine(device=local_rank, window=args.window, profile=True)
+        sched = host.HostScheduler(engine=eng)
+        t0 = time.perf_counter()
+        descs = host.load_workload(sched, wl)
+        t_host_prep = time.perf_counter() - t0
     if args.mode == "churn":
         # BASELINE configs[4] / SURVEY 8d cfg5: place the batch once, then rounds of {reactivate the previous round's
         # drained nodes, drain a seeded random 10 % of the nodes, remove the tasks on them, re-place as many new tasks}.
@@ -213,6 +360,9 @@ def main():
                               "pair_evals_per_s": world * wl.S * wl.N / t_step, "placed": int((out >= 0).sum())}))
         ranks.close()
         return
+    if shard_mode:
+        run_sharded(args, ranks, wl, eng, sched, descs, shard_ranges_, t_host_prep)
+        return
     t0 = time.perf_counter()
     batch = eng.batch_prepare(descs)
     t_prepare = time.perf_counter() - t0
@@ -245,30 +395,38 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = ranks.max_over_ranks(elapsed)
 
+    # end to end, outside the timed region: what a caller of swp_schedule_batch waits for — de-duplication of the predicate
+    # sets + H2D of the descriptors (swp_batch_prepare), the device pass, D2H of placements AND explanation histograms
+    e2e = []
+    for _ in range(2):
+        eng.state_restore()
+        t0 = time.perf_counter()
+        b2 = eng.batch_prepare(descs)
+        b2.run()
+        b2.results(want_hist=True)
+        e2e.append(time.perf_counter() - t0)
+        b2.free()
+    t_e2e = min(e2e)
+
     st = eng.stats()
     K = max(args.steps, 1)
-    windows = st["last_windows"]
+    windows = max(int(st["last_windows"]), 1)
     placed = int((out >= 0).sum())
     pairs = wl.T * wl.N
     row_b = ROW_B.get(args.workload, 48)
     alg_bytes_step = pairs * row_b + wl.T * TASK_B
     t_step = elapsed / K
-    # dominant kernel = k_resolve3 (sequential argmin + residual-update commit): one launch per window
-    res_launch_ms = ms_resolve / K / max(windows, 1)
-    alg_bytes_launch = alg_bytes_step / max(windows, 1)
+    # dominant kernel = the resolver (sequential argmin + residual-update commit): `windows` launches per step (1 for
+    # k_resolve5's exact mode, which needs no scan window)
+    res_launch_ms = ms_resolve / K / windows
+    alg_bytes_launch = alg_bytes_step / windows
     achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(prof):
-        try:
-            traffic = json.load(open(prof)).get("k_resolve_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    kernel = RESOLVER_NAMES.get(int(st.get("last_resolver", 3)), "k_resolve")
+    traffic, traffic_src = profile_traffic(kernel)
 
     result = {
         "metric": f"task placements/sec ({wl.T // 1000}k one-off tasks x {wl.N // 1000}k nodes, "
-                  + {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filters", "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}.get(args.workload, args.workload)
-                  + ", spread)",
+                  + FILTERS.get(args.workload, args.workload) + ", spread)",
         "value": world * wl.T / t_step,
         "unit": "placements/s",
         "n_gpus": world,
@@ -280,22 +438,27 @@ def main():
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
-        "config": dict(wl.describe(), parallelism="replicas" if world > 1 else "single", control_backend=ranks.backend, window=int(st["last_windows"] and -(-wl.T // st["last_windows"])),
-                       static_classes=st["last_static_classes"]),
+        "config": dict(wl.describe(), parallelism="replicas (independent clusters, no data-path collective)" if world > 1 else "single", control_backend=ranks.backend,
+                       resolver_launches_per_step=windows, static_classes=st["last_static_classes"]),
         "pair_evals_per_s": world * pairs / t_step,
         "placed": placed,
         "unplaceable": wl.T - placed,
-        "roofline": {"bound": "hbm", "kernel": {105: "k_resolve5<exact>", 5: "k_resolve5<scan>", 3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}.get(int(st.get("last_resolver", 3)), "k_resolve"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows},
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows,
+                     "note": "algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the resolver decides from bitmaps held in LDS, so its real HBM "
+                             "traffic is far below that (see traffic): the kernel is bound by one workgroup's instruction issue, not by HBM"},
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_scan": ms_scan / K, "k_resolve": ms_resolve / K,
                                 "k_explain": ms_explain / K, "device_total": ms_dev / K},
+        "scan": ({"kernel": "k_scan", "ms_per_step": ms_scan / K, "algorithmic_GBs": alg_bytes_step / (ms_scan / K * 1e-3) / 1e9,
+                  "note": "node rows are re-used from registers across 64 tasks, so the algorithmic figure exceeds the HBM peak; real traffic is ~1 bit per pair"}
+                 if ms_scan / K > 0.05 else {"kernel": None, "note": "no scan pass: k_resolve5's exact mode evaluates the ResourceFilter as membership in demand-class rows kept in LDS"}),
         "whole_job_algorithmic_GBs": alg_bytes_step / t_step / 1e9,
-        "k_scan_algorithmic_GBs": (alg_bytes_step / (ms_scan / K * 1e-3) / 1e9) if ms_scan > 0 else None,
+        "end_to_end": {"ms": t_e2e * 1e3, "placements_per_s": wl.T / t_e2e,
+                       "includes": "swp_batch_prepare (predicate de-duplication + H2D of the task descriptors) + device pass + D2H of placements and Explain histograms",
+                       "swp_batch_prepare_ms": t_prepare * 1e3},
         "host_prep_s": {"intern+descriptors": t_host_prep, "swp_batch_prepare": t_prepare},
         "resolver_raw": {k: st[k] for k in ("generic_tasks", "resolver_spins", "verify_retries", "slow_path_tasks", "rebase_events", "batches")},
-        "resolver": {"verify_retries": st["verify_retries"] // max(st["resolve_launches"] // max(windows, 1), 1),
-                     "slow_path_tasks": st["slow_path_tasks"] // max(st["resolve_launches"] // max(windows, 1), 1)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bounded sample, ~15 s of one host core)
         result["cpu_baseline"] = cpu_baseline(wl)

@@ -236,6 +236,60 @@ void swp_batch_free(swp_engine*, swp_batch*);
 int swp_state_save(swp_engine*);
 int swp_state_restore(swp_engine*);
 
+/* ------------------------------------------------------------------------------------------ */
+/* node-range shards: the nodeSet split over several engines — one per GPU of a  */
+/* node, or several on one GPU — each owning a contiguous range of the canonical node order      */
+/* (shard g's nodes all precede shard g+1's). The scan nodeSet.tree does over ALL nodes           */
+/* (nodeset.go:57-120) becomes: every shard proposes, for a block of pending tasks, its best       */
+/* candidates against its current state; the proposals are exchanged (RCCL all-gather between     */
+/* ranks, plain pointers inside one process); every participant merges them with the SAME          */
+/* deterministic rule and learns which tasks of the block are decided; the owner of each picked    */
+/* node applies the placement (NodeInfo.addTask, nodeinfo.go:108-154).                             */
+/*                                                                                                 */
+/* Exactness: inside a batch a node's key (scheduler.go:708-735) only grows and feasibility only    */
+/* shrinks, so a task's best node against the block's snapshot stays its best node until an         */
+/* earlier task of the same block takes it. A proposal therefore lists the first SWP_SHARD_CAND      */
+/* non-empty 64-node words of the task's survivors at its minimum level, in node order (a wave's     */
+/* ballot IS such a word); the merge walks the shards in range order at the global minimum level     */
+/* and gives the task the first listed node no earlier task of the block took. The block is cut — the remaining tasks are proposed again against the new        */
+/* state — when a list runs out (a taken node sits one level up and may precede what was not         */
+/* listed) or when a task must fall back to its service's exception list (nodes where the service    */
+/* already runs / that failed it: their order changes with every placement of that service), unless  */
+/* it is the first task of the block, for which the snapshot IS the sequential state. The first      */
+/* task of a block is always decided, so every round makes progress.                                 */
+#define SWP_SHARD_CAND 4
+typedef struct {
+    uint32_t level;          /* ActiveTasksCount of the shard's best plain candidates; 0xFFFFFFFF = none */
+    uint32_t n_cand;         /* words listed; bit 31: the shard has more nodes of that level after the last word listed */
+    uint32_t word[SWP_SHARD_CAND]; /* shard-local word indices (node = 64 * word + bit), ascending */
+    uint64_t bits[SWP_SHARD_CAND]; /* the level's survivors inside each word */
+    uint64_t exc_hi;         /* best exception-list candidate: (failure class << 32 | svcCount); ~0 = none */
+    uint64_t exc_lo;         /*                                (ActiveTasksCount << 32 | shard-local node) */
+    uint32_t exc_entry;      /* its entry in the shard's exception list */
+    uint32_t reserved;
+} swp_proposal;              /* 80 bytes */
+typedef struct {
+    int32_t  shard;          /* owner of the picked node; -1 = no suitable node on any shard */
+    uint32_t node;           /* shard-local node index */
+    uint32_t entry;          /* exception-list entry the pick came from, 0xFFFFFFFF for a plain node */
+    uint32_t reserved;
+} swp_shard_pick;            /* 16 bytes */
+/* per-batch device state to pristine + predicate class bitmaps (what swp_batch_run does before its first window) */
+int swp_shard_begin(swp_engine*, swp_batch*);
+/* proposals of tasks [j0, j0+count) against the shard's current state; out = host array[count]; blocks until done */
+int swp_shard_propose(swp_engine*, swp_batch*, uint32_t j0, uint32_t count, swp_proposal* out);
+/* the merge (pure function, no engine): proposals[g] = shard g's array[count], shards in range order.
+ * picks[0 .. *accepted) are decided; the next block starts at j0 + *accepted (>= 1 whenever count >= 1). */
+int swp_shard_merge(const swp_proposal* const* proposals, const uint32_t* shard_first_node, uint32_t n_shards, uint32_t count,
+                    swp_shard_pick* picks, uint32_t* accepted);
+/* apply the decided prefix: the picks whose shard == swp_config.shard_rank change this engine's node rows, exception
+ * bitmaps / lists, host ports and commit log; every engine counts all of them (the commit log is numbered globally) and
+ * records the unplaceable tasks for its explain pass */
+int swp_shard_commit(swp_engine*, swp_batch*, uint32_t j0, const swp_shard_pick* picks, uint32_t accepted);
+/* end of the batch: Explain histograms of the unplaceable tasks over THIS shard's nodes (sum them over the shards),
+ * shard-local node index of the tasks placed here (-1 elsewhere), and the placements folded into the host mirror */
+int swp_shard_end(swp_engine*, swp_batch*, int32_t* out_node_local, uint32_t* out_fail_hist);
+
 /* NodeInfo.addTask / removeTask for tasks the engine did not place itself (event handlers
  * scheduler.go:254-366; rollback :472-487). add_or_remove: 1 = add, 0 = remove. */
 typedef struct {
@@ -296,7 +350,11 @@ typedef struct {
     uint32_t n_nodes, n_words, last_windows, last_static_classes;
     float    ms_classes, ms_scan, ms_resolve, ms_explain, ms_total;   /* last batch, SWP_CFG_PROFILE */
     uint32_t scan_launches, resolve_launches;
-    uint32_t last_resolver;     /* resolver kernel of the last batch: 3 = k_resolve3, 2 = k_resolve2, 1 = k_resolve1, 0 = k_resolve */
+    uint32_t last_resolver;     /* resolver kernel of the last batch: 105 = k_resolve5 exact mode, 5 = k_resolve5 over the scan's rows,
+                                   3 = k_resolve3, 2 = k_resolve2, 1 = k_resolve1, 0 = k_resolve */
+    /* node-range shard protocol, last batch (since swp_shard_begin); the times need SWP_CFG_PROFILE */
+    float    ms_propose, ms_apply;          /* Σ k_propose / k_shard_apply launch durations */
+    uint32_t propose_launches, propose_tasks;   /* launches and Σ tasks proposed (a task cut off a block is proposed again) */
 } swp_stats_t;
 
 int swp_create(const swp_config*, swp_engine** out);

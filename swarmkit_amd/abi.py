@@ -71,7 +71,8 @@ class Stats(C.Structure):
                 ("generic_tasks", C.c_uint64), ("resolver_spins", C.c_uint64),
                 ("n_nodes", C.c_uint32), ("n_words", C.c_uint32), ("last_windows", C.c_uint32), ("last_static_classes", C.c_uint32),
                 ("ms_classes", C.c_float), ("ms_scan", C.c_float), ("ms_resolve", C.c_float), ("ms_explain", C.c_float), ("ms_total", C.c_float),
-                ("scan_launches", C.c_uint32), ("resolve_launches", C.c_uint32), ("last_resolver", C.c_uint32)]
+                ("scan_launches", C.c_uint32), ("resolve_launches", C.c_uint32), ("last_resolver", C.c_uint32),
+                ("ms_propose", C.c_float), ("ms_apply", C.c_float), ("propose_launches", C.c_uint32), ("propose_tasks", C.c_uint32)]
 
 
 # numpy views of the POD structs, for bulk construction
@@ -82,6 +83,12 @@ PLACEMENT_DTYPE = np.dtype([("node", "<u4"), ("service", "<u4"), ("cpu", "<i8"),
 ENF_NODE_DTYPE = np.dtype([("node", "<u4"), ("first_task", "<u4"), ("n_tasks", "<u4"), ("reserved", "<u4"), ("cpu", "<i8"), ("mem", "<i8")])
 ENF_TASK_DTYPE = np.dtype([("cpu", "<i8"), ("mem", "<i8"), ("constraint_set", "<u4"), ("flags", "<u4"), ("desired_state", "<u4"), ("state", "<u4")])
 ENF_RESERVATIONS = 1
+# node-range shards (include/swp.h): swp_proposal / swp_shard_pick
+SHARD_CAND = 4
+PROPOSAL_DTYPE = np.dtype([("level", "<u4"), ("n_cand", "<u4"), ("word", "<u4", (SHARD_CAND,)), ("bits", "<u8", (SHARD_CAND,)), ("exc_hi", "<u8"),
+                           ("exc_lo", "<u8"), ("exc_entry", "<u4"), ("reserved", "<u4")])
+PICK_DTYPE = np.dtype([("shard", "<i4"), ("node", "<u4"), ("entry", "<u4"), ("reserved", "<u4")])
+assert PROPOSAL_DTYPE.itemsize == 80 and PICK_DTYPE.itemsize == 16
 assert ENF_NODE_DTYPE.itemsize == 32 and ENF_TASK_DTYPE.itemsize == 32
 assert TASK_DTYPE.itemsize == C.sizeof(TaskDesc) == 64
 assert PLACEMENT_DTYPE.itemsize == C.sizeof(Placement) == 32
@@ -168,6 +175,11 @@ def load_library(path=None):
         "swp_state_save": ([vp], C.c_int),
         "swp_state_restore": ([vp], C.c_int),
         "swp_commit": ([vp, vp, u32, C.c_int], C.c_int),
+        "swp_shard_begin": ([vp, vp], C.c_int),
+        "swp_shard_propose": ([vp, vp, u32, u32, vp], C.c_int),
+        "swp_shard_merge": ([P(vp), P(u32), u32, u32, vp, P(u32)], C.c_int),
+        "swp_shard_commit": ([vp, vp, u32, vp, u32], C.c_int),
+        "swp_shard_end": ([vp, vp, vp, vp], C.c_int),
         "swp_check_node": ([vp, P(TaskDesc), u32, P(i32)], C.c_int),
         "swp_enforce": ([vp, vp, u32, vp, u32, vp], C.c_int),
         "swp_node_matches": ([vp, vp, u32, vp, u32], C.c_int),
@@ -215,6 +227,22 @@ def load_library(path=None):
     return L
 
 
+def shard_merge(proposals, first_nodes, lib_path=None):
+    """swp_shard_merge: proposals = one PROPOSAL_DTYPE array per shard (range order, same length), first_nodes = the global
+    index of each shard's first node. Returns the decided prefix as a PICK_DTYPE array (length >= 1 for a non-empty block)."""
+    L = load_library(lib_path)
+    G, count = len(proposals), len(proposals[0])
+    props = [np.ascontiguousarray(p, dtype=PROPOSAL_DTYPE) for p in proposals]
+    ptrs = (C.c_void_p * G)(*[p.ctypes.data for p in props])
+    firsts = (C.c_uint32 * G)(*[int(x) for x in first_nodes])
+    picks = np.zeros(count, dtype=PICK_DTYPE)
+    acc = C.c_uint32(0)
+    rc = L.swp_shard_merge(ptrs, firsts, G, count, picks.ctypes.data, C.byref(acc))
+    if rc != 0:
+        raise SwpError(rc, "swp_shard_merge")
+    return picks[:acc.value]
+
+
 class Batch:
     def __init__(self, eng, handle, n):
         self.eng, self.h, self.n = eng, handle, n
@@ -234,6 +262,25 @@ class Batch:
         self.eng._ck(self.eng.L.swp_batch_results(self.eng.h, self.h, out.ctypes.data, hist.ctypes.data if want_hist else None))
         return out, hist
 
+    # ---- node-range shard protocol (include/swp.h "node-range shards") ----
+    def shard_begin(self):
+        self.eng._ck(self.eng.L.swp_shard_begin(self.eng.h, self.h))
+
+    def shard_propose(self, j0, count):
+        out = np.empty(count, dtype=PROPOSAL_DTYPE)
+        self.eng._ck(self.eng.L.swp_shard_propose(self.eng.h, self.h, j0, count, out.ctypes.data))
+        return out
+
+    def shard_commit(self, j0, picks):
+        picks = np.ascontiguousarray(picks, dtype=PICK_DTYPE)
+        self.eng._ck(self.eng.L.swp_shard_commit(self.eng.h, self.h, j0, picks.ctypes.data, len(picks)))
+
+    def shard_end(self, want_hist=True):
+        out = np.empty(self.n, dtype=np.int32)
+        hist = np.zeros((self.n, NFILTERS), dtype=np.uint32) if want_hist else None
+        self.eng._ck(self.eng.L.swp_shard_end(self.eng.h, self.h, out.ctypes.data, hist.ctypes.data if want_hist else None))
+        return out, hist
+
     def free(self):
         if self.h:
             self.eng.L.swp_batch_free(self.eng.h, self.h)
@@ -249,9 +296,10 @@ class Batch:
 class Engine:
     """One swp_engine handle. Raises SwpError(SWP_ENODEVICE) when no gfx950 is present: there is no CPU path."""
 
-    def __init__(self, device=0, window=0, resolver_threads=0, profile=False, lib_path=None):
+    def __init__(self, device=0, window=0, resolver_threads=0, profile=False, lib_path=None, shard_rank=0, shard_count=0):
         self.L = load_library(lib_path)
-        cfg = Config(device=device, window=window, resolver_threads=resolver_threads, flags=CFG_PROFILE if profile else 0)
+        cfg = Config(device=device, window=window, resolver_threads=resolver_threads, flags=CFG_PROFILE if profile else 0,
+                     shard_rank=shard_rank, shard_count=shard_count)
         h = C.c_void_p()
         rc = self.L.swp_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -23,6 +23,7 @@
 #include "../../include/swp.h"
 #include "swp_device.hpp"
 #include "swp_launch.hpp"
+#include "swp_shard.hpp"
 
 using namespace swpdev;
 
@@ -158,6 +159,13 @@ struct swp_batch {
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
     DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
     DevBuf d_thr;                          // k_resolve5 exact mode: thresholds of the demand-class rows
+    // node-range shard protocol (swp_shard_*): commits / unplaceable tasks of ALL shards so far, this shard's results
+    bool shard_open = false, shard_apply_timed = false;
+    uint32_t shard_ncommit = 0, shard_ninf = 0;
+    std::vector<int32_t> shard_out;        // [T] shard-local node of the tasks placed here, else -1
+    std::vector<ShardPickDev> shard_mine;  // upload sources of the last commit (alive until the stream has consumed them)
+    std::vector<ShardInfDev> shard_infs;
+    DevBuf d_prop, d_picks, d_infs;
 };
 
 struct swp_engine {
@@ -692,14 +700,77 @@ int run_classes(swp_engine* e, swp_batch* b) {
     return SWP_OK;
 }
 
-int batch_run(swp_engine* e, swp_batch* b) {
-    const uint32_t N = e->n_nodes, Wn = n_words_of(N), T = b->T;
-    if (N == 0 || T == 0) { b->ran = true; return SWP_OK; }
-    const bool prof = (e->cfg.flags & SWP_CFG_PROFILE) != 0;
+// explain pass over the batch's unplaceable tasks (first failing filter per node at the task's moment, rebuilt from the commit log)
+int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N);
     hipStream_t st = e->stream;
-    if (prof) HIPCHECK(e, hipEventRecord(e->ev[0], st));
+    {
+        ExplainArgs xa{};
+        xa.n_nodes = N;
+        xa.n_words = Wn;
+        xa.n_inf = n_inf;
+        xa.inf_task = b->d_inf_task.as<uint32_t>();
+        xa.inf_pos = b->d_inf_pos.as<uint32_t>();
+        xa.rt = b->d_rt.as<RTask>();
+        xa.valid = e->d_valid.as<u64>();
+        xa.ready = e->d_ready.as<u64>();
+        xa.con = b->d_con.as<u64>();
+        xa.plat = b->d_plat.as<u64>();
+        xa.plug = b->d_plug.as<u64>();
+        xa.cpu = e->d_cpu.as<long long>();
+        xa.mem = e->d_mem.as<long long>();
+        xa.portmap = b->d_portmap.as<u64>();
+        xa.pset_off = b->d_pset_off.as<uint32_t>();
+        xa.pset_ids = b->d_pset_ids.as<uint32_t>();
+        xa.list_node = b->d_list_node.as<uint32_t>();
+        xa.list_svc = b->d_list_svc.as<uint32_t>();
+        xa.list_off = b->d_list_off.as<uint32_t>();
+        xa.log_task = b->d_log_task.as<uint32_t>();
+        xa.log_prev = b->d_log_prev.as<int32_t>();
+        xa.last = b->d_last.as<int32_t>();
+        xa.hist = b->d_hist.as<uint32_t>();
+        // per-node commit segments (sorted, suffix sums) for the residual-at-the-moment lookups
+        HIPCHECK(e, b->d_seg_off.reserve((size_t)N * 4));
+        HIPCHECK(e, b->d_seg_len.reserve((size_t)N * 4));
+        HIPCHECK(e, hipMemsetAsync(b->d_seg_alloc.p, 0, 4, st));
+        SegArgs sg{};
+        sg.n_nodes = N;
+        sg.rt = b->d_rt.as<RTask>();
+        sg.log_task = b->d_log_task.as<uint32_t>();
+        sg.log_prev = b->d_log_prev.as<int32_t>();
+        sg.last = b->d_last.as<int32_t>();
+        sg.alloc = b->d_seg_alloc.as<uint32_t>();
+        sg.seg_off = b->d_seg_off.as<uint32_t>();
+        sg.seg_len = b->d_seg_len.as<uint32_t>();
+        sg.ent_ci = b->d_ent_ci.as<uint32_t>();
+        sg.ent_scpu = b->d_ent_scpu.as<long long>();
+        sg.ent_smem = b->d_ent_smem.as<long long>();
+        hipLaunchKernelGGL(k_chain_segments, dim3((N + 255) / 256), dim3(256), 0, st, sg);
+        xa.seg_off = sg.seg_off;
+        xa.seg_len = sg.seg_len;
+        xa.ent_ci = sg.ent_ci;
+        xa.ent_scpu = sg.ent_scpu;
+        xa.ent_smem = sg.ent_smem;
+        uint32_t done = 0;
+        while (done < n_inf) {   // grid.y ≤ 65535 blocks of EX_TCH tasks
+            uint32_t chunk = std::min<uint32_t>(n_inf - done, 32768u * EX_TCH);
+            ExplainArgs xc = xa;
+            xc.inf_task += done;
+            xc.inf_pos += done;
+            xc.n_inf = chunk;
+            hipLaunchKernelGGL(k_explain, dim3((N + 255) / 256, (chunk + EX_TCH - 1) / EX_TCH), dim3(256), 0, st, xc);
+            done += chunk;
+        }
+        HIPCHECK(e, hipGetLastError());
+    }
+    return SWP_OK;
+}
 
-    // per-batch device state back to pristine
+// per-batch device state back to pristine (exception lists and bitmaps, host ports, commit log, results) + the predicate
+// class bitmaps: what a run does before its first resolver launch
+int batch_begin(swp_engine* e, swp_batch* b) {
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N), T = b->T;
+    hipStream_t st = e->stream;
     size_t L = b->list_node0.size();
     if (L) {
         HIPCHECK(e, hipMemcpyAsync(b->d_list_node.p, b->d_list_node0.p, L * 4, hipMemcpyDeviceToDevice, st));
@@ -718,7 +789,17 @@ int batch_run(swp_engine* e, swp_batch* b) {
     if (!b->prow.empty())
         hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b->prow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b->prow.size(),
                            b->d_prow.as<uint32_t>(), b->d_pnode.as<uint32_t>(), Wn, b->d_portmap.as<u64>());
-    int rc = run_classes(e, b);
+    return run_classes(e, b);
+}
+
+int batch_run(swp_engine* e, swp_batch* b) {
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N), T = b->T;
+    if (N == 0 || T == 0) { b->ran = true; return SWP_OK; }
+    const bool prof = (e->cfg.flags & SWP_CFG_PROFILE) != 0;
+    hipStream_t st = e->stream;
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[0], st));
+
+    int rc = batch_begin(e, b);
     if (rc) return rc;
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[1], st));
 
@@ -927,65 +1008,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
     }
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
     if (ctl.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the level planes that fit in LDS");
-    if (ctl.ninf) {
-        ExplainArgs xa{};
-        xa.n_nodes = N;
-        xa.n_words = Wn;
-        xa.n_inf = ctl.ninf;
-        xa.inf_task = b->d_inf_task.as<uint32_t>();
-        xa.inf_pos = b->d_inf_pos.as<uint32_t>();
-        xa.rt = b->d_rt.as<RTask>();
-        xa.valid = e->d_valid.as<u64>();
-        xa.ready = e->d_ready.as<u64>();
-        xa.con = b->d_con.as<u64>();
-        xa.plat = b->d_plat.as<u64>();
-        xa.plug = b->d_plug.as<u64>();
-        xa.cpu = e->d_cpu.as<long long>();
-        xa.mem = e->d_mem.as<long long>();
-        xa.portmap = b->d_portmap.as<u64>();
-        xa.pset_off = b->d_pset_off.as<uint32_t>();
-        xa.pset_ids = b->d_pset_ids.as<uint32_t>();
-        xa.list_node = b->d_list_node.as<uint32_t>();
-        xa.list_svc = b->d_list_svc.as<uint32_t>();
-        xa.list_off = b->d_list_off.as<uint32_t>();
-        xa.log_task = b->d_log_task.as<uint32_t>();
-        xa.log_prev = b->d_log_prev.as<int32_t>();
-        xa.last = b->d_last.as<int32_t>();
-        xa.hist = b->d_hist.as<uint32_t>();
-        // per-node commit segments (sorted, suffix sums) for the residual-at-the-moment lookups
-        HIPCHECK(e, b->d_seg_off.reserve((size_t)N * 4));
-        HIPCHECK(e, b->d_seg_len.reserve((size_t)N * 4));
-        HIPCHECK(e, hipMemsetAsync(b->d_seg_alloc.p, 0, 4, st));
-        SegArgs sg{};
-        sg.n_nodes = N;
-        sg.rt = b->d_rt.as<RTask>();
-        sg.log_task = b->d_log_task.as<uint32_t>();
-        sg.log_prev = b->d_log_prev.as<int32_t>();
-        sg.last = b->d_last.as<int32_t>();
-        sg.alloc = b->d_seg_alloc.as<uint32_t>();
-        sg.seg_off = b->d_seg_off.as<uint32_t>();
-        sg.seg_len = b->d_seg_len.as<uint32_t>();
-        sg.ent_ci = b->d_ent_ci.as<uint32_t>();
-        sg.ent_scpu = b->d_ent_scpu.as<long long>();
-        sg.ent_smem = b->d_ent_smem.as<long long>();
-        hipLaunchKernelGGL(k_chain_segments, dim3((N + 255) / 256), dim3(256), 0, st, sg);
-        xa.seg_off = sg.seg_off;
-        xa.seg_len = sg.seg_len;
-        xa.ent_ci = sg.ent_ci;
-        xa.ent_scpu = sg.ent_scpu;
-        xa.ent_smem = sg.ent_smem;
-        uint32_t done = 0;
-        while (done < ctl.ninf) {   // grid.y ≤ 65535 blocks of EX_TCH tasks
-            uint32_t chunk = std::min<uint32_t>(ctl.ninf - done, 32768u * EX_TCH);
-            ExplainArgs xc = xa;
-            xc.inf_task += done;
-            xc.inf_pos += done;
-            xc.n_inf = chunk;
-            hipLaunchKernelGGL(k_explain, dim3((N + 255) / 256, (chunk + EX_TCH - 1) / EX_TCH), dim3(256), 0, st, xc);
-            done += chunk;
-        }
-        HIPCHECK(e, hipGetLastError());
-    }
+    if (ctl.ninf && (rc = run_explain(e, b, ctl.ninf))) return rc;
     if (prof) {
         HIPCHECK(e, hipEventRecord(e->ev[3], st));
         HIPCHECK(e, hipEventSynchronize(e->ev[3]));
@@ -1624,6 +1647,245 @@ void swp_batch_free(swp_engine* e, swp_batch* b) {
         if (e->stream) (void)hipStreamSynchronize(e->stream);
     }
     delete b;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// node-range shards (include/swp.h): propose / merge / commit over a block of tasks
+int swp_shard_begin(swp_engine* e, swp_batch* b) {
+    if (!e || !b) return SWP_EINVAL;
+    (void)hipSetDevice(e->device);
+    b->shard_open = true;
+    b->shard_ncommit = b->shard_ninf = 0;
+    e->stats.ms_propose = e->stats.ms_apply = 0.f;
+    e->stats.propose_launches = e->stats.propose_tasks = 0;
+    b->shard_out.assign(b->T, -1);
+    if (e->n_nodes == 0 || b->T == 0) return SWP_OK;
+    int rc = batch_begin(e, b);
+    if (rc) return rc;
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return SWP_OK;
+}
+
+int swp_shard_propose(swp_engine* e, swp_batch* b, uint32_t j0, uint32_t count, swp_proposal* out) {
+    if (!e || !b || (!out && count)) return SWP_EINVAL;
+    if (!b->shard_open) return e->fail(SWP_EINVAL, "swp_shard_propose before swp_shard_begin");
+    if (j0 > b->T || count > b->T - j0) return e->fail(SWP_ERANGE, "tasks [%u, %u) are outside the batch of %u", j0, j0 + count, b->T);
+    static_assert(sizeof(swp_proposal) == sizeof(Proposal), "swp_proposal layout");
+    if (count == 0) return SWP_OK;
+    if (e->n_nodes == 0) {   // an empty shard has nothing to offer
+        for (uint32_t i = 0; i < count; ++i) {
+            std::memset(&out[i], 0, sizeof out[i]);
+            out[i].level = 0xFFFFFFFFu;
+            out[i].exc_hi = out[i].exc_lo = ~0ull;
+        }
+        return SWP_OK;
+    }
+    (void)hipSetDevice(e->device);
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N);
+    HIPCHECK(e, b->d_prop.reserve((size_t)count * sizeof(Proposal)));
+    ProposeArgs a{};
+    a.n_nodes = N;
+    a.n_words = Wn;
+    a.j0 = j0;
+    a.count = count;
+    a.xs = Wn;
+    a.cpu = e->d_cpu.as<long long>();
+    a.mem = e->d_mem.as<long long>();
+    a.total = e->d_total.as<uint32_t>();
+    a.rt = b->d_rt.as<RTask>();
+    a.sc = b->d_sc.as<u64>();
+    a.X = b->d_X.as<u64>();
+    a.portmap = b->d_portmap.as<u64>();
+    a.pset_off = b->d_pset_off.as<uint32_t>();
+    a.pset_ids = b->d_pset_ids.as<uint32_t>();
+    a.list_node = b->d_list_node.as<uint32_t>();
+    a.list_svc = b->d_list_svc.as<uint32_t>();
+    a.list_fail = b->d_list_fail.as<uint32_t>();
+    a.list_off = b->d_list_off.as<uint32_t>();
+    a.out = b->d_prop.as<Proposal>();
+    const bool prof = (e->cfg.flags & SWP_CFG_PROFILE) != 0;
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[0], e->stream));
+    hipError_t r = launch_propose(a, e->stream);
+    if (r != hipSuccess) return e->fail(SWP_EHIP, "k_propose launch: %s", hipGetErrorString(r));
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[1], e->stream));
+    HIPCHECK(e, hipMemcpyAsync(out, b->d_prop.p, (size_t)count * sizeof(Proposal), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    if (prof) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
+        e->stats.ms_propose += ms;
+        if (b->shard_apply_timed) {   // the commit that ran in front of this propose on the same stream
+            (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]);
+            e->stats.ms_apply += ms;
+            b->shard_apply_timed = false;
+        }
+    }
+    e->stats.propose_launches += 1;
+    e->stats.propose_tasks += count;
+    return SWP_OK;
+}
+
+int swp_shard_merge(const swp_proposal* const* proposals, const uint32_t* shard_first_node, uint32_t n_shards, uint32_t count, swp_shard_pick* picks,
+                    uint32_t* accepted) {
+    if (!proposals || !shard_first_node || !n_shards || (!picks && count) || !accepted) return SWP_EINVAL;
+    *accepted = 0;
+    std::unordered_map<uint64_t, uint64_t> taken;   // (shard << 32 | local word) -> bits picked earlier in this block
+    for (uint32_t i = 0; i < count; ++i) {
+        uint32_t lmin = 0xFFFFFFFFu;
+        for (uint32_t g = 0; g < n_shards; ++g) lmin = std::min(lmin, proposals[g][i].level);
+        swp_shard_pick pk{-1, 0, 0xFFFFFFFFu, 0};
+        if (lmin == 0xFFFFFFFFu) {
+            // no plain node anywhere — and there will be none later in the batch (feasibility only shrinks). The exception lists
+            // decide; their order moves with every placement of the service, so only the block's first task may use them.
+            uint64_t bhi = ~0ull, btot = 0, bnode = 0;
+            int32_t bg = -1;
+            uint32_t bent = 0, blocal = 0;
+            for (uint32_t g = 0; g < n_shards; ++g) {
+                const swp_proposal& p = proposals[g][i];
+                if (p.exc_hi == ~0ull) continue;
+                const uint64_t tot = p.exc_lo >> 32, node = (uint64_t)shard_first_node[g] + (uint32_t)p.exc_lo;
+                if (bg < 0 || p.exc_hi < bhi || (p.exc_hi == bhi && (tot < btot || (tot == btot && node < bnode)))) {
+                    bhi = p.exc_hi;
+                    btot = tot;
+                    bnode = node;
+                    bg = (int32_t)g;
+                    bent = p.exc_entry;
+                    blocal = (uint32_t)p.exc_lo;
+                }
+            }
+            if (bg >= 0) {
+                if (i != 0) break;   // cut in front of it
+                pk.shard = bg;
+                pk.node = blocal;
+                pk.entry = bent;
+                picks[i] = pk;
+                *accepted = 1;
+                break;   // and right behind it
+            }
+            picks[i] = pk;   // no suitable node: final whatever the earlier tasks of the block did
+            *accepted = i + 1;
+            continue;
+        }
+        bool decided = false, cut = false;
+        for (uint32_t g = 0; g < n_shards && !decided && !cut; ++g) {
+            const swp_proposal& p = proposals[g][i];
+            if (p.level != lmin) continue;
+            const uint32_t nc = p.n_cand & 0x7FFFFFFFu;
+            for (uint32_t c = 0; c < nc; ++c) {
+                auto it = taken.find(((uint64_t)g << 32) | p.word[c]);
+                const uint64_t avail = p.bits[c] & ~(it == taken.end() ? 0ull : it->second);
+                if (avail) {
+                    pk.shard = (int32_t)g;
+                    pk.node = p.word[c] * 64u + (uint32_t)__builtin_ctzll(avail);
+                    decided = true;
+                    break;
+                }
+            }
+            if (!decided && (p.n_cand & 0x80000000u)) cut = true;   // this shard has more nodes of the level that were not listed
+        }
+        if (!decided) break;   // every listed node is taken: propose again against the new state
+        taken[((uint64_t)(uint32_t)pk.shard << 32) | (pk.node >> 6)] |= 1ull << (pk.node & 63);
+        picks[i] = pk;
+        *accepted = i + 1;
+    }
+    return SWP_OK;
+}
+
+int swp_shard_commit(swp_engine* e, swp_batch* b, uint32_t j0, const swp_shard_pick* picks, uint32_t accepted) {
+    if (!e || !b || (!picks && accepted)) return SWP_EINVAL;
+    if (!b->shard_open) return e->fail(SWP_EINVAL, "swp_shard_commit before swp_shard_begin");
+    if (j0 > b->T || accepted > b->T - j0) return e->fail(SWP_ERANGE, "tasks [%u, %u) are outside the batch of %u", j0, j0 + accepted, b->T);
+    (void)hipSetDevice(e->device);
+    HIPCHECK(e, hipStreamSynchronize(e->stream));   // the previous commit's copies have left the staging vectors
+    std::vector<ShardPickDev>& mine = b->shard_mine;
+    std::vector<ShardInfDev>& infs = b->shard_infs;
+    mine.clear();
+    infs.clear();
+    const uint32_t inf_base = b->shard_ninf;
+    for (uint32_t i = 0; i < accepted; ++i) {
+        const swp_shard_pick& p = picks[i];
+        if (p.shard < 0) {
+            infs.push_back(ShardInfDev{j0 + i, b->shard_ncommit});
+            b->shard_ninf++;
+            continue;
+        }
+        if ((uint32_t)p.shard == e->cfg.shard_rank) {
+            if (p.node >= e->n_nodes || !e->nodes[p.node].present) return e->fail(SWP_EINVAL, "pick of task %u names node %u, which this shard does not hold", j0 + i, p.node);
+            mine.push_back(ShardPickDev{j0 + i, p.node, p.entry, b->shard_ncommit});
+            b->shard_out[j0 + i] = (int32_t)p.node;
+        }
+        b->shard_ncommit++;
+    }
+    if (e->n_nodes == 0 || (mine.empty() && infs.empty())) return SWP_OK;
+    int rc;
+    if ((rc = upload(e, b->d_picks, mine))) return rc;
+    if ((rc = upload(e, b->d_infs, infs))) return rc;
+    const uint32_t Wn = n_words_of(e->n_nodes);
+    ShardApplyArgs a{};
+    a.n_picks = (uint32_t)mine.size();
+    a.n_inf = (uint32_t)infs.size();
+    a.inf_base = inf_base;
+    a.n_words = Wn;
+    a.xs = Wn;
+    a.picks = b->d_picks.as<ShardPickDev>();
+    a.infs = b->d_infs.as<ShardInfDev>();
+    a.rt = b->d_rt.as<RTask>();
+    a.cpu = e->d_cpu.as<long long>();
+    a.mem = e->d_mem.as<long long>();
+    a.total = e->d_total.as<uint32_t>();
+    a.X = b->d_X.as<u64>();
+    a.list_node = b->d_list_node.as<uint32_t>();
+    a.list_svc = b->d_list_svc.as<uint32_t>();
+    a.list_fail = b->d_list_fail.as<uint32_t>();
+    a.portmap = b->d_portmap.as<u64>();
+    a.pset_off = b->d_pset_off.as<uint32_t>();
+    a.pset_ids = b->d_pset_ids.as<uint32_t>();
+    a.out_node = b->d_out.as<int32_t>();
+    a.log_node = b->d_log_node.as<uint32_t>();
+    a.log_task = b->d_log_task.as<uint32_t>();
+    a.log_prev = b->d_log_prev.as<int32_t>();
+    a.last = b->d_last.as<int32_t>();
+    a.inf_task = b->d_inf_task.as<uint32_t>();
+    a.inf_pos = b->d_inf_pos.as<uint32_t>();
+    const bool prof = (e->cfg.flags & SWP_CFG_PROFILE) != 0;
+    if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], e->stream));
+    hipError_t r = launch_shard_apply(a, e->stream);
+    if (r != hipSuccess) return e->fail(SWP_EHIP, "k_shard_apply launch: %s", hipGetErrorString(r));
+    if (prof) {
+        HIPCHECK(e, hipEventRecord(e->ev[3], e->stream));
+        b->shard_apply_timed = true;
+    }
+    return SWP_OK;   // not waited for: the next propose (same stream) is ordered behind it
+}
+
+int swp_shard_end(swp_engine* e, swp_batch* b, int32_t* out_node_local, uint32_t* out_fail_hist) {
+    if (!e || !b || (!out_node_local && b->T)) return SWP_EINVAL;
+    if (!b->shard_open) return e->fail(SWP_EINVAL, "swp_shard_end before swp_shard_begin");
+    (void)hipSetDevice(e->device);
+    b->shard_open = false;
+    const uint32_t T = b->T;
+    if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
+    if (T == 0) return SWP_OK;
+    if (e->n_nodes && b->shard_ninf) {
+        int rc = run_explain(e, b, b->shard_ninf);
+        if (rc) return rc;
+        if (out_fail_hist) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, b->d_hist.p, (size_t)T * 8 * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+    }
+    uint64_t placed = 0;
+    for (uint32_t i = 0; i < T; ++i) {
+        const int32_t n = b->shard_out[i];
+        out_node_local[i] = n;
+        if (n < 0) continue;
+        const swp_task_desc& d = b->tasks[i];
+        host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+        ++placed;
+    }
+    e->stats.batches++;
+    e->stats.tasks += T;
+    e->stats.placed += placed;
+    e->stats.pair_evals += (uint64_t)T * e->n_present;
+    return SWP_OK;
 }
 
 int swp_schedule_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t n_tasks, int32_t* out_node, uint32_t* out_fail_hist) {

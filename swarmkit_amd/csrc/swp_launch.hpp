@@ -18,4 +18,10 @@ uint32_t r5_max_rows();
 bool r5_supports(uint32_t n_words);
 hipError_t launch_resolve5(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev);
 
+// sharded scan (swp_shard.hip)
+struct ProposeArgs;
+struct ShardApplyArgs;
+hipError_t launch_propose(const ProposeArgs& a, hipStream_t s);
+hipError_t launch_shard_apply(const ShardApplyArgs& a, hipStream_t s);
+
 }  // namespace swpdev

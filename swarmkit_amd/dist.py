@@ -1,9 +1,9 @@
-"""One process per GPU: the little that bench.py (and a multi-manager deployment) needs from torch.distributed.
+"""One process per GPU: the process group and the measurement protocol of bench.py (a barrier on both sides of the timed
+region, the max-over-ranks elapsed time, the sum of the units every rank processed).
 
-Placement of ONE cluster is a strictly sequential decision chain, so ranks do not
-exchange data on the data path: each rank schedules its own cluster replica ("replicas only", weak scaling).
-What IS shared is the measurement protocol of bench.py: a barrier on both sides of the timed region, the
-max-over-ranks elapsed time, and the sum of the units every rank processed."""
+The data path between ranks — node-range shards of ONE cluster exchanging their proposals with an RCCL all-gather per
+round — is swarmkit_amd/shard.py (RankShard) on top of the group this module opens. `--parallelism replicas` of bench.py
+(every rank its own cluster, no data-path collective) uses the measurement protocol only."""
 import os
 
 

@@ -727,10 +727,11 @@ def _py_enforce(sched, node_docs, tasks_by_node, services=None):
     return out
 
 
-def load_workload(sched, wl):
+def load_workload(sched, wl, first=0, count=None):
     """Bulk path used by bench.py / large parity tests: nodes through create_node, tasks as one
-    descriptor array (per-service spec translated once, then tiled)."""
-    for i in range(wl.N):
+    descriptor array (per-service spec translated once, then tiled). first / count: only that range of the
+    workload's nodes (a node-range shard, swarmkit_amd.shard); every shard sees every task."""
+    for i in range(first, wl.N if count is None else first + count):
         sched.create_node(wl.node_doc(i))
     for k in range(wl.S):
         sched.set_service(wl.service_id(k))

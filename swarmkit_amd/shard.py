@@ -1,0 +1,114 @@
+"""Node-range shards of the nodeSet (include/swp.h "node-range shards"): the driver of the
+propose / exchange / merge / commit rounds.
+
+Two deployments of the same protocol:
+
+  ShardGroup      G engines in ONE process (one per GPU of the box, or several on one GPU — that is how the GPU parity tests
+                  run it): the exchange is a list of host arrays.
+  RankShard       one engine per process / GPU (torch.distributed, backend nccl == RCCL on ROCm, gloo on CPU test doubles): the
+                  exchange is an all_gather of the block's proposal records (48 B per task and shard) over xGMI; every rank
+                  runs the same deterministic merge, so no second collective is needed to agree on the picks.
+
+What crosses the exchange is each shard's argmin candidates for the block (minimum level + the first nodes of that level in
+node order + the best exception-list node): the per-task "allreduce(min-score, argmin-node)" of the north star, widened to a
+short list so that one exchange decides MANY tasks of the block instead of one (see include/swp.h for the exactness
+argument). The node set is static while a batch runs; nodes are assigned to shards by contiguous ranges of the canonical
+node order, so "lowest node index wins ties" is "lowest shard, then lowest local index".
+"""
+import numpy as np
+
+from . import abi
+
+BLOCK = 256   # tasks proposed per round (the merge accepts a prefix; the rest is proposed again)
+
+
+def shard_ranges(n_nodes, n_shards):
+    """Contiguous ranges of the canonical node order, sizes differing by at most one: [(first, count)] per shard."""
+    base, extra = divmod(n_nodes, n_shards)
+    out, first = [], 0
+    for g in range(n_shards):
+        cnt = base + (1 if g < extra else 0)
+        out.append((first, cnt))
+        first += cnt
+    return out
+
+
+def _finish(picked_shard, picked_node, firsts, hists):
+    out = np.where(picked_shard >= 0, np.asarray(firsts, dtype=np.int64)[np.maximum(picked_shard, 0)] + picked_node, -1).astype(np.int64)
+    return out, (sum(hists) if hists and hists[0] is not None else None)
+
+
+class ShardGroup:
+    """G (engine, batch) pairs in one process. `batches[g]` was prepared on shard g's engine from the SAME task list."""
+
+    def __init__(self, batches, firsts, block=BLOCK):
+        self.batches, self.firsts, self.block = list(batches), [int(f) for f in firsts], int(block)
+        self.T = self.batches[0].n
+        self.rounds = 0
+
+    def run(self, want_hist=True):
+        T, G = self.T, len(self.batches)
+        shard = np.full(T, -1, dtype=np.int64)
+        node = np.zeros(T, dtype=np.int64)
+        for b in self.batches:
+            b.shard_begin()
+        j = 0
+        while j < T:
+            cnt = min(self.block, T - j)
+            props = [b.shard_propose(j, cnt) for b in self.batches]
+            picks = abi.shard_merge(props, self.firsts)
+            assert len(picks) >= 1
+            for b in self.batches:
+                b.shard_commit(j, picks)
+            shard[j:j + len(picks)] = picks["shard"]
+            node[j:j + len(picks)] = picks["node"]
+            j += len(picks)
+            self.rounds += 1
+        hists = []
+        for g, b in enumerate(self.batches):
+            local, h = b.shard_end(want_hist)
+            mine = np.nonzero(shard == g)[0]
+            assert np.array_equal(local[mine], node[mine]) and (np.delete(local, mine) == -1).all()
+            hists.append(h)
+        return _finish(shard, node, self.firsts, hists)
+
+
+class RankShard:
+    """This process' shard of a job of `world` ranks (rank g owns range g). `dist` is torch.distributed (initialised);
+    `device` the torch device the exchange buffers live on (cuda:<local rank> under nccl, cpu under gloo)."""
+
+    def __init__(self, batch, rank, world, firsts, dist, device, block=BLOCK):
+        self.b, self.rank, self.world, self.firsts, self.dist, self.device, self.block = batch, rank, world, [int(f) for f in firsts], dist, device, int(block)
+        self.T = batch.n
+        self.rounds = 0
+
+    def _all_gather(self, props):
+        import torch
+        mine = torch.from_numpy(props.view(np.uint8).reshape(-1)).to(self.device)
+        out = torch.empty(self.world * mine.numel(), dtype=torch.uint8, device=self.device)
+        self.dist.all_gather_into_tensor(out, mine)
+        raw = out.cpu().numpy().reshape(self.world, -1)
+        return [raw[g].view(abi.PROPOSAL_DTYPE) for g in range(self.world)]
+
+    def run(self, want_hist=True):
+        import torch
+        T = self.T
+        shard = np.full(T, -1, dtype=np.int64)
+        node = np.zeros(T, dtype=np.int64)
+        self.b.shard_begin()
+        j = 0
+        while j < T:
+            cnt = min(self.block, T - j)
+            props = self._all_gather(self.b.shard_propose(j, cnt))
+            picks = abi.shard_merge(props, self.firsts)   # same inputs, same rule on every rank: same picks
+            self.b.shard_commit(j, picks)
+            shard[j:j + len(picks)] = picks["shard"]
+            node[j:j + len(picks)] = picks["node"]
+            j += len(picks)
+            self.rounds += 1
+        _local, h = self.b.shard_end(want_hist)
+        if want_hist:   # Explain counters are per-node sums: add the shards' histograms
+            t = torch.from_numpy(h.astype(np.int64)).to(self.device)
+            self.dist.all_reduce(t)
+            h = t.cpu().numpy().astype(np.uint32)
+        return _finish(shard, node, self.firsts, [h])

@@ -49,3 +49,30 @@ def assert_same(a_placed, a_errs, b_placed, b_errs):
     assert not diff, f"{len(diff)} placements differ, first: {diff[:5]}"
     ediff = [(k, a_errs[k], b_errs.get(k)) for k in a_errs if a_errs[k] != b_errs.get(k)]
     assert not ediff, f"{len(ediff)} explanations differ, first: {ediff[:3]}"
+
+
+def sharded_run(wl, n_shards, block=256, **engine_kw):
+    """The same workload over `n_shards` node-range shards (swarmkit_amd.shard.ShardGroup), every shard an engine of its own
+    on this process' device. Returns (placed, errs, rounds) in the oracle's vocabulary."""
+    from swarmkit_amd import shard as swshard
+    ranges = swshard.shard_ranges(wl.N, n_shards)
+    scheds, batches = [], []
+    for g, (first, cnt) in enumerate(ranges):
+        s = swhost.HostScheduler(shard_rank=g, shard_count=n_shards, **engine_kw)
+        descs = swhost.load_workload(s, wl, first, cnt)
+        scheds.append(s)
+        batches.append(s.e.batch_prepare(descs))
+    grp = swshard.ShardGroup(batches, [r[0] for r in ranges], block=block)
+    out, hist = grp.run()
+    placed, errs = {}, {}
+    for j in range(wl.T):
+        tid = wl.task_id(j)
+        if out[j] >= 0:
+            placed[tid] = wl.node_id(int(out[j]))
+        else:
+            placed[tid] = None
+            ex = scheds[0].explain(hist[j])
+            errs[tid] = "no suitable node (" + ex + ")" if ex else "no suitable node"
+    for b in batches:
+        b.free()
+    return placed, errs, grp.rounds

@@ -1,0 +1,65 @@
+"""GPU parity of the node-range sharded scan (include/swp.h "node-range shards"): the node set split over
+2 / 3 / 4 engines — here all on one device, the exchange being host arrays; between GPUs it is an RCCL all-gather
+(swarmkit_amd.shard.RankShard, tests/test_dist_gloo.py) — must place every task exactly where the oracle's single
+sequential scan does, with the same explanation for every unplaceable task."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+from swarmkit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shards", [2, 3, 4])
+@pytest.mark.parametrize("name,T,N,kw", [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg2", 3000, 50, {}), ("cfg1", 500, 40, {})])
+def test_shards_agree_with_oracle(shards, name, T, N, kw):
+    wl = synth.Workload(name, T=T, N=N, **kw)
+    op, oe, _ = pu.oracle_run(wl)
+    sp, se, rounds = pu.sharded_run(wl, shards)
+    pu.assert_same(op, oe, sp, se)
+    assert rounds <= T
+
+
+@pytest.mark.parametrize("services,order", [(1, "rr"), (3, "major"), (40, "major")])
+def test_shards_same_service_runs(services, order):
+    """Few services: almost every task ends on its service's exception list (nodes where it already runs), the path where a
+    block is cut after one task."""
+    wl = synth.Workload("cfg3", T=1200, N=200, services=services, order=order)
+    op, oe, _ = pu.oracle_run(wl)
+    sp, se, _ = pu.sharded_run(wl, 3)
+    pu.assert_same(op, oe, sp, se)
+
+
+@pytest.mark.parametrize("block", [1, 7, 64, 1024])
+def test_block_size_does_not_matter(block):
+    wl = synth.Workload("cfg4", T=1500, N=400)
+    op, oe, _ = pu.oracle_run(wl)
+    sp, se, _ = pu.sharded_run(wl, 4, block=block)
+    pu.assert_same(op, oe, sp, se)
+
+
+def test_more_shards_than_nodes():
+    wl = synth.Workload("cfg2", T=200, N=3)
+    op, oe, _ = pu.oracle_run(wl)
+    sp, se, _ = pu.sharded_run(wl, 4)   # one shard is empty
+    pu.assert_same(op, oe, sp, se)
+
+
+def test_sharded_equals_single_engine_at_scale():
+    """20k x 6k over 4 shards against the single-engine placement vector (itself pinned to the oracle by the other suites)."""
+    wl = synth.Workload("cfg4", T=20000, N=6000)
+    ep, ee, *_ = pu.engine_run(wl)
+    sp, se, rounds = pu.sharded_run(wl, 4)
+    pu.assert_same(ep, ee, sp, se)
+    assert rounds < wl.T // 4   # an exchange decides many tasks
+
+
+def test_sharded_cfg4_200k_x_40k_equals_single_engine():
+    """BASELINE configs[3] at a fifth of its size — past the 16k-node range of the round resolver, so the single engine runs
+    the workgroup resolver — against 4 shards of 10k nodes. (The single-engine placement of exactly this case is pinned to the
+    oracle's offline digest by tests/test_engine_bigcases.py::cfg4_mid.)"""
+    wl = synth.Workload("cfg4", T=200_000, N=40_000)
+    ep, ee, *_ = pu.engine_run(wl)
+    sp, se, rounds = pu.sharded_run(wl, 4)
+    pu.assert_same(ep, ee, sp, se)
