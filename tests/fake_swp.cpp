@@ -279,6 +279,11 @@ int swp_batch_run(swp_engine*, swp_batch*) { return SWP_EUNSUPPORTED; }
 int swp_batch_fetch(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_batch_results(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
 void swp_batch_free(swp_engine*, swp_batch*) {}
+int swp_shard_begin(swp_engine*, swp_batch*) { return SWP_EUNSUPPORTED; }
+int swp_shard_propose(swp_engine*, swp_batch*, uint32_t, uint32_t, swp_proposal*) { return SWP_EUNSUPPORTED; }
+int swp_shard_merge(const swp_proposal* const*, const uint32_t*, uint32_t, uint32_t, swp_shard_pick*, uint32_t*) { return SWP_EUNSUPPORTED; }
+int swp_shard_commit(swp_engine*, swp_batch*, uint32_t, const swp_shard_pick*, uint32_t) { return SWP_EUNSUPPORTED; }
+int swp_shard_end(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_state_save(swp_engine*) { return SWP_EUNSUPPORTED; }
 int swp_state_restore(swp_engine*) { return SWP_EUNSUPPORTED; }
 int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add) {
