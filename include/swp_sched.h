@@ -60,6 +60,15 @@ int swp_sched_delete_task(swp_sched*, const char* task_json, size_t len, int* ti
 int swp_sched_tick(swp_sched*, const char** decisions_json);
 /* processPreassignedTasks + taskFitNode (scheduler.go:398-426, 646-690) through swp_check_node */
 int swp_sched_process_preassigned(swp_sched*, const char** decisions_json);
+/* The failed half of applySchedulingDecisions (scheduler.go:472-487 after tick, :416-425 after processPreassignedTasks):
+ * the caller could not commit a decision to the store (stale Meta.Version :533-545, node no longer READY :560-567, a
+ * conflicting write). The decision is undone — allTasks gets the old task back, NodeInfo.removeTask(new) returns the node's
+ * resources in the engine, the old task is queued again (or stays a pending preassigned task). Decisions can be rejected
+ * until the next swp_sched_tick / swp_sched_process_preassigned; *found = 0 when the task has no decision to undo.
+ * A decision line of swp_sched_tick with "Deferred": true is no placement at all: the engine refused the device call for
+ * that task (the line's Err says why), the task is back on the queue, and the caller should hand it to the reference's
+ * own scheduleTaskGroup. */
+int swp_sched_reject_decision(swp_sched*, const char* task_id, size_t len, int* found);
 
 /* Pipeline.SetTask (pipeline.go:76-81) for one task: every Filter.SetTask (filter.go) translated into predicate-set
  * registrations; the descriptor is what swp_schedule_batch consumes. CSI cluster volumes / generic resources →

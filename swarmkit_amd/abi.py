@@ -115,11 +115,12 @@ class SwpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"swp error {code}: {msg}")
         self.code = code
+        self.msg = msg
 
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). In-tree output: swarmkit_amd/lib/libswp.so."""
-    srcs = [os.path.join(CSRC, f) for f in ("swp_engine.hip", "swp_device.hpp", "swp_resolve4.hpp", "swp_sched.cpp", "swp_json.hpp", "Makefile")] \
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile"] \
         + [os.path.join(ROOT, "include", h) for h in ("swp.h", "swp_sched.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -206,6 +207,7 @@ def load_library(path=None):
         "swp_sched_delete_task": ([vp, cp, sz, P(C.c_int)], C.c_int),
         "swp_sched_tick": ([vp, PP], C.c_int),
         "swp_sched_process_preassigned": ([vp, PP], C.c_int),
+        "swp_sched_reject_decision": ([vp, cp, sz, P(C.c_int)], C.c_int),
         "swp_sched_task_desc": ([vp, cp, sz, P(TaskDesc)], C.c_int),
         "swp_sched_constraint_set": ([vp, cp, sz, P(u32)], C.c_int),
         "swp_sched_enforce": ([vp, cp, sz, PP], C.c_int),

@@ -143,6 +143,7 @@ struct swp_batch {
     std::vector<uint4> triples;
     uint32_t n_con = 0, n_plat = 0, n_plug = 0, n_sc = 0, n_svc = 0, n_ports = 0;
     uint32_t window = 0, n_windows = 0;
+    uint32_t n_nodes_prepared = 0;         // e->n_nodes when the batch was prepared: its bitmap rows are sized for that
     bool ran = false;
     int64_t unit_cpu = 1, unit_mem = 1;   // k_resolve5: gcd of the batch's reservations (RTask.kc / km count these units)
     bool units_ok = false;                // every reservation fits 2^30 units
@@ -793,6 +794,8 @@ int batch_begin(swp_engine* e, swp_batch* b) {
 }
 
 int batch_run(swp_engine* e, swp_batch* b) {
+    if (e->n_nodes != b->n_nodes_prepared)
+        return e->fail(SWP_EINVAL, "the nodeSet grew from %u to %u node slots since swp_batch_prepare: prepare the batch again", b->n_nodes_prepared, e->n_nodes);
     const uint32_t N = e->n_nodes, Wn = n_words_of(N), T = b->T;
     if (N == 0 || T == 0) { b->ran = true; return SWP_OK; }
     const bool prof = (e->cfg.flags & SWP_CFG_PROFILE) != 0;
@@ -1583,6 +1586,7 @@ int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_task
     if ((rc = build_batch(e, tasks, n_tasks, b.get()))) return rc;
     if (e->dev_static_dirty && (rc = flush_nodes(e))) return rc;
     if (n_tasks && e->n_nodes && (rc = upload_batch(e, b.get()))) return rc;
+    b->n_nodes_prepared = e->n_nodes;
     *out = b.release();
     return SWP_OK;
 }
@@ -1654,6 +1658,8 @@ void swp_batch_free(swp_engine* e, swp_batch* b) {
 int swp_shard_begin(swp_engine* e, swp_batch* b) {
     if (!e || !b) return SWP_EINVAL;
     (void)hipSetDevice(e->device);
+    if (e->n_nodes != b->n_nodes_prepared)
+        return e->fail(SWP_EINVAL, "the nodeSet grew from %u to %u node slots since swp_batch_prepare: prepare the batch again", b->n_nodes_prepared, e->n_nodes);
     b->shard_open = true;
     b->shard_ncommit = b->shard_ninf = 0;
     e->stats.ms_propose = e->stats.ms_apply = 0.f;

@@ -390,6 +390,13 @@ class Scheduler {
     // leaves them to the Go scheduler's own path — so that a tick never meets one half-way through a batch.
     static void requireSupported(const Value& t) {
         if (truthy(at(&t, {"Spec", "Resources", "Reservations", "Generic"}))) unsupported("generic resources stay on the Go path");
+        if (const Value* ports = at(&t, {"Endpoint", "Ports"}))
+            if (ports->is_arr()) {
+                size_t host_ports = 0;
+                for (const Value& p : *ports->a)
+                    if (enum_value(p.get("PublishMode"), {{"INGRESS", 0}, {"HOST", 1}}) == PUBLISH_HOST && as_i64(p.get("PublishedPort")) != 0) ++host_ports;
+                if (host_ports > 32) unsupported("more than 32 host-mode ports in one task stay on the Go path");   // swp_port_set's limit
+            }
         const Value* mounts = at(&t, {"Spec", "Container", "Mounts"});
         if (mounts != nullptr && mounts->is_arr())
             for (const Value& m : *mounts->a)
@@ -570,6 +577,8 @@ class Scheduler {
     // processPreassignedTasks + taskFitNode, scheduler.go:398-426, 646-690
     Value processPreassignedTasks() {
         Value decisions = Value::array();
+        for (auto it = lastDecisions_.begin(); it != lastDecisions_.end();)
+            it = it->second.preassigned ? lastDecisions_.erase(it) : std::next(it);
         for (auto& kv : pendingPreassignedTasks_.snapshot()) {
             const std::string& tid = kv.first;
             const Value& t = kv.second;
@@ -595,6 +604,7 @@ class Scheduler {
                 addTask(n->second, newT);
                 pendingPreassignedTasks_.erase(tid);
             }
+            lastDecisions_[tid] = PendingDecision{t, true};
             decisions.push(decision(t, newT));
         }
         return decisions;
@@ -610,10 +620,17 @@ class Scheduler {
             if (!truthy(kv.second.get("NodeID"))) queue.push_back(std::move(kv));
         unassignedTasks_.clear();
         Value decisions = Value::array();
+        for (auto it = lastDecisions_.begin(); it != lastDecisions_.end();)   // the previous tick's decisions are final now
+            it = it->second.preassigned ? std::next(it) : lastDecisions_.erase(it);
         if (queue.empty()) return decisions;
         std::set<std::string> sids;
         for (const Item& it : queue) sids.insert(as_str(it.second.get("ServiceID")));
-        pushFailures(sids);
+        try {
+            pushFailures(sids);
+        } catch (const Fail& f) {   // nothing was scheduled: the whole queue stays queued
+            for (const Item& it : queue) defer(it.first, it.second, f, decisions);
+            return decisions;
+        }
         std::vector<std::vector<Item>> groups;
         std::map<FailureKey, size_t> group_of;
         std::vector<Item> one_off;
@@ -633,7 +650,13 @@ class Scheduler {
         std::vector<Item> run;
         std::vector<swp_task_desc> run_descs;   // Pipeline.SetTask once per task
         for (Item& it : one_off) {
-            const swp_task_desc d = taskDesc(it.second);
+            swp_task_desc d;
+            try {
+                d = taskDesc(it.second);
+            } catch (const Fail& f) {
+                defer(it.first, it.second, f, decisions);
+                continue;
+            }
             if (d.spread_set != 0) {
                 runOneOffs(run, run_descs, decisions);
                 run.clear();
@@ -648,6 +671,28 @@ class Scheduler {
         }
         runOneOffs(run, run_descs, decisions);
         return decisions;
+    }
+
+    // The failed half of applySchedulingDecisions (scheduler.go:472-487 for tick, :416-425 for preassigned tasks): the store
+    // commit of a decision did not go through (stale Meta.Version :533-545, node no longer READY :560-567, a conflicting
+    // write). Undo it: allTasks gets the old task back, NodeInfo.removeTask(new) returns the resources, and the old task is
+    // queued again (tick) or stays pending (preassigned). Valid until the next tick / processPreassignedTasks.
+    bool rejectDecision(const std::string& tid) {
+        auto it = lastDecisions_.find(tid);
+        if (it == lastDecisions_.end()) return false;
+        const PendingDecision pd = it->second;
+        lastDecisions_.erase(it);
+        auto cur = allTasks_.find(tid);
+        if (cur != allTasks_.end()) {
+            const Value newT = cur->second;
+            auto n = nodes_.find(as_str(newT.get("NodeID")));
+            if (n != nodes_.end() && !truthy(pd.old.get("NodeID")) ) removeTask(n->second, newT);                 // tick: the node was chosen by this decision
+            else if (n != nodes_.end() && pd.preassigned && task_state(at(&newT, {"Status", "State"})) == ASSIGNED) removeTask(n->second, newT);
+        }
+        allTasks_[tid] = pd.old;
+        if (pd.preassigned) pendingPreassignedTasks_.put(tid, pd.old);
+        else unassignedTasks_.put(tid, pd.old);   // enqueue(decision.old), :486
+        return true;
     }
 
     // ---------------------------------------------------------------------------------------------- constraint enforcer
@@ -723,11 +768,21 @@ class Scheduler {
     std::unordered_map<std::string, std::optional<uint64_t>> services_;   // store.GetService: existence + SpecVersion
     OrderedTasks unassignedTasks_;                                         // Scheduler.unassignedTasks
     OrderedTasks pendingPreassignedTasks_;                                 // Scheduler.pendingPreassignedTasks
+    // the `old` half of every decision of the last tick / processPreassignedTasks (schedulingDecision.old, scheduler.go:53-56),
+    // kept until the next one so that the caller can roll a decision back when its store commit failed (rejectDecision)
+    struct PendingDecision { Value old; bool preassigned; };
+    std::map<std::string, PendingDecision> lastDecisions_;
+    std::string engine_detail_;   // "<strerror>: <engine message>" of the last failed engine call
+    // failure counts pushed to the engine: (node index, service, spec version) -> count, so that a bucket the clean-up
+    // erased (nodeinfo.go:163-183) is reset there too
+    std::map<std::tuple<uint32_t, std::string, int64_t>, uint32_t> pushedFailures_;
     std::set<std::string> preassignedTasks_;                               // Scheduler.preassignedTasks
     std::unordered_map<std::string, Value> allTasks_;                      // Scheduler.allTasks
 
     void ck(int rc, const char* what) {
-        if (rc != SWP_OK) fail(rc, std::string(what) + ": " + swp_strerror(rc) + ": " + swp_last_error(e_));
+        if (rc == SWP_OK) return;
+        engine_detail_ = std::string(swp_strerror(rc)) + ": " + swp_last_error(e_);   // what a deferred decision line reports
+        fail(rc, std::string(what) + ": " + engine_detail_);
     }
     uint32_t intern(int space, const std::string& s) {
         uint32_t id = 0;
@@ -971,11 +1026,23 @@ class Scheduler {
     }
     // the failure counts nodeLess reads (scheduler.go:706-735) for the services of the coming batch, at its `now`
     void pushFailures(const std::set<std::string>& sids) {
+        std::map<std::tuple<uint32_t, std::string, int64_t>, uint32_t> now;
         for (auto& kv : nodes_)
             for (auto& f : kv.second.recentFailures)
-                if (sids.count(f.first.first))
-                    ck(swp_node_set_failures(e_, kv.second.idx, intern(SWP_SPACE_SERVICE, f.first.first), (uint64_t)f.first.second, countRecentFailures(kv.second, f.first)),
-                       "swp_node_set_failures");
+                if (sids.count(f.first.first)) now[{kv.second.idx, f.first.first, f.first.second}] = countRecentFailures(kv.second, f.first);
+        // buckets the engine still holds a count for but the node no longer has (erased by cleanupFailures, or the node left):
+        // countRecentFailures would say 0 (nodeinfo.go:206-221), so must the engine
+        for (auto it = pushedFailures_.begin(); it != pushedFailures_.end();) {
+            if (sids.count(std::get<1>(it->first)) && now.find(it->first) == now.end()) {
+                if (it->second != 0 && std::get<0>(it->first) < idx_to_id_.size() && nodes_.count(idx_to_id_[std::get<0>(it->first)]))
+                    ck(swp_node_set_failures(e_, std::get<0>(it->first), intern(SWP_SPACE_SERVICE, std::get<1>(it->first)), (uint64_t)std::get<2>(it->first), 0), "swp_node_set_failures");
+                it = pushedFailures_.erase(it);
+            } else ++it;
+        }
+        for (auto& kv : now) {
+            ck(swp_node_set_failures(e_, std::get<0>(kv.first), intern(SWP_SPACE_SERVICE, std::get<1>(kv.first)), (uint64_t)std::get<2>(kv.first), kv.second), "swp_node_set_failures");
+            pushedFailures_[kv.first] = kv.second;
+        }
     }
 
     static Value statusCopy(const Value& t) {
@@ -1009,6 +1076,7 @@ class Scheduler {
         auto ni = nodes_.find(nid);
         if (ni == nodes_.end()) fail(SWP_EINVAL, "engine placed a task on a node the nodeSet does not hold");
         ni->second.Tasks[tid] = newT;
+        lastDecisions_[tid] = PendingDecision{t, false};
         decisions.push(decision(t, newT));
     }
     // noSuitableNode, scheduler.go:928-971
@@ -1033,7 +1101,21 @@ class Scheduler {
             unassignedTasks_.put(tid, newT);   // enqueue again, :968
         }
         allTasks_[tid] = newT;
+        lastDecisions_[tid] = PendingDecision{t, false};
         decisions.push(decision(t, newT));
+    }
+    // A device call failed for these tasks (a group beyond the engine's heap capacity, a spread tree beyond its branch limit,
+    // ...): nothing of the call was applied, so the tasks go back on the queue — the Go shim routes a deferred task to the
+    // reference's own scheduleTaskGroup — and the tick carries on with the rest. One decision line per task says why.
+    void defer(const std::string& tid, const Value& t, const Fail& f, Value& decisions) {
+        unassignedTasks_.put(tid, t);
+        last_error = f.msg;
+        Value d = decision(t, t);
+        const bool from_engine = !engine_detail_.empty() && f.msg.size() >= engine_detail_.size() &&
+                                 f.msg.compare(f.msg.size() - engine_detail_.size(), engine_detail_.size(), engine_detail_) == 0;
+        d.set("Err", Value::str("swp: deferred to the host scheduler: " + (from_engine ? engine_detail_ : f.msg)));
+        d.set("Deferred", Value::boolean(true));
+        decisions.push(d);
     }
     // groups[from, to): one swp_schedule_groups call, groups in order. One device call must not mix spec versions of one
     // service (the failure buckets are per (service, version)): cut the ordered list where that would happen.
@@ -1060,13 +1142,29 @@ class Scheduler {
         std::vector<uint32_t> sizes;
         size_t total = 0;
         for (size_t i = from; i < to; ++i) {
-            descs.push_back(taskDesc(groups[i][0].second));
+            try {
+                descs.push_back(taskDesc(groups[i][0].second));
+            } catch (const Fail& f) {   // a predicate set the engine refuses: this group is deferred, the others run
+                runGroups(groups, from, i, decisions);
+                for (const Item& it : groups[i]) defer(it.first, it.second, f, decisions);
+                runGroups(groups, i + 1, to, decisions);
+                return;
+            }
             sizes.push_back((uint32_t)groups[i].size());
             total += groups[i].size();
         }
         std::vector<int32_t> out(total, -1);
         std::vector<uint32_t> hist(descs.size() * SWP_NFILTERS, 0);
-        ck(swp_schedule_groups(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_groups");
+        try {
+            ck(swp_schedule_groups(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_groups");
+        } catch (const Fail& f) {
+            if (to - from > 1) {   // find the group(s) the engine cannot take: run them one by one
+                for (size_t g = from; g < to; ++g) runGroups(groups, g, g + 1, decisions);
+                return;
+            }
+            for (const Item& it : groups[from]) defer(it.first, it.second, f, decisions);
+            return;
+        }
         size_t off = 0;
         for (size_t g = from; g < to; ++g) {
             for (size_t i = 0; i < groups[g].size(); ++i) {
@@ -1081,7 +1179,12 @@ class Scheduler {
         if (run.empty()) return;
         std::vector<int32_t> out(run.size(), -1);
         std::vector<uint32_t> hist(run.size() * SWP_NFILTERS, 0);
-        ck(swp_schedule_batch(e_, descs.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_batch");
+        try {
+            ck(swp_schedule_batch(e_, descs.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_batch");
+        } catch (const Fail& f) {
+            for (const Item& it : run) defer(it.first, it.second, f, decisions);
+            return;
+        }
         for (size_t i = 0; i < run.size(); ++i) {
             if (out[i] >= 0) place(run[i].first, run[i].second, out[i], decisions);
             else noSuitableNode(run[i].first, run[i].second, &hist[i * SWP_NFILTERS], decisions);
@@ -1201,6 +1304,14 @@ int swp_sched_tick(swp_sched* s, const char** decisions_json) {
         const swp::json::Value d = impl.tick();
         impl.scratch = swp::json::dump(d);
         *decisions_json = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_reject_decision(swp_sched* s, const char* task_id, size_t len, int* found) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (task_id == nullptr) return (int)SWP_EINVAL;
+        const bool r = impl.rejectDecision(std::string(task_id, len));
+        if (found != nullptr) *found = r ? 1 : 0;
         return (int)SWP_OK;
     });
 }

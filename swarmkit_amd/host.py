@@ -119,6 +119,9 @@ class PyHostScheduler:
         self.services = {}         # id -> spec version index or None
         self.unassigned = {}       # insertion-ordered: id -> task doc
         self.pending_preassigned = {}
+        self.last_decisions = {}   # task id -> (old task, preassigned?) of the last tick / process_preassigned (reject_decision)
+        self.pushed_failures = {}  # (node index, service, spec version) -> count the engine holds
+        self.last_error = ""
         self.preassigned = set()
         self.all_tasks = {}
         self._desc_cache = {}
@@ -325,6 +328,9 @@ class PyHostScheduler:
         the shim leaves them to the Go scheduler's own path — so that a tick never meets one half-way through a batch."""
         if _get(t, "Spec", "Resources", "Reservations", "Generic"):
             raise Unsupported("generic resources stay on the Go path")
+        host_ports = sum(1 for p in (_get(t, "Endpoint", "Ports") or []) if p.get("PublishMode") in (1, "HOST") and p.get("PublishedPort"))
+        if host_ports > 32:
+            raise Unsupported("more than 32 host-mode ports in one task stay on the Go path")   # swp_port_set's limit
         for m in _get(t, "Spec", "Container", "Mounts") or []:
             if m.get("Type") in (MOUNT_CLUSTER, "CLUSTER"):
                 raise Unsupported("CSI cluster volumes stay on the Go path")
@@ -542,14 +548,29 @@ class PyHostScheduler:
 
     # ------------------------------------------------------------------------------ tick
     def _push_failures(self, service_ids):
-        for _nid, ent in sorted(self.nodes.items()):
-            for (sid, ver) in sorted(ent["failures"]):
+        """The failure counts nodeLess reads (scheduler.go:706-735) for the services of the coming batch, at its `now`. A bucket
+        the engine still holds a count for but the node no longer has (erased by cleanupFailures, nodeinfo.go:163-183, or the
+        node left) is reset to 0: that is what countRecentFailures would say."""
+        now = {}
+        for _nid, ent in self.nodes.items():
+            for (sid, ver) in ent["failures"]:
                 if sid in service_ids:
-                    self.e.node_set_failures(ent["idx"], self.e.intern(abi.SPACE_SERVICE, sid), ver, self._count_recent_failures(ent, (sid, ver)))
+                    now[(ent["idx"], sid, ver)] = self._count_recent_failures(ent, (sid, ver))
+        for key in sorted(self.pushed_failures):
+            idx, sid, ver = key
+            if sid in service_ids and key not in now:
+                if self.pushed_failures[key] != 0 and idx < len(self.idx_to_id) and self.idx_to_id[idx] in self.nodes:
+                    self.e.node_set_failures(idx, self.e.intern(abi.SPACE_SERVICE, sid), ver, 0)
+                del self.pushed_failures[key]
+        for key in sorted(now):
+            idx, sid, ver = key
+            self.e.node_set_failures(idx, self.e.intern(abi.SPACE_SERVICE, sid), ver, now[key])
+            self.pushed_failures[key] = now[key]
 
     def process_preassigned(self):
         """processPreassignedTasks + taskFitNode, scheduler.go:398-426, 646-690."""
         decisions = []
+        self.last_decisions = {k: v for k, v in self.last_decisions.items() if not v[1]}
         for tid, t in list(self.pending_preassigned.items()):
             ent = self.nodes.get(t.get("NodeID", ""))
             if ent is None:
@@ -566,6 +587,7 @@ class PyHostScheduler:
                 self.all_tasks[tid] = new_t
                 self._add_task(ent, new_t)
                 del self.pending_preassigned[tid]
+            self.last_decisions[tid] = (t, True)
             decisions.append(self._decision(t, new_t))
         return decisions
 
@@ -582,6 +604,7 @@ class PyHostScheduler:
         new_t["Status"] = {"State": ASSIGNED, "Message": "scheduler assigned task to node"}
         self.all_tasks[tid] = new_t
         self.nodes[nid]["tasks"][tid] = new_t   # numeric addTask already happened on the device
+        self.last_decisions[tid] = (t, False)
         decisions.append(self._decision(t, new_t))
 
     def _no_suitable_node(self, tid, t, hist, decisions):
@@ -599,7 +622,41 @@ class PyHostScheduler:
             new_t["Status"] = dict(t.get("Status", {}), Err="no suitable node (" + ex + ")" if ex else "no suitable node")
             self.unassigned[tid] = new_t
         self.all_tasks[tid] = new_t
+        self.last_decisions[tid] = (t, False)
         decisions.append(self._decision(t, new_t))
+
+    def _defer(self, tid, t, err, decisions):
+        """A device call failed for this task (a group beyond the engine's capacity, ...): nothing of the call was applied, the
+        task goes back on the queue and the tick carries on; the Go shim routes a deferred task to the reference's own path."""
+        self.unassigned[tid] = t
+        self.last_error = str(err)
+        d = self._decision(t, t)
+        d["Err"] = "swp: deferred to the host scheduler: " + self._err_text(err)
+        d["Deferred"] = True
+        decisions.append(d)
+
+    @staticmethod
+    def _err_text(err):
+        return getattr(err, "msg", None) or str(err)
+
+    def reject_decision(self, tid):
+        """The failed half of applySchedulingDecisions (scheduler.go:472-487 after tick, :416-425 for preassigned tasks)."""
+        if tid not in self.last_decisions:
+            return False
+        old, preassigned = self.last_decisions.pop(tid)
+        new_t = self.all_tasks.get(tid)
+        if new_t is not None:
+            ent = self.nodes.get(new_t.get("NodeID", ""))
+            if ent is not None and not old.get("NodeID"):
+                self._remove_task(ent, new_t)
+            elif ent is not None and preassigned and _state(_get(new_t, "Status", "State")) == ASSIGNED:
+                self._remove_task(ent, new_t)
+        self.all_tasks[tid] = old
+        if preassigned:
+            self.pending_preassigned[tid] = old
+        else:
+            self.unassigned[tid] = old
+        return True
 
     def _run_groups(self, groups, decisions):
         """groups: list of [(tid, task)...] sharing a spec; one swp_schedule_groups call, groups in order."""
@@ -618,9 +675,28 @@ class PyHostScheduler:
             self._push_failures({g[0][1].get("ServiceID", "") for g in groups[cut:]})
             self._run_groups(groups[cut:], decisions)
             return
-        descs = np.concatenate([self.task_desc(g[0][1]) for g in groups])
+        descs = []
+        for i, g in enumerate(groups):
+            try:
+                descs.append(self.task_desc(g[0][1]))
+            except (abi.SwpError, abi.Unsupported) as err:   # a predicate set the engine refuses: this group is deferred, the others run
+                self._run_groups(groups[:i], decisions)
+                for tid, t in g:
+                    self._defer(tid, t, err, decisions)
+                self._run_groups(groups[i + 1:], decisions)
+                return
+        descs = np.concatenate(descs)
         sizes = np.array([len(g) for g in groups], dtype=np.uint32)
-        out, hist = self.e.schedule_groups(descs, sizes)
+        try:
+            out, hist = self.e.schedule_groups(descs, sizes)
+        except (abi.SwpError, abi.Unsupported) as err:
+            if len(groups) > 1:   # find the group(s) the engine cannot take: run them one by one
+                for g in groups:
+                    self._run_groups([g], decisions)
+                return
+            for tid, t in groups[0]:
+                self._defer(tid, t, err, decisions)
+            return
         off = 0
         for gi, g in enumerate(groups):
             for i, (tid, t) in enumerate(g):
@@ -634,9 +710,14 @@ class PyHostScheduler:
     def _run_one_offs(self, run, decisions):
         if not run:
             return
-        descs = np.concatenate([self.task_desc(t) for _, t in run])
-        out, hist = self.e.schedule_batch(descs)
-        for (tid, t), n, h in zip(run, out, hist):
+        descs = np.concatenate([d for _, _, d in run])
+        try:
+            out, hist = self.e.schedule_batch(descs)
+        except (abi.SwpError, abi.Unsupported) as err:
+            for tid, t, _ in run:
+                self._defer(tid, t, err, decisions)
+            return
+        for (tid, t, _), n, h in zip(run, out, hist):
             if n >= 0:
                 self._place(tid, t, n, decisions)
             else:
@@ -648,9 +729,15 @@ class PyHostScheduler:
         queue = [(tid, t) for tid, t in self.unassigned.items() if t is not None and not t.get("NodeID")]
         self.unassigned.clear()
         decisions = []
+        self.last_decisions = {k: v for k, v in self.last_decisions.items() if v[1]}   # the previous tick's decisions are final now
         if not queue:
             return decisions
-        self._push_failures({t.get("ServiceID", "") for _, t in queue})
+        try:
+            self._push_failures({t.get("ServiceID", "") for _, t in queue})
+        except (abi.SwpError, abi.Unsupported) as err:   # nothing was scheduled: the whole queue stays queued
+            for tid, t in queue:
+                self._defer(tid, t, err, decisions)
+            return decisions
         grouped, one_off = {}, []
         for tid, t in queue:
             if t.get("SpecVersion") is not None:
@@ -661,12 +748,17 @@ class PyHostScheduler:
         # one-off tasks: a task with spread preferences is a group of one and must keep its place in the order
         run = []
         for tid, t in one_off:
-            if int(self.task_desc(t)["spread_set"][0]):
+            try:
+                d = self.task_desc(t)   # Pipeline.SetTask once per one-off task
+            except (abi.SwpError, abi.Unsupported) as err:
+                self._defer(tid, t, err, decisions)
+                continue
+            if int(d["spread_set"][0]):
                 self._run_one_offs(run, decisions)
                 run = []
                 self._run_groups([[(tid, t)]], decisions)
             else:
-                run.append((tid, t))
+                run.append((tid, t, d))
         self._run_one_offs(run, decisions)
         return decisions
 

@@ -109,6 +109,13 @@ class Scheduler:
     def tick(self):
         return self._json_result(self.L.swp_sched_tick)
 
+    def reject_decision(self, tid):
+        """The failed half of applySchedulingDecisions (scheduler.go:472-487): undo the decision of the last tick for `tid`."""
+        b = _b(tid)
+        found = C.c_int(0)
+        self._ck(self.L.swp_sched_reject_decision(self.h, b, len(b), C.byref(found)))
+        return bool(found.value)
+
     def process_preassigned(self):
         return self._json_result(self.L.swp_sched_process_preassigned)
 

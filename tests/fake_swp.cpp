@@ -252,8 +252,17 @@ int swp_spread_set(swp_engine* e, const swp_spread* lv, uint32_t n, uint32_t* id
     *id_out = n ? e->add_set(4, t) : 0;
     return SWP_OK;
 }
+// failure injection for the host layer's error paths: a device call that carries a task of a service named "boom..." is
+// refused as a whole (nothing applied), the way the real engine refuses a group beyond its heap capacity
+static bool boom(const swp_engine* e, const swp_task_desc& d) { return e->name(SWP_SPACE_SERVICE, d.service).rfind("boom", 0) == 0; }
 int swp_schedule_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t n, int32_t* out_node, uint32_t* hist) {
     e->say("schedule_batch n=%u", n);
+    for (uint32_t i = 0; i < n; ++i)
+        if (boom(e, tasks[i])) {
+            e->err = "fake: batch refused";
+            e->say("  refused");
+            return SWP_ERANGE;
+        }
     for (uint32_t i = 0; i < n; ++i) {
         out_node[i] = e->answer(tasks[i], hist ? hist + (size_t)i * SWP_NFILTERS : nullptr);
         if (!e->quiet) e->say("  task %s -> %d", e->desc(tasks[i]).c_str(), out_node[i]);
@@ -262,6 +271,12 @@ int swp_schedule_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t n, in
 }
 int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node, uint32_t* hist) {
     e->say("schedule_groups n=%u", n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (boom(e, groups[g])) {
+            e->err = "fake: group refused";
+            e->say("  refused");
+            return SWP_ERANGE;
+        }
     size_t off = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {
         if (!e->quiet) e->say("  group k=%u %s", sizes[g], e->desc(groups[g]).c_str());

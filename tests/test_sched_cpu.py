@@ -327,3 +327,103 @@ def test_cxx_json_boundary_round_trips_strings_and_numbers():
     for bad in [b"", b"{", b'{"ID": "x",}', b'{"ID": "\\ud800"} trailing', b'[1, 2', b'{"a": tru}', b'"\\x"', b"{" * 100 + b"}" * 100]:
         flag = C.c_int()
         assert s.L.swp_sched_create_task(s.h, bad, len(bad), C.byref(flag)) == abi.SWP_EINVAL, bad
+
+
+# ------------------------------------------------------------------------------------------------ round-2 host-layer fixes
+def _both_hosts():
+    lib = fakelib.build()
+    return [swhost.PyHostScheduler(engine=abi.Engine(lib_path=lib)), swsched.Scheduler(engine=abi.Engine(lib_path=lib))]
+
+
+def _task(tid, sid, ver=None, **kw):
+    t = dict({"ID": tid, "ServiceID": sid, "DesiredState": 512, "Status": {"State": 64}}, **kw)
+    if ver is not None:
+        t["SpecVersion"] = {"Index": ver}
+    return t
+
+
+def test_tick_survives_a_refused_device_call():
+    """A device call the engine refuses (here: the test double refuses every call that carries a task of service "boom*")
+    must not lose the tick: the other groups / tasks are placed, the refused ones come back as Deferred decision lines and
+    stay queued (tick was not failure-atomic)."""
+    logs = []
+    for s in _both_hosts():
+        for i in range(4):
+            s.create_node({"ID": "n%d" % i, "Status": {"State": 2}, "Spec": {"Availability": 0}})
+        for sid in ("good1", "boom-group", "good2", "boom-oneoff", "plain"):
+            s.set_service(sid)
+        tasks = [_task("g1a", "good1", 1), _task("g1b", "good1", 1), _task("b1", "boom-group", 1), _task("b2", "boom-group", 1),
+                 _task("g2a", "good2", 3), _task("o1", "plain"), _task("ob", "boom-oneoff"), _task("o2", "plain")]
+        for t in tasks:
+            s.create_task(t)
+        d1 = s.tick()
+        by = {d["ID"]: d for d in d1}
+        assert set(by) == {t["ID"] for t in tasks}
+        for tid in ("b1", "b2"):
+            assert by[tid].get("Deferred") is True and by[tid]["NodeID"] == "" and "refused" in by[tid]["Err"]
+        for tid in ("g1a", "g1b", "g2a"):
+            assert not by[tid].get("Deferred")
+        # one-off run: the refused batch defers every task of that run (one device call), nothing is lost
+        assert by["ob"].get("Deferred") is True
+        d2 = s.tick()                      # the deferred tasks are still queued
+        assert {"b1", "b2", "ob"} <= {d["ID"] for d in d2}
+        logs.append((d1, d2, fakelib.take_log(s.e)))
+    assert logs[0][0] == logs[1][0] and logs[0][1] == logs[1][1] and logs[0][2] == logs[1][2]   # the twins agree call by call
+
+
+def test_failure_buckets_are_reset_when_cleanup_erases_them():
+    """after cleanupFailures (nodeinfo.go:163-183) erased a (service, version) bucket the engine kept the old count
+    (>= 5 down-ranks the node for ever). The next tick of that service must push 0."""
+    logs = []
+    for s in _both_hosts():
+        s.create_node({"ID": "n0", "Status": {"State": 2}, "Spec": {"Availability": 0}})
+        s.set_service("svc")
+        s.set_service("other")
+        for k in range(5):                 # five failures of svc on n0
+            t = _task("f%d" % k, "svc", NodeID="n0")
+            t["Status"] = {"State": 512}
+            s.create_task(t)
+            s.update_task(dict(t, Status={"State": 704}))   # FAILED
+        s.create_task(_task("q1", "svc"))
+        s.tick()
+        pushed = [l for l in fakelib.take_log(s.e) if l.startswith("failures ")]
+        assert pushed and pushed[-1].rstrip().endswith("5"), pushed
+        s.advance(6 * 60)                  # past monitorFailures (5 min)
+        t = _task("x", "other", NodeID="n0")
+        t["Status"] = {"State": 512}
+        s.create_task(t)
+        s.update_task(dict(t, Status={"State": 704}))       # taskFailed -> cleanupFailures erases svc's bucket
+        s.create_task(_task("q2", "svc"))
+        s.tick()
+        pushed = [l for l in fakelib.take_log(s.e) if l.startswith("failures ") and "svc@" in l]
+        assert pushed and pushed[-1].rstrip().endswith("0"), pushed
+        logs.append(pushed)
+    assert logs[0] == logs[1]
+
+
+def test_reject_decision_rolls_a_placement_back():
+    """scheduler.go:472-487: a decision whose store commit failed is undone — old task back in allTasks and on the queue,
+    NodeInfo.removeTask(new) in the engine (one swp_commit(remove))."""
+    logs = []
+    for s in _both_hosts():
+        for i in range(2):
+            s.create_node({"ID": "n%d" % i, "Status": {"State": 2}, "Spec": {"Availability": 0}, "Description": {"Resources": {"NanoCPUs": 8 * 10**9, "MemoryBytes": 2**34}}})
+        s.set_service("svc")
+        s.create_task(_task("t1", "svc", Spec={"Resources": {"Reservations": {"NanoCPUs": 10**9}}}))
+        s.create_task(_task("t2", "svc"))
+        d = {x["ID"]: x for x in s.tick()}
+        assert d["t1"]["NodeID"]
+        fakelib.take_log(s.e)
+        assert s.reject_decision("t1") is True
+        log = fakelib.take_log(s.e)
+        assert len(log) == 1 and "commit" in log[0] and "remove" in log[0], log
+        assert s.reject_decision("t1") is False            # only once
+        assert s.reject_decision("nope") is False
+        info = s.node_info(d["t1"]["NodeID"])
+        assert "t1" not in info["Tasks"]
+        d2 = {x["ID"]: x for x in s.tick()}                # t1 is queued again, t2 is not
+        assert "t1" in d2 and (("t2" in d2) == (not d["t2"]["NodeID"]))   # (the double answers at random: t2 may have been unplaceable)
+        if "t2" not in d2:
+            assert s.reject_decision("t2") is False        # the earlier tick's decisions are final
+        logs.append((d, d2, log))
+    assert logs[0] == logs[1]
