@@ -258,13 +258,13 @@ def main():
         t_rounds = []
         for rnd in range(args.rounds):
             t0 = time.perf_counter()
-            for n in prev:                             # reactivate
-                row = eng.node_get(int(n))
-                eng.node_update_dynamic(int(n), row.flags | abi.NODE_READY, row.cpu, row.mem, row.total)
             drained = rng.choice(wl.N, size=max(wl.N // 10, 1), replace=False)
-            for n in drained:                          # Availability = DRAIN
-                row = eng.node_get(int(n))
-                eng.node_update_dynamic(int(n), row.flags & ~abi.NODE_READY, row.cpu, row.mem, row.total)
+            touched = np.concatenate([prev, drained]).astype(np.uint32)
+            rows = eng.node_get_many(touched)          # two calls per round instead of four per node
+            upd = np.zeros(len(touched), dtype=abi.NODE_DYNAMIC_DTYPE)
+            upd["node"], upd["cpu"], upd["mem"], upd["total"] = touched, rows["cpu"], rows["mem"], rows["total"]
+            upd["flags"] = np.where(np.arange(len(touched)) < len(prev), rows["flags"] | abi.NODE_READY, rows["flags"] & ~np.uint32(abi.NODE_READY))
+            eng.node_update_dynamic_many(upd)          # reactivate the previous round's nodes, Availability = DRAIN for this round's
             gone = np.nonzero(np.isin(assign, drained))[0]
             if len(gone):
                 pl = np.zeros(len(gone), dtype=abi.PLACEMENT_DTYPE)

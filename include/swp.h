@@ -122,6 +122,16 @@ int swp_node_upsert(swp_engine*, const swp_node_row* row,
 int swp_node_update_dynamic(swp_engine*, uint32_t node, uint32_t flags, int64_t cpu, int64_t mem, uint32_t total);
 /* nodeSet.remove, nodeset.go:46-48 */
 int swp_node_remove(swp_engine*, uint32_t node);
+/* Bulk forms for bursts of node events (a drain round touches 10 % of the cluster: scheduler.go:368-396 once per node): one
+ * call instead of one per node. Same semantics and error behaviour as the single-node calls, applied in array order; the
+ * first failing row stops the call (rows before it stay applied) and is named in swp_last_error. */
+typedef struct {
+    uint32_t node, flags;      /* SWP_NODE_* as in swp_node_row.flags */
+    int64_t  cpu, mem;         /* AvailableResources */
+    uint32_t total, reserved;  /* ActiveTasksCount */
+} swp_node_dynamic;            /* 32 bytes */
+int swp_node_update_dynamic_many(swp_engine*, const swp_node_dynamic* rows, uint32_t n);
+int swp_node_get_many(swp_engine*, const uint32_t* nodes, uint32_t n, swp_node_row* out);
 /* nodeSet.nodeInfo, nodeset.go:23-29: SWP_ENOTFOUND <-> errNodeNotFound */
 int swp_node_get(swp_engine*, uint32_t node, swp_node_row* out);
 /* NodeInfo.ActiveTasksCountByService[service] = count (nodeinfo.go:32) */

@@ -83,6 +83,10 @@ PLACEMENT_DTYPE = np.dtype([("node", "<u4"), ("service", "<u4"), ("cpu", "<i8"),
 ENF_NODE_DTYPE = np.dtype([("node", "<u4"), ("first_task", "<u4"), ("n_tasks", "<u4"), ("reserved", "<u4"), ("cpu", "<i8"), ("mem", "<i8")])
 ENF_TASK_DTYPE = np.dtype([("cpu", "<i8"), ("mem", "<i8"), ("constraint_set", "<u4"), ("flags", "<u4"), ("desired_state", "<u4"), ("state", "<u4")])
 ENF_RESERVATIONS = 1
+NODE_DYNAMIC_DTYPE = np.dtype([("node", "<u4"), ("flags", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("total", "<u4"), ("reserved", "<u4")])
+NODE_ROW_DTYPE = np.dtype([("node", "<u4"), ("flags", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("total", "<u4"), ("os", "<u4"), ("arch", "<u4"), ("os_fold", "<u4"),
+                           ("arch_fold", "<u4"), ("hostname_fold", "<u4"), ("id_fold", "<u4"), ("reserved", "<u4"), ("ip", "u1", (16,)), ("version", "<u8")])
+assert NODE_DYNAMIC_DTYPE.itemsize == 32 and NODE_ROW_DTYPE.itemsize == C.sizeof(NodeRow)
 # node-range shards (include/swp.h): swp_proposal / swp_shard_pick
 SHARD_CAND = 4
 PROPOSAL_DTYPE = np.dtype([("level", "<u4"), ("n_cand", "<u4"), ("word", "<u4", (SHARD_CAND,)), ("bits", "<u8", (SHARD_CAND,)), ("exc_hi", "<u8"),
@@ -156,6 +160,8 @@ def load_library(path=None):
         "swp_node_upsert": ([vp, P(NodeRow), P(KV), u32, P(KV), u32, P(u32), u32], C.c_int),
         "swp_node_update_dynamic": ([vp, u32, u32, i64, i64, u32], C.c_int),
         "swp_node_remove": ([vp, u32], C.c_int),
+        "swp_node_update_dynamic_many": ([vp, vp, u32], C.c_int),
+        "swp_node_get_many": ([vp, vp, u32, vp], C.c_int),
         "swp_node_get": ([vp, u32, P(NodeRow)], C.c_int),
         "swp_node_set_svc_count": ([vp, u32, u32, u32], C.c_int),
         "swp_node_get_svc_count": ([vp, u32, u32, P(u32)], C.c_int),
@@ -340,6 +346,17 @@ class Engine:
 
     def node_update_dynamic(self, node, flags, cpu, mem, total):
         self._ck(self.L.swp_node_update_dynamic(self.h, node, flags, cpu, mem, total))
+
+    def node_update_dynamic_many(self, rows):
+        """rows: NODE_DYNAMIC_DTYPE array (swp_node_update_dynamic_many: a burst of node events in one call)."""
+        rows = np.ascontiguousarray(rows, dtype=NODE_DYNAMIC_DTYPE)
+        self._ck(self.L.swp_node_update_dynamic_many(self.h, rows.ctypes.data, len(rows)))
+
+    def node_get_many(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+        out = np.zeros(len(nodes), dtype=NODE_ROW_DTYPE)
+        self._ck(self.L.swp_node_get_many(self.h, nodes.ctypes.data, len(nodes), out.ctypes.data))
+        return out
 
     def node_remove(self, node):
         self._ck(self.L.swp_node_remove(self.h, node))

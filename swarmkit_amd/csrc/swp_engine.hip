@@ -1265,6 +1265,24 @@ int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_
     return SWP_OK;
 }
 
+int swp_node_update_dynamic_many(swp_engine* e, const swp_node_dynamic* rows, uint32_t n) {
+    if (!e || (!rows && n)) return SWP_EINVAL;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int rc = swp_node_update_dynamic(e, rows[i].node, rows[i].flags, rows[i].cpu, rows[i].mem, rows[i].total);
+        if (rc) return e->fail(rc, "swp_node_update_dynamic_many: row %u (node %u)", i, rows[i].node);
+    }
+    return SWP_OK;
+}
+
+int swp_node_get_many(swp_engine* e, const uint32_t* nodes, uint32_t n, swp_node_row* out) {
+    if (!e || ((!nodes || !out) && n)) return SWP_EINVAL;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int rc = swp_node_get(e, nodes[i], &out[i]);
+        if (rc) return e->fail(rc, "swp_node_get_many: row %u (node %u)", i, nodes[i]);
+    }
+    return SWP_OK;
+}
+
 int swp_node_remove(swp_engine* e, uint32_t node) {
     if (!e) return SWP_EINVAL;
     e->host_dirty_since_save = true;

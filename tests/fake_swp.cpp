@@ -184,6 +184,16 @@ int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_
     e->say("update_dynamic %s", e->name(SWP_SPACE_NODE_ID, node).c_str());
     return SWP_OK;
 }
+int swp_node_update_dynamic_many(swp_engine* e, const swp_node_dynamic* rows, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (int rc = swp_node_update_dynamic(e, rows[i].node, rows[i].flags, rows[i].cpu, rows[i].mem, rows[i].total)) return rc;
+    return SWP_OK;
+}
+int swp_node_get_many(swp_engine* e, const uint32_t* nodes, uint32_t n, swp_node_row* out) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (int rc = swp_node_get(e, nodes[i], &out[i])) return rc;
+    return SWP_OK;
+}
 int swp_node_remove(swp_engine* e, uint32_t node) {
     if (node < e->nodes.size()) e->nodes[node] = FakeNode();
     e->present_dirty = true;
