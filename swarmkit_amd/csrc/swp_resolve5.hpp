@@ -72,7 +72,6 @@ struct R5Lds {
     u64* lv;         // [R5_J][rs]      nodes at level lb .. lb+J-1 (slot = level % J)
     u64* below;      // [rs]            nodes below the ring
     u64* tk;         // [2][rs]         picks of the previous / the current round
-    u64* scratch;    // [R5_LW][rs]     per lister wave: same-service commits of the last round as a row
     u64* rr;         // [n_rr][rs]      exact mode: nodes whose residual cpu (rows 0..n_dc-1) / memory (rows n_dc..) is >= the row's threshold
     int32_t* thr;    // [R5_RRMAX]      the thresholds, resource units
     u64* red;        // [64]            block reductions
@@ -84,10 +83,11 @@ struct R5Lds {
     u32 rs;          // row stride in words
 };
 
-inline __host__ __device__ u32 r5_row_stride(u32 n_words) { return (n_words + 7u) & ~7u; }
+// rows are padded to whole 64-word windows: lane l of a wave owns words {l + 64 k}, k < K, all of them inside the row (no bounds checks)
+inline __host__ __device__ u32 r5_row_stride(u32 n_words) { return (n_words + 63u) & ~63u; }
 inline __host__ __device__ size_t r5_lds_bytes(u32 n_nodes, u32 n_words, u32 n_rr) {
     const size_t rs = r5_row_stride(n_words);
-    return (size_t)(R5_NBMAX + R5_J + 1 + 2 + R5_LW + n_rr) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
+    return (size_t)(R5_NBMAX + R5_J + 1 + 2 + n_rr) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
            (size_t)2 * R5_B * R5_HAND_U32 * 4 + R5S_COUNT * 4 + R5_RRMAX * 4 + (size_t)n_nodes * 8;
 }
 WV_DEV R5Lds r5_layout(u64* lds, u32 n_words, u32 n_rr) {
@@ -97,8 +97,7 @@ WV_DEV R5Lds r5_layout(u64* lds, u32 n_words, u32 n_rr) {
     L.lv = L.planes + (size_t)R5_NBMAX * L.rs;
     L.below = L.lv + (size_t)R5_J * L.rs;
     L.tk = L.below + L.rs;
-    L.scratch = L.tk + 2 * L.rs;
-    L.rr = L.scratch + (size_t)R5_LW * L.rs;
+    L.rr = L.tk + 2 * L.rs;
     L.red = L.rr + (size_t)n_rr * L.rs;
     L.lists = reinterpret_cast<u32*>(L.red + 64);
     L.ring = L.lists + 2 * R5_B * R5_LIST_U32;
@@ -291,14 +290,12 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
     u64 LV0[K], BEL[K];
     for (int k = 0; k < K; ++k) {
         const u32 w = lane + 64 * k;
-        const bool in = w < L.rs;
-        LV0[k] = in ? L.lv[(size_t)(lb % R5_J) * L.rs + w] : 0ull;
-        BEL[k] = in ? L.below[w] : 0ull;
+        LV0[k] = L.lv[(size_t)(lb % R5_J) * L.rs + w];
+        BEL[k] = L.below[w];
     }
     // (service, node) of the last two rounds' commits: lanes 0..B-1 hold one round, lanes ... the other needs a second pair
     const u32 r0_svc = lane < R5_B ? L.ring[2 * lane] : 0xFFFFFFFFu, r0_node = lane < R5_B ? L.ring[2 * lane + 1] : 0u;
     const u32 r1_svc = lane < R5_B ? L.ring[2 * (R5_B + lane)] : 0xFFFFFFFFu, r1_node = lane < R5_B ? L.ring[2 * (R5_B + lane) + 1] : 0u;
-    u64* sr = L.scratch + (size_t)lw * L.rs;
     R5_LT(0);   // prologue: task records, first row requests, ring masks
 
     for (u32 t = 0; t < R5_TPW; ++t) {
@@ -333,26 +330,20 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
         if (EXACT && (flags & RT_RES)) {   // uniform
             const u64* rc = L.rr + (size_t)((flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * L.rs;
             const u64* rm = L.rr + (size_t)(a.n_dc + ((flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * L.rs;
-            for (int k = 0; k < K; ++k) {
-                const u32 w = lane + 64 * k;
-                if (w < L.rs) F[k] &= rc[w] & rm[w];
-            }
+            for (int k = 0; k < K; ++k) F[k] &= rc[lane + 64 * k] & rm[lane + 64 * k];
         }
         u64 mk[K];
         // commits of the last two rounds may still be on their way to X in memory: patch them in from the ring
-        const u64 match = wv::ballot(r0_svc == svc || r1_svc == svc);
+        u64 match = wv::ballot(r0_svc == svc || r1_svc == svc);
         R5_LT(1);   // rows have arrived
-        if (match) {
-            if (r0_svc == svc) wv::lds_or64(sr + (r0_node >> 6), 1ull << (r0_node & 63));
-            if (r1_svc == svc) wv::lds_or64(sr + (r1_node >> 6), 1ull << (r1_node & 63));
-            wv::wave_sync();
+        while (match) {   // seldom any: one ring entry at a time, on the scalar side
+            const u32 l = (u32)wv::ffs64(match);
+            match &= match - 1;
+            const u32 s0 = wv::readlane(r0_svc, l), n0 = wv::readlane(r0_node, l), s1 = wv::readlane(r1_svc, l), n1 = wv::readlane(r1_node, l);
             for (int k = 0; k < K; ++k) {
-                const u32 w = lane + 64 * k;
-                if (w < L.rs) X[k] |= sr[w];
+                if (s0 == svc && (n0 >> 6) == lane + 64 * k) X[k] |= 1ull << (n0 & 63);
+                if (s1 == svc && (n1 >> 6) == lane + 64 * k) X[k] |= 1ull << (n1 & 63);
             }
-            wv::wave_sync();
-            if (r0_svc == svc) sr[r0_node >> 6] = 0;
-            if (r1_svc == svc) sr[r1_node >> 6] = 0;
         }
         u64 any_mk = 0;
         for (int k = 0; k < K; ++k) {
@@ -385,8 +376,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             for (u32 jl = 1; jl < R5_J && lvl == 0xFFFFFFFFu; ++jl) {
                 u64 any = 0;
                 for (int k = 0; k < K; ++k) {
-                    const u32 w = lane + 64 * k;
-                    c[k] = w < L.rs ? mk[k] & L.lv[(size_t)((lb + jl) % R5_J) * L.rs + w] : 0ull;
+                    c[k] = mk[k] & L.lv[(size_t)((lb + jl) % R5_J) * L.rs + lane + 64 * k];
                     any |= c[k];
                 }
                 if (wv::ballot(any != 0)) lvl = lb + jl;
@@ -690,7 +680,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
     const R5Lds L = r5_layout(wv::lds(), a.n_words, EXACT ? a.n_dc + a.n_dm : 0u);
     u32 par = 0;   // parity of the reduction scratch
 
-    for (u32 i = tid; i < (2 + R5_LW) * L.rs; i += R5_THREADS) L.tk[i] = 0;   // TK rows and scratch rows are contiguous
+    for (u32 i = tid; i < 2 * L.rs; i += R5_THREADS) L.tk[i] = 0;
     for (u32 i = tid; i < a.n_nodes * 2; i += R5_THREADS) L.q[i] = a.qres[i];
     for (u32 i = tid; i < 2 * R5_B * 2; i += R5_THREADS) L.ring[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
     if (tid < R5S_COUNT) L.sh[tid] = 0;
