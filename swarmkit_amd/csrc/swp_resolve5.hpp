@@ -50,6 +50,9 @@ namespace swpdev {
 #define R5_KMAX 4                 // node words per lane: n_words <= 256 (16 384 nodes)
 #define R5_QLIM (1 << 30)         // residuals in resource units must stay below this (host checks)
 #define R5_RRMAX 64               // exact mode: demand-class rows (distinct cpu reservations + distinct memory reservations)
+#define R5_TREC 256               // task-record ring in LDS (entries; power of two, > 3 rounds + slack)
+#define R5_TREC_U32 8             // flags, svc, sc, kc, km, slot, -, -
+#define R5_AHEAD (3 * R5_B + 8)   // records staged this far beyond the current round's first task
 
 enum { R5_NONE = 0, R5_FAST = 1, R5_INFEASIBLE = 2, R5_COMPLEX = 3 };
 enum { R5_CUT_NOT = 0, R5_CUT_RELIST = 1, R5_CUT_GENERIC = 2 };
@@ -74,6 +77,7 @@ struct R5Lds {
     u64* tk;         // [2][rs]         picks of the previous / the current round
     u64* rr;         // [n_rr][rs]      exact mode: nodes whose residual cpu (rows 0..n_dc-1) / memory (rows n_dc..) is >= the row's threshold
     int32_t* thr;    // [R5_RRMAX]      the thresholds, resource units
+    u32* trec;       // [R5_TREC][R5_TREC_U32]  the listers' fields of the upcoming tasks, staged by the committer wave (ring by task index)
     u64* red;        // [64]            block reductions
     u32* lists;      // [2][R5_B][R5_LIST_U32]
     u32* ring;       // [2][R5_B][2]    (service, node) of the last two rounds' commits, by round parity
@@ -88,7 +92,7 @@ inline __host__ __device__ u32 r5_row_stride(u32 n_words) { return (n_words + 63
 inline __host__ __device__ size_t r5_lds_bytes(u32 n_nodes, u32 n_words, u32 n_rr) {
     const size_t rs = r5_row_stride(n_words);
     return (size_t)(R5_NBMAX + R5_J + 1 + 2 + n_rr) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
-           (size_t)2 * R5_B * R5_HAND_U32 * 4 + R5S_COUNT * 4 + R5_RRMAX * 4 + (size_t)n_nodes * 8;
+           (size_t)2 * R5_B * R5_HAND_U32 * 4 + R5S_COUNT * 4 + R5_RRMAX * 4 + (size_t)R5_TREC * R5_TREC_U32 * 4 + (size_t)n_nodes * 8;
 }
 WV_DEV R5Lds r5_layout(u64* lds, u32 n_words, u32 n_rr) {
     R5Lds L;
@@ -104,7 +108,8 @@ WV_DEV R5Lds r5_layout(u64* lds, u32 n_words, u32 n_rr) {
     L.hand = L.ring + 2 * R5_B * 2;
     L.sh = L.hand + 2 * R5_B * R5_HAND_U32;
     L.thr = reinterpret_cast<int32_t*>(L.sh + R5S_COUNT);
-    L.q = L.thr + R5_RRMAX;
+    L.trec = reinterpret_cast<u32*>(L.thr + R5_RRMAX);
+    L.q = reinterpret_cast<int32_t*>(L.trec + R5_TREC * R5_TREC_U32);
     return L;
 }
 
@@ -253,6 +258,22 @@ WV_DEV void r5_rr_update(const R5Lds& L, u32 n_dc, u32 n_dm, u32 w, u64 bit, int
             if (qm < L.thr[n_dc + c]) wv::lds_andn64(L.rr + (size_t)(n_dc + c) * L.rs + w, bit);
 }
 
+// ---- task records: the six fields the listers need, from the batch's task array into the LDS ring -------------------
+// The task array is read once, front to back: every record is an L2 miss. The committer wave, idle most of a round, fetches
+// the records of the rounds to come; the listers then start from LDS instead of waiting for scalar loads. One lane per task.
+WV_DEV void r5_stage_records(const ResolveArgs& a, const R5Lds& L, u32 from, u32 to) {
+    for (u32 jj = from + wv::lane(); jj < to; jj += 64) {
+        const RTask* rt = a.rt + a.j0 + jj;
+        u32* o = L.trec + (size_t)(jj & (R5_TREC - 1)) * R5_TREC_U32;
+        o[0] = rt->flags;
+        o[1] = rt->svc;
+        o[2] = rt->sc;
+        o[3] = rt->kc;
+        o[4] = rt->km;
+        o[5] = rt->slot;
+    }
+}
+
 // ---- lister: candidate lists of the round that starts at window-local task jbase, into list buffer `buf` ------------
 // F and X rows are requested one task ahead. (F was written by the scan on other XCDs — an L2 miss here, ~1 µs — so the
 // committer wave touches the rows of the round after next while it has nothing else to do: r5_touch_rows.)
@@ -272,10 +293,10 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
         sv_[t] = 0;
         sc_[t] = 0;
         if (jj < a.count) {   // uniform
-            const RTask* rt = a.rt + a.j0 + jj;
-            fl_[t] = wv::uload(&rt->flags);
-            sv_[t] = wv::uload(&rt->svc);
-            if (EXACT) sc_[t] = wv::uload(&rt->sc);
+            const u32* rec = L.trec + (size_t)(jj & (R5_TREC - 1)) * R5_TREC_U32;   // broadcast reads, made scalar for the row addresses
+            fl_[t] = wv::readfirstlane(rec[0]);
+            sv_[t] = wv::readfirstlane(rec[1]);
+            sc_[t] = wv::readfirstlane(rec[2]);
         }
     }
     u64 Fn[K], Xn[K];
@@ -321,7 +342,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             if (lane == 0) { out[0] = R5_NONE; out[1] = 0; }
             continue;
         }
-        const RTask* rt = a.rt + a.j0 + jj;
+        const u32* rec = L.trec + (size_t)(jj & (R5_TREC - 1)) * R5_TREC_U32;
         const u32 flags = fl_[t], svc = sv_[t];
         if (flags & (RT_PORTS | RT_UNCOUNTED)) {
             if (lane == 0) { out[0] = R5_COMPLEX; out[1] = 0; }
@@ -424,7 +445,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
         cnt = min(cnt, (u32)R5_Q);
         R5_LT(3);   // entries
         // ResourceFilter against the exact residuals (filter.go:77-84 in resource units): lane b checks node 64w + b
-        const int32_t kc = (int32_t)wv::uload(&rt->kc), km = (int32_t)wv::uload(&rt->km);
+        const int32_t kc = (int32_t)rec[3], km = (int32_t)rec[4];
         u32 some = 1;
         if (!EXACT && (flags & RT_RES)) {
             wv::wave_sync();
@@ -458,7 +479,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             out[3] = svc;
             out[4] = (u32)kc;
             out[5] = (u32)km;
-            out[6] = wv::uload(&rt->slot);
+            out[6] = rec[5];
         }
         R5_LT(4);   // validation + header
     }
@@ -685,6 +706,8 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
     for (u32 i = tid; i < 2 * R5_B * 2; i += R5_THREADS) L.ring[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
     if (tid < R5S_COUNT) L.sh[tid] = 0;
     if (EXACT && tid < a.n_dc + a.n_dm) L.thr[tid] = a.thr[tid];
+    if (wave == R5_CW) r5_stage_records(a, L, 0, min((u32)R5_AHEAD, a.count));
+    u32 staged = min((u32)R5_AHEAD, a.count);   // committer wave: records of window-local tasks < staged are in the ring
     wv::barrier();
     if (tid == 0) {
         L.sh[R5S_NCOMMIT] = a.ctl->ncommit;
@@ -736,6 +759,11 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         } else if (wave == R5_CW) {
             r5_commit_memory(a, L, rpar ^ 1, pend, false);
             if (!EXACT) r5_touch_rows(a, j + nb + R5_B);   // what the listers will read in the next round
+            const u32 want = min(j + (u32)R5_AHEAD, a.count);   // read by the listers from the next round on (barriers in between)
+            if (staged < want) {
+                r5_stage_records(a, L, staged, want);
+                staged = want;
+            }
         } else {
             const u32* li = L.lists + ((size_t)buf * R5_B + lane) * R5_LIST_U32;
             const u32* tkprev = reinterpret_cast<const u32*>(L.tk + (size_t)tkp * L.rs);
