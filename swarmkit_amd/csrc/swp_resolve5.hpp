@@ -744,18 +744,12 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
 
     while (!fatal && j < a.count) {
         const u32 nb = min((u32)R5_B, a.count - j);
-        if (!have_lists) {
-            // (re)fill: lists of [j, j+nb) against the state as it is; no earlier picks to strike
-            if (wave >= 1 && wave <= R5_LW) r5_list<K, EXACT>(a, L, j, buf, wave - 1, nullptr);
-            else if (wave == 0)
-                for (u32 i = lane; i < 2 * L.rs; i += 64) L.tk[i] = 0;
-            wv::barrier();
-            have_lists = true;
-            R5_TICK(4);
-        }
         // ---------------- phase 1: match round [j, j+nb) || list round [j+nb, ...) || memory side of the last round ----------
+        // A (re)fill — no lists yet, or the prefetched ones were dropped by a cut — is the same phase with nothing to match:
+        // the lists of [j, j+nb) are built against the state as it is (one call site: the lister is the bulk of the code).
+        const bool matching = have_lists;
         if (wave >= 1 && wave <= R5_LW) {
-            r5_list<K, EXACT>(a, L, j + nb, buf ^ 1, wave - 1, (prof && wave == 1) ? lcy : nullptr);
+            r5_list<K, EXACT>(a, L, matching ? j + nb : j, matching ? buf ^ 1 : buf, wave - 1, (prof && wave == 1) ? lcy : nullptr);
         } else if (wave == R5_CW) {
             r5_commit_memory(a, L, rpar ^ 1, pend, false);
             if (!EXACT) r5_touch_rows(a, j + nb + R5_B);   // what the listers will read in the next round
@@ -764,6 +758,8 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 r5_stage_records(a, L, staged, want);
                 staged = want;
             }
+        } else if (!matching) {
+            for (u32 i = lane; i < 2 * L.rs; i += 64) L.tk[i] = 0;   // no earlier picks to strike
         } else {
             const u32* li = L.lists + ((size_t)buf * R5_B + lane) * R5_LIST_U32;
             const u32* tkprev = reinterpret_cast<const u32*>(L.tk + (size_t)tkp * L.rs);
@@ -840,6 +836,10 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         R5_TICK(0);
         wv::barrier();
         R5_TICK(1);
+        if (!matching) {   // uniform
+            have_lists = true;
+            continue;
+        }
         // ---------------- phase 2: the round's prefix into the LDS state + hand-over record ----------------
         if (wave == 0) {
             const u32 cut = L.sh[R5S_CUT0 + rpar];
