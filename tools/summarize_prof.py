@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Summarise a tools/profile_round.sh output directory: per-kernel stats (copied) and HBM bytes per launch from
-the FETCH_SIZE / WRITE_SIZE passes. rocprofv3 reports both counters in KB on gfx950 here; FETCH_SIZE
-under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section), so the corrected
-traffic is 2*FETCH + WRITE."""
+"""Summarise a tools/profile_round.sh output directory: HBM bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE
+passes (pmc_fetch_<name> / pmc_write_<name>). rocprofv3 reports both counters in KB on gfx950 here; FETCH_SIZE under-reports
+wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section), so the corrected traffic is 2*FETCH + WRITE."""
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
 
 
@@ -27,24 +27,33 @@ def per_kernel(dirname, counter):
 
 def main():
     out, tag = sys.argv[1], sys.argv[2]
-    fetch = per_kernel(os.path.join(out, "pmc_fetch"), "FETCH_SIZE")
-    write = per_kernel(os.path.join(out, "pmc_write"), "WRITE_SIZE")
-    kernels = {}
-    for k in sorted(set(fetch) | set(write)):
-        fk, fl = fetch.get(k, (0.0, 1))
-        wk, wl = write.get(k, (0.0, 1))
-        kernels[k] = {"launches": max(fl, wl), "FETCH_SIZE_KB_per_launch": fk / fl, "WRITE_SIZE_KB_per_launch": wk / wl,
-                      "hbm_bytes_per_launch_corrected": int((2 * fk / fl + wk / wl) * 1024)}
-    res = [v["hbm_bytes_per_launch_corrected"] for k, v in kernels.items() if "k_resolve" in k]
-    summary = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0, "
-                       "cfg3 100k x 10k; KB per launch as reported; corrected = 2*FETCH + WRITE (gfx950 FETCH_SIZE under-reports "
-                       "wide coalesced reads by 2x, MI355X_MICROARCH.md HBM section)",
-               "kernels": kernels, "k_resolve_hbm_bytes_per_launch": res[0] if res else None}
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except Exception:
+        commit = ""
+    runs = {}
+    per_launch = {}
+    for d in sorted(glob.glob(os.path.join(out, "pmc_fetch_*"))):
+        name = os.path.basename(d)[len("pmc_fetch_"):]
+        fetch = per_kernel(d, "FETCH_SIZE")
+        write = per_kernel(os.path.join(out, "pmc_write_" + name), "WRITE_SIZE")
+        kernels = {}
+        for k in sorted(set(fetch) | set(write)):
+            fk, fl = fetch.get(k, (0.0, 1))
+            wk, wl = write.get(k, (0.0, 1))
+            kernels[k] = {"launches": max(fl, wl), "FETCH_SIZE_KB_per_launch": fk / fl, "WRITE_SIZE_KB_per_launch": wk / wl,
+                          "hbm_bytes_per_launch_corrected": int((2 * fk / fl + wk / wl) * 1024)}
+            base = k.split("::")[-1].split("<")[0]
+            if base.startswith("k_"):
+                per_launch.setdefault(base, kernels[k]["hbm_bytes_per_launch_corrected"])
+        runs[name] = kernels
+    summary = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 0 [--shards 4]; "
+                       "KB per launch as reported; corrected = 2*FETCH + WRITE (gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, "
+                       "MI355X_MICROARCH.md HBM section)",
+               "source": "tools/profile_round.sh %s at commit %s" % (tag, commit or "?"),
+               "hbm_bytes_per_launch": per_launch, "runs": runs}
     json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
-    st = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
-    if st:
-        open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w").write(open(st[0]).read())
-    print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in kernels.items()}))
+    print(json.dumps(per_launch))
 
 
 if __name__ == "__main__":
