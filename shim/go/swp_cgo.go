@@ -455,7 +455,7 @@ func (sch *Scheduler) pushFailures(now time.Time, tasks []*api.Task) {
 	}
 }
 
-// explainFromHist: Pipeline.Explain (pipeline.go:84-103) from the engine's per-filter counters, in pipeline order
+// explainFromHist: Pipeline.Explain (pipeline.go:84-103) from the engine's per-filter counters (index = position in the pipeline)
 func explainFromHist(h []C.uint32_t) string {
 	one := [...]string{"1 node not available for new tasks", "insufficient resources on 1 node", "missing plugin on 1 node",
 		"scheduling constraints not satisfied on 1 node", "unsupported platform on 1 node", "host-mode port already in use on 1 node",
@@ -463,9 +463,14 @@ func explainFromHist(h []C.uint32_t) string {
 	many := [...]string{"%d nodes not available for new tasks", "insufficient resources on %d nodes", "missing plugin on %d nodes",
 		"scheduling constraints not satisfied on %d nodes", "unsupported platform on %d nodes", "host-mode port already in use on %d nodes",
 		"max replicas per node limit exceed", "cannot fulfill requested CSI volume mounts on %d nodes"}
+	order := make([]int, len(h))
+	for i := range order {
+		order[i] = i
+	}
+	sort.SliceStable(order, func(a, b int) bool { return h[order[a]] > h[order[b]] }) // pipeline.go:90-93: most failures first, ties in pipeline order
 	var parts []string
-	for i, n := range h {
-		switch {
+	for _, i := range order {
+		switch n := h[i]; {
 		case n == 1:
 			parts = append(parts, one[i])
 		case n > 1:
