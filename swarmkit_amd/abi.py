@@ -102,11 +102,12 @@ EXPORTS = [
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
     "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce", "swp_node_matches",
-    "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check",
+    "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check", "swp_node_update_dynamic_many", "swp_node_get_many",
+    "swp_shard_begin", "swp_shard_propose", "swp_shard_merge", "swp_shard_commit", "swp_shard_end",
     # include/swp_sched.h — the host layer above the engine
     "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
     "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
-    "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce",
+    "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_reject_decision", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce",
     "swp_constraint_parse", "swp_key_equal_fold", "swp_explain", "swp_parse_ip",
 ]
 
