@@ -813,7 +813,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 // registers is idempotent.
                 if (lane >= flushed && lane < at && m_pick != 0xFFFFFFFFu) wv::lds_or32(tkcur + (m_pick >> 5), 1u << (m_pick & 31));
                 flushed = at;
-                wv::wave_sync();
+                wv::lockstep();   // one wave's LDS operations execute in order: the gathers below see the atomics above without a wait
                 if (fast && bits == 0) {
                     u32 t[2 * R5_Q];
                     for (int k = 0; k < 2 * R5_Q; ++k) t[k] = eb[k] & ~tkcur[ew[k]];
@@ -832,6 +832,16 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 L.sh[R5S_CUT0 + rpar] = cut;
                 L.sh[R5S_WHY0 + rpar] = why;
             }
+            // the round's outcome per task, for the wave that writes the hand-over record in phase 2 (this one updates the levels)
+            if (lane < R5_B) {
+                u32* h = L.hand + ((size_t)rpar * R5_B + lane) * R5_HAND_U32;
+                h[0] = m_cls;   // R5_FAST / R5_INFEASIBLE / anything else: turned into R5H_* below
+                h[1] = m_pick;
+                h[4] = m_slot;
+                h[5] = m_svc;
+                h[6] = m_kc;
+                h[7] = m_km;
+            }
         }
         R5_TICK(0);
         wv::barrier();
@@ -841,34 +851,50 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
             continue;
         }
         // ---------------- phase 2: the round's prefix into the LDS state + hand-over record ----------------
+        // Three waves share it: the matcher moves the picked nodes one level up (planes, ring masks); waves 1 and 2 — idle, like
+        // all listers, until the next phase — read the matcher's outcome back from LDS: wave 1 turns it into the hand-over
+        // record and numbers the commits, wave 2 charges the reservations to the residuals and the demand-class rows.
+        static_assert((int)R5_FAST == (int)R5H_COMMIT && (int)R5_INFEASIBLE == (int)R5H_INF, "the matcher's class codes double as hand-over kinds");
         if (wave == 0) {
             const u32 cut = L.sh[R5S_CUT0 + rpar];
             const u32 NB = L.sh[R5S_NB], lb = L.sh[R5S_LB];
+            const bool com = lane < cut && m_cls == R5_FAST;
+            bool over = false;
+            if (com) over = r5_bump_level(L, NB, lb, m_pick >> 6, 1ull << (m_pick & 63), m_lvl);
+            const u64 mc = wv::ballot(com);
+            const bool low_pick = wv::ballot(com && m_lvl <= lb) != 0;
+            const bool any_over = wv::ballot(over) != 0;
+            if (lane == 0) {
+                if (any_over) L.sh[R5S_REBUILD] = 1;
+                // ring policy: two rounds in a row without a pick at the ring's lowest level → the ring moves up one level
+                if (mc) {
+                    if (!low_pick) {
+                        const u32 qn = L.sh[R5S_QUIET] + 1;
+                        L.sh[R5S_QUIET] = qn;
+                        if (qn >= 2) L.sh[R5S_ADVANCE] = 1;
+                    } else
+                        L.sh[R5S_QUIET] = 0;
+                }
+                L.sh[R5S_ROUNDS] += 1;
+                if (cut == nb) L.sh[R5S_FULL] += 1;
+                else if (L.sh[R5S_WHY0 + rpar] == R5_CUT_GENERIC) L.sh[R5S_CUT_CLASS] += 1;
+                else L.sh[R5S_CUT_EMPTY] += 1;
+            }
+        } else if (wave == 1) {
+            const u32 cut = L.sh[R5S_CUT0 + rpar];
+            u32* h = L.hand + ((size_t)rpar * R5_B + (lane < R5_B ? lane : 0u)) * R5_HAND_U32;
+            const u32 kind0 = lane < R5_B ? h[0] : (u32)R5_NONE;
             const bool act = lane < cut;
-            const bool com = act && m_cls == R5_FAST, inf = act && m_cls == R5_INFEASIBLE;
+            const bool com = act && kind0 == R5_FAST, inf = act && kind0 == R5_INFEASIBLE;
             const u64 mc = wv::ballot(com), mi = wv::ballot(inf);
             const u32 nc0 = L.sh[R5S_NCOMMIT], ni0 = L.sh[R5S_NINF];
             const u32 ci = nc0 + wv::mbcnt(mc);
             u32 rsvc = 0xFFFFFFFFu, rnode = 0;
-            bool over = false;
-            u32* h = L.hand + ((size_t)rpar * R5_B + lane) * R5_HAND_U32;
             if (com) {
-                const u32 n = m_pick, w = n >> 6;
-                const u64 bit = 1ull << (n & 63);
-                over = r5_bump_level(L, NB, lb, w, bit, m_lvl);
-                L.q[2 * n] -= (int32_t)m_kc;
-                L.q[2 * n + 1] -= (int32_t)m_km;
-                rsvc = m_svc;
-                rnode = n;
-                h[0] = R5H_COMMIT;
-                h[1] = n;
+                rsvc = h[5];
+                rnode = h[1];
                 h[2] = ci;
-                h[4] = m_slot;
-                h[5] = m_svc;
-                h[6] = m_kc;
-                h[7] = m_km;
             } else if (inf) {
-                h[0] = R5H_INF;
                 h[2] = ni0 + wv::mbcnt(mi);
                 h[3] = ci;   // commits before this task
             } else if (lane < R5_B)
@@ -877,12 +903,29 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 L.ring[2 * (rpar * R5_B + lane)] = rsvc;
                 L.ring[2 * (rpar * R5_B + lane) + 1] = rnode;
             }
+            wv::lockstep();   // every lane has read the counters before lane 0 moves them on
+            if (lane == 0) {
+                L.sh[R5S_NCOMMIT] = nc0 + (u32)wv::popc64(mc);
+                L.sh[R5S_NINF] = ni0 + (u32)wv::popc64(mi);
+                L.sh[R5S_HJ0 + rpar] = j;
+                L.sh[R5S_HV0 + rpar] = 1;
+            }
+        } else if (wave == 2) {
+            const u32 cut = L.sh[R5S_CUT0 + rpar];
+            const u32* h = L.hand + ((size_t)rpar * R5_B + (lane < R5_B ? lane : 0u)) * R5_HAND_U32;
+            // (wave 1 rewrites h[0] of the tasks behind the cut only: the ones read here keep the matcher's code)
+            const bool com = lane < cut && h[0] == R5_FAST;
+            const u32 n = com ? h[1] : 0u;
+            int32_t qc = R5_QLIM, qm = R5_QLIM;
+            if (com) {
+                qc = L.q[2 * n] - (int32_t)h[6];
+                qm = L.q[2 * n + 1] - (int32_t)h[7];
+                L.q[2 * n] = qc;
+                L.q[2 * n + 1] = qm;
+            }
             if (EXACT) {
-                // demand-class rows: a committed node leaves every row whose threshold its residual no longer meets. The
-                // thresholds come through the scalar cache in a wave-uniform loop (ascending within each group: the largest
-                // one tells whether any lane has anything to do — mostly not)
-                const u32 n = com ? m_pick : 0u;
-                const int32_t qc = com ? L.q[2 * n] : R5_QLIM, qm = com ? L.q[2 * n + 1] : R5_QLIM;
+                // demand-class rows: a committed node leaves every row whose threshold its residual no longer meets
+                // (ascending thresholds within each group: the largest one tells whether any lane has anything to do)
                 const u32 ndc = a.n_dc, ndm = a.n_dm;
                 u64* const rw = L.rr + (n >> 6);
                 const u64 rbit = 1ull << (n & 63);
@@ -901,28 +944,6 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                         for (u32 c = 0; c < ndm; ++c)
                             if (qm < wv::uload(a.thr + ndc + c)) wv::lds_andn64(rw + (size_t)(ndc + c) * L.rs, rbit);
                 }
-            }
-            const bool low_pick = wv::ballot(com && m_lvl <= lb) != 0;
-            const bool any_over = wv::ballot(over) != 0;
-            if (lane == 0) {
-                L.sh[R5S_NCOMMIT] = nc0 + (u32)wv::popc64(mc);
-                L.sh[R5S_NINF] = ni0 + (u32)wv::popc64(mi);
-                L.sh[R5S_HJ0 + rpar] = j;
-                L.sh[R5S_HV0 + rpar] = 1;
-                if (any_over) L.sh[R5S_REBUILD] = 1;
-                // ring policy: two rounds in a row without a pick at the ring's lowest level → the ring moves up one level
-                if (mc) {
-                    if (!low_pick) {
-                        const u32 qn = L.sh[R5S_QUIET] + 1;
-                        L.sh[R5S_QUIET] = qn;
-                        if (qn >= 2) L.sh[R5S_ADVANCE] = 1;
-                    } else
-                        L.sh[R5S_QUIET] = 0;
-                }
-                L.sh[R5S_ROUNDS] += 1;
-                if (cut == nb) L.sh[R5S_FULL] += 1;
-                else if (L.sh[R5S_WHY0 + rpar] == R5_CUT_GENERIC) L.sh[R5S_CUT_CLASS] += 1;
-                else L.sh[R5S_CUT_EMPTY] += 1;
             }
         } else if (wave == R5_CW) {
             for (u32 i = lane; i < L.rs; i += 64) L.tk[(size_t)tkp * L.rs + i] = 0;   // the previous round's picks are history
