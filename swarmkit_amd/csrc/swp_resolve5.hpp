@@ -492,7 +492,9 @@ WV_DEV void r5_touch_rows(const ResolveArgs& a, u32 j0) {
     const u32 j1 = min(j0 + (u32)R5_B, a.count);
     const char* p0 = reinterpret_cast<const char*>(a.F + (size_t)j0 * a.n_words);
     const size_t bytes = (size_t)(j1 - j0) * a.n_words * 8;
-    for (size_t off = (size_t)wv::lane() * 128; off < bytes; off += 64 * 128) wv::prefetch_l2(p0 + off);
+    u32 acc = 0;
+    for (size_t off = (size_t)wv::lane() * 128; off < bytes; off += 64 * 128) acc += wv::prefetch_l2(p0 + off);
+    wv::keep(acc);
 }
 
 // ---- committer: the memory side effects of one finished round, from its hand-over record ---------------------------

@@ -86,11 +86,12 @@ WV_DEV u64 g_fresh64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXE
 WV_DEV u32 g_fresh32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV i64 g_fresh64s(const i64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void g_store32_fresh(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// pull the cache line at p into this XCD's L2 (the value is dropped; a later vmcnt wait of the wave covers it)
-WV_DEV void prefetch_l2(const void* p) {
-    u32 dummy;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(p) : "memory");
-}
+// pull the cache line at p into this XCD's L2. An ordinary load whose value the caller must consume (sum it up and hand the
+// sum to keep()): the compiler then orders the wait itself. (A bare global_load in inline asm returns into a register the
+// compiler believes free — the late write corrupted whatever lived there next: found by the 12 400-node scan-mode case.)
+WV_DEV u32 prefetch_l2(const void* p) { return *reinterpret_cast<const volatile u32*>(p); }
+// keeps a value alive without doing anything with it
+WV_DEV void keep(u32 v) { asm volatile("" ::"v"(v)); }
 // wave-uniform read-only load: constant address space → s_load through the scalar cache
 template <class T>
 WV_DEV T uload(const T* p) {

@@ -267,7 +267,8 @@ inline u64 g_fresh64(const u64* p) { return *p; }
 inline u32 g_fresh32(const u32* p) { return *p; }
 inline i64 g_fresh64s(const i64* p) { return *p; }
 inline void g_store32_fresh(u32* p, u32 v) { *p = v; }
-inline void prefetch_l2(const void*) {}
+inline u32 prefetch_l2(const void* p) { return *reinterpret_cast<const volatile u32*>(p); }
+inline void keep(u32) {}
 template <class T>
 inline T uload(const T* p) { return *p; }
 

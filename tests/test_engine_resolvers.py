@@ -52,6 +52,18 @@ def test_words_per_lane(N):
     pu.assert_same(op, oe, ep, ee)
 
 
+@pytest.mark.parametrize("N", [4100, 8200, 12400])
+def test_round_resolver_scan_mode_words_per_lane(resolver_env, N):
+    """k_resolve5 over the scan's F rows (the mode batches with more than 64 distinct reservations run in) at K = 2, 3, 4 words per
+    lane: the default run of these sizes takes the exact mode where it fits. (The 12 400-node case once faulted on the GPU only:
+    a prefetch written as a bare inline-asm load returned into a register the compiler had reused.)"""
+    wl = synth.Workload("cfg3", T=1200, N=N)
+    op, oe, _ = pu.oracle_run(wl)
+    pick_variant("5s")
+    ep, ee, *_ = pu.engine_run(wl)
+    pu.assert_same(op, oe, ep, ee)
+
+
 @pytest.mark.parametrize("variant", [2, 3, 5, "5s"])
 @pytest.mark.parametrize("services,order", [(1, "rr"), (2, "rr"), (3, "major"), (40, "major"), (7, "rr")])
 def test_same_service_runs(resolver_env, variant, services, order):
