@@ -220,9 +220,8 @@ WV_DEV u32 r5_level_of(const R5Lds& L, u32 NB, u32 w, u64 bit) {
 
 // one node moves from level rl to rl + 1 in the LDS level structures; true when rl + 1 does not fit the planes
 WV_DEV bool r5_bump_level(const R5Lds& L, u32 NB, u32 lb, u32 w, u64 bit, u32 rl) {
-    const u32 nl = rl + 1, xm = rl ^ nl;
-    for (u32 b = 0; b < NB; ++b)
-        if ((xm >> b) & 1u) wv::lds_xor64(L.planes + (size_t)b * L.rs + w, bit);
+    const u32 nl = rl + 1, xm = rl ^ nl;   // the bits a +1 flips are a run of ones from bit 0: mostly just bit 0
+    for (u32 b = 0; b < NB && ((xm >> b) & 1u); ++b) wv::lds_xor64(L.planes + (size_t)b * L.rs + w, bit);
     if (rl < lb) {
         if (nl >= lb) wv::lds_andn64(L.below + w, bit);
     } else if (rl < lb + R5_J)
@@ -877,10 +876,12 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                     } else
                         L.sh[R5S_QUIET] = 0;
                 }
-                L.sh[R5S_ROUNDS] += 1;
-                if (cut == nb) L.sh[R5S_FULL] += 1;
-                else if (L.sh[R5S_WHY0 + rpar] == R5_CUT_GENERIC) L.sh[R5S_CUT_CLASS] += 1;
-                else L.sh[R5S_CUT_EMPTY] += 1;
+                if (prof) {   // statistics of the SWP_DBG=16 report
+                    L.sh[R5S_ROUNDS] += 1;
+                    if (cut == nb) L.sh[R5S_FULL] += 1;
+                    else if (L.sh[R5S_WHY0 + rpar] == R5_CUT_GENERIC) L.sh[R5S_CUT_CLASS] += 1;
+                    else L.sh[R5S_CUT_EMPTY] += 1;
+                }
             }
         } else if (wave == 1) {
             const u32 cut = L.sh[R5S_CUT0 + rpar];
