@@ -62,7 +62,7 @@ enum {   // u32 scalars in LDS
     R5S_WHY0, R5S_WHY1,           // why it was cut
     R5S_HJ0, R5S_HJ1,             // hand-over: window-local first task of the round, by round parity
     R5S_HV0, R5S_HV1,             // hand-over record is pending
-    R5S_BELANY, R5S_RETRIES, R5S_SLOW, R5S_GENERIC, R5S_REBASES, R5S_ROUNDS, R5S_FULL, R5S_CUT_CLASS, R5S_CUT_EMPTY, R5S_RINGADV, R5S_DEEP,
+    R5S_BELANY, R5S_RETRIES, R5S_SLOW, R5S_GENERIC, R5S_REBASES, R5S_ROUNDS, R5S_FULL, R5S_CUT_CLASS, R5S_CUT_EMPTY, R5S_RINGADV, R5S_DEEP, R5S_NREL, R5S_SHIFTS,
     R5S_COUNT = 32
 };
 #define R5_HDR_U32 8                            // list header: class, entries, level, service, kc, km, list slot, -
@@ -80,9 +80,10 @@ struct R5Lds {
     int32_t* thr;    // [R5_RRMAX]      the thresholds, resource units
     u32* trec;       // [R5_TREC][R5_TREC_U32]  the listers' fields of the upcoming tasks, staged by the committer wave (ring by task index)
     u64* red;        // [64]            block reductions
-    u32* lists;      // [2][R5_B][R5_LIST_U32]
+    u32* lists;      // [3][R5_B][R5_LIST_U32]  current round / next round / spare (target of a carry-over)
     u32* ring;       // [2][R5_B][2]    (service, node) of the last two rounds' commits, by round parity
     u32* hand;       // [2][R5_B][R5_HAND_U32]  hand-over to the committer, by round parity
+    u32* relist;     // [R5_B]          slots of the round whose lists came out empty when a cut round's lists were carried over
     u32* sh;         // [R5S_COUNT]
     int32_t* q;      // [n_nodes][2]    residual cpu / mem in resource units
     u32 rs;          // row stride in words
@@ -92,8 +93,8 @@ struct R5Lds {
 inline __host__ __device__ u32 r5_row_stride(u32 n_words) { return (n_words + 63u) & ~63u; }
 inline __host__ __device__ size_t r5_lds_bytes(u32 n_nodes, u32 n_words, u32 n_rr) {
     const size_t rs = r5_row_stride(n_words);
-    return (size_t)(R5_NBMAX + R5_J + 1 + 2 + n_rr) * rs * 8 + 64 * 8 + (size_t)2 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
-           (size_t)2 * R5_B * R5_HAND_U32 * 4 + R5S_COUNT * 4 + R5_RRMAX * 4 + (size_t)R5_TREC * R5_TREC_U32 * 4 + (size_t)n_nodes * 8;
+    return (size_t)(R5_NBMAX + R5_J + 1 + 2 + n_rr) * rs * 8 + 64 * 8 + (size_t)3 * R5_B * R5_LIST_U32 * 4 + (size_t)2 * R5_B * 2 * 4 +
+           (size_t)2 * R5_B * R5_HAND_U32 * 4 + (size_t)R5_B * 4 + R5S_COUNT * 4 + R5_RRMAX * 4 + (size_t)R5_TREC * R5_TREC_U32 * 4 + (size_t)n_nodes * 8;
 }
 WV_DEV R5Lds r5_layout(u64* lds, u32 n_words, u32 n_rr) {
     R5Lds L;
@@ -105,9 +106,10 @@ WV_DEV R5Lds r5_layout(u64* lds, u32 n_words, u32 n_rr) {
     L.rr = L.tk + 2 * L.rs;
     L.red = L.rr + (size_t)n_rr * L.rs;
     L.lists = reinterpret_cast<u32*>(L.red + 64);
-    L.ring = L.lists + 2 * R5_B * R5_LIST_U32;
+    L.ring = L.lists + 3 * R5_B * R5_LIST_U32;
     L.hand = L.ring + 2 * R5_B * 2;
-    L.sh = L.hand + 2 * R5_B * R5_HAND_U32;
+    L.relist = L.hand + 2 * R5_B * R5_HAND_U32;
+    L.sh = L.relist + R5_B;
     L.thr = reinterpret_cast<int32_t*>(L.sh + R5S_COUNT);
     L.trec = reinterpret_cast<u32*>(L.thr + R5_RRMAX);
     L.q = reinterpret_cast<int32_t*>(L.trec + R5_TREC * R5_TREC_U32);
@@ -279,16 +281,23 @@ WV_DEV void r5_stage_records(const ResolveArgs& a, const R5Lds& L, u32 from, u32
 // committer wave touches the rows of the round after next while it has nothing else to do: r5_touch_rows.)
 // EXACT: the rows are sc[static class] & RC & RM (exact at the list's snapshot) instead of the scan's F row (a stale superset
 // that needs the validation step at the end).
+// slots == nullptr: the wave lists the tasks of slots lw, lw + R5_LW, ... of the round that starts at jbase. Otherwise `slots`
+// (LDS, n_slots entries) names the slots to list — the relist pass after a cut round — and the wave takes entries lw, lw + R5_LW, ...
 template <int K, bool EXACT>
-WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u32 lw, u64* lt) {
+WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u32 lw, u64* lt, const u32* slots = nullptr, u32 n_slots = 0) {
     const u32 lane = wv::lane();
+    u32 sl_[R5_TPW];   // slot of the wave's t-th task, 0xFFFFFFFF = none
+    for (u32 t = 0; t < R5_TPW; ++t) {
+        const u32 idx = lw + R5_LW * t;
+        sl_[t] = slots == nullptr ? idx : (idx < n_slots ? wv::readfirstlane(slots[idx]) : 0xFFFFFFFFu);
+    }
     u64 lmark = lt ? wv::clock64() : 0;
 #define R5_LT(slot) do { if (lt) { const u64 n_ = wv::clock64(); lt[slot] += n_ - lmark; lmark = n_; } } while (0)
     const u32 NB = L.sh[R5S_NB], lb = L.sh[R5S_LB];
     const bool bel_any = L.sh[R5S_BELANY] != 0;
     u32 fl_[R5_TPW], sv_[R5_TPW], sc_[R5_TPW];
     for (u32 t = 0; t < R5_TPW; ++t) {
-        const u32 jj = jbase + lw + R5_LW * t;
+        const u32 jj = sl_[t] == 0xFFFFFFFFu ? 0xFFFFFFFFu : jbase + sl_[t];
         fl_[t] = 0;
         sv_[t] = 0;
         sc_[t] = 0;
@@ -302,9 +311,10 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
     u64 Fn[K], Xn[K];
     for (int k = 0; k < K; ++k) {
         const u32 w = lane + 64 * k;
-        const bool in = jbase + lw < a.count && w < a.n_words;
+        const u32 j0_ = sl_[0] == 0xFFFFFFFFu ? 0xFFFFFFFFu : jbase + sl_[0];
+        const bool in = j0_ < a.count && w < a.n_words;
         if (EXACT) Fn[k] = in ? a.sc[(size_t)sc_[0] * a.n_words + w] : 0ull;
-        else Fn[k] = in ? a.F[(size_t)(jbase + lw) * a.n_words + w] : 0ull;
+        else Fn[k] = in ? a.F[(size_t)j0_ * a.n_words + w] : 0ull;
         Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[0] * a.xs + w) : 0ull;
     }
     // the lowest ring level and BELOW of this wave's words stay in registers for the round
@@ -320,16 +330,17 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
     R5_LT(0);   // prologue: task records, first row requests, ring masks
 
     for (u32 t = 0; t < R5_TPW; ++t) {
-        const u32 s = lw + R5_LW * t;   // task slot of the round == lane of the matcher
-        const u32 jj = jbase + s;
-        u32* out = L.lists + ((size_t)buf * R5_B + s) * R5_LIST_U32;
+        const u32 s = sl_[t];   // task slot of the round == lane of the matcher
+        const bool none = s == 0xFFFFFFFFu;   // (relist pass: fewer slots than waves x tasks)
+        const u32 jj = none ? 0xFFFFFFFFu : jbase + s;
+        u32* out = L.lists + ((size_t)buf * R5_B + (none ? 0u : s)) * R5_LIST_U32;
         u64 F[K], X[K];
         for (int k = 0; k < K; ++k) {
             F[k] = Fn[k];
             X[k] = Xn[k];
         }
         if (t + 1 < R5_TPW) {
-            const u32 jn = jj + R5_LW;
+            const u32 jn = sl_[t + 1] == 0xFFFFFFFFu ? 0xFFFFFFFFu : jbase + sl_[t + 1];
             for (int k = 0; k < K; ++k) {
                 const u32 w = lane + 64 * k;
                 const bool in = jn < a.count && w < a.n_words;
@@ -338,6 +349,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
                 Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[t + 1] * a.xs + w) : 0ull;
             }
         }
+        if (none) continue;   // uniform
         if (jj >= a.count) {   // uniform
             if (lane == 0) { out[0] = R5_NONE; out[1] = 0; }
             continue;
@@ -730,6 +742,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
 
     u32 j = 0;           // next window-local task
     u32 buf = 0;         // list buffer of the current round
+    u32 bnx = 1, bsp = 2;   // ... of the round being prepared; spare (target of a carry-over)
     u32 tkp = 0;         // TK row that holds the previous round's picks
     u32 rpar = 0;        // round parity (cut flag / hand-over / ring slot)
     bool have_lists = false;
@@ -751,7 +764,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         // the lists of [j, j+nb) are built against the state as it is (one call site: the lister is the bulk of the code).
         const bool matching = have_lists;
         if (wave >= 1 && wave <= R5_LW) {
-            r5_list<K, EXACT>(a, L, matching ? j + nb : j, matching ? buf ^ 1 : buf, wave - 1, (prof && wave == 1) ? lcy : nullptr);
+            r5_list<K, EXACT>(a, L, matching ? j + nb : j, matching ? bnx : buf, wave - 1, (prof && wave == 1) ? lcy : nullptr);
         } else if (wave == R5_CW) {
             r5_commit_memory(a, L, rpar ^ 1, pend, false);
             if (!EXACT) r5_touch_rows(a, j + nb + R5_B);   // what the listers will read in the next round
@@ -950,7 +963,11 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 }
             }
         } else if (wave == R5_CW) {
-            for (u32 i = lane; i < L.rs; i += 64) L.tk[(size_t)tkp * L.rs + i] = 0;   // the previous round's picks are history
+            // the previous round's picks are history — unless this round was cut by an exhausted list: the carry-over below
+            // strikes them from the lists it keeps
+            const bool relist_cut = L.sh[R5S_CUT0 + rpar] < nb && L.sh[R5S_WHY0 + rpar] == R5_CUT_RELIST;
+            if (!relist_cut)
+                for (u32 i = lane; i < L.rs; i += 64) L.tk[(size_t)tkp * L.rs + i] = 0;
         }
         R5_TICK(2);
         wv::barrier();
@@ -959,7 +976,9 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         const bool rebuild = L.sh[R5S_REBUILD] != 0, advance = L.sh[R5S_ADVANCE] != 0;
         j += cut;
         bool flush = false;
-        if (cut < nb || rebuild) {
+        // A round cut by an exhausted list keeps its pipeline: see the carry-over below
+        const bool shift = cut < nb && why == R5_CUT_RELIST && !rebuild;
+        if ((cut < nb && !shift) || rebuild) {
             // off the pipeline: the memory side of both outstanding rounds lands now (the generic path, the plane rebuild and
             // the fresh lists read it back)
             if (wave == R5_CW) {
@@ -975,6 +994,61 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         } else if (advance) {
             if (tid == 0) L.sh[R5S_RINGADV] += 1;
             r5_ring_build(L, L.sh[R5S_LB] + 1);   // lists carry absolute levels: the pipeline goes on
+        }
+        if (shift) {
+            // ---- carry-over. The round was cut at a task whose list ran out. Nothing is flushed and nothing is listed twice: the
+            // next round [j, j+nb2) takes the lists of the cut round's unprocessed tasks (this buffer, slots cut..nb-1: built
+            // before round r-1, so the picks of r-1 and r are struck from them now) and, behind them, the first lists of the
+            // round that was being prepared (the other buffer: built before r, struck by r's picks). A list struck of the picks
+            // made since its snapshot IS a list built after them (the list rule), so the TK rows start empty again. Lists that
+            // came out empty — the task that cut the round is one — are built afresh by the lister waves, one task each.
+            const u32 keep = nb - cut, nb2 = min((u32)R5_B, a.count - j);
+            const u32* tkprev = reinterpret_cast<const u32*>(L.tk + (size_t)tkp * L.rs);
+            const u32* tkcur = reinterpret_cast<const u32*>(L.tk + (size_t)(tkp ^ 1) * L.rs);
+            // one list word per thread, into the spare buffer (no list is read and written in the same pass)
+            for (u32 e = tid; e < nb2 * R5_LIST_U32; e += R5_THREADS) {
+                const u32 sl = e / R5_LIST_U32, q = e % R5_LIST_U32;
+                const bool old = sl < keep;
+                const u32* src = L.lists + ((size_t)(old ? buf : bnx) * R5_B + (old ? cut + sl : sl - keep)) * R5_LIST_U32;
+                u32 v = src[q];
+                if (q >= R5_HDR_U32 && ((q - R5_HDR_U32) & 3u) >= 2u && src[0] == R5_FAST) {   // a half of an entry's candidate word
+                    const u32 r = (q - R5_HDR_U32) >> 2, hw = 2 * src[R5_HDR_U32 + 4 * r] + ((q - R5_HDR_U32) & 1u);
+                    if (2 * r < src[1]) {
+                        v &= ~tkcur[hw];
+                        if (old) v &= ~tkprev[hw];
+                    } else
+                        v = 0;
+                }
+                L.lists[((size_t)bsp * R5_B + sl) * R5_LIST_U32 + q] = v;
+            }
+            wv::barrier();
+            for (u32 i = tid; i < 2 * L.rs; i += R5_THREADS) L.tk[i] = 0;
+            if (wave == 0) {
+                bool empty = false;
+                if (lane < nb2) {
+                    const u32* li = L.lists + ((size_t)bsp * R5_B + lane) * R5_LIST_U32;
+                    if (li[0] == R5_FAST) {
+                        u32 any = 0;
+                        for (u32 r = 0; r < R5_Q; ++r) any |= li[R5_HDR_U32 + 4 * r + 2] | li[R5_HDR_U32 + 4 * r + 3];
+                        empty = any == 0;
+                    }
+                }
+                const u64 em = wv::ballot(empty);
+                if (empty) L.relist[wv::mbcnt(em)] = lane;
+                if (lane == 0) {
+                    L.sh[R5S_NREL] = (u32)wv::popc64(em);
+                    L.sh[R5S_SHIFTS] += 1;
+
+                }
+            }
+            wv::barrier();
+            {   // the spare buffer is the current one now
+                const u32 t_ = buf;
+                buf = bsp;
+                bsp = t_;
+            }
+            if (wave >= 1 && wave <= R5_LW) r5_list<K, EXACT>(a, L, j, buf, wave - 1, nullptr, L.relist, L.sh[R5S_NREL]);
+            wv::barrier();
         }
         if (cut < nb && why == R5_CUT_GENERIC) {
             r5_generic<EXACT>(a, L, j, par);   // ends with a barrier
@@ -993,8 +1067,12 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 L.ring[2 * (R5_B + lane)] = 0xFFFFFFFFu;
             }
             tkp = 0;
+        } else if (shift) {
+            tkp = 0;   // the carried lists are in `buf` already; both TK rows are empty
         } else {
-            buf ^= 1;
+            const u32 t_ = buf;   // the next round's lists become the current ones; the old current buffer is listed into next
+            buf = bnx;
+            bnx = t_;
             tkp ^= 1;
         }
         R5_TICK(4);
