@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--tasks", type=int, default=None)
     ap.add_argument("--nodes", type=int, default=None)
+    ap.add_argument("--services", type=int, default=None, help="number of services of the synthetic workload (default T/100); 1 = the reference's benchScheduler shape: every task of ONE service")
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--order", default="rr", choices=["rr", "major"], help="task order: round-robin over services (SURVEY 8d) or service-major")
     ap.add_argument("--rounds", type=int, default=20, help="churn rounds (--mode churn; BASELINE configs[4] uses 100)")
@@ -219,6 +220,39 @@ def main():
 
     from swarmkit_amd import abi, host, synth
 
+    if args.workload == "refbench":
+        # The reference's own benchmark, benchScheduler (manager/scheduler/scheduler_test.go:3375-3465, sizes :3335-3373): tasks
+        # WITHOUT ServiceID / SpecVersion — one service "" for every task — on nodes with an empty Engine description, every third
+        # one advertising the Network plugin; timed around Scheduler.tick() of the C++ host layer (JSON decisions included), a
+        # fresh scheduler per step as the Go benchmark builds a fresh store per iteration.
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bigcases
+        n_nodes, n_tasks = args.nodes or 1000, args.tasks or 100000
+        ticks, placed = [], 0
+        for it in range(args.warmup + args.steps):
+            s = host.HostScheduler(engine=abi.Engine(device=local_rank, profile=True))
+            for i in range(n_nodes):
+                s.create_node(bigcases.ref_node(i))
+            s.set_service("")
+            for i in range(n_tasks):
+                s.create_task(bigcases.ref_task(i, False))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec = s.tick()
+            dt = time.perf_counter() - t0
+            if it >= args.warmup:
+                ticks.append(dt)
+                placed = sum(1 for d in dec if d["NodeID"])
+            st = s.e.stats()
+        t_step = sum(ticks) / max(len(ticks), 1)
+        print(json.dumps({"metric": f"task placements/sec, the reference's benchScheduler shape ({n_tasks // 1000}k tasks of one service x {n_nodes} nodes), end to end through Scheduler.tick()",
+                          "value": n_tasks / t_step, "unit": "placements/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                          "config": {"workload": "refbench", "tasks": n_tasks, "nodes": n_nodes, "services": 1, "path": "k_waterfill" if st["waterfill_tasks"] else "resolver"},
+                          "placed": placed, "device_ms": st["ms_total"], "waterfill_tasks_total": st["waterfill_tasks"],
+                          "note": "tick() = grouping + descriptors + one swp_schedule_batch + 100k decision documents as JSON; device_ms is the engine's share"}))
+        ranks.close()
+        return
     par = args.parallelism
     if par == "auto":
         par = "node-shard" if (world > 1 or args.shards > 1) else "single"
@@ -226,7 +260,7 @@ def main():
     if shard_mode:
         # every rank sees the SAME cluster and task list and owns one contiguous range of the canonical node order
         from swarmkit_amd import shard as swshard
-        wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, order=args.order)
+        wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, order=args.order, services=args.services)
         n_shards = world if world > 1 else max(args.shards, 1)
         shard_ranges_ = swshard.shard_ranges(wl.N, n_shards)
         my = rank if world > 1 else 0
@@ -238,7 +272,7 @@ def main():
     else:
         # replicas: every rank schedules its own cluster of the same shape (seed offset by rank); no data-path collective
         shard_ranges_ = None
-        wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=ranks.replica_seed(0x5EED0000), order=args.order)
+        wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=ranks.replica_seed(0x5EED0000), order=args.order, services=args.services)
         eng = abi.Engine(device=local_rank, window=args.window, profile=True)
         sched = host.HostScheduler(engine=eng)
         t0 = time.perf_counter()

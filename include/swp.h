@@ -365,6 +365,8 @@ typedef struct {
     /* node-range shard protocol, last batch (since swp_shard_begin); the times need SWP_CFG_PROFILE */
     float    ms_propose, ms_apply;          /* Σ k_propose / k_shard_apply launch durations */
     uint32_t propose_launches, propose_tasks;   /* launches and Σ tasks proposed (a task cut off a block is proposed again) */
+    uint32_t waterfill_tasks;   /* tasks placed as runs of identical tasks (k_waterfill), since swp_create */
+    uint32_t reserved2;
 } swp_stats_t;
 
 int swp_create(const swp_config*, swp_engine** out);

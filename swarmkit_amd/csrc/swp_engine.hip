@@ -24,6 +24,7 @@
 #include "swp_device.hpp"
 #include "swp_launch.hpp"
 #include "swp_shard.hpp"
+#include "swp_waterfill.hpp"
 
 using namespace swpdev;
 
@@ -160,6 +161,10 @@ struct swp_batch {
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
     DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
     DevBuf d_thr;                          // k_resolve5 exact mode: thresholds of the demand-class rows
+    // segments of the batch: runs of identical tasks (k_waterfill) and the stretches between them (the resolvers)
+    struct Seg { uint32_t j0, n; bool run; };
+    std::vector<Seg> segs;
+    DevBuf d_wf;                           // k_waterfill scratch: [3][n_nodes] u32
     // node-range shard protocol (swp_shard_*): commits / unplaceable tasks of ALL shards so far, this shard's results
     bool shard_open = false, shard_apply_timed = false;
     uint32_t shard_ncommit = 0, shard_ninf = 0;
@@ -468,6 +473,39 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
                 b->exact_ok = true;
             }
         }
+    }
+    // runs of identical one-off tasks (same service, filters, reservations; only their list slot differs) are placed by
+    // water-filling instead of task by task (csrc/swp_waterfill.hpp). A run must be long enough to pay for its launch, and
+    // splitting the batch must not shred the round resolver's work into many launches: runs are used when they make up most
+    // of the batch or one of them is long. SWP_WATERFILL=0 switches them off, =1 forces every run of 2 or more (tests).
+    b->segs.clear();
+    {
+        const char* env_wf = getenv("SWP_WATERFILL");
+        const int mode = env_wf ? atoi(env_wf) : -1;
+        const uint32_t run_min = mode == 1 ? 2u : 64u;
+        auto same = [&](uint32_t i, uint32_t k) {
+            RTask x = b->rt[i], y = b->rt[k];
+            x.slot = y.slot = 0;
+            return std::memcmp(&x, &y, sizeof x) == 0;
+        };
+        std::vector<swp_batch::Seg> segs;
+        uint64_t in_runs = 0;
+        uint32_t longest = 0, i = 0;
+        while (i < T) {
+            uint32_t k = i + 1;
+            const bool can = !(b->rt[i].flags & (RT_PORTS | RT_UNCOUNTED));
+            while (can && k < T && same(i, k)) ++k;
+            const bool run = k - i >= run_min;
+            if (run) {
+                in_runs += k - i;
+                longest = std::max(longest, k - i);
+            }
+            if (!segs.empty() && !run && !segs.back().run) segs.back().n += k - i;
+            else segs.push_back({i, k - i, run});
+            i = k;
+        }
+        const bool use = mode != 0 && (mode == 1 || in_runs * 2 >= T || longest >= 4096);
+        if (use && in_runs) b->segs = std::move(segs);
     }
     b->n_svc = (uint32_t)b->svc_global.size();
     b->n_sc = (uint32_t)b->triples.size();
@@ -882,12 +920,18 @@ int batch_run(swp_engine* e, swp_batch* b) {
         }
     }
     uint32_t wi = 0;   // windows launched so far (profiling slots)
-    auto run_windows = [&](uint32_t start, int variant) -> int {
+    auto run_windows = [&](uint32_t start, uint32_t end, int variant) -> int {
     const bool exact = r5_exact && variant == 5;
     const uint32_t win = exact ? T : b->window;
     if (!exact) HIPCHECK(e, b->d_F.reserve((size_t)b->window * Wn * 8));
-    for (uint32_t j0 = start; j0 < T; j0 += win, ++wi) {
-        const uint32_t cnt = std::min(win, T - j0);
+    if (prof)
+        while (e->ev_pool.size() < (size_t)4 * (wi + (end - start + win - 1) / win + 1)) {
+            hipEvent_t x;
+            HIPCHECK(e, hipEventCreate(&x));
+            e->ev_pool.push_back(x);
+        }
+    for (uint32_t j0 = start; j0 < end; j0 += win, ++wi) {
+        const uint32_t cnt = std::min(win, end - j0);
         ScanArgs sa{};
         sa.n_nodes = N;
         sa.n_words = Wn;
@@ -990,7 +1034,47 @@ int batch_run(swp_engine* e, swp_batch* b) {
     }
     return SWP_OK;
     };
-    rc = run_windows(0, variant);
+    if (b->segs.empty()) rc = run_windows(0, T, variant);
+    else {
+        HIPCHECK(e, b->d_wf.reserve((size_t)3 * N * 4));
+        for (const swp_batch::Seg& sg : b->segs) {
+            if (!sg.run) {
+                if ((rc = run_windows(sg.j0, sg.j0 + sg.n, variant))) break;
+                continue;
+            }
+            WaterArgs wa{};
+            wa.n_nodes = N;
+            wa.n_words = Wn;
+            wa.xs = Wn;
+            wa.j0 = sg.j0;
+            wa.count = sg.n;
+            wa.rt = b->d_rt.as<RTask>();
+            wa.sc = b->d_sc.as<u64>();
+            wa.cpu = e->d_cpu.as<long long>();
+            wa.mem = e->d_mem.as<long long>();
+            wa.total = e->d_total.as<uint32_t>();
+            wa.X = b->d_X.as<u64>();
+            wa.list_node = b->d_list_node.as<uint32_t>();
+            wa.list_svc = b->d_list_svc.as<uint32_t>();
+            wa.list_fail = b->d_list_fail.as<uint32_t>();
+            wa.list_off = b->d_list_off.as<uint32_t>();
+            wa.out_node = b->d_out.as<int32_t>();
+            wa.log_node = b->d_log_node.as<uint32_t>();
+            wa.log_task = b->d_log_task.as<uint32_t>();
+            wa.log_prev = b->d_log_prev.as<int32_t>();
+            wa.last = b->d_last.as<int32_t>();
+            wa.inf_task = b->d_inf_task.as<uint32_t>();
+            wa.inf_pos = b->d_inf_pos.as<uint32_t>();
+            wa.ctl = b->d_ctl.as<Ctl>();
+            wa.qres = variant == 5 ? b->d_qres.as<int32_t>() : nullptr;
+            wa.ps = b->d_wf.as<uint32_t>();
+            wa.cap = wa.ps + N;
+            wa.ent = wa.cap + N;
+            hipError_t r = launch_waterfill(wa, st);
+            if (r != hipSuccess) return e->fail(SWP_EHIP, "k_waterfill launch: %s", hipGetErrorString(r));
+            e->stats.waterfill_tasks += sg.n;
+        }
+    }
     if (rc) return rc;
 
     // explain pass: needs the number of unplaceable tasks (one small D2H, once per batch)
@@ -1004,7 +1088,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         const uint32_t zero = 0;
         HIPCHECK(e, hipMemcpyAsync((char*)b->d_ctl.p + offsetof(Ctl, error), &zero, 4, hipMemcpyHostToDevice, st));
         variant = 0;
-        rc = run_windows(ctl.resume, 0);
+        rc = run_windows(ctl.resume, T, 0);   // (runs included: task by task from here on)
         if (rc) return rc;
         HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
         HIPCHECK(e, hipStreamSynchronize(st));

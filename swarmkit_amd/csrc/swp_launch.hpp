@@ -24,4 +24,8 @@ struct ShardApplyArgs;
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t s);
 hipError_t launch_shard_apply(const ShardApplyArgs& a, hipStream_t s);
 
+// runs of identical tasks (swp_waterfill.hip)
+struct WaterArgs;
+hipError_t launch_waterfill(const WaterArgs& a, hipStream_t s);
+
 }  // namespace swpdev
