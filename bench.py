@@ -27,7 +27,7 @@ ROW_B = {"cfg2": 32, "cfg3": 48, "cfg4": 64}   # algorithmic node-row bytes per 
 TASK_B = 64 + 8                # descriptor + result per task, SURVEY.md §8d
 
 
-RESOLVER_NAMES = {105: "k_resolve5<exact>", 5: "k_resolve5<scan>", 3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}
+RESOLVER_NAMES = {105: "k_resolve5<exact>", 5: "k_resolve5<scan>", 6: "k_resolve6 (rounds of k_r6_propose + k_r6_commit; one 'launch' = the whole batch)", 3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}
 FILTERS = {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filters",
            "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}
 

@@ -276,7 +276,8 @@ typedef struct {
     uint64_t exc_hi;         /* best exception-list candidate: (failure class << 32 | svcCount); ~0 = none */
     uint64_t exc_lo;         /*                                (ActiveTasksCount << 32 | shard-local node) */
     uint32_t exc_entry;      /* its entry in the shard's exception list */
-    uint32_t reserved;
+    uint32_t flags;          /* bit 0: the task does not count on its node (DesiredState > COMPLETED, nodeinfo.go:131-134): its node stays
+                              * on its level, so the merge ends the block behind its pick */
 } swp_proposal;              /* 80 bytes */
 typedef struct {
     int32_t  shard;          /* owner of the picked node; -1 = no suitable node on any shard */

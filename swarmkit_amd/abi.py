@@ -91,7 +91,7 @@ assert NODE_DYNAMIC_DTYPE.itemsize == 32 and NODE_ROW_DTYPE.itemsize == C.sizeof
 # node-range shards (include/swp.h): swp_proposal / swp_shard_pick
 SHARD_CAND = 4
 PROPOSAL_DTYPE = np.dtype([("level", "<u4"), ("n_cand", "<u4"), ("word", "<u4", (SHARD_CAND,)), ("bits", "<u8", (SHARD_CAND,)), ("exc_hi", "<u8"),
-                           ("exc_lo", "<u8"), ("exc_entry", "<u4"), ("reserved", "<u4")])
+                           ("exc_lo", "<u8"), ("exc_entry", "<u4"), ("flags", "<u4")])
 PICK_DTYPE = np.dtype([("shard", "<i4"), ("node", "<u4"), ("entry", "<u4"), ("reserved", "<u4")])
 assert PROPOSAL_DTYPE.itemsize == 80 and PICK_DTYPE.itemsize == 16
 assert ENF_NODE_DTYPE.itemsize == 32 and ENF_TASK_DTYPE.itemsize == 32

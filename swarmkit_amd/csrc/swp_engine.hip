@@ -23,6 +23,7 @@
 #include "../../include/swp.h"
 #include "swp_device.hpp"
 #include "swp_launch.hpp"
+#include "swp_resolve6.hpp"
 #include "swp_shard.hpp"
 #include "swp_waterfill.hpp"
 
@@ -153,6 +154,10 @@ struct swp_batch {
     std::vector<int32_t> thr;
     uint32_t n_dc = 0, n_dm = 0;
     bool exact_ok = false;
+    // k_resolve6 (block resolver): the same classes with the thresholds in raw units (NanoCPUs / bytes); usable whenever the
+    // class indices fit the 8 bits RTask.flags has for each
+    std::vector<int64_t> thr64;
+    bool classes_ok = false;
 
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
@@ -161,6 +166,7 @@ struct swp_batch {
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
     DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
     DevBuf d_thr;                          // k_resolve5 exact mode: thresholds of the demand-class rows
+    DevBuf d_thr64, d_planes6, d_rr6, d_blk6;   // k_resolve6: raw thresholds, level planes, demand-class rows, control block
     // segments of the batch: runs of identical tasks (k_waterfill) and the stretches between them (the resolvers)
     struct Seg { uint32_t j0, n; bool run; };
     std::vector<Seg> segs;
@@ -451,26 +457,34 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             b->rt[i].kc = (uint32_t)kc;
             b->rt[i].km = (uint32_t)km;
         }
-        // demand classes of the exact mode: ResourceFilter (filter.go:77-84) becomes membership in two LDS rows per task
-        b->exact_ok = false;
+        // demand classes: ResourceFilter (filter.go:77-84) becomes membership in two bitmap rows per task — the distinct cpu /
+        // memory reservations of the batch, ascending; RTask.flags carries the task's two row indices. k_resolve5's exact mode
+        // keeps the rows in LDS (thresholds in resource units, at most r5_max_rows() of them), k_resolve6 in global memory.
+        b->exact_ok = b->classes_ok = false;
         b->thr.clear();
+        b->thr64.clear();
         b->n_dc = b->n_dm = 0;
-        if (b->units_ok) {
-            std::set<uint32_t> sc_, sm_;
+        {
+            std::set<int64_t> sc_, sm_;
             for (uint32_t i = 0; i < T; ++i)
                 if (b->rt[i].flags & RT_RES) {
-                    sc_.insert(b->rt[i].kc);
-                    sm_.insert(b->rt[i].km);
+                    sc_.insert(b->rt[i].cpu);
+                    sm_.insert(b->rt[i].mem);
                 }
-            if (sc_.size() + sm_.size() <= r5_max_rows() && sc_.size() <= RT_DCLS_MASK && sm_.size() <= RT_DCLS_MASK) {
-                std::unordered_map<uint32_t, uint32_t> ic, im;
-                for (uint32_t v : sc_) { ic[v] = (uint32_t)b->thr.size(); b->thr.push_back((int32_t)v); }
+            if (sc_.size() <= RT_DCLS_MASK && sm_.size() <= RT_DCLS_MASK) {
+                std::unordered_map<int64_t, uint32_t> ic, im;
+                for (int64_t v : sc_) { ic[v] = (uint32_t)b->thr64.size(); b->thr64.push_back(v); }
                 b->n_dc = (uint32_t)sc_.size();
-                for (uint32_t v : sm_) { im[v] = (uint32_t)b->thr.size() - b->n_dc; b->thr.push_back((int32_t)v); }
+                for (int64_t v : sm_) { im[v] = (uint32_t)b->thr64.size() - b->n_dc; b->thr64.push_back(v); }
                 b->n_dm = (uint32_t)sm_.size();
                 for (uint32_t i = 0; i < T; ++i)
-                    if (b->rt[i].flags & RT_RES) b->rt[i].flags |= (ic[b->rt[i].kc] << RT_DC_SHIFT) | (im[b->rt[i].km] << RT_DM_SHIFT);
-                b->exact_ok = true;
+                    if (b->rt[i].flags & RT_RES) b->rt[i].flags |= (ic[b->rt[i].cpu] << RT_DC_SHIFT) | (im[b->rt[i].mem] << RT_DM_SHIFT);
+                b->classes_ok = true;
+                if (b->units_ok && b->n_dc + b->n_dm <= r5_max_rows()) {   // the same order in resource units (division by the gcd is monotone)
+                    for (uint32_t c = 0; c < b->n_dc; ++c) b->thr.push_back((int32_t)(b->thr64[c] / b->unit_cpu));
+                    for (uint32_t c = 0; c < b->n_dm; ++c) b->thr.push_back((int32_t)(b->thr64[b->n_dc + c] / b->unit_mem));
+                    b->exact_ok = true;
+                }
             }
         }
     }
@@ -620,6 +634,7 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     int rc;
     if ((rc = upload(e, b->d_rt, b->rt))) return rc;
     if ((rc = upload(e, b->d_thr, b->thr))) return rc;
+    if ((rc = upload(e, b->d_thr64, b->thr64))) return rc;
     if ((rc = upload(e, b->d_list_node0, b->list_node0))) return rc;
     if ((rc = upload(e, b->d_list_svc0, b->list_svc0))) return rc;
     if ((rc = upload(e, b->d_list_fail0, b->list_fail0))) return rc;
@@ -883,6 +898,14 @@ int batch_run(swp_engine* e, swp_batch* b) {
         }
         if (!ok) variant = 3;
     }
+    // k_resolve6 (block resolver): lists built by the whole chip from bitmap rows in global memory, matched by one wave. For node
+    // sets beyond k_resolve5's LDS; needs the demand classes and two candidate buffers of the propose kernel in LDS (≈ 650k nodes).
+    // SWP_RESOLVER=6 forces it at any size; SWP_R6_BLOCK sets the tasks per round.
+    const char* env_blk = getenv("SWP_R6_BLOCK");
+    const uint32_t r6_block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    const bool r6_ok = b->classes_ok && r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, b->n_dc + b->n_dm) <= lds_budget;
+    if (variant == 6 && !r6_ok) variant = 3;
+    if (variant == 3 && !env_res && r6_ok) variant = 6;   // default beyond k_resolve5's reach
     if (variant != 5) r5_exact = false;
     if (variant == 5) {
         HIPCHECK(e, b->d_qres.reserve((size_t)N * 8));
@@ -920,7 +943,94 @@ int batch_run(swp_engine* e, swp_batch* b) {
         }
     }
     uint32_t wi = 0;   // windows launched so far (profiling slots)
+    uint64_t r6_rounds = 0;
+    // k_resolve6 over the stretch [start, end): build the bitmaps from the node rows as they are, then rounds of propose + commit.
+    // The device advances on its own (the position lives in the control block); the host only learns every so many rounds how far it is.
+    auto run_blocks = [&](uint32_t start, uint32_t end) -> int {
+        HIPCHECK(e, b->d_planes6.reserve((size_t)R6_NP * Wn * 8));
+        HIPCHECK(e, b->d_rr6.reserve((size_t)std::max<uint32_t>(b->n_dc + b->n_dm, 1) * Wn * 8));
+        HIPCHECK(e, b->d_blk6.reserve(sizeof(Blk6)));
+        HIPCHECK(e, b->d_prop.reserve((size_t)r6_block * sizeof(R6Prop)));
+        if (prof)
+            while (e->ev_pool.size() < (size_t)4 * (wi + 1)) {
+                hipEvent_t x;
+                HIPCHECK(e, hipEventCreate(&x));
+                e->ev_pool.push_back(x);
+            }
+        R6Args ra{};
+        ra.n_nodes = N;
+        ra.n_words = Wn;
+        ra.xs = Wn;
+        ra.block = r6_block;
+        ra.n_dc = b->n_dc;
+        ra.n_dm = b->n_dm;
+        ra.dbg = dbg_bits;
+        ra.valid = e->d_valid.as<u64>();
+        ra.sc = b->d_sc.as<u64>();
+        ra.X = b->d_X.as<u64>();
+        ra.rt = b->d_rt.as<RTask>();
+        ra.cpu = e->d_cpu.as<long long>();
+        ra.mem = e->d_mem.as<long long>();
+        ra.total = e->d_total.as<uint32_t>();
+        ra.list_node = b->d_list_node.as<uint32_t>();
+        ra.list_svc = b->d_list_svc.as<uint32_t>();
+        ra.list_fail = b->d_list_fail.as<uint32_t>();
+        ra.list_off = b->d_list_off.as<uint32_t>();
+        ra.portmap = b->d_portmap.as<u64>();
+        ra.pset_off = b->d_pset_off.as<uint32_t>();
+        ra.pset_ids = b->d_pset_ids.as<uint32_t>();
+        ra.out_node = b->d_out.as<int32_t>();
+        ra.log_node = b->d_log_node.as<uint32_t>();
+        ra.log_task = b->d_log_task.as<uint32_t>();
+        ra.log_prev = b->d_log_prev.as<int32_t>();
+        ra.last = b->d_last.as<int32_t>();
+        ra.inf_task = b->d_inf_task.as<uint32_t>();
+        ra.inf_pos = b->d_inf_pos.as<uint32_t>();
+        ra.ctl = b->d_ctl.as<Ctl>();
+        ra.planes = b->d_planes6.as<u64>();
+        ra.rr = b->d_rr6.as<u64>();
+        ra.thr = b->d_thr64.as<long long>();
+        ra.blk = b->d_blk6.as<Blk6>();
+        ra.prop = b->d_prop.as<R6Prop>();
+        if (prof) {
+            HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 0], st));
+            HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 1], st));
+            HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
+        }
+        Blk6 hb{};
+        hb.pos = start;
+        hb.end = end;
+        HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, st));
+        hipError_t r = launch_r6_build(ra, st);
+        if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(r));
+        uint32_t pos = start, chunk = 16;
+        while (pos < end) {
+            r = launch_r6_rounds(ra, chunk, st, e->device);
+            if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
+            HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
+            HIPCHECK(e, hipStreamSynchronize(st));
+            if (hb.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP);
+            if (hb.pos <= pos) return e->fail(SWP_EHIP, "block resolver made no progress at task %u", pos);   // a round decides its first task at least
+            // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
+            const double pace = std::max(1.0, (double)(hb.pos - start) / (double)std::max<uint32_t>(hb.rounds, 1));
+            pos = hb.pos;
+            chunk = (uint32_t)std::min<double>(4096.0, (double)(end - pos) / pace * 1.05 + 4.0);
+        }
+        r6_rounds += hb.rounds;
+        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
+        ++wi;
+        if (dbg_bits & 16)
+            fprintf(stderr, "[swp] k_resolve6 tasks [%u, %u): %u rounds of %u (%.1f decided each) | cut by an exhausted list %u, an exception-list task %u, an uncounted task %u\n", start, end,
+                    hb.rounds, r6_block, (double)(end - start) / std::max<uint32_t>(hb.rounds, 1), hb.cut_exhausted, hb.cut_exception, hb.cut_uncounted);
+        if (dbg_bits & 16) {
+            const double rr_ = std::max<uint32_t>(hb.rounds, 1);
+            fprintf(stderr, "[swp] k_r6_commit shader cycles per round: prologue %.0f, matching (wave 0) %.0f, the others' wait for it %.0f, apply %.0f | %.1f matcher stops at an emptied half-word per round\n",
+                    hb.cyc[0] * 64.0 / rr_, hb.cyc[1] * 64.0 / rr_, hb.cyc[2] * 64.0 / rr_, hb.cyc[3] * 64.0 / rr_, hb.reseats / rr_);
+        }
+        return SWP_OK;
+    };
     auto run_windows = [&](uint32_t start, uint32_t end, int variant) -> int {
+    if (variant == 6) return run_blocks(start, end);
     const bool exact = r5_exact && variant == 5;
     const uint32_t win = exact ? T : b->window;
     if (!exact) HIPCHECK(e, b->d_F.reserve((size_t)b->window * Wn * 8));
@@ -1149,8 +1259,8 @@ fprintf(stderr, "[swp] k_resolve5 lister wave 1 per round (cycles): prologue %.0
         fprintf(stderr, "[swp] shader clock: %llu cycles / %llu x10ns => %.0f MHz\n", ctl.cyc[6], ctl.cyc[7], (double)ctl.cyc[6] / ((double)ctl.cyc[7] * 0.01));
     e->stats.last_windows = wi;   // resolver launches of this batch (1 in k_resolve5's exact mode: no scan windows)
     e->stats.last_static_classes = b->n_sc;
-    e->stats.scan_launches += r5_exact ? 0u : wi;
-    e->stats.resolve_launches += wi;
+    e->stats.scan_launches += (r5_exact || variant == 6) ? 0u : wi;
+    e->stats.resolve_launches += variant == 6 ? (uint32_t)(2 * r6_rounds) : wi;   // k_resolve6: a propose and a commit launch per round
     e->stats.last_resolver = (uint32_t)variant + (r5_exact ? 100u : 0u);   // 105 = k_resolve5, exact mode
     b->ran = true;
     return SWP_OK;
@@ -1895,6 +2005,7 @@ int swp_shard_merge(const swp_proposal* const* proposals, const uint32_t* shard_
         taken[((uint64_t)(uint32_t)pk.shard << 32) | (pk.node >> 6)] |= 1ull << (pk.node & 63);
         picks[i] = pk;
         *accepted = i + 1;
+        if (proposals[0][i].flags & 1u) break;   // an uncounted task: its node did not move up a level, the later lists are stale about it
     }
     return SWP_OK;
 }

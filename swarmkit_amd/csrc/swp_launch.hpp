@@ -18,6 +18,14 @@ uint32_t r5_max_rows();
 bool r5_supports(uint32_t n_words);
 hipError_t launch_resolve5(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev);
 
+// k_resolve6, the block resolver (swp_resolve6.hip)
+struct R6Args;
+size_t r6_propose_lds_size(uint32_t n_words);
+size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr);
+uint32_t r6_block_max();
+hipError_t launch_r6_build(const R6Args& a, hipStream_t s);
+hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int dev);
+
 // sharded scan (swp_shard.hip)
 struct ProposeArgs;
 struct ShardApplyArgs;

@@ -1,0 +1,35 @@
+// swp_resolve6.hip — translation unit of the block resolver (k_r6_*, swp_resolve6.hpp) and its launchers.
+#include <hip/hip_runtime.h>
+
+#include "swp_launch.hpp"
+#include "swp_wave.hpp"
+#define SWP_R6_KERNELS
+#include "swp_resolve6.hpp"
+
+namespace swpdev {
+
+size_t r6_propose_lds_size(uint32_t n_words) { return r6_propose_lds(n_words); }
+size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr) { return r6_commit_lds(n_words, block, n_rr); }
+uint32_t r6_block_max() { return R6_BMAX; }
+
+// base / highest level, then level planes + demand-class rows from the node rows as they are
+hipError_t launch_r6_build(const R6Args& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_r6_minmax, dim3(1), dim3(1024), 256, s, a);
+    hipLaunchKernelGGL(k_r6_rows, dim3((a.n_words + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// `rounds` rounds of propose + commit; a round past the end of the stretch is a no-op
+hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int dev) {
+    const size_t lp = r6_propose_lds(a.n_words), lc = r6_commit_lds(a.n_words, a.block, a.n_dc + a.n_dm);
+    hipError_t r;
+    if (lp > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r6_propose), dev)) != hipSuccess) return r;
+    if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r6_commit), dev)) != hipSuccess) return r;
+    for (uint32_t i = 0; i < rounds; ++i) {
+        hipLaunchKernelGGL(k_r6_propose, dim3(a.block), dim3(64), lp, s, a);
+        hipLaunchKernelGGL(k_r6_commit, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace swpdev

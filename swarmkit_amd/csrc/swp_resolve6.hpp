@@ -1,0 +1,479 @@
+// swp_resolve6.hpp — the BLOCK resolver: the sequential argmin + commit pass of the tick (nodeSet.tree with a heap of one,
+// nodeset.go:50-124; nodeLess, scheduler.go:708-735; NodeInfo.addTask, nodeinfo.go:108-154) for node sets that do not fit
+// one workgroup's LDS (k_resolve5: ≈ 12 000 nodes). The whole chip builds the candidate lists, one wave matches them.
+//
+// State in global memory (L2-resident), all of it bitmaps over the node words, kept exact by every commit:
+//   planes[b]   bit b of (ActiveTasksCount − base) per node, base = the lowest count among the valid nodes at build time
+//   rr[c]       ResourceFilter (filter.go:77-84) as set membership, as in k_resolve5's exact mode: nodes whose residual
+//               cpu (rows 0..n_dc−1) / memory (rows n_dc..) is >= the row's threshold; thresholds = the batch's distinct reservations
+//   sc, X, portmap   static class rows, per-service exception bitmaps, host ports: the rows every resolver uses
+//
+// One ROUND decides a block of up to `block` tasks, two launches:
+//   k_r6_propose   one wavefront per task, lanes over the node WORDS: m = sc & ~X & RC & RM & ~ports (the task's plain
+//                  candidates, 64 nodes per operation), then a descent over the level planes from the top
+//                  (m & ~plane ≠ ∅ ? keep that : the bit is set in the minimum) leaves exactly the candidates of the
+//                  minimum level; the first R6_CAND non-empty words of it go into the task's proposal, with the best node
+//                  of the service's exception list by the full key when there is no plain candidate (the record of the
+//                  node-range shard protocol, include/swp.h swp_proposal, with more candidate words).
+//   k_r6_commit    one workgroup. Wave 0 walks the block in task order, 64 proposals in registers at a time, with k_resolve5's
+//                  matcher (swp_wave.hpp match_run64: the lists as 32-node half-words, one scalar loop iteration per task): a
+//                  task takes the first listed node nobody before it took, the node is struck from every later list (a taken
+//                  node moved up a level). The block is CUT — committed up to there, proposed again from there — in front of a task whose
+//                  listed nodes are all taken, around a task that must use its exception list (its order moves with every
+//                  placement of the service) and behind an uncounted task (its node did NOT move up). Then all threads apply
+//                  the accepted picks: NodeInfo.addTask on the node rows + the bitmaps above + commit log.
+// The exactness argument is k_resolve5's list rule: inside a batch levels only grow and feasibility only shrinks, and a list
+// holds ALL plain candidates of the task's minimum level in node order up to its last word.
+//
+// Written against swp_wave.hpp only, so tests/emu runs the same source on CPU fibers (tests/test_emu_resolve6.py).
+#pragma once
+#include "swp_shard.hpp"
+#include "swp_types.hpp"
+
+namespace swpdev {
+
+#define R6_NP 16                 // level planes: 65 535 levels above the lowest valid node
+#define R6_CAND 8                // candidate words per proposal: a block is cut where a task finds all its listed nodes taken
+#define R6_BMAX 1024             // largest block
+#define R6_COMMIT_THREADS 1024      // == R6_BMAX: one accepted pick per thread in the apply phase
+#define R6_NONE 0xFFFFFFFFu
+
+struct Blk6 {   // control block, global memory
+    u32 pos, end;          // next undecided task, end of the stretch
+    u32 base, maxrel;      // lowest task count among the valid nodes at build time; highest level above it so far
+    u32 error, rounds, cut_exhausted, cut_exception, cut_uncounted;
+    u32 cyc[4];            // R6Args.dbg & 16: shader cycles / 64 of k_r6_commit's sections (prologue, matching, wait for it, apply)
+    u32 reseats, pad[2];   // ... and how often the matcher stopped at an emptied half-word
+};
+static_assert(sizeof(Blk6) == 64, "Blk6 layout");
+
+struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidate words
+    u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); words listed | bit 31: there are more
+    u32 word[R6_CAND];
+    u64 bits[R6_CAND];
+    u64 exc_hi, exc_lo;      // best node of the service's exception list by nodeLess' key, KEY_NONE: none
+    u32 exc_entry, flags;    // flags bit 0: the task does not count on its node
+};
+static_assert(sizeof(R6Prop) == 24 + 12 * R6_CAND + 8, "R6Prop layout");
+
+struct R6Args {
+    u32 n_nodes, n_words, xs, block;
+    u32 n_dc, n_dm;
+    u32 dbg, pad0;           // timing experiments only (env SWP_DBG); 0 in production
+    const u64* valid;        // [n_words]
+    const u64* sc;           // [n_sc][n_words]
+    u64* X;                  // [n_svc][xs]
+    const RTask* rt;
+    i64* cpu;
+    i64* mem;
+    u32* total;
+    u32* list_node;
+    u32* list_svc;
+    u32* list_fail;
+    const u32* list_off;
+    u64* portmap;
+    const u32* pset_off;
+    const u32* pset_ids;
+    int32_t* out_node;
+    u32* log_node;
+    u32* log_task;
+    int32_t* log_prev;
+    int32_t* last;
+    u32* inf_task;
+    u32* inf_pos;
+    Ctl* ctl;
+    u64* planes;             // [R6_NP][n_words]
+    u64* rr;                 // [n_dc + n_dm][n_words]
+    const i64* thr;          // [n_dc + n_dm] the distinct cpu reservations (ascending), then the memory ones
+    Blk6* blk;
+    R6Prop* prop;            // [block]
+};
+
+#define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together
+inline __host__ __device__ u32 r6_chunks(u32 n_words) { return (((n_words + 63u) >> 6) + R6_UNROLL - 1u) & ~(u32)(R6_UNROLL - 1); }
+inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8; }
+inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * 3 * 4 + 64; }
+
+#ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
+WV_DEV u64 r6_wave_min64(u64 v) {
+    const u32 hi = (u32)(v >> 32), lo = (u32)v;
+    const u32 mh = wv::min_u32(hi);
+    const u32 ml = wv::min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((u64)mh << 32) | ml;
+}
+
+// ---- build: base / highest level (one workgroup of 1024), then planes and demand-class rows (one wave per node word) ----
+WV_KERNEL(1024) void k_r6_minmax(R6Args a) {
+    u32* red = reinterpret_cast<u32*>(wv::lds());
+    u32 lo = 0xFFFFFFFFu, hi = 0;
+    for (u32 n = wv::tid(); n < a.n_nodes; n += 1024)
+        if ((a.valid[n >> 6] >> (n & 63)) & 1) {
+            const u32 t = a.total[n];
+            lo = min(lo, t);
+            hi = max(hi, t);
+        }
+    lo = wv::min_u32(lo);
+    hi = ~wv::min_u32(~hi);
+    if (wv::lane() == 0) {
+        red[wv::wave()] = lo;
+        red[16 + wv::wave()] = hi;
+    }
+    wv::barrier();
+    if (wv::tid() == 0) {
+        for (u32 i = 1; i < 16; ++i) {
+            lo = min(lo, red[i]);
+            hi = max(hi, red[16 + i]);
+        }
+        if (lo == 0xFFFFFFFFu) lo = hi = 0;   // no valid node
+        a.blk->base = lo;
+        a.blk->maxrel = hi - lo;
+        a.blk->error = (hi - lo) >> R6_NP ? (u32)ERR_LEVEL_RANGE : (u32)ERR_NONE;
+    }
+}
+
+WV_KERNEL(256) void k_r6_rows(R6Args a) {
+    const u32 w = wv::block() * 4 + wv::wave(), lane = wv::lane();
+    if (w >= a.n_words) return;
+    const u32 base = wv::uload(&a.blk->base);   // written by the launch before this one
+    const u32 n = w * 64 + lane;
+    const bool in = n < a.n_nodes;
+    const bool v = in && ((wv::uload(a.valid + w) >> lane) & 1);
+    const u32 lvl = v ? a.total[n] - base : 0u;
+    for (u32 b = 0; b < R6_NP; ++b) {
+        const u64 word = wv::ballot(v && ((lvl >> b) & 1u));
+        if (lane == 0) a.planes[(size_t)b * a.n_words + w] = word;
+    }
+    const i64 qc = in ? a.cpu[n] : 0, qm = in ? a.mem[n] : 0;
+    for (u32 c = 0; c < a.n_dc + a.n_dm; ++c) {
+        const u64 word = wv::ballot(in && (c < a.n_dc ? qc : qm) >= wv::uload(a.thr + c));
+        if (lane == 0) a.rr[(size_t)c * a.n_words + w] = word;
+    }
+}
+
+// ---- propose: one wave per task of the block ------------------------------------------------------------------------------
+WV_KERNEL(64) void k_r6_propose(R6Args a) {
+    const u32 lane = wv::lane();
+    const u32 t = wv::uload(&a.blk->pos) + wv::block();
+    if (t >= wv::uload(&a.blk->end)) return;
+    const RTask* rt = a.rt + t;
+    const i64 rcpu = wv::uload(&rt->cpu), rmem = wv::uload(&rt->mem);
+    const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc), scid = wv::uload(&rt->sc), pset = wv::uload(&rt->pset);
+    const u64 maxrep = wv::uload(&rt->maxrep);
+    const u32 Wn = a.n_words, KC = r6_chunks(Wn);   // a multiple of R6_UNROLL; the chunks beyond the row hold no candidates
+    u64* A = wv::lds();
+    u64* Bf = A + (size_t)KC * 64;
+    const u64* scrow = a.sc + (size_t)scid * Wn;
+    const u64* xrow = a.X + (size_t)svc * a.xs;
+    const bool res = (flags & RT_RES) != 0;
+    const u64* rc = a.rr + (size_t)((flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * Wn;
+    const u64* rm = a.rr + (size_t)(a.n_dc + ((flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * Wn;
+    u32 p0 = 0, p1 = 0;
+    if (flags & RT_PORTS) {
+        p0 = wv::uload(a.pset_off + pset);
+        p1 = wv::uload(a.pset_off + pset + 1);
+    }
+    // the task's plain candidates, lane l owns words {l + 64 k}; R6_UNROLL chunks per step so that their loads are in flight together
+    bool any = false;
+    for (u32 k0 = 0; k0 < KC; k0 += R6_UNROLL) {
+        u64 m[R6_UNROLL], f[R6_UNROLL];
+WV_UNROLL
+        for (int u = 0; u < R6_UNROLL; ++u) {
+            const u32 w = (k0 + u) * 64 + lane;
+            const bool in = w < Wn;
+            m[u] = in ? scrow[w] : 0ull;
+            f[u] = in ? xrow[w] : 0ull;
+            if (res && in) f[u] |= ~(rc[w] & rm[w]);
+        }
+WV_UNROLL
+        for (int u = 0; u < R6_UNROLL; ++u) {
+            const u32 w = (k0 + u) * 64 + lane;
+            m[u] &= ~f[u];
+            for (u32 p = p0; p < p1; ++p)
+                if (m[u]) m[u] &= ~a.portmap[(size_t)wv::uload(a.pset_ids + p) * Wn + w];
+            A[(k0 + u) * 64 + lane] = m[u];
+            any = any || m[u] != 0;
+        }
+    }
+    // the minimum level among them: descent over the planes, the candidate set narrows to that level's nodes
+    u32 level = R6_NONE;
+    if (wv::ballot(any)) {
+        const u32 maxrel = wv::uload(&a.blk->maxrel);
+        u32 rel = 0;
+        for (int b = 31 - wv::clz32(maxrel); b >= 0; --b) {
+            const u64* pl = a.planes + (size_t)b * Wn;
+            bool h = false;
+            for (u32 k0 = 0; k0 < KC; k0 += R6_UNROLL) {
+                u64 m[R6_UNROLL], q[R6_UNROLL];
+WV_UNROLL
+                for (int u = 0; u < R6_UNROLL; ++u) {
+                    m[u] = A[(k0 + u) * 64 + lane];
+                    q[u] = m[u] ? pl[(k0 + u) * 64 + lane] : 0ull;   // m != 0 only inside the row
+                }
+WV_UNROLL
+                for (int u = 0; u < R6_UNROLL; ++u) {
+                    const u64 c = m[u] & ~q[u];
+                    Bf[(k0 + u) * 64 + lane] = c;
+                    h = h || c != 0;
+                }
+            }
+            if (wv::ballot(h)) {
+                u64* x = A;
+                A = Bf;
+                Bf = x;
+            } else
+                rel |= 1u << b;
+        }
+        level = wv::uload(&a.blk->base) + rel;
+    }
+    R6Prop* out = a.prop + wv::block();
+    // its first non-empty words, in node order
+    u32 cnt = 0, more = 0;
+    if (level != R6_NONE)
+        for (u32 k = 0; k < KC && !more; ++k) {
+            const u64 m = A[k * 64 + lane];
+            u64 bal = wv::ballot(m != 0);
+            while (bal) {
+                const u32 l = (u32)wv::ffs64(bal);
+                bal &= bal - 1;
+                if (cnt == R6_CAND) {
+                    more = 1;
+                    break;
+                }
+                const u64 bits = wv::readlane64(m, l);
+                if (lane == 0) {
+                    out->word[cnt] = k * 64 + l;
+                    out->bits[cnt] = bits;
+                }
+                ++cnt;
+            }
+        }
+    // no plain candidate: the service's exception list by the full key (scheduler.go:708-735), lanes stride over the entries
+    u64 bhi = KEY_NONE, blo = KEY_NONE;
+    u32 be = 0;
+    const u32 e0 = wv::uload(a.list_off + svc), e1 = level == R6_NONE ? wv::uload(a.list_off + svc + 1) : e0;
+    for (u32 e = e0 + lane; e < e1; e += 64) {
+        const u32 n = a.list_node[e];
+        if (n == LIST_EMPTY) continue;
+        const u32 w = n >> 6;
+        const u64 bit = 1ull << (n & 63);
+        if (!(scrow[w] & bit)) continue;
+        if (res && !(rcpu <= a.cpu[n] && rmem <= a.mem[n])) continue;
+        bool used = false;
+        for (u32 p = p0; p < p1; ++p)
+            if (a.portmap[(size_t)a.pset_ids[p] * Wn + w] & bit) used = true;
+        if (used) continue;
+        const u32 sv = a.list_svc[e], fl = a.list_fail[e];
+        if ((flags & RT_MAXREP) && !((u64)sv < maxrep)) continue;   // filter.go:373-375
+        const u32 fcl = fl >= MAX_FAILURES ? fl - (MAX_FAILURES - 1) : 0u;
+        const u64 hi = ((u64)fcl << 32) | sv, lo = ((u64)a.total[n] << 32) | n;
+        if (hi < bhi || (hi == bhi && lo < blo)) {
+            bhi = hi;
+            blo = lo;
+            be = e;
+        }
+    }
+    const u64 ghi = r6_wave_min64(bhi);
+    const u64 glo = r6_wave_min64(bhi == ghi ? blo : KEY_NONE);
+    const u64 who = wv::ballot(bhi == ghi && blo == glo && ghi != KEY_NONE);
+    const u32 gentry = who ? wv::readlane(be, (u32)wv::ffs64(who)) : 0u;
+    if (lane == 0) {
+        out->level = level;
+        out->n_cand = cnt | (more ? 0x80000000u : 0u);
+        for (u32 i = cnt; i < R6_CAND; ++i) {
+            out->word[i] = 0;
+            out->bits[i] = 0;
+        }
+        out->exc_hi = ghi;
+        out->exc_lo = ghi == KEY_NONE ? KEY_NONE : glo;
+        out->exc_entry = gentry;
+        out->flags = (flags & RT_UNCOUNTED) ? 1u : 0u;
+    }
+}
+
+// ---- commit: match the block in task order (wave 0), then apply the accepted picks (all threads) ---------------------------
+WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
+    const u32 tid = wv::tid(), lane = wv::lane();
+    const u32 pos = a.blk->pos, end = a.blk->end;
+    if (pos >= end) return;
+    const u32 n = min(a.block, end - pos), Wn = a.n_words, n_rr = a.n_dc + a.n_dm;
+    u64* tk = wv::lds();                                         // [Wn] nodes taken by this block so far
+    i64* thr = reinterpret_cast<i64*>(tk + Wn);                  // [n_rr] the demand-class thresholds
+    u32* pk_node = reinterpret_cast<u32*>(thr + n_rr);           // [block] node, R6_NONE = no suitable node
+    u32* pk_idx = pk_node + a.block;                             // [block] commit index / index among the unplaceable tasks
+    u32* pk_aux = pk_idx + a.block;                              // [block] exception-list entry (LIST_EMPTY: plain node) / commits before an unplaceable task
+    u32* sh = pk_aux + a.block;                                  // [0] accepted, [1] ncommit, [2] ninf
+    for (u32 w = tid; w < Wn; w += R6_COMMIT_THREADS) tk[w] = 0;
+    for (u32 c = tid; c < n_rr; c += R6_COMMIT_THREADS) thr[c] = a.thr[c];
+    // thread i applies the block's i-th task once wave 0 has decided it: its record is requested now, while the matching runs
+    RTask r{};
+    if (tid < n) r = a.rt[pos + tid];
+    const bool prof = (a.dbg & 16u) != 0;
+    const u64 t0 = prof ? wv::clock64() : 0;
+    wv::barrier();
+    const u64 t1 = prof ? wv::clock64() : 0;
+    u32 reseats = 0;
+    if (wv::wave() == 0) {
+        u32 nc = a.ctl->ncommit, ni = a.ctl->ninf, acc = 0, why = 0;
+        u32* tk32 = reinterpret_cast<u32*>(tk);   // the same row as 32-node half-words
+        bool stop = false;
+        R6Prop nxt = a.prop[lane < n ? lane : 0];   // the records of the next 64 tasks are in flight while a group is matched
+        for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
+            const u32 i = g0 + lane, glim = min(64u, n - g0);
+            const bool have = i < n;
+            const R6Prop rec = nxt;
+            const R6Prop* p = &rec;
+            if (g0 + 64 < n) nxt = a.prop[i + 64 < n ? i + 64 : 0];
+            const u32 level = have ? p->level : 0u;
+            const u32 nent = (have && level != R6_NONE) ? 2 * (p->n_cand & 0x7FFFFFFFu) : 0u;
+            const bool plain = nent != 0;
+            const bool exc = have && level == R6_NONE && p->exc_hi != KEY_NONE;
+            const bool inf = have && level == R6_NONE && !exc;
+            // the list as 32-node half-words (registers), minus the picks of the earlier groups
+            u32 eb[2 * R6_CAND], ew[2 * R6_CAND];
+            for (int k = 0; k < 2 * R6_CAND; ++k) {
+                ew[k] = 2 * p->word[k >> 1] + (k & 1);
+                eb[k] = (u32)k < nent ? ((u32)(p->bits[k >> 1] >> (32 * (k & 1))) & ~tk32[ew[k]]) : 0u;
+            }
+            u32 bits = 0, w = 0;   // current half-word of every lane: the first one of its list that still has a candidate
+            for (int k = 2 * R6_CAND - 1; k >= 0; --k)
+                if (eb[k]) { bits = eb[k]; w = ew[k]; }
+            const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
+            const u64 m_plain = wv::ballot(plain), m_inf = wv::ballot(inf), m_exc = wv::ballot(exc), m_unc = wv::ballot(plain && (p->flags & 1u));
+            // the group ends in front of a task that must use its exception list (its order moves with every placement of the service:
+            // only a block's first task may) and behind an uncounted task (its node stays on its level: the later lists are stale about it)
+            u32 cut = glim;
+            bool last = false;   // the block ends with this group even if the group is walked to its end
+            if (m_exc) { cut = (u32)wv::ffs64(m_exc); why = 2; }
+            if (m_unc && (u32)wv::ffs64(m_unc) < cut) { cut = (u32)wv::ffs64(m_unc) + 1; why = 3; last = true; }
+            u32 m_pick = R6_NONE;
+            if (g0 == 0 && (m_exc & 1ull)) {   // the block's first task, from its exception list; the block ends behind it
+                if (lane == 0) {
+                    pk_node[0] = (u32)p->exc_lo;
+                    pk_idx[0] = nc;
+                    pk_aux[0] = p->exc_entry;
+                }
+                ++nc;
+                acc = 1;
+                why = 2;
+                break;
+            }
+            u64 todo = m_plain & (cut == 64 ? ~0ull : (1ull << cut) - 1ull);
+            u32 flushed = 0;   // picks of lanes < flushed are in the TK row
+            for (;;) {
+                const u32 at = wv::match_run64(todo, bits, w, m_pick);
+                if (at == 0xFFFFFFFFu) break;
+                ++reseats;
+                // task `at` ran out of its current half-word — and so, usually, did others that sat on it: this group's picks so far go to
+                // the TK row, every such lane cleans all its half-words of them and takes the first one that still has a candidate
+                if (lane >= flushed && lane < at && m_pick != R6_NONE) wv::lds_or32(tk32 + (m_pick >> 5), 1u << (m_pick & 31));
+                flushed = at;
+                wv::lockstep();   // one wave's LDS operations execute in order: the reads below see the atomics above
+                if (plain && bits == 0) {
+                    u32 t[2 * R6_CAND];
+                    for (int k = 0; k < 2 * R6_CAND; ++k) t[k] = eb[k] & ~tk32[ew[k]];
+                    for (int k = 2 * R6_CAND - 1; k >= 0; --k)
+                        if (t[k]) { bits = t[k]; w = ew[k]; }
+                }
+                if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
+                    cut = at;
+                    why = 1;
+                    break;
+                }
+            }
+            if (lane >= flushed && lane < cut && m_pick != R6_NONE) wv::lds_or32(tk32 + (m_pick >> 5), 1u << (m_pick & 31));   // for the later groups
+            const u64 below = cut == 64 ? ~0ull : (1ull << cut) - 1ull;
+            const u64 mc = m_plain & below & lanes, mi = m_inf & below & lanes;
+            if (lane < cut && have) {
+                if (plain) {
+                    pk_node[i] = m_pick;
+                    pk_idx[i] = nc + wv::mbcnt(mc);
+                    pk_aux[i] = LIST_EMPTY;
+                } else {   // no suitable node: final whatever the earlier tasks of the block did (feasibility only shrinks)
+                    pk_node[i] = R6_NONE;
+                    pk_idx[i] = ni + wv::mbcnt(mi);
+                    pk_aux[i] = nc + wv::mbcnt(mc);
+                }
+            }
+            nc += (u32)wv::popc64(mc);
+            ni += (u32)wv::popc64(mi);
+            acc = g0 + cut;
+            if (cut < glim || (last && why == 3)) stop = true;
+            else why = 0;
+            wv::wave_sync();
+        }
+        if (lane == 0) {
+            sh[0] = acc;
+            sh[1] = nc;
+            sh[2] = ni;
+            a.blk->rounds += 1;
+            if (why == 1) a.blk->cut_exhausted += 1;
+            if (why == 2) a.blk->cut_exception += 1;
+            if (why == 3) a.blk->cut_uncounted += 1;
+            if (prof) {
+                a.blk->cyc[0] += (u32)((t1 - t0) >> 6);
+                a.blk->cyc[1] += (u32)((wv::clock64() - t1) >> 6);
+                a.blk->reseats += reseats;
+            }
+        }
+    }
+    wv::barrier();
+    const u64 t2 = prof ? wv::clock64() : 0;
+    const u32 acc = sh[0], base = a.blk->base;
+    if (tid < acc) {
+        const u32 t = pos + tid, nd = pk_node[tid];
+        if (nd == R6_NONE) {
+            a.inf_task[pk_idx[tid]] = t;
+            a.inf_pos[pk_idx[tid]] = pk_aux[tid];
+        } else {
+            const u32 w = nd >> 6, ci = pk_idx[tid], entry = pk_aux[tid];
+            const u64 bit = 1ull << (nd & 63);
+            // the node row, requested in one go. No two picks of one block share a node: plain read-modify-write of the row; bitmap
+            // words are shared between nodes: atomics
+            const i64 qc = a.cpu[nd] - r.cpu, qm = a.mem[nd] - r.mem;
+            const u32 old = a.total[nd];
+            const int32_t prev = a.last[nd];
+            if (r.cpu) {
+                a.cpu[nd] = qc;
+                for (int c = (int)a.n_dc - 1; c >= 0 && thr[c] > qc; --c) wv::g_andn64(a.rr + (size_t)c * Wn + w, bit);
+            }
+            if (r.mem) {
+                a.mem[nd] = qm;
+                for (int c = (int)a.n_dm - 1; c >= 0 && thr[a.n_dc + c] > qm; --c) wv::g_andn64(a.rr + (size_t)(a.n_dc + c) * Wn + w, bit);
+            }
+            if (r.flags & RT_PORTS)
+                for (u32 q = a.pset_off[r.pset]; q < a.pset_off[r.pset + 1]; ++q) wv::g_or64(a.portmap + (size_t)a.pset_ids[q] * Wn + w, bit);
+            if (!(r.flags & RT_UNCOUNTED)) {
+                a.total[nd] = old + 1;
+                const u32 rl = old - base, nl = rl + 1, xm = rl ^ nl;   // the bits a +1 flips: a run of ones from bit 0
+                for (u32 b = 0; b < R6_NP && ((xm >> b) & 1u); ++b) wv::g_xor64(a.planes + (size_t)b * Wn + w, bit);
+                wv::g_max32(&a.blk->maxrel, nl);
+                if (nl >> R6_NP) a.blk->error = ERR_LEVEL_RANGE;
+                if (entry == LIST_EMPTY) {
+                    wv::g_or64(a.X + (size_t)r.svc * a.xs + w, bit);
+                    a.list_node[r.slot] = nd;
+                    a.list_svc[r.slot] = 1;
+                    a.list_fail[r.slot] = 0;
+                } else
+                    a.list_svc[entry] += 1;
+            }
+            a.log_node[ci] = nd;
+            a.log_task[ci] = t;
+            a.log_prev[ci] = prev;
+            a.last[nd] = (int32_t)ci;
+            a.out_node[t] = (int32_t)nd;
+        }
+    }
+    if (tid == 0) {
+        a.blk->pos = pos + acc;
+        a.ctl->ncommit = sh[1];
+        a.ctl->ninf = sh[2];
+        if (prof) {
+            a.blk->cyc[2] += (u32)((t2 - t1) >> 6);
+            a.blk->cyc[3] += (u32)((wv::clock64() - t2) >> 6);
+        }
+    }
+}
+
+#endif   // SWP_R6_KERNELS
+
+}  // namespace swpdev

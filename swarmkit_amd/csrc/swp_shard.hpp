@@ -21,7 +21,7 @@ struct Proposal {   // == swp_proposal (include/swp.h)
     u32 word[4];
     u64 bits[4];
     u64 exc_hi, exc_lo;
-    u32 exc_entry, reserved;
+    u32 exc_entry, flags;   // flags bit 0: an uncounted task (its pick ends the block)
 };
 static_assert(sizeof(Proposal) == 80, "swp_proposal layout");
 
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void k_propose(ProposeArgs a) {
         pr.exc_hi = ghi;
         pr.exc_lo = ghi == KEY_NONE ? KEY_NONE : glo;
         pr.exc_entry = gentry;
-        pr.reserved = 0;
+        pr.flags = (flags & RT_UNCOUNTED) ? 1u : 0u;
         a.out[t] = pr;
     }
 }

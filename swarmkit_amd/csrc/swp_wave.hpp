@@ -14,6 +14,7 @@
 
 #define WV_DEV __device__ __forceinline__
 #define WV_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+#define WV_UNROLL _Pragma("unroll")
 
 namespace wv {
 using swpdev::i64;
@@ -25,6 +26,7 @@ WV_DEV u32 nthreads() { return blockDim.x; }
 WV_DEV u32 lane() { return threadIdx.x & 63u; }
 // wave index as a scalar (threadIdx.x >> 6 is uniform, the compiler does not always know)
 WV_DEV u32 wave() { return (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+WV_DEV u32 block() { return blockIdx.x; }   // workgroup index of a multi-workgroup launch (swp_resolve6.hpp)
 WV_DEV u64* lds() {
     extern __shared__ u64 wv_lds_[];
     return wv_lds_;
@@ -80,6 +82,9 @@ WV_DEV void lds_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_R
 WV_DEV void g_add64(i64* p, i64 v) { __hip_atomic_fetch_add(reinterpret_cast<u64*>(p), (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void g_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void g_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void g_xor64(u64* p, u64 v) { __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV void g_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV void g_max32(u32* p, u32 v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV_DEV u32 g_exch32(u32* p, u32 v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // loads that must see what other waves of this workgroup wrote through L2 (bypass the CU's vector L1)
 WV_DEV u64 g_fresh64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -151,5 +156,6 @@ WV_DEV u64 clock64() { return __builtin_amdgcn_s_memtime(); }
 
 WV_DEV int ffs64(u64 v) { return __ffsll((long long)v) - 1; }   // index of the lowest set bit (v != 0)
 WV_DEV int popc64(u64 v) { return __popcll(v); }
+WV_DEV int clz32(u32 v) { return __clz((int)v); }   // 32 for v == 0
 
 }  // namespace wv

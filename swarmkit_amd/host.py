@@ -830,4 +830,8 @@ def load_workload(sched, wl, first=0, count=None):
     per_service = np.concatenate([sched.task_desc(dict(wl.service_spec(k), ID="x", ServiceID=wl.service_id(k), DesiredState=RUNNING))
                                   for k in range(wl.S)])
     svc_of_task = np.array([wl.task_service(j) for j in range(wl.T)], dtype=np.int64) if getattr(wl, "order", "rr") != "rr" else np.arange(wl.T) % wl.S
-    return per_service[svc_of_task]
+    descs = per_service[svc_of_task]
+    k = getattr(wl, "uncounted_every", 0)
+    if k:
+        descs["flags"][k - 1::k] |= abi.TASK_UNCOUNTED
+    return descs

@@ -10,7 +10,7 @@ import numpy as np
 MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
 GOLDEN = np.uint64(0x9E3779B97F4A7C15)
 
-READY, RUNNING, PENDING = 2, 512, 64
+READY, RUNNING, PENDING, SHUTDOWN = 2, 512, 64, 640
 GIB = 1 << 30
 MIB = 1 << 20
 
@@ -66,6 +66,7 @@ class Workload:
         self.order = order   # "rr": task j belongs to service j % S; "major": tasks of one service are consecutive
         self.features = c
         self.grouped = grouped
+        self.uncounted_every = 0   # tests: every k-th task has DesiredState SHUTDOWN — placed, but not counted on its node (nodeinfo.go:131-134)
         self._gen_nodes()
         self._gen_services()
 
@@ -170,6 +171,8 @@ class Workload:
     def task_doc(self, j):
         k = self.task_service(j)
         t = {"ID": self.task_id(j), "ServiceID": self.service_id(k), "DesiredState": RUNNING, "Status": {"State": PENDING}}
+        if self.uncounted_every and j % self.uncounted_every == self.uncounted_every - 1:
+            t["DesiredState"] = SHUTDOWN
         if self.grouped:
             t["SpecVersion"] = {"Index": 1}
         t.update(self.service_spec(k))

@@ -22,6 +22,7 @@
 #define __device__
 #define WV_DEV inline
 #define WV_KERNEL(bounds)
+#define WV_UNROLL
 
 #include "../../swarmkit_amd/csrc/swp_types.hpp"
 
@@ -96,6 +97,10 @@ struct Block {
     std::vector<void*> last_site;   // per thread: return address of its last collective / barrier call (deadlock report)
     std::vector<u64> ncoll;
 };
+inline u32& blockidx() {   // workgroup index seen by wv::block(): the harness runs the workgroups of a grid one after the other
+    static u32 b = 0;
+    return b;
+}
 inline Block*& B() {
     static Block* b = nullptr;
     return b;
@@ -240,6 +245,7 @@ inline u32 tid() { return emu::B()->cur; }
 inline u32 nthreads() { return emu::B()->nthreads; }
 inline u32 lane() { return emu::B()->cur & 63u; }
 inline u32 wave() { return emu::B()->cur >> 6; }
+inline u32 block() { return emu::blockidx(); }
 inline u64* lds() { return emu::B()->lds.data(); }
 
 inline u64 ballot(bool p) { return emu::collective(emu::OP_BALLOT, p ? 1 : 0, 0); }
@@ -262,6 +268,9 @@ inline void lds_andn64(u64* p, u64 v) { *p &= ~v; }
 inline void g_add64(i64* p, i64 v) { *p += v; }
 inline void g_add32(u32* p, u32 v) { *p += v; }
 inline void g_or64(u64* p, u64 v) { *p |= v; }
+inline void g_xor64(u64* p, u64 v) { *p ^= v; }
+inline void g_andn64(u64* p, u64 v) { *p &= ~v; }
+inline void g_max32(u32* p, u32 v) { if (v > *p) *p = v; }
 inline u32 g_exch32(u32* p, u32 v) { u32 o = *p; *p = v; return o; }
 inline u64 g_fresh64(const u64* p) { return *p; }
 inline u32 g_fresh32(const u32* p) { return *p; }
@@ -290,4 +299,5 @@ inline u64 clock64() { return 0; }
 
 inline int ffs64(u64 v) { return __builtin_ffsll((long long)v) - 1; }
 inline int popc64(u64 v) { return __builtin_popcountll(v); }
+inline int clz32(u32 v) { return v ? __builtin_clz(v) : 32; }
 }  // namespace wv

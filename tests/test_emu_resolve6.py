@@ -1,0 +1,44 @@
+"""CPU: the block resolver's kernel SOURCE (swarmkit_amd/csrc/swp_resolve6.hpp) run on fibers (tests/emu/wv_emu.hpp), workgroup by
+workgroup, against the sequential model of tests/emu/emu_model.hpp: every output, every mutated array, and the level planes /
+demand-class rows the kernels maintain incrementally against a rebuild. No GPU involved; the GPU parity is tests/test_engine_blocks.py."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu")
+BIN = os.path.join(HERE, "_build", "emu_resolve6")
+CSRC = os.path.join(HERE, "..", "swarmkit_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu_bin():
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    srcs = [os.path.join(EMU, "emu_resolve6.cpp"), os.path.join(EMU, "wv_emu.hpp"), os.path.join(EMU, "emu_model.hpp"),
+            os.path.join(CSRC, "swp_resolve6.hpp"), os.path.join(CSRC, "swp_shard.hpp"), os.path.join(CSRC, "swp_types.hpp")]
+    if not os.path.exists(BIN) or any(os.path.getmtime(s) > os.path.getmtime(BIN) for s in srcs):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-o", BIN, srcs[0]], check=True)
+    return BIN
+
+
+# (seed, nodes, tasks, services, block, task order, feature level, extra)
+CASES = [
+    (1, 300, 1000, 20, 64, 0, 0, ""),        # few services on few nodes: the exception lists take over, one task per round
+    (2, 700, 3000, 30, 128, 0, 1, ""),       # heavy services, max-replicas, pre-existing exception lists
+    (3, 1000, 2500, 40, 64, 2, 2, ""),       # host ports, uncounted tasks, random task order
+    (4, 5000, 3000, 300, 256, 0, 2, "s"),    # two node words per lane chunk, two stretches with a rebuild of the bitmaps between
+    (12, 5924, 1856, 377, 128, 0, 0, "s"),   # the fast path carries the block: > 100 tasks per round
+    (13, 901, 2469, 8, 256, 1, 1, ""),       # service-major
+    (17, 2000, 1500, 100, 1, 2, 2, ""),      # a block of one task
+    (21, 4500, 2000, 200, 1024, 0, 1, ""),   # the largest block
+    (40, 3280, 1020, 45, 8, 1, 1, "s"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d-N%d-B%d-f%d%s" % (c[0], c[1], c[4], c[6], c[7]))
+def test_block_resolver_source_matches_sequential_model(emu_bin, case):
+    args = [str(x) for x in case[:7]] + ["v"] + ([case[7]] if case[7] else [])
+    r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr

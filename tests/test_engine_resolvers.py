@@ -1,6 +1,7 @@
 """GPU parity across the resolver kernels and their geometries: every variant (0 workgroup, 1 one-wave, 2 two-wave,
-3 two-wave specialised, 5 round resolver = the default, in its exact mode — demand-class rows, no scan — and "5s", the
-same kernel over the scan's F rows) and every owned-words-per-lane count K must reproduce the oracle bit for bit."""
+3 two-wave specialised, 5 round resolver = the default, in its exact mode — demand-class rows, no scan — "5s", the
+same kernel over the scan's F rows, and 6, the block resolver that takes over beyond k_resolve5's node limit) and every
+owned-words-per-lane count K must reproduce the oracle bit for bit."""
 import os
 
 import pytest
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def resolver_env():
-    old = {k: os.environ.get(k) for k in ("SWP_RESOLVER", "SWP_R5_EXACT")}
+    old = {k: os.environ.get(k) for k in ("SWP_RESOLVER", "SWP_R5_EXACT", "SWP_R6_BLOCK")}
     yield
     for k, v in old.items():
         if v is None:
@@ -32,7 +33,7 @@ def pick_variant(variant):
 
 
 CASES = [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg1", 500, 40, {}), ("cfg2", 3000, 50, {})]
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, "5s"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, "5s", 6])
 @pytest.mark.parametrize("name,T,N,kw", CASES)
 def test_variants_agree_with_oracle(resolver_env, variant, name, T, N, kw):
     wl = synth.Workload(name, T=T, N=N, **kw)
@@ -64,7 +65,7 @@ def test_round_resolver_scan_mode_words_per_lane(resolver_env, N):
     pu.assert_same(op, oe, ep, ee)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 5, "5s"])
+@pytest.mark.parametrize("variant", [2, 3, 5, "5s", 6])
 @pytest.mark.parametrize("services,order", [(1, "rr"), (2, "rr"), (3, "major"), (40, "major"), (7, "rr")])
 def test_same_service_runs(resolver_env, variant, services, order):
     """Consecutive tasks of one service: every commit must be visible to the next task of that service although

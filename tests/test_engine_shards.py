@@ -39,6 +39,16 @@ def test_block_size_does_not_matter(block):
     pu.assert_same(op, oe, sp, se)
 
 
+def test_uncounted_tasks_end_the_block():
+    """A task that does not count on its node (DesiredState beyond COMPLETED, nodeinfo.go:131-134) leaves the node on its level: the
+    proposals of the later tasks of the block are stale about it, so the merge ends the block behind such a pick."""
+    wl = synth.Workload("cfg2", T=1500, N=300)
+    wl.uncounted_every = 4
+    op, oe, _ = pu.oracle_run(wl)
+    sp, se, _ = pu.sharded_run(wl, 3)
+    pu.assert_same(op, oe, sp, se)
+
+
 def test_more_shards_than_nodes():
     wl = synth.Workload("cfg2", T=200, N=3)
     op, oe, _ = pu.oracle_run(wl)
