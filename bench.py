@@ -46,6 +46,8 @@ def profile_traffic(kernel):
             continue
         per = doc.get("hbm_bytes_per_launch", {})
         base = kernel.split("<")[0]
+        if kernel.startswith("k_resolve6") and "k_r6_propose" in per and "k_r6_commit" in per:   # per ROUND: one launch of each
+            return per["k_r6_propose"] + per["k_r6_commit"], "profiles/%s_pmc_summary.json, k_r6_propose + k_r6_commit per round (%s)" % (tag, doc.get("source_cfg4_200k_40k", ""))
         if base in per:
             return per[base], "profiles/%s_pmc_summary.json (%s)" % (tag, doc.get("source", "rocprofv3 --pmc"))
         if tag == "r01" and "k_resolve_hbm_bytes_per_launch" in doc and base == "k_resolve3":
