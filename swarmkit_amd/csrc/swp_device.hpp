@@ -2562,6 +2562,12 @@ __global__ __launch_bounds__(256) void k_explain(ExplainArgs a) {
     __shared__ u32 cnt[EX_TCH][8];
     for (u32 q = threadIdx.x; q < EX_TCH * 8; q += blockDim.x) (&cnt[0][0])[q] = 0;
     __syncthreads();
+    // the node's commit segment is walked ONCE per block: the unplaceable tasks are recorded in batch order, so their moments
+    // (commits before them) ascend and the cursor only moves forward (a moment that steps back restarts it)
+    const u32 seg_o = present ? a.seg_off[n] : 0u, seg_n = present ? a.seg_len[n] : 0u;
+    u32 seg_p = 0, seg_cached = 0xFFFFFFFFu;
+    int32_t seg_pos = 0;
+    i64 seg_c = 0, seg_m = 0;
     for (u32 e = e0; e < e1; ++e) {
         const u32 gj = cload(a.inf_task + e);
         const int32_t pos = (int32_t)cload(a.inf_pos + e);
@@ -2600,11 +2606,15 @@ __global__ __launch_bounds__(256) void k_explain(ExplainArgs a) {
             bool res_fail = false;
             if ((rflags & RT_RES) && is_ready && !(rcpu <= c_end && rmem <= m_end)) {
                 // residuals at the task's moment = end state + reservations of the node's commits with index >= pos
-                const u32 off = a.seg_off[n], len = a.seg_len[n];
-                u32 p = 0;
-                while (p < len && a.ent_ci[off + p] < (u32)pos) ++p;
-                const i64 cc = c_end + (p < len ? a.ent_scpu[off + p] : 0), mm = m_end + (p < len ? a.ent_smem[off + p] : 0);
-                res_fail = !(rcpu <= cc && rmem <= mm);
+                if (pos < seg_pos) seg_p = 0;
+                seg_pos = pos;
+                while (seg_p < seg_n && a.ent_ci[seg_o + seg_p] < (u32)pos) ++seg_p;
+                if (seg_p != seg_cached) {
+                    seg_cached = seg_p;
+                    seg_c = seg_p < seg_n ? a.ent_scpu[seg_o + seg_p] : 0;
+                    seg_m = seg_p < seg_n ? a.ent_smem[seg_o + seg_p] : 0;
+                }
+                res_fail = !(rcpu <= c_end + seg_c && rmem <= m_end + seg_m);
             }
             if (!is_ready) ff = 0;
             else if (res_fail) ff = 1;
@@ -2744,26 +2754,51 @@ struct GHeap {   // heap positions hold (key, state id); the node state itself n
         const u32 t = pay[a]; pay[a] = pay[b]; pay[b] = t;
     }
 };
-// container/heap (go stdlib) over nodeMaxHeap: Less(i,j) = lessFunc(nodes[j], nodes[i]) (nodeheap.go:17-20)
-template <class HP> __device__ inline void g_up(HP& h, u32 base, int j) {
+// container/heap (go stdlib) over nodeMaxHeap: Less(i,j) = lessFunc(nodes[j], nodes[i]) (nodeheap.go:17-20).
+// up / down move ONE element along a path and swap it with what it meets: the element rides in registers and every step copies
+// the other one into the hole — the same comparisons, the same final arrangement as the swap sequence, but one LDS round trip
+// per level (both children's keys and payloads are requested together) instead of three. The walk is the serial chain of
+// k_groups: LDS latency of a single thread.
+template <class HP> __device__ inline void g_up(HP& h, u32 base, int j0) {
+    int j = j0;
+    const u64 kv = h.key[base + j];
+    const u32 pv = h.pay[base + j];
     for (;;) {
-        int i = (j - 1) / 2;
-        if (i == j || !h.less(base + i, base + j)) break;   // !Less(j,i)
-        h.swap(base + i, base + j);
+        const int i = (j - 1) / 2;   // j == 0: i == 0 (Go's integer division truncates, too)
+        if (i == j) break;
+        const u64 ki = h.key[base + i];
+        const u32 pi = h.pay[base + i];
+        if (!(ki < kv)) break;       // !Less(j, i)
+        h.key[base + j] = ki;
+        h.pay[base + j] = pi;
         j = i;
+    }
+    if (j != j0) {
+        h.key[base + j] = kv;
+        h.pay[base + j] = pv;
     }
 }
 template <class HP> __device__ inline bool g_down(HP& h, u32 base, int i0, int n) {
     int i = i0;
+    const u64 kv = h.key[base + i];
+    const u32 pv = h.pay[base + i];
     for (;;) {
-        int j1 = 2 * i + 1;
+        const int j1 = 2 * i + 1;
         if (j1 >= n || j1 < 0) break;
-        int j = j1;
-        int j2 = j1 + 1;
-        if (j2 < n && h.less(base + j1, base + j2)) j = j2;   // Less(j2,j1)
-        if (!h.less(base + i, base + j)) break;                // !Less(j,i)
-        h.swap(base + i, base + j);
-        i = j;
+        const int j2 = j1 + 1;
+        const bool two = j2 < n;
+        const u64 k1 = h.key[base + j1], k2 = two ? h.key[base + j2] : 0ull;
+        const u32 p1 = h.pay[base + j1], p2 = two ? h.pay[base + j2] : 0u;
+        const bool right = two && k1 < k2;   // Less(j2, j1)
+        const u64 kj = right ? k2 : k1;
+        if (!(kv < kj)) break;               // !Less(j, i)
+        h.key[base + i] = kj;
+        h.pay[base + i] = right ? p2 : p1;
+        i = right ? j2 : j1;
+    }
+    if (i > i0) {
+        h.key[base + i] = kv;
+        h.pay[base + i] = pv;
     }
     return i > i0;
 }
@@ -2872,12 +2907,15 @@ __global__ __launch_bounds__(G_THREADS) void k_groups(GroupArgs a) {
         }
 
         G_TICK(1);
-        // ---------- (B) heap admission in node order, G_THREADS nodes at a time (nodeset.go:107-120) ----------
-        for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
+        // ---------- (B) heap admission in node order, a chunk of nodes at a time (nodeset.go:107-120) ----------
+        // The pre-filter compares with the heap roots as they are at the chunk's start, so it is the sharper the shorter the chunk:
+        // the first G_THREADS nodes (while the heaps fill and their roots still drop fast) go in chunks of 128.
+        for (u32 n0 = 0; n0 < N;) {
+            const u32 step = n0 < G_THREADS ? 128u : (u32)G_THREADS;
             const u32 n = n0 + tid;
             bool cand = false;
             u32 leaf = 0, sv = 0, fl = 0, tot = 0;
-            if (n < N && ((a.valid[n >> 6] >> (n & 63)) & 1ull) && a.ff[n] == FF_PASS) {
+            if (tid < step && n < N && ((a.valid[n >> 6] >> (n & 63)) & 1ull) && a.ff[n] == FF_PASS) {
                 leaf = leaf_of[n];
                 sv = a.svc_dense[n];
                 fl = a.fail_dense[n];
@@ -2900,13 +2938,23 @@ __global__ __launch_bounds__(G_THREADS) void k_groups(GroupArgs a) {
             __syncthreads();
             if (tid == 0) {
                 const u32 ne = shv[S_NENT];
+                // the leaf of the last entry, its heap's base / length / root key ride in registers: a run of entries of one leaf
+                // (every group without spread preferences) pays one LDS round trip per entry that does not enter the heap
+                u32 c_lf = 0xFFFFFFFFu, base = 0;
+                int len = 0;
+                u64 root = 0;
                 for (u32 i = 0; i < ne; ++i) {
-                    const u32 lf = e_leaf[i], base = h_off[lf];
-                    const int len = h_len[lf];
+                    const u32 lf = e_leaf[i];
                     const u64 ek = g_key(e_fail[i], e_svc[i], e_total[i]);
+                    if (lf != c_lf) {
+                        c_lf = lf;
+                        base = h_off[lf];
+                        len = h_len[lf];
+                        root = len ? H.key[base] : 0ull;
+                    }
                     u32 sid;
                     if (len < (int)k) sid = base + (u32)len;          // heap.Push: a fresh state slot
-                    else if (ek < H.key[base]) sid = H.pay[base];      // replaces the root: the evicted node's state slot is reused
+                    else if (ek < root) sid = H.pay[base];             // replaces the root: the evicted node's state slot is reused
                     else continue;
                     shv[S_LASTPASS] = e_node[i] + 1;   // the last Process that returned true inside tree()
                     H.node[sid] = e_node[i]; H.total[sid] = e_total[i]; H.svc[sid] = e_svc[i]; H.fail[sid] = e_fail[i];
@@ -2915,13 +2963,16 @@ __global__ __launch_bounds__(G_THREADS) void k_groups(GroupArgs a) {
                         H.key[sid] = ek; H.pay[sid] = sid;
                         h_len[lf] = len + 1; h_cnt[lf] = len + 1; h_adm[lf] = len + 1;
                         g_up(H, base, len);
+                        ++len;
                     } else {
                         H.key[base] = ek;
                         if (!g_down(H, base, 0, len)) g_up(H, base, 0);   // heap.Fix(0)
                     }
+                    root = H.key[base];
                 }
             }
             __syncthreads();
+            n0 += step;
         }
 
         G_TICK(2);

@@ -9,7 +9,7 @@
 //   sc, X, portmap   static class rows, per-service exception bitmaps, host ports: the rows every resolver uses
 //
 // One ROUND decides a block of up to `block` tasks, two launches:
-//   k_r6_propose   one wavefront per task, lanes over the node WORDS: m = sc & ~X & RC & RM & ~ports (the task's plain
+//   k_r6_propose   one workgroup of four wavefronts per task, lanes over the node WORDS: m = sc & ~X & RC & RM & ~ports (the task's plain
 //                  candidates, 64 nodes per operation), then a descent over the level planes from the top
 //                  (m & ~plane ≠ ∅ ? keep that : the bit is set in the minimum) leaves exactly the candidates of the
 //                  minimum level; the first R6_CAND non-empty words of it go into the task's proposal, with the best node
@@ -90,8 +90,9 @@ struct R6Args {
 };
 
 #define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together
-inline __host__ __device__ u32 r6_chunks(u32 n_words) { return (((n_words + 63u) >> 6) + R6_UNROLL - 1u) & ~(u32)(R6_UNROLL - 1); }
-inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8; }
+#define R6_PW 4                  // waves per task in the propose kernel
+inline __host__ __device__ u32 r6_chunks(u32 n_words) { return (((n_words + 63u) >> 6) + R6_UNROLL * R6_PW - 1u) / (R6_UNROLL * R6_PW) * (R6_UNROLL * R6_PW); }
+inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8 + 128; }
 inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * 3 * 4 + 64; }
 
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
@@ -150,18 +151,21 @@ WV_KERNEL(256) void k_r6_rows(R6Args a) {
     }
 }
 
-// ---- propose: one wave per task of the block ------------------------------------------------------------------------------
-WV_KERNEL(64) void k_r6_propose(R6Args a) {
-    const u32 lane = wv::lane();
+// ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
+// The waves split the task's node words (wave v owns the chunks of 64 words k = v, v + R6_PW, ...): the passes are latency-bound,
+// so more waves per task is what shortens them. A pass ends with one barrier (has any wave a candidate left?).
+WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
+    const u32 lane = wv::lane(), wave = wv::wave();
     const u32 t = wv::uload(&a.blk->pos) + wv::block();
     if (t >= wv::uload(&a.blk->end)) return;
     const RTask* rt = a.rt + t;
     const i64 rcpu = wv::uload(&rt->cpu), rmem = wv::uload(&rt->mem);
     const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc), scid = wv::uload(&rt->sc), pset = wv::uload(&rt->pset);
     const u64 maxrep = wv::uload(&rt->maxrep);
-    const u32 Wn = a.n_words, KC = r6_chunks(Wn);   // a multiple of R6_UNROLL; the chunks beyond the row hold no candidates
+    const u32 Wn = a.n_words, KC = r6_chunks(Wn);   // a multiple of R6_UNROLL * R6_PW; the chunks beyond the row hold no candidates
     u64* A = wv::lds();
     u64* Bf = A + (size_t)KC * 64;
+    u32* flag = reinterpret_cast<u32*>(Bf + (size_t)KC * 64);   // [R6_NP + 2] "some wave still has a candidate", one word per pass
     const u64* scrow = a.sc + (size_t)scid * Wn;
     const u64* xrow = a.X + (size_t)svc * a.xs;
     const bool res = (flags & RT_RES) != 0;
@@ -172,51 +176,58 @@ WV_KERNEL(64) void k_r6_propose(R6Args a) {
         p0 = wv::uload(a.pset_off + pset);
         p1 = wv::uload(a.pset_off + pset + 1);
     }
-    // the task's plain candidates, lane l owns words {l + 64 k}; R6_UNROLL chunks per step so that their loads are in flight together
+    if (wv::tid() < R6_NP + 2) flag[wv::tid()] = 0;
+    wv::barrier();
+    // the task's plain candidates, lane l of wave v owns words {l + 64 k}, k = v (mod R6_PW); R6_UNROLL chunks per step so that
+    // their loads are in flight together
     bool any = false;
-    for (u32 k0 = 0; k0 < KC; k0 += R6_UNROLL) {
+    for (u32 k0 = wave; k0 < KC; k0 += R6_UNROLL * R6_PW) {
         u64 m[R6_UNROLL], f[R6_UNROLL];
-WV_UNROLL
+        WV_UNROLL
         for (int u = 0; u < R6_UNROLL; ++u) {
-            const u32 w = (k0 + u) * 64 + lane;
+            const u32 w = (k0 + u * R6_PW) * 64 + lane;
             const bool in = w < Wn;
             m[u] = in ? scrow[w] : 0ull;
             f[u] = in ? xrow[w] : 0ull;
             if (res && in) f[u] |= ~(rc[w] & rm[w]);
         }
-WV_UNROLL
+        WV_UNROLL
         for (int u = 0; u < R6_UNROLL; ++u) {
-            const u32 w = (k0 + u) * 64 + lane;
+            const u32 w = (k0 + u * R6_PW) * 64 + lane;
             m[u] &= ~f[u];
             for (u32 p = p0; p < p1; ++p)
                 if (m[u]) m[u] &= ~a.portmap[(size_t)wv::uload(a.pset_ids + p) * Wn + w];
-            A[(k0 + u) * 64 + lane] = m[u];
+            A[(k0 + u * R6_PW) * 64 + lane] = m[u];
             any = any || m[u] != 0;
         }
     }
+    if (wv::ballot(any) && lane == 0) flag[0] = 1;   // many writers, one value
+    wv::barrier();
     // the minimum level among them: descent over the planes, the candidate set narrows to that level's nodes
     u32 level = R6_NONE;
-    if (wv::ballot(any)) {
+    if (flag[0]) {
         const u32 maxrel = wv::uload(&a.blk->maxrel);
-        u32 rel = 0;
-        for (int b = 31 - wv::clz32(maxrel); b >= 0; --b) {
+        u32 rel = 0, pass = 1;
+        for (int b = 31 - wv::clz32(maxrel); b >= 0; --b, ++pass) {
             const u64* pl = a.planes + (size_t)b * Wn;
             bool h = false;
-            for (u32 k0 = 0; k0 < KC; k0 += R6_UNROLL) {
+            for (u32 k0 = wave; k0 < KC; k0 += R6_UNROLL * R6_PW) {
                 u64 m[R6_UNROLL], q[R6_UNROLL];
-WV_UNROLL
+                WV_UNROLL
                 for (int u = 0; u < R6_UNROLL; ++u) {
-                    m[u] = A[(k0 + u) * 64 + lane];
-                    q[u] = m[u] ? pl[(k0 + u) * 64 + lane] : 0ull;   // m != 0 only inside the row
+                    m[u] = A[(k0 + u * R6_PW) * 64 + lane];
+                    q[u] = m[u] ? pl[(k0 + u * R6_PW) * 64 + lane] : 0ull;   // m != 0 only inside the row
                 }
-WV_UNROLL
+                WV_UNROLL
                 for (int u = 0; u < R6_UNROLL; ++u) {
                     const u64 c = m[u] & ~q[u];
-                    Bf[(k0 + u) * 64 + lane] = c;
+                    Bf[(k0 + u * R6_PW) * 64 + lane] = c;
                     h = h || c != 0;
                 }
             }
-            if (wv::ballot(h)) {
+            if (wv::ballot(h) && lane == 0) flag[pass] = 1;
+            wv::barrier();
+            if (flag[pass]) {
                 u64* x = A;
                 A = Bf;
                 Bf = x;
@@ -225,6 +236,7 @@ WV_UNROLL
         }
         level = wv::uload(&a.blk->base) + rel;
     }
+    if (wave != 0) return;   // (every wave is past the last barrier) wave 0 lists the candidates and writes the proposal
     R6Prop* out = a.prop + wv::block();
     // its first non-empty words, in node order
     u32 cnt = 0, more = 0;

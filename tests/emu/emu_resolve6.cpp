@@ -100,14 +100,14 @@ int main(int argc, char** argv) {
         while (blk.pos < blk.end) {
             const u32 before = blk.pos;
             for (R6Prop& q : prop) memset(&q, 0xEE, sizeof q);
-            grid(B, 64, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
+            grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
             grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
             ++rounds;
             if (blk.error) { fprintf(stderr, "kernel reported error %u at task %u\n", blk.error, blk.pos); return false; }
             if (blk.pos <= before) { fprintf(stderr, "no progress at task %u\n", before); return false; }
         }
         // one more round past the end must be a no-op
-        grid(B, 64, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
+        grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
         grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
         return blk.pos == j1;
     };

@@ -27,8 +27,16 @@ trace shards4 --steps 2 --warmup 1 --shards 4
 pmc shards4 --steps 1 --warmup 0 --shards 4
 trace cfg2 --steps 5 --warmup 1 --workload cfg2
 trace cfg4_200k_40k --steps 2 --warmup 1 --workload cfg4 --tasks 200000 --nodes 40000
+pmc cfg4_200k_40k --steps 1 --warmup 0 --workload cfg4 --tasks 200000 --nodes 40000
+trace cfg3_200k_100k --steps 2 --warmup 1 --tasks 200000 --nodes 100000
 trace grouped --steps 3 --warmup 1 --mode grouped
 trace enforce --steps 3 --warmup 1 --mode enforce
 cd "$ROOT" && timeout 300 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 timeout 300 python bench.py --shards 4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_shards4.json" 2> "$OUT/bench_shards4.err"
+timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload cfg4 --tasks 200000 --nodes 40000 > "$OUT/bench_cfg4_200k_40k.json" 2> "$OUT/bench_cfg4_200k_40k.err"
+timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --tasks 200000 --nodes 100000 > "$OUT/bench_cfg3_200k_100k.json" 2> "$OUT/bench_cfg3_200k_100k.err"
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload cfg4 > "$OUT/bench_cfg4_1M_100k.json" 2> "$OUT/bench_cfg4_1M_100k.err"
+timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode grouped > "$OUT/bench_grouped.json" 2> "$OUT/bench_grouped.err"
+timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --order major > "$OUT/bench_cfg3_major.json" 2> "$OUT/bench_cfg3_major.err"
 python "$ROOT/tools/summarize_prof.py" "$OUT" "$TAG"
+find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*.db" -delete
