@@ -482,8 +482,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows,
-                     "note": "algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the resolver decides from bitmaps held in LDS, so its real HBM "
-                             "traffic is far below that (see traffic): the kernel is bound by one workgroup's instruction issue, not by HBM"},
+                     "note": ("algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the block resolver reads bitmap ROWS from L2 (one bit per pair and "
+                              "filter) instead of a node row per pair, so the algorithmic figure can exceed the HBM peak (frac > 1 is that, not a "
+                              "measurement error); the rounds are bound by one wave's instruction issue in k_r6_commit" if kernel.startswith("k_resolve6") else
+                              "algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the resolver decides from bitmaps held in LDS, so its real HBM "
+                              "traffic is far below that (see traffic): the kernel is bound by one workgroup's instruction issue, not by HBM")},
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_scan": ms_scan / K, "k_resolve": ms_resolve / K,
                                 "k_explain": ms_explain / K, "device_total": ms_dev / K},
         "scan": ({"kernel": "k_scan", "ms_per_step": ms_scan / K, "algorithmic_GBs": alg_bytes_step / (ms_scan / K * 1e-3) / 1e9,
