@@ -33,6 +33,9 @@ CASES = [
     (17, 2000, 1500, 100, 1, 2, 2, ""),      # a block of one task
     (21, 4500, 2000, 200, 1024, 0, 1, ""),   # the largest block
     (40, 3280, 1020, 45, 8, 1, 1, "s"),
+    (77, 70000, 300, 30, 64, 0, 1, ""),      # beyond 65 536 nodes: every propose wave loops over more than one group of chunks
+    (78, 140000, 400, 50, 128, 2, 2, "s"),
+    (79, 66000, 1500, 200, 512, 0, 0, ""),
 ]
 
 
