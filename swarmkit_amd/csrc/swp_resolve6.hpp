@@ -157,7 +157,7 @@ WV_KERNEL(256) void k_r6_rows(R6Args a) {
 WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
     const u32 lane = wv::lane(), wave = wv::wave();
     const u32 t = wv::uload(&a.blk->pos) + wv::block();
-    if (t >= wv::uload(&a.blk->end)) return;
+    if (t >= wv::uload(&a.blk->end) || wv::uload(&a.blk->error) != ERR_NONE) return;   // (an error stops the rounds until the host has seen it)
     const RTask* rt = a.rt + t;
     const i64 rcpu = wv::uload(&rt->cpu), rmem = wv::uload(&rt->mem);
     const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc), scid = wv::uload(&rt->sc), pset = wv::uload(&rt->pset);
@@ -306,7 +306,7 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
 WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     const u32 tid = wv::tid(), lane = wv::lane();
     const u32 pos = a.blk->pos, end = a.blk->end;
-    if (pos >= end) return;
+    if (pos >= end || a.blk->error != ERR_NONE) return;   // a level beyond the planes: the proposals of this round were not written
     const u32 n = min(a.block, end - pos), Wn = a.n_words, n_rr = a.n_dc + a.n_dm;
     u64* tk = wv::lds();                                         // [Wn] nodes taken by this block so far
     i64* thr = reinterpret_cast<i64*>(tk + Wn);                  // [n_rr] the demand-class thresholds

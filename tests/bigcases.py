@@ -126,6 +126,12 @@ CASES = {
     "cfg4_mid": lambda s: run_cfg4(s, T=200_000, N=40_000),
     "cfg5_churn": lambda s: run_churn(s),
     "cfg5_churn_small": lambda s: run_churn(s, T0=5_000, N=500, rounds=12, services=50),
+    "cfg5_churn_mid": lambda s: run_churn(s, T0=20_000, N=2_000, rounds=100, services=200),   # all 100 rounds, a fifth of the cluster
+    # cfg3's reservations fill the cluster at 100k x 10k (9.6 % of the first tick is unplaceable already), so draining 10 % of the nodes
+    # leaves a backlog that every later tick re-evaluates and after ~10 rounds nothing moves any more: the oracle needs many hours
+    # for that, and the rounds test little. The same script at 60 % load keeps re-placing ~10 % of the tasks in every round:
+    "cfg5_churn_60k": lambda s: run_churn(s, T0=60_000, N=10_000, rounds=100, services=600),
+    "cfg5_churn_12k": lambda s: run_churn(s, T0=12_000, N=2_000, rounds=100, services=120),
     "refbench_1k_100k": lambda s: run_refbench(s, 1_000, 100_000, False),
     "refbench_net_5k_100k": lambda s: run_refbench(s, 5_000, 100_000, True),
     "refbench_100k_100k": lambda s: run_refbench(s, 100_000, 100_000, False),

@@ -4,7 +4,7 @@ SHA-256 decision digest and assignment count:
 
   cfg4 (BASELINE.json configs[3], every filter incl. HostPort / MaxReplicas / Plugin) at 200k x 40k and at its full
   1M x 100k size, cfg5 churn (configs[4]: drain 10 % of the nodes, delete their tasks, re-place, round after round) at
-  its full 100 rounds x 100k x 10k and in miniature, and the reference's own benchmark shape (benchScheduler,
+  its full 100 rounds x 100k x 10k, at 100 rounds x 20k x 2k and in miniature, and the reference's own benchmark shape (benchScheduler,
   manager/scheduler/scheduler_test.go:3375-3465: ONE service for 100k tasks, every third node with the Network plugin).
 
 A case whose digest file has not been generated yet (hours of oracle time) is skipped, not passed."""
@@ -21,7 +21,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # (case, rough engine-side seconds): the default GPU suite runs everything that finishes in a few minutes; the two
 # BASELINE-size scripts are included because they are exactly what the judge asked to see at the stated size
-CASES = ["refbench_small", "cfg5_churn_small", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid", "cfg5_churn", "cfg4_full"]
+CASES = ["refbench_small", "cfg5_churn_small", "cfg5_churn_12k", "cfg5_churn_mid", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid", "cfg5_churn", "cfg4_full"]
 
 
 @pytest.mark.parametrize("case", CASES)
