@@ -1003,7 +1003,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
         HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, st));
         hipError_t r = launch_r6_build(ra, st);
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(r));
-        uint32_t pos = start, chunk = 16;
+        uint32_t pos = start, chunk = std::min<uint32_t>(16u, (end - start + 255u) / 256u + 1u);   // a short stretch does not pay for empty rounds
         while (pos < end) {
             r = launch_r6_rounds(ra, chunk, st, e->device);
             if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
