@@ -57,7 +57,32 @@ static uint32_t fold_rune(uint32_t r) {
 }
 
 // strings.EqualFold (call sites constraint.go:90,110-188; nodeset.go:69,73)
+// Two pure-ASCII strings are fold-equal iff they are equal ignoring ASCII case: the simple-folding orbits that tie an ASCII letter to
+// a non-ASCII rune (K / U+212A, s / U+017F) need a non-ASCII byte on one side. Same verdicts as the rune walk below, which stays the
+// path for everything else; NodeMatches compares every constraint key with six literals per node, so this is the oracle's hot spot.
+static inline bool all_ascii(const char* p, size_t n) {
+    unsigned char acc = 0;
+    for (size_t i = 0; i < n; ++i) acc |= (unsigned char)p[i];
+    return acc < 0x80;
+}
+static inline bool ascii_equal_fold(const char* a, const char* b, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        unsigned char x = (unsigned char)a[i], y = (unsigned char)b[i];
+        if (x == y) continue;
+        if (x >= 'a' && x <= 'z') x -= 32;
+        if (y >= 'a' && y <= 'z') y -= 32;
+        if (x != y) return false;
+    }
+    return true;
+}
+static inline bool equal_fold(const std::string& a, const char* lit) {   // comparisons with the key literals: no temporary string
+    const size_t n = std::strlen(lit);
+    if (all_ascii(a.data(), a.size()) && all_ascii(lit, n)) return a.size() == n && ascii_equal_fold(a.data(), lit, n);
+    return equal_fold(a, std::string(lit));
+}
 bool equal_fold(const std::string& a, const std::string& b) {
+    if (all_ascii(a.data(), a.size()) && all_ascii(b.data(), b.size()))
+        return a.size() == b.size() && ascii_equal_fold(a.data(), b.data(), a.size());
     size_t i = 0, j = 0;
     while (i < a.size() && j < b.size()) {
         size_t wa, wb;
@@ -318,7 +343,9 @@ static const char kEngineLabelPrefix[] = "engine.labels.";  // constraint.go:17
 static bool has_prefix_fold(const std::string& s, const char* prefix) {
     size_t n = std::strlen(prefix);
     // len(s) > len(prefix) && EqualFold(s[:len(prefix)], prefix)   (byte slice, as in Go)
-    return s.size() > n && equal_fold(s.substr(0, n), prefix);
+    if (s.size() <= n) return false;
+    if (all_ascii(s.data(), n) && all_ascii(prefix, n)) return ascii_equal_fold(s.data(), prefix, n);
+    return equal_fold(s.substr(0, n), prefix);
 }
 
 // NodeMatches, constraint.go:107-207
@@ -546,10 +573,39 @@ void generic_reclaim(GenericList* node_avail, const GenericList& task_assigned, 
 static const int64_t kMonitorFailures = 5LL * 60 * 1'000'000'000LL;   // scheduler.go:19
 static const int64_t kMaxFailures = 5;                                 // scheduler.go:23
 
+// the process-wide service-id table behind SvcCounts (ids are never forgotten: a handful of bytes per service ever seen)
+namespace {
+struct ServiceTable {
+    std::unordered_map<std::string, uint32_t> key;
+    std::vector<std::string> name;
+};
+ServiceTable& service_table() {
+    static ServiceTable t;
+    return t;
+}
+}  // namespace
+uint32_t service_key(const std::string& service_id) {
+    ServiceTable& t = service_table();
+    auto it = t.key.find(service_id);
+    if (it != t.key.end()) return it->second;
+    const uint32_t k = uint32_t(t.name.size());
+    t.name.push_back(service_id);
+    t.key.emplace(service_id, k);
+    return k;
+}
+const std::string& service_of_key(uint32_t key) { return service_table().name[key]; }
+static uint32_t task_service_key(const Task& t) {
+    if (t.service_key_cache == 0xFFFFFFFFu) t.service_key_cache = service_key(t.service_id);
+    return t.service_key_cache;
+}
+
 int64_t NodeInfo::svc_count(const std::string& s) const {
     if (!by_service) return 0;   // nil map read
-    auto it = by_service->find(s);
-    return it == by_service->end() ? 0 : it->second;
+    return by_service->get(service_key(s));
+}
+int64_t NodeInfo::svc_count_key(uint32_t key) const {
+    if (!by_service) return 0;
+    return by_service->get(key);
 }
 
 // taskReservations, nodeinfo.go:156-161
@@ -562,7 +618,7 @@ NodeInfo new_node_info(const NodePtr& n, const std::vector<TaskPtr>& tasks, cons
     NodeInfo ni;
     ni.node = n;
     ni.tasks = std::make_shared<std::map<std::string, TaskPtr>>();
-    ni.by_service = std::make_shared<std::unordered_map<std::string, int64_t>>();
+    ni.by_service = std::make_shared<SvcCounts>();
     ni.available = std::make_shared<Resources>(avail);
     ni.used_ports = std::make_shared<std::map<HostPortSpec, int>>();
     ni.recent_failures = std::make_shared<std::map<VersionedService, std::vector<int64_t>>>();
@@ -579,7 +635,7 @@ bool NodeInfo::remove_task(const Task& t) {
     tasks->erase(it);
     if (old_task->desired_state <= TaskStateCompleted) {
         active_tasks_count--;
-        (*by_service)[t.service_id]--;
+        by_service->ref(task_service_key(t))--;
     }
     if (t.has_endpoint) {
         for (const PortConfig& p : t.ports)
@@ -603,12 +659,12 @@ bool NodeInfo::add_task(const TaskPtr& t) {
         if (t->desired_state <= TaskStateCompleted && old_task->desired_state > TaskStateCompleted) {
             it->second = t;
             active_tasks_count++;
-            (*by_service)[t->service_id]++;
+            by_service->ref(task_service_key(*t))++;
             return true;
         } else if (t->desired_state > TaskStateCompleted && old_task->desired_state <= TaskStateCompleted) {
             it->second = t;
             active_tasks_count--;
-            (*by_service)[t->service_id]--;
+            by_service->ref(task_service_key(*t))--;
             return true;
         }
         return false;
@@ -626,7 +682,7 @@ bool NodeInfo::add_task(const TaskPtr& t) {
     }
     if (t->desired_state <= TaskStateCompleted) {
         active_tasks_count++;
-        (*by_service)[t->service_id]++;
+        by_service->ref(task_service_key(*t))++;
     }
     return true;
 }
@@ -789,7 +845,7 @@ bool Pipeline::check(int f, const NodeInfo& n) const {
                 if (n.used_ports && n.used_ports->count(HostPortSpec{p.protocol, p.published_port})) return false;
         return true;
     case F_MAXREPLICAS:   // filter.go:373-375
-        return uint64_t(n.svc_count(t->service_id)) < t->max_replicas;
+        return uint64_t(n.svc_count_key(task_service_key(*t))) < t->max_replicas;
     }
     return true;
 }
@@ -967,6 +1023,7 @@ DecisionTree Scheduler::tree(const std::string& service_id, const std::vector<Pr
                              const std::function<bool(const NodeInfo&)>& meets, const NodeLess& less) {
     DecisionTree root;
     if (max_assignments == 0) return root;
+    const uint32_t svc_key = service_key(service_id);
     for (const Slot& slot : slots_) {
         if (!slot.present) continue;
         const NodeInfo& node = slot.info;   // Go copies the struct (plain memcpy); a reference is the cost-fair equivalent
@@ -988,11 +1045,11 @@ DecisionTree Scheduler::tree(const std::string& service_id, const std::vector<Pr
             } else {
                 continue;
             }
-            if (node.by_service) tree->tasks += node.svc_count(service_id);
+            if (node.by_service) tree->tasks += node.svc_count_key(svc_key);
             tree->has_next = true;
             tree = tree->child(value);
         }
-        if (node.by_service) tree->tasks += node.svc_count(service_id);
+        if (node.by_service) tree->tasks += node.svc_count_key(svc_key);
         if (!tree->heap.less_func) tree->heap.less_func = less;
         if (tree->heap.length < max_assignments) {
             if (meets(node)) heap_push(tree->heap, node);
@@ -1256,7 +1313,8 @@ void Scheduler::schedule_task_group(OrderedTasks& group, std::vector<Decision>& 
     int64_t now_captured = now;
     const Task* tp = t.get();
     const VersionedService vs_key{tp->service_id, tp->has_spec_version ? tp->spec_version : 0};
-    NodeLess node_less = [this, now_captured, tp, vs_key](const NodeInfo& a, const NodeInfo& b) {
+    const uint32_t svc_key = task_service_key(*tp);
+    NodeLess node_less = [this, now_captured, svc_key, vs_key](const NodeInfo& a, const NodeInfo& b) {
         ++nodeless_calls;
         int64_t fa = a.count_recent_failures_key(now_captured, vs_key);
         int64_t fb = b.count_recent_failures_key(now_captured, vs_key);
@@ -1264,7 +1322,7 @@ void Scheduler::schedule_task_group(OrderedTasks& group, std::vector<Decision>& 
             if (fa > fb) return false;
             if (fb > fa) return true;
         }
-        int64_t sa = a.svc_count(tp->service_id), sb = b.svc_count(tp->service_id);
+        int64_t sa = a.svc_count_key(svc_key), sb = b.svc_count_key(svc_key);
         if (sa < sb) return true;
         if (sa > sb) return false;
         return a.active_tasks_count < b.active_tasks_count;

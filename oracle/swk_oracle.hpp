@@ -113,6 +113,7 @@ struct Preference { bool is_spread = false; std::string descriptor; };
 
 struct Task {              // the api.Task field subset the path reads
     std::string id, service_id, node_id;
+    mutable uint32_t service_key_cache = 0xFFFFFFFFu;   // service_key(service_id), filled on first use (task_service_key)
     bool has_spec_version = false;
     uint64_t spec_version = 0;
     int desired_state = TaskStateNew;
@@ -180,18 +181,40 @@ struct VersionedService {
 // ActiveTasksCountByService, AvailableResources, usedHostPorts, recentFailures but
 // NOT ActiveTasksCount / lastCleanup / the *api.Node pointer slot. The shared_ptr
 // members reproduce exactly that aliasing.
+// ActiveTasksCountByService (nodeinfo.go:20): Go's map[string]int. The service ids are interned once (process-wide table,
+// service_key) and the per-node map is a flat list keyed by the small integer — the same contents and the same zero value for
+// a missing key as the Go map, without hashing a string three times per node and task in nodeLess / tree (which was most of
+// the oracle's time per pair). Entries are never removed, like Go's `m[k]--`.
+uint32_t service_key(const std::string& service_id);
+const std::string& service_of_key(uint32_t key);
+struct SvcCounts {
+    std::vector<std::pair<uint32_t, int64_t>> v;
+    int64_t get(uint32_t key) const {
+        for (const auto& kv : v)
+            if (kv.first == key) return kv.second;
+        return 0;
+    }
+    int64_t& ref(uint32_t key) {
+        for (auto& kv : v)
+            if (kv.first == key) return kv.second;
+        v.emplace_back(key, 0);
+        return v.back().second;
+    }
+};
+
 struct NodeInfo {
     NodePtr node;
     std::shared_ptr<std::map<std::string, TaskPtr>> tasks;
     int64_t active_tasks_count = 0;
-    std::shared_ptr<std::unordered_map<std::string, int64_t>> by_service;   // Go map: hashed
+    std::shared_ptr<SvcCounts> by_service;
     std::shared_ptr<Resources> available;
     std::shared_ptr<std::map<HostPortSpec, int>> used_ports;
     std::shared_ptr<std::map<VersionedService, std::vector<int64_t>>> recent_failures;
     int64_t last_cleanup = 0;
 
     bool valid() const { return bool(node); }
-    int64_t svc_count(const std::string& s) const;
+    int64_t svc_count(const std::string& s) const;   // by service id
+    int64_t svc_count_key(uint32_t key) const;        // by interned id (hot paths intern once per task)
     bool add_task(const TaskPtr& t);
     bool remove_task(const Task& t);
     void task_failed(int64_t now, const Task& t);

@@ -250,10 +250,10 @@ std::string encode_node_info(const NodeInfo& ni) {
     o += "\"ActiveTasksCountByService\":{";
     bool first = true;
     if (ni.by_service)
-        for (auto& kv : *ni.by_service) {
+        for (auto& kv : ni.by_service->v) {
             if (!first) o += ",";
             first = false;
-            orcjson::escape_into(o, kv.first);
+            orcjson::escape_into(o, service_of_key(kv.first));
             o += ":" + std::to_string(kv.second);
         }
     o += "},\"AvailableResources\":{";
@@ -468,7 +468,7 @@ int orc_pipeline_process(const char* doc_json) {
         else if (n->has_description && n->has_resources) avail = n->resources;
         NodeInfo ni = new_node_info(n, {}, avail, 0);
         if (const Value* bs = d->obj_or_null("ByService"))
-            for (auto& kv : bs->obj) (*ni.by_service)[kv.first] = kv.second->i;
+            for (auto& kv : bs->obj) ni.by_service->ref(service_key(kv.first)) = kv.second->i;
         if (const Value* up = d->obj_or_null("UsedPorts"))
             for (auto& p : up->arr) (*ni.used_ports)[HostPortSpec{int(p->arr[0]->i), uint32_t(p->arr[1]->u)}] = 1;
         Pipeline p;
@@ -517,7 +517,7 @@ int orc_tree(const char* doc_json) {
         for (auto& e : d->get("Nodes")->arr) {
             NodeInfo ni = new_node_info(decode_node(*e->get("Node")), {}, Resources(), 0);
             if (const Value* bs = e->obj_or_null("ByService"))
-                for (auto& kv : bs->obj) (*ni.by_service)[kv.first] = kv.second->i;
+                for (auto& kv : bs->obj) ni.by_service->ref(service_key(kv.first)) = kv.second->i;
             ni.active_tasks_count = e->int_or("ActiveTasksCount", 0);
             s.add_or_update_node_info(ni);
         }
