@@ -319,7 +319,11 @@ bool constraint_parse(const std::vector<std::string>& env, std::vector<Constrain
                 if (err) *err = "value '" + part1 + "' is invalid";
                 return false;
             }
-            out->push_back(Constraint{part0, i, part1});
+            Constraint c;
+            c.key = part0;
+            c.op = i;
+            c.exp = part1;
+            out->push_back(std::move(c));
             found = true;
             break;
         }
@@ -348,18 +352,43 @@ static bool has_prefix_fold(const std::string& s, const char* prefix) {
     return equal_fold(s.substr(0, n), prefix);
 }
 
-// NodeMatches, constraint.go:107-207
+// NodeMatches, constraint.go:107-207. The switch over the key (`case strings.EqualFold(constraint.key, "node.id")`, … in this
+// order, then the two label prefixes) depends on the key alone: constraint_kind() evaluates it once per constraint.
+enum { CK_ID = 0, CK_HOSTNAME, CK_IP, CK_ROLE, CK_OS, CK_ARCH, CK_NODE_LABEL, CK_ENGINE_LABEL, CK_OTHER };
+static int constraint_kind(const Constraint& c) {
+    if (c.kind >= 0) return c.kind;
+    int k = CK_OTHER;
+    if (equal_fold(c.key, "node.id")) k = CK_ID;
+    else if (equal_fold(c.key, "node.hostname")) k = CK_HOSTNAME;
+    else if (equal_fold(c.key, "node.ip")) k = CK_IP;
+    else if (equal_fold(c.key, "node.role")) k = CK_ROLE;
+    else if (equal_fold(c.key, "node.platform.os")) k = CK_OS;
+    else if (equal_fold(c.key, "node.platform.arch")) k = CK_ARCH;
+    else if (has_prefix_fold(c.key, kNodeLabelPrefix)) {
+        k = CK_NODE_LABEL;
+        c.label = c.key.substr(sizeof(kNodeLabelPrefix) - 1);   // label name is case sensitive
+    } else if (has_prefix_fold(c.key, kEngineLabelPrefix)) {
+        k = CK_ENGINE_LABEL;
+        c.label = c.key.substr(sizeof(kEngineLabelPrefix) - 1);
+    }
+    c.kind = k;
+    return k;
+}
 bool node_matches(const std::vector<Constraint>& cs, const Node& n) {
+    static const std::string kEmpty;
     for (const Constraint& c : cs) {
-        if (equal_fold(c.key, "node.id")) {
+        switch (constraint_kind(c)) {
+        case CK_ID:
             if (!constraint_match(c, n.id)) return false;
-        } else if (equal_fold(c.key, "node.hostname")) {
+            break;
+        case CK_HOSTNAME:
             if (!n.has_description) {
-                if (!constraint_match(c, "")) return false;
+                if (!constraint_match(c, kEmpty)) return false;
                 continue;
             }
             if (!constraint_match(c, n.hostname)) return false;
-        } else if (equal_fold(c.key, "node.ip")) {
+            break;
+        case CK_IP: {
             IPAddr node_ip = parse_ip(n.addr);
             IPAddr ip = parse_ip(c.exp);
             if (ip.ok) {
@@ -374,38 +403,44 @@ bool node_matches(const std::vector<Constraint>& cs, const Node& n) {
                 continue;
             }
             return false;   // malformed address/network: both operators fail
-        } else if (equal_fold(c.key, "node.role")) {
+        }
+        case CK_ROLE:
             if (!constraint_match(c, n.role == NodeRoleManager ? "MANAGER" : (n.role == NodeRoleWorker ? "WORKER" : std::to_string(n.role))))
                 return false;
-        } else if (equal_fold(c.key, "node.platform.os")) {
+            break;
+        case CK_OS:
             if (!n.has_description || !n.has_platform) {
-                if (!constraint_match(c, "")) return false;
+                if (!constraint_match(c, kEmpty)) return false;
                 continue;
             }
             if (!constraint_match(c, n.platform.os)) return false;
-        } else if (equal_fold(c.key, "node.platform.arch")) {
+            break;
+        case CK_ARCH:
             if (!n.has_description || !n.has_platform) {
-                if (!constraint_match(c, "")) return false;
+                if (!constraint_match(c, kEmpty)) return false;
                 continue;
             }
             if (!constraint_match(c, n.platform.arch)) return false;
-        } else if (has_prefix_fold(c.key, kNodeLabelPrefix)) {
+            break;
+        case CK_NODE_LABEL: {
             if (n.labels_nil) {
-                if (!constraint_match(c, "")) return false;
+                if (!constraint_match(c, kEmpty)) return false;
                 continue;
             }
-            std::string label = c.key.substr(sizeof(kNodeLabelPrefix) - 1);   // label name is case sensitive
-            auto it = n.labels.find(label);
-            if (!constraint_match(c, it == n.labels.end() ? std::string() : it->second)) return false;
-        } else if (has_prefix_fold(c.key, kEngineLabelPrefix)) {
+            auto it = n.labels.find(c.label);
+            if (!constraint_match(c, it == n.labels.end() ? kEmpty : it->second)) return false;
+            break;
+        }
+        case CK_ENGINE_LABEL: {
             if (!n.has_description || !n.has_engine || n.engine_labels_nil) {
-                if (!constraint_match(c, "")) return false;
+                if (!constraint_match(c, kEmpty)) return false;
                 continue;
             }
-            std::string label = c.key.substr(sizeof(kEngineLabelPrefix) - 1);
-            auto it = n.engine_labels.find(label);
-            if (!constraint_match(c, it == n.engine_labels.end() ? std::string() : it->second)) return false;
-        } else {
+            auto it = n.engine_labels.find(c.label);
+            if (!constraint_match(c, it == n.engine_labels.end() ? kEmpty : it->second)) return false;
+            break;
+        }
+        default:
             return false;   // key doesn't match predefined syntax
         }
     }

@@ -151,7 +151,13 @@ std::vector<std::string> enforce_node(const Node& node, const std::vector<TaskPt
 bool generic_has_resource(const GenericResource& res, const GenericList& resources);   // validate.go:54-85
 
 // ---- manager/constraint/constraint.go -------------------------------------
-struct Constraint { std::string key; int op = 0; std::string exp; };   // op: 0 ==, 1 !=
+struct Constraint {
+    std::string key; int op = 0; std::string exp;   // op: 0 ==, 1 !=
+    // which case of NodeMatches' switch (constraint.go:109-200) the key selects, and the label name behind a label prefix: pure
+    // functions of `key`, worked out at the first node instead of at every node (-1: not yet)
+    mutable int kind = -1;
+    mutable std::string label;
+};
 bool constraint_parse(const std::vector<std::string>& env, std::vector<Constraint>* out, std::string* err);
 bool constraint_match(const Constraint& c, const std::string& what);
 bool node_matches(const std::vector<Constraint>& cs, const Node& n);
