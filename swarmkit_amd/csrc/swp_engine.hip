@@ -846,7 +846,16 @@ int batch_begin(swp_engine* e, swp_batch* b) {
     return run_classes(e, b);
 }
 
+int batch_run_impl(swp_engine* e, swp_batch* b);
+// Every failure exit of the device pass leaves the device node rows (cpu / mem / total) possibly half-updated — the resolvers commit
+// while they run — so the untouched host mirror is uploaded again before the next device call (as swp_schedule_groups does).
 int batch_run(swp_engine* e, swp_batch* b) {
+    const int rc = batch_run_impl(e, b);
+    if (rc != SWP_OK) e->dev_dynamic_dirty = true;
+    return rc;
+}
+
+int batch_run_impl(swp_engine* e, swp_batch* b) {
     if (e->n_nodes != b->n_nodes_prepared)
         return e->fail(SWP_EINVAL, "the nodeSet grew from %u to %u node slots since swp_batch_prepare: prepare the batch again", b->n_nodes_prepared, e->n_nodes);
     const uint32_t N = e->n_nodes, Wn = n_words_of(N), T = b->T;
@@ -902,7 +911,8 @@ int batch_run(swp_engine* e, swp_batch* b) {
     // sets beyond k_resolve5's LDS; needs the demand classes and two candidate buffers of the propose kernel in LDS (≈ 650k nodes).
     // SWP_RESOLVER=6 forces it at any size; SWP_R6_BLOCK sets the tasks per round.
     const char* env_blk = getenv("SWP_R6_BLOCK");
-    const uint32_t r6_block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    uint32_t r6_block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    while (r6_block > 64 && r6_commit_lds_size(Wn, r6_block, b->n_dc + b->n_dm) > lds_budget) r6_block /= 2;   // the block's proposals are staged in LDS
     const bool r6_ok = b->classes_ok && r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, b->n_dc + b->n_dm) <= lds_budget;
     if (variant == 6 && !r6_ok) variant = 3;
     if (variant == 3 && !env_res && r6_ok) variant = 6;   // default beyond k_resolve5's reach
@@ -944,6 +954,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
     }
     uint32_t wi = 0;   // windows launched so far (profiling slots)
     uint64_t r6_rounds = 0;
+    bool stopped = false;   // the block resolver ran out of level planes: the rest of the batch goes through the fall-back below
     // k_resolve6 over the stretch [start, end): build the bitmaps from the node rows as they are, then rounds of propose + commit.
     // The device advances on its own (the position lives in the control block); the host only learns every so many rounds how far it is.
     auto run_blocks = [&](uint32_t start, uint32_t end) -> int {
@@ -1009,7 +1020,20 @@ int batch_run(swp_engine* e, swp_batch* b) {
             if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
             HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
             HIPCHECK(e, hipStreamSynchronize(st));
-            if (hb.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP);
+            if (hb.error != ERR_NONE) {
+                // A node's task count moved 65 535 levels above the lowest one: the round that noticed committed its picks and the later
+                // rounds returned at once. Hand the rest of the batch to the fall-back at the end of batch_run, exactly as the wave
+                // resolvers do (Ctl.error / Ctl.resume), instead of failing the whole batch.
+                Ctl part{};
+                part.error = ERR_LEVEL_RANGE;
+                part.resume = hb.pos;
+                HIPCHECK(e, hipMemcpyAsync((char*)b->d_ctl.p + offsetof(Ctl, error), &part.error, 4, hipMemcpyHostToDevice, st));
+                HIPCHECK(e, hipMemcpyAsync((char*)b->d_ctl.p + offsetof(Ctl, resume), &part.resume, 4, hipMemcpyHostToDevice, st));
+                HIPCHECK(e, hipStreamSynchronize(st));
+                stopped = true;
+                r6_rounds += hb.rounds;
+                return SWP_OK;
+            }
             if (hb.pos <= pos) return e->fail(SWP_EHIP, "block resolver made no progress at task %u", pos);   // a round decides its first task at least
             // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
             const double pace = std::max(1.0, (double)(hb.pos - start) / (double)std::max<uint32_t>(hb.rounds, 1));
@@ -1024,12 +1048,13 @@ int batch_run(swp_engine* e, swp_batch* b) {
                     hb.rounds, r6_block, (double)(end - start) / std::max<uint32_t>(hb.rounds, 1), hb.cut_exhausted, hb.cut_exception, hb.cut_uncounted);
         if (dbg_bits & 16) {
             const double rr_ = std::max<uint32_t>(hb.rounds, 1);
-            fprintf(stderr, "[swp] k_r6_commit shader cycles per round: prologue %.0f, matching (wave 0) %.0f, the others' wait for it %.0f, apply %.0f | %.1f matcher stops at an emptied half-word per round\n",
-                    hb.cyc[0] * 64.0 / rr_, hb.cyc[1] * 64.0 / rr_, hb.cyc[2] * 64.0 / rr_, hb.cyc[3] * 64.0 / rr_, hb.reseats / rr_);
+            fprintf(stderr, "[swp] k_r6_commit shader cycles per round: prologue %.0f, matching (wave 0) %.0f (list loads %.0f, walks %.0f), the others' wait for it %.0f, apply %.0f | %.1f matcher stops at an emptied half-word per round\n",
+                    hb.cyc[0] * 64.0 / rr_, hb.cyc[1] * 64.0 / rr_, hb.cyc_load * 64.0 / rr_, hb.cyc_walk * 64.0 / rr_, hb.cyc[2] * 64.0 / rr_, hb.cyc[3] * 64.0 / rr_, hb.reseats / rr_);
         }
         return SWP_OK;
     };
     auto run_windows = [&](uint32_t start, uint32_t end, int variant) -> int {
+    if (stopped && variant != 0) return SWP_OK;
     if (variant == 6) return run_blocks(start, end);
     const bool exact = r5_exact && variant == 5;
     const uint32_t win = exact ? T : b->window;
@@ -1148,6 +1173,7 @@ int batch_run(swp_engine* e, swp_batch* b) {
     else {
         HIPCHECK(e, b->d_wf.reserve((size_t)3 * N * 4));
         for (const swp_batch::Seg& sg : b->segs) {
+            if (stopped) break;
             if (!sg.run) {
                 if ((rc = run_windows(sg.j0, sg.j0 + sg.n, variant))) break;
                 continue;

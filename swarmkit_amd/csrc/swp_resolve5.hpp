@@ -802,10 +802,11 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                         eb[k] = li[R5_HDR_U32 + 4 * (k >> 1) + 2 + (k & 1)] & ~tkprev[ew[k]];
                     }
             }
-            // current half-word of every lane: the first one of its list that still has a candidate
-            u32 bits = 0, w = 0;
+            // current half-word of every lane: the first one of its list that still has a candidate — and the one after it, which a lane
+            // moves on to in a single step when its current half-word runs empty (cleaned of this round's picks only then)
+            u32 bits = 0, w = 0, bits2 = 0, w2 = 0;
             for (int k = 2 * R5_Q - 1; k >= 0; --k)
-                if (eb[k]) { bits = eb[k]; w = ew[k]; }
+                if (eb[k]) { bits2 = bits; w2 = w; bits = eb[k]; w = ew[k]; }
             const u64 fastmask = wv::ballot(fast), infmask = wv::ballot(m_cls == R5_INFEASIBLE);
             u64 tq = prof ? wv::clock64() : 0;
             if (prof) tm[0] += tq - tmark;
@@ -814,35 +815,44 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
             const u64 stop = ~(fastmask | infmask) & lanes;
             u32 cut = stop ? (u32)wv::ffs64(stop) : nb;
             u32 why = stop ? (u32)R5_CUT_GENERIC : (u32)R5_CUT_NOT;
-            u64 todo = fastmask & ((1ull << cut) - 1ull);
+            // the unrolled walk (wv::match_seq64) passes every lane in order: the tasks it serves are the fast ones in front of the cut, the
+            // no-ops among them carry a dummy, and the lane at the cut (cut <= R5_B < 64: there always is one) stops it with empty bits
+            const bool served = ((fastmask >> lane) & 1ull) && lane < cut;
+            if (!served) { bits = lane == cut ? 0u : 1u; bits2 = 0; w = WV_DUMMY_W | lane; }
+            u32 pickb = 0, from = 0;
             u32 flushed = 0;   // picks of lanes < flushed are in tkcur
             for (;;) {
                 const u64 ta_ = prof ? wv::clock64() : 0;
-                const u32 at = wv::match_run64(todo, bits, w, m_pick);
+                const u32 at = wv::match_seq64(bits, w, bits2, w2, pickb, lane, from);
                 if (prof) { tm[2] += wv::clock64() - ta_; ++nadv; }
-                if (at == 0xFFFFFFFFu) break;
-                // Task `at` ran out of its current half-word — and so, usually, did others that sat on it. Every such lane moves
-                // on in one go: this round's picks so far go to the TK row, each lane cleans all its half-words of them (the
-                // gathers are in flight together) and takes the first one that still has a candidate. Straight-line code, no
-                // loop: a lane's earlier half-words stay empty once they are (picks only accumulate), so recomputing from the
-                // registers is idempotent.
-                if (lane >= flushed && lane < at && m_pick != 0xFFFFFFFFu) wv::lds_or32(tkcur + (m_pick >> 5), 1u << (m_pick & 31));
+                if (at >= cut) break;
+                // Task `at` ran out of its current half-word — and so, usually, did others that sat on it. This round's picks so far go
+                // to the TK row (a pick = the lowest bit of the bits the lane had at its turn, in the half-word it still sits on), then
+                // every such lane steps to its next half-word, cleaned of them: one gather. Only when that one is empty too does the
+                // lane clean all its half-words (the gathers are in flight together) and take the first two that still have a candidate.
+                // Straight-line code: a lane's earlier half-words stay empty once they are (picks only accumulate), so recomputing from
+                // the registers is idempotent. Served lanes in front of `at` are never touched: their w is where their pick was made.
+                if (served && lane >= flushed && lane < at) wv::lds_or32(tkcur + w, pickb & (0u - pickb));
                 flushed = at;
                 wv::lockstep();   // one wave's LDS operations execute in order: the gathers below see the atomics above without a wait
-                if (fast && bits == 0) {
-                    u32 t[2 * R5_Q];
-                    for (int k = 0; k < 2 * R5_Q; ++k) t[k] = eb[k] & ~tkcur[ew[k]];
-                    for (int k = 2 * R5_Q - 1; k >= 0; --k)
-                        if (t[k]) { bits = t[k]; w = ew[k]; }
+                {
+                    if (served && lane >= at && bits == 0) {
+                        u32 t[2 * R5_Q];
+                        for (int k = 0; k < 2 * R5_Q; ++k) t[k] = eb[k] & ~tkcur[ew[k]];
+                        for (int k = 2 * R5_Q - 1; k >= 0; --k)
+                            if (t[k]) { bits2 = bits; w2 = w; bits = t[k]; w = ew[k]; }
+                    }
+                    if (wv::readlane(bits, at) == 0) {   // list exhausted: the next round starts here with a fresh list
+                        cut = at;
+                        why = R5_CUT_RELIST;
+                        break;
+                    }
                 }
-                if (wv::readlane(bits, at) == 0) {   // list exhausted: the next round starts here with a fresh list
-                    cut = at;
-                    why = R5_CUT_RELIST;
-                    break;
-                }
+                from = at;
             }
             if (prof) { const u64 n_ = wv::clock64(); tm[1] += n_ - tq; tq = n_; }
-            if (lane >= flushed && lane < cut && m_pick != 0xFFFFFFFFu) wv::lds_or32(tkcur + (m_pick >> 5), 1u << (m_pick & 31));
+            if (served && lane < cut) m_pick = (w << 5) + (u32)wv::ffs64((u64)pickb);
+            if (served && lane >= flushed && lane < cut) wv::lds_or32(tkcur + w, pickb & (0u - pickb));
             if (lane == 0) {
                 L.sh[R5S_CUT0 + rpar] = cut;
                 L.sh[R5S_WHY0 + rpar] = why;

@@ -27,13 +27,15 @@
 //
 // Written against swp_wave.hpp only, so tests/emu runs the same source on CPU fibers (tests/test_emu_resolve6.py).
 #pragma once
+#include <stddef.h>
+
 #include "swp_shard.hpp"
 #include "swp_types.hpp"
 
 namespace swpdev {
 
 #define R6_NP 16                 // level planes: 65 535 levels above the lowest valid node
-#define R6_CAND 8                // candidate words per proposal: a block is cut where a task finds all its listed nodes taken
+#define R6_CAND 8                // a proposal lists 2 * R6_CAND non-empty 32-node half-words: a block is cut where a task finds all its listed nodes taken
 #define R6_BMAX 1024             // largest block
 #define R6_COMMIT_THREADS 1024      // == R6_BMAX: one accepted pick per thread in the apply phase
 #define R6_NONE 0xFFFFFFFFu
@@ -43,18 +45,18 @@ struct Blk6 {   // control block, global memory
     u32 base, maxrel;      // lowest task count among the valid nodes at build time; highest level above it so far
     u32 error, rounds, cut_exhausted, cut_exception, cut_uncounted;
     u32 cyc[4];            // R6Args.dbg & 16: shader cycles / 64 of k_r6_commit's sections (prologue, matching, wait for it, apply)
-    u32 reseats, pad[2];   // ... and how often the matcher stopped at an emptied half-word
+    u32 reseats, cyc_load, cyc_walk;   // ... how often the matcher stopped at an emptied half-word; cycles / 64 of a group's list load and of its walk
 };
 static_assert(sizeof(Blk6) == 64, "Blk6 layout");
 
-struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidate words
-    u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); words listed | bit 31: there are more
-    u32 word[R6_CAND];
-    u64 bits[R6_CAND];
+struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidates, as 32-node half-words
+    u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); half-words listed | bit 31: there are more
+    u32 hw[2 * R6_CAND];     // half-word index (node = 32 * hw + bit), ascending: the first 2 * R6_CAND NON-EMPTY half-words of the level
+    u32 hb[2 * R6_CAND];     // the level's survivors inside each
     u64 exc_hi, exc_lo;      // best node of the service's exception list by nodeLess' key, KEY_NONE: none
     u32 exc_entry, flags;    // flags bit 0: the task does not count on its node
 };
-static_assert(sizeof(R6Prop) == 24 + 12 * R6_CAND + 8, "R6Prop layout");
+static_assert(sizeof(R6Prop) == 8 + 16 * R6_CAND + 24, "R6Prop layout");
 
 struct R6Args {
     u32 n_nodes, n_words, xs, block;
@@ -93,6 +95,7 @@ struct R6Args {
 #define R6_PW 4                  // waves per task in the propose kernel
 inline __host__ __device__ u32 r6_chunks(u32 n_words) { return (((n_words + 63u) >> 6) + R6_UNROLL * R6_PW - 1u) / (R6_UNROLL * R6_PW) * (R6_UNROLL * R6_PW); }
 inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8 + 128; }
+// TK row, thresholds, the picks of the block, a few scalars
 inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * 3 * 4 + 64; }
 
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
@@ -238,7 +241,7 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
     }
     if (wave != 0) return;   // (every wave is past the last barrier) wave 0 lists the candidates and writes the proposal
     R6Prop* out = a.prop + wv::block();
-    // its first non-empty words, in node order
+    // its first non-empty half-words, in node order (what the matcher walks: a word that is half empty does not cost a list entry)
     u32 cnt = 0, more = 0;
     if (level != R6_NONE)
         for (u32 k = 0; k < KC && !more; ++k) {
@@ -247,16 +250,21 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
             while (bal) {
                 const u32 l = (u32)wv::ffs64(bal);
                 bal &= bal - 1;
-                if (cnt == R6_CAND) {
-                    more = 1;
-                    break;
-                }
                 const u64 bits = wv::readlane64(m, l);
-                if (lane == 0) {
-                    out->word[cnt] = k * 64 + l;
-                    out->bits[cnt] = bits;
+                for (u32 h = 0; h < 2; ++h) {
+                    const u32 hb = (u32)(bits >> (32 * h));
+                    if (!hb) continue;
+                    if (cnt == 2 * R6_CAND) {
+                        more = 1;
+                        break;
+                    }
+                    if (lane == 0) {
+                        out->hw[cnt] = 2 * (k * 64 + l) + h;
+                        out->hb[cnt] = hb;
+                    }
+                    ++cnt;
                 }
-                ++cnt;
+                if (more) break;
             }
         }
     // no plain candidate: the service's exception list by the full key (scheduler.go:708-735), lanes stride over the entries
@@ -291,9 +299,9 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
     if (lane == 0) {
         out->level = level;
         out->n_cand = cnt | (more ? 0x80000000u : 0u);
-        for (u32 i = cnt; i < R6_CAND; ++i) {
-            out->word[i] = 0;
-            out->bits[i] = 0;
+        for (u32 i = cnt; i < 2 * R6_CAND; ++i) {
+            out->hw[i] = 0;
+            out->hb[i] = 0;
         }
         out->exc_hi = ghi;
         out->exc_lo = ghi == KEY_NONE ? KEY_NONE : glo;
@@ -313,18 +321,24 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     u32* pk_node = reinterpret_cast<u32*>(thr + n_rr);           // [block] node, R6_NONE = no suitable node
     u32* pk_idx = pk_node + a.block;                             // [block] commit index / index among the unplaceable tasks
     u32* pk_aux = pk_idx + a.block;                              // [block] exception-list entry (LIST_EMPTY: plain node) / commits before an unplaceable task
-    u32* sh = pk_aux + a.block;                                  // [0] accepted, [1] ncommit, [2] ninf
+    u32* sh = pk_aux + a.block;                                  // [0] accepted, [1] ncommit, [2] ninf, [3] tasks decided so far, [4] the matching is over
     for (u32 w = tid; w < Wn; w += R6_COMMIT_THREADS) tk[w] = 0;
     for (u32 c = tid; c < n_rr; c += R6_COMMIT_THREADS) thr[c] = a.thr[c];
-    // thread i applies the block's i-th task once wave 0 has decided it: its record is requested now, while the matching runs
+    // Wave v >= 1 applies the picks of the block's group v - 1 (tasks 64 (v - 1) ...) as soon as wave 0 has matched that group, while
+    // it matches the next ones; the task records are requested now. The groups no wave is left for (a block of more than 960 tasks)
+    // are applied by wave 0 behind its matching.
+    const u32 wave_ = wv::wave();
+    const u32 mine = wave_ == 0 ? 15u * 64u + lane : (wave_ - 1u) * 64u + lane;   // the block-local task this thread applies
     RTask r{};
-    if (tid < n) r = a.rt[pos + tid];
+    if (mine < n) r = a.rt[pos + mine];
+    if (tid == 0) { sh[3] = 0; sh[4] = 0; }
     const bool prof = (a.dbg & 16u) != 0;
     const u64 t0 = prof ? wv::clock64() : 0;
     wv::barrier();
     const u64 t1 = prof ? wv::clock64() : 0;
     u32 reseats = 0;
-    if (wv::wave() == 0) {
+    u64 cy_load = 0, cy_walk = 0;
+    if (wave_ == 0) {
         u32 nc = a.ctl->ncommit, ni = a.ctl->ninf, acc = 0, why = 0;
         u32* tk32 = reinterpret_cast<u32*>(tk);   // the same row as 32-node half-words
         bool stop = false;
@@ -335,20 +349,23 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             const R6Prop rec = nxt;
             const R6Prop* p = &rec;
             if (g0 + 64 < n) nxt = a.prop[i + 64 < n ? i + 64 : 0];
+            const u64 tg0 = prof ? wv::clock64() : 0;
             const u32 level = have ? p->level : 0u;
-            const u32 nent = (have && level != R6_NONE) ? 2 * (p->n_cand & 0x7FFFFFFFu) : 0u;
+            const u32 nent = (have && level != R6_NONE) ? (p->n_cand & 0x7FFFFFFFu) : 0u;
             const bool plain = nent != 0;
             const bool exc = have && level == R6_NONE && p->exc_hi != KEY_NONE;
             const bool inf = have && level == R6_NONE && !exc;
             // the list as 32-node half-words (registers), minus the picks of the earlier groups
             u32 eb[2 * R6_CAND], ew[2 * R6_CAND];
             for (int k = 0; k < 2 * R6_CAND; ++k) {
-                ew[k] = 2 * p->word[k >> 1] + (k & 1);
-                eb[k] = (u32)k < nent ? ((u32)(p->bits[k >> 1] >> (32 * (k & 1))) & ~tk32[ew[k]]) : 0u;
+                ew[k] = p->hw[k];
+                eb[k] = (u32)k < nent ? (p->hb[k] & ~tk32[ew[k]]) : 0u;
             }
-            u32 bits = 0, w = 0;   // current half-word of every lane: the first one of its list that still has a candidate
+            // current half-word of every lane: the first one of its list that still has a candidate — and the one after it, which a
+            // lane steps to when its current half-word runs empty (cleaned of this group's picks only then)
+            u32 bits = 0, w = 0, bits2 = 0, w2 = 0;
             for (int k = 2 * R6_CAND - 1; k >= 0; --k)
-                if (eb[k]) { bits = eb[k]; w = ew[k]; }
+                if (eb[k]) { bits2 = bits; w2 = w; bits = eb[k]; w = ew[k]; }
             const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
             const u64 m_plain = wv::ballot(plain), m_inf = wv::ballot(inf), m_exc = wv::ballot(exc), m_unc = wv::ballot(plain && (p->flags & 1u));
             // the group ends in front of a task that must use its exception list (its order moves with every placement of the service:
@@ -369,30 +386,41 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
                 why = 2;
                 break;
             }
-            u64 todo = m_plain & (cut == 64 ? ~0ull : (1ull << cut) - 1ull);
+            // the unrolled walk (wv::match_seq64) passes every lane in order: it serves the plain tasks in front of the cut, the others
+            // carry a dummy, and the lane at the cut (if the cut is inside the group) stops it with empty bits
+            const bool served = plain && lane < cut;
+            if (!served) { bits = lane == cut ? 0u : 1u; bits2 = 0; w = WV_DUMMY_W | lane; }
+            u32 pickb = 0, from = 0;
             u32 flushed = 0;   // picks of lanes < flushed are in the TK row
+            const u64 tg1 = prof ? wv::clock64() : 0;
             for (;;) {
-                const u32 at = wv::match_run64(todo, bits, w, m_pick);
-                if (at == 0xFFFFFFFFu) break;
+                const u32 at = wv::match_seq64(bits, w, bits2, w2, pickb, lane, from);
+                if (at >= cut) break;
                 ++reseats;
                 // task `at` ran out of its current half-word — and so, usually, did others that sat on it: this group's picks so far go to
-                // the TK row, every such lane cleans all its half-words of them and takes the first one that still has a candidate
-                if (lane >= flushed && lane < at && m_pick != R6_NONE) wv::lds_or32(tk32 + (m_pick >> 5), 1u << (m_pick & 31));
+                // the TK row (a pick = the lowest bit the lane had at its turn, in the half-word it still sits on), every such lane steps to
+                // its next half-word cleaned of them, and only a lane whose next one is empty too cleans all its half-words
+                if (served && lane >= flushed && lane < at) wv::lds_or32(tk32 + w, pickb & (0u - pickb));
                 flushed = at;
                 wv::lockstep();   // one wave's LDS operations execute in order: the reads below see the atomics above
-                if (plain && bits == 0) {
-                    u32 t[2 * R6_CAND];
-                    for (int k = 0; k < 2 * R6_CAND; ++k) t[k] = eb[k] & ~tk32[ew[k]];
-                    for (int k = 2 * R6_CAND - 1; k >= 0; --k)
-                        if (t[k]) { bits = t[k]; w = ew[k]; }
+                {
+                    if (served && lane >= at && bits == 0) {
+                        u32 t[2 * R6_CAND];
+                        for (int k = 0; k < 2 * R6_CAND; ++k) t[k] = eb[k] & ~tk32[ew[k]];
+                        for (int k = 2 * R6_CAND - 1; k >= 0; --k)
+                            if (t[k]) { bits2 = bits; w2 = w; bits = t[k]; w = ew[k]; }
+                    }
+                    if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
+                        cut = at;
+                        why = 1;
+                        break;
+                    }
                 }
-                if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
-                    cut = at;
-                    why = 1;
-                    break;
-                }
+                from = at;
             }
-            if (lane >= flushed && lane < cut && m_pick != R6_NONE) wv::lds_or32(tk32 + (m_pick >> 5), 1u << (m_pick & 31));   // for the later groups
+            if (prof) { const u64 tg2 = wv::clock64(); cy_load += tg1 - tg0; cy_walk += tg2 - tg1; }
+            if (served && lane < cut) m_pick = (w << 5) + (u32)wv::ffs64((u64)pickb);
+            if (served && lane >= flushed && lane < cut) wv::lds_or32(tk32 + w, pickb & (0u - pickb));   // for the later groups
             const u64 below = cut == 64 ? ~0ull : (1ull << cut) - 1ull;
             const u64 mc = m_plain & below & lanes, mi = m_inf & below & lanes;
             if (lane < cut && have) {
@@ -412,11 +440,14 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             if (cut < glim || (last && why == 3)) stop = true;
             else why = 0;
             wv::wave_sync();
+            if (lane == 0) wv::lds_publish32(sh + 3, acc);   // the picks of tasks < acc are in the pk arrays: their wave applies them now
         }
         if (lane == 0) {
             sh[0] = acc;
             sh[1] = nc;
             sh[2] = ni;
+            wv::lds_publish32(sh + 3, acc);   // (the first task from its exception list leaves the loop before the publish above)
+            wv::lds_publish32(sh + 4, 1u);
             a.blk->rounds += 1;
             if (why == 1) a.blk->cut_exhausted += 1;
             if (why == 2) a.blk->cut_exception += 1;
@@ -425,19 +456,27 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
                 a.blk->cyc[0] += (u32)((t1 - t0) >> 6);
                 a.blk->cyc[1] += (u32)((wv::clock64() - t1) >> 6);
                 a.blk->reseats += reseats;
+                a.blk->cyc_load += (u32)(cy_load >> 6);
+                a.blk->cyc_walk += (u32)(cy_walk >> 6);
             }
         }
     }
-    wv::barrier();
     const u64 t2 = prof ? wv::clock64() : 0;
-    const u32 acc = sh[0], base = a.blk->base;
-    if (tid < acc) {
-        const u32 t = pos + tid, nd = pk_node[tid];
+    const u32 base = a.blk->base;
+    // a wave waits (polling LDS, asleep in between) until its group is matched or the matching is over, and applies what was accepted of it
+    if (wave_ != 0) {
+        const u32 g0 = (wave_ - 1u) * 64u, need = min(g0 + 64u, n);
+        if (g0 < n)
+            while (wv::lds_poll32(sh + 3) < need && wv::lds_poll32(sh + 4) == 0) wv::spin_pause();
+    }
+    const u32 acc_now = wv::readfirstlane(wv::lds_poll32(sh + 3));
+    if (mine < acc_now) {
+        const u32 t = pos + mine, nd = pk_node[mine];
         if (nd == R6_NONE) {
-            a.inf_task[pk_idx[tid]] = t;
-            a.inf_pos[pk_idx[tid]] = pk_aux[tid];
+            a.inf_task[pk_idx[mine]] = t;
+            a.inf_pos[pk_idx[mine]] = pk_aux[mine];
         } else {
-            const u32 w = nd >> 6, ci = pk_idx[tid], entry = pk_aux[tid];
+            const u32 w = nd >> 6, ci = pk_idx[mine], entry = pk_aux[mine];
             const u64 bit = 1ull << (nd & 63);
             // the node row, requested in one go. No two picks of one block share a node: plain read-modify-write of the row; bitmap
             // words are shared between nodes: atomics
@@ -475,6 +514,8 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             a.out_node[t] = (int32_t)nd;
         }
     }
+    wv::barrier();
+    const u32 acc = sh[0];
     if (tid == 0) {
         a.blk->pos = pos + acc;
         a.ctl->ncommit = sh[1];

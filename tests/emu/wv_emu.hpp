@@ -106,6 +106,12 @@ inline Block*& B() {
     return b;
 }
 
+inline void yield_ready() {   // a polling loop: let the others run, come back later
+    Block* b = B();
+    b->switches++;
+    b->runq.push_back(b->cur);
+    emu_switch(&b->fib[b->cur].ctx, &b->sched);
+}
 inline void yield_blocked() {   // park the current fiber; somebody else re-queues it
     Block* b = B();
     b->switches++;
@@ -260,6 +266,9 @@ inline void wave_sync() { (void)emu::collective(emu::OP_SYNC, 0, 0); }
 inline void lockstep() { (void)emu::collective(emu::OP_SYNC, 1, 1); }
 inline void wait_vm() {}
 
+inline void lds_publish32(u32* p, u32 v) { *reinterpret_cast<volatile u32*>(p) = v; }
+inline u32 lds_poll32(const u32* p) { return *reinterpret_cast<const volatile u32*>(p); }
+inline void spin_pause() { emu::yield_ready(); }
 inline void lds_or64(u64* p, u64 v) { *p |= v; }
 inline void lds_xor64(u64* p, u64 v) { *p ^= v; }
 inline void lds_or32(u32* p, u32 v) { *p |= v; }
@@ -293,6 +302,27 @@ inline u32 match_run64(u64& todo, u32& bits, u32 w, u32& pick) {
         if (w == sw) bits &= ~(1u << p);
     }
     return 0xFFFFFFFFu;
+}
+
+// ... and of its unrolled successor: every lane in [from, 64) in order; a lane whose current half-word is empty steps to its next one
+// (together with every later lane in the same state); stop in front of the first lane that has no candidate in either
+#define WV_DUMMY_W 0x80000000u
+inline u32 match_seq64(u32& bits, u32& w, u32& bits2, u32 w2, u32& pickb, u32 lid, u32 from) {
+    (void)lid;
+    for (u32 l = from; l < 64; ++l) {
+        u32 sb = readlane(bits, l);
+        if (sb == 0) {
+            if (lane() >= l && bits == 0) { bits = bits2; w = w2; bits2 = 0; }
+            sb = readlane(bits, l);
+            if (sb == 0) return l;
+        }
+        const u32 sw = readlane(w, l);
+        if (lane() == l) pickb = sb;
+        const u32 sm = sb & (0u - sb);
+        if (w == sw) bits &= ~sm;
+        if (w2 == sw) bits2 &= ~sm;
+    }
+    return 64;
 }
 
 inline u64 clock64() { return 0; }
