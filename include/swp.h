@@ -35,7 +35,7 @@ enum {
     SWP_ENOTFOUND = -2,    /* errNodeNotFound, nodeset.go:12 */
     SWP_ENOMEM = -3,
     SWP_EHIP = -4,         /* HIP runtime error; swp_last_error() has the text */
-    SWP_EUNSUPPORTED = -5, /* feature kept on the Go path (generic resources, CSI volumes, ...) */
+    SWP_EUNSUPPORTED = -5, /* feature kept on the Go path (CSI volumes, generic reservations of whole task groups, ...) */
     SWP_ERANGE = -6,       /* value outside the engine's documented limits */
     SWP_ENODEVICE = -7     /* no gfx950 device: the engine has no CPU fallback */
 };
@@ -69,7 +69,8 @@ enum {
     SWP_SPACE_ARCH = 5,      /* Platform.Architecture after x86_64→amd64, aarch64→arm64 (filter.go:285-299) */
     SWP_SPACE_PLUGIN = 6,    /* "<Type>\0<Name>" (filter.go:179-202) */
     SWP_SPACE_RAW = 7,       /* label values as written, case-sensitive: decision-tree branches (nodeset.go:84-101) */
-    SWP_SPACE_COUNT = 8
+    SWP_SPACE_GENERIC_KIND = 8, /* GenericResource kinds, case-sensitive (api/genericresource/helpers.go Kind()) */
+    SWP_SPACE_COUNT = 9
 };
 /* id 0 is reserved for the empty string in every space except NODE_ID (node index 0 is a node). */
 int swp_intern(swp_engine*, int space, const char* utf8, size_t len, uint32_t* id_out);
@@ -144,6 +145,23 @@ int swp_node_set_failures(swp_engine*, uint32_t node, uint32_t service, uint64_t
 /* usedHostPorts insert/delete (nodeinfo.go:78-84,139-145). protocol: TCP 0 / UDP 1 / SCTP 2 */
 int swp_node_port(swp_engine*, uint32_t node, uint32_t protocol, uint32_t port, int set);
 
+/* Generic resources (api/genericresource). What the placement decision reads of a node's AvailableResources.Generic is ONE number
+ * per kind: genericresource.HasEnough (validate.go:24-52) looks at the entries of the kind — none: not enough, whatever the
+ * request; the first one Discrete: its Value; Named: how many there are — and ResourceFilter.Check (filter.go:86-91) compares
+ * that with the task's Discrete reservation. The caller keeps the LIST (which named values a task is given — Claim,
+ * resource_management.go:11-72 — is its bookkeeping; so are Reclaim and sanitize after a node update, :75-153) and mirrors the
+ * counts: after every change of a node's list it passes the kinds that are present with their count; kinds not named are absent
+ * (count 0: a request of at least 1 never fits, as for a kind the node does not offer). Inside a batch the engine does the
+ * arithmetic of Claim itself: count -= request, an entry that reaches 0 is gone (helpers.go:87-111 remove()). */
+typedef struct {
+    uint32_t kind;       /* SWP_SPACE_GENERIC_KIND id */
+    uint32_t reserved;
+    int64_t  value;      /* a node's count / a task's Discrete reservation; 1 <= value < 2^31 */
+} swp_generic;           /* 16 bytes */
+/* replaces the node's counts (n == 0: the node offers nothing). A kind listed twice: SWP_EINVAL. */
+int swp_node_set_generic(swp_engine*, uint32_t node, const swp_generic* counts, uint32_t n);
+int swp_node_get_generic(swp_engine*, uint32_t node, uint32_t kind, int64_t* count_out);
+
 /* ------------------------------------------------------------------------------------------ */
 /* task-side predicate sets (what Filter.SetTask extracts from a task, filter.go)               */
 enum {   /* constraint kinds, constraint.go:109-203 */
@@ -178,6 +196,11 @@ int swp_platform_set(swp_engine*, const swp_platform* ps, uint32_t n, uint32_t* 
 int swp_plugin_set(swp_engine*, const uint32_t* required, uint32_t n, uint32_t log_plugin, uint32_t* id_out);
 /* HostPortFilter.SetTask (filter.go:322-333): host-mode published ports of the task (at most 32 per task: SWP_ERANGE) */
 int swp_port_set(swp_engine*, const swp_port* ports, uint32_t n, uint32_t* id_out);
+/* ResourceFilter.SetTask's generic half (filter.go:61-74): the task's Reservations.Generic, all Discrete (ValidateTask,
+ * validate.go:11-22), one entry per kind, each value >= 1 (a request of 0 makes selectNodeResources claim every named value of the
+ * kind, resource_management.go:52-66: such a task stays on the Go path, SWP_EUNSUPPORTED; so does a kind requested twice).
+ * At most 8 kinds per task (SWP_ERANGE). */
+int swp_generic_set(swp_engine*, const swp_generic* items, uint32_t n, uint32_t* id_out);
 /* Spread preferences that create a decision-tree level (nodeset.go:59-82): kind is SWP_CK_NODE_LABEL or
  * SWP_CK_ENGINE_LABEL, key the LABEL_KEY id of the part after the prefix; other descriptors are skipped by
  * the caller exactly as the reference skips them. */
@@ -198,7 +221,7 @@ typedef struct {
     uint64_t max_replicas;   /* 0 = MaxReplicasFilter disabled (filter.go:363-370) */
     uint64_t spec_version;   /* SpecVersion.Index (0 when nil) — selects the failure bucket */
     uint32_t spread_set;     /* 0 = no spread preferences (Placement.Preferences, nodeset.go:59-82) */
-    uint32_t reserved;
+    uint32_t generic_set;    /* 0 = no generic reservations (swp_generic_set); such a task needs SWP_TASK_RES_ENABLED */
 } swp_task_desc;             /* 64 bytes */
 
 /* ------------------------------------------------------------------------------------------ */
@@ -376,7 +399,7 @@ int swp_stats(swp_engine*, swp_stats_t* out);
 const char* swp_strerror(int code);
 const char* swp_last_error(swp_engine*);   /* engine may be NULL: last swp_create failure */
 /* sizeof() of every ABI struct, so that a binding can assert its own layout */
-int swp_abi_check(uint32_t* sizes, uint32_t n);   /* order: config,node_row,kv,constraint,platform,port,task_desc,placement,stats,spread */
+int swp_abi_check(uint32_t* sizes, uint32_t n);   /* order: config,node_row,kv,constraint,platform,port,task_desc,placement,stats,spread,generic */
 
 #ifdef __cplusplus
 }

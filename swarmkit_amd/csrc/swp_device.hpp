@@ -2497,6 +2497,14 @@ struct ExplainArgs {
     const u32* ent_ci;    // [ncommit]
     const i64* ent_scpu;  // [ncommit] sum of cpu over this entry and every later one of the node
     const i64* ent_smem;
+    // generic reservations (n_rg == 0: none): the rows and sets of the batch, the END-of-batch counts
+    u32 n_rg, gstride;
+    const int32_t* gcnt;
+    const u32* tg;
+    const u32* gs_off;
+    const u32* gs_row;
+    const u32* rg_kind;
+    const int32_t* rg_val;
 };
 
 // One thread per node: the node's chain of commits (arbitrary order) → a contiguous segment sorted by commit index
@@ -2615,6 +2623,25 @@ __global__ __launch_bounds__(256) void k_explain(ExplainArgs a) {
                     seg_m = seg_p < seg_n ? a.ent_smem[seg_o + seg_p] : 0;
                 }
                 res_fail = !(rcpu <= c_end + seg_c && rmem <= m_end + seg_m);
+            }
+            if (a.n_rg && (rflags & RT_RES) && is_ready && !res_fail) {
+                // generic reservations (filter.go:86-91): count at the task's moment = end-of-batch count + what the node's commits
+                // with index >= pos claimed of the kind. Counts only shrink inside a batch: the chain is walked only for a kind the
+                // node lacks at the end.
+                const u32 gset = cload(a.tg + gj);
+                for (u32 g = cload(a.gs_off + gset); g < cload(a.gs_off + gset + 1) && !res_fail; ++g) {
+                    const u32 row = cload(a.gs_row + g), kind = cload(a.rg_kind + row);
+                    const int32_t want = cload(a.rg_val + row);
+                    int32_t have = a.gcnt[(size_t)kind * a.gstride + n];
+                    if (have >= want) continue;
+                    for (int32_t ci = a.last[n]; ci >= 0; ci = a.log_prev[ci]) {
+                        if (ci < pos) continue;
+                        const u32 ts = a.tg[a.log_task[ci]];
+                        for (u32 z = a.gs_off[ts]; z < a.gs_off[ts + 1]; ++z)
+                            if (a.rg_kind[a.gs_row[z]] == kind) have += a.rg_val[a.gs_row[z]];
+                    }
+                    if (have < want) res_fail = true;
+                }
             }
             if (!is_ready) ff = 0;
             else if (res_fail) ff = 1;
@@ -3296,6 +3323,10 @@ struct CheckArgs {
     u32 port_busy;    // host-evaluated (port sets live on the host between batches)
     u32 svc_count;    // host-evaluated ActiveTasksCountByService[service]
     int32_t* out;
+    u32 n_gen, gstride;        // the task's generic reservations (at most 8) against the device's counts
+    u32 gkind[8];
+    int32_t gval[8];
+    const int32_t* gcnt;
 };
 __global__ void k_check_pair(CheckArgs a) {
     if (threadIdx.x != 0) return;
@@ -3305,6 +3336,12 @@ __global__ void k_check_pair(CheckArgs a) {
     if (!(a.valid[w] & bit)) ff = -2;
     else if (!(a.ready[w] & bit)) ff = 0;
     else if ((a.rt.flags & RT_RES) && !(a.rt.cpu <= a.cpu[n] && a.rt.mem <= a.mem[n])) ff = 1;
+    else if ((a.rt.flags & RT_RES) && [&] {
+                 for (u32 g = 0; g < a.n_gen; ++g)
+                     if (a.gcnt[(size_t)a.gkind[g] * a.gstride + n] < a.gval[g]) return true;   // HasEnough, validate.go:24-52
+                 return false;
+             }())
+        ff = 1;
     else if (a.rt.cls_plug && !(a.plug[(size_t)a.rt.cls_plug * a.n_words + w] & bit)) ff = 2;
     else if (a.rt.cls_con && !(a.con[(size_t)a.rt.cls_con * a.n_words + w] & bit)) ff = 3;
     else if (a.rt.cls_plat && !(a.plat[(size_t)a.rt.cls_plat * a.n_words + w] & bit)) ff = 4;

@@ -121,6 +121,7 @@ struct HostNode {
     std::map<uint32_t, uint32_t> svc;                             // service -> ActiveTasksCountByService
     std::map<std::pair<uint32_t, uint64_t>, uint32_t> fails;      // (service, specVersion) -> recent failures
     std::set<uint64_t> ports;                                     // protocol<<32 | port
+    std::vector<std::pair<uint32_t, int64_t>> gen;                // (GENERIC_KIND id, count) of AvailableResources.Generic, counts >= 1, by kind
 };
 
 inline uint64_t port_key(uint32_t proto, uint32_t port) { return ((uint64_t)proto << 32) | port; }
@@ -158,6 +159,14 @@ struct swp_batch {
     // class indices fit the 8 bits RTask.flags has for each
     std::vector<int64_t> thr64;
     bool classes_ok = false;
+    // generic reservations (filter.go:86-91): the distinct (kind, value) pairs of the batch's tasks are more demand-class rows,
+    // rg[r] = {count[kind_r] >= value_r}, sorted by (kind, value); a task names the rows of its set
+    bool has_generic = false;
+    std::vector<uint32_t> tg;                 // [T] batch-local generic set of the task, 0 = none
+    std::vector<uint32_t> gs_off, gs_row;     // CSR: batch-local set -> rows
+    std::vector<uint32_t> rg_kind, rg_k0, rg_k1;   // per row: kind id, first / one-past-last row of the same kind
+    std::vector<int32_t> rg_val;
+    DevBuf d_tg, d_gs_off, d_gs_row, d_rg_kind, d_rg_k0, d_rg_k1, d_rg_val, d_rg;
 
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
@@ -202,7 +211,8 @@ struct swp_engine {
     std::vector<PlugSet> plug_sets{1};
     std::vector<std::vector<swp_port>> port_sets{1};
     std::vector<std::vector<swp_spread>> spread_sets{1};
-    std::map<std::string, uint32_t> con_index, plat_index, plug_index, port_index, spread_index;
+    std::vector<std::vector<swp_generic>> gen_sets{1};
+    std::map<std::string, uint32_t> con_index, plat_index, plug_index, port_index, spread_index, gen_index;
 
     // label columns of attr[][]: 0 id, 1 hostname, 2 os, 3 arch, 4.. labels
     std::map<uint32_t, uint32_t> node_label_col, engine_label_col;
@@ -212,6 +222,8 @@ struct swp_engine {
     uint32_t ncap = 0;
     DevBuf d_flags, d_cpu, d_mem, d_total, d_os, d_arch, d_attr, d_ip, d_plug_off, d_plug_ids, d_ready, d_valid;
     DevBuf d_save_cpu, d_save_mem, d_save_total;
+    DevBuf d_gcnt, d_save_gcnt;      // [dev_gkinds][ncap] int32: generic counts per (kind, node), part of the dynamic state
+    uint32_t dev_gkinds = 0;
     bool dev_static_dirty = true;    // flags/os/arch/attr/ip/plugins need a re-upload
     bool dev_dynamic_dirty = true;   // cpu/mem/total need a re-upload
     uint32_t dev_cols = 0;
@@ -281,6 +293,7 @@ uint32_t label_value(const std::vector<swp_kv>& kv, uint32_t key) {
 int flush_nodes(swp_engine* e) {
     uint32_t N = e->n_nodes;
     uint32_t need_cap = std::max<uint32_t>(64, ((N + 63) / 64) * 64);
+    if (e->dev_gkinds != (uint32_t)e->spaces[SWP_SPACE_GENERIC_KIND].strs.size()) e->dev_dynamic_dirty = true;   // a new kind: a new row
     bool grow = need_cap > e->ncap || e->dev_cols != e->n_cols;
     if (grow) {
         e->ncap = std::max(need_cap, e->ncap);
@@ -336,6 +349,18 @@ int flush_nodes(swp_engine* e) {
         if ((rc = upload(e, e->d_cpu, cpu))) return rc;
         if ((rc = upload(e, e->d_mem, mem))) return rc;
         if ((rc = upload(e, e->d_total, total))) return rc;
+        const uint32_t K = (uint32_t)e->spaces[SWP_SPACE_GENERIC_KIND].strs.size();   // kind ids are 1 .. K - 1
+        std::vector<int32_t> gcnt;
+        if (K > 1) {
+            gcnt.assign((size_t)K * cap, 0);
+            for (uint32_t n = 0; n < N; ++n) {
+                const HostNode& h = e->nodes[n];
+                if (!h.present) continue;
+                for (const auto& kv : h.gen) gcnt[(size_t)kv.first * cap + n] = (int32_t)kv.second;
+            }
+            if ((rc = upload(e, e->d_gcnt, gcnt))) return rc;
+        }
+        e->dev_gkinds = K;
         HIPCHECK(e, hipStreamSynchronize(e->stream));
         e->dev_dynamic_dirty = false;
     }
@@ -386,6 +411,8 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         if (d.service >= e->spaces[SWP_SPACE_SERVICE].strs.size()) return e->fail(SWP_EINVAL, "task %u: unknown service id %u", i, d.service);
         if (d.spread_set >= e->spread_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown spread set", i);
         if (d.spread_set && !weights) return e->fail(SWP_EUNSUPPORTED, "task %u has spread preferences: schedule it through swp_schedule_groups", i);
+        if (d.generic_set >= e->gen_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown generic set", i);
+        if (d.generic_set && weights) return e->fail(SWP_EUNSUPPORTED, "group %u reserves generic resources: task groups with generic reservations stay on the Go path", i);
         // the exactness argument (feasibility only shrinks inside a batch) needs non-negative reservations; the API layer
         // rejects negative ones (manager/controlapi validateResources), a task that carries them stays on the Go path
         if (d.cpu < 0 || d.mem < 0) return e->fail(SWP_EUNSUPPORTED, "task %u has a negative resource reservation", i);
@@ -488,6 +515,52 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             }
         }
     }
+    // generic reservations: the distinct (kind, value) pairs become rows sorted by (kind, value); a task's set names its rows
+    b->has_generic = false;
+    b->tg.clear();
+    b->gs_off.assign(2, 0);   // local set 0 = "none": the empty range
+    b->gs_row.clear();
+    b->rg_kind.clear();
+    b->rg_val.clear();
+    b->rg_k0.clear();
+    b->rg_k1.clear();
+    {
+        std::set<std::pair<uint32_t, int32_t>> pairs;
+        for (uint32_t i = 0; i < T; ++i)
+            if (tasks[i].generic_set)
+                for (const swp_generic& g : e->gen_sets[tasks[i].generic_set]) pairs.insert({g.kind, (int32_t)g.value});
+        if (!pairs.empty()) {
+            b->has_generic = true;
+            std::map<std::pair<uint32_t, int32_t>, uint32_t> row_of;
+            for (const auto& pr : pairs) {
+                row_of[pr] = (uint32_t)b->rg_kind.size();
+                b->rg_kind.push_back(pr.first);
+                b->rg_val.push_back(pr.second);
+            }
+            const uint32_t R = (uint32_t)b->rg_kind.size();
+            b->rg_k0.resize(R);
+            b->rg_k1.resize(R);
+            for (uint32_t r = 0; r < R;) {
+                uint32_t q = r;
+                while (q < R && b->rg_kind[q] == b->rg_kind[r]) ++q;
+                for (uint32_t x = r; x < q; ++x) { b->rg_k0[x] = r; b->rg_k1[x] = q; }
+                r = q;
+            }
+            std::unordered_map<uint32_t, uint32_t> set_local;
+            b->tg.assign(T, 0);
+            for (uint32_t i = 0; i < T; ++i) {
+                const uint32_t gs = tasks[i].generic_set;
+                if (!gs) continue;
+                auto it = set_local.find(gs);
+                if (it == set_local.end()) {
+                    it = set_local.emplace(gs, (uint32_t)b->gs_off.size() - 1).first;
+                    for (const swp_generic& g : e->gen_sets[gs]) b->gs_row.push_back(row_of[{g.kind, (int32_t)g.value}]);
+                    b->gs_off.push_back((uint32_t)b->gs_row.size());
+                }
+                b->tg[i] = it->second;
+            }
+        }
+    }
     // runs of identical one-off tasks (same service, filters, reservations; only their list slot differs) are placed by
     // water-filling instead of task by task (csrc/swp_waterfill.hpp). A run must be long enough to pay for its launch, and
     // splitting the batch must not shred the round resolver's work into many launches: runs are used when they make up most
@@ -507,7 +580,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         uint32_t longest = 0, i = 0;
         while (i < T) {
             uint32_t k = i + 1;
-            const bool can = !(b->rt[i].flags & (RT_PORTS | RT_UNCOUNTED));
+            const bool can = !(b->rt[i].flags & (RT_PORTS | RT_UNCOUNTED)) && !b->has_generic;   // (a batch with generic reservations is decided by the block resolver alone)
             while (can && k < T && same(i, k)) ++k;
             const bool run = k - i >= run_min;
             if (run) {
@@ -635,6 +708,15 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     if ((rc = upload(e, b->d_rt, b->rt))) return rc;
     if ((rc = upload(e, b->d_thr, b->thr))) return rc;
     if ((rc = upload(e, b->d_thr64, b->thr64))) return rc;
+    if (b->has_generic) {
+        if ((rc = upload(e, b->d_tg, b->tg))) return rc;
+        if ((rc = upload(e, b->d_gs_off, b->gs_off))) return rc;
+        if ((rc = upload(e, b->d_gs_row, b->gs_row))) return rc;
+        if ((rc = upload(e, b->d_rg_kind, b->rg_kind))) return rc;
+        if ((rc = upload(e, b->d_rg_k0, b->rg_k0))) return rc;
+        if ((rc = upload(e, b->d_rg_k1, b->rg_k1))) return rc;
+        if ((rc = upload(e, b->d_rg_val, b->rg_val))) return rc;
+    }
     if ((rc = upload(e, b->d_list_node0, b->list_node0))) return rc;
     if ((rc = upload(e, b->d_list_svc0, b->list_svc0))) return rc;
     if ((rc = upload(e, b->d_list_fail0, b->list_fail0))) return rc;
@@ -782,6 +864,16 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
         xa.log_task = b->d_log_task.as<uint32_t>();
         xa.log_prev = b->d_log_prev.as<int32_t>();
         xa.last = b->d_last.as<int32_t>();
+        if (b->has_generic) {
+            xa.n_rg = (u32)b->rg_kind.size();
+            xa.gstride = e->ncap;
+            xa.gcnt = e->d_gcnt.as<int32_t>();
+            xa.tg = b->d_tg.as<uint32_t>();
+            xa.gs_off = b->d_gs_off.as<uint32_t>();
+            xa.gs_row = b->d_gs_row.as<uint32_t>();
+            xa.rg_kind = b->d_rg_kind.as<uint32_t>();
+            xa.rg_val = b->d_rg_val.as<int32_t>();
+        }
         xa.hist = b->d_hist.as<uint32_t>();
         // per-node commit segments (sorted, suffix sums) for the residual-at-the-moment lookups
         HIPCHECK(e, b->d_seg_off.reserve((size_t)N * 4));
@@ -914,6 +1006,10 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     uint32_t r6_block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
     while (r6_block > 64 && r6_commit_lds_size(Wn, r6_block, b->n_dc + b->n_dm) > lds_budget) r6_block /= 2;   // the block's proposals are staged in LDS
     const bool r6_ok = b->classes_ok && r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, b->n_dc + b->n_dm) <= lds_budget;
+    if (b->has_generic) {   // generic reservations are rows of the block resolver only
+        if (!r6_ok) return e->fail(SWP_EUNSUPPORTED, "a batch with generic reservations needs the block resolver (more than 255 distinct cpu or memory reservations, or too many nodes)");
+        variant = 6;
+    }
     if (variant == 6 && !r6_ok) variant = 3;
     if (variant == 3 && !env_res && r6_ok) variant = 6;   // default beyond k_resolve5's reach
     if (variant != 5) r5_exact = false;
@@ -1003,6 +1099,20 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         ra.thr = b->d_thr64.as<long long>();
         ra.blk = b->d_blk6.as<Blk6>();
         ra.prop = b->d_prop.as<R6Prop>();
+        if (b->has_generic) {
+            HIPCHECK(e, b->d_rg.reserve((size_t)b->rg_kind.size() * Wn * 8));
+            ra.n_rg = (u32)b->rg_kind.size();
+            ra.gstride = e->ncap;
+            ra.gcnt = e->d_gcnt.as<int32_t>();
+            ra.rg = b->d_rg.as<u64>();
+            ra.tg = b->d_tg.as<uint32_t>();
+            ra.gs_off = b->d_gs_off.as<uint32_t>();
+            ra.gs_row = b->d_gs_row.as<uint32_t>();
+            ra.rg_kind = b->d_rg_kind.as<uint32_t>();
+            ra.rg_val = b->d_rg_val.as<int32_t>();
+            ra.rg_k0 = b->d_rg_k0.as<uint32_t>();
+            ra.rg_k1 = b->d_rg_k1.as<uint32_t>();
+        }
         if (prof) {
             HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 0], st));
             HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 1], st));
@@ -1292,9 +1402,19 @@ fprintf(stderr, "[swp] k_resolve5 lister wave 1 per round (cycles): prologue %.0
     return SWP_OK;
 }
 
-void host_apply_placement(swp_engine* e, uint32_t node, uint32_t service, int64_t cpu, int64_t mem, uint32_t port_set, bool counted, bool add) {
+// generic_set: only for placements the engine made itself (Claim's arithmetic, resource_management.go:11-72 with helpers.go:87-111:
+// count -= request, an entry that reaches 0 leaves the list); the caller's own addTask / removeTask push the node's counts afterwards
+void host_apply_placement(swp_engine* e, uint32_t node, uint32_t service, int64_t cpu, int64_t mem, uint32_t port_set, bool counted, bool add, uint32_t generic_set = 0) {
     e->host_dirty_since_save = true;
     HostNode& h = e->nodes[node];
+    if (generic_set && add)
+        for (const swp_generic& g : e->gen_sets[generic_set])
+            for (size_t q = 0; q < h.gen.size(); ++q)
+                if (h.gen[q].first == g.kind) {
+                    h.gen[q].second -= g.value;
+                    if (h.gen[q].second <= 0) h.gen.erase(h.gen.begin() + (long)q);
+                    break;
+                }
     if (add) {
         h.row.cpu -= cpu;
         h.row.mem -= mem;
@@ -1369,7 +1489,7 @@ const char* swp_last_error(swp_engine* e) { return e ? e->last_error.c_str() : g
 
 int swp_abi_check(uint32_t* sizes, uint32_t n) {
     const uint32_t s[] = {sizeof(swp_config), sizeof(swp_node_row), sizeof(swp_kv), sizeof(swp_constraint), sizeof(swp_platform),
-                          sizeof(swp_port), sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t), sizeof(swp_spread)};
+                          sizeof(swp_port), sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t), sizeof(swp_spread), sizeof(swp_generic)};
     uint32_t m = sizeof s / sizeof s[0];
     for (uint32_t i = 0; i < n && i < m; ++i) sizes[i] = s[i];
     return (int)m;
@@ -1626,6 +1746,52 @@ int swp_spread_set(swp_engine* e, const swp_spread* levels, uint32_t n, uint32_t
     return register_set(e->spread_index, e->spread_sets, bytes_of(levels, n), std::vector<swp_spread>(levels, levels + n), id_out);
 }
 
+int swp_generic_set(swp_engine* e, const swp_generic* items, uint32_t n, uint32_t* id_out) {
+    if (!e || !id_out || (!items && n)) return SWP_EINVAL;
+    if (n == 0) { *id_out = 0; return SWP_OK; }
+    if (n > 8) return e->fail(SWP_ERANGE, "a task reserves %u generic kinds (the engine takes 8)", n);
+    std::vector<swp_generic> v(items, items + n);
+    for (swp_generic& g : v) {
+        g.reserved = 0;
+        if (g.kind == 0 || g.kind >= e->spaces[SWP_SPACE_GENERIC_KIND].strs.size()) return e->fail(SWP_EINVAL, "unknown generic kind id %u", g.kind);
+        if (g.value < 1) return e->fail(SWP_EUNSUPPORTED, "a generic reservation of %lld (a request of 0 claims every named value of the kind in the reference): the task stays on the Go path", (long long)g.value);
+        if (g.value >= (1ll << 31)) return e->fail(SWP_ERANGE, "generic reservation %lld exceeds 2^31", (long long)g.value);
+    }
+    std::sort(v.begin(), v.end(), [](const swp_generic& a, const swp_generic& b) { return a.kind < b.kind; });
+    for (size_t i = 1; i < v.size(); ++i)
+        if (v[i].kind == v[i - 1].kind) return e->fail(SWP_EUNSUPPORTED, "a task reserves generic kind %u twice: it stays on the Go path", v[i].kind);
+    return register_set(e->gen_index, e->gen_sets, bytes_of(v.data(), v.size()), std::move(v), id_out);
+}
+
+int swp_node_set_generic(swp_engine* e, uint32_t node, const swp_generic* counts, uint32_t n) {
+    if (!e || (!counts && n)) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    std::vector<std::pair<uint32_t, int64_t>> v;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (counts[i].kind == 0 || counts[i].kind >= e->spaces[SWP_SPACE_GENERIC_KIND].strs.size()) return e->fail(SWP_EINVAL, "unknown generic kind id %u", counts[i].kind);
+        if (counts[i].value < 0 || counts[i].value >= (1ll << 31)) return e->fail(SWP_ERANGE, "generic count %lld outside [0, 2^31)", (long long)counts[i].value);
+        if (counts[i].value > 0) v.emplace_back(counts[i].kind, counts[i].value);
+    }
+    std::sort(v.begin(), v.end());
+    for (size_t i = 1; i < v.size(); ++i)
+        if (v[i].first == v[i - 1].first) return e->fail(SWP_EINVAL, "generic kind %u listed twice", v[i].first);
+    if (v != e->nodes[node].gen) {
+        e->nodes[node].gen = std::move(v);
+        e->dev_dynamic_dirty = true;
+        e->host_dirty_since_save = true;
+    }
+    return SWP_OK;
+}
+
+int swp_node_get_generic(swp_engine* e, uint32_t node, uint32_t kind, int64_t* count_out) {
+    if (!e || !count_out) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    *count_out = 0;
+    for (const auto& kv : e->nodes[node].gen)
+        if (kv.first == kind) *count_out = kv.second;
+    return SWP_OK;
+}
+
 int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node,
                         uint32_t* out_fail_hist) {
     if (!e || (!groups && n_groups) || (!sizes && n_groups)) return SWP_EINVAL;
@@ -1860,7 +2026,7 @@ int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* ou
         if (n < 0) continue;
         if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return e->fail(SWP_EHIP, "device returned an invalid node index %d for task %u", n, i);
         const swp_task_desc& d = b->tasks[i];
-        host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+        host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
         ++placed;
     }
     e->stats.batches++;
@@ -1898,6 +2064,7 @@ int swp_shard_begin(swp_engine* e, swp_batch* b) {
     (void)hipSetDevice(e->device);
     if (e->n_nodes != b->n_nodes_prepared)
         return e->fail(SWP_EINVAL, "the nodeSet grew from %u to %u node slots since swp_batch_prepare: prepare the batch again", b->n_nodes_prepared, e->n_nodes);
+    if (b->has_generic) return e->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the node-range shard protocol yet");
     b->shard_open = true;
     b->shard_ncommit = b->shard_ninf = 0;
     e->stats.ms_propose = e->stats.ms_apply = 0.f;
@@ -2155,6 +2322,10 @@ int swp_state_save(swp_engine* e) {
     HIPCHECK(e, hipMemcpyAsync(e->d_save_cpu.p, e->d_cpu.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHECK(e, hipMemcpyAsync(e->d_save_mem.p, e->d_mem.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHECK(e, hipMemcpyAsync(e->d_save_total.p, e->d_total.p, cap * 4, hipMemcpyDeviceToDevice, e->stream));
+    if (e->dev_gkinds > 1) {
+        HIPCHECK(e, e->d_save_gcnt.reserve((size_t)e->dev_gkinds * cap * 4));
+        HIPCHECK(e, hipMemcpyAsync(e->d_save_gcnt.p, e->d_gcnt.p, (size_t)e->dev_gkinds * cap * 4, hipMemcpyDeviceToDevice, e->stream));
+    }
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     e->saved.nodes = e->nodes;
     e->saved.svc_nodes_ = e->svc_nodes;
@@ -2173,6 +2344,7 @@ int swp_state_restore(swp_engine* e) {
     HIPCHECK(e, hipMemcpyAsync(e->d_cpu.p, e->d_save_cpu.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHECK(e, hipMemcpyAsync(e->d_mem.p, e->d_save_mem.p, cap * 8, hipMemcpyDeviceToDevice, e->stream));
     HIPCHECK(e, hipMemcpyAsync(e->d_total.p, e->d_save_total.p, cap * 4, hipMemcpyDeviceToDevice, e->stream));
+    if (e->dev_gkinds > 1) HIPCHECK(e, hipMemcpyAsync(e->d_gcnt.p, e->d_save_gcnt.p, (size_t)e->dev_gkinds * cap * 4, hipMemcpyDeviceToDevice, e->stream));
     if (e->host_dirty_since_save) {   // the host mirror only moves in swp_batch_fetch / swp_commit / node mutators
         HIPCHECK(e, hipStreamSynchronize(e->stream));
         e->nodes = e->saved.nodes;
@@ -2239,6 +2411,14 @@ int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int3
             if (h.ports.count(port_key(p.protocol, p.port))) ca.port_busy = 1;
     auto it = h.svc.find(task->service);
     ca.svc_count = it == h.svc.end() ? 0 : it->second;
+    if (task->generic_set) {
+        for (const swp_generic& g : e->gen_sets[task->generic_set]) {
+            ca.gkind[ca.n_gen] = g.kind;
+            ca.gval[ca.n_gen++] = (int32_t)g.value;
+        }
+        ca.gstride = e->ncap;
+        ca.gcnt = e->d_gcnt.as<int32_t>();
+    }
     DevBuf out;
     HIPCHECK(e, out.reserve(4));
     ca.out = out.as<int32_t>();

@@ -89,6 +89,18 @@ struct R6Args {
     const i64* thr;          // [n_dc + n_dm] the distinct cpu reservations (ascending), then the memory ones
     Blk6* blk;
     R6Prop* prop;            // [block]
+    // generic reservations (filter.go:86-91, validate.go:24-52): n_rg more demand-class rows, rg[r] = {count[rg_kind[r]] >= rg_val[r]},
+    // sorted by (kind, value); a task's set (tg[task] -> gs_off / gs_row) names its rows. n_rg == 0: none of the pointers is read.
+    u32 n_rg, gstride;       // rows; node stride of gcnt
+    int32_t* gcnt;           // [kind][gstride] the node's count of the kind (0: the kind is absent)
+    u64* rg;                 // [n_rg][n_words]
+    const u32* tg;           // [tasks of the batch] batch-local generic set, 0 = none
+    const u32* gs_off;       // [sets + 1]
+    const u32* gs_row;
+    const u32* rg_kind;      // [n_rg]
+    const int32_t* rg_val;   // [n_rg]
+    const u32* rg_k0;        // [n_rg] first row of the row's kind ...
+    const u32* rg_k1;        // ... and one past its last
 };
 
 #define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together
@@ -152,6 +164,10 @@ WV_KERNEL(256) void k_r6_rows(R6Args a) {
         const u64 word = wv::ballot(in && (c < a.n_dc ? qc : qm) >= wv::uload(a.thr + c));
         if (lane == 0) a.rr[(size_t)c * a.n_words + w] = word;
     }
+    for (u32 r = 0; r < a.n_rg; ++r) {
+        const u64 word = wv::ballot(in && a.gcnt[(size_t)wv::uload(a.rg_kind + r) * a.gstride + n] >= wv::uload(a.rg_val + r));
+        if (lane == 0) a.rg[(size_t)r * a.n_words + w] = word;
+    }
 }
 
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
@@ -179,6 +195,12 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
         p0 = wv::uload(a.pset_off + pset);
         p1 = wv::uload(a.pset_off + pset + 1);
     }
+    u32 g0 = 0, g1 = 0;   // the task's generic rows
+    if (a.n_rg) {
+        const u32 gset = wv::uload(a.tg + t);
+        g0 = wv::uload(a.gs_off + gset);
+        g1 = wv::uload(a.gs_off + gset + 1);
+    }
     if (wv::tid() < R6_NP + 2) flag[wv::tid()] = 0;
     wv::barrier();
     // the task's plain candidates, lane l of wave v owns words {l + 64 k}, k = v (mod R6_PW); R6_UNROLL chunks per step so that
@@ -193,6 +215,8 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
             m[u] = in ? scrow[w] : 0ull;
             f[u] = in ? xrow[w] : 0ull;
             if (res && in) f[u] |= ~(rc[w] & rm[w]);
+            for (u32 g = g0; g < g1; ++g)
+                if (in) f[u] |= ~a.rg[(size_t)wv::uload(a.gs_row + g) * Wn + w];
         }
         WV_UNROLL
         for (int u = 0; u < R6_UNROLL; ++u) {
@@ -278,6 +302,12 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
         const u64 bit = 1ull << (n & 63);
         if (!(scrow[w] & bit)) continue;
         if (res && !(rcpu <= a.cpu[n] && rmem <= a.mem[n])) continue;
+        bool lacks = false;   // HasEnough per reservation, validate.go:24-52
+        for (u32 g = g0; g < g1; ++g) {
+            const u32 r = a.gs_row[g];
+            if (a.gcnt[(size_t)a.rg_kind[r] * a.gstride + n] < a.rg_val[r]) lacks = true;
+        }
+        if (lacks) continue;
         bool used = false;
         for (u32 p = p0; p < p1; ++p)
             if (a.portmap[(size_t)a.pset_ids[p] * Wn + w] & bit) used = true;
@@ -493,6 +523,17 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             }
             if (r.flags & RT_PORTS)
                 for (u32 q = a.pset_off[r.pset]; q < a.pset_off[r.pset + 1]; ++q) wv::g_or64(a.portmap + (size_t)a.pset_ids[q] * Wn + w, bit);
+            if (a.n_rg) {   // Claim (resource_management.go:11-72): the count drops by the request; the node leaves the kind's rows it no longer meets
+                const u32 gset = a.tg[t];
+                for (u32 g = a.gs_off[gset]; g < a.gs_off[gset + 1]; ++g) {
+                    const u32 row = a.gs_row[g];
+                    int32_t* cp = a.gcnt + (size_t)a.rg_kind[row] * a.gstride + nd;
+                    const int32_t c = *cp - a.rg_val[row];
+                    *cp = c;
+                    for (u32 r2 = a.rg_k0[row]; r2 < a.rg_k1[row]; ++r2)
+                        if (a.rg_val[r2] > c) wv::g_andn64(a.rg + (size_t)r2 * Wn + w, bit);
+                }
+            }
             if (!(r.flags & RT_UNCOUNTED)) {
                 a.total[nd] = old + 1;
                 const u32 rl = old - base, nl = rl + 1, xm = rl ^ nl;   // the bits a +1 flips: a run of ones from bit 0

@@ -4,6 +4,7 @@
 // The model follows k_resolve (swp_device.hpp): plain nodes by (level, index) with a re-check of the dynamic filters, then the
 // service's exception list by nodeLess, scheduler.go:708-735; NodeInfo.addTask, nodeinfo.go:108-154.
 #pragma once
+#include <algorithm>
 #include <map>
 #include <random>
 #include <set>
@@ -23,6 +24,19 @@ struct Problem {
     std::vector<u64> portmap;   // [n_ports][Wn]
     std::vector<u32> pset_off, pset_ids;
     i64 UC, UM;
+    // feature level 3: generic reservations. n_kinds kinds (ids 1..n_kinds); gcnt[kind][N] the nodes' counts; a task's set names
+    // rows of the (kind, value) table sorted by (kind, value) — the engine's batch layout (swp_engine.hip build_batch)
+    u32 n_kinds = 0;
+    std::vector<int32_t> gcnt;             // [(n_kinds + 1)][N]
+    std::vector<u32> tg;                   // [T] set of the task, 0 = none
+    std::vector<u32> gs_off, gs_row, rg_kind, rg_k0, rg_k1;
+    std::vector<int32_t> rg_val;
+    bool lacks(const std::vector<int32_t>& cnt, u32 j, u32 n) const {   // HasEnough fails for one of task j's reservations
+        if (tg.empty()) return false;
+        for (u32 g = gs_off[tg[j]]; g < gs_off[tg[j] + 1]; ++g)
+            if (cnt[(size_t)rg_kind[gs_row[g]] * N + n] < rg_val[gs_row[g]]) return true;
+        return false;
+    }
 };
 
 struct State {   // everything a resolver mutates or emits
@@ -32,6 +46,7 @@ struct State {   // everything a resolver mutates or emits
     std::vector<u32> list_node, list_svc, list_fail;
     std::vector<int32_t> out, log_prev, last;
     std::vector<u32> log_node, log_task, inf_task, inf_pos;
+    std::vector<int32_t> gcnt;
     Ctl ctl{};
 };
 
@@ -144,6 +159,54 @@ static Problem make_problem(u32 seed, u32 N, u32 T, u32 S, int order, int feat) 
     }
     p.list_off[S] = (u32)p.list_node.size();
     for (u32 j = 0; j < T; ++j) p.rt[j].slot = p.list_off[p.rt[j].svc] + init_cnt[p.rt[j].svc] + rank[j];
+    if (feat >= 3) {   // generic reservations: 3 kinds, a third of the services reserve one or two of them
+        p.n_kinds = 3;
+        p.gcnt.assign((size_t)(p.n_kinds + 1) * N, 0);
+        for (u32 k = 1; k <= p.n_kinds; ++k)
+            for (u32 n = 0; n < N; ++n)
+                if (rnd(4)) p.gcnt[(size_t)k * N + n] = (int32_t)rnd(k == 1 ? 4 : 12);   // scarce / plentiful, some nodes offer none
+        std::vector<std::vector<std::pair<u32, int32_t>>> svc_set(S);
+        std::set<std::pair<u32, int32_t>> pairs;
+        for (u32 s = 0; s < S; ++s) {
+            if (rnd(3)) continue;
+            const u32 k1 = 1 + rnd(p.n_kinds);
+            svc_set[s].push_back({k1, (int32_t)(1 + rnd(3))});
+            if (rnd(2)) {
+                const u32 k2 = 1 + rnd(p.n_kinds);
+                if (k2 != k1) svc_set[s].push_back({k2, (int32_t)(1 + rnd(2))});
+            }
+            std::sort(svc_set[s].begin(), svc_set[s].end());
+            for (auto& pr : svc_set[s]) pairs.insert(pr);
+        }
+        std::map<std::pair<u32, int32_t>, u32> row_of;
+        for (auto& pr : pairs) {
+            row_of[pr] = (u32)p.rg_kind.size();
+            p.rg_kind.push_back(pr.first);
+            p.rg_val.push_back(pr.second);
+        }
+        const u32 R = (u32)p.rg_kind.size();
+        p.rg_k0.resize(R);
+        p.rg_k1.resize(R);
+        for (u32 r = 0; r < R;) {
+            u32 q = r;
+            while (q < R && p.rg_kind[q] == p.rg_kind[r]) ++q;
+            for (u32 x = r; x < q; ++x) { p.rg_k0[x] = r; p.rg_k1[x] = q; }
+            r = q;
+        }
+        p.gs_off.assign(2, 0);
+        std::vector<u32> set_of(S, 0);
+        for (u32 s = 0; s < S; ++s) {
+            if (svc_set[s].empty()) continue;
+            set_of[s] = (u32)p.gs_off.size() - 1;
+            for (auto& pr : svc_set[s]) p.gs_row.push_back(row_of[pr]);
+            p.gs_off.push_back((u32)p.gs_row.size());
+        }
+        p.tg.assign(T, 0);
+        for (u32 j = 0; j < T; ++j) {
+            p.tg[j] = set_of[p.rt[j].svc];
+            if (p.tg[j]) p.rt[j].flags |= RT_RES;   // ResourceFilter.SetTask: enabled by a generic reservation alone (filter.go:61-74)
+        }
+    }
     return p;
 }
 
@@ -164,6 +227,7 @@ static State initial_state(const Problem& p) {
     s.log_task.assign(p.T, 0);
     s.inf_task.assign(p.T, 0);
     s.inf_pos.assign(p.T, 0);
+    s.gcnt = p.gcnt;
     return s;
 }
 
@@ -177,7 +241,7 @@ static void scan_window(const Problem& p, const State& s, u32 j0, u32 cnt, std::
             if (r.flags & RT_RES) {
                 u64 fit = 0;
                 for (u32 i = 0; i < 64 && w * 64 + i < p.N; ++i)
-                    if (r.cpu <= s.cpu[w * 64 + i] && r.mem <= s.mem[w * 64 + i]) fit |= 1ull << i;
+                    if (r.cpu <= s.cpu[w * 64 + i] && r.mem <= s.mem[w * 64 + i] && !p.lacks(s.gcnt, j0 + j, w * 64 + i)) fit |= 1ull << i;
                 word &= fit;
             }
             if (r.flags & RT_PORTS)
@@ -197,6 +261,8 @@ static void ref_window(const Problem& p, State& s, u32 j0, u32 cnt, const std::v
     auto commit = [&](const RTask& r, u32 gj, u32 n, u32 e) {
         s.cpu[n] -= r.cpu;
         s.mem[n] -= r.mem;
+        if (!p.tg.empty())   // Claim: the count drops by the request
+            for (u32 g = p.gs_off[p.tg[gj]]; g < p.gs_off[p.tg[gj] + 1]; ++g) s.gcnt[(size_t)p.rg_kind[p.gs_row[g]] * p.N + n] -= p.rg_val[p.gs_row[g]];
         if (r.flags & RT_PORTS)
             for (u32 q = p.pset_off[r.pset]; q < p.pset_off[r.pset + 1]; ++q) s.portmap[(size_t)p.pset_ids[q] * p.Wn + (n >> 6)] |= 1ull << (n & 63);
         if (!(r.flags & RT_UNCOUNTED)) {
@@ -226,6 +292,7 @@ static void ref_window(const Problem& p, State& s, u32 j0, u32 cnt, const std::v
             if (!((f[n >> 6] >> (n & 63)) & 1)) continue;
             if ((s.X[(size_t)r.svc * p.Wn + (n >> 6)] >> (n & 63)) & 1) continue;
             if ((r.flags & RT_RES) && !(r.cpu <= s.cpu[n] && r.mem <= s.mem[n])) continue;
+            if ((r.flags & RT_RES) && p.lacks(s.gcnt, gj, n)) continue;
             if ((r.flags & RT_PORTS) && !ports_free(r, n)) continue;
             u64 k = ((u64)s.total[n] << 32) | n;
             if (k < bestk) bestk = k;
@@ -239,6 +306,7 @@ static void ref_window(const Problem& p, State& s, u32 j0, u32 cnt, const std::v
             if (n == LIST_EMPTY) continue;
             if (!((f[n >> 6] >> (n & 63)) & 1)) continue;
             if ((r.flags & RT_RES) && !(r.cpu <= s.cpu[n] && r.mem <= s.mem[n])) continue;
+            if ((r.flags & RT_RES) && p.lacks(s.gcnt, gj, n)) continue;
             if ((r.flags & RT_PORTS) && !ports_free(r, n)) continue;
             u32 svc = s.list_svc[e], fl = s.list_fail[e];
             if ((r.flags & RT_MAXREP) && !((u64)svc < r.maxrep)) continue;

@@ -3,7 +3,7 @@
 // with the sequential model of emu_model.hpp; the bitmaps the kernels maintain incrementally (level planes, demand-class
 // rows) are compared with a rebuild from the final node rows. TEST INFRASTRUCTURE (tests/test_emu_resolve6.py); not product.
 //
-//   emu_resolve6 <seed> <N> <T> <S> <block> <order: 0 rr | 1 major | 2 random> <features 0..2> [v] [s: two stretches with a rebuild between]
+//   emu_resolve6 <seed> <N> <T> <S> <block> <order: 0 rr | 1 major | 2 random> <features 0..3> [v] [s: two stretches with a rebuild between]
 #include "wv_emu.hpp"
 
 #define SWP_R6_KERNELS
@@ -21,7 +21,7 @@ static void grid(u32 blocks, u32 threads, size_t lds, F body) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..2) [v] [s]\n", argv[0]); return 2; }
+    if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
     bool verbose = false, split = false;
@@ -86,6 +86,20 @@ int main(int argc, char** argv) {
     a.thr = thr.data();
     a.blk = &blk;
     a.prop = prop.data();
+    std::vector<u64> rg((size_t)std::max<size_t>(p.rg_kind.size(), 1) * p.Wn, 0x3333333333333333ull);
+    if (!p.rg_kind.empty()) {   // feature level 3: generic reservations
+        a.n_rg = (u32)p.rg_kind.size();
+        a.gstride = N;
+        a.gcnt = em.gcnt.data();
+        a.rg = rg.data();
+        a.tg = p.tg.data();
+        a.gs_off = p.gs_off.data();
+        a.gs_row = p.gs_row.data();
+        a.rg_kind = p.rg_kind.data();
+        a.rg_val = p.rg_val.data();
+        a.rg_k0 = p.rg_k0.data();
+        a.rg_k1 = p.rg_k1.data();
+    }
 
     u64 rounds = 0;
     auto build = [&]() {
@@ -117,7 +131,7 @@ int main(int argc, char** argv) {
     ok = ok && same("out", em.out, ref.out, T) && same("cpu", em.cpu, ref.cpu, N) && same("mem", em.mem, ref.mem, N) && same("total", em.total, ref.total, N) &&
          same("X", em.X, ref.X, em.X.size()) && same("portmap", em.portmap, ref.portmap, em.portmap.size()) &&
          same("list_node", em.list_node, ref.list_node, em.list_node.size()) && same("list_svc", em.list_svc, ref.list_svc, em.list_svc.size()) &&
-         same("list_fail", em.list_fail, ref.list_fail, em.list_fail.size());
+         same("list_fail", em.list_fail, ref.list_fail, em.list_fail.size()) && same("gcnt", em.gcnt, ref.gcnt, em.gcnt.size());
     ok = ok && em.ctl.ncommit == ref.ctl.ncommit && em.ctl.ninf == ref.ctl.ninf;
     if (!ok) fprintf(stderr, "ncommit emu %u ref %u, ninf emu %u ref %u\n", em.ctl.ncommit, ref.ctl.ncommit, em.ctl.ninf, ref.ctl.ninf);
     ok = ok && same("log_node", em.log_node, ref.log_node, ref.ctl.ncommit) && same("log_task", em.log_task, ref.log_task, ref.ctl.ncommit) &&
@@ -125,10 +139,10 @@ int main(int argc, char** argv) {
          same("inf_task", em.inf_task, ref.inf_task, ref.ctl.ninf) && same("inf_pos", em.inf_pos, ref.inf_pos, ref.ctl.ninf);
     // the incrementally maintained bitmaps against a rebuild from the final node rows (same base: levels are relative to it)
     if (ok) {
-        std::vector<u64> planes2 = planes, rr2 = rr;
+        std::vector<u64> planes2 = planes, rr2 = rr, rg2 = rg;
         const u32 base = blk.base, maxrel = blk.maxrel;
         grid((p.Wn + 3) / 4, 256, 0, [a]() { k_r6_rows(a); });
-        ok = same("planes", planes2, planes, planes.size()) && same("rr", rr2, rr, (size_t)(n_dc + n_dm) * p.Wn);
+        ok = same("planes", planes2, planes, planes.size()) && same("rr", rr2, rr, (size_t)(n_dc + n_dm) * p.Wn) && same("rg", rg2, rg, p.rg_kind.size() * p.Wn);
         u32 hi = 0;
         for (u32 n = 0; n < N; ++n)
             if ((p.valid[n >> 6] >> (n & 63)) & 1) hi = std::max(hi, em.total[n] - base);

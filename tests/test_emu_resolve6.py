@@ -36,6 +36,10 @@ CASES = [
     (77, 70000, 300, 30, 64, 0, 1, ""),      # beyond 65 536 nodes: every propose wave loops over more than one group of chunks
     (78, 140000, 400, 50, 128, 2, 2, "s"),
     (79, 66000, 1500, 200, 512, 0, 0, ""),
+    (7, 500, 2000, 40, 256, 0, 3, ""),       # feature level 3: generic reservations (counts per kind as more demand-class rows, Claim in the apply step)
+    (8, 885, 1500, 125, 64, 2, 3, ""),
+    (9, 300, 1500, 6, 512, 1, 3, ""),        # ... with the exception lists deciding: HasEnough per listed node
+    (10, 3000, 2500, 300, 512, 0, 3, "s"),
 ]
 
 

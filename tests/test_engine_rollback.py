@@ -1,0 +1,80 @@
+"""GPU: the failed half of applySchedulingDecisions (manager/scheduler/scheduler.go:472-487, node-version check :533-545) against the
+REAL engine. A tick places a batch; the store "refuses" a sample of the decisions (`reject_decision`): the reference puts the old task
+back into allTasks, calls NodeInfo.removeTask(new) and enqueues the old task again. The oracle has no commit step, so the same thing is
+spelled through its event handlers — delete_task(the assigned task) + create_task(the pending one), in the order of the rejections —
+and must then agree with the engine on every node's residuals / counts / per-service counts (as if the rejected tasks had never been
+placed) and on every decision of the next tick. Both host layers (the C++ one inside libswp.so and the Python twin) run it."""
+import os
+
+import pytest
+
+import orc
+from swarmkit_amd import host as swhost
+from swarmkit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["cxx", "py"])
+def host_kind(request):
+    old = os.environ.get("SWP_HOST")
+    os.environ["SWP_HOST"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("SWP_HOST", None)
+    else:
+        os.environ["SWP_HOST"] = old
+
+
+def key(d):
+    return (d["ID"], d["NodeID"], d["Err"], d["State"])
+
+
+def same_nodes(o, e, wl):
+    for i in range(wl.N):
+        nid = wl.node_id(i)
+        a, b = o.node_info(nid), e.node_info(nid)
+        assert a["ActiveTasksCount"] == b["ActiveTasksCount"], nid
+        assert a["AvailableResources"]["NanoCPUs"] == b["AvailableResources"]["NanoCPUs"], nid
+        assert a["AvailableResources"]["MemoryBytes"] == b["AvailableResources"]["MemoryBytes"], nid
+        assert a["ActiveTasksCountByService"] == b["ActiveTasksCountByService"], nid
+        assert sorted(a["Tasks"]) == sorted(b["Tasks"]), nid
+
+
+@pytest.mark.parametrize("name,T,N,every", [("cfg4", 3000, 400, 7), ("cfg3", 2500, 300, 3), ("cfg2", 1200, 60, 2)])
+def test_rejected_decisions_are_rolled_back(host_kind, name, T, N, every):
+    wl = synth.Workload(name, T=T, N=N)
+    o, e = orc.Oracle(), swhost.HostScheduler()
+    for s in (o, e):
+        for i in range(wl.N):
+            s.create_node(wl.node_doc(i))
+        for k in range(wl.S):
+            s.set_service(wl.service_id(k))
+        for j in range(wl.T):
+            s.create_task(wl.task_doc(j))
+    do, de = sorted(map(key, o.tick())), sorted(map(key, e.tick()))
+    assert do == de
+    placed = [(tid, nid) for tid, nid, err, st in do if nid and st >= orc.ASSIGNED]
+    assert len(placed) > 100
+    same_nodes(o, e, wl)
+    # the store refuses every `every`-th placement (in task order: the order the reference walks its decisions map is unspecified;
+    # the shim hands the failed ones back one by one)
+    rejected = placed[::every]
+    for tid, nid in rejected:
+        assert e.reject_decision(tid) is True
+        j = int(tid[1:])
+        doc = wl.task_doc(j)
+        o.delete_task(dict(doc, NodeID=nid, Status={"State": orc.ASSIGNED}))
+        o.create_task(doc)
+    assert e.reject_decision(rejected[0][0]) is False   # a decision is handed back once
+    same_nodes(o, e, wl)   # residuals, counts, per-service counts and task sets as if those tasks had never been placed
+    # the next tick sees them again, together with some new work
+    extra = [dict(wl.task_doc(j), ID="x%06d" % j) for j in range(0, wl.T, 11)]
+    for t in extra:
+        for s in (o, e):
+            s.create_task(t)
+    do2, de2 = sorted(map(key, o.tick())), sorted(map(key, e.tick()))
+    assert do2 == de2
+    again = {d[0] for d in do2}
+    assert {tid for tid, _ in rejected} <= again
+    same_nodes(o, e, wl)
