@@ -10,7 +10,7 @@ CSRC = os.path.join(ROOT, "swarmkit_amd", "csrc")
 LIB_PATH = os.environ.get("SWP_LIB_PATH") or os.path.join(ROOT, "swarmkit_amd", "lib", "libswp.so")
 
 SWP_OK, SWP_EINVAL, SWP_ENOTFOUND, SWP_ENOMEM, SWP_EHIP, SWP_EUNSUPPORTED, SWP_ERANGE, SWP_ENODEVICE = 0, -1, -2, -3, -4, -5, -6, -7
-(SPACE_NODE_ID, SPACE_SERVICE, SPACE_LABEL_KEY, SPACE_FOLDED, SPACE_OS, SPACE_ARCH, SPACE_PLUGIN, SPACE_RAW) = range(8)
+(SPACE_NODE_ID, SPACE_SERVICE, SPACE_LABEL_KEY, SPACE_FOLDED, SPACE_OS, SPACE_ARCH, SPACE_PLUGIN, SPACE_RAW, SPACE_GENERIC_KIND) = range(9)
 NODE_READY, NODE_HAS_DESC, NODE_HAS_PLATFORM, NODE_HAS_ENGINE = 0x1, 0x2, 0x4, 0x8
 NODE_HAS_LABELS, NODE_HAS_ELABELS, NODE_MANAGER, NODE_HAS_LOGPLUG, NODE_IP_VALID, NODE_IP_V4 = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 (CK_NODE_ID, CK_HOSTNAME, CK_IP, CK_ROLE, CK_PLATFORM_OS, CK_PLATFORM_ARCH, CK_NODE_LABEL, CK_ENGINE_LABEL, CK_INVALID) = range(9)
@@ -57,7 +57,7 @@ class Spread(C.Structure):
 class TaskDesc(C.Structure):
     _fields_ = [("service", C.c_uint32), ("flags", C.c_uint32), ("cpu", C.c_int64), ("mem", C.c_int64),
                 ("constraint_set", C.c_uint32), ("platform_set", C.c_uint32), ("plugin_set", C.c_uint32), ("port_set", C.c_uint32),
-                ("max_replicas", C.c_uint64), ("spec_version", C.c_uint64), ("spread_set", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_replicas", C.c_uint64), ("spec_version", C.c_uint64), ("spread_set", C.c_uint32), ("generic_set", C.c_uint32)]
 
 
 class Placement(C.Structure):
@@ -79,7 +79,7 @@ class Stats(C.Structure):
 # numpy views of the POD structs, for bulk construction
 TASK_DTYPE = np.dtype([("service", "<u4"), ("flags", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("constraint_set", "<u4"),
                        ("platform_set", "<u4"), ("plugin_set", "<u4"), ("port_set", "<u4"), ("max_replicas", "<u8"),
-                       ("spec_version", "<u8"), ("spread_set", "<u4"), ("reserved", "<u4")])
+                       ("spec_version", "<u8"), ("spread_set", "<u4"), ("generic_set", "<u4")])
 PLACEMENT_DTYPE = np.dtype([("node", "<u4"), ("service", "<u4"), ("cpu", "<i8"), ("mem", "<i8"), ("port_set", "<u4"), ("counted", "<u4")])
 ENF_NODE_DTYPE = np.dtype([("node", "<u4"), ("first_task", "<u4"), ("n_tasks", "<u4"), ("reserved", "<u4"), ("cpu", "<i8"), ("mem", "<i8")])
 ENF_TASK_DTYPE = np.dtype([("cpu", "<i8"), ("mem", "<i8"), ("constraint_set", "<u4"), ("flags", "<u4"), ("desired_state", "<u4"), ("state", "<u4")])
@@ -98,7 +98,12 @@ assert ENF_NODE_DTYPE.itemsize == 32 and ENF_TASK_DTYPE.itemsize == 32
 assert TASK_DTYPE.itemsize == C.sizeof(TaskDesc) == 64
 assert PLACEMENT_DTYPE.itemsize == C.sizeof(Placement) == 32
 
+class Generic(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("reserved", C.c_uint32), ("value", C.c_int64)]
+
+
 EXPORTS = [
+    "swp_generic_set", "swp_node_set_generic", "swp_node_get_generic",
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
@@ -174,6 +179,9 @@ def load_library(path=None):
         "swp_plugin_set": ([vp, P(u32), u32, u32, P(u32)], C.c_int),
         "swp_port_set": ([vp, P(Port), u32, P(u32)], C.c_int),
         "swp_spread_set": ([vp, P(Spread), u32, P(u32)], C.c_int),
+        "swp_generic_set": ([vp, P(Generic), u32, P(u32)], C.c_int),
+        "swp_node_set_generic": ([vp, u32, P(Generic), u32], C.c_int),
+        "swp_node_get_generic": ([vp, u32, u32, P(C.c_int64)], C.c_int),
         "swp_schedule_groups": ([vp, vp, vp, u32, vp, vp], C.c_int),
         "swp_schedule_batch": ([vp, vp, u32, vp, vp], C.c_int),
         "swp_batch_prepare": ([vp, vp, u32, P(vp)], C.c_int),
@@ -230,7 +238,7 @@ def load_library(path=None):
         fn.restype = res
     sizes = (u32 * 16)()
     n = L.swp_abi_check(sizes, 16)
-    want = [C.sizeof(x) for x in (Config, NodeRow, KV, Constraint, Platform, Port, TaskDesc, Placement, Stats, Spread)]
+    want = [C.sizeof(x) for x in (Config, NodeRow, KV, Constraint, Platform, Port, TaskDesc, Placement, Stats, Spread, Generic)]
     if list(sizes[:n]) != want:
         raise RuntimeError(f"ABI struct size mismatch: lib {list(sizes[:n])} vs binding {want}")
     _libs[path] = L
@@ -407,6 +415,23 @@ class Engine:
         arr = (Port * max(1, len(ports)))(*[Port(p, q) for p, q in ports])
         out = C.c_uint32()
         self._ck(self.L.swp_port_set(self.h, arr, len(ports), C.byref(out)))
+        return out.value
+
+    def generic_set(self, items):
+        """items: (GENERIC_KIND id, value) pairs — the task's Discrete reservations."""
+        arr = (Generic * max(1, len(items)))(*[Generic(k, 0, v) for k, v in items])
+        out = C.c_uint32()
+        self._ck(self.L.swp_generic_set(self.h, arr, len(items), C.byref(out)))
+        return out.value
+
+    def node_set_generic(self, node, counts):
+        """counts: (GENERIC_KIND id, count) pairs of the node's available generic resources (replaces)."""
+        arr = (Generic * max(1, len(counts)))(*[Generic(k, 0, v) for k, v in counts])
+        self._ck(self.L.swp_node_set_generic(self.h, node, arr, len(counts)))
+
+    def node_get_generic(self, node, kind):
+        out = C.c_int64()
+        self._ck(self.L.swp_node_get_generic(self.h, node, kind, C.byref(out)))
         return out.value
 
     def spread_set(self, levels):

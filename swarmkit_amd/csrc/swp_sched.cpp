@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/swp_sched.h"
+#include "swp_generic.hpp"
 #include "swp_json.hpp"
 
 namespace swp {
@@ -291,6 +292,7 @@ struct NodeInfo {
     std::map<std::string, Value> Tasks;                   // NodeInfo.Tasks
     std::map<FailureKey, std::vector<int64_t>> recentFailures;
     int64_t lastCleanup = 0;
+    generic::List availGeneric;                           // AvailableResources.Generic (the engine holds one count per kind of it)
 };
 
 class Scheduler {
@@ -308,16 +310,18 @@ class Scheduler {
         NodeInfo* ni = it == nodes_.end() ? nullptr : &it->second;
         const Value* res = at(&n, {"Description", "Resources"});
         int64_t cpu = 0, mem = 0;
+        generic::List avail;
         if (res != nullptr) {
-            if (truthy(res->get("Generic"))) unsupported("generic resources stay on the Go path");
             cpu = as_i64(res->get("NanoCPUs"));
             mem = as_i64(res->get("MemoryBytes"));
-            if (ni != nullptr) {   // :376-381: subtract the reservations of the tasks already on the node
+            avail = generic::decode(res->get("Generic"));
+            if (ni != nullptr) {   // :376-384: subtract the reservations of the tasks already on the node, take their generic resources out
                 for (const auto& kv : ni->Tasks) {
                     int64_t c, m;
                     taskReservations(kv.second, c, m);
                     cpu -= c;
                     mem -= m;
+                    generic::consume(&avail, generic::decode(kv.second.get("AssignedGenericResources")));
                 }
             }
         }
@@ -337,7 +341,9 @@ class Scheduler {
             idx_to_id_[idx] = nid;
         }
         ni->node = n;
+        ni->availGeneric = std::move(avail);
         upsertRow(n, idx, cpu, mem, total);
+        pushGeneric(*ni);
     }
     // nodeSet.remove, nodeset.go:46-48
     void deleteNode(const std::string& nid) {
@@ -366,7 +372,7 @@ class Scheduler {
         Value avail = Value::object();
         avail.set("NanoCPUs", Value::integer(row.cpu));
         avail.set("MemoryBytes", Value::integer(row.mem));
-        avail.set("Generic", Value::array());
+        avail.set("Generic", generic::encode(ni.availGeneric));
         Value info = Value::object();
         info.set("ID", Value::str(nid));
         info.set("ActiveTasksCount", Value::integer(row.total));
@@ -386,10 +392,25 @@ class Scheduler {
     void advance(int64_t ns) { now_ += ns; }
 
     // ---------------------------------------------------------------------------------------------- task events
+    // The task's Reservations.Generic as the engine takes them (swp_generic_set): Discrete entries, one per kind, values >= 1, at
+    // most 8 kinds. Anything else — a Named reservation (HasEnough's error return, validate.go:26-29: such a task fits nowhere in
+    // the reference), a request of 0 (selectNodeResources would claim every named value, resource_management.go:52-66), a kind
+    // listed twice — stays on the Go path.
+    static generic::List genericReservations(const Value& t) {
+        generic::List r = generic::decode(at(&t, {"Spec", "Resources", "Reservations", "Generic"}));
+        if (r.size() > 8) unsupported("more than 8 generic reservations in one task stay on the Go path");
+        std::set<std::string> kinds;
+        for (const generic::Res& g : r) {
+            if (g.named) unsupported("a Named generic reservation stays on the Go path");
+            if (g.ival < 1) unsupported("a generic reservation below 1 stays on the Go path");
+            if (!kinds.insert(g.kind).second) unsupported("a generic kind reserved twice stays on the Go path");
+        }
+        return r;
+    }
     // Tasks the engine cannot judge (generic resources, CSI cluster volumes) are refused at the event boundary — the shim
     // leaves them to the Go scheduler's own path — so that a tick never meets one half-way through a batch.
     static void requireSupported(const Value& t) {
-        if (truthy(at(&t, {"Spec", "Resources", "Reservations", "Generic"}))) unsupported("generic resources stay on the Go path");
+        (void)genericReservations(t);   // refuses what swp_generic_set would refuse
         if (const Value* ports = at(&t, {"Endpoint", "Ports"}))
             if (ports->is_arr()) {
                 size_t host_ports = 0;
@@ -491,10 +512,13 @@ class Scheduler {
         std::memset(&d, 0, sizeof d);
         d.service = intern(SWP_SPACE_SERVICE, as_str(t.get("ServiceID")));
         if (const Value* res = at(&t, {"Spec", "Resources", "Reservations"})) {   // ResourceFilter.SetTask, filter.go:61-74
-            if (truthy(res->get("Generic"))) unsupported("generic resources stay on the Go path");
             d.cpu = as_i64(res->get("NanoCPUs"));
             d.mem = as_i64(res->get("MemoryBytes"));
-            if (d.cpu != 0 || d.mem != 0) d.flags |= SWP_TASK_RES_ENABLED;
+            const bool any_generic = res->get("Generic") != nullptr && res->get("Generic")->is_arr() && res->get("Generic")->size() > 0;
+            if (d.cpu != 0 || d.mem != 0 || any_generic) d.flags |= SWP_TASK_RES_ENABLED;
+            std::vector<swp_generic> items;
+            for (const generic::Res& g : genericReservations(t)) items.push_back({intern(SWP_SPACE_GENERIC_KIND, g.kind), 0u, g.ival});
+            if (!items.empty()) ck(swp_generic_set(e_, items.data(), (uint32_t)items.size(), &d.generic_set), "swp_generic_set");
         }
         if (task_state(t.get("DesiredState")) > COMPLETE) d.flags |= 0x2u;   // SWP_TASK_UNCOUNTED: nodeinfo.go:148
         if (const Value* pl = at(&t, {"Spec", "Placement"})) {
@@ -946,6 +970,15 @@ class Scheduler {
         ck(swp_port_set(e_, ps.data(), (uint32_t)ps.size(), &id), "swp_port_set");
         return id;
     }
+    // the node's available generic list as the engine sees it: one count per kind (swp_node_set_generic)
+    void pushGeneric(const NodeInfo& ni) {
+        std::vector<swp_generic> items;
+        for (const auto& kv : generic::counts(ni.availGeneric)) {
+            if (kv.second >= (1ll << 31)) unsupported("a generic resource count of 2^31 or more stays on the Go path");
+            items.push_back({intern(SWP_SPACE_GENERIC_KIND, kv.first), 0u, kv.second});
+        }
+        ck(swp_node_set_generic(e_, ni.idx, items.data(), (uint32_t)items.size()), "swp_node_set_generic");
+    }
     void commit(const NodeInfo& ni, const Value& t, bool counted, bool with_resources, bool add) {
         swp_placement p;
         std::memset(&p, 0, sizeof p);
@@ -977,8 +1010,16 @@ class Scheduler {
             }
             return false;
         }
-        ni.Tasks[id] = t;
+        // :128-137: a fresh AssignedGenericResources, then Claim against the node's available list
+        Value stored = t.shallow_copy();
+        generic::List assigned;
+        generic::claim(&ni.availGeneric, &assigned, generic::decode(at(&t, {"Spec", "Resources", "Reservations", "Generic"})));
+        stored.set("AssignedGenericResources", generic::encode(assigned));
+        ni.Tasks[id] = stored;
+        auto all = allTasks_.find(id);
+        if (all != allTasks_.end()) all->second = stored;   // (the reference writes through the one *api.Task both maps point to)
         commit(ni, t, ds <= COMPLETE, true, true);
+        pushGeneric(ni);
         return true;
     }
     // NodeInfo.removeTask, nodeinfo.go:66-104
@@ -988,6 +1029,13 @@ class Scheduler {
         const bool counted = task_state(old->second.get("DesiredState")) <= COMPLETE;
         ni.Tasks.erase(old);
         commit(ni, t, counted, true, false);
+        // :95-104: the task's AssignedGenericResources go back — unless the node's description lists no generic resources at all
+        bool desc_nil = true;
+        const generic::List node_res = generic::decode(at(&ni.node, {"Description", "Resources", "Generic"}), &desc_nil);
+        if (!desc_nil) {
+            generic::reclaim(&ni.availGeneric, generic::decode(t.get("AssignedGenericResources")), node_res);
+            pushGeneric(ni);
+        }
         return true;
     }
     // NodeInfo.taskFailed (+ cleanupFailures), nodeinfo.go:163-202
@@ -1072,12 +1120,23 @@ class Scheduler {
         status.set("State", Value::integer(ASSIGNED));
         status.set("Message", Value::str("scheduler assigned task to node"));
         newT.set("Status", status);
-        allTasks_[tid] = newT;
         auto ni = nodes_.find(nid);
         if (ni == nodes_.end()) fail(SWP_EINVAL, "engine placed a task on a node the nodeSet does not hold");
+        // nodeInfo.addTask(&newT) (:886-888): the counts moved on the device already; WHICH resources the task holds is decided here
+        const generic::List want = generic::decode(at(&t, {"Spec", "Resources", "Reservations", "Generic"}));
+        if (!want.empty()) {
+            generic::List assigned;
+            generic::claim(&ni->second.availGeneric, &assigned, want);
+            newT.set("AssignedGenericResources", generic::encode(assigned));
+            genericTouched_.insert(nid);   // pushed once the whole call's placements are booked (pushTouched): then the counts equal
+                                           // what the engine's own arithmetic left and the call changes nothing
+        }
+        allTasks_[tid] = newT;
         ni->second.Tasks[tid] = newT;
         lastDecisions_[tid] = PendingDecision{t, false};
-        decisions.push(decision(t, newT));
+        Value d = decision(t, newT);
+        if (!want.empty()) d.set("AssignedGenericResources", *newT.get("AssignedGenericResources"));
+        decisions.push(d);
     }
     // noSuitableNode, scheduler.go:928-971
     void noSuitableNode(const std::string& tid, const Value& t, const uint32_t* hist, Value& decisions) {
@@ -1189,7 +1248,16 @@ class Scheduler {
             if (out[i] >= 0) place(run[i].first, run[i].second, out[i], decisions);
             else noSuitableNode(run[i].first, run[i].second, &hist[i * SWP_NFILTERS], decisions);
         }
+        pushTouched();
     }
+    void pushTouched() {
+        for (const std::string& nid : genericTouched_) {
+            auto ni = nodes_.find(nid);
+            if (ni != nodes_.end()) pushGeneric(ni->second);
+        }
+        genericTouched_.clear();
+    }
+    std::set<std::string> genericTouched_;   // nodes whose available generic list place() changed during the current device call
 };
 
 }   // namespace swp

@@ -21,6 +21,7 @@ import re
 import numpy as np
 
 from . import abi
+from . import generic as gres
 
 DEFAULT_HOST = "cxx"   # "cxx" = swp::Scheduler inside libswp.so; "py" = the Python twin below (SWP_HOST overrides)
 
@@ -125,6 +126,7 @@ class PyHostScheduler:
         self.preassigned = set()
         self.all_tasks = {}
         self._desc_cache = {}
+        self._generic_touched = {}   # nodes whose available generic list _place changed during the current device call
 
     # ------------------------------------------------------------------------------ interning helpers
     def _folded(self, s):
@@ -196,15 +198,16 @@ class PyHostScheduler:
         ent = self.nodes.get(nid)
         res = _get(doc, "Description", "Resources")
         cpu = mem = 0
+        avail = []
         if res is not None:
-            if res.get("Generic"):
-                raise Unsupported("generic resources stay on the Go path")
             cpu, mem = int(res.get("NanoCPUs", 0) or 0), int(res.get("MemoryBytes", 0) or 0)
-            if ent is not None:
+            avail, _ = gres.decode(res.get("Generic"))
+            if ent is not None:   # :376-384: the reservations of the tasks already on the node, their generic resources taken out
                 for t in ent["tasks"].values():
                     c, m = self._reservations(t)
                     cpu -= c
                     mem -= m
+                    avail = gres.consume(avail, gres.decode(t.get("AssignedGenericResources"))[0])
         idx = self.e.intern(abi.SPACE_NODE_ID, nid)
         total = 0
         if ent is not None:
@@ -215,8 +218,36 @@ class PyHostScheduler:
             self.nodes[nid] = ent
             self.idx_to_id[idx] = nid
         ent["doc"] = doc
+        ent["generic"] = avail
         row, lab, elab, plugins = self._node_row(doc, idx, cpu, mem, total)
         self.e.node_upsert(row, lab, elab, plugins)
+        self._push_generic(ent)
+
+    def _push_generic(self, ent):
+        """the node's available generic list as the engine sees it: one count per kind (swp_node_set_generic)"""
+        items = []
+        for kind, c in gres.counts(ent["generic"]).items():
+            if c >= 1 << 31:
+                raise Unsupported("a generic resource count of 2^31 or more stays on the Go path")
+            items.append((self.e.intern(abi.SPACE_GENERIC_KIND, kind), c))
+        self.e.node_set_generic(ent["idx"], items)
+
+    @staticmethod
+    def _generic_reservations(t):
+        """What swp_generic_set takes: Discrete entries, one per kind, values >= 1, at most 8 kinds; anything else stays on the Go path."""
+        r, _ = gres.decode(_get(t, "Spec", "Resources", "Reservations", "Generic"))
+        if len(r) > 8:
+            raise Unsupported("more than 8 generic reservations in one task stay on the Go path")
+        kinds = set()
+        for named, kind, val in r:
+            if named:
+                raise Unsupported("a Named generic reservation stays on the Go path")
+            if val < 1:
+                raise Unsupported("a generic reservation below 1 stays on the Go path")
+            if kind in kinds:
+                raise Unsupported("a generic kind reserved twice stays on the Go path")
+            kinds.add(kind)
+        return r
 
     update_node = create_node
 
@@ -238,7 +269,7 @@ class PyHostScheduler:
             if c:
                 by_service[sid] = c
         return {"ID": nid, "ActiveTasksCount": row.total, "ActiveTasksCountByService": by_service,
-                "AvailableResources": {"NanoCPUs": row.cpu, "MemoryBytes": row.mem, "Generic": []},
+                "AvailableResources": {"NanoCPUs": row.cpu, "MemoryBytes": row.mem, "Generic": gres.encode(ent["generic"])},
                 "Tasks": sorted(ent["tasks"]),
                 "RecentFailures": {"%s@%d" % (sid, ver): len(ts) for (sid, ver), ts in ent["failures"].items()}}
 
@@ -275,8 +306,15 @@ class PyHostScheduler:
                 self.e.commit(self._placement(ent, t, True, with_resources=False), add=False)
                 return True
             return False
-        ent["tasks"][t["ID"]] = t
+        # :128-137: a fresh AssignedGenericResources, then Claim against the node's available list
+        stored = dict(t)
+        ent["generic"], assigned = gres.claim(ent["generic"], gres.decode(_get(t, "Spec", "Resources", "Reservations", "Generic"))[0])
+        stored["AssignedGenericResources"] = gres.encode(assigned)
+        ent["tasks"][t["ID"]] = stored
+        if t["ID"] in self.all_tasks:
+            self.all_tasks[t["ID"]] = stored   # (the reference writes through the one *api.Task both maps point to)
         self.e.commit(self._placement(ent, t, ds <= COMPLETE), add=True)
+        self._push_generic(ent)
         return True
 
     def _remove_task(self, ent, t):
@@ -285,6 +323,11 @@ class PyHostScheduler:
         if old is None:
             return False
         self.e.commit(self._placement(ent, t, _state(old.get("DesiredState")) <= COMPLETE), add=False)
+        # :95-104: the task's AssignedGenericResources go back — unless the node's description lists no generic resources at all
+        node_res, desc_nil = gres.decode(_get(ent["doc"], "Description", "Resources", "Generic"))
+        if not desc_nil:
+            ent["generic"] = gres.reclaim(ent["generic"], gres.decode(t.get("AssignedGenericResources"))[0], node_res)
+            self._push_generic(ent)
         return True
 
     def _task_failed(self, ent, t):
@@ -326,8 +369,7 @@ class PyHostScheduler:
     def _require_supported(t):
         """Tasks the engine cannot judge (generic resources, CSI cluster volumes) are refused at the event boundary —
         the shim leaves them to the Go scheduler's own path — so that a tick never meets one half-way through a batch."""
-        if _get(t, "Spec", "Resources", "Reservations", "Generic"):
-            raise Unsupported("generic resources stay on the Go path")
+        PyHostScheduler._generic_reservations(t)   # refuses what swp_generic_set would refuse
         host_ports = sum(1 for p in (_get(t, "Endpoint", "Ports") or []) if p.get("PublishMode") in (1, "HOST") and p.get("PublishedPort"))
         if host_ports > 32:
             raise Unsupported("more than 32 host-mode ports in one task stay on the Go path")   # swp_port_set's limit
@@ -467,12 +509,14 @@ class PyHostScheduler:
         d["service"] = self.e.intern(abi.SPACE_SERVICE, t.get("ServiceID", ""))
         res = _get(t, "Spec", "Resources", "Reservations")
         if res is not None:
-            if res.get("Generic"):
-                raise Unsupported("generic resources stay on the Go path")
             cpu, mem = int(res.get("NanoCPUs", 0) or 0), int(res.get("MemoryBytes", 0) or 0)
             d["cpu"], d["mem"] = cpu, mem
-            if cpu != 0 or mem != 0:   # ResourceFilter.SetTask, filter.go:61-74
+            any_generic = isinstance(res.get("Generic"), list) and len(res["Generic"]) > 0
+            if cpu != 0 or mem != 0 or any_generic:   # ResourceFilter.SetTask, filter.go:61-74
                 d["flags"] |= abi.TASK_RES_ENABLED
+            items = [(self.e.intern(abi.SPACE_GENERIC_KIND, kind), val) for _, kind, val in self._generic_reservations(t)]
+            if items:
+                d["generic_set"] = self.e.generic_set(items)
         if _state(t.get("DesiredState")) > COMPLETE:
             d["flags"] |= abi.TASK_UNCOUNTED
         pl = _get(t, "Spec", "Placement")
@@ -602,10 +646,26 @@ class PyHostScheduler:
         new_t = dict(t)
         new_t["NodeID"] = nid
         new_t["Status"] = {"State": ASSIGNED, "Message": "scheduler assigned task to node"}
+        # nodeInfo.addTask(&newT) (:886-888): the counts moved on the device already; WHICH resources the task holds is decided here
+        want, _ = gres.decode(_get(t, "Spec", "Resources", "Reservations", "Generic"))
+        ent = self.nodes[nid]
+        if want:
+            ent["generic"], assigned = gres.claim(ent["generic"], want)
+            new_t["AssignedGenericResources"] = gres.encode(assigned)
+            self._generic_touched[nid] = True   # pushed once the whole call's placements are booked (_push_touched)
         self.all_tasks[tid] = new_t
-        self.nodes[nid]["tasks"][tid] = new_t   # numeric addTask already happened on the device
+        ent["tasks"][tid] = new_t   # numeric addTask already happened on the device
         self.last_decisions[tid] = (t, False)
-        decisions.append(self._decision(t, new_t))
+        d = self._decision(t, new_t)
+        if want:
+            d["AssignedGenericResources"] = new_t["AssignedGenericResources"]
+        decisions.append(d)
+
+    def _push_touched(self):
+        for nid in sorted(self._generic_touched):
+            if nid in self.nodes:
+                self._push_generic(self.nodes[nid])
+        self._generic_touched = {}
 
     def _no_suitable_node(self, tid, t, hist, decisions):
         """noSuitableNode, scheduler.go:928-971."""
@@ -722,6 +782,7 @@ class PyHostScheduler:
                 self._place(tid, t, n, decisions)
             else:
                 self._no_suitable_node(tid, t, h, decisions)
+        self._push_touched()
 
     def tick(self):
         """scheduler.go:429-488: groups (ServiceID, SpecVersion) in first-seen order, then the one-off tasks in

@@ -28,9 +28,10 @@ struct swp_engine {
     std::vector<std::vector<std::string>> names = std::vector<std::vector<std::string>>(SWP_SPACE_COUNT);
     std::vector<std::map<std::string, uint32_t>> ids = std::vector<std::map<std::string, uint32_t>>(SWP_SPACE_COUNT);
     std::vector<FakeNode> nodes;
-    std::vector<std::string> sets[5];   // textual form of every registered predicate set: constraint, platform, plugin, port, spread
+    std::vector<std::string> sets[6];   // textual form of every registered predicate set: constraint, platform, plugin, port, spread, generic
     std::vector<std::vector<swp_port>> port_sets;
     std::string log;
+    bool generic_seen = false;
     std::string err;
     uint64_t counter = 0;
 
@@ -80,12 +81,13 @@ struct swp_engine {
         return present_cache;
     }
     std::string desc(const swp_task_desc& d) const {
-        char buf[512];
-        std::snprintf(buf, sizeof buf, "svc=%s flags=%u cpu=%lld mem=%lld con=%s plat=%s plug=%s port=%s maxrep=%llu ver=%llu spread=%s",
+        char buf[640];
+        std::snprintf(buf, sizeof buf, "svc=%s flags=%u cpu=%lld mem=%lld con=%s plat=%s plug=%s port=%s maxrep=%llu ver=%llu spread=%s generic=%s",
                       printable(name(SWP_SPACE_SERVICE, d.service)).c_str(), d.flags, (long long)d.cpu, (long long)d.mem,
                       d.constraint_set < sets[0].size() ? sets[0][d.constraint_set].c_str() : "?", d.platform_set < sets[1].size() ? sets[1][d.platform_set].c_str() : "?",
                       d.plugin_set < sets[2].size() ? sets[2][d.plugin_set].c_str() : "?", d.port_set < sets[3].size() ? sets[3][d.port_set].c_str() : "?",
-                      (unsigned long long)d.max_replicas, (unsigned long long)d.spec_version, d.spread_set < sets[4].size() ? sets[4][d.spread_set].c_str() : "?");
+                      (unsigned long long)d.max_replicas, (unsigned long long)d.spec_version, d.spread_set < sets[4].size() ? sets[4][d.spread_set].c_str() : "?",
+                      d.generic_set < sets[5].size() ? sets[5][d.generic_set].c_str() : "?");
         return buf;
     }
     void apply(uint32_t n, uint32_t service, int64_t cpu, int64_t mem, bool counted, bool add) {
@@ -262,6 +264,26 @@ int swp_spread_set(swp_engine* e, const swp_spread* lv, uint32_t n, uint32_t* id
     *id_out = n ? e->add_set(4, t) : 0;
     return SWP_OK;
 }
+int swp_generic_set(swp_engine* e, const swp_generic* items, uint32_t n, uint32_t* id_out) {
+    std::string t;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (items[i].value < 1) return SWP_EUNSUPPORTED;
+        t += "[" + e->name(SWP_SPACE_GENERIC_KIND, items[i].kind) + "=" + std::to_string(items[i].value) + "]";
+    }
+    *id_out = n ? e->add_set(5, t) : 0;
+    return SWP_OK;
+}
+int swp_node_set_generic(swp_engine* e, uint32_t node, const swp_generic* counts, uint32_t n) {
+    std::string t;
+    for (uint32_t i = 0; i < n; ++i) t += " " + e->name(SWP_SPACE_GENERIC_KIND, counts[i].kind) + "=" + std::to_string(counts[i].value);
+    if (n || e->generic_seen) e->say("node_set_generic %s%s", e->name(SWP_SPACE_NODE_ID, node).c_str(), t.c_str());   // (silent until a script uses generic resources)
+    if (n) e->generic_seen = true;
+    return SWP_OK;
+}
+int swp_node_get_generic(swp_engine*, uint32_t, uint32_t, int64_t* out) {
+    *out = 0;
+    return SWP_OK;
+}
 // failure injection for the host layer's error paths: a device call that carries a task of a service named "boom..." is
 // refused as a whole (nothing applied), the way the real engine refuses a group beyond its heap capacity
 static bool boom(const swp_engine* e, const swp_task_desc& d) { return e->name(SWP_SPACE_SERVICE, d.service).rfind("boom", 0) == 0; }
@@ -359,9 +381,9 @@ const char* swp_strerror(int code) {
 const char* swp_last_error(swp_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 int swp_abi_check(uint32_t* sizes, uint32_t n) {
     const uint32_t s[] = {sizeof(swp_config), sizeof(swp_node_row), sizeof(swp_kv), sizeof(swp_constraint), sizeof(swp_platform), sizeof(swp_port),
-                          sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t), sizeof(swp_spread)};
+                          sizeof(swp_task_desc), sizeof(swp_placement), sizeof(swp_stats_t), sizeof(swp_spread), sizeof(swp_generic)};
     uint32_t k = 0;
-    for (; k < n && k < 10; ++k) sizes[k] = s[k];
+    for (; k < n && k < 11; ++k) sizes[k] = s[k];
     return (int)k;
 }
 // test-only: the call log so far (and clear it)

@@ -1,0 +1,131 @@
+"""GPU: generic resources through the engine — ResourceFilter's generic half (filter.go:86-91, HasEnough
+validate.go:24-52) as demand-class rows of the block resolver, Claim (resource_management.go:11-72) in its apply step, the Explain
+verdict at the task's moment, taskFitNode's pair check; Reclaim / sanitize / which named values a task holds in the host layer.
+Seeded event scripts against the oracle: every tick's decisions (node, error string, state) and, after every step, every node's
+available generic LIST must agree. Both host layers."""
+import os
+import random
+
+import pytest
+
+import orc
+from swarmkit_amd import host as swhost
+
+pytestmark = pytest.mark.gpu
+GIB = 1 << 30
+KINDS = ["gpu", "fpga", "ssd"]
+
+
+@pytest.fixture(autouse=True, params=["cxx", "py"])
+def host_kind(request, monkeypatch):
+    monkeypatch.setenv("SWP_HOST", request.param)
+
+
+def node_doc(rng, i, scarce):
+    gen = []
+    for k in KINDS:
+        r = rng.random()
+        if r < 0.35:
+            gen.append({"Discrete": {"Kind": k, "Value": rng.randrange(1, 4 if scarce else 12)}})
+        elif r < 0.7:
+            gen.extend({"Named": {"Kind": k, "Value": "%s%d" % (k, q)}} for q in range(rng.randrange(1, 4 if scarce else 9)))
+    res = {"NanoCPUs": rng.choice([4, 8, 16]) * 10**9, "MemoryBytes": rng.choice([8, 16, 64]) * GIB}
+    if gen or rng.random() < 0.7:
+        res["Generic"] = gen
+    return {"ID": "n%04d" % i, "Spec": {"Annotations": {"Name": "node%d" % i, "Labels": {"zone": rng.choice("abc")}}, "Availability": 0},
+            "Status": {"State": orc.READY}, "Description": {"Hostname": "h%d" % i, "Resources": res}}
+
+
+def service_spec(rng):
+    res = {"NanoCPUs": rng.choice([0, 250, 1000]) * 10**6, "MemoryBytes": rng.choice([0, 256, 1024]) << 20}
+    if rng.random() < 0.75:
+        res["Generic"] = [{"Discrete": {"Kind": k, "Value": rng.randrange(1, 4)}} for k in rng.sample(KINDS, rng.randrange(1, 3))]
+    spec = {"Resources": {"Reservations": res}}
+    if rng.random() < 0.3:
+        spec["Placement"] = {"Constraints": ["node.labels.zone==%s" % rng.choice("abc")]}
+    if rng.random() < 0.15:
+        spec.setdefault("Placement", {})["MaxReplicas"] = rng.choice([1, 2])
+    return {"Spec": spec}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "24"))))
+def test_generic_event_scripts(seed):
+    rng = random.Random(0x6E0E + seed)
+    o, e = orc.Oracle(), swhost.HostScheduler()
+    both = (o, e)
+    n_nodes = rng.choice([1, 5, 40, 130, 700])
+    scarce = rng.random() < 0.6
+    nodes = {i: node_doc(rng, i, scarce) for i in range(n_nodes)}
+    for d in nodes.values():
+        for s in both:
+            s.create_node(d)
+    n_svc = rng.randrange(1, 10)
+    specs = [service_spec(rng) for _ in range(n_svc)]
+    for k in range(n_svc):
+        for s in both:
+            s.set_service("svc%02d" % k)
+    placed, docs, tid = {}, {}, 0
+
+    def same_lists():
+        for i in nodes:
+            nid = nodes[i]["ID"]
+            a, b = o.node_info(nid), e.node_info(nid)
+            assert a["AvailableResources"]["Generic"] == b["AvailableResources"]["Generic"], (seed, nid)
+            assert a["AvailableResources"]["NanoCPUs"] == b["AvailableResources"]["NanoCPUs"], (seed, nid)
+            assert a["ActiveTasksCount"] == b["ActiveTasksCount"], (seed, nid)
+
+    def tick():
+        de_raw = e.tick()
+        do = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in o.tick())
+        de = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in de_raw)
+        assert do == de, (seed, [(a, b) for a, b in zip(do, de) if a != b][:5])
+        for d in de_raw:
+            if d["NodeID"] and d["State"] >= orc.ASSIGNED:
+                placed[d["ID"]] = (d["NodeID"], d.get("AssignedGenericResources", []))
+        same_lists()
+
+    for rnd in range(rng.randrange(2, 6)):
+        for _ in range(rng.randrange(1, 4)):
+            k = rng.randrange(n_svc)
+            for _ in range(rng.choice([1, 3, 10, 40, 120])):
+                t = {"ID": "t%06d" % tid, "ServiceID": "svc%02d" % k, "DesiredState": orc.RUNNING, "Status": {"State": orc.PENDING}}
+                t.update(specs[k])
+                docs[t["ID"]] = t
+                for s in both:
+                    s.create_task(t)
+                tid += 1
+        tick()
+        for _ in range(rng.randrange(0, 5)):
+            act = rng.random()
+            if act < 0.55 and placed:     # a running task goes away: its resources come back (Reclaim + sanitize)
+                t = rng.choice(sorted(placed))
+                nid, assigned = placed.pop(t)
+                d = dict(docs[t], NodeID=nid, Status={"State": orc.RUNNING}, AssignedGenericResources=assigned)
+                for s in both:
+                    s.delete_task(d)
+            elif act < 0.8:               # the node's description changes under its tasks
+                i = rng.choice(sorted(nodes))
+                nodes[i] = node_doc(rng, i, scarce)
+                for s in both:
+                    s.update_node(nodes[i])
+            else:                         # drain / reactivate
+                i = rng.choice(sorted(nodes))
+                nodes[i] = dict(nodes[i], Spec=dict(nodes[i]["Spec"], Availability=rng.choice([0, 2])))
+                for s in both:
+                    s.update_node(nodes[i])
+            same_lists()
+    tick()
+
+
+def test_preassigned_task_is_checked_against_the_counts():
+    """taskFitNode (scheduler.go:646-654) for a task that arrives with its node: the pair check reads the device's counts."""
+    for s in (orc.Oracle(), swhost.HostScheduler()):
+        s.create_node({"ID": "n1", "Status": {"State": orc.READY}, "Spec": {"Availability": 0},
+                       "Description": {"Resources": {"NanoCPUs": 4 * 10**9, "MemoryBytes": 8 * GIB, "Generic": [{"Discrete": {"Kind": "gpu", "Value": 2}}]}}})
+        spec = {"Resources": {"Reservations": {"Generic": [{"Discrete": {"Kind": "gpu", "Value": 2}}]}}}
+        for tid in ("a", "b"):
+            s.create_task({"ID": tid, "NodeID": "n1", "DesiredState": orc.RUNNING, "Status": {"State": orc.PENDING}, "Spec": spec})
+        d = {x["ID"]: x for x in s.process_preassigned()}
+        assert d["a"]["State"] == orc.ASSIGNED
+        assert d["b"]["State"] == orc.PENDING and d["b"]["Err"] == "insufficient resources on 1 node"
+        assert s.node_info("n1")["AvailableResources"]["Generic"] == []

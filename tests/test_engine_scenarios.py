@@ -31,8 +31,11 @@ def test_no_ready_nodes():
     sc.scenario_no_ready_nodes(factory)
 
 
-def test_resource_constraint():
-    sc.scenario_resource_constraint(factory, with_generic=False)
+@pytest.mark.parametrize("with_generic", [False, True])
+def test_resource_constraint(with_generic):
+    """with_generic: the reference's own version (scheduler_test.go:1617-1775) — orange x 2 + apple x 2 against Named / Discrete node
+    resources; HasEnough as demand-class rows on the device, Claim in the apply step, the available LIST in the host layer."""
+    sc.scenario_resource_constraint(factory, with_generic=with_generic)
 
 
 def test_platform():
@@ -72,16 +75,19 @@ def test_faulty_node_spec_version():
     sc.scenario_faulty_node_spec_version(factory)
 
 
-def test_resource_constraint_ha():
-    sc.scenario_resource_constraint_ha(factory, with_generic=False)
+@pytest.mark.parametrize("with_generic", [False, True])
+def test_resource_constraint_ha(with_generic):
+    sc.scenario_resource_constraint_ha(factory, with_generic=with_generic)
 
 
-def test_resource_constraint_dead_task():
-    sc.scenario_resource_constraint_dead_task(factory, with_generic=False)
+@pytest.mark.parametrize("with_generic", [False, True])
+def test_resource_constraint_dead_task(with_generic):
+    sc.scenario_resource_constraint_dead_task(factory, with_generic=with_generic)
 
 
-def test_preexisting_dead_task():
-    sc.scenario_preexisting_dead_task(factory, with_generic=False)
+@pytest.mark.parametrize("with_generic", [False, True])
+def test_preexisting_dead_task(with_generic):
+    sc.scenario_preexisting_dead_task(factory, with_generic=with_generic)
 
 
 def test_unassigned_map():

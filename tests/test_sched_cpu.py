@@ -285,9 +285,13 @@ def test_cxx_host_error_behaviour():
     assert L.swp_sched_create_task(s.h, None, 0, C.byref(flag)) == abi.SWP_EINVAL
     assert L.swp_sched_node_info(s.h, b"nope", 4, C.byref(out)) == abi.SWP_ENOTFOUND      # errNodeNotFound
     generic = {"ID": "n1", "Description": {"Resources": {"NanoCPUs": 1, "Generic": [{"DiscreteResourceSpec": {"Kind": "gpu", "Value": 1}}]}}}
-    with pytest.raises(abi.Unsupported):
-        s.create_node(generic)
-    assert s.node_info("n1") is None                                                      # refused, not half-created
+    s.create_node(generic)                                                                # generic resources are mirrored as counts (round 3)
+    assert s.node_info("n1")["AvailableResources"]["Generic"] == [{"Discrete": {"Kind": "gpu", "Value": 1}}]
+    named = {"ID": "tg", "ServiceID": "svc", "DesiredState": 512, "Status": {"State": 64},
+             "Spec": {"Resources": {"Reservations": {"Generic": [{"Named": {"Kind": "gpu", "Value": "a"}}]}}}}
+    with pytest.raises(abi.Unsupported):                                                  # a Named reservation: HasEnough's error return, Go path
+        s.create_task(named)
+    s.delete_node("n1")
     with pytest.raises(abi.SwpError) as ei:                                               # enforcer on a node the nodeSet does not hold
         s.enforce([{"ID": "ghost", "Spec": {"Availability": 0}}], {"ghost": [{"ID": "t", "DesiredState": 512, "Status": {"State": 512}}]})
     assert ei.value.code == abi.SWP_ENOTFOUND
