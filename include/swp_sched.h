@@ -31,7 +31,8 @@ void swp_sched_destroy(swp_sched*);
 const char* swp_sched_last_error(swp_sched*);
 
 /* createOrUpdateNode (scheduler.go:368-396), reached from EventCreateNode / EventUpdateNode (:191-196) and
- * buildNodeSet (:973-990). node_json = api.Node. Generic resources → SWP_EUNSUPPORTED (node stays on the Go path). */
+ * buildNodeSet (:973-990). node_json = api.Node. Description.Resources.Generic is kept as the node's available LIST here
+ * (Claim / Reclaim / sanitize, api/genericresource) and mirrored into the engine as one count per kind (swp_node_set_generic). */
 int swp_sched_create_or_update_node(swp_sched*, const char* node_json, size_t len);
 /* EventDeleteNode → nodeSet.remove (scheduler.go:197-198, nodeset.go:46-48) */
 int swp_sched_delete_node(swp_sched*, const char* node_id, size_t len);
@@ -55,7 +56,7 @@ int swp_sched_delete_task(swp_sched*, const char* task_json, size_t len, int* ti
 
 /* tick (scheduler.go:429-488): task groups (ServiceID, SpecVersion) in first-seen order through swp_schedule_groups,
  * then the one-off tasks in queue order through swp_schedule_batch; left-overs through noSuitableNode (:928-971).
- * *decisions_json = JSON array of {ID, ServiceID, NodeID, State, Message, Err, OldState} — what
+ * *decisions_json = JSON array of {ID, ServiceID, NodeID, State, Message, Err, OldState[, AssignedGenericResources]} — what
  * applySchedulingDecisions (:490-643) would write to the store. */
 int swp_sched_tick(swp_sched*, const char** decisions_json);
 /* processPreassignedTasks + taskFitNode (scheduler.go:398-426, 646-690) through swp_check_node */
@@ -70,9 +71,24 @@ int swp_sched_process_preassigned(swp_sched*, const char** decisions_json);
  * own scheduleTaskGroup. */
 int swp_sched_reject_decision(swp_sched*, const char* task_id, size_t len, int* found);
 
+/* The commit path, minimal useful form. applySchedulingDecisions (scheduler.go:490-643) walks its decisions map in
+ * map order, looks the task's node up in the nodeSet and in the store for EVERY decision (:533-545: a node whose Meta.Version moved
+ * since the scheduler saw it fails the decision) and commits one task per batch.Update, 200 changes per store transaction
+ * (manager/state/store/memory.go:47). This call hands the decisions of the last swp_sched_tick / swp_sched_process_preassigned back
+ * in commit order: grouped by node (node index order), every group with the Meta.Version the scheduler's NodeInfo holds for that node
+ * (echoed from swp_node_row.version) — ONE version check per node — and cut into transactions of at most max_changes updates
+ * (0 = the store's 200). *plan_json = {"Nodes": [{"NodeID", "Version", "Tasks": [task ids]}...],
+ * "Unassigned": [ids of the decisions that name no node: "no suitable node" status updates], "Transactions": [[task ids]...]}. */
+int swp_sched_commit_plan(swp_sched*, uint32_t max_changes, const char** plan_json);
+/* swp_sched_reject_decision for a JSON array of task ids; *n_undone = how many had a decision to undo */
+int swp_sched_reject_decisions(swp_sched*, const char* ids_json, size_t len, uint32_t* n_undone);
+/* ... and for every decision of the last tick that landed on one node: what a failed version check (:540-545) means for the
+ * caller that checks per node */
+int swp_sched_reject_node(swp_sched*, const char* node_id, size_t len, uint32_t* n_undone);
+
 /* Pipeline.SetTask (pipeline.go:76-81) for one task: every Filter.SetTask (filter.go) translated into predicate-set
- * registrations; the descriptor is what swp_schedule_batch consumes. CSI cluster volumes / generic resources →
- * SWP_EUNSUPPORTED. */
+ * registrations; the descriptor is what swp_schedule_batch consumes. CSI cluster volumes, and generic reservations the engine
+ * does not take (Named, below 1, a kind twice, more than 8 kinds) → SWP_EUNSUPPORTED. */
 int swp_sched_task_desc(swp_sched*, const char* task_json, size_t len, swp_task_desc* out);
 /* ConstraintFilter.SetTask alone (filter.go:218-232): Placement.Constraints (JSON array of strings) → set id;
  * *set_out = 0 when the list is empty or constraint.Parse fails (the filter is then disabled, :223-229). */

@@ -719,6 +719,58 @@ class Scheduler {
         return true;
     }
 
+    // the commit path (include/swp_sched.h swp_sched_commit_plan): the last call's decisions in commit order
+    Value commitPlan(uint32_t max_changes) {
+        if (max_changes == 0) max_changes = 200;   // MaxChangesPerTransaction, manager/state/store/memory.go:47
+        std::map<uint32_t, std::vector<std::string>> by_node;   // engine node index -> task ids (map order: ascending id)
+        Value unassigned = Value::array();
+        for (const auto& kv : lastDecisions_) {
+            auto cur = allTasks_.find(kv.first);
+            const std::string nid = cur != allTasks_.end() ? as_str(cur->second.get("NodeID")) : std::string();
+            auto n = nid.empty() ? nodes_.end() : nodes_.find(nid);
+            if (n == nodes_.end()) unassigned.push(Value::str(kv.first));
+            else by_node[n->second.idx].push_back(kv.first);
+        }
+        Value nodes = Value::array(), txs = Value::array(), tx = Value::array();
+        auto add = [&](const std::string& tid) {
+            if (tx.size() == max_changes) {
+                txs.push(tx);
+                tx = Value::array();
+            }
+            tx.push(Value::str(tid));
+        };
+        for (const auto& kv : by_node) {
+            swp_node_row row;
+            ck(swp_node_get(e_, kv.first, &row), "swp_node_get");
+            Value g = Value::object(), ids = Value::array();
+            for (const std::string& tid : kv.second) {
+                ids.push(Value::str(tid));
+                add(tid);
+            }
+            g.set("NodeID", Value::str(idx_to_id_[kv.first]));
+            g.set("Version", Value::integer((int64_t)row.version));
+            g.set("Tasks", ids);
+            nodes.push(g);
+        }
+        for (const Value& v : *unassigned.a) add(v.s);
+        if (tx.size() > 0) txs.push(tx);
+        Value plan = Value::object();
+        plan.set("Nodes", nodes);
+        plan.set("Unassigned", unassigned);
+        plan.set("Transactions", txs);
+        return plan;
+    }
+    uint32_t rejectNode(const std::string& nid) {
+        std::vector<std::string> ids;
+        for (const auto& kv : lastDecisions_) {
+            auto cur = allTasks_.find(kv.first);
+            if (cur != allTasks_.end() && as_str(cur->second.get("NodeID")) == nid) ids.push_back(kv.first);
+        }
+        uint32_t n = 0;
+        for (const std::string& tid : ids) n += rejectDecision(tid) ? 1u : 0u;
+        return n;
+    }
+
     // ---------------------------------------------------------------------------------------------- constraint enforcer
     // constraintenforcer.rejectNoncompliantTasks for many nodes (constraint_enforcer.go:65-196) through swp_enforce.
     Value enforce(const Value& req) {
@@ -1380,6 +1432,32 @@ int swp_sched_reject_decision(swp_sched* s, const char* task_id, size_t len, int
         if (task_id == nullptr) return (int)SWP_EINVAL;
         const bool r = impl.rejectDecision(std::string(task_id, len));
         if (found != nullptr) *found = r ? 1 : 0;
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_commit_plan(swp_sched* s, uint32_t max_changes, const char** plan_json) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (plan_json == nullptr) return (int)SWP_EINVAL;
+        impl.scratch = swp::json::dump(impl.commitPlan(max_changes));
+        *plan_json = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_reject_decisions(swp_sched* s, const char* ids_json, size_t len, uint32_t* n_undone) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (ids_json == nullptr || n_undone == nullptr) return (int)SWP_EINVAL;
+        const swp::json::Value ids = swp::json::parse(ids_json, len);
+        if (!ids.is_arr()) swp::fail(SWP_EINVAL, "a JSON array of task ids is expected");
+        *n_undone = 0;
+        for (const swp::json::Value& v : *ids.a)
+            if (v.is_str() && impl.rejectDecision(v.s)) *n_undone += 1;
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_reject_node(swp_sched* s, const char* node_id, size_t len, uint32_t* n_undone) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (node_id == nullptr || n_undone == nullptr) return (int)SWP_EINVAL;
+        *n_undone = impl.rejectNode(std::string(node_id, len));
         return (int)SWP_OK;
     });
 }

@@ -718,6 +718,34 @@ class PyHostScheduler:
             self.unassigned[tid] = old
         return True
 
+    def commit_plan(self, max_changes=0):
+        """swp_sched_commit_plan: the last call's decisions grouped by node (node index order) with the node's Meta.Version, the
+        decisions that name no node, and transactions of at most max_changes (200) updates."""
+        max_changes = max_changes or 200
+        by_node, unassigned = {}, []
+        for tid in sorted(self.last_decisions):
+            nid = (self.all_tasks.get(tid) or {}).get("NodeID", "")
+            ent = self.nodes.get(nid) if nid else None
+            if ent is None:
+                unassigned.append(tid)
+            else:
+                by_node.setdefault(ent["idx"], []).append(tid)
+        nodes, order = [], []
+        for idx in sorted(by_node):
+            row = self.e.node_get(idx)
+            nodes.append({"NodeID": self.idx_to_id[idx], "Version": int(row.version), "Tasks": by_node[idx]})
+            order.extend(by_node[idx])
+        order.extend(unassigned)
+        txs = [order[i:i + max_changes] for i in range(0, len(order), max_changes)]
+        return {"Nodes": nodes, "Unassigned": unassigned, "Transactions": txs}
+
+    def reject_decisions(self, tids):
+        return sum(1 for t in tids if self.reject_decision(t))
+
+    def reject_node(self, nid):
+        ids = [tid for tid in sorted(self.last_decisions) if (self.all_tasks.get(tid) or {}).get("NodeID", "") == nid]
+        return sum(1 for t in ids if self.reject_decision(t))
+
     def _run_groups(self, groups, decisions):
         """groups: list of [(tid, task)...] sharing a spec; one swp_schedule_groups call, groups in order."""
         if not groups:

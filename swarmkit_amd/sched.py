@@ -116,6 +116,24 @@ class Scheduler:
         self._ck(self.L.swp_sched_reject_decision(self.h, b, len(b), C.byref(found)))
         return bool(found.value)
 
+    def commit_plan(self, max_changes=0):
+        """The last tick's decisions in commit order: grouped by node with the node's Meta.Version, cut into transactions
+        (applySchedulingDecisions, scheduler.go:490-643; 200 changes per store transaction)."""
+        return self._json_result(self.L.swp_sched_commit_plan, max_changes)
+
+    def reject_decisions(self, tids):
+        b = _b(json.dumps(list(tids)))
+        n = C.c_uint32(0)
+        self._ck(self.L.swp_sched_reject_decisions(self.h, b, len(b), C.byref(n)))
+        return n.value
+
+    def reject_node(self, nid):
+        """Every decision of the last tick that landed on `nid` is undone (a failed Meta.Version check, scheduler.go:540-545)."""
+        b = _b(nid)
+        n = C.c_uint32(0)
+        self._ck(self.L.swp_sched_reject_node(self.h, b, len(b), C.byref(n)))
+        return n.value
+
     def process_preassigned(self):
         return self._json_result(self.L.swp_sched_process_preassigned)
 

@@ -79,3 +79,49 @@ def test_rejected_decisions_are_rolled_back(host_kind, name, T, N, every):
     again = {d[0] for d in do2}
     assert {tid for tid, _ in rejected} <= again
     same_nodes(o, e, wl)
+
+
+def test_a_stale_node_version_fails_its_whole_group(host_kind):
+    """scheduler.go:533-545 through the commit plan: between the tick and the store commit two nodes were updated in the
+    store (their Meta.Version moved). The caller finds the mismatch ONCE per node in the plan, hands both groups back (reject_node), and
+    applies the node updates; the oracle gets the same story through its event handlers. Residuals and the next tick must agree."""
+    wl = synth.Workload("cfg3", T=2000, N=120)
+    o, e = orc.Oracle(), swhost.HostScheduler()
+    for s in (o, e):
+        for i in range(wl.N):
+            s.create_node(dict(wl.node_doc(i), Meta={"Version": {"Index": 10 + i}}))
+        for k in range(wl.S):
+            s.set_service(wl.service_id(k))
+        for j in range(wl.T):
+            s.create_task(wl.task_doc(j))
+    do, de = sorted(map(key, o.tick())), sorted(map(key, e.tick()))
+    assert do == de
+    plan = e.commit_plan()
+    assert all(g["Version"] == 10 + int(g["NodeID"][1:]) for g in plan["Nodes"])
+    assert all(len(tx) <= 200 for tx in plan["Transactions"])
+    store_version = {g["NodeID"]: g["Version"] for g in plan["Nodes"]}
+    moved = [plan["Nodes"][3], plan["Nodes"][17]]
+    for g in moved:
+        store_version[g["NodeID"]] += 1
+    placed = {tid: nid for tid, nid, err, st in do if nid}
+    for g in plan["Nodes"]:
+        if store_version[g["NodeID"]] == g["Version"]:
+            continue                                    # node unchanged: its whole group commits
+        assert e.reject_node(g["NodeID"]) == len(g["Tasks"])
+        for tid in g["Tasks"]:                          # (plan order == the order reject_node walks: ascending task id)
+            doc = wl.task_doc(int(tid[1:]))
+            o.delete_task(dict(doc, NodeID=placed[tid], Status={"State": orc.ASSIGNED}))
+            o.create_task(doc)
+    for g in moved:                                     # the node events that caused the mismatch arrive
+        i = int(g["NodeID"][1:])
+        doc = dict(wl.node_doc(i), Meta={"Version": {"Index": store_version[g["NodeID"]]}})
+        for s in (o, e):
+            s.update_node(doc)
+    same_nodes(o, e, wl)
+    do2, de2 = sorted(map(key, o.tick())), sorted(map(key, e.tick()))
+    assert do2 == de2
+    assert {t for g in moved for t in g["Tasks"]} <= {d[0] for d in do2}
+    plan2 = e.commit_plan()
+    assert {g["NodeID"]: g["Version"] for g in plan2["Nodes"] if g["NodeID"] in store_version and store_version[g["NodeID"]] != 10 + int(g["NodeID"][1:])} == \
+        {g["NodeID"]: store_version[g["NodeID"]] for g in plan2["Nodes"] if g["NodeID"] in {m["NodeID"] for m in moved}}
+    same_nodes(o, e, wl)

@@ -431,3 +431,47 @@ def test_reject_decision_rolls_a_placement_back():
             assert s.reject_decision("t2") is False        # the earlier tick's decisions are final
         logs.append((d, d2, log))
     assert logs[0] == logs[1]
+
+
+def test_commit_plan_groups_by_node_and_a_stale_node_is_rolled_back_once():
+    """SURVEY 8f-3, applySchedulingDecisions (scheduler.go:490-643). The plan hands the tick's decisions back grouped by node with the
+    Meta.Version the scheduler's NodeInfo holds (:540), cut into transactions of at most 200 updates (store/memory.go:47); a node whose
+    version moved in the store fails ALL its decisions (:533-545): reject_node undoes them in one call — NodeInfo.removeTask for each,
+    old task back in allTasks and on the queue — and the next tick sees them again. Both host layers make the same engine calls."""
+    logs = []
+    for s in _both_hosts():
+        for i in range(5):
+            s.create_node({"ID": "n%d" % i, "Meta": {"Version": {"Index": 100 + i}}, "Status": {"State": 2}, "Spec": {"Availability": 0},
+                           "Description": {"Resources": {"NanoCPUs": 64 * 10**9, "MemoryBytes": 2**40}}})
+        s.set_service("svc")
+        for j in range(450):
+            s.create_task(_task("t%03d" % j, "svc", Spec={"Resources": {"Reservations": {"NanoCPUs": 10**6}}}))
+        d = {x["ID"]: x for x in s.tick()}
+        plan = s.commit_plan()
+        placed = {tid: x["NodeID"] for tid, x in d.items() if x["NodeID"]}
+        # every decision appears exactly once, node groups in node order, each with the version the node document carried
+        assert sorted(t for g in plan["Nodes"] for t in g["Tasks"]) == sorted(placed)
+        assert sorted(plan["Unassigned"]) == sorted(set(d) - set(placed))
+        assert [g["NodeID"] for g in plan["Nodes"]] == sorted({n for n in placed.values()})
+        for g in plan["Nodes"]:
+            assert g["Version"] == 100 + int(g["NodeID"][1:]) and all(placed[t] == g["NodeID"] for t in g["Tasks"])
+        flat = [t for tx in plan["Transactions"] for t in tx]
+        assert flat == [t for g in plan["Nodes"] for t in g["Tasks"]] + plan["Unassigned"]
+        assert all(len(tx) <= 200 for tx in plan["Transactions"]) and len(plan["Transactions"]) == -(-len(d) // 200)
+        assert [len(tx) for tx in s.commit_plan(64)["Transactions"]][:-1] == [64] * (len(d) // 64)
+        # the store's copy of one node moved on: the version check fails once, for the whole group
+        stale = plan["Nodes"][0]
+        fakelib.take_log(s.e)
+        assert s.reject_node(stale["NodeID"]) == len(stale["Tasks"])
+        log = fakelib.take_log(s.e)
+        assert len(log) == len(stale["Tasks"]) and all("commit" in l and "remove" in l for l in log)
+        assert s.reject_node(stale["NodeID"]) == 0
+        info = s.node_info(stale["NodeID"])
+        assert not set(stale["Tasks"]) & set(info["Tasks"])
+        other = plan["Nodes"][1] if len(plan["Nodes"]) > 1 else None
+        if other:
+            assert s.reject_decisions(other["Tasks"][:3] + ["nope"]) == min(3, len(other["Tasks"]))
+        d2 = {x["ID"] for x in s.tick()}
+        assert set(stale["Tasks"]) <= d2
+        logs.append((plan, log))
+    assert logs[0] == logs[1]
