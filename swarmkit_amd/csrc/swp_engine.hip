@@ -175,6 +175,7 @@ struct swp_batch {
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
     DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
     DevBuf d_thr;                          // k_resolve5 exact mode: thresholds of the demand-class rows
+    DevBuf d_trows;                        // k_resolve6, task-rows mode: [block][n_words]
     DevBuf d_thr64, d_planes6, d_rr6, d_blk6;   // k_resolve6: raw thresholds, level planes, demand-class rows, control block
     // segments of the batch: runs of identical tasks (k_waterfill) and the stretches between them (the resolvers)
     struct Seg { uint32_t j0, n; bool run; };
@@ -1004,14 +1005,20 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     // SWP_RESOLVER=6 forces it at any size; SWP_R6_BLOCK sets the tasks per round.
     const char* env_blk = getenv("SWP_R6_BLOCK");
     uint32_t r6_block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
-    while (r6_block > 64 && r6_commit_lds_size(Wn, r6_block, b->n_dc + b->n_dm) > lds_budget) r6_block /= 2;   // the block's proposals are staged in LDS
-    const bool r6_ok = b->classes_ok && r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, b->n_dc + b->n_dm) <= lds_budget;
+    // demand-class rows patched by every commit while the batch has few distinct reservations; rows per task of the block, rebuilt
+    // every round from the exact residuals, when it has many (a commit would cross too many thresholds) — no limit then
+    const char* env_tr = getenv("SWP_R6_TASKROWS");
+    const bool r6_task_rows = env_tr ? atoi(env_tr) != 0 : (!b->classes_ok || b->n_dc + b->n_dm > 128);
+    const uint32_t r6_nrr = r6_task_rows ? 0u : b->n_dc + b->n_dm;
+    const bool r6_ok = r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, r6_nrr) <= lds_budget;
     if (b->has_generic) {   // generic reservations are rows of the block resolver only
-        if (!r6_ok) return e->fail(SWP_EUNSUPPORTED, "a batch with generic reservations needs the block resolver (more than 255 distinct cpu or memory reservations, or too many nodes)");
+        if (!r6_ok) return e->fail(SWP_EUNSUPPORTED, "a batch with generic reservations needs the block resolver: too many nodes for its LDS");
         variant = 6;
     }
     if (variant == 6 && !r6_ok) variant = 3;
     if (variant == 3 && !env_res && r6_ok) variant = 6;   // default beyond k_resolve5's reach
+    // more distinct reservations than k_resolve5 has LDS rows for: the block resolver keeps its rows in global memory
+    if (variant == 5 && !r5_exact && !env_res && !env_exact && r6_ok) variant = 6;
     if (variant != 5) r5_exact = false;
     if (variant == 5) {
         HIPCHECK(e, b->d_qres.reserve((size_t)N * 8));
@@ -1055,7 +1062,8 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     // The device advances on its own (the position lives in the control block); the host only learns every so many rounds how far it is.
     auto run_blocks = [&](uint32_t start, uint32_t end) -> int {
         HIPCHECK(e, b->d_planes6.reserve((size_t)R6_NP * Wn * 8));
-        HIPCHECK(e, b->d_rr6.reserve((size_t)std::max<uint32_t>(b->n_dc + b->n_dm, 1) * Wn * 8));
+        HIPCHECK(e, b->d_rr6.reserve((size_t)std::max<uint32_t>(r6_nrr, 1) * Wn * 8));
+        if (r6_task_rows) HIPCHECK(e, b->d_trows.reserve((size_t)r6_block * Wn * 8));
         HIPCHECK(e, b->d_blk6.reserve(sizeof(Blk6)));
         HIPCHECK(e, b->d_prop.reserve((size_t)r6_block * sizeof(R6Prop)));
         if (prof)
@@ -1069,8 +1077,10 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         ra.n_words = Wn;
         ra.xs = Wn;
         ra.block = r6_block;
-        ra.n_dc = b->n_dc;
-        ra.n_dm = b->n_dm;
+        ra.n_dc = r6_task_rows ? 0u : b->n_dc;
+        ra.n_dm = r6_task_rows ? 0u : b->n_dm;
+        ra.task_rows = r6_task_rows ? 1u : 0u;
+        ra.trows = r6_task_rows ? b->d_trows.as<u64>() : nullptr;
         ra.dbg = dbg_bits;
         ra.valid = e->d_valid.as<u64>();
         ra.sc = b->d_sc.as<u64>();

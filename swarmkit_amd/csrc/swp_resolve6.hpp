@@ -61,7 +61,8 @@ static_assert(sizeof(R6Prop) == 8 + 16 * R6_CAND + 24, "R6Prop layout");
 struct R6Args {
     u32 n_nodes, n_words, xs, block;
     u32 n_dc, n_dm;
-    u32 dbg, pad0;           // timing experiments only (env SWP_DBG); 0 in production
+    u32 dbg;                 // timing experiments only (env SWP_DBG); 0 in production
+    u32 task_rows;           // != 0: ResourceFilter rows per TASK of the block, rebuilt every round (k_r6_taskrows), instead of per demand class
     const u64* valid;        // [n_words]
     const u64* sc;           // [n_sc][n_words]
     u64* X;                  // [n_svc][xs]
@@ -89,6 +90,7 @@ struct R6Args {
     const i64* thr;          // [n_dc + n_dm] the distinct cpu reservations (ascending), then the memory ones
     Blk6* blk;
     R6Prop* prop;            // [block]
+    u64* trows;              // [block][n_words] task_rows mode: {cpu residual >= the task's NanoCPUs && memory residual >= its MemoryBytes}
     // generic reservations (filter.go:86-91, validate.go:24-52): n_rg more demand-class rows, rg[r] = {count[rg_kind[r]] >= rg_val[r]},
     // sorted by (kind, value); a task's set (tg[task] -> gs_off / gs_row) names its rows. n_rg == 0: none of the pointers is read.
     u32 n_rg, gstride;       // rows; node stride of gcnt
@@ -170,6 +172,46 @@ WV_KERNEL(256) void k_r6_rows(R6Args a) {
     }
 }
 
+// ---- task rows: ResourceFilter.Check (filter.go:77-84) of every task of the coming block against the residuals as they are ------
+// A batch whose tasks carry hundreds of distinct reservations (every service its own NanoCPUs / MemoryBytes) would make every commit
+// cross hundreds of demand-class thresholds. For such a batch the rows are not kept per class and patched by the commits but built
+// per task at the start of every round, from the exact residuals: one wave per node word (a ballot IS a row word), the block's
+// reservations staged in LDS. No limit on the number of distinct reservations.
+WV_KERNEL(256) void k_r6_taskrows(R6Args a) {
+    const u32 pos = wv::uload(&a.blk->pos), end = wv::uload(&a.blk->end);
+    if (pos >= end || wv::uload(&a.blk->error) != ERR_NONE) return;
+    const u32 cnt = min(a.block, end - pos);
+    i64* res = reinterpret_cast<i64*>(wv::lds());   // [block][2], a task without the filter: (INT64_MIN, INT64_MIN): every node passes
+    for (u32 j = wv::tid(); j < cnt; j += 256) {
+        const RTask* rt = a.rt + pos + j;
+        const bool on = (rt->flags & RT_RES) != 0;
+        res[2 * j] = on ? rt->cpu : (i64)0x8000000000000000ull;
+        res[2 * j + 1] = on ? rt->mem : (i64)0x8000000000000000ull;
+    }
+    wv::barrier();
+    const u32 w = wv::block() * 4 + wv::wave(), lane = wv::lane();
+    if (w >= a.n_words) return;
+    const u32 n = w * 64 + lane;
+    const bool in = n < a.n_nodes;
+    const i64 qc = in ? a.cpu[n] : 0, qm = in ? a.mem[n] : 0;
+    const u64 inmask = wv::ballot(in);
+    // lanes = 64 tasks of the block at a time, the word's 64 residual pairs walked on the scalar side: ten instructions per (node, 64
+    // tasks) and one store per lane and group, instead of a ballot and a one-lane store per task
+    for (u32 g0 = 0; g0 < cnt; g0 += 64) {
+        const u32 j = g0 + lane;
+        const bool have = j < cnt;
+        const i64 rc = have ? res[2 * j] : 0, rm = have ? res[2 * j + 1] : 0;
+        u32 lo = 0, hi = 0;
+        for (u32 i = 0; i < 32; ++i) {
+            const i64 c0 = (i64)wv::readlane64((u64)qc, i), m0 = (i64)wv::readlane64((u64)qm, i);
+            const i64 c1 = (i64)wv::readlane64((u64)qc, i + 32), m1 = (i64)wv::readlane64((u64)qm, i + 32);
+            if (rc <= c0 && rm <= m0) lo |= 1u << i;
+            if (rc <= c1 && rm <= m1) hi |= 1u << i;
+        }
+        if (have) a.trows[(size_t)j * a.n_words + w] = (((u64)hi << 32) | lo) & inmask;
+    }
+}
+
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
 // The waves split the task's node words (wave v owns the chunks of 64 words k = v, v + R6_PW, ...): the passes are latency-bound,
 // so more waves per task is what shortens them. A pass ends with one barrier (has any wave a candidate left?).
@@ -188,8 +230,9 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
     const u64* scrow = a.sc + (size_t)scid * Wn;
     const u64* xrow = a.X + (size_t)svc * a.xs;
     const bool res = (flags & RT_RES) != 0;
-    const u64* rc = a.rr + (size_t)((flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * Wn;
-    const u64* rm = a.rr + (size_t)(a.n_dc + ((flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * Wn;
+    // the two demand-class rows of the task — or, in task-rows mode, its own row of this round (twice)
+    const u64* rc = a.task_rows ? a.trows + (size_t)wv::block() * Wn : a.rr + (size_t)((flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * Wn;
+    const u64* rm = a.task_rows ? rc : a.rr + (size_t)(a.n_dc + ((flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * Wn;
     u32 p0 = 0, p1 = 0;
     if (flags & RT_PORTS) {
         p0 = wv::uload(a.pset_off + pset);
@@ -338,6 +381,17 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
         out->exc_entry = gentry;
         out->flags = (flags & RT_UNCOUNTED) ? 1u : 0u;
     }
+}
+
+// index of the first of n ascending thresholds that is greater than q (n: none)
+WV_DEV u32 r6_first_above(const i64* thr, u32 n, i64 q) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (thr[mid] > q) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
 }
 
 // ---- commit: match the block in task order (wave 0), then apply the accepted picks (all threads) ---------------------------
@@ -513,13 +567,16 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             const i64 qc = a.cpu[nd] - r.cpu, qm = a.mem[nd] - r.mem;
             const u32 old = a.total[nd];
             const int32_t prev = a.last[nd];
+            // the node leaves the demand-class rows whose threshold lies in (new residual, old residual]: the rows above the old
+            // residual never held it. Thresholds ascend; a batch may have thousands of them, so the upper end is found by bisection.
             if (r.cpu) {
                 a.cpu[nd] = qc;
-                for (int c = (int)a.n_dc - 1; c >= 0 && thr[c] > qc; --c) wv::g_andn64(a.rr + (size_t)c * Wn + w, bit);
+                for (int c = (int)r6_first_above(thr, a.n_dc, qc + r.cpu) - 1; c >= 0 && thr[c] > qc; --c) wv::g_andn64(a.rr + (size_t)c * Wn + w, bit);
             }
             if (r.mem) {
                 a.mem[nd] = qm;
-                for (int c = (int)a.n_dm - 1; c >= 0 && thr[a.n_dc + c] > qm; --c) wv::g_andn64(a.rr + (size_t)(a.n_dc + c) * Wn + w, bit);
+                for (int c = (int)r6_first_above(thr + a.n_dc, a.n_dm, qm + r.mem) - 1; c >= 0 && thr[a.n_dc + c] > qm; --c)
+                    wv::g_andn64(a.rr + (size_t)(a.n_dc + c) * Wn + w, bit);
             }
             if (r.flags & RT_PORTS)
                 for (u32 q = a.pset_off[r.pset]; q < a.pset_off[r.pset + 1]; ++q) wv::g_or64(a.portmap + (size_t)a.pset_ids[q] * Wn + w, bit);

@@ -28,11 +28,11 @@ typedef uint32_t u32;
 #define RT_PORTS 0x2u      // host-port filter enabled
 #define RT_MAXREP 0x4u     // max-replicas filter enabled
 #define RT_UNCOUNTED 0x8u  // DesiredState > COMPLETED: placement does not bump the task counts
-// k_resolve5, exact mode: the task's demand classes (index into the batch's sorted distinct cpu / memory reservations,
-// ResolveArgs.thr) ride in the flag word. Meaningful only with RT_RES.
+// The task's demand classes (index into the batch's sorted distinct cpu / memory reservations: ResolveArgs.thr in k_resolve5's
+// exact mode, R6Args.thr in the block resolver) ride in the flag word. Meaningful only with RT_RES.
 #define RT_DC_SHIFT 8
-#define RT_DM_SHIFT 16
-#define RT_DCLS_MASK 0xFFu
+#define RT_DM_SHIFT 20
+#define RT_DCLS_MASK 0xFFFu   // 12 bits each: up to 4 095 distinct cpu and 4 095 distinct memory reservations per batch
 
 #define LIST_EMPTY 0xFFFFFFFFu
 #define KEY_NONE 0xFFFFFFFFFFFFFFFFull

@@ -50,6 +50,9 @@ CONFIGS = {
     "cfg2": dict(cfg=2, T=10_000, N=1_000, services=None, resources=True, constraints=False, platforms=False, extras=False),
     "cfg3": dict(cfg=3, T=100_000, N=10_000, services=None, resources=True, constraints=True, platforms=True, extras=False),
     "cfg4": dict(cfg=4, T=1_000_000, N=100_000, services=None, resources=True, constraints=True, platforms=True, extras=True),
+    # cfg3 with every service picking its own NanoCPUs / MemoryBytes (hundreds of distinct reservations per batch instead of 4 + 5:
+    # what real services do). Same nodes, constraints and platforms as cfg3 (same seed).
+    "cfg3m": dict(cfg=3, T=100_000, N=10_000, services=None, resources=True, constraints=True, platforms=True, extras=False, many_reservations=True),
 }
 
 
@@ -113,6 +116,9 @@ class Workload:
         self.svc_cpu = CPU_TASK[pick(s, 11, S, 4)] if f["resources"] else np.zeros(S, dtype=np.int64)
         self.svc_mem = MEM_TASK[pick(s, 12, S, 5)] if f["resources"] else np.zeros(S, dtype=np.int64)
         idx = np.arange(S)
+        if f.get("many_reservations"):   # 0.25 .. 2 cores in steps of a millicore, 256 MiB .. 4 GiB in steps of a MiB: (almost) every service its own pair
+            self.svc_cpu = (250 + (idx * 7919) % 1751).astype(np.int64) * 1_000_000
+            self.svc_mem = (256 + (idx * 104_729) % 3841).astype(np.int64) * MIB
         self.svc_zone = np.where(percent(s, 13, S) < 50, idx % 10, -1) if f["constraints"] else np.full(S, -1)
         self.svc_nohdd = (percent(s, 14, S) < 30) if f["constraints"] else np.zeros(S, dtype=bool)
         pp = percent(s, 15, S)

@@ -6,6 +6,7 @@ set_service / create_task / delete_task / tick — orc.Oracle and swarmkit_amd.h
 methods) and folds every tick's decisions into SHA-256 digests, so both sides run EXACTLY the same protocol.
 
   cfg4_full     BASELINE.json configs[3]: 1M one-off tasks x 100k nodes, every filter (synth cfg4)
+  cfg3m_*       cfg3's cluster with hundreds of distinct reservations per batch (synth cfg3m): the demand-class rows of the block resolver
   cfg5_churn    BASELINE.json configs[4]: 100k tasks x 10k nodes placed, then 100 rounds of {reactivate the previous
                 round's drained nodes, drain 10 % of the nodes, delete the tasks on them, create as many new tasks, tick}
   refbench_*    the reference's own benchmark shape, benchScheduler (manager/scheduler/scheduler_test.go:3375-3465,
@@ -28,8 +29,8 @@ def tick_digest(decisions):
 
 
 # ------------------------------------------------------------------------------------------------ cfg4
-def run_cfg4(s, T=None, N=None):
-    wl = synth.Workload("cfg4", T=T, N=N)
+def run_cfg4(s, T=None, N=None, name="cfg4"):
+    wl = synth.Workload(name, T=T, N=N)
     for i in range(wl.N):
         s.create_node(wl.node_doc(i))
     for k in range(wl.S):
@@ -37,7 +38,7 @@ def run_cfg4(s, T=None, N=None):
     for j in range(wl.T):
         s.create_task(wl.task_doc(j))
     h, placed = tick_digest(s.tick())
-    return {"case": "cfg4", "T": wl.T, "N": wl.N, "seed": hex(wl.seed), "ticks": [h], "placed": [placed]}
+    return {"case": name, "T": wl.T, "N": wl.N, "seed": hex(wl.seed), "ticks": [h], "placed": [placed]}
 
 
 # ------------------------------------------------------------------------------------------------ cfg5
@@ -124,6 +125,10 @@ def run_refbench(s, nodes, tasks, net):
 CASES = {
     "cfg4_full": lambda s: run_cfg4(s),
     "cfg4_mid": lambda s: run_cfg4(s, T=200_000, N=40_000),
+    # cfg3 with (almost) every service its own reservation pair: 1 000 / 1 750 distinct cpu and 1 000 / 2 000 distinct memory values per batch
+    "cfg3m_full": lambda s: run_cfg4(s, T=100_000, N=10_000, name="cfg3m"),
+    "cfg3m_mid": lambda s: run_cfg4(s, T=200_000, N=40_000, name="cfg3m"),
+    "cfg3m_small": lambda s: run_cfg4(s, T=6_000, N=700, name="cfg3m"),
     "cfg5_churn": lambda s: run_churn(s),
     "cfg5_churn_small": lambda s: run_churn(s, T0=5_000, N=500, rounds=12, services=50),
     "cfg5_churn_mid": lambda s: run_churn(s, T0=20_000, N=2_000, rounds=100, services=200),   # all 100 rounds, a fifth of the cluster

@@ -24,10 +24,11 @@ int main(int argc, char** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
-    bool verbose = false, split = false;
+    bool verbose = false, split = false, task_rows = false;
     for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 's') split = true;
+        if (argv[i][0] == 't') task_rows = true;   // rows per task of the block, rebuilt every round, instead of demand-class rows
     }
     Problem p = make_problem(seed, N, T, S, order, feat);
     // demand classes over the raw reservations (what the engine's batch preparation does)
@@ -38,12 +39,13 @@ int main(int argc, char** argv) {
     std::vector<i64> thr;
     std::map<i64, u32> ic, im;
     for (i64 v : sc) { ic[v] = (u32)thr.size(); thr.push_back(v); }
-    const u32 n_dc = (u32)sc.size();
+    u32 n_dc = (u32)sc.size();
     for (i64 v : sm) { im[v] = (u32)thr.size() - n_dc; thr.push_back(v); }
-    const u32 n_dm = (u32)sm.size();
+    u32 n_dm = (u32)sm.size();
     for (RTask& r : p.rt)
         if (r.flags & RT_RES) r.flags |= (ic[r.cpu] << RT_DC_SHIFT) | (im[r.mem] << RT_DM_SHIFT);
 
+    if (task_rows) n_dc = n_dm = 0;
     State ref = initial_state(p), em = initial_state(p);
     std::vector<u64> F;
     scan_window(p, ref, 0, T, F);
@@ -86,6 +88,9 @@ int main(int argc, char** argv) {
     a.thr = thr.data();
     a.blk = &blk;
     a.prop = prop.data();
+    std::vector<u64> trows((size_t)B * p.Wn, 0x7777777777777777ull);
+    a.task_rows = task_rows ? 1u : 0u;
+    a.trows = trows.data();
     std::vector<u64> rg((size_t)std::max<size_t>(p.rg_kind.size(), 1) * p.Wn, 0x3333333333333333ull);
     if (!p.rg_kind.empty()) {   // feature level 3: generic reservations
         a.n_rg = (u32)p.rg_kind.size();
@@ -114,6 +119,7 @@ int main(int argc, char** argv) {
         while (blk.pos < blk.end) {
             const u32 before = blk.pos;
             for (R6Prop& q : prop) memset(&q, 0xEE, sizeof q);
+            if (task_rows) grid((p.Wn + 3) / 4, 256, (size_t)B * 16, [a]() { k_r6_taskrows(a); });
             grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
             grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
             ++rounds;

@@ -40,12 +40,15 @@ CASES = [
     (8, 885, 1500, 125, 64, 2, 3, ""),
     (9, 300, 1500, 6, 512, 1, 3, ""),        # ... with the exception lists deciding: HasEnough per listed node
     (10, 3000, 2500, 300, 512, 0, 3, "s"),
+    (2, 700, 3000, 30, 128, 0, 1, "t"),      # task-rows mode: ResourceFilter rows per task of the block, rebuilt every round (k_r6_taskrows)
+    (4, 5000, 3000, 300, 256, 0, 2, "st"),
+    (8, 885, 1500, 125, 64, 2, 3, "t"),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d-N%d-B%d-f%d%s" % (c[0], c[1], c[4], c[6], c[7]))
 def test_block_resolver_source_matches_sequential_model(emu_bin, case):
-    args = [str(x) for x in case[:7]] + ["v"] + ([case[7]] if case[7] else [])
+    args = [str(x) for x in case[:7]] + ["v"] + list(case[7])
     r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr

@@ -5,7 +5,10 @@ SHA-256 decision digest and assignment count:
   cfg4 (BASELINE.json configs[3], every filter incl. HostPort / MaxReplicas / Plugin) at 200k x 40k, cfg5 churn (configs[4]: drain
   10 % of the nodes, delete their tasks, re-place, round after round) over all 100 rounds at 20k x 2k and 12k x 2k and in miniature,
   and the reference's own benchmark shape (benchScheduler, manager/scheduler/scheduler_test.go:3375-3465: ONE service for 100k
-  tasks, every third node with the Network plugin). The scripts at the full BASELINE size: tests/test_zz_baseline_size_scripts.py.
+  tasks, every third node with the Network plugin), and cfg3's cluster with (almost) every service its own reservation pair (cfg3m:
+  1 000 + 1 000 distinct values at 100k x 10k, 1 751 + 2 000 at 200k x 40k — through the default dispatch, which hands such a batch
+  to the block resolver: its demand-class rows live in global memory). The scripts at the full BASELINE size:
+  tests/test_zz_baseline_size_scripts.py.
 
 A case whose digest file has not been generated yet is skipped, not passed."""
 import json
@@ -20,9 +23,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # The cases whose digest AND engine side finish within seconds. The scripts at the full BASELINE size (cfg4 at 1M x 100k, the churn
-# at 60k / 100k x 10k) live in tests/test_zz_baseline_size_scripts.py: the last file of the suite, because their digests were
-# finished when this round's GPU budget was spent and they have not run on a GPU yet.
-CASES = ["refbench_small", "cfg5_churn_small", "cfg5_churn_12k", "cfg5_churn_mid", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid"]
+# at 60k / 100k x 10k: minutes of host-layer work each) live in tests/test_zz_baseline_size_scripts.py, the last file of the suite.
+CASES = ["refbench_small", "cfg5_churn_small", "cfg5_churn_12k", "cfg5_churn_mid", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid",
+         "cfg3m_small", "cfg3m_full", "cfg3m_mid"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -31,7 +34,10 @@ def test_big_case_matches_oracle_digests(case):
     if not os.path.exists(path):
         pytest.skip("no oracle digest for %s yet (tests/golden/make_golden_big.py %s)" % (case, case))
     want = json.load(open(path))
-    got = bigcases.CASES[case](swhost.HostScheduler())
+    sched = swhost.HostScheduler()
+    got = bigcases.CASES[case](sched)
+    if case.startswith("cfg3m"):   # hundreds of distinct reservations: the default dispatch is the block resolver, not a round-1 fall-back
+        assert sched.e.stats()["last_resolver"] == 6
     assert got["placed"] == want["placed"]
     bad = [i for i, (a, b) in enumerate(zip(got["ticks"], want["ticks"])) if a != b]
     assert not bad, "tick digests differ at ticks %s" % bad[:10]

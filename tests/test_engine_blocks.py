@@ -99,3 +99,12 @@ def test_level_spread_needs_more_than_eight_planes(env):
         do = sorted((d["ID"], d["NodeID"], d["Err"]) for d in o.tick())
         de = sorted((d["ID"], d["NodeID"], d["Err"]) for d in e.tick())
         assert do == de
+
+
+@pytest.mark.parametrize("T,N,S", [(6000, 700, 1500), (3000, 13000, 900), (5000, 300, 4000)])
+def test_many_distinct_reservations_go_to_the_block_resolver(T, N, S):
+    """Every service its own NanoCPUs / MemoryBytes pair (synth cfg3m): far more demand classes than k_resolve5 has LDS rows for. No
+    knob set: the batch must run through the block resolver (rows in global memory, class indices of 12 bits, the apply step bisects
+    the thresholds a commit crosses) — not through a round-1 fall-back — and agree with the oracle."""
+    s = run_both(synth.Workload("cfg3m", T=T, N=N, services=S))
+    assert s.e.stats()["last_resolver"] == 6
