@@ -6,7 +6,7 @@ A "step" = one full pass of the hot path over one batch of synthetic pending tas
 (BASELINE.json configs[2]: 100k one-off tasks x 10k nodes, Resource + Constraint + Platform
 filters, spread strategy), starting from the same cluster state every step, with the node rows and
 task descriptors already resident in HBM. Inside the timed region, per step:
-    device state restore (3 small D2D copies) -> class bitmaps -> [scan -> resolve/commit] per window
+    device state restore (3 small D2D copies) -> class bitmaps -> resolve/commit (k_resolve5: one launch; k_resolve6: rounds)
     -> explain pass -> placements copied back to the host (400 KB).
 Host-side descriptor building / interning (what the Go shim does while it enqueues tasks) is
 outside the timed region; its cost and the PCIe-inclusive rate are reported in DESIGN.md.
@@ -23,11 +23,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-ROW_B = {"cfg2": 32, "cfg3": 48, "cfg4": 64}   # algorithmic node-row bytes per (task,node) pair, SURVEY.md §8a
+ROW_B = {"cfg2": 32, "cfg3": 48, "cfg3m": 48, "cfg4": 64}   # algorithmic node-row bytes per (task,node) pair, SURVEY.md §8a
 TASK_B = 64 + 8                # descriptor + result per task, SURVEY.md §8d
 
 
-RESOLVER_NAMES = {105: "k_resolve5<exact>", 5: "k_resolve5<scan>", 6: "k_resolve6 (rounds of k_r6_propose + k_r6_commit; one 'launch' = the whole batch)", 3: "k_resolve3", 2: "k_resolve2", 1: "k_resolve1", 0: "k_resolve"}
+RESOLVER_NAMES = {105: "k_resolve5", 6: "k_resolve6 (rounds of k_r6_propose + k_r6_commit; one 'launch' = the whole batch)"}
+SHADER_GHZ = 2.4               # MI355X peak engine clock, /opt/skills/guides/MI355X_MICROARCH.md: cycles_per_task is quoted at this clock
 FILTERS = {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filters",
            "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}
 
@@ -417,12 +418,11 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    ms_scan = ms_resolve = ms_explain = ms_classes = ms_dev = 0.0
+    ms_resolve = ms_explain = ms_classes = ms_dev = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, _ = step()
         st = eng.stats()
-        ms_scan += st["ms_scan"]
         ms_resolve += st["ms_resolve"]
         ms_explain += st["ms_explain"]
         ms_classes += st["ms_classes"]
@@ -457,7 +457,7 @@ def main():
     res_launch_ms = ms_resolve / K / windows
     alg_bytes_launch = alg_bytes_step / windows
     achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0
-    kernel = RESOLVER_NAMES.get(int(st.get("last_resolver", 3)), "k_resolve")
+    kernel = RESOLVER_NAMES.get(int(st.get("last_resolver", 105)), "k_resolve5")
     traffic, traffic_src = profile_traffic(kernel)
 
     result = {
@@ -487,17 +487,17 @@ def main():
                               "measurement error); the rounds are bound by one wave's instruction issue in k_r6_commit" if kernel.startswith("k_resolve6") else
                               "algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the resolver decides from bitmaps held in LDS, so its real HBM "
                               "traffic is far below that (see traffic): the kernel is bound by one workgroup's instruction issue, not by HBM")},
-        "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_scan": ms_scan / K, "k_resolve": ms_resolve / K,
-                                "k_explain": ms_explain / K, "device_total": ms_dev / K},
-        "scan": ({"kernel": "k_scan", "ms_per_step": ms_scan / K, "algorithmic_GBs": alg_bytes_step / (ms_scan / K * 1e-3) / 1e9,
-                  "note": "node rows are re-used from registers across 64 tasks, so the algorithmic figure exceeds the HBM peak; real traffic is ~1 bit per pair"}
-                 if ms_scan / K > 0.05 else {"kernel": None, "note": "no scan pass: k_resolve5's exact mode evaluates the ResourceFilter as membership in demand-class rows kept in LDS"}),
+        "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_resolve": ms_resolve / K, "k_explain": ms_explain / K, "device_total": ms_dev / K},
+        # what really bounds the resolver: the instruction issue of ONE wavefront (the matcher's dependent chain), not bytes
+        "resolver": {"kernel": kernel.split(" ")[0], "ms_per_step": ms_resolve / K, "cycles_per_task": ms_resolve / K * 1e-3 * SHADER_GHZ * 1e9 / wl.T,
+                     "clock_GHz": SHADER_GHZ, "measured_HBM_GBs": (traffic * windows / (ms_resolve / K * 1e-3) / 1e9) if traffic else None,
+                     "note": "cycles of the matching wave's CU per task of the batch, at the peak engine clock; measured_HBM_GBs = PMC bytes per launch (roofline.traffic) / launch time"},
         "whole_job_algorithmic_GBs": alg_bytes_step / t_step / 1e9,
         "end_to_end": {"ms": t_e2e * 1e3, "placements_per_s": wl.T / t_e2e,
                        "includes": "swp_batch_prepare (predicate de-duplication + H2D of the task descriptors) + device pass + D2H of placements and Explain histograms",
                        "swp_batch_prepare_ms": t_prepare * 1e3},
         "host_prep_s": {"intern+descriptors": t_host_prep, "swp_batch_prepare": t_prepare},
-        "resolver_raw": {k: st[k] for k in ("generic_tasks", "resolver_spins", "verify_retries", "slow_path_tasks", "rebase_events", "batches")},
+        "resolver_raw": {k: st[k] for k in ("generic_tasks", "resolver_spins", "slow_path_tasks", "rebase_events", "batches")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bounded sample, ~15 s of one host core)
         result["cpu_baseline"] = cpu_baseline(wl)

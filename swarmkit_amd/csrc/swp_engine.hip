@@ -145,7 +145,6 @@ struct swp_batch {
     std::vector<uint2> plats;
     std::vector<uint4> triples;
     uint32_t n_con = 0, n_plat = 0, n_plug = 0, n_sc = 0, n_svc = 0, n_ports = 0;
-    uint32_t window = 0, n_windows = 0;
     uint32_t n_nodes_prepared = 0;         // e->n_nodes when the batch was prepared: its bitmap rows are sized for that
     bool ran = false;
     int64_t unit_cpu = 1, unit_mem = 1;   // k_resolve5: gcd of the batch's reservations (RTask.kc / km count these units)
@@ -171,7 +170,7 @@ struct swp_batch {
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
     DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
-    DevBuf d_con, d_plat, d_plug, d_sc, d_F, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
+    DevBuf d_con, d_plat, d_plug, d_sc, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
     DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
     DevBuf d_thr;                          // k_resolve5 exact mode: thresholds of the demand-class rows
@@ -747,16 +746,6 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     HIPCHECK(e, b->d_plat.reserve((size_t)b->n_plat * Wn * 8));
     HIPCHECK(e, b->d_plug.reserve((size_t)b->n_plug * Wn * 8));
     HIPCHECK(e, b->d_sc.reserve((size_t)b->n_sc * Wn * 8));
-    uint32_t W = e->cfg.window;
-    if (W == 0) {
-        W = std::max<uint32_t>(e->n_nodes / 2, 1024);
-        W = std::min<uint32_t>(W, 65536);
-    }
-    W = ((W + 63) / 64) * 64;
-    W = std::min<uint32_t>(W, ((T + 63) / 64) * 64);
-    b->window = W;
-    b->n_windows = (T + W - 1) / W;
-    // d_F (the scan's window of feasibility rows) is reserved at run time: the exact mode of k_resolve5 does not use it
     HIPCHECK(e, b->d_log_node.reserve((size_t)T * 4));
     HIPCHECK(e, b->d_log_task.reserve((size_t)T * 4));
     HIPCHECK(e, b->d_log_prev.reserve((size_t)T * 4));
@@ -770,50 +759,6 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     HIPCHECK(e, b->d_ctl.reserve(sizeof(Ctl)));
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     return SWP_OK;
-}
-
-template <int K, int D>
-hipError_t launch_resolve1(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
-    (void)lds;
-    size_t need = (size_t)ra.n_nodes * 4 + 64;   // last commit per node
-    if (need > 64 * 1024) {
-        hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve1<K, D>), dev);
-        if (r != hipSuccess) return r;
-    }
-    hipLaunchKernelGGL((k_resolve1<K, D>), dim3(1), dim3(64), need, s, ra);
-    return hipGetLastError();
-}
-
-template <int K, bool PROF>
-hipError_t launch_resolve2p(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
-    hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve2<K, PROF>), dev);
-    if (r != hipSuccess) return r;
-    hipLaunchKernelGGL((k_resolve2<K, PROF>), dim3(1), dim3(128), lds, s, ra);
-    return hipGetLastError();
-}
-template <int K>
-hipError_t launch_resolve2(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
-    return (ra.dbg & 16u) ? launch_resolve2p<K, true>(ra, lds, s, dev) : launch_resolve2p<K, false>(ra, lds, s, dev);
-}
-
-template <int K, bool PROF>
-hipError_t launch_resolve3p(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
-    hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve3<K, PROF>), dev);
-    if (r != hipSuccess) return r;
-    hipLaunchKernelGGL((k_resolve3<K, PROF>), dim3(1), dim3(256), lds, s, ra);
-    return hipGetLastError();
-}
-template <int K>
-hipError_t launch_resolve3(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev) {
-    return (ra.dbg & 16u) ? launch_resolve3p<K, true>(ra, lds, s, dev) : launch_resolve3p<K, false>(ra, lds, s, dev);
-}
-
-template <int K>
-hipError_t launch_resolve(const ResolveArgs& ra, uint32_t threads, size_t lds, hipStream_t s, int dev) {
-    hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_resolve<K>), dev);
-    if (r != hipSuccess) return r;
-    hipLaunchKernelGGL(k_resolve<K>, dim3(1), dim3(threads), lds, s, ra);
-    return hipGetLastError();
 }
 
 int run_classes(swp_engine* e, swp_batch* b) {
@@ -961,44 +906,24 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     if (rc) return rc;
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[1], st));
 
-    // resolver geometry: one wavefront (barrier-free) when the node words fit 64 lanes x 8, else one workgroup
-    const bool one_wave = (e->cfg.resolver_threads == 0 ? Wn <= 512 : e->cfg.resolver_threads == 64) && (size_t)N * 4 + 64 <= 160 * 1024 - 512;
-    uint32_t threads = e->cfg.resolver_threads;
-    if (one_wave) threads = 64;
-    if (threads == 0) threads = Wn <= 256 ? 256 : 1024;
-    threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, (threads / 64) * 64));
-    uint32_t K = (Wn + threads - 1) / threads;
-    if (K > 16) return e->fail(SWP_ERANGE, "node count %u exceeds the single-GPU resolver (shard the node set)", N);
     const size_t lds_budget = 160 * 1024 - 512;
-    const size_t fixed = (size_t)Wn * 8 + 2 * 16 * 8 + 64;
-    if (fixed + (size_t)Wn * 8 * 2 > lds_budget) return e->fail(SWP_ERANGE, "node count %u: level planes do not fit LDS (shard the node set)", N);
-    uint32_t nb_alloc = (uint32_t)std::min<size_t>(16, (lds_budget - fixed) / ((size_t)Wn * 8));
-    size_t lds = fixed + (size_t)nb_alloc * Wn * 8;
-
-    // resolver variant: 2 = two-wave LDS-staged (default when it fits), 1 = one wave + register ring, 0 = one workgroup
-    // test / debugging knobs, read once per batch: SWP_RESOLVER forces a resolver generation (tests/test_engine_resolvers.py),
-    // SWP_DBG bit 16 switches the in-kernel section timers on
+    // Two resolver families. k_resolve5, the ROUND resolver: everything it decides from lives in one workgroup's LDS (<= ~12 000
+    // nodes, the batch's distinct reservations as at most r5_max_rows() demand-class rows, residuals as 32-bit counts of the
+    // batch's resource units) — one launch per batch. k_resolve6, the BLOCK resolver: bitmap rows in global memory, lists built by
+    // the whole chip — everything else. Test / debugging knobs, read once per batch: SWP_RESOLVER=5|6 forces a family
+    // (tests/test_engine_resolvers.py), SWP_DBG bit 16 switches the in-kernel section timers on.
     const char* env_res = getenv("SWP_RESOLVER");
     const char* env_dbg = getenv("SWP_DBG");
     const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
     int variant = env_res ? atoi(env_res) : 5;
-    uint32_t r2_tb = 0;
-    size_t r2_lds = 0;
-    // k_resolve5 (round resolver, default): needs <= 64 * R5_KMAX node words, its LDS layout (planes, lists, exact residuals as
-    // 32-bit counts of the batch's resource units) and every residual / reservation below 2^30 units; else k_resolve3 and down
-    // exact mode (default when the batch's demand classes fit): no scan, no F, the whole batch in one launch
-    const char* env_exact = getenv("SWP_R5_EXACT");
-    bool r5_exact = variant == 5 && b->exact_ok && !(env_exact && atoi(env_exact) == 0) && r5_lds_size(N, Wn, b->n_dc + b->n_dm) <= lds_budget;
-    const size_t r5_lds = r5_lds_size(N, Wn, r5_exact ? b->n_dc + b->n_dm : 0u);
-    if (variant == 5) {
-        bool ok = b->units_ok && r5_supports(Wn) && r5_lds <= lds_budget;
-        for (uint32_t n = 0; ok && n < N; ++n) {
-            const HostNode& h = e->nodes[n];
-            if (!h.present) continue;
-            const int64_t qc = h.row.cpu / b->unit_cpu, qm = h.row.mem / b->unit_mem;
-            if (qc >= R5_QLIM_HOST || qc <= -R5_QLIM_HOST || qm >= R5_QLIM_HOST || qm <= -R5_QLIM_HOST) ok = false;
-        }
-        if (!ok) variant = 3;
+    if (variant != 5 && variant != 6) return e->fail(SWP_EINVAL, "SWP_RESOLVER=%d: the resolver families are 5 (round) and 6 (block)", variant);
+    const size_t r5_lds = r5_lds_size(N, Wn, b->exact_ok ? b->n_dc + b->n_dm : 0u);
+    bool r5_ok = b->exact_ok && b->units_ok && r5_supports(Wn) && r5_lds <= lds_budget && !b->has_generic;
+    for (uint32_t n = 0; r5_ok && n < N; ++n) {
+        const HostNode& h = e->nodes[n];
+        if (!h.present) continue;
+        const int64_t qc = h.row.cpu / b->unit_cpu, qm = h.row.mem / b->unit_mem;
+        if (qc >= R5_QLIM_HOST || qc <= -R5_QLIM_HOST || qm >= R5_QLIM_HOST || qm <= -R5_QLIM_HOST) r5_ok = false;
     }
     // k_resolve6 (block resolver): lists built by the whole chip from bitmap rows in global memory, matched by one wave. For node
     // sets beyond k_resolve5's LDS; needs the demand classes and two candidate buffers of the propose kernel in LDS (≈ 650k nodes).
@@ -1011,53 +936,18 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     const bool r6_task_rows = env_tr ? atoi(env_tr) != 0 : (!b->classes_ok || b->n_dc + b->n_dm > 128);
     const uint32_t r6_nrr = r6_task_rows ? 0u : b->n_dc + b->n_dm;
     const bool r6_ok = r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, r6_nrr) <= lds_budget;
-    if (b->has_generic) {   // generic reservations are rows of the block resolver only
-        if (!r6_ok) return e->fail(SWP_EUNSUPPORTED, "a batch with generic reservations needs the block resolver: too many nodes for its LDS");
-        variant = 6;
+    if (variant == 5 && !r5_ok) variant = 6;
+    if (variant == 6 && !r6_ok) {
+        if (env_res && r5_ok) variant = 5;   // (forced at a size it cannot hold)
+        else return e->fail(SWP_ERANGE, "node count %u exceeds the block resolver's LDS (shard the node set)", N);
     }
-    if (variant == 6 && !r6_ok) variant = 3;
-    if (variant == 3 && !env_res && r6_ok) variant = 6;   // default beyond k_resolve5's reach
-    // more distinct reservations than k_resolve5 has LDS rows for: the block resolver keeps its rows in global memory
-    if (variant == 5 && !r5_exact && !env_res && !env_exact && r6_ok) variant = 6;
-    if (variant != 5) r5_exact = false;
     if (variant == 5) {
         HIPCHECK(e, b->d_qres.reserve((size_t)N * 8));
         hipLaunchKernelGGL(k_units, dim3((N + 255) / 256), dim3(256), 0, st, N, e->d_cpu.as<long long>(), e->d_mem.as<long long>(), (long long)b->unit_cpu,
                            (long long)b->unit_mem, b->d_qres.as<int32_t>());
     }
-    if (variant == 3) {
-        // k_resolve3: staged mk rows padded to 64*K words, 2*TB+1 slots (+ records), one published BELOW row, flags
-        const uint32_t K3 = (Wn + 63) / 64;
-        const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
-        const size_t per_slot = (size_t)K3 * 64 * 8 + 32;
-        const size_t fixed3 = off_f + (size_t)2 * K3 * 64 * 8 + 32 + 2 * R2_TB_MAX * 16 + 256;   // + BELOW row, ring-fix row, pad record, commit dump, flags
-        const size_t avail = lds_budget > fixed3 ? lds_budget - fixed3 : 0;
-        const size_t slots = avail / per_slot;
-        if (K3 <= 8 && slots >= 2 * 4 + 1) {
-            r2_tb = (uint32_t)std::min<size_t>(R2_TB_MAX, (slots - 1) / 2);
-            r2_lds = fixed3 + (size_t)(2 * r2_tb + 1) * per_slot;
-        } else variant = 2;
-    }
-    if (variant == 2) {
-        const size_t off_f = (((size_t)N * 4 + 15) / 16) * 16;
-        const size_t fixed2 = off_f + 2 * R2_TB_MAX * 32 + 64;
-        size_t per_task = (size_t)4 * Wn * 8;   // two buffers x (F row + X row)
-        if (fixed2 + 4 * per_task <= lds_budget && Wn <= 512) {
-            r2_tb = (uint32_t)std::min<size_t>(R2_TB_MAX, (lds_budget - fixed2) / per_task);
-            r2_lds = fixed2 + (size_t)r2_tb * per_task;
-        } else variant = one_wave ? 1 : 0;
-    }
-    if (variant == 1 && !one_wave) variant = 0;
-    if (prof) {
-        while (e->ev_pool.size() < (size_t)4 * (2 * b->n_windows + 2)) {   // + the windows of a fall-back pass
-            hipEvent_t x;
-            HIPCHECK(e, hipEventCreate(&x));
-            e->ev_pool.push_back(x);
-        }
-    }
-    uint32_t wi = 0;   // windows launched so far (profiling slots)
+    uint32_t wi = 0;   // resolver stretches launched so far (profiling slots)
     uint64_t r6_rounds = 0;
-    bool stopped = false;   // the block resolver ran out of level planes: the rest of the batch goes through the fall-back below
     // k_resolve6 over the stretch [start, end): build the bitmaps from the node rows as they are, then rounds of propose + commit.
     // The device advances on its own (the position lives in the control block); the host only learns every so many rounds how far it is.
     auto run_blocks = [&](uint32_t start, uint32_t end) -> int {
@@ -1140,20 +1030,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
             HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
             HIPCHECK(e, hipStreamSynchronize(st));
-            if (hb.error != ERR_NONE) {
-                // A node's task count moved 65 535 levels above the lowest one: the round that noticed committed its picks and the later
-                // rounds returned at once. Hand the rest of the batch to the fall-back at the end of batch_run, exactly as the wave
-                // resolvers do (Ctl.error / Ctl.resume), instead of failing the whole batch.
-                Ctl part{};
-                part.error = ERR_LEVEL_RANGE;
-                part.resume = hb.pos;
-                HIPCHECK(e, hipMemcpyAsync((char*)b->d_ctl.p + offsetof(Ctl, error), &part.error, 4, hipMemcpyHostToDevice, st));
-                HIPCHECK(e, hipMemcpyAsync((char*)b->d_ctl.p + offsetof(Ctl, resume), &part.resume, 4, hipMemcpyHostToDevice, st));
-                HIPCHECK(e, hipStreamSynchronize(st));
-                stopped = true;
-                r6_rounds += hb.rounds;
-                return SWP_OK;
-            }
+            if (hb.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP);
             if (hb.pos <= pos) return e->fail(SWP_EHIP, "block resolver made no progress at task %u", pos);   // a round decides its first task at least
             // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
             const double pace = std::max(1.0, (double)(hb.pos - start) / (double)std::max<uint32_t>(hb.rounds, 1));
@@ -1173,48 +1050,22 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         }
         return SWP_OK;
     };
-    auto run_windows = [&](uint32_t start, uint32_t end, int variant) -> int {
-    if (stopped && variant != 0) return SWP_OK;
-    if (variant == 6) return run_blocks(start, end);
-    const bool exact = r5_exact && variant == 5;
-    const uint32_t win = exact ? T : b->window;
-    if (!exact) HIPCHECK(e, b->d_F.reserve((size_t)b->window * Wn * 8));
-    if (prof)
-        while (e->ev_pool.size() < (size_t)4 * (wi + (end - start + win - 1) / win + 1)) {
-            hipEvent_t x;
-            HIPCHECK(e, hipEventCreate(&x));
-            e->ev_pool.push_back(x);
-        }
-    for (uint32_t j0 = start; j0 < end; j0 += win, ++wi) {
-        const uint32_t cnt = std::min(win, end - j0);
-        ScanArgs sa{};
-        sa.n_nodes = N;
-        sa.n_words = Wn;
-        sa.j0 = j0;
-        sa.count = cnt;
-        sa.cpu = e->d_cpu.as<long long>();
-        sa.mem = e->d_mem.as<long long>();
-        sa.rt = b->d_rt.as<RTask>();
-        sa.sc = b->d_sc.as<u64>();
-        sa.portmap = b->d_portmap.as<u64>();
-        sa.pset_off = b->d_pset_off.as<uint32_t>();
-        sa.pset_ids = b->d_pset_ids.as<uint32_t>();
-        sa.F = b->d_F.as<u64>();
-        dim3 sgrid((Wn + SCAN_WPW - 1) / SCAN_WPW, (cnt + SCAN_TCH - 1) / SCAN_TCH);
-        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 0], st));
-        if (!exact) hipLaunchKernelGGL(k_scan, sgrid, dim3(64), 0, st, sa);
-        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 1], st));
-
+    // one stretch of tasks through the chosen family: the round resolver decides it in ONE launch
+    auto run_stretch = [&](uint32_t start, uint32_t end, int variant) -> int {
+        if (variant == 6) return run_blocks(start, end);
+        if (prof)
+            while (e->ev_pool.size() < (size_t)4 * (wi + 1)) {
+                hipEvent_t x;
+                HIPCHECK(e, hipEventCreate(&x));
+                e->ev_pool.push_back(x);
+            }
         ResolveArgs ra{};
         ra.n_nodes = N;
         ra.n_words = Wn;
-        ra.j0 = j0;
-        ra.count = cnt;
-        ra.nb_alloc = nb_alloc;
+        ra.j0 = start;
+        ra.count = end - start;
         ra.dbg = dbg_bits;
         ra.xs = Wn;
-        ra.tb = r2_tb;
-        ra.F = b->d_F.as<u64>();
         ra.valid = e->d_valid.as<u64>();
         ra.X = b->d_X.as<u64>();
         ra.rt = b->d_rt.as<RTask>();
@@ -1236,66 +1087,30 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         ra.inf_task = b->d_inf_task.as<uint32_t>();
         ra.inf_pos = b->d_inf_pos.as<uint32_t>();
         ra.ctl = b->d_ctl.as<Ctl>();
-        hipError_t r;
-        if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
-        if (variant == 5) {
-            ra.qres = b->d_qres.as<int32_t>();
-            ra.unit_cpu = b->unit_cpu;
-            ra.unit_mem = b->unit_mem;
-            ra.sc = b->d_sc.as<u64>();
-            ra.thr = b->d_thr.as<int32_t>();
-            ra.n_dc = exact ? b->n_dc : 0u;
-            ra.n_dm = exact ? b->n_dm : 0u;
-            ra.exact = exact ? 1u : 0u;
-            r = launch_resolve5(ra, r5_lds, st, e->device);
-        } else if (variant == 3) {
-            switch ((Wn + 63) / 64) {
-            case 1: r = launch_resolve3<1>(ra, r2_lds, st, e->device); break;
-            case 2: r = launch_resolve3<2>(ra, r2_lds, st, e->device); break;
-            case 3: r = launch_resolve3<3>(ra, r2_lds, st, e->device); break;
-            case 4: r = launch_resolve3<4>(ra, r2_lds, st, e->device); break;
-            case 5: r = launch_resolve3<5>(ra, r2_lds, st, e->device); break;
-            case 6: r = launch_resolve3<6>(ra, r2_lds, st, e->device); break;
-            case 7: r = launch_resolve3<7>(ra, r2_lds, st, e->device); break;
-            default: r = launch_resolve3<8>(ra, r2_lds, st, e->device); break;
-            }
-        } else if (variant == 2) {
-            const uint32_t K2 = (Wn + 63) / 64;
-            switch (K2) {
-            case 1: r = launch_resolve2<1>(ra, r2_lds, st, e->device); break;
-            case 2: r = launch_resolve2<2>(ra, r2_lds, st, e->device); break;
-            case 3: r = launch_resolve2<3>(ra, r2_lds, st, e->device); break;
-            case 4: r = launch_resolve2<4>(ra, r2_lds, st, e->device); break;
-            default: r = launch_resolve2<8>(ra, r2_lds, st, e->device); break;
-            }
-        } else if (variant == 1) {
-            switch (K) {
-            case 1: r = launch_resolve1<1, 8>(ra, lds, st, e->device); break;
-            case 2: r = launch_resolve1<2, 8>(ra, lds, st, e->device); break;
-            case 3: r = launch_resolve1<3, 8>(ra, lds, st, e->device); break;
-            case 4: r = launch_resolve1<4, 8>(ra, lds, st, e->device); break;
-            default: r = launch_resolve1<8, 4>(ra, lds, st, e->device); break;
-            }
-        } else
-        switch (K) {
-        case 1: r = launch_resolve<1>(ra, threads, lds, st, e->device); break;
-        case 2: r = launch_resolve<2>(ra, threads, lds, st, e->device); break;
-        case 3: case 4: r = launch_resolve<4>(ra, threads, lds, st, e->device); break;
-        case 5: case 6: case 7: case 8: r = launch_resolve<8>(ra, threads, lds, st, e->device); break;
-        default: r = launch_resolve<16>(ra, threads, lds, st, e->device); break;
+        ra.qres = b->d_qres.as<int32_t>();
+        ra.unit_cpu = b->unit_cpu;
+        ra.unit_mem = b->unit_mem;
+        ra.sc = b->d_sc.as<u64>();
+        ra.thr = b->d_thr.as<int32_t>();
+        ra.n_dc = b->n_dc;
+        ra.n_dm = b->n_dm;
+        if (prof) {
+            HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 0], st));
+            HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 1], st));
+            HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 2], st));
         }
-        if (r != hipSuccess) return e->fail(SWP_EHIP, "k_resolve launch: %s", hipGetErrorString(r));
+        const hipError_t r = launch_resolve5(ra, r5_lds, st, e->device);
+        if (r != hipSuccess) return e->fail(SWP_EHIP, "k_resolve5 launch: %s", hipGetErrorString(r));
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
-    }
-    return SWP_OK;
+        ++wi;
+        return SWP_OK;
     };
-    if (b->segs.empty()) rc = run_windows(0, T, variant);
+    if (b->segs.empty()) rc = run_stretch(0, T, variant);
     else {
         HIPCHECK(e, b->d_wf.reserve((size_t)3 * N * 4));
         for (const swp_batch::Seg& sg : b->segs) {
-            if (stopped) break;
             if (!sg.run) {
-                if ((rc = run_windows(sg.j0, sg.j0 + sg.n, variant))) break;
+                if ((rc = run_stretch(sg.j0, sg.j0 + sg.n, variant))) break;
                 continue;
             }
             WaterArgs wa{};
@@ -1337,20 +1152,20 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     Ctl ctl{};
     HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
     HIPCHECK(e, hipStreamSynchronize(st));
-    if (ctl.error == ERR_LEVEL_RANGE && variant != 0 && ctl.resume < T) {
-        // The per-node task-count spread outgrew the 8 register planes of the wave resolvers (255 levels). The kernel
-        // stopped cleanly after task `resume` - 1 and every later window returned at once: carry on from there with the
-        // workgroup resolver (16 planes in LDS).
+    if (ctl.error == ERR_LEVEL_RANGE && variant == 5 && r6_ok && ctl.resume < T) {
+        // The per-node task-count spread outgrew the 8 level planes the round resolver keeps in LDS (255 levels). It stopped cleanly
+        // after task `resume` - 1 and every later launch returned at once: the block resolver (16 planes in global memory) carries
+        // on from there — runs of identical tasks included, task by task.
         const uint32_t zero = 0;
         HIPCHECK(e, hipMemcpyAsync((char*)b->d_ctl.p + offsetof(Ctl, error), &zero, 4, hipMemcpyHostToDevice, st));
-        variant = 0;
-        rc = run_windows(ctl.resume, T, 0);   // (runs included: task by task from here on)
+        variant = 6;
+        rc = run_stretch(ctl.resume, T, 6);
         if (rc) return rc;
         HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
         HIPCHECK(e, hipStreamSynchronize(st));
     }
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[2], st));
-    if (ctl.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the level planes that fit in LDS");
+    if (ctl.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the resolvers' level planes");
     if (ctl.ninf && (rc = run_explain(e, b, ctl.ninf))) return rc;
     if (prof) {
         HIPCHECK(e, hipEventRecord(e->ev[3], st));
@@ -1405,9 +1220,8 @@ fprintf(stderr, "[swp] k_resolve5 lister wave 1 per round (cycles): prologue %.0
         fprintf(stderr, "[swp] shader clock: %llu cycles / %llu x10ns => %.0f MHz\n", ctl.cyc[6], ctl.cyc[7], (double)ctl.cyc[6] / ((double)ctl.cyc[7] * 0.01));
     e->stats.last_windows = wi;   // resolver launches of this batch (1 in k_resolve5's exact mode: no scan windows)
     e->stats.last_static_classes = b->n_sc;
-    e->stats.scan_launches += (r5_exact || variant == 6) ? 0u : wi;
     e->stats.resolve_launches += variant == 6 ? (uint32_t)(2 * r6_rounds) : wi;   // k_resolve6: a propose and a commit launch per round
-    e->stats.last_resolver = (uint32_t)variant + (r5_exact ? 100u : 0u);   // 105 = k_resolve5, exact mode
+    e->stats.last_resolver = variant == 5 ? 105u : 6u;   // 105 = k_resolve5 (its demand-class rows in LDS), 6 = k_resolve6
     b->ran = true;
     return SWP_OK;
 }

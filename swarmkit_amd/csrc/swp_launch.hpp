@@ -13,7 +13,7 @@ namespace swpdev {
 hipError_t ensure_big_lds(const void* fn, int device);
 
 // k_resolve5 (swp_resolve5.hip)
-size_t r5_lds_size(uint32_t n_nodes, uint32_t n_words, uint32_t n_rr);   // n_rr: demand-class rows of the exact mode (0: scan mode)
+size_t r5_lds_size(uint32_t n_nodes, uint32_t n_words, uint32_t n_rr);   // n_rr: demand-class rows
 uint32_t r5_max_rows();
 bool r5_supports(uint32_t n_words);
 hipError_t launch_resolve5(const ResolveArgs& ra, size_t lds, hipStream_t s, int dev);

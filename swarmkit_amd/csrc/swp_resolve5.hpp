@@ -2,14 +2,16 @@
 // (nodeSet.tree with a heap of one, nodeset.go:50-124; nodeLess, scheduler.go:708-735; NodeInfo.addTask,
 // nodeinfo.go:108-154) decided R5_B tasks at a time by ONE workgroup of 16 wavefronts.
 //
-// Why rounds. A lone wavefront retires one instruction per ≈ 4 ns; k_resolve3 needs ≈ 85 per task and is the whole batch
-// time (0.38 µs per task). The work per task that is really sequential is tiny — "take the first candidate nobody before
-// you took" — while finding the candidates (157 words of F & ~X against the node levels at 10k nodes) is wide and
-// independent of the other tasks of the round as long as every node is taken at most once per round. So:
+// Why rounds. A lone wavefront retires one instruction per ≈ 4 ns; a resolver that decides task after task on one wave (round
+// 1: ≈ 85 instructions per task) IS the whole batch time. The work per task that is really sequential is tiny — "take the first
+// candidate nobody before you took" — while finding the candidates (157 words of F & ~X against the node levels at 10k nodes,
+// F = static class & demand-class rows) is wide and independent of the other tasks of the round as long as every node is
+// taken at most once per round. So:
 //
 //   lister waves 1..14  build, for each task of the NEXT round, a candidate list: the first R5_Q non-empty words of
-//                       F & ~X restricted to the task's minimum level, in node order, each word validated against the
-//                       exact residuals (kept in LDS in the batch's resource units). One wave per task, 4 tasks per
+//                       F & ~X restricted to the task's minimum level, in node order. ResourceFilter.Check (filter.go:77-84)
+//                       is membership in two demand-class rows (the batch's distinct reservations, kept exact in LDS by
+//                       every commit). One wave per task, 4 tasks per
 //                       wave and round; everything is word-parallel over the lanes {lane + 64k}. Levels come from a
 //                       ring of R5_J per-level node masks in LDS (the levels where the picks happen) and, for anything
 //                       below or above the ring, from the bit-planes of all levels.
@@ -26,9 +28,9 @@
 // level L+1 > L, so "first listed bit nobody took" is exactly the sequential argmin(level, index) — as long as the list
 // is not exhausted. When it is, the round is CUT there: the tasks before it are committed and the next round starts at
 // that task with fresh lists (its own list cannot be exhausted at position 0). A task that must look at its service's
-// exception list (no plain candidate, but F & X ≠ 0), whose listed nodes all filled up since the scan, with host ports or
-// uncounted: cut, and that one task runs the generic workgroup path (r5_generic: k_resolve's algorithm on this kernel's
-// state). A task with F == 0 and no exception candidate ("no suitable node") passes through the round as a no-op.
+// exception list (no plain candidate, but F & X ≠ 0), with host ports or
+// uncounted: cut, and that one task runs the generic workgroup path (r5_generic: one task decided by all 1024 threads from
+// this kernel's state). A task with F == 0 and no exception candidate ("no suitable node") passes through the round as a no-op.
 //
 // Pipeline: while the matcher works on round r, the listers build round r+1 against the state after round r-1; the
 // picks of round r are removed from those lists when the matcher loads them (TK row of the previous round).
@@ -49,7 +51,7 @@ namespace swpdev {
 #define R5_THREADS 1024
 #define R5_KMAX 4                 // node words per lane: n_words <= 256 (16 384 nodes)
 #define R5_QLIM (1 << 30)         // residuals in resource units must stay below this (host checks)
-#define R5_RRMAX 64               // exact mode: demand-class rows (distinct cpu reservations + distinct memory reservations)
+#define R5_RRMAX 64               // demand-class rows (distinct cpu reservations + distinct memory reservations)
 #define R5_TREC 256               // task-record ring in LDS (entries; power of two, > 3 rounds + slack)
 #define R5_TREC_U32 8             // flags, svc, sc, kc, km, slot, -, -
 #define R5_AHEAD (3 * R5_B + 8)   // records staged this far beyond the current round's first task
@@ -76,7 +78,7 @@ struct R5Lds {
     u64* lv;         // [R5_J][rs]      nodes at level lb .. lb+J-1 (slot = level % J)
     u64* below;      // [rs]            nodes below the ring
     u64* tk;         // [2][rs]         picks of the previous / the current round
-    u64* rr;         // [n_rr][rs]      exact mode: nodes whose residual cpu (rows 0..n_dc-1) / memory (rows n_dc..) is >= the row's threshold
+    u64* rr;         // [n_rr][rs]      nodes whose residual cpu (rows 0..n_dc-1) / memory (rows n_dc..) is >= the row's threshold
     int32_t* thr;    // [R5_RRMAX]      the thresholds, resource units
     u32* trec;       // [R5_TREC][R5_TREC_U32]  the listers' fields of the upcoming tasks, staged by the committer wave (ring by task index)
     u64* red;        // [64]            block reductions
@@ -233,7 +235,7 @@ WV_DEV bool r5_bump_level(const R5Lds& L, u32 NB, u32 lb, u32 w, u64 bit, u32 rl
     return (nl >> NB) != 0;
 }
 
-// ---- exact mode: the demand-class rows ------------------------------------------------------------------------------
+// ---- the demand-class rows -------------------------------------------------------------------------------------------
 // ResourceFilter.Check (filter.go:77-84) as set membership: node n passes a task with reservations (kc, km) <=> n is in
 // RC[class of kc] & RM[class of km], RC[c] = {q_cpu >= thr[c]}, RM[c] = {q_mem >= thr[n_dc + c]}. Residuals only shrink inside a
 // batch, so a commit can only take bits away. One wave per node word: a ballot IS a row word. Needs q and thr in LDS.
@@ -277,13 +279,11 @@ WV_DEV void r5_stage_records(const ResolveArgs& a, const R5Lds& L, u32 from, u32
 }
 
 // ---- lister: candidate lists of the round that starts at window-local task jbase, into list buffer `buf` ------------
-// F and X rows are requested one task ahead. (F was written by the scan on other XCDs — an L2 miss here, ~1 µs — so the
-// committer wave touches the rows of the round after next while it has nothing else to do: r5_touch_rows.)
-// EXACT: the rows are sc[static class] & RC & RM (exact at the list's snapshot) instead of the scan's F row (a stale superset
-// that needs the validation step at the end).
+// The static-class and X rows are requested one task ahead. A task's feasible set is sc[static class] & RC[cpu class] & RM[memory
+// class], exact at the list's snapshot (the demand-class rows are kept exact by every commit).
 // slots == nullptr: the wave lists the tasks of slots lw, lw + R5_LW, ... of the round that starts at jbase. Otherwise `slots`
 // (LDS, n_slots entries) names the slots to list — the relist pass after a cut round — and the wave takes entries lw, lw + R5_LW, ...
-template <int K, bool EXACT>
+template <int K>
 WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u32 lw, u64* lt, const u32* slots = nullptr, u32 n_slots = 0) {
     const u32 lane = wv::lane();
     u32 sl_[R5_TPW];   // slot of the wave's t-th task, 0xFFFFFFFF = none
@@ -313,8 +313,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
         const u32 w = lane + 64 * k;
         const u32 j0_ = sl_[0] == 0xFFFFFFFFu ? 0xFFFFFFFFu : jbase + sl_[0];
         const bool in = j0_ < a.count && w < a.n_words;
-        if (EXACT) Fn[k] = in ? a.sc[(size_t)sc_[0] * a.n_words + w] : 0ull;
-        else Fn[k] = in ? a.F[(size_t)j0_ * a.n_words + w] : 0ull;
+        Fn[k] = in ? a.sc[(size_t)sc_[0] * a.n_words + w] : 0ull;
         Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[0] * a.xs + w) : 0ull;
     }
     // the lowest ring level and BELOW of this wave's words stay in registers for the round
@@ -344,8 +343,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             for (int k = 0; k < K; ++k) {
                 const u32 w = lane + 64 * k;
                 const bool in = jn < a.count && w < a.n_words;
-                if (EXACT) Fn[k] = in ? a.sc[(size_t)sc_[t + 1] * a.n_words + w] : 0ull;
-                else Fn[k] = in ? a.F[(size_t)jn * a.n_words + w] : 0ull;
+                Fn[k] = in ? a.sc[(size_t)sc_[t + 1] * a.n_words + w] : 0ull;
                 Xn[k] = in ? wv::g_fresh64(a.X + (size_t)sv_[t + 1] * a.xs + w) : 0ull;
             }
         }
@@ -360,7 +358,7 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             if (lane == 0) { out[0] = R5_COMPLEX; out[1] = 0; }
             continue;
         }
-        if (EXACT && (flags & RT_RES)) {   // uniform
+        if (flags & RT_RES) {   // uniform
             const u64* rc = L.rr + (size_t)((flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * L.rs;
             const u64* rm = L.rr + (size_t)(a.n_dc + ((flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * L.rs;
             for (int k = 0; k < K; ++k) F[k] &= rc[lane + 64 * k] & rm[lane + 64 * k];
@@ -456,36 +454,9 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
         }
         cnt = min(cnt, (u32)R5_Q);
         R5_LT(3);   // entries
-        // ResourceFilter against the exact residuals (filter.go:77-84 in resource units): lane b checks node 64w + b
         const int32_t kc = (int32_t)rec[3], km = (int32_t)rec[4];
-        u32 some = 1;
-        if (!EXACT && (flags & RT_RES)) {
-            wv::wave_sync();
-            // all four entries are read back first (same address in every lane: broadcast reads), then the residuals of the
-            // four words, then the verdicts: two LDS latencies instead of eight
-            u32 sw[R5_Q];
-            u64 sb[R5_Q];
-            for (u32 q = 0; q < R5_Q; ++q) {
-                sw[q] = out[R5_HDR_U32 + 4 * q];
-                sb[q] = *reinterpret_cast<const u64*>(out + R5_HDR_U32 + 4 * q + 2);
-            }
-            int32_t qc[R5_Q], qm[R5_Q];
-            for (u32 q = 0; q < R5_Q; ++q) {
-                const u32 n = q < cnt ? sw[q] * 64 + lane : 0u;   // entries beyond cnt hold leftovers: read node 0, ignore
-                qc[q] = L.q[2 * n];
-                qm[q] = L.q[2 * n + 1];
-            }
-            wv::lockstep();   // every lane has read the entries before lane 0 rewrites them
-            some = 0;
-            for (u32 q = 0; q < R5_Q; ++q) {
-                const bool ok = q < cnt && ((sb[q] >> lane) & 1) && qc[q] >= kc && qm[q] >= km;
-                const u64 v = wv::ballot(ok);
-                if (v) some = 1;
-                if (lane == 0 && q < cnt) *reinterpret_cast<u64*>(out + R5_HDR_U32 + 4 * q + 2) = v;
-            }
-        }
         if (lane == 0) {
-            out[0] = some ? R5_FAST : R5_COMPLEX;   // every listed node is full by now: let the generic path look further
+            out[0] = R5_FAST;
             out[1] = 2 * cnt;
             out[2] = lvl;
             out[3] = svc;
@@ -493,20 +464,9 @@ WV_DEV void r5_list(const ResolveArgs& a, const R5Lds& L, u32 jbase, u32 buf, u3
             out[5] = (u32)km;
             out[6] = rec[5];
         }
-        R5_LT(4);   // validation + header
+        R5_LT(4);   // header
     }
 #undef R5_LT
-}
-
-// the F rows of window-local tasks [j0, j0 + R5_B) into this XCD's L2: one 128-byte line per lane and step
-WV_DEV void r5_touch_rows(const ResolveArgs& a, u32 j0) {
-    if (j0 >= a.count) return;
-    const u32 j1 = min(j0 + (u32)R5_B, a.count);
-    const char* p0 = reinterpret_cast<const char*>(a.F + (size_t)j0 * a.n_words);
-    const size_t bytes = (size_t)(j1 - j0) * a.n_words * 8;
-    u32 acc = 0;
-    for (size_t off = (size_t)wv::lane() * 128; off < bytes; off += 64 * 128) acc += wv::prefetch_l2(p0 + off);
-    wv::keep(acc);
 }
 
 // ---- committer: the memory side effects of one finished round, from its hand-over record ---------------------------
@@ -585,7 +545,7 @@ WV_DEV void r5_commit_one(const ResolveArgs& a, const R5Lds& L, const R5Rt& r, u
     if (r.mem) wv::g_add64(a.mem + n, -r.mem);
     L.q[2 * n] -= r.kc;
     L.q[2 * n + 1] -= r.km;
-    if (a.exact && (r.kc | r.km)) r5_rr_update(L, a.n_dc, a.n_dm, w, bit, L.q[2 * n], L.q[2 * n + 1]);
+    if (r.kc | r.km) r5_rr_update(L, a.n_dc, a.n_dm, w, bit, L.q[2 * n], L.q[2 * n + 1]);
     if (r.flags & RT_PORTS)
         for (u32 p = a.pset_off[r.pset]; p < a.pset_off[r.pset + 1]; ++p) wv::g_or64(a.portmap + (size_t)a.pset_ids[p] * a.n_words + w, bit);
     if (!(r.flags & RT_UNCOUNTED)) {
@@ -608,7 +568,6 @@ WV_DEV void r5_commit_one(const ResolveArgs& a, const R5Lds& L, const R5Rt& r, u
     wv::wait_vm();   // the listers read X / the lists through L2 right after the next barrier
 }
 
-template <bool EXACT>
 WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
     const u32 tid = wv::tid();
     const u32 gj = a.j0 + jj;
@@ -617,14 +576,12 @@ WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
     const bool mine = tid < a.n_words;
     u64 f = 0;
     if (mine) {
-        if (EXACT) {   // what the scan would have written for this task, against the state as it is now
-            f = a.sc[(size_t)r.sc * a.n_words + tid];
-            if (r.flags & RT_RES)
-                f &= L.rr[(size_t)((r.flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * L.rs + tid] & L.rr[(size_t)(a.n_dc + ((r.flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * L.rs + tid];
-            if (r.flags & RT_PORTS)
-                for (u32 p = a.pset_off[r.pset]; p < a.pset_off[r.pset + 1]; ++p) f &= ~wv::g_fresh64(a.portmap + (size_t)a.pset_ids[p] * a.n_words + tid);
-        } else
-            f = a.F[(size_t)jj * a.n_words + tid];
+        // the task's feasible set against the state as it is now: static class & demand-class rows & ~used host ports
+        f = a.sc[(size_t)r.sc * a.n_words + tid];
+        if (r.flags & RT_RES)
+            f &= L.rr[(size_t)((r.flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * L.rs + tid] & L.rr[(size_t)(a.n_dc + ((r.flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * L.rs + tid];
+        if (r.flags & RT_PORTS)
+            for (u32 p = a.pset_off[r.pset]; p < a.pset_off[r.pset + 1]; ++p) f &= ~wv::g_fresh64(a.portmap + (size_t)a.pset_ids[p] * a.n_words + tid);
     }
     u64 mk = mine ? f & ~wv::g_fresh64(a.X + (size_t)r.svc * a.xs + tid) : 0ull;
     const u32 idx_bits = 14, idx_mask = (1u << idx_bits) - 1u;   // n_nodes <= 16 384, levels < 256
@@ -672,7 +629,7 @@ WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
             if (n == LIST_EMPTY) continue;
             const u32 w = n >> 6;
             const u64 bit = 1ull << (n & 63);
-            if (!((EXACT ? a.sc[(size_t)r.sc * a.n_words + w] : a.F[(size_t)jj * a.n_words + w]) & bit)) continue;
+            if (!(a.sc[(size_t)r.sc * a.n_words + w] & bit)) continue;
             if ((r.flags & RT_RES) && !(L.q[2 * n] >= r.kc && L.q[2 * n + 1] >= r.km)) continue;
             if (r.flags & RT_PORTS) {
                 bool used = false;
@@ -708,18 +665,18 @@ WV_DEV void r5_generic(const ResolveArgs& a, const R5Lds& L, u32 jj, u32& par) {
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------
-template <int K, bool EXACT>
+template <int K>
 WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
     const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave();
     if (wv::uload(&a.ctl->error) != ERR_NONE) return;   // an earlier window stopped: the host carries on from ctl->resume
-    const R5Lds L = r5_layout(wv::lds(), a.n_words, EXACT ? a.n_dc + a.n_dm : 0u);
+    const R5Lds L = r5_layout(wv::lds(), a.n_words, a.n_dc + a.n_dm);
     u32 par = 0;   // parity of the reduction scratch
 
     for (u32 i = tid; i < 2 * L.rs; i += R5_THREADS) L.tk[i] = 0;
     for (u32 i = tid; i < a.n_nodes * 2; i += R5_THREADS) L.q[i] = a.qres[i];
     for (u32 i = tid; i < 2 * R5_B * 2; i += R5_THREADS) L.ring[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
     if (tid < R5S_COUNT) L.sh[tid] = 0;
-    if (EXACT && tid < a.n_dc + a.n_dm) L.thr[tid] = a.thr[tid];
+    if (tid < a.n_dc + a.n_dm) L.thr[tid] = a.thr[tid];
     if (wave == R5_CW) r5_stage_records(a, L, 0, min((u32)R5_AHEAD, a.count));
     u32 staged = min((u32)R5_AHEAD, a.count);   // committer wave: records of window-local tasks < staged are in the ring
     wv::barrier();
@@ -727,18 +684,18 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         L.sh[R5S_NCOMMIT] = a.ctl->ncommit;
         L.sh[R5S_NINF] = a.ctl->ninf;
     }
-    if (EXACT) r5_rr_build(a, L);   // the barriers of r5_build_planes order it before the first lister
+    r5_rr_build(a, L);   // the barriers of r5_build_planes order it before the first lister
     bool fatal = !r5_build_planes(a, L, par);   // ends with a barrier
-    // exact mode, matcher wave: the demand-class thresholds it compares every commit with. Up to 8 + 8 of them live in
+    // matcher wave: the demand-class thresholds it compares every commit with. Up to 8 + 8 of them live in
     // registers (padding = a residual no node can have: never "below"); more than that are re-read through the scalar cache.
     int32_t thr_c[8], thr_m[8], thr_cmax = -R5_QLIM, thr_mmax = -R5_QLIM;
-    const bool small_rr = EXACT && a.n_dc <= 8 && a.n_dm <= 8;
+    const bool small_rr = a.n_dc <= 8 && a.n_dm <= 8;
     for (u32 c = 0; c < 8; ++c) {
-        thr_c[c] = (EXACT && c < a.n_dc && small_rr) ? wv::uload(a.thr + c) : -R5_QLIM;
-        thr_m[c] = (EXACT && c < a.n_dm && small_rr) ? wv::uload(a.thr + a.n_dc + c) : -R5_QLIM;
+        thr_c[c] = (c < a.n_dc && small_rr) ? wv::uload(a.thr + c) : -R5_QLIM;
+        thr_m[c] = (c < a.n_dm && small_rr) ? wv::uload(a.thr + a.n_dc + c) : -R5_QLIM;
     }
-    if (EXACT && a.n_dc) thr_cmax = wv::uload(a.thr + a.n_dc - 1);
-    if (EXACT && a.n_dm) thr_mmax = wv::uload(a.thr + a.n_dc + a.n_dm - 1);
+    if (a.n_dc) thr_cmax = wv::uload(a.thr + a.n_dc - 1);
+    if (a.n_dm) thr_mmax = wv::uload(a.thr + a.n_dc + a.n_dm - 1);
 
     u32 j = 0;           // next window-local task
     u32 buf = 0;         // list buffer of the current round
@@ -764,10 +721,9 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
         // the lists of [j, j+nb) are built against the state as it is (one call site: the lister is the bulk of the code).
         const bool matching = have_lists;
         if (wave >= 1 && wave <= R5_LW) {
-            r5_list<K, EXACT>(a, L, matching ? j + nb : j, matching ? bnx : buf, wave - 1, (prof && wave == 1) ? lcy : nullptr);
+            r5_list<K>(a, L, matching ? j + nb : j, matching ? bnx : buf, wave - 1, (prof && wave == 1) ? lcy : nullptr);
         } else if (wave == R5_CW) {
             r5_commit_memory(a, L, rpar ^ 1, pend, false);
-            if (!EXACT) r5_touch_rows(a, j + nb + R5_B);   // what the listers will read in the next round
             const u32 want = min(j + (u32)R5_AHEAD, a.count);   // read by the listers from the next round on (barriers in between)
             if (staged < want) {
                 r5_stage_records(a, L, staged, want);
@@ -950,7 +906,7 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 L.q[2 * n] = qc;
                 L.q[2 * n + 1] = qm;
             }
-            if (EXACT) {
+            {
                 // demand-class rows: a committed node leaves every row whose threshold its residual no longer meets
                 // (ascending thresholds within each group: the largest one tells whether any lane has anything to do)
                 const u32 ndc = a.n_dc, ndm = a.n_dm;
@@ -1057,11 +1013,11 @@ WV_KERNEL(R5_THREADS) void k_resolve5(ResolveArgs a) {
                 buf = bsp;
                 bsp = t_;
             }
-            if (wave >= 1 && wave <= R5_LW) r5_list<K, EXACT>(a, L, j, buf, wave - 1, nullptr, L.relist, L.sh[R5S_NREL]);
+            if (wave >= 1 && wave <= R5_LW) r5_list<K>(a, L, j, buf, wave - 1, nullptr, L.relist, L.sh[R5S_NREL]);
             wv::barrier();
         }
         if (cut < nb && why == R5_CUT_GENERIC) {
-            r5_generic<EXACT>(a, L, j, par);   // ends with a barrier
+            r5_generic(a, L, j, par);   // ends with a barrier
             j += 1;
             if (L.sh[R5S_REBUILD]) {
                 if (tid == 0) L.sh[R5S_REBASES] += 1;

@@ -68,15 +68,12 @@ struct Ctl {
 
 enum { ERR_NONE = 0, ERR_LEVEL_RANGE = 1, ERR_GROUP_RANGE = 2 };
 
-// arguments of every resolver generation (k_resolve … k_resolve5); one launch = one scan window of tasks
+// arguments of the round resolver (k_resolve5, swp_resolve5.hpp); one launch = one stretch of the batch's tasks
 struct ResolveArgs {
     u32 n_nodes, n_words;
-    u32 j0, count;
-    u32 nb_alloc;            // planes that fit in LDS
+    u32 j0, count;           // the stretch: tasks [j0, j0 + count) of the batch
     u32 dbg;                 // timing experiments only (env SWP_DBG); 0 in production
     u32 xs;                  // row stride of X in words
-    u32 tb;                  // k_resolve2: tasks per staged block
-    const u64* F;            // [count][n_words] for this window
     const u64* valid;        // [n_words]
     u64* X;                  // [n_svc][n_words]
     const RTask* rt;
@@ -98,15 +95,14 @@ struct ResolveArgs {
     u32* inf_task;
     u32* inf_pos;
     Ctl* ctl;
-    int32_t* qres;           // k_resolve5: [n_nodes][2] residual cpu / mem in the batch's resource units (floor division)
-    i64 unit_cpu, unit_mem;  // k_resolve5: the units (RTask.cpu == kc * unit_cpu, RTask.mem == km * unit_mem)
-    // k_resolve5, exact mode (n_dc + n_dm > 0 or exact != 0): F is not used. Feasibility of a plain task is
-    // sc[task's static class] & RC[its cpu class] & RM[its memory class], where the demand-class rows live in LDS and are
-    // kept exact by every commit (a node's bit leaves a row when its residual drops below the row's threshold).
+    int32_t* qres;           // [n_nodes][2] residual cpu / mem in the batch's resource units (floor division)
+    i64 unit_cpu, unit_mem;  // the units (RTask.cpu == kc * unit_cpu, RTask.mem == km * unit_mem)
+    // Feasibility of a plain task is sc[task's static class] & RC[its cpu class] & RM[its memory class], where the demand-class
+    // rows live in LDS and are kept exact by every commit (a node's bit leaves a row when its residual drops below the row's
+    // threshold).
     const u64* sc;           // [n_sc][n_words] static class rows (ready & constraint & platform & plugin)
     const int32_t* thr;      // [n_dc + n_dm] thresholds in resource units: the distinct cpu reservations, then the memory ones
     u32 n_dc, n_dm;
-    u32 exact;
 };
 
 }  // namespace swpdev

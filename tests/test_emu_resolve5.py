@@ -41,11 +41,11 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["exact", "scan"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "s%d_n%d_t%d_o%d_f%d" % (c[0], c[1], c[2], c[5], c[6]))
-def test_round_resolver_source_matches_sequential_model(emu_bin, case, mode):
-    """exact: demand-class rows instead of the scan's F rows whenever the problem's distinct reservations fit (the engine's
-    default); scan: F rows + validation against the residuals."""
-    r = subprocess.run([emu_bin] + [str(x) for x in case] + ["v"] + (["x"] if mode == "exact" else []), capture_output=True, text=True, timeout=600)
+def test_round_resolver_source_matches_sequential_model(emu_bin, case):
+    """The batch goes through the kernel in stretches of `window` tasks (the engine's stretches between runs of identical tasks)."""
+    r = subprocess.run([emu_bin] + [str(x) for x in case] + ["v"], capture_output=True, text=True, timeout=600)
+    if r.returncode == 77:
+        pytest.skip("this problem has more distinct reservations than the round resolver has LDS rows for (the engine gives such a batch to the block resolver)")
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr

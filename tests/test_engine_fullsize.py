@@ -35,12 +35,14 @@ def test_full_size_matches_oracle_digest(key):
     assert h2 == doc["sha256_errors"]
 
 
-def test_full_size_window_independence_and_determinism():
+def test_full_size_resolver_independence_and_determinism(monkeypatch):
     wl = synth.Workload("cfg3")
     _, e1, _, out1, _ = pu.engine_run(wl)
-    _, e2, _, out2, _ = pu.engine_run(wl, window=1024)
+    monkeypatch.setenv("SWP_RESOLVER", "6")
+    _, e2, _, out2, _ = pu.engine_run(wl)
+    monkeypatch.delenv("SWP_RESOLVER")
     _, e3, _, out3, _ = pu.engine_run(wl)
-    assert np.array_equal(out1, out2) and e1 == e2      # the scan window (snapshot freshness) must not matter
+    assert np.array_equal(out1, out2) and e1 == e2      # round resolver vs block resolver: the same 100 000 decisions
     assert np.array_equal(out1, out3) and e1 == e3      # run-to-run
 
 

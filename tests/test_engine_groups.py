@@ -86,14 +86,25 @@ def test_spread_with_constraints_and_leftovers():
     both(ev)
 
 
-def test_generic_resources_are_refused_not_faked():
+def test_what_stays_on_the_go_path_is_refused_not_faked():
+    """Refused at the event boundary (the task never enters a batch): generic reservations the engine does not take — Named, below 1,
+    a kind twice — and CSI cluster volumes. A GROUP with generic reservations is not refused but deferred: its decision line says so
+    and the task stays queued for the reference's own scheduleTaskGroup."""
     s = factory()
-    s.create_node(sc.node("n1"))
-    with pytest.raises(swhost.Unsupported):   # refused at the event boundary: the task never enters a batch
-        s.create_task(sc.pending("t1", "svc", Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))
+    s.create_node(sc.node("n1", Description={"Resources": {"NanoCPUs": 10**9, "MemoryBytes": 10**9, "Generic": sc.discrete("apple", 4)}}))
+    s.set_service("svc")
+    for bad in (sc.named("apple", "red"), sc.discrete("apple", 0), sc.discrete("apple", 1) + sc.discrete("apple", 2)):
+        with pytest.raises(swhost.Unsupported):
+            s.create_task(sc.pending("t1", "svc", Spec={"Resources": {"Reservations": {"Generic": bad}}}))
     assert s.tick() == []
     with pytest.raises(swhost.Unsupported):
         s.task_desc(sc.pending("t2", "svc", Spec={"Container": {"Mounts": [{"Type": 4, "Source": "vol"}]}}))
+    s.create_task(sc.pending("g1", "svc", 1, Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))   # SpecVersion 1: a group
+    d = s.tick()
+    assert len(d) == 1 and d[0]["ID"] == "g1" and d[0].get("Deferred") is True and not d[0]["NodeID"]
+    s.create_task(sc.pending("o1", "svc", Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 3)}}}))       # one-off: placed
+    d = {x["ID"]: x for x in s.tick()}
+    assert d["o1"]["NodeID"] == "n1" and d["o1"]["AssignedGenericResources"] == sc.discrete("apple", 3)
 
 
 def test_churn_rounds():
