@@ -124,10 +124,12 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
     for e in engines:
         e.state_save()
 
+    device_rounds = world == 1 and not args.host_merge   # one process: the rounds stay on the device (swp_shard_run)
+
     def make_driver():
         if world > 1:
             return swshard.RankShard(batches[0], rank, world, firsts, dist, ranks.device)   # cuda:<local rank> under RCCL, cpu if it fell back to gloo
-        return swshard.ShardGroup(batches, firsts)
+        return swshard.DeviceShardGroup(batches, firsts, fold=False) if device_rounds else swshard.ShardGroup(batches, firsts)
 
     def sync():
         torch.cuda.synchronize()
@@ -166,15 +168,20 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
     launch_ms = ms_prop / max(n_launch, 1)
     achieved = alg_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     traffic, traffic_src = profile_traffic("k_propose")
+    if device_rounds:   # no per-kernel events on this path: the step time over the rounds is what there is
+        launch_ms, achieved, n_launch = t_step * 1e3 / max(rounds, 1), 0.0, rounds * K
+        alg_launch = (wl.T / max(rounds, 1)) * wl.N * row_b + (wl.T / max(rounds, 1)) * TASK_B
+        achieved = alg_launch / (launch_ms * 1e-3) / 1e9
     result = {
         "metric": f"task placements/sec ({wl.T // 1000}k one-off tasks x {wl.N // 1000}k nodes, " + FILTERS.get(args.workload, args.workload) + ", spread)",
         "value": wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": dict(wl.describe(), parallelism="node-shard", shards=len(ranges), engines_per_gpu=1 if world > 1 else len(ranges),
-                       exchange="all_gather of %d-byte proposal records per task and shard (%s)" % (abi.PROPOSAL_DTYPE.itemsize, "RCCL" if world > 1 else "host arrays, one process"),
-                       control_backend=ranks.backend, block=swshard.BLOCK, rounds_per_step=rounds, tasks_decided_per_round=wl.T / max(rounds, 1)),
+                       exchange=("rounds on the device (swp_shard_run): block-resolver proposals per shard, one matching wave on the leader over the folded records, every shard applies its picks"
+                                 if device_rounds else "all_gather of %d-byte proposal records per task and shard (%s)" % (abi.PROPOSAL_DTYPE.itemsize, "RCCL" if world > 1 else "host arrays, one process")),
+                       control_backend=ranks.backend, block=512 if device_rounds else swshard.BLOCK, rounds_per_step=rounds, tasks_decided_per_round=wl.T / max(rounds, 1)),
         "pair_evals_per_s": wl.T * wl.N / t_step, "placed": placed, "unplaceable": wl.T - placed,
-        "roofline": {"bound": "hbm", "kernel": "k_propose", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "one sharded round (k_r6_propose x shards + k_r7_match + k_r7_apply x shards)" if device_rounds else "k_propose", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": launch_ms,
                      "launches_per_step": n_launch / K,
                      "note": "rank 0's shard; a task cut off a block is proposed again, so the tasks proposed per step exceed the batch (%.2fx)" % (n_ptasks / K / max(wl.T, 1))},
@@ -210,6 +217,7 @@ def main():
                     help="auto: one engine at N=1; at N>1 the node set is sharded over the ranks (SURVEY 8e: contiguous node ranges, RCCL "
                          "all-gather of the block's proposals, same merge on every rank). replicas: N independent clusters (no collective).")
     ap.add_argument("--shards", type=int, default=0, help="N=1 only: run the node-shard protocol over this many engines on the one GPU")
+    ap.add_argument("--host-merge", action="store_true", help="--shards: the round-2 protocol (proposals merged on the host) instead of the rounds on the device")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))

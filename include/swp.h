@@ -324,6 +324,22 @@ int swp_shard_commit(swp_engine*, swp_batch*, uint32_t j0, const swp_shard_pick*
  * shard-local node index of the tasks placed here (-1 elsewhere), and the placements folded into the host mirror */
 int swp_shard_end(swp_engine*, swp_batch*, int32_t* out_node_local, uint32_t* out_fail_hist);
 
+/* The same job with the ROUNDS ON THE DEVICE, for the deployment a Go manager is: ONE process, n engines — one per GPU of the box
+ * (peer access over xGMI), or several on one GPU — engines[g] owning node range g of the canonical order, batches[g] prepared on
+ * engines[g] from the SAME task list. Per round every shard proposes for a block of tasks over its own nodes (the block resolver's
+ * propose kernel, 16 non-empty half-words per task), the leader (shard 0) folds the records of all shards into one list per task in
+ * global node order and walks the block with its matching wave — the per-task "allreduce(min-score, argmin-node)" of the node-range
+ * split, done for the whole block by the one wave that has to order it — and every shard applies the picks of its range. No host
+ * work inside a round: the call enqueues rounds on the engines' streams (events order them across engines) and reads the leader's
+ * counters every few dozen rounds. At most 8 shards; generic reservations are not part of it yet (SWP_EUNSUPPORTED).
+ *   out_shard[i]    owner of task i's node, -1 = no suitable node
+ *   out_node[i]     shard-LOCAL node index on that engine
+ *   out_fail_hist   [n_tasks][SWP_NFILTERS], summed over the shards; may be NULL
+ * The placements are folded into each engine's host mirror (as swp_batch_fetch does) unless flags has SWP_SHARD_NO_FOLD. */
+#define SWP_SHARD_NO_FOLD 1u   /* leave the host mirrors alone (replay benchmarking, as swp_batch_results: run -> swp_state_restore -> run ...) */
+int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_t n_shards, uint32_t flags, int32_t* out_shard, int32_t* out_node,
+                  uint32_t* out_fail_hist);
+
 /* NodeInfo.addTask / removeTask for tasks the engine did not place itself (event handlers
  * scheduler.go:254-366; rollback :472-487). add_or_remove: 1 = add, 0 = remove. */
 typedef struct {

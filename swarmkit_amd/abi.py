@@ -109,7 +109,7 @@ EXPORTS = [
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
     "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce", "swp_node_matches",
     "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check", "swp_node_update_dynamic_many", "swp_node_get_many",
-    "swp_shard_begin", "swp_shard_propose", "swp_shard_merge", "swp_shard_commit", "swp_shard_end",
+    "swp_shard_begin", "swp_shard_propose", "swp_shard_merge", "swp_shard_commit", "swp_shard_end", "swp_shard_run",
     # include/swp_sched.h — the host layer above the engine
     "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
     "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
@@ -197,6 +197,7 @@ def load_library(path=None):
         "swp_shard_merge": ([P(vp), P(u32), u32, u32, vp, P(u32)], C.c_int),
         "swp_shard_commit": ([vp, vp, u32, vp, u32], C.c_int),
         "swp_shard_end": ([vp, vp, vp, vp], C.c_int),
+        "swp_shard_run": ([vp, vp, u32, u32, vp, vp, vp], C.c_int),
         "swp_check_node": ([vp, P(TaskDesc), u32, P(i32)], C.c_int),
         "swp_enforce": ([vp, vp, u32, vp, u32, vp], C.c_int),
         "swp_node_matches": ([vp, vp, u32, vp, u32], C.c_int),
@@ -246,6 +247,22 @@ def load_library(path=None):
         raise RuntimeError(f"ABI struct size mismatch: lib {list(sizes[:n])} vs binding {want}")
     _libs[path] = L
     return L
+
+
+def shard_run(batches, want_hist=True, fold=True):
+    """swp_shard_run: the node-range shards of ONE process with the rounds on the device. batches[g] = the Batch prepared on
+    engine g from the same task list. Returns (shard int32[T], shard-local node int32[T], hist uint32[T, 8] or None)."""
+    G, T = len(batches), batches[0].n
+    L = batches[0].eng.L
+    eh = (C.c_void_p * G)(*[b.eng.h for b in batches])
+    bh = (C.c_void_p * G)(*[b.h for b in batches])
+    shard = np.empty(T, dtype=np.int32)
+    node = np.empty(T, dtype=np.int32)
+    hist = np.zeros((T, NFILTERS), dtype=np.uint32) if want_hist else None
+    rc = L.swp_shard_run(eh, bh, G, 0 if fold else 1, shard.ctypes.data, node.ctypes.data, hist.ctypes.data if want_hist else None)
+    if rc != 0:
+        batches[0].eng._ck(rc)
+    return shard, node, hist
 
 
 def shard_merge(proposals, first_nodes, lib_path=None):

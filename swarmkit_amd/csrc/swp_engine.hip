@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +25,7 @@
 #include "swp_device.hpp"
 #include "swp_launch.hpp"
 #include "swp_resolve6.hpp"
+#include "swp_resolve7.hpp"
 #include "swp_shard.hpp"
 #include "swp_waterfill.hpp"
 
@@ -44,9 +46,13 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
+struct DevBuf {   // owns one device allocation: movable, not copyable
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
     ~DevBuf() { release(); }
     void release() {
         if (p) (void)hipFree(p);
@@ -884,6 +890,71 @@ int batch_begin(swp_engine* e, swp_batch* b) {
     return run_classes(e, b);
 }
 
+// The block resolver's argument record for (engine, batch): reserves the buffers it names. task_rows: ResourceFilter rows per task of
+// the block instead of per demand class (swp_resolve6.hpp k_r6_taskrows).
+int r6_args_for(swp_engine* e, swp_batch* b, uint32_t r6_block, bool r6_task_rows, uint32_t dbg_bits, R6Args* out) {
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N);
+    const uint32_t r6_nrr = r6_task_rows ? 0u : b->n_dc + b->n_dm;
+    HIPCHECK(e, b->d_planes6.reserve((size_t)R6_NP * Wn * 8));
+    HIPCHECK(e, b->d_rr6.reserve((size_t)std::max<uint32_t>(r6_nrr, 1) * Wn * 8));
+    if (r6_task_rows) HIPCHECK(e, b->d_trows.reserve((size_t)r6_block * Wn * 8));
+    HIPCHECK(e, b->d_blk6.reserve(sizeof(Blk6)));
+    HIPCHECK(e, b->d_prop.reserve((size_t)r6_block * sizeof(R6Prop)));
+    R6Args ra{};
+    ra.n_nodes = N;
+    ra.n_words = Wn;
+    ra.xs = Wn;
+    ra.block = r6_block;
+    ra.n_dc = r6_task_rows ? 0u : b->n_dc;
+    ra.n_dm = r6_task_rows ? 0u : b->n_dm;
+    ra.task_rows = r6_task_rows ? 1u : 0u;
+    ra.trows = r6_task_rows ? b->d_trows.as<u64>() : nullptr;
+    ra.dbg = dbg_bits;
+    ra.valid = e->d_valid.as<u64>();
+    ra.sc = b->d_sc.as<u64>();
+    ra.X = b->d_X.as<u64>();
+    ra.rt = b->d_rt.as<RTask>();
+    ra.cpu = e->d_cpu.as<long long>();
+    ra.mem = e->d_mem.as<long long>();
+    ra.total = e->d_total.as<uint32_t>();
+    ra.list_node = b->d_list_node.as<uint32_t>();
+    ra.list_svc = b->d_list_svc.as<uint32_t>();
+    ra.list_fail = b->d_list_fail.as<uint32_t>();
+    ra.list_off = b->d_list_off.as<uint32_t>();
+    ra.portmap = b->d_portmap.as<u64>();
+    ra.pset_off = b->d_pset_off.as<uint32_t>();
+    ra.pset_ids = b->d_pset_ids.as<uint32_t>();
+    ra.out_node = b->d_out.as<int32_t>();
+    ra.log_node = b->d_log_node.as<uint32_t>();
+    ra.log_task = b->d_log_task.as<uint32_t>();
+    ra.log_prev = b->d_log_prev.as<int32_t>();
+    ra.last = b->d_last.as<int32_t>();
+    ra.inf_task = b->d_inf_task.as<uint32_t>();
+    ra.inf_pos = b->d_inf_pos.as<uint32_t>();
+    ra.ctl = b->d_ctl.as<Ctl>();
+    ra.planes = b->d_planes6.as<u64>();
+    ra.rr = b->d_rr6.as<u64>();
+    ra.thr = b->d_thr64.as<long long>();
+    ra.blk = b->d_blk6.as<Blk6>();
+    ra.prop = b->d_prop.as<R6Prop>();
+    if (b->has_generic) {
+        HIPCHECK(e, b->d_rg.reserve((size_t)b->rg_kind.size() * Wn * 8));
+        ra.n_rg = (u32)b->rg_kind.size();
+        ra.gstride = e->ncap;
+        ra.gcnt = e->d_gcnt.as<int32_t>();
+        ra.rg = b->d_rg.as<u64>();
+        ra.tg = b->d_tg.as<uint32_t>();
+        ra.gs_off = b->d_gs_off.as<uint32_t>();
+        ra.gs_row = b->d_gs_row.as<uint32_t>();
+        ra.rg_kind = b->d_rg_kind.as<uint32_t>();
+        ra.rg_val = b->d_rg_val.as<int32_t>();
+        ra.rg_k0 = b->d_rg_k0.as<uint32_t>();
+        ra.rg_k1 = b->d_rg_k1.as<uint32_t>();
+    }
+    *out = ra;
+    return SWP_OK;
+}
+
 int batch_run_impl(swp_engine* e, swp_batch* b);
 // Every failure exit of the device pass leaves the device node rows (cpu / mem / total) possibly half-updated — the resolvers commit
 // while they run — so the untouched host mirror is uploaded again before the next device call (as swp_schedule_groups does).
@@ -951,11 +1022,6 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     // k_resolve6 over the stretch [start, end): build the bitmaps from the node rows as they are, then rounds of propose + commit.
     // The device advances on its own (the position lives in the control block); the host only learns every so many rounds how far it is.
     auto run_blocks = [&](uint32_t start, uint32_t end) -> int {
-        HIPCHECK(e, b->d_planes6.reserve((size_t)R6_NP * Wn * 8));
-        HIPCHECK(e, b->d_rr6.reserve((size_t)std::max<uint32_t>(r6_nrr, 1) * Wn * 8));
-        if (r6_task_rows) HIPCHECK(e, b->d_trows.reserve((size_t)r6_block * Wn * 8));
-        HIPCHECK(e, b->d_blk6.reserve(sizeof(Blk6)));
-        HIPCHECK(e, b->d_prop.reserve((size_t)r6_block * sizeof(R6Prop)));
         if (prof)
             while (e->ev_pool.size() < (size_t)4 * (wi + 1)) {
                 hipEvent_t x;
@@ -963,56 +1029,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 e->ev_pool.push_back(x);
             }
         R6Args ra{};
-        ra.n_nodes = N;
-        ra.n_words = Wn;
-        ra.xs = Wn;
-        ra.block = r6_block;
-        ra.n_dc = r6_task_rows ? 0u : b->n_dc;
-        ra.n_dm = r6_task_rows ? 0u : b->n_dm;
-        ra.task_rows = r6_task_rows ? 1u : 0u;
-        ra.trows = r6_task_rows ? b->d_trows.as<u64>() : nullptr;
-        ra.dbg = dbg_bits;
-        ra.valid = e->d_valid.as<u64>();
-        ra.sc = b->d_sc.as<u64>();
-        ra.X = b->d_X.as<u64>();
-        ra.rt = b->d_rt.as<RTask>();
-        ra.cpu = e->d_cpu.as<long long>();
-        ra.mem = e->d_mem.as<long long>();
-        ra.total = e->d_total.as<uint32_t>();
-        ra.list_node = b->d_list_node.as<uint32_t>();
-        ra.list_svc = b->d_list_svc.as<uint32_t>();
-        ra.list_fail = b->d_list_fail.as<uint32_t>();
-        ra.list_off = b->d_list_off.as<uint32_t>();
-        ra.portmap = b->d_portmap.as<u64>();
-        ra.pset_off = b->d_pset_off.as<uint32_t>();
-        ra.pset_ids = b->d_pset_ids.as<uint32_t>();
-        ra.out_node = b->d_out.as<int32_t>();
-        ra.log_node = b->d_log_node.as<uint32_t>();
-        ra.log_task = b->d_log_task.as<uint32_t>();
-        ra.log_prev = b->d_log_prev.as<int32_t>();
-        ra.last = b->d_last.as<int32_t>();
-        ra.inf_task = b->d_inf_task.as<uint32_t>();
-        ra.inf_pos = b->d_inf_pos.as<uint32_t>();
-        ra.ctl = b->d_ctl.as<Ctl>();
-        ra.planes = b->d_planes6.as<u64>();
-        ra.rr = b->d_rr6.as<u64>();
-        ra.thr = b->d_thr64.as<long long>();
-        ra.blk = b->d_blk6.as<Blk6>();
-        ra.prop = b->d_prop.as<R6Prop>();
-        if (b->has_generic) {
-            HIPCHECK(e, b->d_rg.reserve((size_t)b->rg_kind.size() * Wn * 8));
-            ra.n_rg = (u32)b->rg_kind.size();
-            ra.gstride = e->ncap;
-            ra.gcnt = e->d_gcnt.as<int32_t>();
-            ra.rg = b->d_rg.as<u64>();
-            ra.tg = b->d_tg.as<uint32_t>();
-            ra.gs_off = b->d_gs_off.as<uint32_t>();
-            ra.gs_row = b->d_gs_row.as<uint32_t>();
-            ra.rg_kind = b->d_rg_kind.as<uint32_t>();
-            ra.rg_val = b->d_rg_val.as<int32_t>();
-            ra.rg_k0 = b->d_rg_k0.as<uint32_t>();
-            ra.rg_k1 = b->d_rg_k1.as<uint32_t>();
-        }
+        if (int rc6 = r6_args_for(e, b, r6_block, r6_task_rows, dbg_bits, &ra)) return rc6;
         if (prof) {
             HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 0], st));
             HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 1], st));
@@ -2121,6 +2138,238 @@ int swp_shard_end(swp_engine* e, swp_batch* b, int32_t* out_node_local, uint32_t
     e->stats.tasks += T;
     e->stats.placed += placed;
     e->stats.pair_evals += (uint64_t)T * e->n_present;
+    return SWP_OK;
+}
+
+int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_t G, uint32_t flags, int32_t* out_shard, int32_t* out_node, uint32_t* out_fail_hist) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!engines || !batches || G == 0 || !engines[0] || !batches[0]) return SWP_EINVAL;
+    swp_engine* e0 = engines[0];
+    if (G > R7_MAXS) return e0->fail(SWP_ERANGE, "%u shards: the device-side rounds take at most %d", G, R7_MAXS);
+    const uint32_t T = batches[0]->T;
+    if ((!out_shard || !out_node) && T) return SWP_EINVAL;
+    for (uint32_t g = 0; g < G; ++g) {
+        if (!engines[g] || !batches[g] || batches[g]->T != T) return e0->fail(SWP_EINVAL, "shard %u: every shard's batch must hold the same %u tasks", g, T);
+        if (engines[g]->n_nodes != batches[g]->n_nodes_prepared) return e0->fail(SWP_EINVAL, "shard %u: the nodeSet grew since swp_batch_prepare", g);
+        if (batches[g]->has_generic) return e0->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the node-range shard protocol yet");
+        for (uint32_t h = 0; h < g; ++h)
+            if (engines[h] == engines[g]) return e0->fail(SWP_EINVAL, "shards %u and %u name the same engine", h, g);
+    }
+    if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
+    for (uint32_t i = 0; i < T; ++i) out_shard[i] = out_node[i] = -1;
+    if (T == 0) return SWP_OK;
+    const char* env_dbg = getenv("SWP_DBG");
+    const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
+    const char* env_blk = getenv("SWP_R6_BLOCK");
+    const uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    const size_t lds_budget = 160 * 1024 - 512;
+    // one failure anywhere leaves every shard's device rows possibly half-updated: the host mirrors (untouched) are uploaded again
+    auto fail_all = [&](int rc) {
+        for (uint32_t g = 0; g < G; ++g) engines[g]->dev_dynamic_dirty = true;
+        return rc;
+    };
+    // per shard: state to pristine + class bitmaps (what swp_batch_run does first), the block resolver's bitmaps, its argument record
+    std::vector<R6Args> ra(G);
+    R7Args ma{};
+    ma.n_shards = G;
+    ma.block = block;
+    ma.dbg = dbg_bits;
+    uint32_t first = 0, hw = 0;
+    const bool task_rows = [&] {
+        const char* env_tr = getenv("SWP_R6_TASKROWS");
+        if (env_tr) return atoi(env_tr) != 0;
+        for (uint32_t g = 0; g < G; ++g)
+            if (!batches[g]->classes_ok || batches[g]->n_dc + batches[g]->n_dm > 128) return true;
+        return false;
+    }();
+    for (uint32_t g = 0; g < G; ++g) {
+        swp_engine* e = engines[g];
+        swp_batch* b = batches[g];
+        (void)hipSetDevice(e->device);
+        ma.hw_base[g] = hw;
+        ma.first_node[g] = first;
+        first += e->n_nodes;
+        hw += (e->n_nodes + 31) / 32;
+        if (g > 0 && e->device != e0->device) {   // the leader reads this shard's proposals, this shard reads the leader's picks: peer memory
+            int ok01 = 0, ok10 = 0;
+            (void)hipDeviceCanAccessPeer(&ok01, e0->device, e->device);
+            (void)hipDeviceCanAccessPeer(&ok10, e->device, e0->device);
+            if (!ok01 || !ok10) return e0->fail(SWP_EUNSUPPORTED, "devices %d and %d cannot access each other's memory", e0->device, e->device);
+            (void)hipSetDevice(e0->device);
+            hipError_t pr = hipDeviceEnablePeerAccess(e->device, 0);
+            if (pr != hipSuccess && pr != hipErrorPeerAccessAlreadyEnabled) return e0->fail(SWP_EHIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(pr));
+            (void)hipSetDevice(e->device);
+            pr = hipDeviceEnablePeerAccess(e0->device, 0);
+            if (pr != hipSuccess && pr != hipErrorPeerAccessAlreadyEnabled) return e0->fail(SWP_EHIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(pr));
+            (void)hipGetLastError();
+        }
+        if (e->n_nodes == 0) return e0->fail(SWP_EINVAL, "shard %u owns no node", g);
+        const uint32_t Wn = n_words_of(e->n_nodes);
+        const uint32_t nrr = task_rows ? 0u : b->n_dc + b->n_dm;
+        if (r6_propose_lds_size(Wn) > lds_budget || r6_commit_lds_size(Wn, block, nrr) > lds_budget)
+            return e0->fail(SWP_ERANGE, "shard %u: %u nodes exceed the block resolver's LDS", g, e->n_nodes);
+        int rc = batch_begin(e, b);
+        if (rc) return fail_all(rc);
+        if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra[g]))) return fail_all(rc);
+        Blk6 hb{};
+        hb.pos = 0;
+        hb.end = T;
+        HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, e->stream));
+        hipError_t r = launch_r6_build(ra[g], e->stream);
+        if (r != hipSuccess) return fail_all(e0->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(r)));
+        ma.prop[g] = ra[g].prop;
+    }
+    ma.hw_base[G] = ma.hw_total = hw;
+    if (r7_match_lds_size(hw) > lds_budget) return fail_all(e0->fail(SWP_ERANGE, "%u nodes over all shards exceed the matching wave's LDS", first));
+    // shards that live on one device are served by ONE propose and ONE apply launch per round, on the stream of the first of them
+    struct Group { uint32_t g0, count, max_words; int device; hipStream_t stream; DevBuf d_args; hipEvent_t ev_prop = nullptr; };
+    std::vector<Group> groups;
+    for (uint32_t g = 0; g < G; ++g) {
+        if (groups.empty() || groups.back().device != engines[g]->device) {
+            groups.emplace_back();
+            groups.back().g0 = g;
+            groups.back().count = 0;
+            groups.back().max_words = 0;
+            groups.back().device = engines[g]->device;
+            groups.back().stream = engines[g]->stream;
+        }
+        groups.back().count += 1;
+        groups.back().max_words = std::max(groups.back().max_words, n_words_of(engines[g]->n_nodes));
+    }
+    (void)hipSetDevice(e0->device);
+    DevBuf d_picks, d_head, d_merged;
+    HIPCHECK(e0, d_picks.reserve((size_t)block * sizeof(R7Pick)));
+    HIPCHECK(e0, d_head.reserve(sizeof(R7Head)));
+    HIPCHECK(e0, d_merged.reserve((size_t)block * sizeof(R6Prop)));
+    HIPCHECK(e0, hipMemsetAsync(d_head.p, 0, sizeof(R7Head), e0->stream));
+    ma.blk = ra[0].blk;
+    ma.ctl = ra[0].ctl;
+    ma.picks = d_picks.as<R7Pick>();
+    ma.head = d_head.as<R7Head>();
+    ma.merged = d_merged.as<R6Prop>();
+    hipEvent_t ev_match = nullptr;
+    auto cleanup = [&] {
+        for (Group& gr : groups)
+            if (gr.ev_prop) (void)hipEventDestroy(gr.ev_prop);
+        if (ev_match) (void)hipEventDestroy(ev_match);
+    };
+    auto die = [&](int rc) {
+        for (uint32_t g = 0; g < G; ++g) {
+            (void)hipSetDevice(engines[g]->device);
+            (void)hipStreamSynchronize(engines[g]->stream);
+        }
+        cleanup();
+        return fail_all(rc);
+    };
+    for (Group& gr : groups) {
+        (void)hipSetDevice(gr.device);
+        if (gr.d_args.reserve((size_t)gr.count * sizeof(R6Args)) != hipSuccess ||
+            hipMemcpyAsync(gr.d_args.p, &ra[gr.g0], (size_t)gr.count * sizeof(R6Args), hipMemcpyHostToDevice, gr.stream) != hipSuccess ||
+            hipEventCreateWithFlags(&gr.ev_prop, hipEventDisableTiming) != hipSuccess)
+            return die(e0->fail(SWP_EHIP, "setting up the shards of device %d: %s", gr.device, hipGetErrorString(hipGetLastError())));
+    }
+    (void)hipSetDevice(e0->device);
+    if (hipEventCreateWithFlags(&ev_match, hipEventDisableTiming) != hipSuccess) return die(e0->fail(SWP_EHIP, "hipEventCreate"));
+    // the per-engine streams have the batch set-up in flight: the group streams start behind it
+    for (uint32_t g = 0; g < G; ++g) {
+        (void)hipSetDevice(engines[g]->device);
+        if (hipStreamSynchronize(engines[g]->stream) != hipSuccess) return die(e0->fail(SWP_EHIP, "shard %u set-up: %s", g, hipGetErrorString(hipGetLastError())));
+    }
+    const auto t_rounds0 = std::chrono::steady_clock::now();
+    // rounds: enqueued blindly, the leader's header read every `chunk` rounds (a round past the end is a handful of empty launches)
+    uint32_t pos = 0, chunk = std::min<uint32_t>(16u, (T + 255u) / 256u + 1u);
+    uint64_t rounds = 0;
+    Blk6 hb{};
+    while (pos < T) {
+        for (uint32_t r = 0; r < chunk; ++r) {
+            for (Group& gr : groups) {
+                (void)hipSetDevice(gr.device);
+                hipError_t x = launch_r7_propose(gr.d_args.as<R6Args>(), gr.count, block, gr.max_words, task_rows, gr.stream, gr.device);
+                if (x == hipSuccess && groups.size() > 1) x = hipEventRecord(gr.ev_prop, gr.stream);
+                if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "propose on device %d: %s", gr.device, hipGetErrorString(x)));
+            }
+            (void)hipSetDevice(e0->device);
+            for (size_t q = 1; q < groups.size(); ++q)
+                if (hipStreamWaitEvent(groups[0].stream, groups[q].ev_prop, 0) != hipSuccess) return die(e0->fail(SWP_EHIP, "hipStreamWaitEvent"));
+            hipError_t x = launch_r7_match(ma, groups[0].stream, e0->device);
+            if (x == hipSuccess && groups.size() > 1) x = hipEventRecord(ev_match, groups[0].stream);
+            if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "k_r7_match: %s", hipGetErrorString(x)));
+            for (size_t q = 0; q < groups.size(); ++q) {
+                Group& gr = groups[q];
+                (void)hipSetDevice(gr.device);
+                if (q > 0 && hipStreamWaitEvent(gr.stream, ev_match, 0) != hipSuccess) return die(e0->fail(SWP_EHIP, "hipStreamWaitEvent"));
+                x = launch_r7_apply(gr.d_args.as<R6Args>(), gr.count, ma.picks, ma.head, gr.g0, gr.stream);
+                if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "apply on device %d: %s", gr.device, hipGetErrorString(x)));
+            }
+        }
+        rounds += chunk;
+        (void)hipSetDevice(e0->device);
+        if (hipMemcpyAsync(&hb, batches[0]->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, groups[0].stream) != hipSuccess || hipStreamSynchronize(groups[0].stream) != hipSuccess)
+            return die(e0->fail(SWP_EHIP, "reading the leader's control block: %s", hipGetErrorString(hipGetLastError())));
+        if (hb.error != ERR_NONE) return die(e0->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP));
+        if (hb.pos <= pos) return die(e0->fail(SWP_EHIP, "sharded rounds made no progress at task %u", pos));
+        const double pace = std::max(1.0, (double)hb.pos / (double)std::max<uint32_t>(hb.rounds, 1));
+        pos = hb.pos;
+        chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / pace * 1.05 + 4.0);
+    }
+    for (Group& gr : groups) {
+        (void)hipSetDevice(gr.device);
+        if (hipStreamSynchronize(gr.stream) != hipSuccess) return die(e0->fail(SWP_EHIP, "device %d: %s", gr.device, hipGetErrorString(hipGetLastError())));
+    }
+    const auto t_rounds1 = std::chrono::steady_clock::now();
+    // every shard: wait, check, explain the unplaceable tasks over its own nodes, results back, host mirror
+    std::vector<int32_t> local(T);
+    std::vector<uint32_t> hist;
+    if (out_fail_hist) hist.resize((size_t)T * SWP_NFILTERS);
+    for (uint32_t g = 0; g < G; ++g) {
+        swp_engine* e = engines[g];
+        swp_batch* b = batches[g];
+        (void)hipSetDevice(e->device);
+        Ctl ctl{};
+        Blk6 sb{};
+        if (hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipMemcpyAsync(&sb, b->d_blk6.p, sizeof sb, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+            return die(e0->fail(SWP_EHIP, "shard %u: %s", g, hipGetErrorString(hipGetLastError())));
+        if (sb.error != ERR_NONE) return die(e0->fail(SWP_ERANGE, "shard %u: per-node task-count spread exceeds the %d level planes", g, R6_NP));
+        if (sb.pos != T) return die(e0->fail(SWP_EHIP, "shard %u stopped at task %u of %u", g, sb.pos, T));
+        if (ctl.ninf) {
+            int rc = run_explain(e, b, ctl.ninf);
+            if (rc) return die(rc);
+        }
+        if (hipMemcpyAsync(local.data(), b->d_out.p, (size_t)T * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return die(e0->fail(SWP_EHIP, "results of shard %u", g));
+        if (out_fail_hist && ctl.ninf && hipMemcpyAsync(hist.data(), b->d_hist.p, (size_t)T * 8 * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+            return die(e0->fail(SWP_EHIP, "histograms of shard %u", g));
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return die(e0->fail(SWP_EHIP, "shard %u: %s", g, hipGetErrorString(hipGetLastError())));
+        uint64_t placed = 0;
+        for (uint32_t i = 0; i < T; ++i) {
+            const int32_t nloc = local[i];
+            if (nloc < 0) continue;
+            if ((uint32_t)nloc >= e->nodes.size() || !e->nodes[nloc].present || out_shard[i] >= 0) return die(e0->fail(SWP_EHIP, "shard %u returned an invalid placement for task %u", g, i));
+            out_shard[i] = (int32_t)g;
+            out_node[i] = nloc;
+            const swp_task_desc& d = b->tasks[i];
+            if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)nloc, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+            ++placed;
+        }
+        if (out_fail_hist && ctl.ninf)
+            for (size_t q = 0; q < hist.size(); ++q) out_fail_hist[q] += hist[q];
+        e->stats.batches++;
+        e->stats.tasks += T;
+        e->stats.placed += placed;
+        e->stats.pair_evals += (uint64_t)T * e->n_present;
+        e->stats.last_resolver = 7;   // node-range shards, rounds on the device
+        e->stats.resolve_launches += (uint32_t)rounds;
+    }
+    if (dbg_bits & 16) {
+        R7Head hh{};
+        (void)hipSetDevice(e0->device);
+        (void)hipMemcpy(&hh, d_head.p, sizeof hh, hipMemcpyDeviceToHost);
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[swp] sharded rounds over %u engines: %u rounds of %u (%.1f decided each) | cut by an exhausted list %u, an exception-list task %u, an uncounted task %u | set-up %.2f ms, rounds %.2f ms, explain + results %.2f ms\n", G,
+                hh.rounds, block, (double)T / std::max<uint32_t>(hh.rounds, 1), hh.cut_exhausted, hh.cut_exception, hh.cut_uncounted, ms(t_begin, t_rounds0), ms(t_rounds0, t_rounds1),
+                ms(t_rounds1, std::chrono::steady_clock::now()));
+    }
+    cleanup();
     return SWP_OK;
 }
 

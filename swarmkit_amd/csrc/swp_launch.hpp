@@ -26,7 +26,16 @@ uint32_t r6_block_max();
 hipError_t launch_r6_build(const R6Args& a, hipStream_t s);
 hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int dev);
 
-// sharded scan (swp_shard.hip)
+// node-range shards, rounds on the device (swp_resolve7.hpp, built in swp_resolve6.hip)
+struct R7Args;
+struct R7Pick;
+struct R7Head;
+size_t r7_match_lds_size(uint32_t hw_total);
+hipError_t launch_r7_propose(const R6Args* args, uint32_t count, uint32_t block, uint32_t max_words, bool task_rows, hipStream_t s, int dev);
+hipError_t launch_r7_match(const R7Args& a, hipStream_t s, int dev);   // fold + match
+hipError_t launch_r7_apply(const R6Args* args, uint32_t count, const R7Pick* picks, const R7Head* head, uint32_t shard0, hipStream_t s);
+
+// sharded scan, host-merged rounds (swp_shard.hip)
 struct ProposeArgs;
 struct ShardApplyArgs;
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t s);

@@ -177,7 +177,7 @@ WV_KERNEL(256) void k_r6_rows(R6Args a) {
 // cross hundreds of demand-class thresholds. For such a batch the rows are not kept per class and patched by the commits but built
 // per task at the start of every round, from the exact residuals: one wave per node word (a ballot IS a row word), the block's
 // reservations staged in LDS. No limit on the number of distinct reservations.
-WV_KERNEL(256) void k_r6_taskrows(R6Args a) {
+WV_DEV void r6_taskrows(const R6Args& a) {
     const u32 pos = wv::uload(&a.blk->pos), end = wv::uload(&a.blk->end);
     if (pos >= end || wv::uload(&a.blk->error) != ERR_NONE) return;
     const u32 cnt = min(a.block, end - pos);
@@ -212,10 +212,12 @@ WV_KERNEL(256) void k_r6_taskrows(R6Args a) {
     }
 }
 
+WV_KERNEL(256) void k_r6_taskrows(R6Args a) { r6_taskrows(a); }
+
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
 // The waves split the task's node words (wave v owns the chunks of 64 words k = v, v + R6_PW, ...): the passes are latency-bound,
 // so more waves per task is what shortens them. A pass ends with one barrier (has any wave a candidate left?).
-WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
+WV_DEV void r6_propose(const R6Args& a) {
     const u32 lane = wv::lane(), wave = wv::wave();
     const u32 t = wv::uload(&a.blk->pos) + wv::block();
     if (t >= wv::uload(&a.blk->end) || wv::uload(&a.blk->error) != ERR_NONE) return;   // (an error stops the rounds until the host has seen it)
@@ -382,6 +384,8 @@ WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) {
         out->flags = (flags & RT_UNCOUNTED) ? 1u : 0u;
     }
 }
+
+WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) { r6_propose(a); }
 
 // index of the first of n ascending thresholds that is greater than q (n: none)
 WV_DEV u32 r6_first_above(const i64* thr, u32 n, i64 q) {

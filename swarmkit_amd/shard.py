@@ -1,13 +1,19 @@
 """Node-range shards of the nodeSet (include/swp.h "node-range shards"): the driver of the
 propose / exchange / merge / commit rounds.
 
-Two deployments of the same protocol:
+Three drivers:
 
-  ShardGroup      G engines in ONE process (one per GPU of the box, or several on one GPU — that is how the GPU parity tests
-                  run it): the exchange is a list of host arrays.
+  DeviceShardGroup  G engines in ONE process — the deployment a Go manager is: one engine per GPU of the box (peer access over
+                  xGMI), or several on one GPU — with the ROUNDS ON THE DEVICE (swp_shard_run in libswp.so, csrc/swp_resolve7.hpp):
+                  every shard proposes with the block resolver's kernel, the leader's matching wave folds the shards' records per
+                  task and walks the block, every shard applies its picks; the host only enqueues and reads a counter now and then.
+  ShardGroup      G engines in ONE process, the round-2 protocol: proposals back to the host, merged there (swp_shard_merge), picks
+                  sent down: the exchange is a list of host arrays.
   RankShard       one engine per process / GPU (torch.distributed, backend nccl == RCCL on ROCm, gloo on CPU test doubles): the
-                  exchange is an all_gather of the block's proposal records (48 B per task and shard) over xGMI; every rank
-                  runs the same deterministic merge, so no second collective is needed to agree on the picks.
+                  exchange is an all_gather of the block's proposal records (80 B per task and shard, include/swp.h swp_proposal)
+                  over xGMI; every rank runs the same deterministic merge, so no second collective is needed to agree on the
+                  picks. A task that must use its service's exception list costs a round of its own here (one collective per such
+                  task): runs of identical tasks should be water-filled before a batch is sharded.
 
 What crosses the exchange is each shard's argmin candidates for the block (minimum level + the first nodes of that level in
 node order + the best exception-list node): the per-task "allreduce(min-score, argmin-node)" of the north star, widened to a
@@ -36,6 +42,23 @@ def shard_ranges(n_nodes, n_shards):
 def _finish(picked_shard, picked_node, firsts, hists):
     out = np.where(picked_shard >= 0, np.asarray(firsts, dtype=np.int64)[np.maximum(picked_shard, 0)] + picked_node, -1).astype(np.int64)
     return out, (sum(hists) if hists and hists[0] is not None else None)
+
+
+class DeviceShardGroup:
+    """G (engine, batch) pairs in one process, rounds on the device (swp_shard_run). Shards without nodes are left out."""
+
+    def __init__(self, batches, firsts, fold=True):
+        self.fold = fold
+        keep = [g for g, b in enumerate(batches) if b.eng.stats()["n_nodes"] > 0]
+        self.batches, self.firsts = [batches[g] for g in keep], [int(firsts[g]) for g in keep]
+        self.T = batches[0].n
+        self.rounds = 0
+
+    def run(self, want_hist=True):
+        before = self.batches[0].eng.stats()["resolve_launches"]
+        shard, node, hist = abi.shard_run(self.batches, want_hist, self.fold)
+        self.rounds = self.batches[0].eng.stats()["resolve_launches"] - before
+        return _finish(shard.astype(np.int64), node.astype(np.int64), self.firsts, [hist])
 
 
 class ShardGroup:

@@ -252,6 +252,7 @@ inline u32 nthreads() { return emu::B()->nthreads; }
 inline u32 lane() { return emu::B()->cur & 63u; }
 inline u32 wave() { return emu::B()->cur >> 6; }
 inline u32 block() { return emu::blockidx(); }
+inline u32 block_y() { return 0; }
 inline u64* lds() { return emu::B()->lds.data(); }
 
 inline u64 ballot(bool p) { return emu::collective(emu::OP_BALLOT, p ? 1 : 0, 0); }

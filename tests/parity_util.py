@@ -51,7 +51,7 @@ def assert_same(a_placed, a_errs, b_placed, b_errs):
     assert not ediff, f"{len(ediff)} explanations differ, first: {ediff[:3]}"
 
 
-def sharded_run(wl, n_shards, block=256, **engine_kw):
+def sharded_run(wl, n_shards, block=256, mode="host", **engine_kw):
     """The same workload over `n_shards` node-range shards (swarmkit_amd.shard.ShardGroup), every shard an engine of its own
     on this process' device. Returns (placed, errs, rounds) in the oracle's vocabulary."""
     from swarmkit_amd import shard as swshard
@@ -62,7 +62,10 @@ def sharded_run(wl, n_shards, block=256, **engine_kw):
         descs = swhost.load_workload(s, wl, first, cnt)
         scheds.append(s)
         batches.append(s.e.batch_prepare(descs))
-    grp = swshard.ShardGroup(batches, [r[0] for r in ranges], block=block)
+    if mode == "device":   # rounds on the device (swp_shard_run); the block size is the block resolver's (SWP_R6_BLOCK)
+        grp = swshard.DeviceShardGroup(batches, [r[0] for r in ranges])
+    else:
+        grp = swshard.ShardGroup(batches, [r[0] for r in ranges], block=block)
     out, hist = grp.run()
     placed, errs = {}, {}
     for j in range(wl.T):

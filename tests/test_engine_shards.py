@@ -1,7 +1,9 @@
 """GPU parity of the node-range sharded scan (include/swp.h "node-range shards"): the node set split over
-2 / 3 / 4 engines — here all on one device, the exchange being host arrays; between GPUs it is an RCCL all-gather
-(swarmkit_amd.shard.RankShard, tests/test_dist_gloo.py) — must place every task exactly where the oracle's single
-sequential scan does, with the same explanation for every unplaceable task."""
+2 / 3 / 4 engines — here all on one device — must place every task exactly where the oracle's single sequential scan does, with the
+same explanation for every unplaceable task. Two drivers: "device" = the rounds on the device (swp_shard_run, csrc/swp_resolve7.hpp:
+block-resolver proposals per shard, one matching wave over the folded records, every shard applies its picks — what a one-process
+manager over the GPUs of a box runs), "host" = the round-2 protocol with the merge on the host (between processes the exchange is an
+RCCL all-gather: swarmkit_amd.shard.RankShard, tests/test_dist_gloo.py)."""
 import numpy as np
 import pytest
 
@@ -11,65 +13,76 @@ from swarmkit_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+MODES = ["device", "host"]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("shards", [2, 3, 4])
-@pytest.mark.parametrize("name,T,N,kw", [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg2", 3000, 50, {}), ("cfg1", 500, 40, {})])
-def test_shards_agree_with_oracle(shards, name, T, N, kw):
+@pytest.mark.parametrize("name,T,N,kw", [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg2", 3000, 50, {}), ("cfg1", 500, 40, {}), ("cfg3m", 3000, 500, {"services": 900})])
+def test_shards_agree_with_oracle(mode, shards, name, T, N, kw):
     wl = synth.Workload(name, T=T, N=N, **kw)
     op, oe, _ = pu.oracle_run(wl)
-    sp, se, rounds = pu.sharded_run(wl, shards)
+    sp, se, rounds = pu.sharded_run(wl, shards, mode=mode)
     pu.assert_same(op, oe, sp, se)
     assert rounds <= T
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("services,order", [(1, "rr"), (3, "major"), (40, "major")])
-def test_shards_same_service_runs(services, order):
+def test_shards_same_service_runs(mode, services, order):
     """Few services: almost every task ends on its service's exception list (nodes where it already runs), the path where a
     block is cut after one task."""
     wl = synth.Workload("cfg3", T=1200, N=200, services=services, order=order)
     op, oe, _ = pu.oracle_run(wl)
-    sp, se, _ = pu.sharded_run(wl, 3)
+    sp, se, _ = pu.sharded_run(wl, 3, mode=mode)
     pu.assert_same(op, oe, sp, se)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("block", [1, 7, 64, 1024])
-def test_block_size_does_not_matter(block):
+def test_block_size_does_not_matter(mode, block, monkeypatch):
+    monkeypatch.setenv("SWP_R6_BLOCK", str(block))
     wl = synth.Workload("cfg4", T=1500, N=400)
     op, oe, _ = pu.oracle_run(wl)
-    sp, se, _ = pu.sharded_run(wl, 4, block=block)
+    sp, se, _ = pu.sharded_run(wl, 4, block=block, mode=mode)
     pu.assert_same(op, oe, sp, se)
 
 
-def test_uncounted_tasks_end_the_block():
+@pytest.mark.parametrize("mode", MODES)
+def test_uncounted_tasks_end_the_block(mode):
     """A task that does not count on its node (DesiredState beyond COMPLETED, nodeinfo.go:131-134) leaves the node on its level: the
     proposals of the later tasks of the block are stale about it, so the merge ends the block behind such a pick."""
     wl = synth.Workload("cfg2", T=1500, N=300)
     wl.uncounted_every = 4
     op, oe, _ = pu.oracle_run(wl)
-    sp, se, _ = pu.sharded_run(wl, 3)
+    sp, se, _ = pu.sharded_run(wl, 3, mode=mode)
     pu.assert_same(op, oe, sp, se)
 
 
-def test_more_shards_than_nodes():
+@pytest.mark.parametrize("mode", MODES)
+def test_more_shards_than_nodes(mode):
     wl = synth.Workload("cfg2", T=200, N=3)
     op, oe, _ = pu.oracle_run(wl)
-    sp, se, _ = pu.sharded_run(wl, 4)   # one shard is empty
+    sp, se, _ = pu.sharded_run(wl, 4, mode=mode)   # one shard is empty
     pu.assert_same(op, oe, sp, se)
 
 
-def test_sharded_equals_single_engine_at_scale():
+@pytest.mark.parametrize("mode", MODES)
+def test_sharded_equals_single_engine_at_scale(mode):
     """20k x 6k over 4 shards against the single-engine placement vector (itself pinned to the oracle by the other suites)."""
     wl = synth.Workload("cfg4", T=20000, N=6000)
     ep, ee, *_ = pu.engine_run(wl)
-    sp, se, rounds = pu.sharded_run(wl, 4)
+    sp, se, rounds = pu.sharded_run(wl, 4, mode=mode)
     pu.assert_same(ep, ee, sp, se)
     assert rounds < wl.T // 4   # an exchange decides many tasks
 
 
-def test_sharded_cfg4_200k_x_40k_equals_single_engine():
-    """BASELINE configs[3] at a fifth of its size — past the 16k-node range of the round resolver, so the single engine runs
-    the workgroup resolver — against 4 shards of 10k nodes. (The single-engine placement of exactly this case is pinned to the
-    oracle's offline digest by tests/test_engine_bigcases.py::cfg4_mid.)"""
+@pytest.mark.parametrize("mode", MODES)
+def test_sharded_cfg4_200k_x_40k_equals_single_engine(mode):
+    """BASELINE configs[3] at a fifth of its size — past the node range of the round resolver, so the single engine runs the block
+    resolver — against 4 shards of 10k nodes. (The single-engine placement of exactly this case is pinned to the oracle's offline
+    digest by tests/test_engine_bigcases.py::cfg4_mid.)"""
     wl = synth.Workload("cfg4", T=200_000, N=40_000)
     ep, ee, *_ = pu.engine_run(wl)
-    sp, se, rounds = pu.sharded_run(wl, 4)
+    sp, se, rounds = pu.sharded_run(wl, 4, mode=mode)
     pu.assert_same(ep, ee, sp, se)
