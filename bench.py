@@ -124,9 +124,11 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
     for e in engines:
         e.state_save()
 
-    device_rounds = world == 1 and not args.host_merge   # one process: the rounds stay on the device (swp_shard_run)
+    device_rounds = not args.host_merge   # the rounds stay on the device: swp_shard_run (one process) / swp_shard_run_rank (RCCL between ranks)
 
     def make_driver():
+        if world > 1 and not args.host_merge:   # rounds on the device, an ncclAllGather of the block's proposals per round (swp_shard_run_rank)
+            return swshard.DeviceRankShard(batches[0], rank, world, ranges, dist, ranks.device, fold=False)
         if world > 1:
             return swshard.RankShard(batches[0], rank, world, firsts, dist, ranks.device)   # cuda:<local rank> under RCCL, cpu if it fell back to gloo
         return swshard.DeviceShardGroup(batches, firsts, fold=False) if device_rounds else swshard.ShardGroup(batches, firsts)

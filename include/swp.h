@@ -340,6 +340,22 @@ int swp_shard_end(swp_engine*, swp_batch*, int32_t* out_node_local, uint32_t* ou
 int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_t n_shards, uint32_t flags, int32_t* out_shard, int32_t* out_node,
                   uint32_t* out_fail_hist);
 
+/* The rank variant: ONE engine per process / GPU, the ranks of a job connected by RCCL over xGMI (librccl.so is loaded on first use;
+ * the engine links nothing of it). The rounds are the same kernels — every rank proposes over its own node range, an
+ * ncclAllGather on the engine's stream hands every rank the proposals of all of them (block x 160 bytes per rank and round), and
+ * EVERY rank folds + matches the block (the same deterministic wave everywhere: no second collective to agree on the picks) and
+ * applies the picks of its own range. Bootstrap as usual with RCCL: rank 0 fills an id (swp_rccl_unique_id), the application
+ * hands it to the other ranks over whatever it has (the Go manager's raft / gRPC; bench.py: torch.distributed), every rank calls
+ * swp_rccl_init once per engine.
+ *   shard_nodes[g]   node count of rank g's range (every rank passes the same array: the global tie order)
+ *   out_node_local   this rank's node index of the tasks placed here, -1 elsewhere
+ *   out_fail_hist    this rank's share of the Explain histograms (sum over the ranks), may be NULL */
+#define SWP_RCCL_ID_BYTES 128
+int swp_rccl_unique_id(swp_engine*, uint8_t id_out[SWP_RCCL_ID_BYTES]);
+int swp_rccl_init(swp_engine*, const uint8_t id[SWP_RCCL_ID_BYTES], uint32_t rank, uint32_t n_ranks);
+int swp_rccl_finalize(swp_engine*);   /* ncclCommDestroy; swp_destroy does not (an engine often dies with the process, after RCCL itself) */
+int swp_shard_run_rank(swp_engine*, swp_batch*, const uint32_t* shard_nodes, uint32_t flags, int32_t* out_node_local, uint32_t* out_fail_hist);
+
 /* NodeInfo.addTask / removeTask for tasks the engine did not place itself (event handlers
  * scheduler.go:254-366; rollback :472-487). add_or_remove: 1 = add, 0 = remove. */
 typedef struct {

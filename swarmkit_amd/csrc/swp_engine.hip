@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -241,6 +243,10 @@ struct swp_engine {
         decltype(svc_nodes) svc_nodes_;
         decltype(port_nodes) port_nodes_;
     } saved;
+
+    // RCCL communicator of this rank (swp_rccl_init); librccl.so is loaded on first use
+    void* rccl_comm = nullptr;
+    uint32_t rccl_rank = 0, rccl_ranks = 0;
 
     swp_stats_t stats{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1378,6 +1384,8 @@ void swp_destroy(swp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    // (an RCCL communicator is NOT torn down here: engines are often destroyed while the process exits, after RCCL's own static
+    // state is gone — swp_rccl_finalize is the orderly way)
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -2370,6 +2378,190 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
                 ms(t_rounds1, std::chrono::steady_clock::now()));
     }
     cleanup();
+    return SWP_OK;
+}
+
+// ---- RCCL, loaded lazily: the four entry points the rank variant needs ---------------------------------------------------------
+namespace {
+struct RcclId { char internal[SWP_RCCL_ID_BYTES]; };   // ncclUniqueId, passed by value
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        // an RCCL the process already holds (PyTorch ships its own) is the one to use: two copies in one process corrupt each other
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (r.lib) break;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (r.lib) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+            if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.lib = nullptr;
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+}  // namespace
+
+int swp_rccl_finalize(swp_engine* e) {
+    if (!e) return SWP_EINVAL;
+    Rccl* r = rccl();
+    if (r && e->rccl_comm) {
+        (void)hipSetDevice(e->device);
+        (void)hipStreamSynchronize(e->stream);
+        (void)r->CommDestroy(e->rccl_comm);
+    }
+    e->rccl_comm = nullptr;
+    e->rccl_ranks = 0;
+    return SWP_OK;
+}
+
+int swp_rccl_unique_id(swp_engine* e, uint8_t* id_out) {
+    if (!e || !id_out) return SWP_EINVAL;
+    Rccl* r = rccl();
+    if (!r) return e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded: %s", dlerror());
+    (void)hipSetDevice(e->device);
+    const int rc = r->GetUniqueId(id_out);
+    return rc == 0 ? SWP_OK : e->fail(SWP_EHIP, "ncclGetUniqueId: %s", r->GetErrorString ? r->GetErrorString(rc) : "error");
+}
+
+int swp_rccl_init(swp_engine* e, const uint8_t* id, uint32_t rank, uint32_t n_ranks) {
+    if (!e || !id || n_ranks == 0 || rank >= n_ranks) return SWP_EINVAL;
+    if (n_ranks > R7_MAXS) return e->fail(SWP_ERANGE, "%u ranks: the device-side rounds take at most %d", n_ranks, R7_MAXS);
+    Rccl* r = rccl();
+    if (!r) return e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded: %s", dlerror());
+    (void)hipSetDevice(e->device);
+    if (e->rccl_comm) (void)swp_rccl_finalize(e);
+    RcclId uid;
+    std::memcpy(uid.internal, id, SWP_RCCL_ID_BYTES);
+    const int rc = r->CommInitRank(&e->rccl_comm, (int)n_ranks, uid, (int)rank);
+    if (rc != 0) return e->fail(SWP_EHIP, "ncclCommInitRank: %s", r->GetErrorString ? r->GetErrorString(rc) : "error");
+    e->rccl_rank = rank;
+    e->rccl_ranks = n_ranks;
+    return SWP_OK;
+}
+
+int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes, uint32_t flags, int32_t* out_node_local, uint32_t* out_fail_hist) {
+    if (!e || !b || !shard_nodes || (!out_node_local && b->T)) return SWP_EINVAL;
+    if (!e->rccl_comm) return e->fail(SWP_EINVAL, "swp_shard_run_rank before swp_rccl_init");
+    Rccl* r = rccl();
+    const uint32_t G = e->rccl_ranks, me = e->rccl_rank, T = b->T;
+    if (e->n_nodes != b->n_nodes_prepared) return e->fail(SWP_EINVAL, "the nodeSet grew since swp_batch_prepare");
+    if (shard_nodes[me] != e->n_nodes) return e->fail(SWP_EINVAL, "rank %u holds %u node slots, shard_nodes says %u", me, e->n_nodes, shard_nodes[me]);
+    if (b->has_generic) return e->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the node-range shard protocol yet");
+    if (e->n_nodes == 0) return e->fail(SWP_EINVAL, "rank %u owns no node", me);
+    if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
+    for (uint32_t i = 0; i < T; ++i) out_node_local[i] = -1;
+    if (T == 0) return SWP_OK;
+    (void)hipSetDevice(e->device);
+    hipStream_t st = e->stream;
+    const char* env_dbg = getenv("SWP_DBG");
+    const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
+    const char* env_blk = getenv("SWP_R6_BLOCK");
+    const uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    const size_t lds_budget = 160 * 1024 - 512;
+    // every rank must choose the same row mode: task rows whenever any rank might (the choice only depends on the task list, which is shared)
+    const char* env_tr = getenv("SWP_R6_TASKROWS");
+    const bool task_rows = env_tr ? atoi(env_tr) != 0 : (!b->classes_ok || b->n_dc + b->n_dm > 128);
+    const uint32_t Wn = n_words_of(e->n_nodes);
+    if (r6_propose_lds_size(Wn) > lds_budget || r6_commit_lds_size(Wn, block, task_rows ? 0u : b->n_dc + b->n_dm) > lds_budget)
+        return e->fail(SWP_ERANGE, "%u nodes exceed the block resolver's LDS", e->n_nodes);
+    auto bad = [&](int rc) { e->dev_dynamic_dirty = true; return rc; };
+    int rc = batch_begin(e, b);
+    if (rc) return bad(rc);
+    R6Args ra{};
+    if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra))) return bad(rc);
+    Blk6 hb{};
+    hb.end = T;
+    HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, st));
+    hipError_t x = launch_r6_build(ra, st);
+    if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(x)));
+    DevBuf d_all, d_picks, d_head, d_merged, d_args;
+    HIPCHECK(e, d_all.reserve((size_t)G * block * sizeof(R6Prop)));
+    HIPCHECK(e, d_picks.reserve((size_t)block * sizeof(R7Pick)));
+    HIPCHECK(e, d_head.reserve(sizeof(R7Head)));
+    HIPCHECK(e, d_merged.reserve((size_t)block * sizeof(R6Prop)));
+    HIPCHECK(e, d_args.reserve(sizeof(R6Args)));
+    HIPCHECK(e, hipMemsetAsync(d_head.p, 0, sizeof(R7Head), st));
+    HIPCHECK(e, hipMemcpyAsync(d_args.p, &ra, sizeof ra, hipMemcpyHostToDevice, st));
+    R7Args ma{};
+    ma.n_shards = G;
+    ma.block = block;
+    ma.dbg = dbg_bits;
+    uint32_t first = 0, hw = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        ma.hw_base[g] = hw;
+        ma.first_node[g] = first;
+        first += shard_nodes[g];
+        hw += (shard_nodes[g] + 31) / 32;
+        ma.prop[g] = d_all.as<R6Prop>() + (size_t)g * block;
+    }
+    ma.hw_base[G] = ma.hw_total = hw;
+    if (r7_match_lds_size(hw) > lds_budget) return bad(e->fail(SWP_ERANGE, "%u nodes over all ranks exceed the matching wave's LDS", first));
+    ma.blk = ra.blk;
+    ma.ctl = ra.ctl;
+    ma.picks = d_picks.as<R7Pick>();
+    ma.head = d_head.as<R7Head>();
+    ma.merged = d_merged.as<R6Prop>();
+    uint32_t pos = 0, chunk = std::min<uint32_t>(16u, (T + 255u) / 256u + 1u);
+    uint64_t rounds = 0;
+    while (pos < T) {   // (every rank computes the same positions, hence the same chunks: the collectives line up)
+        for (uint32_t q = 0; q < chunk; ++q) {
+            x = launch_r7_propose(d_args.as<R6Args>(), 1, block, Wn, task_rows, st, e->device);
+            if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "propose: %s", hipGetErrorString(x)));
+            const int nr = r->AllGather(ra.prop, d_all.p, (size_t)block * sizeof(R6Prop), /* ncclInt8 */ 0, e->rccl_comm, st);
+            if (nr != 0) return bad(e->fail(SWP_EHIP, "ncclAllGather: %s", r->GetErrorString ? r->GetErrorString(nr) : "error"));
+            x = launch_r7_match(ma, st, e->device);
+            if (x == hipSuccess) x = launch_r7_apply(d_args.as<R6Args>(), 1, ma.picks, ma.head, me, st);
+            if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "match / apply: %s", hipGetErrorString(x)));
+        }
+        rounds += chunk;
+        HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
+        HIPCHECK(e, hipStreamSynchronize(st));
+        if (hb.error != ERR_NONE) return bad(e->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP));
+        if (hb.pos <= pos) return bad(e->fail(SWP_EHIP, "sharded rounds made no progress at task %u", pos));
+        const double pace = std::max(1.0, (double)hb.pos / (double)std::max<uint32_t>(hb.rounds, 1));
+        pos = hb.pos;
+        chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / pace * 1.05 + 4.0);
+    }
+    Ctl ctl{};
+    HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));
+    HIPCHECK(e, hipStreamSynchronize(st));
+    if (ctl.ninf && (rc = run_explain(e, b, ctl.ninf))) return bad(rc);
+    HIPCHECK(e, hipMemcpyAsync(out_node_local, b->d_out.p, (size_t)T * 4, hipMemcpyDeviceToHost, st));
+    if (out_fail_hist && ctl.ninf) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, b->d_hist.p, (size_t)T * 8 * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(e, hipStreamSynchronize(st));
+    uint64_t placed = 0;
+    for (uint32_t i = 0; i < T; ++i) {
+        const int32_t n = out_node_local[i];
+        if (n < 0) continue;
+        if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return bad(e->fail(SWP_EHIP, "device returned an invalid node index %d for task %u", n, i));
+        const swp_task_desc& d = b->tasks[i];
+        if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+        ++placed;
+    }
+    e->stats.batches++;
+    e->stats.tasks += T;
+    e->stats.placed += placed;
+    e->stats.pair_evals += (uint64_t)T * e->n_present;
+    e->stats.last_resolver = 7;
+    e->stats.resolve_launches += (uint32_t)rounds;
     return SWP_OK;
 }
 

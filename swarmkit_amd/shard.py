@@ -1,12 +1,14 @@
 """Node-range shards of the nodeSet (include/swp.h "node-range shards"): the driver of the
 propose / exchange / merge / commit rounds.
 
-Three drivers:
+Drivers:
 
   DeviceShardGroup  G engines in ONE process — the deployment a Go manager is: one engine per GPU of the box (peer access over
                   xGMI), or several on one GPU — with the ROUNDS ON THE DEVICE (swp_shard_run in libswp.so, csrc/swp_resolve7.hpp):
                   every shard proposes with the block resolver's kernel, the leader's matching wave folds the shards' records per
                   task and walks the block, every shard applies its picks; the host only enqueues and reads a counter now and then.
+  DeviceRankShard one engine per process / GPU, the same device-side rounds with an ncclAllGather of the block's proposals on the
+                  engine's stream (swp_shard_run_rank; RCCL loaded by libswp.so itself) — every rank folds and matches, applies its own.
   ShardGroup      G engines in ONE process, the round-2 protocol: proposals back to the host, merged there (swp_shard_merge), picks
                   sent down: the exchange is a list of host arrays.
   RankShard       one engine per process / GPU (torch.distributed, backend nccl == RCCL on ROCm, gloo on CPU test doubles): the
@@ -94,6 +96,41 @@ class ShardGroup:
             assert np.array_equal(local[mine], node[mine]) and (np.delete(local, mine) == -1).all()
             hists.append(h)
         return _finish(shard, node, self.firsts, hists)
+
+
+class DeviceRankShard:
+    """This process' shard of a job of `world` ranks with the rounds on the device and RCCL between the ranks
+    (swp_shard_run_rank). `dist` (torch.distributed) only carries the RCCL bootstrap id and, at the end, the sum of the Explain
+    histograms and the union of the placements."""
+
+    def __init__(self, batch, rank, world, ranges, dist, device, fold=True):
+        self.b, self.rank, self.world, self.dist, self.device, self.fold = batch, rank, world, dist, device, fold
+        self.firsts, self.counts = [int(r[0]) for r in ranges], [int(r[1]) for r in ranges]
+        self.T = batch.n
+        self.rounds = 0
+        eng = batch.eng
+        if not getattr(eng, "_rccl_ready", False):
+            box = [eng.rccl_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            eng.rccl_init(box[0], rank, world)
+            eng._rccl_ready = True
+
+    def run(self, want_hist=True):
+        before = self.b.eng.stats()["resolve_launches"]
+        local, h = self.b.eng.shard_run_rank(self.b, self.counts, want_hist, self.fold)
+        self.rounds = self.b.eng.stats()["resolve_launches"] - before
+        glob = np.where(local >= 0, local.astype(np.int64) + self.firsts[self.rank], -1)
+        if self.world > 1:   # a task is placed on exactly one rank: the maximum over the ranks is its node (or -1)
+            import torch
+            t = torch.from_numpy(glob).to(self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            glob = t.cpu().numpy()
+            if want_hist:
+                th = torch.from_numpy(h.astype(np.int64)).to(self.device)
+                self.dist.all_reduce(th)
+                h = th.cpu().numpy().astype(np.uint32)
+        return glob, h
 
 
 class RankShard:

@@ -86,3 +86,32 @@ def test_sharded_cfg4_200k_x_40k_equals_single_engine(mode):
     ep, ee, *_ = pu.engine_run(wl)
     sp, se, rounds = pu.sharded_run(wl, 4, mode=mode)
     pu.assert_same(ep, ee, sp, se)
+
+
+@pytest.mark.parametrize("name,T,N", [("cfg3", 2500, 300), ("cfg4", 3000, 700), ("cfg3m", 3000, 500)])
+def test_rank_variant_over_rccl_with_one_rank(name, T, N):
+    """swp_shard_run_rank on a job of ONE rank: librccl.so loaded by libswp.so, communicator from a unique id, an ncclAllGather per
+    round on the engine's stream (here: a copy), fold + match + apply — the path every rank of an 8-GPU job runs — against the oracle.
+    (Two ranks cannot share the one GPU of the test box; the folding of several shards' records is covered by the one-process driver
+    above, which runs the same kernels.)"""
+    from swarmkit_amd import host as swhost
+    from swarmkit_amd import shard as swshard
+    wl = synth.Workload(name, T=T, N=N)
+    op, oe, _ = pu.oracle_run(wl)
+    s = swhost.HostScheduler()
+    descs = swhost.load_workload(s, wl)
+    b = s.e.batch_prepare(descs)
+    drv = swshard.DeviceRankShard(b, 0, 1, [(0, wl.N)], None, None)
+    out, hist = drv.run()
+    placed, errs = {}, {}
+    for j in range(wl.T):
+        tid = wl.task_id(j)
+        if out[j] >= 0:
+            placed[tid] = wl.node_id(int(out[j]))
+        else:
+            placed[tid] = None
+            ex = s.explain(hist[j])
+            errs[tid] = "no suitable node (" + ex + ")" if ex else "no suitable node"
+    b.free()
+    s.e.rccl_finalize()
+    pu.assert_same(op, oe, placed, errs)
