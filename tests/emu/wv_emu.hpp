@@ -89,6 +89,7 @@ struct Block {
     std::vector<WaveSync> waves;
     int bar_arrived = 0;
     std::deque<u32> runq;
+    std::vector<u32> pollers;   // fibers parked in a polling loop (spin_pause) until the next lds_publish32
     std::vector<u64> lds;
     std::function<void()> body;
     Ctx sched;
@@ -106,11 +107,16 @@ inline Block*& B() {
     return b;
 }
 
-inline void yield_ready() {   // a polling loop: let the others run, come back later
+inline void yield_until_publish() {   // a polling loop: parked until some fiber publishes a flag (wake_pollers), then it polls again
     Block* b = B();
     b->switches++;
-    b->runq.push_back(b->cur);
+    b->pollers.push_back(b->cur);
     emu_switch(&b->fib[b->cur].ctx, &b->sched);
+}
+inline void wake_pollers() {
+    Block* b = B();
+    for (u32 t : b->pollers) b->runq.push_back(t);
+    b->pollers.clear();
 }
 inline void yield_blocked() {   // park the current fiber; somebody else re-queues it
     Block* b = B();
@@ -138,8 +144,17 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
     blk.lds.assign((lds_bytes + 7) / 8 + 8, 0xCDCDCDCDCDCDCDCDull);   // LDS is NOT zero-initialised on the device either
     blk.body = body;
     const size_t STK = 256 * 1024;
-    char* stacks = (char*)mmap(nullptr, STK * nthreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (stacks == MAP_FAILED) { perror("mmap"); abort(); }
+    // one stack area for the process, kept between launches: a run makes thousands of launches, and fresh mappings would be
+    // paged in (zeroed) again every time
+    static char* pool = nullptr;
+    static size_t pool_bytes = 0;
+    if (pool_bytes < STK * nthreads) {
+        if (pool) munmap(pool, pool_bytes);
+        pool_bytes = STK * nthreads;
+        pool = (char*)mmap(nullptr, pool_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (pool == MAP_FAILED) { perror("mmap"); abort(); }
+    }
+    char* stacks = pool;
     for (u32 t = 0; t < nthreads; ++t) {
         Fiber& f = blk.fib[t];
         f.stack = stacks + STK * t;
@@ -169,7 +184,6 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
         emu_switch(&blk.sched, &blk.fib[blk.cur].ctx);
         if (blk.fib[blk.cur].done) --alive;
     }
-    munmap(stacks, STK * nthreads);
     B() = nullptr;
 }
 
@@ -267,9 +281,9 @@ inline void wave_sync() { (void)emu::collective(emu::OP_SYNC, 0, 0); }
 inline void lockstep() { (void)emu::collective(emu::OP_SYNC, 1, 1); }
 inline void wait_vm() {}
 
-inline void lds_publish32(u32* p, u32 v) { *reinterpret_cast<volatile u32*>(p) = v; }
+inline void lds_publish32(u32* p, u32 v) { *reinterpret_cast<volatile u32*>(p) = v; emu::wake_pollers(); }
 inline u32 lds_poll32(const u32* p) { return *reinterpret_cast<const volatile u32*>(p); }
-inline void spin_pause() { emu::yield_ready(); }
+inline void spin_pause() { emu::yield_until_publish(); }
 inline void lds_or64(u64* p, u64 v) { *p |= v; }
 inline void lds_xor64(u64* p, u64 v) { *p ^= v; }
 inline void lds_or32(u32* p, u32 v) { *p |= v; }

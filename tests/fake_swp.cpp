@@ -331,6 +331,11 @@ int swp_shard_propose(swp_engine*, swp_batch*, uint32_t, uint32_t, swp_proposal*
 int swp_shard_merge(const swp_proposal* const*, const uint32_t*, uint32_t, uint32_t, swp_shard_pick*, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_shard_commit(swp_engine*, swp_batch*, uint32_t, const swp_shard_pick*, uint32_t) { return SWP_EUNSUPPORTED; }
 int swp_shard_end(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
+int swp_shard_run(swp_engine* const*, swp_batch* const*, uint32_t, uint32_t, int32_t*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
+int swp_rccl_unique_id(swp_engine*, uint8_t*) { return SWP_EUNSUPPORTED; }
+int swp_rccl_init(swp_engine*, const uint8_t*, uint32_t, uint32_t) { return SWP_EUNSUPPORTED; }
+int swp_rccl_finalize(swp_engine*) { return SWP_EUNSUPPORTED; }
+int swp_shard_run_rank(swp_engine*, swp_batch*, const uint32_t*, uint32_t, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_state_save(swp_engine*) { return SWP_EUNSUPPORTED; }
 int swp_state_restore(swp_engine*) { return SWP_EUNSUPPORTED; }
 int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add) {

@@ -25,23 +25,23 @@ def emu_bin():
 # (seed, nodes, tasks, services, block, task order, feature level, extra)
 CASES = [
     (1, 300, 1000, 20, 64, 0, 0, ""),        # few services on few nodes: the exception lists take over, one task per round
-    (2, 700, 3000, 30, 128, 0, 1, ""),       # heavy services, max-replicas, pre-existing exception lists
+    (2, 700, 1500, 30, 64, 0, 1, ""),        # heavy services, max-replicas, pre-existing exception lists
     (3, 1000, 2500, 40, 64, 2, 2, ""),       # host ports, uncounted tasks, random task order
-    (4, 5000, 3000, 300, 256, 0, 2, "s"),    # two node words per lane chunk, two stretches with a rebuild of the bitmaps between
+    (4, 5000, 2000, 300, 256, 0, 2, "s"),    # two node words per lane chunk, two stretches with a rebuild of the bitmaps between
     (12, 5924, 1856, 377, 128, 0, 0, "s"),   # the fast path carries the block: > 100 tasks per round
-    (13, 901, 2469, 8, 256, 1, 1, ""),       # service-major
+    (13, 901, 1200, 8, 64, 1, 1, ""),        # service-major
     (17, 2000, 1500, 100, 1, 2, 2, ""),      # a block of one task
-    (21, 4500, 2000, 200, 1024, 0, 1, ""),   # the largest block
+    (21, 4500, 1500, 200, 1024, 0, 1, ""),   # the largest block
     (40, 3280, 1020, 45, 8, 1, 1, "s"),
     (77, 70000, 300, 30, 64, 0, 1, ""),      # beyond 65 536 nodes: every propose wave loops over more than one group of chunks
     (78, 140000, 400, 50, 128, 2, 2, "s"),
     (79, 66000, 1500, 200, 512, 0, 0, ""),
-    (7, 500, 2000, 40, 256, 0, 3, ""),       # feature level 3: generic reservations (counts per kind as more demand-class rows, Claim in the apply step)
+    (7, 500, 1200, 40, 128, 0, 3, ""),       # feature level 3: generic reservations (counts per kind as more demand-class rows, Claim in the apply step)
     (8, 885, 1500, 125, 64, 2, 3, ""),
-    (9, 300, 1500, 6, 512, 1, 3, ""),        # ... with the exception lists deciding: HasEnough per listed node
-    (10, 3000, 2500, 300, 512, 0, 3, "s"),
-    (2, 700, 3000, 30, 128, 0, 1, "t"),      # task-rows mode: ResourceFilter rows per task of the block, rebuilt every round (k_r6_taskrows)
-    (4, 5000, 3000, 300, 256, 0, 2, "st"),
+    (9, 300, 600, 6, 64, 1, 3, ""),          # ... with the exception lists deciding: HasEnough per listed node
+    (10, 3000, 1500, 300, 256, 0, 3, "s"),
+    (2, 700, 1500, 30, 64, 0, 1, "t"),       # task-rows mode: ResourceFilter rows per task of the block, rebuilt every round (k_r6_taskrows)
+    (4, 5000, 1200, 300, 128, 0, 2, "st"),
     (8, 885, 1500, 125, 64, 2, 3, "t"),
 ]
 
