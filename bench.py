@@ -37,7 +37,7 @@ def profile_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary of this round (profiles/r02_pmc_summary.json,
     produced by tools/profile_round.sh on the GPU box) — a separate rocprofv3 --pmc pass cannot run inside the timed bench.
     Returns (bytes or None, provenance string)."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
         if not os.path.exists(path):
             continue
@@ -302,6 +302,7 @@ def main():
         rng = np.random.default_rng(wl.seed)
         prev = np.zeros(0, dtype=np.int64)
         replaced = 0
+        dev_ms = 0.0
         t_rounds = []
         for rnd in range(args.rounds):
             t0 = time.perf_counter()
@@ -321,15 +322,26 @@ def main():
                 new_out, _h = eng.schedule_batch(descs[gone], want_hist=False)   # as many new tasks of the same services
                 assign[gone] = new_out
                 replaced += len(gone)
+                dev_ms += eng.stats()["ms_total"]
             prev = drained
             t_rounds.append(time.perf_counter() - t0)
         tt = sum(t_rounds)
-        print(json.dumps({"metric": "reschedule churn: placements/sec over rounds of {drain 10 % of the nodes, remove their tasks, re-place} (end to end)",
-                          "value": replaced / tt if tt else 0.0, "unit": "placements/s", "n_gpus": 1, "steps": args.rounds, "warmup": 0,
-                          "ms_per_step": 1e3 * tt / max(args.rounds, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "int64", "data": "synthetic",
-                          "config": dict(wl.describe(), mode="churn", rounds=args.rounds, replaced=int(replaced)),
-                          "still_placed": int((assign >= 0).sum())}))
+        row_b = ROW_B.get(args.workload, 48)
+        alg = (replaced / max(args.rounds, 1)) * wl.N * row_b + (replaced / max(args.rounds, 1)) * TASK_B
+        res = {"metric": "reschedule churn: placements/sec over rounds of {drain 10 % of the nodes, remove their tasks, re-place} (end to end)",
+               "value": replaced / tt if tt else 0.0, "unit": "placements/s", "n_gpus": 1, "steps": args.rounds, "warmup": 0,
+               "ms_per_step": 1e3 * tt / max(args.rounds, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int64", "data": "synthetic",
+               "config": dict(wl.describe(), mode="churn", rounds=args.rounds, replaced=int(replaced)),
+               "still_placed": int((assign >= 0).sum()), "device_ms_per_round": dev_ms / max(args.rounds, 1),
+               "roofline": {"bound": "hbm", "kernel": "the round's swp_schedule_batch (k_resolve5 / k_resolve6 + explain)", "achieved": alg / (dev_ms / max(args.rounds, 1) * 1e-3) / 1e9 if dev_ms else 0.0,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / (dev_ms / max(args.rounds, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms else 0.0,
+                            "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dev_ms / max(args.rounds, 1),
+                            "note": "device time of the re-placement batch of a round (engine events); the round itself is dominated by the host side: two bulk node calls, "
+                                    "swp_commit(remove) and swp_batch_prepare for ~9k descriptors"}}
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl, budget_s=8.0)
+        print(json.dumps(res))
         ranks.close()
         return
     if args.mode == "enforce":
@@ -400,11 +412,41 @@ def main():
         torch.cuda.synchronize(); ranks.barrier()
         t_step = ranks.max_over_ranks(time.perf_counter() - t0) / max(args.steps, 1)
         if rank == 0:
-            print(json.dumps({"metric": "task placements/sec, grouped mode (S groups of T/S tasks, end to end through swp_schedule_groups)",
-                              "value": world * wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
-                              "data": "synthetic", "config": dict(wl.describe(), mode="grouped", groups=int(wl.S)),
-                              "pair_evals_per_s": world * wl.S * wl.N / t_step, "placed": int((out >= 0).sum())}))
+            row_b = ROW_B.get(args.workload, 48)
+            alg = wl.S * wl.N * row_b + wl.T * TASK_B          # pairs = S x N in grouped mode
+            res = {"metric": "task placements/sec, grouped mode (S groups of T/S tasks, end to end through swp_schedule_groups)",
+                   "value": world * wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+                   "data": "synthetic", "config": dict(wl.describe(), mode="grouped", groups=int(wl.S)),
+                   "pair_evals_per_s": world * wl.S * wl.N / t_step, "placed": int((out >= 0).sum()),
+                   "roofline": {"bound": "hbm", "kernel": "k_groups", "achieved": alg / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": alg / t_step / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                "avg_launch_ms": t_step * 1e3,
+                                "note": "one launch = the whole tick (S groups, one workgroup); end-to-end step time (no separate kernel events on this path). The kernel is bound by ONE thread's "
+                                        "replay of container/heap on LDS (the exact order of nodeheap.go), not by bytes: the fraction says how far from a streaming scan that is"}}
+            if world == 1 and not args.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import orc
+                o = orc.Oracle()
+                for i in range(wl.N):
+                    o.create_node(wl.node_doc(i))
+                gsz = max(wl.T // wl.S, 1)
+                n_groups = min(wl.S, max(8, int(10.0 / (2.0e-7 * wl.N + 1.0e-6 * gsz))))   # ~10 s of oracle time at ~0.2 us per (group, node)
+                for k in range(n_groups):
+                    o.set_service(wl.service_id(k))
+                wl_g = synth.Workload(args.workload, T=args.tasks, N=args.nodes, order=args.order, services=args.services, grouped=True)
+                cnt = 0
+                for j in range(wl.T):
+                    if wl.task_service(j) < n_groups:
+                        o.create_task(wl_g.task_doc(j))
+                        cnt += 1
+                t0 = time.perf_counter()
+                o.tick()
+                dt = time.perf_counter() - t0
+                model, nproc = host_cpu()
+                res["cpu_baseline"] = {"value": cnt / dt, "unit": "placements/s", "cores": 1, "kind": "port", "cpu_model": model, "nproc": nproc,
+                                       "sample": f"the first {n_groups} groups of the same workload ({cnt} tasks) against all {wl.N} nodes, oracle tick() {dt:.2f} s"}
+            print(json.dumps(res))
         ranks.close()
         return
     if shard_mode:
@@ -500,7 +542,7 @@ def main():
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_resolve": ms_resolve / K, "k_explain": ms_explain / K, "device_total": ms_dev / K},
         # what really bounds the resolver: the instruction issue of ONE wavefront (the matcher's dependent chain), not bytes
         "resolver": {"kernel": kernel.split(" ")[0], "ms_per_step": ms_resolve / K, "cycles_per_task": ms_resolve / K * 1e-3 * SHADER_GHZ * 1e9 / wl.T,
-                     "clock_GHz": SHADER_GHZ, "measured_HBM_GBs": (traffic * windows / (ms_resolve / K * 1e-3) / 1e9) if traffic else None,
+                     "clock_GHz": SHADER_GHZ, "measured_HBM_GBs": (traffic * windows / (ms_resolve / K * 1e-3) / 1e9) if (traffic and ms_resolve > 0) else None,
                      "note": "cycles of the matching wave's CU per task of the batch, at the peak engine clock; measured_HBM_GBs = PMC bytes per launch (roofline.traffic) / launch time"},
         "whole_job_algorithmic_GBs": alg_bytes_step / t_step / 1e9,
         "end_to_end": {"ms": t_e2e * 1e3, "placements_per_s": wl.T / t_e2e,

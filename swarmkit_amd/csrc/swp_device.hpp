@@ -416,6 +416,273 @@ __global__ __launch_bounds__(256) void k_explain(ExplainArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The explain pass BY GROUP. Inside a batch residuals only shrink, host ports are only taken and a service's count on a node only
+// grows: for every filter whose verdict depends on the task's moment (Resource, HostPort, MaxReplicas) a node has ONE commit from
+// which on it fails a given request, and that commit is one of the node's own. Unplaceable tasks that share their predicate classes,
+// reservations, port set and (with MaxReplicas) service form a group whose entries are sorted by moment; per (group, node) the
+// kernel finds the thresholds in the node's commit segment, bisects them into the group's moments and books +1 / -1 into
+// difference arrays over the entries: first-failing-filter counts for ALL entries of the group at the cost of one node pass per
+// GROUP instead of one per task (cfg4 at 1M x 100k: 104k unplaceable tasks, most of them from services with MaxReplicas).
+//   k_xg_nodes    grid (nodes / 256, groups)           difference arrays for every filter but MaxReplicas
+//   k_xg_maxrep   grid (list chunks, MaxReplicas groups)  the service's own (node, count) list instead of the node set
+//   k_xg_write    one workgroup per group              prefix sums -> hist[task][filter]
+// Tasks with generic reservations keep the per-task pass (k_explain).
+// ---------------------------------------------------------------------------------------------
+#define XG_RES 1u      // ResourceFilter enabled
+#define XG_PORTS 2u    // HostPortFilter enabled (pset)
+#define XG_MAXREP 4u   // MaxReplicasFilter enabled (svc, maxrep)
+struct XGroup {   // 64 B
+    i64 cpu, mem;                      // the group's reservations
+    u32 cls_con, cls_plat, cls_plug;   // its predicate class rows (0 = filter disabled)
+    u32 flags;                         // XG_*
+    u32 off, cnt;                      // its entries in xpos / xtask: [off, off + cnt), moments ascending
+    u32 doff, pset;                    // its cnt + 1 difference slots start here; its host-port set
+    u32 svc, pad;                      // batch-local service (XG_MAXREP)
+    u64 maxrep;
+};
+static_assert(sizeof(XGroup) == 64, "XGroup layout");
+#define XG_PLANES 6
+#define XG_LDS_CNT 1024   // a group of up to this many entries is bisected and booked in LDS
+#define XG_NPT 4          // nodes per thread of k_xg_nodes: one flush of the LDS planes per 1024 nodes
+#define XG_NEVER 0xFFFFFFFFu
+struct XGArgs {
+    u32 n_nodes, n_words, n_groups, dstride;   // dstride: slots per filter plane of the difference arrays
+    const XGroup* g;
+    const u32* gorder;    // the groups ordered by reservation pair
+    const uint2* chunks;  // [grid.y of k_xg_nodes] (first, count) in gorder: groups that share their reservations
+    const u32* xpos;      // [entries] commits before the task (its moment)
+    const u32* xtask;     // [entries] the task
+    const RTask* rt;
+    const u64* valid;
+    const u64* ready;
+    const u64* con;
+    const u64* plat;
+    const u64* plug;
+    const i64* cpu;       // end-of-batch residuals
+    const i64* mem;
+    const u64* portmap;   // end-of-batch host ports
+    const u32* pset_off;
+    const u32* pset_ids;
+    const u32* list_node; // end-of-batch per-service (node, count) lists
+    const u32* list_svc;
+    const u32* list_off;
+    const u32* log_task;
+    const u32* seg_off;
+    const u32* seg_len;
+    const u32* ent_ci;
+    const i64* ent_scpu;
+    const i64* ent_smem;
+    const u32* mr;        // [grid.y of k_xg_maxrep] the groups with XG_MAXREP
+    int32_t* diff;        // [XG_PLANES][dstride]: plane f = hist column 1 + f (Resource, Plugin, Constraint, Platform, HostPort, MaxReplicas)
+    u32* notready;        // one counter: nodes that fail the ReadyFilter (the same for every entry of every group)
+    u32* hist;            // [T][8]
+};
+
+// Thresholds are commits: 0 = "from the start of the batch", XG_NEVER = "not by the end of the batch", else 1 + the index of the
+// commit behind which the node fails. xg_index turns one into the first entry (of moments pos[0..cnt), ascending) that sees the failure.
+template <class P> __device__ __forceinline__ u32 xg_index(P pos, u32 cnt, u32 thr) {
+    if (thr == 0) return 0;
+    if (thr == XG_NEVER) return cnt;
+    const u32 ci = thr - 1u;   // first entry whose moment lies behind commit ci (pos > ci)
+    u32 lo = 0, hi = cnt;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (pos[mid] > ci) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+// ResourceFilter threshold of node n for a reservation pair (resources only shrink: a node that fits at the end fitted all along)
+__device__ __forceinline__ u32 xg_res_thr(const XGArgs& a, i64 cpu, i64 mem, u32 n) {
+    const i64 c_end = a.cpu[n], m_end = a.mem[n];
+    if (cpu <= c_end && mem <= m_end) return XG_NEVER;
+    const u32 so = a.seg_off[n], sl = a.seg_len[n];
+    u32 k = 0;   // commits of this node that must have happened: the smallest k whose residual no longer fits (k == sl does not)
+    for (; k < sl; ++k)
+        if (!(cpu <= c_end + a.ent_scpu[so + k] && mem <= m_end + a.ent_smem[so + k])) break;
+    return k == 0 ? 0u : a.ent_ci[so + k - 1] + 1u;
+}
+
+// HostPortFilter threshold: a port of the set that is taken at the end of the batch was taken by ONE commit of this node (the filter
+// keeps a second one away) or before the batch; the earliest taking decides
+__device__ __forceinline__ u32 xg_port_thr(const XGArgs& a, u32 pset, u32 n) {
+    const u32 w = n >> 6;
+    const u64 bit = 1ull << (n & 63);
+    const u32 so = a.seg_off[n], sl = a.seg_len[n];
+    u32 first = XG_NEVER;
+    for (u32 q = a.pset_off[pset]; q < a.pset_off[pset + 1]; ++q) {
+        const u32 port = a.pset_ids[q];
+        if (!(a.portmap[(size_t)port * a.n_words + w] & bit)) continue;
+        u32 tq = 0;
+        for (u32 k = 0; k < sl && !tq; ++k) {
+            const u32 ci = a.ent_ci[so + k];
+            const RTask* tk = a.rt + a.log_task[ci];
+            if (!(tk->flags & RT_PORTS)) continue;
+            for (u32 z = a.pset_off[tk->pset]; z < a.pset_off[tk->pset + 1]; ++z)
+                if (a.pset_ids[z] == port) tq = ci + 1u;
+        }
+        first = min(first, tq);
+    }
+    return first;
+}
+
+// first failing static filter behind the ResourceFilter, in pipeline order (pipeline.go:9-20): 0 = none, 1 Plugin, 2 Constraint, 3 Platform
+__device__ __forceinline__ u32 xg_static(const XGArgs& a, const XGroup& G, u32 w, u64 bit) {
+    if (G.cls_plug && !(cload(a.plug + (size_t)G.cls_plug * a.n_words + w) & bit)) return 1;
+    if (G.cls_con && !(cload(a.con + (size_t)G.cls_con * a.n_words + w) & bit)) return 2;
+    if (G.cls_plat && !(cload(a.plat + (size_t)G.cls_plat * a.n_words + w) & bit)) return 3;
+    return 0;
+}
+
+// What a READY node shows a group's entries, filter by filter: entries [idx_r, cnt) see it short of resources, the ones before see
+// the static verdict s, and when that passes entries [idx_p, idx_r) see a host port taken.
+__global__ __launch_bounds__(256) void k_xg_nodes(XGArgs a) {
+    __shared__ u32 sh_pos[XG_LDS_CNT];
+    __shared__ int32_t sh_diff[5][XG_LDS_CNT + 1];
+    const uint2 ch = a.chunks[blockIdx.y];
+    const u32 tid = threadIdx.x;
+    const XGroup G0 = a.g[a.gorder[ch.x]];
+    u32 thr_r[XG_NPT];
+    u32 rdy = 0;   // bit j: node j of this thread is ready
+    for (int j = 0; j < XG_NPT; ++j) {
+        const u32 n = (blockIdx.x * XG_NPT + j) * 256 + tid;
+        const u32 w = n >> 6;
+        const u64 bit = 1ull << (n & 63);
+        const bool present = n < a.n_nodes && (cload(a.valid + w) & bit);
+        const bool is_ready = present && (cload(a.ready + w) & bit);
+        if (blockIdx.y == 0) {
+            const u64 nr = ballot64(present && !is_ready);
+            if (nr && (tid & 63) == 0) atomicAdd(a.notready, (u32)__popcll(nr));
+        }
+        thr_r[j] = XG_NEVER;
+        if (is_ready) {
+            rdy |= 1u << j;
+            if (G0.flags & XG_RES) thr_r[j] = xg_res_thr(a, G0.cpu, G0.mem, n);   // the chunk's groups share the pair
+        }
+    }
+    for (u32 i = 0; i < ch.y; ++i) {
+        const XGroup G = a.g[a.gorder[ch.x + i]];
+        const bool in_lds = G.cnt <= XG_LDS_CNT;
+        const u32* gpos = a.xpos + G.off;
+        if (in_lds) {
+            for (u32 q = tid; q < G.cnt; q += 256) sh_pos[q] = gpos[q];
+            for (int f = 0; f < 5; ++f)
+                for (u32 q = tid; q <= G.cnt; q += 256) sh_diff[f][q] = 0;
+            __syncthreads();
+        }
+        auto book = [&](u32 plane, u32 at, int32_t v) {
+            if (in_lds) atomicAdd(&sh_diff[plane][at], v);
+            else atomicAdd(a.diff + (size_t)plane * a.dstride + G.doff + at, v);
+        };
+        for (int j = 0; j < XG_NPT; ++j) {
+            const u32 n = (blockIdx.x * XG_NPT + j) * 256 + tid;
+            const u32 w = n >> 6;
+            const u64 bit = 1ull << (n & 63);
+            const bool is_ready = (rdy >> j) & 1u;
+            u32 s = 0, idx_r = G.cnt, idx_p = G.cnt;
+            if (is_ready) {
+                s = xg_static(a, G, w, bit);
+                idx_r = in_lds ? xg_index(sh_pos, G.cnt, thr_r[j]) : xg_index(gpos, G.cnt, thr_r[j]);
+                if ((G.flags & XG_PORTS) && s == 0 && idx_r > 0) {
+                    const u32 tp = xg_port_thr(a, G.pset, n);
+                    idx_p = in_lds ? xg_index(sh_pos, G.cnt, tp) : xg_index(gpos, G.cnt, tp);
+                }
+            }
+            // the common cases are booked once per wave (by lane 0 whatever its own node is): short from the start; a static
+            // verdict from the start (its end at idx_r is booked by the node itself unless idx_r == cnt, a slot nobody reads)
+            const u64 always = ballot64(is_ready && idx_r == 0);
+            if (always && (tid & 63) == 0) book(0, 0, (int32_t)__popcll(always));
+            for (u32 f = 1; f <= 3; ++f) {
+                const u64 bm = ballot64(is_ready && idx_r > 0 && s == f);
+                if (bm && (tid & 63) == 0) book(f, 0, (int32_t)__popcll(bm));
+            }
+            if (is_ready && idx_r > 0) {
+                if (idx_r != G.cnt) {
+                    book(0, idx_r, 1);
+                    if (s) book(s, idx_r, -1);
+                }
+                if (!s && idx_p < idx_r) {   // entries [idx_p, idx_r) see the port taken
+                    book(4, idx_p, 1);
+                    book(4, idx_r, -1);
+                }
+            }
+        }
+        if (in_lds) {
+            __syncthreads();
+            for (int f = 0; f < 5; ++f)
+                for (u32 q = tid; q <= G.cnt; q += 256) {
+                    const int32_t v = sh_diff[f][q];
+                    if (v) atomicAdd(a.diff + (size_t)f * a.dstride + G.doff + q, v);
+                }
+            __syncthreads();
+        }
+    }
+}
+
+// MaxReplicasFilter (the last of the pipeline): only a node ON the service's list can fail it, so the list is walked instead of the
+// node set. The service's count on a node only grows inside a batch: from the commit that brought it to MaxReplicas on, the entries
+// see this filter — as far as an earlier filter does not claim them (evaluated again for this one node).
+__global__ __launch_bounds__(256) void k_xg_maxrep(XGArgs a) {
+    const XGroup G = a.g[a.mr[blockIdx.y]];
+    const u32* gpos = a.xpos + G.off;
+    const u32 l0 = a.list_off[G.svc], l1 = a.list_off[G.svc + 1];
+    for (u32 z = l0 + blockIdx.x * blockDim.x + threadIdx.x; z < l1; z += gridDim.x * blockDim.x) {
+        const u32 n = a.list_node[z];
+        if (n == LIST_EMPTY || n >= a.n_nodes) continue;
+        const u32 sv = a.list_svc[z];
+        if ((u64)sv < G.maxrep) continue;
+        const u32 w = n >> 6;
+        const u64 bit = 1ull << (n & 63);
+        if (!(a.valid[w] & bit) || !(a.ready[w] & bit)) continue;
+        if (xg_static(a, G, w, bit)) continue;
+        u32 hi = (G.flags & XG_RES) ? xg_index(gpos, G.cnt, xg_res_thr(a, G.cpu, G.mem, n)) : G.cnt;
+        if (hi && (G.flags & XG_PORTS)) hi = min(hi, xg_index(gpos, G.cnt, xg_port_thr(a, G.pset, n)));
+        if (hi == 0) continue;
+        // the service's counted commits on this node, latest first: the count at the end is sv; stepping back over `over` of them
+        // brings it below MaxReplicas
+        const u32 so = a.seg_off[n], sl = a.seg_len[n];
+        const u64 over = (u64)sv - G.maxrep + 1u;   // >= 1
+        u64 seen = 0;
+        u32 thr = 0;                                // reached before the batch
+        for (u32 k = sl; k-- > 0;) {
+            const u32 ci = a.ent_ci[so + k];
+            const RTask* tk = a.rt + a.log_task[ci];
+            if (tk->svc != G.svc || (tk->flags & RT_UNCOUNTED)) continue;
+            if (++seen == over) { thr = ci + 1u; break; }
+        }
+        const u32 idx_m = xg_index(gpos, G.cnt, thr);
+        if (idx_m < hi) {
+            atomicAdd(a.diff + (size_t)5 * a.dstride + G.doff + idx_m, 1);
+            atomicAdd(a.diff + (size_t)5 * a.dstride + G.doff + hi, -1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xg_write(XGArgs a) {
+    const XGroup G = a.g[blockIdx.x];
+    __shared__ int32_t part[XG_PLANES][256];
+    const u32 tid = threadIdx.x, per = (G.cnt + 255) / 256, e0 = min(tid * per, G.cnt), e1 = min(e0 + per, G.cnt);
+    int32_t sum[XG_PLANES] = {};
+    for (u32 e = e0; e < e1; ++e)
+        for (int f = 0; f < XG_PLANES; ++f) sum[f] += a.diff[(size_t)f * a.dstride + G.doff + e];
+    for (int f = 0; f < XG_PLANES; ++f) part[f][tid] = sum[f];
+    __syncthreads();
+    int32_t run[XG_PLANES] = {};
+    for (u32 t = 0; t < tid; ++t)
+        for (int f = 0; f < XG_PLANES; ++f) run[f] += part[f][t];
+    const u32 nr = a.notready[0];
+    for (u32 e = e0; e < e1; ++e) {
+        u32* h = a.hist + (size_t)a.xtask[G.off + e] * 8;
+        for (int f = 0; f < XG_PLANES; ++f) {
+            run[f] += a.diff[(size_t)f * a.dstride + G.doff + e];
+            h[1 + f] = (u32)run[f];
+        }
+        h[0] = nr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_groups — grouped tasks (SpecVersion != nil): scheduleTaskGroup with k = len(group)
 // (scheduler.go:694-748), nodeSet.tree with a bounded max-heap per leaf (nodeset.go:50-124,
 // container/heap mechanics reproduced step for step: nodeheap.go, decision_tree.go:24-52),

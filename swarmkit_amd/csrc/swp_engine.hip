@@ -72,6 +72,26 @@ struct DevBuf {   // owns one device allocation: movable, not copyable
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+struct PinBuf {   // owns one pinned host allocation (async copies in both directions without a staging pass)
+    void* p = nullptr;
+    size_t cap = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    PinBuf(PinBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+};
+
 struct Interner {
     std::unordered_map<std::string, uint32_t> map;
     std::vector<std::string> strs;
@@ -180,6 +200,12 @@ struct swp_batch {
     DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
     DevBuf d_con, d_plat, d_plug, d_sc, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
+    DevBuf d_xpack, d_xdiff, d_xnr;  // explain pass by group: one packed upload (groups, entries, orders) + the difference planes
+    PinBuf hx_in, hx_pack;           // its host staging: the unplaceable list as it comes back; the packed upload
+    std::vector<uint32_t> xg_of;     // [T] explain group of the task (0xFFFFFFFF: per-task pass), fixed when the batch is built
+    std::vector<XGroup> xg_proto;    // the groups (off / cnt / doff filled per run; pad = reservation pair)
+    uint32_t xg_pairs = 0;
+    std::vector<uint32_t> hx_fill, hx_pair_cnt, hx_compact;
     DevBuf d_qres;                         // k_resolve5: [n_nodes][2] residuals in resource units
     DevBuf d_thr;                          // k_resolve5 exact mode: thresholds of the demand-class rows
     DevBuf d_trows;                        // k_resolve6, task-rows mode: [block][n_words]
@@ -414,9 +440,40 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     std::vector<uint32_t> svc_ntasks;
     std::vector<uint32_t> task_rank(T);
     std::unordered_map<uint64_t, uint32_t> port_local;
+    // Tasks of one service carry the same descriptor: everything below that depends on the descriptor alone is done once per DISTINCT
+    // descriptor (tmpl_of[i] = the first task with task i's descriptor) and copied to the others.
+    struct DescKey {
+        uint64_t w[8];
+        bool operator==(const DescKey& o) const { return std::memcmp(w, o.w, sizeof w) == 0; }
+    };
+    struct DescHash {
+        size_t operator()(const DescKey& k) const {
+            uint64_t h = 0x9E3779B97F4A7C15ull;
+            for (uint64_t x : k.w) h = (h ^ x) * 0xFF51AFD7ED558CCDull + (h >> 29);
+            return (size_t)h;
+        }
+    };
+    static_assert(sizeof(swp_task_desc) == sizeof(DescKey), "descriptor key");
+    std::unordered_map<DescKey, uint32_t, DescHash> tmpl_index;
+    std::vector<uint32_t> tmpl_of(T), firsts;
 
     for (uint32_t i = 0; i < T; ++i) {
         const swp_task_desc& d = tasks[i];
+        {
+            DescKey key;
+            std::memcpy(key.w, &d, sizeof key);
+            auto hit = tmpl_index.find(key);
+            if (hit != tmpl_index.end()) {
+                tmpl_of[i] = hit->second;
+                const uint32_t sv = b->rt[hit->second].svc;
+                task_rank[i] = svc_ntasks[sv];
+                svc_ntasks[sv] += weights ? weights[i] : 1u;
+                continue;
+            }
+            tmpl_index.emplace(key, i);
+            tmpl_of[i] = i;
+            firsts.push_back(i);
+        }
         if (d.constraint_set >= e->con_sets.size() || d.platform_set >= e->plat_sets.size() || d.plugin_set >= e->plug_sets.size() ||
             d.port_set >= e->port_sets.size())
             return e->fail(SWP_EINVAL, "task %u references an unknown predicate set", i);
@@ -483,14 +540,14 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     // multiple of the unit, so the kernel can keep exact residuals as 32-bit counts in LDS
     {
         int64_t gc = 0, gm = 0;
-        for (uint32_t i = 0; i < T; ++i) {
+        for (uint32_t i : firsts) {
             gc = std::gcd(gc, b->rt[i].cpu);
             gm = std::gcd(gm, b->rt[i].mem);
         }
         b->unit_cpu = gc ? gc : 1;
         b->unit_mem = gm ? gm : 1;
         b->units_ok = true;
-        for (uint32_t i = 0; i < T; ++i) {
+        for (uint32_t i : firsts) {
             const int64_t kc = b->rt[i].cpu / b->unit_cpu, km = b->rt[i].mem / b->unit_mem;
             if (kc >= R5_QLIM_HOST || km >= R5_QLIM_HOST) { b->units_ok = false; break; }
             b->rt[i].kc = (uint32_t)kc;
@@ -505,7 +562,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         b->n_dc = b->n_dm = 0;
         {
             std::set<int64_t> sc_, sm_;
-            for (uint32_t i = 0; i < T; ++i)
+            for (uint32_t i : firsts)
                 if (b->rt[i].flags & RT_RES) {
                     sc_.insert(b->rt[i].cpu);
                     sm_.insert(b->rt[i].mem);
@@ -516,7 +573,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
                 b->n_dc = (uint32_t)sc_.size();
                 for (int64_t v : sm_) { im[v] = (uint32_t)b->thr64.size() - b->n_dc; b->thr64.push_back(v); }
                 b->n_dm = (uint32_t)sm_.size();
-                for (uint32_t i = 0; i < T; ++i)
+                for (uint32_t i : firsts)
                     if (b->rt[i].flags & RT_RES) b->rt[i].flags |= (ic[b->rt[i].cpu] << RT_DC_SHIFT) | (im[b->rt[i].mem] << RT_DM_SHIFT);
                 b->classes_ok = true;
                 if (b->units_ok && b->n_dc + b->n_dm <= r5_max_rows()) {   // the same order in resource units (division by the gcd is monotone)
@@ -527,6 +584,8 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             }
         }
     }
+    for (uint32_t i = 0; i < T; ++i)   // every other task of a descriptor gets the record of the first one (its list slot follows below)
+        if (tmpl_of[i] != i) b->rt[i] = b->rt[tmpl_of[i]];
     // generic reservations: the distinct (kind, value) pairs become rows sorted by (kind, value); a task's set names its rows
     b->has_generic = false;
     b->tg.clear();
@@ -573,6 +632,39 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             }
         }
     }
+    // explain groups (k_xg_nodes): tasks that share predicate classes, reservations, port set and — with MaxReplicas — service
+    b->xg_of.assign(T, 0xFFFFFFFFu);
+    b->xg_proto.clear();
+    {
+        typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, int64_t, int64_t, uint32_t, uint32_t, uint64_t> GKey;
+        std::map<GKey, uint32_t> gid;
+        std::map<std::tuple<uint32_t, int64_t, int64_t>, uint32_t> pair_id;
+        for (uint32_t i : firsts) {
+            const RTask& r = b->rt[i];
+            if (b->has_generic && b->tg[i]) continue;   // generic reservations: the per-task pass
+            XGroup g{};
+            g.flags = ((r.flags & RT_RES) ? XG_RES : 0u) | ((r.flags & RT_PORTS) ? XG_PORTS : 0u) | ((r.flags & RT_MAXREP) ? XG_MAXREP : 0u);
+            g.cpu = (g.flags & XG_RES) ? r.cpu : 0;
+            g.mem = (g.flags & XG_RES) ? r.mem : 0;
+            g.cls_con = r.cls_con;
+            g.cls_plat = r.cls_plat;
+            g.cls_plug = r.cls_plug;
+            g.pset = (g.flags & XG_PORTS) ? r.pset : 0u;
+            g.svc = (g.flags & XG_MAXREP) ? r.svc : 0u;
+            g.maxrep = (g.flags & XG_MAXREP) ? r.maxrep : 0u;
+            const GKey k{g.cls_con, g.cls_plat, g.cls_plug, g.flags, g.cpu, g.mem, g.pset, g.svc, g.maxrep};
+            auto it = gid.find(k);
+            if (it == gid.end()) {
+                it = gid.emplace(k, (uint32_t)b->xg_proto.size()).first;
+                g.pad = pair_id.emplace(std::make_tuple(g.flags & XG_RES, g.cpu, g.mem), (uint32_t)pair_id.size()).first->second;
+                b->xg_proto.push_back(g);
+            }
+            b->xg_of[i] = it->second;
+        }
+        for (uint32_t i = 0; i < T; ++i)
+            if (tmpl_of[i] != i) b->xg_of[i] = b->xg_of[tmpl_of[i]];
+        b->xg_pairs = (uint32_t)pair_id.size();
+    }
     // runs of identical one-off tasks (same service, filters, reservations; only their list slot differs) are placed by
     // water-filling instead of task by task (csrc/swp_waterfill.hpp). A run must be long enough to pay for its launch, and
     // splitting the batch must not shred the round resolver's work into many launches: runs are used when they make up most
@@ -582,11 +674,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         const char* env_wf = getenv("SWP_WATERFILL");
         const int mode = env_wf ? atoi(env_wf) : -1;
         const uint32_t run_min = mode == 1 ? 2u : 64u;
-        auto same = [&](uint32_t i, uint32_t k) {
-            RTask x = b->rt[i], y = b->rt[k];
-            x.slot = y.slot = 0;
-            return std::memcmp(&x, &y, sizeof x) == 0;
-        };
+        auto same = [&](uint32_t i, uint32_t k) { return tmpl_of[i] == tmpl_of[k]; };   // identical descriptors
         std::vector<swp_batch::Seg> segs;
         uint64_t in_runs = 0;
         uint32_t longest = 0, i = 0;
@@ -855,15 +943,176 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
         xa.ent_ci = sg.ent_ci;
         xa.ent_scpu = sg.ent_scpu;
         xa.ent_smem = sg.ent_smem;
-        uint32_t done = 0;
-        while (done < n_inf) {   // grid.y ≤ 65535 blocks of EX_TCH tasks
-            uint32_t chunk = std::min<uint32_t>(n_inf - done, 32768u * EX_TCH);
-            ExplainArgs xc = xa;
-            xc.inf_task += done;
-            xc.inf_pos += done;
-            xc.n_inf = chunk;
-            hipLaunchKernelGGL(k_explain, dim3((N + 255) / 256, (chunk + EX_TCH - 1) / EX_TCH), dim3(256), 0, st, xc);
-            done += chunk;
+        // Which unplaceable tasks are explained BY GROUP (k_xg_nodes / k_xg_maxrep / k_xg_write) and which need the per-task pass was
+        // fixed when the batch was built (xg_of). The list of unplaceable tasks comes back once (4 + 4 bytes each), is dealt into the
+        // groups by a counting sort that keeps the list's order (moments ascend), and goes up again as ONE packed buffer together
+        // with the groups, their order by reservation pair and the chunks of that order (pinned staging both ways).
+        HIPCHECK(e, b->hx_in.reserve((size_t)n_inf * 8));
+        uint32_t* h_task = static_cast<uint32_t*>(b->hx_in.p);
+        uint32_t* h_pos = h_task + n_inf;
+        HIPCHECK(e, hipMemcpyAsync(h_task, b->d_inf_task.p, (size_t)n_inf * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(e, hipMemcpyAsync(h_pos, b->d_inf_pos.p, (size_t)n_inf * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(e, hipStreamSynchronize(st));
+        const char* env_xg = getenv("SWP_EXPLAIN_GROUPS");
+        const bool use_groups = !(env_xg && atoi(env_xg) == 0);
+        const uint32_t NG = (uint32_t)b->xg_proto.size(), NONE = 0xFFFFFFFFu;
+        std::vector<uint32_t>&fill = b->hx_fill, &pair_cnt = b->hx_pair_cnt, &compact = b->hx_compact;
+        fill.assign(NG + 1, 0);   // group -> its entries, then -> the next free one
+        uint32_t n_fast = 0, n_slow = 0;
+        for (uint32_t q = 0; q < n_inf; ++q) {
+            const uint32_t g = use_groups ? b->xg_of[h_task[q]] : NONE;
+            if (g == NONE) ++n_slow;
+            else {
+                ++fill[g];
+                ++n_fast;
+            }
+        }
+        if (getenv("SWP_DEBUG_EXPLAIN")) fprintf(stderr, "explain: %u unplaceable, %u by group (%u groups known), %u per task\n", n_inf, n_fast, NG, n_slow);
+        uint32_t ng = 0, nm = 0;
+        pair_cnt.assign(b->xg_pairs + 1, 0);
+        for (uint32_t g = 0; g < NG; ++g)
+            if (fill[g]) {
+                ++ng;
+                nm += (b->xg_proto[g].flags & XG_MAXREP) ? 1u : 0u;
+                ++pair_cnt[b->xg_proto[g].pad];
+            }
+        // chunks: groups of one pair, few enough per chunk that the launch still fills the device
+        const uint32_t bx = (N + 256 * XG_NPT - 1) / (256 * XG_NPT);
+        const uint32_t csize = std::max<uint32_t>(1, std::min<uint32_t>(32, (uint32_t)(((uint64_t)ng * bx) / 2048)));
+        uint32_t nc = 0;
+        for (uint32_t p = 0; p < b->xg_pairs; ++p) nc += (pair_cnt[p] + csize - 1) / csize;
+        auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        const size_t o_g = 0, o_pos = al(o_g + (size_t)ng * sizeof(XGroup)), o_task = al(o_pos + (size_t)n_fast * 4), o_mr = al(o_task + (size_t)n_fast * 4),
+                     o_ord = al(o_mr + (size_t)nm * 4), o_ch = al(o_ord + (size_t)ng * 4), o_st = al(o_ch + (size_t)nc * 8), o_sp = al(o_st + (size_t)n_slow * 4),
+                     total = al(o_sp + (size_t)n_slow * 4);
+        HIPCHECK(e, b->hx_pack.reserve(total));
+        HIPCHECK(e, b->d_xpack.reserve(total));
+        char* hp = static_cast<char*>(b->hx_pack.p);
+        char* dp = static_cast<char*>(b->d_xpack.p);
+        XGroup* groups = reinterpret_cast<XGroup*>(hp + o_g);
+        uint32_t *xpos = reinterpret_cast<uint32_t*>(hp + o_pos), *xtask = reinterpret_cast<uint32_t*>(hp + o_task), *mr = reinterpret_cast<uint32_t*>(hp + o_mr),
+                 *gorder = reinterpret_cast<uint32_t*>(hp + o_ord), *slow_task = reinterpret_cast<uint32_t*>(hp + o_st), *slow_pos = reinterpret_cast<uint32_t*>(hp + o_sp);
+        uint2* chunks = reinterpret_cast<uint2*>(hp + o_ch);
+        if (n_fast) {
+            compact.assign(NG, NONE);
+            uint32_t off = 0, gi = 0, mi = 0;
+            for (uint32_t g = 0; g < NG; ++g) {
+                const uint32_t cnt = fill[g];
+                if (!cnt) continue;
+                XGroup x = b->xg_proto[g];
+                x.off = off;
+                x.cnt = cnt;
+                x.doff = off + gi;   // cnt + 1 difference slots per group
+                if (x.flags & XG_MAXREP) mr[mi++] = gi;
+                groups[gi] = x;
+                compact[g] = gi++;
+                fill[g] = off;
+                off += cnt;
+            }
+            // the groups by pair (counting sort), then the chunks of that order
+            uint32_t run = 0;
+            for (uint32_t p = 0; p <= b->xg_pairs; ++p) {
+                const uint32_t c = pair_cnt[p];
+                pair_cnt[p] = run;
+                run += c;
+            }
+            for (uint32_t g = 0; g < NG; ++g)
+                if (compact[g] != NONE) gorder[pair_cnt[b->xg_proto[g].pad]++] = compact[g];
+            uint32_t ci = 0;
+            for (uint32_t q = 0; q < ng;) {
+                uint32_t r = q + 1;
+                const uint32_t pr = groups[gorder[q]].pad;
+                while (r < ng && r - q < csize && groups[gorder[r]].pad == pr) ++r;
+                chunks[ci++] = make_uint2(q, r - q);
+                q = r;
+            }
+            nc = ci;
+        }
+        uint32_t si = 0;
+        for (uint32_t q = 0; q < n_inf; ++q) {
+            const uint32_t g = use_groups ? b->xg_of[h_task[q]] : NONE;
+            if (g == NONE) {
+                slow_task[si] = h_task[q];
+                slow_pos[si++] = h_pos[q];
+            } else {
+                const uint32_t at = fill[g]++;
+                xtask[at] = h_task[q];
+                xpos[at] = h_pos[q];
+            }
+        }
+        HIPCHECK(e, hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, st));
+        if (n_fast) {
+            const uint32_t dstride = n_fast + ng;
+            HIPCHECK(e, b->d_xdiff.reserve((size_t)XG_PLANES * dstride * 4));
+            HIPCHECK(e, b->d_xnr.reserve(256));
+            HIPCHECK(e, hipMemsetAsync(b->d_xdiff.p, 0, (size_t)XG_PLANES * dstride * 4, st));
+            HIPCHECK(e, hipMemsetAsync(b->d_xnr.p, 0, 4, st));
+            XGArgs ga{};
+            ga.n_nodes = N;
+            ga.n_words = Wn;
+            ga.n_groups = ng;
+            ga.dstride = dstride;
+            ga.g = reinterpret_cast<const XGroup*>(dp + o_g);
+            ga.gorder = reinterpret_cast<const uint32_t*>(dp + o_ord);
+            ga.chunks = reinterpret_cast<const uint2*>(dp + o_ch);
+            ga.xpos = reinterpret_cast<const uint32_t*>(dp + o_pos);
+            ga.xtask = reinterpret_cast<const uint32_t*>(dp + o_task);
+            ga.rt = xa.rt;
+            ga.valid = xa.valid;
+            ga.ready = xa.ready;
+            ga.con = xa.con;
+            ga.plat = xa.plat;
+            ga.plug = xa.plug;
+            ga.cpu = xa.cpu;
+            ga.mem = xa.mem;
+            ga.portmap = xa.portmap;
+            ga.pset_off = xa.pset_off;
+            ga.pset_ids = xa.pset_ids;
+            ga.list_node = xa.list_node;
+            ga.list_svc = xa.list_svc;
+            ga.list_off = xa.list_off;
+            ga.log_task = xa.log_task;
+            ga.seg_off = xa.seg_off;
+            ga.seg_len = xa.seg_len;
+            ga.ent_ci = xa.ent_ci;
+            ga.ent_scpu = xa.ent_scpu;
+            ga.ent_smem = xa.ent_smem;
+            ga.mr = reinterpret_cast<const uint32_t*>(dp + o_mr);
+            ga.diff = b->d_xdiff.as<int32_t>();
+            ga.notready = b->d_xnr.as<uint32_t>();
+            ga.hist = xa.hist;
+            const uint32_t GY = 32768u;   // grid.y <= 65535
+            for (uint32_t c0 = 0; c0 < nc; c0 += GY) {
+                XGArgs gc = ga;
+                gc.chunks += c0;
+                // (the ReadyFilter counter is taken by the blocks of chunk 0 of the FIRST launch only)
+                if (c0) gc.notready = b->d_xnr.as<uint32_t>() + 1;
+                hipLaunchKernelGGL(k_xg_nodes, dim3(bx, std::min<uint32_t>(GY, nc - c0)), dim3(256), 0, st, gc);
+            }
+            for (uint32_t m0 = 0; m0 < nm; m0 += GY) {
+                XGArgs gc = ga;
+                gc.mr += m0;
+                hipLaunchKernelGGL(k_xg_maxrep, dim3(8, std::min<uint32_t>(GY, nm - m0)), dim3(256), 0, st, gc);
+            }
+            for (uint32_t g0 = 0; g0 < ng; g0 += GY) {
+                XGArgs gc = ga;
+                gc.g += g0;
+                hipLaunchKernelGGL(k_xg_write, dim3(std::min<uint32_t>(GY, ng - g0)), dim3(256), 0, st, gc);
+            }
+        }
+        if (n_slow) {
+            xa.inf_task = reinterpret_cast<const uint32_t*>(dp + o_st);
+            xa.inf_pos = reinterpret_cast<const uint32_t*>(dp + o_sp);
+            uint32_t done = 0;
+            while (done < n_slow) {   // grid.y ≤ 65535 blocks of EX_TCH tasks
+                uint32_t chunk = std::min<uint32_t>(n_slow - done, 32768u * EX_TCH);
+                ExplainArgs xc = xa;
+                xc.inf_task += done;
+                xc.inf_pos += done;
+                xc.n_inf = chunk;
+                hipLaunchKernelGGL(k_explain, dim3((N + 255) / 256, (chunk + EX_TCH - 1) / EX_TCH), dim3(256), 0, st, xc);
+                done += chunk;
+            }
         }
         HIPCHECK(e, hipGetLastError());
     }
@@ -1206,10 +1455,9 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             scan_sum += x;
             res_sum += y;
         }
-        (void)c;
         e->stats.ms_classes = a;
         e->stats.ms_scan = scan_sum;      // Σ over windows of k_scan launch durations
-        e->stats.ms_resolve = res_sum;    // Σ over windows of k_resolve launch durations
+        e->stats.ms_resolve = b->segs.empty() ? res_sum : c;   // Σ of the resolver launches; with runs of identical tasks in the batch: the whole phase (k_waterfill launches + the stretches between them)
         e->stats.ms_explain = d;
         e->stats.ms_total = t;
     }

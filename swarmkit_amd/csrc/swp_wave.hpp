@@ -161,17 +161,18 @@ WV_DEV u32 match_run64(u64& todo_io, u32& bits, u32 w, u32& pick) {
 // The same chain with the loop unrolled over the 64 lanes (round 3): lane indices are immediates, so the scalar side no longer
 // finds the next lane (s_ff1 on a todo mask), clears it, moves it to m0 or branches back, and a lane carries TWO half-words — the
 // current one (bits, w) and the next of its list (bits2, w2), both struck by every pick — so that a lane whose current half-word
-// ran empty steps to the next one inside the walk (11 instructions, no LDS, no exit). 12 instructions per task:
+// ran empty steps to the next one inside the walk (11 instructions, no LDS, no exit). 13 instructions per task, no exec-mask
+// round trips (two compare -> select -> clear chains interleaved, so that no instruction waits for the one before it):
 //   v_readlane sb ← bits[L];  v_readlane sw ← w[L];  s_sub t ← 0 − sb;  s_and sm ← sb & t  (the lowest candidate, SCC = any);
-//   s_cbranch_scc0 step_L;  v_cmpx_eq (w == sw);  v_bfi bits &= ~sm;  s_mov exec ← −1;  the same three for (bits2, w2);
-//   v_writelane pickb[L] ← sb
+//   s_cbranch_scc0 step_L;  v_cmp vcc ← (w == sw);  v_cmp m2 ← (w2 == sw);  v_mov vsm ← sm;  v_cndmask t1 ← vcc ? vsm : 0;
+//   v_cndmask t2 ← m2 ? vsm : 0;  v_bfi bits &= ~t1;  v_bfi bits2 &= ~t2;  v_writelane pickb[L] ← sb
 //   step_L: every lane >= L with empty bits takes (bits2, w2) and leaves bits2 empty; lane L is tried again; still empty: stop.
 // Every lane in [from, 64) is walked in order. A lane the caller does not want served carries a dummy (bits = 1, bits2 = 0,
 // w = WV_DUMMY_W | lane: no real half-word index has bit 31, so nobody else is struck); the walk stops in front of the first lane whose
 // two half-words are both empty and returns its index (64: walked to the end) — the caller's stop sentinel is simply bits = bits2 = 0
 // in the lane behind its last task.
 //   pickb[L] = lane L's candidate bits at its turn: the node it took is w[L] * 32 + ctz(pickb[L]) (a served lane never moves).
-//   lid = the lane index in a register. Entry at lane `from` is a computed jump: every body is WV_MB_BYTES = 68 bytes
+//   lid = the lane index in a register. Entry at lane `from` is a computed jump: every body is WV_MB_BYTES = 80 bytes
 //   (tools/check_matcher_asm.sh disassembles and checks). s[94:95] holds the jump target (clobbered); exec is all ones afterwards.
 #define WV_DUMMY_W 0x80000000u
 #define WV_MB(L)                                                                                                                       \
@@ -181,12 +182,13 @@ WV_DEV u32 match_run64(u64& todo_io, u32& bits, u32 w, u32& pick) {
     "s_sub_u32 %[st], 0, %[sb]\n\t"                                                                                                    \
     "s_and_b32 %[sm], %[sb], %[st]\n\t"                                                                                                \
     "s_cbranch_scc0 4" #L "f\n\t"                                                                                                      \
-    "v_cmpx_eq_u32_e32 vcc, %[sw], %[w]\n\t"                                                                                           \
-    "v_bfi_b32 %[bits], %[sm], 0, %[bits]\n\t"                                                                                         \
-    "s_mov_b64 exec, -1\n\t"                                                                                                           \
-    "v_cmpx_eq_u32_e32 vcc, %[sw], %[w2]\n\t"                                                                                          \
-    "v_bfi_b32 %[bits2], %[sm], 0, %[bits2]\n\t"                                                                                       \
-    "s_mov_b64 exec, -1\n\t"                                                                                                           \
+    "v_cmp_eq_u32_e32 vcc, %[sw], %[w]\n\t"                                                                                            \
+    "v_cmp_eq_u32_e64 %[m2], %[sw], %[w2]\n\t"                                                                                         \
+    "v_mov_b32_e32 %[vsm], %[sm]\n\t"                                                                                                  \
+    "v_cndmask_b32_e32 %[t1], 0, %[vsm], vcc\n\t"                                                                                      \
+    "v_cndmask_b32_e64 %[t2], 0, %[vsm], %[m2]\n\t"                                                                                    \
+    "v_bfi_b32 %[bits], %[t1], 0, %[bits]\n\t"                                                                                         \
+    "v_bfi_b32 %[bits2], %[t2], 0, %[bits2]\n\t"                                                                                       \
     "v_writelane_b32 %[pickb], %[sb], " #L "\n\t"
 #define WV_MS(L)                                                                                                                       \
     "4" #L ":\n\t"                                                                                                                     \
@@ -205,16 +207,17 @@ WV_DEV u32 match_run64(u64& todo_io, u32& bits, u32 w, u32& pick) {
     F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17) F(18) F(19) F(20) F(21) F(22)    \
     F(23) F(24) F(25) F(26) F(27) F(28) F(29) F(30) F(31) F(32) F(33) F(34) F(35) F(36) F(37) F(38) F(39) F(40) F(41) F(42) F(43)      \
     F(44) F(45) F(46) F(47) F(48) F(49) F(50) F(51) F(52) F(53) F(54) F(55) F(56) F(57) F(58) F(59) F(60) F(61) F(62) F(63)
-#define WV_MB_BYTES 68
+#define WV_MB_BYTES 80
 WV_DEV u32 match_seq64(u32& bits, u32& w, u32& bits2, u32 w2, u32& pickb, u32 lid, u32 from) {
-    u32 at, sb, sw, sm, st;
+    u32 at, sb, sw, sm, st, vsm, t1, t2;
+    u64 m2;
     from = (u32)__builtin_amdgcn_readfirstlane((int)from);
     asm volatile(
         "s_setprio 3\n\t"
         "s_mov_b64 exec, -1\n\t"
         "s_getpc_b64 s[94:95]\n"
         "9:\n\t"
-        "s_mul_i32 %[st], %[from], 68\n\t"
+        "s_mul_i32 %[st], %[from], 80\n\t"
         "s_add_u32 %[st], %[st], 30f-9b\n\t"
         "s_add_u32 s94, s94, %[st]\n\t"
         "s_addc_u32 s95, s95, 0\n\t"
@@ -226,7 +229,7 @@ WV_DEV u32 match_seq64(u32& bits, u32& w, u32& bits2, u32 w2, u32& pickb, u32 li
         "99:\n\t"
         "s_setprio 0\n\t"
         : [bits] "+v"(bits), [w] "+v"(w), [bits2] "+v"(bits2), [pickb] "+v"(pickb), [at] "=&s"(at), [sb] "=&s"(sb), [sw] "=&s"(sw), [sm] "=&s"(sm),
-          [st] "=&s"(st)
+          [st] "=&s"(st), [m2] "=&s"(m2), [vsm] "=&v"(vsm), [t1] "=&v"(t1), [t2] "=&v"(t2)
         : [w2] "v"(w2), [lid] "v"(lid), [from] "s"(from)
         : "vcc", "scc", "s94", "s95", "memory");
     return at;
