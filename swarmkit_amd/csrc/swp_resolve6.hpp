@@ -35,7 +35,7 @@
 namespace swpdev {
 
 #define R6_NP 16                 // level planes: 65 535 levels above the lowest valid node
-#define R6_CAND 8                // a proposal lists 2 * R6_CAND non-empty 32-node half-words: a block is cut where a task finds all its listed nodes taken
+#define R6_CAND 16               // a proposal lists 2 * R6_CAND non-empty 32-node half-words: a block is cut where a task finds all its listed nodes taken
 #define R6_BMAX 1024             // largest block
 #define R6_COMMIT_THREADS 1024      // == R6_BMAX: one accepted pick per thread in the apply phase
 #define R6_NONE 0xFFFFFFFFu
@@ -57,6 +57,7 @@ struct R6Prop {   // one task's proposal: the shard protocol's record (include/s
     u32 exc_entry, flags;    // flags bit 0: the task does not count on its node
 };
 static_assert(sizeof(R6Prop) == 8 + 16 * R6_CAND + 24, "R6Prop layout");
+static_assert(2 * R6_CAND <= 64, "one lane per list entry");
 
 struct R6Args {
     u32 n_nodes, n_words, xs, block;
@@ -106,11 +107,11 @@ struct R6Args {
 };
 
 #define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together
-#define R6_PW 4                  // waves per task in the propose kernel
+#define R6_PW 8                  // waves per task in the propose kernel
 inline __host__ __device__ u32 r6_chunks(u32 n_words) { return (((n_words + 63u) >> 6) + R6_UNROLL * R6_PW - 1u) / (R6_UNROLL * R6_PW) * (R6_UNROLL * R6_PW); }
 inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8 + 128; }
-// TK row, thresholds, the picks of the block, a few scalars
-inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * 3 * 4 + 64; }
+// TK row, thresholds, the picks of the block, a few scalars, the block's lists (entry-major)
+inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * (4 + 4 * R6_CAND) * 4 + 64; }
 
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
 WV_DEV u64 r6_wave_min64(u64 v) {
@@ -246,11 +247,13 @@ WV_DEV void r6_propose(const R6Args& a) {
         g0 = wv::uload(a.gs_off + gset);
         g1 = wv::uload(a.gs_off + gset + 1);
     }
-    if (wv::tid() < R6_NP + 2) flag[wv::tid()] = 0;
-    wv::barrier();
-    // the task's plain candidates, lane l of wave v owns words {l + 64 k}, k = v (mod R6_PW); R6_UNROLL chunks per step so that
-    // their loads are in flight together
-    bool any = false;
+    // The task's plain candidates AND the minimum level among them in one pass: lane l of wave v owns words {l + 64 k}, k = v (mod
+    // R6_PW); per word the candidate set is narrowed over the level planes from the top in registers (m & ~plane ≠ ∅ ? keep that : the
+    // bit is set in the word's minimum), the planes of R6_UNROLL words requested together; the minimum over the words is one reduction.
+    const u32 maxrel = wv::uload(&a.blk->maxrel);
+    const int nb = 32 - wv::clz32(maxrel);          // planes in use (0: every valid node sits on the base level)
+    u32* R = reinterpret_cast<u32*>(Bf);            // [KC * 64] the word's own minimum level above the base, R6_NONE: no candidate in it
+    u32 best = R6_NONE;
     for (u32 k0 = wave; k0 < KC; k0 += R6_UNROLL * R6_PW) {
         u64 m[R6_UNROLL], f[R6_UNROLL];
         WV_UNROLL
@@ -263,78 +266,73 @@ WV_DEV void r6_propose(const R6Args& a) {
             for (u32 g = g0; g < g1; ++g)
                 if (in) f[u] |= ~a.rg[(size_t)wv::uload(a.gs_row + g) * Wn + w];
         }
+        u32 rel[R6_UNROLL];
         WV_UNROLL
         for (int u = 0; u < R6_UNROLL; ++u) {
             const u32 w = (k0 + u * R6_PW) * 64 + lane;
             m[u] &= ~f[u];
             for (u32 p = p0; p < p1; ++p)
                 if (m[u]) m[u] &= ~a.portmap[(size_t)wv::uload(a.pset_ids + p) * Wn + w];
-            A[(k0 + u * R6_PW) * 64 + lane] = m[u];
-            any = any || m[u] != 0;
+            rel[u] = 0;
         }
-    }
-    if (wv::ballot(any) && lane == 0) flag[0] = 1;   // many writers, one value
-    wv::barrier();
-    // the minimum level among them: descent over the planes, the candidate set narrows to that level's nodes
-    u32 level = R6_NONE;
-    if (flag[0]) {
-        const u32 maxrel = wv::uload(&a.blk->maxrel);
-        u32 rel = 0, pass = 1;
-        for (int b = 31 - wv::clz32(maxrel); b >= 0; --b, ++pass) {
-            const u64* pl = a.planes + (size_t)b * Wn;
-            bool h = false;
-            for (u32 k0 = wave; k0 < KC; k0 += R6_UNROLL * R6_PW) {
-                u64 m[R6_UNROLL], q[R6_UNROLL];
+        for (int hi = nb; hi > 0; hi -= 8) {   // eight planes a batch (a batch is all there is below 256 levels)
+            const int lo = hi > 8 ? hi - 8 : 0;
+            u64 q[R6_UNROLL][8];
+            WV_UNROLL
+            for (int u = 0; u < R6_UNROLL; ++u) {
+                const u32 w = (k0 + u * R6_PW) * 64 + lane;
                 WV_UNROLL
-                for (int u = 0; u < R6_UNROLL; ++u) {
-                    m[u] = A[(k0 + u * R6_PW) * 64 + lane];
-                    q[u] = m[u] ? pl[(k0 + u * R6_PW) * 64 + lane] : 0ull;   // m != 0 only inside the row
-                }
+                for (int b = 0; b < 8; ++b) q[u][b] = (lo + b < hi && m[u]) ? a.planes[(size_t)(lo + b) * Wn + w] : 0ull;   // m != 0 only inside the row
+            }
+            WV_UNROLL
+            for (int u = 0; u < R6_UNROLL; ++u) {
                 WV_UNROLL
-                for (int u = 0; u < R6_UNROLL; ++u) {
-                    const u64 c = m[u] & ~q[u];
-                    Bf[(k0 + u * R6_PW) * 64 + lane] = c;
-                    h = h || c != 0;
+                for (int b = 7; b >= 0; --b) {
+                    if (lo + b >= hi) continue;
+                    const u64 c = m[u] & ~q[u][b];
+                    if (c) m[u] = c;
+                    else if (m[u]) rel[u] |= 1u << (lo + b);
                 }
             }
-            if (wv::ballot(h) && lane == 0) flag[pass] = 1;
-            wv::barrier();
-            if (flag[pass]) {
-                u64* x = A;
-                A = Bf;
-                Bf = x;
-            } else
-                rel |= 1u << b;
         }
-        level = wv::uload(&a.blk->base) + rel;
+        WV_UNROLL
+        for (int u = 0; u < R6_UNROLL; ++u) {
+            const u32 idx = (k0 + u * R6_PW) * 64 + lane;
+            A[idx] = m[u];
+            const u32 r = m[u] ? rel[u] : R6_NONE;
+            R[idx] = r;
+            best = min(best, r);
+        }
     }
+    best = wv::min_u32(best);
+    if (lane == 0) flag[wave] = best;
+    wv::barrier();
+    u32 gmin = R6_NONE;
+    for (u32 v = 0; v < R6_PW; ++v) gmin = min(gmin, flag[v]);
+    const u32 level = gmin == R6_NONE ? R6_NONE : wv::uload(&a.blk->base) + gmin;
     if (wave != 0) return;   // (every wave is past the last barrier) wave 0 lists the candidates and writes the proposal
     R6Prop* out = a.prop + wv::block();
-    // its first non-empty half-words, in node order (what the matcher walks: a word that is half empty does not cost a list entry)
+    // its first non-empty half-words, in node order (what the matcher walks: a word that is half empty does not cost a list entry):
+    // 64 words a step, a lane's place in the list = the non-empty half-words in front of it (two ballots)
     u32 cnt = 0, more = 0;
     if (level != R6_NONE)
         for (u32 k = 0; k < KC && !more; ++k) {
-            const u64 m = A[k * 64 + lane];
-            u64 bal = wv::ballot(m != 0);
-            while (bal) {
-                const u32 l = (u32)wv::ffs64(bal);
-                bal &= bal - 1;
-                const u64 bits = wv::readlane64(m, l);
-                for (u32 h = 0; h < 2; ++h) {
-                    const u32 hb = (u32)(bits >> (32 * h));
-                    if (!hb) continue;
-                    if (cnt == 2 * R6_CAND) {
-                        more = 1;
-                        break;
-                    }
-                    if (lane == 0) {
-                        out->hw[cnt] = 2 * (k * 64 + l) + h;
-                        out->hb[cnt] = hb;
-                    }
-                    ++cnt;
-                }
-                if (more) break;
+            const u64 m = R[k * 64 + lane] == gmin ? A[k * 64 + lane] : 0ull;   // the words whose own minimum is the task's
+            const u32 lo = (u32)m, hi = (u32)(m >> 32);
+            const u64 b_lo = wv::ballot(lo != 0), b_hi = wv::ballot(hi != 0);
+            if (!(b_lo | b_hi)) continue;
+            const u32 at_lo = cnt + wv::mbcnt(b_lo) + wv::mbcnt(b_hi), at_hi = at_lo + (lo != 0 ? 1u : 0u);
+            if (lo && at_lo < 2 * R6_CAND) {
+                out->hw[at_lo] = 2 * (k * 64 + lane);
+                out->hb[at_lo] = lo;
             }
+            if (hi && at_hi < 2 * R6_CAND) {
+                out->hw[at_hi] = 2 * (k * 64 + lane) + 1;
+                out->hb[at_hi] = hi;
+            }
+            const u32 total = cnt + (u32)wv::popc64(b_lo) + (u32)wv::popc64(b_hi);
+            if (total > 2 * R6_CAND) more = 1;
+            cnt = min(total, (u32)(2 * R6_CAND));
         }
     // no plain candidate: the service's exception list by the full key (scheduler.go:708-735), lanes stride over the entries
     u64 bhi = KEY_NONE, blo = KEY_NONE;
@@ -371,13 +369,13 @@ WV_DEV void r6_propose(const R6Args& a) {
     const u64 glo = r6_wave_min64(bhi == ghi ? blo : KEY_NONE);
     const u64 who = wv::ballot(bhi == ghi && blo == glo && ghi != KEY_NONE);
     const u32 gentry = who ? wv::readlane(be, (u32)wv::ffs64(who)) : 0u;
+    if (lane >= cnt && lane < 2 * R6_CAND) {
+        out->hw[lane] = 0;
+        out->hb[lane] = 0;
+    }
     if (lane == 0) {
         out->level = level;
         out->n_cand = cnt | (more ? 0x80000000u : 0u);
-        for (u32 i = cnt; i < 2 * R6_CAND; ++i) {
-            out->hw[i] = 0;
-            out->hb[i] = 0;
-        }
         out->exc_hi = ghi;
         out->exc_lo = ghi == KEY_NONE ? KEY_NONE : glo;
         out->exc_entry = gentry;
@@ -410,8 +408,21 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     u32* pk_idx = pk_node + a.block;                             // [block] commit index / index among the unplaceable tasks
     u32* pk_aux = pk_idx + a.block;                              // [block] exception-list entry (LIST_EMPTY: plain node) / commits before an unplaceable task
     u32* sh = pk_aux + a.block;                                  // [0] accepted, [1] ncommit, [2] ninf, [3] tasks decided so far, [4] the matching is over
+    u32* L_hw = sh + 16;                                         // [2 * R6_CAND][block] the block's lists, entry-major: lane i of the matcher reads
+    u32* L_hb = L_hw + (size_t)2 * R6_CAND * a.block;            // ... entry k of task i at [k * block + i] (no bank conflicts)
+    u32* L_cur = L_hb + (size_t)2 * R6_CAND * a.block;           // [block] a lower bound of every task's cursor: the entries in front of it are dead
+    for (u32 j = tid; j < a.block; j += R6_COMMIT_THREADS) L_cur[j] = 0;
     for (u32 w = tid; w < Wn; w += R6_COMMIT_THREADS) tk[w] = 0;
     for (u32 c = tid; c < n_rr; c += R6_COMMIT_THREADS) thr[c] = a.thr[c];
+    // every thread stages the lists of its task: the matcher walks them with a cursor (an entry is looked at once) instead of holding
+    // all of them in registers
+    for (u32 j = tid; j < n; j += R6_COMMIT_THREADS) {
+        const R6Prop* q = a.prop + j;
+        for (int k = 0; k < 2 * R6_CAND; ++k) {
+            L_hw[(size_t)k * a.block + j] = q->hw[k];
+            L_hb[(size_t)k * a.block + j] = q->hb[k];
+        }
+    }
     // Wave v >= 1 applies the picks of the block's group v - 1 (tasks 64 (v - 1) ...) as soon as wave 0 has matched that group, while
     // it matches the next ones; the task records are requested now. The groups no wave is left for (a block of more than 960 tasks)
     // are applied by wave 0 behind its matching.
@@ -430,30 +441,55 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
         u32 nc = a.ctl->ncommit, ni = a.ctl->ninf, acc = 0, why = 0;
         u32* tk32 = reinterpret_cast<u32*>(tk);   // the same row as 32-node half-words
         bool stop = false;
-        R6Prop nxt = a.prop[lane < n ? lane : 0];   // the records of the next 64 tasks are in flight while a group is matched
+        // the scalar part of a task's record (level, list length, exception-list candidate); the next group's is in flight while a group is matched
+        struct Head { u32 level, n_cand; u64 exc_hi, exc_lo; u32 exc_entry, flags; };
+        auto head_of = [&](u32 j) {
+            const R6Prop* q = a.prop + j;
+            return Head{q->level, q->n_cand, q->exc_hi, q->exc_lo, q->exc_entry, q->flags};
+        };
+        Head nxt = head_of(lane < n ? lane : 0);
         for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
             const u32 i = g0 + lane, glim = min(64u, n - g0);
             const bool have = i < n;
-            const R6Prop rec = nxt;
-            const R6Prop* p = &rec;
-            if (g0 + 64 < n) nxt = a.prop[i + 64 < n ? i + 64 : 0];
+            const Head rec = nxt;
+            const Head* p = &rec;
+            if (g0 + 64 < n) nxt = head_of(i + 64 < n ? i + 64 : 0);
             const u64 tg0 = prof ? wv::clock64() : 0;
             const u32 level = have ? p->level : 0u;
             const u32 nent = (have && level != R6_NONE) ? (p->n_cand & 0x7FFFFFFFu) : 0u;
             const bool plain = nent != 0;
             const bool exc = have && level == R6_NONE && p->exc_hi != KEY_NONE;
             const bool inf = have && level == R6_NONE && !exc;
-            // the list as 32-node half-words (registers), minus the picks of the earlier groups
-            u32 eb[2 * R6_CAND], ew[2 * R6_CAND];
-            for (int k = 0; k < 2 * R6_CAND; ++k) {
-                ew[k] = p->hw[k];
-                eb[k] = (u32)k < nent ? (p->hb[k] & ~tk32[ew[k]]) : 0u;
-            }
-            // current half-word of every lane: the first one of its list that still has a candidate — and the one after it, which a
-            // lane steps to when its current half-word runs empty (cleaned of this group's picks only then)
-            u32 bits = 0, w = 0, bits2 = 0, w2 = 0;
-            for (int k = 2 * R6_CAND - 1; k >= 0; --k)
-                if (eb[k]) { bits2 = bits; w2 = w; bits = eb[k]; w = ew[k]; }
+            // Every lane carries two half-words of its list — the current one (bits, w) and the next one with a candidate left
+            // (bits2, w2), which it steps to inside the walk — and a cursor behind them. An entry is looked at ONCE, against the TK
+            // row as it is then (the picks of the earlier groups, and of this group's tasks in front of a stop): what it finds empty
+            // stays empty, what it seats is struck by the walk from then on.
+            u32 bits = 0, w = 0, bits2 = 0, w2 = 0, cur = have ? L_cur[i] : 0u;   // (the group's applying wave has skipped the dead entries so far)
+            auto seat = [&](bool want) {   // lanes with `want` fill their free seats from their cursor on, two entries a step
+                for (;;) {
+                    const bool go = want && bits2 == 0 && cur < nent;
+                    if (!wv::ballot(go)) break;
+                    if (go) {
+                        const u32 h0 = L_hw[(size_t)cur * a.block + i], b0 = L_hb[(size_t)cur * a.block + i];
+                        const bool two = cur + 1 < nent;
+                        const u32 h1 = two ? L_hw[(size_t)(cur + 1) * a.block + i] : 0u, b1 = two ? L_hb[(size_t)(cur + 1) * a.block + i] : 0u;
+                        const u32 c0 = b0 & ~tk32[h0], c1 = two ? b1 & ~tk32[h1] : 0u;
+                        cur += 1;
+                        if (c0) {
+                            if (!bits) { bits = c0; w = h0; }
+                            else { bits2 = c0; w2 = h0; }
+                        }
+                        if (two && bits2 == 0) {   // (a second seat taken by entry 0 leaves entry 1 for the next visit)
+                            cur += 1;
+                            if (c1) {
+                                if (!bits) { bits = c1; w = h1; }
+                                else { bits2 = c1; w2 = h1; }
+                            }
+                        }
+                    }
+                }
+            };
+            seat(plain);
             const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
             const u64 m_plain = wv::ballot(plain), m_inf = wv::ballot(inf), m_exc = wv::ballot(exc), m_unc = wv::ballot(plain && (p->flags & 1u));
             // the group ends in front of a task that must use its exception list (its order moves with every placement of the service:
@@ -485,19 +521,14 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
                 const u32 at = wv::match_seq64(bits, w, bits2, w2, pickb, lane, from);
                 if (at >= cut) break;
                 ++reseats;
-                // task `at` ran out of its current half-word — and so, usually, did others that sat on it: this group's picks so far go to
-                // the TK row (a pick = the lowest bit the lane had at its turn, in the half-word it still sits on), every such lane steps to
-                // its next half-word cleaned of them, and only a lane whose next one is empty too cleans all its half-words
+                // task `at` ran out of both its half-words — and so, usually, did others that sat on them: this group's picks so far go to
+                // the TK row (a pick = the lowest bit the lane had at its turn, in the half-word it still sits on), and every lane still
+                // to be served fills its free seats from its cursor on
                 if (served && lane >= flushed && lane < at) wv::lds_or32(tk32 + w, pickb & (0u - pickb));
                 flushed = at;
                 wv::lockstep();   // one wave's LDS operations execute in order: the reads below see the atomics above
                 {
-                    if (served && lane >= at && bits == 0) {
-                        u32 t[2 * R6_CAND];
-                        for (int k = 0; k < 2 * R6_CAND; ++k) t[k] = eb[k] & ~tk32[ew[k]];
-                        for (int k = 2 * R6_CAND - 1; k >= 0; --k)
-                            if (t[k]) { bits2 = bits; w2 = w; bits = t[k]; w = ew[k]; }
-                    }
+                    seat(served && lane >= at);
                     if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
                         cut = at;
                         why = 1;
@@ -554,6 +585,21 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     // a wave waits (polling LDS, asleep in between) until its group is matched or the matching is over, and applies what was accepted of it
     if (wave_ != 0) {
         const u32 g0 = (wave_ - 1u) * 64u, need = min(g0 + 64u, n);
+        if (g0 > 0 && mine < n) {
+            // until the matcher reaches this wave's group: move every task's cursor over the entries that are dead by now (taken nodes
+            // stay taken: what is dead against an older TK row is dead), so that the matcher seats the group in a step or two
+            const u32 lv = a.prop[mine].level, nent = lv != R6_NONE ? (a.prop[mine].n_cand & 0x7FFFFFFFu) : 0u;
+            const u32* tk32 = reinterpret_cast<const u32*>(tk);
+            u32 cur = 0;
+            while (wv::lds_poll32(sh + 3) + 64u < g0 && wv::lds_poll32(sh + 4) == 0) {   // (stops a group early: the last value must be in LDS when it is read)
+                for (int q = 0; q < 4 && cur < nent; ++q) {
+                    if (L_hb[(size_t)cur * a.block + mine] & ~tk32[L_hw[(size_t)cur * a.block + mine]]) break;
+                    ++cur;
+                }
+                L_cur[mine] = cur;
+                wv::spin_pause();
+            }
+        }
         if (g0 < n)
             while (wv::lds_poll32(sh + 3) < need && wv::lds_poll32(sh + 4) == 0) wv::spin_pause();
     }

@@ -52,3 +52,13 @@ def test_block_resolver_source_matches_sequential_model(emu_bin, case):
     r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr
+
+
+@pytest.mark.parametrize("case", [(5, 1500, 1200, 60, 64, 0, 1, ""), (6, 3000, 900, 40, 128, 2, 2, "t")], ids=lambda c: "seed%d-N%d-B%d-f%d%s" % (c[0], c[1], c[4], c[6], c[7]))
+def test_hundreds_of_levels(emu_bin, case):
+    """Task counts spread over ~700 levels: ten level planes in use, so the propose kernel's per-word descent takes its second batch of
+    planes (eight a batch)."""
+    args = [str(x) for x in case[:7]] + ["v"] + list(case[7])
+    r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, EMU_LVL_MODE="4"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr

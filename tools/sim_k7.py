@@ -141,6 +141,83 @@ def cuts_for(wl, rows, picks, B, H, unit=32, policy="lag"):
     return cuts, wrong
 
 
+def spec_rounds(wl, rows, picks, B, H, unit=32):
+    """The one-block-lag pipeline: while block k is matched, the lists of the tasks behind it are built against the state WITHOUT
+    block k (its picks are applied when both are done); a block that is accepted in full makes those lists usable (strike set = block
+    k's picks + the own ones), a cut throws them away and costs a round that only builds lists ("bubble"). A task without plain
+    candidates (exception list) needs a fresh list and a block of its own. Returns (matching rounds, bubbles, cuts)."""
+    N, T, S = wl.N, wl.T, wl.S
+    cpu = wl.node_cpu.copy()
+    mem = wl.node_mem.copy()
+    total = np.zeros(N, dtype=np.int64)
+    on = np.zeros((S, N), dtype=bool)
+    hw = np.arange(N) // unit
+    applied = 0
+
+    def apply_to(a):
+        nonlocal applied
+        while applied < a:
+            n = picks[applied]
+            if n >= 0:
+                k = applied % S
+                cpu[n] -= wl.svc_cpu[k]
+                mem[n] -= wl.svc_mem[k]
+                total[n] += 1
+                on[k, n] = True
+            applied += 1
+
+    pos, fresh, prev_start = 0, True, 0
+    rounds = bubbles = cuts = 0
+    since = np.zeros(N, dtype=bool)
+    while pos < T:
+        a = pos if fresh else prev_start
+        apply_to(a)
+        since[:] = False
+        for q in range(a, pos):
+            if picks[q] >= 0:
+                since[picks[q]] = True
+        if fresh:
+            bubbles += 1   # a round that only built lists (the very first one included)
+        rounds += 1
+        end = min(T, pos + B)
+        t = pos
+        cut = False
+        while t < end:
+            n = picks[t]
+            k = t % S
+            if n >= 0:
+                p = rows[k] & (cpu >= wl.svc_cpu[k]) & (mem >= wl.svc_mem[k]) & ~on[k]
+                ok = False
+                if p.any():
+                    lv = total[p].min()
+                    c = np.flatnonzero(p & (total == lv))
+                    units = hw[c]
+                    edge = np.flatnonzero(np.diff(units, prepend=-1) != 0)
+                    if len(edge) > H:
+                        c = c[:edge[H]]
+                    left = c[~since[c]]
+                    ok = len(left) > 0
+                    assert not ok or left[0] == n
+                    if not ok:   # exhausted list
+                        if t == pos and fresh:
+                            raise AssertionError("fresh list exhausted")
+                elif t == pos and fresh:   # exception-list task opening a fresh block: decided, block ends behind it
+                    since[n] = True
+                    t += 1
+                    cut = True
+                    break
+                if not ok:
+                    cuts += 1
+                    cut = True
+                    break
+                since[n] = True
+            t += 1
+        prev_start = pos
+        pos = t
+        fresh = cut
+    return rounds, bubbles, cuts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--T", type=int, default=100_000)
@@ -158,6 +235,10 @@ def main():
     for B in [int(x) for x in a.B.split(",")]:
         for H in [int(x) for x in a.H.split(",")]:
             t0 = time.time()
+            if a.policy == "spec":
+                r, bub, c = spec_rounds(wl, rows, picks, B, H, a.unit)
+                print("spec B=%4d H=%3d: matching rounds %d, list-only rounds %d, cuts %d   [%.0f s]" % (B, H, r, bub, c, time.time() - t0), flush=True)
+                continue
             c, w = cuts_for(wl, rows, picks, B, H, a.unit, a.policy)
             print(a.policy, "B=%4d H=%3d unit=%d: cuts %6d (1 per %.0f tasks), list-rule violations %d   [%.0f s]" % (B, H, a.unit, c, wl.T / max(c, 1), w, time.time() - t0), flush=True)
 
