@@ -111,7 +111,7 @@ struct R6Args {
 inline __host__ __device__ u32 r6_chunks(u32 n_words) { return (((n_words + 63u) >> 6) + R6_UNROLL * R6_PW - 1u) / (R6_UNROLL * R6_PW) * (R6_UNROLL * R6_PW); }
 inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8 + 128; }
 // TK row, thresholds, the picks of the block, a few scalars, the block's lists (entry-major)
-inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * (4 + 4 * R6_CAND) * 4 + 64; }
+inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * (4 + 4 * R6_CAND) * 4 + 128; }
 
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
 WV_DEV u64 r6_wave_min64(u64 v) {
@@ -408,21 +408,14 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     u32* pk_idx = pk_node + a.block;                             // [block] commit index / index among the unplaceable tasks
     u32* pk_aux = pk_idx + a.block;                              // [block] exception-list entry (LIST_EMPTY: plain node) / commits before an unplaceable task
     u32* sh = pk_aux + a.block;                                  // [0] accepted, [1] ncommit, [2] ninf, [3] tasks decided so far, [4] the matching is over
-    u32* L_hw = sh + 16;                                         // [2 * R6_CAND][block] the block's lists, entry-major: lane i of the matcher reads
+    u32* staged = sh + 16;                                       // [16] group g's lists are in LDS
+    u32* L_hw = sh + 32;                                         // [2 * R6_CAND][block] the block's lists, entry-major: lane i of the matcher reads
     u32* L_hb = L_hw + (size_t)2 * R6_CAND * a.block;            // ... entry k of task i at [k * block + i] (no bank conflicts)
     u32* L_cur = L_hb + (size_t)2 * R6_CAND * a.block;           // [block] a lower bound of every task's cursor: the entries in front of it are dead
     for (u32 j = tid; j < a.block; j += R6_COMMIT_THREADS) L_cur[j] = 0;
     for (u32 w = tid; w < Wn; w += R6_COMMIT_THREADS) tk[w] = 0;
     for (u32 c = tid; c < n_rr; c += R6_COMMIT_THREADS) thr[c] = a.thr[c];
-    // every thread stages the lists of its task: the matcher walks them with a cursor (an entry is looked at once) instead of holding
-    // all of them in registers
-    for (u32 j = tid; j < n; j += R6_COMMIT_THREADS) {
-        const R6Prop* q = a.prop + j;
-        for (int k = 0; k < 2 * R6_CAND; ++k) {
-            L_hw[(size_t)k * a.block + j] = q->hw[k];
-            L_hb[(size_t)k * a.block + j] = q->hb[k];
-        }
-    }
+    if (tid < 16) staged[tid] = 0;
     // Wave v >= 1 applies the picks of the block's group v - 1 (tasks 64 (v - 1) ...) as soon as wave 0 has matched that group, while
     // it matches the next ones; the task records are requested now. The groups no wave is left for (a block of more than 960 tasks)
     // are applied by wave 0 behind its matching.
@@ -434,6 +427,17 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     const bool prof = (a.dbg & 16u) != 0;
     const u64 t0 = prof ? wv::clock64() : 0;
     wv::barrier();
+    // every thread stages the lists of its task (wave g: the block's group g): the matcher walks them with a cursor (an entry is looked
+    // at once) instead of holding all of them in registers. No barrier: a group's flag is published when its lists are in LDS.
+    if (tid < n) {
+        const R6Prop* q = a.prop + tid;
+        for (int k = 0; k < 2 * R6_CAND; ++k) {
+            L_hw[(size_t)k * a.block + tid] = q->hw[k];
+            L_hb[(size_t)k * a.block + tid] = q->hb[k];
+        }
+    }
+    wv::lockstep();
+    if (lane == 0) wv::lds_publish32(staged + wave_, 1u);
     const u64 t1 = prof ? wv::clock64() : 0;
     u32 reseats = 0;
     u64 cy_load = 0, cy_walk = 0;
@@ -451,6 +455,7 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
         for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
             const u32 i = g0 + lane, glim = min(64u, n - g0);
             const bool have = i < n;
+            while (wv::lds_poll32(staged + (g0 >> 6)) == 0) wv::spin_pause();   // (long there, but for the first groups of a block)
             const Head rec = nxt;
             const Head* p = &rec;
             if (g0 + 64 < n) nxt = head_of(i + 64 < n ? i + 64 : 0);
@@ -565,6 +570,9 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             sh[0] = acc;
             sh[1] = nc;
             sh[2] = ni;
+            a.blk->pos = pos + acc;   // (every thread read the old position before the barrier above)
+            a.ctl->ncommit = nc;
+            a.ctl->ninf = ni;
             wv::lds_publish32(sh + 3, acc);   // (the first task from its exception list leaves the loop before the publish above)
             wv::lds_publish32(sh + 4, 1u);
             a.blk->rounds += 1;
@@ -585,6 +593,8 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     // a wave waits (polling LDS, asleep in between) until its group is matched or the matching is over, and applies what was accepted of it
     if (wave_ != 0) {
         const u32 g0 = (wave_ - 1u) * 64u, need = min(g0 + 64u, n);
+        if (g0 > 0 && g0 < n)
+            while (wv::lds_poll32(staged + (g0 >> 6)) == 0) wv::spin_pause();
         if (g0 > 0 && mine < n) {
             // until the matcher reaches this wave's group: move every task's cursor over the entries that are dead by now (taken nodes
             // stay taken: what is dead against an older TK row is dead), so that the matcher seats the group in a step or two
@@ -662,17 +672,7 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             a.out_node[t] = (int32_t)nd;
         }
     }
-    wv::barrier();
-    const u32 acc = sh[0];
-    if (tid == 0) {
-        a.blk->pos = pos + acc;
-        a.ctl->ncommit = sh[1];
-        a.ctl->ninf = sh[2];
-        if (prof) {
-            a.blk->cyc[2] += (u32)((t2 - t1) >> 6);
-            a.blk->cyc[3] += (u32)((wv::clock64() - t2) >> 6);
-        }
-    }
+    if (prof && wave_ == 1 && lane == 0) a.blk->cyc[3] += (u32)((wv::clock64() - t2) >> 6);   // the first group's applying wave: waiting for it + applying
 }
 
 #endif   // SWP_R6_KERNELS
