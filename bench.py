@@ -27,7 +27,7 @@ ROW_B = {"cfg2": 32, "cfg3": 48, "cfg3m": 48, "cfg4": 64}   # algorithmic node-r
 TASK_B = 64 + 8                # descriptor + result per task, SURVEY.md §8d
 
 
-RESOLVER_NAMES = {105: "k_resolve5", 6: "k_resolve6 (rounds of k_r6_propose + k_r6_commit; one 'launch' = the whole batch)"}
+RESOLVER_NAMES = {105: "k_resolve5", 6: "k_resolve6 (one 'launch' = one ROUND: k_r6_propose + k_r6_commit)"}
 SHADER_GHZ = 2.4               # MI355X peak engine clock, /opt/skills/guides/MI355X_MICROARCH.md: cycles_per_task is quoted at this clock
 FILTERS = {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filters",
            "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}
@@ -48,7 +48,7 @@ def profile_traffic(kernel):
         per = doc.get("hbm_bytes_per_launch", {})
         base = kernel.split("<")[0]
         if kernel.startswith("k_resolve6") and "k_r6_propose" in per and "k_r6_commit" in per:   # per ROUND: one launch of each
-            return per["k_r6_propose"] + per["k_r6_commit"], "profiles/%s_pmc_summary.json, k_r6_propose + k_r6_commit per round (%s)" % (tag, doc.get("source_cfg4_200k_40k", ""))
+            return per["k_r6_propose"] + per["k_r6_commit"], "profiles/%s_pmc_summary.json, k_r6_propose + k_r6_commit per round (%s)" % (tag, doc.get("source", ""))
         if base in per:
             return per[base], "profiles/%s_pmc_summary.json (%s)" % (tag, doc.get("source", "rocprofv3 --pmc"))
         if tag == "r01" and "k_resolve_hbm_bytes_per_launch" in doc and base == "k_resolve3":
@@ -471,6 +471,7 @@ def main():
         step()
     sync()
     ms_resolve = ms_explain = ms_classes = ms_dev = 0.0
+    launches0 = eng.stats()["resolve_launches"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, _ = step()
@@ -506,10 +507,12 @@ def main():
     t_step = elapsed / K
     # dominant kernel = the resolver (sequential argmin + residual-update commit): `windows` launches per step (1 for
     # k_resolve5's exact mode, which needs no scan window)
+    kernel = RESOLVER_NAMES.get(int(st.get("last_resolver", 105)), "k_resolve5")
+    if kernel.startswith("k_resolve6"):   # the block resolver: a "launch" is one round (two kernel launches), decided tasks per round vary
+        windows = max((st["resolve_launches"] - launches0) / 2.0 / K, 1.0)
     res_launch_ms = ms_resolve / K / windows
     alg_bytes_launch = alg_bytes_step / windows
     achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0
-    kernel = RESOLVER_NAMES.get(int(st.get("last_resolver", 105)), "k_resolve5")
     traffic, traffic_src = profile_traffic(kernel)
 
     result = {
@@ -533,16 +536,18 @@ def main():
         "unplaceable": wl.T - placed,
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows,
-                     "note": ("algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the block resolver reads bitmap ROWS from L2 (one bit per pair and "
-                              "filter) instead of a node row per pair, so the algorithmic figure can exceed the HBM peak (frac > 1 is that, not a "
-                              "measurement error); the rounds are bound by one wave's instruction issue in k_r6_commit" if kernel.startswith("k_resolve6") else
+                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows, "tasks_per_launch": wl.T / windows,
+                     "note": ("per ROUND of the block resolver (launches_per_step rounds, tasks_per_launch decided each): algorithmic bytes = the round's "
+                              "(task, node) pairs x node-row bytes (SURVEY 8d); traffic = PMC bytes of one k_r6_propose + one k_r6_commit. The resolver reads "
+                              "bitmap ROWS (one bit per pair and filter, L2-resident) instead of a node row per pair, so real traffic is a small fraction "
+                              "of the algorithmic figure; a round is bound by one wave's instruction issue in k_r6_commit (resolver.cycles_per_task), "
+                              "not by HBM" if kernel.startswith("k_resolve6") else
                               "algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the resolver decides from bitmaps held in LDS, so its real HBM "
                               "traffic is far below that (see traffic): the kernel is bound by one workgroup's instruction issue, not by HBM")},
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_resolve": ms_resolve / K, "k_explain": ms_explain / K, "device_total": ms_dev / K},
         # what really bounds the resolver: the instruction issue of ONE wavefront (the matcher's dependent chain), not bytes
         "resolver": {"kernel": kernel.split(" ")[0], "ms_per_step": ms_resolve / K, "cycles_per_task": ms_resolve / K * 1e-3 * SHADER_GHZ * 1e9 / wl.T,
-                     "clock_GHz": SHADER_GHZ, "measured_HBM_GBs": (traffic * windows / (ms_resolve / K * 1e-3) / 1e9) if (traffic and ms_resolve > 0) else None,
+                     "clock_GHz": SHADER_GHZ, "measured_HBM_GBs": (traffic / (res_launch_ms * 1e-3) / 1e9) if (traffic and res_launch_ms > 0) else None,
                      "note": "cycles of the matching wave's CU per task of the batch, at the peak engine clock; measured_HBM_GBs = PMC bytes per launch (roofline.traffic) / launch time"},
         "whole_job_algorithmic_GBs": alg_bytes_step / t_step / 1e9,
         "end_to_end": {"ms": t_e2e * 1e3, "placements_per_s": wl.T / t_e2e,

@@ -682,6 +682,12 @@ __global__ __launch_bounds__(256) void k_xg_write(XGArgs a) {
     }
 }
 
+// the Explain rows of the unplaceable tasks, gathered for one short copy to the host (hist is [T][8], mostly zeros)
+__global__ __launch_bounds__(256) void k_gather_rows(const u32* idx, const u32* src, u32* dst, u32 n) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n * 8u) dst[g] = src[(size_t)idx[g >> 3] * 8u + (g & 7u)];
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_groups — grouped tasks (SpecVersion != nil): scheduleTaskGroup with k = len(group)
 // (scheduler.go:694-748), nodeSet.tree with a bounded max-heap per leaf (nodeset.go:50-124,

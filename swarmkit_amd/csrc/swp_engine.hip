@@ -48,16 +48,58 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Device allocations of freed batches are kept for the next batch (a tick prepares and frees one batch after the other: ~50
+// hipMalloc / hipFree pairs per tick otherwise). Per device, keyed by capacity; bounded.
+struct DevPool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> free_blocks;   // (device, capacity) -> block
+    size_t held = 0;
+    static constexpr size_t LIMIT = (size_t)8 << 30;
+    void* take(int dev, size_t want, size_t* cap) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = free_blocks.lower_bound({dev, want});
+        if (it == free_blocks.end() || it->first.first != dev || it->first.second > want + want / 2 + 4096) return nullptr;
+        void* p = it->second;
+        *cap = it->first.second;
+        held -= *cap;
+        free_blocks.erase(it);
+        return p;
+    }
+    bool give(int dev, size_t cap, void* p) {
+        std::lock_guard<std::mutex> g(mu);
+        if (held + cap > LIMIT) return false;
+        free_blocks.emplace(std::make_pair(dev, cap), p);
+        held += cap;
+        return true;
+    }
+    void drain(int dev) {   // swp_destroy: nothing of this device stays behind
+        std::lock_guard<std::mutex> g(mu);
+        for (auto it = free_blocks.begin(); it != free_blocks.end();) {
+            if (it->first.first == dev) {
+                (void)hipFree(it->second);
+                held -= it->first.second;
+                it = free_blocks.erase(it);
+            } else
+                ++it;
+        }
+    }
+};
+inline DevPool& dev_pool() {
+    static DevPool* p = new DevPool();   // (never destroyed: frees at process exit would race the HIP runtime's own teardown)
+    return *p;
+}
+
 struct DevBuf {   // owns one device allocation: movable, not copyable
     void* p = nullptr;
     size_t cap = 0;
+    int dev = -1;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), dev(o.dev) { o.p = nullptr; o.cap = 0; }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !dev_pool().give(dev, cap, p)) (void)hipFree(p);
         p = nullptr;
         cap = 0;
     }
@@ -65,8 +107,11 @@ struct DevBuf {   // owns one device allocation: movable, not copyable
         if (bytes <= cap && p) return hipSuccess;
         release();
         size_t want = bytes < 256 ? 256 : bytes;
+        if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if ((p = dev_pool().take(dev, want, &cap))) return hipSuccess;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
+        else p = nullptr;
         return e;
     }
     template <class T> T* as() const { return static_cast<T*>(p); }
@@ -200,6 +245,9 @@ struct swp_batch {
     DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
     DevBuf d_con, d_plat, d_plug, d_sc, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
+    uint32_t x_ninf = 0;             // unplaceable tasks of the last run (their list is in hx_in)
+    DevBuf d_xrows;                  // their Explain rows, gathered for the copy to the host
+    PinBuf hx_rows;
     DevBuf d_xpack, d_xdiff, d_xnr;  // explain pass by group: one packed upload (groups, entries, orders) + the difference planes
     PinBuf hx_in, hx_pack;           // its host staging: the unplaceable list as it comes back; the packed upload
     std::vector<uint32_t> xg_of;     // [T] explain group of the task (0xFFFFFFFF: per-task pass), fixed when the batch is built
@@ -430,6 +478,14 @@ std::string bytes_of(const T* p, size_t n) { return std::string(reinterpret_cast
 
 // ---- batch construction -------------------------------------------------------------------------
 int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch* b, const uint32_t* weights = nullptr) {
+    const bool dbg_prep = getenv("SWP_DEBUG_PREPARE") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!dbg_prep) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[swp]   build_batch %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+        tp = now;
+    };
     b->T = T;
     b->tasks.assign(tasks, tasks + T);
     b->rt.resize(T);
@@ -454,23 +510,54 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         }
     };
     static_assert(sizeof(swp_task_desc) == sizeof(DescKey), "descriptor key");
-    std::unordered_map<DescKey, uint32_t, DescHash> tmpl_index;
+    // descriptor -> the first task that carries it: open addressing over (hash, task) pairs — one probe and one 64-byte compare per
+    // task in the common case, no node allocations (1M tasks over 10k services: the map lookups were most of the preparation)
+    struct Slot { uint64_t h; uint32_t first, pad; };
+    std::vector<Slot> table((size_t)1 << 12, Slot{0, 0, 0});
+    size_t table_used = 0;
+    auto desc_hash = [](const swp_task_desc& d) {
+        DescKey key;
+        std::memcpy(key.w, &d, sizeof key);
+        return (uint64_t)DescHash()(key) | 1ull;   // 0 = empty slot
+    };
+    auto same_desc = [&](uint32_t a, uint32_t c) { return std::memcmp(&tasks[a], &tasks[c], sizeof(swp_task_desc)) == 0; };
     std::vector<uint32_t> tmpl_of(T), firsts;
 
     for (uint32_t i = 0; i < T; ++i) {
         const swp_task_desc& d = tasks[i];
         {
-            DescKey key;
-            std::memcpy(key.w, &d, sizeof key);
-            auto hit = tmpl_index.find(key);
-            if (hit != tmpl_index.end()) {
-                tmpl_of[i] = hit->second;
-                const uint32_t sv = b->rt[hit->second].svc;
+            uint32_t hit = 0xFFFFFFFFu;
+            uint64_t h = 0;
+            size_t at = 0;
+            if (i && same_desc(i, i - 1)) hit = tmpl_of[i - 1];   // (service-major batches: a run of one descriptor)
+            else {
+                h = desc_hash(d);
+                const size_t mask = table.size() - 1;
+                for (at = (size_t)(h >> 7) & mask; table[at].h; at = (at + 1) & mask)
+                    if (table[at].h == h && same_desc(table[at].first, i)) {
+                        hit = table[at].first;
+                        break;
+                    }
+            }
+            if (hit != 0xFFFFFFFFu) {
+                tmpl_of[i] = hit;
+                const uint32_t sv = b->rt[hit].svc;
                 task_rank[i] = svc_ntasks[sv];
                 svc_ntasks[sv] += weights ? weights[i] : 1u;
                 continue;
             }
-            tmpl_index.emplace(key, i);
+            table[at] = Slot{h, i, 0};
+            if (++table_used * 2 > table.size()) {   // grow: re-insert by the stored hashes
+                std::vector<Slot> bigger(table.size() * 4, Slot{0, 0, 0});
+                const size_t m2 = bigger.size() - 1;
+                for (const Slot& sl : table)
+                    if (sl.h) {
+                        size_t q = (size_t)(sl.h >> 7) & m2;
+                        while (bigger[q].h) q = (q + 1) & m2;
+                        bigger[q] = sl;
+                    }
+                table.swap(bigger);
+            }
             tmpl_of[i] = i;
             firsts.push_back(i);
         }
@@ -584,8 +671,10 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             }
         }
     }
+    mark("templates + first records");
     for (uint32_t i = 0; i < T; ++i)   // every other task of a descriptor gets the record of the first one (its list slot follows below)
         if (tmpl_of[i] != i) b->rt[i] = b->rt[tmpl_of[i]];
+    mark("records copied to the tasks");
     // generic reservations: the distinct (kind, value) pairs become rows sorted by (kind, value); a task's set names its rows
     b->has_generic = false;
     b->tg.clear();
@@ -632,6 +721,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             }
         }
     }
+    mark("generic sets");
     // explain groups (k_xg_nodes): tasks that share predicate classes, reservations, port set and — with MaxReplicas — service
     b->xg_of.assign(T, 0xFFFFFFFFu);
     b->xg_proto.clear();
@@ -665,6 +755,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             if (tmpl_of[i] != i) b->xg_of[i] = b->xg_of[tmpl_of[i]];
         b->xg_pairs = (uint32_t)pair_id.size();
     }
+    mark("explain groups");
     // runs of identical one-off tasks (same service, filters, reservations; only their list slot differs) are placed by
     // water-filling instead of task by task (csrc/swp_waterfill.hpp). A run must be long enough to pay for its launch, and
     // splitting the batch must not shred the round resolver's work into many launches: runs are used when they make up most
@@ -700,8 +791,12 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     b->n_plat = (uint32_t)plat_ids.size();
     b->n_plug = (uint32_t)plug_ids.size();
 
+    mark("runs");
     // per-service exception lists: nodes with svcCount>0 or ≥ maxFailures recent failures
     b->list_off.assign(b->n_svc + 1, 0);
+    b->list_node0.reserve((size_t)T + 1024);
+    b->list_svc0.reserve((size_t)T + 1024);
+    b->list_fail0.reserve((size_t)T + 1024);
     std::vector<uint32_t> init_cnt(b->n_svc, 0);
     for (uint32_t s = 0; s < b->n_svc; ++s) {
         uint32_t g = b->svc_global[s];
@@ -727,15 +822,14 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             b->list_fail0.push_back(kv.second.second);
         }
         init_cnt[s] = (uint32_t)b->list_node0.size() - b->list_off[s];
-        for (uint32_t k = 0; k < svc_ntasks[s]; ++k) {
-            b->list_node0.push_back(LIST_EMPTY);
-            b->list_svc0.push_back(0);
-            b->list_fail0.push_back(0);
-        }
+        b->list_node0.insert(b->list_node0.end(), svc_ntasks[s], LIST_EMPTY);   // one free entry per task of the service
+        b->list_svc0.insert(b->list_svc0.end(), svc_ntasks[s], 0u);
+        b->list_fail0.insert(b->list_fail0.end(), svc_ntasks[s], 0u);
     }
     b->list_off[b->n_svc] = (uint32_t)b->list_node0.size();
     for (uint32_t i = 0; i < T; ++i) b->rt[i].slot = b->list_off[b->rt[i].svc] + init_cnt[b->rt[i].svc] + task_rank[i];
 
+    mark("exception lists + slots");
     // host ports
     b->pset_off.assign(1, 0);
     for (uint32_t gs : pset_ids_global) {
@@ -947,6 +1041,7 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
         // fixed when the batch was built (xg_of). The list of unplaceable tasks comes back once (4 + 4 bytes each), is dealt into the
         // groups by a counting sort that keeps the list's order (moments ascend), and goes up again as ONE packed buffer together
         // with the groups, their order by reservation pair and the chunks of that order (pinned staging both ways).
+        b->x_ninf = n_inf;
         HIPCHECK(e, b->hx_in.reserve((size_t)n_inf * 8));
         uint32_t* h_task = static_cast<uint32_t*>(b->hx_in.p);
         uint32_t* h_pos = h_task + n_inf;
@@ -1123,6 +1218,7 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
 // class bitmaps: what a run does before its first resolver launch
 int batch_begin(swp_engine* e, swp_batch* b) {
     const uint32_t N = e->n_nodes, Wn = n_words_of(N), T = b->T;
+    b->x_ninf = 0;
     hipStream_t st = e->stream;
     size_t L = b->list_node0.size();
     if (L) {
@@ -1642,7 +1738,9 @@ void swp_destroy(swp_engine* e) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    const int dev = e->device;
     delete e;
+    dev_pool().drain(dev);   // (the allocations the engine just handed back, and whatever freed batches left)
 }
 
 int swp_reset(swp_engine* e, uint32_t n_nodes_hint) {
@@ -2081,6 +2179,22 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     return SWP_OK;
 }
 
+// [T][8] Explain counters to the caller's buffer: zeros but for the unplaceable tasks, whose rows come over as one gathered block
+static int download_hist(swp_engine* e, swp_batch* b, uint32_t* out_fail_hist) {
+    const uint32_t T = b->T, n = b->x_ninf;
+    std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
+    if (!n) return SWP_OK;
+    HIPCHECK(e, b->d_xrows.reserve((size_t)n * 32));
+    HIPCHECK(e, b->hx_rows.reserve((size_t)n * 32));
+    hipLaunchKernelGGL(k_gather_rows, dim3((n * 8u + 255u) / 256u), dim3(256), 0, e->stream, b->d_inf_task.as<uint32_t>(), b->d_hist.as<uint32_t>(), b->d_xrows.as<uint32_t>(), n);
+    HIPCHECK(e, hipMemcpyAsync(b->hx_rows.p, b->d_xrows.p, (size_t)n * 32, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    const uint32_t* tasks = static_cast<const uint32_t*>(b->hx_in.p);   // the unplaceable list as run_explain fetched it
+    const uint32_t* rows = static_cast<const uint32_t*>(b->hx_rows.p);
+    for (uint32_t q = 0; q < n; ++q) std::memcpy(out_fail_hist + (size_t)tasks[q] * SWP_NFILTERS, rows + (size_t)q * 8, 32);
+    return SWP_OK;
+}
+
 int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_tasks, swp_batch** out) {
     if (!e || !out || (!tasks && n_tasks)) return SWP_EINVAL;
     *out = nullptr;
@@ -2088,9 +2202,17 @@ int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_task
     int rc = flush_nodes(e);
     if (rc) return rc;
     auto b = std::make_unique<swp_batch>();
+    const bool dbg = getenv("SWP_DEBUG_PREPARE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if ((rc = build_batch(e, tasks, n_tasks, b.get()))) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     if (e->dev_static_dirty && (rc = flush_nodes(e))) return rc;
     if (n_tasks && e->n_nodes && (rc = upload_batch(e, b.get()))) return rc;
+    if (dbg) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[swp] swp_batch_prepare %u tasks: build %.2f ms, upload %.2f ms\n", n_tasks, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
     b->n_nodes_prepared = e->n_nodes;
     *out = b.release();
     return SWP_OK;
@@ -2119,7 +2241,9 @@ int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* ou
         return SWP_OK;
     }
     HIPCHECK(e, hipMemcpyAsync(out_node, b->d_out.p, (size_t)T * 4, hipMemcpyDeviceToHost, e->stream));
-    if (out_fail_hist) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, b->d_hist.p, (size_t)T * 8 * 4, hipMemcpyDeviceToHost, e->stream));
+    if (out_fail_hist) {
+        if (int rch = download_hist(e, b, out_fail_hist)) return rch;
+    }
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     uint64_t placed = 0;
     for (uint32_t i = 0; i < T; ++i) {
@@ -2145,7 +2269,9 @@ int swp_batch_results(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* 
     (void)hipSetDevice(e->device);
     if (b->T == 0 || e->n_nodes == 0) return SWP_OK;
     HIPCHECK(e, hipMemcpyAsync(out_node, b->d_out.p, (size_t)b->T * 4, hipMemcpyDeviceToHost, e->stream));
-    if (out_fail_hist) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, b->d_hist.p, (size_t)b->T * 8 * 4, hipMemcpyDeviceToHost, e->stream));
+    if (out_fail_hist) {
+        if (int rch = download_hist(e, b, out_fail_hist)) return rch;
+    }
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     return SWP_OK;
 }

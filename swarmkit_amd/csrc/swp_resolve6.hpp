@@ -178,17 +178,21 @@ WV_KERNEL(256) void k_r6_rows(R6Args a) {
 // cross hundreds of demand-class thresholds. For such a batch the rows are not kept per class and patched by the commits but built
 // per task at the start of every round, from the exact residuals: one wave per node word (a ballot IS a row word), the block's
 // reservations staged in LDS. No limit on the number of distinct reservations.
-WV_DEV void r6_taskrows(const R6Args& a) {
+// `g_first`, `g_step`: the 64-task groups of the block this workgroup works for (k_r6_taskrows: one group per workgroup row of the
+// grid, so that the launch fills the chip; the shard driver's launch uses its second grid dimension for the shards and walks all groups).
+WV_DEV void r6_taskrows(const R6Args& a, u32 g_first, u32 g_step) {
     const u32 pos = wv::uload(&a.blk->pos), end = wv::uload(&a.blk->end);
     if (pos >= end || wv::uload(&a.blk->error) != ERR_NONE) return;
     const u32 cnt = min(a.block, end - pos);
+    if (g_first * 64u >= cnt) return;
     i64* res = reinterpret_cast<i64*>(wv::lds());   // [block][2], a task without the filter: (INT64_MIN, INT64_MIN): every node passes
-    for (u32 j = wv::tid(); j < cnt; j += 256) {
-        const RTask* rt = a.rt + pos + j;
-        const bool on = (rt->flags & RT_RES) != 0;
-        res[2 * j] = on ? rt->cpu : (i64)0x8000000000000000ull;
-        res[2 * j + 1] = on ? rt->mem : (i64)0x8000000000000000ull;
-    }
+    for (u32 g0 = g_first * 64u; g0 < cnt; g0 += g_step * 64u)
+        for (u32 j = g0 + wv::tid(); j < min(g0 + 64u, cnt); j += 256) {
+            const RTask* rt = a.rt + pos + j;
+            const bool on = (rt->flags & RT_RES) != 0;
+            res[2 * j] = on ? rt->cpu : (i64)0x8000000000000000ull;
+            res[2 * j + 1] = on ? rt->mem : (i64)0x8000000000000000ull;
+        }
     wv::barrier();
     const u32 w = wv::block() * 4 + wv::wave(), lane = wv::lane();
     if (w >= a.n_words) return;
@@ -198,7 +202,7 @@ WV_DEV void r6_taskrows(const R6Args& a) {
     const u64 inmask = wv::ballot(in);
     // lanes = 64 tasks of the block at a time, the word's 64 residual pairs walked on the scalar side: ten instructions per (node, 64
     // tasks) and one store per lane and group, instead of a ballot and a one-lane store per task
-    for (u32 g0 = 0; g0 < cnt; g0 += 64) {
+    for (u32 g0 = g_first * 64u; g0 < cnt; g0 += g_step * 64u) {
         const u32 j = g0 + lane;
         const bool have = j < cnt;
         const i64 rc = have ? res[2 * j] : 0, rm = have ? res[2 * j + 1] : 0;
@@ -213,7 +217,7 @@ WV_DEV void r6_taskrows(const R6Args& a) {
     }
 }
 
-WV_KERNEL(256) void k_r6_taskrows(R6Args a) { r6_taskrows(a); }
+WV_KERNEL(256) void k_r6_taskrows(R6Args a) { r6_taskrows(a, wv::block_y(), (a.block + 63u) / 64u); }   // grid (words / 4, groups of the block)
 
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
 // The waves split the task's node words (wave v owns the chunks of 64 words k = v, v + R6_PW, ...): the passes are latency-bound,

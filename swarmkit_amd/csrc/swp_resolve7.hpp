@@ -104,6 +104,7 @@ WV_KERNEL(64) void k_r7_fold(R7Args a) {
 }
 
 // ---- match: one wave on the leader -------------------------------------------------------------------------------------------
+#define R7_LIST 16   // half-words of a folded list the matching wave holds in registers: the first ones (the list rule holds for any prefix)
 WV_KERNEL(64) void k_r7_match(R7Args a) {
     const u32 lane = wv::lane();
     const u32 pos = a.blk->pos, end = a.blk->end;
@@ -123,19 +124,19 @@ WV_KERNEL(64) void k_r7_match(R7Args a) {
         const R6Prop* p = &rec;
         if (g0 + 64 < n) nxt = a.merged[i + 64 < n ? i + 64 : 0];
         const u32 level = have ? p->level : 0u;
-        const u32 cnt = (have && level != R6_NONE) ? (p->n_cand & 0x7FFFFFFFu) : 0u;
+        const u32 cnt = (have && level != R6_NONE) ? min(p->n_cand & 0x7FFFFFFFu, (u32)R7_LIST) : 0u;   // (a prefix of a list is a list)
         const bool plain = cnt != 0;
         const bool exc = have && level == R6_NONE && p->exc_hi != KEY_NONE;
         const bool inf = have && level == R6_NONE && !exc;
         const u32 uncounted = p->flags & 1u, bshard = (p->flags >> 8) & 0xFFu, bnode = (u32)p->exc_lo, bentry = p->exc_entry;
         // ---- the list as 32-node half-words (registers), minus the picks of the earlier groups
-        u32 eb[2 * R6_CAND], ew[2 * R6_CAND];
-        for (int k = 0; k < 2 * R6_CAND; ++k) {
+        u32 eb[R7_LIST], ew[R7_LIST];
+        for (int k = 0; k < R7_LIST; ++k) {
             ew[k] = p->hw[k];
             eb[k] = (u32)k < cnt ? (p->hb[k] & ~tk32[ew[k]]) : 0u;
         }
         u32 bits = 0, w = 0, bits2 = 0, w2 = 0;
-        for (int k = 2 * R6_CAND - 1; k >= 0; --k)
+        for (int k = R7_LIST - 1; k >= 0; --k)
             if (eb[k]) { bits2 = bits; w2 = w; bits = eb[k]; w = ew[k]; }
         const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
         const u64 m_plain = wv::ballot(plain), m_inf = wv::ballot(inf), m_exc = wv::ballot(exc), m_unc = wv::ballot(plain && uncounted);
@@ -160,9 +161,9 @@ WV_KERNEL(64) void k_r7_match(R7Args a) {
             flushed = at;
             wv::lockstep();
             if (served && lane >= at && bits == 0) {
-                u32 t[2 * R6_CAND];
-                for (int k = 0; k < 2 * R6_CAND; ++k) t[k] = eb[k] & ~tk32[ew[k]];
-                for (int k = 2 * R6_CAND - 1; k >= 0; --k)
+                u32 t[R7_LIST];
+                for (int k = 0; k < R7_LIST; ++k) t[k] = eb[k] & ~tk32[ew[k]];
+                for (int k = R7_LIST - 1; k >= 0; --k)
                     if (t[k]) { bits2 = bits; w2 = w; bits = t[k]; w = ew[k]; }
             }
             if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
@@ -205,7 +206,7 @@ WV_KERNEL(64) void k_r7_match(R7Args a) {
 
 // ---- apply: every shard, the picks of its own range ------------------------------------------------------------------------------
 // One launch covers the shards that live on one device: workgroup b works for shard shard0 + b with the argument record args[b].
-WV_KERNEL(256) void k_r7_taskrows(const R6Args* args) { r6_taskrows(args[wv::block_y()]); }
+WV_KERNEL(256) void k_r7_taskrows(const R6Args* args) { r6_taskrows(args[wv::block_y()], 0u, 1u); }
 WV_KERNEL(64 * R6_PW) void k_r7_propose(const R6Args* args) { r6_propose(args[wv::block_y()]); }
 
 WV_KERNEL(R6_COMMIT_THREADS) void k_r7_apply(const R6Args* args, const R7Pick* picks, const R7Head* head, u32 shard0) {

@@ -119,7 +119,12 @@ int main(int argc, char** argv) {
         while (blk.pos < blk.end) {
             const u32 before = blk.pos;
             for (R6Prop& q : prop) memset(&q, 0xEE, sizeof q);
-            if (task_rows) grid((p.Wn + 3) / 4, 256, (size_t)B * 16, [a]() { k_r6_taskrows(a); });
+            if (task_rows)
+                for (u32 gy = 0; gy < (B + 63) / 64; ++gy) {   // grid (words / 4, groups of the block)
+                    emu::blockidx_y() = gy;
+                    grid((p.Wn + 3) / 4, 256, (size_t)B * 16, [a]() { k_r6_taskrows(a); });
+                }
+            emu::blockidx_y() = 0;
             grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
             grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
             ++rounds;

@@ -98,6 +98,10 @@ struct Block {
     std::vector<void*> last_site;   // per thread: return address of its last collective / barrier call (deadlock report)
     std::vector<u64> ncoll;
 };
+inline u32& blockidx_y() {   // second grid dimension (wv::block_y()): set by the harness around a launch
+    static u32 v = 0;
+    return v;
+}
 inline u32& blockidx() {   // workgroup index seen by wv::block(): the harness runs the workgroups of a grid one after the other
     static u32 b = 0;
     return b;
@@ -266,7 +270,7 @@ inline u32 nthreads() { return emu::B()->nthreads; }
 inline u32 lane() { return emu::B()->cur & 63u; }
 inline u32 wave() { return emu::B()->cur >> 6; }
 inline u32 block() { return emu::blockidx(); }
-inline u32 block_y() { return 0; }
+inline u32 block_y() { return emu::blockidx_y(); }
 inline u64* lds() { return emu::B()->lds.data(); }
 
 inline u64 ballot(bool p) { return emu::collective(emu::OP_BALLOT, p ? 1 : 0, 0); }
