@@ -486,16 +486,18 @@ def main():
 
     # end to end, outside the timed region: what a caller of swp_schedule_batch waits for — de-duplication of the predicate
     # sets + H2D of the descriptors (swp_batch_prepare), the device pass, D2H of placements AND explanation histograms
-    e2e = []
-    for _ in range(2):
+    e2e, prep = [], []
+    for _ in range(3):
         eng.state_restore()
         t0 = time.perf_counter()
         b2 = eng.batch_prepare(descs)
+        prep.append(time.perf_counter() - t0)
         b2.run()
         b2.results(want_hist=True)
         e2e.append(time.perf_counter() - t0)
         b2.free()
     t_e2e = min(e2e)
+    t_prepare_warm = min(prep)   # (the first prepare of the process also pays for the device allocations: reported as "cold")
 
     st = eng.stats()
     K = max(args.steps, 1)
@@ -552,7 +554,7 @@ def main():
         "whole_job_algorithmic_GBs": alg_bytes_step / t_step / 1e9,
         "end_to_end": {"ms": t_e2e * 1e3, "placements_per_s": wl.T / t_e2e,
                        "includes": "swp_batch_prepare (predicate de-duplication + H2D of the task descriptors) + device pass + D2H of placements and Explain histograms",
-                       "swp_batch_prepare_ms": t_prepare * 1e3},
+                       "swp_batch_prepare_ms": t_prepare_warm * 1e3, "swp_batch_prepare_cold_ms": t_prepare * 1e3},
         "host_prep_s": {"intern+descriptors": t_host_prep, "swp_batch_prepare": t_prepare},
         "resolver_raw": {k: st[k] for k in ("generic_tasks", "resolver_spins", "slow_path_tasks", "rebase_events", "batches")},
     }

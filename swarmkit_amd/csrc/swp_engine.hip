@@ -764,7 +764,8 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     {
         const char* env_wf = getenv("SWP_WATERFILL");
         const int mode = env_wf ? atoi(env_wf) : -1;
-        const uint32_t run_min = mode == 1 ? 2u : 64u;
+        // (the block resolver decides a task in ~130 ns; a water-fill launch costs ~50 µs: a run pays from a few hundred tasks on)
+        const uint32_t run_min = mode == 1 ? 2u : 512u;
         auto same = [&](uint32_t i, uint32_t k) { return tmpl_of[i] == tmpl_of[k]; };   // identical descriptors
         std::vector<swp_batch::Seg> segs;
         uint64_t in_runs = 0;
@@ -1074,12 +1075,13 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
         // chunks: groups of one pair, few enough per chunk that the launch still fills the device
         const uint32_t bx = (N + 256 * XG_NPT - 1) / (256 * XG_NPT);
         const uint32_t csize = std::max<uint32_t>(1, std::min<uint32_t>(32, (uint32_t)(((uint64_t)ng * bx) / 2048)));
-        uint32_t nc = 0;
+        uint32_t nc = 0, nw = 0;
         for (uint32_t p = 0; p < b->xg_pairs; ++p) nc += (pair_cnt[p] + csize - 1) / csize;
+        for (uint32_t g = 0; g < NG; ++g) nw += (fill[g] + XG_WCH - 1) / XG_WCH;   // k_xg_write's chunks
         auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
         const size_t o_g = 0, o_pos = al(o_g + (size_t)ng * sizeof(XGroup)), o_task = al(o_pos + (size_t)n_fast * 4), o_mr = al(o_task + (size_t)n_fast * 4),
                      o_ord = al(o_mr + (size_t)nm * 4), o_ch = al(o_ord + (size_t)ng * 4), o_st = al(o_ch + (size_t)nc * 8), o_sp = al(o_st + (size_t)n_slow * 4),
-                     total = al(o_sp + (size_t)n_slow * 4);
+                     o_wch = al(o_sp + (size_t)n_slow * 4), total = al(o_wch + (size_t)nw * 8);
         HIPCHECK(e, b->hx_pack.reserve(total));
         HIPCHECK(e, b->d_xpack.reserve(total));
         char* hp = static_cast<char*>(b->hx_pack.p);
@@ -1088,9 +1090,10 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
         uint32_t *xpos = reinterpret_cast<uint32_t*>(hp + o_pos), *xtask = reinterpret_cast<uint32_t*>(hp + o_task), *mr = reinterpret_cast<uint32_t*>(hp + o_mr),
                  *gorder = reinterpret_cast<uint32_t*>(hp + o_ord), *slow_task = reinterpret_cast<uint32_t*>(hp + o_st), *slow_pos = reinterpret_cast<uint32_t*>(hp + o_sp);
         uint2* chunks = reinterpret_cast<uint2*>(hp + o_ch);
+        uint2* wchunks = reinterpret_cast<uint2*>(hp + o_wch);
         if (n_fast) {
             compact.assign(NG, NONE);
-            uint32_t off = 0, gi = 0, mi = 0;
+            uint32_t off = 0, gi = 0, mi = 0, wi = 0;
             for (uint32_t g = 0; g < NG; ++g) {
                 const uint32_t cnt = fill[g];
                 if (!cnt) continue;
@@ -1100,6 +1103,7 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
                 x.doff = off + gi;   // cnt + 1 difference slots per group
                 if (x.flags & XG_MAXREP) mr[mi++] = gi;
                 groups[gi] = x;
+                for (uint32_t s0 = 0; s0 < cnt; s0 += XG_WCH) wchunks[wi++] = make_uint2(gi, s0);
                 compact[g] = gi++;
                 fill[g] = off;
                 off += cnt;
@@ -1173,6 +1177,7 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
             ga.ent_scpu = xa.ent_scpu;
             ga.ent_smem = xa.ent_smem;
             ga.mr = reinterpret_cast<const uint32_t*>(dp + o_mr);
+            ga.wchunks = reinterpret_cast<const uint2*>(dp + o_wch);
             ga.diff = b->d_xdiff.as<int32_t>();
             ga.notready = b->d_xnr.as<uint32_t>();
             ga.hist = xa.hist;
@@ -1189,11 +1194,7 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
                 gc.mr += m0;
                 hipLaunchKernelGGL(k_xg_maxrep, dim3(8, std::min<uint32_t>(GY, nm - m0)), dim3(256), 0, st, gc);
             }
-            for (uint32_t g0 = 0; g0 < ng; g0 += GY) {
-                XGArgs gc = ga;
-                gc.g += g0;
-                hipLaunchKernelGGL(k_xg_write, dim3(std::min<uint32_t>(GY, ng - g0)), dim3(256), 0, st, gc);
-            }
+            hipLaunchKernelGGL(k_xg_write, dim3(nw), dim3(256), 0, st, ga);
         }
         if (n_slow) {
             xa.inf_task = reinterpret_cast<const uint32_t*>(dp + o_st);
