@@ -483,6 +483,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     elapsed = ranks.max_over_ranks(elapsed)
+    launches1 = eng.stats()["resolve_launches"]   # (before the end-to-end runs below add theirs)
 
     # end to end, outside the timed region: what a caller of swp_schedule_batch waits for — de-duplication of the predicate
     # sets + H2D of the descriptors (swp_batch_prepare), the device pass, D2H of placements AND explanation histograms
@@ -511,7 +512,7 @@ def main():
     # k_resolve5's exact mode, which needs no scan window)
     kernel = RESOLVER_NAMES.get(int(st.get("last_resolver", 105)), "k_resolve5")
     if kernel.startswith("k_resolve6"):   # the block resolver: a "launch" is one round (two kernel launches), decided tasks per round vary
-        windows = max((st["resolve_launches"] - launches0) / 2.0 / K, 1.0)
+        windows = max((launches1 - launches0) / 2.0 / K, 1.0)
     res_launch_ms = ms_resolve / K / windows
     alg_bytes_launch = alg_bytes_step / windows
     achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0

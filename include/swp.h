@@ -342,7 +342,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
 
 /* The rank variant: ONE engine per process / GPU, the ranks of a job connected by RCCL over xGMI (librccl.so is loaded on first use;
  * the engine links nothing of it). The rounds are the same kernels — every rank proposes over its own node range, an
- * ncclAllGather on the engine's stream hands every rank the proposals of all of them (block x 160 bytes per rank and round), and
+ * ncclAllGather on the engine's stream hands every rank the proposals of all of them (block x 288 bytes per rank and round), and
  * EVERY rank folds + matches the block (the same deterministic wave everywhere: no second collective to agree on the picks) and
  * applies the picks of its own range. Bootstrap as usual with RCCL: rank 0 fills an id (swp_rccl_unique_id), the application
  * hands it to the other ranks over whatever it has (the Go manager's raft / gRPC; bench.py: torch.distributed), every rank calls
