@@ -609,9 +609,20 @@ class Scheduler {
             auto n = nodes_.find(as_str(t.get("NodeID")));
             if (n == nodes_.end()) continue;   // node not (yet) known: the task stays pending, :651-656
             Value newT = t.shallow_copy();
-            const swp_task_desc d = taskDesc(t);
             int32_t ff = -1;
-            ck(swp_check_node(e_, &d, n->second.idx, &ff), "swp_check_node");
+            try {
+                const swp_task_desc d = taskDesc(t);
+                ck(swp_check_node(e_, &d, n->second.idx, &ff), "swp_check_node");
+            } catch (const Fail& f) {   // the engine cannot judge this task: it stays pending, the loop carries on
+                last_error = f.msg;
+                Value dd = decision(t, t);
+                const bool from_engine = !engine_detail_.empty() && f.msg.size() >= engine_detail_.size() &&
+                                         f.msg.compare(f.msg.size() - engine_detail_.size(), engine_detail_.size(), engine_detail_) == 0;
+                dd.set("Err", Value::str("swp: deferred to the host scheduler: " + (from_engine ? engine_detail_ : f.msg)));
+                dd.set("Deferred", Value::boolean(true));
+                decisions.push(dd);
+                continue;
+            }
             if (ff >= 0) {
                 uint32_t hist[SWP_NFILTERS] = {0};
                 hist[ff] = 1;
@@ -655,6 +666,26 @@ class Scheduler {
             for (const Item& it : queue) defer(it.first, it.second, f, decisions);
             return decisions;
         }
+        // Whatever else fails below (every device call has its own handler; this is for the ones nobody thought of): the tasks without
+        // a decision line go back on the queue and the decisions made so far are still returned — they are applied to allTasks_ and
+        // the node rows already.
+        std::vector<std::string> ids;
+        for (const Item& it : queue) ids.push_back(it.first);
+        try {
+            scheduleQueue(queue, decisions);
+        } catch (const Fail& f) {
+            std::set<std::string> have;
+            for (const Value& d : *decisions.a) have.insert(as_str(d.get("ID")));
+            for (const std::string& id : ids) {
+                if (have.count(id)) continue;
+                auto t = allTasks_.find(id);
+                if (t != allTasks_.end()) defer(id, t->second, f, decisions);
+            }
+        }
+        return decisions;
+    }
+    void scheduleQueue(std::vector<std::pair<std::string, Value>>& queue, Value& decisions) {
+        using Item = std::pair<std::string, Value>;
         std::vector<std::vector<Item>> groups;
         std::map<FailureKey, size_t> group_of;
         std::vector<Item> one_off;
@@ -694,7 +725,6 @@ class Scheduler {
             }
         }
         runOneOffs(run, run_descs, decisions);
-        return decisions;
     }
 
     // The failed half of applySchedulingDecisions (scheduler.go:472-487 for tick, :416-425 for preassigned tasks): the store
@@ -1245,7 +1275,13 @@ class Scheduler {
             runGroups(groups, from, cut, decisions);
             std::set<std::string> sids;
             for (size_t i = cut; i < to; ++i) sids.insert(as_str(groups[i][0].second.get("ServiceID")));
-            pushFailures(sids);
+            try {
+                pushFailures(sids);
+            } catch (const Fail& f) {   // the counts of the other spec version did not reach the engine: those groups wait for the next tick
+                for (size_t i = cut; i < to; ++i)
+                    for (const Item& it : groups[i]) defer(it.first, it.second, f, decisions);
+                return;
+            }
             runGroups(groups, cut, to, decisions);
             return;
         }

@@ -620,7 +620,15 @@ class PyHostScheduler:
             if ent is None:
                 continue
             new_t = dict(t)
-            ff = self.e.check_node(self.task_desc(t), ent["idx"])
+            try:
+                ff = self.e.check_node(self.task_desc(t), ent["idx"])
+            except (abi.SwpError, abi.Unsupported) as err:   # the engine cannot judge this task: it stays pending, the loop carries on
+                self.last_error = str(err)
+                d = self._decision(t, t)
+                d["Err"] = "swp: deferred to the host scheduler: " + self._err_text(err)
+                d["Deferred"] = True
+                decisions.append(d)
+                continue
             if ff >= 0:
                 hist = [0] * abi.NFILTERS
                 hist[ff] = 1
@@ -760,7 +768,13 @@ class PyHostScheduler:
                 break
         if cut is not None:
             self._run_groups(groups[:cut], decisions)
-            self._push_failures({g[0][1].get("ServiceID", "") for g in groups[cut:]})
+            try:
+                self._push_failures({g[0][1].get("ServiceID", "") for g in groups[cut:]})
+            except (abi.SwpError, abi.Unsupported) as err:   # the other spec version's counts did not reach the engine: those groups wait
+                for g in groups[cut:]:
+                    for tid, t in g:
+                        self._defer(tid, t, err, decisions)
+                return
             self._run_groups(groups[cut:], decisions)
             return
         descs = []
@@ -827,6 +841,18 @@ class PyHostScheduler:
             for tid, t in queue:
                 self._defer(tid, t, err, decisions)
             return decisions
+        # whatever else fails below (every device call has its own handler): the tasks without a decision line go back on the queue and
+        # the decisions made so far are still returned — they are applied to all_tasks and the node rows already
+        try:
+            self._schedule_queue(queue, decisions)
+        except (abi.SwpError, abi.Unsupported) as err:
+            have = {d["ID"] for d in decisions}
+            for tid, _ in queue:
+                if tid not in have and tid in self.all_tasks:
+                    self._defer(tid, self.all_tasks[tid], err, decisions)
+        return decisions
+
+    def _schedule_queue(self, queue, decisions):
         grouped, one_off = {}, []
         for tid, t in queue:
             if t.get("SpecVersion") is not None:
@@ -849,7 +875,6 @@ class PyHostScheduler:
             else:
                 run.append((tid, t, d))
         self._run_one_offs(run, decisions)
-        return decisions
 
 
 def HostScheduler(engine=None, **engine_kw):

@@ -350,6 +350,11 @@ int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add) {
 }
 int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int32_t* first_fail) {
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    if (e->name(SWP_SPACE_SERVICE, task->service).rfind("boom", 0) == 0) {   // (failure injection, as in swp_schedule_batch)
+        e->err = "fake: check refused";
+        e->say("check_node refused");
+        return SWP_ERANGE;
+    }
     const uint32_t r = e->next();
     *first_fail = (r % 3u == 0u) ? (int32_t)((r >> 4) % SWP_NFILTERS) : -1;
     e->say("check_node %s %s -> %d", e->name(SWP_SPACE_NODE_ID, node).c_str(), e->desc(*task).c_str(), *first_fail);

@@ -375,6 +375,27 @@ def test_tick_survives_a_refused_device_call():
     assert logs[0][0] == logs[1][0] and logs[0][1] == logs[1][1] and logs[0][2] == logs[1][2]   # the twins agree call by call
 
 
+def test_preassigned_loop_survives_a_refused_check():
+    """a throwing swp_check_node in processPreassignedTasks aborted the loop and lost the decisions made so far. The
+    refused task stays pending with a Deferred decision line, the others are confirmed."""
+    logs = []
+    for s in _both_hosts():
+        s.create_node({"ID": "n0", "Status": {"State": 2}, "Spec": {"Availability": 0}})
+        for sid in ("ok", "boom-pre"):
+            s.set_service(sid)
+        for tid, sid in (("p1", "ok"), ("pb", "boom-pre"), ("p2", "ok")):
+            s.create_task(_task(tid, sid, NodeID="n0"))
+        d1 = s.process_preassigned()
+        by = {d["ID"]: d for d in d1}
+        assert set(by) == {"p1", "pb", "p2"}
+        assert by["pb"].get("Deferred") is True and "refused" in by["pb"]["Err"]
+        assert not by["p1"].get("Deferred") and not by["p2"].get("Deferred")
+        d2 = s.process_preassigned()       # still pending: tried again
+        assert "pb" in {d["ID"] for d in d2}
+        logs.append((d1, d2, fakelib.take_log(s.e)))
+    assert logs[0] == logs[1]
+
+
 def test_failure_buckets_are_reset_when_cleanup_erases_them():
     """after cleanupFailures (nodeinfo.go:163-183) erased a (service, version) bucket the engine kept the old count
     (>= 5 down-ranks the node for ever). The next tick of that service must push 0."""
