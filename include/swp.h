@@ -46,7 +46,7 @@ typedef struct swp_engine swp_engine;
 /* configuration                                                                               */
 typedef struct {
     int32_t  device;        /* HIP device ordinal */
-    uint32_t window;        /* tasks per scan window; 0 = auto (about N/2, clamped) */
+    uint32_t window;        /* unused since round 3 (the scan mode and its windows are gone); kept for the struct layout, pass 0 */
     uint32_t resolver_threads; /* 0 = auto (256 or 1024 by node count) */
     uint32_t flags;         /* SWP_CFG_* */
     /* node-range shard owned by this engine for the sharded scan; [0,0) = all */

@@ -1,29 +1,32 @@
 // swp_resolve6.hpp — the BLOCK resolver: the sequential argmin + commit pass of the tick (nodeSet.tree with a heap of one,
-// nodeset.go:50-124; nodeLess, scheduler.go:708-735; NodeInfo.addTask, nodeinfo.go:108-154) for node sets that do not fit
-// one workgroup's LDS (k_resolve5: ≈ 12 000 nodes). The whole chip builds the candidate lists, one wave matches them.
+// nodeset.go:50-124; nodeLess, scheduler.go:708-735; NodeInfo.addTask, nodeinfo.go:108-154). The whole chip builds the candidate
+// lists, one wave matches them. The engine's default from 16 384 tasks on and for every node set beyond k_resolve5's LDS.
 //
 // State in global memory (L2-resident), all of it bitmaps over the node words, kept exact by every commit:
 //   planes[b]   bit b of (ActiveTasksCount − base) per node, base = the lowest count among the valid nodes at build time
-//   rr[c]       ResourceFilter (filter.go:77-84) as set membership, as in k_resolve5's exact mode: nodes whose residual
-//               cpu (rows 0..n_dc−1) / memory (rows n_dc..) is >= the row's threshold; thresholds = the batch's distinct reservations
+//   rr[c]       ResourceFilter (filter.go:77-84) as set membership: nodes whose residual cpu (rows 0..n_dc−1) / memory (rows n_dc..)
+//               is >= the row's threshold; thresholds = the batch's distinct reservations. In TASK-ROWS mode (a batch with more
+//               than 128 of them) the rows are built per task of the coming block instead (k_r6_taskrows): no limit.
+//   rg[r]       generic reservations (filter.go:86-91): nodes whose count of the row's kind is >= the row's value
 //   sc, X, portmap   static class rows, per-service exception bitmaps, host ports: the rows every resolver uses
 //
 // One ROUND decides a block of up to `block` tasks, two launches:
-//   k_r6_propose   one workgroup of four wavefronts per task, lanes over the node WORDS: m = sc & ~X & RC & RM & ~ports (the task's plain
-//                  candidates, 64 nodes per operation), then a descent over the level planes from the top
-//                  (m & ~plane ≠ ∅ ? keep that : the bit is set in the minimum) leaves exactly the candidates of the
-//                  minimum level; the first R6_CAND non-empty words of it go into the task's proposal, with the best node
-//                  of the service's exception list by the full key when there is no plain candidate (the record of the
-//                  node-range shard protocol, include/swp.h swp_proposal, with more candidate words).
-//   k_r6_commit    one workgroup. Wave 0 walks the block in task order, 64 proposals in registers at a time, with k_resolve5's
-//                  matcher (swp_wave.hpp match_run64: the lists as 32-node half-words, one scalar loop iteration per task): a
-//                  task takes the first listed node nobody before it took, the node is struck from every later list (a taken
-//                  node moved up a level). The block is CUT — committed up to there, proposed again from there — in front of a task whose
-//                  listed nodes are all taken, around a task that must use its exception list (its order moves with every
-//                  placement of the service) and behind an uncounted task (its node did NOT move up). Then all threads apply
-//                  the accepted picks: NodeInfo.addTask on the node rows + the bitmaps above + commit log.
-// The exactness argument is k_resolve5's list rule: inside a batch levels only grow and feasibility only shrinks, and a list
-// holds ALL plain candidates of the task's minimum level in node order up to its last word.
+//   k_r6_propose   one workgroup of eight wavefronts per task, lanes over the node WORDS: m = sc & ~X & RC & RM & RG & ~ports (the
+//                  task's plain candidates, 64 nodes per operation); the level planes of a lane's words are requested together and
+//                  the candidates are narrowed from the top plane down IN REGISTERS (m & ~plane ≠ ∅ ? keep that : the bit is set in
+//                  the word's minimum level); one reduction gives the task's minimum level, the words whose own minimum equals it
+//                  hold exactly its candidates. The first 2 * R6_CAND non-empty half-words go into the task's proposal, with the
+//                  best node of the service's exception list by the full key when there is no plain candidate.
+//   k_r6_commit    one workgroup of 1 024. Every thread stages its task's list into LDS (entry-major). Wave 0 walks the block in
+//                  task order, 64 tasks at a time: a lane seats the first two half-words of its list that still have a candidate
+//                  (cursor: an entry is looked at once) and wv::match_seq64 gives every task in turn the first listed node nobody
+//                  before it took, struck from every later list. The block is CUT — committed up to there, proposed again from
+//                  there — in front of a task whose listed nodes are all taken, around a task that must use its exception list
+//                  (its order moves with every placement of the service) and behind an uncounted task (its node did NOT move
+//                  up). Waves 1..15 move the cursors of "their" group over dead entries while they wait, then apply the group's
+//                  picks: NodeInfo.addTask on the node rows + the bitmaps above + commit log.
+// The exactness argument is the list rule: inside a batch levels only grow and feasibility only shrinks, and a list
+// holds ALL plain candidates of the task's minimum level in node order up to its last half-word.
 //
 // Written against swp_wave.hpp only, so tests/emu runs the same source on CPU fibers (tests/test_emu_resolve6.py).
 #pragma once

@@ -110,55 +110,10 @@ WV_DEV T uload(const T* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
 }
 
-// The matcher's inner loop (swp_resolve5.hpp), hand-scheduled: the serial chain of the whole engine.
-//   `todo`  scalar mask of the lanes still to be served, in lane order
-//   `bits`  per lane: candidate bits of its current 32-node half-word `w`;  `pick` per lane: node taken (output)
-// while todo: i = lowest lane of todo; if lane i's bits are empty: stop and return i (todo keeps bit i);
-//             else lane i takes its lowest bit (pick[i] = w[i] * 32 + bit), the bit is struck from EVERY lane that sits on
-//             the same half-word, and i leaves todo.            Returns 0xFFFFFFFF when todo ran empty.
-// m0 (the lane select of v_writelane: two SGPR operands exceed the constant bus) is clobbered, not saved: the compiler uses m0
-// nowhere in these kernels (checked in the ISA), and carrying a save register through the asm cost 1.2 % of the batch.
-// 17 instructions per task; the dependent chain is v_bfi → v_readlane → s_ff1 → s_lshl → v_bfi. The wave must enter with all
-// 64 lanes active (exec is all ones afterwards). SALU-written lane selects need no wait states on gfx9 (only VALU-written
-// ones do), which is why the lane index is computed on the scalar unit.
-WV_DEV u32 match_run64(u64& todo_io, u32& bits, u32 w, u32& pick) {
-    // uniform values the compiler may keep in vector registers: the asm needs them on the scalar side
-    u64 todo = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(todo_io >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)todo_io);
-    u32 si, sb, sw, sp, sn, sm;
-    asm volatile(
-        "s_setprio 3\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_cmp_eq_u64 %[todo], 0\n\t"
-        "s_cbranch_scc1 3f\n"
-        "1:\n\t"
-        "s_ff1_i32_b64 %[si], %[todo]\n\t"
-        "v_readlane_b32 %[sb], %[bits], %[si]\n\t"
-        "v_readlane_b32 %[sw], %[w], %[si]\n\t"
-        "s_cmp_eq_u32 %[sb], 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "s_bitset0_b64 %[todo], %[si]\n\t"
-        "s_ff1_i32_b32 %[sp], %[sb]\n\t"
-        "s_lshl_b32 %[sn], %[sw], 5\n\t"
-        "s_lshl_b32 %[sm], 1, %[sp]\n\t"
-        "s_or_b32 %[sn], %[sn], %[sp]\n\t"
-        "v_cmpx_eq_u32_e32 vcc, %[sw], %[w]\n\t"
-        "v_bfi_b32 %[bits], %[sm], 0, %[bits]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_mov_b32 m0, %[si]\n\t"
-        "v_writelane_b32 %[pick], %[sn], m0\n\t"
-        "s_cmp_lg_u64 %[todo], 0\n\t"
-        "s_cbranch_scc1 1b\n"
-        "3:\n\t"
-        "s_setprio 0\n\t"
-        : [todo] "+s"(todo), [bits] "+v"(bits), [pick] "+v"(pick), [si] "=&s"(si), [sb] "=&s"(sb), [sw] "=&s"(sw), [sp] "=&s"(sp), [sn] "=&s"(sn),
-          [sm] "=&s"(sm)
-        : [w] "v"(w)
-        : "vcc", "scc", "m0", "memory");
-    todo_io = todo;
-    return todo ? (u32)__builtin_ctzll(todo) : 0xFFFFFFFFu;
-}
-
-// The same chain with the loop unrolled over the 64 lanes (round 3): lane indices are immediates, so the scalar side no longer
+// The matcher's walk (swp_resolve5.hpp, swp_resolve6.hpp, swp_resolve7.hpp), hand-scheduled: the serial chain of the whole engine.
+// Round 2's version was a scalar loop of 17 instructions per task over a mask of lanes still to serve (s_ff1 for the next lane, m0 as
+// the lane select of v_writelane); this one is unrolled over the 64 lanes.
+// Lane indices are immediates, so the scalar side no longer
 // finds the next lane (s_ff1 on a todo mask), clears it, moves it to m0 or branches back, and a lane carries TWO half-words — the
 // current one (bits, w) and the next of its list (bits2, w2), both struck by every pick — so that a lane whose current half-word
 // ran empty steps to the next one inside the walk (11 instructions, no LDS, no exit). 13 instructions per task, no exec-mask

@@ -309,21 +309,7 @@ inline void keep(u32) {}
 template <class T>
 inline T uload(const T* p) { return *p; }
 
-// reference semantics of the hand-scheduled matcher loop of swp_wave.hpp, on the collectives above
-inline u32 match_run64(u64& todo, u32& bits, u32 w, u32& pick) {
-    while (todo) {
-        const u32 l = (u32)__builtin_ctzll(todo);
-        const u32 sb = readlane(bits, l), sw = readlane(w, l);
-        if (sb == 0) return l;
-        todo &= todo - 1;
-        const u32 p = (u32)__builtin_ctz(sb);
-        if (lane() == l) pick = sw * 32 + p;
-        if (w == sw) bits &= ~(1u << p);
-    }
-    return 0xFFFFFFFFu;
-}
-
-// ... and of its unrolled successor: every lane in [from, 64) in order; a lane whose current half-word is empty steps to its next one
+// reference semantics of the hand-scheduled matcher walk of swp_wave.hpp, on the collectives above: every lane in [from, 64) in order; a lane whose current half-word is empty steps to its next one
 // (together with every later lane in the same state); stop in front of the first lane that has no candidate in either
 #define WV_DUMMY_W 0x80000000u
 inline u32 match_seq64(u32& bits, u32& w, u32& bits2, u32 w2, u32& pickb, u32 lid, u32 from) {
