@@ -124,11 +124,24 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
     for e in engines:
         e.state_save()
 
-    device_rounds = not args.host_merge   # the rounds stay on the device: swp_shard_run (one process) / swp_shard_run_rank (RCCL between ranks)
+    device_rounds = not args.host_merge and os.environ.get("SWP_SHARD_EXCHANGE") != "host"   # the rounds stay on the device: swp_shard_run (one process) / swp_shard_run_rank (RCCL between ranks)
+
+    state = {"host_merge": bool(args.host_merge) or os.environ.get("SWP_SHARD_EXCHANGE") == "host"}
 
     def make_driver():
-        if world > 1 and not args.host_merge:   # rounds on the device, an ncclAllGather of the block's proposals per round (swp_shard_run_rank)
-            return swshard.DeviceRankShard(batches[0], rank, world, ranges, dist, ranks.device, fold=False)
+        if world > 1 and not state["host_merge"]:   # rounds on the device, an ncclAllGather of the block's proposals per round (swp_shard_run_rank)
+            drv, err = None, None
+            try:
+                drv = swshard.DeviceRankShard(batches[0], rank, world, ranges, dist, ranks.device, fold=False)
+            except Exception as exc:   # librccl not loadable, communicator refused, ...: every rank must take the same way out
+                err = exc
+            ok = torch.tensor([0 if drv is None else 1], device=ranks.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                return drv
+            state["host_merge"] = True
+            if rank == 0:
+                print("bench: RCCL inside libswp.so is not usable here (%s): the proposals are exchanged through torch.distributed and merged on the host" % (err,), file=sys.stderr)
         if world > 1:
             return swshard.RankShard(batches[0], rank, world, firsts, dist, ranks.device)   # cuda:<local rank> under RCCL, cpu if it fell back to gloo
         return swshard.DeviceShardGroup(batches, firsts, fold=False) if device_rounds else swshard.ShardGroup(batches, firsts)
@@ -160,6 +173,7 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
         n_ptasks += st["propose_tasks"]
     sync()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    device_rounds = device_rounds and not state["host_merge"]   # (what really ran: the labels below follow it)
     K = max(args.steps, 1)
     t_step = elapsed / K
     placed = int((out >= 0).sum())
