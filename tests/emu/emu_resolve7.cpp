@@ -1,0 +1,268 @@
+// emu_resolve7.cpp — runs the node-range shard kernels (swarmkit_amd/csrc/swp_resolve7.hpp: per-shard k_r6_propose, k_r7_fold,
+// k_r7_match, per-shard k_r7_apply) on CPU fibers (wv_emu.hpp) over a random problem whose node set is split into G contiguous
+// ranges, and compares the placements (shard-local node + the range's first node), the node rows of every shard and the counters
+// with the sequential model of emu_model.hpp run over the WHOLE node set. What a job of G GPUs computes, without a GPU.
+// TEST INFRASTRUCTURE (tests/test_emu_resolve7.py); not product.
+//
+//   emu_resolve7 <seed> <N> <T> <S> <block> <order: 0 rr | 1 major | 2 random> <features 0..2> <shards> [v] [t: task rows]
+#include "wv_emu.hpp"
+
+#define SWP_R6_KERNELS
+#include "../../swarmkit_amd/csrc/swp_resolve6.hpp"
+#include "../../swarmkit_amd/csrc/swp_resolve7.hpp"
+
+#include "emu_model.hpp"
+
+template <class F>
+static void grid(u32 blocks, u32 threads, size_t lds, F body) {
+    for (u32 b = 0; b < blocks; ++b) {
+        emu::blockidx() = b;
+        emu::launch(threads, lds, body);
+    }
+    emu::blockidx() = 0;
+}
+
+// rows of `src` ([rows][Wn of the whole set]) restricted to nodes [first, first + cnt), re-packed from bit 0
+static std::vector<u64> slice_rows(const std::vector<u64>& src, u32 rows, u32 WnAll, u32 first, u32 cnt) {
+    const u32 Wn = (cnt + 63) / 64;
+    std::vector<u64> out((size_t)rows * Wn, 0);
+    for (u32 r = 0; r < rows; ++r)
+        for (u32 i = 0; i < cnt; ++i) {
+            const u32 n = first + i;
+            if ((src[(size_t)r * WnAll + (n >> 6)] >> (n & 63)) & 1) out[(size_t)r * Wn + (i >> 6)] |= 1ull << (i & 63);
+        }
+    return out;
+}
+
+// the part of the problem one shard holds: its nodes re-indexed from 0, the whole task list, per-service exception lists with the
+// entries of its own nodes (and a free slot per task, as every engine reserves them)
+static Problem shard_of(const Problem& p, u32 first, u32 cnt) {
+    Problem q;
+    q.N = cnt;
+    q.Wn = (cnt + 63) / 64;
+    q.T = p.T;
+    q.S = p.S;
+    q.n_sc = p.n_sc;
+    q.n_ports = p.n_ports;
+    q.UC = p.UC;
+    q.UM = p.UM;
+    q.valid = slice_rows(p.valid, 1, p.Wn, first, cnt);
+    q.cpu.assign(p.cpu.begin() + first, p.cpu.begin() + first + cnt);
+    q.mem.assign(p.mem.begin() + first, p.mem.begin() + first + cnt);
+    q.total.assign(p.total.begin() + first, p.total.begin() + first + cnt);
+    q.sc = slice_rows(p.sc, p.n_sc, p.Wn, first, cnt);
+    q.X = slice_rows(p.X, p.S, p.Wn, first, cnt);
+    q.portmap = slice_rows(p.portmap, p.n_ports, p.Wn, first, cnt);
+    q.pset_off = p.pset_off;
+    q.pset_ids = p.pset_ids;
+    q.rt = p.rt;
+    std::vector<u32> ntasks(p.S, 0), rank(p.T), init_cnt(p.S, 0);
+    for (u32 j = 0; j < p.T; ++j) rank[j] = ntasks[p.rt[j].svc]++;
+    q.list_off.assign(p.S + 1, 0);
+    for (u32 s = 0; s < p.S; ++s) {
+        q.list_off[s] = (u32)q.list_node.size();
+        for (u32 e = p.list_off[s]; e < p.list_off[s + 1]; ++e) {
+            const u32 n = p.list_node[e];
+            if (n == LIST_EMPTY || n < first || n >= first + cnt) continue;
+            q.list_node.push_back(n - first);
+            q.list_svc.push_back(p.list_svc[e]);
+            q.list_fail.push_back(p.list_fail[e]);
+        }
+        init_cnt[s] = (u32)q.list_node.size() - q.list_off[s];
+        for (u32 i = 0; i < ntasks[s]; ++i) {
+            q.list_node.push_back(LIST_EMPTY);
+            q.list_svc.push_back(0);
+            q.list_fail.push_back(0);
+        }
+    }
+    q.list_off[p.S] = (u32)q.list_node.size();
+    for (u32 j = 0; j < p.T; ++j) q.rt[j].slot = q.list_off[q.rt[j].svc] + init_cnt[q.rt[j].svc] + rank[j];
+    return q;
+}
+
+struct Shard {
+    Problem p;
+    State em;
+    std::vector<u64> planes, rr, trows;
+    std::vector<R6Prop> prop;
+    Blk6 blk{};
+    u32 first = 0;
+};
+
+int main(int argc, char** argv) {
+    if (argc < 9) { fprintf(stderr, "usage: %s seed N T S block order features(0..2) shards [v] [t]\n", argv[0]); return 2; }
+    const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
+    const int order = atoi(argv[6]), feat = std::min(atoi(argv[7]), 2);
+    const u32 G = atoi(argv[8]);
+    bool verbose = false, task_rows = false;
+    for (int i = 9; i < argc; ++i) {
+        if (argv[i][0] == 'v') verbose = true;
+        if (argv[i][0] == 't') task_rows = true;
+    }
+    if (G < 1 || G > R7_MAXS || G > N) { fprintf(stderr, "1..%d shards, at most one per node\n", R7_MAXS); return 2; }
+    Problem p = make_problem(seed, N, T, S, order, feat);
+    std::set<i64> sc, sm;
+    for (const RTask& r : p.rt)
+        if (r.flags & RT_RES) { sc.insert(r.cpu); sm.insert(r.mem); }
+    std::vector<i64> thr;
+    std::map<i64, u32> ic, im;
+    for (i64 v : sc) { ic[v] = (u32)thr.size(); thr.push_back(v); }
+    u32 n_dc = (u32)sc.size();
+    for (i64 v : sm) { im[v] = (u32)thr.size() - n_dc; thr.push_back(v); }
+    u32 n_dm = (u32)sm.size();
+    for (RTask& r : p.rt)
+        if (r.flags & RT_RES) r.flags |= (ic[r.cpu] << RT_DC_SHIFT) | (im[r.mem] << RT_DM_SHIFT);
+    if (task_rows) n_dc = n_dm = 0;
+
+    State ref = initial_state(p);
+    std::vector<u64> F;
+    scan_window(p, ref, 0, T, F);
+    ref_window(p, ref, 0, T, F);
+
+    // contiguous ranges of the canonical order, sizes differing by at most one
+    std::vector<Shard> sh(G);
+    std::vector<R6Args> args(G);
+    u32 first = 0, max_words = 0;
+    for (u32 g = 0; g < G; ++g) {
+        const u32 cnt = N / G + (g < N % G ? 1u : 0u);
+        Shard& s = sh[g];
+        s.first = first;
+        s.p = shard_of(p, first, cnt);
+        s.em = initial_state(s.p);
+        s.planes.assign((size_t)R6_NP * s.p.Wn, 0xAAAAAAAAAAAAAAAAull);
+        s.rr.assign((size_t)std::max<u32>(n_dc + n_dm, 1) * s.p.Wn, 0x5555555555555555ull);
+        s.trows.assign((size_t)B * s.p.Wn, 0x7777777777777777ull);
+        s.prop.resize(B);
+        max_words = std::max(max_words, s.p.Wn);
+        first += cnt;
+    }
+    for (u32 g = 0; g < G; ++g) {   // (pointers into the shards: taken once the vector of shards no longer moves)
+        Shard& s = sh[g];
+        R6Args& a = args[g];
+        a = R6Args{};
+        a.n_nodes = s.p.N;
+        a.n_words = s.p.Wn;
+        a.xs = s.p.Wn;
+        a.block = B;
+        a.n_dc = n_dc;
+        a.n_dm = n_dm;
+        a.task_rows = task_rows ? 1u : 0u;
+        a.trows = s.trows.data();
+        a.valid = s.p.valid.data();
+        a.sc = s.p.sc.data();
+        a.X = s.em.X.data();
+        a.rt = s.p.rt.data();
+        a.cpu = s.em.cpu.data();
+        a.mem = s.em.mem.data();
+        a.total = s.em.total.data();
+        a.list_node = s.em.list_node.data();
+        a.list_svc = s.em.list_svc.data();
+        a.list_fail = s.em.list_fail.data();
+        a.list_off = s.p.list_off.data();
+        a.portmap = s.em.portmap.data();
+        a.pset_off = s.p.pset_off.data();
+        a.pset_ids = s.p.pset_ids.data();
+        a.out_node = s.em.out.data();
+        a.log_node = s.em.log_node.data();
+        a.log_task = s.em.log_task.data();
+        a.log_prev = s.em.log_prev.data();
+        a.last = s.em.last.data();
+        a.inf_task = s.em.inf_task.data();
+        a.inf_pos = s.em.inf_pos.data();
+        a.ctl = &s.em.ctl;
+        a.planes = s.planes.data();
+        a.rr = s.rr.data();
+        a.thr = thr.data();
+        a.blk = &s.blk;
+        a.prop = s.prop.data();
+    }
+    std::vector<R6Prop> merged(B);
+    std::vector<R7Pick> picks(B);
+    R7Head head{};
+    R7Args ma{};
+    ma.n_shards = G;
+    ma.block = B;
+    u32 hw = 0;
+    for (u32 g = 0; g < G; ++g) {
+        ma.hw_base[g] = hw;
+        ma.first_node[g] = sh[g].first;
+        hw += (sh[g].p.N + 31) / 32;
+        ma.prop[g] = sh[g].prop.data();
+    }
+    ma.hw_base[G] = ma.hw_total = hw;
+    ma.merged = merged.data();
+    ma.blk = &sh[0].blk;
+    ma.ctl = &sh[0].em.ctl;
+    ma.picks = picks.data();
+    ma.head = &head;
+
+    for (u32 g = 0; g < G; ++g) {   // build: base / highest level, planes and rows per shard
+        const R6Args a = args[g];
+        grid(1, 1024, 256, [a]() { k_r6_minmax(a); });
+        grid((a.n_words + 3) / 4, 256, 0, [a]() { k_r6_rows(a); });
+        if (sh[g].blk.error) { fprintf(stderr, "build of shard %u reported error %u\n", g, sh[g].blk.error); return 3; }
+        sh[g].blk.pos = 0;
+        sh[g].blk.end = T;
+    }
+    const R6Args* ap = args.data();
+    u64 rounds = 0;
+    auto round = [&]() {
+        for (u32 g = 0; g < G; ++g) {
+            for (R6Prop& q : sh[g].prop) memset(&q, 0xEE, sizeof q);
+            emu::blockidx_y() = g;
+            if (task_rows) grid((max_words + 3) / 4, 256, (size_t)B * 16, [ap]() { k_r7_taskrows(ap); });
+            grid(B, 64 * R6_PW, r6_propose_lds(max_words), [ap]() { k_r7_propose(ap); });
+        }
+        emu::blockidx_y() = 0;
+        grid((B + 63) / 64, 64, 0, [ma]() { k_r7_fold(ma); });
+        grid(1, 64, r7_match_lds(ma.hw_total), [ma]() { k_r7_match(ma); });
+        const R7Pick* pk = picks.data();
+        const R7Head* hd = &head;
+        grid(G, R6_COMMIT_THREADS, 0, [ap, pk, hd]() { k_r7_apply(ap, pk, hd, 0u); });
+    };
+    while (sh[0].blk.pos < T) {
+        const u32 before = sh[0].blk.pos;
+        round();
+        ++rounds;
+        for (u32 g = 0; g < G; ++g) {
+            if (sh[g].blk.error) { fprintf(stderr, "shard %u reported error %u at task %u\n", g, sh[g].blk.error, sh[g].blk.pos); return 3; }
+            if (sh[g].blk.pos != sh[0].blk.pos) { fprintf(stderr, "shard %u is at task %u, the leader at %u\n", g, sh[g].blk.pos, sh[0].blk.pos); return 3; }
+        }
+        if (sh[0].blk.pos <= before) { fprintf(stderr, "no progress at task %u\n", before); return 3; }
+    }
+    round();   // a round past the end must be a no-op
+    if (sh[0].blk.pos != T) return 3;
+
+    bool ok = true;
+    std::vector<int32_t> out(T, -1);
+    for (u32 g = 0; g < G && ok; ++g)
+        for (u32 j = 0; j < T; ++j) {
+            const int32_t n = sh[g].em.out[j];
+            if (n < 0) continue;
+            if (out[j] >= 0) { fprintf(stderr, "task %u placed on two shards\n", j); ok = false; break; }
+            out[j] = (int32_t)sh[g].first + n;
+        }
+    ok = ok && same("out", out, ref.out, T);
+    for (u32 g = 0; g < G && ok; ++g) {
+        const Shard& s = sh[g];
+        for (u32 i = 0; i < s.p.N && ok; ++i) {
+            const u32 n = s.first + i;
+            if (s.em.cpu[i] != ref.cpu[n] || s.em.mem[i] != ref.mem[n] || s.em.total[i] != ref.total[n]) {
+                fprintf(stderr, "MISMATCH node %u (shard %u local %u): cpu %lld/%lld mem %lld/%lld total %u/%u\n", n, g, i, (long long)s.em.cpu[i], (long long)ref.cpu[n],
+                        (long long)s.em.mem[i], (long long)ref.mem[n], s.em.total[i], ref.total[n]);
+                ok = false;
+            }
+        }
+        // host ports and the services' node sets, bit by bit against the whole-set rows
+        const std::vector<u64> pm = slice_rows(ref.portmap, p.n_ports, p.Wn, s.first, s.p.N), xs = slice_rows(ref.X, p.S, p.Wn, s.first, s.p.N);
+        ok = ok && same("portmap", s.em.portmap, pm, pm.size()) && same("X", s.em.X, xs, xs.size());
+        ok = ok && s.em.ctl.ncommit == ref.ctl.ncommit && s.em.ctl.ninf == ref.ctl.ninf;
+        if (!ok) fprintf(stderr, "shard %u: ncommit %u (ref %u) ninf %u (ref %u)\n", g, s.em.ctl.ncommit, ref.ctl.ncommit, s.em.ctl.ninf, ref.ctl.ninf);
+        ok = ok && same("inf_task", s.em.inf_task, ref.inf_task, ref.ctl.ninf) && same("inf_pos", s.em.inf_pos, ref.inf_pos, ref.ctl.ninf);
+    }
+    if (verbose || !ok)
+        fprintf(stderr, "seed %u N %u T %u S %u block %u order %d feat %d shards %u: placed %u inf %u | rounds %llu (%.1f tasks each) cut: exhausted %u exception %u uncounted %u -> %s\n", seed,
+                N, T, S, B, order, feat, G, ref.ctl.ncommit, ref.ctl.ninf, (unsigned long long)rounds, rounds ? (double)T / (double)rounds : 0.0, head.cut_exhausted, head.cut_exception,
+                head.cut_uncounted, ok ? "OK" : "FAIL");
+    return ok ? 0 : 1;
+}

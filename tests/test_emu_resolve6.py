@@ -18,7 +18,9 @@ def emu_bin():
     srcs = [os.path.join(EMU, "emu_resolve6.cpp"), os.path.join(EMU, "wv_emu.hpp"), os.path.join(EMU, "emu_model.hpp"),
             os.path.join(CSRC, "swp_resolve6.hpp"), os.path.join(CSRC, "swp_shard.hpp"), os.path.join(CSRC, "swp_types.hpp")]
     if not os.path.exists(BIN) or any(os.path.getmtime(s) > os.path.getmtime(BIN) for s in srcs):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-o", BIN, srcs[0]], check=True)
+        tmp = BIN + ".%d.tmp" % os.getpid()   # (xdist workers may build at the same time)
+        subprocess.run(["g++", "-O1", "-std=c++17", "-o", tmp, srcs[0]], check=True)
+        os.replace(tmp, BIN)
     return BIN
 
 
