@@ -236,6 +236,11 @@ std::string encode_decisions(const std::vector<Decision>& ds) {
         put_ki(o, "State", t.state);
         put_kv(o, "Message", t.message);
         put_kv(o, "Err", t.err);
+        if (!t.assigned_generic.empty()) {   // what NodeInfo.addTask's Claim gave the task (nodeinfo.go:134-137): part of decision.new
+            o += "\"AssignedGenericResources\":";
+            encode_generic(o, t.assigned_generic);
+            o += ",";
+        }
         put_ki(o, "OldState", ds[i].old_task->state, false);
         o += "}";
     }

@@ -9,7 +9,7 @@
 //     ready[w], con[class][w], plat[class][w], plug[class][w], sc[static class][w]
 //     X[svc][w]    nodes that are NOT "plain" for a service (svcCount>0 or recent failures ≥5)
 //
-// This header holds the kernels around the resolvers: predicate classes, the explain pass, task groups (k_groups), the
+// This header holds the kernels around the resolvers: predicate classes, the explain pass, the
 // event-handler residual updates, the enforcer sweep and the pair check. The sequential argmin + commit pass itself lives in
 // swp_resolve5.hpp (round resolver, node sets that fit one workgroup's LDS), swp_resolve6.hpp (block resolver, bitmap rows in
 // global memory), swp_waterfill.hpp (runs of identical tasks) and swp_shard.hpp (node-range shards). Why parallel kernels
@@ -715,565 +715,6 @@ __global__ __launch_bounds__(256) void k_xg_write(XGArgs a) {
 __global__ __launch_bounds__(256) void k_gather_rows(const u32* idx, const u32* src, u32* dst, u32 n) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n * 8u) dst[g] = src[(size_t)idx[g >> 3] * 8u + (g & 7u)];
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_groups — grouped tasks (SpecVersion != nil): scheduleTaskGroup with k = len(group)
-// (scheduler.go:694-748), nodeSet.tree with a bounded max-heap per leaf (nodeset.go:50-124,
-// container/heap mechanics reproduced step for step: nodeheap.go, decision_tree.go:24-52),
-// scheduleNTasksOnSubtree (:772-825) and the fill loop scheduleNTasksOnNodes (:844-924).
-// One workgroup walks the groups of a tick in order (a group sees the previous group's commits).
-// Per group: (A) all threads evaluate Pipeline.Process + the nodeLess key for every node in parallel;
-// (B) nodes are admitted to their leaf's heap in index order, 256 at a time: threads pre-filter
-// against the heap root at chunk start (the root key only decreases, so the pre-filter is a superset),
-// thread 0 replays the survivors exactly; (C) thread 0 runs the tree walk and the fill loops on the
-// heap nodes' state held in LDS; (D) results are written back and the service's (node, count) list is
-// rebuilt. The Explain counters of a group that could not be placed completely are recovered by
-// replaying the Process call sequence of tree() and appending the fill phase's logged calls.
-// ---------------------------------------------------------------------------------------------
-#define G_HCAP 1536      // heap slots over all leaves of one group
-#define G_MAXT 512       // tree nodes of one spread set
-#define G_LOG 8192       // Process results logged by the fill phase
-#define FF_PASS 255u
-
-struct GroupRec {   // one per group
-    i64 cpu, mem;
-    u32 flags;          // RT_*
-    u32 k;              // group size
-    u32 svc;            // batch-local service
-    u32 out_off;        // first output index
-    u32 pset;
-    u32 cls_con, cls_plat, cls_plug;
-    u64 maxrep;
-    u32 tree;           // spread set (0 = no preferences)
-    u32 pad;
-};
-static_assert(sizeof(GroupRec) == 64, "GroupRec layout");
-
-struct GroupArgs {
-    u32 n_nodes, n_words, n_groups, n_trees;
-    const GroupRec* g;
-    const u64* valid;
-    const u64* ready;
-    const u64* con;
-    const u64* plat;
-    const u64* plug;
-    i64* cpu;
-    i64* mem;
-    u32* total;
-    u64* portmap;
-    const u32* pset_off;
-    const u32* pset_ids;
-    u32* list_node;
-    u32* list_svc;
-    u32* list_fail;
-    const u32* list_off;     // [n_svc+1]
-    // tree topology per spread set: tnodes of tree t are [tree_off[t], tree_off[t+1]) ; indices are relative
-    const u32* tree_off;
-    const u32* tn_parent;    // 0xFFFFFFFF for the root
-    const u32* tn_first;     // first child or 0xFFFFFFFF
-    const u32* tn_next;      // next sibling or 0xFFFFFFFF
-    const u32* tn_nchild;
-    const u32* tn_nodes;     // nodes whose leaf this tnode is
-    const u32* leaf_of_node; // [n_trees][n_nodes] tnode of the node's leaf
-    unsigned char* ff;       // scratch [n_nodes]
-    u32* svc_dense;          // scratch [n_nodes]
-    u32* fail_dense;         // scratch [n_nodes]
-    int32_t* out_node;
-    u32* hist;               // [n_groups][8]
-    Ctl* ctl;
-};
-
-// nodeLess, scheduler.go:708-735
-__device__ __forceinline__ bool g_less_vals(u32 fa, u32 sa, u32 ta, u32 fb, u32 sb, u32 tb) {
-    if (fa >= MAX_FAILURES || fb >= MAX_FAILURES) {
-        if (fa > fb) return false;
-        if (fb > fa) return true;
-    }
-    if (sa < sb) return true;
-    if (sa > sb) return false;
-    return ta < tb;
-}
-
-// nodeLess as ONE integer compare: key = (failures if >= 5 else 0, svcCount, total) packed 8 | 24 | 32 bits
-// (both sides below 5 failures skip the failure compare, scheduler.go:713-722; a side at >= 5 beats any side below).
-__device__ __forceinline__ u64 g_key(u32 fail, u32 svc, u32 total) {
-    const u32 fc = fail >= MAX_FAILURES ? fail : 0u;
-    return ((u64)fc << 56) | ((u64)svc << 32) | total;
-}
-__device__ __forceinline__ bool g_key_ok(u32 fail, u32 svc) { return fail < 256u && svc < (1u << 24); }
-
-struct GHeap {   // heap positions hold (key, state id); the node state itself never moves
-    u64* key;
-    u32* pay;
-    u32 *node, *total, *svc, *fail, *placed;   // state, indexed by state id
-    i64 *cpu, *mem;
-    __device__ __forceinline__ bool less(u32 a, u32 b) const { return key[a] < key[b]; }
-    __device__ __forceinline__ void swap(u32 a, u32 b) {
-        const u64 k = key[a]; key[a] = key[b]; key[b] = k;
-        const u32 t = pay[a]; pay[a] = pay[b]; pay[b] = t;
-    }
-};
-// container/heap (go stdlib) over nodeMaxHeap: Less(i,j) = lessFunc(nodes[j], nodes[i]) (nodeheap.go:17-20).
-// up / down move ONE element along a path and swap it with what it meets: the element rides in registers and every step copies
-// the other one into the hole — the same comparisons, the same final arrangement as the swap sequence, but one LDS round trip
-// per level (both children's keys and payloads are requested together) instead of three. The walk is the serial chain of
-// k_groups: LDS latency of a single thread.
-template <class HP> __device__ inline void g_up(HP& h, u32 base, int j0) {
-    int j = j0;
-    const u64 kv = h.key[base + j];
-    const u32 pv = h.pay[base + j];
-    for (;;) {
-        const int i = (j - 1) / 2;   // j == 0: i == 0 (Go's integer division truncates, too)
-        if (i == j) break;
-        const u64 ki = h.key[base + i];
-        const u32 pi = h.pay[base + i];
-        if (!(ki < kv)) break;       // !Less(j, i)
-        h.key[base + j] = ki;
-        h.pay[base + j] = pi;
-        j = i;
-    }
-    if (j != j0) {
-        h.key[base + j] = kv;
-        h.pay[base + j] = pv;
-    }
-}
-template <class HP> __device__ inline bool g_down(HP& h, u32 base, int i0, int n) {
-    int i = i0;
-    const u64 kv = h.key[base + i];
-    const u32 pv = h.pay[base + i];
-    for (;;) {
-        const int j1 = 2 * i + 1;
-        if (j1 >= n || j1 < 0) break;
-        const int j2 = j1 + 1;
-        const bool two = j2 < n;
-        const u64 k1 = h.key[base + j1], k2 = two ? h.key[base + j2] : 0ull;
-        const u32 p1 = h.pay[base + j1], p2 = two ? h.pay[base + j2] : 0u;
-        const bool right = two && k1 < k2;   // Less(j2, j1)
-        const u64 kj = right ? k2 : k1;
-        if (!(kv < kj)) break;               // !Less(j, i)
-        h.key[base + i] = kj;
-        h.pay[base + i] = right ? p2 : p1;
-        i = right ? j2 : j1;
-    }
-    if (i > i0) {
-        h.key[base + i] = kv;
-        h.pay[base + i] = pv;
-    }
-    return i > i0;
-}
-
-#define G_THREADS 1024   // one workgroup; every N-long loop strides by it
-__global__ __launch_bounds__(G_THREADS) void k_groups(GroupArgs a) {
-    extern __shared__ unsigned char g_lds[];
-    GHeap H;
-    unsigned char* p = g_lds;
-    H.key = reinterpret_cast<u64*>(p); p += G_HCAP * 8;
-    H.cpu = reinterpret_cast<i64*>(p); p += G_HCAP * 8;
-    H.mem = reinterpret_cast<i64*>(p); p += G_HCAP * 8;
-    i64* tsum = reinterpret_cast<i64*>(p); p += G_MAXT * 8;              // decisionTree.tasks
-    i64* e_cpu = reinterpret_cast<i64*>(p); p += G_THREADS * 8;
-    i64* e_mem = reinterpret_cast<i64*>(p); p += G_THREADS * 8;
-    H.node = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H.total = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H.svc = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H.fail = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H.placed = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    H.pay = reinterpret_cast<u32*>(p); p += G_HCAP * 4;
-    u32* h_off = reinterpret_cast<u32*>(p); p += G_MAXT * 4;              // first heap slot of a leaf
-    int32_t* h_len = reinterpret_cast<int32_t*>(p); p += G_MAXT * 4;      // nodeMaxHeap.length
-    int32_t* h_cnt = reinterpret_cast<int32_t*>(p); p += G_MAXT * 4;      // len(nodeMaxHeap.nodes)
-    int32_t* h_adm = reinterpret_cast<int32_t*>(p); p += G_MAXT * 4;      // slots ever filled (write-back range)
-    u32* e_node = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
-    u32* e_total = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
-    u32* e_svc = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
-    u32* e_fail = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
-    u32* e_leaf = reinterpret_cast<u32*>(p); p += G_THREADS * 4;
-    p += G_THREADS * 4;   // (spare staging column)
-    u32* wcnt = reinterpret_cast<u32*>(p); p += 16 * 4;
-    u32* shv = reinterpret_cast<u32*>(p); p += 16 * 4;
-    u32* cntx = reinterpret_cast<u32*>(p); p += 8 * 4;                    // Explain counters
-    u64* failed = reinterpret_cast<u64*>(p); p += (G_HCAP / 64) * 8;     // fill loop: slots that failed Process
-    u64* rootkey = reinterpret_cast<u64*>(p); p += G_MAXT * 8;             // per leaf: heap root key after tree()
-    unsigned char* plog = p; p += G_LOG;
-    enum { S_NENT = 0, S_ERR = 1, S_LEFT = 2, S_NLOG = 3, S_LISTPOS = 4, S_LASTPASS = 5 };
-
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 N = a.n_nodes, Wn = a.n_words;
-    if (a.ctl->error != ERR_NONE) return;
-
-    u64 gt[6] = {0, 0, 0, 0, 0, 0};
-    u64 gtk = wall_clock64();
-#define G_TICK(q) do { u64 _n = wall_clock64(); gt[q] += _n - gtk; gtk = _n; } while (0)
-    for (u32 gi = 0; gi < a.n_groups; ++gi) {
-        const GroupRec G = a.g[gi];
-        const u32 tbase = a.tree_off[G.tree], ntn = a.tree_off[G.tree + 1] - tbase;
-        const u32* leaf_of = a.leaf_of_node + (size_t)G.tree * N;
-        const u32 k = G.k;
-        // ---------- per-group reset ----------
-        for (u32 i = tid; i < ntn; i += G_THREADS) { tsum[i] = 0; h_off[i] = 0; h_len[i] = 0; h_cnt[i] = 0; h_adm[i] = 0; }
-        for (u32 n = tid; n < N; n += G_THREADS) { a.svc_dense[n] = 0; a.fail_dense[n] = 0; }
-        if (tid == 0) { shv[S_ERR] = 0; shv[S_NLOG] = 0; shv[S_LEFT] = 0; shv[S_LASTPASS] = 0; }
-        __syncthreads();
-        // the service's (node, svcCount, failures) list → dense per-node columns
-        for (u32 e = a.list_off[G.svc] + tid; e < a.list_off[G.svc + 1]; e += G_THREADS) {
-            u32 n = a.list_node[e];
-            if (n != LIST_EMPTY) { a.svc_dense[n] = a.list_svc[e]; a.fail_dense[n] = a.list_fail[e]; }
-        }
-        __syncthreads();
-
-        G_TICK(0);
-        // ---------- (A) Pipeline.Process on every node: first failing filter or FF_PASS ----------
-        for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
-            const u32 n = n0 + tid;
-            if (n < N) {
-                const u32 w = n >> 6;
-                const u64 bit = 1ull << (n & 63);
-                if (a.valid[w] & bit) {
-                    u32 ff = FF_PASS;
-                    if (!(a.ready[w] & bit)) ff = 0;
-                    else if ((G.flags & RT_RES) && !(G.cpu <= a.cpu[n] && G.mem <= a.mem[n])) ff = 1;
-                    else if (G.cls_plug && !(a.plug[(size_t)G.cls_plug * Wn + w] & bit)) ff = 2;
-                    else if (G.cls_con && !(a.con[(size_t)G.cls_con * Wn + w] & bit)) ff = 3;
-                    else if (G.cls_plat && !(a.plat[(size_t)G.cls_plat * Wn + w] & bit)) ff = 4;
-                    else {
-                        bool busy = false;
-                        if (G.flags & RT_PORTS)
-                            for (u32 q = a.pset_off[G.pset]; q < a.pset_off[G.pset + 1]; ++q)
-                                if (a.portmap[(size_t)a.pset_ids[q] * Wn + w] & bit) busy = true;
-                        if (busy) ff = 5;
-                        else if ((G.flags & RT_MAXREP) && !((u64)a.svc_dense[n] < G.maxrep)) ff = 6;
-                    }
-                    a.ff[n] = (unsigned char)ff;
-                    // tree(): the node's service count is added at its leaf (and, below, at every ancestor)
-                    // whether or not the node is feasible (nodeset.go:88-90,103-105)
-                    u32 sv = a.svc_dense[n];
-                    if (sv) atomicAdd(reinterpret_cast<u64*>(&tsum[leaf_of[n]]), (u64)sv);
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = (int)ntn - 1; i > 0; --i) tsum[a.tn_parent[tbase + i]] += tsum[i];   // children follow their parent
-            u32 off = 0;
-            for (u32 i = 0; i < ntn; ++i)
-                if (a.tn_nchild[tbase + i] == 0) { h_off[i] = off; off += min(k, a.tn_nodes[tbase + i]); }   // a leaf's heap holds ≤ its node count
-            if (off > G_HCAP || ntn > G_MAXT) shv[S_ERR] = 1;
-        }
-        __syncthreads();
-        if (shv[S_ERR]) {
-            if (tid == 0) a.ctl->error = ERR_GROUP_RANGE;
-            return;
-        }
-
-        G_TICK(1);
-        // ---------- (B) heap admission in node order, a chunk of nodes at a time (nodeset.go:107-120) ----------
-        // The pre-filter compares with the heap roots as they are at the chunk's start, so it is the sharper the shorter the chunk:
-        // the first G_THREADS nodes (while the heaps fill and their roots still drop fast) go in chunks of 128.
-        for (u32 n0 = 0; n0 < N;) {
-            const u32 step = n0 < G_THREADS ? 128u : (u32)G_THREADS;
-            const u32 n = n0 + tid;
-            bool cand = false;
-            u32 leaf = 0, sv = 0, fl = 0, tot = 0;
-            if (tid < step && n < N && ((a.valid[n >> 6] >> (n & 63)) & 1ull) && a.ff[n] == FF_PASS) {
-                leaf = leaf_of[n];
-                sv = a.svc_dense[n];
-                fl = a.fail_dense[n];
-                tot = a.total[n];
-                if (!g_key_ok(fl, sv)) shv[S_ERR] = 1;
-                if (h_len[leaf] < (int)k) cand = true;
-                else cand = g_key(fl, sv, tot) < H.key[h_off[leaf]];
-            }
-            const u64 bal = ballot64(cand);
-            if (lane == 0) wcnt[wave] = (u32)__popcll(bal);
-            __syncthreads();
-            u32 before = 0;
-            for (u32 q = 0; q < wave; ++q) before += wcnt[q];
-            const u32 pos = before + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-            if (cand) {
-                e_node[pos] = n; e_leaf[pos] = leaf; e_svc[pos] = sv; e_fail[pos] = fl; e_total[pos] = tot;
-                e_cpu[pos] = a.cpu[n]; e_mem[pos] = a.mem[n];
-            }
-            if (tid == G_THREADS - 1) shv[S_NENT] = before + (u32)__popcll(bal);
-            __syncthreads();
-            if (tid == 0) {
-                const u32 ne = shv[S_NENT];
-                // the leaf of the last entry, its heap's base / length / root key ride in registers: a run of entries of one leaf
-                // (every group without spread preferences) pays one LDS round trip per entry that does not enter the heap
-                u32 c_lf = 0xFFFFFFFFu, base = 0;
-                int len = 0;
-                u64 root = 0;
-                for (u32 i = 0; i < ne; ++i) {
-                    const u32 lf = e_leaf[i];
-                    const u64 ek = g_key(e_fail[i], e_svc[i], e_total[i]);
-                    if (lf != c_lf) {
-                        c_lf = lf;
-                        base = h_off[lf];
-                        len = h_len[lf];
-                        root = len ? H.key[base] : 0ull;
-                    }
-                    u32 sid;
-                    if (len < (int)k) sid = base + (u32)len;          // heap.Push: a fresh state slot
-                    else if (ek < root) sid = H.pay[base];             // replaces the root: the evicted node's state slot is reused
-                    else continue;
-                    shv[S_LASTPASS] = e_node[i] + 1;   // the last Process that returned true inside tree()
-                    H.node[sid] = e_node[i]; H.total[sid] = e_total[i]; H.svc[sid] = e_svc[i]; H.fail[sid] = e_fail[i];
-                    H.cpu[sid] = e_cpu[i]; H.mem[sid] = e_mem[i]; H.placed[sid] = 0;
-                    if (len < (int)k) {
-                        H.key[sid] = ek; H.pay[sid] = sid;
-                        h_len[lf] = len + 1; h_cnt[lf] = len + 1; h_adm[lf] = len + 1;
-                        g_up(H, base, len);
-                        ++len;
-                    } else {
-                        H.key[base] = ek;
-                        if (!g_down(H, base, 0, len)) g_up(H, base, 0);   // heap.Fix(0)
-                    }
-                    root = H.key[base];
-                }
-            }
-            __syncthreads();
-            n0 += step;
-        }
-
-        G_TICK(2);
-        // heap roots and lengths as tree() left them: the Explain pass needs them after (C) has spent the heaps
-        for (u32 i = tid; i < ntn; i += G_THREADS) {
-            rootkey[i] = H.key[h_off[i]];
-            h_adm[i] = h_len[i];   // == slots ever filled (pushes only grow the heap)
-        }
-        __syncthreads();
-        // ---------- (C) tree walk + fill loops: thread 0, on LDS state only ----------
-        if (tid == 0) {
-            u32 next_task = 0, nlog = 0;
-            bool bad_key = false;
-            const bool has_ports = (G.flags & RT_PORTS) != 0;
-            // Pipeline.Process on a heap slot: the static filters passed at admission and cannot change
-            auto process = [&](u32 pos) -> bool {
-                const u32 sl = H.pay[pos];
-                u32 ff = FF_PASS;
-                if ((G.flags & RT_RES) && !(G.cpu <= H.cpu[sl] && G.mem <= H.mem[sl])) ff = 1;
-                else if (has_ports && H.placed[sl] > 0) ff = 5;
-                else if ((G.flags & RT_MAXREP) && !((u64)H.svc[sl] < G.maxrep)) ff = 6;
-                if (nlog < G_LOG) plog[nlog] = (unsigned char)ff;
-                ++nlog;
-                return ff == FF_PASS;
-            };
-            // scheduleNTasksOnNodes, scheduler.go:844-924, on the leaf's slots [base, base+cnt)
-            auto fill = [&](int want, u32 base, int cnt) -> int {
-                int scheduled = 0, iter = 0;
-                for (int q = 0; q <= (cnt >> 6); ++q) failed[q] = 0;
-                while (next_task < k) {
-                    const u32 pos = base + (u32)(iter % cnt);
-                    const u32 sl = H.pay[pos];
-                    a.out_node[G.out_off + next_task] = (int32_t)H.node[sl];
-                    ++next_task;
-                    H.cpu[sl] -= G.cpu;   // NodeInfo.addTask (nodeinfo.go:108-154)
-                    H.mem[sl] -= G.mem;
-                    H.placed[sl] += 1;
-                    if (!(G.flags & RT_UNCOUNTED)) {
-                        H.total[sl] += 1; H.svc[sl] += 1;
-                        if (!g_key_ok(H.fail[sl], H.svc[sl])) bad_key = true;
-                        H.key[pos] = g_key(H.fail[sl], H.svc[sl], H.total[sl]);
-                    }
-                    ++scheduled;
-                    if (scheduled == want) return scheduled;
-                    if (iter + 1 < cnt) {
-                        if (H.less(base + (u32)((iter + 1) % cnt), pos)) ++iter;   // first pass
-                    } else ++iter;                                                 // later passes: round robin
-                    const int orig = iter;
-                    for (;;) {
-                        const int ix = iter % cnt;
-                        const bool bad = (failed[ix >> 6] >> (ix & 63)) & 1ull;
-                        if (!bad && process(base + (u32)ix)) break;
-                        failed[ix >> 6] |= 1ull << (ix & 63);
-                        ++iter;
-                        if (iter - orig == cnt) return scheduled;
-                    }
-                }
-                return scheduled;
-            };
-            // decisionTree.orderedNodes, decision_tree.go:24-52
-            auto ordered = [&](u32 lf) -> int {
-                const u32 base = h_off[lf];
-                if (h_len[lf] != h_cnt[lf]) {
-                    int cnt = h_cnt[lf];
-                    for (int i = 0; i < cnt;) {
-                        if (process(base + (u32)i)) ++i;
-                        else {
-                            --cnt;
-                            if (i != cnt) H.swap(base + (u32)i, base + (u32)cnt);   // nodes[i] = nodes[last]; the dropped
-                        }                                                            // node keeps its slot for the write-back
-                    }
-                    h_cnt[lf] = cnt;
-                    h_len[lf] = cnt;
-                    for (int i = cnt / 2 - 1; i >= 0; --i) g_down(H, base, i, cnt);   // heap.Init
-                }
-                while (h_len[lf] > 0) {   // heap.Pop: Swap(0,n-1); down(0,n-1); length--
-                    const int nn = h_len[lf] - 1;
-                    H.swap(base, base + (u32)nn);
-                    g_down(H, base, 0, nn);
-                    h_len[lf] = nn;
-                }
-                return h_cnt[lf];
-            };
-            // scheduleNTasksOnSubtree, scheduler.go:772-825, as an explicit stack machine
-            struct Frame { u32 tn; int n; int scheduled; i64 usable; u64 noroom; i64 desired; i64 rem; u32 child; int child_pos; int assign; bool converging; int phase; };
-            Frame st[8];
-            int sp = 0, ret = 0;
-            bool bad = false;
-            st[0] = Frame{0u, (int)k, 0, 0, 0ull, 0, 0, 0xFFFFFFFFu, 0, 0, true, 0};
-            while (sp >= 0 && !bad) {
-                Frame& f = st[sp];
-                const u32 nch = a.tn_nchild[tbase + f.tn];
-                if (f.phase == 0) {
-                    if (nch == 0) {   // leaf
-                        const int cnt = ordered(f.tn);
-                        ret = cnt == 0 ? 0 : fill(f.n, h_off[f.tn], cnt);
-                        --sp;
-                        continue;
-                    }
-                    if (nch > 64) { bad = true; break; }
-                    f.scheduled = 0;
-                    f.usable = tsum[f.tn];
-                    f.noroom = 0;
-                    f.converging = true;
-                    f.phase = 1;
-                }
-                if (f.phase == 3) {   // a child call returned `ret`
-                    if (ret < f.assign) {
-                        f.noroom |= 1ull << f.child_pos;
-                        f.usable -= tsum[f.child];
-                    } else if (f.rem > 0) f.rem--;
-                    f.scheduled += ret;
-                    f.child = a.tn_next[tbase + f.child];
-                    f.child_pos++;
-                    f.phase = 2;
-                }
-                if (f.phase == 1) {   // while condition + per-round quantities
-                    const int room = (int)nch - __popcll(f.noroom);
-                    if (!(f.scheduled != f.n && room != 0 && f.converging)) {
-                        ret = f.scheduled;
-                        --sp;
-                        continue;
-                    }
-                    const i64 tot = f.usable + f.n - f.scheduled;
-                    f.desired = tot / room;
-                    f.rem = tot % room;
-                    f.converging = false;
-                    f.child = a.tn_first[tbase + f.tn];
-                    f.child_pos = 0;
-                    f.phase = 2;
-                }
-                // phase 2: `for _, subtree := range tree.next`
-                bool called = false;
-                while (f.child != 0xFFFFFFFFu) {
-                    if (!((f.noroom >> f.child_pos) & 1ull)) {
-                        const i64 sub = tsum[f.child];
-                        if (sub < f.desired || (sub == f.desired && f.rem > 0)) {
-                            f.converging = true;
-                            f.assign = (int)(f.desired - sub) + (f.rem > 0 ? 1 : 0);
-                            if (sp + 1 >= 8) { bad = true; break; }
-                            f.phase = 3;
-                            st[sp + 1] = Frame{f.child, f.assign, 0, 0, 0ull, 0, 0, 0xFFFFFFFFu, 0, 0, true, 0};
-                            ++sp;
-                            called = true;
-                            break;
-                        }
-                    }
-                    f.child = a.tn_next[tbase + f.child];
-                    f.child_pos++;
-                }
-                if (!called && !bad) f.phase = 1;
-            }
-            if (bad || bad_key) shv[S_ERR] = 1;
-            shv[S_LEFT] = k - next_task;
-            shv[S_NLOG] = nlog;
-            for (u32 i = next_task; i < k; ++i) a.out_node[G.out_off + i] = -1;
-        }
-        __syncthreads();
-        if (shv[S_ERR]) {
-            if (tid == 0) a.ctl->error = ERR_GROUP_RANGE;
-            return;
-        }
-
-        G_TICK(3);
-        // ---------- Explain counters for a group with leftovers (pipeline.go:56-68 call sequence) ----------
-        if (shv[S_LEFT] > 0) {
-            // Every passing Process zeroes the counters (pipeline.go:64-66), so only the calls AFTER the last passing one
-            // count. Inside tree() the heaps stop changing after that call: a later node was "called" (nodeset.go:108-116)
-            // iff its leaf's heap was not full or the node is less than the final root — evaluated in parallel.
-            if (tid < 8) cntx[tid] = 0;
-            __syncthreads();
-            const u32 lastp = shv[S_LASTPASS];   // node index + 1 of the last passing call (0: none)
-            for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
-                const u32 n = n0 + tid;
-                u32 f = 0xFFu;
-                if (n < N && n >= lastp && ((a.valid[n >> 6] >> (n & 63)) & 1ull)) {
-                    const u32 ffn = a.ff[n];
-                    if (ffn != FF_PASS) {
-                        const u32 lf = leaf_of[n];
-                        const bool called = h_adm[lf] < (int)k ||
-                                            g_key(a.fail_dense[n], a.svc_dense[n], a.total[n]) < rootkey[lf];   // (D) has not run yet: tree()-time values
-                        if (called) f = ffn;
-                    }
-                }
-                for (u32 q = 0; q < 7; ++q) {
-                    const u64 bm = ballot64(f == q);
-                    if (bm && lane == 0) atomicAdd(&cntx[q], (u32)__popcll(bm));
-                }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                const u32 nl = min(shv[S_NLOG], (u32)G_LOG);
-                for (u32 i = 0; i < nl; ++i) {
-                    if (plog[i] == FF_PASS) { for (int q = 0; q < 8; ++q) cntx[q] = 0; }
-                    else cntx[plog[i]]++;
-                }
-                for (int q = 0; q < 8; ++q) a.hist[(size_t)gi * 8 + q] = cntx[q];
-                if (shv[S_NLOG] > G_LOG) a.ctl->error = ERR_GROUP_RANGE;
-            }
-            __syncthreads();
-        }
-
-        // ---------- (D) write-back: node rows, host ports, the service's (node, count) list ----------
-        for (u32 i = tid; i < ntn; i += G_THREADS) {
-            if (a.tn_nchild[tbase + i] != 0) continue;
-            const u32 base = h_off[i];
-            for (int q = 0; q < h_adm[i]; ++q) {
-                const u32 sl = base + (u32)q;
-                if (H.placed[sl] == 0) continue;
-                const u32 n = H.node[sl];
-                a.cpu[n] = H.cpu[sl];
-                a.mem[n] = H.mem[sl];
-                a.total[n] = H.total[sl];
-                a.svc_dense[n] = H.svc[sl];
-                if (G.flags & RT_PORTS)
-                    for (u32 z = a.pset_off[G.pset]; z < a.pset_off[G.pset + 1]; ++z)
-                        atomicOr(&a.portmap[(size_t)a.pset_ids[z] * Wn + (n >> 6)], 1ull << (n & 63));
-            }
-        }
-        if (tid == 0) shv[S_LISTPOS] = a.list_off[G.svc];
-        __syncthreads();
-        const u32 lend = a.list_off[G.svc + 1];
-        for (u32 n0 = 0; n0 < N; n0 += G_THREADS) {
-            const u32 n = n0 + tid;
-            const bool keep = n < N && (a.svc_dense[n] > 0 || a.fail_dense[n] >= MAX_FAILURES);
-            const u64 bal = ballot64(keep);
-            if (lane == 0) wcnt[wave] = (u32)__popcll(bal);
-            __syncthreads();
-            u32 before = shv[S_LISTPOS];
-            for (u32 q = 0; q < wave; ++q) before += wcnt[q];
-            const u32 pos = before + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-            if (keep && pos < lend) { a.list_node[pos] = n; a.list_svc[pos] = a.svc_dense[n]; a.list_fail[pos] = a.fail_dense[n]; }
-            __syncthreads();
-            if (tid == 0) { u32 t_ = 0; for (u32 q = 0; q < G_THREADS / 64; ++q) t_ += wcnt[q]; shv[S_LISTPOS] += t_; }
-            __syncthreads();
-        }
-        for (u32 e = shv[S_LISTPOS] + tid; e < lend; e += G_THREADS) a.list_node[e] = LIST_EMPTY;
-        __syncthreads();
-        G_TICK(5);
-    }
-    if (tid == 0) for (int q = 0; q < 6; ++q) a.ctl->cyc[q] = gt[q];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@
 
 #include "../../include/swp.h"
 #include "swp_device.hpp"
+#include "swp_groups.hpp"
 #include "swp_launch.hpp"
 #include "swp_resolve6.hpp"
 #include "swp_resolve7.hpp"
@@ -209,6 +210,7 @@ struct swp_batch {
     std::vector<uint32_t> svc_global;      // batch-local service -> SERVICE id
     std::vector<uint32_t> list_off;        // [n_svc+1]
     std::vector<uint32_t> list_node0, list_svc0, list_fail0;   // pristine lists
+    std::vector<uint32_t> list_cnt0;                            // [n_svc] entries in use at the front of a service's range
     std::vector<uint32_t> xrow, xnode;     // scatter sources for X
     std::vector<uint32_t> prow, pnode;     // scatter sources for portmap
     std::vector<uint64_t> port_keys;       // batch-local port -> (proto,port)
@@ -568,7 +570,6 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         if (d.spread_set >= e->spread_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown spread set", i);
         if (d.spread_set && !weights) return e->fail(SWP_EUNSUPPORTED, "task %u has spread preferences: schedule it through swp_schedule_groups", i);
         if (d.generic_set >= e->gen_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown generic set", i);
-        if (d.generic_set && weights) return e->fail(SWP_EUNSUPPORTED, "group %u reserves generic resources: task groups with generic reservations stay on the Go path", i);
         // the exactness argument (feasibility only shrinks inside a batch) needs non-negative reservations; the API layer
         // rejects negative ones (manager/controlapi validateResources), a task that carries them stays on the Go path
         if (d.cpu < 0 || d.mem < 0) return e->fail(SWP_EUNSUPPORTED, "task %u has a negative resource reservation", i);
@@ -795,6 +796,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     mark("runs");
     // per-service exception lists: nodes with svcCount>0 or ≥ maxFailures recent failures
     b->list_off.assign(b->n_svc + 1, 0);
+    b->list_cnt0.clear();
     b->list_node0.reserve((size_t)T + 1024);
     b->list_svc0.reserve((size_t)T + 1024);
     b->list_fail0.reserve((size_t)T + 1024);
@@ -823,6 +825,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             b->list_fail0.push_back(kv.second.second);
         }
         init_cnt[s] = (uint32_t)b->list_node0.size() - b->list_off[s];
+        b->list_cnt0.push_back(init_cnt[s]);
         b->list_node0.insert(b->list_node0.end(), svc_ntasks[s], LIST_EMPTY);   // one free entry per task of the service
         b->list_svc0.insert(b->list_svc0.end(), svc_ntasks[s], 0u);
         b->list_fail0.insert(b->list_fail0.end(), svc_ntasks[s], 0u);
@@ -1992,6 +1995,8 @@ int swp_node_get_generic(swp_engine* e, uint32_t node, uint32_t kind, int64_t* c
     return SWP_OK;
 }
 
+static int groups_apply_to_host(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, uint64_t total, const int32_t* out_node);
+
 int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node,
                         uint32_t* out_fail_hist) {
     if (!e || (!groups && n_groups) || (!sizes && n_groups)) return SWP_EINVAL;
@@ -2026,6 +2031,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
             tree_sets.push_back(groups[g].spread_set);
         }
     std::vector<uint32_t> tree_off{0}, tn_parent, tn_first, tn_next, tn_nchild, tn_nodes, leaf_of((size_t)tree_sets.size() * N, 0xFFFFFFFFu);
+    uint32_t max_ntn = 1, max_depth = 0;
     for (size_t t = 0; t < tree_sets.size(); ++t) {
         const auto& levels = e->spread_sets[tree_sets[t]];
         const uint32_t base = (uint32_t)tn_parent.size();
@@ -2071,27 +2077,35 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
             tn_nodes[base + tn]++;   // nodes of this leaf: its heap never holds more (nodeset.go:107-120)
         }
         tree_off.push_back((uint32_t)tn_parent.size());
-        if (tn_parent.size() - base > G_MAXT) return e->fail(SWP_ERANGE, "spread tree with %zu branches exceeds the device limit %d", tn_parent.size() - base, G_MAXT);
+        max_ntn = std::max<uint32_t>(max_ntn, (uint32_t)tn_parent.size() - base);
+        max_depth = std::max<uint32_t>(max_depth, (uint32_t)levels.size());
     }
-    std::vector<GroupRec> recs(n_groups);
+    std::vector<GroupRec2> recs(n_groups);
     uint32_t off = 0;
+    size_t arena_bytes = 64;
     for (uint32_t g = 0; g < n_groups; ++g) {
         const RTask& r = b.rt[g];
-        GroupRec& q = recs[g];
+        GroupRec2& q = recs[g];
         std::memset(&q, 0, sizeof q);
         q.cpu = r.cpu; q.mem = r.mem; q.flags = r.flags; q.k = sizes[g]; q.svc = r.svc; q.out_off = off; q.pset = r.pset;
         q.cls_con = r.cls_con; q.cls_plat = r.cls_plat; q.cls_plug = r.cls_plug; q.maxrep = r.maxrep;
         q.tree = tree_local[groups[g].spread_set];
-        {   // heap slots the group needs: per leaf min(k, nodes of the leaf)
-            const uint32_t t = q.tree;
-            uint64_t need = 0;
-            for (uint32_t i = tree_off[t]; i < tree_off[t + 1]; ++i)
-                if (tn_nchild[i] == 0) need += std::min<uint32_t>(sizes[g], tn_nodes[i]);
-            if (need > G_HCAP) return e->fail(SWP_ERANGE, "group of %u tasks needs %llu heap slots over its spread tree, the device holds %d", sizes[g], (unsigned long long)need, G_HCAP);
+        q.dep_prev = g > 0 && b.rt[g - 1].svc == r.svc;
+        if (groups[g].generic_set) {
+            const auto& gs = e->gen_sets[groups[g].generic_set];
+            if (gs.size() > G2_MAXGEN) return e->fail(SWP_ERANGE, "group %u reserves %zu generic kinds (the engine takes %d)", g, gs.size(), G2_MAXGEN);
+            for (const swp_generic& x : gs) { q.gkind[q.n_gen] = x.kind; q.gval[q.n_gen++] = (int32_t)x.value; }
         }
+        // heap slots the group needs: per leaf min(k, nodes of the leaf) (nodeset.go:107-120: a leaf's heap never holds more)
+        uint64_t need = 0;
+        for (uint32_t i = tree_off[q.tree]; i < tree_off[q.tree + 1]; ++i)
+            if (tn_nchild[i] == 0) need += std::min<uint32_t>(sizes[g], tn_nodes[i]);
+        q.n_slots = (uint32_t)need;
+        const size_t ab = g2_arena_bytes(q.n_slots, tree_off[q.tree + 1] - tree_off[q.tree], q.n_gen, max_depth, q.k);
+        if (ab > G2_ARENA_LDS) arena_bytes = std::max(arena_bytes, ab);   // this group's working set lives in global memory
         off += sizes[g];
     }
-    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_tnn, d_leaf, d_ff, d_svcd, d_faild, d_out, d_hist;
+    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_tnn, d_leaf, d_ff, d_key, d_dense, d_tsum, d_xroot, d_xadm, d_arena, d_lcnt, d_out, d_hist;
     if ((rc = upload(e, d_recs, recs))) return rc;
     if ((rc = upload(e, d_tree_off, tree_off))) return rc;
     if ((rc = upload(e, d_par, tn_parent))) return rc;
@@ -2100,11 +2114,17 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     if ((rc = upload(e, d_nch, tn_nchild))) return rc;
     if ((rc = upload(e, d_tnn, tn_nodes))) return rc;
     if ((rc = upload(e, d_leaf, leaf_of))) return rc;
-    HIPCHECK(e, d_ff.reserve(N));
-    HIPCHECK(e, d_svcd.reserve((size_t)N * 4));
-    HIPCHECK(e, d_faild.reserve((size_t)N * 4));
+    if ((rc = upload(e, d_lcnt, b.list_cnt0))) return rc;
+    HIPCHECK(e, d_ff.reserve((size_t)2 * N));
+    HIPCHECK(e, d_key.reserve((size_t)2 * N * 8));
+    HIPCHECK(e, d_dense.reserve((size_t)6 * N * 4));
+    HIPCHECK(e, d_tsum.reserve((size_t)2 * max_ntn * 8));
+    HIPCHECK(e, d_xroot.reserve((size_t)max_ntn * 8));
+    HIPCHECK(e, d_xadm.reserve((size_t)max_ntn * 4));
+    HIPCHECK(e, d_arena.reserve(arena_bytes));
     HIPCHECK(e, d_out.reserve((size_t)total * 4));
     HIPCHECK(e, d_hist.reserve((size_t)n_groups * 8 * 4));
+    HIPCHECK(e, hipMemsetAsync(d_dense.p, 0, (size_t)6 * N * 4, st));   // the dense service columns start (and end) all zero
     HIPCHECK(e, hipMemsetAsync(d_hist.p, 0, (size_t)n_groups * 8 * 4, st));
     HIPCHECK(e, hipMemsetAsync(d_out.p, 0xFF, (size_t)total * 4, st));
     size_t L = b.list_node0.size();
@@ -2119,26 +2139,27 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
         hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b.prow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b.prow.size(),
                            b.d_prow.as<uint32_t>(), b.d_pnode.as<uint32_t>(), Wn, b.d_portmap.as<u64>());
     if ((rc = run_classes(e, &b))) return rc;
-    GroupArgs ga{};
-    ga.n_nodes = N; ga.n_words = Wn; ga.n_groups = n_groups; ga.n_trees = (uint32_t)tree_sets.size();
-    ga.g = d_recs.as<GroupRec>();
+    Groups2Args ga{};
+    ga.n_nodes = N; ga.n_words = Wn; ga.n_groups = n_groups; ga.gstride = e->ncap; ga.max_ntn = max_ntn; ga.max_depth = max_depth;
+    const bool gdbg = getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16);
+    ga.dbg = gdbg ? 16u : 0u;
+    ga.g = d_recs.as<GroupRec2>();
     ga.valid = e->d_valid.as<u64>(); ga.ready = e->d_ready.as<u64>();
     ga.con = b.d_con.as<u64>(); ga.plat = b.d_plat.as<u64>(); ga.plug = b.d_plug.as<u64>();
     ga.cpu = e->d_cpu.as<long long>(); ga.mem = e->d_mem.as<long long>(); ga.total = e->d_total.as<uint32_t>();
+    ga.gcnt = e->d_gcnt.as<int32_t>();
     ga.portmap = b.d_portmap.as<u64>(); ga.pset_off = b.d_pset_off.as<uint32_t>(); ga.pset_ids = b.d_pset_ids.as<uint32_t>();
     ga.list_node = b.d_list_node.as<uint32_t>(); ga.list_svc = b.d_list_svc.as<uint32_t>(); ga.list_fail = b.d_list_fail.as<uint32_t>();
-    ga.list_off = b.d_list_off.as<uint32_t>();
+    ga.list_off = b.d_list_off.as<uint32_t>(); ga.list_cnt = d_lcnt.as<uint32_t>();
     ga.tree_off = d_tree_off.as<uint32_t>(); ga.tn_parent = d_par.as<uint32_t>(); ga.tn_first = d_first.as<uint32_t>();
     ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.tn_nodes = d_tnn.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
-    ga.ff = d_ff.as<unsigned char>(); ga.svc_dense = d_svcd.as<uint32_t>(); ga.fail_dense = d_faild.as<uint32_t>();
+    ga.ffbuf = d_ff.as<unsigned char>(); ga.keybuf = d_key.as<u64>();
+    ga.svc_dense = d_dense.as<uint32_t>(); ga.fail_dense = d_dense.as<uint32_t>() + (size_t)2 * N; ga.lpos_dense = d_dense.as<uint32_t>() + (size_t)4 * N;
+    ga.tsumbuf = d_tsum.as<long long>(); ga.xroot = d_xroot.as<u64>(); ga.xadm = d_xadm.as<int32_t>(); ga.arena = d_arena.as<unsigned char>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
-    const size_t lds = (size_t)G_HCAP * (8 * 3 + 4 * 6) + (size_t)G_MAXT * (8 + 4 * 4 + 8) + (size_t)G_THREADS * (8 * 2 + 4 * 6) + (16 + 16 + 8) * 4 + (G_HCAP / 64) * 8 + G_LOG + 256;
-    HIPCHECK(e, ensure_big_lds(reinterpret_cast<const void*>(&k_groups), e->device));
-    const bool gdbg = getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16);
     hipEvent_t gev0 = nullptr, gev1 = nullptr;
     if (gdbg) { (void)hipEventCreate(&gev0); (void)hipEventCreate(&gev1); (void)hipEventRecord(gev0, st); }
-    hipLaunchKernelGGL(k_groups, dim3(1), dim3(G_THREADS), lds, st, ga);
-    HIPCHECK(e, hipGetLastError());
+    HIPCHECK(e, launch_groups2(ga, st, e->device));
     if (gdbg) {
         (void)hipEventRecord(gev1, st);
         (void)hipEventSynchronize(gev1);
@@ -2146,8 +2167,8 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
         (void)hipEventElapsedTime(&ms, gev0, gev1);
         Ctl c2{};
         (void)hipMemcpy(&c2, b.d_ctl.p, sizeof c2, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[swp] k_groups %.3f ms for %u groups | ticks(10ns): reset %llu scan %llu admit %llu walk %llu explain %llu writeback %llu\n", ms, n_groups,
-                c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5]);
+        fprintf(stderr, "[swp] k_groups2 %.3f ms for %u groups | ticks(10ns): wait-prep %llu reset %llu admit %llu load %llu walk %llu explain %llu writeback %llu patch %llu\n", ms, n_groups,
+                c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5], c2.cyc[6], c2.cyc[7]);
         (void)hipEventDestroy(gev0); (void)hipEventDestroy(gev1);
     }
     Ctl ctl{};
@@ -2157,17 +2178,23 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     HIPCHECK(e, hipStreamSynchronize(st));
     if (ctl.error != ERR_NONE) {
         e->dev_dynamic_dirty = true;   // device rows may be half-updated: the host mirror (untouched) is re-uploaded
-        return e->fail(SWP_ERANGE, "a group or its spread tree exceeds the device limits (heap slots %d, branches %d)", G_HCAP, G_MAXT);
+        if (ctl.error == ERR_GROUP_HANG) return e->fail(SWP_EHIP, "the group kernel's waves lost each other (a wait exceeded its bound): nothing was applied");
+        return e->fail(SWP_ERANGE, "a node's key left its range (>= 256 recent failures or >= 2^24 tasks of one service on a node)");
     }
+    return groups_apply_to_host(e, groups, sizes, n_groups, total, out_node);
+}
+
+// the host mirror follows the device: NodeInfo.addTask for every placement of the call
+static int groups_apply_to_host(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, uint64_t total, const int32_t* out_node) {
     uint64_t placed = 0;
-    off = 0;
+    uint32_t off = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {
         const swp_task_desc& d = groups[g];
         for (uint32_t i = 0; i < sizes[g]; ++i) {
             int32_t n = out_node[off + i];
             if (n < 0) continue;
             if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return e->fail(SWP_EHIP, "device returned an invalid node index %d", n);
-            host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+            host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
             ++placed;
         }
         off += sizes[g];

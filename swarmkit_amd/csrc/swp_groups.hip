@@ -1,0 +1,19 @@
+// swp_groups.hip — translation unit of the task-group kernel (k_groups2, swp_groups.hpp) and its launcher.
+#include <hip/hip_runtime.h>
+
+#include "swp_launch.hpp"
+#include "swp_wave.hpp"
+#define SWP_G2_KERNELS
+#include "swp_groups.hpp"
+
+namespace swpdev {
+
+// one workgroup for the whole tick: the machine wave + 15 helper waves (swp_groups.hpp)
+hipError_t launch_groups2(const Groups2Args& a, hipStream_t s, int dev) {
+    hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_groups2), dev);
+    if (r != hipSuccess) return r;
+    hipLaunchKernelGGL(k_groups2, dim3(1), dim3(G2_THREADS), g2_lds_bytes(), s, a);
+    return hipGetLastError();
+}
+
+}  // namespace swpdev

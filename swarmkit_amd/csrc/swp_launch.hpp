@@ -41,6 +41,10 @@ struct ShardApplyArgs;
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t s);
 hipError_t launch_shard_apply(const ShardApplyArgs& a, hipStream_t s);
 
+// task groups (swp_groups.hip)
+struct Groups2Args;
+hipError_t launch_groups2(const Groups2Args& a, hipStream_t s, int dev);
+
 // runs of identical tasks (swp_waterfill.hip)
 struct WaterArgs;
 hipError_t launch_waterfill(const WaterArgs& a, hipStream_t s);

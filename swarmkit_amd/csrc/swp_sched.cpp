@@ -638,9 +638,15 @@ class Scheduler {
                 allTasks_[tid] = newT;
                 addTask(n->second, newT);
                 pendingPreassignedTasks_.erase(tid);
+                // taskFitNode hands addTask the task the decision carries (scheduler.go:676-688): what Claim assigned is part of decision.new
+                auto st = allTasks_.find(tid);
+                if (st != allTasks_.end() && st->second.get("AssignedGenericResources")) newT.set("AssignedGenericResources", *st->second.get("AssignedGenericResources"));
             }
             lastDecisions_[tid] = PendingDecision{t, true};
-            decisions.push(decision(t, newT));
+            Value d = decision(t, newT);
+            const Value* ag = newT.get("AssignedGenericResources");
+            if (ag && ag->is_arr() && ag->size() > 0) d.set("AssignedGenericResources", *ag);
+            decisions.push(d);
         }
         return decisions;
     }
@@ -1245,8 +1251,7 @@ class Scheduler {
         lastDecisions_[tid] = PendingDecision{t, false};
         decisions.push(decision(t, newT));
     }
-    // A device call failed for these tasks (a group beyond the engine's heap capacity, a spread tree beyond its branch limit,
-    // ...): nothing of the call was applied, so the tasks go back on the queue — the Go shim routes a deferred task to the
+    // A device call failed for these tasks (a predicate set the engine refuses, a device error): nothing of the call was applied, so the tasks go back on the queue — the Go shim routes a deferred task to the
     // reference's own scheduleTaskGroup — and the tick carries on with the rest. One decision line per task says why.
     void defer(const std::string& tid, const Value& t, const Fail& f, Value& decisions) {
         unassignedTasks_.put(tid, t);
@@ -1321,6 +1326,7 @@ class Scheduler {
             }
             off += groups[g].size();
         }
+        pushTouched();   // groups with generic reservations: the nodes' available lists after place()'s Claim
     }
     void runOneOffs(const std::vector<Item>& run, const std::vector<swp_task_desc>& descs, Value& decisions) {
         if (run.empty()) return;

@@ -75,11 +75,15 @@ WV_DEV void lds_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAX
 WV_DEV void lds_xor64(u64* p, u64 v) { __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_or32(u32* p, u32 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void lds_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ---- flags between waves of one workgroup that do NOT meet at a barrier (k_r6_commit: the matching wave runs on while the others apply) ----
 // publish: everything this wave wrote to LDS before is visible to a wave that polls the new value; poll + spin_pause: the waiting side
 WV_DEV void lds_publish32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV u32 lds_poll32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// a counter several waves bump when their share of a job is done (k_groups2's helper waves): everything the wave wrote before —
+// LDS and global — is visible to the wave that polls the sum
+WV_DEV void lds_add_release32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void spin_pause() { __builtin_amdgcn_s_sleep(8); }   // ~0.2 µs off the CU's issue slots between two polls
 
 // ---- global memory ----

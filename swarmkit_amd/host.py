@@ -639,8 +639,15 @@ class PyHostScheduler:
                 self.all_tasks[tid] = new_t
                 self._add_task(ent, new_t)
                 del self.pending_preassigned[tid]
+                # taskFitNode hands addTask the task the decision carries (scheduler.go:676-688): what Claim assigned is part of decision.new
+                stored = self.all_tasks.get(tid, {})
+                if stored.get("AssignedGenericResources"):
+                    new_t["AssignedGenericResources"] = stored["AssignedGenericResources"]
             self.last_decisions[tid] = (t, True)
-            decisions.append(self._decision(t, new_t))
+            d = self._decision(t, new_t)
+            if new_t.get("AssignedGenericResources"):
+                d["AssignedGenericResources"] = new_t["AssignedGenericResources"]
+            decisions.append(d)
         return decisions
 
     @staticmethod
@@ -808,6 +815,7 @@ class PyHostScheduler:
                 else:
                     self._no_suitable_node(tid, t, hist[gi], decisions)
             off += len(g)
+        self._push_touched()   # groups with generic reservations: the nodes' available lists after _place's Claim
 
     def _run_one_offs(self, run, decisions):
         if not run:

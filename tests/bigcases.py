@@ -122,7 +122,70 @@ def run_refbench(s, nodes, tasks, net):
     return {"case": "refbench", "nodes": nodes, "tasks": tasks, "net": bool(net), "ticks": [h], "placed": [placed]}
 
 
+# ------------------------------------------------------------------------------------------------ task groups (SpecVersion set)
+def run_grouped(s, name="cfg3", T=None, N=None, services=None):
+    """SURVEY 8d's secondary mode: every task carries a SpecVersion, so a tick is S calls of scheduleTaskGroup with k = T / S."""
+    wl = synth.Workload(name, T=T, N=N, services=services, grouped=True)
+    for i in range(wl.N):
+        s.create_node(wl.node_doc(i))
+    for k in range(wl.S):
+        s.set_service(wl.service_id(k))
+    for j in range(wl.T):
+        s.create_task(wl.task_doc(j))
+    h, placed = tick_digest(s.tick())
+    return {"case": "grouped_" + name, "T": wl.T, "N": wl.N, "services": wl.S, "seed": hex(wl.seed), "ticks": [h], "placed": [placed]}
+
+
+def run_spread(s, N=6_000, groups=24, k=700, generic=False):
+    """Three spread levels (node.labels.az / rack / engine.labels.slot: 16 x 9 x 8 values, ~1 100 leaves of ~5 nodes), a constraint, tight
+    memory on a third of the services so that branches run out of room (noRoom, scheduler.go:810-813) and groups are left over; two
+    ticks (the second one re-tries the leftovers against the residuals the first one left)."""
+    GIB = 1 << 30
+    for i in range(N):
+        labels = {"az": "az%d" % (i % 16), "rack": "r%d" % ((i // 16) % 9), "tier": "a" if i % 4 else "b"}
+        if i % 37 == 0:
+            del labels["rack"]   # a missing label is the branch "" (nodeset.go:84-87)
+        res = {"NanoCPUs": int((1 + i % 4) * 1e9), "MemoryBytes": (1 + (i * 5) % 7) * GIB}
+        if generic:
+            res["Generic"] = [{"Discrete": {"Kind": "gpu", "Value": i % 5}}] if i % 5 else []
+        s.create_node({"ID": "n%08d" % i, "Spec": {"Annotations": {"Name": "node%d" % i, "Labels": labels}}, "Status": {"State": READY},
+                       "Description": {"Hostname": "h%d" % i, "Resources": res, "Engine": {"Labels": {"slot": "s%d" % ((i // 144) % 8)}}}})
+    prefs = [{"Spread": {"SpreadDescriptor": "node.labels.az"}}, {"Spread": {"SpreadDescriptor": "node.labels.rack"}},
+             {"Spread": {"SpreadDescriptor": "engine.labels.slot"}}]
+    j = 0
+    for g in range(groups):
+        sid = "svc%03d" % g
+        s.set_service(sid)
+        spec = {"Placement": {"Preferences": prefs[: 1 + g % 3] if g % 5 else prefs}}
+        if g % 4 == 1:
+            spec["Placement"]["Constraints"] = ["node.labels.tier==a"]
+        if g % 3 == 0:
+            spec["Resources"] = {"Reservations": {"MemoryBytes": (2 + g % 4) * GIB, "NanoCPUs": int(2e9)}}
+        if g % 7 == 3:
+            spec["Placement"]["MaxReplicas"] = 1 + g % 2
+        if generic and g % 2 == 0:
+            spec.setdefault("Resources", {}).setdefault("Reservations", {})["Generic"] = [{"Discrete": {"Kind": "gpu", "Value": 1 + g % 2}}]
+        for _ in range(k + 17 * g):
+            s.create_task({"ID": "t%08d" % j, "ServiceID": sid, "DesiredState": RUNNING, "Status": {"State": PENDING}, "SpecVersion": {"Index": 1}, "Spec": spec})
+            j += 1
+    ticks, counts = [], []
+    for _ in range(2):
+        h, c = tick_digest(s.tick())
+        ticks.append(h)
+        counts.append(c)
+    return {"case": "spread3", "N": N, "tasks": j, "ticks": ticks, "placed": counts}
+
+
 CASES = {
+    # task groups at BASELINE size (VERDICT r3 #1): cfg3 as 1 000 groups of 100, cfg1 at its stated 1 000 x 10, ONE group of 20 000
+    # tasks on 10 000 nodes (every heap takes its whole leaf; more than one task per node), three spread levels with > 512 leaves
+    "grouped_cfg3_full": lambda s: run_grouped(s, "cfg3"),
+    "grouped_cfg1_full": lambda s: run_grouped(s, "cfg1"),
+    "grouped_one_20k": lambda s: run_grouped(s, "cfg3", T=20_000, N=10_000, services=1),
+    "grouped_cfg4_mid": lambda s: run_grouped(s, "cfg4", T=60_000, N=20_000, services=300),
+    "grouped_spread3": lambda s: run_spread(s),
+    "grouped_spread3_generic": lambda s: run_spread(s, N=3_000, groups=12, k=800, generic=True),
+    "grouped_small": lambda s: run_grouped(s, "cfg3", T=3_000, N=400),
     "cfg4_full": lambda s: run_cfg4(s),
     "cfg4_mid": lambda s: run_cfg4(s, T=200_000, N=40_000),
     # cfg3 with (almost) every service its own reservation pair: 1 000 / 1 750 distinct cpu and 1 000 / 2 000 distinct memory values per batch

@@ -292,6 +292,8 @@ inline void lds_or64(u64* p, u64 v) { *p |= v; }
 inline void lds_xor64(u64* p, u64 v) { *p ^= v; }
 inline void lds_or32(u32* p, u32 v) { *p |= v; }
 inline void lds_andn64(u64* p, u64 v) { *p &= ~v; }
+inline void lds_add32(u32* p, u32 v) { *p += v; }
+inline void lds_add_release32(u32* p, u32 v) { *reinterpret_cast<volatile u32*>(p) += v; emu::wake_pollers(); }
 
 inline void g_add64(i64* p, i64 v) { *p += v; }
 inline void g_add32(u32* p, u32 v) { *p += v; }

@@ -357,6 +357,7 @@ int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int3
     }
     const uint32_t r = e->next();
     *first_fail = (r % 3u == 0u) ? (int32_t)((r >> 4) % SWP_NFILTERS) : -1;
+    if (e->name(SWP_SPACE_SERVICE, task->service).rfind("fits", 0) == 0) *first_fail = -1;   // (scripted verdict: tests that follow the oracle's state)
     e->say("check_node %s %s -> %d", e->name(SWP_SPACE_NODE_ID, node).c_str(), e->desc(*task).c_str(), *first_fail);
     return SWP_OK;
 }

@@ -1,0 +1,68 @@
+"""CPU: the task-group kernel's SOURCE (swarmkit_amd/csrc/swp_groups.hpp: the machine wave, its helper waves and the LDS command ring
+between them) run on fibers (tests/emu/wv_emu.hpp) against a sequential model written from the reference's text (tests/emu/emu_groups.cpp):
+every placement, every Explain histogram, every mutated node row, host-port row, generic count and per-service list. Built twice: with
+the product's LDS arena and with a tiny one, so that the global-memory instance of the machine runs the same cases. No GPU involved;
+the GPU parity is tests/test_engine_groups.py."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu")
+CSRC = os.path.join(HERE, "..", "swarmkit_amd", "csrc")
+
+
+def build(name, flags):
+    out = os.path.join(HERE, "_build", name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    srcs = [os.path.join(EMU, "emu_groups.cpp"), os.path.join(EMU, "wv_emu.hpp"), os.path.join(CSRC, "swp_groups.hpp"), os.path.join(CSRC, "swp_types.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        tmp = out + ".%d.tmp" % os.getpid()   # (xdist workers may build at the same time)
+        subprocess.run(["g++", "-O1", "-std=c++17"] + flags + ["-o", tmp, srcs[0]], check=True)
+        os.replace(tmp, out)
+    return out
+
+
+@pytest.fixture(scope="module")
+def emu_lds():
+    return build("emu_groups", [])
+
+
+@pytest.fixture(scope="module")
+def emu_global():
+    return build("emu_groups_small", ["-DG2_ARENA_LDS=3072"])
+
+
+# (seed, nodes, groups, largest group, spread trees, feature level, threads)
+#   feature 0: reservations + static filters; 1: + service lists (svcCount, failures >= 5), MaxReplicas; 2: + host ports, uncounted tasks;
+#   3: + generic reservations
+CASES = [
+    (1, 300, 12, 60, 1, 0, 256),       # no spread preferences: one leaf, one heap
+    (3, 300, 12, 60, 1, 0, 128),       # a single helper wave
+    (11, 500, 16, 80, 4, 1, 256),
+    (13, 500, 16, 80, 4, 2, 256),
+    (14, 500, 16, 80, 4, 3, 1024),     # the product's geometry: 15 helper waves
+    (21, 400, 14, 900, 5, 1, 256),     # groups far larger than the node set: leftovers, Explain histograms
+    (22, 400, 14, 900, 5, 2, 256),
+    (23, 400, 14, 900, 5, 3, 256),
+    (31, 3000, 10, 300, 6, 3, 512),    # 47 node words, trees of up to a few thousand branches
+    (32, 70, 40, 30, 3, 3, 256),       # barely more than one node word, many small groups
+    (33, 64, 25, 200, 2, 2, 128),      # exactly one node word
+    (41, 1500, 30, 5, 4, 3, 256),      # groups of a handful of tasks
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d-N%d-g%d-k%d-t%d-f%d-w%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6] // 64))
+def test_group_kernel_source_matches_sequential_model(emu_lds, case):
+    r = subprocess.run([emu_lds] + [str(x) for x in case] + ["v"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in (11, 14, 21, 23, 31, 32)], ids=lambda c: "seed%d-N%d-g%d-k%d-t%d-f%d-w%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6] // 64))
+def test_global_memory_instance(emu_global, case):
+    """The same machine with its working set in global memory (groups whose heaps exceed the LDS arena)."""
+    r = subprocess.run([emu_global] + [str(x) for x in case] + ["v"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr

@@ -25,7 +25,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # The cases whose digest AND engine side finish within seconds. The scripts at the full BASELINE size (cfg4 at 1M x 100k, the churn
 # at 60k / 100k x 10k: minutes of host-layer work each) live in tests/test_zz_baseline_size_scripts.py, the last file of the suite.
 CASES = ["refbench_small", "cfg5_churn_small", "cfg5_churn_12k", "cfg5_churn_mid", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid",
-         "cfg3m_small", "cfg3m_full", "cfg3m_mid"]
+         "cfg3m_small", "cfg3m_full", "cfg3m_mid",
+         # task groups (k_groups2): BASELINE sizes, one group larger than the node set, three spread levels with > 1 000 leaves, generic reservations
+         "grouped_small", "grouped_cfg1_full", "grouped_cfg3_full", "grouped_one_20k", "grouped_cfg4_mid", "grouped_spread3", "grouped_spread3_generic"]
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -38,9 +38,11 @@ def test_preferences(use_spec_version):
     sc.scenario_preferences(factory, use_spec_version)
 
 
+@pytest.mark.parametrize("with_generic", [False, True])
 @pytest.mark.parametrize("use_spec_version", [False, True])
-def test_multiple_preferences(use_spec_version):
-    sc.scenario_multiple_preferences(factory, use_spec_version, with_generic=False)
+def test_multiple_preferences(use_spec_version, with_generic):
+    """with_generic: the reference's own version (scheduler_test.go:808-1106) — every task reserves apple x 2 on top of its memory."""
+    sc.scenario_multiple_preferences(factory, use_spec_version, with_generic=with_generic)
 
 
 @pytest.mark.parametrize("name,T,N", [("cfg2", 3000, 150), ("cfg3", 4000, 500), ("cfg4", 4000, 600), ("cfg1", 600, 10)])
@@ -88,8 +90,7 @@ def test_spread_with_constraints_and_leftovers():
 
 def test_what_stays_on_the_go_path_is_refused_not_faked():
     """Refused at the event boundary (the task never enters a batch): generic reservations the engine does not take — Named, below 1,
-    a kind twice — and CSI cluster volumes. A GROUP with generic reservations is not refused but deferred: its decision line says so
-    and the task stays queued for the reference's own scheduleTaskGroup."""
+    a kind twice — and CSI cluster volumes. A GROUP with generic reservations is placed like a one-off task (round 3 deferred it)."""
     s = factory()
     s.create_node(sc.node("n1", Description={"Resources": {"NanoCPUs": 10**9, "MemoryBytes": 10**9, "Generic": sc.discrete("apple", 4)}}))
     s.set_service("svc")
@@ -101,10 +102,49 @@ def test_what_stays_on_the_go_path_is_refused_not_faked():
         s.task_desc(sc.pending("t2", "svc", Spec={"Container": {"Mounts": [{"Type": 4, "Source": "vol"}]}}))
     s.create_task(sc.pending("g1", "svc", 1, Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))   # SpecVersion 1: a group
     d = s.tick()
-    assert len(d) == 1 and d[0]["ID"] == "g1" and d[0].get("Deferred") is True and not d[0]["NodeID"]
+    assert len(d) == 1 and d[0]["ID"] == "g1" and not d[0].get("Deferred") and d[0]["NodeID"] == "n1"
+    assert d[0]["AssignedGenericResources"] == sc.discrete("apple", 1)
     s.create_task(sc.pending("o1", "svc", Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 3)}}}))       # one-off: placed
     d = {x["ID"]: x for x in s.tick()}
     assert d["o1"]["NodeID"] == "n1" and d["o1"]["AssignedGenericResources"] == sc.discrete("apple", 3)
+    s.create_task(sc.pending("g2", "svc", 1, Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))   # nothing left
+    d = s.tick()
+    assert len(d) == 1 and not d[0]["NodeID"] and d[0]["Err"] == "no suitable node (insufficient resources on 1 node)"
+
+
+def test_groups_with_generic_reservations_vs_oracle():
+    """Task groups that reserve Discrete generic resources on nodes that advertise Discrete counts and Named sets (the counts decide on
+    the device; which named values a task holds is the host layer's Claim): decisions incl. AssignedGenericResources against the oracle,
+    two ticks so that the second one sees the first one's claims."""
+    ev = []
+    for i in range(60):
+        gen = sc.discrete("gpu", i % 4) if i % 3 else sc.named("gpu", *["g%d-%d" % (i, q) for q in range(1 + i % 3)])
+        gen = gen + (sc.discrete("fpga", 2) if i % 5 == 0 else [])
+        ev.append(("create_node", sc.node(f"n{i:02d}", Spec={"Annotations": {"Labels": {"az": f"az{i % 4}"}}},
+                                          Description={"Resources": {"NanoCPUs": int(4e9), "MemoryBytes": int(4e9), "Generic": gen}})))
+    for sname in ("svcA", "svcB", "svcC", "svcD"):
+        ev.append(("set_service", sname))
+    prefs = [{"Spread": {"SpreadDescriptor": "node.labels.az"}}]
+    for i in range(40):
+        ev.append(("create_task", sc.pending(f"a{i:03d}", "svcA", 1, Spec={"Resources": {"Reservations": {"Generic": sc.discrete("gpu", 1), "MemoryBytes": int(5e8)}}})))
+    for i in range(30):
+        ev.append(("create_task", sc.pending(f"b{i:03d}", "svcB", 1, Spec={"Placement": {"Preferences": prefs},
+                                                                         "Resources": {"Reservations": {"Generic": sc.discrete("gpu", 2)}}})))
+    for i in range(20):
+        ev.append(("create_task", sc.pending(f"c{i:03d}", "svcC", 3, Spec={"Resources": {"Reservations": {"Generic": sc.discrete("gpu", 1) + sc.discrete("fpga", 1)}}})))
+    ev.append(("tick",))
+    for i in range(25):
+        ev.append(("create_task", sc.pending(f"d{i:03d}", "svcD", 1, Spec={"Resources": {"Reservations": {"Generic": sc.discrete("gpu", 1)}}})))
+    ev.append(("tick",))
+    o, e = orc.Oracle(), swhost.HostScheduler()
+    for evt in ev:
+        if evt[0] == "tick":
+            key = lambda d: (d["ID"], d["NodeID"], d["Err"], d["State"], str(d.get("AssignedGenericResources")))
+            do, de = sorted(map(key, o.tick())), sorted(map(key, e.tick()))
+            assert do == de, [(a, b) for a, b in zip(do, de) if a != b][:5]
+        else:
+            for s in (o, e):
+                getattr(s, evt[0])(*evt[1:])
 
 
 def test_churn_rounds():

@@ -120,3 +120,30 @@ def test_event_scripts_keep_the_available_lists_of_both_twins_equal_to_the_oracl
         check()
     logs = [fakelib.take_log(s.e) for s in hs[1:]]
     assert logs[0] == logs[1]
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_preassigned_decisions_carry_what_claim_assigned(seed):
+    """processPreassignedTasks' decisions must carry AssignedGenericResources (taskFitNode hands addTask the very task the
+    decision holds, scheduler.go:676-688) — named values included — exactly as the oracle's decision.new does."""
+    rng = random.Random(7000 + seed)
+    hs = hosts()
+    docs = {i: node_doc(rng, i) for i in range(3)}
+    for d in docs.values():
+        for s in hs:
+            s.create_node(d)
+    for s in hs:
+        s.set_service("fits-svc")
+    for tid in range(8):
+        i = rng.randrange(3)
+        avail = gres.counts(T(hs[0].node_info("n%d" % i)["AvailableResources"]["Generic"]))
+        kinds = [k for k in KINDS if avail.get(k, 0) >= 1]
+        want = [{"Discrete": {"Kind": k, "Value": 1}} for k in rng.sample(kinds, min(len(kinds), rng.randrange(0, 3)))]
+        t = {"ID": "p%03d" % tid, "ServiceID": "fits-svc", "NodeID": "n%d" % i, "DesiredState": orc.RUNNING, "Status": {"State": orc.PENDING},
+             "Spec": {"Resources": {"Reservations": {"NanoCPUs": 10**8, "Generic": want}}}}
+        for s in hs:
+            s.create_task(t)
+        ds = [sorted((d["ID"], d["NodeID"], d["State"], str(d.get("AssignedGenericResources"))) for d in s.process_preassigned()) for s in hs]
+        assert ds[0] == ds[1] == ds[2], (seed, tid, ds)
+        if want:
+            assert "Kind" in ds[0][0][3]
