@@ -2105,7 +2105,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
         if (ab > G2_ARENA_LDS) arena_bytes = std::max(arena_bytes, ab);   // this group's working set lives in global memory
         off += sizes[g];
     }
-    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_tnn, d_leaf, d_ff, d_key, d_dense, d_tsum, d_xroot, d_xadm, d_arena, d_lcnt, d_out, d_hist;
+    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_tnn, d_leaf, d_ff, d_key, d_ckey, d_min, d_dense, d_tsum, d_xroot, d_xadm, d_arena, d_lcnt, d_out, d_hist;
     if ((rc = upload(e, d_recs, recs))) return rc;
     if ((rc = upload(e, d_tree_off, tree_off))) return rc;
     if ((rc = upload(e, d_par, tn_parent))) return rc;
@@ -2117,6 +2117,8 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     if ((rc = upload(e, d_lcnt, b.list_cnt0))) return rc;
     HIPCHECK(e, d_ff.reserve((size_t)2 * N));
     HIPCHECK(e, d_key.reserve((size_t)2 * N * 8));
+    HIPCHECK(e, d_ckey.reserve((size_t)2 * N * 8));
+    HIPCHECK(e, d_min.reserve((size_t)2 * Wn * 8));
     HIPCHECK(e, d_dense.reserve((size_t)6 * N * 4));
     HIPCHECK(e, d_tsum.reserve((size_t)2 * max_ntn * 8));
     HIPCHECK(e, d_xroot.reserve((size_t)max_ntn * 8));
@@ -2153,7 +2155,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     ga.list_off = b.d_list_off.as<uint32_t>(); ga.list_cnt = d_lcnt.as<uint32_t>();
     ga.tree_off = d_tree_off.as<uint32_t>(); ga.tn_parent = d_par.as<uint32_t>(); ga.tn_first = d_first.as<uint32_t>();
     ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.tn_nodes = d_tnn.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
-    ga.ffbuf = d_ff.as<unsigned char>(); ga.keybuf = d_key.as<u64>();
+    ga.ffbuf = d_ff.as<unsigned char>(); ga.keybuf = d_key.as<u64>(); ga.minbuf = d_min.as<u64>(); ga.ckeybuf = d_ckey.as<u64>();
     ga.svc_dense = d_dense.as<uint32_t>(); ga.fail_dense = d_dense.as<uint32_t>() + (size_t)2 * N; ga.lpos_dense = d_dense.as<uint32_t>() + (size_t)4 * N;
     ga.tsumbuf = d_tsum.as<long long>(); ga.xroot = d_xroot.as<u64>(); ga.xadm = d_xadm.as<int32_t>(); ga.arena = d_arena.as<unsigned char>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
@@ -2167,8 +2169,8 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
         (void)hipEventElapsedTime(&ms, gev0, gev1);
         Ctl c2{};
         (void)hipMemcpy(&c2, b.d_ctl.p, sizeof c2, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[swp] k_groups2 %.3f ms for %u groups | ticks(10ns): wait-prep %llu reset %llu admit %llu load %llu walk %llu explain %llu writeback %llu patch %llu\n", ms, n_groups,
-                c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5], c2.cyc[6], c2.cyc[7]);
+        fprintf(stderr, "[swp] k_groups2 %.3f ms for %u groups | shader cycles: wait-prep %llu reset %llu admit %llu load %llu walk %llu explain %llu writeback %llu patch %llu | in walk: ordered %llu fill %llu | admission: words %llu candidates %llu heap ops %llu replay cycles %llu parallel pushes %llu load-wait cycles %llu\n", ms, n_groups,
+                c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5], c2.cyc[6], c2.cyc[7], c2.m_cyc[0], c2.m_cyc[1], c2.l_cyc[0], c2.l_cyc[1], c2.l_cyc[2], c2.l_cyc[3], c2.l_cyc[4], c2.l_cyc[5]);
         (void)hipEventDestroy(gev0); (void)hipEventDestroy(gev1);
     }
     Ctl ctl{};

@@ -101,6 +101,8 @@ struct Groups2Args {
     // scratch, all double-buffered by group parity
     unsigned char* ffbuf;    // [2][n_nodes] first failing filter of Pipeline.Process, G2_FF_PASS, G2_FF_ABSENT
     u64* keybuf;             // [2][n_nodes] nodeLess key at tree() time
+    u64* ckeybuf;            // [2][n_nodes] the key again for a node that passes every filter, KEY_NONE otherwise: all the admission scan reads
+    u64* minbuf;             // [2][n_words] the lowest key among the word's nodes that pass every filter (KEY_NONE: none passes)
     u32* svc_dense;          // [2][n_nodes] the group's service: ActiveTasksCountByService per node (zero outside the list)
     u32* fail_dense;         // [2][n_nodes] recent failures (only values >= maxFailures are listed)
     u32* lpos_dense;         // [2][n_nodes] list entry of the node + 1, 0: not listed
@@ -127,10 +129,11 @@ static_assert(sizeof(G2Frame) == 64, "G2Frame layout");
 
 inline __host__ __device__ size_t g2_arena_bytes(u32 S, u32 ntn, u32 ngen, u32 depth, u32 k) {
     const size_t fw = (size_t)(S + 63) / 64 + 1, kt = k < S ? k : S;
-    return 8 * (3 * (size_t)S + 2 * (size_t)ntn + fw) + 64 * ((size_t)depth + 2) + 4 * (4 * (size_t)S + kt + (size_t)S * ngen + 5 * (size_t)ntn) + 64;
+    return 32 * (size_t)S + 64 * ((size_t)depth + 2) + 8 * (2 * (size_t)ntn + fw) + 4 * ((size_t)S * ngen + 2 * kt + 6 * (size_t)ntn) + 64;
 }
 // mailbox, staging of one chunk of candidates, a few scalars
-#define G2_LDS_FIXED 4096
+#define G2_LDS_FIXED 8192
+#define G2_VISW 8              // node words whose candidate keys are staged through LDS together
 inline __host__ __device__ size_t g2_lds_bytes() { return (size_t)G2_LDS_FIXED + G2_ARENA_LDS; }
 
 #ifdef SWP_G2_KERNELS
@@ -143,95 +146,164 @@ WV_DEV u64 g2_key(u32 fail, u32 svc, u32 total) {
 WV_DEV bool g2_key_ok(u32 fail, u32 svc) { return fail < 256u && svc < (1u << 24); }
 #define G2_KEY_STEP ((1ull << 32) + 1ull)   // one more task of the service on the node: svcCount + 1, ActiveTasksCount + 1
 
+// A heap position holds ONE 16-byte record — key, node, index into the touched list — so a sift step is one wide load per element
+// (both children of a position are adjacent: 32 bytes), and the node's residuals ride in a second 16-byte record at the SAME
+// position once the leaf is sorted: nothing the fill loop touches is behind an indirection.
+struct alignas(16) G2Ent {
+    u64 key;
+    u32 node;
+    u32 tix;     // G2_NONE until the node got its first task of the group, then its index in tnode / tcount
+};
+struct alignas(16) G2Res {
+    i64 cpu, mem;
+};
+static_assert(sizeof(G2Ent) == 16 && sizeof(G2Res) == 16, "heap record layout");
+
 struct G2Arena {
-    u64* HK;            // heap position -> key
-    i64* s_cpu;         // slot state (a slot's state never moves; heap positions hold (key, slot))
-    i64* s_mem;
+    G2Ent* HE;          // [slots] heap position -> entry
+    G2Res* PS;          // [slots] residual cpu / memory of the entry's node (loaded once the leaf is sorted)
     i64* tsum;          // decisionTree.tasks
     u64* rootkey;       // per leaf: heap root key as tree() left it (Explain)
     u64* failed;        // fill loop: positions that failed Process (failedConstraints, scheduler.go:846)
     G2Frame* st;
-    u32* HP;            // heap position -> slot
-    u32* s_node;
-    u32* s_placed;
-    u32* live;          // slots ever filled
-    u32* touched;       // slots that got a task
-    int32_t* s_gen;     // [slot][n_gen] generic counts of the group's kinds
+    int32_t* gen;       // [slot][n_gen] generic counts of the group's kinds, by position like PS
+    u32* tnode;         // nodes that got a task ...
+    u32* tcount;        // ... and how many
     u32* h_off;         // first heap position of a leaf
-    int32_t* h_len;     // nodeMaxHeap.length
+    int32_t* h_len;     // nodeMaxHeap.length while tree() runs
     int32_t* h_cnt;     // len(nodeMaxHeap.nodes)
     int32_t* h_adm;     // length as tree() left it
     u32* noroom;        // per tree node: member of its parent's noRoom set (scheduler.go:787,810-813)
+    u32* h_vis;         // the leaf was handed to scheduleNTasksOnNodes before (orderedNodes filters from the second call on)
 };
 WV_DEV void g2_carve(G2Arena& A, unsigned char* p, u32 S, u32 ntn, u32 ngen, u32 depth, u32 k) {
     const size_t fw = (size_t)(S + 63) / 64 + 1, kt = k < S ? k : S;
-    A.HK = reinterpret_cast<u64*>(p); p += 8 * (size_t)S;
-    A.s_cpu = reinterpret_cast<i64*>(p); p += 8 * (size_t)S;
-    A.s_mem = reinterpret_cast<i64*>(p); p += 8 * (size_t)S;
+    A.HE = reinterpret_cast<G2Ent*>(p); p += 16 * (size_t)S;
+    A.PS = reinterpret_cast<G2Res*>(p); p += 16 * (size_t)S;
+    A.st = reinterpret_cast<G2Frame*>(p); p += 64 * ((size_t)depth + 2);
     A.tsum = reinterpret_cast<i64*>(p); p += 8 * (size_t)ntn;
     A.rootkey = reinterpret_cast<u64*>(p); p += 8 * (size_t)ntn;
     A.failed = reinterpret_cast<u64*>(p); p += 8 * fw;
-    A.st = reinterpret_cast<G2Frame*>(p); p += 64 * ((size_t)depth + 2);
-    A.HP = reinterpret_cast<u32*>(p); p += 4 * (size_t)S;
-    A.s_node = reinterpret_cast<u32*>(p); p += 4 * (size_t)S;
-    A.s_placed = reinterpret_cast<u32*>(p); p += 4 * (size_t)S;
-    A.live = reinterpret_cast<u32*>(p); p += 4 * (size_t)S;
-    A.touched = reinterpret_cast<u32*>(p); p += 4 * kt;
-    A.s_gen = reinterpret_cast<int32_t*>(p); p += 4 * (size_t)S * ngen;
+    A.gen = reinterpret_cast<int32_t*>(p); p += 4 * (size_t)S * ngen;
+    A.tnode = reinterpret_cast<u32*>(p); p += 4 * kt;
+    A.tcount = reinterpret_cast<u32*>(p); p += 4 * kt;
     A.h_off = reinterpret_cast<u32*>(p); p += 4 * (size_t)ntn;
     A.h_len = reinterpret_cast<int32_t*>(p); p += 4 * (size_t)ntn;
     A.h_cnt = reinterpret_cast<int32_t*>(p); p += 4 * (size_t)ntn;
     A.h_adm = reinterpret_cast<int32_t*>(p); p += 4 * (size_t)ntn;
-    A.noroom = reinterpret_cast<u32*>(p);
+    A.noroom = reinterpret_cast<u32*>(p); p += 4 * (size_t)ntn;
+    A.h_vis = reinterpret_cast<u32*>(p);
 }
 
 // container/heap (go stdlib) over nodeMaxHeap: Less(i,j) = lessFunc(nodes[j], nodes[i]) (nodeheap.go:17-20). up / down move ONE
 // element along a path and swap it with what it meets: the element rides in registers and every step copies the other one into the
-// hole — the same comparisons and the same final arrangement as the swap sequence, one memory round trip per level (both children
-// are requested together).
-WV_DEV void g2_up(const G2Arena& A, u32 base, int j0) {
+// hole — the same comparisons and the same final arrangement as the swap sequence, one memory round trip per level.
+// up(j0) for the element `e` that is (conceptually) at j0; returns its final position (it is stored there).
+WV_DEV int g2_up_val(const G2Arena& A, u32 base, int j0, G2Ent e) {
     int j = j0;
-    const u64 kv = A.HK[base + j];
-    const u32 pv = A.HP[base + j];
-    for (;;) {
-        const int i = (j - 1) / 2;   // j == 0: i == 0 (Go's integer division truncates, too)
-        if (i == j) break;
-        const u64 ki = A.HK[base + i];
-        const u32 pi = A.HP[base + i];
-        if (!(ki < kv)) break;       // !Less(j, i)
-        A.HK[base + j] = ki;
-        A.HP[base + j] = pi;
+    while (j > 0) {                  // j == 0: i == j, break (Go's (j-1)/2 truncates to 0)
+        const int i = (j - 1) / 2;
+        const G2Ent pe = A.HE[base + i];
+        if (!(pe.key < e.key)) break;   // !Less(j, i)
+        A.HE[base + j] = pe;
         j = i;
     }
-    if (j != j0) {
-        A.HK[base + j] = kv;
-        A.HP[base + j] = pv;
-    }
+    A.HE[base + j] = e;
+    return j;
 }
-// down(i0, n) for the element (kv, pv) that is (conceptually) at i0; the caller has NOT necessarily stored it there. Returns the
-// element's final position; it is stored there unless `lazy_same` and it did not move.
-WV_DEV int g2_down_val(const G2Arena& A, u32 base, int i0, int n, u64 kv, u32 pv) {
+// Records travel BY VALUE and are picked field by field: a record that is selected as a whole, or handed out through a reference,
+// ends up in scratch memory (a global-memory round trip inside the serial chain).
+WV_DEV G2Ent g2_pick(bool c, G2Ent x, G2Ent y) {
+    G2Ent r;
+    r.key = c ? x.key : y.key;
+    r.node = c ? x.node : y.node;
+    r.tix = c ? x.tix : y.tix;
+    return r;
+}
+struct G2Down {
+    int pos;     // where the element came to rest
+    G2Ent top;   // the record that ended up AT i0 (what a caller that tracks the root in registers wants to know)
+};
+// down(i0, n) for the element `e` that is (conceptually) at i0 (it is stored where it comes to rest)
+WV_DEV G2Down g2_down_val(const G2Arena& A, u32 base, int i0, int n, G2Ent e) {
     int i = i0;
+    G2Ent top = e;
     for (;;) {
         const int j1 = 2 * i + 1;
         if (j1 >= n || j1 < 0) break;
         const int j2 = j1 + 1;
         const bool two = j2 < n;
-        const u64 k1 = A.HK[base + j1], k2 = two ? A.HK[base + j2] : 0ull;
-        const u32 p1 = A.HP[base + j1], p2 = two ? A.HP[base + j2] : 0u;
-        const bool right = two && k1 < k2;   // Less(j2, j1)
-        const u64 kj = right ? k2 : k1;
-        if (!(kv < kj)) break;               // !Less(j, i)
-        A.HK[base + i] = kj;
-        A.HP[base + i] = right ? p2 : p1;
+        const G2Ent c1 = A.HE[base + j1];
+        const G2Ent c2 = A.HE[base + (two ? j2 : j1)];
+        const bool right = two && c1.key < c2.key;   // Less(j2, j1)
+        const G2Ent cj = g2_pick(right, c2, c1);
+        if (!(e.key < cj.key)) break;                // !Less(j, i)
+        A.HE[base + i] = cj;
+        top = g2_pick(i == i0, cj, top);
         i = right ? j2 : j1;
     }
-    A.HK[base + i] = kv;
-    A.HP[base + i] = pv;
-    return i;
+    A.HE[base + i] = e;
+    G2Down r;
+    r.pos = i;
+    r.top = top;
+    return r;
 }
-WV_DEV bool g2_down(const G2Arena& A, u32 base, int i0, int n) {
-    return g2_down_val(A, base, i0, n, A.HK[base + i0], A.HP[base + i0]) > i0;
+// the same for a leaf that is handed out again (orderedNodes' second call on): the residual records move with the entries
+WV_DEV void g2_move_full(const G2Arena& A, u32 ngen, u32 dst, u32 src) {
+    A.HE[dst] = A.HE[src];
+    A.PS[dst] = A.PS[src];
+    for (u32 q = 0; q < ngen; ++q) A.gen[(size_t)dst * ngen + q] = A.gen[(size_t)src * ngen + q];
+}
+WV_DEV bool g2_down_full(const G2Arena& A, u32 ngen, u32 base, int i0, int n) {   // swap-based: only the rare second hand-out pays it
+    int i = i0;
+    for (;;) {
+        const int j1 = 2 * i + 1;
+        if (j1 >= n || j1 < 0) break;
+        int j = j1;
+        const int j2 = j1 + 1;
+        if (j2 < n && A.HE[base + j1].key < A.HE[base + j2].key) j = j2;
+        if (!(A.HE[base + i].key < A.HE[base + j].key)) break;
+        const G2Ent te = A.HE[base + i]; A.HE[base + i] = A.HE[base + j]; A.HE[base + j] = te;
+        const G2Res tr = A.PS[base + i]; A.PS[base + i] = A.PS[base + j]; A.PS[base + j] = tr;
+        for (u32 q = 0; q < ngen; ++q) {
+            const int32_t tg = A.gen[(size_t)(base + i) * ngen + q];
+            A.gen[(size_t)(base + i) * ngen + q] = A.gen[(size_t)(base + j) * ngen + q];
+            A.gen[(size_t)(base + j) * ngen + q] = tg;
+        }
+        i = j;
+    }
+    return i > i0;
+}
+// heap-sort of one leaf in place: heap.Pop until empty (decision_tree.go:46-49; Pop = Swap(0, n-1); down(0, n-1); length--).
+// The root rides in registers: after a sift it is either the element that was sifted (it did not move) or the child that took its place.
+WV_DEV void g2_pop_all(const G2Arena& A, u32 base, int len) {
+    if (len < 2) return;
+    G2Ent root = A.HE[base];
+    G2Ent last = A.HE[base + len - 1];
+    for (int n = len - 1; n >= 1; --n) {
+        // the element the NEXT pop takes from the end is requested now; only this pop's sifted element can land on it
+        const G2Ent nlast = A.HE[base + (n >= 2 ? n - 1 : 0)];
+        A.HE[base + n] = root;
+        int fin = 0;
+        if (n >= 3) {   // equal keys are the rule: the element from the end usually stays at the root (one compare, no loop)
+            const G2Ent c1 = A.HE[base + 1], c2 = A.HE[base + 2];
+            const bool right = c1.key < c2.key;
+            const G2Ent cj = g2_pick(right, c2, c1);
+            if (!(last.key < cj.key)) {
+                A.HE[base] = last;
+                root = last;
+            } else {
+                A.HE[base] = cj;
+                root = cj;
+                fin = g2_down_val(A, base, right ? 2 : 1, n, last).pos;
+            }
+        } else {
+            const G2Down d = g2_down_val(A, base, 0, n, last);
+            fin = d.pos;
+            root = d.top;
+        }
+        last = g2_pick(fin == n - 1, last, nlast);
+    }
 }
 
 // (a group's record is copied to registers field by field; its two small arrays are only ever read through the record in
@@ -244,7 +316,8 @@ WV_DEV bool g2_res_ok(const Groups2Args& a, const GroupRec2& G, const GroupRec2*
 }
 
 // Pipeline.Process on node n for group G (pipeline.go:56-68: the FIRST failing filter in checklist order) and the node's key
-WV_DEV void g2_eval_node(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n) {
+// (returns the key of a node that passes, KEY_NONE otherwise)
+WV_DEV u64 g2_eval_node(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n) {
     const u32 N = a.n_nodes, Wn = a.n_words, w = n >> 6;
     const u64 bit = 1ull << (n & 63);
     u32 ff = G2_FF_PASS;
@@ -270,6 +343,15 @@ WV_DEV void g2_eval_node(const Groups2Args& a, const GroupRec2& G, const GroupRe
     }
     a.ffbuf[(size_t)b * N + n] = (unsigned char)ff;
     a.keybuf[(size_t)b * N + n] = key;
+    const u64 ck = ff == G2_FF_PASS ? key : KEY_NONE;
+    a.ckeybuf[(size_t)b * N + n] = ck;
+    return ck;
+}
+WV_DEV u64 g2_wave_min64(u64 v) {
+    const u32 hi = (u32)(v >> 32), lo = (u32)v;
+    const u32 mh = wv::min_u32(hi);
+    const u32 ml = wv::min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((u64)mh << 32) | ml;
 }
 
 struct G2Mail {   // LDS
@@ -284,12 +366,11 @@ struct G2Mail {   // LDS
     // what lane 0 of the machine hands to its other lanes
     u32 sh[16];
 };
-enum { SH_LEN0 = 0, SH_NLIVE = 1, SH_LEFT = 2, SH_NTOUCH = 3, SH_ERR = 4, SH_LASTP = 5, SH_C1 = 6, SH_C5 = 7, SH_C6 = 8, SH_FPASS = 9, SH_ROOT_LO = 10, SH_ROOT_HI = 11 };
+enum { SH_LEFT = 2, SH_NTOUCH = 3, SH_ERR = 4, SH_LASTP = 5, SH_C1 = 6, SH_C5 = 7, SH_C6 = 8, SH_FPASS = 9 };
 
-struct G2Stage {   // LDS: the candidates of one 64-node chunk, compacted in node order
-    u64 key[64];
-    u32 node[64];
-    u32 leaf[64];
+struct G2Stage {   // LDS: the candidates of one 64-node word, compacted in node order: {key, node, leaf} as one 16-byte record each
+    G2Ent ent[64];
+    u32 scan[64];  // scratch of the offset scan over the tree's leaves
 };
 
 WV_DEV bool g2_wait_ge(const u32* p, u32 want, G2Mail* mb) {
@@ -341,9 +422,12 @@ WV_DEV void g2_helper(const Groups2Args& a, G2Mail* mb, u32 hid, u32 nh) {
                     for (u32 t = leaf_of[n]; t != G2_NONE; t = a.tn_parent[tbase + t]) wv::g_add64(&a.tsumbuf[(size_t)b * a.max_ntn + t], (i64)sv);
             }
         } else if (op == G2_OP_EVAL) {
+            // + the word's lowest passing key: what lets the machine skip 64 nodes at a time. (Keys only grow and nodes only drop out
+            // while the tick runs, so a minimum taken early stays a lower bound: the patch after a write-back need not touch it.)
             for (u32 w = hid; w < Wn; w += nh) {
                 const u32 n = w * 64u + lane;
-                if (n < N) g2_eval_node(a, G, Gm, b, n);
+                const u64 mk = g2_wave_min64(n < N ? g2_eval_node(a, G, Gm, b, n) : KEY_NONE);
+                if (lane == 0) a.minbuf[(size_t)b * Wn + w] = mk;
             }
         } else if (op == G2_OP_EXPLAIN) {
             // Every passing Process zeroes the counters (pipeline.go:64-66), so only the calls AFTER the last passing one count. Inside
@@ -390,16 +474,16 @@ WV_DEV void g2_post(G2Mail* mb, G2Post& P, u32 op, u32 gi) {
 // One group, state in the arena A (LDS instance: L == true). Returns false when the launch must end (error / hang).
 // gi + 1 < n_groups: `eval_next` is the ring position behind the next group's EVAL command if it was posted ahead (0: it was not,
 // dep_prev); on return it always is.
-template <bool L>
+// GEN: the group reserves generic resources (the instance without them carries none of that code)
+template <bool L, bool GEN>
 WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned char* arena_base, const GroupRec2& G, u32 gi, u64* gt, G2Post& P, u32 nh,
                      u32& eval_next) {
     const u32 lane = wv::lane(), N = a.n_nodes, Wn = a.n_words, b = gi & 1u, k = G.k;
     const u32 tbase = a.tree_off[G.tree], ntn = a.tree_off[G.tree + 1] - tbase;
     const u32* leaf_of = a.leaf_of_node + (size_t)G.tree * N;
-    const unsigned char* ffb = a.ffbuf + (size_t)b * N;
-    const u64* keyb = a.keybuf + (size_t)b * N;
     const bool single = ntn == 1;
     const GroupRec2* Gm = a.g + gi;
+    const u32 NG = GEN ? G.n_gen : 0u;   // generic kinds the group reserves
     G2Arena A;
     g2_carve(A, arena_base, G.n_slots, ntn, G.n_gen, a.max_depth, k);
     u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
@@ -413,14 +497,14 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             u32 cap = 0;
             if (i < ntn) {
                 A.tsum[i] = a.tsumbuf[(size_t)b * a.max_ntn + i];
-                A.h_len[i] = 0; A.h_cnt[i] = 0; A.h_adm[i] = 0; A.noroom[i] = 0;
+                A.h_len[i] = 0; A.h_cnt[i] = 0; A.h_adm[i] = 0; A.noroom[i] = 0; A.h_vis[i] = 0;
                 if (a.tn_nchild[tbase + i] == 0) cap = min(k, a.tn_nodes[tbase + i]);
             }
-            // exclusive prefix over the wave (ntn is small: a shuffle-free ballot-per-bit scan would not pay; lanes add through LDS)
-            sg->node[lane] = cap;
+            // exclusive prefix over the wave (ntn is small: lanes add through LDS)
+            sg->scan[lane] = cap;
             wv::wave_sync();
             u32 before = 0;
-            for (u32 q = 0; q < lane; ++q) before += sg->node[q];
+            for (u32 q = 0; q < lane; ++q) before += sg->scan[q];
             u32 tot = 0;
             if (lane == 63) tot = before + cap;
             tot = wv::readlane(tot, 63);
@@ -432,132 +516,372 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             if (lane == 0) a.ctl->error = ERR_GROUP_RANGE;
             return false;
         }
-        if (lane == 0) {
-            mb->sh[SH_LEN0] = 0; mb->sh[SH_NLIVE] = 0; mb->sh[SH_ERR] = 0; mb->sh[SH_LASTP] = 0;
-            mb->sh[SH_ROOT_LO] = 0; mb->sh[SH_ROOT_HI] = 0;
+        {
+            const u32 kt = k < G.n_slots ? k : G.n_slots;
+            for (u32 i = lane; i < kt; i += 64) A.tcount[i] = 0;
         }
+        if (lane == 0) { mb->sh[SH_ERR] = 0; mb->sh[SH_LASTP] = 0; }
         wv::wave_sync();
     }
     G2_TICK(1);
 
     // ---------- tree(): heap admission in node order (nodeset.go:107-120) ----------
     {
-        u32 len0 = 0;          // single leaf: its heap length and root key ride in registers
+        u32 len0 = 0;          // single leaf: its heap length and root key ride in registers (every lane's copy, for the pre-filter)
         u64 root0 = 0;
-        u32 nlive = 0, lastp = 0;   // lane 0 only
-        u32 ffn = lane < N ? (u32)ffb[lane] : G2_FF_ABSENT;
-        u64 keyn = lane < N ? keyb[lane] : 0ull;
-        for (u32 n0 = 0; n0 < N; n0 += 64) {
-            const u32 n = n0 + lane;
-            const u32 ff = ffn;
-            const u64 key = keyn;
-            if (n0 + 64 < N) {   // the next chunk's loads are in flight while this one is replayed
-                const u32 nn = n + 64;
-                ffn = nn < N ? (u32)ffb[nn] : G2_FF_ABSENT;
-                keyn = nn < N ? keyb[nn] : 0ull;
-            }
-            bool cand = ff == G2_FF_PASS;
-            u32 leaf = 0;
-            if (cand) {
-                if (single) cand = len0 < k || key < root0;
-                else {
-                    leaf = leaf_of[n];
-                    const int len = A.h_len[leaf];
-                    cand = len < (int)k || key < A.HK[A.h_off[leaf]];
-                }
-            }
-            const u64 bal = wv::ballot(cand);
-            if (bal == 0) continue;
-            if (cand) {
-                const u32 pos = wv::mbcnt(bal);
-                sg->key[pos] = key; sg->node[pos] = n; sg->leaf[pos] = leaf;
-            }
-            wv::wave_sync();
-            if (lane == 0) {
-                const u32 ne = (u32)wv::popc64(bal);
-                // the leaf of the last entry, its heap's base / length / root key ride in registers: a run of entries of one leaf
-                // (every group without spread preferences) pays one round trip per entry that does not enter the heap
-                u32 c_lf = G2_NONE, base = 0;
-                int len = 0;
-                u64 root = 0;
-                for (u32 i = 0; i < ne; ++i) {
-                    const u32 lf = sg->leaf[i];
-                    const u64 ek = sg->key[i];
-                    if (lf != c_lf) {
-                        if (c_lf != G2_NONE) A.h_len[c_lf] = len;
-                        c_lf = lf;
-                        base = A.h_off[lf];
-                        len = A.h_len[lf];
-                        root = len ? A.HK[base] : 0ull;
+        u32 lastp = 0;         // node + 1 of the last Process that returned true inside tree() (every lane's copy)
+        u32 c_lf = G2_NONE, hbase = 0;   // lane 0 only: the leaf of the last replayed entry, its heap's base / length / root key
+        int hlen = 0;
+        u64 hroot = 0;
+        // One leaf whose heap is full: root replacements in flight, one per lane (see g2_pipe_tick). p_since: ticks since the last one
+        // started; p_slots: how many were started (the next one takes lane p_slots % 64).
+        bool p_act = false;
+        u64 p_key = 0;
+        u32 p_node = 0, p_hole = 0, p_since = 2, p_slots = 0;
+        const u64* minb = a.minbuf + (size_t)b * Wn;
+        const u64* ckb = a.ckeybuf + (size_t)b * N;
+        u64* vis = reinterpret_cast<u64*>(reinterpret_cast<unsigned char*>(mb) + 2048);                       // [G2_VISW][64] candidate keys
+        u32* visl = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + 2048 + G2_VISW * 64 * 8);   // [G2_VISW][64] leaves
+        for (u32 w0 = 0; w0 < Wn; w0 += 64) {
+            // 64 node words at a time: which of them can hold a candidate at all? (a superset: the root only drops from here on)
+            const u64 mk = w0 + lane < Wn ? minb[w0 + lane] : KEY_NONE;
+            bool visit = mk != KEY_NONE;
+            if (visit && single) visit = len0 < k || mk < root0;
+            u64 vm = wv::ballot(visit);
+            while (vm) {
+              // The candidate keys of the next G2_VISW words to visit go through LDS: their loads are all in flight together, so the
+              // replay below never waits for global memory.
+              u64 sm = 0;
+              {
+                u64 r[G2_VISW];
+                u32 rl[G2_VISW];
+                const u64 tw_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                WV_UNROLL
+                for (int q = 0; q < G2_VISW; ++q) {
+                    r[q] = KEY_NONE;
+                    rl[q] = 0;
+                    if (vm) {
+                        const u32 c = (u32)wv::ffs64(vm);
+                        vm &= vm - 1ull;
+                        sm |= 1ull << c;
+                        const u32 n = (w0 + c) * 64u + lane;
+                        if (n < N) {
+                            r[q] = ckb[n];
+                            if (!single) rl[q] = leaf_of[n];
+                        }
                     }
-                    if (len < (int)k) {            // heap.Push: a fresh slot
-                        const u32 sl = base + (u32)len;
-                        A.HK[sl] = ek; A.HP[sl] = sl;
-                        A.s_node[sl] = sg->node[i];
-                        A.live[nlive++] = sl;
-                        g2_up(A, base, len);
-                        ++len;
-                        root = A.HK[base];
-                    } else if (ek < root) {        // replaces the root (the evicted node's slot is reused) + heap.Fix(0)
-                        const u32 sl = A.HP[base];
-                        A.s_node[sl] = sg->node[i];
-                        g2_down_val(A, base, 0, len, ek, sl);
-                        root = A.HK[base];
-                    } else continue;
-                    lastp = sg->node[i] + 1;       // the last Process that returned true inside tree()
                 }
-                if (c_lf != G2_NONE) A.h_len[c_lf] = len;
-                if (single) { mb->sh[SH_LEN0] = (u32)len; mb->sh[SH_ROOT_LO] = (u32)root; mb->sh[SH_ROOT_HI] = (u32)(root >> 32); }
+                WV_UNROLL
+                for (int q = 0; q < G2_VISW; ++q) {
+                    vis[q * 64 + (int)lane] = r[q];
+                    if (!single) visl[q * 64 + (int)lane] = rl[q];
+                }
+                if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;   // (mostly: waiting for the loads)
+              }
+              u32 vq = 0;
+              while (sm) {
+                const u32 c = (u32)wv::ffs64(sm);
+                sm &= sm - 1ull;
+                const u64 key = vis[vq * 64u + lane];   // (a lane reads back what it wrote itself)
+                u32 leaf = single ? 0u : visl[vq * 64u + lane];
+                ++vq;
+                const u32 n = (w0 + c) * 64u + lane;
+                const u64 mkc = single ? wv::readlane64(mk, c) : 0ull;
+                if (single && !(len0 < k || mkc < root0)) continue;   // the root dropped below the word's minimum since the batch was looked at
+                bool cand = key != KEY_NONE;
+                if (cand) {
+                    if (single) cand = len0 < k || key < root0;
+                    else {
+                        const int len = A.h_len[leaf];
+                        cand = len < (int)k || key < A.HE[A.h_off[leaf]].key;
+                    }
+                }
+                const u64 bal = wv::ballot(cand);
+                if (bal == 0) continue;
+                const u32 ne = (u32)wv::popc64(bal), myj = wv::mbcnt(bal);
+                if (cand) {
+                    G2Ent se;
+                    se.key = key; se.node = n; se.tix = leaf;
+                    sg->ent[myj] = se;
+                }
+                wv::wave_sync();
+                if (a.dbg & 16u) { gt[10] += 1; gt[11] += ne; }
+                // heap.Push moves nothing when the new element is not above its parent — with equal keys all around, the usual case.
+                // All lanes check that for their candidate at once (the parent is in the heap already or an earlier candidate of this
+                // word); if it holds for every push of the word, the pushes are one parallel append.
+                u32 first = 0;
+                if (single && len0 < k) {
+                    const u32 np = min(ne, k - len0);
+                    bool moves = false;
+                    if (cand && myj < np) {
+                        const u32 pos = len0 + myj;
+                        if (pos > 0) {
+                            const u32 pp = (pos - 1u) >> 1;
+                            const u64 pk = pp < len0 ? A.HE[pp].key : sg->ent[pp - len0].key;
+                            moves = pk < key;   // Less(j, i)
+                        }
+                    }
+                    if (wv::ballot(moves) == 0) {
+                        if (cand && myj < np) {
+                            G2Ent he;
+                            he.key = key; he.node = n; he.tix = G2_NONE;
+                            A.HE[len0 + myj] = he;
+                        }
+                        if (len0 == 0) root0 = sg->ent[0].key;
+                        lastp = sg->ent[np - 1u].node + 1u;
+                        len0 += np;
+                        first = np;
+                        if (a.dbg & 16u) gt[14] += np;
+                        wv::wave_sync();
+                    }
+                }
+                if (first == ne) continue;
+                if (single && len0 >= k) {
+                    // ---- the heap is full: every remaining candidate either replaces the root (heap.Fix(0), a sift from the top) or is not
+                    // less than it. A sift only ever touches deeper levels as it goes, so the next replacement may start two steps behind
+                    // the previous one: the operation that started 2j steps ago works on level 2j while the new one works on level 0
+                    // (it reads level 1, which the one before it finished with a step ago). Lanes hold the operations in flight; every
+                    // tick all of them take one step. Same comparisons, same writes, same final array as one after the other.
+                    const u64 ta_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                    const G2Ent mine = sg->ent[lane < ne ? lane : 0u];   // lane j looks after candidate j of the word
+                    u32 ci = first;
+                    while (ci < ne) {
+                        // one step of every operation in flight
+                        {
+                            const u32 j1 = 2u * p_hole + 1u;
+                            const bool has = p_act && j1 < k;
+                            const G2Ent c1 = A.HE[has ? j1 : 0u];
+                            const G2Ent c2 = A.HE[has && j1 + 1u < k ? j1 + 1u : 0u];
+                            const bool right = j1 + 1u < k && c1.key < c2.key;   // Less(j2, j1)
+                            const G2Ent cj = g2_pick(right, c2, c1);
+                            const bool moves = has && p_key < cj.key;             // Less(j, i)
+                            G2Ent pe;
+                            pe.key = p_key; pe.node = p_node; pe.tix = G2_NONE;
+                            if (p_act) A.HE[p_hole] = g2_pick(moves, cj, pe);
+                            p_hole = moves ? (right ? j1 + 1u : j1) : p_hole;
+                            p_act = moves;
+                        }
+                        ++p_since;
+                        wv::lockstep();   // what this tick wrote is what the next tick reads
+                        if (p_since >= 2u) {   // the next candidate that is less than the root starts; those in front of it never enter
+                            const u64 root = A.HE[0].key;
+                            const u64 hb = wv::ballot(lane >= ci && lane < ne && mine.key < root);
+                            root0 = root;
+                            if (hb == 0) ci = ne;
+                            else {
+                                const u32 f = (u32)wv::ffs64(hb);
+                                const u64 ek = wv::readlane64(mine.key, f);
+                                const u32 en = wv::readlane(mine.node, f);
+                                if (lane == (p_slots & 63u)) { p_act = true; p_key = ek; p_node = en; p_hole = 0; }
+                                ++p_slots;
+                                p_since = 0;
+                                lastp = en + 1u;       // the last Process that returned true inside tree()
+                                ci = f + 1u;
+                                if (a.dbg & 16u) gt[12] += 1;
+                            }
+                        }
+                    }
+                    if (a.dbg & 16u) gt[13] += wv::clock64() - ta_;
+                    continue;
+                }
+                if (lane == 0) {
+                    const u64 ta_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                    if (single) { c_lf = 0; hbase = 0; hlen = (int)len0; hroot = root0; }
+                    G2Ent cur = sg->ent[first];
+                    for (u32 i = first; i < ne; ++i) {
+                        const G2Ent e = cur;
+                        if (i + 1 < ne) cur = sg->ent[i + 1];   // in flight while this one is replayed
+                        const u32 lf = e.tix;
+                        if (lf != c_lf) {
+                            if (c_lf != G2_NONE) A.h_len[c_lf] = hlen;
+                            c_lf = lf;
+                            hbase = A.h_off[lf];
+                            hlen = A.h_len[lf];
+                            hroot = hlen ? A.HE[hbase].key : 0ull;
+                        }
+                        G2Ent he;
+                        he.key = e.key; he.node = e.node; he.tix = G2_NONE;
+                        // Equal keys are the rule, so both operations usually end at their first compare: those paths are straight-line.
+                        if (hlen < (int)k) {            // heap.Push
+                            if (hlen == 0) {
+                                A.HE[hbase] = he;
+                                hroot = he.key;
+                            } else {
+                                const int pp = (hlen - 1) >> 1;
+                                const G2Ent pe = A.HE[hbase + pp];
+                                if (!(pe.key < he.key)) A.HE[hbase + hlen] = he;
+                                else {
+                                    A.HE[hbase + hlen] = pe;
+                                    if (g2_up_val(A, hbase, pp, he) == 0) hroot = he.key;
+                                }
+                            }
+                            ++hlen;
+                        } else if (he.key < hroot) {    // replaces the root + heap.Fix(0)
+                            if (hlen >= 3) {
+                                const G2Ent c1 = A.HE[hbase + 1], c2 = A.HE[hbase + 2];
+                                const bool right = c1.key < c2.key;
+                                const G2Ent cj = g2_pick(right, c2, c1);
+                                if (!(he.key < cj.key)) {
+                                    A.HE[hbase] = he;
+                                    hroot = he.key;
+                                } else {
+                                    A.HE[hbase] = cj;
+                                    hroot = cj.key;
+                                    g2_down_val(A, hbase, right ? 2 : 1, hlen, he);
+                                }
+                            } else hroot = g2_down_val(A, hbase, 0, hlen, he).top.key;
+                        } else continue;
+                        lastp = e.node + 1;            // the last Process that returned true inside tree()
+                        if (a.dbg & 16u) gt[12] += 1;
+                    }
+                    if (a.dbg & 16u) gt[13] += wv::clock64() - ta_;
+                    if (!single && c_lf != G2_NONE) A.h_len[c_lf] = hlen;   // the other lanes' pre-filter reads the lengths of all leaves
+                }
+                lastp = wv::readfirstlane(lastp);
+                if (single) {   // ... and lane 0's registers when there is one leaf
+                    len0 = wv::readfirstlane((u32)hlen);
+                    root0 = ((u64)wv::readfirstlane((u32)(hroot >> 32)) << 32) | wv::readfirstlane((u32)hroot);
+                } else wv::wave_sync();
+              }
             }
-            wv::wave_sync();
-            if (single) { len0 = mb->sh[SH_LEN0]; root0 = ((u64)mb->sh[SH_ROOT_HI] << 32) | mb->sh[SH_ROOT_LO]; }
         }
-        if (lane == 0) { mb->sh[SH_NLIVE] = nlive; mb->sh[SH_LASTP] = lastp; }
+        while (wv::ballot(p_act)) {   // the replacements still in flight run to their ends
+            const u32 j1 = 2u * p_hole + 1u;
+            const bool has = p_act && j1 < k;
+            const G2Ent c1 = A.HE[has ? j1 : 0u];
+            const G2Ent c2 = A.HE[has && j1 + 1u < k ? j1 + 1u : 0u];
+            const bool right = j1 + 1u < k && c1.key < c2.key;
+            const G2Ent cj = g2_pick(right, c2, c1);
+            const bool moves = has && p_key < cj.key;
+            G2Ent pe;
+            pe.key = p_key; pe.node = p_node; pe.tix = G2_NONE;
+            if (p_act) A.HE[p_hole] = g2_pick(moves, cj, pe);
+            p_hole = moves ? (right ? j1 + 1u : j1) : p_hole;
+            p_act = moves;
+            wv::lockstep();
+        }
+        if (lane == 0) {
+            if (single) A.h_len[0] = (int)len0;
+            else if (c_lf != G2_NONE) A.h_len[c_lf] = hlen;
+        }
+        if (lane == 0) mb->sh[SH_LASTP] = lastp;
         wv::wave_sync();
     }
     G2_TICK(2);
-    // heap roots and lengths as tree() left them (the Explain pass needs them after the walk has spent the heaps); the state of
-    // every slot that holds a node, loaded by all lanes at once
+    // Every leaf is heap-sorted NOW, a lane per leaf (the reference pops a leaf's heap when scheduleNTasksOnSubtree first reaches it,
+    // decision_tree.go:46-49; no Process call is involved, so doing it for all leaves at once — and for leaves the walk never
+    // reaches — is unobservable). Before that: heap roots and lengths as tree() left them, for the Explain pass. After it: the residuals
+    // of every node that sits in a heap, by position.
     {
         for (u32 i = lane; i < ntn; i += 64) {
             const int len = A.h_len[i];
-            A.rootkey[i] = len ? A.HK[A.h_off[i]] : 0ull;
+            const u32 base = A.h_off[i];
+            A.rootkey[i] = len ? A.HE[base].key : 0ull;
             A.h_adm[i] = len;
             A.h_cnt[i] = len;
-        }
-        const u32 nlive = mb->sh[SH_NLIVE];
-        for (u32 i = lane; i < nlive; i += 64) {
-            const u32 sl = A.live[i], n = A.s_node[sl];
-            A.s_cpu[sl] = a.cpu[n];
-            A.s_mem[sl] = a.mem[n];
-            A.s_placed[sl] = 0;
-            for (u32 q = 0; q < G.n_gen; ++q) A.s_gen[(size_t)sl * G.n_gen + q] = a.gcnt[(size_t)Gm->gkind[q] * a.gstride + n];
+            if (single) continue;
+            g2_pop_all(A, base, len);
+            for (int q = 0; q < len; ++q) {
+                const u32 pos = base + (u32)q, n = A.HE[pos].node;
+                G2Res r;
+                r.cpu = a.cpu[n]; r.mem = a.mem[n];
+                A.PS[pos] = r;
+                for (u32 z = 0; z < NG; ++z) A.gen[(size_t)pos * NG + z] = a.gcnt[(size_t)Gm->gkind[z] * a.gstride + n];
+            }
         }
         wv::wave_sync();
+        if (single) {
+            // One leaf. When every key in the heap is the same, no pop moves anything but the two elements it swaps, and the heap-sort
+            // comes out as a rotation by one — new[j] = old[(j + 1) % len] — which all lanes do together; otherwise lane 0 pops.
+            const u32 len = (u32)A.h_cnt[0];
+            const u64 k0 = len ? A.HE[0].key : 0ull;
+            bool differs = false;
+            for (u32 pos = lane; pos < len; pos += 64) differs |= A.HE[pos].key != k0;
+            if (wv::ballot(differs) == 0) {
+                if (len >= 2) {
+                    const G2Ent head = A.HE[0];
+                    for (u32 j0 = 0; j0 < len; j0 += 64) {
+                        const u32 j = j0 + lane;
+                        G2Ent v = head;
+                        if (j + 1 < len) v = A.HE[j + 1];
+                        wv::lockstep();   // every lane has read its element before any lane overwrites one
+                        if (j < len) A.HE[j] = v;
+                    }
+                }
+            } else if (lane == 0) g2_pop_all(A, 0u, (int)len);
+            wv::wave_sync();
+        }
+        if (single) {   // one leaf: all lanes load its positions
+            const u32 len = (u32)A.h_cnt[0];
+            for (u32 pos = lane; pos < len; pos += 64) {
+                const u32 n = A.HE[pos].node;
+                G2Res r;
+                r.cpu = a.cpu[n]; r.mem = a.mem[n];
+                A.PS[pos] = r;
+                for (u32 z = 0; z < NG; ++z) A.gen[(size_t)pos * NG + z] = a.gcnt[(size_t)Gm->gkind[z] * a.gstride + n];
+            }
+            wv::wave_sync();
+        }
     }
     G2_TICK(3);
 
+    // ---------- the usual fill, done by all lanes at once ----------
+    // One leaf, at least as many nodes in it as tasks, every task counts on its node, and every sorted node's key + one task exceeds
+    // its successor's: scheduleNTasksOnNodes (scheduler.go:844-924) then gives task j to node j — after each placement the next node is
+    // the lesser one (:899-903), it passes Process (it did at admission and nothing touched it since), and the k-th placement returns
+    // (:893-895). All lanes verify the key condition for their positions; if it holds, they place their tasks themselves.
+    bool filled = false;
+    if (single && !(G.flags & RT_UNCOUNTED) && k <= (u32)A.h_cnt[0]) {
+        bool off = false;
+        for (u32 j = lane; j < k; j += 64) {
+            const u64 kj = A.HE[j].key + G2_KEY_STEP;
+            if (((kj >> 32) & 0xFFFFFFull) == 0) off = true;               // svcCount would leave its 24 bits: the serial path reports it
+            if (j + 1 < k && !(A.HE[j + 1].key < kj)) off = true;          // the fill loop would stay on node j
+        }
+        if (wv::ballot(off) == 0) {
+            for (u32 j = lane; j < k; j += 64) {
+                G2Ent e = A.HE[j];
+                G2Res r = A.PS[j];
+                a.out_node[G.out_off + j] = (int32_t)e.node;
+                r.cpu -= G.cpu;
+                r.mem -= G.mem;
+                A.PS[j] = r;
+                for (u32 q = 0; q < NG; ++q) A.gen[(size_t)j * NG + q] -= Gm->gval[q];
+                e.key += G2_KEY_STEP;
+                e.tix = j;
+                A.HE[j] = e;
+                A.tnode[j] = e.node;
+                A.tcount[j] = 1;
+            }
+            if (lane == 0) {
+                mb->sh[SH_LEFT] = 0; mb->sh[SH_NTOUCH] = k; mb->sh[SH_ERR] = 0;
+                mb->sh[SH_C1] = 0; mb->sh[SH_C5] = 0; mb->sh[SH_C6] = 0; mb->sh[SH_FPASS] = k >= 2 ? 1u : 0u;
+            }
+            filled = true;
+        }
+    }
+
     // ---------- tree walk + fill loops: lane 0, on the arena only ----------
-    if (lane == 0) {
+    if (!filled && lane == 0) {
         u32 next_task = 0, ntouch = 0;
         u32 c1 = 0, c5 = 0, c6 = 0, fpass = 0;   // Explain counters of the fill phase (only Resource / HostPort / MaxReplicas can fail there)
         bool bad_key = false;
         const bool has_ports = (G.flags & RT_PORTS) != 0, has_res = (G.flags & RT_RES) != 0, has_maxrep = (G.flags & RT_MAXREP) != 0;
         const bool counted = !(G.flags & RT_UNCOUNTED);
-        const u32 ngen = G.n_gen;
-        // Pipeline.Process on a heap position: the static filters passed at admission and cannot change
-        auto process = [&](u32 pos) -> bool {
-            const u32 sl = A.HP[pos];
+        const u32 ngen = NG;
+        // Pipeline.Process on the entry at a heap position (its records are passed in: the fill loop has them in registers): the
+        // static filters passed at admission and cannot change
+        auto process = [&](u32 pos, G2Ent e, G2Res r) -> bool {
             u32 ff = G2_FF_PASS;
             if (has_res) {
-                if (!(G.cpu <= A.s_cpu[sl] && G.mem <= A.s_mem[sl])) ff = 1;
+                if (!(G.cpu <= r.cpu && G.mem <= r.mem)) ff = 1;
                 else
                     for (u32 q = 0; q < ngen; ++q)
-                        if (A.s_gen[(size_t)sl * ngen + q] < Gm->gval[q]) ff = 1;
+                        if (A.gen[(size_t)pos * ngen + q] < Gm->gval[q]) ff = 1;
             }
             if (ff == G2_FF_PASS) {
-                if (has_ports && A.s_placed[sl] > 0) ff = 5;
-                else if (has_maxrep && !((u64)((u32)(A.HK[pos] >> 32) & 0xFFFFFFu) < G.maxrep)) ff = 6;
+                if (has_ports && e.tix != G2_NONE) ff = 5;
+                else if (has_maxrep && !((u64)((u32)(e.key >> 32) & 0xFFFFFFu) < G.maxrep)) ff = 6;
             }
             if (ff == G2_FF_PASS) { c1 = c5 = c6 = 0; fpass = 1; }
             else if (ff == 1) ++c1;
@@ -565,74 +889,94 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             else ++c6;
             return ff == G2_FF_PASS;
         };
-        // scheduleNTasksOnNodes, scheduler.go:844-924, on the leaf's positions [base, base+cnt)
+        // scheduleNTasksOnNodes, scheduler.go:844-924, on the leaf's positions [base, base+cnt). The current entry and the one behind
+        // it ride in registers; the one behind is loaded while the current one is worked on (it cannot change meanwhile: a placement
+        // only touches the current entry).
         auto fill = [&](int want, u32 base, int cnt) -> int {
             int scheduled = 0, iter = 0, ix = 0;
+            u32 nfailed = 0;
             for (u32 q = base >> 6; q <= (base + (u32)cnt - 1u) >> 6; ++q) A.failed[q] = 0;
+            G2Ent ce = A.HE[base];
+            G2Res cr = A.PS[base];
+            int nx = cnt > 1 ? 1 : 0;
+            G2Ent ne = A.HE[base + (u32)nx];
+            G2Res nr = A.PS[base + (u32)nx];
+            const u64 kstep = counted ? G2_KEY_STEP : 0ull;
+            const bool one = cnt == 1;
             while (next_task < k) {
                 const u32 pos = base + (u32)ix;
-                const u32 sl = A.HP[pos];
-                a.out_node[G.out_off + next_task] = (int32_t)A.s_node[sl];
+                a.out_node[G.out_off + next_task] = (int32_t)ce.node;
                 ++next_task;
-                A.s_cpu[sl] -= G.cpu;   // NodeInfo.addTask (nodeinfo.go:108-154)
-                A.s_mem[sl] -= G.mem;
-                for (u32 q = 0; q < ngen; ++q) A.s_gen[(size_t)sl * ngen + q] -= Gm->gval[q];   // Claim, resource_management.go:11-39 (counts)
-                const u32 pl = A.s_placed[sl];
-                A.s_placed[sl] = pl + 1;
-                if (pl == 0) A.touched[ntouch++] = sl;
-                u64 kcur = A.HK[pos];
-                if (counted) {
-                    kcur += G2_KEY_STEP;
-                    if (((kcur >> 32) & 0xFFFFFFull) == 0) bad_key = true;   // svcCount left its 24 bits
-                    A.HK[pos] = kcur;
-                }
+                cr.cpu -= G.cpu;   // NodeInfo.addTask (nodeinfo.go:108-154)
+                cr.mem -= G.mem;
+                A.PS[pos] = cr;
+                for (u32 q = 0; q < ngen; ++q) A.gen[(size_t)pos * ngen + q] -= Gm->gval[q];   // Claim, resource_management.go:11-39 (counts)
+                // the node's entry in the touched list (tcount starts all zero): no branch on "first task here"
+                const bool fresh = ce.tix == G2_NONE;
+                const u32 t = fresh ? ntouch : ce.tix;
+                ntouch += fresh ? 1u : 0u;
+                ce.tix = t;
+                A.tnode[t] = ce.node;
+                wv::lds_add32(&A.tcount[t], 1u);
+                ce.key += kstep;
+                bad_key |= counted && ((ce.key >> 32) & 0xFFFFFFull) == 0;   // svcCount left its 24 bits
+                A.HE[pos] = ce;
                 ++scheduled;
                 if (scheduled == want) return scheduled;
-                const int nx = ix + 1 == cnt ? 0 : ix + 1;
-                if (iter + 1 < cnt) {
-                    if (A.HK[base + (u32)nx] < kcur) { ++iter; ix = nx; }   // first pass: on to the next node once it is the lesser
-                } else { ++iter; ix = nx; }                                 // later passes: round robin
+                if (one) { ne = ce; nr = cr; }   // the entry behind the only entry is that entry
+                // first pass: on to the next node once it is the lesser; later passes: round robin
+                if (iter + 1 >= cnt || ne.key < ce.key) {
+                    ++iter;
+                    ix = nx; ce = ne; cr = nr;
+                    nx = ix + 1 == cnt ? 0 : ix + 1;
+                    ne = A.HE[base + (u32)nx]; nr = A.PS[base + (u32)nx];
+                }
                 const int orig = iter;
                 for (;;) {
                     const u32 bi = base + (u32)ix;
-                    const bool bad = (A.failed[bi >> 6] >> (bi & 63)) & 1ull;
-                    if (!bad && process(bi)) break;
-                    A.failed[bi >> 6] |= 1ull << (bi & 63);
+                    const bool bad = nfailed != 0 && ((A.failed[bi >> 6] >> (bi & 63)) & 1ull);
+                    if (!bad && process(bi, ce, cr)) break;
+                    if (!bad) { A.failed[bi >> 6] |= 1ull << (bi & 63); ++nfailed; }
                     ++iter;
-                    ix = ix + 1 == cnt ? 0 : ix + 1;
+                    ix = nx; ce = ne; cr = nr;
+                    nx = ix + 1 == cnt ? 0 : ix + 1;
+                    ne = A.HE[base + (u32)nx]; nr = A.PS[base + (u32)nx];
                     if (iter - orig == cnt) return scheduled;
                 }
             }
             return scheduled;
         };
-        // decisionTree.orderedNodes, decision_tree.go:24-52
+        // decisionTree.orderedNodes, decision_tree.go:24-52. The first hand-out of a leaf finds it sorted already (above); from the
+        // second one on the nodes that no longer pass are dropped, the rest is heapified and popped again.
         auto ordered = [&](u32 lf) -> int {
-            const u32 base = A.h_off[lf];
-            int len = A.h_len[lf], cnt = A.h_cnt[lf];
-            if (len != cnt) {
-                for (int i = 0; i < cnt;) {
-                    if (process(base + (u32)i)) ++i;
-                    else {
-                        --cnt;
-                        if (i != cnt) {   // nodes[i] = nodes[last]; nodes = nodes[:last] (the dropped node's slot stays on the touched list)
-                            A.HK[base + i] = A.HK[base + cnt];
-                            A.HP[base + i] = A.HP[base + cnt];
-                        }
-                    }
-                }
-                len = cnt;
-                for (int i = cnt / 2 - 1; i >= 0; --i) g2_down(A, base, i, cnt);   // heap.Init
+            int cnt = A.h_cnt[lf];
+            if (!A.h_vis[lf]) {
+                A.h_vis[lf] = 1;
+                return cnt;
             }
-            while (len > 0) {   // heap.Pop: Swap(0, n-1); down(0, n-1); length--
-                const int nn = len - 1;
-                const u64 kr = A.HK[base]; const u32 pr = A.HP[base];
-                const u64 kl = A.HK[base + nn]; const u32 plast = A.HP[base + nn];
-                A.HK[base + nn] = kr; A.HP[base + nn] = pr;
-                if (nn > 0) g2_down_val(A, base, 0, nn, kl, plast);
-                len = nn;
+            if (cnt == 0) return 0;
+            const u32 base = A.h_off[lf];
+            for (int i = 0; i < cnt;) {
+                const G2Ent e = A.HE[base + i];
+                const G2Res r = A.PS[base + i];
+                if (process(base + (u32)i, e, r)) ++i;
+                else {
+                    --cnt;
+                    if (i != cnt) g2_move_full(A, ngen, base + (u32)i, base + (u32)cnt);   // nodes[i] = nodes[last]; nodes = nodes[:last]
+                }
+            }
+            for (int i = cnt / 2 - 1; i >= 0; --i) g2_down_full(A, ngen, base, i, cnt);   // heap.Init
+            for (int n = cnt - 1; n >= 1; --n) {                                          // heap.Pop until empty
+                const G2Ent te = A.HE[base]; A.HE[base] = A.HE[base + n]; A.HE[base + n] = te;
+                const G2Res tr = A.PS[base]; A.PS[base] = A.PS[base + n]; A.PS[base + n] = tr;
+                for (u32 q = 0; q < ngen; ++q) {
+                    const int32_t tg = A.gen[(size_t)base * ngen + q];
+                    A.gen[(size_t)base * ngen + q] = A.gen[(size_t)(base + n) * ngen + q];
+                    A.gen[(size_t)(base + n) * ngen + q] = tg;
+                }
+                g2_down_full(A, ngen, base, 0, n);
             }
             A.h_cnt[lf] = cnt;
-            A.h_len[lf] = 0;
             return cnt;
         };
         // scheduleNTasksOnSubtree, scheduler.go:772-825, as an explicit stack machine (frames in the arena: any depth)
@@ -647,8 +991,11 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             const u32 nch = a.tn_nchild[tbase + f.tn];
             if (f.phase == 0) {
                 if (nch == 0) {   // leaf
+                    const u64 t0_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
                     const int cnt = ordered(f.tn);
+                    const u64 t1_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
                     ret = cnt == 0 ? 0 : fill(f.n, A.h_off[f.tn], cnt);
+                    if (a.dbg & 16u) { gt[8] += t1_ - t0_; gt[9] += wv::clock64() - t1_; }
                     --sp;
                     continue;
                 }
@@ -748,12 +1095,11 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             bool app = false;
             u32 n = 0, pl = 0;
             if (i < nt) {
-                const u32 sl = A.touched[i];
-                n = A.s_node[sl];
-                pl = A.s_placed[sl];
-                a.cpu[n] = A.s_cpu[sl];
-                a.mem[n] = A.s_mem[sl];
-                for (u32 q = 0; q < G.n_gen; ++q) a.gcnt[(size_t)Gm->gkind[q] * a.gstride + n] = A.s_gen[(size_t)sl * G.n_gen + q];
+                n = A.tnode[i];
+                pl = A.tcount[i];
+                a.cpu[n] -= (i64)pl * G.cpu;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
+                a.mem[n] -= (i64)pl * G.mem;
+                for (u32 q = 0; q < NG; ++q) a.gcnt[(size_t)Gm->gkind[q] * a.gstride + n] -= (int32_t)pl * Gm->gval[q];
                 if (counted) {
                     a.total[n] += pl;
                     const u32 e1 = a.lpos_dense[(size_t)b * N + n];
@@ -789,7 +1135,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             eval_next = P.n;
         } else {
             if (!g2_wait_ge(&mb->done, eval_next * nh, mb)) return false;
-            for (u32 i = lane; i < nt; i += 64) g2_eval_node(a, Gn, a.g + gi + 1, bn, A.s_node[A.touched[i]]);
+            for (u32 i = lane; i < nt; i += 64) g2_eval_node(a, Gn, a.g + gi + 1, bn, A.tnode[i]);
             wv::wait_vm();
         }
     }
@@ -803,7 +1149,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
     G2Mail* mb = reinterpret_cast<G2Mail*>(l);
     G2Stage* sg = reinterpret_cast<G2Stage*>(l + 512);
-    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= G2_LDS_FIXED, "fixed LDS layout");
+    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 12 <= G2_LDS_FIXED, "fixed LDS layout");
     const u32 wave = wv::wave(), lane = wv::lane(), nh = wv::nthreads() / 64u - 1u;
     if (wv::tid() == 0) { mb->posted = 0; mb->done = 0; mb->quit = 0; }
     wv::barrier();
@@ -812,7 +1158,8 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         g2_helper(a, mb, wave - 1u, nh);
         return;
     }
-    u64 gt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    wv::setprio<3>();   // the machine's instructions go first on its SIMD: the helper waves it shares it with only fill the gaps
+    u64 gt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
     G2Post P{0};
     {   // the first group is prepared with nothing to overlap
@@ -843,8 +1190,10 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
             }
         }
         const u32 ntn = a.tree_off[G.tree + 1] - a.tree_off[G.tree];
-        if (g2_arena_bytes(G.n_slots, ntn, G.n_gen, a.max_depth, G.k) <= G2_ARENA_LDS) ok = g2_group<true>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, P, nh, eval_next);
-        else ok = g2_group<false>(a, mb, sg, a.arena, G, gi, gt, P, nh, eval_next);
+        const bool in_lds = g2_arena_bytes(G.n_slots, ntn, G.n_gen, a.max_depth, G.k) <= G2_ARENA_LDS;
+        if (in_lds && !G.n_gen) ok = g2_group<true, false>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, P, nh, eval_next);
+        else if (in_lds) ok = g2_group<true, true>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, P, nh, eval_next);
+        else ok = g2_group<false, true>(a, mb, sg, a.arena, G, gi, gt, P, nh, eval_next);
         eval_cur = eval_next;
         if (a.dbg & 16u) tk = wv::clock64();
     }
@@ -853,8 +1202,12 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         wv::lds_publish32(&mb->quit, 1u);   // helpers leave their wait loops
     }
     g2_post(mb, P, G2_OP_QUIT, 0);
-    if (lane == 0 && (a.dbg & 16u))
+    if (lane == 0 && (a.dbg & 16u)) {
         for (int q = 0; q < 8; ++q) a.ctl->cyc[q] = gt[q];
+        a.ctl->m_cyc[0] = gt[8];   // inside the walk: orderedNodes ...
+        a.ctl->m_cyc[1] = gt[9];   // ... and the fill loops
+        for (int q = 0; q < 6; ++q) a.ctl->l_cyc[q] = gt[10 + q];   // admission: words visited, candidates staged, heap operations, cycles inside lane 0's replay
+    }
 }
 
 #endif   // SWP_G2_KERNELS

@@ -84,6 +84,8 @@ WV_DEV u32 lds_poll32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUI
 // a counter several waves bump when their share of a job is done (k_groups2's helper waves): everything the wave wrote before —
 // LDS and global — is visible to the wave that polls the sum
 WV_DEV void lds_add_release32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// issue priority of this wave among the waves of its SIMD (0 lowest .. 3 highest): the one wave that carries a serial chain asks for 3
+template <int P> WV_DEV void setprio() { __builtin_amdgcn_s_setprio(P); }
 WV_DEV void spin_pause() { __builtin_amdgcn_s_sleep(8); }   // ~0.2 µs off the CU's issue slots between two polls
 
 // ---- global memory ----

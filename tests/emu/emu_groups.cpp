@@ -437,7 +437,7 @@ int main(int argc, char** argv) {
         total_out += g.k;
     }
     std::vector<unsigned char> ffbuf((size_t)2 * N, 0xEE), arena(arena_bytes + 64, 0xCD);
-    std::vector<u64> keybuf((size_t)2 * N, 0xEEEEEEEEEEEEEEEEull), xroot(max_ntn, 0);
+    std::vector<u64> keybuf((size_t)2 * N, 0xEEEEEEEEEEEEEEEEull), xroot(max_ntn, 0), minbuf((size_t)2 * Wn, 0x1111), ckeybuf((size_t)2 * N, 0x2222);
     std::vector<u32> svc_dense((size_t)2 * N, 0), fail_dense((size_t)2 * N, 0), lpos_dense((size_t)2 * N, 0);
     std::vector<i64> tsumbuf((size_t)2 * max_ntn, 0x7777);
     std::vector<int32_t> xadm(max_ntn, 0), out(total_out, -7);
@@ -454,7 +454,7 @@ int main(int argc, char** argv) {
     a.list_node = list_node.data(); a.list_svc = list_svc.data(); a.list_fail = list_fail.data(); a.list_off = list_off.data(); a.list_cnt = list_cnt.data();
     a.tree_off = tree_off.data(); a.tn_parent = tn_parent.data(); a.tn_first = tn_first.data(); a.tn_next = tn_next.data();
     a.tn_nchild = tn_nchild.data(); a.tn_nodes = tn_nodes.data(); a.leaf_of_node = leaf_of.data();
-    a.ffbuf = ffbuf.data(); a.keybuf = keybuf.data(); a.svc_dense = svc_dense.data(); a.fail_dense = fail_dense.data(); a.lpos_dense = lpos_dense.data();
+    a.ffbuf = ffbuf.data(); a.keybuf = keybuf.data(); a.minbuf = minbuf.data(); a.ckeybuf = ckeybuf.data(); a.svc_dense = svc_dense.data(); a.fail_dense = fail_dense.data(); a.lpos_dense = lpos_dense.data();
     a.tsumbuf = tsumbuf.data(); a.xroot = xroot.data(); a.xadm = xadm.data(); a.arena = arena.data();
     a.out_node = out.data(); a.hist = hist.data(); a.ctl = &ctl;
 

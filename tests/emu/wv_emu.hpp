@@ -287,6 +287,7 @@ inline void wait_vm() {}
 
 inline void lds_publish32(u32* p, u32 v) { *reinterpret_cast<volatile u32*>(p) = v; emu::wake_pollers(); }
 inline u32 lds_poll32(const u32* p) { return *reinterpret_cast<const volatile u32*>(p); }
+template <int P> inline void setprio() {}
 inline void spin_pause() { emu::yield_until_publish(); }
 inline void lds_or64(u64* p, u64 v) { *p |= v; }
 inline void lds_xor64(u64* p, u64 v) { *p ^= v; }
