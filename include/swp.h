@@ -351,10 +351,16 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
  *   out_node_local   this rank's node index of the tasks placed here, -1 elsewhere
  *   out_fail_hist    this rank's share of the Explain histograms (sum over the ranks), may be NULL */
 #define SWP_RCCL_ID_BYTES 128
+int swp_rccl_available(swp_engine*);   /* SWP_OK: librccl.so loads with every symbol the engine uses. Ranks exchange this BEFORE any of them calls swp_rccl_init (a rank that cannot would leave the others inside ncclCommInitRank) */
 int swp_rccl_unique_id(swp_engine*, uint8_t id_out[SWP_RCCL_ID_BYTES]);
 int swp_rccl_init(swp_engine*, const uint8_t id[SWP_RCCL_ID_BYTES], uint32_t rank, uint32_t n_ranks);
 int swp_rccl_finalize(swp_engine*);   /* ncclCommDestroy; swp_destroy does not (an engine often dies with the process, after RCCL itself) */
 int swp_shard_run_rank(swp_engine*, swp_batch*, const uint32_t* shard_nodes, uint32_t flags, int32_t* out_node_local, uint32_t* out_fail_hist);
+/* The ranks leave swp_shard_run_rank TOGETHER: before the first round and after every stretch of rounds each rank contributes one
+ * status word {int32 code, uint32 position, uint32 kernel error, uint32 rounds} to a 16-byte ncclAllGather, and every rank derives
+ * the same verdict from the same words: 0 go on, 1 a rank could not take part (*who_out names it), 2 a rank's kernels reported an
+ * error, 3 the positions differ (the ranks diverged). Exposed for the host layer's tests; words = n_ranks x 4 uint32. */
+int swp_shard_verdict(const uint32_t* words, uint32_t n_ranks, uint32_t* who_out);
 
 /* NodeInfo.addTask / removeTask for tasks the engine did not place itself (event handlers
  * scheduler.go:254-366; rollback :472-487). add_or_remove: 1 = add, 0 = remove. */

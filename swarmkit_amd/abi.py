@@ -109,7 +109,7 @@ EXPORTS = [
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
     "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce", "swp_node_matches",
     "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check", "swp_node_update_dynamic_many", "swp_node_get_many",
-    "swp_shard_begin", "swp_shard_propose", "swp_shard_merge", "swp_shard_commit", "swp_shard_end", "swp_shard_run", "swp_rccl_unique_id", "swp_rccl_init", "swp_rccl_finalize", "swp_shard_run_rank",
+    "swp_shard_begin", "swp_shard_propose", "swp_shard_merge", "swp_shard_commit", "swp_shard_end", "swp_shard_run", "swp_rccl_available", "swp_rccl_unique_id", "swp_rccl_init", "swp_rccl_finalize", "swp_shard_run_rank", "swp_shard_verdict",
     # include/swp_sched.h — the host layer above the engine
     "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
     "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
@@ -198,6 +198,8 @@ def load_library(path=None):
         "swp_shard_commit": ([vp, vp, u32, vp, u32], C.c_int),
         "swp_shard_end": ([vp, vp, vp, vp], C.c_int),
         "swp_shard_run": ([vp, vp, u32, u32, vp, vp, vp], C.c_int),
+        "swp_rccl_available": ([vp], C.c_int),
+        "swp_shard_verdict": ([vp, u32, vp], C.c_int),
         "swp_rccl_unique_id": ([vp, vp], C.c_int),
         "swp_rccl_init": ([vp, vp, u32, u32], C.c_int),
         "swp_rccl_finalize": ([vp], C.c_int),
@@ -459,6 +461,10 @@ class Engine:
         return out.value
 
     # ---- the rank variant of the node-range shards: one engine per process / GPU, RCCL between them ----
+    def rccl_available(self):
+        """librccl.so loads with every symbol the engine uses (what the ranks exchange before any of them calls rccl_init)."""
+        return self.L.swp_rccl_available(self.h) == 0
+
     def rccl_unique_id(self):
         buf = (C.c_uint8 * 128)()
         self._ck(self.L.swp_rccl_unique_id(self.h, buf))

@@ -2321,7 +2321,7 @@ int swp_shard_begin(swp_engine* e, swp_batch* b) {
     (void)hipSetDevice(e->device);
     if (e->n_nodes != b->n_nodes_prepared)
         return e->fail(SWP_EINVAL, "the nodeSet grew from %u to %u node slots since swp_batch_prepare: prepare the batch again", b->n_nodes_prepared, e->n_nodes);
-    if (b->has_generic) return e->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the node-range shard protocol yet");
+    if (b->has_generic) return e->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the HOST-merged shard protocol (swp_shard_run / swp_shard_run_rank carry them)");
     b->shard_open = true;
     b->shard_ncommit = b->shard_ninf = 0;
     e->stats.ms_propose = e->stats.ms_apply = 0.f;
@@ -2567,7 +2567,6 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     for (uint32_t g = 0; g < G; ++g) {
         if (!engines[g] || !batches[g] || batches[g]->T != T) return e0->fail(SWP_EINVAL, "shard %u: every shard's batch must hold the same %u tasks", g, T);
         if (engines[g]->n_nodes != batches[g]->n_nodes_prepared) return e0->fail(SWP_EINVAL, "shard %u: the nodeSet grew since swp_batch_prepare", g);
-        if (batches[g]->has_generic) return e0->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the node-range shard protocol yet");
         for (uint32_t h = 0; h < g; ++h)
             if (engines[h] == engines[g]) return e0->fail(SWP_EINVAL, "shards %u and %u name the same engine", h, g);
     }
@@ -2764,7 +2763,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
             out_shard[i] = (int32_t)g;
             out_node[i] = nloc;
             const swp_task_desc& d = b->tasks[i];
-            if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)nloc, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+            if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)nloc, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
             ++placed;
         }
         if (out_fail_hist && ctl.ninf)
@@ -2840,10 +2839,15 @@ int swp_rccl_finalize(swp_engine* e) {
     return SWP_OK;
 }
 
+int swp_rccl_available(swp_engine* e) {
+    if (!e) return SWP_EINVAL;
+    return rccl() ? SWP_OK : e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy)");
+}
+
 int swp_rccl_unique_id(swp_engine* e, uint8_t* id_out) {
     if (!e || !id_out) return SWP_EINVAL;
     Rccl* r = rccl();
-    if (!r) return e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded: %s", dlerror());
+    if (!r) return e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy)");
     (void)hipSetDevice(e->device);
     const int rc = r->GetUniqueId(id_out);
     return rc == 0 ? SWP_OK : e->fail(SWP_EHIP, "ncclGetUniqueId: %s", r->GetErrorString ? r->GetErrorString(rc) : "error");
@@ -2853,7 +2857,7 @@ int swp_rccl_init(swp_engine* e, const uint8_t* id, uint32_t rank, uint32_t n_ra
     if (!e || !id || n_ranks == 0 || rank >= n_ranks) return SWP_EINVAL;
     if (n_ranks > R7_MAXS) return e->fail(SWP_ERANGE, "%u ranks: the device-side rounds take at most %d", n_ranks, R7_MAXS);
     Rccl* r = rccl();
-    if (!r) return e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded: %s", dlerror());
+    if (!r) return e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy)");
     (void)hipSetDevice(e->device);
     if (e->rccl_comm) (void)swp_rccl_finalize(e);
     RcclId uid;
@@ -2865,18 +2869,46 @@ int swp_rccl_init(swp_engine* e, const uint8_t* id, uint32_t rank, uint32_t n_ra
     return SWP_OK;
 }
 
+// What the ranks of a sharded run tell each other between stretches of rounds: one tiny ncclAllGather on the engine's stream. Every
+// rank sees every rank's word, so they all leave the round loop in the SAME place — a rank that returned on its own would leave its
+// peers inside the next collective for ever.
+namespace {
+struct RankStatus { int32_t code; uint32_t pos, error, rounds; };
+int rank_agree(swp_engine* e, Rccl* r, hipStream_t st, DevBuf& d_stat, const RankStatus& mine, std::vector<RankStatus>& all) {
+    const uint32_t G = e->rccl_ranks;
+    HIPCHECK(e, d_stat.reserve((size_t)(G + 1) * sizeof(RankStatus)));
+    RankStatus* dev = d_stat.as<RankStatus>();
+    HIPCHECK(e, hipMemcpyAsync(dev + G, &mine, sizeof mine, hipMemcpyHostToDevice, st));
+    const int nr = r->AllGather(dev + G, dev, sizeof(RankStatus), /* ncclInt8 */ 0, e->rccl_comm, st);
+    if (nr != 0) return e->fail(SWP_EHIP, "ncclAllGather (status): %s", r->GetErrorString ? r->GetErrorString(nr) : "error");
+    all.resize(G);
+    HIPCHECK(e, hipMemcpyAsync(all.data(), dev, (size_t)G * sizeof(RankStatus), hipMemcpyDeviceToHost, st));
+    HIPCHECK(e, hipStreamSynchronize(st));
+    return SWP_OK;
+}
+// the verdict every rank derives from the same gathered words (tests/test_product_cpu.py checks the rule through swp_shard_verdict)
+int rank_verdict(const RankStatus* all, uint32_t G, uint32_t* who) {
+    for (uint32_t g = 0; g < G; ++g)
+        if (all[g].code != SWP_OK) { *who = g; return 1; }        // a rank could not take part
+    for (uint32_t g = 0; g < G; ++g)
+        if (all[g].error != ERR_NONE) { *who = g; return 2; }     // a rank's kernels reported an error (level range)
+    for (uint32_t g = 1; g < G; ++g)
+        if (all[g].pos != all[0].pos) { *who = g; return 3; }     // the ranks no longer agree on the batch position: they diverged
+    return 0;
+}
+}  // namespace
+
+int swp_shard_verdict(const uint32_t* words, uint32_t n_ranks, uint32_t* who_out) {
+    if (!words || !who_out || n_ranks == 0) return SWP_EINVAL;
+    *who_out = 0;
+    return rank_verdict(reinterpret_cast<const RankStatus*>(words), n_ranks, who_out);
+}
+
 int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes, uint32_t flags, int32_t* out_node_local, uint32_t* out_fail_hist) {
     if (!e || !b || !shard_nodes || (!out_node_local && b->T)) return SWP_EINVAL;
     if (!e->rccl_comm) return e->fail(SWP_EINVAL, "swp_shard_run_rank before swp_rccl_init");
     Rccl* r = rccl();
     const uint32_t G = e->rccl_ranks, me = e->rccl_rank, T = b->T;
-    if (e->n_nodes != b->n_nodes_prepared) return e->fail(SWP_EINVAL, "the nodeSet grew since swp_batch_prepare");
-    if (shard_nodes[me] != e->n_nodes) return e->fail(SWP_EINVAL, "rank %u holds %u node slots, shard_nodes says %u", me, e->n_nodes, shard_nodes[me]);
-    if (b->has_generic) return e->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the node-range shard protocol yet");
-    if (e->n_nodes == 0) return e->fail(SWP_EINVAL, "rank %u owns no node", me);
-    if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
-    for (uint32_t i = 0; i < T; ++i) out_node_local[i] = -1;
-    if (T == 0) return SWP_OK;
     (void)hipSetDevice(e->device);
     hipStream_t st = e->stream;
     const char* env_dbg = getenv("SWP_DBG");
@@ -2888,48 +2920,73 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
     const char* env_tr = getenv("SWP_R6_TASKROWS");
     const bool task_rows = env_tr ? atoi(env_tr) != 0 : (!b->classes_ok || b->n_dc + b->n_dm > 128);
     const uint32_t Wn = n_words_of(e->n_nodes);
-    if (r6_propose_lds_size(Wn) > lds_budget)
-        return e->fail(SWP_ERANGE, "%u nodes exceed the block resolver's LDS", e->n_nodes);
-    auto bad = [&](int rc) { e->dev_dynamic_dirty = true; return rc; };
-    int rc = batch_begin(e, b);
-    if (rc) return bad(rc);
+    auto bad = [&](int rc) { e->dev_dynamic_dirty = true; (void)hipStreamSynchronize(st); return rc; };
+    // ---- everything that can go wrong on THIS rank before the first round is checked here, and the outcome is exchanged: either all
+    // ranks start the rounds or none does (a lone early return would leave the others inside ncclAllGather)
     R6Args ra{};
-    if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra))) return bad(rc);
-    Blk6 hb{};
-    hb.end = T;
-    HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, st));
-    hipError_t x = launch_r6_build(ra, st);
-    if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(x)));
-    DevBuf d_all, d_picks, d_head, d_merged, d_args;
-    HIPCHECK(e, d_all.reserve((size_t)G * block * sizeof(R6Prop)));
-    HIPCHECK(e, d_picks.reserve((size_t)block * sizeof(R7Pick)));
-    HIPCHECK(e, d_head.reserve(sizeof(R7Head)));
-    HIPCHECK(e, d_merged.reserve((size_t)block * sizeof(R6Prop)));
-    HIPCHECK(e, d_args.reserve(sizeof(R6Args)));
-    HIPCHECK(e, hipMemsetAsync(d_head.p, 0, sizeof(R7Head), st));
-    HIPCHECK(e, hipMemcpyAsync(d_args.p, &ra, sizeof ra, hipMemcpyHostToDevice, st));
     R7Args ma{};
-    ma.n_shards = G;
-    ma.block = block;
-    ma.dbg = dbg_bits;
-    uint32_t first = 0, hw = 0;
-    for (uint32_t g = 0; g < G; ++g) {
-        ma.hw_base[g] = hw;
-        ma.first_node[g] = first;
-        first += shard_nodes[g];
-        hw += (shard_nodes[g] + 31) / 32;
-        ma.prop[g] = d_all.as<R6Prop>() + (size_t)g * block;
+    DevBuf d_all, d_picks, d_head, d_merged, d_args, d_stat;
+    Blk6 hb{};
+    int pre = SWP_OK;
+    if (e->n_nodes != b->n_nodes_prepared) pre = e->fail(SWP_EINVAL, "the nodeSet grew since swp_batch_prepare");
+    else if (shard_nodes[me] != e->n_nodes) pre = e->fail(SWP_EINVAL, "rank %u holds %u node slots, shard_nodes says %u", me, e->n_nodes, shard_nodes[me]);
+    else if (e->n_nodes == 0) pre = e->fail(SWP_EINVAL, "rank %u owns no node", me);
+    else if (r6_propose_lds_size(Wn) > lds_budget) pre = e->fail(SWP_ERANGE, "%u nodes exceed the block resolver's LDS", e->n_nodes);
+    if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
+    for (uint32_t i = 0; i < T; ++i) out_node_local[i] = -1;
+    auto setup = [&]() -> int {
+        int rc = batch_begin(e, b);
+        if (rc) return rc;
+        if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra))) return rc;
+        hb.end = T;
+        HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, st));
+        hipError_t x = launch_r6_build(ra, st);
+        if (x != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(x));
+        HIPCHECK(e, d_all.reserve((size_t)G * block * sizeof(R6Prop)));
+        HIPCHECK(e, d_picks.reserve((size_t)block * sizeof(R7Pick)));
+        HIPCHECK(e, d_head.reserve(sizeof(R7Head)));
+        HIPCHECK(e, d_merged.reserve((size_t)block * sizeof(R6Prop)));
+        HIPCHECK(e, d_args.reserve(sizeof(R6Args)));
+        HIPCHECK(e, hipMemsetAsync(d_head.p, 0, sizeof(R7Head), st));
+        HIPCHECK(e, hipMemcpyAsync(d_args.p, &ra, sizeof ra, hipMemcpyHostToDevice, st));
+        ma.n_shards = G;
+        ma.block = block;
+        ma.dbg = dbg_bits;
+        uint32_t first = 0, hw = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            ma.hw_base[g] = hw;
+            ma.first_node[g] = first;
+            first += shard_nodes[g];
+            hw += (shard_nodes[g] + 31) / 32;
+            ma.prop[g] = d_all.as<R6Prop>() + (size_t)g * block;
+        }
+        ma.hw_base[G] = ma.hw_total = hw;
+        if (r7_match_lds_size(hw) > lds_budget) return e->fail(SWP_ERANGE, "%u nodes over all ranks exceed the matching wave's LDS", first);
+        ma.blk = ra.blk;
+        ma.ctl = ra.ctl;
+        ma.picks = d_picks.as<R7Pick>();
+        ma.head = d_head.as<R7Head>();
+        ma.merged = d_merged.as<R6Prop>();
+        // the build kernel's verdict (the level range of THIS rank's nodes) is part of what is exchanged
+        HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
+        HIPCHECK(e, hipStreamSynchronize(st));
+        return SWP_OK;
+    };
+    if (pre == SWP_OK && T) pre = setup();
+    std::vector<RankStatus> all;
+    uint32_t who = 0;
+    int rc = rank_agree(e, r, st, d_stat, RankStatus{pre, 0u, pre == SWP_OK ? hb.error : 0u, 0u}, all);
+    if (rc) return bad(rc);   // (the collective itself failed: nothing sensible is left to agree on)
+    switch (rank_verdict(all.data(), G, &who)) {
+    case 1: return bad(pre != SWP_OK ? pre : e->fail(SWP_EINVAL, "rank %u could not start the sharded run (code %d): no rank runs it", who, all[who].code));
+    case 2: return bad(e->fail(SWP_ERANGE, "rank %u: per-node task-count spread exceeds the %d level planes of the block resolver", who, R6_NP));
+    default: break;
     }
-    ma.hw_base[G] = ma.hw_total = hw;
-    if (r7_match_lds_size(hw) > lds_budget) return bad(e->fail(SWP_ERANGE, "%u nodes over all ranks exceed the matching wave's LDS", first));
-    ma.blk = ra.blk;
-    ma.ctl = ra.ctl;
-    ma.picks = d_picks.as<R7Pick>();
-    ma.head = d_head.as<R7Head>();
-    ma.merged = d_merged.as<R6Prop>();
+    if (T == 0) return SWP_OK;
     uint32_t pos = 0, chunk = std::min<uint32_t>(16u, (T + 255u) / 256u + 1u);
     uint64_t rounds = 0;
-    while (pos < T) {   // (every rank computes the same positions, hence the same chunks: the collectives line up)
+    hipError_t x = hipSuccess;
+    while (pos < T) {   // (every rank computes the same positions from the same gathered words, hence the same chunks: the collectives line up)
         for (uint32_t q = 0; q < chunk; ++q) {
             x = launch_r7_propose(d_args.as<R6Args>(), 1, block, Wn, task_rows, st, e->device);
             if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "propose: %s", hipGetErrorString(x)));
@@ -2942,8 +2999,13 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
         rounds += chunk;
         HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
         HIPCHECK(e, hipStreamSynchronize(st));
-        if (hb.error != ERR_NONE) return bad(e->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP));
-        if (hb.pos <= pos) return bad(e->fail(SWP_EHIP, "sharded rounds made no progress at task %u", pos));
+        if ((rc = rank_agree(e, r, st, d_stat, RankStatus{SWP_OK, hb.pos, hb.error, hb.rounds}, all))) return bad(rc);
+        switch (rank_verdict(all.data(), G, &who)) {
+        case 2: return bad(e->fail(SWP_ERANGE, "rank %u: per-node task-count spread exceeds the %d level planes of the block resolver", who, R6_NP));
+        case 3: return bad(e->fail(SWP_EHIP, "the ranks diverged: rank %u stands at task %u, rank 0 at %u", who, all[who].pos, all[0].pos));
+        default: break;
+        }
+        if (hb.pos <= pos) return bad(e->fail(SWP_EHIP, "sharded rounds made no progress at task %u", pos));   // (the same on every rank: the positions agree)
         const double pace = std::max(1.0, (double)hb.pos / (double)std::max<uint32_t>(hb.rounds, 1));
         pos = hb.pos;
         chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / pace * 1.05 + 4.0);
@@ -2961,7 +3023,7 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
         if (n < 0) continue;
         if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return bad(e->fail(SWP_EHIP, "device returned an invalid node index %d for task %u", n, i));
         const swp_task_desc& d = b->tasks[i];
-        if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
+        if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
         ++placed;
     }
     e->stats.batches++;

@@ -240,6 +240,17 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r7_apply(const R6Args* args, const R7Pick* p
             }
             if (r.flags & RT_PORTS)
                 for (u32 q = a.pset_off[r.pset]; q < a.pset_off[r.pset + 1]; ++q) wv::g_or64(a.portmap + (size_t)a.pset_ids[q] * Wn + w, bit);
+            if (a.n_rg) {   // Claim (resource_management.go:11-72), as k_r6_commit does it: the count drops by the request; the node leaves the kind's rows it no longer meets
+                const u32 gset = a.tg[t];
+                for (u32 g = a.gs_off[gset]; g < a.gs_off[gset + 1]; ++g) {
+                    const u32 row = a.gs_row[g];
+                    int32_t* cp = a.gcnt + (size_t)a.rg_kind[row] * a.gstride + nd;
+                    const int32_t c = *cp - a.rg_val[row];
+                    *cp = c;
+                    for (u32 r2 = a.rg_k0[row]; r2 < a.rg_k1[row]; ++r2)
+                        if (a.rg_val[r2] > c) wv::g_andn64(a.rg + (size_t)r2 * Wn + w, bit);
+                }
+            }
             if (!(r.flags & RT_UNCOUNTED)) {
                 a.total[nd] = old + 1;
                 const u32 rl = old - base, nl = rl + 1, xm = rl ^ nl;

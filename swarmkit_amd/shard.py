@@ -98,6 +98,10 @@ class ShardGroup:
         return _finish(shard, node, self.firsts, hists)
 
 
+class RcclUnavailable(RuntimeError):
+    """The job's ranks agreed that the RCCL path inside libswp.so cannot be used (raised on EVERY rank)."""
+
+
 class DeviceRankShard:
     """This process' shard of a job of `world` ranks with the rounds on the device and RCCL between the ranks
     (swp_shard_run_rank). `dist` (torch.distributed) only carries the RCCL bootstrap id and, at the end, the sum of the Explain
@@ -110,11 +114,44 @@ class DeviceRankShard:
         self.rounds = 0
         eng = batch.eng
         if not getattr(eng, "_rccl_ready", False):
-            box = [eng.rccl_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            eng.rccl_init(box[0], rank, world)
+            self._bootstrap(eng)
             eng._rccl_ready = True
+
+    def _agree(self, ok):
+        """min over the ranks of a 0 / 1 flag: every rank takes the same way out of the bootstrap."""
+        if self.world == 1:
+            return bool(ok)
+        import torch
+        t = torch.tensor([1 if ok else 0], device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def _bootstrap(self, eng):
+        """The RCCL communicator of the job, failure-symmetric: (1) every rank says whether its librccl.so is usable BEFORE anybody
+        enters ncclCommInitRank, (2) rank 0's unique id travels as (ok, id) so that a failure there is a message, not a missing
+        broadcast, (3) the outcome of the init is agreed on again. Whatever fails, every rank raises RcclUnavailable."""
+        rank, world, dist = self.rank, self.world, self.dist
+        if not self._agree(eng.rccl_available()):
+            raise RcclUnavailable("librccl.so is not usable on every rank of the job")
+        box = [None]
+        if rank == 0:
+            try:
+                box = [eng.rccl_unique_id()]
+            except Exception:   # the broadcast below still happens: it carries None
+                box = [None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise RcclUnavailable("rank 0 could not create the RCCL unique id")
+        err = None
+        try:
+            eng.rccl_init(box[0], rank, world)
+        except Exception as exc:
+            err = exc
+        if not self._agree(err is None):
+            if err is None:
+                eng.rccl_finalize()
+            raise RcclUnavailable("ncclCommInitRank failed on a rank of the job: %s" % (err,))
 
     def run(self, want_hist=True):
         before = self.b.eng.stats()["resolve_launches"]

@@ -4,8 +4,13 @@
 // with the sequential model of emu_model.hpp run over the WHOLE node set. What a job of G GPUs computes, without a GPU.
 // TEST INFRASTRUCTURE (tests/test_emu_resolve7.py); not product.
 //
-//   emu_resolve7 <seed> <N> <T> <S> <block> <order: 0 rr | 1 major | 2 random> <features 0..2> <shards> [v] [t: task rows]
+//   emu_resolve7 <seed> <N> <T> <S> <block> <order: 0 rr | 1 major | 2 random> <features 0..3> <shards> [v] [t: task rows] [r<rank>]
+// r<rank>: the RANK variant (swp_shard_run_rank's protocol): this process runs the kernels of ONE shard only; per round it writes its
+// block of R6Prop records to stdout (a u32 1 in front; a u32 0 when the batch is done), reads the blocks of ALL ranks back from stdin
+// in rank order — the layout ncclAllGather leaves in d_all — folds + matches them itself and applies the picks of its own range.
+// tests/test_dist_gloo.py runs one such process per rank and carries the blocks with torch.distributed.all_gather_into_tensor.
 #include "wv_emu.hpp"
+#include <unistd.h>
 
 #define SWP_R6_KERNELS
 #include "../../swarmkit_amd/csrc/swp_resolve6.hpp"
@@ -56,6 +61,11 @@ static Problem shard_of(const Problem& p, u32 first, u32 cnt) {
     q.pset_off = p.pset_off;
     q.pset_ids = p.pset_ids;
     q.rt = p.rt;
+    q.n_kinds = p.n_kinds;   // feature level 3: the counts of this range's nodes, the task sets and rows as they are
+    q.gcnt.assign(p.gcnt.empty() ? 0 : (size_t)(p.n_kinds + 1) * cnt, 0);
+    for (u32 k = 0; !p.gcnt.empty() && k <= p.n_kinds; ++k)
+        for (u32 i = 0; i < cnt; ++i) q.gcnt[(size_t)k * cnt + i] = p.gcnt[(size_t)k * p.N + first + i];
+    q.tg = p.tg; q.gs_off = p.gs_off; q.gs_row = p.gs_row; q.rg_kind = p.rg_kind; q.rg_val = p.rg_val; q.rg_k0 = p.rg_k0; q.rg_k1 = p.rg_k1;
     std::vector<u32> ntasks(p.S, 0), rank(p.T), init_cnt(p.S, 0);
     for (u32 j = 0; j < p.T; ++j) rank[j] = ntasks[p.rt[j].svc]++;
     q.list_off.assign(p.S + 1, 0);
@@ -83,7 +93,7 @@ static Problem shard_of(const Problem& p, u32 first, u32 cnt) {
 struct Shard {
     Problem p;
     State em;
-    std::vector<u64> planes, rr, trows;
+    std::vector<u64> planes, rr, trows, rg;
     std::vector<R6Prop> prop;
     Blk6 blk{};
     u32 first = 0;
@@ -92,13 +102,16 @@ struct Shard {
 int main(int argc, char** argv) {
     if (argc < 9) { fprintf(stderr, "usage: %s seed N T S block order features(0..2) shards [v] [t]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
-    const int order = atoi(argv[6]), feat = std::min(atoi(argv[7]), 2);
+    const int order = atoi(argv[6]), feat = std::min(atoi(argv[7]), 3);
     const u32 G = atoi(argv[8]);
     bool verbose = false, task_rows = false;
+    int my_rank = -1;   // >= 0: the rank variant
     for (int i = 9; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 't') task_rows = true;
+        if (argv[i][0] == 'r') my_rank = atoi(argv[i] + 1);
     }
+    if (my_rank >= (int)atoi(argv[8])) { fprintf(stderr, "rank %d of %s shards\n", my_rank, argv[8]); return 2; }
     if (G < 1 || G > R7_MAXS || G > N) { fprintf(stderr, "1..%d shards, at most one per node\n", R7_MAXS); return 2; }
     Problem p = make_problem(seed, N, T, S, order, feat);
     std::set<i64> sc, sm;
@@ -132,6 +145,7 @@ int main(int argc, char** argv) {
         s.planes.assign((size_t)R6_NP * s.p.Wn, 0xAAAAAAAAAAAAAAAAull);
         s.rr.assign((size_t)std::max<u32>(n_dc + n_dm, 1) * s.p.Wn, 0x5555555555555555ull);
         s.trows.assign((size_t)B * s.p.Wn, 0x7777777777777777ull);
+        s.rg.assign(std::max<size_t>(p.rg_kind.size(), 1) * s.p.Wn, 0x3333333333333333ull);
         s.prop.resize(B);
         max_words = std::max(max_words, s.p.Wn);
         first += cnt;
@@ -175,6 +189,19 @@ int main(int argc, char** argv) {
         a.thr = thr.data();
         a.blk = &s.blk;
         a.prop = s.prop.data();
+        if (!p.rg_kind.empty()) {   // feature level 3: generic reservations
+            a.n_rg = (u32)p.rg_kind.size();
+            a.gstride = s.p.N;
+            a.gcnt = s.em.gcnt.data();
+            a.rg = s.rg.data();
+            a.tg = s.p.tg.data();
+            a.gs_off = s.p.gs_off.data();
+            a.gs_row = s.p.gs_row.data();
+            a.rg_kind = s.p.rg_kind.data();
+            a.rg_val = s.p.rg_val.data();
+            a.rg_k0 = s.p.rg_k0.data();
+            a.rg_k1 = s.p.rg_k1.data();
+        }
     }
     std::vector<R6Prop> merged(B);
     std::vector<R7Pick> picks(B);
@@ -193,10 +220,18 @@ int main(int argc, char** argv) {
     ma.merged = merged.data();
     ma.blk = &sh[0].blk;
     ma.ctl = &sh[0].em.ctl;
+    std::vector<R6Prop> gathered;   // the rank variant: [G][B], what the all-gather leaves on every rank
+    if (my_rank >= 0) {
+        gathered.resize((size_t)G * B);
+        for (u32 g = 0; g < G; ++g) ma.prop[g] = gathered.data() + (size_t)g * B;
+        ma.blk = &sh[my_rank].blk;
+        ma.ctl = &sh[my_rank].em.ctl;
+    }
     ma.picks = picks.data();
     ma.head = &head;
 
     for (u32 g = 0; g < G; ++g) {   // build: base / highest level, planes and rows per shard
+        if (my_rank >= 0 && (int)g != my_rank) continue;
         const R6Args a = args[g];
         grid(1, 1024, 256, [a]() { k_r6_minmax(a); });
         grid((a.n_words + 3) / 4, 256, 0, [a]() { k_r6_rows(a); });
@@ -220,6 +255,57 @@ int main(int argc, char** argv) {
         const R7Head* hd = &head;
         grid(G, R6_COMMIT_THREADS, 0, [ap, pk, hd]() { k_r7_apply(ap, pk, hd, 0u); });
     };
+    auto io_all = [](int fd, void* buf, size_t n, bool wr) {
+        char* p = static_cast<char*>(buf);
+        while (n) {
+            const ssize_t k = wr ? write(fd, p, n) : read(fd, p, n);
+            if (k <= 0) { fprintf(stderr, "exchange pipe closed\n"); exit(4); }
+            p += k; n -= (size_t)k;
+        }
+    };
+    if (my_rank >= 0) {   // ---- the rank variant: one shard here, the blocks of the others arrive through the pipe
+        const u32 me = (u32)my_rank;
+        Shard& S0 = sh[me];
+        const R6Args* am = args.data() + me;
+        while (true) {
+            u32 go = S0.blk.pos < T ? 1u : 0u;
+            io_all(1, &go, 4, true);
+            if (!go) break;
+            const u32 before = S0.blk.pos;
+            for (R6Prop& q : S0.prop) memset(&q, 0xEE, sizeof q);
+            emu::blockidx_y() = 0;
+            if (task_rows) grid((S0.p.Wn + 3) / 4, 256, (size_t)B * 16, [am]() { k_r7_taskrows(am); });
+            grid(B, 64 * R6_PW, r6_propose_lds(S0.p.Wn), [am]() { k_r7_propose(am); });
+            io_all(1, S0.prop.data(), (size_t)B * sizeof(R6Prop), true);
+            io_all(0, gathered.data(), (size_t)G * B * sizeof(R6Prop), false);
+            if (memcmp(gathered.data() + (size_t)me * B, S0.prop.data(), (size_t)B * sizeof(R6Prop)) != 0) { fprintf(stderr, "rank %u: its own block came back changed\n", me); return 3; }
+            grid((B + 63) / 64, 64, 0, [ma]() { k_r7_fold(ma); });
+            grid(1, 64, r7_match_lds(ma.hw_total), [ma]() { k_r7_match(ma); });
+            const R7Pick* pk = picks.data();
+            const R7Head* hd = &head;
+            grid(1, R6_COMMIT_THREADS, 0, [am, pk, hd, me]() { k_r7_apply(am, pk, hd, me); });
+            ++rounds;
+            if (S0.blk.error) { fprintf(stderr, "rank %u reported error %u at task %u\n", me, S0.blk.error, S0.blk.pos); return 3; }
+            if (S0.blk.pos <= before) { fprintf(stderr, "no progress at task %u\n", before); return 3; }
+        }
+        bool ok = true;
+        for (u32 j = 0; j < T && ok; ++j) {   // the tasks placed in this range, and nothing else
+            const int32_t n = S0.em.out[j], want = ref.out[j];
+            const bool mine = want >= (int32_t)S0.first && want < (int32_t)(S0.first + S0.p.N);
+            if (mine ? n != want - (int32_t)S0.first : n >= 0) { fprintf(stderr, "rank %u task %u: local node %d, the model says global %d\n", me, j, n, want); ok = false; }
+        }
+        for (u32 i = 0; i < S0.p.N && ok; ++i) {
+            const u32 n = S0.first + i;
+            if (S0.em.cpu[i] != ref.cpu[n] || S0.em.mem[i] != ref.mem[n] || S0.em.total[i] != ref.total[n]) { fprintf(stderr, "rank %u node %u differs\n", me, n); ok = false; }
+            for (u32 k = 1; ok && !p.gcnt.empty() && k <= p.n_kinds; ++k)
+                if (S0.em.gcnt[(size_t)k * S0.p.N + i] != ref.gcnt[(size_t)k * N + n]) { fprintf(stderr, "rank %u node %u kind %u count differs\n", me, n, k); ok = false; }
+        }
+        ok = ok && S0.em.ctl.ncommit == ref.ctl.ncommit && S0.em.ctl.ninf == ref.ctl.ninf;
+        ok = ok && same("inf_task", S0.em.inf_task, ref.inf_task, ref.ctl.ninf) && same("inf_pos", S0.em.inf_pos, ref.inf_pos, ref.ctl.ninf);
+        fprintf(stderr, "rank %u of %u: seed %u N %u T %u block %u feat %d: %llu rounds, placed %u inf %u -> %s\n", me, G, seed, N, T, B, feat, (unsigned long long)rounds, ref.ctl.ncommit,
+                ref.ctl.ninf, ok ? "OK" : "FAIL");
+        return ok ? 0 : 1;
+    }
     while (sh[0].blk.pos < T) {
         const u32 before = sh[0].blk.pos;
         round();
@@ -256,6 +342,9 @@ int main(int argc, char** argv) {
         // host ports and the services' node sets, bit by bit against the whole-set rows
         const std::vector<u64> pm = slice_rows(ref.portmap, p.n_ports, p.Wn, s.first, s.p.N), xs = slice_rows(ref.X, p.S, p.Wn, s.first, s.p.N);
         ok = ok && same("portmap", s.em.portmap, pm, pm.size()) && same("X", s.em.X, xs, xs.size());
+        for (u32 k = 1; ok && !p.gcnt.empty() && k <= p.n_kinds; ++k)
+            for (u32 i = 0; i < s.p.N && ok; ++i)
+                if (s.em.gcnt[(size_t)k * s.p.N + i] != ref.gcnt[(size_t)k * N + s.first + i]) { fprintf(stderr, "MISMATCH generic count kind %u node %u\n", k, s.first + i); ok = false; }
         ok = ok && s.em.ctl.ncommit == ref.ctl.ncommit && s.em.ctl.ninf == ref.ctl.ninf;
         if (!ok) fprintf(stderr, "shard %u: ncommit %u (ref %u) ninf %u (ref %u)\n", g, s.em.ctl.ncommit, ref.ctl.ncommit, s.em.ctl.ninf, ref.ctl.ninf);
         ok = ok && same("inf_task", s.em.inf_task, ref.inf_task, ref.ctl.ninf) && same("inf_pos", s.em.inf_pos, ref.inf_pos, ref.ctl.ninf);

@@ -108,3 +108,82 @@ def test_node_range_shards_over_gloo(world, block):
         assert np.array_equal(np.asarray(out), want), rank
         assert rounds == got[0][2] and rounds < 900   # lock-step rounds; an exchange decides more than one task on average
     assert (want >= 0).sum() > 100 and (want < 0).sum() > 0   # the toy problem places most tasks and rejects some
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The DEVICE-ROUNDS protocol bench.py --gpus N runs (swp_shard_run_rank): one process per rank, each with ONE shard; per round the rank
+# proposes over its own range with the product's kernel source, the blocks of R6Prop records of all ranks are all-gathered in rank order
+# (the layout ncclAllGather leaves in d_all), EVERY rank folds + matches the gathered blocks itself and applies the picks of its range.
+# Here the kernels run on CPU fibers (tests/emu/emu_resolve7.cpp, rank variant) and torch.distributed over gloo carries the blocks.
+def _emu7():
+    import subprocess
+    here = os.path.join(ROOT, "tests")
+    out = os.path.join(here, "_build", "emu_resolve7")
+    csrc = os.path.join(ROOT, "swarmkit_amd", "csrc")
+    srcs = [os.path.join(here, "emu", f) for f in ("emu_resolve7.cpp", "wv_emu.hpp", "emu_model.hpp")] + [os.path.join(csrc, f) for f in ("swp_resolve6.hpp", "swp_resolve7.hpp", "swp_shard.hpp", "swp_types.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        tmp = out + ".%d.tmp" % os.getpid()
+        subprocess.run(["g++", "-O1", "-std=c++17", "-o", tmp, srcs[0]], check=True)
+        os.replace(tmp, out)
+    return out
+
+
+def _rounds_worker(rank, world, port, q, emu, case):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import subprocess
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seed, N, T, S, block, order, feat = case
+    prop_bytes = 8 + 16 * 16 + 24   # sizeof(R6Prop): level, n_cand, 2 x 32 half-word entries, the exception-list candidate
+    proc = subprocess.Popen([emu] + [str(x) for x in (seed, N, T, S, block, order, feat, world)] + ["r%d" % rank], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    rounds = 0
+    try:
+        while True:
+            go = int.from_bytes(proc.stdout.read(4), "little")
+            flags = torch.tensor([go], dtype=torch.int64)
+            all_flags = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(all_flags, flags)
+            assert len({int(f.item()) for f in all_flags}) == 1, "the ranks disagree on whether the batch is done: %s" % all_flags
+            if not go:
+                break
+            mine = torch.frombuffer(bytearray(proc.stdout.read(block * prop_bytes)), dtype=torch.uint8)
+            assert mine.numel() == block * prop_bytes
+            gathered = torch.empty(world * mine.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, mine)     # rank order: [rank 0's block][rank 1's block]...
+            proc.stdin.write(gathered.numpy().tobytes())
+            proc.stdin.flush()
+            rounds += 1
+        proc.stdin.close()
+        err = proc.stderr.read().decode()
+        rc = proc.wait(timeout=120)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    q.put((rank, rc, rounds, err[-600:]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# (seed, nodes, tasks, services, block, task order, feature level)
+@pytest.mark.parametrize("world,case", [(2, (2, 700, 900, 30, 64, 0, 1)), (3, (3, 1000, 700, 40, 64, 2, 2)), (3, (7, 500, 600, 40, 32, 0, 3)), (2, (13, 401, 500, 8, 128, 1, 1))],
+                         ids=["2ranks-maxrep", "3ranks-ports-uncounted", "3ranks-generic", "2ranks-service-major"])
+def test_device_rounds_protocol_over_gloo(world, case):
+    """Every rank's shard ends exactly where the sequential model over the WHOLE node set puts it; the ranks take the same number of
+    rounds and agree on the end of the batch in the same round."""
+    import torch.multiprocessing as mp
+    emu = _emu7()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_rounds_worker, args=(rk, world, port, q, emu, case)) for rk in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rc, rounds, err in got:
+        assert rc == 0 and "-> OK" in err, (rank, rc, err)
+        assert rounds == got[0][2] and 0 < rounds < case[2]   # lock-step rounds; an exchange decides more than one task on average

@@ -40,6 +40,9 @@ CASES = [
     (21, 2000, 1050, 150, 1024, 0, 0, 3, ""),  # the largest block
     (7, 1500, 1200, 60, 64, 0, 1, 4, "t"),     # task-rows mode
     (9, 37, 150, 12, 32, 2, 2, 8, ""),         # shards of four or five nodes
+    (7, 500, 800, 40, 64, 0, 3, 3, ""),        # feature level 3: generic reservations (HasEnough rows per shard, Claim in k_r7_apply on the owner)
+    (8, 885, 1000, 125, 64, 2, 3, 4, ""),
+    (10, 1200, 900, 90, 128, 0, 3, 8, "t"),    # ... in task-rows mode
 ]
 
 

@@ -115,3 +115,53 @@ def test_rank_variant_over_rccl_with_one_rank(name, T, N):
     b.free()
     s.e.rccl_finalize()
     pu.assert_same(op, oe, placed, errs)
+
+
+class GenericWorkload(synth.Workload):
+    """cfg3's cluster with Discrete generic resources on the nodes and Discrete reservations on two thirds of the services."""
+
+    def node_doc(self, i):
+        d = super().node_doc(i)
+        gen = []
+        if i % 4:
+            gen.append({"Discrete": {"Kind": "gpu", "Value": i % 4}})
+        if i % 7 == 0:
+            gen.append({"Discrete": {"Kind": "fpga", "Value": 2}})
+        d["Description"]["Resources"]["Generic"] = gen
+        return d
+
+    def service_spec(self, k):
+        t = super().service_spec(k)
+        if k % 3:
+            gen = [{"Discrete": {"Kind": "gpu", "Value": 1 + k % 2}}] + ([{"Discrete": {"Kind": "fpga", "Value": 1}}] if k % 5 == 0 else [])
+            t.setdefault("Spec", {}).setdefault("Resources", {}).setdefault("Reservations", {})["Generic"] = gen
+        return t
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_shards_with_generic_reservations(shards):
+    """Generic reservations through the sharded rounds (round 3 refused them): HasEnough as rows of every shard's propose, Claim in
+    k_r7_apply on the owner — against the oracle and against the single engine."""
+    wl = GenericWorkload("cfg3", T=3000, N=500)
+    op, oe, _ = pu.oracle_run(wl)
+    sp, se, _ = pu.sharded_run(wl, shards, mode="device")
+    pu.assert_same(op, oe, sp, se)
+
+
+def _digest(wl, placed, errs):
+    """The tick digest of tests/bigcases.py from a placement map (what the host layer's decision lines would say)."""
+    import hashlib
+    lines = sorted("%s|%s|%s|%d" % (tid, placed[tid] or "", "" if placed[tid] else errs[tid], 192 if placed[tid] else 64) for tid in placed)
+    return hashlib.sha256("\n".join(lines).encode()).hexdigest(), sum(1 for v in placed.values() if v)
+
+
+def test_cfg4_200k_x_40k_over_8_shards_matches_the_oracle_digest():
+    """BASELINE configs[3] at a fifth of its size over EIGHT shards (the job size SURVEY 8e names) against the oracle's offline digest."""
+    import json
+    import os
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_cfg4_mid.json")))
+    wl = synth.Workload("cfg4", T=200_000, N=40_000)
+    sp, se, _ = pu.sharded_run(wl, 8, mode="device")
+    h, placed = _digest(wl, sp, se)
+    assert placed == want["placed"][0]
+    assert h == want["ticks"][0]

@@ -84,3 +84,23 @@ def test_oracle_matches_golden_fixture(name):
     placed, errs, _ = pu.oracle_run(wl)
     assert [placed[wl.task_id(j)] for j in range(wl.T)] == g["node_of_task"]
     assert {k: v for k, v in errs.items()} == g["errors"]
+
+
+def test_the_ranks_of_a_sharded_run_derive_one_verdict_from_the_gathered_status_words():
+    """swp_shard_run_rank's agreed abort (a rank that returned on its own left its peers inside ncclAllGather): every rank
+    contributes {code, position, kernel error, rounds}, every rank derives the same verdict from the same gathered words."""
+    import ctypes as C
+    import numpy as np
+    from swarmkit_amd import abi
+    L = abi.load_library()
+
+    def verdict(*ranks):
+        a = np.array([w for r in ranks for w in r], dtype=np.uint32)
+        who = C.c_uint32(99)
+        return L.swp_shard_verdict(a.ctypes.data, len(ranks), C.byref(who)), who.value
+    ok = (0, 512, 0, 3)
+    assert verdict(ok, ok, ok) == (0, 0)
+    assert verdict(ok, (0xFFFFFFFF, 0, 0, 0), ok) == (1, 1)          # rank 1 could not start: nobody runs
+    assert verdict(ok, ok, (0, 512, 1, 3)) == (2, 2)                  # rank 2's kernels reported the level range
+    assert verdict(ok, (0, 500, 0, 3), ok) == (3, 1)                  # the positions differ: the ranks diverged
+    assert verdict((0xFFFFFFFA, 0, 0, 0), (0, 0, 1, 0)) == (1, 0)    # a refusal outranks a kernel error

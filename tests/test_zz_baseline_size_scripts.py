@@ -34,3 +34,20 @@ def test_baseline_size_script_matches_oracle_digests(case):
     for k in ("T", "N", "seed", "created", "still_placed", "rounds"):
         if k in want:
             assert got[k] == want[k], k
+
+
+def test_cfg4_1m_x_100k_over_8_shards_matches_the_oracle_digest():
+    """BASELINE configs[3] at its full size with the node set split over 8 engines (here: on the one GPU; swp_shard_run, the kernels a
+    job of 8 ranks runs) against the digest the oracle produced offline for the single sequential scan."""
+    import test_engine_shards as tes
+    import parity_util as pu
+    from swarmkit_amd import synth
+    path = os.path.join(GOLD, "big_cfg4_full.json")
+    if not os.path.exists(path) or os.environ.get("SWP_TEST_HUGE") == "0":
+        pytest.skip("no digest / SWP_TEST_HUGE=0")
+    want = json.load(open(path))
+    wl = synth.Workload("cfg4")
+    sp, se, _ = pu.sharded_run(wl, 8, mode="device")
+    h, placed = tes._digest(wl, sp, se)
+    assert placed == want["placed"][0]
+    assert h == want["ticks"][0]
