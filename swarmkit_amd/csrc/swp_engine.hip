@@ -29,6 +29,7 @@
 #include "swp_launch.hpp"
 #include "swp_resolve6.hpp"
 #include "swp_resolve7.hpp"
+#include "swp_scan.hpp"
 #include "swp_shard.hpp"
 #include "swp_waterfill.hpp"
 
@@ -243,6 +244,7 @@ struct swp_batch {
     DevBuf d_tg, d_gs_off, d_gs_row, d_rg_kind, d_rg_k0, d_rg_k1, d_rg_val, d_rg;
 
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
+    DevBuf d_hmat, d_emat;   // the scan resolver's (service, node) matrices, allocated when a stretch first goes to it
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
     DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
     DevBuf d_con, d_plat, d_plug, d_sc, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
@@ -1341,9 +1343,11 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     const char* env_res = getenv("SWP_RESOLVER");
     const char* env_dbg = getenv("SWP_DBG");
     const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
-    // (without the knob: the round resolver for a short batch it can hold — one launch, no bitmaps to build — the block resolver for
-    // everything else: measured faster from a few ten thousand tasks on even where both apply, 12.8 vs 14.9 ms on 100k x 10k)
-    int variant = env_res ? atoi(env_res) : (T < 16384u ? 5 : 6);
+    // (without the knob: the block resolver. Round 4 measured it ahead of the round resolver at EVERY batch size on 10 000 nodes — 0.21 vs
+    // 0.54 ms for 256 tasks, 1.1 vs 1.5 ms for 8 192, 12.8 vs 14.9 ms for 100 000 — and twice as fast on the churn rounds, whose ~9 000
+    // re-placements all aim at the few emptied nodes (profiles/r04_*). The round resolver stays as the family that needs no bitmaps:
+    // SWP_RESOLVER=5, and the fall-back below.)
+    int variant = env_res ? atoi(env_res) : 6;
     if (variant != 5 && variant != 6) return e->fail(SWP_EINVAL, "SWP_RESOLVER=%d: the resolver families are 5 (round) and 6 (block)", variant);
     const size_t r5_lds = r5_lds_size(N, Wn, b->exact_ok ? b->n_dc + b->n_dm : 0u);
     bool r5_ok = b->exact_ok && b->units_ok && r5_supports(Wn) && r5_lds <= lds_budget && !b->has_generic;
@@ -1368,7 +1372,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     const bool r6_ok = r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, r6_nrr) <= lds_budget;
     if (variant == 5 && !r5_ok) variant = 6;
     if (variant == 6 && !r6_ok) {
-        if (env_res && r5_ok) variant = 5;   // (forced at a size it cannot hold)
+        if (r5_ok) variant = 5;   // (a node set whose rows leave the block resolver no LDS but fits the round resolver's: cannot happen with today's limits)
         else return e->fail(SWP_ERANGE, "node count %u exceeds the block resolver's LDS (shard the node set)", N);
     }
     if (variant == 5) {
@@ -1401,18 +1405,50 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         hipError_t r = launch_r6_build(ra, st);
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(r));
         uint32_t pos = start, chunk = std::min<uint32_t>(16u, (end - start + 255u) / 256u + 1u);   // a short stretch does not pay for empty rounds
+        uint32_t rounds_seen = 0, scan_len = 2048, scanned = 0;
+        const char* env_scan = getenv("SWP_SCAN");   // 0: never hand a stretch to the scan resolver (tests, A/B runs)
+        const bool scan_ok = N <= scan_max_nodes() && !(env_scan && atoi(env_scan) == 0);
         while (pos < end) {
             r = launch_r6_rounds(ra, chunk, st, e->device);
             if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
             HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
             HIPCHECK(e, hipStreamSynchronize(st));
+            if (hb.error == ERR_GROUP_RANGE) return e->fail(SWP_ERANGE, "a node's key left its range (>= 256 recent failures or >= 2^24 tasks of one service on a node)");
             if (hb.error != ERR_NONE) return e->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP);
             if (hb.pos <= pos) return e->fail(SWP_EHIP, "block resolver made no progress at task %u", pos);   // a round decides its first task at least
-            // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
-            const double pace = std::max(1.0, (double)(hb.pos - start) / (double)std::max<uint32_t>(hb.rounds, 1));
+            // The rounds of this chunk decided only a handful of tasks each: the tasks here have no plain candidates (their services run on
+            // every node that could take them) and a round ends behind the first of them. The scan resolver decides such a stretch one task
+            // after the other at ~1 us each (swp_scan.hpp); afterwards the bitmaps are rebuilt and the rounds are tried again.
+            const uint32_t used = hb.rounds - rounds_seen;   // rounds that found work
+            const double recent = (double)(hb.pos - pos) / (double)std::max<uint32_t>(used, 1);
+            rounds_seen = hb.rounds;
             pos = hb.pos;
+            if (scan_ok && used >= 8 && recent < 8.0 && end - pos >= 64) {
+                const uint32_t upto = std::min<uint64_t>(end, (uint64_t)pos + scan_len);
+                ScanArgs sa{};
+                sa.a = ra;
+                sa.j0 = pos;
+                sa.j1 = upto;
+                sa.n_svc = b->n_svc;
+                HIPCHECK(e, b->d_hmat.reserve((size_t)b->n_svc * N * 4));
+                HIPCHECK(e, b->d_emat.reserve((size_t)b->n_svc * N * 4));
+                sa.hmat = b->d_hmat.as<uint32_t>();
+                sa.emat = b->d_emat.as<uint32_t>();
+                r = launch_scan(sa, st, e->device);
+                if (r == hipSuccess) r = launch_r6_build(ra, st);   // the rounds go on from the rows as the scan left them
+                if (r != hipSuccess) return e->fail(SWP_EHIP, "k_scan launch: %s", hipGetErrorString(r));
+                scanned += upto - pos;
+                pos = upto;
+                scan_len = std::min<uint32_t>(scan_len * 2, 1u << 20);   // still no plain candidates afterwards: the next stretch is twice as long
+                chunk = 16;
+                continue;
+            }
+            // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
+            const double pace = std::max(1.0, recent);
             chunk = (uint32_t)std::min<double>(4096.0, (double)(end - pos) / pace * 1.05 + 4.0);
+            if (scan_ok) chunk = std::min<uint32_t>(chunk, recent < 32.0 ? 64u : 256u);   // (look again soon: rounds that hit such a stretch decide one task each)
         }
+        if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u)\n", scanned, start, end);
         r6_rounds += hb.rounds;
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
         ++wi;

@@ -41,6 +41,11 @@ struct ShardApplyArgs;
 hipError_t launch_propose(const ProposeArgs& a, hipStream_t s);
 hipError_t launch_shard_apply(const ShardApplyArgs& a, hipStream_t s);
 
+// the scan resolver (swp_scan.hpp, built in swp_resolve6.hip)
+struct ScanArgs;
+uint32_t scan_max_nodes();
+hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev);
+
 // task groups (swp_groups.hip)
 struct Groups2Args;
 hipError_t launch_groups2(const Groups2Args& a, hipStream_t s, int dev);

@@ -6,6 +6,8 @@
 #define SWP_R6_KERNELS
 #include "swp_resolve6.hpp"
 #include "swp_resolve7.hpp"
+#define SWP_SCAN_KERNELS
+#include "swp_scan.hpp"
 
 namespace swpdev {
 
@@ -56,6 +58,23 @@ hipError_t launch_r7_match(const R7Args& a, hipStream_t s, int dev) {
 }
 hipError_t launch_r7_apply(const R6Args* args, uint32_t count, const R7Pick* picks, const R7Head* head, uint32_t shard0, hipStream_t s) {
     hipLaunchKernelGGL(k_r7_apply, dim3(count), dim3(R6_COMMIT_THREADS), 0, s, args, picks, head, shard0);
+    return hipGetLastError();
+}
+
+
+// ---- the scan resolver (swp_scan.hpp): a stretch of tasks one after the other, every task by one workgroup over all nodes ----
+uint32_t scan_max_nodes() { return SCAN_MAXN; }
+hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev) {
+    const size_t lds = scan_lds(s.a.n_nodes);
+    hipError_t r;
+    const uint32_t nq = (s.a.n_nodes + SCAN_THREADS - 1) / SCAN_THREADS;
+    const void* fn = nq <= 1 ? reinterpret_cast<const void*>(&k_scan<1>) : nq == 2 ? reinterpret_cast<const void*>(&k_scan<2>) : reinterpret_cast<const void*>(&k_scan<4>);
+    if (lds > 48 * 1024 && (r = ensure_big_lds(fn, dev)) != hipSuccess) return r;
+    hipLaunchKernelGGL(k_scan_fill, dim3(1024), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(k_scan_lists, dim3(64, s.n_svc), dim3(256), 0, st, s);
+    if (nq <= 1) hipLaunchKernelGGL(k_scan<1>, dim3(1), dim3(SCAN_THREADS), lds, st, s);
+    else if (nq == 2) hipLaunchKernelGGL(k_scan<2>, dim3(1), dim3(SCAN_THREADS), lds, st, s);
+    else hipLaunchKernelGGL(k_scan<4>, dim3(1), dim3(SCAN_THREADS), lds, st, s);
     return hipGetLastError();
 }
 

@@ -1,0 +1,221 @@
+// swp_scan.hpp — the SCAN resolver: the sequential argmin of the tick taken literally (nodeSet.tree with a heap of one, nodeset.go:50-124:
+// the node with the least nodeLess key, scheduler.go:708-735, the lowest index among equals; NodeInfo.addTask, nodeinfo.go:108-154),
+// one task after the other, every task by ALL threads of one workgroup over ALL nodes.
+//
+// What it is for. The block resolver (swp_resolve6.hpp) decides hundreds of tasks a round as long as tasks find PLAIN nodes (the task's
+// service does not run there yet, fewer than five recent failures). A task without one must take the best node of its service's
+// exception list by the full key, and that order moves with every placement of the service: the block resolver lets such a task be only
+// a block's first (one task per ~50 us round). A stretch of such tasks — a service with more tasks than the cluster has nodes: every
+// small cluster, BASELINE configs[0]'s 1 000 tasks on 10 nodes once they belong to several services — goes through this kernel instead:
+// ~1 us per task on up to SCAN_MAXN nodes, whatever the tasks are. The engine switches to it when the block resolver's rounds decide
+// fewer than a handful of tasks each, and back after the stretch (swp_engine.hip, run_blocks).
+//
+// State: the node rows (cpu, mem, total) live in LDS for the stretch; per (service, node) the key's upper half — failures >= 5 in bits
+// 24-31, ActiveTasksCountByService in bits 0-23 — and the service's list entry of the node sit in two dense matrices in global memory
+// (built from the lists by k_scan_prep; a node is only ever looked at by the one thread that owns it, so nothing there is shared).
+// Written against swp_wave.hpp only (tests/emu/emu_scan.cpp runs it on CPU fibers against the sequential model).
+#pragma once
+#include "swp_resolve6.hpp"
+
+namespace swpdev {
+
+#define SCAN_THREADS 1024
+#define SCAN_MAXN 4096      // nodes: (8 + 8 + 4 + 4) bytes of LDS each
+
+struct ScanArgs {
+    R6Args a;          // the block resolver's argument record: node rows, static class rows, lists, host ports, generic sets, logs
+    u32 j0, j1;        // the stretch: tasks [j0, j1)
+    u32 n_svc, pad;
+    u32* hmat;         // [n_svc][n_nodes] (failures >= 5 ? failures : 0) << 24 | ActiveTasksCountByService
+    u32* emat;         // [n_svc][n_nodes] list entry of (service, node), LIST_EMPTY: none
+};
+#define SCAN_RTQ 32         // task records staged through LDS at a time (their loads are misses: a record is read once)
+inline __host__ __device__ size_t scan_lds(u32 n_nodes) { return (size_t)n_nodes * 24 + 16 * 16 + 64 + 2 * SCAN_RTQ * 64; }
+
+#ifdef SWP_SCAN_KERNELS
+// hmat / emat from the per-service lists: grid (entries of the longest list / 256, services)
+WV_KERNEL(256) void k_scan_fill(ScanArgs s) {
+    const size_t n = (size_t)s.n_svc * s.a.n_nodes;
+    for (size_t i = (size_t)wv::block() * 256 + wv::tid(); i < n; i += (size_t)256 * 1024) {
+        s.hmat[i] = 0;
+        s.emat[i] = LIST_EMPTY;
+    }
+}
+WV_KERNEL(256) void k_scan_lists(ScanArgs s) {
+    const u32 svc = wv::block_y();
+    const u32 e0 = s.a.list_off[svc], e1 = s.a.list_off[svc + 1];
+    for (u32 e = e0 + wv::block() * 256 + wv::tid(); e < e1; e += 256u * 64u) {
+        const u32 n = s.a.list_node[e];
+        if (n == LIST_EMPTY) continue;
+        const u32 fl = s.a.list_fail[e], sv = s.a.list_svc[e];
+        if (fl >= 256u || sv >= (1u << 24)) s.a.blk->error = ERR_GROUP_RANGE;
+        s.hmat[(size_t)svc * s.a.n_nodes + n] = ((fl >= MAX_FAILURES ? fl : 0u) << 24) | sv;
+        s.emat[(size_t)svc * s.a.n_nodes + n] = e;
+    }
+}
+
+// SCAN_NQ: nodes per thread (the launcher instantiates 1, 2 and 4: a thread of a 1 000-node scan carries no code for nodes it has not)
+template <int SCAN_NQ>
+WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
+    const R6Args& a = s.a;
+    const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave(), N = a.n_nodes, Wn = a.n_words;
+    unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
+    i64* cpu = reinterpret_cast<i64*>(l);
+    i64* mem = cpu + N;
+    u32* tot = reinterpret_cast<u32*>(mem + N);
+    int32_t* lastc = reinterpret_cast<int32_t*>(tot + N);                               // the node's last commit (Explain's chains)
+    u64* red_k = reinterpret_cast<u64*>(l + (((size_t)N * 24 + 15) & ~(size_t)15));   // [16] per wave: its least key ...
+    u32* red_n = reinterpret_cast<u32*>(red_k + 16);                                     // ... and the lowest node that has it
+    u32* rtq = red_n + 16;                                                               // [2][SCAN_RTQ] task records, as dwords
+    if (a.blk->error != ERR_NONE) return;
+    for (u32 n = tid; n < N; n += SCAN_THREADS) { cpu[n] = a.cpu[n]; mem[n] = a.mem[n]; tot[n] = a.total[n]; lastc[n] = a.last[n]; }
+    u32 nc = a.ctl->ncommit, ni = a.ctl->ninf;
+    wv::barrier();
+    // What a task reads from global memory — its record, its static-class word and the key halves of this thread's nodes — is
+    // requested one task AHEAD: a task's turn then starts with everything in registers (a global round trip per task would be most
+    // of its time). The one value the task in between can change, the key half of the node it takes, is corrected by its owner.
+    // The task records themselves stream through LDS, SCAN_RTQ at a time, a chunk ahead (each is read once: a miss all the way to HBM).
+    const u32* rt32 = reinterpret_cast<const u32*>(a.rt);
+    const u32 cdw = SCAN_RTQ * 16u;   // dwords of a chunk
+    auto chunk_load = [&](u32 c) -> u32 {   // this thread's dword of chunk c (tasks j0 + c * SCAN_RTQ ...), 0 beyond the stretch
+        const u32 t0 = s.j0 + c * SCAN_RTQ;
+        return (tid < cdw && t0 + tid / 16u < s.j1) ? rt32[(size_t)t0 * 16u + tid] : 0u;
+    };
+    if (tid < cdw) rtq[tid] = chunk_load(0);
+    u32 next_dw = chunk_load(1);
+    wv::barrier();
+    auto task_rec = [&](u32 t) -> RTask {
+        const u32 i = t - s.j0;
+        return *reinterpret_cast<const RTask*>(rtq + ((i / SCAN_RTQ) & 1u) * cdw + (i % SCAN_RTQ) * 16u);
+    };
+    RTask rn = task_rec(s.j0 < s.j1 ? s.j0 : 0);
+    u64 scn[SCAN_NQ];
+    u32 hin[SCAN_NQ], ein[SCAN_NQ];
+    WV_UNROLL
+    for (int q = 0; q < SCAN_NQ; ++q) {
+        const u32 n = tid + (u32)q * SCAN_THREADS;
+        scn[q] = n < N ? a.sc[(size_t)rn.sc * Wn + (n >> 6)] : 0ull;
+        hin[q] = n < N ? s.hmat[(size_t)rn.svc * N + n] : 0u;
+        ein[q] = n < N ? s.emat[(size_t)rn.svc * N + n] : LIST_EMPTY;
+    }
+    for (u32 t = s.j0; t < s.j1; ++t) {
+        const RTask r = rn;
+        u64 scw[SCAN_NQ];
+        u32 hiw[SCAN_NQ], enw[SCAN_NQ];
+        WV_UNROLL
+        for (int q = 0; q < SCAN_NQ; ++q) { scw[q] = scn[q]; hiw[q] = hin[q]; enw[q] = ein[q]; }
+        if (t + 1 < s.j1) {
+            if ((t + 1 - s.j0) % SCAN_RTQ == 0) {   // the next task opens a chunk: it is in this thread's register since the chunk before
+                const u32 c = (t + 1 - s.j0) / SCAN_RTQ;
+                if (tid < cdw) rtq[(c & 1u) * cdw + tid] = next_dw;   // (that half was last read a chunk ago: a barrier per task lies in between)
+                next_dw = chunk_load(c + 1);
+                wv::barrier();
+            }
+            rn = task_rec(t + 1);
+            WV_UNROLL
+            for (int q = 0; q < SCAN_NQ; ++q) {
+                const u32 n = tid + (u32)q * SCAN_THREADS;
+                scn[q] = n < N ? a.sc[(size_t)rn.sc * Wn + (n >> 6)] : 0ull;
+                hin[q] = n < N ? s.hmat[(size_t)rn.svc * N + n] : 0u;
+                ein[q] = n < N ? s.emat[(size_t)rn.svc * N + n] : LIST_EMPTY;
+            }
+        }
+        const u32 gset = a.n_rg ? a.tg[t] : 0u;
+        // ---- every thread: the best of its own nodes
+        u64 bk = KEY_NONE;
+        u32 bn = R6_NONE;
+        WV_UNROLL
+        for (int q = 0; q < SCAN_NQ; ++q) {
+            const u32 n = tid + (u32)q * SCAN_THREADS;
+            if (n >= N) continue;
+            const u32 w = n >> 6;
+            const u64 bit = 1ull << (n & 63);
+            if (!(scw[q] & bit)) continue;   // (the static class row holds valid & ready & constraints & platform & plugins)
+            const u32 hi = hiw[q];
+            if ((r.flags & RT_RES) && !(r.cpu <= cpu[n] && r.mem <= mem[n])) continue;
+            bool ok = true;
+            if (gset)
+                for (u32 g = a.gs_off[gset]; g < a.gs_off[gset + 1]; ++g) {
+                    const u32 row = a.gs_row[g];
+                    if (a.gcnt[(size_t)a.rg_kind[row] * a.gstride + n] < a.rg_val[row]) ok = false;   // HasEnough, validate.go:24-52
+                }
+            if (ok && (r.flags & RT_PORTS))
+                for (u32 z = a.pset_off[r.pset]; z < a.pset_off[r.pset + 1]; ++z)
+                    if (wv::g_fresh64(a.portmap + (size_t)a.pset_ids[z] * Wn + w) & bit) ok = false;
+            if (ok && (r.flags & RT_MAXREP) && !((u64)(hi & 0xFFFFFFu) < r.maxrep)) ok = false;
+            if (!ok) continue;
+            const u64 key = ((u64)hi << 32) | tot[n];
+            if (key < bk) { bk = key; bn = n; }   // (a thread's nodes ascend: the first of equal keys stays)
+        }
+        // ---- the workgroup's argmin: least key, lowest node among equals. Every wave reduces the 16 wave results itself (no second barrier).
+        const u64 wk = r6_wave_min64(bk);
+        const u32 wn = wv::min_u32(bk == wk ? bn : R6_NONE);
+        if (lane == 0) { red_k[wave] = wk; red_n[wave] = wn; }
+        wv::barrier();
+        const u64 k2 = lane < SCAN_THREADS / 64 ? red_k[lane] : KEY_NONE;
+        const u32 n2 = lane < SCAN_THREADS / 64 ? red_n[lane] : R6_NONE;
+        const u64 gk = r6_wave_min64(k2);
+        const u32 gn = wv::min_u32(k2 == gk ? n2 : R6_NONE);
+        // ---- the owner of the node applies the placement (NodeInfo.addTask); everybody counts
+        if (gn == R6_NONE) {
+            if (tid == 0) {
+                a.inf_task[ni] = t;
+                a.inf_pos[ni] = nc;
+                a.out_node[t] = -1;
+            }
+            ++ni;
+        } else {
+            if ((gn & (SCAN_THREADS - 1u)) == tid) {
+                const u32 nd = gn, w = nd >> 6;
+                const u64 bit = 1ull << (nd & 63);
+                if (r.cpu) cpu[nd] -= r.cpu;
+                if (r.mem) mem[nd] -= r.mem;
+                if (gset)
+                    for (u32 g = a.gs_off[gset]; g < a.gs_off[gset + 1]; ++g) a.gcnt[(size_t)a.rg_kind[a.gs_row[g]] * a.gstride + nd] -= a.rg_val[a.gs_row[g]];   // Claim
+                if (r.flags & RT_PORTS)
+                    for (u32 q = a.pset_off[r.pset]; q < a.pset_off[r.pset + 1]; ++q) wv::g_or64(a.portmap + (size_t)a.pset_ids[q] * Wn + w, bit);
+                if (!(r.flags & RT_UNCOUNTED)) {
+                    tot[nd] += 1;
+                    u32 hi = 0, entry = LIST_EMPTY;   // the node's key half and list entry for this service: read a task ago, in registers
+                    WV_UNROLL
+                    for (int q = 0; q < SCAN_NQ; ++q)
+                        if (tid + (u32)q * SCAN_THREADS == nd) { hi = hiw[q]; entry = enw[q]; }
+                    hi += 1u;
+                    if ((hi & 0xFFFFFFu) == 0) a.blk->error = ERR_GROUP_RANGE;
+                    s.hmat[(size_t)r.svc * N + nd] = hi;
+                    if (entry == LIST_EMPTY) {
+                        wv::g_or64(a.X + (size_t)r.svc * a.xs + w, bit);
+                        a.list_node[r.slot] = nd;
+                        a.list_svc[r.slot] = 1;
+                        a.list_fail[r.slot] = 0;
+                        s.emat[(size_t)r.svc * N + nd] = r.slot;
+                        entry = r.slot;
+                    } else
+                        a.list_svc[entry] = hi & 0xFFFFFFu;   // (the entry's count is the key half's low 24 bits)
+                    if (rn.svc == r.svc) {   // the next task is of the same service: what it read of this node is a placement old
+                        WV_UNROLL
+                        for (int q = 0; q < SCAN_NQ; ++q)
+                            if (tid + (u32)q * SCAN_THREADS == nd) { hin[q] = hi; ein[q] = entry; }
+                    }
+                }
+                const int32_t prev = lastc[nd];
+                a.log_node[nc] = nd;
+                a.log_task[nc] = t;
+                a.log_prev[nc] = prev;
+                lastc[nd] = (int32_t)nc;
+                a.out_node[t] = (int32_t)nd;
+            }
+            ++nc;
+        }
+        wv::barrier();   // the next task sees this one's node row; red_k / red_n are free again
+    }
+    for (u32 n = tid; n < N; n += SCAN_THREADS) { a.cpu[n] = cpu[n]; a.mem[n] = mem[n]; a.total[n] = tot[n]; a.last[n] = lastc[n]; }
+    if (tid == 0) {
+        a.ctl->ncommit = nc;
+        a.ctl->ninf = ni;
+        a.blk->pos = s.j1;
+    }
+}
+#endif   // SWP_SCAN_KERNELS
+
+}  // namespace swpdev

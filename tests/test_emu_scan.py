@@ -1,0 +1,48 @@
+"""CPU: the scan resolver's kernel SOURCE (swarmkit_amd/csrc/swp_scan.hpp) on fibers against the sequential model of tests/emu/emu_model.hpp:
+every output and every mutated array; alone, and in the middle of a batch between two stretches of the block resolver (the hand-over the
+engine does when a stretch of tasks has no plain candidates). No GPU involved; the GPU parity is tests/test_engine_dense.py."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu")
+BIN = os.path.join(HERE, "_build", "emu_scan")
+CSRC = os.path.join(HERE, "..", "swarmkit_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu_bin():
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    srcs = [os.path.join(EMU, "emu_scan.cpp"), os.path.join(EMU, "wv_emu.hpp"), os.path.join(EMU, "emu_model.hpp"),
+            os.path.join(CSRC, "swp_scan.hpp"), os.path.join(CSRC, "swp_resolve6.hpp"), os.path.join(CSRC, "swp_shard.hpp"), os.path.join(CSRC, "swp_types.hpp")]
+    if not os.path.exists(BIN) or any(os.path.getmtime(s) > os.path.getmtime(BIN) for s in srcs):
+        tmp = BIN + ".%d.tmp" % os.getpid()   # (xdist workers may build at the same time)
+        subprocess.run(["g++", "-O1", "-std=c++17", "-o", tmp, srcs[0]], check=True)
+        os.replace(tmp, BIN)
+    return BIN
+
+
+# (seed, nodes, tasks, services, block, task order, feature level, extra)
+CASES = [
+    (1, 300, 1000, 20, 64, 0, 0, ""),       # few services on few nodes: every node soon runs every service
+    (1, 300, 1000, 20, 64, 0, 0, "m"),      # ... block resolver / scan resolver / block resolver in thirds
+    (2, 700, 1500, 30, 64, 0, 1, "m"),      # heavy services, max-replicas, pre-existing exception lists
+    (3, 1000, 2500, 40, 64, 2, 2, ""),      # host ports, uncounted tasks, random task order
+    (3, 1000, 2500, 40, 64, 2, 2, "m"),
+    (7, 500, 1200, 40, 128, 0, 3, "m"),     # generic reservations
+    (9, 300, 600, 6, 64, 1, 3, ""),         # service-major
+    (11, 10, 900, 7, 64, 0, 1, ""),         # ten nodes (BASELINE configs[0]'s cluster) and several services
+    (12, 4096, 700, 25, 256, 0, 2, "m"),    # the most nodes the kernel takes (four per thread)
+    (14, 1900, 900, 30, 128, 0, 3, "m"),    # two nodes per thread
+    (13, 65, 800, 3, 32, 2, 2, "m"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d-N%d-T%d-f%d%s" % (c[0], c[1], c[2], c[6], c[7]))
+def test_scan_resolver_source_matches_sequential_model(emu_bin, case):
+    args = [str(x) for x in case[:7]] + ["v"] + list(case[7])
+    r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr
