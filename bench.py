@@ -34,10 +34,10 @@ FILTERS = {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filt
 
 
 def profile_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary of this round (profiles/r02_pmc_summary.json,
-    produced by tools/profile_round.sh on the GPU box) — a separate rocprofv3 --pmc pass cannot run inside the timed bench.
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/r04_pmc_summary.json, produced by
+    tools/profile_round4.sh on the GPU box) — a separate rocprofv3 --pmc pass cannot run inside the timed bench.
     Returns (bytes or None, provenance string)."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03"):   # this round's summary, else the last one that measured the same kernels (its provenance string says which)
         path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
         if not os.path.exists(path):
             continue
@@ -51,8 +51,6 @@ def profile_traffic(kernel):
             return per["k_r6_propose"] + per["k_r6_commit"], "profiles/%s_pmc_summary.json, k_r6_propose + k_r6_commit per round (%s)" % (tag, doc.get("source", ""))
         if base in per:
             return per[base], "profiles/%s_pmc_summary.json (%s)" % (tag, doc.get("source", "rocprofv3 --pmc"))
-        if tag == "r01" and "k_resolve_hbm_bytes_per_launch" in doc and base == "k_resolve3":
-            return doc["k_resolve_hbm_bytes_per_launch"], "profiles/r01_pmc_summary.json (k_resolve3, round 1)"
     return None, "no PMC summary for %s under profiles/" % kernel
 
 
@@ -538,6 +536,13 @@ def main():
     alg_bytes_launch = alg_bytes_step / windows
     achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0
     traffic, traffic_src = profile_traffic(kernel)
+    measured_gbs = (traffic / (res_launch_ms * 1e-3) / 1e9) if (traffic and res_launch_ms > 0) else None
+    # The algorithmic figure counts a node ROW per (task, node) pair; the resolver reads one BIT per pair and filter from L2-resident
+    # rows, so on large node sets "algorithmic bytes / time" passes the HBM peak without the kernel being anywhere near it. A
+    # fraction above 1 is not a roofline: such a line reports the measured HBM rate and says what the bound is instead.
+    roof_frac = achieved / HBM_PEAK_GBS
+    not_hbm = roof_frac > 1.0
+    cycles_per_task = ms_resolve / K * 1e-3 * SHADER_GHZ * 1e9 / wl.T
 
     result = {
         "metric": f"task placements/sec ({wl.T // 1000}k one-off tasks x {wl.N // 1000}k nodes, "
@@ -558,8 +563,10 @@ def main():
         "pair_evals_per_s": world * pairs / t_step,
         "placed": placed,
         "unplaceable": wl.T - placed,
-        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": (measured_gbs if not_hbm else achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ((measured_gbs / HBM_PEAK_GBS) if (not_hbm and measured_gbs is not None) else (None if not_hbm else roof_frac)),
+                     "not_hbm_bound": not_hbm, "algorithmic_GBs": achieved,
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows, "tasks_per_launch": wl.T / windows,
                      "note": ("per ROUND of the block resolver (launches_per_step rounds, tasks_per_launch decided each): algorithmic bytes = the round's "
                               "(task, node) pairs x node-row bytes (SURVEY 8d); traffic = PMC bytes of one k_r6_propose + one k_r6_commit. The resolver reads "
@@ -570,8 +577,12 @@ def main():
                               "traffic is far below that (see traffic): the kernel is bound by one workgroup's instruction issue, not by HBM")},
         "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_resolve": ms_resolve / K, "k_explain": ms_explain / K, "device_total": ms_dev / K},
         # what really bounds the resolver: the instruction issue of ONE wavefront (the matcher's dependent chain), not bytes
-        "resolver": {"kernel": kernel.split(" ")[0], "ms_per_step": ms_resolve / K, "cycles_per_task": ms_resolve / K * 1e-3 * SHADER_GHZ * 1e9 / wl.T,
-                     "clock_GHz": SHADER_GHZ, "measured_HBM_GBs": (traffic / (res_launch_ms * 1e-3) / 1e9) if (traffic and res_launch_ms > 0) else None,
+        "issue_bound": {"matcher_instr_per_task": 13, "issue_cycles_per_instr": 5.0, "floor_cycles_per_task": 65.0, "cycles_per_task": cycles_per_task,
+                        "note": "the serial chain of the batch is wv::match_seq64 on ONE wave: 13 instructions per task (tools/check_matcher_asm.sh), a lone wave issues one "
+                                "every ~5 cycles (tools/mb/mb_issue.hip) -> 65 cycles per task is the floor of this design; cycles_per_task is the resolver's whole device time "
+                                "(propose, launch gaps, staging, stops at emptied half-words, the last group's apply) over the tasks, at the peak engine clock"},
+        "resolver": {"kernel": kernel.split(" ")[0], "ms_per_step": ms_resolve / K, "cycles_per_task": cycles_per_task,
+                     "clock_GHz": SHADER_GHZ, "measured_HBM_GBs": measured_gbs,
                      "note": "cycles of the matching wave's CU per task of the batch, at the peak engine clock; measured_HBM_GBs = PMC bytes per launch (roofline.traffic) / launch time"},
         "whole_job_algorithmic_GBs": alg_bytes_step / t_step / 1e9,
         "end_to_end": {"ms": t_e2e * 1e3, "placements_per_s": wl.T / t_e2e,

@@ -121,7 +121,11 @@ int swp_node_upsert(swp_engine*, const swp_node_row* row,
 /* numeric-only fast path of swp_node_upsert: update flags/cpu/mem/total of an existing node
  * (availability flips, resource reconciliation) without touching labels/plugins */
 int swp_node_update_dynamic(swp_engine*, uint32_t node, uint32_t flags, int64_t cpu, int64_t mem, uint32_t total);
-/* nodeSet.remove, nodeset.go:46-48 */
+/* nodeSet.remove, nodeset.go:46-48: the node leaves the set AND its index goes back to the pool — the next node id that is new to
+ * swp_intern(SWP_SPACE_NODE_ID, ...) is given the LOWEST free index (the index space, i.e. the width of every bitmap row, is bounded
+ * by the nodes alive at once). The canonical tie order among equal-score nodes is the index order, so a recycled index places its
+ * new node where the old one stood; Go's map iteration order is unspecified, the CPU oracle recycles its slots by the same rule.
+ * A caller must therefore forget the index of a removed node (intern its id again if it comes back). */
 int swp_node_remove(swp_engine*, uint32_t node);
 /* Bulk forms for bursts of node events (a drain round touches 10 % of the cluster: scheduler.go:368-396 once per node): one
  * call instead of one per node. Same semantics and error behaviour as the single-node calls, applied in array order; the

@@ -1016,8 +1016,17 @@ std::vector<NodeInfo>& DecisionTree::ordered_nodes(const std::function<bool(cons
 void Scheduler::ns_add_or_update(const NodeInfo& ni) {   // addOrUpdateNode nodeset.go:33-35
     auto it = slot_of_.find(ni.node->id);
     if (it == slot_of_.end()) {
-        slot_of_[ni.node->id] = slots_.size();
-        slots_.push_back(Slot{true, ni});
+        // the canonical scan order (Go's map order is unspecified) is the SLOT order; a node that is new to the set takes the lowest
+        // slot a removed node left behind, else a new one at the end — the rule the engine's node index follows
+        if (!free_slots_.empty()) {
+            const size_t sl = *free_slots_.begin();
+            free_slots_.erase(free_slots_.begin());
+            slot_of_[ni.node->id] = sl;
+            slots_[sl] = Slot{true, ni};
+        } else {
+            slot_of_[ni.node->id] = slots_.size();
+            slots_.push_back(Slot{true, ni});
+        }
     } else {
         slots_[it->second].present = true;
         slots_[it->second].info = ni;
@@ -1050,6 +1059,8 @@ void Scheduler::delete_node(const std::string& id) {   // remove nodeset.go:46-4
     if (it != slot_of_.end()) {
         slots_[it->second].present = false;
         slots_[it->second].info = NodeInfo();
+        free_slots_.insert(it->second);   // delete(ns.nodes, nodeID): the entry is gone, its place in the canonical order is free
+        slot_of_.erase(it);
     }
 }
 

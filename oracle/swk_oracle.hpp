@@ -38,6 +38,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -306,6 +307,7 @@ class Scheduler {
     struct Slot { bool present = false; NodeInfo info; };
     std::vector<Slot> slots_;                               // canonical node order
     std::unordered_map<std::string, size_t> slot_of_;
+    std::set<size_t> free_slots_;                           // slots of removed nodes, lowest first
     std::map<std::string, ServiceRec> services_;
 
     // insertion-ordered id -> task maps (Go maps with canonical iteration order)

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <map>
+#include <queue>
 #include <mutex>
 #include <numeric>
 #include <memory>
@@ -147,18 +148,42 @@ struct Interner {
         zero_is_empty = zero_empty;
         map.clear();
         strs.clear();
+        free_ids = decltype(free_ids)();
+        freed.clear();
         if (zero_empty) {
             strs.emplace_back();
             map.emplace(std::string(), 0u);
         }
     }
+    // ids handed back (the node space only: swp_node_remove): the next NEW string takes the LOWEST free id, so that the node index
+    // space — the width of every bitmap row — is bounded by the number of nodes alive at once, not by the nodes ever seen
+    std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> free_ids;
+    std::vector<char> freed;   // [id] the id is on the free heap
     uint32_t get(const std::string& s) {
         auto it = map.find(s);
         if (it != map.end()) return it->second;
-        uint32_t id = (uint32_t)strs.size();
-        strs.push_back(s);
+        uint32_t id;
+        if (!free_ids.empty()) {
+            id = free_ids.top();
+            free_ids.pop();
+            freed[id] = 0;
+            strs[id] = s;
+        } else {
+            id = (uint32_t)strs.size();
+            strs.push_back(s);
+        }
         map.emplace(s, id);
         return id;
+    }
+    void release(uint32_t id) {
+        if (id >= strs.size()) return;
+        if (freed.size() < strs.size()) freed.resize(strs.size(), 0);
+        if (freed[id]) return;
+        auto it = map.find(strs[id]);
+        if (it != map.end() && it->second == id) map.erase(it);
+        strs[id].clear();
+        freed[id] = 1;
+        free_ids.push(id);
     }
 };
 
@@ -1873,6 +1898,10 @@ int swp_node_remove(swp_engine* e, uint32_t node) {
     h = HostNode();
     e->n_present--;
     e->dev_static_dirty = e->dev_dynamic_dirty = true;
+    // nodeSet.remove deletes the map entry (nodeset.go:46-48): the node's index goes back to the pool, the next node id that is new to
+    // swp_intern(SWP_SPACE_NODE_ID) gets the lowest free one (the canonical scan order is the index order; the oracle recycles its
+    // slots by the same rule)
+    e->spaces[SWP_SPACE_NODE_ID].release(node);
     return SWP_OK;
 }
 

@@ -85,6 +85,21 @@ inline bool remove_one(Res& na, const Res& r) {
     return r.sval == na.sval;         // not the right item otherwise
 }
 
+// HasResource, validate.go:53-85: is there enough of `res` in `resources`
+inline bool has_resource(const Res& res, const List& resources) {
+    for (const Res& r : resources) {
+        if (res.kind != r.kind) continue;
+        if (!r.named) {                       // DiscreteResourceSpec
+            if (res.named) return false;
+            return !(res.ival > r.ival);
+        }
+        if (!res.named) return false;         // NamedResourceSpec
+        if (res.sval != r.sval) continue;
+        return true;
+    }
+    return false;
+}
+
 // ConsumeNodeResources, helpers.go:58-85
 inline void consume(List* avail, const List& res) {
     List kept;

@@ -352,6 +352,9 @@ class Scheduler {
         const uint32_t idx = it->second.idx;
         nodes_.erase(it);
         ck(swp_node_remove(e_, idx), "swp_node_remove");
+        // the engine hands the index to the next node that is new to it: nothing here may remember it as this node's
+        if (idx < idx_to_id_.size()) idx_to_id_[idx].clear();
+        for (auto pf = pushedFailures_.begin(); pf != pushedFailures_.end();) pf = std::get<0>(pf->first) == idx ? pushedFailures_.erase(pf) : std::next(pf);
     }
     // nodeSet.nodeInfo, nodeset.go:23-29
     bool nodeInfo(const std::string& nid, std::string& out) {
@@ -816,6 +819,8 @@ class Scheduler {
         std::vector<swp_enforce_node> nrec;
         std::vector<swp_enforce_task> trec;
         std::vector<std::pair<std::string, std::string>> owners;
+        struct GenericWalk { std::string nid; uint32_t first; generic::List avail; std::vector<generic::List> assigned; std::vector<bool> has; };
+        std::vector<GenericWalk> walks;
         Value out = Value::object();
         if (node_docs == nullptr || !node_docs->is_arr()) return out;
         for (const Value& nd : *node_docs->a) {
@@ -827,9 +832,23 @@ class Scheduler {
                     for (const Value& t : *lst->a) tasks.push_back(&t);
             std::stable_sort(tasks.begin(), tasks.end(), [](const Value* a, const Value* b) { return task_id(*a) < task_id(*b); });
             const Value* res = at(&nd, {"Description", "Resources"});
-            bool generic = res != nullptr && truthy(res->get("Generic"));
-            for (const Value* t : tasks) generic = generic || truthy(t->get("AssignedGenericResources"));
-            if (generic) unsupported("generic resources stay on the Go path");
+            // The generic half (constraint_enforcer.go:186-200) is walked on the host AFTER the device call (below): the device's verdicts
+            // — constraints, then memory and cpu accounted task by task — do not depend on it.
+            bool generic = false;
+            for (const Value* t : tasks) generic = generic || t->get("AssignedGenericResources") != nullptr;
+            if (generic) {
+                GenericWalk w;
+                w.nid = nid;
+                w.first = (uint32_t)trec.size();
+                w.avail = generic::decode(res != nullptr ? res->get("Generic") : nullptr);
+                for (const Value* t : tasks) {
+                    bool nil = false;
+                    generic::List a = generic::decode(t->get("AssignedGenericResources"), &nil);
+                    w.assigned.push_back(std::move(a));
+                    w.has.push_back(t->get("AssignedGenericResources") != nullptr && !nil);
+                }
+                walks.push_back(std::move(w));
+            }
             auto ni = nodes_.find(nid);
             if (ni == nodes_.end()) fail(SWP_ENOTFOUND, "enforce: node " + nid + " is not in the nodeSet");
             const uint32_t first = (uint32_t)trec.size();
@@ -864,6 +883,24 @@ class Scheduler {
         if (trec.empty()) return out;
         std::vector<uint8_t> rej(trec.size(), 0);
         ck(swp_enforce(e_, nrec.data(), (uint32_t)nrec.size(), trec.data(), (uint32_t)trec.size(), rej.data()), "swp_enforce");
+        // :186-200 for the nodes whose tasks hold generic resources: a task the device kept claims what it was assigned from the node's
+        // list (ClaimResources against a throw-away store); the first task whose assignment is no longer there is rejected and ENDS the
+        // node's loop (`break loop`): nothing behind it is looked at, whatever the device said about it.
+        for (GenericWalk& w : walks) {
+            bool broke = false;
+            for (size_t k = 0; k < w.assigned.size(); ++k) {
+                uint8_t& verdict = rej[w.first + k];
+                if (broke) { verdict = 0; continue; }
+                const swp_enforce_task& tr = trec[w.first + k];
+                if (tr.desired_state < (uint32_t)ASSIGNED || tr.desired_state > (uint32_t)COMPLETE || tr.state >= (uint32_t)COMPLETE) continue;   // :118-126 (never rejected)
+                if (verdict || !w.has[k]) continue;   // rejected by constraints / reservations (`continue`), or AssignedGenericResources == nil
+                bool gone = false;
+                for (const generic::Res& ta : w.assigned[k])
+                    if (!generic::has_resource(ta, w.avail)) { gone = true; break; }
+                if (gone) { verdict = 1; broke = true; continue; }
+                generic::consume(&w.avail, w.assigned[k]);
+            }
+        }
         for (size_t i = 0; i < rej.size(); ++i)
             if (rej[i])
                 for (json::Member& m : *out.o)

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,7 @@ struct swp_engine {
     std::vector<std::vector<std::string>> names = std::vector<std::vector<std::string>>(SWP_SPACE_COUNT);
     std::vector<std::map<std::string, uint32_t>> ids = std::vector<std::map<std::string, uint32_t>>(SWP_SPACE_COUNT);
     std::vector<FakeNode> nodes;
+    std::set<uint32_t> free_nodes;
     std::vector<std::string> sets[6];   // textual form of every registered predicate set: constraint, platform, plugin, port, spread, generic
     std::vector<std::vector<swp_port>> port_sets;
     std::string log;
@@ -145,8 +147,15 @@ int swp_intern(swp_engine* e, int space, const char* s, size_t len, uint32_t* id
     std::string k(s ? s : "", s ? len : 0);
     auto it = e->ids[space].find(k);
     if (it == e->ids[space].end()) {
-        it = e->ids[space].emplace(k, (uint32_t)e->names[space].size()).first;
-        e->names[space].push_back(k);
+        if (space == SWP_SPACE_NODE_ID && !e->free_nodes.empty()) {   // the engine's rule: a new node id takes the lowest index a removed node left
+            const uint32_t id = *e->free_nodes.begin();
+            e->free_nodes.erase(e->free_nodes.begin());
+            e->names[space][id] = k;
+            it = e->ids[space].emplace(k, id).first;
+        } else {
+            it = e->ids[space].emplace(k, (uint32_t)e->names[space].size()).first;
+            e->names[space].push_back(k);
+        }
     }
     *id_out = it->second;
     return SWP_OK;
@@ -197,9 +206,14 @@ int swp_node_get_many(swp_engine* e, const uint32_t* nodes, uint32_t n, swp_node
     return SWP_OK;
 }
 int swp_node_remove(swp_engine* e, uint32_t node) {
+    const bool was = node < e->nodes.size() && e->nodes[node].present;
     if (node < e->nodes.size()) e->nodes[node] = FakeNode();
     e->present_dirty = true;
     e->say("remove %s", e->name(SWP_SPACE_NODE_ID, node).c_str());
+    if (was) {   // the index goes back to the pool
+        e->ids[SWP_SPACE_NODE_ID].erase(e->names[SWP_SPACE_NODE_ID][node]);
+        e->free_nodes.insert(node);
+    }
     return SWP_OK;
 }
 int swp_node_get(swp_engine* e, uint32_t node, swp_node_row* out) {
@@ -332,6 +346,8 @@ int swp_shard_merge(const swp_proposal* const*, const uint32_t*, uint32_t, uint3
 int swp_shard_commit(swp_engine*, swp_batch*, uint32_t, const swp_shard_pick*, uint32_t) { return SWP_EUNSUPPORTED; }
 int swp_shard_end(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_shard_run(swp_engine* const*, swp_batch* const*, uint32_t, uint32_t, int32_t*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
+int swp_rccl_available(swp_engine*) { return SWP_EUNSUPPORTED; }
+int swp_shard_verdict(const uint32_t*, uint32_t, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_rccl_unique_id(swp_engine*, uint8_t*) { return SWP_EUNSUPPORTED; }
 int swp_rccl_init(swp_engine*, const uint8_t*, uint32_t, uint32_t) { return SWP_EUNSUPPORTED; }
 int swp_rccl_finalize(swp_engine*) { return SWP_EUNSUPPORTED; }

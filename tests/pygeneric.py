@@ -39,6 +39,23 @@ def _remove(na, r):
     return na, r[2] == na[2]
 
 
+def has_resource(res, resources):
+    """HasResource, validate.go:53-85: is there enough of `res` in `resources` (entries are (named, kind, value))."""
+    for r in resources:
+        if res[1] != r[1]:
+            continue
+        if not r[0]:                      # DiscreteResourceSpec
+            if res[0]:
+                return False
+            return not (res[2] > r[2])
+        if not res[0]:                    # NamedResourceSpec
+            return False
+        if res[2] != r[2]:
+            continue
+        return True
+    return False
+
+
 def consume(avail, res):
     """ConsumeNodeResources, helpers.go:58-85."""
     kept = []

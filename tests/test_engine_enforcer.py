@@ -5,6 +5,8 @@ import random
 
 import pytest
 
+import pyhost
+
 import orc
 import test_oracle_enforcer as kat
 from swarmkit_amd import host as swhost
@@ -53,12 +55,23 @@ def test_outdated_task_constraints_on_the_device():
     assert engine_enforce([bare], [task], {"id1": broken}) == {"id0": []}
 
 
-def test_generic_resources_stay_on_the_go_path():
-    node = {"ID": "id0", "Spec": {"Availability": 0}, "Description": {"Resources": {"NanoCPUs": 1}}}
-    task = {"ID": "t", "NodeID": "id0", "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING},
-            "AssignedGenericResources": [{"Discrete": {"Kind": "gpu", "Value": 1}}]}
-    with pytest.raises(swhost.Unsupported):
-        engine_enforce([node], [task])
+def test_generic_resources_the_loop_ends_at_the_first_missing_assignment():
+    """constraint_enforcer.go:186-200: a kept task claims its AssignedGenericResources from the node's list; the first task whose
+    assignment is gone is rejected and `break loop` ends the node's walk — a later task that fails its constraint is NOT rejected."""
+    node = {"ID": "id0", "Spec": {"Annotations": {"Labels": {"zone": "a"}}, "Availability": 0}, "Status": {"State": orc.READY},
+            "Description": {"Resources": {"NanoCPUs": 10**10, "MemoryBytes": 10**10, "Generic": [{"Discrete": {"Kind": "gpu", "Value": 2}}, {"Named": {"Kind": "fpga", "Value": "f0"}}]}}}
+    def task(i, gen, cons=None):
+        t = {"ID": "t%d" % i, "NodeID": "id0", "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING}, "Spec": {}}
+        if gen is not None:
+            t["AssignedGenericResources"] = gen
+        if cons:
+            t["Spec"]["Placement"] = {"Constraints": cons}
+        return t
+    tasks = [task(0, [{"Discrete": {"Kind": "gpu", "Value": 1}}]), task(1, [{"Named": {"Kind": "fpga", "Value": "f0"}}]), task(2, None, ["node.labels.zone==b"]),
+             task(3, [{"Discrete": {"Kind": "gpu", "Value": 2}}]), task(4, None, ["node.labels.zone==b"]), task(5, [{"Named": {"Kind": "fpga", "Value": "f0"}}])]
+    want = oracle_enforce([node], tasks)
+    assert want == {"id0": ["t2", "t3"]}   # t2: constraint; t3: one gpu left, two assigned -> rejected, the loop ends: t4 (constraint) and t5 (fpga gone) stay
+    assert engine_enforce([node], tasks) == want
 
 
 STATES = [orc.NEW, orc.PENDING, orc.ASSIGNED, orc.READY_T, orc.RUNNING, orc.COMPLETE, orc.SHUTDOWN, orc.FAILED, orc.REJECTED]
@@ -85,6 +98,8 @@ def test_random_clusters(seed):
                                 "Engine": {"Labels": {"tier": rng.choice(["gold", "tin"])}} if rng.random() < 0.5 else {}}
             if rng.random() < 0.85:
                 d["Description"]["Resources"] = {"NanoCPUs": rng.choice([0, 1, 2, 4]) * 10**9, "MemoryBytes": rng.choice([0, 1, 4, 8]) << 30}
+                if rng.random() < 0.6:
+                    d["Description"]["Resources"]["Generic"] = [{"Discrete": {"Kind": "gpu", "Value": rng.randrange(0, 5)}}] + [{"Named": {"Kind": "fpga", "Value": "f%d" % q} } for q in range(rng.randrange(0, 3))]
         nodes.append(d)
     services = {}
     for k in range(rng.randrange(0, 8)):
@@ -98,6 +113,9 @@ def test_random_clusters(seed):
             t["Spec"]["Resources"] = {"Reservations": {"NanoCPUs": rng.choice([0, 5, 10, 20]) * 10**8, "MemoryBytes": rng.choice([0, 256, 1024, 3000]) << 20}}
         if rng.random() < 0.4:
             t["Spec"]["Placement"] = {"Constraints": rng.sample(CONS, rng.randrange(0, 3))}
+        if rng.random() < 0.3:
+            t["AssignedGenericResources"] = rng.choice([[], [{"Discrete": {"Kind": "gpu", "Value": rng.randrange(1, 3)}}], [{"Named": {"Kind": "fpga", "Value": "f%d" % rng.randrange(3)}}],
+                                                        [{"Discrete": {"Kind": "gpu", "Value": 1}}, {"Named": {"Kind": "fpga", "Value": "f%d" % rng.randrange(3)}}]])
         tasks.append(t)
     tasks = list({t["ID"]: t for t in tasks}.values())
     assert engine_enforce(nodes, tasks, services) == oracle_enforce(nodes, tasks, services)
@@ -134,7 +152,7 @@ def test_node_matches_matrix_equals_per_pair_oracle():
             continue
         s2 = swhost.HostScheduler()
         s2.create_node(node)
-        parsed = swhost.parse_constraints(cons)
+        parsed = pyhost.parse_constraints(cons)
         assert parsed is not None
         row = s2.e.node_matches([s2.constraint_set(cons)])
         assert bool(int(row[0, 0]) & 1) == want, (cons, node)

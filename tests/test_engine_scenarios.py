@@ -3,6 +3,7 @@ host mirror). Same scenario code as tests/test_oracle_scheduler.py."""
 import pytest
 
 import kat_tables as kt
+import orc
 import scenarios as sc
 from swarmkit_amd import host as swhost
 
@@ -108,3 +109,44 @@ def test_unscheduleable_task():
 
 def test_plugin_constraint():
     sc.scenario_plugin_constraint(factory)
+
+
+def test_node_indices_are_recycled_and_the_tie_order_follows(host_kind):
+    """nodeSet.remove (nodeset.go:46-48) frees the node's index: ten times the cluster's size in node arrivals and departures leaves the
+    engine's node space no wider than the cluster (a removed node's slot was never recycled), and every tick still places
+    exactly like the oracle — whose canonical scan order recycles its slots by the same lowest-free rule."""
+    import random
+    rng = random.Random(0x51075)
+    o, e = orc.Oracle(), factory()
+    alive, serial = [], 0
+
+    def doc(i):
+        return sc.node("node-%05d" % i, Spec={"Annotations": {"Labels": {"zone": "z%d" % (i % 3)}}},
+                       Description={"Resources": {"NanoCPUs": int(4e9), "MemoryBytes": int(8e9)}})
+    for _ in range(64):
+        for s in (o, e):
+            s.create_node(doc(serial))
+        alive.append(serial)
+        serial += 1
+    for s in (o, e):
+        s.set_service("svc")
+    tid = 0
+    for step in range(40):
+        for _ in range(16):   # 16 nodes leave, 16 new ones arrive: 640 arrivals over the run
+            gone = alive.pop(rng.randrange(len(alive)))
+            for s in (o, e):
+                s.delete_node("node-%05d" % gone)
+            for s in (o, e):
+                s.create_node(doc(serial))
+            alive.append(serial)
+            serial += 1
+        for _ in range(24):
+            t = sc.pending("t%05d" % tid, "svc", Spec={"Resources": {"Reservations": {"NanoCPUs": int(1e8)}}})
+            tid += 1
+            for s in (o, e):
+                s.create_task(t)
+        do = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in o.tick())
+        de = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in e.tick())
+        assert do == de, (step, [(a, b) for a, b in zip(do, de) if a != b][:5])
+    st = e.e.stats()
+    assert st["n_nodes"] == 64 and st["n_words"] <= 2, st   # 64 nodes alive: at most 80 indices were ever in use at once

@@ -9,10 +9,12 @@ import random
 
 import pytest
 
+import pyhost
+
 import fakelib
 import orc
 from swarmkit_amd import abi
-from swarmkit_amd import generic as gres
+import pygeneric as gres
 from swarmkit_amd import host as swhost
 from swarmkit_amd import sched as swsched
 
@@ -68,7 +70,7 @@ def node_doc(rng, i):
 
 def hosts():
     lib = fakelib.build()
-    return [orc.Oracle(), swsched.Scheduler(engine=abi.Engine(lib_path=lib)), swhost.PyHostScheduler(engine=abi.Engine(lib_path=lib))]
+    return [orc.Oracle(), swsched.Scheduler(engine=abi.Engine(lib_path=lib)), pyhost.PyHostScheduler(engine=abi.Engine(lib_path=lib))]
 
 
 @pytest.mark.parametrize("seed", range(60))

@@ -52,13 +52,13 @@ def test_product_does_not_import_the_oracle():
 
 @pytest.mark.parametrize("expr,ok,key,exp", __import__("kat_tables").PARSE_CASES)
 def test_host_constraint_parse(expr, ok, key, exp):
-    p = host.parse_constraints([expr])
+    p = __import__("pyhost").parse_constraints([expr])   # (the Python twin; the C++ parser is checked against it and the oracle in tests/test_sched_cpu.py)
     assert (p is not None) == ok
     if ok:
         assert p[0][0] == key and p[0][2] == exp
 
 
-@pytest.mark.parametrize("explain_fn", [host.PyHostScheduler.explain, __import__("swarmkit_amd.sched", fromlist=["explain"]).explain], ids=["py", "cxx"])
+@pytest.mark.parametrize("explain_fn", [__import__("pyhost").PyHostScheduler.explain, __import__("swarmkit_amd.sched", fromlist=["explain"]).explain], ids=["py", "cxx"])
 def test_host_explain_strings(explain_fn):
     e = explain_fn
     assert e([2, 1, 0, 0, 0, 0, 0, 0]) == "2 nodes not available for new tasks; insufficient resources on 1 node"

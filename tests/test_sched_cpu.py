@@ -10,6 +10,8 @@ import random
 
 import pytest
 
+import pyhost
+
 import fakelib
 import orc
 import test_engine_fuzz as fz
@@ -68,7 +70,7 @@ def test_cxx_parse_ip_matches_the_python_twin():
                 s = ":".join(groups[:cut]) + "::" + ":".join(groups[cut + 1:])
             corpus.append(s)
     for s in corpus:
-        assert swsched.parse_ip(s) == swhost._parse_ip(s), s
+        assert swsched.parse_ip(s) == pyhost._parse_ip(s), s
 
 
 # ------------------------------------------------------------------------------------------------ twin test
@@ -77,7 +79,7 @@ class Pair:
 
     def __init__(self):
         lib = fakelib.build()
-        self.py = swhost.PyHostScheduler(engine=abi.Engine(lib_path=lib))
+        self.py = pyhost.PyHostScheduler(engine=abi.Engine(lib_path=lib))
         self.cx = swsched.Scheduler(engine=abi.Engine(lib_path=lib))
         self.steps = 0
 
@@ -256,7 +258,7 @@ def test_cxx_wrapper_has_the_twins_surface(monkeypatch):
     """Everything the parity tests and bench.py call on a host scheduler exists on both implementations, and the bulk
     workload path (host.load_workload / parity_util.engine_run) runs through the C++ layer (scripted engine: the
     placements themselves mean nothing here)."""
-    public = {n for n in dir(swhost.PyHostScheduler) if not n.startswith("_") and callable(getattr(swhost.PyHostScheduler, n))}
+    public = {n for n in dir(pyhost.PyHostScheduler) if not n.startswith("_") and callable(getattr(pyhost.PyHostScheduler, n))}
     missing = sorted(n for n in public if not hasattr(swsched.Scheduler, n))
     assert not missing, missing
     import parity_util as pu
@@ -336,7 +338,7 @@ def test_cxx_json_boundary_round_trips_strings_and_numbers():
 # ------------------------------------------------------------------------------------------------ round-2 host-layer fixes
 def _both_hosts():
     lib = fakelib.build()
-    return [swhost.PyHostScheduler(engine=abi.Engine(lib_path=lib)), swsched.Scheduler(engine=abi.Engine(lib_path=lib))]
+    return [pyhost.PyHostScheduler(engine=abi.Engine(lib_path=lib)), swsched.Scheduler(engine=abi.Engine(lib_path=lib))]
 
 
 def _task(tid, sid, ver=None, **kw):
