@@ -38,7 +38,9 @@
 namespace swpdev {
 
 #define R6_NP 16                 // level planes: 65 535 levels above the lowest valid node
+#ifndef R6_CAND
 #define R6_CAND 16               // a proposal lists 2 * R6_CAND non-empty 32-node half-words: a block is cut where a task finds all its listed nodes taken
+#endif
 #define R6_BMAX 1024             // largest block
 #define R6_COMMIT_THREADS 1024      // == R6_BMAX: one accepted pick per thread in the apply phase
 #define R6_NONE 0xFFFFFFFFu
