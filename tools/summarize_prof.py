@@ -27,10 +27,12 @@ def per_kernel(dirname, counter):
 
 def main():
     out, tag = sys.argv[1], sys.argv[2]
-    try:
-        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
-    except Exception:
-        commit = ""
+    commit = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("SWP_COMMIT", "")   # the GPU box has no .git: the caller passes `git rev-parse --short HEAD`
+    if not commit:
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+        except Exception:
+            commit = ""
     runs = {}
     per_launch = {}
     for d in sorted(glob.glob(os.path.join(out, "pmc_fetch_*"))):
@@ -50,7 +52,7 @@ def main():
     summary = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 0 [--shards 4]; "
                        "KB per launch as reported; corrected = 2*FETCH + WRITE (gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, "
                        "MI355X_MICROARCH.md HBM section)",
-               "source": "tools/profile_round.sh %s at commit %s" % (tag, commit or "?"),
+               "source": "tools/profile_round4.sh %s at commit %s" % (tag, commit or "?"),
                "hbm_bytes_per_launch": per_launch, "runs": runs}
     json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(per_launch))
