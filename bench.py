@@ -325,27 +325,51 @@ def main():
         replaced = 0
         dev_ms = 0.0
         t_rounds = []
+        phases = {"node calls (get_many + update_dynamic_many)": 0.0, "swp_commit(remove)": 0.0, "swp_batch_prepare": 0.0, "swp_batch_run": 0.0,
+                  "swp_batch_fetch": 0.0, "the script itself (which tasks sat on the drained nodes, their descriptors)": 0.0}
+        is_drained = np.zeros(wl.N + 1, dtype=bool)   # (index -1 = unplaced: the extra last entry)
         for rnd in range(args.rounds):
             t0 = time.perf_counter()
             drained = rng.choice(wl.N, size=max(wl.N // 10, 1), replace=False)
             touched = np.concatenate([prev, drained]).astype(np.uint32)
+            ta = time.perf_counter()
             rows = eng.node_get_many(touched)          # two calls per round instead of four per node
             upd = np.zeros(len(touched), dtype=abi.NODE_DYNAMIC_DTYPE)
             upd["node"], upd["cpu"], upd["mem"], upd["total"] = touched, rows["cpu"], rows["mem"], rows["total"]
             upd["flags"] = np.where(np.arange(len(touched)) < len(prev), rows["flags"] | abi.NODE_READY, rows["flags"] & ~np.uint32(abi.NODE_READY))
             eng.node_update_dynamic_many(upd)          # reactivate the previous round's nodes, Availability = DRAIN for this round's
-            gone = np.nonzero(np.isin(assign, drained))[0]
+            tb = time.perf_counter()
+            is_drained[:] = False
+            is_drained[drained] = True
+            gone = np.nonzero(is_drained[assign])[0]
+            tc = tb
             if len(gone):
                 pl = np.zeros(len(gone), dtype=abi.PLACEMENT_DTYPE)
                 pl["node"], pl["service"] = assign[gone], descs["service"][gone]
                 pl["cpu"], pl["mem"], pl["counted"] = descs["cpu"][gone], descs["mem"][gone], 1
+                again = descs[gone]                    # as many new tasks of the same services
+                tc = time.perf_counter()
                 eng.commit(pl, add=False)              # NodeInfo.removeTask for every task on a drained node
-                new_out, _h = eng.schedule_batch(descs[gone], want_hist=False)   # as many new tasks of the same services
+                td = time.perf_counter()
+                bt = eng.batch_prepare(again)
+                te = time.perf_counter()
+                bt.run()
+                tf = time.perf_counter()
+                new_out, _h = bt.fetch(want_hist=False)   # (fetch: the placements enter the engine's node mirror, as in swp_schedule_batch)
+                bt.free()
+                tg = time.perf_counter()
                 assign[gone] = new_out
                 replaced += len(gone)
                 dev_ms += eng.stats()["ms_total"]
+                phases["swp_commit(remove)"] += td - tc
+                phases["swp_batch_prepare"] += te - td
+                phases["swp_batch_run"] += tf - te
+                phases["swp_batch_fetch"] += tg - tf
             prev = drained
-            t_rounds.append(time.perf_counter() - t0)
+            t1 = time.perf_counter()
+            t_rounds.append(t1 - t0)
+            phases["node calls (get_many + update_dynamic_many)"] += tb - ta
+            phases["the script itself (which tasks sat on the drained nodes, their descriptors)"] += (ta - t0) + (tc - tb) + ((t1 - tg) if len(gone) else 0.0)
         tt = sum(t_rounds)
         row_b = ROW_B.get(args.workload, 48)
         alg = (replaced / max(args.rounds, 1)) * wl.N * row_b + (replaced / max(args.rounds, 1)) * TASK_B
@@ -355,6 +379,7 @@ def main():
                "dtype": "int64", "data": "synthetic",
                "config": dict(wl.describe(), mode="churn", rounds=args.rounds, replaced=int(replaced)),
                "still_placed": int((assign >= 0).sum()), "device_ms_per_round": dev_ms / max(args.rounds, 1),
+               "ms_per_round_by_phase": {k: 1e3 * v / max(args.rounds, 1) for k, v in phases.items()},
                "roofline": {"bound": "hbm", "kernel": "the round's swp_schedule_batch (k_resolve5 / k_resolve6 + explain)", "achieved": alg / (dev_ms / max(args.rounds, 1) * 1e-3) / 1e9 if dev_ms else 0.0,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / (dev_ms / max(args.rounds, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms else 0.0,
                             "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dev_ms / max(args.rounds, 1),

@@ -267,6 +267,8 @@ struct swp_batch {
     std::vector<uint32_t> rg_kind, rg_k0, rg_k1;   // per row: kind id, first / one-past-last row of the same kind
     std::vector<int32_t> rg_val;
     DevBuf d_tg, d_gs_off, d_gs_row, d_rg_kind, d_rg_k0, d_rg_k1, d_rg_val, d_rg;
+    std::vector<uint32_t> tmpl;   // [T] the first task with this task's descriptor (identical tasks: swp_resolve6.hpp R6Args.tmpl)
+    DevBuf d_tmpl;
 
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_hmat, d_emat;   // the scan resolver's (service, node) matrices, allocated when a stretch first goes to it
@@ -820,6 +822,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     b->n_plat = (uint32_t)plat_ids.size();
     b->n_plug = (uint32_t)plug_ids.size();
 
+    b->tmpl = std::move(tmpl_of);
     mark("runs");
     // per-service exception lists: nodes with svcCount>0 or ≥ maxFailures recent failures
     b->list_off.assign(b->n_svc + 1, 0);
@@ -931,6 +934,7 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     const uint32_t T = b->T;
     int rc;
     if ((rc = upload(e, b->d_rt, b->rt))) return rc;
+    if ((rc = upload(e, b->d_tmpl, b->tmpl))) return rc;
     if ((rc = upload(e, b->d_thr, b->thr))) return rc;
     if ((rc = upload(e, b->d_thr64, b->thr64))) return rc;
     if (b->has_generic) {
@@ -1319,6 +1323,10 @@ int r6_args_for(swp_engine* e, swp_batch* b, uint32_t r6_block, bool r6_task_row
     ra.thr = b->d_thr64.as<long long>();
     ra.blk = b->d_blk6.as<Blk6>();
     ra.prop = b->d_prop.as<R6Prop>();
+    {   // SWP_R6_TWINS=0: every list starts at its level's first candidate (A/B runs)
+        const char* env_tw = getenv("SWP_R6_TWINS");
+        ra.tmpl = (env_tw && atoi(env_tw) == 0) ? nullptr : b->d_tmpl.as<uint32_t>();
+    }
     if (b->has_generic) {
         HIPCHECK(e, b->d_rg.reserve((size_t)b->rg_kind.size() * Wn * 8));
         ra.n_rg = (u32)b->rg_kind.size();
@@ -2691,6 +2699,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         int rc = batch_begin(e, b);
         if (rc) return fail_all(rc);
         if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra[g]))) return fail_all(rc);
+        ra[g].tmpl = nullptr;   // a range sees only its own part of a level: its lists start at the level's first candidate
         Blk6 hb{};
         hb.pos = 0;
         hb.end = T;
@@ -3003,6 +3012,7 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
         int rc = batch_begin(e, b);
         if (rc) return rc;
         if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra))) return rc;
+        ra.tmpl = nullptr;   // (as in swp_shard_run)
         hb.end = T;
         HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, st));
         hipError_t x = launch_r6_build(ra, st);

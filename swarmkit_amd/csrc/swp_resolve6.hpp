@@ -109,6 +109,9 @@ struct R6Args {
     const int32_t* rg_val;   // [n_rg]
     const u32* rg_k0;        // [n_rg] first row of the row's kind ...
     const u32* rg_k1;        // ... and one past its last
+    // [tasks of the batch] the first task of the batch with this task's descriptor: equal values = identical tasks, whose plain candidates
+    // of a round are the same set. nullptr: lists start at the level's first candidate (the shard drivers: a range sees only its own part).
+    const u32* tmpl;
 };
 
 #define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together
@@ -259,6 +262,21 @@ WV_DEV void r6_propose(const R6Args& a) {
     // The task's plain candidates AND the minimum level among them in one pass: lane l of wave v owns words {l + 64 k}, k = v (mod
     // R6_PW); per word the candidate set is narrowed over the level planes from the top in registers (m & ~plane ≠ ∅ ? keep that : the
     // bit is set in the word's minimum), the planes of R6_UNROLL words requested together; the minimum over the words is one reduction.
+    // How many tasks of the block in front of this one are IDENTICAL to it (same descriptor): each of them takes — strikes — the first
+    // candidate nobody took before it, out of the same set in the same order, so when this task's turn comes the first `twins`
+    // candidates of the level are gone whatever the other tasks did. Its list starts behind them (below): a block of one service's
+    // tasks then walks 32 half-words PER TASK into the level instead of sharing one window of 32. The ids are requested here and
+    // counted behind the pass.
+    u32 tw_id[(R6_BMAX + 64 * R6_PW - 1) / (64 * R6_PW)], tw_mine = 0;
+    const u32 tw_pos = wv::uload(&a.blk->pos);
+    if (a.tmpl) {
+        tw_mine = wv::uload(a.tmpl + t);
+        WV_UNROLL
+        for (u32 q = 0; q < (R6_BMAX + 64 * R6_PW - 1) / (64 * R6_PW); ++q) {
+            const u32 u = tw_pos + (q * R6_PW + wave) * 64 + lane;
+            tw_id[q] = u < t ? a.tmpl[u] : R6_NONE;
+        }
+    }
     const u32 maxrel = wv::uload(&a.blk->maxrel);
     const int nb = 32 - wv::clz32(maxrel);          // planes in use (0: every valid node sits on the base level)
     u32* R = reinterpret_cast<u32*>(Bf);            // [KC * 64] the word's own minimum level above the base, R6_NONE: no candidate in it
@@ -290,8 +308,11 @@ WV_DEV void r6_propose(const R6Args& a) {
             WV_UNROLL
             for (int u = 0; u < R6_UNROLL; ++u) {
                 const u32 w = (k0 + u * R6_PW) * 64 + lane;
+                // (a word without candidates needs no planes — but on a small node set waiting for m costs more than the loads: there the top
+                // batch is requested together with the rows)
+                const bool want = (hi == nb && Wn <= 512u) ? w < Wn : m[u] != 0;   // m != 0 only inside the row
                 WV_UNROLL
-                for (int b = 0; b < 8; ++b) q[u][b] = (lo + b < hi && m[u]) ? a.planes[(size_t)(lo + b) * Wn + w] : 0ull;   // m != 0 only inside the row
+                for (int b = 0; b < 8; ++b) q[u][b] = (lo + b < hi && want) ? a.planes[(size_t)(lo + b) * Wn + w] : 0ull;
             }
             WV_UNROLL
             for (int u = 0; u < R6_UNROLL; ++u) {
@@ -314,22 +335,67 @@ WV_DEV void r6_propose(const R6Args& a) {
         }
     }
     best = wv::min_u32(best);
-    if (lane == 0) flag[wave] = best;
+    u32 tw_cnt = 0;
+    if (a.tmpl) {
+        WV_UNROLL
+        for (u32 q = 0; q < (R6_BMAX + 64 * R6_PW - 1) / (64 * R6_PW); ++q) tw_cnt += (u32)wv::popc64(wv::ballot(tw_id[q] == tw_mine && tw_pos + (q * R6_PW + wave) * 64 + lane < t));
+    }
+    if (lane == 0) {
+        flag[wave] = best;
+        flag[R6_PW + wave] = tw_cnt;
+    }
     wv::barrier();
-    u32 gmin = R6_NONE;
-    for (u32 v = 0; v < R6_PW; ++v) gmin = min(gmin, flag[v]);
+    u32 gmin = R6_NONE, twins = 0;
+    for (u32 v = 0; v < R6_PW; ++v) {
+        gmin = min(gmin, flag[v]);
+        twins += flag[R6_PW + v];
+    }
     const u32 level = gmin == R6_NONE ? R6_NONE : wv::uload(&a.blk->base) + gmin;
     if (wave != 0) return;   // (every wave is past the last barrier) wave 0 lists the candidates and writes the proposal
     R6Prop* out = a.prop + wv::block();
     // its first non-empty half-words, in node order (what the matcher walks: a word that is half empty does not cost a list entry):
     // 64 words a step, a lane's place in the list = the non-empty half-words in front of it (two ballots)
     u32 cnt = 0, more = 0;
+    u32 skip = twins, last_hw = 0, last_hb = 0;   // candidates still to pass over; the last non-empty half-word passed over
     if (level != R6_NONE)
-        for (u32 k = 0; k < KC && !more; ++k) {
+        for (u32 k = 0; k < (Wn + 63u) / 64u && !more; ++k) {   // (the chunks beyond the row hold nothing)
             const u64 m = R[k * 64 + lane] == gmin ? A[k * 64 + lane] : 0ull;   // the words whose own minimum is the task's
-            const u32 lo = (u32)m, hi = (u32)(m >> 32);
-            const u64 b_lo = wv::ballot(lo != 0), b_hi = wv::ballot(hi != 0);
+            u32 lo = (u32)m, hi = (u32)(m >> 32);
+            u64 b_lo = wv::ballot(lo != 0), b_hi = wv::ballot(hi != 0);
             if (!(b_lo | b_hi)) continue;
+            if (skip) {
+                // candidates in front of a lane's word: the popcounts (<= 64: seven bits) summed over the lower lanes plane by plane
+                const u32 pl = (u32)wv::popc64((u64)lo), pc = pl + (u32)wv::popc64((u64)hi);
+                u32 ex = 0, tot = 0;
+                WV_UNROLL
+                for (u32 bit = 0; bit < 7; ++bit) {
+                    const u64 bm = wv::ballot(((pc >> bit) & 1u) != 0);
+                    ex += wv::mbcnt(bm) << bit;
+                    tot += (u32)wv::popc64(bm) << bit;
+                }
+                // a half-word whose candidates ALL lie among the first `skip` is passed over (the others keep their struck bits: the
+                // matcher meets them in the TK row)
+                const bool drop_lo = ex + pl <= skip, drop_hi = ex + pc <= skip;
+                const u64 gone = wv::ballot(pc != 0 && drop_hi);   // words passed over entirely ...
+                const u64 half = wv::ballot(lo != 0 && drop_lo && !(pc != 0 && drop_hi));   // ... and the one word whose low half alone is
+                if (gone | half) {   // remember the last half-word passed over: a level with no more than `skip` candidates lists that one
+                    const u32 lg = gone ? 63u - (u32)__builtin_clzll(gone) : 0u, lh = half ? 63u - (u32)__builtin_clzll(half) : 0u;
+                    if (half && (!gone || lh > lg)) {
+                        last_hw = 2 * (k * 64 + lh);
+                        last_hb = wv::readlane(lo, lh);
+                    } else {
+                        const u32 hi_l = wv::readlane(hi, lg), lo_l = wv::readlane(lo, lg);
+                        last_hw = 2 * (k * 64 + lg) + (hi_l ? 1u : 0u);
+                        last_hb = hi_l ? hi_l : lo_l;
+                    }
+                }
+                if (drop_lo) lo = 0;
+                if (drop_hi) hi = 0;
+                skip = tot <= skip ? skip - tot : 0u;
+                b_lo = wv::ballot(lo != 0);
+                b_hi = wv::ballot(hi != 0);
+                if (!(b_lo | b_hi)) continue;
+            }
             const u32 at_lo = cnt + wv::mbcnt(b_lo) + wv::mbcnt(b_hi), at_hi = at_lo + (lo != 0 ? 1u : 0u);
             if (lo && at_lo < 2 * R6_CAND) {
                 out->hw[at_lo] = 2 * (k * 64 + lane);
@@ -378,6 +444,13 @@ WV_DEV void r6_propose(const R6Args& a) {
     const u64 glo = r6_wave_min64(bhi == ghi ? blo : KEY_NONE);
     const u64 who = wv::ballot(bhi == ghi && blo == glo && ghi != KEY_NONE);
     const u32 gentry = who ? wv::readlane(be, (u32)wv::ffs64(who)) : 0u;
+    if (level != R6_NONE && cnt == 0) {   // every candidate of the level lies among the twins' share: the level's last half-word, all taken by then (a cut)
+        if (lane == 0) {
+            out->hw[0] = last_hw;
+            out->hb[0] = last_hb;
+        }
+        cnt = 1;
+    }
     if (lane >= cnt && lane < 2 * R6_CAND) {
         out->hw[lane] = 0;
         out->hb[lane] = 0;

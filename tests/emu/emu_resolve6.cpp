@@ -9,6 +9,8 @@
 #define SWP_R6_KERNELS
 #include "../../swarmkit_amd/csrc/swp_resolve6.hpp"
 
+#include <tuple>
+
 #include "emu_model.hpp"
 
 template <class F>
@@ -24,11 +26,12 @@ int main(int argc, char** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
-    bool verbose = false, split = false, task_rows = false;
+    bool verbose = false, split = false, task_rows = false, twins = true;
     for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 's') split = true;
         if (argv[i][0] == 't') task_rows = true;   // rows per task of the block, rebuilt every round, instead of demand-class rows
+        if (argv[i][0] == 'n') twins = false;      // lists start at the level's first candidate (R6Args.tmpl == nullptr: what the shard drivers run)
     }
     Problem p = make_problem(seed, N, T, S, order, feat);
     // demand classes over the raw reservations (what the engine's batch preparation does)
@@ -105,6 +108,18 @@ int main(int argc, char** argv) {
         a.rg_k0 = p.rg_k0.data();
         a.rg_k1 = p.rg_k1.data();
     }
+
+    // identical tasks: the first task with the same record (but for its list slot) and generic set — what the engine's batch preparation
+    // derives from the descriptors
+    std::vector<u32> tmpl(T);
+    {
+        std::map<std::tuple<u32, u32, u32, i64, i64, u32, u64, u32>, u32> first;
+        for (u32 j = 0; j < T; ++j) {
+            const RTask& r = p.rt[j];
+            tmpl[j] = first.emplace(std::make_tuple(r.svc, r.sc, r.flags, r.cpu, r.mem, r.pset, r.maxrep, p.tg.empty() ? 0u : p.tg[j]), j).first->second;
+        }
+    }
+    a.tmpl = twins ? tmpl.data() : nullptr;
 
     u64 rounds = 0;
     auto build = [&]() {
