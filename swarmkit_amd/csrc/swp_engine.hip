@@ -213,12 +213,38 @@ std::string fold_canon(const char* s, size_t len) {
     return out;
 }
 
+// uint32 -> uint32 as a vector sorted by key: the per-node service counts (a dozen entries) and the per-service node counts (a hundred):
+// a binary search and a short memmove per change instead of a tree / hash node, and batch preparation reads a service's nodes in order
+struct FlatMap32 {
+    typedef std::pair<uint32_t, uint32_t> Ent;
+    std::vector<Ent> v;
+    typedef std::vector<Ent>::iterator iterator;
+    typedef std::vector<Ent>::const_iterator const_iterator;
+    iterator begin() { return v.begin(); }
+    iterator end() { return v.end(); }
+    const_iterator begin() const { return v.begin(); }
+    const_iterator end() const { return v.end(); }
+    size_t size() const { return v.size(); }
+    bool empty() const { return v.empty(); }
+    void clear() { v.clear(); }
+    iterator lower(uint32_t k) { return std::lower_bound(v.begin(), v.end(), k, [](const Ent& e, uint32_t key) { return e.first < key; }); }
+    const_iterator lower(uint32_t k) const { return std::lower_bound(v.begin(), v.end(), k, [](const Ent& e, uint32_t key) { return e.first < key; }); }
+    iterator find(uint32_t k) { auto it = lower(k); return it != v.end() && it->first == k ? it : v.end(); }
+    const_iterator find(uint32_t k) const { auto it = lower(k); return it != v.end() && it->first == k ? it : v.end(); }
+    uint32_t& operator[](uint32_t k) {
+        auto it = lower(k);
+        if (it == v.end() || it->first != k) it = v.insert(it, Ent(k, 0u));
+        return it->second;
+    }
+    void erase(uint32_t k) { auto it = find(k); if (it != v.end()) v.erase(it); }
+};
+
 struct HostNode {
     bool present = false;
     swp_node_row row{};
     std::vector<swp_kv> labels, elabels;
     std::vector<uint32_t> plugins;
-    std::map<uint32_t, uint32_t> svc;                             // service -> ActiveTasksCountByService
+    FlatMap32 svc;                                                // service -> ActiveTasksCountByService
     std::map<std::pair<uint32_t, uint64_t>, uint32_t> fails;      // (service, specVersion) -> recent failures
     std::set<uint64_t> ports;                                     // protocol<<32 | port
     std::vector<std::pair<uint32_t, int64_t>> gen;                // (GENERIC_KIND id, count) of AvailableResources.Generic, counts >= 1, by kind
@@ -313,7 +339,7 @@ struct swp_engine {
     std::vector<HostNode> nodes;
     uint32_t n_nodes = 0;   // highest node index in use + 1
     uint32_t n_present = 0;
-    std::unordered_map<uint32_t, std::unordered_map<uint32_t, uint32_t>> svc_nodes;   // service -> node -> count (>0)
+    std::unordered_map<uint32_t, FlatMap32> svc_nodes;   // service -> node -> count (>0), nodes ascending
     std::unordered_map<uint32_t, std::unordered_set<uint32_t>> fail_nodes;            // service -> nodes with failure records
     std::unordered_map<uint64_t, std::unordered_set<uint32_t>> port_nodes;            // (proto,port) -> nodes
 
@@ -834,25 +860,33 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     for (uint32_t s = 0; s < b->n_svc; ++s) {
         uint32_t g = b->svc_global[s];
         b->list_off[s] = (uint32_t)b->list_node0.size();
-        std::map<uint32_t, std::pair<uint32_t, uint32_t>> ent;   // node -> (svc, fail), node-ordered
+        auto emit = [&](uint32_t node, uint32_t cnt, uint32_t fails) {
+            b->xrow.push_back(s);
+            b->xnode.push_back(node);
+            b->list_node0.push_back(node);
+            b->list_svc0.push_back(cnt);
+            b->list_fail0.push_back(fails);
+        };
         auto sn = e->svc_nodes.find(g);
-        if (sn != e->svc_nodes.end())
-            for (auto& kv : sn->second)
-                if (kv.second > 0 && e->nodes[kv.first].present) ent[kv.first].first = kv.second;
         auto fn = e->fail_nodes.find(g);
-        if (fn != e->fail_nodes.end())
+        if (fn == e->fail_nodes.end() || fn->second.empty()) {   // the common case: the service's nodes, already in node order
+            if (sn != e->svc_nodes.end())
+                for (const auto& kv : sn->second)
+                    if (kv.second > 0 && e->nodes[kv.first].present) emit(kv.first, kv.second, 0u);
+        } else {
+            std::map<uint32_t, std::pair<uint32_t, uint32_t>> ent;   // node -> (svc, fail), node-ordered
+            if (sn != e->svc_nodes.end())
+                for (const auto& kv : sn->second)
+                    if (kv.second > 0 && e->nodes[kv.first].present) ent[kv.first].first = kv.second;
             for (uint32_t n : fn->second) {
                 if (!e->nodes[n].present) continue;
                 auto fit = e->nodes[n].fails.find({g, svc_ver[s]});
                 if (fit != e->nodes[n].fails.end() && fit->second >= MAX_FAILURES) ent[n].second = fit->second;
             }
-        for (auto& kv : ent) {
-            if (kv.second.first == 0 && kv.second.second == 0) continue;
-            b->xrow.push_back(s);
-            b->xnode.push_back(kv.first);
-            b->list_node0.push_back(kv.first);
-            b->list_svc0.push_back(kv.second.first);
-            b->list_fail0.push_back(kv.second.second);
+            for (auto& kv : ent) {
+                if (kv.second.first == 0 && kv.second.second == 0) continue;
+                emit(kv.first, kv.second.first, kv.second.second);
+            }
         }
         init_cnt[s] = (uint32_t)b->list_node0.size() - b->list_off[s];
         b->list_cnt0.push_back(init_cnt[s]);
@@ -1492,6 +1526,8 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             const double rr_ = std::max<uint32_t>(hb.rounds, 1);
             fprintf(stderr, "[swp] k_r6_commit shader cycles per round: prologue %.0f, matching (wave 0) %.0f (list loads %.0f, walks %.0f), the others' wait for it %.0f, apply %.0f | %.1f matcher stops at an emptied half-word per round\n",
                     hb.cyc[0] * 64.0 / rr_, hb.cyc[1] * 64.0 / rr_, hb.cyc_load * 64.0 / rr_, hb.cyc_walk * 64.0 / rr_, hb.cyc[2] * 64.0 / rr_, hb.cyc[3] * 64.0 / rr_, hb.reseats / rr_);
+            fprintf(stderr, "[swp] ... of the list loads: waiting for a group's lists %.0f, its head records %.0f, seating %.0f (%.1f steps of the seating loop, stops included) per round\n", hb.cyc_g[0] * 64.0 / rr_,
+                    hb.cyc_g[1] * 64.0 / rr_, hb.cyc_g[2] * 64.0 / rr_, hb.cyc_g[3] / rr_);
         }
         return SWP_OK;
     };

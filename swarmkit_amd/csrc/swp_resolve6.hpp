@@ -41,6 +41,7 @@ namespace swpdev {
 #ifndef R6_CAND
 #define R6_CAND 16               // a proposal lists 2 * R6_CAND non-empty 32-node half-words: a block is cut where a task finds all its listed nodes taken
 #endif
+#define R6_SEAT 2                 // list entries a seating step of the matcher looks at (4 measured no better: fewer steps, each longer)
 #define R6_BMAX 1024             // largest block
 #define R6_COMMIT_THREADS 1024      // == R6_BMAX: one accepted pick per thread in the apply phase
 #define R6_NONE 0xFFFFFFFFu
@@ -51,8 +52,9 @@ struct Blk6 {   // control block, global memory
     u32 error, rounds, cut_exhausted, cut_exception, cut_uncounted;
     u32 cyc[4];            // R6Args.dbg & 16: shader cycles / 64 of k_r6_commit's sections (prologue, matching, wait for it, apply)
     u32 reseats, cyc_load, cyc_walk;   // ... how often the matcher stopped at an emptied half-word; cycles / 64 of a group's list load and of its walk
+    u32 cyc_g[4];          // ... of the list load: waiting for the group's lists, the head records, seating; seating steps
 };
-static_assert(sizeof(Blk6) == 64, "Blk6 layout");
+static_assert(sizeof(Blk6) == 80, "Blk6 layout");
 
 struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidates, as 32-node half-words
     u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); half-words listed | bit 31: there are more
@@ -521,8 +523,8 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     wv::lockstep();
     if (lane == 0) wv::lds_publish32(staged + wave_, 1u);
     const u64 t1 = prof ? wv::clock64() : 0;
-    u32 reseats = 0;
-    u64 cy_load = 0, cy_walk = 0;
+    u32 reseats = 0, seat_steps = 0;
+    u64 cy_load = 0, cy_walk = 0, cy_g0 = 0, cy_g1 = 0, cy_g2 = 0;
     if (wave_ == 0) {
         u32 nc = a.ctl->ncommit, ni = a.ctl->ninf, acc = 0, why = 0;
         u32* tk32 = reinterpret_cast<u32*>(tk);   // the same row as 32-node half-words
@@ -537,11 +539,12 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
         for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
             const u32 i = g0 + lane, glim = min(64u, n - g0);
             const bool have = i < n;
+            const u64 tg0 = prof ? wv::clock64() : 0;
             while (wv::lds_poll32(staged + (g0 >> 6)) == 0) wv::spin_pause();   // (long there, but for the first groups of a block)
+            const u64 tga = prof ? wv::clock64() : 0;
             const Head rec = nxt;
             const Head* p = &rec;
             if (g0 + 64 < n) nxt = head_of(i + 64 < n ? i + 64 : 0);
-            const u64 tg0 = prof ? wv::clock64() : 0;
             const u32 level = have ? p->level : 0u;
             const u32 nent = (have && level != R6_NONE) ? (p->n_cand & 0x7FFFFFFFu) : 0u;
             const bool plain = nent != 0;
@@ -552,31 +555,44 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             // row as it is then (the picks of the earlier groups, and of this group's tasks in front of a stop): what it finds empty
             // stays empty, what it seats is struck by the walk from then on.
             u32 bits = 0, w = 0, bits2 = 0, w2 = 0, cur = have ? L_cur[i] : 0u;   // (the group's applying wave has skipped the dead entries so far)
-            auto seat = [&](bool want) {   // lanes with `want` fill their free seats from their cursor on, two entries a step
-                for (;;) {
+            // (straight-line: every lane reads R6_SEAT entries — clamped to its list, the unused entries of a list are zero — and the TK
+            // words behind them, the seats are filled by selects: a step is two LDS round trips and no divergent branch. An entry is
+            // consumed while a seat is free; the first one that finds none stays for the next visit, and so do those behind it)
+            const u32 li = have ? i : 0u;
+            auto seat = [&](bool want, u32 opt_steps) {   // lanes with `want` fill their free seats from their cursor on
+                for (u32 step = 0;; ++step) {   // (after opt_steps steps: only as long as a lane has NO seat)
                     const bool go = want && bits2 == 0 && cur < nent;
-                    if (!wv::ballot(go)) break;
-                    if (go) {
-                        const u32 h0 = L_hw[(size_t)cur * a.block + i], b0 = L_hb[(size_t)cur * a.block + i];
-                        const bool two = cur + 1 < nent;
-                        const u32 h1 = two ? L_hw[(size_t)(cur + 1) * a.block + i] : 0u, b1 = two ? L_hb[(size_t)(cur + 1) * a.block + i] : 0u;
-                        const u32 c0 = b0 & ~tk32[h0], c1 = two ? b1 & ~tk32[h1] : 0u;
-                        cur += 1;
-                        if (c0) {
-                            if (!bits) { bits = c0; w = h0; }
-                            else { bits2 = c0; w2 = h0; }
-                        }
-                        if (two && bits2 == 0) {   // (a second seat taken by entry 0 leaves entry 1 for the next visit)
-                            cur += 1;
-                            if (c1) {
-                                if (!bits) { bits = c1; w = h1; }
-                                else { bits2 = c1; w2 = h1; }
-                            }
-                        }
+                    if (!(step < opt_steps ? wv::ballot(go) : wv::ballot(go && bits == 0))) break;
+                    ++seat_steps;
+                    u32 h[R6_SEAT], b[R6_SEAT], t[R6_SEAT];
+                    WV_UNROLL
+                    for (int q = 0; q < R6_SEAT; ++q) {
+                        const u32 c = min(cur + (u32)q, 2u * R6_CAND - 1u);
+                        h[q] = L_hw[c * a.block + li];
+                        b[q] = L_hb[c * a.block + li];
                     }
+                    WV_UNROLL
+                    for (int q = 0; q < R6_SEAT; ++q) t[q] = tk32[h[q]];
+                    bool open = go;
+                    u32 adv = 0;
+                    WV_UNROLL
+                    for (int q = 0; q < R6_SEAT; ++q) {
+                        open = open && cur + (u32)q < nent && bits2 == 0;
+                        const u32 c = open ? b[q] & ~t[q] : 0u;
+                        const bool first = bits == 0;
+                        bits2 = (c && !first) ? c : bits2;
+                        w2 = (c && !first) ? h[q] : w2;
+                        w = (c && first) ? h[q] : w;
+                        bits = (c && first) ? c : bits;
+                        adv += open ? 1u : 0u;
+                    }
+                    cur += adv;
                 }
             };
-            seat(plain);
+            const u64 tgb = prof ? wv::clock64() : 0;
+            seat(plain, 1u);   // (a second optional step costs more than the stops it saves)
+            const u64 tgc = prof ? wv::clock64() : 0;
+            if (prof) { cy_g0 += tga - tg0; cy_g1 += tgb - tga; cy_g2 += tgc - tgb; }
             const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
             const u64 m_plain = wv::ballot(plain), m_inf = wv::ballot(inf), m_exc = wv::ballot(exc), m_unc = wv::ballot(plain && (p->flags & 1u));
             // the group ends in front of a task that must use its exception list (its order moves with every placement of the service:
@@ -615,7 +631,7 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
                 flushed = at;
                 wv::lockstep();   // one wave's LDS operations execute in order: the reads below see the atomics above
                 {
-                    seat(served && lane >= at);
+                    seat(served && lane >= at, 1u);
                     if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
                         cut = at;
                         why = 1;
@@ -667,6 +683,10 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
                 a.blk->reseats += reseats;
                 a.blk->cyc_load += (u32)(cy_load >> 6);
                 a.blk->cyc_walk += (u32)(cy_walk >> 6);
+                a.blk->cyc_g[0] += (u32)(cy_g0 >> 6);
+                a.blk->cyc_g[1] += (u32)(cy_g1 >> 6);
+                a.blk->cyc_g[2] += (u32)(cy_g2 >> 6);
+                a.blk->cyc_g[3] += seat_steps;
             }
         }
     }
