@@ -1428,15 +1428,16 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     // sets beyond k_resolve5's LDS; needs the demand classes and two candidate buffers of the propose kernel in LDS (≈ 650k nodes).
     // SWP_RESOLVER=6 forces it at any size; SWP_R6_BLOCK sets the tasks per round.
     const char* env_blk = getenv("SWP_R6_BLOCK");
-    uint32_t r6_block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    // (without the knob: as many 64-task groups as the commit kernel's LDS holds next to the TK row, at most R6_BLOCK_DEFAULT_CAP tasks)
+    uint32_t r6_block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : R6_BLOCK_DEFAULT_CAP));
     // demand-class rows patched by every commit while the batch has few distinct reservations; rows per task of the block, rebuilt
     // every round from the exact residuals, when it has many (a commit would cross too many thresholds) — no limit then
     const char* env_tr = getenv("SWP_R6_TASKROWS");
     const bool r6_task_rows = env_tr ? atoi(env_tr) != 0 : (!b->classes_ok || b->n_dc + b->n_dm > 128);
     const uint32_t r6_nrr = r6_task_rows ? 0u : b->n_dc + b->n_dm;
     // (the commit kernel stages the block's lists in LDS next to the TK row: a very large node set gets a smaller block)
-    while (r6_block > 64 && r6_commit_lds_size(Wn, r6_block, r6_nrr) > lds_budget) r6_block /= 2;
-    const bool r6_ok = r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, r6_nrr) <= lds_budget;
+    while (r6_block > 64 && r6_commit_lds_size(Wn, r6_block, r6_nrr) > lds_budget) r6_block = (r6_block - 1u) / 64u * 64u;
+    const bool r6_ok = r6_propose_lds_size(Wn) <= lds_budget && r6_commit_lds_size(Wn, r6_block, r6_nrr) <= lds_budget && Wn <= 32768u;   // (half-word indices of 16 bits in the commit kernel's LDS)
     if (variant == 5 && !r5_ok) variant = 6;
     if (variant == 6 && !r6_ok) {
         if (r5_ok) variant = 5;   // (a node set whose rows leave the block resolver no LDS but fits the round resolver's: cannot happen with today's limits)

@@ -23,6 +23,7 @@ struct R6Args;
 size_t r6_propose_lds_size(uint32_t n_words);
 size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr);
 uint32_t r6_block_max();
+#define R6_BLOCK_DEFAULT_CAP 768u   // tasks per round of the block resolver unless SWP_R6_BLOCK says otherwise (and as the LDS allows)
 hipError_t launch_r6_build(const R6Args& a, hipStream_t s);
 hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int dev);
 

@@ -30,7 +30,8 @@ hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int
     if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r6_commit), dev)) != hipSuccess) return r;
     for (uint32_t i = 0; i < rounds; ++i) {
         if (a.task_rows) hipLaunchKernelGGL(k_r6_taskrows, dim3((a.n_words + 3) / 4, (a.block + 63) / 64), dim3(256), (size_t)a.block * 16, s, a);
-        hipLaunchKernelGGL(k_r6_propose, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
+        if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small, dim3(a.block), dim3(64 * R6_PW), lp, s, a);   // (LDS of 8 chunks: never beyond 48 KB)
+        else hipLaunchKernelGGL(k_r6_propose, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
         hipLaunchKernelGGL(k_r6_commit, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
     }
     return hipGetLastError();

@@ -116,12 +116,16 @@ struct R6Args {
     const u32* tmpl;
 };
 
-#define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together
+#define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together ...
+#define R6_SMALL_WORDS 512u      // ... on node sets beyond this many words (32 768 nodes); up to there a wave has ONE chunk: a quarter of the registers, so that
+                                 // the workgroups of a large block are all resident at once
 #define R6_PW 8                  // waves per task in the propose kernel
-inline __host__ __device__ u32 r6_chunks(u32 n_words) { return (((n_words + 63u) >> 6) + R6_UNROLL * R6_PW - 1u) / (R6_UNROLL * R6_PW) * (R6_UNROLL * R6_PW); }
+inline __host__ __device__ u32 r6_unroll(u32 n_words) { return n_words <= R6_SMALL_WORDS ? 1u : (u32)R6_UNROLL; }
+inline __host__ __device__ u32 r6_chunks(u32 n_words) { const u32 g = r6_unroll(n_words) * R6_PW; return (((n_words + 63u) >> 6) + g - 1u) / g * g; }
 inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8 + 128; }
 // TK row, thresholds, the picks of the block, a few scalars, the block's lists (entry-major)
-inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * (4 + 4 * R6_CAND) * 4 + 128; }
+// (per task: pick node / index / aux, the cursor, 2 * R6_CAND candidate masks and as many half-word indices of 16 bits: node sets of up to 2^21 nodes)
+inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * (16 + 2 * R6_CAND * 6) + 128; }
 
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
 WV_DEV u64 r6_wave_min64(u64 v) {
@@ -232,7 +236,7 @@ WV_KERNEL(256) void k_r6_taskrows(R6Args a) { r6_taskrows(a, wv::block_y(), (a.b
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
 // The waves split the task's node words (wave v owns the chunks of 64 words k = v, v + R6_PW, ...): the passes are latency-bound,
 // so more waves per task is what shortens them. A pass ends with one barrier (has any wave a candidate left?).
-WV_DEV void r6_propose(const R6Args& a) {
+template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
     const u32 lane = wv::lane(), wave = wv::wave();
     const u32 t = wv::uload(&a.blk->pos) + wv::block();
     if (t >= wv::uload(&a.blk->end) || wv::uload(&a.blk->error) != ERR_NONE) return;   // (an error stops the rounds until the host has seen it)
@@ -240,7 +244,7 @@ WV_DEV void r6_propose(const R6Args& a) {
     const i64 rcpu = wv::uload(&rt->cpu), rmem = wv::uload(&rt->mem);
     const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc), scid = wv::uload(&rt->sc), pset = wv::uload(&rt->pset);
     const u64 maxrep = wv::uload(&rt->maxrep);
-    const u32 Wn = a.n_words, KC = r6_chunks(Wn);   // a multiple of R6_UNROLL * R6_PW; the chunks beyond the row hold no candidates
+    const u32 Wn = a.n_words, KC = r6_chunks(Wn);   // a multiple of UN * R6_PW; the chunks beyond the row hold no candidates
     u64* A = wv::lds();
     u64* Bf = A + (size_t)KC * 64;
     u32* flag = reinterpret_cast<u32*>(Bf + (size_t)KC * 64);   // [R6_NP + 2] "some wave still has a candidate", one word per pass
@@ -263,7 +267,7 @@ WV_DEV void r6_propose(const R6Args& a) {
     }
     // The task's plain candidates AND the minimum level among them in one pass: lane l of wave v owns words {l + 64 k}, k = v (mod
     // R6_PW); per word the candidate set is narrowed over the level planes from the top in registers (m & ~plane ≠ ∅ ? keep that : the
-    // bit is set in the word's minimum), the planes of R6_UNROLL words requested together; the minimum over the words is one reduction.
+    // bit is set in the word's minimum), the planes of UN words requested together; the minimum over the words is one reduction.
     // How many tasks of the block in front of this one are IDENTICAL to it (same descriptor): each of them takes — strikes — the first
     // candidate nobody took before it, out of the same set in the same order, so when this task's turn comes the first `twins`
     // candidates of the level are gone whatever the other tasks did. Its list starts behind them (below): a block of one service's
@@ -283,10 +287,10 @@ WV_DEV void r6_propose(const R6Args& a) {
     const int nb = 32 - wv::clz32(maxrel);          // planes in use (0: every valid node sits on the base level)
     u32* R = reinterpret_cast<u32*>(Bf);            // [KC * 64] the word's own minimum level above the base, R6_NONE: no candidate in it
     u32 best = R6_NONE;
-    for (u32 k0 = wave; k0 < KC; k0 += R6_UNROLL * R6_PW) {
-        u64 m[R6_UNROLL], f[R6_UNROLL];
+    for (u32 k0 = wave; k0 < KC; k0 += UN * R6_PW) {
+        u64 m[UN], f[UN];
         WV_UNROLL
-        for (int u = 0; u < R6_UNROLL; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const u32 w = (k0 + u * R6_PW) * 64 + lane;
             const bool in = w < Wn;
             m[u] = in ? scrow[w] : 0ull;
@@ -295,9 +299,9 @@ WV_DEV void r6_propose(const R6Args& a) {
             for (u32 g = g0; g < g1; ++g)
                 if (in) f[u] |= ~a.rg[(size_t)wv::uload(a.gs_row + g) * Wn + w];
         }
-        u32 rel[R6_UNROLL];
+        u32 rel[UN];
         WV_UNROLL
-        for (int u = 0; u < R6_UNROLL; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const u32 w = (k0 + u * R6_PW) * 64 + lane;
             m[u] &= ~f[u];
             for (u32 p = p0; p < p1; ++p)
@@ -306,9 +310,9 @@ WV_DEV void r6_propose(const R6Args& a) {
         }
         for (int hi = nb; hi > 0; hi -= 8) {   // eight planes a batch (a batch is all there is below 256 levels)
             const int lo = hi > 8 ? hi - 8 : 0;
-            u64 q[R6_UNROLL][8];
+            u64 q[UN][8];
             WV_UNROLL
-            for (int u = 0; u < R6_UNROLL; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const u32 w = (k0 + u * R6_PW) * 64 + lane;
                 // (a word without candidates needs no planes — but on a small node set waiting for m costs more than the loads: there the top
                 // batch is requested together with the rows)
@@ -317,7 +321,7 @@ WV_DEV void r6_propose(const R6Args& a) {
                 for (int b = 0; b < 8; ++b) q[u][b] = (lo + b < hi && want) ? a.planes[(size_t)(lo + b) * Wn + w] : 0ull;
             }
             WV_UNROLL
-            for (int u = 0; u < R6_UNROLL; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 WV_UNROLL
                 for (int b = 7; b >= 0; --b) {
                     if (lo + b >= hi) continue;
@@ -328,7 +332,7 @@ WV_DEV void r6_propose(const R6Args& a) {
             }
         }
         WV_UNROLL
-        for (int u = 0; u < R6_UNROLL; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const u32 idx = (k0 + u * R6_PW) * 64 + lane;
             A[idx] = m[u];
             const u32 r = m[u] ? rel[u] : R6_NONE;
@@ -467,7 +471,13 @@ WV_DEV void r6_propose(const R6Args& a) {
     }
 }
 
+// (UN follows the node set: r6_unroll(n_words); the shard drivers' ranges may differ in size, so they pass it per range)
+WV_DEV void r6_propose(const R6Args& a) {
+    if (a.n_words <= R6_SMALL_WORDS) r6_propose_t<1>(a);
+    else r6_propose_t<R6_UNROLL>(a);
+}
 WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) { r6_propose(a); }
+WV_KERNEL(64 * R6_PW) void k_r6_propose_small(R6Args a) { r6_propose_t<1>(a); }   // n_words <= R6_SMALL_WORDS only: the registers of ONE chunk
 
 // index of the first of n ascending thresholds that is greater than q (n: none)
 WV_DEV u32 r6_first_above(const i64* thr, u32 n, i64 q) {
@@ -493,9 +503,9 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     u32* pk_aux = pk_idx + a.block;                              // [block] exception-list entry (LIST_EMPTY: plain node) / commits before an unplaceable task
     u32* sh = pk_aux + a.block;                                  // [0] accepted, [1] ncommit, [2] ninf, [3] tasks decided so far, [4] the matching is over
     u32* staged = sh + 16;                                       // [16] group g's lists are in LDS
-    u32* L_hw = sh + 32;                                         // [2 * R6_CAND][block] the block's lists, entry-major: lane i of the matcher reads
-    u32* L_hb = L_hw + (size_t)2 * R6_CAND * a.block;            // ... entry k of task i at [k * block + i] (no bank conflicts)
-    u32* L_cur = L_hb + (size_t)2 * R6_CAND * a.block;           // [block] a lower bound of every task's cursor: the entries in front of it are dead
+    u32* L_hb = sh + 32;                                         // [2 * R6_CAND][block] the block's lists, entry-major: lane i of the matcher reads
+    u32* L_cur = L_hb + (size_t)2 * R6_CAND * a.block;           // ... entry k of task i at [k * block + i] (no bank conflicts); [block] a lower bound of every task's cursor: the entries in front of it are dead
+    unsigned short* L_hw = reinterpret_cast<unsigned short*>(L_cur + a.block);   // [2 * R6_CAND][block] the half-word indices, 16 bits each (the engine refuses node sets beyond 2^21 nodes)
     for (u32 j = tid; j < a.block; j += R6_COMMIT_THREADS) L_cur[j] = 0;
     for (u32 w = tid; w < Wn; w += R6_COMMIT_THREADS) tk[w] = 0;
     for (u32 c = tid; c < n_rr; c += R6_COMMIT_THREADS) thr[c] = a.thr[c];
@@ -516,7 +526,7 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     if (tid < n) {
         const R6Prop* q = a.prop + tid;
         for (int k = 0; k < 2 * R6_CAND; ++k) {
-            L_hw[(size_t)k * a.block + tid] = q->hw[k];
+            L_hw[(size_t)k * a.block + tid] = (unsigned short)q->hw[k];
             L_hb[(size_t)k * a.block + tid] = q->hb[k];
         }
     }
