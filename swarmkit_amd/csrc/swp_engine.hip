@@ -1514,7 +1514,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
             const double pace = std::max(1.0, recent);
             chunk = (uint32_t)std::min<double>(4096.0, (double)(end - pos) / pace * 1.05 + 4.0);
-            if (scan_ok) chunk = std::min<uint32_t>(chunk, recent < 32.0 ? 64u : 256u);   // (look again soon: rounds that hit such a stretch decide one task each)
+            if (scan_ok) chunk = std::min<uint32_t>(chunk, recent < 16.0 ? 16u : recent < 64.0 ? 48u : 256u);   // (look again soon: rounds that hit such a stretch decide one task each)
         }
         if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u)\n", scanned, start, end);
         r6_rounds += hb.rounds;

@@ -65,18 +65,28 @@ hipError_t launch_r7_apply(const R6Args* args, uint32_t count, const R7Pick* pic
 
 // ---- the scan resolver (swp_scan.hpp): a stretch of tasks one after the other, every task by one workgroup over all nodes ----
 uint32_t scan_max_nodes() { return SCAN_MAXN; }
-hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev) {
-    const size_t lds = scan_lds(s.a.n_nodes);
+template <int NQ, bool LM>
+static hipError_t launch_scan_as(const ScanArgs& s, size_t lds, hipStream_t st, int dev) {
     hipError_t r;
-    const uint32_t nq = (s.a.n_nodes + SCAN_THREADS - 1) / SCAN_THREADS;
-    const void* fn = nq <= 1 ? reinterpret_cast<const void*>(&k_scan<1>) : nq == 2 ? reinterpret_cast<const void*>(&k_scan<2>) : reinterpret_cast<const void*>(&k_scan<4>);
-    if (lds > 48 * 1024 && (r = ensure_big_lds(fn, dev)) != hipSuccess) return r;
+    if (lds > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_scan<NQ, LM>), dev)) != hipSuccess) return r;
+    hipLaunchKernelGGL((k_scan<NQ, LM>), dim3(1), dim3(SCAN_THREADS), lds, st, s);
+    return hipGetLastError();
+}
+template <bool LM>
+static hipError_t launch_scan_nq(const ScanArgs& s, size_t lds, hipStream_t st, int dev) {
+    switch (scan_nq(s.a.n_nodes)) {
+        case 1: return launch_scan_as<1, LM>(s, lds, st, dev);
+        case 2: return launch_scan_as<2, LM>(s, lds, st, dev);
+        default: return launch_scan_as<4, LM>(s, lds, st, dev);
+    }
+}
+bool scan_matrices_in_lds(uint32_t n_nodes, uint32_t n_svc) { return scan_lds_lm(n_nodes, n_svc) <= (size_t)160 * 1024 - 512; }
+hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev) {
     hipLaunchKernelGGL(k_scan_fill, dim3(1024), dim3(256), 0, st, s);
     hipLaunchKernelGGL(k_scan_lists, dim3(64, s.n_svc), dim3(256), 0, st, s);
-    if (nq <= 1) hipLaunchKernelGGL(k_scan<1>, dim3(1), dim3(SCAN_THREADS), lds, st, s);
-    else if (nq == 2) hipLaunchKernelGGL(k_scan<2>, dim3(1), dim3(SCAN_THREADS), lds, st, s);
-    else hipLaunchKernelGGL(k_scan<4>, dim3(1), dim3(SCAN_THREADS), lds, st, s);
-    return hipGetLastError();
+    // the (service, node) matrices in LDS when they fit next to the node rows: a task's turn then waits for no global load
+    if (scan_matrices_in_lds(s.a.n_nodes, s.n_svc)) return launch_scan_nq<true>(s, scan_lds_lm(s.a.n_nodes, s.n_svc), st, dev);
+    return launch_scan_nq<false>(s, scan_lds(s.a.n_nodes), st, dev);
 }
 
 }  // namespace swpdev

@@ -19,8 +19,17 @@
 
 namespace swpdev {
 
+// A task's turn is a dependent chain — evaluate the thread's nodes, the wave's least key (two DPP reductions: the key carries the node), one
+// LDS atomic min per wave, ONE barrier, the owner applies — and a wave issues an instruction every ~5 cycles whatever its neighbours do:
+// the chain is shortest with one node per thread (four waves over 1 000 nodes were no faster than sixteen; what cost 3 800 cycles a task
+// was the second reduction level behind a barrier and the second barrier).
 #define SCAN_THREADS 1024
 #define SCAN_MAXN 4096      // nodes: (8 + 8 + 4 + 4) bytes of LDS each
+inline __host__ __device__ u32 scan_nq(u32 n_nodes) {   // nodes per thread of the instance for this node count: 1, 2 or 4
+    u32 q = 1;
+    while (q * SCAN_THREADS < n_nodes) q *= 2;
+    return q;
+}
 
 struct ScanArgs {
     R6Args a;          // the block resolver's argument record: node rows, static class rows, lists, host ports, generic sets, logs
@@ -31,6 +40,8 @@ struct ScanArgs {
 };
 #define SCAN_RTQ 32         // task records staged through LDS at a time (their loads are misses: a record is read once)
 inline __host__ __device__ size_t scan_lds(u32 n_nodes) { return (size_t)n_nodes * 24 + 16 * 16 + 64 + 2 * SCAN_RTQ * 64; }
+// ... plus the two (service, node) matrices when they fit next to it (SCAN_LM instances): a task then reads nothing but its static-class words from global memory
+inline __host__ __device__ size_t scan_lds_lm(u32 n_nodes, u32 n_svc) { return ((scan_lds(n_nodes) + 15) & ~(size_t)15) + (size_t)2 * n_svc * n_nodes * 4; }
 
 #ifdef SWP_SCAN_KERNELS
 // hmat / emat from the per-service lists: grid (entries of the longest list / 256, services)
@@ -54,8 +65,8 @@ WV_KERNEL(256) void k_scan_lists(ScanArgs s) {
     }
 }
 
-// SCAN_NQ: nodes per thread (the launcher instantiates 1, 2 and 4: a thread of a 1 000-node scan carries no code for nodes it has not)
-template <int SCAN_NQ>
+// SCAN_NQ: nodes per thread (the launcher instantiates 1, 2 and 4 — scan_nq: a thread of a 1 000-node scan carries no code for nodes it has not)
+template <int SCAN_NQ, bool SCAN_LM>
 WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
     const R6Args& a = s.a;
     const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave(), N = a.n_nodes, Wn = a.n_words;
@@ -64,11 +75,15 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
     i64* mem = cpu + N;
     u32* tot = reinterpret_cast<u32*>(mem + N);
     int32_t* lastc = reinterpret_cast<int32_t*>(tot + N);                               // the node's last commit (Explain's chains)
-    u64* red_k = reinterpret_cast<u64*>(l + (((size_t)N * 24 + 15) & ~(size_t)15));   // [16] per wave: its least key ...
-    u32* red_n = reinterpret_cast<u32*>(red_k + 16);                                     // ... and the lowest node that has it
+    u64* red_k = reinterpret_cast<u64*>(l + (((size_t)N * 24 + 15) & ~(size_t)15));   // [3] the least key of a task, in rotation: the waves' minima meet here (atomic min)
+    u32* red_n = reinterpret_cast<u32*>(red_k + 16);                                     // (spare)
     u32* rtq = red_n + 16;                                                               // [2][SCAN_RTQ] task records, as dwords
+    u32* hm = reinterpret_cast<u32*>(l + ((scan_lds(N) + 15) & ~(size_t)15));           // SCAN_LM: [n_svc][N] the key halves ...
+    u32* em = hm + (size_t)s.n_svc * N;                                                  // ... and the list entries, here instead of in global memory
     if (a.blk->error != ERR_NONE) return;
     for (u32 n = tid; n < N; n += SCAN_THREADS) { cpu[n] = a.cpu[n]; mem[n] = a.mem[n]; tot[n] = a.total[n]; lastc[n] = a.last[n]; }
+    if (SCAN_LM)
+        for (u32 x = tid; x < s.n_svc * N; x += SCAN_THREADS) { hm[x] = s.hmat[x]; em[x] = s.emat[x]; }
     u32 nc = a.ctl->ncommit, ni = a.ctl->ninf;
     wv::barrier();
     // What a task reads from global memory — its record, its static-class word and the key halves of this thread's nodes — is
@@ -82,7 +97,9 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
         return (tid < cdw && t0 + tid / 16u < s.j1) ? rt32[(size_t)t0 * 16u + tid] : 0u;
     };
     if (tid < cdw) rtq[tid] = chunk_load(0);
+    if (tid < 3) red_k[tid] = KEY_NONE;
     u32 next_dw = chunk_load(1);
+    u32 slot = 0;   // red_k[slot] takes this task's minimum
     wv::barrier();
     auto task_rec = [&](u32 t) -> RTask {
         const u32 i = t - s.j0;
@@ -95,8 +112,8 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
     for (int q = 0; q < SCAN_NQ; ++q) {
         const u32 n = tid + (u32)q * SCAN_THREADS;
         scn[q] = n < N ? a.sc[(size_t)rn.sc * Wn + (n >> 6)] : 0ull;
-        hin[q] = n < N ? s.hmat[(size_t)rn.svc * N + n] : 0u;
-        ein[q] = n < N ? s.emat[(size_t)rn.svc * N + n] : LIST_EMPTY;
+        hin[q] = (!SCAN_LM && n < N) ? s.hmat[(size_t)rn.svc * N + n] : 0u;
+        ein[q] = (!SCAN_LM && n < N) ? s.emat[(size_t)rn.svc * N + n] : LIST_EMPTY;
     }
     for (u32 t = s.j0; t < s.j1; ++t) {
         const RTask r = rn;
@@ -116,14 +133,13 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
             for (int q = 0; q < SCAN_NQ; ++q) {
                 const u32 n = tid + (u32)q * SCAN_THREADS;
                 scn[q] = n < N ? a.sc[(size_t)rn.sc * Wn + (n >> 6)] : 0ull;
-                hin[q] = n < N ? s.hmat[(size_t)rn.svc * N + n] : 0u;
-                ein[q] = n < N ? s.emat[(size_t)rn.svc * N + n] : LIST_EMPTY;
+                hin[q] = (!SCAN_LM && n < N) ? s.hmat[(size_t)rn.svc * N + n] : 0u;
+                ein[q] = (!SCAN_LM && n < N) ? s.emat[(size_t)rn.svc * N + n] : LIST_EMPTY;
             }
         }
         const u32 gset = a.n_rg ? a.tg[t] : 0u;
         // ---- every thread: the best of its own nodes
-        u64 bk = KEY_NONE;
-        u32 bn = R6_NONE;
+        u64 bk = KEY_NONE;   // nodeLess' key with the node index in its lowest 12 bits: the least key IS the pick (lowest node among equals)
         WV_UNROLL
         for (int q = 0; q < SCAN_NQ; ++q) {
             const u32 n = tid + (u32)q * SCAN_THREADS;
@@ -131,7 +147,7 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
             const u32 w = n >> 6;
             const u64 bit = 1ull << (n & 63);
             if (!(scw[q] & bit)) continue;   // (the static class row holds valid & ready & constraints & platform & plugins)
-            const u32 hi = hiw[q];
+            const u32 hi = SCAN_LM ? hm[(size_t)r.svc * N + n] : hiw[q];
             if ((r.flags & RT_RES) && !(r.cpu <= cpu[n] && r.mem <= mem[n])) continue;
             bool ok = true;
             if (gset)
@@ -144,18 +160,21 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
                     if (wv::g_fresh64(a.portmap + (size_t)a.pset_ids[z] * Wn + w) & bit) ok = false;
             if (ok && (r.flags & RT_MAXREP) && !((u64)(hi & 0xFFFFFFu) < r.maxrep)) ok = false;
             if (!ok) continue;
-            const u64 key = ((u64)hi << 32) | tot[n];
-            if (key < bk) { bk = key; bn = n; }   // (a thread's nodes ascend: the first of equal keys stays)
+            const u32 tn = tot[n];
+            if (tn >> 20) a.blk->error = ERR_LEVEL_RANGE;   // (a million tasks on one node: beyond the 20 bits the packed key has for the count)
+            const u64 key = ((u64)hi << 32) | ((u64)tn << 12) | n;
+            if (key < bk) bk = key;
         }
-        // ---- the workgroup's argmin: least key, lowest node among equals. Every wave reduces the 16 wave results itself (no second barrier).
+        // ---- the workgroup's argmin: every wave's least key goes into the task's LDS word by an atomic min; behind the one barrier everybody
+        // reads the result. The words rotate (three): the one two tasks ahead is reset behind this barrier — everybody is past reading it
+        // (it was the previous task's) and nobody writes it before the next barrier.
         const u64 wk = r6_wave_min64(bk);
-        const u32 wn = wv::min_u32(bk == wk ? bn : R6_NONE);
-        if (lane == 0) { red_k[wave] = wk; red_n[wave] = wn; }
+        if (lane == 0 && wk != KEY_NONE) wv::lds_min64(red_k + slot, wk);
         wv::barrier();
-        const u64 k2 = lane < SCAN_THREADS / 64 ? red_k[lane] : KEY_NONE;
-        const u32 n2 = lane < SCAN_THREADS / 64 ? red_n[lane] : R6_NONE;
-        const u64 gk = r6_wave_min64(k2);
-        const u32 gn = wv::min_u32(k2 == gk ? n2 : R6_NONE);
+        const u64 gk = wv::lds_read64(red_k + slot);
+        const u32 gn = gk == KEY_NONE ? R6_NONE : (u32)gk & 0xFFFu;
+        if (tid == 0) red_k[slot == 0 ? 2 : slot - 1] = KEY_NONE;
+        slot = slot == 2 ? 0 : slot + 1;
         // ---- the owner of the node applies the placement (NodeInfo.addTask); everybody counts
         if (gn == R6_NONE) {
             if (tid == 0) {
@@ -177,22 +196,29 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
                 if (!(r.flags & RT_UNCOUNTED)) {
                     tot[nd] += 1;
                     u32 hi = 0, entry = LIST_EMPTY;   // the node's key half and list entry for this service: read a task ago, in registers
-                    WV_UNROLL
-                    for (int q = 0; q < SCAN_NQ; ++q)
-                        if (tid + (u32)q * SCAN_THREADS == nd) { hi = hiw[q]; entry = enw[q]; }
+                    if (SCAN_LM) {
+                        hi = hm[(size_t)r.svc * N + nd];
+                        entry = em[(size_t)r.svc * N + nd];
+                    } else {
+                        WV_UNROLL
+                        for (int q = 0; q < SCAN_NQ; ++q)
+                            if (tid + (u32)q * SCAN_THREADS == nd) { hi = hiw[q]; entry = enw[q]; }
+                    }
                     hi += 1u;
                     if ((hi & 0xFFFFFFu) == 0) a.blk->error = ERR_GROUP_RANGE;
-                    s.hmat[(size_t)r.svc * N + nd] = hi;
+                    if (SCAN_LM) hm[(size_t)r.svc * N + nd] = hi;
+                    else s.hmat[(size_t)r.svc * N + nd] = hi;
                     if (entry == LIST_EMPTY) {
                         wv::g_or64(a.X + (size_t)r.svc * a.xs + w, bit);
                         a.list_node[r.slot] = nd;
                         a.list_svc[r.slot] = 1;
                         a.list_fail[r.slot] = 0;
-                        s.emat[(size_t)r.svc * N + nd] = r.slot;
+                        if (SCAN_LM) em[(size_t)r.svc * N + nd] = r.slot;
+                        else s.emat[(size_t)r.svc * N + nd] = r.slot;
                         entry = r.slot;
                     } else
                         a.list_svc[entry] = hi & 0xFFFFFFu;   // (the entry's count is the key half's low 24 bits)
-                    if (rn.svc == r.svc) {   // the next task is of the same service: what it read of this node is a placement old
+                    if (!SCAN_LM && rn.svc == r.svc) {   // the next task is of the same service: what it read of this node is a placement old
                         WV_UNROLL
                         for (int q = 0; q < SCAN_NQ; ++q)
                             if (tid + (u32)q * SCAN_THREADS == nd) { hin[q] = hi; ein[q] = entry; }
@@ -207,7 +233,7 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
             }
             ++nc;
         }
-        wv::barrier();   // the next task sees this one's node row; red_k / red_n are free again
+        // (no second barrier: a node's row is read and written by its owner only, the records of a chunk are staged behind a barrier of their own)
     }
     for (u32 n = tid; n < N; n += SCAN_THREADS) { a.cpu[n] = cpu[n]; a.mem[n] = mem[n]; a.total[n] = tot[n]; a.last[n] = lastc[n]; }
     if (tid == 0) {

@@ -75,6 +75,8 @@ WV_DEV void lds_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAX
 WV_DEV void lds_xor64(u64* p, u64 v) { __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_or32(u32* p, u32 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void lds_min64(u64* p, u64 v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV u64 lds_read64(const u64* p) { return *reinterpret_cast<const volatile u64*>(p); }   // (behind a barrier: not to be merged with an earlier read)
 WV_DEV void lds_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ---- flags between waves of one workgroup that do NOT meet at a barrier (k_r6_commit: the matching wave runs on while the others apply) ----

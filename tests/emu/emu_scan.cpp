@@ -26,10 +26,11 @@ int main(int argc, char** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
-    bool verbose = false, split = false, task_rows = false, mixed = false;
+    bool verbose = false, split = false, task_rows = false, mixed = false, no_lm = false;
     for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 'm') mixed = true;
+        if (argv[i][0] == 'g') no_lm = true;   // the (service, node) matrices stay in global memory even if they would fit in LDS
     }
     if (N > SCAN_MAXN) { fprintf(stderr, "the scan resolver takes %d nodes\n", SCAN_MAXN); return 2; }
     Problem p = make_problem(seed, N, T, S, order, feat);
@@ -154,9 +155,16 @@ int main(int argc, char** argv) {
             grid(64, 256, 0, [s]() { k_scan_lists(s); });
         }
         emu::blockidx_y() = 0;
-        if (N <= SCAN_THREADS) grid(1, SCAN_THREADS, scan_lds(N), [s]() { k_scan<1>(s); });   // the instance the launcher picks for this node count
-        else if (N <= 2 * SCAN_THREADS) grid(1, SCAN_THREADS, scan_lds(N), [s]() { k_scan<2>(s); });
-        else grid(1, SCAN_THREADS, scan_lds(N), [s]() { k_scan<4>(s); });
+        const bool lm = scan_lds_lm(N, s.n_svc) <= (size_t)160 * 1024 - 512 && !no_lm;   // the launcher's rule: the matrices in LDS when they fit
+        const size_t lds = lm ? scan_lds_lm(N, s.n_svc) : scan_lds(N);
+        switch (scan_nq(N) * 2 + (lm ? 1 : 0)) {   // the instance the launcher picks for this node count
+            case 2: grid(1, SCAN_THREADS, lds, [s]() { k_scan<1, false>(s); }); break;
+            case 3: grid(1, SCAN_THREADS, lds, [s]() { k_scan<1, true>(s); }); break;
+            case 4: grid(1, SCAN_THREADS, lds, [s]() { k_scan<2, false>(s); }); break;
+            case 5: grid(1, SCAN_THREADS, lds, [s]() { k_scan<2, true>(s); }); break;
+            case 8: grid(1, SCAN_THREADS, lds, [s]() { k_scan<4, false>(s); }); break;
+            default: grid(1, SCAN_THREADS, lds, [s]() { k_scan<4, true>(s); }); break;
+        }
         ++rounds;
         if (blk.error) { fprintf(stderr, "k_scan reported error %u\n", blk.error); return false; }
         return blk.pos == j1;

@@ -294,6 +294,8 @@ inline void lds_xor64(u64* p, u64 v) { *p ^= v; }
 inline void lds_or32(u32* p, u32 v) { *p |= v; }
 inline void lds_andn64(u64* p, u64 v) { *p &= ~v; }
 inline void lds_add32(u32* p, u32 v) { *p += v; }
+inline void lds_min64(u64* p, u64 v) { if (v < *p) *p = v; }
+inline u64 lds_read64(const u64* p) { return *reinterpret_cast<const volatile u64*>(p); }
 inline void lds_add_release32(u32* p, u32 v) { *reinterpret_cast<volatile u32*>(p) += v; emu::wake_pollers(); }
 
 inline void g_add64(i64* p, i64 v) { *p += v; }

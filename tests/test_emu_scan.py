@@ -37,6 +37,11 @@ CASES = [
     (12, 4096, 700, 25, 256, 0, 2, "m"),    # the most nodes the kernel takes (four per thread)
     (14, 1900, 900, 30, 128, 0, 3, "m"),    # two nodes per thread
     (13, 65, 800, 3, 32, 2, 2, "m"),
+    # (up to here the (service, node) matrices fit in LDS next to the node rows where services x nodes allows; "g": the global-memory instances)
+    (1, 300, 1000, 20, 64, 0, 0, "g"),
+    (3, 1000, 2500, 40, 64, 2, 2, "mg"),
+    (7, 500, 1200, 40, 128, 0, 3, "mg"),
+    (13, 65, 800, 3, 32, 2, 2, "g"),
 ]
 
 
