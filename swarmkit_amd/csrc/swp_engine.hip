@@ -1515,6 +1515,13 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             const double pace = std::max(1.0, recent);
             chunk = (uint32_t)std::min<double>(4096.0, (double)(end - pos) / pace * 1.05 + 4.0);
             if (scan_ok) chunk = std::min<uint32_t>(chunk, recent < 16.0 ? 16u : recent < 64.0 ? 48u : 256u);   // (look again soon: rounds that hit such a stretch decide one task each)
+            // the block follows the pace: rounds that are cut after a few dozen tasks (re-placements that all aim at the few emptied nodes)
+            // need not propose and stage hundreds of lists each; rounds that fill their block get the next size up
+            if (!env_blk) {
+                if (recent > 0.4 * ra.block) ra.block = std::min<uint32_t>(r6_block, ra.block * 2u);
+                else ra.block = std::min<uint32_t>(r6_block, std::max<uint32_t>(128u, ((uint32_t)(2.0 * recent) + 63u) / 64u * 64u));
+                chunk = std::min<uint32_t>(chunk, ra.block < r6_block ? 64u : 4096u);   // (look again before long while the block is small)
+            }
         }
         if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u)\n", scanned, start, end);
         r6_rounds += hb.rounds;
