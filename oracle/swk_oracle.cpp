@@ -828,11 +828,10 @@ void Pipeline::set_task(const Task* task) {
             if (p.publish_mode == PublishModeHost && p.published_port != 0) { checklist[F_HOSTPORT].enabled = true; break; }
     // MaxReplicasFilter.SetTask filter.go:363-370
     if (t->has_placement && t->max_replicas > 0) checklist[F_MAXREPLICAS].enabled = true;
-    // VolumesFilter (appended by Run, scheduler.go:132): enabled only for MountTypeCluster mounts,
-    // which this oracle does not model (out of scope).
-    if (t->has_container)
+    // VolumesFilter.SetTask filter.go:392-422 (the filter Run appends, scheduler.go:132): enabled iff the task has a MountTypeCluster mount
+    if (vs && t->has_container)
         for (const Mount& m : t->mounts)
-            if (m.type == MountTypeCluster) throw std::runtime_error("oracle: CSI cluster mounts are out of scope");
+            if (m.type == MountTypeCluster) { checklist[F_VOLUMES].enabled = true; break; }
 }
 
 bool Pipeline::check(int f, const NodeInfo& n) const {
@@ -881,6 +880,10 @@ bool Pipeline::check(int f, const NodeInfo& n) const {
         return true;
     case F_MAXREPLICAS:   // filter.go:373-375
         return uint64_t(n.svc_count_key(task_service_key(*t))) < t->max_replicas;
+    case F_VOLUMES:   // filter.go:424-432: passes when ANY requested cluster mount has an available volume on the node
+        for (const Mount& m : t->mounts)
+            if (m.type == MountTypeCluster && !vs->is_available_on_node(m, n).empty()) return true;
+        return false;
     }
     return true;
 }
@@ -912,6 +915,7 @@ std::string filter_explain(int f, int64_t nodes) {
     case F_PLATFORM: return nodes == 1 ? "unsupported platform on 1 node" : "unsupported platform on " + std::to_string(nodes) + " nodes";
     case F_HOSTPORT: return nodes == 1 ? "host-mode port already in use on 1 node" : "host-mode port already in use on " + std::to_string(nodes) + " nodes";
     case F_MAXREPLICAS: return "max replicas per node limit exceed";
+    case F_VOLUMES: return nodes == 1 ? "cannot fulfill requested CSI volume mounts on 1 node" : "cannot fulfill requested CSI volume mounts on " + std::to_string(nodes) + " nodes";   // filter.go:434-441
     }
     return "";
 }
@@ -934,6 +938,141 @@ std::string Pipeline::explain() const {
         }
     }
     return out;
+}
+
+// ============================================================================
+// topology.go:23-47, volumes.go:19-316
+// ============================================================================
+
+// IsInTopology: `top` (a node's topology for one plugin; nil = has_top false) lies within `accessible` when one of its topologies has
+// every (subdomain, segment) pair in `top` as well. Anything missing = it fits.
+bool is_in_topology(bool has_top, const std::map<std::string, std::string>& top, const std::vector<Topology>& accessible) {
+    if (!has_top || accessible.empty()) return true;
+    for (const Topology& topology : accessible) {
+        bool all = true;
+        for (const auto& kv : topology.segments) {
+            auto it = top.find(kv.first);
+            if ((it == top.end() ? std::string() : it->second) != kv.second) { all = false; break; }   // (a missing map key reads as "")
+        }
+        if (all) return true;
+    }
+    return false;
+}
+
+void VolumeSet::add_or_update(const VolumePtr& v) {
+    auto it = volumes_.find(v->id);
+    if (it == volumes_.end()) {
+        Info info;
+        info.volume = v;
+        info.order = next_order_++;
+        volumes_.emplace(v->id, std::move(info));
+    } else {
+        it->second.volume = v;   // only the volume object: the tasks stay
+    }
+    std::vector<std::string>& set = by_group_[v->group];
+    if (std::find(set.begin(), set.end(), v->id) == set.end()) set.push_back(v->id);
+    by_name_[v->name] = v->id;
+}
+
+void VolumeSet::remove(const std::string& id) {
+    auto it = volumes_.find(id);
+    if (it == volumes_.end()) return;
+    std::vector<std::string>& set = by_group_[it->second.volume->group];
+    set.erase(std::remove(set.begin(), set.end(), id), set.end());
+    by_name_.erase(it->second.volume->name);
+    volumes_.erase(it);
+}
+
+bool VolumeSet::choose_task_volumes(const Task& task, const NodeInfo& node, std::vector<VolumeAttachment>* out, std::string* err) {
+    out->clear();
+    if (!task.has_container) return true;
+    bool ok = true;
+    for (const Mount& m : task.mounts) {
+        if (m.type != MountTypeCluster) continue;
+        const std::string candidate = is_available_on_node(m, node);
+        if (candidate.empty()) {
+            if (err) *err = "cannot find volume to satisfy mount with source " + m.source;
+            ok = false;
+            break;
+        }
+        reserve(candidate, task.id, node.node->id, m.read_only);   // (so that the task's next mount sees this one; released below)
+        out->push_back(VolumeAttachment{candidate, m.source, m.target});
+    }
+    for (const VolumeAttachment& va : *out) release(va.id, task.id);   // the deferred release: the caller reserves for good
+    if (!ok) out->clear();   // (the reference returns nil attachments with the error)
+    return ok;
+}
+
+void VolumeSet::reserve_task_volumes(const Task& task) {
+    for (const VolumeAttachment& va : task.volumes)
+        for (const Mount& m : task.mounts)
+            if (m.source == va.source && m.target == va.target) reserve(va.id, task.id, task.node_id, m.read_only);
+}
+
+void VolumeSet::reserve(const std::string& volume_id, const std::string& task_id, const std::string& node_id, bool read_only) {
+    auto it = volumes_.find(volume_id);
+    if (it == volumes_.end()) return;
+    it->second.tasks[task_id] = Usage{node_id, read_only};
+    it->second.nodes[node_id] += 1;
+}
+
+void VolumeSet::release(const std::string& volume_id, const std::string& task_id) {
+    auto it = volumes_.find(volume_id);
+    if (it == volumes_.end()) return;
+    auto ut = it->second.tasks.find(task_id);
+    if (ut == it->second.tasks.end()) return;
+    int& c = it->second.nodes[ut->second.node_id];
+    if (c > 0) c -= 1;
+    it->second.tasks.erase(ut);
+}
+
+std::string VolumeSet::is_available_on_node(const Mount& mount, const NodeInfo& node) const {
+    static const std::string prefix = "group:";
+    if (mount.source.compare(0, prefix.size(), prefix) == 0) {
+        auto g = by_group_.find(mount.source.substr(prefix.size()));
+        if (g == by_group_.end()) return "";
+        for (const std::string& id : g->second)
+            if (check_volume(id, node, mount.read_only)) return id;
+        return "";
+    }
+    auto n = by_name_.find(mount.source);
+    if (n == by_name_.end() || !check_volume(n->second, node, mount.read_only)) return "";
+    return n->second;
+}
+
+bool VolumeSet::check_volume(const std::string& id, const NodeInfo& node, bool read_only) const {
+    auto it = volumes_.find(id);
+    if (it == volumes_.end()) return false;   // (the reference would dereference a nil volume here; ids come from byGroup / byName, which only hold volumes of the set)
+    const Info& vi = it->second;
+    if (vi.volume->availability != VolumeAvailabilityActive) return false;
+    bool has_top = false;
+    const std::map<std::string, std::string>* top = nullptr;
+    static const std::map<std::string, std::string> none;
+    if (node.node->has_description)
+        for (const Node::CSIInfo& c : node.node->csi)
+            if (c.plugin_name == vi.volume->driver_name) {
+                has_top = c.has_topology;
+                top = &c.segments;
+                break;
+            }
+    if (vi.volume->scope == VolumeScopeSingleNode)
+        for (const auto& kv : vi.tasks)
+            if (kv.second.node_id != node.node->id) return false;
+    switch (vi.volume->sharing) {
+    case VolumeSharingNone:
+        if (!vi.tasks.empty()) return false;
+        break;
+    case VolumeSharingOneWriter:
+        if (!read_only)
+            for (const auto& kv : vi.tasks)
+                if (!kv.second.read_only) return false;
+        break;
+    case VolumeSharingReadOnly:
+        if (!read_only) return false;
+        break;
+    default: break;
+    }
+    return is_in_topology(has_top, top ? *top : none, vi.volume->accessible);
 }
 
 // ============================================================================
@@ -1177,6 +1316,7 @@ bool Scheduler::setup_task(const TaskPtr& t) {
         pending_preassigned_.put(t->id, t);
         return false;
     }
+    volumes_.reserve_task_volumes(*t);   // scheduler.go:115-116
     NodeInfo ni;
     if (node_info(t->node_id, &ni) && ni.add_task(t)) ns_update(ni);
     return false;
@@ -1226,6 +1366,7 @@ bool Scheduler::delete_task(const Task& t) {
     all_tasks_.erase(t.id);
     preassigned_.erase(t.id);
     pending_preassigned_.erase(t.id);
+    for (const VolumeAttachment& va : t.volumes) volumes_.release(va.id, t.id);   // scheduler.go:355-358
     NodeInfo ni;
     if (node_info(t.node_id, &ni) && ni.remove_task(t)) {
         ns_update(ni);
@@ -1234,6 +1375,11 @@ bool Scheduler::delete_task(const Task& t) {
     return false;
 }
 bool Scheduler::delete_task_event(const TaskPtr& t) { return delete_task(*t); }
+
+// EventUpdateVolume, scheduler.go:200-213 (and the volumes of the store at start, :70-81): only volumes the plugin has created
+void Scheduler::update_volume(const VolumePtr& v) {
+    if (v->has_volume_info && !v->volume_id.empty()) volumes_.add_or_update(v);
+}
 
 // createOrUpdateNode, scheduler.go:368-396
 void Scheduler::create_or_update_node(const NodePtr& n) {
@@ -1278,6 +1424,18 @@ TaskPtr Scheduler::task_fit_node(const TaskPtr& t, const std::string& node_id) {
         new_t->err = pipeline.explain();
         all_tasks_[t->id] = new_t;
         return new_t;
+    }
+    // scheduler.go:663-677: the attachments for the task on this node (chosen, NOT reserved: the reference reserves only in
+    // scheduleNTasksOnNodes and at start-up)
+    {
+        std::vector<VolumeAttachment> attachments;
+        std::string verr;
+        if (!volumes_.choose_task_volumes(*t, ni, &attachments, &verr)) {
+            new_t->err = verr;
+            all_tasks_[t->id] = new_t;
+            return new_t;
+        }
+        new_t->volumes = attachments;
     }
     new_t->state = TaskStateAssigned;
     new_t->message = "scheduler confirmed task can run on preassigned node";
@@ -1436,7 +1594,13 @@ int Scheduler::schedule_n_on_nodes(int n, OrderedTasks& group, std::vector<NodeI
 
         NodeInfo* node = &nodes[size_t(node_iter % node_count)];
         auto new_t = std::make_shared<Task>(*t);
+        {   // scheduler.go:857-874: choose the volumes on this node (an error is logged, the task is assigned without them), then reserve
+            std::vector<VolumeAttachment> attachments;
+            volumes_.choose_task_volumes(*t, *node, &attachments, nullptr);
+            new_t->volumes = attachments;
+        }
         new_t->node_id = node->node->id;
+        volumes_.reserve_task_volumes(*new_t);
         new_t->state = TaskStateAssigned;
         new_t->message = "scheduler assigned task to node";
         new_t->err.clear();

@@ -100,11 +100,30 @@ struct Node {              // the api.Node field subset the path reads (SURVEY.m
     bool engine_labels_nil = true;
     std::map<std::string, std::string> engine_labels;
     std::vector<Plugin> plugins;
+    // Description.CSIInfo (api/types.proto NodeCSIInfo): the node's topology per CSI plugin (volumes.go:272-278)
+    struct CSIInfo { std::string plugin_name; bool has_topology = false; std::map<std::string, std::string> segments; };
+    std::vector<CSIInfo> csi;
 };
+
+// ---- CSI volumes: api.Volume, the field subset volumes.go / topology.go read -----------------------------------------------
+enum { VolumeScopeSingleNode = 0, VolumeScopeMultiNode = 1 };
+enum { VolumeSharingNone = 0, VolumeSharingReadOnly = 1, VolumeSharingOneWriter = 2, VolumeSharingAll = 3 };
+enum { VolumeAvailabilityActive = 0, VolumeAvailabilityPause = 1, VolumeAvailabilityDrain = 2 };
+struct Topology { std::map<std::string, std::string> segments; };
+struct Volume {
+    std::string id, name, group, driver_name;   // ID, Spec.Annotations.Name, Spec.Group, Spec.Driver.Name
+    int scope = VolumeScopeSingleNode, sharing = VolumeSharingNone, availability = VolumeAvailabilityActive;
+    bool has_volume_info = false;
+    std::string volume_id;                       // VolumeInfo.VolumeID ("" = not created by the plugin yet: the scheduler ignores it)
+    std::vector<Topology> accessible;            // VolumeInfo.AccessibleTopology
+};
+using VolumePtr = std::shared_ptr<Volume>;
+struct VolumeAttachment { std::string id, source, target; };
 
 struct PortConfig { int protocol = 0; uint32_t published_port = 0; int publish_mode = 0; };
 struct Mount {
     int type = 0;
+    bool read_only = false;
     std::string source, target;
     bool has_driver_config = false;   // VolumeOptions != nil && DriverConfig != nil
     std::string driver_name;
@@ -137,6 +156,7 @@ struct Task {              // the api.Task field subset the path reads
     bool has_endpoint = false;
     std::vector<PortConfig> ports;
     GenericList assigned_generic;      // AssignedGenericResources
+    std::vector<VolumeAttachment> volumes;   // Volumes (written by the path: scheduler.go:677,872)
 };
 using TaskPtr = std::shared_ptr<Task>;
 using NodePtr = std::shared_ptr<Node>;
@@ -231,13 +251,47 @@ struct NodeInfo {
 };
 NodeInfo new_node_info(const NodePtr& n, const std::vector<TaskPtr>& tasks, const Resources& avail, int64_t now);
 
+// ---- topology.go / volumes.go ---------------------------------------------------------
+struct NodeInfo;
+bool is_in_topology(bool has_top, const std::map<std::string, std::string>& top, const std::vector<Topology>& accessible);   // topology.go:23-47
+// volumeSet (volumes.go:19-316). The reference walks a group's volumes in Go map order (volumes.go:250): canonical order here = the
+// order in which the volumes were first added.
+class VolumeSet {
+  public:
+    struct Usage { std::string node_id; bool read_only = false; };
+    struct Info {
+        VolumePtr volume;
+        std::map<std::string, Usage> tasks;        // task id -> usage
+        std::map<std::string, int> nodes;          // node id -> reference count
+        uint64_t order = 0;                        // creation ordinal (canonical group order)
+    };
+    void add_or_update(const VolumePtr& v);        // volumes.go:62-82
+    void remove(const std::string& id);            // volumes.go:85-95
+    // chooseTaskVolumes, volumes.go:101-140: false + *err = the reference's error string
+    bool choose_task_volumes(const Task& task, const NodeInfo& node, std::vector<VolumeAttachment>* out, std::string* err);
+    void reserve_task_volumes(const Task& task);   // volumes.go:144-154
+    void reserve(const std::string& volume_id, const std::string& task_id, const std::string& node_id, bool read_only);   // :156-167
+    void release(const std::string& volume_id, const std::string& task_id);                                              // :169-187
+    std::string is_available_on_node(const Mount& mount, const NodeInfo& node) const;                                     // :223-257
+    bool check_volume(const std::string& id, const NodeInfo& node, bool read_only) const;                                 // :261-316
+    const Info* info(const std::string& id) const { auto it = volumes_.find(id); return it == volumes_.end() ? nullptr : &it->second; }
+    size_t size() const { return volumes_.size(); }
+
+  private:
+    std::map<std::string, Info> volumes_;
+    std::map<std::string, std::vector<std::string>> by_group_;   // group -> volume ids in creation order
+    std::map<std::string, std::string> by_name_;
+    uint64_t next_order_ = 0;
+};
+
 // ---- filter.go / pipeline.go -----------------------------------------------------
-enum FilterId { F_READY = 0, F_RESOURCE, F_PLUGIN, F_CONSTRAINT, F_PLATFORM, F_HOSTPORT, F_MAXREPLICAS, F_COUNT };
+enum FilterId { F_READY = 0, F_RESOURCE, F_PLUGIN, F_CONSTRAINT, F_PLATFORM, F_HOSTPORT, F_MAXREPLICAS, F_VOLUMES, F_COUNT };
 
 struct Pipeline {
     struct Entry { bool enabled = false; int64_t failure_count = 0; };
     Entry checklist[F_COUNT];
     const Task* t = nullptr;
+    const VolumeSet* vs = nullptr;   // VolumesFilter.vs (filter.go:383): nil = the filter is never enabled (a pipeline built outside Run)
     std::vector<Constraint> constraints;
     uint64_t process_calls = 0;   // instrumentation (pair evaluations), not reference state
 
@@ -282,6 +336,11 @@ class Scheduler {
     bool setup_task(const TaskPtr& t);   // setupTasksList, scheduler.go:88-124: a task of the store at scheduler start
     bool update_task(const TaskPtr& t);
     bool delete_task_event(const TaskPtr& t);
+    void update_volume(const VolumePtr& v);   // EventUpdateVolume (scheduler.go:200-213) and setupTasksList's volumes (:70-81)
+    const VolumeSet& volumes() const { return volumes_; }
+    Scheduler() { pipeline.vs = &volumes_; }   // Run appends the VolumesFilter (scheduler.go:132)
+    Scheduler(const Scheduler&) = delete;
+    Scheduler& operator=(const Scheduler&) = delete;
     void set_service(const std::string& id, const ServiceRec& rec) { services_[id] = rec; }
     void delete_service(const std::string& id) { services_.erase(id); }
 
@@ -309,6 +368,7 @@ class Scheduler {
     std::unordered_map<std::string, size_t> slot_of_;
     std::set<size_t> free_slots_;                           // slots of removed nodes, lowest first
     std::map<std::string, ServiceRec> services_;
+    VolumeSet volumes_;
 
     // insertion-ordered id -> task maps (Go maps with canonical iteration order)
     struct OrderedTasks {

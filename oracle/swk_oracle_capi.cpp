@@ -102,8 +102,46 @@ NodePtr decode_node(const Value& v) {
             if (const Value* pl = e->obj_or_null("Plugins"))
                 for (auto& p : pl->arr) n->plugins.push_back(Plugin{p->str_or("Type", ""), p->str_or("Name", "")});
         }
+        if (const Value* cs = d->obj_or_null("CSIInfo"))
+            for (auto& c : cs->arr) {
+                Node::CSIInfo ci;
+                ci.plugin_name = c->str_or("PluginName", "");
+                if (const Value* top = c->obj_or_null("AccessibleTopology")) {
+                    ci.has_topology = true;
+                    bool nil;
+                    decode_labels(top->obj_or_null("Segments"), &nil, &ci.segments);
+                }
+                n->csi.push_back(ci);
+            }
     }
     return n;
+}
+
+VolumePtr decode_volume(const Value& v) {
+    auto vol = std::make_shared<Volume>();
+    vol->id = v.str_or("ID", "");
+    if (const Value* spec = v.obj_or_null("Spec")) {
+        if (const Value* ann = spec->obj_or_null("Annotations")) vol->name = ann->str_or("Name", "");
+        vol->group = spec->str_or("Group", "");
+        if (const Value* d = spec->obj_or_null("Driver")) vol->driver_name = d->str_or("Name", "");
+        if (const Value* am = spec->obj_or_null("AccessMode")) {
+            vol->scope = enum_of(am->get("Scope"), {{"SINGLE_NODE", 0}, {"MULTI_NODE", 1}}, 0);
+            vol->sharing = enum_of(am->get("Sharing"), {{"NONE", 0}, {"READ_ONLY", 1}, {"ONE_WRITER", 2}, {"ALL", 3}}, 0);
+        }
+        vol->availability = enum_of(spec->get("Availability"), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}, 0);
+    }
+    if (const Value* vi = v.obj_or_null("VolumeInfo")) {
+        vol->has_volume_info = true;
+        vol->volume_id = vi->str_or("VolumeID", "");
+        if (const Value* at = vi->obj_or_null("AccessibleTopology"))
+            for (auto& t : at->arr) {
+                Topology top;
+                bool nil;
+                decode_labels(t->obj_or_null("Segments"), &nil, &top.segments);
+                vol->accessible.push_back(top);
+            }
+    }
+    return vol;
 }
 
 TaskPtr decode_task(const Value& v) {
@@ -156,6 +194,7 @@ TaskPtr decode_task(const Value& v) {
                     mt.type = enum_of(m->get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, 0);
                     mt.source = m->str_or("Source", "");
                     mt.target = m->str_or("Target", "");
+                    if (const Value* ro = m->get("ReadOnly")) mt.read_only = ro->kind == Value::Bool ? ro->b : (ro->kind == Value::Int && ro->i != 0);
                     if (const Value* vo = m->obj_or_null("VolumeOptions"))
                         if (const Value* dc = vo->obj_or_null("DriverConfig")) {
                             mt.has_driver_config = true;
@@ -190,6 +229,8 @@ TaskPtr decode_task(const Value& v) {
     }
     bool nil;
     t->assigned_generic = decode_generic(v.obj_or_null("AssignedGenericResources"), &nil);
+    if (const Value* vols = v.obj_or_null("Volumes"))
+        for (auto& va : vols->arr) t->volumes.push_back(VolumeAttachment{va->str_or("ID", ""), va->str_or("Source", ""), va->str_or("Target", "")});
     return t;
 }
 
@@ -240,6 +281,18 @@ std::string encode_decisions(const std::vector<Decision>& ds) {
             o += "\"AssignedGenericResources\":";
             encode_generic(o, t.assigned_generic);
             o += ",";
+        }
+        if (!t.volumes.empty()) {   // decision.new.Volumes (scheduler.go:677,872)
+            o += "\"Volumes\":[";
+            for (size_t q = 0; q < t.volumes.size(); ++q) {
+                if (q) o += ",";
+                o += "{";
+                put_kv(o, "ID", t.volumes[q].id);
+                put_kv(o, "Source", t.volumes[q].source);
+                put_kv(o, "Target", t.volumes[q].target, false);
+                o += "}";
+            }
+            o += "],";
         }
         put_ki(o, "OldState", ds[i].old_task->state, false);
         o += "}";
@@ -371,6 +424,100 @@ int orc_delete_task(void* s, const char* task_json) {
     int rc = guarded([&] { r = static_cast<Scheduler*>(s)->delete_task_event(decode_task(*orcjson::parse(task_json))); });
     return rc ? rc : r;
 }
+int orc_update_volume(void* s, const char* volume_json) {
+    return guarded([&] { static_cast<Scheduler*>(s)->update_volume(decode_volume(*orcjson::parse(volume_json))); });
+}
+// the volumeSet's view of one volume: {"Tasks": {task: {"NodeID", "ReadOnly"}}, "Nodes": {node: refcount}} or null
+int orc_volume_info(void* s, const char* id) {
+    return guarded([&] {
+        const VolumeSet::Info* vi = static_cast<Scheduler*>(s)->volumes().info(id);
+        if (!vi) { g_out = "null"; return; }
+        std::string o = "{\"Tasks\":{";
+        bool first = true;
+        for (auto& kv : vi->tasks) {
+            if (!first) o += ",";
+            first = false;
+            orcjson::escape_into(o, kv.first);
+            o += ":{";
+            put_kv(o, "NodeID", kv.second.node_id);
+            o += std::string("\"ReadOnly\":") + (kv.second.read_only ? "true" : "false") + "}";
+        }
+        o += "},\"Nodes\":{";
+        first = true;
+        for (auto& kv : vi->nodes) {
+            if (!first) o += ",";
+            first = false;
+            orcjson::escape_into(o, kv.first);
+            o += ":" + std::to_string(kv.second);
+        }
+        o += "}}";
+        g_out = o;
+    });
+}
+// volumes.go in isolation: doc = {"Volumes": [api.Volume...], "Reserve": [[volume, task, node, readOnly]...], "Node": api.Node, then ONE of
+// "Check": {"ID", "ReadOnly"} -> true/false | "Mount": api.Mount -> the volume id or "" | "Task": api.Task -> {"Attachments": [...], "Err": ""}
+// | "Topology": {"Top": {Segments}|null, "Accessible": [{Segments}...]} -> true/false
+int orc_volumes(const char* doc_json) {
+    return guarded([&] {
+        auto doc = orcjson::parse(doc_json);
+        if (const Value* tp = doc->obj_or_null("Topology")) {
+            std::map<std::string, std::string> top;
+            bool has_top = false, nil;
+            if (const Value* t = tp->obj_or_null("Top")) {
+                has_top = true;
+                decode_labels(t->obj_or_null("Segments"), &nil, &top);
+            }
+            std::vector<Topology> acc;
+            if (const Value* a = tp->obj_or_null("Accessible"))
+                for (auto& t : a->arr) {
+                    Topology x;
+                    decode_labels(t->obj_or_null("Segments"), &nil, &x.segments);
+                    acc.push_back(x);
+                }
+            g_out = is_in_topology(has_top, top, acc) ? "true" : "false";
+            return;
+        }
+        VolumeSet vs;
+        if (const Value* vols = doc->obj_or_null("Volumes"))
+            for (auto& v : vols->arr) vs.add_or_update(decode_volume(*v));
+        if (const Value* rs = doc->obj_or_null("Reserve"))
+            for (auto& r : rs->arr) vs.reserve(r->arr[0]->s, r->arr[1]->s, r->arr[2]->s, r->arr[3]->kind == Value::Bool ? r->arr[3]->b : r->arr[3]->i != 0);
+        NodeInfo ni;
+        if (const Value* n = doc->obj_or_null("Node")) ni = new_node_info(decode_node(*n), {}, Resources{}, 0);
+        if (const Value* c = doc->obj_or_null("Check")) {
+            const Value* ro = c->get("ReadOnly");
+            g_out = vs.check_volume(c->str_or("ID", ""), ni, ro && ro->kind == Value::Bool && ro->b) ? "true" : "false";
+        } else if (const Value* m = doc->obj_or_null("Mount")) {
+            Mount mt;
+            mt.type = MountTypeCluster;
+            mt.source = m->str_or("Source", "");
+            const Value* ro = m->get("ReadOnly");
+            mt.read_only = ro && ro->kind == Value::Bool && ro->b;
+            g_out.clear();
+            orcjson::escape_into(g_out, vs.is_available_on_node(mt, ni));
+        } else if (const Value* t = doc->obj_or_null("Task")) {
+            TaskPtr task = decode_task(*t);
+            std::vector<VolumeAttachment> out;
+            std::string err;
+            vs.choose_task_volumes(*task, ni, &out, &err);
+            std::string o = "{\"Attachments\":[";
+            for (size_t q = 0; q < out.size(); ++q) {
+                if (q) o += ",";
+                o += "{";
+                put_kv(o, "ID", out[q].id);
+                put_kv(o, "Source", out[q].source);
+                put_kv(o, "Target", out[q].target, false);
+                o += "}";
+            }
+            o += "],";
+            put_kv(o, "Err", err, false);
+            o += "}";
+            g_out = o;
+        } else
+            throw std::runtime_error("orc_volumes: nothing asked");
+    });
+}
+
 int orc_set_service(void* s, const char* id, int has_spec_version, uint64_t spec_version) {
     return guarded([&] { static_cast<Scheduler*>(s)->set_service(id, ServiceRec{has_spec_version != 0, spec_version}); });
 }

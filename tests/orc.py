@@ -44,7 +44,7 @@ def lib():
         L.orc_get_now.argtypes = [ctypes.c_void_p]
         L.orc_get_now.restype = ctypes.c_int64
         for name in ("orc_create_or_update_node", "orc_delete_node", "orc_create_task", "orc_setup_task", "orc_update_task",
-                     "orc_delete_task", "orc_delete_service", "orc_node_info"):
+                     "orc_delete_task", "orc_delete_service", "orc_node_info", "orc_update_volume", "orc_volume_info"):
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         L.orc_set_service.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint64]
         L.orc_tick.argtypes = [ctypes.c_void_p]
@@ -62,6 +62,7 @@ def lib():
         L.orc_generic.argtypes = [ctypes.c_char_p]
         L.orc_nodeinfo_ops.argtypes = [ctypes.c_char_p]
         L.orc_tree.argtypes = [ctypes.c_char_p]
+        L.orc_volumes.argtypes = [ctypes.c_char_p]
         _lib = L
     return _lib
 
@@ -119,6 +120,14 @@ class Oracle:
 
     def set_service(self, service_id, spec_version=None):
         _check(self.L.orc_set_service(self.h, service_id.encode(), 0 if spec_version is None else 1, spec_version or 0))
+
+    def update_volume(self, volume):
+        """EventUpdateVolume (scheduler.go:200-213) / a volume of the store at start (:70-81): taken only once the plugin has created it."""
+        _check(self.L.orc_update_volume(self.h, _j(volume)))
+
+    def volume_info(self, volume_id):
+        _check(self.L.orc_volume_info(self.h, volume_id.encode()))
+        return json.loads(self.L.orc_result().decode())
 
     def delete_service(self, service_id):
         _check(self.L.orc_delete_service(self.h, service_id.encode()))
@@ -184,6 +193,18 @@ def enforce(node, tasks, services=None):
     """constraintenforcer.rejectNoncompliantTasks for one node: ids of the tasks that would be REJECTED.
     tasks: api.Task docs in store order (canonical: ascending ID); services: {ServiceID: api.Service doc}."""
     _check(lib().orc_enforce(_j({"Node": node, "Tasks": list(tasks), "Services": services or {}})))
+    return json.loads(lib().orc_result().decode())
+
+
+def volumes(volumes=(), reserve=(), node=None, check=None, mount=None, task=None, topology=None):
+    """volumes.go / topology.go in isolation (a fresh volumeSet per call): checkVolume, isVolumeAvailableOnNode, chooseTaskVolumes, IsInTopology."""
+    doc = {"Volumes": list(volumes), "Reserve": [list(r) for r in reserve]}
+    if node is not None:
+        doc["Node"] = node
+    for k, v in (("Check", check), ("Mount", mount), ("Task", task), ("Topology", topology)):
+        if v is not None:
+            doc[k] = v
+    _check(lib().orc_volumes(_j(doc)))
     return json.loads(lib().orc_result().decode())
 
 

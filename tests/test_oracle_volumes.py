@@ -1,0 +1,125 @@
+"""CPU: the oracle's restatement of volumes.go / topology.go / VolumesFilter against the reference's own test vectors (tests/kat_volumes.py),
+and the scheduler-level scenarios of scheduler_ginkgo_test.go through the oracle."""
+import pytest
+
+import kat_volumes as kv
+import orc
+import scenarios as sc
+
+
+@pytest.mark.parametrize("top,accessible,want", kv.TOPOLOGY)
+def test_is_in_topology(top, accessible, want):
+    assert orc.volumes(topology={"Top": top, "Accessible": accessible}) is want
+
+
+@pytest.mark.parametrize("name,mode,in_use,in_top,ro,want", kv.CHECK_VOLUME, ids=[c[0] for c in kv.CHECK_VOLUME])
+def test_check_volume_table(name, mode, in_use, in_top, ro, want):
+    v, n, reserve = kv.check_volume_case(mode, in_use, in_top)
+    assert orc.volumes([v], reserve, n, check={"ID": v["ID"], "ReadOnly": ro}) is want
+
+
+def test_volume_or_group_availability_on_a_node():
+    node, vols = kv.group_fixture()
+    assert orc.volumes(vols, node=node, mount={"Source": "volumeName1"}) == "volume1"
+    assert orc.volumes(vols, node=node, mount={"Source": "volumeNameNotReal"}) == ""
+    assert orc.volumes(vols, node=node, mount={"Source": "group:someVolumeGroup"}) in ("volume3", "volume4")
+    assert orc.volumes(vols, node=node, mount={"Source": "group:someVolumeGroup"}) == "volume3"   # canonical order: the first one added
+    assert orc.volumes(vols, node=node, mount={"Source": "group:noSuchGroup"}) == ""
+    # the first of the group in use on another node (single-node scope): the second one
+    assert orc.volumes(vols, [("volume3", "t", "elsewhere", False)], node, mount={"Source": "group:someVolumeGroup"}) == "volume4"
+
+
+def test_choose_task_volumes():
+    """volumes_test.go:468-531: a group mount, two named mounts and a bind mount between them; a node without CSI info."""
+    v1, v2, v3 = kv.canned_volume(1, "volumeGroup"), kv.canned_volume(2), kv.canned_volume(3)
+    mounts = [kv.cluster_mount("group:volumeGroup", "/somedir", True), kv.cluster_mount("volume2", "/someOtherDir"),
+              {"Type": "BIND", "Source": "/some/subdir", "Target": "/some/container/dir"}, kv.cluster_mount("volume3", "/some/third/dir")]
+    task = {"ID": "taskID1", "Spec": {"Container": {"Mounts": mounts}}}
+    node = {"ID": "node1", "Description": {}}
+    got = orc.volumes([v1, v2, v3], node=node, task=task)
+    assert got["Err"] == ""
+    assert got["Attachments"] == [{"ID": "volumeID1", "Source": "group:volumeGroup", "Target": "/somedir"},
+                                  {"ID": "volumeID2", "Source": "volume2", "Target": "/someOtherDir"},
+                                  {"ID": "volumeID3", "Source": "volume3", "Target": "/some/third/dir"}]
+    # a mount nothing satisfies: the reference's error string, no attachments (volumes.go:122-127)
+    task2 = {"ID": "t2", "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume2", "/a"), kv.cluster_mount("nothing", "/b")]}}}
+    got = orc.volumes([v1, v2, v3], node=node, task=task2)
+    assert got == {"Attachments": [], "Err": "cannot find volume to satisfy mount with source nothing"}
+    # two mounts of one task on a volume that cannot be shared: the second finds the first one's reservation (volumes.go:128)
+    solo = dict(kv.canned_volume(7), Spec=dict(kv.canned_volume(7)["Spec"], AccessMode={"Scope": kv.SINGLE, "Sharing": kv.NONE}))
+    task3 = {"ID": "t3", "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume7", "/a"), kv.cluster_mount("volume7", "/b")]}}}
+    assert orc.volumes([solo], node=node, task=task3)["Err"] == "cannot find volume to satisfy mount with source volume7"
+
+
+def _csi_node(i):
+    return {"ID": "nodeID%d" % i, "Spec": {"Annotations": {"Name": "node%d" % i}}, "Status": {"State": orc.READY},
+            "Description": {"Hostname": "nodeHost%d" % i, "CSIInfo": [{"PluginName": "somePlug", "NodeID": "nodeCSI%d" % i}]}}
+
+
+def _vol(i, group, scope, sharing):
+    return {"ID": "volumeID%d" % i, "Spec": {"Annotations": {"Name": "volume%d" % i}, "Group": group, "Driver": {"Name": "somePlug"},
+                                             "AccessMode": {"Scope": scope, "Sharing": sharing}}, "VolumeInfo": {"VolumeID": "csi%d" % i}}
+
+
+def test_scheduler_initialization_tracks_the_volumes_in_use():
+    """scheduler_ginkgo_test.go:376-596: a running task reserves its attachments, a shut-down one and a pending preassigned one do not."""
+    o = orc.Oracle()
+    for i in range(3):
+        o.create_node(_csi_node(i))
+    for v in (_vol(1, "group1", kv.MULTI, kv.ALL), _vol(2, "group2", kv.SINGLE, kv.NONE), _vol(3, "group2", kv.SINGLE, kv.NONE)):
+        o.update_volume(v)
+    running = {"ID": "runningTask", "NodeID": "nodeID0", "Status": {"State": orc.RUNNING}, "DesiredState": orc.RUNNING,
+               "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume1", "/var/"), kv.cluster_mount("group:group2", "/home/")]}},
+               "Volumes": [{"Source": "volume1", "Target": "/var/", "ID": "volumeID1"}, {"Source": "group:group2", "Target": "/home/", "ID": "volumeID3"}]}
+    shutdown = {"ID": "shutdownTask", "NodeID": "nodeID1", "Status": {"State": orc.SHUTDOWN}, "DesiredState": orc.SHUTDOWN,
+                "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume1", "/foo/")]}}, "Volumes": [{"Source": "volume1", "Target": "/foo/", "ID": "volumeID1"}]}
+    pending = {"ID": "pendingID", "NodeID": "nodeID2", "Status": {"State": orc.PENDING}, "DesiredState": orc.RUNNING,
+               "Spec": {"Container": {"Mounts": [kv.cluster_mount("group:group2", "/foo/")]}}}
+    for t in (running, shutdown, pending):
+        o.setup_task(t)
+    assert o.volume_info("volumeID1")["Tasks"] == {"runningTask": {"NodeID": "nodeID0", "ReadOnly": False}}
+    assert o.volume_info("volumeID2")["Tasks"] == {}
+    assert o.volume_info("volumeID3")["Tasks"] == {"runningTask": {"NodeID": "nodeID0", "ReadOnly": False}}
+    # the pending preassigned task: volumeID3 is taken (sharing none), volumeID2 is free -> it fits its node with volumeID2
+    d = o.process_preassigned()
+    assert [(x["ID"], x["NodeID"], x["State"], x.get("Volumes")) for x in d] == [("pendingID", "nodeID2", orc.ASSIGNED, [{"ID": "volumeID2", "Source": "group:group2", "Target": "/foo/"}])]
+    assert o.volume_info("volumeID2")["Tasks"] == {}   # taskFitNode chooses, it does not reserve (scheduler.go:663-677)
+    # deleting the running task releases what it held (scheduler.go:355-358)
+    o.delete_task(running)
+    assert o.volume_info("volumeID3") == {"Tasks": {}, "Nodes": {"nodeID0": 0}}
+
+
+def test_a_task_with_a_cluster_mount_through_the_tick():
+    """scheduler_ginkgo_test.go:80-372: without the volume the task stays pending with the VolumesFilter's explanation; a volume that exists
+    only as a spec (no VolumeInfo yet) does not count; once created, the task is assigned with its attachment and the volume is reserved."""
+    o = orc.Oracle()
+    o.create_node({"ID": "nodeID1", "Status": {"State": orc.READY}, "Description": {"CSIInfo": [{"PluginName": "somePlug", "NodeID": "nodeCSI1"}]}})
+    o.set_service("service1")
+    task = sc.pending("task1", "service1", Spec={"Container": {"Mounts": [kv.cluster_mount("volume1", "/var/")]}})
+    o.create_task(task)
+    d = o.tick()
+    assert [(x["ID"], x["NodeID"], x["Err"]) for x in d] == [("task1", "", "no suitable node (cannot fulfill requested CSI volume mounts on 1 node)")]
+    vol = {"ID": "volumeID1", "Spec": {"Annotations": {"Name": "volume1"}, "Driver": {"Name": "somePlug"}, "AccessMode": {"Scope": kv.SINGLE, "Sharing": kv.NONE}}}
+    o.update_volume(vol)   # not created by the plugin yet: ignored (scheduler.go:207)
+    assert o.volume_info("volumeID1") is None
+    assert o.tick()[0]["NodeID"] == ""
+    o.update_volume(dict(vol, VolumeInfo={"VolumeID": "csi1"}))
+    d = o.tick()
+    assert [(x["ID"], x["NodeID"], x["State"], x["Volumes"]) for x in d] == [("task1", "nodeID1", orc.ASSIGNED, [{"ID": "volumeID1", "Source": "volume1", "Target": "/var/"}])]
+    assert o.volume_info("volumeID1") == {"Tasks": {"task1": {"NodeID": "nodeID1", "ReadOnly": False}}, "Nodes": {"nodeID1": 1}}
+    # a second task of the service: the volume cannot be shared
+    o.create_task(sc.pending("task2", "service1", Spec={"Container": {"Mounts": [kv.cluster_mount("volume1", "/var/")]}}))
+    assert o.tick()[0]["Err"] == "no suitable node (cannot fulfill requested CSI volume mounts on 1 node)"
+
+
+def test_any_requested_mount_passes_the_filter_but_every_mount_needs_a_volume():
+    """filter.go:424-432 passes a node when ANY cluster mount is satisfiable; chooseTaskVolumes then fails for
+    the other mount — the reference logs the error and assigns the task WITHOUT attachments (scheduler.go:862-872)."""
+    o = orc.Oracle()
+    o.create_node({"ID": "n1", "Status": {"State": orc.READY}, "Description": {}})
+    o.set_service("svc")
+    o.update_volume(kv.canned_volume(1))
+    o.create_task(sc.pending("t1", "svc", Spec={"Container": {"Mounts": [kv.cluster_mount("volume1", "/a"), kv.cluster_mount("missing", "/b")]}}))
+    d = o.tick()
+    assert [(x["ID"], x["NodeID"], x["State"], x.get("Volumes")) for x in d] == [("t1", "n1", orc.ASSIGNED, None)]
+    assert o.volume_info("volumeID1")["Tasks"] == {}
