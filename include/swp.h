@@ -70,7 +70,11 @@ enum {
     SWP_SPACE_PLUGIN = 6,    /* "<Type>\0<Name>" (filter.go:179-202) */
     SWP_SPACE_RAW = 7,       /* label values as written, case-sensitive: decision-tree branches (nodeset.go:84-101) */
     SWP_SPACE_GENERIC_KIND = 8, /* GenericResource kinds, case-sensitive (api/genericresource/helpers.go Kind()) */
-    SWP_SPACE_COUNT = 9
+    SWP_SPACE_VOLUME = 9,    /* api.Volume.ID -> dense volume index; ascending index = the order a group's volumes are tried in
+                              * (volumes.go:250 ranges over a Go map: any order is legal, this one is the oracle's) */
+    SWP_SPACE_VOLUME_GROUP = 10, /* VolumeSpec.Group */
+    SWP_SPACE_CSI = 11,      /* CSI plugin names, topology subdomains and segments: compared as written (volumes.go:273, topology.go:35) */
+    SWP_SPACE_COUNT = 12
 };
 /* id 0 is reserved for the empty string in every space except NODE_ID (node index 0 is a node). */
 int swp_intern(swp_engine*, int space, const char* utf8, size_t len, uint32_t* id_out);
@@ -167,6 +171,57 @@ int swp_node_set_generic(swp_engine*, uint32_t node, const swp_generic* counts, 
 int swp_node_get_generic(swp_engine*, uint32_t node, uint32_t kind, int64_t* count_out);
 
 /* ------------------------------------------------------------------------------------------ */
+/* CSI volumes: VolumesFilter (filter.go:382-441), volumeSet (volumes.go), IsInTopology (topology.go:23-47).
+ * The engine holds, per volume, what checkVolume reads: availability, access mode, the accessible topologies, and how it is in use —
+ * the number of tasks holding it, how many of them write, and the node they sit on. The caller keeps the maps behind those numbers
+ * (task -> usage, volumes.go:31-46) and sets them with swp_volume_set_usage whenever they change outside a batch; inside a batch the
+ * engine reserves for the tasks it places (scheduler.go:857-874) and swp_batch_fetch leaves the numbers as the batch made them. */
+typedef struct { uint32_t key; uint32_t value; } swp_seg;          /* one (subdomain, segment) pair: SWP_SPACE_CSI ids */
+typedef struct {
+    uint32_t plugin;        /* NodeCSIInfo.PluginName: SWP_SPACE_CSI id */
+    uint32_t has_topology;  /* AccessibleTopology != nil */
+    uint32_t seg_off, n_seg;/* its segments in the array passed along */
+} swp_csi;
+/* Description.CSIInfo of a node (replaces what was set; n == 0: none). checkVolume takes the FIRST entry of the volume's driver. */
+int swp_node_set_csi(swp_engine*, uint32_t node, const swp_csi* infos, uint32_t n, const swp_seg* segs, uint32_t n_segs);
+enum { SWP_VOL_SCOPE_SINGLE_NODE = 0, SWP_VOL_SCOPE_MULTI_NODE = 1 };
+enum { SWP_VOL_SHARING_NONE = 0, SWP_VOL_SHARING_READ_ONLY = 1, SWP_VOL_SHARING_ONE_WRITER = 2, SWP_VOL_SHARING_ALL = 3 };
+typedef struct {
+    uint32_t group;         /* SWP_SPACE_VOLUME_GROUP id of Spec.Group ("" is a group like any other) */
+    uint32_t driver;        /* Spec.Driver.Name: SWP_SPACE_CSI id */
+    uint32_t scope, sharing;/* Spec.AccessMode */
+    uint32_t active;        /* Spec.Availability == ACTIVE (volumes.go:265) */
+    uint32_t n_topologies;  /* VolumeInfo.AccessibleTopology: topology t = segs[topo_off[t] .. topo_off[t + 1]) */
+} swp_volume;
+/* addOrUpdateVolume (volumes.go:62-82): `volume` is the SWP_SPACE_VOLUME index. An update keeps the usage. */
+int swp_volume_upsert(swp_engine*, uint32_t volume, const swp_volume* v, const uint32_t* topo_off, const swp_seg* segs);
+#define SWP_PIN_NONE 0xFFFFFFFFu   /* nobody uses the volume */
+#define SWP_PIN_MANY 0xFFFFFFFEu   /* its users sit on more than one node */
+typedef struct {
+    uint32_t n_tasks;       /* len(volumeInfo.tasks) */
+    uint32_t n_writers;     /* ... of them with readOnly == false (hasWriter, volumes.go:320-327) */
+    uint32_t pin;           /* the node index all usages share, SWP_PIN_NONE, SWP_PIN_MANY (volumes.go:284-292) */
+    uint32_t reserved;
+} swp_volume_usage;
+int swp_volume_set_usage(swp_engine*, uint32_t volume, const swp_volume_usage* u);
+int swp_volume_get_usage(swp_engine*, uint32_t volume, swp_volume_usage* out);
+#define SWP_NO_VOLUME 0xFFFFFFFFu
+#define SWP_MAX_MOUNTS 8
+typedef struct {
+    uint32_t is_group;          /* Source starts with "group:" (volumes.go:229) */
+    uint32_t ref;               /* the SWP_SPACE_VOLUME_GROUP id of the rest, or the SWP_SPACE_VOLUME index byName[Source] gives; SWP_NO_VOLUME: neither exists */
+    uint32_t read_only;         /* Mount.ReadOnly: what checkVolume is asked with */
+    uint32_t reserve_read_only; /* ReadOnly of the LAST mount of the task with this mount's (Source, Target): what reserveTaskVolumes records (volumes.go:144-154) */
+} swp_mount;
+/* VolumesFilter.SetTask (filter.go:392-422): the task's MountTypeCluster mounts in spec order, at most SWP_MAX_MOUNTS (SWP_ERANGE). The set id
+ * goes into bits 8-31 of swp_task_desc.flags (SWP_TASK_MOUNTS); 0 = the filter is disabled. */
+int swp_mount_set(swp_engine*, const swp_mount* mounts, uint32_t n, uint32_t* id_out);
+/* isVolumeAvailableOnNode for every mount of the set on one node, in order, each seeing the ones before it (chooseTaskVolumes,
+ * volumes.go:101-140): out[i] = the volume index for mount i. Returns SWP_OK with *n_out = the set's size, or *n_out = 0 when a mount
+ * finds no volume (the reference's "cannot find volume to satisfy mount"; *failed_mount = its position). Reserves nothing. */
+int swp_choose_volumes(swp_engine*, uint32_t mount_set, uint32_t node, uint32_t* out /* [SWP_MAX_MOUNTS] */, uint32_t* n_out, uint32_t* failed_mount);
+
+/* ------------------------------------------------------------------------------------------ */
 /* task-side predicate sets (what Filter.SetTask extracts from a task, filter.go)               */
 enum {   /* constraint kinds, constraint.go:109-203 */
     SWP_CK_NODE_ID = 0, SWP_CK_HOSTNAME = 1, SWP_CK_IP = 2, SWP_CK_ROLE = 3,
@@ -212,6 +267,8 @@ typedef struct { uint32_t kind; uint32_t key; } swp_spread;
 int swp_spread_set(swp_engine*, const swp_spread* levels, uint32_t n, uint32_t* id_out);
 
 #define SWP_TASK_RES_ENABLED 0x1u   /* ResourceFilter.SetTask returned true (filter.go:61-74) */
+#define SWP_TASK_MOUNTS_SHIFT 8     /* flags >> 8 = the task's mount set (swp_mount_set), 0 = no MountTypeCluster mounts */
+#define SWP_TASK_MOUNTS(set) ((uint32_t)(set) << SWP_TASK_MOUNTS_SHIFT)
 
 typedef struct {
     uint32_t service;        /* SERVICE id */
@@ -267,6 +324,11 @@ int swp_batch_fetch(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fa
 /* copy the device results of the last run back WITHOUT folding them into the host mirror (replay
  * benchmarking: run → results → swp_state_restore → run …) */
 int swp_batch_results(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fail_hist);
+/* The volumes the batch chose for the cluster mounts of `n` of its tasks (chooseTaskVolumes on the node each was placed on,
+ * scheduler.go:857-872): out[i * SWP_MAX_MOUNTS + m] = the SWP_SPACE_VOLUME index for mount m of task tasks[i], SWP_NO_VOLUME for
+ * every mount of a task that was not placed, has no mounts, or for which a mount found no volume (the reference assigns such a task
+ * without attachments). After swp_batch_fetch / swp_batch_results. */
+int swp_batch_attachments(swp_engine*, swp_batch*, const uint32_t* tasks, uint32_t n, uint32_t* out);
 void swp_batch_free(swp_engine*, swp_batch*);
 /* Device-side snapshot / restore of all mutable node state (cpu, mem, total, per-service counts,
  * host ports) so that a benchmark can replay the same batch from the same state. */

@@ -40,6 +40,14 @@ int swp_sched_delete_node(swp_sched*, const char* node_id, size_t len);
  * Tasks, RecentFailures}; SWP_ENOTFOUND <-> errNodeNotFound */
 int swp_sched_node_info(swp_sched*, const char* node_id, size_t len, const char** json_out);
 
+/* EventUpdateVolume (scheduler.go:200-213) and the volumes of the store at start (:70-81). volume_json = api.Volume {ID, Spec {Annotations
+ * {Name}, Group, Driver {Name}, AccessMode {Scope, Sharing}, Availability}, VolumeInfo {VolumeID, AccessibleTopology [{Segments}]}};
+ * a volume the plugin has not created yet (no VolumeInfo.VolumeID) is ignored, as in the reference. There is no removal event. */
+int swp_sched_update_volume(swp_sched*, const char* volume_json, size_t len);
+/* the volumeSet's view of one volume as JSON {Tasks {task: {NodeID, ReadOnly}}, Nodes {node: reference count}, Engine {Tasks, Writers}};
+ * SWP_ENOTFOUND: the set does not hold it */
+int swp_sched_volume_info(swp_sched*, const char* volume_id, size_t len, const char** json_out);
+
 /* What noSuitableNode reads from the store about a service (scheduler.go:934-953): does it exist, and its
  * SpecVersion (has_version = 0: nil). */
 int swp_sched_set_service(swp_sched*, const char* service_id, size_t len, int has_version, uint64_t version);

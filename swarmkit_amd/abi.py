@@ -104,6 +104,7 @@ class Generic(C.Structure):
 
 EXPORTS = [
     "swp_generic_set", "swp_node_set_generic", "swp_node_get_generic",
+    "swp_node_set_csi", "swp_volume_upsert", "swp_volume_set_usage", "swp_volume_get_usage", "swp_mount_set", "swp_choose_volumes", "swp_batch_attachments",
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
@@ -113,7 +114,7 @@ EXPORTS = [
     # include/swp_sched.h — the host layer above the engine
     "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
     "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
-    "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_reject_decision", "swp_sched_commit_plan", "swp_sched_reject_decisions", "swp_sched_reject_node", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce",
+    "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_reject_decision", "swp_sched_commit_plan", "swp_sched_reject_decisions", "swp_sched_reject_node", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce", "swp_sched_update_volume", "swp_sched_volume_info",
     "swp_constraint_parse", "swp_key_equal_fold", "swp_explain", "swp_parse_ip",
 ]
 

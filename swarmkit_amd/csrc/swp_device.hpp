@@ -236,6 +236,9 @@ struct ExplainArgs {
     const u32* gs_row;
     const u32* rg_kind;
     const int32_t* rg_val;
+    // tasks with cluster mounts (nullptr: none): the VolumesFilter row of the task's deciding round — the volumes as they stood at its moment
+    const u32* csi_of;
+    const u64* vrows;
 };
 
 // One thread per node: the node's chain of commits (arbitrary order) → a contiguous segment sorted by commit index
@@ -417,7 +420,11 @@ __global__ __launch_bounds__(256) void k_explain(ExplainArgs a) {
                 }
             }
         }
-        for (int f = 0; f < 7; ++f) {
+        if (present && ff < 0 && a.csi_of) {   // VolumesFilter, the pipeline's last entry (scheduler.go:132)
+            const u32 ck = cload(a.csi_of + gj);
+            if (ck != 0xFFFFFFFFu && !(a.vrows[(size_t)ck * a.n_words + w] & bit)) ff = 7;
+        }
+        for (int f = 0; f < 8; ++f) {
             u64 bm = ballot64(ff == f);
             if (bm && (threadIdx.x & 63) == 0) atomicAdd(&cnt[e - e0][f], (u32)__popcll(bm));
         }

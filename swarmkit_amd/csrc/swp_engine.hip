@@ -248,6 +248,16 @@ struct HostNode {
     std::map<std::pair<uint32_t, uint64_t>, uint32_t> fails;      // (service, specVersion) -> recent failures
     std::set<uint64_t> ports;                                     // protocol<<32 | port
     std::vector<std::pair<uint32_t, int64_t>> gen;                // (GENERIC_KIND id, count) of AvailableResources.Generic, counts >= 1, by kind
+    struct Csi { uint32_t plugin, has_topology; std::vector<swp_seg> segs; };
+    std::vector<Csi> csi;                                         // Description.CSIInfo (swp_node_set_csi)
+};
+
+struct HostVolume {   // swp_volume_upsert / swp_volume_set_usage
+    bool present = false;
+    swp_volume spec{};
+    std::vector<uint32_t> topo_off{0};
+    std::vector<swp_seg> segs;
+    swp_volume_usage use{0, 0, SWP_PIN_NONE, 0};
 };
 
 inline uint64_t port_key(uint32_t proto, uint32_t port) { return ((uint64_t)proto << 32) | port; }
@@ -295,6 +305,10 @@ struct swp_batch {
     DevBuf d_tg, d_gs_off, d_gs_row, d_rg_kind, d_rg_k0, d_rg_k1, d_rg_val, d_rg;
     std::vector<uint32_t> tmpl;   // [T] the first task with this task's descriptor (identical tasks: swp_resolve6.hpp R6Args.tmpl)
     DevBuf d_tmpl;
+    // tasks with cluster mounts (swp_volumes.hpp): csi_of[task] = its index among them (0xFFFFFFFF: none), csi_set[that] = its mount set
+    std::vector<uint32_t> csi_of, csi_set, csi_task;
+    DevBuf d_csi_of, d_csi_set, d_vrows, d_att;
+    std::vector<uint32_t> h_att;   // [csi tasks][SWP_MAX_MOUNTS] after fetch / results
 
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_hmat, d_emat;   // the scan resolver's (service, node) matrices, allocated when a stretch first goes to it
@@ -351,7 +365,17 @@ struct swp_engine {
     std::vector<std::vector<swp_port>> port_sets{1};
     std::vector<std::vector<swp_spread>> spread_sets{1};
     std::vector<std::vector<swp_generic>> gen_sets{1};
-    std::map<std::string, uint32_t> con_index, plat_index, plug_index, port_index, spread_index, gen_index;
+    std::vector<std::vector<swp_mount>> mount_sets{1};
+    std::map<std::string, uint32_t> con_index, plat_index, plug_index, port_index, spread_index, gen_index, mount_index;
+
+    // CSI volumes (swp_volumes.hpp): host mirror and its device tables
+    std::vector<HostVolume> volumes;          // by SWP_SPACE_VOLUME index
+    bool vol_static_dirty = true;             // a volume's spec, a node's CSI info or the node set changed: tables + topology bitmaps again
+    bool vol_dyn_dirty = true;                // usage numbers changed on the host
+    uint32_t dev_vol_words = 0;
+    DevBuf d_vflags, d_vdyn, d_vT, d_grp_off, d_grp_vol, d_ms_off, d_ms_mount;
+    DevBuf d_ncsi_off, d_ncsi, d_ncsi_seg, d_vdriver, d_vtopo_off, d_topo_off, d_vseg;
+    bool has_volumes() const { return volumes.size() > 0 || mount_sets.size() > 1; }
 
     // label columns of attr[][]: 0 id, 1 hostname, 2 os, 3 arch, 4.. labels
     std::map<uint32_t, uint32_t> node_label_col, engine_label_col;
@@ -433,7 +457,9 @@ uint32_t label_value(const std::vector<swp_kv>& kv, uint32_t key) {
 
 // Push the host mirror of the node rows to the device (bulk; node counts are ≤ ~1e5 and a tick
 // is preceded by few mutations, so whole-array uploads of the dirty group are the simple choice).
+int flush_volumes(swp_engine* e);
 int flush_nodes(swp_engine* e) {
+    if (e->dev_static_dirty) e->vol_static_dirty = true;   // the node set or a node's CSI info may have changed: the topology bitmaps follow
     uint32_t N = e->n_nodes;
     uint32_t need_cap = std::max<uint32_t>(64, ((N + 63) / 64) * 64);
     if (e->dev_gkinds != (uint32_t)e->spaces[SWP_SPACE_GENERIC_KIND].strs.size()) e->dev_dynamic_dirty = true;   // a new kind: a new row
@@ -506,6 +532,113 @@ int flush_nodes(swp_engine* e) {
         e->dev_gkinds = K;
         HIPCHECK(e, hipStreamSynchronize(e->stream));
         e->dev_dynamic_dirty = false;
+    }
+    return flush_volumes(e);
+}
+
+// The volume tables on the device (swp_volumes.hpp): flags, groups, mount sets, the node CSI table and the volumes' topologies — and from
+// the last two the topology bitmaps (k_vol_topology) — whenever a volume's spec, a node or a mount set changed; the usage numbers whenever
+// the host changed them.
+VolView vol_view(swp_engine* e) {
+    VolView v{};
+    if (!e->has_volumes()) return v;
+    v.n_vol = (u32)e->volumes.size();
+    v.n_words = e->dev_vol_words;
+    v.vflags = e->d_vflags.as<u32>();
+    v.vdyn = e->d_vdyn.as<VolDyn>();
+    v.T = e->d_vT.as<u64>();
+    v.grp_off = e->d_grp_off.as<u32>();
+    v.grp_vol = e->d_grp_vol.as<u32>();
+    v.ms_off = e->d_ms_off.as<u32>();
+    v.ms_mount = e->d_ms_mount.as<VolMount>();
+    return v;
+}
+int flush_volumes(swp_engine* e) {
+    if (!e->has_volumes()) return SWP_OK;
+    const uint32_t N = e->n_nodes, Wn = n_words_of(N), V = (uint32_t)e->volumes.size();
+    int rc;
+    if (e->vol_static_dirty || e->dev_vol_words != Wn) {
+        std::vector<uint32_t> vflags(V, 0), vdriver(V, 0), vtopo_off(V + 1, 0), topo_off(1, 0), vseg;
+        const uint32_t G = (uint32_t)e->spaces[SWP_SPACE_VOLUME_GROUP].strs.size();
+        std::vector<std::vector<uint32_t>> members(G);
+        for (uint32_t v = 0; v < V; ++v) {
+            const HostVolume& hv = e->volumes[v];
+            vtopo_off[v] = (uint32_t)topo_off.size() - 1;
+            if (!hv.present) continue;
+            vflags[v] = (hv.spec.active ? VOL_ACTIVE : 0u) | (hv.spec.scope == SWP_VOL_SCOPE_MULTI_NODE ? VOL_MULTI : 0u) | ((hv.spec.sharing & 3u) << VOL_SHARING_SHIFT);
+            vdriver[v] = hv.spec.driver;
+            if (hv.spec.group < G) members[hv.spec.group].push_back(v);
+            for (uint32_t t = 0; t < hv.spec.n_topologies; ++t) {
+                for (uint32_t q = hv.topo_off[t]; q < hv.topo_off[t + 1]; ++q) { vseg.push_back(hv.segs[q].key); vseg.push_back(hv.segs[q].value); }
+                topo_off.push_back((uint32_t)vseg.size() / 2);
+            }
+        }
+        vtopo_off[V] = (uint32_t)topo_off.size() - 1;
+        std::vector<uint32_t> grp_off(G + 1, 0), grp_vol;
+        for (uint32_t g = 0; g < G; ++g) {
+            grp_off[g] = (uint32_t)grp_vol.size();
+            grp_vol.insert(grp_vol.end(), members[g].begin(), members[g].end());   // ascending volume index = creation order
+        }
+        grp_off[G] = (uint32_t)grp_vol.size();
+        std::vector<uint32_t> ms_off(e->mount_sets.size() + 1, 0);
+        std::vector<swp_mount> ms;
+        for (size_t q = 0; q < e->mount_sets.size(); ++q) {
+            ms_off[q] = (uint32_t)ms.size();
+            ms.insert(ms.end(), e->mount_sets[q].begin(), e->mount_sets[q].end());
+        }
+        ms_off[e->mount_sets.size()] = (uint32_t)ms.size();
+        std::vector<uint32_t> ncsi_off(N + 1, 0), ncsi, nseg;
+        for (uint32_t n = 0; n < N; ++n) {
+            ncsi_off[n] = (uint32_t)ncsi.size() / 4;
+            const HostNode& h = e->nodes[n];
+            if (!h.present) continue;
+            for (const HostNode::Csi& c : h.csi) {
+                ncsi.push_back(c.plugin);
+                ncsi.push_back(c.has_topology);
+                ncsi.push_back((uint32_t)nseg.size() / 2);
+                ncsi.push_back((uint32_t)c.segs.size());
+                for (const swp_seg& sg : c.segs) { nseg.push_back(sg.key); nseg.push_back(sg.value); }
+            }
+        }
+        ncsi_off[N] = (uint32_t)ncsi.size() / 4;
+        if ((rc = upload(e, e->d_vflags, vflags))) return rc;
+        if ((rc = upload(e, e->d_vdriver, vdriver))) return rc;
+        if ((rc = upload(e, e->d_vtopo_off, vtopo_off))) return rc;
+        if ((rc = upload(e, e->d_topo_off, topo_off))) return rc;
+        if ((rc = upload(e, e->d_vseg, vseg, 2))) return rc;
+        if ((rc = upload(e, e->d_grp_off, grp_off))) return rc;
+        if ((rc = upload(e, e->d_grp_vol, grp_vol))) return rc;
+        if ((rc = upload(e, e->d_ms_off, ms_off))) return rc;
+        if ((rc = upload(e, e->d_ms_mount, ms))) return rc;
+        if ((rc = upload(e, e->d_ncsi_off, ncsi_off))) return rc;
+        if ((rc = upload(e, e->d_ncsi, ncsi, 4))) return rc;
+        if ((rc = upload(e, e->d_ncsi_seg, nseg, 2))) return rc;
+        HIPCHECK(e, e->d_vT.reserve((size_t)std::max<uint32_t>(V, 1) * std::max<uint32_t>(Wn, 1) * 8));
+        VolTopoArgs ta{};
+        ta.n_nodes = N;
+        ta.n_words = Wn;
+        ta.n_vol = V;
+        ta.node_csi_off = e->d_ncsi_off.as<u32>();
+        ta.csi = e->d_ncsi.as<u32>();
+        ta.csi_seg = e->d_ncsi_seg.as<u32>();
+        ta.vol_driver = e->d_vdriver.as<u32>();
+        ta.vol_topo_off = e->d_vtopo_off.as<u32>();
+        ta.topo_off = e->d_topo_off.as<u32>();
+        ta.vol_seg = e->d_vseg.as<u32>();
+        ta.T = e->d_vT.as<u64>();
+        hipError_t r = launch_vol_topology(ta, e->stream);
+        if (r != hipSuccess) return e->fail(SWP_EHIP, "k_vol_topology launch: %s", hipGetErrorString(r));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));   // host vectors die at scope exit
+        e->dev_vol_words = Wn;
+        e->vol_static_dirty = false;
+        e->vol_dyn_dirty = true;
+    }
+    if (e->vol_dyn_dirty) {
+        std::vector<swp_volume_usage> dyn(V);
+        for (uint32_t v = 0; v < V; ++v) dyn[v] = e->volumes[v].use;
+        if ((rc = upload(e, e->d_vdyn, dyn))) return rc;
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        e->vol_dyn_dirty = false;
     }
     return SWP_OK;
 }
@@ -625,6 +758,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         if (d.spread_set >= e->spread_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown spread set", i);
         if (d.spread_set && !weights) return e->fail(SWP_EUNSUPPORTED, "task %u has spread preferences: schedule it through swp_schedule_groups", i);
         if (d.generic_set >= e->gen_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown generic set", i);
+        if ((d.flags >> SWP_TASK_MOUNTS_SHIFT) >= e->mount_sets.size()) return e->fail(SWP_EINVAL, "task %u references an unknown mount set", i);
         // the exactness argument (feasibility only shrinks inside a batch) needs non-negative reservations; the API layer
         // rejects negative ones (manager/controlapi validateResources), a task that carries them stays on the Go path
         if (d.cpu < 0 || d.mem < 0) return e->fail(SWP_EUNSUPPORTED, "task %u has a negative resource reservation", i);
@@ -788,6 +922,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         for (uint32_t i : firsts) {
             const RTask& r = b->rt[i];
             if (b->has_generic && b->tg[i]) continue;   // generic reservations: the per-task pass
+            if (tasks[i].flags >> SWP_TASK_MOUNTS_SHIFT) continue;   // cluster mounts: the per-task pass (its VolumesFilter row)
             XGroup g{};
             g.flags = ((r.flags & RT_RES) ? XG_RES : 0u) | ((r.flags & RT_PORTS) ? XG_PORTS : 0u) | ((r.flags & RT_MAXREP) ? XG_MAXREP : 0u);
             g.cpu = (g.flags & XG_RES) ? r.cpu : 0;
@@ -828,7 +963,7 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         uint32_t longest = 0, i = 0;
         while (i < T) {
             uint32_t k = i + 1;
-            const bool can = !(b->rt[i].flags & (RT_PORTS | RT_UNCOUNTED)) && !b->has_generic;   // (a batch with generic reservations is decided by the block resolver alone)
+            const bool can = !(b->rt[i].flags & (RT_PORTS | RT_UNCOUNTED)) && !b->has_generic && !(tasks[i].flags >> SWP_TASK_MOUNTS_SHIFT);   // (a batch with generic reservations is decided by the block resolver alone; so is a task with cluster mounts)
             while (can && k < T && same(i, k)) ++k;
             const bool run = k - i >= run_min;
             if (run) {
@@ -849,6 +984,17 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
     b->n_plug = (uint32_t)plug_ids.size();
 
     b->tmpl = std::move(tmpl_of);
+    b->csi_of.clear();
+    b->csi_set.clear();
+    b->csi_task.clear();
+    for (uint32_t i = 0; i < T; ++i)
+        if (tasks[i].flags >> SWP_TASK_MOUNTS_SHIFT) {
+            if (b->csi_of.empty()) b->csi_of.assign(T, 0xFFFFFFFFu);
+            b->csi_of[i] = (uint32_t)b->csi_set.size();
+            b->csi_set.push_back(tasks[i].flags >> SWP_TASK_MOUNTS_SHIFT);
+            b->csi_task.push_back(i);
+        }
+    if (!b->csi_set.empty() && weights) return e->fail(SWP_EUNSUPPORTED, "a task group with cluster mounts: its tasks go through swp_schedule_batch one by one");
     mark("runs");
     // per-service exception lists: nodes with svcCount>0 or ≥ maxFailures recent failures
     b->list_off.assign(b->n_svc + 1, 0);
@@ -969,6 +1115,12 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     int rc;
     if ((rc = upload(e, b->d_rt, b->rt))) return rc;
     if ((rc = upload(e, b->d_tmpl, b->tmpl))) return rc;
+    if (!b->csi_set.empty()) {
+        if ((rc = upload(e, b->d_csi_of, b->csi_of))) return rc;
+        if ((rc = upload(e, b->d_csi_set, b->csi_set))) return rc;
+        HIPCHECK(e, b->d_vrows.reserve(b->csi_set.size() * (size_t)std::max<uint32_t>(Wn, 1) * 8));
+        HIPCHECK(e, b->d_att.reserve(b->csi_set.size() * (size_t)SWP_MAX_MOUNTS * 4));
+    }
     if ((rc = upload(e, b->d_thr, b->thr))) return rc;
     if ((rc = upload(e, b->d_thr64, b->thr64))) return rc;
     if (b->has_generic) {
@@ -1082,6 +1234,10 @@ int run_explain(swp_engine* e, swp_batch* b, uint32_t n_inf) {
             xa.gs_row = b->d_gs_row.as<uint32_t>();
             xa.rg_kind = b->d_rg_kind.as<uint32_t>();
             xa.rg_val = b->d_rg_val.as<int32_t>();
+        }
+        if (!b->csi_set.empty()) {
+            xa.csi_of = b->d_csi_of.as<uint32_t>();
+            xa.vrows = b->d_vrows.as<u64>();
         }
         xa.hist = b->d_hist.as<uint32_t>();
         // per-node commit segments (sorted, suffix sums) for the residual-at-the-moment lookups
@@ -1301,6 +1457,11 @@ int batch_begin(swp_engine* e, swp_batch* b) {
     HIPCHECK(e, hipMemsetAsync(b->d_ctl.p, 0, sizeof(Ctl), st));
     HIPCHECK(e, hipMemsetAsync(b->d_hist.p, 0, (size_t)T * 8 * 4, st));
     HIPCHECK(e, hipMemsetAsync(b->d_out.p, 0xFF, (size_t)T * 4, st));   // -1 = no suitable node unless a commit says otherwise
+    if (!b->csi_set.empty()) {   // tasks with cluster mounts: no attachment yet, no node passes the VolumesFilter until a round says so
+        if (int rcv = flush_volumes(e)) return rcv;   // (a usage set since swp_batch_prepare)
+        HIPCHECK(e, hipMemsetAsync(b->d_att.p, 0xFF, b->csi_set.size() * (size_t)SWP_MAX_MOUNTS * 4, st));
+        HIPCHECK(e, hipMemsetAsync(b->d_vrows.p, 0, b->csi_set.size() * (size_t)Wn * 8, st));
+    }
     if (!b->xrow.empty())
         hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b->xrow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b->xrow.size(),
                            b->d_xrow.as<uint32_t>(), b->d_xnode.as<uint32_t>(), Wn, b->d_X.as<u64>());
@@ -1357,6 +1518,13 @@ int r6_args_for(swp_engine* e, swp_batch* b, uint32_t r6_block, bool r6_task_row
     ra.thr = b->d_thr64.as<long long>();
     ra.blk = b->d_blk6.as<Blk6>();
     ra.prop = b->d_prop.as<R6Prop>();
+    if (!b->csi_set.empty()) {
+        ra.csi_of = b->d_csi_of.as<uint32_t>();
+        ra.csi_set = b->d_csi_set.as<uint32_t>();
+        ra.vrows = b->d_vrows.as<u64>();
+        ra.att = b->d_att.as<uint32_t>();
+        ra.vol = vol_view(e);
+    }
     {   // SWP_R6_TWINS=0: every list starts at its level's first candidate (A/B runs)
         const char* env_tw = getenv("SWP_R6_TWINS");
         ra.tmpl = (env_tw && atoi(env_tw) == 0) ? nullptr : b->d_tmpl.as<uint32_t>();
@@ -1416,8 +1584,9 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     // SWP_RESOLVER=5, and the fall-back below.)
     int variant = env_res ? atoi(env_res) : 6;
     if (variant != 5 && variant != 6) return e->fail(SWP_EINVAL, "SWP_RESOLVER=%d: the resolver families are 5 (round) and 6 (block)", variant);
+    if (!b->csi_set.empty()) variant = 6;   // tasks with cluster mounts: the block resolver knows the volumes
     const size_t r5_lds = r5_lds_size(N, Wn, b->exact_ok ? b->n_dc + b->n_dm : 0u);
-    bool r5_ok = b->exact_ok && b->units_ok && r5_supports(Wn) && r5_lds <= lds_budget && !b->has_generic;
+    bool r5_ok = b->exact_ok && b->units_ok && r5_supports(Wn) && r5_lds <= lds_budget && !b->has_generic && b->csi_set.empty();
     for (uint32_t n = 0; r5_ok && n < N; ++n) {
         const HostNode& h = e->nodes[n];
         if (!h.present) continue;
@@ -1475,7 +1644,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         uint32_t pos = start, chunk = std::min<uint32_t>(16u, (end - start + 255u) / 256u + 1u);   // a short stretch does not pay for empty rounds
         uint32_t rounds_seen = 0, scan_len = 2048, scanned = 0;
         const char* env_scan = getenv("SWP_SCAN");   // 0: never hand a stretch to the scan resolver (tests, A/B runs)
-        const bool scan_ok = N <= scan_max_nodes() && !(env_scan && atoi(env_scan) == 0);
+        const bool scan_ok = N <= scan_max_nodes() && !(env_scan && atoi(env_scan) == 0) && b->csi_set.empty();   // (the scan resolver knows no volumes)
         while (pos < end) {
             r = launch_r6_rounds(ra, chunk, st, e->device);
             if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
@@ -2083,6 +2252,118 @@ int swp_generic_set(swp_engine* e, const swp_generic* items, uint32_t n, uint32_
     return register_set(e->gen_index, e->gen_sets, bytes_of(v.data(), v.size()), std::move(v), id_out);
 }
 
+// ---- CSI volumes ------------------------------------------------------------------------------------------------------------
+int swp_node_set_csi(swp_engine* e, uint32_t node, const swp_csi* infos, uint32_t n, const swp_seg* segs, uint32_t n_segs) {
+    if (!e || (!infos && n) || (!segs && n_segs)) return SWP_EINVAL;
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    std::vector<HostNode::Csi> v(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((uint64_t)infos[i].seg_off + infos[i].n_seg > n_segs) return e->fail(SWP_EINVAL, "CSI info %u: segments outside the array", i);
+        v[i].plugin = infos[i].plugin;
+        v[i].has_topology = infos[i].has_topology ? 1u : 0u;
+        v[i].segs.assign(segs + infos[i].seg_off, segs + infos[i].seg_off + infos[i].n_seg);
+    }
+    auto same = [](const HostNode::Csi& a, const HostNode::Csi& b) {
+        return a.plugin == b.plugin && a.has_topology == b.has_topology && a.segs.size() == b.segs.size() &&
+               (a.segs.empty() || std::memcmp(a.segs.data(), b.segs.data(), a.segs.size() * sizeof(swp_seg)) == 0);
+    };
+    HostNode& h = e->nodes[node];
+    if (h.csi.size() != v.size() || !std::equal(v.begin(), v.end(), h.csi.begin(), same)) {
+        h.csi = std::move(v);
+        e->vol_static_dirty = true;
+    }
+    return SWP_OK;
+}
+
+int swp_volume_upsert(swp_engine* e, uint32_t volume, const swp_volume* v, const uint32_t* topo_off, const swp_seg* segs) {
+    if (!e || !v || (v->n_topologies && (!topo_off || !segs))) return SWP_EINVAL;
+    if (volume == 0 || volume >= e->spaces[SWP_SPACE_VOLUME].strs.size()) return e->fail(SWP_EINVAL, "volume id %u was never interned", volume);
+    if (v->group >= e->spaces[SWP_SPACE_VOLUME_GROUP].strs.size()) return e->fail(SWP_EINVAL, "volume group id %u was never interned", v->group);
+    if (v->scope > 1 || v->sharing > 3) return e->fail(SWP_EINVAL, "volume %u: unknown access mode", volume);
+    if (volume >= e->volumes.size()) e->volumes.resize(volume + 1);
+    HostVolume& hv = e->volumes[volume];
+    hv.present = true;
+    hv.spec = *v;
+    hv.topo_off.assign(1, 0);
+    hv.segs.clear();
+    for (uint32_t t = 0; t < v->n_topologies; ++t) {
+        if (topo_off[t + 1] < topo_off[t]) return e->fail(SWP_EINVAL, "volume %u: topology offsets must ascend", volume);
+        hv.segs.insert(hv.segs.end(), segs + topo_off[t], segs + topo_off[t + 1]);
+        hv.topo_off.push_back((uint32_t)hv.segs.size());
+    }
+    e->vol_static_dirty = true;
+    return SWP_OK;
+}
+
+int swp_volume_set_usage(swp_engine* e, uint32_t volume, const swp_volume_usage* u) {
+    if (!e || !u) return SWP_EINVAL;
+    if (volume >= e->volumes.size() || !e->volumes[volume].present) return SWP_ENOTFOUND;
+    if (u->pin < SWP_PIN_MANY && u->pin >= e->nodes.size()) return e->fail(SWP_EINVAL, "volume %u: unknown node %u", volume, u->pin);
+    e->volumes[volume].use = *u;
+    e->volumes[volume].use.reserved = 0;
+    e->vol_dyn_dirty = true;
+    return SWP_OK;
+}
+
+int swp_volume_get_usage(swp_engine* e, uint32_t volume, swp_volume_usage* out) {
+    if (!e || !out) return SWP_EINVAL;
+    if (volume >= e->volumes.size() || !e->volumes[volume].present) return SWP_ENOTFOUND;
+    *out = e->volumes[volume].use;
+    return SWP_OK;
+}
+
+int swp_mount_set(swp_engine* e, const swp_mount* mounts, uint32_t n, uint32_t* id_out) {
+    if (!e || !id_out || (!mounts && n)) return SWP_EINVAL;
+    if (n == 0) { *id_out = 0; return SWP_OK; }
+    if (n > SWP_MAX_MOUNTS) return e->fail(SWP_ERANGE, "a task has %u cluster mounts (the engine takes %d)", n, SWP_MAX_MOUNTS);
+    std::vector<swp_mount> v(mounts, mounts + n);
+    for (swp_mount& m : v) {
+        m.is_group = m.is_group ? 1u : 0u;
+        m.read_only = m.read_only ? 1u : 0u;
+        m.reserve_read_only = m.reserve_read_only ? 1u : 0u;
+        if (m.ref != SWP_NO_VOLUME) {
+            if (m.is_group && m.ref >= e->spaces[SWP_SPACE_VOLUME_GROUP].strs.size()) return e->fail(SWP_EINVAL, "unknown volume group id %u", m.ref);
+            if (!m.is_group && (m.ref >= e->volumes.size() || !e->volumes[m.ref].present)) return e->fail(SWP_EINVAL, "unknown volume %u", m.ref);
+        }
+    }
+    const size_t before = e->mount_sets.size();
+    const int rc = register_set(e->mount_index, e->mount_sets, bytes_of(v.data(), v.size()), std::move(v), id_out);
+    if (e->mount_sets.size() != before) e->vol_static_dirty = true;
+    if (!rc && *id_out >= (1u << 24)) return e->fail(SWP_ERANGE, "too many distinct mount sets");
+    return rc;
+}
+
+int swp_choose_volumes(swp_engine* e, uint32_t mount_set, uint32_t node, uint32_t* out, uint32_t* n_out, uint32_t* failed_mount) {
+    if (!e || !out || !n_out) return SWP_EINVAL;
+    if (mount_set == 0 || mount_set >= e->mount_sets.size()) return e->fail(SWP_EINVAL, "unknown mount set %u", mount_set);
+    if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
+    (void)hipSetDevice(e->device);
+    int rc = flush_nodes(e);
+    if (rc) return rc;
+    for (uint32_t q = 0; q < SWP_MAX_MOUNTS; ++q) out[q] = SWP_NO_VOLUME;
+    *n_out = 0;
+    if (!e->has_volumes()) {   // no volume exists: the first mount fails
+        if (failed_mount) *failed_mount = 0;
+        return SWP_OK;
+    }
+    DevBuf d;
+    HIPCHECK(e, d.reserve((SWP_MAX_MOUNTS + 3) * 4));
+    VolChooseArgs ca{};
+    ca.vol = vol_view(e);
+    ca.set = mount_set;
+    ca.node = node;
+    ca.out = d.as<u32>();
+    hipError_t r = launch_vol_choose(ca, e->stream);
+    if (r != hipSuccess) return e->fail(SWP_EHIP, "k_vol_choose launch: %s", hipGetErrorString(r));
+    uint32_t h[SWP_MAX_MOUNTS + 3];
+    HIPCHECK(e, hipMemcpyAsync(h, d.p, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    for (uint32_t q = 0; q < SWP_MAX_MOUNTS; ++q) out[q] = h[q];
+    *n_out = h[SWP_MAX_MOUNTS];
+    if (failed_mount) *failed_mount = h[SWP_MAX_MOUNTS + 1];
+    return SWP_OK;
+}
+
 int swp_node_set_generic(swp_engine* e, uint32_t node, const swp_generic* counts, uint32_t n) {
     if (!e || (!counts && n)) return SWP_EINVAL;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
@@ -2371,6 +2652,31 @@ int swp_batch_run(swp_engine* e, swp_batch* b) {
     return batch_run(e, b);
 }
 
+// the attachments of the batch's tasks with cluster mounts; with `fold` also the usage numbers as the batch left them (into the host mirror)
+static int download_volumes(swp_engine* e, swp_batch* b, bool fold) {
+    if (b->csi_set.empty()) return SWP_OK;
+    b->h_att.assign(b->csi_set.size() * (size_t)SWP_MAX_MOUNTS, SWP_NO_VOLUME);
+    HIPCHECK(e, hipMemcpyAsync(b->h_att.data(), b->d_att.p, b->h_att.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    std::vector<swp_volume_usage> dyn(e->volumes.size());
+    if (fold && !dyn.empty()) HIPCHECK(e, hipMemcpyAsync(dyn.data(), e->d_vdyn.p, dyn.size() * sizeof(swp_volume_usage), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    if (fold)
+        for (size_t v = 0; v < dyn.size(); ++v)
+            if (e->volumes[v].present) e->volumes[v].use = dyn[v];
+    return SWP_OK;
+}
+
+int swp_batch_attachments(swp_engine* e, swp_batch* b, const uint32_t* tasks, uint32_t n, uint32_t* out) {
+    if (!e || !b || (!tasks && n) || (!out && n)) return SWP_EINVAL;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (tasks[i] >= b->T) return e->fail(SWP_EINVAL, "task %u is not of this batch", tasks[i]);
+        const uint32_t ck = b->csi_of.empty() ? 0xFFFFFFFFu : b->csi_of[tasks[i]];
+        for (uint32_t m = 0; m < SWP_MAX_MOUNTS; ++m)
+            out[(size_t)i * SWP_MAX_MOUNTS + m] = (ck == 0xFFFFFFFFu || b->h_att.empty()) ? SWP_NO_VOLUME : b->h_att[(size_t)ck * SWP_MAX_MOUNTS + m];
+    }
+    return SWP_OK;
+}
+
 int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* out_fail_hist) {
     if (!e || !b || (!out_node && b->T)) return SWP_EINVAL;
     if (!b->ran) return e->fail(SWP_EINVAL, "swp_batch_fetch before swp_batch_run");
@@ -2392,6 +2698,7 @@ int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* ou
         if (int rch = download_hist(e, b, out_fail_hist)) return rch;
     }
     HIPCHECK(e, hipStreamSynchronize(e->stream));
+    if (int rcv = download_volumes(e, b, true)) return rcv;
     uint64_t placed = 0;
     for (uint32_t i = 0; i < T; ++i) {
         int32_t n = out_node[i];
@@ -2420,6 +2727,8 @@ int swp_batch_results(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* 
         if (int rch = download_hist(e, b, out_fail_hist)) return rch;
     }
     HIPCHECK(e, hipStreamSynchronize(e->stream));
+    if (int rcv = download_volumes(e, b, false)) return rcv;
+    if (!b->csi_set.empty()) e->vol_dyn_dirty = true;   // (the device's usage numbers moved on, the host's did not: the next flush restores them)
     return SWP_OK;
 }
 
@@ -2439,6 +2748,7 @@ int swp_shard_begin(swp_engine* e, swp_batch* b) {
     if (e->n_nodes != b->n_nodes_prepared)
         return e->fail(SWP_EINVAL, "the nodeSet grew from %u to %u node slots since swp_batch_prepare: prepare the batch again", b->n_nodes_prepared, e->n_nodes);
     if (b->has_generic) return e->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the HOST-merged shard protocol (swp_shard_run / swp_shard_run_rank carry them)");
+    if (!b->csi_set.empty()) return e->fail(SWP_EUNSUPPORTED, "tasks with cluster mounts are not part of the shard protocols (a volume's use is cluster-wide state)");
     b->shard_open = true;
     b->shard_ncommit = b->shard_ninf = 0;
     e->stats.ms_propose = e->stats.ms_apply = 0.f;
@@ -2684,6 +2994,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     for (uint32_t g = 0; g < G; ++g) {
         if (!engines[g] || !batches[g] || batches[g]->T != T) return e0->fail(SWP_EINVAL, "shard %u: every shard's batch must hold the same %u tasks", g, T);
         if (engines[g]->n_nodes != batches[g]->n_nodes_prepared) return e0->fail(SWP_EINVAL, "shard %u: the nodeSet grew since swp_batch_prepare", g);
+        if (!batches[g]->csi_set.empty()) return e0->fail(SWP_EUNSUPPORTED, "tasks with cluster mounts are not part of the shard protocols (a volume's use is cluster-wide state)");
         for (uint32_t h = 0; h < g; ++h)
             if (engines[h] == engines[g]) return e0->fail(SWP_EINVAL, "shards %u and %u name the same engine", h, g);
     }
@@ -3050,6 +3361,7 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
     else if (shard_nodes[me] != e->n_nodes) pre = e->fail(SWP_EINVAL, "rank %u holds %u node slots, shard_nodes says %u", me, e->n_nodes, shard_nodes[me]);
     else if (e->n_nodes == 0) pre = e->fail(SWP_EINVAL, "rank %u owns no node", me);
     else if (r6_propose_lds_size(Wn) > lds_budget) pre = e->fail(SWP_ERANGE, "%u nodes exceed the block resolver's LDS", e->n_nodes);
+    else if (!b->csi_set.empty()) pre = e->fail(SWP_EUNSUPPORTED, "tasks with cluster mounts are not part of the shard protocols (a volume's use is cluster-wide state)");
     if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
     for (uint32_t i = 0; i < T; ++i) out_node_local[i] = -1;
     auto setup = [&]() -> int {
@@ -3282,6 +3594,25 @@ int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int3
     HIPCHECK(e, hipMemcpyAsync(&ff, out.p, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     *first_fail = ff;
+    if (ff < 0 && (task->flags >> SWP_TASK_MOUNTS_SHIFT)) {   // VolumesFilter, the pipeline's last entry: any mount with a volume on the node
+        uint32_t att[SWP_MAX_MOUNTS], na = 0;
+        if (!e->has_volumes() || e->volumes.empty()) { *first_fail = 7; return SWP_OK; }
+        DevBuf d;
+        HIPCHECK(e, d.reserve((SWP_MAX_MOUNTS + 3) * 4));
+        VolChooseArgs va{};
+        va.vol = vol_view(e);
+        va.set = task->flags >> SWP_TASK_MOUNTS_SHIFT;
+        va.node = node;
+        va.out = d.as<u32>();
+        hipError_t r = launch_vol_choose(va, e->stream);
+        if (r != hipSuccess) return e->fail(SWP_EHIP, "k_vol_choose launch: %s", hipGetErrorString(r));
+        uint32_t h[SWP_MAX_MOUNTS + 3];
+        HIPCHECK(e, hipMemcpyAsync(h, d.p, sizeof h, hipMemcpyDeviceToHost, e->stream));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        (void)att;
+        (void)na;
+        if (!h[SWP_MAX_MOUNTS + 2]) *first_fail = 7;
+    }
     return SWP_OK;
 }
 

@@ -27,6 +27,12 @@ uint32_t r6_block_max();
 hipError_t launch_r6_build(const R6Args& a, hipStream_t s);
 hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int dev);
 
+// CSI volumes (swp_volumes.hpp, built in swp_resolve6.hip)
+struct VolTopoArgs;
+struct VolChooseArgs;
+hipError_t launch_vol_topology(const VolTopoArgs& a, hipStream_t s);
+hipError_t launch_vol_choose(const VolChooseArgs& a, hipStream_t s);
+
 // node-range shards, rounds on the device (swp_resolve7.hpp, built in swp_resolve6.hip)
 struct R7Args;
 struct R7Pick;

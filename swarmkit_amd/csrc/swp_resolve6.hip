@@ -4,6 +4,7 @@
 #include "swp_launch.hpp"
 #include "swp_wave.hpp"
 #define SWP_R6_KERNELS
+#define SWP_VOL_KERNELS
 #include "swp_resolve6.hpp"
 #include "swp_resolve7.hpp"
 #define SWP_SCAN_KERNELS
@@ -30,10 +31,22 @@ hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int
     if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r6_commit), dev)) != hipSuccess) return r;
     for (uint32_t i = 0; i < rounds; ++i) {
         if (a.task_rows) hipLaunchKernelGGL(k_r6_taskrows, dim3((a.n_words + 3) / 4, (a.block + 63) / 64), dim3(256), (size_t)a.block * 16, s, a);
+        if (a.csi_of) hipLaunchKernelGGL(k_r6_volrows, dim3((a.n_words + 255) / 256, a.block), dim3(256), 0, s, a);   // (batches with cluster mounts only)
         if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small, dim3(a.block), dim3(64 * R6_PW), lp, s, a);   // (LDS of 8 chunks: never beyond 48 KB)
         else hipLaunchKernelGGL(k_r6_propose, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
         hipLaunchKernelGGL(k_r6_commit, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
     }
+    return hipGetLastError();
+}
+
+// ---- CSI volumes (swp_volumes.hpp) ----
+hipError_t launch_vol_topology(const VolTopoArgs& a, hipStream_t s) {
+    if (a.n_vol == 0 || a.n_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vol_topology, dim3((a.n_words * 64 + 255) / 256, a.n_vol), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_vol_choose(const VolChooseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_vol_choose, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

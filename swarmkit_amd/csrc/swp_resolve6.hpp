@@ -34,6 +34,7 @@
 
 #include "swp_shard.hpp"
 #include "swp_types.hpp"
+#include "swp_volumes.hpp"
 
 namespace swpdev {
 
@@ -61,7 +62,7 @@ struct R6Prop {   // one task's proposal: the shard protocol's record (include/s
     u32 hw[2 * R6_CAND];     // half-word index (node = 32 * hw + bit), ascending: the first 2 * R6_CAND NON-EMPTY half-words of the level
     u32 hb[2 * R6_CAND];     // the level's survivors inside each
     u64 exc_hi, exc_lo;      // best node of the service's exception list by nodeLess' key, KEY_NONE: none
-    u32 exc_entry, flags;    // flags bit 0: the task does not count on its node
+    u32 exc_entry, flags;    // flags bit 0: the task does not count on its node; bit 1: it has cluster mounts
 };
 static_assert(sizeof(R6Prop) == 8 + 16 * R6_CAND + 24, "R6Prop layout");
 static_assert(2 * R6_CAND <= 64, "one lane per list entry");
@@ -114,6 +115,13 @@ struct R6Args {
     // [tasks of the batch] the first task of the batch with this task's descriptor: equal values = identical tasks, whose plain candidates
     // of a round are the same set. nullptr: lists start at the level's first candidate (the shard drivers: a range sees only its own part).
     const u32* tmpl;
+    // CSI volumes (swp_volumes.hpp). csi_of == nullptr: the batch has no task with cluster mounts. Such a task's candidates depend on the
+    // volumes every earlier one took — on ANY node — so a block decides at most one of them: the second one is where the block is cut.
+    const u32* csi_of;       // [tasks of the batch] index among the batch's tasks with mounts, R6_NONE: it has none
+    const u32* csi_set;      // [those tasks] mount set
+    u64* vrows;              // [those tasks][n_words] VolumesFilter.Check (filter.go:424-432) as the volumes stood at the start of the task's last round
+    u32* att;                // [those tasks][VOL_MAX_MOUNTS] the volumes chosen for its mounts on its node (chooseTaskVolumes), VOL_NONE: none
+    VolView vol;
 };
 
 #define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together ...
@@ -233,6 +241,17 @@ WV_DEV void r6_taskrows(const R6Args& a, u32 g_first, u32 g_step) {
 
 WV_KERNEL(256) void k_r6_taskrows(R6Args a) { r6_taskrows(a, wv::block_y(), (a.block + 63u) / 64u); }   // grid (words / 4, groups of the block)
 
+// ---- volume rows: VolumesFilter.Check of the block's tasks with cluster mounts, from the volumes as they are (grid: words / 256, block) ----
+WV_KERNEL(256) void k_r6_volrows(R6Args a) {
+    const u32 pos = wv::uload(&a.blk->pos), end = wv::uload(&a.blk->end);
+    const u32 t = pos + wv::block_y();
+    if (t >= end || wv::uload(&a.blk->error) != ERR_NONE) return;
+    const u32 ck = wv::uload(a.csi_of + t);
+    if (ck == R6_NONE) return;
+    const u32 w = wv::block() * 256 + wv::tid();
+    if (w < a.n_words) a.vrows[(size_t)ck * a.n_words + w] = vol_filter_word(a.vol, wv::uload(a.csi_set + ck), w);
+}
+
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
 // The waves split the task's node words (wave v owns the chunks of 64 words k = v, v + R6_PW, ...): the passes are latency-bound,
 // so more waves per task is what shortens them. A pass ends with one barrier (has any wave a candidate left?).
@@ -265,6 +284,8 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
         g0 = wv::uload(a.gs_off + gset);
         g1 = wv::uload(a.gs_off + gset + 1);
     }
+    const u32 ck = a.csi_of ? wv::uload(a.csi_of + t) : R6_NONE;   // a task with cluster mounts: its VolumesFilter row of this round
+    const u64* vrow = ck != R6_NONE ? a.vrows + (size_t)ck * a.n_words : nullptr;
     // The task's plain candidates AND the minimum level among them in one pass: lane l of wave v owns words {l + 64 k}, k = v (mod
     // R6_PW); per word the candidate set is narrowed over the level planes from the top in registers (m & ~plane ≠ ∅ ? keep that : the
     // bit is set in the word's minimum), the planes of UN words requested together; the minimum over the words is one reduction.
@@ -298,6 +319,7 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
             if (res && in) f[u] |= ~(rc[w] & rm[w]);
             for (u32 g = g0; g < g1; ++g)
                 if (in) f[u] |= ~a.rg[(size_t)wv::uload(a.gs_row + g) * Wn + w];
+            if (vrow && in) f[u] |= ~vrow[w];
         }
         u32 rel[UN];
         WV_UNROLL
@@ -432,6 +454,7 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
             if (a.gcnt[(size_t)a.rg_kind[r] * a.gstride + n] < a.rg_val[r]) lacks = true;
         }
         if (lacks) continue;
+        if (vrow && !(vrow[w] & bit)) continue;
         bool used = false;
         for (u32 p = p0; p < p1; ++p)
             if (a.portmap[(size_t)a.pset_ids[p] * Wn + w] & bit) used = true;
@@ -467,7 +490,7 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
         out->exc_hi = ghi;
         out->exc_lo = ghi == KEY_NONE ? KEY_NONE : glo;
         out->exc_entry = gentry;
-        out->flags = (flags & RT_UNCOUNTED) ? 1u : 0u;
+        out->flags = ((flags & RT_UNCOUNTED) ? 1u : 0u) | (ck != R6_NONE ? 2u : 0u);
     }
 }
 
@@ -538,7 +561,7 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     if (wave_ == 0) {
         u32 nc = a.ctl->ncommit, ni = a.ctl->ninf, acc = 0, why = 0;
         u32* tk32 = reinterpret_cast<u32*>(tk);   // the same row as 32-node half-words
-        bool stop = false;
+        bool stop = false, csi_seen = false;   // csi_seen: a task with cluster mounts is decided in this block already
         // the scalar part of a task's record (level, list length, exception-list candidate); the next group's is in flight while a group is matched
         struct Head { u32 level, n_cand; u64 exc_hi, exc_lo; u32 exc_entry, flags; };
         auto head_of = [&](u32 j) {
@@ -611,6 +634,13 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             bool last = false;   // the block ends with this group even if the group is walked to its end
             if (m_exc) { cut = (u32)wv::ffs64(m_exc); why = 2; }
             if (m_unc && (u32)wv::ffs64(m_unc) < cut) { cut = (u32)wv::ffs64(m_unc) + 1; why = 3; last = true; }
+            {   // tasks with cluster mounts: the block's first one is decided, the block is cut in front of the next (their lists know nothing of each other's volumes)
+                const u64 all_csi = wv::ballot(have && (p->flags & 2u));
+                u64 m_csi = all_csi;
+                if (m_csi && !csi_seen) m_csi &= m_csi - 1ull;   // (the first one of the block stays)
+                if (m_csi && (u32)wv::ffs64(m_csi) < cut) { cut = (u32)wv::ffs64(m_csi); why = 2; last = false; }
+                if (all_csi & (cut >= 64 ? ~0ull : (1ull << cut) - 1ull)) csi_seen = true;
+            }
             u32 m_pick = R6_NONE;
             if (g0 == 0 && (m_exc & 1ull)) {   // the block's first task, from its exception list; the block ends behind it
                 if (lane == 0) {
@@ -782,6 +812,15 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             a.log_prev[ci] = prev;
             a.last[nd] = (int32_t)ci;
             a.out_node[t] = (int32_t)nd;
+            if (a.csi_of) {   // chooseTaskVolumes + reserveTaskVolumes on the node (scheduler.go:857-874); a mount without a volume: assigned without attachments
+                const u32 ck = a.csi_of[t];
+                if (ck != R6_NONE) {
+                    u32 att[VOL_MAX_MOUNTS];
+                    const u32 set = a.csi_set[ck], na = vol_choose(a.vol, set, nd, att, nullptr);
+                    if (na) vol_reserve(a.vol, set, nd, att, na);
+                    for (u32 q = 0; q < VOL_MAX_MOUNTS; ++q) a.att[(size_t)ck * VOL_MAX_MOUNTS + q] = att[q];
+                }
+            }
         }
     }
     if (prof && wave_ == 1 && lane == 0) a.blk->cyc[3] += (u32)((wv::clock64() - t2) >> 6);   // the first group's applying wave: waiting for it + applying

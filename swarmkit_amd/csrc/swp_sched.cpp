@@ -339,11 +339,22 @@ class Scheduler {
             ni = &nodes_.emplace(nid, std::move(fresh)).first->second;
             if (idx_to_id_.size() <= idx) idx_to_id_.resize(idx + 1);
             idx_to_id_[idx] = nid;
+            repin_after_ = nid;   // volumes in use on a node of this id learn its index below
         }
         ni->node = n;
         ni->availGeneric = std::move(avail);
         upsertRow(n, idx, cpu, mem, total);
         pushGeneric(*ni);
+        if (!repin_after_.empty()) {
+            repinVolumes(repin_after_);
+            repin_after_.clear();
+        }
+    }
+    std::string repin_after_;
+    void repinVolumes(const std::string& nid) {
+        for (const auto& kv : volumes_)
+            for (const auto& u : kv.second.tasks)
+                if (u.second.node == nid) { pushVolumeUsage(kv.second); break; }
     }
     // nodeSet.remove, nodeset.go:46-48
     void deleteNode(const std::string& nid) {
@@ -351,6 +362,7 @@ class Scheduler {
         if (it == nodes_.end()) return;
         const uint32_t idx = it->second.idx;
         nodes_.erase(it);
+        repinVolumes(nid);   // (before the index is free again: no usage number may name it)
         ck(swp_node_remove(e_, idx), "swp_node_remove");
         // the engine hands the index to the next node that is new to it: nothing here may remember it as this node's
         if (idx < idx_to_id_.size()) idx_to_id_[idx].clear();
@@ -383,6 +395,97 @@ class Scheduler {
         info.set("AvailableResources", avail);
         info.set("Tasks", tasks);
         info.set("RecentFailures", fails);
+        out = json::dump(info);
+        return true;
+    }
+
+    // ---------------------------------------------------------------------------------------------- CSI volumes
+    // EventUpdateVolume (scheduler.go:200-213) and the volumes of the store at start (:70-81): addOrUpdateVolume (volumes.go:62-82) once
+    // the plugin has created the volume. The engine gets what checkVolume reads; the maps behind its usage numbers stay here.
+    void updateVolume(const Value& v) {
+        const std::string& plugin_id = as_str(at(&v, {"VolumeInfo", "VolumeID"}));
+        if (v.get("VolumeInfo") == nullptr || plugin_id.empty()) return;
+        const std::string& vid = task_id(v);
+        auto it = volumes_.find(vid);
+        if (it == volumes_.end()) {
+            VolumeRec rec;
+            rec.idx = intern(SWP_SPACE_VOLUME, vid);
+            it = volumes_.emplace(vid, std::move(rec)).first;
+            if (vol_idx_to_id_.size() <= it->second.idx) vol_idx_to_id_.resize(it->second.idx + 1);
+            vol_idx_to_id_[it->second.idx] = vid;
+        }
+        it->second.doc = v;
+        swp_volume sv;
+        std::memset(&sv, 0, sizeof sv);
+        sv.group = intern(SWP_SPACE_VOLUME_GROUP, as_str(at(&v, {"Spec", "Group"})));
+        sv.driver = intern(SWP_SPACE_CSI, as_str(at(&v, {"Spec", "Driver", "Name"})));
+        sv.scope = (uint32_t)enum_value(at(&v, {"Spec", "AccessMode", "Scope"}), {{"SINGLE_NODE", 0}, {"MULTI_NODE", 1}});
+        sv.sharing = (uint32_t)enum_value(at(&v, {"Spec", "AccessMode", "Sharing"}), {{"NONE", 0}, {"READ_ONLY", 1}, {"ONE_WRITER", 2}, {"ALL", 3}});
+        sv.active = enum_value(at(&v, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) == 0 ? 1u : 0u;
+        std::vector<uint32_t> topo_off(1, 0);
+        std::vector<swp_seg> segs;
+        if (const Value* at_ = at(&v, {"VolumeInfo", "AccessibleTopology"}))
+            if (at_->is_arr())
+                for (const Value& top : *at_->a) {
+                    if (const Value* sg = top.get("Segments"))
+                        if (sg->is_obj())
+                            for (const json::Member& m : *sg->o) segs.push_back({intern(SWP_SPACE_CSI, m.first), intern(SWP_SPACE_CSI, as_str(&m.second))});
+                    topo_off.push_back((uint32_t)segs.size());
+                }
+        sv.n_topologies = (uint32_t)topo_off.size() - 1;
+        static const swp_seg no_seg = {0, 0};
+        ck(swp_volume_upsert(e_, it->second.idx, &sv, topo_off.data(), segs.empty() ? &no_seg : segs.data()), "swp_volume_upsert");
+        volByName_[as_str(at(&v, {"Spec", "Annotations", "Name"}))] = vid;
+    }
+    // volumeSet.reserveVolume / releaseVolume (volumes.go:156-187) + the usage numbers the engine judges by
+    void reserveVolume(const std::string& vid, const std::string& tid, const std::string& nid, bool ro) {
+        auto it = volumes_.find(vid);
+        if (it == volumes_.end()) return;
+        it->second.tasks[tid] = VolumeUse{nid, ro};
+        pushVolumeUsage(it->second);
+    }
+    void releaseVolume(const std::string& vid, const std::string& tid) {
+        auto it = volumes_.find(vid);
+        if (it == volumes_.end()) return;
+        if (it->second.tasks.erase(tid)) pushVolumeUsage(it->second);
+    }
+    // reserveTaskVolumes, volumes.go:144-154
+    void reserveTaskVolumes(const Value& t) {
+        const Value* vols = t.get("Volumes");
+        const Value* mounts = at(&t, {"Spec", "Container", "Mounts"});
+        if (vols == nullptr || !vols->is_arr() || mounts == nullptr || !mounts->is_arr()) return;
+        for (const Value& va : *vols->a)
+            for (const Value& m : *mounts->a)
+                if (as_str(m.get("Source")) == as_str(va.get("Source")) && as_str(m.get("Target")) == as_str(va.get("Target")))
+                    reserveVolume(as_str(va.get("ID")), task_id(t), as_str(t.get("NodeID")), truthy(m.get("ReadOnly")));
+    }
+    void releaseTaskVolumes(const Value& t) {
+        const Value* vols = t.get("Volumes");
+        if (vols != nullptr && vols->is_arr())
+            for (const Value& va : *vols->a) releaseVolume(as_str(va.get("ID")), task_id(t));
+    }
+    bool volumeInfo(const std::string& vid, std::string& out) {
+        auto it = volumes_.find(vid);
+        if (it == volumes_.end()) return false;
+        Value tasks = Value::object(), nodes = Value::object();
+        std::map<std::string, int64_t> refs;
+        for (const auto& kv : it->second.tasks) {
+            Value u = Value::object();
+            u.set("NodeID", Value::str(kv.second.node));
+            u.set("ReadOnly", Value::boolean(kv.second.read_only));
+            tasks.set(kv.first, u);
+            refs[kv.second.node] += 1;
+        }
+        for (const auto& kv : refs) nodes.set(kv.first, Value::integer(kv.second));
+        swp_volume_usage use;
+        ck(swp_volume_get_usage(e_, it->second.idx, &use), "swp_volume_get_usage");
+        Value eng = Value::object();
+        eng.set("Tasks", Value::integer(use.n_tasks));
+        eng.set("Writers", Value::integer(use.n_writers));
+        Value info = Value::object();
+        info.set("Tasks", tasks);
+        info.set("Nodes", nodes);
+        info.set("Engine", eng);
         out = json::dump(info);
         return true;
     }
@@ -421,11 +524,17 @@ class Scheduler {
                     if (enum_value(p.get("PublishMode"), {{"INGRESS", 0}, {"HOST", 1}}) == PUBLISH_HOST && as_i64(p.get("PublishedPort")) != 0) ++host_ports;
                 if (host_ports > 32) unsupported("more than 32 host-mode ports in one task stay on the Go path");   // swp_port_set's limit
             }
+        if (clusterMounts(t).size() > SWP_MAX_MOUNTS) unsupported("more than 8 cluster mounts in one task stay on the Go path");   // swp_mount_set's limit
+    }
+    // the task's MountTypeCluster mounts in spec order (VolumesFilter.SetTask, filter.go:412-420)
+    static bool isCluster(const Value& m) { return enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) == MOUNT_CLUSTER; }
+    static std::vector<const Value*> clusterMounts(const Value& t) {
+        std::vector<const Value*> out;
         const Value* mounts = at(&t, {"Spec", "Container", "Mounts"});
         if (mounts != nullptr && mounts->is_arr())
             for (const Value& m : *mounts->a)
-                if (enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) == MOUNT_CLUSTER)
-                    unsupported("CSI cluster volumes stay on the Go path");
+                if (isCluster(m)) out.push_back(&m);
+        return out;
     }
     // createTask, scheduler.go:254-283
     bool createTask(const Value& t) {
@@ -450,8 +559,12 @@ class Scheduler {
     // setupTasksList, scheduler.go:68-126: a task found in the store at start-up. One rule differs from the createTask
     // event: a task still PENDING whose desired state is already past COMPLETED is ignored (:93-101).
     bool setupTask(const Value& t) {
-        if (task_state(at(&t, {"Status", "State"})) == PENDING && task_state(t.get("DesiredState")) > COMPLETE) return false;
-        return createTask(t);
+        const int64_t st = task_state(at(&t, {"Status", "State"}));
+        if (st == PENDING && task_state(t.get("DesiredState")) > COMPLETE) return false;
+        const bool r = createTask(t);
+        // :115-116: the volumes in use by a task that sits on its node already (NOT what the createTask event does)
+        if (st > PENDING && st <= RUNNING && truthy(t.get("NodeID"))) reserveTaskVolumes(t);
+        return r;
     }
     // updateTask, scheduler.go:283-348
     bool updateTask(const Value& t) {
@@ -503,6 +616,7 @@ class Scheduler {
         allTasks_.erase(id);
         preassignedTasks_.erase(id);
         pendingPreassignedTasks_.erase(id);
+        releaseTaskVolumes(t);   // :355-358
         auto n = nodes_.find(as_str(t.get("NodeID")));
         if (n != nodes_.end() && removeTask(n->second, t)) return true;
         return false;
@@ -551,9 +665,33 @@ class Scheduler {
         std::vector<std::string> vol;
         if (const Value* mounts = at(&t, {"Spec", "Container", "Mounts"})) {
             if (mounts->is_arr()) {
-                for (const Value& m : *mounts->a)
-                    if (enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) == MOUNT_CLUSTER)
-                        unsupported("CSI cluster volumes stay on the Go path");
+                {   // VolumesFilter.SetTask, filter.go:392-422: the cluster mounts as a mount set (a name resolves through byName NOW, volumes.go:252)
+                    std::vector<swp_mount> ms;
+                    for (const Value* m : clusterMounts(t)) {
+                        swp_mount mm;
+                        std::memset(&mm, 0, sizeof mm);
+                        const std::string& src = as_str(m->get("Source"));
+                        static const std::string prefix = "group:";
+                        if (src.compare(0, prefix.size(), prefix) == 0) {
+                            mm.is_group = 1;
+                            mm.ref = intern(SWP_SPACE_VOLUME_GROUP, src.substr(prefix.size()));
+                        } else {
+                            auto bn = volByName_.find(src);
+                            mm.ref = bn == volByName_.end() ? SWP_NO_VOLUME : volumes_.at(bn->second).idx;
+                        }
+                        mm.read_only = truthy(m->get("ReadOnly")) ? 1u : 0u;
+                        mm.reserve_read_only = mm.read_only;   // what reserveTaskVolumes records: the LAST mount with this (Source, Target) speaks (volumes.go:148-151)
+                        for (const Value& other : *mounts->a)
+                            if (as_str(other.get("Source")) == src && as_str(other.get("Target")) == as_str(m->get("Target"))) mm.reserve_read_only = truthy(other.get("ReadOnly")) ? 1u : 0u;
+                        ms.push_back(mm);
+                    }
+                    if (ms.size() > SWP_MAX_MOUNTS) unsupported("more than 8 cluster mounts in one task stay on the Go path");
+                    if (!ms.empty()) {
+                        uint32_t set = 0;
+                        ck(swp_mount_set(e_, ms.data(), (uint32_t)ms.size(), &set), "swp_mount_set");
+                        d.flags |= SWP_TASK_MOUNTS(set);
+                    }
+                }
                 for (const Value& m : *mounts->a) {
                     if (enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) != MOUNT_VOLUME) continue;
                     const Value* dc = at(&m, {"VolumeOptions", "DriverConfig"});
@@ -633,6 +771,8 @@ class Scheduler {
                 status.set("Err", Value::str(explain(hist)));   // newT.Status.Err = s.pipeline.Explain(), :660
                 newT.set("Status", status);
                 allTasks_[tid] = newT;
+            } else if (!chooseForPreassigned(t, n->second, newT)) {   // scheduler.go:663-674: the error string is the task's new status
+                allTasks_[tid] = newT;
             } else {
                 Value status = Value::object();
                 status.set("State", Value::integer(ASSIGNED));
@@ -649,9 +789,37 @@ class Scheduler {
             Value d = decision(t, newT);
             const Value* ag = newT.get("AssignedGenericResources");
             if (ag && ag->is_arr() && ag->size() > 0) d.set("AssignedGenericResources", *ag);
+            if (newT.get("Volumes") != nullptr && task_state(at(&newT, {"Status", "State"})) == ASSIGNED) d.set("Volumes", *newT.get("Volumes"));
             decisions.push(d);
         }
         return decisions;
+    }
+
+    // chooseTaskVolumes for a preassigned task on its node (scheduler.go:663-677): the attachments go into newT — nothing is reserved,
+    // the reference reserves only in scheduleNTasksOnNodes and at start-up. false: a mount found no volume, newT carries the error.
+    bool chooseForPreassigned(const Value& t, const NodeInfo& ni, Value& newT) {
+        const std::vector<const Value*> cms = clusterMounts(t);
+        if (cms.empty()) return true;
+        const swp_task_desc d = taskDesc(t);
+        uint32_t att[SWP_MAX_MOUNTS], n_out = 0, failed = 0;
+        ck(swp_choose_volumes(e_, d.flags >> SWP_TASK_MOUNTS_SHIFT, ni.idx, att, &n_out, &failed), "swp_choose_volumes");
+        if (n_out == 0) {
+            Value status = statusCopy(t);
+            status.set("Err", Value::str("cannot find volume to satisfy mount with source " + as_str(cms[std::min<size_t>(failed, cms.size() - 1)]->get("Source"))));
+            newT.set("Status", status);
+            return false;
+        }
+        Value vols = Value::array();
+        for (size_t m = 0; m < cms.size(); ++m) {
+            if (att[m] >= vol_idx_to_id_.size()) fail(SWP_EINVAL, "engine returned an unknown volume index");
+            Value va = Value::object();
+            va.set("ID", Value::str(vol_idx_to_id_[att[m]]));
+            va.set("Source", Value::str(as_str(cms[m]->get("Source"))));
+            va.set("Target", Value::str(as_str(cms[m]->get("Target"))));
+            vols.push(va);
+        }
+        newT.set("Volumes", vols);
+        return true;
     }
 
     // ---------------------------------------------------------------------------------------------- tick
@@ -748,6 +916,7 @@ class Scheduler {
         auto cur = allTasks_.find(tid);
         if (cur != allTasks_.end()) {
             const Value newT = cur->second;
+            if (!pd.preassigned) releaseTaskVolumes(newT);   // scheduler.go:480-483 (a preassigned task's attachments were never reserved)
             auto n = nodes_.find(as_str(newT.get("NodeID")));
             if (n != nodes_.end() && !truthy(pd.old.get("NodeID")) ) removeTask(n->second, newT);                 // tick: the node was chosen by this decision
             else if (n != nodes_.end() && pd.preassigned && task_state(at(&newT, {"Status", "State"})) == ASSIGNED) removeTask(n->second, newT);
@@ -926,6 +1095,23 @@ class Scheduler {
     // erased (nodeinfo.go:163-183) is reset there too
     std::map<std::tuple<uint32_t, std::string, int64_t>, uint32_t> pushedFailures_;
     std::set<std::string> preassignedTasks_;                               // Scheduler.preassignedTasks
+    // Scheduler.volumes (volumes.go:19-46): the task -> usage maps; the engine holds the numbers checkVolume derives from them
+    struct VolumeUse { std::string node; bool read_only; };
+    struct VolumeRec { Value doc; uint32_t idx = 0; std::map<std::string, VolumeUse> tasks; };
+    std::map<std::string, VolumeRec> volumes_;
+    std::map<std::string, std::string> volByName_;
+    std::vector<std::string> vol_idx_to_id_;
+    void pushVolumeUsage(const VolumeRec& r) {
+        swp_volume_usage u{0, 0, SWP_PIN_NONE, 0};
+        for (const auto& kv : r.tasks) {
+            u.n_tasks += 1;
+            if (!kv.second.read_only) u.n_writers += 1;
+            auto n = nodes_.find(kv.second.node);
+            const uint32_t idx = n == nodes_.end() ? SWP_PIN_MANY : n->second.idx;   // (a user on a node the nodeSet does not hold: no node of the set is that node)
+            u.pin = u.pin == SWP_PIN_NONE ? idx : (u.pin == idx ? idx : SWP_PIN_MANY);
+        }
+        ck(swp_volume_set_usage(e_, r.idx, &u), "swp_volume_set_usage");
+    }
     std::unordered_map<std::string, Value> allTasks_;                      // Scheduler.allTasks
 
     void ck(int rc, const char* what) {
@@ -1071,6 +1257,28 @@ class Scheduler {
         ck(swp_node_upsert(e_, &row, lab.empty() ? &no_kv : lab.data(), (uint32_t)lab.size(), elab.empty() ? &no_kv : elab.data(), (uint32_t)elab.size(),
                            plugins.empty() ? &no_plugin : plugins.data(), (uint32_t)plugins.size()),
            "swp_node_upsert");
+        // Description.CSIInfo: the node's topology per CSI plugin (volumes.go:272-278)
+        std::vector<swp_csi> infos;
+        std::vector<swp_seg> segs;
+        if (const Value* cs = at(&doc, {"Description", "CSIInfo"}))
+            if (cs->is_arr())
+                for (const Value& c : *cs->a) {
+                    swp_csi ci;
+                    std::memset(&ci, 0, sizeof ci);
+                    ci.plugin = intern(SWP_SPACE_CSI, as_str(c.get("PluginName")));
+                    ci.seg_off = (uint32_t)segs.size();
+                    if (const Value* top = c.get("AccessibleTopology")) {
+                        ci.has_topology = 1;
+                        if (const Value* sg = top->get("Segments"))
+                            if (sg->is_obj())
+                                for (const json::Member& m : *sg->o) segs.push_back({intern(SWP_SPACE_CSI, m.first), intern(SWP_SPACE_CSI, as_str(&m.second))});
+                    }
+                    ci.n_seg = (uint32_t)segs.size() - ci.seg_off;
+                    infos.push_back(ci);
+                }
+        static const swp_csi no_csi = {0, 0, 0, 0};
+        static const swp_seg no_seg = {0, 0};
+        ck(swp_node_set_csi(e_, idx, infos.empty() ? &no_csi : infos.data(), (uint32_t)infos.size(), segs.empty() ? &no_seg : segs.data(), (uint32_t)segs.size()), "swp_node_set_csi");
     }
 
     // taskReservations, nodeinfo.go:156-161
@@ -1236,7 +1444,7 @@ class Scheduler {
     }
     // scheduleNTasksOnNodes' bookkeeping for one placed task (scheduler.go:868-897); the numeric addTask already
     // happened on the device
-    void place(const std::string& tid, const Value& t, int32_t n, Value& decisions) {
+    void place(const std::string& tid, const Value& t, int32_t n, Value& decisions, const uint32_t* att = nullptr) {
         if ((size_t)n >= idx_to_id_.size()) fail(SWP_EINVAL, "engine returned an unknown node index");
         const std::string& nid = idx_to_id_[(size_t)n];
         Value newT = t.shallow_copy();
@@ -1256,11 +1464,28 @@ class Scheduler {
             genericTouched_.insert(nid);   // pushed once the whole call's placements are booked (pushTouched): then the counts equal
                                            // what the engine's own arithmetic left and the call changes nothing
         }
+        // newT.Volumes = attachments; reserveTaskVolumes(&newT) (scheduler.go:862-874): what the engine chose on the node, in mount order; a
+        // mount that found no volume leaves the task without attachments (the reference logs the error and assigns it all the same)
+        const std::vector<const Value*> cms = clusterMounts(t);
+        if (!cms.empty() && att != nullptr && att[0] != SWP_NO_VOLUME) {
+            Value vols = Value::array();
+            for (size_t m = 0; m < cms.size(); ++m) {
+                if (att[m] >= vol_idx_to_id_.size()) fail(SWP_EINVAL, "engine returned an unknown volume index");
+                Value va = Value::object();
+                va.set("ID", Value::str(vol_idx_to_id_[att[m]]));
+                va.set("Source", Value::str(as_str(cms[m]->get("Source"))));
+                va.set("Target", Value::str(as_str(cms[m]->get("Target"))));
+                vols.push(va);
+            }
+            newT.set("Volumes", vols);
+            reserveTaskVolumes(newT);
+        }
         allTasks_[tid] = newT;
         ni->second.Tasks[tid] = newT;
         lastDecisions_[tid] = PendingDecision{t, false};
         Value d = decision(t, newT);
         if (!want.empty()) d.set("AssignedGenericResources", *newT.get("AssignedGenericResources"));
+        if (newT.get("Volumes") != nullptr) d.set("Volumes", *newT.get("Volumes"));
         decisions.push(d);
     }
     // noSuitableNode, scheduler.go:928-971
@@ -1369,14 +1594,31 @@ class Scheduler {
         if (run.empty()) return;
         std::vector<int32_t> out(run.size(), -1);
         std::vector<uint32_t> hist(run.size() * SWP_NFILTERS, 0);
+        std::vector<uint32_t> with_mounts;   // tasks whose attachments are read back
+        for (size_t i = 0; i < run.size(); ++i)
+            if (descs[i].flags >> SWP_TASK_MOUNTS_SHIFT) with_mounts.push_back((uint32_t)i);
+        std::vector<uint32_t> att(with_mounts.size() * SWP_MAX_MOUNTS, SWP_NO_VOLUME);
         try {
-            ck(swp_schedule_batch(e_, descs.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_batch");
+            if (with_mounts.empty()) ck(swp_schedule_batch(e_, descs.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_batch");
+            else {   // the same in three steps: the batch is needed for its attachments
+                swp_batch* b = nullptr;
+                ck(swp_batch_prepare(e_, descs.data(), (uint32_t)descs.size(), &b), "swp_batch_prepare");
+                int rc = swp_batch_run(e_, b);
+                if (rc == SWP_OK) rc = swp_batch_fetch(e_, b, out.data(), hist.data());
+                if (rc == SWP_OK) rc = swp_batch_attachments(e_, b, with_mounts.data(), (uint32_t)with_mounts.size(), att.data());
+                if (rc != SWP_OK) engine_detail_ = std::string(swp_strerror(rc)) + ": " + swp_last_error(e_);
+                swp_batch_free(e_, b);
+                if (rc != SWP_OK) fail(rc, "swp_batch_run: " + engine_detail_);
+            }
         } catch (const Fail& f) {
             for (const Item& it : run) defer(it.first, it.second, f, decisions);
             return;
         }
+        size_t wm = 0;
         for (size_t i = 0; i < run.size(); ++i) {
-            if (out[i] >= 0) place(run[i].first, run[i].second, out[i], decisions);
+            const uint32_t* a = nullptr;
+            if (wm < with_mounts.size() && with_mounts[wm] == i) a = &att[wm++ * SWP_MAX_MOUNTS];
+            if (out[i] >= 0) place(run[i].first, run[i].second, out[i], decisions, a);
             else noSuitableNode(run[i].first, run[i].second, &hist[i * SWP_NFILTERS], decisions);
         }
         pushTouched();
@@ -1468,6 +1710,21 @@ int swp_sched_node_info(swp_sched* s, const char* node_id, size_t len, const cha
     return guarded(s, [&](swp::Scheduler& impl) {
         if (node_id == nullptr || json_out == nullptr) return (int)SWP_EINVAL;
         if (!impl.nodeInfo(std::string(node_id, len), impl.scratch)) return (int)SWP_ENOTFOUND;
+        *json_out = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_update_volume(swp_sched* s, const char* volume_json, size_t len) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (volume_json == nullptr) return (int)SWP_EINVAL;
+        impl.updateVolume(swp::json::parse(volume_json, len));
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_volume_info(swp_sched* s, const char* volume_id, size_t len, const char** json_out) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (volume_id == nullptr || json_out == nullptr) return (int)SWP_EINVAL;
+        if (!impl.volumeInfo(std::string(volume_id, len), impl.scratch)) return (int)SWP_ENOTFOUND;
         *json_out = impl.scratch.c_str();
         return (int)SWP_OK;
     });

@@ -81,6 +81,20 @@ class Scheduler:
         return self.e.intern(abi.SPACE_NODE_ID, nid)
 
     # ---- services / clock ----
+    def update_volume(self, doc):
+        """EventUpdateVolume (scheduler.go:200-213): taken once the plugin has created the volume (VolumeInfo.VolumeID)."""
+        b = _b(json.dumps(doc))
+        self._ck(self.L.swp_sched_update_volume(self.h, b, len(b)))
+
+    def volume_info(self, vid):
+        b = _b(vid)
+        out = C.c_char_p()
+        rc = self.L.swp_sched_volume_info(self.h, b, len(b), C.byref(out))
+        if rc == abi.SWP_ENOTFOUND:
+            return None
+        self._ck(rc)
+        return json.loads(out.value.decode())
+
     def set_service(self, sid, spec_version=None):
         b = _b(sid)
         self._ck(self.L.swp_sched_set_service(self.h, b, len(b), 0 if spec_version is None else 1, int(spec_version or 0)))

@@ -335,6 +335,21 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     }
     return SWP_OK;
 }
+// CSI volumes: the double keeps no volume model — node and volume updates are accepted and forgotten, a task with cluster mounts is refused
+// (the host layer defers it); the volume logic itself is tested against the oracle on the GPU (tests/test_engine_volumes.py)
+int swp_node_set_csi(swp_engine*, uint32_t, const swp_csi*, uint32_t, const swp_seg*, uint32_t) { return SWP_OK; }
+int swp_volume_upsert(swp_engine*, uint32_t, const swp_volume*, const uint32_t*, const swp_seg*) { return SWP_OK; }
+int swp_volume_set_usage(swp_engine*, uint32_t, const swp_volume_usage*) { return SWP_OK; }
+int swp_volume_get_usage(swp_engine*, uint32_t, swp_volume_usage* out) {
+    if (out) *out = swp_volume_usage{0, 0, SWP_PIN_NONE, 0};
+    return SWP_OK;
+}
+int swp_mount_set(swp_engine* e, const swp_mount*, uint32_t, uint32_t*) {
+    if (e) e->err = "the scripted engine double knows no volumes";
+    return SWP_EUNSUPPORTED;
+}
+int swp_choose_volumes(swp_engine*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
+int swp_batch_attachments(swp_engine*, swp_batch*, const uint32_t*, uint32_t, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_batch_prepare(swp_engine*, const swp_task_desc*, uint32_t, swp_batch**) { return SWP_EUNSUPPORTED; }
 int swp_batch_run(swp_engine*, swp_batch*) { return SWP_EUNSUPPORTED; }
 int swp_batch_fetch(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }

@@ -1,0 +1,224 @@
+"""GPU: CSI volumes through the host layer inside libswp.so + the HIP engine (VolumesFilter rows per round, chooseTaskVolumes and the
+reservations in the apply step, the pair check of preassigned tasks) against the oracle: the reference's vectors (tests/kat_volumes.py)
+as event scripts, and seeded random clusters."""
+import os
+import random
+
+import pytest
+
+import kat_volumes as kv
+import orc
+import scenarios as sc
+from swarmkit_amd import host as swhost
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def cxx_host(monkeypatch):
+    monkeypatch.setenv("SWP_HOST", "cxx")   # (the Python twin of the host layer knows no volumes)
+
+
+class Both:
+    """The same events into the oracle and into the engine's host layer; every tick's decisions and the volumes' users must agree."""
+
+    def __init__(self):
+        self.o, self.e = orc.Oracle(), swhost.HostScheduler()
+        self.vols = []
+
+    def __getattr__(self, name):
+        def call(*a):
+            ro, re = getattr(self.o, name)(*a), getattr(self.e, name)(*a)
+            if name == "update_volume":
+                self.vols.append(a[0]["ID"])
+            return ro, re
+        return call
+
+    @staticmethod
+    def _norm(ds):
+        return sorted((d["ID"], d["NodeID"], d["State"], d["Err"], tuple((v["ID"], v["Source"], v["Target"]) for v in d.get("Volumes") or ())) for d in ds)
+
+    def tick(self):
+        do, de = self._norm(self.o.tick()), self._norm(self.e.tick())
+        assert do == de, [(a, b) for a, b in zip(do, de) if a != b][:4]
+        self.check_volumes()
+        return do
+
+    def process_preassigned(self):
+        do, de = self._norm(self.o.process_preassigned()), self._norm(self.e.process_preassigned())
+        assert do == de, [(a, b) for a, b in zip(do, de) if a != b][:4]
+        self.check_volumes()
+        return do
+
+    def check_volumes(self):
+        for vid in self.vols:
+            io, ie = self.o.volume_info(vid), self.e.volume_info(vid)
+            assert (io is None) == (ie is None), vid
+            if io is None:
+                continue
+            assert io["Tasks"] == ie["Tasks"], (vid, io, ie)
+            assert ie["Engine"]["Tasks"] == len(io["Tasks"]) and ie["Engine"]["Writers"] == sum(1 for u in io["Tasks"].values() if not u["ReadOnly"]), (vid, io, ie)
+
+
+def _mount_task(tid, svc, mounts, **kw):
+    return sc.pending(tid, svc, Spec={"Container": {"Mounts": mounts}}, **kw)
+
+
+@pytest.mark.parametrize("name,mode,in_use,in_top,ro,want", kv.CHECK_VOLUME, ids=[c[0] for c in kv.CHECK_VOLUME])
+def test_check_volume_table_through_the_tick(name, mode, in_use, in_top, ro, want):
+    """volumes_test.go:270-341 as a cluster: the table's node, its volume (named here, so that a mount can ask for it), the users the entry
+    says, and one new task whose mount asks for the volume: it is placed on the node iff checkVolume says so."""
+    v, n, reserve = kv.check_volume_case(mode, in_use, in_top)
+    v["Spec"]["Annotations"] = {"Name": "theVolume"}
+    b = Both()
+    b.create_node(dict(n, Status={"State": orc.READY}))
+    b.create_node({"ID": "someOtherNode", "Status": {"State": orc.DOWN}, "Description": {}})
+    b.update_volume(v)
+    b.set_service("svc")
+    for vol, task, node, usage_ro in reserve:   # the users: tasks that sit on their nodes when the scheduler starts
+        b.setup_task({"ID": task, "ServiceID": "other", "NodeID": node, "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING},
+                      "Spec": {"Container": {"Mounts": [kv.cluster_mount("theVolume", "/m", usage_ro)]}}, "Volumes": [{"ID": vol, "Source": "theVolume", "Target": "/m"}]})
+    b.create_task(_mount_task("new", "svc", [kv.cluster_mount("theVolume", "/data", ro)]))
+    d = b.tick()
+    assert (d[0][1] == "someNode") is want, d
+
+
+def test_group_and_name_mounts_and_the_order_of_a_group():
+    node, vols = kv.group_fixture()
+    b = Both()
+    b.create_node(dict(node, Status={"State": orc.READY}))
+    for v in vols:
+        b.update_volume(v)
+    b.set_service("svc")
+    b.create_task(_mount_task("t1", "svc", [kv.cluster_mount("volumeName1", "/a")]))
+    b.create_task(_mount_task("t2", "svc", [kv.cluster_mount("volumeNameNotReal", "/a")]))
+    b.create_task(_mount_task("t3", "svc", [kv.cluster_mount("group:someVolumeGroup", "/a")]))
+    b.create_task(_mount_task("t4", "svc", [kv.cluster_mount("group:noSuchGroup", "/a")]))
+    d = {x[0]: x for x in b.tick()}
+    assert d["t1"][1] == "someNode" and d["t1"][4] == (("volume1", "volumeName1", "/a"),)
+    assert d["t2"][1] == "" and d["t2"][3] == "no suitable node (cannot fulfill requested CSI volume mounts on 1 node)"
+    assert d["t3"][4] == (("volume3", "group:someVolumeGroup", "/a"),)   # the group's first volume
+    assert d["t4"][1] == ""
+
+
+def test_choose_task_volumes_in_the_apply_step():
+    """volumes_test.go:468-531 through a tick: a group mount, two named mounts, a bind mount between them."""
+    v1, v2, v3 = kv.canned_volume(1, "volumeGroup"), kv.canned_volume(2), kv.canned_volume(3)
+    b = Both()
+    b.create_node({"ID": "node1", "Status": {"State": orc.READY}, "Description": {}})
+    for v in (v1, v2, v3):
+        b.update_volume(v)
+    b.set_service("svc")
+    mounts = [kv.cluster_mount("group:volumeGroup", "/somedir", True), kv.cluster_mount("volume2", "/someOtherDir"),
+              {"Type": "BIND", "Source": "/some/subdir", "Target": "/some/container/dir"}, kv.cluster_mount("volume3", "/some/third/dir")]
+    b.create_task(_mount_task("taskID1", "svc", mounts))
+    d = b.tick()
+    assert d[0][4] == (("volumeID1", "group:volumeGroup", "/somedir"), ("volumeID2", "volume2", "/someOtherDir"), ("volumeID3", "volume3", "/some/third/dir"))
+    # ANY mount satisfiable passes the filter; a mount without a volume: assigned without attachments (filter.go:424-432, scheduler.go:862-872)
+    b.create_task(_mount_task("t2", "svc", [kv.cluster_mount("volume2", "/a"), kv.cluster_mount("missing", "/b")]))
+    d = b.tick()
+    assert d[0][1] == "node1" and d[0][4] == ()
+
+
+def test_scheduler_start_up_and_a_preassigned_task():
+    """scheduler_ginkgo_test.go:376-596 (+ the pair check of the pending preassigned task, scheduler.go:646-690)."""
+    def csi_node(i):
+        return {"ID": "nodeID%d" % i, "Spec": {"Annotations": {"Name": "node%d" % i}}, "Status": {"State": orc.READY},
+                "Description": {"Hostname": "nodeHost%d" % i, "CSIInfo": [{"PluginName": "somePlug", "NodeID": "nodeCSI%d" % i}]}}
+
+    def vol(i, group, scope, sharing):
+        return {"ID": "volumeID%d" % i, "Spec": {"Annotations": {"Name": "volume%d" % i}, "Group": group, "Driver": {"Name": "somePlug"},
+                                                 "AccessMode": {"Scope": scope, "Sharing": sharing}}, "VolumeInfo": {"VolumeID": "csi%d" % i}}
+    b = Both()
+    for i in range(3):
+        b.create_node(csi_node(i))
+    for v in (vol(1, "group1", kv.MULTI, kv.ALL), vol(2, "group2", kv.SINGLE, kv.NONE), vol(3, "group2", kv.SINGLE, kv.NONE)):
+        b.update_volume(v)
+    running = {"ID": "runningTask", "NodeID": "nodeID0", "Status": {"State": orc.RUNNING}, "DesiredState": orc.RUNNING,
+               "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume1", "/var/"), kv.cluster_mount("group:group2", "/home/")]}},
+               "Volumes": [{"Source": "volume1", "Target": "/var/", "ID": "volumeID1"}, {"Source": "group:group2", "Target": "/home/", "ID": "volumeID3"}]}
+    shutdown = {"ID": "shutdownTask", "NodeID": "nodeID1", "Status": {"State": orc.SHUTDOWN}, "DesiredState": orc.SHUTDOWN,
+                "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume1", "/foo/")]}}, "Volumes": [{"Source": "volume1", "Target": "/foo/", "ID": "volumeID1"}]}
+    pending = {"ID": "pendingID", "NodeID": "nodeID2", "Status": {"State": orc.PENDING}, "DesiredState": orc.RUNNING,
+               "Spec": {"Container": {"Mounts": [kv.cluster_mount("group:group2", "/foo/")]}}}
+    for t in (running, shutdown, pending):
+        b.setup_task(t)
+    b.check_volumes()
+    d = b.process_preassigned()
+    assert d == [("pendingID", "nodeID2", orc.ASSIGNED, "", (("volumeID2", "group:group2", "/foo/"),))]
+    b.delete_task(running)
+    b.check_volumes()
+
+
+def test_a_volume_that_is_not_created_yet_and_one_that_cannot_be_shared():
+    b = Both()
+    b.create_node({"ID": "nodeID1", "Status": {"State": orc.READY}, "Description": {"CSIInfo": [{"PluginName": "somePlug", "NodeID": "nodeCSI1"}]}})
+    b.set_service("service1")
+    b.create_task(_mount_task("task1", "service1", [kv.cluster_mount("volume1", "/var/")]))
+    assert b.tick()[0][3] == "no suitable node (cannot fulfill requested CSI volume mounts on 1 node)"
+    volume = {"ID": "volumeID1", "Spec": {"Annotations": {"Name": "volume1"}, "Driver": {"Name": "somePlug"}, "AccessMode": {"Scope": kv.SINGLE, "Sharing": kv.NONE}}}
+    b.update_volume(volume)
+    assert b.tick()[0][1] == ""
+    b.update_volume(dict(volume, VolumeInfo={"VolumeID": "csi1"}))
+    assert b.tick() == [("task1", "nodeID1", orc.ASSIGNED, "", (("volumeID1", "volume1", "/var/"),))]
+    b.create_task(_mount_task("task2", "service1", [kv.cluster_mount("volume1", "/var/")]))
+    assert b.tick()[0][1] == ""
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
+def test_random_clusters_with_volumes(seed):
+    """Nodes with CSI topologies, volumes of every access mode in groups, tasks with one to three cluster mounts (named, grouped, read-only)
+    next to plain tasks, several ticks with tasks going away in between: every decision, attachment and reservation as the oracle's."""
+    rng = random.Random(0xC51 + seed)
+    b = Both()
+    zones = ["z1", "z2", "z3"]
+    n_nodes = rng.choice([3, 8, 40, 150])
+    for i in range(n_nodes):
+        csi = []
+        for plug in ("p1", "p2"):
+            if rng.random() < 0.8:
+                c = {"PluginName": plug}
+                if rng.random() < 0.8:
+                    c["AccessibleTopology"] = {"Segments": {"zone": rng.choice(zones), **({"rack": rng.choice("ab")} if rng.random() < 0.5 else {})}}
+                csi.append(c)
+        b.create_node({"ID": "n%04d" % i, "Status": {"State": orc.READY}, "Spec": {"Annotations": {"Labels": {"zone": rng.choice(zones)}}},
+                       "Description": {"Resources": {"NanoCPUs": 8 * 10**9, "MemoryBytes": 16 << 30}, "CSIInfo": csi}})
+    n_vol = rng.choice([2, 6, 20])
+    for v in range(n_vol):
+        acc = []
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            acc.append({"Segments": {"zone": rng.choice(zones), **({"rack": rng.choice("ab")} if rng.random() < 0.3 else {})}})
+        b.update_volume({"ID": "vol%02d" % v, "Spec": {"Annotations": {"Name": "name%02d" % v}, "Group": rng.choice(["", "g1", "g2"]), "Driver": {"Name": rng.choice(["p1", "p2"])},
+                                                       "AccessMode": {"Scope": rng.choice([kv.SINGLE, kv.MULTI]), "Sharing": rng.choice([kv.NONE, kv.READ_ONLY, kv.ONE_WRITER, kv.ALL])},
+                                                       "Availability": rng.choice(["ACTIVE", "ACTIVE", "ACTIVE", "PAUSE"])},
+                         "VolumeInfo": {"VolumeID": "csi%02d" % v, "AccessibleTopology": acc}})
+    for s in range(4):
+        b.set_service("svc%d" % s)
+    placed, tid, docs = [], 0, {}
+    for tick in range(5):
+        for _ in range(rng.choice([5, 30, 120])):
+            tid += 1
+            if rng.random() < 0.5:
+                mounts = []
+                for m in range(rng.choice([1, 1, 2, 3])):
+                    src = rng.choice(["name%02d" % rng.randrange(n_vol + 1), "group:" + rng.choice(["", "g1", "g2", "g9"])])
+                    mounts.append(kv.cluster_mount(src, rng.choice(["/a", "/b", "/c"]), rng.random() < 0.4))
+                if rng.random() < 0.2:
+                    mounts.insert(rng.randrange(len(mounts) + 1), {"Type": "BIND", "Source": "/x", "Target": "/y"})
+                t = _mount_task("t%05d" % tid, "svc%d" % rng.randrange(4), mounts)
+            else:
+                t = sc.pending("t%05d" % tid, "svc%d" % rng.randrange(4))
+            if rng.random() < 0.5:
+                t.setdefault("Spec", {})["Resources"] = {"Reservations": {"NanoCPUs": rng.choice([1, 2]) * 10**8, "MemoryBytes": 64 << 20}}
+            docs[t["ID"]] = t
+            b.create_task(t)
+        for d in b.tick():
+            if d[1]:
+                placed.append(d)
+        # some of the placed tasks go away: their volumes are free again
+        rng.shuffle(placed)
+        for d in placed[: len(placed) // 3]:
+            doc = dict(docs[d[0]], NodeID=d[1], Status={"State": orc.ASSIGNED}, Volumes=[{"ID": v[0], "Source": v[1], "Target": v[2]} for v in d[4]])
+            b.delete_task(doc)
+        placed = placed[len(placed) // 3:]
+        b.check_volumes()

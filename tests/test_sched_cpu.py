@@ -121,7 +121,7 @@ def odd_task_bits(rng, t):
         spec["Container"] = {"Mounts": [{"Type": rng.choice([1, "VOLUME", 0, "BIND"]), "VolumeOptions": {"DriverConfig": {"Name": rng.choice(["nfs", "local", "", "ceph"])}}},
                                         {"Type": 1, "VolumeOptions": {}}]}
     elif r < 0.22:
-        spec["Container"] = {"Mounts": [{"Type": rng.choice([4, "CLUSTER"])}]}          # CSI: unsupported
+        spec["Container"] = {"Mounts": [{"Type": rng.choice([4, "CLUSTER"]), "Source": "v%d" % q, "Target": "/m%d" % q} for q in range(9)]}   # more cluster mounts than swp_mount_set takes: unsupported (the Python twin knows no volumes at all)
     elif r < 0.25:
         spec["Resources"] = {"Reservations": {"NanoCPUs": 10**9, "Generic": [{"DiscreteResourceSpec": {"Kind": "gpu", "Value": 1}}]}}   # unsupported
     pl = dict(spec.get("Placement") or {})
