@@ -312,6 +312,11 @@ int swp_schedule_batch(swp_engine*, const swp_task_desc* tasks, uint32_t n_tasks
  *                  (scheduler.go:929), written for groups with left-over tasks */
 int swp_schedule_groups(swp_engine*, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups,
                         int32_t* out_node, uint32_t* out_fail_hist);
+/* The same for a call with groups whose tasks have cluster mounts (SWP_TASK_MOUNTS): out_att[i * SWP_MAX_MOUNTS + m] = the volume chosen for
+ * mount m of the call's i-th task on its node (chooseTaskVolumes, scheduler.go:857-872), SWP_NO_VOLUME as for swp_batch_attachments. The
+ * volumes' usage numbers are left as the call made them. */
+int swp_schedule_groups_volumes(swp_engine*, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups,
+                                int32_t* out_node, uint32_t* out_fail_hist, uint32_t* out_att);
 
 /* The same in three steps so that a caller (bench.py) can time the device pass alone:
  *   prepare: de-duplicate predicate sets, upload descriptors and per-service state

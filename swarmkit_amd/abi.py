@@ -104,7 +104,7 @@ class Generic(C.Structure):
 
 EXPORTS = [
     "swp_generic_set", "swp_node_set_generic", "swp_node_get_generic",
-    "swp_node_set_csi", "swp_volume_upsert", "swp_volume_set_usage", "swp_volume_get_usage", "swp_mount_set", "swp_choose_volumes", "swp_batch_attachments",
+    "swp_node_set_csi", "swp_volume_upsert", "swp_volume_set_usage", "swp_volume_get_usage", "swp_mount_set", "swp_choose_volumes", "swp_batch_attachments", "swp_schedule_groups_volumes",
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",

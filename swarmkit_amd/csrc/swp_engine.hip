@@ -994,7 +994,6 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             b->csi_set.push_back(tasks[i].flags >> SWP_TASK_MOUNTS_SHIFT);
             b->csi_task.push_back(i);
         }
-    if (!b->csi_set.empty() && weights) return e->fail(SWP_EUNSUPPORTED, "a task group with cluster mounts: its tasks go through swp_schedule_batch one by one");
     mark("runs");
     // per-service exception lists: nodes with svcCount>0 or ≥ maxFailures recent failures
     b->list_off.assign(b->n_svc + 1, 0);
@@ -2395,8 +2394,18 @@ int swp_node_get_generic(swp_engine* e, uint32_t node, uint32_t kind, int64_t* c
 
 static int groups_apply_to_host(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, uint64_t total, const int32_t* out_node);
 
+static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node, uint32_t* out_fail_hist, uint32_t* out_att);
 int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node,
                         uint32_t* out_fail_hist) {
+    return schedule_groups_impl(e, groups, sizes, n_groups, out_node, out_fail_hist, nullptr);
+}
+int swp_schedule_groups_volumes(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node,
+                                uint32_t* out_fail_hist, uint32_t* out_att) {
+    if (!out_att && n_groups) return SWP_EINVAL;
+    return schedule_groups_impl(e, groups, sizes, n_groups, out_node, out_fail_hist, out_att);
+}
+static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node,
+                                uint32_t* out_fail_hist, uint32_t* out_att) {
     if (!e || (!groups && n_groups) || (!sizes && n_groups)) return SWP_EINVAL;
     if (n_groups == 0) return SWP_OK;
     (void)hipSetDevice(e->device);
@@ -2479,7 +2488,7 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
         max_depth = std::max<uint32_t>(max_depth, (uint32_t)levels.size());
     }
     std::vector<GroupRec2> recs(n_groups);
-    uint32_t off = 0;
+    uint32_t off = 0, att_rows = 0;   // att_rows: tasks of the groups with cluster mounts
     size_t arena_bytes = 64;
     for (uint32_t g = 0; g < n_groups; ++g) {
         const RTask& r = b.rt[g];
@@ -2489,6 +2498,12 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
         q.cls_con = r.cls_con; q.cls_plat = r.cls_plat; q.cls_plug = r.cls_plug; q.maxrep = r.maxrep;
         q.tree = tree_local[groups[g].spread_set];
         q.dep_prev = g > 0 && b.rt[g - 1].svc == r.svc;
+        q.mset = groups[g].flags >> SWP_TASK_MOUNTS_SHIFT;
+        if (q.mset) {   // its VolumesFilter depends on the volumes every earlier group took: nothing of it is prepared ahead
+            q.att_off = att_rows;
+            att_rows += sizes[g];
+            if (g > 0) q.dep_prev = 1;
+        }
         if (groups[g].generic_set) {
             const auto& gs = e->gen_sets[groups[g].generic_set];
             if (gs.size() > G2_MAXGEN) return e->fail(SWP_ERANGE, "group %u reserves %zu generic kinds (the engine takes %d)", g, gs.size(), G2_MAXGEN);
@@ -2559,6 +2574,14 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
     hipEvent_t gev0 = nullptr, gev1 = nullptr;
     if (gdbg) { (void)hipEventCreate(&gev0); (void)hipEventCreate(&gev1); (void)hipEventRecord(gev0, st); }
+    DevBuf d_gatt;
+    if (att_rows) {
+        if ((rc = flush_volumes(e))) return rc;
+        HIPCHECK(e, d_gatt.reserve((size_t)att_rows * SWP_MAX_MOUNTS * 4));
+        HIPCHECK(e, hipMemsetAsync(d_gatt.p, 0xFF, (size_t)att_rows * SWP_MAX_MOUNTS * 4, st));
+        ga.vol = vol_view(e);
+        ga.att = d_gatt.as<uint32_t>();
+    }
     HIPCHECK(e, launch_groups2(ga, st, e->device));
     if (gdbg) {
         (void)hipEventRecord(gev1, st);
@@ -2578,8 +2601,23 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     HIPCHECK(e, hipStreamSynchronize(st));
     if (ctl.error != ERR_NONE) {
         e->dev_dynamic_dirty = true;   // device rows may be half-updated: the host mirror (untouched) is re-uploaded
+        e->vol_dyn_dirty = true;
         if (ctl.error == ERR_GROUP_HANG) return e->fail(SWP_EHIP, "the group kernel's waves lost each other (a wait exceeded its bound): nothing was applied");
         return e->fail(SWP_ERANGE, "a node's key left its range (>= 256 recent failures or >= 2^24 tasks of one service on a node)");
+    }
+    if (out_att) std::fill(out_att, out_att + (size_t)total * SWP_MAX_MOUNTS, SWP_NO_VOLUME);
+    if (att_rows) {   // the attachments of the groups with cluster mounts, and the volumes' usage as the call left it
+        std::vector<uint32_t> h((size_t)att_rows * SWP_MAX_MOUNTS);
+        std::vector<swp_volume_usage> dyn(e->volumes.size());
+        HIPCHECK(e, hipMemcpyAsync(h.data(), d_gatt.p, h.size() * 4, hipMemcpyDeviceToHost, st));
+        if (!dyn.empty()) HIPCHECK(e, hipMemcpyAsync(dyn.data(), e->d_vdyn.p, dyn.size() * sizeof(swp_volume_usage), hipMemcpyDeviceToHost, st));
+        HIPCHECK(e, hipStreamSynchronize(st));
+        for (size_t v = 0; v < dyn.size(); ++v)
+            if (e->volumes[v].present) e->volumes[v].use = dyn[v];
+        if (out_att)
+            for (uint32_t g = 0; g < n_groups; ++g)
+                if (recs[g].mset)
+                    std::memcpy(out_att + (size_t)recs[g].out_off * SWP_MAX_MOUNTS, h.data() + (size_t)recs[g].att_off * SWP_MAX_MOUNTS, (size_t)sizes[g] * SWP_MAX_MOUNTS * 4);
     }
     return groups_apply_to_host(e, groups, sizes, n_groups, total, out_node);
 }

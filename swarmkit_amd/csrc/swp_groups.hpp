@@ -31,6 +31,7 @@
 #include <stddef.h>
 
 #include "swp_types.hpp"
+#include "swp_volumes.hpp"
 
 namespace swpdev {
 
@@ -63,7 +64,8 @@ struct GroupRec2 {   // one per group, 144 B
     u32 dep_prev;       // the previous group of the call is of the same service: nothing of this group is prepared ahead of its write-back
     u32 gkind[G2_MAXGEN];
     int32_t gval[G2_MAXGEN];
-    u32 pad[2];
+    u32 mset;           // mount set of the group's tasks (swp_volumes.hpp), 0: no cluster mounts
+    u32 att_off;        // first row of the group's tasks in Groups2Args.att
 };
 static_assert(sizeof(GroupRec2) == 144, "GroupRec2 layout");
 
@@ -113,6 +115,10 @@ struct Groups2Args {
     int32_t* out_node;
     u32* hist;               // [n_groups][8]
     Ctl* ctl;
+    // CSI volumes (groups with mset != 0): the VolumesFilter is evaluated from the volumes as they are — at tree() time and whenever the
+    // fill loop re-checks a node — and every placement chooses and reserves its volumes (scheduler.go:857-874)
+    VolView vol;
+    u32* att;                // [tasks of the groups with mounts][VOL_MAX_MOUNTS]
 };
 
 struct G2Frame {   // one invocation of scheduleNTasksOnSubtree (scheduler.go:772-825)
@@ -337,6 +343,7 @@ WV_DEV u64 g2_eval_node(const Groups2Args& a, const GroupRec2& G, const GroupRec
                     if (a.portmap[(size_t)a.pset_ids[q] * Wn + w] & bit) busy = true;
             if (busy) ff = 5;
             else if ((G.flags & RT_MAXREP) && !((u64)sv < G.maxrep)) ff = 6;
+            else if (G.mset && !((vol_filter_word(a.vol, G.mset, w) >> (n & 63u)) & 1ull)) ff = 7;   // VolumesFilter, the pipeline's last entry
         }
         if (!g2_key_ok(fl, sv)) a.ctl->error = ERR_GROUP_RANGE;
         key = g2_key(fl, sv, a.total[n]);
@@ -366,7 +373,7 @@ struct G2Mail {   // LDS
     // what lane 0 of the machine hands to its other lanes
     u32 sh[16];
 };
-enum { SH_LEFT = 2, SH_NTOUCH = 3, SH_ERR = 4, SH_LASTP = 5, SH_C1 = 6, SH_C5 = 7, SH_C6 = 8, SH_FPASS = 9 };
+enum { SH_LEFT = 2, SH_NTOUCH = 3, SH_ERR = 4, SH_LASTP = 5, SH_C1 = 6, SH_C5 = 7, SH_C6 = 8, SH_FPASS = 9, SH_C7 = 10 };
 
 struct G2Stage {   // LDS: the candidates of one 64-node word, compacted in node order: {key, node, leaf} as one 16-byte record each
     G2Ent ent[64];
@@ -445,7 +452,7 @@ WV_DEV void g2_helper(const Groups2Args& a, G2Mail* mb, u32 hid, u32 nh) {
                         if (a.xadm[lf] < (int32_t)k || a.keybuf[(size_t)b * N + n] < a.xroot[lf]) f = ffn;
                     }
                 }
-                for (u32 q = 0; q < 7; ++q) {
+                for (u32 q = 0; q < 8; ++q) {
                     const u64 bm = wv::ballot(f == q);
                     if (bm && lane == 0) wv::lds_add32(&mb->cntx[q], (u32)wv::popc64(bm));
                 }
@@ -831,7 +838,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
     // the lesser one (:899-903), it passes Process (it did at admission and nothing touched it since), and the k-th placement returns
     // (:893-895). All lanes verify the key condition for their positions; if it holds, they place their tasks themselves.
     bool filled = false;
-    if (single && !(G.flags & RT_UNCOUNTED) && k <= (u32)A.h_cnt[0]) {
+    if (single && !(G.flags & RT_UNCOUNTED) && k <= (u32)A.h_cnt[0] && !G.mset) {   // (a task with cluster mounts changes what the NEXT node's Process sees)
         bool off = false;
         for (u32 j = lane; j < k; j += 64) {
             const u64 kj = A.HE[j].key + G2_KEY_STEP;
@@ -855,7 +862,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             }
             if (lane == 0) {
                 mb->sh[SH_LEFT] = 0; mb->sh[SH_NTOUCH] = k; mb->sh[SH_ERR] = 0;
-                mb->sh[SH_C1] = 0; mb->sh[SH_C5] = 0; mb->sh[SH_C6] = 0; mb->sh[SH_FPASS] = k >= 2 ? 1u : 0u;
+                mb->sh[SH_C1] = 0; mb->sh[SH_C5] = 0; mb->sh[SH_C6] = 0; mb->sh[SH_C7] = 0; mb->sh[SH_FPASS] = k >= 2 ? 1u : 0u;
             }
             filled = true;
         }
@@ -864,7 +871,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
     // ---------- tree walk + fill loops: lane 0, on the arena only ----------
     if (!filled && lane == 0) {
         u32 next_task = 0, ntouch = 0;
-        u32 c1 = 0, c5 = 0, c6 = 0, fpass = 0;   // Explain counters of the fill phase (only Resource / HostPort / MaxReplicas can fail there)
+        u32 c1 = 0, c5 = 0, c6 = 0, c7 = 0, fpass = 0;   // Explain counters of the fill phase (only Resource / HostPort / MaxReplicas / Volumes can fail there)
         bool bad_key = false;
         const bool has_ports = (G.flags & RT_PORTS) != 0, has_res = (G.flags & RT_RES) != 0, has_maxrep = (G.flags & RT_MAXREP) != 0;
         const bool counted = !(G.flags & RT_UNCOUNTED);
@@ -883,10 +890,12 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 if (has_ports && e.tix != G2_NONE) ff = 5;
                 else if (has_maxrep && !((u64)((u32)(e.key >> 32) & 0xFFFFFFu) < G.maxrep)) ff = 6;
             }
-            if (ff == G2_FF_PASS) { c1 = c5 = c6 = 0; fpass = 1; }
+            if (ff == G2_FF_PASS && G.mset && !((vol_filter_word(a.vol, G.mset, e.node >> 6) >> (e.node & 63u)) & 1ull)) ff = 7;   // the volumes as the group's placements left them
+            if (ff == G2_FF_PASS) { c1 = c5 = c6 = c7 = 0; fpass = 1; }
             else if (ff == 1) ++c1;
             else if (ff == 5) ++c5;
-            else ++c6;
+            else if (ff == 6) ++c6;
+            else ++c7;
             return ff == G2_FF_PASS;
         };
         // scheduleNTasksOnNodes, scheduler.go:844-924, on the leaf's positions [base, base+cnt). The current entry and the one behind
@@ -906,6 +915,12 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             while (next_task < k) {
                 const u32 pos = base + (u32)ix;
                 a.out_node[G.out_off + next_task] = (int32_t)ce.node;
+                if (G.mset) {   // chooseTaskVolumes + reserveTaskVolumes on the node (scheduler.go:857-874); a mount without a volume: no attachments
+                    u32 att[VOL_MAX_MOUNTS];
+                    const u32 na = vol_choose(a.vol, G.mset, ce.node, att, nullptr);
+                    if (na) vol_reserve(a.vol, G.mset, ce.node, att, na);
+                    for (u32 q = 0; q < VOL_MAX_MOUNTS; ++q) a.att[((size_t)G.att_off + next_task) * VOL_MAX_MOUNTS + q] = att[q];
+                }
                 ++next_task;
                 cr.cpu -= G.cpu;   // NodeInfo.addTask (nodeinfo.go:108-154)
                 cr.mem -= G.mem;
@@ -1055,7 +1070,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         mb->sh[SH_LEFT] = k - next_task;
         mb->sh[SH_NTOUCH] = ntouch;
         mb->sh[SH_ERR] = bad_key ? 1u : 0u;
-        mb->sh[SH_C1] = c1; mb->sh[SH_C5] = c5; mb->sh[SH_C6] = c6; mb->sh[SH_FPASS] = fpass;
+        mb->sh[SH_C1] = c1; mb->sh[SH_C5] = c5; mb->sh[SH_C6] = c6; mb->sh[SH_C7] = c7; mb->sh[SH_FPASS] = fpass;
     }
     wv::wave_sync();
     if (mb->sh[SH_ERR]) {
@@ -1079,6 +1094,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             if (lane == 1) v += mb->sh[SH_C1];
             if (lane == 5) v += mb->sh[SH_C5];
             if (lane == 6) v += mb->sh[SH_C6];
+            if (lane == 7) v += mb->sh[SH_C7];
             a.hist[(size_t)gi * 8 + lane] = v;
         }
     }

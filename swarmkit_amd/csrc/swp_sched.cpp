@@ -1569,8 +1569,12 @@ class Scheduler {
         }
         std::vector<int32_t> out(total, -1);
         std::vector<uint32_t> hist(descs.size() * SWP_NFILTERS, 0);
+        bool any_mounts = false;
+        for (const swp_task_desc& d : descs) any_mounts = any_mounts || (d.flags >> SWP_TASK_MOUNTS_SHIFT) != 0;
+        std::vector<uint32_t> att(any_mounts ? total * SWP_MAX_MOUNTS : 0, SWP_NO_VOLUME);
         try {
-            ck(swp_schedule_groups(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_groups");
+            if (any_mounts) ck(swp_schedule_groups_volumes(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data(), att.data()), "swp_schedule_groups");
+            else ck(swp_schedule_groups(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_groups");
         } catch (const Fail& f) {
             if (to - from > 1) {   // find the group(s) the engine cannot take: run them one by one
                 for (size_t g = from; g < to; ++g) runGroups(groups, g, g + 1, decisions);
@@ -1583,7 +1587,7 @@ class Scheduler {
         for (size_t g = from; g < to; ++g) {
             for (size_t i = 0; i < groups[g].size(); ++i) {
                 const int32_t n = out[off + i];
-                if (n >= 0) place(groups[g][i].first, groups[g][i].second, n, decisions);
+                if (n >= 0) place(groups[g][i].first, groups[g][i].second, n, decisions, any_mounts ? &att[(off + i) * SWP_MAX_MOUNTS] : nullptr);
                 else noSuitableNode(groups[g][i].first, groups[g][i].second, &hist[(g - from) * SWP_NFILTERS], decisions);
             }
             off += groups[g].size();

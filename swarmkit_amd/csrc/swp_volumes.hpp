@@ -39,7 +39,7 @@ struct VolView {   // every pointer null while the engine has no volumes
     const VolMount* ms_mount;
 };
 
-#if defined(SWP_R6_KERNELS) || defined(SWP_VOL_KERNELS)   // device code: translation units that come with swp_wave.hpp (or the emulation's wv_emu.hpp)
+#if defined(SWP_R6_KERNELS) || defined(SWP_VOL_KERNELS) || defined(SWP_G2_KERNELS)   // device code: translation units that come with swp_wave.hpp (or the emulation's wv_emu.hpp)
 // the temporary reservations of the task's earlier mounts (chooseTaskVolumes reserves as it goes, volumes.go:128): the task counts once
 // per volume, its usage is the LAST reservation's (info.tasks[taskID] is overwritten)
 struct VolTemp { u32 vol[VOL_MAX_MOUNTS]; u32 ro[VOL_MAX_MOUNTS]; u32 n; };

@@ -222,3 +222,66 @@ def test_random_clusters_with_volumes(seed):
             b.delete_task(doc)
         placed = placed[len(placed) // 3:]
         b.check_volumes()
+
+
+def test_a_group_whose_tasks_share_a_volume_that_cannot_leave_its_node():
+    """A service's replicas (one task group) on a single-node volume that may be shared: the first placement pins the volume, the fill loop's
+    re-check (scheduler.go:912-920) then fails every other node of the heap, and all the replicas end up where the first one went."""
+    b = Both()
+    for i in range(4):
+        b.create_node({"ID": "n%d" % i, "Status": {"State": orc.READY}, "Description": {"CSIInfo": [{"PluginName": "p"}]}})
+    b.update_volume({"ID": "v1", "Spec": {"Annotations": {"Name": "shared"}, "Driver": {"Name": "p"}, "AccessMode": {"Scope": kv.SINGLE, "Sharing": kv.ALL}}, "VolumeInfo": {"VolumeID": "c1"}})
+    b.update_volume({"ID": "v2", "Spec": {"Annotations": {"Name": "solo"}, "Driver": {"Name": "p"}, "AccessMode": {"Scope": kv.MULTI, "Sharing": kv.NONE}}, "VolumeInfo": {"VolumeID": "c2"}})
+    b.set_service("svc", 1)
+    for j in range(6):
+        b.create_task(_mount_task("a%d" % j, "svc", [kv.cluster_mount("shared", "/data")], SpecVersion={"Index": 1}))
+    d = b.tick()
+    assert len({x[1] for x in d}) == 1 and all(x[4] == (("v1", "shared", "/data"),) for x in d), d
+    # a volume that cannot be shared at all: one replica gets it, the others stay pending with the filter's explanation
+    b.set_service("svc2", 1)
+    for j in range(3):
+        b.create_task(_mount_task("b%d" % j, "svc2", [kv.cluster_mount("solo", "/x")], SpecVersion={"Index": 1}))
+    d = b.tick()
+    assert sorted(bool(x[1]) for x in d) == [False, False, True], d
+    # (the counters are those of the Process calls behind the last passing one, pipeline.go:56-68: the fill loop's re-checks of the other three nodes)
+    assert {x[3] for x in d if not x[1]} == {"no suitable node (cannot fulfill requested CSI volume mounts on 3 nodes)"}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
+def test_random_task_groups_with_volumes(seed):
+    """Services with a spec version (task groups, scheduler.go:442-459) whose specs carry cluster mounts, next to groups without and one-off
+    tasks: tree() with the VolumesFilter, the fill loop's re-checks against the volumes as the group's own placements leave them."""
+    rng = random.Random(0x6C51 + seed)
+    b = Both()
+    zones = ["z1", "z2"]
+    n_nodes = rng.choice([4, 12, 60])
+    for i in range(n_nodes):
+        csi = [{"PluginName": "p1", "AccessibleTopology": {"Segments": {"zone": rng.choice(zones)}}}] if rng.random() < 0.9 else []
+        b.create_node({"ID": "n%04d" % i, "Status": {"State": orc.READY}, "Spec": {"Annotations": {"Labels": {"zone": rng.choice(zones)}}},
+                       "Description": {"Resources": {"NanoCPUs": 4 * 10**9, "MemoryBytes": 8 << 30}, "CSIInfo": csi}})
+    n_vol = rng.choice([3, 8])
+    for v in range(n_vol):
+        acc = [{"Segments": {"zone": rng.choice(zones)}}] if rng.random() < 0.6 else []
+        b.update_volume({"ID": "vol%02d" % v, "Spec": {"Annotations": {"Name": "name%02d" % v}, "Group": rng.choice(["g1", "g2"]), "Driver": {"Name": "p1"},
+                                                       "AccessMode": {"Scope": rng.choice([kv.SINGLE, kv.MULTI]), "Sharing": rng.choice([kv.NONE, kv.READ_ONLY, kv.ONE_WRITER, kv.ALL])}},
+                         "VolumeInfo": {"VolumeID": "csi%02d" % v, "AccessibleTopology": acc}})
+    tid = 0
+    for tick in range(4):
+        for s in range(rng.choice([2, 5])):
+            sid = "svc%d_%d" % (tick, s)
+            b.set_service(sid, 1)
+            spec = {}
+            if rng.random() < 0.7:
+                mounts = [kv.cluster_mount(rng.choice(["name%02d" % rng.randrange(n_vol), "group:" + rng.choice(["g1", "g2"])]), "/m%d" % m, rng.random() < 0.4) for m in range(rng.choice([1, 1, 2]))]
+                spec["Container"] = {"Mounts": mounts}
+            if rng.random() < 0.5:
+                spec["Resources"] = {"Reservations": {"NanoCPUs": 5 * 10**8, "MemoryBytes": 256 << 20}}
+            if rng.random() < 0.3:
+                spec["Placement"] = {"Preferences": [{"Spread": {"SpreadDescriptor": "node.labels.zone"}}]}
+            for _ in range(rng.choice([1, 3, 9, 25])):
+                tid += 1
+                b.create_task(sc.pending("t%05d" % tid, sid, Spec=spec, SpecVersion={"Index": 1}))
+        for _ in range(rng.choice([0, 4])):
+            tid += 1
+            b.create_task(_mount_task("t%05d" % tid, "svc%d_0" % tick, [kv.cluster_mount("group:g1", "/one")]))
+        b.tick()
