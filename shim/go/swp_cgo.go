@@ -37,7 +37,10 @@ import (
 
 type swpEngine struct {
 	e       *C.swp_engine
-	idxNode []string // dense node index (canonical scan order = order of first intern) -> api.Node.ID
+	idxNode []string // dense node index (a removed node's index goes to the next new node: entries are overwritten) -> api.Node.ID
+	nodeIdx map[string]C.uint32_t // the inverse, for volume usage (dropped on nodeSet.remove)
+	volumeID []string             // SWP_SPACE_VOLUME index -> api.Volume.ID
+	vs      *volumeSet            // Scheduler.volumes: byName resolves a mount's Source when the task's descriptor is built
 	// failure counts the engine holds: a bucket erased by cleanupFailures must be reset there too (Scheduler::pushFailures)
 	pushed map[failureBucket]uint32
 }
@@ -195,20 +198,29 @@ func (s *swpEngine) upsert(n NodeInfo) error {
 	return s.pushGeneric(row.node, n.AvailableResources.Generic)
 }
 
-// genericCounts: AvailableResources.Generic as ONE count per kind — the value of a Discrete resource, the number of Named ones
-// (genericresource.HasEnough, validate.go:24-52, compares exactly these for both kinds).
+// genericCounts: AvailableResources.Generic as ONE count per kind, as genericresource.HasEnough (validate.go:24-52) reads the list: the
+// FIRST entry of the kind decides — a Discrete entry counts its Value, a Named one counts the Named entries of the kind (a list that
+// mixes both for one kind, which sanitize can leave behind after a node changed its resource type, is judged by its first entry).
+// Same rule as csrc/swp_generic.hpp counts().
 func (s *swpEngine) genericCounts(rs []*api.GenericResource) []C.swp_generic {
 	acc := map[string]int64{}
+	discrete := map[string]bool{}
 	var order []string
 	for _, r := range rs {
 		k := genericresource.Kind(r)
+		d := r.GetDiscreteResourceSpec()
 		if _, seen := acc[k]; !seen {
 			order = append(order, k)
+			discrete[k] = d != nil
+			if d != nil {
+				acc[k] = d.Value
+			} else {
+				acc[k] = 1
+			}
+			continue
 		}
-		if d := r.GetDiscreteResourceSpec(); d != nil {
-			acc[k] += d.Value
-		} else {
-			acc[k]++
+		if !discrete[k] && d == nil {
+			acc[k]++ // another Named value of a kind whose first entry is Named
 		}
 	}
 	out := make([]C.swp_generic, 0, len(order))
@@ -400,9 +412,6 @@ func (s *swpEngine) pluginSet(t *api.Task) (C.uint32_t, bool) {
 	var req []C.uint32_t
 	if c := t.Spec.GetContainer(); c != nil {
 		for _, m := range c.Mounts {
-			if m.Type == api.MountTypeCluster {
-				return 0, false // CSI cluster volumes stay on the Go path
-			}
 			if m.Type == api.MountTypeVolume && m.VolumeOptions != nil && m.VolumeOptions.DriverConfig != nil {
 				if name := m.VolumeOptions.DriverConfig.Name; name != "" && name != "local" {
 					req = append(req, s.intern(C.SWP_SPACE_PLUGIN, "Volume\x00"+name))
@@ -461,10 +470,158 @@ func (s *swpEngine) desc(t *api.Task) (d C.swp_task_desc, ok bool) {
 	if d.port_set, ok = s.portSet(t); !ok {
 		return d, false
 	}
+	if set, ok := s.mountSet(t); !ok { // VolumesFilter.SetTask, filter.go:392-422
+		return d, false
+	} else if set != 0 {
+		d.flags |= C.uint32_t(set) << C.SWP_TASK_MOUNTS_SHIFT
+	}
 	if t.SpecVersion != nil {
 		d.spec_version = C.uint64_t(t.SpecVersion.Index)
 	}
 	return d, true
+}
+
+// ---- CSI volumes (round 4): the engine judges VolumesFilter.Check and runs chooseTaskVolumes; volumeSet keeps its maps ----------
+
+// upsertVolume: volumeSet.addOrUpdateVolume (volumes.go:62-82), from EventUpdateVolume (scheduler.go:200-213) and setupTasksList (:70-81)
+func (s *swpEngine) upsertVolume(v *api.Volume) error {
+	sv := C.swp_volume{group: s.intern(C.SWP_SPACE_VOLUME_GROUP, v.Spec.Group), driver: s.intern(C.SWP_SPACE_CSI, v.Spec.Driver.Name),
+		scope: C.uint32_t(v.Spec.AccessMode.Scope), sharing: C.uint32_t(v.Spec.AccessMode.Sharing)}
+	if v.Spec.Availability == api.VolumeAvailabilityActive {
+		sv.active = 1
+	}
+	off := []C.uint32_t{0}
+	var segs []C.swp_seg
+	for _, top := range v.VolumeInfo.AccessibleTopology {
+		keys := make([]string, 0, len(top.Segments))
+		for k := range top.Segments {
+			keys = append(keys, k)
+		}
+		sort.Strings(keys)
+		for _, k := range keys {
+			segs = append(segs, C.swp_seg{key: s.intern(C.SWP_SPACE_CSI, k), value: s.intern(C.SWP_SPACE_CSI, top.Segments[k])})
+		}
+		off = append(off, C.uint32_t(len(segs)))
+	}
+	sv.n_topologies = C.uint32_t(len(off) - 1)
+	var none C.swp_seg
+	p := &none
+	if len(segs) > 0 {
+		p = &segs[0]
+	}
+	if rc := C.swp_volume_upsert(s.e, s.intern(C.SWP_SPACE_VOLUME, v.ID), &sv, &off[0], p); rc != C.SWP_OK {
+		return s.err("swp_volume_upsert", rc)
+	}
+	return nil
+}
+
+// pushVolumeUsage: after every volumeSet.reserveVolume / releaseVolume (volumes.go:156-187) — what checkVolume derives from info.tasks
+func (s *swpEngine) pushVolumeUsage(volumeID string, info volumeInfo) {
+	u := C.swp_volume_usage{pin: C.SWP_PIN_NONE}
+	for _, usage := range info.tasks {
+		u.n_tasks++
+		if !usage.readOnly {
+			u.n_writers++
+		}
+		idx, known := s.nodeIdx[usage.nodeID]
+		switch {
+		case !known:
+			u.pin = C.SWP_PIN_MANY // a user on a node the nodeSet does not hold: no node of the set is that node
+		case u.pin == C.SWP_PIN_NONE:
+			u.pin = idx
+		case u.pin != idx:
+			u.pin = C.SWP_PIN_MANY
+		}
+	}
+	C.swp_volume_set_usage(s.e, s.intern(C.SWP_SPACE_VOLUME, volumeID), &u)
+}
+
+// nodeCSI: Description.CSIInfo after swp_node_upsert (the first entry of a plugin is the one checkVolume takes, volumes.go:272-278)
+func (s *swpEngine) nodeCSI(node C.uint32_t, infos []*api.NodeCSIInfo) {
+	var cs []C.swp_csi
+	var segs []C.swp_seg
+	for _, ci := range infos {
+		c := C.swp_csi{plugin: s.intern(C.SWP_SPACE_CSI, ci.PluginName), seg_off: C.uint32_t(len(segs))}
+		if ci.AccessibleTopology != nil {
+			c.has_topology = 1
+			for k, v := range ci.AccessibleTopology.Segments {
+				segs = append(segs, C.swp_seg{key: s.intern(C.SWP_SPACE_CSI, k), value: s.intern(C.SWP_SPACE_CSI, v)})
+			}
+		}
+		c.n_seg = C.uint32_t(len(segs)) - c.seg_off
+		cs = append(cs, c)
+	}
+	var noC C.swp_csi
+	var noS C.swp_seg
+	pc, ps := &noC, &noS
+	if len(cs) > 0 {
+		pc = &cs[0]
+	}
+	if len(segs) > 0 {
+		ps = &segs[0]
+	}
+	C.swp_node_set_csi(s.e, node, pc, C.uint32_t(len(cs)), ps, C.uint32_t(len(segs)))
+}
+
+// mountSet: the task's MountTypeCluster mounts in spec order (VolumesFilter.SetTask); a name resolves through volumeSet.byName NOW
+// (volumes.go:252). false: more mounts than the engine takes — the task stays on the Go path.
+func (s *swpEngine) mountSet(t *api.Task) (C.uint32_t, bool) {
+	c := t.Spec.GetContainer()
+	if c == nil {
+		return 0, true
+	}
+	var ms []C.swp_mount
+	for _, m := range c.Mounts {
+		if m.Type != api.MountTypeCluster {
+			continue
+		}
+		mm := C.swp_mount{ref: C.SWP_NO_VOLUME}
+		if group, ok := strings.CutPrefix(m.Source, "group:"); ok {
+			mm.is_group, mm.ref = 1, s.intern(C.SWP_SPACE_VOLUME_GROUP, group)
+		} else if id, ok := s.vs.byName[m.Source]; ok {
+			mm.ref = s.intern(C.SWP_SPACE_VOLUME, id)
+		}
+		if m.ReadOnly {
+			mm.read_only = 1
+		}
+		for _, other := range c.Mounts { // reserveTaskVolumes (volumes.go:148-151): the LAST mount with this (Source, Target) speaks
+			if other.Source == m.Source && other.Target == m.Target {
+				mm.reserve_read_only = 0
+				if other.ReadOnly {
+					mm.reserve_read_only = 1
+				}
+			}
+		}
+		ms = append(ms, mm)
+	}
+	if len(ms) == 0 {
+		return 0, true
+	}
+	if len(ms) > C.SWP_MAX_MOUNTS {
+		return 0, false
+	}
+	var id C.uint32_t
+	if rc := C.swp_mount_set(s.e, &ms[0], C.uint32_t(len(ms)), &id); rc != C.SWP_OK {
+		return 0, false
+	}
+	return id, true
+}
+
+// attachments: newT.Volumes for a task the batch placed (scheduler.go:862-872) from swp_batch_attachments' row; nil when a mount found no
+// volume (the reference assigns the task without attachments). The caller then runs its own reserveTaskVolumes(&newT) (:874).
+func (s *swpEngine) attachments(t *api.Task, row []C.uint32_t) []*api.VolumeAttachment {
+	if len(row) == 0 || row[0] == C.SWP_NO_VOLUME {
+		return nil
+	}
+	var out []*api.VolumeAttachment
+	i := 0
+	for _, m := range t.Spec.GetContainer().Mounts {
+		if m.Type == api.MountTypeCluster {
+			out = append(out, &api.VolumeAttachment{ID: s.volumeID[row[i]], Source: m.Source, Target: m.Target})
+			i++
+		}
+	}
+	return out
 }
 
 // commit: NodeInfo.addTask / removeTask from the event handlers (scheduler.go:254-366) and the rollback (:472-487)
@@ -643,6 +800,9 @@ func (sch *Scheduler) scheduleOneOffsShardedSWP(ctx context.Context, tasks []*ap
 	kept := make([]*api.Task, 0, len(tasks))
 	for _, t := range tasks {
 		d, ok := sch.swps[0].desc(t) // predicate sets are registered on every engine in the same order: the ids agree
+		if ok && d.flags>>C.SWP_TASK_MOUNTS_SHIFT != 0 {
+			ok = false // cluster mounts: a volume's use is cluster-wide state, swp_shard_* refuses them (SWP_EUNSUPPORTED)
+		}
 		if !ok {
 			rest = append(rest, t)
 			continue
@@ -662,6 +822,9 @@ func (sch *Scheduler) scheduleOneOffsShardedSWP(ctx context.Context, tasks []*ap
 	for g, e := range sch.swps {
 		engines[g] = e.e
 		if rc := C.swp_batch_prepare(e.e, &descs[0], C.uint32_t(len(descs)), &batches[g]); rc != C.SWP_OK {
+			for h := 0; h < g; h++ { // the batches prepared so far go back
+				C.swp_batch_free(sch.swps[h].e, batches[h])
+			}
 			return append(rest, kept...) // the reference decides this tick
 		}
 	}

@@ -47,10 +47,10 @@ CASES = [
     (8, 885, 1500, 125, 64, 2, 3, "t"),
     # identical tasks next to each other (R6Args.tmpl): a task's list starts behind the candidates its twins in front of it take
     (50, 10000, 3000, 20, 512, 1, 0, ""),    # 150 twins in a row on 10 000 nodes: 7 rounds instead of 12
-    (51, 20000, 4000, 25, 512, 1, 1, "s"),
+    (51, 9000, 2500, 25, 512, 1, 1, "s"),
     (52, 6000, 3000, 12, 256, 1, 2, ""),     # ... with host ports and uncounted twins
-    (53, 9000, 2500, 10, 1024, 1, 3, ""),    # ... with generic reservations
-    (54, 12000, 2400, 16, 512, 1, 1, "t"),   # ... in task-rows mode
+    (53, 4000, 1200, 10, 256, 1, 3, ""),     # ... with generic reservations
+    (54, 6000, 1200, 16, 256, 1, 1, "t"),    # ... in task-rows mode
     (55, 8000, 3000, 3, 512, 2, 1, ""),      # three services in random order: twins interleaved with other tasks
     (50, 10000, 3000, 20, 512, 1, 0, "n"),   # the same without the twins' offset (what the shard drivers run)
     (13, 901, 1200, 8, 64, 1, 1, "n"),
