@@ -324,6 +324,10 @@ int swp_schedule_groups_volumes(swp_engine*, const swp_task_desc* groups, const 
  *   fetch:   wait, copy results back, fold the placements into the host-side node mirror */
 typedef struct swp_batch swp_batch;
 int swp_batch_prepare(swp_engine*, const swp_task_desc* tasks, uint32_t n_tasks, swp_batch** out);
+/* swp_batch_prepare for a caller that knows which tasks share a descriptor (tasks of one service spec do): task i carries
+ * templates[template_of_task[i]]. The per-task pass is an array lookup instead of the hash of 64 bytes that finds the same out. */
+int swp_batch_prepare_templates(swp_engine*, const swp_task_desc* templates, uint32_t n_templates, const uint32_t* template_of_task,
+                                uint32_t n_tasks, swp_batch** out);
 int swp_batch_run(swp_engine*, swp_batch*);
 int swp_batch_fetch(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fail_hist);
 /* copy the device results of the last run back WITHOUT folding them into the host mirror (replay

@@ -104,7 +104,7 @@ class Generic(C.Structure):
 
 EXPORTS = [
     "swp_generic_set", "swp_node_set_generic", "swp_node_get_generic",
-    "swp_node_set_csi", "swp_volume_upsert", "swp_volume_set_usage", "swp_volume_get_usage", "swp_mount_set", "swp_choose_volumes", "swp_batch_attachments", "swp_schedule_groups_volumes",
+    "swp_node_set_csi", "swp_volume_upsert", "swp_volume_set_usage", "swp_volume_get_usage", "swp_mount_set", "swp_choose_volumes", "swp_batch_attachments", "swp_schedule_groups_volumes", "swp_batch_prepare_templates",
     "swp_create", "swp_destroy", "swp_reset", "swp_intern", "swp_intern_lookup", "swp_node_upsert", "swp_node_update_dynamic",
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
@@ -186,6 +186,7 @@ def load_library(path=None):
         "swp_schedule_groups": ([vp, vp, vp, u32, vp, vp], C.c_int),
         "swp_schedule_batch": ([vp, vp, u32, vp, vp], C.c_int),
         "swp_batch_prepare": ([vp, vp, u32, P(vp)], C.c_int),
+        "swp_batch_prepare_templates": ([vp, vp, u32, vp, u32, P(vp)], C.c_int),
         "swp_batch_run": ([vp, vp], C.c_int),
         "swp_batch_fetch": ([vp, vp, vp, vp], C.c_int),
         "swp_batch_results": ([vp, vp, vp, vp], C.c_int),
@@ -534,6 +535,14 @@ class Engine:
         h = C.c_void_p()
         self._ck(self.L.swp_batch_prepare(self.h, tasks.ctypes.data, len(tasks), C.byref(h)))
         return Batch(self, h, len(tasks))
+
+    def batch_prepare_templates(self, templates, template_of_task):
+        """swp_batch_prepare for tasks given as (templates, index per task): no per-task de-duplication pass."""
+        templates = np.ascontiguousarray(templates, dtype=TASK_DTYPE)
+        idx = np.ascontiguousarray(template_of_task, dtype=np.uint32)
+        h = C.c_void_p()
+        self._ck(self.L.swp_batch_prepare_templates(self.h, templates.ctypes.data, len(templates), idx.ctypes.data, len(idx), C.byref(h)))
+        return Batch(self, h, len(idx))
 
     def state_save(self):
         self._ck(self.L.swp_state_save(self.h))

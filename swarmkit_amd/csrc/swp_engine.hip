@@ -267,7 +267,9 @@ inline uint64_t svcver_key(uint32_t svc, uint64_t ver) { return ((uint64_t)svc <
 
 struct swp_batch {
     uint32_t T = 0;
-    std::vector<swp_task_desc> tasks;
+    std::vector<swp_task_desc> tasks;      // the descriptors: one per task, or the caller's templates with task_tmpl naming each task's
+    std::vector<uint32_t> task_tmpl;       // (swp_batch_prepare_templates) [T] index into `tasks`; empty: tasks[i] is task i's
+    const swp_task_desc& desc(uint32_t i) const { return task_tmpl.empty() ? tasks[i] : tasks[task_tmpl[i]]; }
     std::vector<RTask> rt;
     std::vector<uint32_t> svc_global;      // batch-local service -> SERVICE id
     std::vector<uint32_t> list_off;        // [n_svc+1]
@@ -667,7 +669,17 @@ template <class T>
 std::string bytes_of(const T* p, size_t n) { return std::string(reinterpret_cast<const char*>(p), n * sizeof(T)); }
 
 // ---- batch construction -------------------------------------------------------------------------
-int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch* b, const uint32_t* weights = nullptr) {
+// tmpl_idx != nullptr: `descs` holds n_tmpl TEMPLATES and task i carries descs[tmpl_idx[i]] (swp_batch_prepare_templates): the caller has
+// done the de-duplication, the per-task pass is an array lookup instead of a hash of 64 bytes
+int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch* b, const uint32_t* weights = nullptr, const uint32_t* tmpl_idx = nullptr, uint32_t n_tmpl = 0) {
+    struct TaskView {   // tasks[i] whatever the form
+        const swp_task_desc* d;
+        const uint32_t* ix;
+        const swp_task_desc& operator[](uint32_t i) const { return ix ? d[ix[i]] : d[i]; }
+    } tasks{descs, tmpl_idx};
+    if (tmpl_idx)
+        for (uint32_t i = 0; i < T; ++i)
+            if (tmpl_idx[i] >= n_tmpl) return e->fail(SWP_EINVAL, "task %u names template %u of %u", i, tmpl_idx[i], n_tmpl);
     const bool dbg_prep = getenv("SWP_DEBUG_PREPARE") != nullptr;
     auto tp = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
@@ -677,7 +689,13 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         tp = now;
     };
     b->T = T;
-    b->tasks.assign(tasks, tasks + T);
+    if (tmpl_idx) {   // (no 64-byte copy per task: a million tasks are 64 MB)
+        b->tasks.assign(descs, descs + n_tmpl);
+        b->task_tmpl.assign(tmpl_idx, tmpl_idx + T);
+    } else {
+        b->tasks.assign(descs, descs + T);
+        b->task_tmpl.clear();
+    }
     b->rt.resize(T);
     std::unordered_map<uint32_t, uint32_t> con_local, plat_local, plug_local, pset_local, svc_local;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> sc_local;
@@ -710,8 +728,8 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
         std::memcpy(key.w, &d, sizeof key);
         return (uint64_t)DescHash()(key) | 1ull;   // 0 = empty slot
     };
-    auto same_desc = [&](uint32_t a, uint32_t c) { return std::memcmp(&tasks[a], &tasks[c], sizeof(swp_task_desc)) == 0; };
-    std::vector<uint32_t> tmpl_of(T), firsts;
+    auto same_desc = [&](uint32_t a, uint32_t c) { return std::memcmp(&tasks[a], &tasks[c], sizeof(swp_task_desc)) == 0; };   // (TaskView: references into the caller's array)
+    std::vector<uint32_t> tmpl_of(T), firsts, first_of_tmpl(tmpl_idx ? n_tmpl : 0, 0xFFFFFFFFu);
 
     for (uint32_t i = 0; i < T; ++i) {
         const swp_task_desc& d = tasks[i];
@@ -719,7 +737,12 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
             uint32_t hit = 0xFFFFFFFFu;
             uint64_t h = 0;
             size_t at = 0;
-            if (i && same_desc(i, i - 1)) hit = tmpl_of[i - 1];   // (service-major batches: a run of one descriptor)
+            if (tmpl_idx) {   // the caller's templates: the first task of each
+                uint32_t& f = first_of_tmpl[tmpl_idx[i]];
+                if (f == 0xFFFFFFFFu) f = i;
+                else hit = f;
+                at = SIZE_MAX;
+            } else if (i && same_desc(i, i - 1)) hit = tmpl_of[i - 1];   // (service-major batches: a run of one descriptor)
             else {
                 h = desc_hash(d);
                 const size_t mask = table.size() - 1;
@@ -736,8 +759,8 @@ int build_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t T, swp_batch
                 svc_ntasks[sv] += weights ? weights[i] : 1u;
                 continue;
             }
-            table[at] = Slot{h, i, 0};
-            if (++table_used * 2 > table.size()) {   // grow: re-insert by the stored hashes
+            if (at != SIZE_MAX) table[at] = Slot{h, i, 0};
+            if (at != SIZE_MAX && ++table_used * 2 > table.size()) {   // grow: re-insert by the stored hashes
                 std::vector<Slot> bigger(table.size() * 4, Slot{0, 0, 0});
                 const size_t m2 = bigger.size() - 1;
                 for (const Slot& sl : table)
@@ -2684,6 +2707,21 @@ int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_task
     return SWP_OK;
 }
 
+int swp_batch_prepare_templates(swp_engine* e, const swp_task_desc* templates, uint32_t n_templates, const uint32_t* template_of_task, uint32_t n_tasks, swp_batch** out) {
+    if (!e || !out || (!templates && n_templates) || (!template_of_task && n_tasks) || (n_tasks && !n_templates)) return SWP_EINVAL;
+    *out = nullptr;
+    (void)hipSetDevice(e->device);
+    int rc = flush_nodes(e);
+    if (rc) return rc;
+    auto b = std::make_unique<swp_batch>();
+    if ((rc = build_batch(e, templates, n_tasks, b.get(), nullptr, template_of_task, n_templates))) return rc;
+    if (e->dev_static_dirty && (rc = flush_nodes(e))) return rc;
+    if (n_tasks && e->n_nodes && (rc = upload_batch(e, b.get()))) return rc;
+    b->n_nodes_prepared = e->n_nodes;
+    *out = b.release();
+    return SWP_OK;
+}
+
 int swp_batch_run(swp_engine* e, swp_batch* b) {
     if (!e || !b) return SWP_EINVAL;
     (void)hipSetDevice(e->device);
@@ -2742,7 +2780,7 @@ int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* ou
         int32_t n = out_node[i];
         if (n < 0) continue;
         if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return e->fail(SWP_EHIP, "device returned an invalid node index %d for task %u", n, i);
-        const swp_task_desc& d = b->tasks[i];
+        const swp_task_desc& d = b->desc(i);
         host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
         ++placed;
     }
@@ -3011,7 +3049,7 @@ int swp_shard_end(swp_engine* e, swp_batch* b, int32_t* out_node_local, uint32_t
         const int32_t n = b->shard_out[i];
         out_node_local[i] = n;
         if (n < 0) continue;
-        const swp_task_desc& d = b->tasks[i];
+        const swp_task_desc& d = b->desc(i);
         host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true);
         ++placed;
     }
@@ -3229,7 +3267,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
             if ((uint32_t)nloc >= e->nodes.size() || !e->nodes[nloc].present || out_shard[i] >= 0) return die(e0->fail(SWP_EHIP, "shard %u returned an invalid placement for task %u", g, i));
             out_shard[i] = (int32_t)g;
             out_node[i] = nloc;
-            const swp_task_desc& d = b->tasks[i];
+            const swp_task_desc& d = b->desc(i);
             if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)nloc, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
             ++placed;
         }
@@ -3491,7 +3529,7 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
         const int32_t n = out_node_local[i];
         if (n < 0) continue;
         if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return bad(e->fail(SWP_EHIP, "device returned an invalid node index %d for task %u", n, i));
-        const swp_task_desc& d = b->tasks[i];
+        const swp_task_desc& d = b->desc(i);
         if (!(flags & SWP_SHARD_NO_FOLD)) host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
         ++placed;
     }

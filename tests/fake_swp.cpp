@@ -352,6 +352,7 @@ int swp_choose_volumes(swp_engine*, uint32_t, uint32_t, uint32_t*, uint32_t*, ui
 int swp_batch_attachments(swp_engine*, swp_batch*, const uint32_t*, uint32_t, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_schedule_groups_volumes(swp_engine*, const swp_task_desc*, const uint32_t*, uint32_t, int32_t*, uint32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_batch_prepare(swp_engine*, const swp_task_desc*, uint32_t, swp_batch**) { return SWP_EUNSUPPORTED; }
+int swp_batch_prepare_templates(swp_engine*, const swp_task_desc*, uint32_t, const uint32_t*, uint32_t, swp_batch**) { return SWP_EUNSUPPORTED; }
 int swp_batch_run(swp_engine*, swp_batch*) { return SWP_EUNSUPPORTED; }
 int swp_batch_fetch(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
 int swp_batch_results(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
