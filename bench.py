@@ -47,8 +47,9 @@ def profile_traffic(kernel):
             continue
         per = doc.get("hbm_bytes_per_launch", {})
         base = kernel.split("<")[0]
-        if kernel.startswith("k_resolve6") and "k_r6_propose" in per and "k_r6_commit" in per:   # per ROUND: one launch of each
-            return per["k_r6_propose"] + per["k_r6_commit"], "profiles/%s_pmc_summary.json, k_r6_propose + k_r6_commit per round (%s)" % (tag, doc.get("source", ""))
+        pk = "k_r6_propose_small" if "k_r6_propose_small" in per else "k_r6_propose"   # (the one-chunk instance is what runs up to 32 768 nodes: the headline)
+        if kernel.startswith("k_resolve6") and pk in per and "k_r6_commit" in per:   # per ROUND: one launch of each
+            return per[pk] + per["k_r6_commit"], "profiles/%s_pmc_summary.json, %s + k_r6_commit per round (%s)" % (tag, pk, doc.get("source", ""))
         if base in per:
             return per[base], "profiles/%s_pmc_summary.json (%s)" % (tag, doc.get("source", "rocprofv3 --pmc"))
     return None, "no PMC summary for %s under profiles/" % kernel
