@@ -90,7 +90,7 @@ def test_spread_with_constraints_and_leftovers():
 
 def test_what_stays_on_the_go_path_is_refused_not_faked():
     """Refused at the event boundary (the task never enters a batch): generic reservations the engine does not take — Named, below 1,
-    a kind twice — and CSI cluster volumes. A GROUP with generic reservations is placed like a one-off task (round 3 deferred it)."""
+    a kind twice — and more CSI cluster mounts than a mount set holds (tests/test_engine_volumes.py has the ones the engine takes). A GROUP with generic reservations is placed like a one-off task (round 3 deferred it)."""
     s = factory()
     s.create_node(sc.node("n1", Description={"Resources": {"NanoCPUs": 10**9, "MemoryBytes": 10**9, "Generic": sc.discrete("apple", 4)}}))
     s.set_service("svc")
@@ -99,7 +99,7 @@ def test_what_stays_on_the_go_path_is_refused_not_faked():
             s.create_task(sc.pending("t1", "svc", Spec={"Resources": {"Reservations": {"Generic": bad}}}))
     assert s.tick() == []
     with pytest.raises(swhost.Unsupported):
-        s.task_desc(sc.pending("t2", "svc", Spec={"Container": {"Mounts": [{"Type": 4, "Source": "vol"}]}}))
+        s.task_desc(sc.pending("t2", "svc", Spec={"Container": {"Mounts": [{"Type": 4, "Source": "vol%d" % q, "Target": "/m%d" % q} for q in range(9)]}}))   # more cluster mounts than swp_mount_set takes
     s.create_task(sc.pending("g1", "svc", 1, Spec={"Resources": {"Reservations": {"Generic": sc.discrete("apple", 1)}}}))   # SpecVersion 1: a group
     d = s.tick()
     assert len(d) == 1 and d[0]["ID"] == "g1" and not d[0].get("Deferred") and d[0]["NodeID"] == "n1"
