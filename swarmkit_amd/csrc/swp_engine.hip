@@ -113,6 +113,11 @@ struct DevBuf {   // owns one device allocation: movable, not copyable
         if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
         if ((p = dev_pool().take(dev, want, &cap))) return hipSuccess;
         hipError_t e = hipMalloc(&p, want);
+        if (e == hipErrorOutOfMemory) {   // the blocks cached for reuse are the first thing to give back: drain them and try once more
+            (void)hipGetLastError();
+            dev_pool().drain(dev);
+            e = hipMalloc(&p, want);
+        }
         if (e == hipSuccess) cap = want;
         else p = nullptr;
         return e;
