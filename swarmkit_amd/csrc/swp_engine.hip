@@ -125,6 +125,35 @@ struct DevBuf {   // owns one device allocation: movable, not copyable
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Pinned host blocks of freed batches, kept for the next batch: hipHostMalloc of a batch's 64 MB of task records costs more than filling them
+struct PinPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;   // capacity -> block
+    size_t held = 0;
+    static constexpr size_t LIMIT = (size_t)1 << 30;
+    void* take(size_t want, size_t* cap) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = free_blocks.lower_bound(want);
+        if (it == free_blocks.end() || it->first > 2 * want + 65536) return nullptr;
+        void* p = it->second;
+        *cap = it->first;
+        held -= *cap;
+        free_blocks.erase(it);
+        return p;
+    }
+    bool give(size_t cap, void* p) {
+        std::lock_guard<std::mutex> g(mu);
+        if (held + cap > LIMIT) return false;
+        free_blocks.emplace(cap, p);
+        held += cap;
+        return true;
+    }
+};
+inline PinPool& pin_pool() {
+    static PinPool* p = new PinPool();   // (never destroyed, as the device pool)
+    return *p;
+}
+
 struct PinBuf {   // owns one pinned host allocation (async copies in both directions without a staging pass)
     void* p = nullptr;
     size_t cap = 0;
@@ -132,17 +161,41 @@ struct PinBuf {   // owns one pinned host allocation (async copies in both direc
     PinBuf(const PinBuf&) = delete;
     PinBuf& operator=(const PinBuf&) = delete;
     PinBuf(PinBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
-    hipError_t reserve(size_t bytes) {
-        if (bytes <= cap && p) return hipSuccess;
-        if (p) (void)hipHostFree(p);
+    ~PinBuf() { release(); }
+    void release() {
+        if (p && !pin_pool().give(cap, p)) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
+    }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        release();
         size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+        if ((p = pin_pool().take(want, &cap))) return hipSuccess;
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
         if (e == hipSuccess) cap = want;
+        else p = nullptr;
         return e;
     }
+};
+
+// A batch's per-task records in pinned memory: NOT initialised by resize (every element is written by the builder), uploaded without a
+// staging pass, and the block goes back to the pool with the batch
+template <class T>
+struct PinVec {
+    PinBuf buf;
+    size_t n = 0;
+    hipError_t resize(size_t k) {
+        hipError_t e = buf.reserve(k * sizeof(T));
+        if (e == hipSuccess) n = k;
+        return e;
+    }
+    T& operator[](size_t i) { return static_cast<T*>(buf.p)[i]; }
+    const T& operator[](size_t i) const { return static_cast<const T*>(buf.p)[i]; }
+    T* data() { return static_cast<T*>(buf.p); }
+    const T* data() const { return static_cast<const T*>(buf.p); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
 };
 
 struct Interner {
@@ -275,7 +328,7 @@ struct swp_batch {
     std::vector<swp_task_desc> tasks;      // the descriptors: one per task, or the caller's templates with task_tmpl naming each task's
     std::vector<uint32_t> task_tmpl;       // (swp_batch_prepare_templates) [T] index into `tasks`; empty: tasks[i] is task i's
     const swp_task_desc& desc(uint32_t i) const { return task_tmpl.empty() ? tasks[i] : tasks[task_tmpl[i]]; }
-    std::vector<RTask> rt;
+    PinVec<RTask> rt;
     std::vector<uint32_t> svc_global;      // batch-local service -> SERVICE id
     std::vector<uint32_t> list_off;        // [n_svc+1]
     std::vector<uint32_t> list_node0, list_svc0, list_fail0;   // pristine lists
@@ -437,7 +490,16 @@ namespace {
 uint32_t n_words_of(uint32_t n) { return (n + 63) / 64; }
 
 template <class T>
+int upload(swp_engine* e, DevBuf& b, const PinVec<T>& v, size_t min_elems = 1);
+template <class T>
 int upload(swp_engine* e, DevBuf& b, const std::vector<T>& v, size_t min_elems = 1) {
+    size_t bytes = std::max(v.size(), min_elems) * sizeof(T);
+    HIPCHECK(e, b.reserve(bytes));
+    if (!v.empty()) HIPCHECK(e, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    return SWP_OK;
+}
+template <class T>
+int upload(swp_engine* e, DevBuf& b, const PinVec<T>& v, size_t min_elems) {
     size_t bytes = std::max(v.size(), min_elems) * sizeof(T);
     HIPCHECK(e, b.reserve(bytes));
     if (!v.empty()) HIPCHECK(e, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, e->stream));
@@ -701,7 +763,7 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
         b->tasks.assign(descs, descs + T);
         b->task_tmpl.clear();
     }
-    b->rt.resize(T);
+    HIPCHECK(e, b->rt.resize(T));
     std::unordered_map<uint32_t, uint32_t> con_local, plat_local, plug_local, pset_local, svc_local;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> sc_local;
     std::vector<uint32_t> con_ids{0}, plat_ids{0}, plug_ids{0}, pset_ids_global;
@@ -735,6 +797,7 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
     };
     auto same_desc = [&](uint32_t a, uint32_t c) { return std::memcmp(&tasks[a], &tasks[c], sizeof(swp_task_desc)) == 0; };   // (TaskView: references into the caller's array)
     std::vector<uint32_t> tmpl_of(T), firsts, first_of_tmpl(tmpl_idx ? n_tmpl : 0, 0xFFFFFFFFu);
+    mark("descriptors kept, per-task arrays");
 
     for (uint32_t i = 0; i < T; ++i) {
         const swp_task_desc& d = tasks[i];
