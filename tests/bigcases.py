@@ -22,8 +22,13 @@ READY, RUNNING, PENDING, ASSIGNED = 2, 512, 64, 192
 
 
 def tick_digest(decisions):
-    """(sha256 over the sorted decision lines, number of assigned tasks)."""
-    lines = sorted("%s|%s|%s|%d" % (d["ID"], d["NodeID"], d["Err"], d["State"]) for d in decisions)
+    """(sha256 over the sorted decision lines, number of assigned tasks). A decision with VolumeAttachments carries them in its line."""
+    def line(d):
+        base = "%s|%s|%s|%d" % (d["ID"], d["NodeID"], d["Err"], d["State"])
+        if d.get("Volumes"):
+            base += "|" + ",".join("%s=%s@%s" % (v["ID"], v["Source"], v["Target"]) for v in d["Volumes"])
+        return base
+    lines = sorted(line(d) for d in decisions)
     h = hashlib.sha256("\n".join(lines).encode()).hexdigest()
     return h, sum(1 for d in decisions if d["NodeID"] and d["State"] >= ASSIGNED)
 
@@ -176,7 +181,72 @@ def run_spread(s, N=6_000, groups=24, k=700, generic=False):
     return {"case": "spread3", "N": N, "tasks": j, "ticks": ticks, "placed": counts}
 
 
+# ------------------------------------------------------------------------------------------------ CSI volumes
+def run_volumes(s, N=20_000, T=40_000, services=400, grouped=False):
+    """cfg4's cluster with CSI topologies (one plugin per node, zone + rack segments) and 600 volumes of every access mode in 40 groups; a
+    quarter of the services mount a volume group, some a named volume too (read-only or not). Two ticks: after the first one every
+    third placed task with mounts goes away, its volumes are free again, and as many new tasks of the same services arrive."""
+    wl = synth.Workload("cfg4", T=T, N=N, services=services, grouped=grouped)
+    for i in range(wl.N):
+        d = wl.node_doc(i)
+        seg = {"zone": "z%d" % wl.node_zone[i]}
+        if i % 3:
+            seg["rack"] = "r%d" % (i % 5)
+        d["Description"]["CSIInfo"] = [{"PluginName": "csi-a" if i % 7 else "csi-b", "NodeID": "c%d" % i, "AccessibleTopology": {"Segments": seg}}] if i % 11 else []
+        s.create_node(d)
+    scopes, sharings = ["SINGLE_NODE", "MULTI_NODE"], ["NONE", "READ_ONLY", "ONE_WRITER", "ALL", "ALL", "ALL"]
+    for v in range(600):
+        acc = []
+        if v % 4:
+            acc.append({"Segments": {"zone": "z%d" % (v % 8)}})
+        if v % 9 == 0:
+            acc.append({"Segments": {"zone": "z%d" % ((v + 3) % 8), "rack": "r%d" % (v % 5)}})
+        s.update_volume({"ID": "vol%04d" % v, "Spec": {"Annotations": {"Name": "name%04d" % v}, "Group": "g%02d" % (v % 40), "Driver": {"Name": "csi-a" if v % 5 else "csi-b"},
+                                                       "AccessMode": {"Scope": scopes[(v // 3) % 2], "Sharing": sharings[v % 6]}, "Availability": "PAUSE" if v % 50 == 49 else "ACTIVE"},
+                         "VolumeInfo": {"VolumeID": "plug%04d" % v, "AccessibleTopology": acc}})
+    for k in range(wl.S):
+        s.set_service(wl.service_id(k))
+
+    def doc(j):
+        t = wl.task_doc(j)
+        k = wl.task_service(j)
+        if k % 4 == 0:
+            mounts = [{"Type": "CLUSTER", "Source": "group:g%02d" % (k % 40), "Target": "/data", "ReadOnly": k % 8 == 0}]
+            if k % 12 == 0:
+                mounts.append({"Type": "CLUSTER", "Source": "name%04d" % ((k * 7) % 600), "Target": "/named"})
+            t.setdefault("Spec", {})["Container"] = {"Mounts": mounts}
+        return t
+    docs = {}
+    for j in range(wl.T):
+        docs[j] = doc(j)
+        s.create_task(docs[j])
+    ticks, counts = [], []
+    dec = s.tick()
+    h, c = tick_digest(dec)
+    ticks.append(h)
+    counts.append(c)
+    gone = 0
+    for d in dec:
+        if d.get("Volumes") and d["NodeID"] and int(d["ID"][1:]) % 3 == 0:
+            j = int(d["ID"][1:])
+            s.delete_task(dict(docs[j], NodeID=d["NodeID"], Status={"State": ASSIGNED}, Volumes=d["Volumes"]))
+            gone += 1
+    total = synth.Workload("cfg4", T=T + gone, N=N, services=services, grouped=grouped)   # (same seed: the first T tasks are the same)
+    wl.T = total.T
+    for j in range(T, T + gone):
+        s.create_task(doc(j))
+    h, c = tick_digest(s.tick())
+    ticks.append(h)
+    counts.append(c)
+    return {"case": "volumes", "T": T, "N": N, "services": services, "grouped": grouped, "released": gone, "ticks": ticks, "placed": counts}
+
+
 CASES = {
+    # CSI volumes (SURVEY 8f-4): cfg4's cluster with topologies, 600 volumes in 40 groups, a quarter of the services with cluster mounts
+    "volumes_mid": lambda s: run_volumes(s),
+    "volumes_grouped_mid": lambda s: run_volumes(s, grouped=True),
+    "volumes_small": lambda s: run_volumes(s, N=1_500, T=4_000, services=80),
+    "volumes_grouped_small": lambda s: run_volumes(s, N=1_500, T=4_000, services=80, grouped=True),
     # task groups at BASELINE size (VERDICT r3 #1): cfg3 as 1 000 groups of 100, cfg1 at its stated 1 000 x 10, ONE group of 20 000
     # tasks on 10 000 nodes (every heap takes its whole leaf; more than one task per node), three spread levels with > 512 leaves
     "grouped_cfg3_full": lambda s: run_grouped(s, "cfg3"),

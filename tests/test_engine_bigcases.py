@@ -27,7 +27,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["refbench_small", "cfg5_churn_small", "cfg5_churn_12k", "cfg5_churn_mid", "refbench_1k_100k", "refbench_net_5k_100k", "refbench_100k_100k", "cfg4_mid",
          "cfg3m_small", "cfg3m_full", "cfg3m_mid",
          # task groups (k_groups2): BASELINE sizes, one group larger than the node set, three spread levels with > 1 000 leaves, generic reservations
-         "grouped_small", "grouped_cfg1_full", "grouped_cfg3_full", "grouped_one_20k", "grouped_cfg4_mid", "grouped_spread3", "grouped_spread3_generic"]
+         "grouped_small", "grouped_cfg1_full", "grouped_cfg3_full", "grouped_one_20k", "grouped_cfg4_mid", "grouped_spread3", "grouped_spread3_generic",
+         # CSI volumes: cfg4's cluster with topologies, 600 volumes in 40 groups, a quarter of the services with cluster mounts, tasks leaving between two ticks
+         "volumes_small", "volumes_grouped_small", "volumes_mid", "volumes_grouped_mid"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -36,6 +38,8 @@ def test_big_case_matches_oracle_digests(case):
     if not os.path.exists(path):
         pytest.skip("no oracle digest for %s yet (tests/golden/make_golden_big.py %s)" % (case, case))
     want = json.load(open(path))
+    if case.startswith("volumes"):
+        os.environ["SWP_HOST"] = "cxx"   # (the Python twin of the host layer knows no volumes)
     sched = swhost.HostScheduler()
     got = bigcases.CASES[case](sched)
     if case.startswith("cfg3m"):   # hundreds of distinct reservations: the default dispatch is the block resolver, not a round-1 fall-back
