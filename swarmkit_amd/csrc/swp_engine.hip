@@ -516,6 +516,8 @@ void engine_reset_nodes(swp_engine* e) {
     e->dev_static_dirty = true;
     e->dev_dynamic_dirty = true;
     e->saved.valid = false;
+    for (HostVolume& v : e->volumes) v.use = swp_volume_usage{0, 0, SWP_PIN_NONE, 0};   // (usage names node indices: none of them survives)
+    e->vol_static_dirty = e->vol_dyn_dirty = true;
 }
 
 uint32_t label_value(const std::vector<swp_kv>& kv, uint32_t key) {
@@ -2209,6 +2211,8 @@ int swp_node_remove(swp_engine* e, uint32_t node) {
     h = HostNode();
     e->n_present--;
     e->dev_static_dirty = e->dev_dynamic_dirty = true;
+    for (HostVolume& v : e->volumes)   // a volume whose users sat on this node: the index will name another node — no node of the set is theirs
+        if (v.use.pin == node) { v.use.pin = SWP_PIN_MANY; e->vol_dyn_dirty = true; }
     // nodeSet.remove deletes the map entry (nodeset.go:46-48): the node's index goes back to the pool, the next node id that is new to
     // swp_intern(SWP_SPACE_NODE_ID) gets the lowest free one (the canonical scan order is the index order; the oracle recycles its
     // slots by the same rule)
