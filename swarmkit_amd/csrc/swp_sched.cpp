@@ -916,7 +916,7 @@ class Scheduler {
         auto cur = allTasks_.find(tid);
         if (cur != allTasks_.end()) {
             const Value newT = cur->second;
-            if (!pd.preassigned) releaseTaskVolumes(newT);   // scheduler.go:480-483 (a preassigned task's attachments were never reserved)
+            releaseTaskVolumes(newT);   // scheduler.go:480-483 and :422-424 (a preassigned task's attachments were never reserved: releasing them finds nothing)
             auto n = nodes_.find(as_str(newT.get("NodeID")));
             if (n != nodes_.end() && !truthy(pd.old.get("NodeID")) ) removeTask(n->second, newT);                 // tick: the node was chosen by this decision
             else if (n != nodes_.end() && pd.preassigned && task_state(at(&newT, {"Status", "State"})) == ASSIGNED) removeTask(n->second, newT);
