@@ -400,6 +400,7 @@ struct swp_batch {
     std::vector<ShardPickDev> shard_mine;  // upload sources of the last commit (alive until the stream has consumed them)
     std::vector<ShardInfDev> shard_infs;
     DevBuf d_prop, d_picks, d_infs;
+    DevBuf d_cmask, d_crank, d_cidx;       // the block resolver's compact index of a round (k_r6_compact)
 };
 
 struct swp_engine {
@@ -463,6 +464,7 @@ struct swp_engine {
     void* rccl_comm = nullptr;
     uint32_t rccl_rank = 0, rccl_ranks = 0;
 
+    bool r6_compact_hint = false;   // the last batch's rounds ended with a compact index (re-placements after a drain): the next one starts with it
     swp_stats_t stats{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;   // per-launch kernel timing (SWP_CFG_PROFILE)
@@ -1573,6 +1575,11 @@ int r6_args_for(swp_engine* e, swp_batch* b, uint32_t r6_block, bool r6_task_row
     if (r6_task_rows) HIPCHECK(e, b->d_trows.reserve((size_t)r6_block * Wn * 8));
     HIPCHECK(e, b->d_blk6.reserve(sizeof(Blk6)));
     HIPCHECK(e, b->d_prop.reserve((size_t)r6_block * sizeof(R6Prop)));
+    if (Wn <= R6_COMPACT_MAX_WORDS) {   // the compact index of a round (k_r6_compact); run_blocks switches it on
+        HIPCHECK(e, b->d_cmask.reserve((size_t)Wn * 8));
+        HIPCHECK(e, b->d_crank.reserve((size_t)Wn * 4));
+        HIPCHECK(e, b->d_cidx.reserve((size_t)r6_compact_cap(Wn) * 4));
+    }
     R6Args ra{};
     ra.n_nodes = N;
     ra.n_words = Wn;
@@ -1610,6 +1617,10 @@ int r6_args_for(swp_engine* e, swp_batch* b, uint32_t r6_block, bool r6_task_row
     ra.thr = b->d_thr64.as<long long>();
     ra.blk = b->d_blk6.as<Blk6>();
     ra.prop = b->d_prop.as<R6Prop>();
+    ra.cbase = e->d_ready.as<u64>();
+    ra.cmask = b->d_cmask.as<u64>();
+    ra.crank = b->d_crank.as<uint32_t>();
+    ra.cidx = b->d_cidx.as<uint32_t>();
     if (!b->csi_set.empty()) {
         ra.csi_of = b->d_csi_of.as<uint32_t>();
         ra.csi_set = b->d_csi_set.as<uint32_t>();
@@ -1735,9 +1746,21 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(r));
         uint32_t pos = start, chunk = std::min<uint32_t>(16u, (end - start + 255u) / 256u + 1u);   // a short stretch does not pay for empty rounds
         uint32_t rounds_seen = 0, scan_len = 2048, scanned = 0;
+        // The compact index (swp_resolve6.hpp, R6Args.compact): one more small launch per round, worth it when the level the tasks aim at is a
+        // sparse set of nodes (re-placements after a drain): the matcher then stops at an emptied half-word every few tasks and the rounds are
+        // cut by exhausted lists after a fraction of their block. Switched on by that symptom (a stop per <= 12 decided tasks; ordinary
+        // batches have one per 30-40), off again when the kernel found no such level in a whole chunk; the next batch starts the way this
+        // one ended if the index was in use then.
+        // SWP_R6_COMPACT=0 never, 1 from the first round on (tests, A/B runs).
+        const char* env_cpt = getenv("SWP_R6_COMPACT");
+        const bool cpt_ok = Wn <= R6_COMPACT_MAX_WORDS && !(env_cpt && atoi(env_cpt) == 0);
+        bool cpt = cpt_ok && ((env_cpt && atoi(env_cpt) != 0) || e->r6_compact_hint);
+        uint32_t exh_seen = 0, crounds_seen = 0, stops_seen = 0;
+        bool cpt_paid = false;   // the last chunk that ran with the index had rounds that used it
         const char* env_scan = getenv("SWP_SCAN");   // 0: never hand a stretch to the scan resolver (tests, A/B runs)
         const bool scan_ok = N <= scan_max_nodes() && !(env_scan && atoi(env_scan) == 0) && b->csi_set.empty();   // (the scan resolver knows no volumes)
         while (pos < end) {
+            ra.compact = cpt ? 1u : 0u;
             r = launch_r6_rounds(ra, chunk, st, e->device);
             if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
             HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
@@ -1752,6 +1775,18 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             const double recent = (double)(hb.pos - pos) / (double)std::max<uint32_t>(used, 1);
             rounds_seen = hb.rounds;
             pos = hb.pos;
+            if (dbg_bits & 32) fprintf(stderr, "[swp] chunk: %u rounds, %.1f tasks each, at %u of %u | block %u compact %u csize %u clevel %u base %u maxrel %u\n", used, recent, pos, end, ra.block, ra.compact, hb.csize, hb.clevel, hb.base, hb.maxrel);
+            {
+                const uint32_t exh = hb.cut_exhausted - exh_seen, cr = hb.crounds - crounds_seen, stops = hb.reseats - stops_seen;
+                exh_seen = hb.cut_exhausted;
+                crounds_seen = hb.crounds;
+                stops_seen = hb.reseats;
+                if (cpt) cpt_paid = cr != 0;
+                if (cpt_ok && !(env_cpt && atoi(env_cpt) != 0)) {
+                    if (!cpt && used >= 4 && 2 * exh >= used && recent < 0.4 * ra.block && (double)stops * 12.0 >= recent * used) cpt = true;
+                    else if (cpt && used >= 4 && cr == 0) cpt = false;
+                }
+            }
             if (scan_ok && used >= 8 && recent < 8.0 && end - pos >= 64) {
                 const uint32_t upto = std::min<uint64_t>(end, (uint64_t)pos + scan_len);
                 ScanArgs sa{};
@@ -1785,6 +1820,8 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             }
         }
         if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u)\n", scanned, start, end);
+        if ((dbg_bits & 16) && hb.crounds) fprintf(stderr, "[swp] %u of the %u rounds with a compact index | of the cuts at an exhausted list: %u full lists, %u lists in compact positions, %u lists of one entry\n", hb.crounds, hb.rounds, hb.dbg_cut[0], hb.dbg_cut[1], hb.dbg_cut[2]);
+        e->r6_compact_hint = cpt && cpt_paid;
         r6_rounds += hb.rounds;
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
         ++wi;

@@ -13,7 +13,7 @@
 namespace swpdev {
 
 size_t r6_propose_lds_size(uint32_t n_words) { return r6_propose_lds(n_words); }
-size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr) { return r6_commit_lds(n_words, block, n_rr); }
+size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr) { return r6_commit_lds(n_words, block, n_rr, n_words <= R6_COMPACT_MAX_WORDS); }   // (room for a compact index where one may be built)
 uint32_t r6_block_max() { return R6_BMAX; }
 
 // base / highest level, then level planes + demand-class rows from the node rows as they are
@@ -25,13 +25,21 @@ hipError_t launch_r6_build(const R6Args& a, hipStream_t s) {
 
 // `rounds` rounds of propose + commit; a round past the end of the stretch is a no-op
 hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int dev) {
-    const size_t lp = r6_propose_lds(a.n_words), lc = r6_commit_lds(a.n_words, a.block, a.n_dc + a.n_dm);
+    const bool cpt = a.compact != 0;
+    const size_t lp = r6_propose_lds(a.n_words), lc = r6_commit_lds(a.n_words, a.block, a.n_dc + a.n_dm, cpt);
     hipError_t r;
-    if (lp > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r6_propose), dev)) != hipSuccess) return r;
-    if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r6_commit), dev)) != hipSuccess) return r;
+    if (lp > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(cpt ? &k_r6_propose_c : &k_r6_propose), dev)) != hipSuccess) return r;
+    if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(cpt ? &k_r6_commit_c : &k_r6_commit), dev)) != hipSuccess) return r;
     for (uint32_t i = 0; i < rounds; ++i) {
         if (a.task_rows) hipLaunchKernelGGL(k_r6_taskrows, dim3((a.n_words + 3) / 4, (a.block + 63) / 64), dim3(256), (size_t)a.block * 16, s, a);
         if (a.csi_of) hipLaunchKernelGGL(k_r6_volrows, dim3((a.n_words + 255) / 256, a.block), dim3(256), 0, s, a);   // (batches with cluster mounts only)
+        if (cpt) {   // rounds with a compact index of the level their first task aims at (run_blocks decides when)
+            hipLaunchKernelGGL(k_r6_compact, dim3(1), dim3(1024), 256, s, a);
+            if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small_c, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
+            else hipLaunchKernelGGL(k_r6_propose_c, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
+            hipLaunchKernelGGL(k_r6_commit_c, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
+            continue;
+        }
         if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small, dim3(a.block), dim3(64 * R6_PW), lp, s, a);   // (LDS of 8 chunks: never beyond 48 KB)
         else hipLaunchKernelGGL(k_r6_propose, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
         hipLaunchKernelGGL(k_r6_commit, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);

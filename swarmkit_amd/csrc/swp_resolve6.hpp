@@ -25,6 +25,11 @@
 //                  (its order moves with every placement of the service) and behind an uncounted task (its node did NOT move
 //                  up). Waves 1..15 move the cursors of "their" group over dead entries while they wait, then apply the group's
 //                  picks: NodeInfo.addTask on the node rows + the bitmaps above + commit log.
+//   k_r6_compact   (only while the host sees the symptom: a matcher stop every few tasks, rounds cut after a fraction of their block)
+//                  one workgroup, in front of the round's propose: numbers the ready nodes on the level the block's first task aims
+//                  at in node order. Tasks whose minimum level is that one list half-words of those POSITIONS — 32 candidates each
+//                  where plain half-words hold three of the few emptied nodes — the others plain half-words behind them
+//                  (R6Args.compact, the _c instances of the two kernels).
 // The exactness argument is the list rule: inside a batch levels only grow and feasibility only shrinks, and a list
 // holds ALL plain candidates of the task's minimum level in node order up to its last half-word.
 //
@@ -52,10 +57,13 @@ struct Blk6 {   // control block, global memory
     u32 base, maxrel;      // lowest task count among the valid nodes at build time; highest level above it so far
     u32 error, rounds, cut_exhausted, cut_exception, cut_uncounted;
     u32 cyc[4];            // R6Args.dbg & 16: shader cycles / 64 of k_r6_commit's sections (prologue, matching, wait for it, apply)
-    u32 reseats, cyc_load, cyc_walk;   // ... how often the matcher stopped at an emptied half-word; cycles / 64 of a group's list load and of its walk
+    u32 reseats, cyc_load, cyc_walk;   // how often the matcher stopped at an emptied half-word (always counted); dbg: cycles / 64 of a group's list load and of its walk
     u32 cyc_g[4];          // ... of the list load: waiting for the group's lists, the head records, seating; seating steps
+    u32 csize, clevel;     // compact index of this round (k_r6_compact): its nodes (0: none, every list in plain half-words), their level above the base
+    u32 crounds;           // rounds that had one
+    u32 dbg_cut[3];        // dbg: of the cuts at an exhausted list, those whose list was full (more candidates on the level), in compact positions, one entry long
 };
-static_assert(sizeof(Blk6) == 80, "Blk6 layout");
+static_assert(sizeof(Blk6) == 104, "Blk6 layout");
 
 struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidates, as 32-node half-words
     u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); half-words listed | bit 31: there are more
@@ -122,6 +130,18 @@ struct R6Args {
     u64* vrows;              // [those tasks][n_words] VolumesFilter.Check (filter.go:424-432) as the volumes stood at the start of the task's last round
     u32* att;                // [those tasks][VOL_MAX_MOUNTS] the volumes chosen for its mounts on its node (chooseTaskVolumes), VOL_NONE: none
     VolView vol;
+    // The compact index (k_r6_compact, one launch in front of a round's propose). Re-placements after a drain all aim at the few emptied
+    // nodes: their level holds, say, 1 000 of 10 000 nodes, three to a half-word, so a list of 32 half-words names 100 of them and the
+    // matcher's two seats hold six. The ready nodes ON the level the block's first task aims at, numbered in node order, are the round's
+    // compact positions; a task whose minimum level is that one lists half-words of POSITIONS (dense: 32 candidates each), every other task plain half-words behind
+    // them (+ 2 * ceil(csize / 64)). One level per list, so a list lives in one of the two address ranges; a node has one address per round,
+    // so strikes meet; numbering in node order keeps every list in node order. The applying threads translate a picked address back.
+    u32 compact;             // != 0: the rounds launch k_r6_compact and the kernels honour Blk6.csize
+    const u64* cbase;        // [n_words] the nodes an index is drawn from: READY && valid — every static class row is a subset, so every task's
+                             // candidates are (a drained node keeps its place in `valid` and its level, which is usually the lowest)
+    u64* cmask;              // [n_words] the nodes of the compact index
+    u32* crank;              // [n_words] compact position of the word's first such node
+    u32* cidx;               // [r6_compact_cap(n_words)] node of a compact position
 };
 
 #define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together ...
@@ -133,7 +153,13 @@ inline __host__ __device__ u32 r6_chunks(u32 n_words) { const u32 g = r6_unroll(
 inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2 * r6_chunks(n_words) * 64 * 8 + 128; }
 // TK row, thresholds, the picks of the block, a few scalars, the block's lists (entry-major)
 // (per task: pick node / index / aux, the cursor, 2 * R6_CAND candidate masks and as many half-word indices of 16 bits: node sets of up to 2^21 nodes)
-inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr) { return (size_t)(n_words + n_rr) * 8 + (size_t)block * (16 + 2 * R6_CAND * 6) + 128; }
+// (the TK row: the node words, and in front of them the words of a compact index — at most a quarter of the nodes)
+#define R6_COMPACT_MAX_WORDS 16384u   // node words up to which a compact index is built (half-word indices are 16 bits in the commit kernel's LDS)
+inline __host__ __device__ u32 r6_compact_cap(u32 n_words) { return 16u * n_words; }
+inline __host__ __device__ u32 r6_tk_words(u32 n_words) { return n_words + n_words / 4u + 2u; }   // (with a compact index; n_words otherwise)
+inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr, bool compact = false) {
+    return (size_t)((compact ? r6_tk_words(n_words) : n_words) + n_rr) * 8 + (size_t)block * (16 + 2 * R6_CAND * 6) + 128;
+}
 
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
 WV_DEV u64 r6_wave_min64(u64 v) {
@@ -252,10 +278,110 @@ WV_KERNEL(256) void k_r6_volrows(R6Args a) {
     if (w < a.n_words) a.vrows[(size_t)ck * a.n_words + w] = vol_filter_word(a.vol, wv::uload(a.csi_set + ck), w);
 }
 
+// ---- compact index: the ready nodes on the level the block's first task aims at, numbered in node order (one workgroup of 1 024) ----
+// The level is the minimum among the plain candidates of the task at Blk6.pos (the rows the propose kernel combines, narrowed over the
+// level planes the same way): after a drain that is the level of the emptied nodes, which the tasks behind it aim at as well — not the
+// lowest level among the ready nodes, where nodes that nobody can use (no room, the wrong platform) sit for ever. The index holds ALL
+// ready nodes on that level (their running count is a word's first position, crank; the nodes themselves go to cidx). More than a
+// quarter of the node set on it, or no plain candidate: no index this round.
+WV_KERNEL(1024) void k_r6_compact(R6Args a) {
+    const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave();
+    const u32 t = wv::uload(&a.blk->pos);
+    if (t >= wv::uload(&a.blk->end) || wv::uload(&a.blk->error) != ERR_NONE) return;
+    u32* red = reinterpret_cast<u32*>(wv::lds());   // [16] a wave's minimum, [16] a wave's count
+    const u32 Wn = a.n_words;
+    const int nb = 32 - wv::clz32(wv::uload(&a.blk->maxrel));
+    const RTask* rt = a.rt + t;
+    const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc), scid = wv::uload(&rt->sc), pset = wv::uload(&rt->pset);
+    const u64* scrow = a.sc + (size_t)scid * Wn;
+    const u64* xrow = a.X + (size_t)svc * a.xs;
+    const bool res = (flags & RT_RES) != 0;
+    const u64* rc = a.task_rows ? a.trows : a.rr + (size_t)((flags >> RT_DC_SHIFT) & RT_DCLS_MASK) * Wn;   // (task-rows mode: the block's first row)
+    const u64* rm = a.task_rows ? rc : a.rr + (size_t)(a.n_dc + ((flags >> RT_DM_SHIFT) & RT_DCLS_MASK)) * Wn;
+    u32 p0 = 0, p1 = 0, g0 = 0, g1 = 0;
+    if (flags & RT_PORTS) {
+        p0 = wv::uload(a.pset_off + pset);
+        p1 = wv::uload(a.pset_off + pset + 1);
+    }
+    if (a.n_rg) {
+        const u32 gset = wv::uload(a.tg + t);
+        g0 = wv::uload(a.gs_off + gset);
+        g1 = wv::uload(a.gs_off + gset + 1);
+    }
+    const u32 ck = a.csi_of ? wv::uload(a.csi_of + t) : R6_NONE;
+    const u64* vrow = ck != R6_NONE ? a.vrows + (size_t)ck * Wn : nullptr;
+    u32 best = R6_NONE;
+    for (u32 w = tid; w < Wn; w += 1024) {
+        u64 m = scrow[w] & ~xrow[w];
+        if (res) m &= rc[w] & rm[w];
+        for (u32 g = g0; g < g1; ++g) m &= a.rg[(size_t)wv::uload(a.gs_row + g) * Wn + w];
+        if (vrow) m &= vrow[w];
+        for (u32 p = p0; p < p1; ++p) m &= ~a.portmap[(size_t)wv::uload(a.pset_ids + p) * Wn + w];
+        u32 rel = 0;
+        for (int b = nb - 1; b >= 0; --b) {
+            const u64 c = m & ~a.planes[(size_t)b * Wn + w];
+            if (c) m = c;
+            else if (m) rel |= 1u << b;
+        }
+        best = min(best, m ? rel : R6_NONE);
+    }
+    best = wv::min_u32(best);
+    if (lane == 0) red[wave] = best;
+    wv::barrier();
+    u32 gl = R6_NONE;
+    for (u32 v = 0; v < 16; ++v) gl = min(gl, red[v]);
+    u32 running = 0;
+    for (u32 w0 = 0; w0 < Wn; w0 += 1024) {
+        const u32 w = w0 + tid;
+        u64 c = (w < Wn && gl != R6_NONE) ? a.cbase[w] : 0ull;   // the ready nodes whose level IS gl
+        for (int b = 0; b < nb && c; ++b) {
+            const u64 pl = a.planes[(size_t)b * Wn + w];
+            c &= ((gl >> b) & 1u) ? pl : ~pl;
+        }
+        const u32 pc = (u32)wv::popc64(c);
+        u32 ex = 0, tot = 0;   // the counts (<= 64: seven bits) summed over the lower lanes plane by plane
+        WV_UNROLL
+        for (u32 bit = 0; bit < 7; ++bit) {
+            const u64 bm = wv::ballot(((pc >> bit) & 1u) != 0);
+            ex += wv::mbcnt(bm) << bit;
+            tot += (u32)wv::popc64(bm) << bit;
+        }
+        wv::barrier();   // (the counts of the chunk before are read)
+        if (lane == 0) red[16 + wave] = tot;
+        wv::barrier();
+        u32 off = 0, all = 0;
+        for (u32 v = 0; v < 16; ++v) {
+            const u32 x = red[16 + v];
+            off += v < wave ? x : 0u;
+            all += x;
+        }
+        if (w < Wn) {
+            a.cmask[w] = c;   // (read back below by the thread that wrote it)
+            a.crank[w] = running + off + ex;
+        }
+        running += all;
+    }
+    const bool on = running != 0 && running <= r6_compact_cap(Wn);
+    if (on)
+        for (u32 w = tid; w < Wn; w += 1024) {
+            u64 c = a.cmask[w];
+            u32 at = a.crank[w];
+            while (c) {
+                a.cidx[at++] = w * 64u + (u32)wv::ffs64(c);
+                c &= c - 1ull;
+            }
+        }
+    if (tid == 0) {
+        a.blk->csize = on ? running : 0u;
+        a.blk->clevel = gl;
+        if (on) a.blk->crounds += 1;
+    }
+}
+
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
 // The waves split the task's node words (wave v owns the chunks of 64 words k = v, v + R6_PW, ...): the passes are latency-bound,
 // so more waves per task is what shortens them. A pass ends with one barrier (has any wave a candidate left?).
-template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
+template <int UN, bool CPT = false> WV_DEV void r6_propose_t(const R6Args& a) {
     const u32 lane = wv::lane(), wave = wv::wave();
     const u32 t = wv::uload(&a.blk->pos) + wv::block();
     if (t >= wv::uload(&a.blk->end) || wv::uload(&a.blk->error) != ERR_NONE) return;   // (an error stops the rounds until the host has seen it)
@@ -307,6 +433,10 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
     const u32 maxrel = wv::uload(&a.blk->maxrel);
     const int nb = 32 - wv::clz32(maxrel);          // planes in use (0: every valid node sits on the base level)
     u32* R = reinterpret_cast<u32*>(Bf);            // [KC * 64] the word's own minimum level above the base, R6_NONE: no candidate in it
+    // the round's compact index (R6Args.compact): VW words of positions, the plain half-words are numbered behind them
+    const u32 csize = CPT ? wv::uload(&a.blk->csize) : 0u, VW = (csize + 63u) >> 6;
+    u64* V = reinterpret_cast<u64*>(R + (size_t)KC * 64);   // [VW <= KC * 16 + 1] the task's candidates by compact position (the upper half of Bf)
+    for (u32 i = wave * 64 + lane; i < VW; i += 64 * R6_PW) V[i] = 0;
     u32 best = R6_NONE;
     for (u32 k0 = wave; k0 < KC; k0 += UN * R6_PW) {
         u64 m[UN], f[UN];
@@ -379,15 +509,35 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
         twins += flag[R6_PW + v];
     }
     const u32 level = gmin == R6_NONE ? R6_NONE : wv::uload(&a.blk->base) + gmin;
+    // the task's minimum level is the compact index's: its candidates are among the index's nodes; every wave moves those of its share of
+    // the words to their positions
+    const bool cmode = CPT && csize != 0 && gmin == wv::uload(&a.blk->clevel);
+    if (CPT && cmode) {
+        u32* V32 = reinterpret_cast<u32*>(V);
+        for (u32 idx = wave * 64 + lane; idx < Wn; idx += 64 * R6_PW) {
+            u64 m = R[idx] == gmin ? A[idx] : 0ull;
+            if (!m) continue;
+            const u64 cm = a.cmask[idx];
+            const u32 r0 = a.crank[idx];
+            while (m) {
+                const u64 low = m & (0ull - m);
+                const u32 vp = r0 + (u32)wv::popc64(cm & (low - 1ull));
+                wv::lds_or32(V32 + (vp >> 5), 1u << (vp & 31u));
+                m ^= low;
+            }
+        }
+        wv::barrier();
+    }
     if (wave != 0) return;   // (every wave is past the last barrier) wave 0 lists the candidates and writes the proposal
+    const u32 nw = cmode ? VW : Wn, hw_off = cmode ? 0u : 2u * VW;
     R6Prop* out = a.prop + wv::block();
     // its first non-empty half-words, in node order (what the matcher walks: a word that is half empty does not cost a list entry):
     // 64 words a step, a lane's place in the list = the non-empty half-words in front of it (two ballots)
     u32 cnt = 0, more = 0;
     u32 skip = twins, last_hw = 0, last_hb = 0;   // candidates still to pass over; the last non-empty half-word passed over
     if (level != R6_NONE)
-        for (u32 k = 0; k < (Wn + 63u) / 64u && !more; ++k) {   // (the chunks beyond the row hold nothing)
-            const u64 m = R[k * 64 + lane] == gmin ? A[k * 64 + lane] : 0ull;   // the words whose own minimum is the task's
+        for (u32 k = 0; k < (nw + 63u) / 64u && !more; ++k) {   // (the chunks beyond the row hold nothing)
+            const u64 m = cmode ? (k * 64 + lane < VW ? V[k * 64 + lane] : 0ull) : (R[k * 64 + lane] == gmin ? A[k * 64 + lane] : 0ull);   // the words whose own minimum is the task's
             u32 lo = (u32)m, hi = (u32)(m >> 32);
             u64 b_lo = wv::ballot(lo != 0), b_hi = wv::ballot(hi != 0);
             if (!(b_lo | b_hi)) continue;
@@ -409,11 +559,11 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
                 if (gone | half) {   // remember the last half-word passed over: a level with no more than `skip` candidates lists that one
                     const u32 lg = gone ? 63u - (u32)__builtin_clzll(gone) : 0u, lh = half ? 63u - (u32)__builtin_clzll(half) : 0u;
                     if (half && (!gone || lh > lg)) {
-                        last_hw = 2 * (k * 64 + lh);
+                        last_hw = hw_off + 2 * (k * 64 + lh);
                         last_hb = wv::readlane(lo, lh);
                     } else {
                         const u32 hi_l = wv::readlane(hi, lg), lo_l = wv::readlane(lo, lg);
-                        last_hw = 2 * (k * 64 + lg) + (hi_l ? 1u : 0u);
+                        last_hw = hw_off + 2 * (k * 64 + lg) + (hi_l ? 1u : 0u);
                         last_hb = hi_l ? hi_l : lo_l;
                     }
                 }
@@ -426,11 +576,11 @@ template <int UN> WV_DEV void r6_propose_t(const R6Args& a) {
             }
             const u32 at_lo = cnt + wv::mbcnt(b_lo) + wv::mbcnt(b_hi), at_hi = at_lo + (lo != 0 ? 1u : 0u);
             if (lo && at_lo < 2 * R6_CAND) {
-                out->hw[at_lo] = 2 * (k * 64 + lane);
+                out->hw[at_lo] = hw_off + 2 * (k * 64 + lane);
                 out->hb[at_lo] = lo;
             }
             if (hi && at_hi < 2 * R6_CAND) {
-                out->hw[at_hi] = 2 * (k * 64 + lane) + 1;
+                out->hw[at_hi] = hw_off + 2 * (k * 64 + lane) + 1;
                 out->hb[at_hi] = hi;
             }
             const u32 total = cnt + (u32)wv::popc64(b_lo) + (u32)wv::popc64(b_hi);
@@ -501,6 +651,12 @@ WV_DEV void r6_propose(const R6Args& a) {
 }
 WV_KERNEL(64 * R6_PW) void k_r6_propose(R6Args a) { r6_propose(a); }
 WV_KERNEL(64 * R6_PW) void k_r6_propose_small(R6Args a) { r6_propose_t<1>(a); }   // n_words <= R6_SMALL_WORDS only: the registers of ONE chunk
+// ... the instances that honour a round's compact index (launched behind k_r6_compact only)
+WV_KERNEL(64 * R6_PW) void k_r6_propose_c(R6Args a) {
+    if (a.n_words <= R6_SMALL_WORDS) r6_propose_t<1, true>(a);
+    else r6_propose_t<R6_UNROLL, true>(a);
+}
+WV_KERNEL(64 * R6_PW) void k_r6_propose_small_c(R6Args a) { r6_propose_t<1, true>(a); }
 
 // index of the first of n ascending thresholds that is greater than q (n: none)
 WV_DEV u32 r6_first_above(const i64* thr, u32 n, i64 q) {
@@ -514,13 +670,15 @@ WV_DEV u32 r6_first_above(const i64* thr, u32 n, i64 q) {
 }
 
 // ---- commit: match the block in task order (wave 0), then apply the accepted picks (all threads) ---------------------------
-WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
+template <bool CPT> WV_DEV void r6_commit_t(const R6Args& a) {
     const u32 tid = wv::tid(), lane = wv::lane();
     const u32 pos = a.blk->pos, end = a.blk->end;
     if (pos >= end || a.blk->error != ERR_NONE) return;   // a level beyond the planes: the proposals of this round were not written
     const u32 n = min(a.block, end - pos), Wn = a.n_words, n_rr = a.n_dc + a.n_dm;
-    u64* tk = wv::lds();                                         // [Wn] nodes taken by this block so far
-    i64* thr = reinterpret_cast<i64*>(tk + Wn);                  // [n_rr] the demand-class thresholds
+    // (with a compact index the positions' words come first, the node words behind them: addresses as the lists carry them)
+    const u32 VW = CPT ? (a.blk->csize + 63u) >> 6 : 0u, tkw = CPT ? r6_tk_words(Wn) : Wn;
+    u64* tk = wv::lds();                                         // [tkw] addresses taken by this block so far
+    i64* thr = reinterpret_cast<i64*>(tk + tkw);                 // [n_rr] the demand-class thresholds
     u32* pk_node = reinterpret_cast<u32*>(thr + n_rr);           // [block] node, R6_NONE = no suitable node
     u32* pk_idx = pk_node + a.block;                             // [block] commit index / index among the unplaceable tasks
     u32* pk_aux = pk_idx + a.block;                              // [block] exception-list entry (LIST_EMPTY: plain node) / commits before an unplaceable task
@@ -530,7 +688,7 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     u32* L_cur = L_hb + (size_t)2 * R6_CAND * a.block;           // ... entry k of task i at [k * block + i] (no bank conflicts); [block] a lower bound of every task's cursor: the entries in front of it are dead
     unsigned short* L_hw = reinterpret_cast<unsigned short*>(L_cur + a.block);   // [2 * R6_CAND][block] the half-word indices, 16 bits each (the engine refuses node sets beyond 2^21 nodes)
     for (u32 j = tid; j < a.block; j += R6_COMMIT_THREADS) L_cur[j] = 0;
-    for (u32 w = tid; w < Wn; w += R6_COMMIT_THREADS) tk[w] = 0;
+    for (u32 w = tid; w < Wn + VW; w += R6_COMMIT_THREADS) tk[w] = 0;
     for (u32 c = tid; c < n_rr; c += R6_COMMIT_THREADS) thr[c] = a.thr[c];
     if (tid < 16) staged[tid] = 0;
     // Wave v >= 1 applies the picks of the block's group v - 1 (tasks 64 (v - 1) ...) as soon as wave 0 has matched that group, while
@@ -644,7 +802,7 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             u32 m_pick = R6_NONE;
             if (g0 == 0 && (m_exc & 1ull)) {   // the block's first task, from its exception list; the block ends behind it
                 if (lane == 0) {
-                    pk_node[0] = (u32)p->exc_lo;
+                    pk_node[0] = (u32)p->exc_lo + 64u * VW;   // (an address, like the matcher's picks)
                     pk_idx[0] = nc;
                     pk_aux[0] = p->exc_entry;
                 }
@@ -673,6 +831,11 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
                 {
                     seat(served && lane >= at, 1u);
                     if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
+                        if (prof && lane == at) {
+                            if (p->n_cand >> 31) a.blk->dbg_cut[0] += 1;
+                            if (CPT && L_hw[li] < 2u * VW) a.blk->dbg_cut[1] += 1;
+                            if ((p->n_cand & 0x7FFFFFFFu) == 1) a.blk->dbg_cut[2] += 1;
+                        }
                         cut = at;
                         why = 1;
                         break;
@@ -717,10 +880,10 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
             if (why == 1) a.blk->cut_exhausted += 1;
             if (why == 2) a.blk->cut_exception += 1;
             if (why == 3) a.blk->cut_uncounted += 1;
+            a.blk->reseats += reseats;   // (the host's sign of sparse lists: run_blocks switches the compact index on by it)
             if (prof) {
                 a.blk->cyc[0] += (u32)((t1 - t0) >> 6);
                 a.blk->cyc[1] += (u32)((wv::clock64() - t1) >> 6);
-                a.blk->reseats += reseats;
                 a.blk->cyc_load += (u32)(cy_load >> 6);
                 a.blk->cyc_walk += (u32)(cy_walk >> 6);
                 a.blk->cyc_g[0] += (u32)(cy_g0 >> 6);
@@ -757,7 +920,9 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     }
     const u32 acc_now = wv::readfirstlane(wv::lds_poll32(sh + 3));
     if (mine < acc_now) {
-        const u32 t = pos + mine, nd = pk_node[mine];
+        const u32 t = pos + mine, addr = pk_node[mine];
+        u32 nd = addr;
+        if (CPT) nd = addr == R6_NONE ? R6_NONE : addr < 64u * VW ? a.cidx[addr] : addr - 64u * VW;   // a compact position, or a node behind them
         if (nd == R6_NONE) {
             a.inf_task[pk_idx[mine]] = t;
             a.inf_pos[pk_idx[mine]] = pk_aux[mine];
@@ -825,6 +990,8 @@ WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) {
     }
     if (prof && wave_ == 1 && lane == 0) a.blk->cyc[3] += (u32)((wv::clock64() - t2) >> 6);   // the first group's applying wave: waiting for it + applying
 }
+WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) { r6_commit_t<false>(a); }
+WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit_c(R6Args a) { r6_commit_t<true>(a); }   // ... with a compact index (launched behind k_r6_compact only)
 
 #endif   // SWP_R6_KERNELS
 

@@ -67,14 +67,14 @@ static Problem make_problem(u32 seed, u32 N, u32 T, u32 S, int order, int feat) 
     p.mem.resize(N);
     p.total.resize(N);
     std::vector<u32> zone(N), ssd(N);
-    u32 lvl_mode = rnd(4);   // 0: all zero, 1: small spread, 2: wide spread, 3: a few stragglers far below, 4 (EMU_LVL_MODE=4 only): hundreds of levels
+    u32 lvl_mode = rnd(4);   // 0: all zero, 1: small spread, 2: wide spread, 3: a few stragglers far below, 4 (EMU_LVL_MODE=4 only): hundreds of levels, 5 (EMU_LVL_MODE=5 only): a tenth of the nodes emptied
     if (const char* lm = getenv("EMU_LVL_MODE")) lvl_mode = (u32)atoi(lm);
     for (u32 n = 0; n < N; ++n) {
         if (rnd(50) != 0) p.valid[n >> 6] |= 1ull << (n & 63);
         p.cpu[n] = (i64)(4 + rnd(60)) * 1'000'000'000 + (rnd(3) ? 0 : rnd(1000));          // not always a multiple of the unit
         p.mem[n] = (i64)(8 + rnd(120)) * (1ll << 30) + (rnd(3) ? 0 : rnd(4096));
         if (rnd(40) == 0) p.cpu[n] = -(i64)rnd(1000);                                       // over-committed node (scheduler.go:378-379)
-        p.total[n] = lvl_mode == 0 ? 0 : lvl_mode == 1 ? rnd(3) : lvl_mode == 2 ? rnd(40) : lvl_mode == 4 ? rnd(700) : (rnd(30) ? 20 + rnd(2) : rnd(5));
+        p.total[n] = lvl_mode == 0 ? 0 : lvl_mode == 1 ? rnd(3) : lvl_mode == 2 ? rnd(40) : lvl_mode == 4 ? rnd(700) : lvl_mode == 5 ? (rnd(10) ? 10 + rnd(2) : 0) : (rnd(30) ? 20 + rnd(2) : rnd(5));
         zone[n] = rnd(8);
         ssd[n] = rnd(10) < 7;
     }

@@ -26,11 +26,12 @@ int main(int argc, char** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
-    bool verbose = false, split = false, task_rows = false, twins = true;
+    bool verbose = false, split = false, task_rows = false, twins = true, compact = false;
     for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 's') split = true;
         if (argv[i][0] == 't') task_rows = true;   // rows per task of the block, rebuilt every round, instead of demand-class rows
+        if (argv[i][0] == 'c') compact = true;     // a compact index of the lowest level's nodes in front of every round (k_r6_compact)
         if (argv[i][0] == 'n') twins = false;      // lists start at the level's first candidate (R6Args.tmpl == nullptr: what the shard drivers run)
     }
     Problem p = make_problem(seed, N, T, S, order, feat);
@@ -120,6 +121,14 @@ int main(int argc, char** argv) {
         }
     }
     a.tmpl = twins ? tmpl.data() : nullptr;
+    std::vector<u64> cmask(p.Wn, 0xDDDDDDDDDDDDDDDDull);
+    std::vector<u32> crank(p.Wn, 0xDDDDDDDDu), cidx(r6_compact_cap(p.Wn), 0xDDDDDDDDu);
+    a.compact = compact ? 1u : 0u;
+    a.cbase = p.valid.data();   // (the harness has no drained nodes: every valid node is ready)
+    a.cmask = cmask.data();
+    a.crank = crank.data();
+    a.cidx = cidx.data();
+    u64 crounds_checked = 0;
 
     u64 rounds = 0;
     auto build = [&]() {
@@ -140,15 +149,38 @@ int main(int argc, char** argv) {
                     grid((p.Wn + 3) / 4, 256, (size_t)B * 16, [a]() { k_r6_taskrows(a); });
                 }
             emu::blockidx_y() = 0;
-            grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
-            grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
+            if (compact) {
+                grid(1, 1024, 256, [a]() { k_r6_compact(a); });
+                // the index against its definition: the ready nodes on ONE level, in node order, no more than a quarter of the node set;
+                // whether that level is the first task's is checked by the outcome (a wrong level only makes the index useless)
+                std::vector<u32> want;
+                for (u32 n = 0; n < N && blk.clevel != R6_NONE; ++n)
+                    if (((p.valid[n >> 6] >> (n & 63)) & 1) && em.total[n] == blk.base + blk.clevel) want.push_back(n);
+                const u32 cnt = (u32)want.size();
+                const bool on = cnt != 0 && cnt <= r6_compact_cap(p.Wn);
+                if (blk.csize != (on ? cnt : 0u)) { fprintf(stderr, "compact index: size %u on level %u, expected %u\n", blk.csize, blk.clevel, on ? cnt : 0u); return false; }
+                for (u32 i = 0; on && i < cnt; ++i)
+                    if (cidx[i] != want[i]) { fprintf(stderr, "compact index: position %u is node %u, expected %u\n", i, cidx[i], want[i]); return false; }
+                if (on) ++crounds_checked;
+                grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose_c(a); });
+                grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm, true), [a]() { k_r6_commit_c(a); });
+            } else {
+                grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
+                grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
+            }
             ++rounds;
             if (blk.error) { fprintf(stderr, "kernel reported error %u at task %u\n", blk.error, blk.pos); return false; }
             if (blk.pos <= before) { fprintf(stderr, "no progress at task %u\n", before); return false; }
         }
         // one more round past the end must be a no-op
-        grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
-        grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
+        if (compact) {
+            grid(1, 1024, 256, [a]() { k_r6_compact(a); });
+            grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose_c(a); });
+            grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm, true), [a]() { k_r6_commit_c(a); });
+        } else {
+            grid(B, 64 * R6_PW, r6_propose_lds(p.Wn), [a]() { k_r6_propose(a); });
+            grid(1, R6_COMMIT_THREADS, r6_commit_lds(p.Wn, B, n_dc + n_dm), [a]() { k_r6_commit(a); });
+        }
         return blk.pos == j1;
     };
     bool ok = split ? (stretch(0, T / 3) && stretch(T / 3, T)) : stretch(0, T);
@@ -175,8 +207,9 @@ int main(int argc, char** argv) {
         if (maxrel < hi) { fprintf(stderr, "maxrel %u below the highest level %u\n", maxrel, hi); ok = false; }
     }
     if (verbose || !ok)
-        fprintf(stderr, "seed %u N %u T %u S %u block %u order %d feat %d split %d: placed %u inf %u | rounds %llu (%.1f tasks each) cut: exhausted %u exception %u uncounted %u | classes %u+%u -> %s\n",
+        fprintf(stderr, "seed %u N %u T %u S %u block %u order %d feat %d split %d: placed %u inf %u | rounds %llu (%.1f tasks each) cut: exhausted %u exception %u uncounted %u | compact rounds %u | classes %u+%u -> %s\n",
                 seed, N, T, S, B, order, feat, (int)split, em.ctl.ncommit, em.ctl.ninf, (unsigned long long)rounds, rounds ? (double)T / (double)rounds : 0.0, blk.cut_exhausted,
-                blk.cut_exception, blk.cut_uncounted, n_dc, n_dm, ok ? "OK" : "FAIL");
+                blk.cut_exception, blk.cut_uncounted, blk.crounds, n_dc, n_dm, ok ? "OK" : "FAIL");
+    if (compact && blk.crounds != crounds_checked) { fprintf(stderr, "compact rounds %u counted, %llu seen\n", blk.crounds, (unsigned long long)crounds_checked); return 1; }
     return ok ? 0 : 1;
 }

@@ -73,3 +73,28 @@ def test_hundreds_of_levels(emu_bin, case):
     r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, EMU_LVL_MODE="4"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr
+
+
+# (the harness checks the index itself against its definition every round: the ready nodes on ONE level, in node order)
+COMPACT = [
+    ((12, 5924, 1856, 377, 512, 0, 0, "c"), "5"),     # a tenth of the nodes emptied: 17 rounds instead of 26
+    ((79, 66000, 1500, 200, 512, 0, 0, "c"), "5"),    # ... on 66 000 nodes: 3 rounds instead of 13
+    ((79, 66000, 1500, 200, 512, 0, 0, "c"), "3"),    # a few stragglers far below the bulk
+    ((2, 700, 1500, 30, 64, 0, 1, "tc"), "5"),        # task-rows mode: the index reads the block's first row
+    ((4, 5000, 2000, 300, 256, 0, 2, "sc"), "3"),     # host ports, uncounted tasks, a rebuild between two stretches
+    ((8, 885, 1500, 125, 64, 2, 3, "c"), "5"),        # generic reservations
+    ((50, 10000, 3000, 20, 512, 1, 0, "c"), "5"),     # twins: the offset counts compact positions
+    ((3, 1000, 2500, 40, 64, 2, 2, "c"), None),       # whatever level mode the seed draws
+    ((21, 4500, 1500, 200, 1024, 0, 1, "c"), None),
+]
+
+
+@pytest.mark.parametrize("case,lvl", COMPACT, ids=lambda c: ("seed%d-N%d-B%d-f%d%s" % (c[0], c[1], c[4], c[6], c[7])) if isinstance(c, tuple) else "lvl%s" % c)
+def test_compact_index(emu_bin, case, lvl):
+    """R6Args.compact: k_r6_compact numbers the ready nodes on the level the block's first task aims at; the tasks whose minimum level
+    is that one list half-words of positions, the others plain half-words behind them; the applying threads translate back."""
+    args = [str(x) for x in case[:7]] + ["v"] + list(case[7])
+    env = dict(os.environ, EMU_LVL_MODE=lvl) if lvl else dict(os.environ)
+    r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr

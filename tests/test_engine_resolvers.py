@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def resolver_env():
-    old = {k: os.environ.get(k) for k in ("SWP_RESOLVER", "SWP_R6_BLOCK", "SWP_R6_TASKROWS")}
+    old = {k: os.environ.get(k) for k in ("SWP_RESOLVER", "SWP_R6_BLOCK", "SWP_R6_TASKROWS", "SWP_R6_COMPACT")}
     yield
     for k, v in old.items():
         if v is None:
@@ -25,7 +25,11 @@ def resolver_env():
 
 def pick_variant(variant):
     os.environ.pop("SWP_R6_TASKROWS", None)
-    if variant == "6t":   # the block resolver with ResourceFilter rows per task of the block instead of per demand class
+    os.environ.pop("SWP_R6_COMPACT", None)
+    if variant == "6c":   # the block resolver with a compact index in front of every round (k_r6_compact; by itself only after the symptom)
+        os.environ["SWP_RESOLVER"] = "6"
+        os.environ["SWP_R6_COMPACT"] = "1"
+    elif variant == "6t":   # the block resolver with ResourceFilter rows per task of the block instead of per demand class
         os.environ["SWP_RESOLVER"] = "6"
         os.environ["SWP_R6_TASKROWS"] = "1"
     else:
@@ -33,7 +37,7 @@ def pick_variant(variant):
 
 
 CASES = [("cfg3", 2500, 300, {}), ("cfg4", 3000, 700, {}), ("cfg1", 500, 40, {}), ("cfg2", 3000, 50, {})]
-@pytest.mark.parametrize("variant", [5, 6, "6t"])
+@pytest.mark.parametrize("variant", [5, 6, "6t", "6c"])
 @pytest.mark.parametrize("name,T,N,kw", CASES)
 def test_variants_agree_with_oracle(resolver_env, variant, name, T, N, kw):
     wl = synth.Workload(name, T=T, N=N, **kw)
@@ -53,7 +57,7 @@ def test_words_per_lane(N):
     pu.assert_same(op, oe, ep, ee)
 
 
-@pytest.mark.parametrize("variant", [5, 6, "6t"])
+@pytest.mark.parametrize("variant", [5, 6, "6t", "6c"])
 @pytest.mark.parametrize("services,order", [(1, "rr"), (2, "rr"), (3, "major"), (40, "major"), (7, "rr")])
 def test_same_service_runs(resolver_env, variant, services, order):
     """Consecutive tasks of one service: every commit must be visible to the next task of that service although
