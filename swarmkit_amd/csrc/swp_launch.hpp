@@ -21,7 +21,7 @@ hipError_t launch_resolve5(const ResolveArgs& ra, size_t lds, hipStream_t s, int
 // k_resolve6, the block resolver (swp_resolve6.hip)
 struct R6Args;
 size_t r6_propose_lds_size(uint32_t n_words);
-size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr);
+size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr, bool compact = false);   // compact: with the room for a compact index (k_r6_compact)
 uint32_t r6_block_max();
 #define R6_BLOCK_DEFAULT_CAP 768u   // tasks per round of the block resolver unless SWP_R6_BLOCK says otherwise (and as the LDS allows)
 hipError_t launch_r6_build(const R6Args& a, hipStream_t s);

@@ -13,7 +13,7 @@
 namespace swpdev {
 
 size_t r6_propose_lds_size(uint32_t n_words) { return r6_propose_lds(n_words); }
-size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr) { return r6_commit_lds(n_words, block, n_rr, n_words <= R6_COMPACT_MAX_WORDS); }   // (room for a compact index where one may be built)
+size_t r6_commit_lds_size(uint32_t n_words, uint32_t block, uint32_t n_rr, bool compact) { return r6_commit_lds(n_words, block, n_rr, compact); }
 uint32_t r6_block_max() { return R6_BMAX; }
 
 // base / highest level, then level planes + demand-class rows from the node rows as they are

@@ -154,7 +154,8 @@ inline __host__ __device__ size_t r6_propose_lds(u32 n_words) { return (size_t)2
 // TK row, thresholds, the picks of the block, a few scalars, the block's lists (entry-major)
 // (per task: pick node / index / aux, the cursor, 2 * R6_CAND candidate masks and as many half-word indices of 16 bits: node sets of up to 2^21 nodes)
 // (the TK row: the node words, and in front of them the words of a compact index — at most a quarter of the nodes)
-#define R6_COMPACT_MAX_WORDS 16384u   // node words up to which a compact index is built (half-word indices are 16 bits in the commit kernel's LDS)
+#define R6_COMPACT_MAX_WORDS 16384u   // node words up to which a compact index may be built (half-word indices are 16 bits in the commit kernel's LDS); the
+                                      // engine builds one only where its quarter more of TK row fits next to the block's lists as they are
 inline __host__ __device__ u32 r6_compact_cap(u32 n_words) { return 16u * n_words; }
 inline __host__ __device__ u32 r6_tk_words(u32 n_words) { return n_words + n_words / 4u + 2u; }   // (with a compact index; n_words otherwise)
 inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr, bool compact = false) {
