@@ -1753,7 +1753,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         // one ended if the index was in use then.
         // SWP_R6_COMPACT=0 never, 1 from the first round on (tests, A/B runs).
         const char* env_cpt = getenv("SWP_R6_COMPACT");
-        const bool cpt_ok = Wn <= R6_COMPACT_MAX_WORDS && r6_commit_lds_size(Wn, r6_block, r6_nrr, true) <= lds_budget && !(env_cpt && atoi(env_cpt) == 0);   // (no smaller blocks for it)
+        const bool cpt_ok = Wn <= R6_COMPACT_MAX_WORDS && r6_commit_lds_size(Wn, r6_block, r6_nrr, true) <= lds_budget && b->csi_set.empty() && !(env_cpt && atoi(env_cpt) == 0);   // (no smaller blocks for it)
         bool cpt = cpt_ok && ((env_cpt && atoi(env_cpt) != 0) || e->r6_compact_hint);
         uint32_t exh_seen = 0, crounds_seen = 0, stops_seen = 0;
         bool cpt_paid = false;   // the last chunk that ran with the index had rounds that used it

@@ -25,11 +25,11 @@ hipError_t launch_r6_build(const R6Args& a, hipStream_t s) {
 
 // `rounds` rounds of propose + commit; a round past the end of the stretch is a no-op
 hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int dev) {
-    const bool cpt = a.compact != 0;
+    const bool cpt = a.compact != 0 && !a.csi_of;   // (a batch with cluster mounts has its own commit instance, without the index)
     const size_t lp = r6_propose_lds(a.n_words), lc = r6_commit_lds(a.n_words, a.block, a.n_dc + a.n_dm, cpt);
     hipError_t r;
     if (lp > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(cpt ? &k_r6_propose_c : &k_r6_propose), dev)) != hipSuccess) return r;
-    if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(cpt ? &k_r6_commit_c : &k_r6_commit), dev)) != hipSuccess) return r;
+    if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(cpt ? &k_r6_commit_c : a.csi_of ? &k_r6_commit_v : &k_r6_commit), dev)) != hipSuccess) return r;
     for (uint32_t i = 0; i < rounds; ++i) {
         if (a.task_rows) hipLaunchKernelGGL(k_r6_taskrows, dim3((a.n_words + 3) / 4, (a.block + 63) / 64), dim3(256), (size_t)a.block * 16, s, a);
         if (a.csi_of) hipLaunchKernelGGL(k_r6_volrows, dim3((a.n_words + 255) / 256, a.block), dim3(256), 0, s, a);   // (batches with cluster mounts only)
@@ -42,7 +42,8 @@ hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int
         }
         if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small, dim3(a.block), dim3(64 * R6_PW), lp, s, a);   // (LDS of 8 chunks: never beyond 48 KB)
         else hipLaunchKernelGGL(k_r6_propose, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
-        hipLaunchKernelGGL(k_r6_commit, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
+        if (a.csi_of) hipLaunchKernelGGL(k_r6_commit_v, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
+        else hipLaunchKernelGGL(k_r6_commit, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
     }
     return hipGetLastError();
 }

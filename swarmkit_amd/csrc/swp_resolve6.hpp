@@ -671,7 +671,9 @@ WV_DEV u32 r6_first_above(const i64* thr, u32 n, i64 q) {
 }
 
 // ---- commit: match the block in task order (wave 0), then apply the accepted picks (all threads) ---------------------------
-template <bool CPT> WV_DEV void r6_commit_t(const R6Args& a) {
+// (CSI: the instance for batches with cluster mounts — choosing volumes indexes a small array dynamically, which costs the kernel a scratch
+// segment; the ordinary instances have none)
+template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
     const u32 tid = wv::tid(), lane = wv::lane();
     const u32 pos = a.blk->pos, end = a.blk->end;
     if (pos >= end || a.blk->error != ERR_NONE) return;   // a level beyond the planes: the proposals of this round were not written
@@ -978,7 +980,7 @@ template <bool CPT> WV_DEV void r6_commit_t(const R6Args& a) {
             a.log_prev[ci] = prev;
             a.last[nd] = (int32_t)ci;
             a.out_node[t] = (int32_t)nd;
-            if (a.csi_of) {   // chooseTaskVolumes + reserveTaskVolumes on the node (scheduler.go:857-874); a mount without a volume: assigned without attachments
+            if (CSI && a.csi_of) {   // chooseTaskVolumes + reserveTaskVolumes on the node (scheduler.go:857-874); a mount without a volume: assigned without attachments
                 const u32 ck = a.csi_of[t];
                 if (ck != R6_NONE) {
                     u32 att[VOL_MAX_MOUNTS];
@@ -991,8 +993,9 @@ template <bool CPT> WV_DEV void r6_commit_t(const R6Args& a) {
     }
     if (prof && wave_ == 1 && lane == 0) a.blk->cyc[3] += (u32)((wv::clock64() - t2) >> 6);   // the first group's applying wave: waiting for it + applying
 }
-WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) { r6_commit_t<false>(a); }
-WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit_c(R6Args a) { r6_commit_t<true>(a); }   // ... with a compact index (launched behind k_r6_compact only)
+WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) { r6_commit_t<false, false>(a); }
+WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit_c(R6Args a) { r6_commit_t<true, false>(a); }   // ... with a compact index (launched behind k_r6_compact only)
+WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit_v(R6Args a) { r6_commit_t<false, true>(a); }   // ... for a batch with cluster mounts (R6Args.csi_of)
 
 #endif   // SWP_R6_KERNELS
 

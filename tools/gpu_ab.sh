@@ -1,11 +1,13 @@
 #!/bin/bash
-# A/B on ONE box: the library built from an earlier commit (tools/_ab/libswp_old.so, not tracked) against the working tree's
+# A/B on ONE box (boxes differ by up to 10 %): the libraries tools/_ab/libswp_<name>.so (built from other commits / with other flags; not
+# tracked) against the tree's library ("new"), twice:  gpurun -- bash tools/gpu_ab.sh <tag> <name> [<name> ...]
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/${1:-ab}; mkdir -p $O
+O=gpurun_out/${1:-ab}; mkdir -p $O; shift
+NAMES="${@:-old}"
 B="timeout 300 python bench.py --no-cpu-baseline"
 for rep in 1 2; do
-for v in old new new_off; do
-  L="SWP_X=1"; [ $v = old ] && L="SWP_LIB_PATH=$PWD/tools/_ab/libswp_old.so"; [ $v = new_off ] && L="SWP_R6_COMPACT=0"
+for v in $NAMES new; do
+  L="SWP_X=1"; [ $v != new ] && L="SWP_LIB_PATH=$PWD/tools/_ab/libswp_$v.so"
   env $L $B > $O/cfg3_$v.json 2> $O/cfg3_$v.err
   env $L $B --order major > $O/major_$v.json 2> $O/major_$v.err
   env $L $B --mode churn --rounds 20 > $O/churn_$v.json 2> $O/churn_$v.err
