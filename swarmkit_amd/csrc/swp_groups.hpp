@@ -809,8 +809,8 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     const G2Ent head = A.HE[0];
                     for (u32 j0 = 0; j0 < len; j0 += 64) {
                         const u32 j = j0 + lane;
-                        G2Ent v = head;
-                        if (j + 1 < len) v = A.HE[j + 1];
+                        const G2Ent nx = A.HE[j + 1 < len ? j + 1 : 0u];
+                        const G2Ent v = g2_pick(j + 1 < len, nx, head);   // (field by field: a record selected as a whole lives in scratch memory)
                         wv::lockstep();   // every lane has read its element before any lane overwrites one
                         if (j < len) A.HE[j] = v;
                     }
