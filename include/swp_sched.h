@@ -47,6 +47,11 @@ int swp_sched_update_volume(swp_sched*, const char* volume_json, size_t len);
 /* the volumeSet's view of one volume as JSON {Tasks {task: {NodeID, ReadOnly}}, Nodes {node: reference count}, Engine {Tasks, Writers}};
  * SWP_ENOTFOUND: the set does not hold it */
 int swp_sched_volume_info(swp_sched*, const char* volume_id, size_t len, const char** json_out);
+/* volumeSet.freeVolumes (volumes.go:181-221), which tick defers as a store batch (scheduler.go:501): JSON [{VolumeID, NodeIDs [...]}...] —
+ * per volume the nodes whose PublishStatus goes from PUBLISHED to PENDING_NODE_UNPUBLISH because nothing on them uses the volume any more.
+ * The caller writes them to its store (store.UpdateVolume); the volume documents kept here are moved along, so a second call is empty.
+ * volume_json of swp_sched_update_volume may carry PublishStatus [{NodeID, State}] for this. Valid until the next call on this handle. */
+int swp_sched_free_volumes(swp_sched*, const char** json_out);
 
 /* What noSuitableNode reads from the store about a service (scheduler.go:934-953): does it exist, and its
  * SpecVersion (has_version = 0: nil). */

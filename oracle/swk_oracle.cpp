@@ -1026,6 +1026,24 @@ void VolumeSet::release(const std::string& volume_id, const std::string& task_id
     it->second.tasks.erase(ut);
 }
 
+std::vector<std::pair<std::string, std::vector<std::string>>> VolumeSet::free_volumes() {
+    std::vector<std::pair<std::string, std::vector<std::string>>> out;
+    for (auto& kv : volumes_) {
+        Info& info = kv.second;
+        if (!info.volume) continue;
+        std::vector<std::string> changed;
+        for (PublishStatus& st : info.volume->publish_status) {
+            auto n = info.nodes.find(st.node_id);
+            if ((n == info.nodes.end() || n->second == 0) && st.state == VolumePublished) {   // volumes.go:200-203
+                st.state = VolumePendingNodeUnpublish;
+                changed.push_back(st.node_id);
+            }
+        }
+        if (!changed.empty()) out.emplace_back(kv.first, std::move(changed));
+    }
+    return out;
+}
+
 std::string VolumeSet::is_available_on_node(const Mount& mount, const NodeInfo& node) const {
     static const std::string prefix = "group:";
     if (mount.source.compare(0, prefix.size(), prefix) == 0) {

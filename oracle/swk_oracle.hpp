@@ -110,12 +110,16 @@ enum { VolumeScopeSingleNode = 0, VolumeScopeMultiNode = 1 };
 enum { VolumeSharingNone = 0, VolumeSharingReadOnly = 1, VolumeSharingOneWriter = 2, VolumeSharingAll = 3 };
 enum { VolumeAvailabilityActive = 0, VolumeAvailabilityPause = 1, VolumeAvailabilityDrain = 2 };
 struct Topology { std::map<std::string, std::string> segments; };
+// api.VolumePublishStatus (types.proto:1337-1385): the two fields freeVolumes reads
+enum { VolumePendingPublish = 0, VolumePublished = 1, VolumePendingNodeUnpublish = 2, VolumePendingUnpublish = 3 };
+struct PublishStatus { std::string node_id; int state = VolumePendingPublish; };
 struct Volume {
     std::string id, name, group, driver_name;   // ID, Spec.Annotations.Name, Spec.Group, Spec.Driver.Name
     int scope = VolumeScopeSingleNode, sharing = VolumeSharingNone, availability = VolumeAvailabilityActive;
     bool has_volume_info = false;
     std::string volume_id;                       // VolumeInfo.VolumeID ("" = not created by the plugin yet: the scheduler ignores it)
     std::vector<Topology> accessible;            // VolumeInfo.AccessibleTopology
+    std::vector<PublishStatus> publish_status;   // PublishStatus
 };
 using VolumePtr = std::shared_ptr<Volume>;
 struct VolumeAttachment { std::string id, source, target; };
@@ -274,6 +278,11 @@ class VolumeSet {
     void release(const std::string& volume_id, const std::string& task_id);                                              // :169-187
     std::string is_available_on_node(const Mount& mount, const NodeInfo& node) const;                                     // :223-257
     bool check_volume(const std::string& id, const NodeInfo& node, bool read_only) const;                                 // :261-316
+    // freeVolumes, volumes.go:181-221: every PUBLISHED status of a volume on a node whose reference count is zero becomes
+    // PENDING_NODE_UNPUBLISH. Returns (volume id, the nodes whose status changed) for the volumes that changed, by volume id (the reference
+    // walks a Go map and writes one store update per volume: the order carries no meaning). The volume object kept here stands for the
+    // store's copy (store.GetVolume, :189): it is updated, as the store's is — a second call reports nothing new.
+    std::vector<std::pair<std::string, std::vector<std::string>>> free_volumes();
     const Info* info(const std::string& id) const { auto it = volumes_.find(id); return it == volumes_.end() ? nullptr : &it->second; }
     size_t size() const { return volumes_.size(); }
 
@@ -338,6 +347,7 @@ class Scheduler {
     bool delete_task_event(const TaskPtr& t);
     void update_volume(const VolumePtr& v);   // EventUpdateVolume (scheduler.go:200-213) and setupTasksList's volumes (:70-81)
     const VolumeSet& volumes() const { return volumes_; }
+    std::vector<std::pair<std::string, std::vector<std::string>>> free_volumes() { return volumes_.free_volumes(); }   // tick's deferred store.Batch(s.volumes.freeVolumes), scheduler.go:501
     Scheduler() { pipeline.vs = &volumes_; }   // Run appends the VolumesFilter (scheduler.go:132)
     Scheduler(const Scheduler&) = delete;
     Scheduler& operator=(const Scheduler&) = delete;

@@ -141,6 +141,13 @@ VolumePtr decode_volume(const Value& v) {
                 vol->accessible.push_back(top);
             }
     }
+    if (const Value* ps = v.obj_or_null("PublishStatus"))
+        for (auto& st : ps->arr) {
+            PublishStatus p;
+            p.node_id = st->str_or("NodeID", "");
+            p.state = enum_of(st->get("State"), {{"PENDING_PUBLISH", 0}, {"PUBLISHED", 1}, {"PENDING_NODE_UNPUBLISH", 2}, {"PENDING_UNPUBLISH", 3}}, 0);
+            vol->publish_status.push_back(p);
+        }
     return vol;
 }
 
@@ -451,6 +458,27 @@ int orc_volume_info(void* s, const char* id) {
             o += ":" + std::to_string(kv.second);
         }
         o += "}}";
+        g_out = o;
+    });
+}
+// freeVolumes (volumes.go:181-221): [{"VolumeID": id, "NodeIDs": [the nodes whose PUBLISHED status became PENDING_NODE_UNPUBLISH]}...]
+int orc_free_volumes(void* s) {
+    return guarded([&] {
+        std::string o = "[";
+        bool first = true;
+        for (auto& kv : static_cast<Scheduler*>(s)->free_volumes()) {
+            if (!first) o += ",";
+            first = false;
+            o += "{";
+            put_kv(o, "VolumeID", kv.first);
+            o += "\"NodeIDs\":[";
+            for (size_t i = 0; i < kv.second.size(); ++i) {
+                if (i) o += ",";
+                orcjson::escape_into(o, kv.second[i]);
+            }
+            o += "]}";
+        }
+        o += "]";
         g_out = o;
     });
 }

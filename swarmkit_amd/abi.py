@@ -114,7 +114,7 @@ EXPORTS = [
     # include/swp_sched.h — the host layer above the engine
     "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
     "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
-    "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_reject_decision", "swp_sched_commit_plan", "swp_sched_reject_decisions", "swp_sched_reject_node", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce", "swp_sched_update_volume", "swp_sched_volume_info",
+    "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_reject_decision", "swp_sched_commit_plan", "swp_sched_reject_decisions", "swp_sched_reject_node", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce", "swp_sched_update_volume", "swp_sched_volume_info", "swp_sched_free_volumes",
     "swp_constraint_parse", "swp_key_equal_fold", "swp_explain", "swp_parse_ip",
 ]
 

@@ -442,13 +442,50 @@ class Scheduler {
         auto it = volumes_.find(vid);
         if (it == volumes_.end()) return;
         it->second.tasks[tid] = VolumeUse{nid, ro};
+        it->second.nodes[nid] += 1;   // (per CALL, volumes.go:159: a task with two mounts on one volume counts its node twice)
         pushVolumeUsage(it->second);
     }
     void releaseVolume(const std::string& vid, const std::string& tid) {
         auto it = volumes_.find(vid);
         if (it == volumes_.end()) return;
-        if (it->second.tasks.erase(tid)) pushVolumeUsage(it->second);
+        auto ut = it->second.tasks.find(tid);
+        if (ut == it->second.tasks.end()) return;
+        int64_t& c = it->second.nodes[ut->second.node];
+        if (c > 0) c -= 1;   // volumes.go:171-176
+        it->second.tasks.erase(ut);
+        pushVolumeUsage(it->second);
     }
+    // freeVolumes (volumes.go:181-221), what tick defers (scheduler.go:501): the PUBLISHED statuses of a volume on nodes whose reference
+    // count is zero become PENDING_NODE_UNPUBLISH. The store is the caller's: this returns the updates to write — [{"VolumeID", "NodeIDs"}]
+    // by volume id — and moves the statuses of the volume documents kept here (they stand for the store's copy, :189; the store's
+    // EventUpdateVolume brings the same back), so a second call reports nothing new.
+    void freeVolumes(std::string& out) {
+        Value updates = Value::array();
+        for (auto& kv : volumes_) {
+            const Value* ps = kv.second.doc.get("PublishStatus");   // (this document is the private copy updateVolume parsed)
+            if (ps == nullptr || !ps->is_arr()) continue;
+            Value changed = Value::array();
+            for (Value& st : *ps->a) {
+                if (!st.is_obj()) continue;
+                const std::string& nid = as_str(st.get("NodeID"));
+                auto n = kv.second.nodes.find(nid);
+                if ((n == kv.second.nodes.end() || n->second == 0) && enum_value(st.get("State"), {{"PENDING_PUBLISH", 0}, {"PUBLISHED", 1}, {"PENDING_NODE_UNPUBLISH", 2}, {"PENDING_UNPUBLISH", 3}}) == 1) {
+                    st.set("State", Value::str("PENDING_NODE_UNPUBLISH"));
+                    changed.push(Value::str(nid));
+                }
+            }
+            if (changed.a->empty()) continue;
+            Value u = Value::object();
+            u.set("VolumeID", Value::str(kv.first));
+            u.set("NodeIDs", changed);
+            updates.push(u);
+        }
+        out = json::dump(updates);
+    }
+    // (One thing the reference's counts do that these do not: chooseTaskVolumes reserves every volume it picks for the task and releases
+    // them all on return, volumes.go:118-131 — but a release finds the task only ONCE per volume, so a volume that serves m of ONE task's
+    // mounts keeps m − 1 counts on the node for ever, whether the choice succeeds or not. The engine chooses here and reserves nothing on
+    // the way, so such a volume is unpublished from a node by freeVolumes when its last user is gone; the reference never does — DESIGN §8.)
     // reserveTaskVolumes, volumes.go:144-154
     void reserveTaskVolumes(const Value& t) {
         const Value* vols = t.get("Volumes");
@@ -468,15 +505,13 @@ class Scheduler {
         auto it = volumes_.find(vid);
         if (it == volumes_.end()) return false;
         Value tasks = Value::object(), nodes = Value::object();
-        std::map<std::string, int64_t> refs;
         for (const auto& kv : it->second.tasks) {
             Value u = Value::object();
             u.set("NodeID", Value::str(kv.second.node));
             u.set("ReadOnly", Value::boolean(kv.second.read_only));
             tasks.set(kv.first, u);
-            refs[kv.second.node] += 1;
         }
-        for (const auto& kv : refs) nodes.set(kv.first, Value::integer(kv.second));
+        for (const auto& kv : it->second.nodes) nodes.set(kv.first, Value::integer(kv.second));   // (volumeInfo.nodes as the reference keeps it: zeros stay)
         swp_volume_usage use;
         ck(swp_volume_get_usage(e_, it->second.idx, &use), "swp_volume_get_usage");
         Value eng = Value::object();
@@ -1097,7 +1132,7 @@ class Scheduler {
     std::set<std::string> preassignedTasks_;                               // Scheduler.preassignedTasks
     // Scheduler.volumes (volumes.go:19-46): the task -> usage maps; the engine holds the numbers checkVolume derives from them
     struct VolumeUse { std::string node; bool read_only; };
-    struct VolumeRec { Value doc; uint32_t idx = 0; std::map<std::string, VolumeUse> tasks; };
+    struct VolumeRec { Value doc; uint32_t idx = 0; std::map<std::string, VolumeUse> tasks; std::map<std::string, int64_t> nodes; };   // volumeInfo, volumes.go:19-36
     std::map<std::string, VolumeRec> volumes_;
     std::map<std::string, std::string> volByName_;
     std::vector<std::string> vol_idx_to_id_;
@@ -1729,6 +1764,14 @@ int swp_sched_volume_info(swp_sched* s, const char* volume_id, size_t len, const
     return guarded(s, [&](swp::Scheduler& impl) {
         if (volume_id == nullptr || json_out == nullptr) return (int)SWP_EINVAL;
         if (!impl.volumeInfo(std::string(volume_id, len), impl.scratch)) return (int)SWP_ENOTFOUND;
+        *json_out = impl.scratch.c_str();
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_free_volumes(swp_sched* s, const char** json_out) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (json_out == nullptr) return (int)SWP_EINVAL;
+        impl.freeVolumes(impl.scratch);
         *json_out = impl.scratch.c_str();
         return (int)SWP_OK;
     });

@@ -95,6 +95,13 @@ class Scheduler:
         self._ck(rc)
         return json.loads(out.value.decode())
 
+    def free_volumes(self):
+        """volumeSet.freeVolumes (volumes.go:181-221), what the reference's tick defers (scheduler.go:501): [{"VolumeID", "NodeIDs"}] — the
+        publish statuses to move from PUBLISHED to PENDING_NODE_UNPUBLISH in the caller's store."""
+        out = C.c_char_p()
+        self._ck(self.L.swp_sched_free_volumes(self.h, C.byref(out)))
+        return json.loads(out.value.decode())
+
     def set_service(self, sid, spec_version=None):
         b = _b(sid)
         self._ck(self.L.swp_sched_set_service(self.h, b, len(b), 0 if spec_version is None else 1, int(spec_version or 0)))

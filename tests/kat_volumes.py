@@ -77,3 +77,24 @@ def cluster_mount(source, target, read_only=False):
     if read_only:
         m["ReadOnly"] = True
     return m
+
+
+def free_volumes_fixture():
+    """volumes_test.go:530-642 (Describe "freeVolumes", BeforeEach): four nodes, four volumes each PUBLISHED on "its" node, a fifth volume
+    PUBLISHED on all four; task i sits on node i and uses volume i and the fifth one. Returns (nodes, volumes, all_volume, tasks)."""
+    all_volume = canned_volume(5)
+    all_volume["PublishStatus"] = []
+    nodes, volumes, tasks = [], [], []
+    for i in range(4):
+        v = canned_volume(i)
+        n = {"ID": "node%d" % i, "Description": {}}
+        v["PublishStatus"] = [{"NodeID": n["ID"], "State": "PUBLISHED"}]
+        all_volume["PublishStatus"].append({"NodeID": n["ID"], "State": "PUBLISHED"})
+        t = {"ID": "task%d" % i, "ServiceID": "svc", "NodeID": n["ID"], "DesiredState": 512, "Status": {"State": 512},
+             "Spec": {"Container": {"Mounts": [cluster_mount(v["Spec"]["Annotations"]["Name"], "bar"), cluster_mount(all_volume["Spec"]["Annotations"]["Name"], "baz")]}},
+             "Volumes": [{"Source": v["Spec"]["Annotations"]["Name"], "Target": "bar", "ID": v["ID"]},
+                         {"Source": all_volume["Spec"]["Annotations"]["Name"], "Target": "baz", "ID": all_volume["ID"]}]}
+        nodes.append(n)
+        volumes.append(v)
+        tasks.append(t)
+    return nodes, volumes, all_volume, tasks

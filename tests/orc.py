@@ -48,6 +48,7 @@ def lib():
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         L.orc_set_service.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint64]
         L.orc_tick.argtypes = [ctypes.c_void_p]
+        L.orc_free_volumes.argtypes = [ctypes.c_void_p]
         L.orc_process_preassigned.argtypes = [ctypes.c_void_p]
         L.orc_process_calls.argtypes = [ctypes.c_void_p]
         L.orc_process_calls.restype = ctypes.c_uint64
@@ -127,6 +128,12 @@ class Oracle:
 
     def volume_info(self, volume_id):
         _check(self.L.orc_volume_info(self.h, volume_id.encode()))
+        return json.loads(self.L.orc_result().decode())
+
+    def free_volumes(self):
+        """freeVolumes (volumes.go:181-221), what tick defers (scheduler.go:501): [{"VolumeID", "NodeIDs"}] = the publish statuses to move
+        from PUBLISHED to PENDING_NODE_UNPUBLISH."""
+        _check(self.L.orc_free_volumes(self.h))
         return json.loads(self.L.orc_result().decode())
 
     def delete_service(self, service_id):

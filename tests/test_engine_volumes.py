@@ -22,9 +22,13 @@ def cxx_host(monkeypatch):
 class Both:
     """The same events into the oracle and into the engine's host layer; every tick's decisions and the volumes' users must agree."""
 
-    def __init__(self):
+    def __init__(self, counts=True):
         self.o, self.e = orc.Oracle(), swhost.HostScheduler()
         self.vols = []
+        # counts: compare the volumes' reference counts per node and every freeVolumes batch too. Not in the seeded clusters: there a task's
+        # mounts may resolve to ONE volume twice, and the reference's chooseTaskVolumes then leaks a count (volumes.go:118-131: its deferred
+        # releases find the task only once per volume) which the host layer does not replay (swp_sched.cpp, above reserveTaskVolumes).
+        self.counts = counts
 
     def __getattr__(self, name):
         def call(*a):
@@ -42,6 +46,9 @@ class Both:
         do, de = self._norm(self.o.tick()), self._norm(self.e.tick())
         assert do == de, [(a, b) for a, b in zip(do, de) if a != b][:4]
         self.check_volumes()
+        if self.counts:
+            fo, fe = self.o.free_volumes(), self.e.free_volumes()   # what the reference's tick defers (scheduler.go:501)
+            assert fo == fe, (fo, fe)
         return do
 
     def process_preassigned(self):
@@ -56,7 +63,11 @@ class Both:
             assert (io is None) == (ie is None), vid
             if io is None:
                 continue
+            # (reference counts: a node that was counted once and given back reads 0 in the oracle's map, as in the reference's — chooseTaskVolumes
+            # reserves and releases on the way, volumes.go:118-131 — and is absent where nothing was ever reserved: the same thing to every reader)
             assert io["Tasks"] == ie["Tasks"], (vid, io, ie)
+            if self.counts:
+                assert {k: c for k, c in io["Nodes"].items() if c} == {k: c for k, c in ie["Nodes"].items() if c}, (vid, io, ie)
             assert ie["Engine"]["Tasks"] == len(io["Tasks"]) and ie["Engine"]["Writers"] == sum(1 for u in io["Tasks"].values() if not u["ReadOnly"]), (vid, io, ie)
 
 
@@ -170,7 +181,7 @@ def test_random_clusters_with_volumes(seed):
     """Nodes with CSI topologies, volumes of every access mode in groups, tasks with one to three cluster mounts (named, grouped, read-only)
     next to plain tasks, several ticks with tasks going away in between: every decision, attachment and reservation as the oracle's."""
     rng = random.Random(0xC51 + seed)
-    b = Both()
+    b = Both(counts=False)
     zones = ["z1", "z2", "z3"]
     n_nodes = rng.choice([3, 8, 40, 150])
     for i in range(n_nodes):
@@ -191,7 +202,8 @@ def test_random_clusters_with_volumes(seed):
         b.update_volume({"ID": "vol%02d" % v, "Spec": {"Annotations": {"Name": "name%02d" % v}, "Group": rng.choice(["", "g1", "g2"]), "Driver": {"Name": rng.choice(["p1", "p2"])},
                                                        "AccessMode": {"Scope": rng.choice([kv.SINGLE, kv.MULTI]), "Sharing": rng.choice([kv.NONE, kv.READ_ONLY, kv.ONE_WRITER, kv.ALL])},
                                                        "Availability": rng.choice(["ACTIVE", "ACTIVE", "ACTIVE", "PAUSE"])},
-                         "VolumeInfo": {"VolumeID": "csi%02d" % v, "AccessibleTopology": acc}})
+                         "VolumeInfo": {"VolumeID": "csi%02d" % v, "AccessibleTopology": acc},
+                         "PublishStatus": [{"NodeID": "n%04d" % k, "State": "PUBLISHED"} for k in range(0, n_nodes, 2)]})   # (what freeVolumes looks at)
     for s in range(4):
         b.set_service("svc%d" % s)
     placed, tid, docs = [], 0, {}
@@ -252,7 +264,7 @@ def test_random_task_groups_with_volumes(seed):
     """Services with a spec version (task groups, scheduler.go:442-459) whose specs carry cluster mounts, next to groups without and one-off
     tasks: tree() with the VolumesFilter, the fill loop's re-checks against the volumes as the group's own placements leave them."""
     rng = random.Random(0x6C51 + seed)
-    b = Both()
+    b = Both(counts=False)
     zones = ["z1", "z2"]
     n_nodes = rng.choice([4, 12, 60])
     for i in range(n_nodes):
@@ -264,7 +276,8 @@ def test_random_task_groups_with_volumes(seed):
         acc = [{"Segments": {"zone": rng.choice(zones)}}] if rng.random() < 0.6 else []
         b.update_volume({"ID": "vol%02d" % v, "Spec": {"Annotations": {"Name": "name%02d" % v}, "Group": rng.choice(["g1", "g2"]), "Driver": {"Name": "p1"},
                                                        "AccessMode": {"Scope": rng.choice([kv.SINGLE, kv.MULTI]), "Sharing": rng.choice([kv.NONE, kv.READ_ONLY, kv.ONE_WRITER, kv.ALL])}},
-                         "VolumeInfo": {"VolumeID": "csi%02d" % v, "AccessibleTopology": acc}})
+                         "VolumeInfo": {"VolumeID": "csi%02d" % v, "AccessibleTopology": acc},
+                         "PublishStatus": [{"NodeID": "n%04d" % k, "State": "PUBLISHED"} for k in range(0, n_nodes, 2)]})   # (what freeVolumes looks at)
     tid = 0
     for tick in range(4):
         for s in range(rng.choice([2, 5])):

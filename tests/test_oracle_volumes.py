@@ -123,3 +123,70 @@ def test_any_requested_mount_passes_the_filter_but_every_mount_needs_a_volume():
     d = o.tick()
     assert [(x["ID"], x["NodeID"], x["State"], x.get("Volumes")) for x in d] == [("t1", "n1", orc.ASSIGNED, None)]
     assert o.volume_info("volumeID1")["Tasks"] == {}
+
+
+def _free_volumes_cluster(s):
+    nodes, volumes, all_volume, tasks = kv.free_volumes_fixture()
+    for n in nodes:
+        s.create_node(dict(n, Status={"State": orc.READY}))
+    for v in volumes + [all_volume]:
+        s.update_volume(v)
+    s.set_service("svc")
+    for t in tasks:
+        s.setup_task(t)
+    return nodes, volumes, all_volume, tasks
+
+
+def test_free_volumes_reference_counts():
+    """volumes_test.go:644-661: every volume is referenced once per node that uses it."""
+    o = orc.Oracle()
+    nodes, volumes, all_volume, tasks = _free_volumes_cluster(o)
+    for i, v in enumerate(volumes):
+        assert o.volume_info(v["ID"])["Nodes"] == {nodes[i]["ID"]: 1}
+    assert o.volume_info(all_volume["ID"])["Nodes"] == {n["ID"]: 1 for n in nodes}
+    assert o.free_volumes() == []   # (nothing to free while every publication is in use)
+
+
+def test_free_volumes_that_are_no_longer_needed():
+    """volumes_test.go:663-697: task0 lets go of its two volumes; volume 0 and the shared volume are to be unpublished from node0, every
+    other publication stays."""
+    o = orc.Oracle()
+    nodes, volumes, all_volume, tasks = _free_volumes_cluster(o)
+    o.delete_task(tasks[0])   # releaseVolume(volumes[0].ID, task0) + releaseVolume(allVolume.ID, task0), scheduler.go:330-332
+    got = o.free_volumes()
+    assert got == [{"VolumeID": volumes[0]["ID"], "NodeIDs": ["node0"]}, {"VolumeID": all_volume["ID"], "NodeIDs": ["node0"]}]
+    assert o.free_volumes() == []   # the store's copy says PENDING_NODE_UNPUBLISH now
+
+
+def test_free_volumes_leaves_other_states_alone():
+    """volumes.go:200: only a PUBLISHED status on a node with a zero reference count changes."""
+    o = orc.Oracle()
+    v = kv.canned_volume(1)
+    v["PublishStatus"] = [{"NodeID": "a", "State": "PENDING_PUBLISH"}, {"NodeID": "b", "State": "PUBLISHED"}, {"NodeID": "c", "State": "PENDING_UNPUBLISH"},
+                          {"NodeID": "d", "State": "PENDING_NODE_UNPUBLISH"}, {"NodeID": "e", "State": "PUBLISHED"}]
+    o.update_volume(v)
+    o.create_node({"ID": "e", "Status": {"State": orc.READY}, "Description": {}})
+    o.set_service("svc")
+    o.setup_task({"ID": "t", "ServiceID": "svc", "NodeID": "e", "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING},
+                  "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume1", "/m")]}}, "Volumes": [{"ID": v["ID"], "Source": "volume1", "Target": "/m"}]})
+    assert o.free_volumes() == [{"VolumeID": v["ID"], "NodeIDs": ["b"]}]
+
+
+def test_a_volume_reserved_twice_by_one_task_keeps_a_reference():
+    """volumes.go:156-160 counts a node once per reserveVolume call, :169-178 gives back one per releaseVolume of a task that still holds
+    the volume: a task with two mounts on ONE volume reserves twice and releases once — the publication is never freed (the
+    reference's behaviour, restated as it is)."""
+    o = orc.Oracle()
+    v = kv.canned_volume(1)
+    v["PublishStatus"] = [{"NodeID": "n", "State": "PUBLISHED"}]
+    o.update_volume(v)
+    o.create_node({"ID": "n", "Status": {"State": orc.READY}, "Description": {}})
+    o.set_service("svc")
+    t = {"ID": "t", "ServiceID": "svc", "NodeID": "n", "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING},
+         "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume1", "/a"), kv.cluster_mount("volume1", "/b")]}},
+         "Volumes": [{"ID": v["ID"], "Source": "volume1", "Target": "/a"}, {"ID": v["ID"], "Source": "volume1", "Target": "/b"}]}
+    o.setup_task(t)
+    assert o.volume_info(v["ID"])["Nodes"] == {"n": 2} and list(o.volume_info(v["ID"])["Tasks"]) == ["t"]
+    o.delete_task(t)
+    assert o.volume_info(v["ID"])["Nodes"] == {"n": 1} and o.volume_info(v["ID"])["Tasks"] == {}
+    assert o.free_volumes() == []

@@ -1,0 +1,163 @@
+"""CPU: the volume bookkeeping of the C++ host layer (csrc/swp_sched.cpp: reserveVolume / releaseVolume / reserveTaskVolumes /
+freeVolumes — the half of volumes.go the engine does not hold) against the oracle, event by event. The engine under the host layer is
+the scripted double (tests/fake_swp.cpp): no task with cluster mounts is ever SCHEDULED here — that is the GPU suite's
+tests/test_engine_volumes.py — the events are the ones that move the reference counts: tasks of the store at start, tasks going away,
+volumes being updated."""
+import copy
+import random
+
+import pytest
+
+import fakelib
+import kat_volumes as kv
+import orc
+from swarmkit_amd import abi, sched as swsched
+
+
+class Both:
+    def __init__(self):
+        self.o = orc.Oracle()
+        self.e = swsched.Scheduler(engine=abi.Engine(lib_path=fakelib.build()))
+        self.vols = []
+
+    def __getattr__(self, name):
+        def call(*a):
+            ro, re = getattr(self.o, name)(*copy.deepcopy(a)), getattr(self.e, name)(*copy.deepcopy(a))
+            if name == "update_volume" and a[0]["ID"] not in self.vols:
+                self.vols.append(a[0]["ID"])
+            return ro, re
+        return call
+
+    def check(self):
+        for vid in self.vols:
+            io, ie = self.o.volume_info(vid), self.e.volume_info(vid)
+            assert (io is None) == (ie is None), vid
+            if io is not None:
+                assert io["Tasks"] == ie["Tasks"] and {k: c for k, c in io["Nodes"].items() if c} == {k: c for k, c in ie["Nodes"].items() if c}, (vid, io, ie)
+
+    def free(self):
+        fo, fe = self.o.free_volumes(), self.e.free_volumes()
+        assert fo == fe, (fo, fe)
+        return fo
+
+
+def _cluster():
+    b = Both()
+    nodes, volumes, all_volume, tasks = kv.free_volumes_fixture()
+    for n in nodes:
+        b.create_node(dict(n, Status={"State": orc.READY}))
+    for v in volumes + [all_volume]:
+        b.update_volume(v)
+    b.set_service("svc")
+    for t in tasks:
+        b.setup_task(t)
+    b.check()
+    return b, nodes, volumes, all_volume, tasks
+
+
+def test_reference_counts_of_the_store_at_start():
+    """volumes_test.go:644-661 through the host layer."""
+    b, nodes, volumes, all_volume, tasks = _cluster()
+    for i, v in enumerate(volumes):
+        assert b.e.volume_info(v["ID"])["Nodes"] == {nodes[i]["ID"]: 1}
+    assert b.e.volume_info(all_volume["ID"])["Nodes"] == {n["ID"]: 1 for n in nodes}
+    assert b.free() == []
+
+
+def test_free_volumes_that_are_no_longer_needed():
+    """volumes_test.go:663-697 through the host layer."""
+    b, nodes, volumes, all_volume, tasks = _cluster()
+    b.delete_task(tasks[0])
+    b.check()
+    assert b.free() == [{"VolumeID": volumes[0]["ID"], "NodeIDs": ["node0"]}, {"VolumeID": all_volume["ID"], "NodeIDs": ["node0"]}]
+    assert b.free() == []
+    # the store's event brings the same statuses back: nothing changes; a fresh PUBLISHED status on a node without users is freed again
+    v0 = copy.deepcopy(volumes[0])
+    v0["PublishStatus"] = [{"NodeID": "node0", "State": "PENDING_NODE_UNPUBLISH"}, {"NodeID": "node3", "State": "PUBLISHED"}]
+    b.update_volume(v0)
+    assert b.free() == [{"VolumeID": volumes[0]["ID"], "NodeIDs": ["node3"]}]
+
+
+def test_a_volume_reserved_twice_by_one_task_keeps_a_reference():
+    """volumes.go:156-160 / :169-178: two mounts of one task on one volume count the node twice and give it back once."""
+    b = Both()
+    v = kv.canned_volume(1)
+    v["PublishStatus"] = [{"NodeID": "n", "State": "PUBLISHED"}]
+    b.update_volume(v)
+    b.create_node({"ID": "n", "Status": {"State": orc.READY}, "Description": {}})
+    b.set_service("svc")
+    t = {"ID": "t", "ServiceID": "svc", "NodeID": "n", "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING},
+         "Spec": {"Container": {"Mounts": [kv.cluster_mount("volume1", "/a"), kv.cluster_mount("volume1", "/b")]}},
+         "Volumes": [{"ID": v["ID"], "Source": "volume1", "Target": "/a"}, {"ID": v["ID"], "Source": "volume1", "Target": "/b"}]}
+    b.setup_task(t)
+    b.check()
+    assert b.e.volume_info(v["ID"])["Nodes"] == {"n": 2}
+    b.delete_task(t)
+    b.check()
+    assert b.e.volume_info(v["ID"])["Nodes"] == {"n": 1} and b.free() == []
+
+
+STATES = ["PENDING_PUBLISH", "PUBLISHED", "PENDING_NODE_UNPUBLISH", "PENDING_UNPUBLISH"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_seeded_event_scripts(seed):
+    """Volumes with random publish statuses, tasks of the store at start holding random attachments (named and group mounts, read-only
+    or not, sometimes the same volume twice, sometimes a volume the set does not know), tasks deleted or failing, volumes updated —
+    the volumeSet's view of every volume and every freeVolumes batch must equal the oracle's."""
+    rng = random.Random(0xF4EE + seed)
+    b = Both()
+    n_nodes, n_vols = rng.randrange(2, 7), rng.randrange(1, 7)
+    nodes = ["n%d" % i for i in range(n_nodes)]
+    for n in nodes:
+        b.create_node({"ID": n, "Status": {"State": orc.READY}, "Description": {}})
+    b.set_service("svc")
+
+    def volume(i):
+        v = kv.canned_volume(i, group=rng.choice(["g1", "g2", ""]))
+        v["Spec"]["AccessMode"] = {"Scope": rng.choice([kv.SINGLE, kv.MULTI]), "Sharing": rng.choice([kv.ALL, "ONE_WRITER", "READ_ONLY", "NONE"])}
+        v["PublishStatus"] = [{"NodeID": n, "State": rng.choice(STATES)} for n in rng.sample(nodes, rng.randrange(0, n_nodes + 1))]
+        if rng.random() < 0.1:
+            del v["VolumeInfo"]   # not created by the plugin yet: the scheduler ignores it
+        return v
+
+    for i in range(n_vols):
+        b.update_volume(volume(i))
+    live = {}
+    next_task = freed = 0
+    for step in range(60):
+        r = rng.random()
+        if r < 0.45 or not live:
+            tid = "t%d" % next_task
+            next_task += 1
+            mounts, atts = [], []
+            for k in range(rng.randrange(1, 4)):
+                vi = rng.randrange(0, n_vols + 1)   # (n_vols: a volume the set never saw)
+                src = rng.choice(["volume%d" % vi, "group:g1"])
+                m = kv.cluster_mount(src, "/m%d" % k, rng.random() < 0.4)
+                mounts.append(m)
+                if rng.random() < 0.85:
+                    atts.append({"ID": "volumeID%d" % vi, "Source": src, "Target": m["Target"]})
+            if rng.random() < 0.2:
+                mounts.append({"Type": "BIND", "Source": "/x", "Target": "/y"})
+            t = {"ID": tid, "ServiceID": "svc", "NodeID": rng.choice(nodes), "DesiredState": orc.RUNNING, "Status": {"State": orc.RUNNING},
+                 "Spec": {"Container": {"Mounts": mounts}}, "Volumes": atts}
+            b.setup_task(t)
+            live[tid] = t
+        elif r < 0.65:
+            tid = rng.choice(sorted(live))
+            b.delete_task(live.pop(tid))
+        elif r < 0.75:   # the task fails: updateTask deletes the old task, its reservations with it (scheduler.go:286-316)
+            tid = rng.choice(sorted(live))
+            b.update_task(dict(live.pop(tid), Status={"State": rng.choice([orc.FAILED, orc.SHUTDOWN, orc.COMPLETE])}))
+        elif r < 0.9:
+            b.update_volume(volume(rng.randrange(0, n_vols)))
+        else:
+            freed += len(b.free())
+        b.check()
+    freed += len(b.free())
+    for tid in sorted(live):
+        b.delete_task(live[tid])
+    b.check()
+    freed += len(b.free())
+    assert freed > 0   # (every script has volumes whose publications outlive their users)
