@@ -33,6 +33,11 @@ struct swp_engine {
     std::vector<std::string> sets[6];   // textual form of every registered predicate set: constraint, platform, plugin, port, spread, generic
     std::vector<std::vector<swp_port>> port_sets;
     std::string log;
+    // CSI volumes: no volume MODEL (no checkVolume, no topology) — what was upserted, the usage numbers as set, the mount sets, and scripted
+    // "choices" among the volumes a mount could name at all
+    struct FakeVolume { bool present = false; swp_volume spec{}; swp_volume_usage use{0, 0, SWP_PIN_NONE, 0}; };
+    std::vector<FakeVolume> volumes;
+    std::vector<std::vector<swp_mount>> mount_sets = std::vector<std::vector<swp_mount>>(1);
     bool generic_seen = false;
     std::string err;
     uint64_t counter = 0;
@@ -118,6 +123,49 @@ struct swp_engine {
         const uint32_t n = p[(r >> 3) % p.size()];
         apply(n, d.service, d.cpu, d.mem, !(d.flags & 0x2u), true);
         return (int32_t)n;
+    }
+    // scripted chooseTaskVolumes for one placed task: per mount a volume the mount could name (the named one; any present volume of the
+    // group), or — one time in seven, or when a mount names nothing that exists — no attachments at all (SWP_NO_VOLUME everywhere: the
+    // reference assigns such a task without attachments). Like the engine, it counts what it reserves: the host layer's own numbers
+    // (swp_volume_set_usage after the call) must agree.
+    bool attachments(const swp_task_desc& d, uint32_t node, uint32_t* out, bool reserve) {
+        for (uint32_t m = 0; m < SWP_MAX_MOUNTS; ++m) out[m] = SWP_NO_VOLUME;
+        const uint32_t set = d.flags >> SWP_TASK_MOUNTS_SHIFT;
+        if (set == 0 || set >= mount_sets.size()) return false;
+        const std::vector<swp_mount>& ms = mount_sets[set];
+        const uint32_t r = next();
+        bool ok = r % 7u != 0u;
+        uint32_t pick[SWP_MAX_MOUNTS];
+        for (size_t m = 0; ok && m < ms.size(); ++m) {
+            pick[m] = SWP_NO_VOLUME;
+            if (ms[m].is_group) {
+                std::vector<uint32_t> cand;
+                for (uint32_t v = 0; v < volumes.size(); ++v)
+                    if (volumes[v].present && volumes[v].spec.group == ms[m].ref) cand.push_back(v);
+                if (!cand.empty()) pick[m] = cand[(r >> (4 + 3 * m)) % cand.size()];
+            } else if (ms[m].ref != SWP_NO_VOLUME && ms[m].ref < volumes.size() && volumes[ms[m].ref].present) {
+                pick[m] = ms[m].ref;
+            }
+            if (pick[m] == SWP_NO_VOLUME) ok = false;
+        }
+        if (!ok) return false;
+        for (size_t m = 0; m < ms.size(); ++m) out[m] = pick[m];
+        if (reserve)
+            for (size_t m = 0; m < ms.size(); ++m) {
+                bool later = false;
+                for (size_t k = m + 1; k < ms.size(); ++k) later = later || pick[k] == pick[m];
+                if (later) continue;   // (per volume the task counts once; the last attachment on it speaks: reserveTaskVolumes, volumes.go:144-154)
+                swp_volume_usage& u = volumes[pick[m]].use;
+                u.pin = u.n_tasks == 0 ? node : (u.pin == node ? node : SWP_PIN_MANY);
+                u.n_tasks += 1;
+                if (!ms[m].reserve_read_only) u.n_writers += 1;
+            }
+        return true;
+    }
+    std::string att_text(const uint32_t* a) const {
+        std::string o = "[";
+        for (uint32_t m = 0; m < SWP_MAX_MOUNTS && a[m] != SWP_NO_VOLUME; ++m) o += (m ? "," : "") + printable(name(SWP_SPACE_VOLUME, a[m]));
+        return o + "]";
     }
     uint32_t add_set(int which, const std::string& text) {
         for (uint32_t i = 1; i < sets[which].size(); ++i)
@@ -335,28 +383,132 @@ int swp_schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32
     }
     return SWP_OK;
 }
-// CSI volumes: the double keeps no volume model — node and volume updates are accepted and forgotten, a task with cluster mounts is refused
-// (the host layer defers it); the volume logic itself is tested against the oracle on the GPU (tests/test_engine_volumes.py)
-int swp_node_set_csi(swp_engine*, uint32_t, const swp_csi*, uint32_t, const swp_seg*, uint32_t) { return SWP_OK; }
-int swp_volume_upsert(swp_engine*, uint32_t, const swp_volume*, const uint32_t*, const swp_seg*) { return SWP_OK; }
-int swp_volume_set_usage(swp_engine*, uint32_t, const swp_volume_usage*) { return SWP_OK; }
-int swp_volume_get_usage(swp_engine*, uint32_t, swp_volume_usage* out) {
-    if (out) *out = swp_volume_usage{0, 0, SWP_PIN_NONE, 0};
+// CSI volumes: the double keeps no volume MODEL — what was upserted, the usage numbers, the mount sets — and scripts the choices
+// (swp_engine::attachments). The volume logic itself is tested against the oracle on the GPU (tests/test_engine_volumes.py); what this
+// gives the CPU tests is the host layer's paths behind a placement with attachments (tests/test_sched_volumes_cpu.py).
+int swp_node_set_csi(swp_engine* e, uint32_t node, const swp_csi* infos, uint32_t n, const swp_seg*, uint32_t n_segs) {
+    std::string o;
+    for (uint32_t i = 0; i < n; ++i) o += (i ? "," : "") + e->printable(e->name(SWP_SPACE_CSI, infos[i].plugin)) + (infos[i].has_topology ? "+" + std::to_string(infos[i].n_seg) : "");
+    if (n) e->say("node_set_csi %s [%s] segs=%u", e->name(SWP_SPACE_NODE_ID, node).c_str(), o.c_str(), n_segs);   // (a node without plugins: not a call the Python twin makes)
     return SWP_OK;
 }
-int swp_mount_set(swp_engine* e, const swp_mount*, uint32_t, uint32_t*) {
-    if (e) e->err = "the scripted engine double knows no volumes";
-    return SWP_EUNSUPPORTED;
+int swp_volume_upsert(swp_engine* e, uint32_t volume, const swp_volume* v, const uint32_t*, const swp_seg*) {
+    if (e->volumes.size() <= volume) e->volumes.resize(volume + 1);
+    e->volumes[volume].present = true;
+    e->volumes[volume].spec = *v;
+    e->say("volume_upsert %s group=%s driver=%s scope=%u sharing=%u active=%u topologies=%u", e->printable(e->name(SWP_SPACE_VOLUME, volume)).c_str(),
+           e->printable(e->name(SWP_SPACE_VOLUME_GROUP, v->group)).c_str(), e->printable(e->name(SWP_SPACE_CSI, v->driver)).c_str(), v->scope, v->sharing, v->active, v->n_topologies);
+    return SWP_OK;
 }
-int swp_choose_volumes(swp_engine*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
-int swp_batch_attachments(swp_engine*, swp_batch*, const uint32_t*, uint32_t, uint32_t*) { return SWP_EUNSUPPORTED; }
-int swp_schedule_groups_volumes(swp_engine*, const swp_task_desc*, const uint32_t*, uint32_t, int32_t*, uint32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
-int swp_batch_prepare(swp_engine*, const swp_task_desc*, uint32_t, swp_batch**) { return SWP_EUNSUPPORTED; }
+int swp_volume_set_usage(swp_engine* e, uint32_t volume, const swp_volume_usage* u) {
+    if (volume >= e->volumes.size() || !e->volumes[volume].present) return SWP_ENOTFOUND;
+    e->volumes[volume].use = *u;
+    e->say("volume_set_usage %s tasks=%u writers=%u pin=%s", e->printable(e->name(SWP_SPACE_VOLUME, volume)).c_str(), u->n_tasks, u->n_writers,
+           u->pin == SWP_PIN_NONE ? "none" : u->pin == SWP_PIN_MANY ? "many" : e->name(SWP_SPACE_NODE_ID, u->pin).c_str());
+    return SWP_OK;
+}
+int swp_volume_get_usage(swp_engine* e, uint32_t volume, swp_volume_usage* out) {
+    if (volume >= e->volumes.size() || !e->volumes[volume].present) return SWP_ENOTFOUND;
+    *out = e->volumes[volume].use;
+    return SWP_OK;
+}
+int swp_mount_set(swp_engine* e, const swp_mount* mounts, uint32_t n, uint32_t* id_out) {
+    if (n > SWP_MAX_MOUNTS) return SWP_ERANGE;
+    if (n == 0) { *id_out = 0; return SWP_OK; }
+    for (uint32_t i = 1; i < e->mount_sets.size(); ++i)
+        if (e->mount_sets[i].size() == n && std::memcmp(e->mount_sets[i].data(), mounts, n * sizeof(swp_mount)) == 0) { *id_out = i; return SWP_OK; }
+    e->mount_sets.emplace_back(mounts, mounts + n);
+    *id_out = (uint32_t)e->mount_sets.size() - 1;
+    std::string o;
+    for (uint32_t i = 0; i < n; ++i)
+        o += (i ? " " : "") + std::string(mounts[i].is_group ? "group:" : "") + (mounts[i].ref == SWP_NO_VOLUME ? "?" : e->printable(e->name(mounts[i].is_group ? SWP_SPACE_VOLUME_GROUP : SWP_SPACE_VOLUME, mounts[i].ref))) +
+             (mounts[i].read_only ? "(ro)" : "") + (mounts[i].reserve_read_only ? "(rro)" : "");
+    e->say("mount_set %u = %s", *id_out, o.c_str());
+    return SWP_OK;
+}
+int swp_choose_volumes(swp_engine* e, uint32_t mount_set, uint32_t node, uint32_t* out, uint32_t* n_out, uint32_t* failed) {
+    if (mount_set == 0 || mount_set >= e->mount_sets.size()) return SWP_EINVAL;
+    swp_task_desc d{};
+    d.flags = SWP_TASK_MOUNTS(mount_set);
+    const bool ok = e->attachments(d, node, out, false);
+    *n_out = ok ? (uint32_t)e->mount_sets[mount_set].size() : 0u;
+    if (failed) *failed = 0;
+    e->say("choose_volumes set=%u node=%s -> %s", mount_set, e->name(SWP_SPACE_NODE_ID, node).c_str(), ok ? e->att_text(out).c_str() : "none");
+    return SWP_OK;
+}
+// the batch object of the three-step call: the scripted answers are made at swp_batch_run
+struct swp_batch {
+    std::vector<swp_task_desc> d;
+    std::vector<int32_t> out;
+    std::vector<uint32_t> hist, att;
+    bool ran = false;
+};
+int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n, swp_batch** out) {
+    e->say("batch_prepare n=%u", n);
+    for (uint32_t i = 0; i < n; ++i)
+        if (boom(e, tasks[i])) {
+            e->err = "fake: batch refused";
+            e->say("  refused");
+            return SWP_ERANGE;
+        }
+    swp_batch* b = new swp_batch();
+    b->d.assign(tasks, tasks + n);
+    *out = b;
+    return SWP_OK;
+}
 int swp_batch_prepare_templates(swp_engine*, const swp_task_desc*, uint32_t, const uint32_t*, uint32_t, swp_batch**) { return SWP_EUNSUPPORTED; }
-int swp_batch_run(swp_engine*, swp_batch*) { return SWP_EUNSUPPORTED; }
-int swp_batch_fetch(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
-int swp_batch_results(swp_engine*, swp_batch*, int32_t*, uint32_t*) { return SWP_EUNSUPPORTED; }
-void swp_batch_free(swp_engine*, swp_batch*) {}
+int swp_batch_run(swp_engine* e, swp_batch* b) {
+    const size_t n = b->d.size();
+    b->out.assign(n, -1);
+    b->hist.assign(n * SWP_NFILTERS, 0);
+    b->att.assign(n * SWP_MAX_MOUNTS, SWP_NO_VOLUME);
+    for (size_t i = 0; i < n; ++i) {
+        b->out[i] = e->answer(b->d[i], &b->hist[i * SWP_NFILTERS]);
+        if (b->out[i] >= 0) e->attachments(b->d[i], (uint32_t)b->out[i], &b->att[i * SWP_MAX_MOUNTS], true);
+        if (!e->quiet) e->say("  task %s -> %d %s", e->desc(b->d[i]).c_str(), b->out[i], e->att_text(&b->att[i * SWP_MAX_MOUNTS]).c_str());
+    }
+    b->ran = true;
+    return SWP_OK;
+}
+int swp_batch_fetch(swp_engine*, swp_batch* b, int32_t* out_node, uint32_t* hist) {
+    if (!b->ran) return SWP_EINVAL;
+    std::copy(b->out.begin(), b->out.end(), out_node);
+    if (hist) std::copy(b->hist.begin(), b->hist.end(), hist);
+    return SWP_OK;
+}
+int swp_batch_results(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* hist) { return swp_batch_fetch(e, b, out_node, hist); }
+int swp_batch_attachments(swp_engine*, swp_batch* b, const uint32_t* tasks, uint32_t n, uint32_t* out) {
+    if (!b->ran) return SWP_EINVAL;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (tasks[i] >= b->d.size()) return SWP_EINVAL;
+        std::copy(b->att.begin() + (size_t)tasks[i] * SWP_MAX_MOUNTS, b->att.begin() + (size_t)(tasks[i] + 1) * SWP_MAX_MOUNTS, out + (size_t)i * SWP_MAX_MOUNTS);
+    }
+    return SWP_OK;
+}
+int swp_schedule_groups_volumes(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node, uint32_t* hist, uint32_t* out_att) {
+    e->say("schedule_groups_volumes n=%u", n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (boom(e, groups[g])) {
+            e->err = "fake: group refused";
+            e->say("  refused");
+            return SWP_ERANGE;
+        }
+    size_t off = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        if (!e->quiet) e->say("  group k=%u %s", sizes[g], e->desc(groups[g]).c_str());
+        uint32_t scratch[SWP_NFILTERS];
+        for (uint32_t i = 0; i < sizes[g]; ++i) {
+            out_node[off + i] = e->answer(groups[g], scratch);
+            for (uint32_t m = 0; m < SWP_MAX_MOUNTS; ++m) out_att[(off + i) * SWP_MAX_MOUNTS + m] = SWP_NO_VOLUME;
+            if (out_node[off + i] >= 0) e->attachments(groups[g], (uint32_t)out_node[off + i], out_att + (off + i) * SWP_MAX_MOUNTS, true);
+            if (out_node[off + i] < 0 && hist) std::memcpy(hist + (size_t)g * SWP_NFILTERS, scratch, sizeof scratch);
+            if (!e->quiet) e->say("    -> %d %s", out_node[off + i], e->att_text(out_att + (off + i) * SWP_MAX_MOUNTS).c_str());
+        }
+        off += sizes[g];
+    }
+    return SWP_OK;
+}
+void swp_batch_free(swp_engine*, swp_batch* b) { delete b; }
 int swp_shard_begin(swp_engine*, swp_batch*) { return SWP_EUNSUPPORTED; }
 int swp_shard_propose(swp_engine*, swp_batch*, uint32_t, uint32_t, swp_proposal*) { return SWP_EUNSUPPORTED; }
 int swp_shard_merge(const swp_proposal* const*, const uint32_t*, uint32_t, uint32_t, swp_shard_pick*, uint32_t*) { return SWP_EUNSUPPORTED; }

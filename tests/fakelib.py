@@ -12,11 +12,19 @@ DEPS = SRCS + [os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_json.hpp"), os.pa
 
 
 def build():
+    # SWP_FAKE_SANITIZE=1: the same library under AddressSanitizer + UBSan (tests/test_sanitized_host_cpu.py runs the host-layer tests
+    # against it in a child process that preloads the sanitizer runtimes)
+    san = os.environ.get("SWP_FAKE_SANITIZE") == "1"
+    out = OUT.replace(".so", "_san.so") if san else OUT
+    return _build(out, ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if san else [])
+
+
+def _build(OUT, extra):
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     tmp = "%s.%d.tmp" % (OUT, os.getpid())   # parallel test workers: build privately, publish atomically
-    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-fPIC", "-shared", "-o", tmp] + SRCS, capture_output=True, text=True)
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-fPIC", "-shared"] + extra + ["-o", tmp] + SRCS, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("libswpfake.so build failed:\n" + r.stdout + r.stderr)
     os.replace(tmp, OUT)

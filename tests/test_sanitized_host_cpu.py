@@ -1,0 +1,27 @@
+"""CPU: the C++ host layer (csrc/swp_sched.cpp, product source) under AddressSanitizer + UndefinedBehaviorSanitizer: the event scripts of
+tests/test_sched_volumes_cpu.py (volume bookkeeping, placements with attachments, freeVolumes) and a few twin scripts of
+tests/test_sched_cpu.py run in a child process over a sanitized build of the scripted engine double + host layer. A finding aborts the
+child; its report is the assertion message."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _runtime(name):
+    p = subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_host_layer_event_scripts_under_the_sanitizers():
+    asan, ubsan = _runtime("libasan.so"), _runtime("libubsan.so")
+    if not asan or not ubsan:
+        pytest.skip("no sanitizer runtimes next to this gcc")
+    env = dict(os.environ, SWP_FAKE_SANITIZE="1", LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", SWP_TWIN_SEEDS="3", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(HERE, "test_sched_volumes_cpu.py"),
+                        os.path.join(HERE, "test_sched_cpu.py"), "-k", "volume or attachments or books or start or twin or refused or survives"], capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])

@@ -161,3 +161,94 @@ def test_seeded_event_scripts(seed):
     b.check()
     freed += len(b.free())
     assert freed > 0   # (every script has volumes whose publications outlive their users)
+
+
+# ---------------------------------------------------------------------------- placements with attachments, over the scripted double
+def _usage_agrees(e, vids):
+    """The engine's usage numbers of a volume — what the double counted for the placements it "made" plus what the host layer pushed —
+    against the host layer's own maps: swp_volume_set_usage with the host's numbers must be idempotent behind a device call."""
+    for vid in vids:
+        info = e.volume_info(vid)
+        if info is None:
+            continue
+        assert info["Engine"]["Tasks"] == len(info["Tasks"]), (vid, info)
+        assert info["Engine"]["Writers"] == sum(1 for u in info["Tasks"].values() if not u["ReadOnly"]), (vid, info)
+        counts = {}
+        for u in info["Tasks"].values():
+            counts[u["NodeID"]] = counts.get(u["NodeID"], 0) + 1
+        assert {k: c for k, c in info["Nodes"].items() if c} == counts, (vid, info)   # (no task here mounts one volume twice)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_placements_with_attachments_keep_the_books(seed):
+    """One-off tasks and task groups with cluster mounts through tick(), preassigned ones through process_preassigned(), over the scripted
+    engine double (its "choices" are pseudo-random volumes a mount could name): every decision's attachments are booked under the task on
+    its node, a rejected decision and a deleted task give them back, the engine's usage numbers follow, and freeVolumes frees exactly
+    the publications nobody uses."""
+    import scenarios as sc
+    rng = random.Random(0xA77A + seed)
+    e = swsched.Scheduler(engine=abi.Engine(lib_path=fakelib.build()))
+    nodes = ["n%d" % i for i in range(rng.randrange(2, 6))]
+    for n in nodes:
+        e.create_node({"ID": n, "Status": {"State": orc.READY}, "Description": {"CSIInfo": [{"PluginName": "driver", "NodeID": "csi-" + n}]}})
+    vids = []
+    for i in range(rng.randrange(2, 7)):
+        v = kv.canned_volume(i, group=rng.choice(["g1", "g2"]))
+        v["PublishStatus"] = [{"NodeID": n, "State": "PUBLISHED"} for n in nodes]
+        e.update_volume(v)
+        vids.append(v["ID"])
+    for s in range(3):
+        e.set_service("svc%d" % s, spec_version=7 if s == 2 else None)
+    held = {}   # task id -> (node, [volume ids]) as decided
+    tid = 0
+    group_mounts = None
+    for round_ in range(8):
+        new = []
+        for _ in range(rng.randrange(1, 6)):
+            # (no task here ends up with one volume on two of its mounts — that case has its own test above: either ONE group mount,
+            # or distinct named volumes, now and then one that does not exist)
+            if rng.random() < 0.4:
+                sources = [rng.choice(["group:g1", "group:g2"])]
+            else:
+                sources = ["volume%d" % i for i in rng.sample(range(len(vids)), rng.randrange(1, min(3, len(vids)) + 1))] + (["volume99"] if rng.random() < 0.15 else [])
+            mounts = [kv.cluster_mount(src, "/m%d" % k, rng.random() < 0.4) for k, src in enumerate(sources)]
+            svc = rng.randrange(0, 3)
+            if svc == 2:   # the tasks of one (service, SpecVersion) share their spec: that is what makes them a group (scheduler.go:442-459)
+                group_mounts = group_mounts or mounts
+                mounts = group_mounts
+            t = sc.pending("t%03d" % tid, "svc%d" % svc, spec_version=7 if svc == 2 else None, Spec={"Container": {"Mounts": mounts}})
+            if rng.random() < 0.2:   # a preassigned task: decided by process_preassigned on its node
+                t["NodeID"] = rng.choice(nodes)
+            tid += 1
+            new.append(t)
+            e.create_task(t)
+        e.process_preassigned()   # taskFitNode chooses volumes for the decision and reserves NOTHING (scheduler.go:663-677): not tracked here
+        decisions = e.tick()
+        for d in decisions:
+            if d.get("Deferred"):
+                continue
+            vols = [v["ID"] for v in d.get("Volumes") or []]
+            if d["NodeID"] and d["State"] == orc.ASSIGNED:
+                held[d["ID"]] = (d["NodeID"], vols)
+        for t_id, (nid, vols) in held.items():
+            for v in vols:
+                info = e.volume_info(v)
+                assert info is not None and info["Tasks"].get(t_id, {}).get("NodeID") == nid, (t_id, nid, v, info)
+        _usage_agrees(e, vids)
+        # some of them go away again
+        for t_id in sorted(held):
+            r = rng.random()
+            if r < 0.15:
+                e.delete_task({"ID": t_id, "NodeID": held[t_id][0], "ServiceID": "svc0", "Volumes": [{"ID": v, "Source": "", "Target": ""} for v in held[t_id][1]]})
+            elif r < 0.25 and any(d["ID"] == t_id for d in decisions):
+                e.reject_decision(t_id)
+            else:
+                continue
+            for v in held.pop(t_id)[1]:
+                info = e.volume_info(v)
+                assert t_id not in info["Tasks"], (t_id, v, info)
+        _usage_agrees(e, vids)
+        for upd in e.free_volumes():
+            info = e.volume_info(upd["VolumeID"])
+            for n in upd["NodeIDs"]:
+                assert not info["Nodes"].get(n), (upd, info)
