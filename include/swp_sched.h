@@ -91,7 +91,9 @@ int swp_sched_reject_decision(swp_sched*, const char* task_id, size_t len, int* 
  * in commit order: grouped by node (node index order), every group with the Meta.Version the scheduler's NodeInfo holds for that node
  * (echoed from swp_node_row.version) — ONE version check per node — and cut into transactions of at most max_changes updates
  * (0 = the store's 200). *plan_json = {"Nodes": [{"NodeID", "Version", "Tasks": [task ids]}...],
- * "Unassigned": [ids of the decisions that name no node: "no suitable node" status updates], "Transactions": [[task ids]...]}. */
+ * "Unassigned": [ids of the decisions that name no node: "no suitable node" status updates], "Transactions": [[task ids]...],
+ * "VolumeFailed": [ids of the decisions with an attachment on a volume that is not ACTIVE any more: call them off, scheduler.go:548-590],
+ * "Publish": [{"VolumeID", "NodeIDs"}: the PENDING_PUBLISH statuses the other decisions' attachments need, :591-606]}. */
 int swp_sched_commit_plan(swp_sched*, uint32_t max_changes, const char** plan_json);
 /* swp_sched_reject_decision for a JSON array of task ids; *n_undone = how many had a decision to undo */
 int swp_sched_reject_decisions(swp_sched*, const char* ids_json, size_t len, uint32_t* n_undone);

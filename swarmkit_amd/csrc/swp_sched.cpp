@@ -997,10 +997,52 @@ class Scheduler {
         }
         for (const Value& v : *unassigned.a) add(v.s);
         if (tx.size() > 0) txs.push(tx);
+        // the volume side of a commit (scheduler.go:548-610): a decision whose attachment names a volume that is not ACTIVE any more (or
+        // that this scheduler does not hold) is called off; every other attachment wants its volume published on the task's node — a
+        // PENDING_PUBLISH status where the volume has none for that node yet. Computed from the volume documents as EventUpdateVolume left
+        // them; the caller repeats the "already published?" look at its store's copy inside its transaction, as :591-606 does.
+        Value vol_failed = Value::array(), publish = Value::array();
+        std::vector<std::pair<std::string, std::vector<std::string>>> pub;   // volume -> nodes, in commit order
+        for (const auto& kv : lastDecisions_) {
+            auto cur = allTasks_.find(kv.first);
+            if (cur == allTasks_.end()) continue;
+            const Value* vols = cur->second.get("Volumes");
+            const std::string& nid = as_str(cur->second.get("NodeID"));
+            if (vols == nullptr || !vols->is_arr() || nid.empty()) continue;
+            bool ok = true;
+            for (const Value& va : *vols->a) {
+                auto v = volumes_.find(as_str(va.get("ID")));
+                if (v == volumes_.end() || enum_value(at(&v->second.doc, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) != 0) ok = false;
+            }
+            if (!ok) {
+                vol_failed.push(Value::str(kv.first));
+                continue;
+            }
+            for (const Value& va : *vols->a) {
+                const std::string& vid = as_str(va.get("ID"));
+                bool published = false;
+                if (const Value* ps = volumes_.at(vid).doc.get("PublishStatus"))
+                    if (ps->is_arr())
+                        for (const Value& st : *ps->a) published = published || as_str(st.get("NodeID")) == nid;
+                if (published) continue;
+                auto it = std::find_if(pub.begin(), pub.end(), [&](const auto& p) { return p.first == vid; });
+                if (it == pub.end()) it = pub.insert(pub.end(), {vid, {}});
+                if (std::find(it->second.begin(), it->second.end(), nid) == it->second.end()) it->second.push_back(nid);
+            }
+        }
+        for (const auto& p : pub) {
+            Value u = Value::object(), ns = Value::array();
+            for (const std::string& n : p.second) ns.push(Value::str(n));
+            u.set("VolumeID", Value::str(p.first));
+            u.set("NodeIDs", ns);
+            publish.push(u);
+        }
         Value plan = Value::object();
         plan.set("Nodes", nodes);
         plan.set("Unassigned", unassigned);
         plan.set("Transactions", txs);
+        plan.set("VolumeFailed", vol_failed);
+        plan.set("Publish", publish);
         return plan;
     }
     uint32_t rejectNode(const std::string& nid) {

@@ -760,7 +760,7 @@ class PyHostScheduler:
             order.extend(by_node[idx])
         order.extend(unassigned)
         txs = [order[i:i + max_changes] for i in range(0, len(order), max_changes)]
-        return {"Nodes": nodes, "Unassigned": unassigned, "Transactions": txs}
+        return {"Nodes": nodes, "Unassigned": unassigned, "Transactions": txs, "VolumeFailed": [], "Publish": []}   # (this twin takes no task with cluster mounts)
 
     def reject_decisions(self, tids):
         return sum(1 for t in tids if self.reject_decision(t))

@@ -252,3 +252,38 @@ def test_placements_with_attachments_keep_the_books(seed):
             info = e.volume_info(upd["VolumeID"])
             for n in upd["NodeIDs"]:
                 assert not info["Nodes"].get(n), (upd, info)
+
+
+def test_the_commit_plan_names_the_publications_and_the_decisions_to_call_off():
+    """applySchedulingDecisions' volume side (scheduler.go:548-610) as the commit plan reports it: an attachment on a volume that has no
+    PublishStatus for the task's node wants a PENDING_PUBLISH one; a decision with an attachment on a volume that was paused or drained
+    since is called off and publishes nothing."""
+    e = swsched.Scheduler(engine=abi.Engine(lib_path=fakelib.build()))
+    import scenarios as sc
+    for n in ("n0", "n1"):
+        e.create_node({"ID": n, "Status": {"State": orc.READY}, "Description": {"CSIInfo": [{"PluginName": "driver", "NodeID": "csi-" + n}]}})
+    v0, v1 = kv.canned_volume(0), kv.canned_volume(1)
+    v0["PublishStatus"] = [{"NodeID": "n0", "State": "PUBLISHED"}, {"NodeID": "n1", "State": "PUBLISHED"}]
+    e.update_volume(v0)
+    e.update_volume(v1)
+    e.set_service("svc")
+    placed = {}
+    for i in range(12):   # (the double leaves a task without a node or without attachments now and then)
+        e.create_task(sc.pending("t%02d" % i, "svc", Spec={"Container": {"Mounts": [kv.cluster_mount("volume0", "/a"), kv.cluster_mount("volume1", "/b")]}}))
+    for d in e.tick():
+        if d["NodeID"] and d.get("Volumes"):
+            placed[d["ID"]] = d["NodeID"]
+    assert placed
+    plan = e.commit_plan()
+    assert plan["VolumeFailed"] == []
+    assert len(plan["Publish"]) == 1 and plan["Publish"][0]["VolumeID"] == "volumeID1"   # (volume0 is published on both nodes already)
+    assert sorted(plan["Publish"][0]["NodeIDs"]) == sorted(set(placed.values()))
+    # volume1 is drained before the commit: every decision that uses it is called off, nothing is published
+    v1d = copy.deepcopy(v1)
+    v1d["Spec"]["Availability"] = "DRAIN"
+    e.update_volume(v1d)
+    plan = e.commit_plan()
+    assert sorted(plan["VolumeFailed"]) == sorted(placed) and plan["Publish"] == []
+    for tid in plan["VolumeFailed"]:
+        assert e.reject_decision(tid)
+    assert e.volume_info("volumeID1")["Tasks"] == {} and e.volume_info("volumeID0")["Tasks"] == {}
