@@ -38,6 +38,13 @@ struct swp_engine {
     struct FakeVolume { bool present = false; swp_volume spec{}; swp_volume_usage use{0, 0, SWP_PIN_NONE, 0}; };
     std::vector<FakeVolume> volumes;
     std::vector<std::vector<swp_mount>> mount_sets = std::vector<std::vector<swp_mount>>(1);
+    // REPLAY mode (swp_fake_script): per service a queue of answers — a node (or none) and the volumes of its cluster mounts — that are given
+    // out instead of the pseudo-random ones, task after task of that service. tests/test_sched_volumes_cpu.py feeds it the oracle's
+    // decisions, so that the host layer above can be compared with the oracle end to end on CPU.
+    struct Scripted { std::string node; std::vector<std::string> volumes; };
+    std::map<std::string, std::vector<Scripted>> script;   // service name -> answers, front first
+    bool replay_att = false;                // the answer just given was a scripted one: its volumes are the next attachments
+    std::vector<std::string> replay_vols;
     bool generic_seen = false;
     std::string err;
     uint64_t counter = 0;
@@ -108,6 +115,21 @@ struct swp_engine {
     }
     // one scripted answer for one task: a present node, or -1 with a scripted histogram
     int32_t answer(const swp_task_desc& d, uint32_t* hist) {
+        replay_att = false;
+        auto sq = script.find(name(SWP_SPACE_SERVICE, d.service));
+        if (sq != script.end() && !sq->second.empty()) {
+            const Scripted a = sq->second.front();
+            sq->second.erase(sq->second.begin());
+            if (hist != nullptr)
+                for (int k = 0; k < SWP_NFILTERS; ++k) hist[k] = a.node.empty() ? 1u : 0u;
+            if (a.node.empty()) return -1;
+            auto it = ids[SWP_SPACE_NODE_ID].find(a.node);
+            if (it == ids[SWP_SPACE_NODE_ID].end() || it->second >= nodes.size() || !nodes[it->second].present) return -1;
+            apply(it->second, d.service, d.cpu, d.mem, !(d.flags & 0x2u), true);
+            replay_att = true;
+            replay_vols = a.volumes;
+            return (int32_t)it->second;
+        }
         const std::vector<uint32_t>& p = present();
         const uint32_t r = next();
         if (p.empty() || r % 5u == 0u) {
@@ -133,9 +155,19 @@ struct swp_engine {
         const uint32_t set = d.flags >> SWP_TASK_MOUNTS_SHIFT;
         if (set == 0 || set >= mount_sets.size()) return false;
         const std::vector<swp_mount>& ms = mount_sets[set];
+        uint32_t pick[SWP_MAX_MOUNTS];
+        if (replay_att) {   // the scripted answer's volumes, mount by mount (none: the task is assigned without attachments)
+            replay_att = false;
+            if (replay_vols.size() != ms.size()) return false;
+            for (size_t m = 0; m < ms.size(); ++m) {
+                auto it = ids[SWP_SPACE_VOLUME].find(replay_vols[m]);
+                if (it == ids[SWP_SPACE_VOLUME].end() || it->second >= volumes.size() || !volumes[it->second].present) return false;
+                pick[m] = it->second;
+            }
+            return book(ms, pick, node, out, reserve);
+        }
         const uint32_t r = next();
         bool ok = r % 7u != 0u;
-        uint32_t pick[SWP_MAX_MOUNTS];
         for (size_t m = 0; ok && m < ms.size(); ++m) {
             pick[m] = SWP_NO_VOLUME;
             if (ms[m].is_group) {
@@ -149,6 +181,9 @@ struct swp_engine {
             if (pick[m] == SWP_NO_VOLUME) ok = false;
         }
         if (!ok) return false;
+        return book(ms, pick, node, out, reserve);
+    }
+    bool book(const std::vector<swp_mount>& ms, const uint32_t* pick, uint32_t node, uint32_t* out, bool reserve) {
         for (size_t m = 0; m < ms.size(); ++m) out[m] = pick[m];
         if (reserve)
             for (size_t m = 0; m < ms.size(); ++m) {
@@ -581,6 +616,15 @@ int swp_abi_check(uint32_t* sizes, uint32_t n) {
     uint32_t k = 0;
     for (; k < n && k < 11; ++k) sizes[k] = s[k];
     return (int)k;
+}
+// test-only: one more scripted answer for the tasks of `service` (REPLAY mode): node "" = no suitable node; volumes = the ids of the volumes
+// for its cluster mounts in mount order (n_volumes == 0 for a task with mounts: assigned without attachments)
+int swp_fake_script(swp_engine* e, const char* service, const char* node, const char* const* volumes, uint32_t n_volumes) {
+    swp_engine::Scripted a;
+    a.node = node ? node : "";
+    for (uint32_t i = 0; i < n_volumes; ++i) a.volumes.push_back(volumes[i]);
+    e->script[service ? service : ""].push_back(a);
+    return SWP_OK;
 }
 // test-only: the call log so far (and clear it)
 const char* swp_fake_take_log(swp_engine* e) {

@@ -37,3 +37,13 @@ def take_log(engine):
     fn.argtypes = [ctypes.c_void_p]
     fn.restype = ctypes.c_char_p
     return fn(engine.h).decode().splitlines()
+
+
+def script(engine, service, node, volumes=()):
+    """REPLAY mode of the double: the next task of `service` that reaches it is answered with `node` ("" / None: no suitable node) and, for
+    its cluster mounts, `volumes` (ids, mount order; empty: assigned without attachments)."""
+    fn = engine.L.swp_fake_script
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
+    fn.restype = ctypes.c_int
+    arr = (ctypes.c_char_p * max(len(volumes), 1))(*[v.encode() for v in volumes])
+    assert fn(engine.h, service.encode(), (node or "").encode(), arr, len(volumes)) == 0

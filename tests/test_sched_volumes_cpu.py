@@ -287,3 +287,102 @@ def test_the_commit_plan_names_the_publications_and_the_decisions_to_call_off():
     for tid in plan["VolumeFailed"]:
         assert e.reject_decision(tid)
     assert e.volume_info("volumeID1")["Tasks"] == {} and e.volume_info("volumeID0")["Tasks"] == {}
+
+
+# ---------------------------------------------------------------------------- REPLAY: the oracle's decisions through the host layer
+@pytest.mark.parametrize("seed", range(10))
+def test_the_host_layer_replays_the_oracles_ticks(seed):
+    """End to end on CPU, without an engine: a seeded cluster with CSI volumes (topologies, access modes, groups, paused volumes), one-off
+    tasks with and without cluster mounts over several ticks, a third of the placed tasks going away after every tick. The ORACLE decides
+    each tick; its decisions — node and volumes per task — are scripted into the engine double (fakelib.script), the C++ host layer runs
+    the same tick above it and must report the same assignments and attachments, book the same users under every volume and free the
+    same publications. (What the double cannot replay: WHY a task found no node — those decisions are compared by node only.)"""
+    import scenarios as sc
+    rng = random.Random(0x7E91A + seed)
+    o = orc.Oracle()
+    e = swsched.Scheduler(engine=abi.Engine(lib_path=fakelib.build()))
+    zones = ["z1", "z2", "z3"]
+    n_nodes = rng.choice([3, 8, 30])
+    for i in range(n_nodes):
+        csi = []
+        for plug in ("p1", "p2"):
+            if rng.random() < 0.8:
+                c = {"PluginName": plug}
+                if rng.random() < 0.8:
+                    c["AccessibleTopology"] = {"Segments": {"zone": rng.choice(zones)}}
+                csi.append(c)
+        n = {"ID": "n%04d" % i, "Status": {"State": orc.READY}, "Description": {"Resources": {"NanoCPUs": 8 * 10**9, "MemoryBytes": 16 << 30}, "CSIInfo": csi}}
+        o.create_node(copy.deepcopy(n))
+        e.create_node(copy.deepcopy(n))
+    n_vol = rng.choice([2, 6, 14])
+    vids = []
+    for v in range(n_vol):
+        acc = [{"Segments": {"zone": rng.choice(zones)}} for _ in range(rng.choice([0, 1, 1, 2]))]
+        vol = {"ID": "vol%02d" % v, "Spec": {"Annotations": {"Name": "name%02d" % v}, "Group": rng.choice(["", "g1", "g2"]), "Driver": {"Name": rng.choice(["p1", "p2"])},
+                                           "AccessMode": {"Scope": rng.choice([kv.SINGLE, kv.MULTI]), "Sharing": rng.choice([kv.NONE, kv.READ_ONLY, kv.ONE_WRITER, kv.ALL])},
+                                           "Availability": rng.choice(["ACTIVE", "ACTIVE", "ACTIVE", "PAUSE"])},
+               "VolumeInfo": {"VolumeID": "csi%02d" % v, "AccessibleTopology": acc},
+               "PublishStatus": [{"NodeID": "n%04d" % k, "State": "PUBLISHED"} for k in range(0, n_nodes, 2)]}
+        o.update_volume(copy.deepcopy(vol))
+        e.update_volume(copy.deepcopy(vol))
+        vids.append(vol["ID"])
+    for s in range(4):   # svc3's tasks carry a SpecVersion: one task group per tick (scheduler.go:442-459), all with the same spec
+        o.set_service("svc%d" % s, spec_version=3 if s == 3 else None)
+        e.set_service("svc%d" % s, spec_version=3 if s == 3 else None)
+    group_mounts = None
+    placed, tid, docs, waiting = [], 0, {}, []
+    n_placed = n_attached = 0
+    for tick in range(5):
+        for _ in range(rng.choice([5, 20, 60])):
+            tid += 1
+            mounts = []
+            if rng.random() < 0.6:
+                # ONE group mount, or distinct named volumes (one of them may not exist): no task can end up with one volume on two of its
+                # mounts, so chooseTaskVolumes leaves no remainder in the reference's counts (DESIGN §8) and the counts are comparable
+                if rng.random() < 0.4:
+                    sources = ["group:" + rng.choice(["", "g1", "g2", "g9"])]
+                else:
+                    sources = ["name%02d" % i for i in rng.sample(range(n_vol + 1), rng.choice([1, 1, 2, min(3, n_vol)]))]
+                mounts = [kv.cluster_mount(src, "/m%d" % m, rng.random() < 0.4) for m, src in enumerate(sources)]
+                if rng.random() < 0.2:
+                    mounts.insert(rng.randrange(len(mounts) + 1), {"Type": "BIND", "Source": "/x", "Target": "/y"})
+            svc = rng.randrange(4)
+            if svc == 3:
+                group_mounts = mounts if group_mounts is None else group_mounts
+                mounts = group_mounts
+            t = sc.pending("t%05d" % tid, "svc%d" % svc, spec_version=3 if svc == 3 else None, **({"Spec": {"Container": {"Mounts": mounts}}} if mounts else {}))
+            docs[t["ID"]] = t
+            waiting.append(t["ID"])
+            o.create_task(copy.deepcopy(t))
+            e.create_task(copy.deepcopy(t))
+        do = {d["ID"]: d for d in o.tick()}
+        # the double answers the tasks of a service in the order the host layer hands them over: the queue's order, task id order here
+        for t_id in sorted(do):
+            d = do[t_id]
+            fakelib.script(e.e, d["ServiceID"] if "ServiceID" in d else docs[t_id]["ServiceID"], d["NodeID"], [v["ID"] for v in d.get("Volumes") or []])
+        de = {d["ID"]: d for d in e.tick()}
+        assert sorted(do) == sorted(de)
+        for t_id in do:
+            a, b = do[t_id], de[t_id]
+            assert (a["NodeID"], a["State"]) == (b["NodeID"], b["State"]), (t_id, a, b)
+            assert [(v["ID"], v["Source"], v["Target"]) for v in a.get("Volumes") or []] == [(v["ID"], v["Source"], v["Target"]) for v in b.get("Volumes") or []], (t_id, a, b)
+            if a["NodeID"]:
+                placed.append(a)
+                n_placed += 1
+                n_attached += 1 if a.get("Volumes") else 0
+        for vid in vids:
+            io, ie = o.volume_info(vid), e.volume_info(vid)
+            assert (io is None) == (ie is None), vid
+            if io is None:
+                continue
+            assert io["Tasks"] == ie["Tasks"], (vid, io, ie)
+            assert {k: c for k, c in io["Nodes"].items() if c} == {k: c for k, c in ie["Nodes"].items() if c}, (vid, io, ie)
+        assert o.free_volumes() == e.free_volumes()
+        rng.shuffle(placed)
+        for d in placed[: len(placed) // 3]:
+            doc = dict(docs[d["ID"]], NodeID=d["NodeID"], Status={"State": orc.ASSIGNED}, Volumes=d.get("Volumes") or [])
+            o.delete_task(copy.deepcopy(doc))
+            e.delete_task(copy.deepcopy(doc))
+        placed = placed[len(placed) // 3:]
+    assert n_placed > 0
+    print("placed %d, with attachments %d" % (n_placed, n_attached))
