@@ -41,7 +41,7 @@ struct swp_engine {
     // REPLAY mode (swp_fake_script): per service a queue of answers — a node (or none) and the volumes of its cluster mounts — that are given
     // out instead of the pseudo-random ones, task after task of that service. tests/test_sched_volumes_cpu.py feeds it the oracle's
     // decisions, so that the host layer above can be compared with the oracle end to end on CPU.
-    struct Scripted { std::string node; std::vector<std::string> volumes; };
+    struct Scripted { std::string node; std::vector<std::string> volumes; uint32_t hist[SWP_NFILTERS] = {}; bool has_hist = false; };
     std::map<std::string, std::vector<Scripted>> script;   // service name -> answers, front first
     bool replay_att = false;                // the answer just given was a scripted one: its volumes are the next attachments
     std::vector<std::string> replay_vols;
@@ -121,7 +121,7 @@ struct swp_engine {
             const Scripted a = sq->second.front();
             sq->second.erase(sq->second.begin());
             if (hist != nullptr)
-                for (int k = 0; k < SWP_NFILTERS; ++k) hist[k] = a.node.empty() ? 1u : 0u;
+                for (int k = 0; k < SWP_NFILTERS; ++k) hist[k] = a.has_hist ? a.hist[k] : (a.node.empty() ? 1u : 0u);
             if (a.node.empty()) return -1;
             auto it = ids[SWP_SPACE_NODE_ID].find(a.node);
             if (it == ids[SWP_SPACE_NODE_ID].end() || it->second >= nodes.size() || !nodes[it->second].present) return -1;
@@ -623,6 +623,14 @@ int swp_fake_script(swp_engine* e, const char* service, const char* node, const 
     swp_engine::Scripted a;
     a.node = node ? node : "";
     for (uint32_t i = 0; i < n_volumes; ++i) a.volumes.push_back(volumes[i]);
+    e->script[service ? service : ""].push_back(a);
+    return SWP_OK;
+}
+// ... the same with the Pipeline counters a task without a node is explained by (what noSuitableNode reads, scheduler.go:929)
+int swp_fake_script_hist(swp_engine* e, const char* service, const uint32_t* hist) {
+    swp_engine::Scripted a;
+    a.has_hist = true;
+    for (int k = 0; k < SWP_NFILTERS; ++k) a.hist[k] = hist[k];
     e->script[service ? service : ""].push_back(a);
     return SWP_OK;
 }

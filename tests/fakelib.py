@@ -39,6 +39,14 @@ def take_log(engine):
     return fn(engine.h).decode().splitlines()
 
 
+def script_hist(engine, service, hist):
+    """REPLAY mode: the next task of `service` finds no node; `hist` = the eight Pipeline counters its explanation is made of."""
+    fn = engine.L.swp_fake_script_hist
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)]
+    fn.restype = ctypes.c_int
+    assert fn(engine.h, service.encode(), (ctypes.c_uint32 * 8)(*hist)) == 0
+
+
 def script(engine, service, node, volumes=()):
     """REPLAY mode of the double: the next task of `service` that reaches it is answered with `node` ("" / None: no suitable node) and, for
     its cluster mounts, `volumes` (ids, mount order; empty: assigned without attachments)."""
