@@ -81,11 +81,11 @@ COMPACT = [
     ((79, 66000, 1500, 200, 512, 0, 0, "c"), "5"),    # ... on 66 000 nodes: 3 rounds instead of 13
     ((79, 66000, 1500, 200, 512, 0, 0, "c"), "3"),    # a few stragglers far below the bulk
     ((2, 700, 1500, 30, 64, 0, 1, "tc"), "5"),        # task-rows mode: the index reads the block's first row
-    ((4, 5000, 2000, 300, 256, 0, 2, "sc"), "3"),     # host ports, uncounted tasks, a rebuild between two stretches
+    ((4, 5000, 1000, 300, 256, 0, 2, "sc"), "3"),     # host ports, uncounted tasks, a rebuild between two stretches
     ((8, 885, 1500, 125, 64, 2, 3, "c"), "5"),        # generic reservations
     ((50, 10000, 3000, 20, 512, 1, 0, "c"), "5"),     # twins: the offset counts compact positions
     ((3, 1000, 2500, 40, 64, 2, 2, "c"), None),       # whatever level mode the seed draws
-    ((21, 4500, 1500, 200, 1024, 0, 1, "c"), None),
+    ((21, 4500, 600, 200, 1024, 0, 1, "c"), None),    # the largest block
 ]
 
 
