@@ -210,6 +210,10 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
         # True: the RCCL path inside libswp.so could not be used and the ranks fell back to the host-merged round-2 protocol (an order
         # of magnitude slower: NOT the design's number). bench.py --strict exits non-zero instead of measuring that.
         "exchange_fallback": bool(state.get("exchange_fallback")),
+        # the node-range split exists for node sets beyond one engine's LDS budget (~650k nodes). Below that a sharded round
+        # pays a propose + a commit launch per device plus the exchange for work one engine does in the same two launches: the 1 -> N
+        # curve points DOWN at every size one GPU holds.
+        "expected_speedup": "<1 below ~650k nodes",
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(wl)
@@ -217,6 +221,152 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
         print(json.dumps(result))
     for b in batches:
         b.free()
+    ranks.close()
+
+
+def run_churn(args, ranks, wl, eng, descs, ranges):
+    """BASELINE configs[4] / SURVEY 8d cfg5: place the batch once, then rounds of {reactivate the previous round's drained nodes, drain a
+    seeded random 10 % of the nodes, remove the tasks on them, re-place as many new tasks}. The incremental path (scheduler.go:254-396,
+    nodeinfo.go:66-154): swp_node_update_dynamic_many, swp_commit(remove), a re-placement batch — timed end to end, round by round.
+
+      one engine            the calls as they are;
+      --shards G (N = 1)    `eng` is a shard SET (swp_shardset_create): the same calls, routed to the owner of every node's range,
+                            the re-placement batch by swp_shard_run;
+      --gpus N   (N > 1)    one engine per rank holding ITS node range: every rank follows the same script, applies the drains and
+                            swp_commit(remove) for its own nodes, and takes part in one sharded re-placement batch per round
+                            (swp_shard_run_rank: an ncclAllGather of the block's proposals per round of the resolver)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from swarmkit_amd import abi, shard as swshard
+    rank, world = ranks.rank, ranks.world
+    by_rank = world > 1
+    first, cnt = (ranges[rank] if by_rank else (0, wl.N))
+    state = {"rounds_total": 0}
+
+    def place(batch_descs, timed=None):
+        """one placement batch over the whole node set -> (global node per task, device ms or None)"""
+        if not by_rank:
+            ta = time.perf_counter()
+            bt = eng.batch_prepare(batch_descs)
+            tb = time.perf_counter()
+            bt.run()
+            tc = time.perf_counter()
+            out, _h = bt.fetch(want_hist=False)   # (fetch: the placements enter the engine's node mirror, as in swp_schedule_batch)
+            bt.free()
+            td = time.perf_counter()
+            st = eng.stats()
+            state["rounds_total"] += st["resolve_launches"] if st["last_resolver"] == 7 else 0
+            if timed is not None:
+                timed["swp_batch_prepare"] += tb - ta
+                timed["swp_batch_run"] += tc - tb
+                timed["swp_batch_fetch"] += td - tc
+            return out.astype(np.int64), st["ms_total"]
+        ta = time.perf_counter()
+        bt = eng.batch_prepare(batch_descs)
+        tb = time.perf_counter()
+        drv = swshard.DeviceRankShard(bt, rank, world, ranges, dist, ranks.device, fold=True)   # raises RcclUnavailable on EVERY rank: no silent fallback
+        out, _h = drv.run(want_hist=False)
+        tc = time.perf_counter()
+        bt.free()
+        state["rounds_total"] += drv.rounds
+        if timed is not None:
+            timed["swp_batch_prepare"] += tb - ta
+            timed["swp_batch_run"] += tc - tb
+        return out.astype(np.int64), (tc - tb) * 1e3
+
+    assign, _ms = place(descs)          # task -> global node (or -1)
+    assign = assign.copy()
+    rng = np.random.default_rng(wl.seed)
+    prev = np.zeros(0, dtype=np.int64)
+    replaced = 0
+    dev_ms = 0.0
+    t_rounds = []
+    phases = {"node calls (get_many + update_dynamic_many)": 0.0, "swp_commit(remove)": 0.0, "swp_batch_prepare": 0.0, "swp_batch_run": 0.0,
+              "swp_batch_fetch": 0.0, "the script itself (which tasks sat on the drained nodes, their descriptors)": 0.0}
+    is_drained = np.zeros(wl.N + 1, dtype=bool)   # (index -1 = unplaced: the extra last entry)
+    state["rounds_total"] = 0
+    if by_rank:
+        torch.cuda.synchronize()
+        ranks.barrier()
+    for rnd in range(args.rounds):
+        t0 = time.perf_counter()
+        drained = rng.choice(wl.N, size=max(wl.N // 10, 1), replace=False)
+        touched = np.concatenate([prev, drained]).astype(np.int64)
+        reactivate = np.arange(len(touched)) < len(prev)
+        if by_rank:   # the rows of THIS rank's range, by local index
+            mine = (touched >= first) & (touched < first + cnt)
+            touched, reactivate = touched[mine] - first, reactivate[mine]
+        ta = time.perf_counter()
+        rows = eng.node_get_many(touched.astype(np.uint32))          # two calls per round instead of four per node
+        upd = np.zeros(len(touched), dtype=abi.NODE_DYNAMIC_DTYPE)
+        upd["node"], upd["cpu"], upd["mem"], upd["total"] = touched, rows["cpu"], rows["mem"], rows["total"]
+        upd["flags"] = np.where(reactivate, rows["flags"] | abi.NODE_READY, rows["flags"] & ~np.uint32(abi.NODE_READY))
+        eng.node_update_dynamic_many(upd)          # reactivate the previous round's nodes, Availability = DRAIN for this round's
+        tb = time.perf_counter()
+        is_drained[:] = False
+        is_drained[drained] = True
+        gone = np.nonzero(is_drained[assign])[0]
+        tc = td = tg = tb
+        if len(gone):
+            own = gone if not by_rank else gone[(assign[gone] >= first) & (assign[gone] < first + cnt)]
+            pl = np.zeros(len(own), dtype=abi.PLACEMENT_DTYPE)
+            pl["node"], pl["service"] = assign[own] - first, descs["service"][own]
+            pl["cpu"], pl["mem"], pl["counted"] = descs["cpu"][own], descs["mem"][own], 1
+            again = descs[gone]                    # as many new tasks of the same services
+            tc = time.perf_counter()
+            if len(own):
+                eng.commit(pl, add=False)          # NodeInfo.removeTask for every task on a drained node (on its owner)
+            td = time.perf_counter()
+            new_out, ms = place(again, phases)
+            tg = time.perf_counter()
+            assign[gone] = new_out
+            replaced += len(gone)
+            dev_ms += ms
+            phases["swp_commit(remove)"] += td - tc
+        prev = drained
+        t1 = time.perf_counter()
+        t_rounds.append(t1 - t0)
+        phases["node calls (get_many + update_dynamic_many)"] += tb - ta
+        phases["the script itself (which tasks sat on the drained nodes, their descriptors)"] += (ta - t0) + (tc - tb) + ((t1 - tg) if len(gone) else 0.0)
+    if by_rank:
+        torch.cuda.synchronize()
+        ranks.barrier()
+    tt = ranks.max_over_ranks(sum(t_rounds)) if by_rank else sum(t_rounds)
+    R = max(args.rounds, 1)
+    row_b = ROW_B.get(args.workload, 48)
+    alg = (replaced / R) * wl.N * row_b + (replaced / R) * TASK_B
+    n_shards = world if by_rank else (eng.shards or 1)
+    if by_rank:
+        par, exch = "node-shard", "one engine per rank over its node range; per round of the resolver an ncclAllGather of the block's proposals (swp_shard_run_rank); drains and swp_commit(remove) on the owner rank"
+    elif n_shards > 1:
+        par, exch = "node-shard", "a shard SET of %d engines on one GPU behind one handle (swp_shardset_create): node calls and swp_commit(remove) routed to the owner, the re-placement batch by swp_shard_run" % n_shards
+    else:
+        par, exch = "single", None
+    res = {"metric": "reschedule churn: placements/sec over rounds of {drain 10 % of the nodes, remove their tasks, re-place} (end to end)",
+           "value": replaced / tt if tt else 0.0, "unit": "placements/s", "n_gpus": world, "steps": args.rounds, "warmup": 0,
+           "ms_per_step": 1e3 * tt / R, "higher_is_better": True, "scaling": "strong" if n_shards > 1 else "weak", "vs_baseline": None,
+           "dtype": "int64", "data": "synthetic",
+           "config": dict(wl.describe(), mode="churn", rounds=args.rounds, replaced=int(replaced), parallelism=par, shards=n_shards),
+           "still_placed": int((assign >= 0).sum()), "device_ms_per_round": dev_ms / R,
+           "ms_per_round_by_phase": {k: 1e3 * v / R for k, v in phases.items()},
+           "roofline": {"bound": "hbm", "kernel": "the round's re-placement batch (k_r6_propose + k_r6_commit rounds, or the sharded rounds k_r7_*) + explain",
+                        "achieved": alg / (dev_ms / R * 1e-3) / 1e9 if dev_ms else 0.0,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / (dev_ms / R * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms else 0.0,
+                        "traffic": profile_traffic("k_resolve6")[0], "traffic_source": "per resolver ROUND, " + profile_traffic("k_resolve6")[1],
+                        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dev_ms / R,
+                        "note": "device time of the re-placement batch of a round (engine events; over shards: the wall time of the sharded run); the round "
+                                "itself also pays the host side: two bulk node calls, swp_commit(remove) and swp_batch_prepare for ~9k descriptors"}}
+    if n_shards > 1:
+        res["config"]["exchange"] = exch
+        res["config"]["resolver_rounds_per_churn_round"] = state["rounds_total"] / R
+        # (DESIGN §7: a sharded round costs a propose + a commit launch per device plus the exchange, against the same two launches on one
+        # engine: below the node count one engine's LDS holds, sharding cannot be faster)
+        res["expected_speedup"] = "<1 below ~650k nodes: the node-range split exists for node sets one engine cannot hold"
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline(wl, budget_s=8.0)
+    if rank == 0:
+        print(json.dumps(res))
     ranks.close()
 
 
@@ -291,8 +441,23 @@ def main():
     par = args.parallelism
     if par == "auto":
         par = "node-shard" if (world > 1 or args.shards > 1) else "single"
-    shard_mode = par == "node-shard" and args.mode == "one-off"
-    if shard_mode:
+    if par == "node-shard" and args.mode not in ("one-off", "churn"):
+        # (task groups and the enforcer's sweep over node ranges go through a shard SET in one process — tests/test_engine_shardset.py;
+        # this harness measures them on one engine. Refuse rather than measure N independent replicas under a sharded label.)
+        print(f"bench.py: --mode {args.mode} is not run over node-range shards here; use --parallelism replicas (or single)", file=sys.stderr)
+        sys.exit(2)
+    shard_mode = par == "node-shard"
+    churn_set = shard_mode and args.mode == "churn" and world == 1   # --shards G: ONE handle over G engines on this GPU (swp_shardset_create)
+    if churn_set:
+        from swarmkit_amd import shard as swshard
+        wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, order=args.order, services=args.services)
+        shard_ranges_ = swshard.shard_ranges(wl.N, args.shards)
+        eng = abi.Engine(device=local_rank, profile=True, shards=args.shards, nodes_per_shard=shard_ranges_[0][1])
+        sched = host.HostScheduler(engine=eng)
+        t0 = time.perf_counter()
+        descs = host.load_workload(sched, wl)
+        t_host_prep = time.perf_counter() - t0
+    elif shard_mode:
         # every rank sees the SAME cluster and task list and owns one contiguous range of the canonical node order
         from swarmkit_amd import shard as swshard
         wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, order=args.order, services=args.services)
@@ -314,82 +479,7 @@ def main():
         descs = host.load_workload(sched, wl)
         t_host_prep = time.perf_counter() - t0
     if args.mode == "churn":
-        # BASELINE configs[4] / SURVEY 8d cfg5: place the batch once, then rounds of {reactivate the previous round's
-        # drained nodes, drain a seeded random 10 % of the nodes, remove the tasks on them, re-place as many new tasks}.
-        # Exercises the incremental path (swp_node_update_dynamic, swp_commit(remove), swp_schedule_batch), timed end to end.
-        import numpy as np
-        out, _h = eng.schedule_batch(descs, want_hist=False)
-        assign = out.astype(np.int64).copy()          # task -> node (or -1)
-        svc_of = np.array([wl.task_service(j) for j in range(wl.T)])
-        rng = np.random.default_rng(wl.seed)
-        prev = np.zeros(0, dtype=np.int64)
-        replaced = 0
-        dev_ms = 0.0
-        t_rounds = []
-        phases = {"node calls (get_many + update_dynamic_many)": 0.0, "swp_commit(remove)": 0.0, "swp_batch_prepare": 0.0, "swp_batch_run": 0.0,
-                  "swp_batch_fetch": 0.0, "the script itself (which tasks sat on the drained nodes, their descriptors)": 0.0}
-        is_drained = np.zeros(wl.N + 1, dtype=bool)   # (index -1 = unplaced: the extra last entry)
-        for rnd in range(args.rounds):
-            t0 = time.perf_counter()
-            drained = rng.choice(wl.N, size=max(wl.N // 10, 1), replace=False)
-            touched = np.concatenate([prev, drained]).astype(np.uint32)
-            ta = time.perf_counter()
-            rows = eng.node_get_many(touched)          # two calls per round instead of four per node
-            upd = np.zeros(len(touched), dtype=abi.NODE_DYNAMIC_DTYPE)
-            upd["node"], upd["cpu"], upd["mem"], upd["total"] = touched, rows["cpu"], rows["mem"], rows["total"]
-            upd["flags"] = np.where(np.arange(len(touched)) < len(prev), rows["flags"] | abi.NODE_READY, rows["flags"] & ~np.uint32(abi.NODE_READY))
-            eng.node_update_dynamic_many(upd)          # reactivate the previous round's nodes, Availability = DRAIN for this round's
-            tb = time.perf_counter()
-            is_drained[:] = False
-            is_drained[drained] = True
-            gone = np.nonzero(is_drained[assign])[0]
-            tc = tb
-            if len(gone):
-                pl = np.zeros(len(gone), dtype=abi.PLACEMENT_DTYPE)
-                pl["node"], pl["service"] = assign[gone], descs["service"][gone]
-                pl["cpu"], pl["mem"], pl["counted"] = descs["cpu"][gone], descs["mem"][gone], 1
-                again = descs[gone]                    # as many new tasks of the same services
-                tc = time.perf_counter()
-                eng.commit(pl, add=False)              # NodeInfo.removeTask for every task on a drained node
-                td = time.perf_counter()
-                bt = eng.batch_prepare(again)
-                te = time.perf_counter()
-                bt.run()
-                tf = time.perf_counter()
-                new_out, _h = bt.fetch(want_hist=False)   # (fetch: the placements enter the engine's node mirror, as in swp_schedule_batch)
-                bt.free()
-                tg = time.perf_counter()
-                assign[gone] = new_out
-                replaced += len(gone)
-                dev_ms += eng.stats()["ms_total"]
-                phases["swp_commit(remove)"] += td - tc
-                phases["swp_batch_prepare"] += te - td
-                phases["swp_batch_run"] += tf - te
-                phases["swp_batch_fetch"] += tg - tf
-            prev = drained
-            t1 = time.perf_counter()
-            t_rounds.append(t1 - t0)
-            phases["node calls (get_many + update_dynamic_many)"] += tb - ta
-            phases["the script itself (which tasks sat on the drained nodes, their descriptors)"] += (ta - t0) + (tc - tb) + ((t1 - tg) if len(gone) else 0.0)
-        tt = sum(t_rounds)
-        row_b = ROW_B.get(args.workload, 48)
-        alg = (replaced / max(args.rounds, 1)) * wl.N * row_b + (replaced / max(args.rounds, 1)) * TASK_B
-        res = {"metric": "reschedule churn: placements/sec over rounds of {drain 10 % of the nodes, remove their tasks, re-place} (end to end)",
-               "value": replaced / tt if tt else 0.0, "unit": "placements/s", "n_gpus": 1, "steps": args.rounds, "warmup": 0,
-               "ms_per_step": 1e3 * tt / max(args.rounds, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "int64", "data": "synthetic",
-               "config": dict(wl.describe(), mode="churn", rounds=args.rounds, replaced=int(replaced)),
-               "still_placed": int((assign >= 0).sum()), "device_ms_per_round": dev_ms / max(args.rounds, 1),
-               "ms_per_round_by_phase": {k: 1e3 * v / max(args.rounds, 1) for k, v in phases.items()},
-               "roofline": {"bound": "hbm", "kernel": "the round's swp_schedule_batch (k_resolve5 / k_resolve6 + explain)", "achieved": alg / (dev_ms / max(args.rounds, 1) * 1e-3) / 1e9 if dev_ms else 0.0,
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / (dev_ms / max(args.rounds, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms else 0.0,
-                            "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dev_ms / max(args.rounds, 1),
-                            "note": "device time of the re-placement batch of a round (engine events); the round itself is dominated by the host side: two bulk node calls, "
-                                    "swp_commit(remove) and swp_batch_prepare for ~9k descriptors"}}
-        if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(wl, budget_s=8.0)
-        print(json.dumps(res))
-        ranks.close()
+        run_churn(args, ranks, wl, eng, descs, shard_ranges_)
         return
     if args.mode == "enforce":
         # constraintenforcer.rejectNoncompliantTasks for EVERY node (the enforcer's start-up sweep,

@@ -437,6 +437,17 @@ int swp_shard_run_rank(swp_engine*, swp_batch*, const uint32_t* shard_nodes, uin
  * error, 3 the positions differ (the ranks diverged). Exposed for the host layer's tests; words = n_ranks x 4 uint32. */
 int swp_shard_verdict(const uint32_t* words, uint32_t n_ranks, uint32_t* who_out);
 
+/* A shard SET: the same node-range split behind ONE engine handle — what a Go manager on a multi-GPU box holds instead of an engine.
+ * swp_shardset_create makes n_shards engines (devices[g]: the HIP device of shard g; NULL: all on cfg->device) and returns a handle that
+ * every entry point of this header takes like an engine's: the set interns node ids itself (lowest free index first, as swp_node_remove
+ * documents) and owns the GLOBAL node index — node i lives on shard i / nodes_per_shard —, routes every node call to the owner
+ * (nodeSet.addOrUpdateNode / remove, NodeInfo.addTask / removeTask: the incremental path between two batches, scheduler.go:254-396,
+ * nodeinfo.go:66-154), replicates services, predicate sets, volumes and mount sets on every shard, and runs a batch with swp_shard_run
+ * (the rounds on the device); swp_batch_fetch returns global node indices and folds every shard's placements into its mirror. What a
+ * range cannot hold is refused when a node id is interned (SWP_ERANGE: n_shards x nodes_per_shard slots). swp_destroy destroys the
+ * shards. The swp_shard_* / swp_rccl_* calls take the engine of ONE range, never a set (SWP_EINVAL). */
+int swp_shardset_create(const swp_config* cfg, const int32_t* devices, uint32_t n_shards, uint32_t nodes_per_shard, swp_engine** out);
+
 /* NodeInfo.addTask / removeTask for tasks the engine did not place itself (event handlers
  * scheduler.go:254-366; rollback :472-487). add_or_remove: 1 = add, 0 = remove. */
 typedef struct {

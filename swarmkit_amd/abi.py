@@ -109,7 +109,7 @@ EXPORTS = [
     "swp_node_remove", "swp_node_get", "swp_node_set_svc_count", "swp_node_get_svc_count", "swp_node_set_failures", "swp_node_port",
     "swp_constraint_set", "swp_platform_set", "swp_plugin_set", "swp_port_set", "swp_spread_set", "swp_schedule_groups", "swp_schedule_batch", "swp_batch_prepare",
     "swp_batch_run", "swp_batch_fetch", "swp_batch_results", "swp_batch_free", "swp_state_save", "swp_state_restore", "swp_commit", "swp_check_node", "swp_enforce", "swp_node_matches",
-    "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check", "swp_node_update_dynamic_many", "swp_node_get_many",
+    "swp_stats", "swp_strerror", "swp_last_error", "swp_abi_check", "swp_node_update_dynamic_many", "swp_node_get_many", "swp_shardset_create",
     "swp_shard_begin", "swp_shard_propose", "swp_shard_merge", "swp_shard_commit", "swp_shard_end", "swp_shard_run", "swp_rccl_available", "swp_rccl_unique_id", "swp_rccl_init", "swp_rccl_finalize", "swp_shard_run_rank", "swp_shard_verdict",
     # include/swp_sched.h — the host layer above the engine
     "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
@@ -162,6 +162,7 @@ def load_library(path=None):
     sig = {
         "swp_create": ([P(Config), P(vp)], C.c_int),
         "swp_destroy": ([vp], None),
+        "swp_shardset_create": ([P(Config), P(i32), u32, u32, P(vp)], C.c_int),
         "swp_reset": ([vp, u32], C.c_int),
         "swp_intern": ([vp, C.c_int, cp, C.c_size_t, P(u32)], C.c_int),
         "swp_intern_lookup": ([vp, C.c_int, u32, cp, C.c_size_t], C.c_int),
@@ -342,12 +343,27 @@ class Batch:
 class Engine:
     """One swp_engine handle. Raises SwpError(SWP_ENODEVICE) when no gfx950 is present: there is no CPU path."""
 
-    def __init__(self, device=0, window=0, resolver_threads=0, profile=False, lib_path=None, shard_rank=0, shard_count=0):
+    def __init__(self, device=0, window=0, resolver_threads=0, profile=False, lib_path=None, shard_rank=0, shard_count=0,
+                 shards=None, nodes_per_shard=None, devices=None):
+        """shards=G, nodes_per_shard=cap: a shard SET (swp_shardset_create) — G engines of this process behind the one handle, on
+        `devices` (one ordinal per shard; default: all on `device`). SWP_SHARDSET="G:cap" in the environment turns every engine
+        created without shard arguments into such a set (how the whole scenario suite is run over node-range shards)."""
         self.L = load_library(lib_path)
         cfg = Config(device=device, window=window, resolver_threads=resolver_threads, flags=CFG_PROFILE if profile else 0,
                      shard_rank=shard_rank, shard_count=shard_count)
+        env = os.environ.get("SWP_SHARDSET")
+        if shards is None and env and not shard_count and lib_path is None:
+            shards, nodes_per_shard = (int(x) for x in env.split(":"))
         h = C.c_void_p()
-        rc = self.L.swp_create(C.byref(cfg), C.byref(h))
+        self.shards = int(shards or 0)
+        if self.shards:
+            if not nodes_per_shard:
+                raise ValueError("a shard set needs nodes_per_shard (the node slots of every range)")
+            self.nodes_per_shard = int(nodes_per_shard)
+            dev = (C.c_int32 * self.shards)(*[int(d) for d in devices]) if devices is not None else None
+            rc = self.L.swp_shardset_create(C.byref(cfg), dev, self.shards, self.nodes_per_shard, C.byref(h))
+        else:
+            rc = self.L.swp_create(C.byref(cfg), C.byref(h))
         if rc != 0:
             raise SwpError(rc, self.L.swp_last_error(None).decode())
         self.h = h

@@ -401,10 +401,25 @@ struct swp_batch {
     std::vector<ShardInfDev> shard_infs;
     DevBuf d_prop, d_picks, d_infs;
     DevBuf d_cmask, d_crank, d_cidx;       // the block resolver's compact index of a round (k_r6_compact)
+    // a batch of a shard SET (swp_shardset.hpp): one part per shard, prepared from the same task list; the last run's results
+    bool is_set = false;
+    std::vector<swp_batch*> parts;
+    std::vector<int32_t> set_shard, set_node;   // [T] owner shard (-1: no suitable node) and its local node index
+    std::vector<uint32_t> set_hist;             // [T][SWP_NFILTERS] summed over the shards
+    int32_t set_single = -1;                    // >= 0: only that shard holds nodes, its own batch path ran
+};
+
+// A shard set (swp_shardset.hpp): the engines of one process behind one handle. The set owns the global node index space.
+struct ShardSet {
+    std::vector<swp_engine*> sh;   // owned
+    uint32_t cap = 0;              // node slots per shard: global index i = shard i / cap, local index i % cap
+    Interner nodes;                // SWP_SPACE_NODE_ID of the set (lowest free index first, as every engine's)
+    uint32_t hi = 0;               // highest global index handed out so far + 1
 };
 
 struct swp_engine {
     swp_config cfg{};
+    ShardSet* set = nullptr;   // != nullptr: this handle is a shard SET (swp_shardset_create): no device state of its own, every call is routed
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -490,6 +505,13 @@ struct swp_engine {
 namespace {
 
 uint32_t n_words_of(uint32_t n) { return (n + 63) / 64; }
+
+// a node index that swp_node_remove handed back to the pool and no swp_intern has taken again: a caller that still holds it is stale
+// (the next new node id will be given exactly this index)
+bool node_index_released(const swp_engine* e, uint32_t node) {
+    const Interner& sp = e->spaces[SWP_SPACE_NODE_ID];
+    return node < sp.freed.size() && sp.freed[node] != 0;
+}
 
 template <class T>
 int upload(swp_engine* e, DevBuf& b, const PinVec<T>& v, size_t min_elems = 1);
@@ -2078,6 +2100,50 @@ int register_set(Index& index, Vec& sets, const std::string& key, Set&& value, u
 
 }  // namespace
 
+// the shard set's side of every entry point (swp_shardset.hpp, included behind the extern "C" block)
+namespace ss {
+int create(const swp_config*, const int32_t*, uint32_t, uint32_t, swp_engine**);
+void destroy(swp_engine*);
+int reset(swp_engine*, uint32_t);
+int intern(swp_engine*, int, const char*, size_t, uint32_t*);
+int intern_lookup(swp_engine*, int, uint32_t, char*, size_t);
+int node_upsert(swp_engine*, const swp_node_row*, const swp_kv*, uint32_t, const swp_kv*, uint32_t, const uint32_t*, uint32_t);
+int node_update_dynamic(swp_engine*, uint32_t, uint32_t, int64_t, int64_t, uint32_t);
+int node_get(swp_engine*, uint32_t, swp_node_row*);
+int node_remove(swp_engine*, uint32_t);
+int node_set_svc_count(swp_engine*, uint32_t, uint32_t, uint32_t);
+int node_get_svc_count(swp_engine*, uint32_t, uint32_t, uint32_t*);
+int node_set_failures(swp_engine*, uint32_t, uint32_t, uint64_t, uint32_t);
+int node_port(swp_engine*, uint32_t, uint32_t, uint32_t, int);
+int node_set_generic(swp_engine*, uint32_t, const swp_generic*, uint32_t);
+int node_get_generic(swp_engine*, uint32_t, uint32_t, int64_t*);
+int node_set_csi(swp_engine*, uint32_t, const swp_csi*, uint32_t, const swp_seg*, uint32_t);
+int constraint_set(swp_engine*, const swp_constraint*, uint32_t, uint32_t*);
+int platform_set(swp_engine*, const swp_platform*, uint32_t, uint32_t*);
+int plugin_set(swp_engine*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+int port_set(swp_engine*, const swp_port*, uint32_t, uint32_t*);
+int spread_set(swp_engine*, const swp_spread*, uint32_t, uint32_t*);
+int generic_set(swp_engine*, const swp_generic*, uint32_t, uint32_t*);
+int mount_set(swp_engine*, const swp_mount*, uint32_t, uint32_t*);
+int volume_upsert(swp_engine*, uint32_t, const swp_volume*, const uint32_t*, const swp_seg*);
+int volume_set_usage(swp_engine*, uint32_t, const swp_volume_usage*);
+int volume_get_usage(swp_engine*, uint32_t, swp_volume_usage*);
+int choose_volumes(swp_engine*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+int batch_prepare(swp_engine*, const swp_task_desc*, uint32_t, const uint32_t*, uint32_t, bool, swp_batch**);
+int batch_run(swp_engine*, swp_batch*);
+int batch_collect(swp_engine*, swp_batch*, int32_t*, uint32_t*, bool);
+int batch_attachments(swp_engine*, swp_batch*, const uint32_t*, uint32_t, uint32_t*);
+void batch_free(swp_engine*, swp_batch*);
+int schedule_groups(swp_engine*, const swp_task_desc*, const uint32_t*, uint32_t, int32_t*, uint32_t*, uint32_t*);
+int state_save(swp_engine*);
+int state_restore(swp_engine*);
+int commit(swp_engine*, const swp_placement*, uint32_t, int);
+int check_node(swp_engine*, const swp_task_desc*, uint32_t, int32_t*);
+int enforce(swp_engine*, const swp_enforce_node*, uint32_t, const swp_enforce_task*, uint32_t, uint8_t*);
+int node_matches(swp_engine*, const uint32_t*, uint32_t, uint64_t*, uint32_t);
+int stats(swp_engine*, swp_stats_t*);
+}   // namespace ss
+
 // =================================================================================================
 extern "C" {
 
@@ -2145,6 +2211,7 @@ int swp_create(const swp_config* cfg, swp_engine** out) {
 
 void swp_destroy(swp_engine* e) {
     if (!e) return;
+    if (e->set) { ss::destroy(e); return; }
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     // (an RCCL communicator is NOT torn down here: engines are often destroyed while the process exits, after RCCL's own static
@@ -2159,6 +2226,7 @@ void swp_destroy(swp_engine* e) {
 }
 
 int swp_reset(swp_engine* e, uint32_t n_nodes_hint) {
+    if (e && e->set) return ss::reset(e, n_nodes_hint);
     if (!e) return SWP_EINVAL;
     engine_reset_nodes(e);
     e->spaces[SWP_SPACE_NODE_ID].init(false);
@@ -2167,6 +2235,7 @@ int swp_reset(swp_engine* e, uint32_t n_nodes_hint) {
 }
 
 int swp_intern(swp_engine* e, int space, const char* utf8, size_t len, uint32_t* id_out) {
+    if (e && e->set) return ss::intern(e, space, utf8, len, id_out);
     if (!e || space < 0 || space >= SWP_SPACE_COUNT || !id_out || (!utf8 && len)) return SWP_EINVAL;
     std::string s = space == SWP_SPACE_FOLDED ? fold_canon(utf8, len) : std::string(utf8 ? utf8 : "", len);
     if (space == SWP_SPACE_ARCH) {   // filter.go:285-299
@@ -2178,6 +2247,7 @@ int swp_intern(swp_engine* e, int space, const char* utf8, size_t len, uint32_t*
 }
 
 int swp_intern_lookup(swp_engine* e, int space, uint32_t id, char* out, size_t cap) {
+    if (e && e->set) return ss::intern_lookup(e, space, id, out, cap);
     if (!e || space < 0 || space >= SWP_SPACE_COUNT) return SWP_EINVAL;
     const auto& strs = e->spaces[space].strs;
     if (id >= strs.size()) return SWP_ENOTFOUND;
@@ -2188,9 +2258,11 @@ int swp_intern_lookup(swp_engine* e, int space, uint32_t id, char* out, size_t c
 
 int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* node_labels, uint32_t n_node_labels, const swp_kv* engine_labels,
                     uint32_t n_engine_labels, const uint32_t* plugins, uint32_t n_plugins) {
+    if (e && e->set) return ss::node_upsert(e, row, node_labels, n_node_labels, engine_labels, n_engine_labels, plugins, n_plugins);
     if (!e || !row) return SWP_EINVAL;
     e->host_dirty_since_save = true;
     if (row->node >= e->spaces[SWP_SPACE_NODE_ID].strs.size()) return e->fail(SWP_EINVAL, "node id %u was never interned", row->node);
+    if (node_index_released(e, row->node)) return e->fail(SWP_EINVAL, "node index %u was released by swp_node_remove: intern the node id again", row->node);
     if (row->total >= (1u << 30)) return e->fail(SWP_ERANGE, "ActiveTasksCount out of range");
     if (row->node >= e->nodes.size()) e->nodes.resize(row->node + 1);
     HostNode& h = e->nodes[row->node];
@@ -2206,6 +2278,7 @@ int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* node_l
 }
 
 int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_t cpu, int64_t mem, uint32_t total) {
+    if (e && e->set) return ss::node_update_dynamic(e, node, flags, cpu, mem, total);
     if (!e) return SWP_EINVAL;
     e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
@@ -2238,6 +2311,7 @@ int swp_node_get_many(swp_engine* e, const uint32_t* nodes, uint32_t n, swp_node
 }
 
 int swp_node_remove(swp_engine* e, uint32_t node) {
+    if (e && e->set) return ss::node_remove(e, node);
     if (!e) return SWP_EINVAL;
     e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_OK;   // delete of an absent key is a no-op
@@ -2258,6 +2332,7 @@ int swp_node_remove(swp_engine* e, uint32_t node) {
 }
 
 int swp_node_get(swp_engine* e, uint32_t node, swp_node_row* out) {
+    if (e && e->set) return ss::node_get(e, node, out);
     if (!e || !out) return SWP_EINVAL;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     *out = e->nodes[node].row;
@@ -2265,6 +2340,7 @@ int swp_node_get(swp_engine* e, uint32_t node, swp_node_row* out) {
 }
 
 int swp_node_set_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint32_t count) {
+    if (e && e->set) return ss::node_set_svc_count(e, node, service, count);
     if (!e) return SWP_EINVAL;
     e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
@@ -2281,6 +2357,7 @@ int swp_node_set_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint3
 }
 
 int swp_node_get_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint32_t* count_out) {
+    if (e && e->set) return ss::node_get_svc_count(e, node, service, count_out);
     if (!e || !count_out) return SWP_EINVAL;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     auto it = e->nodes[node].svc.find(service);
@@ -2289,6 +2366,7 @@ int swp_node_get_svc_count(swp_engine* e, uint32_t node, uint32_t service, uint3
 }
 
 int swp_node_set_failures(swp_engine* e, uint32_t node, uint32_t service, uint64_t spec_version, uint32_t count) {
+    if (e && e->set) return ss::node_set_failures(e, node, service, spec_version, count);
     if (!e) return SWP_EINVAL;
     e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
@@ -2304,6 +2382,7 @@ int swp_node_set_failures(swp_engine* e, uint32_t node, uint32_t service, uint64
 }
 
 int swp_node_port(swp_engine* e, uint32_t node, uint32_t protocol, uint32_t port, int set) {
+    if (e && e->set) return ss::node_port(e, node, protocol, port, set);
     if (!e) return SWP_EINVAL;
     e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
@@ -2319,6 +2398,7 @@ int swp_node_port(swp_engine* e, uint32_t node, uint32_t protocol, uint32_t port
 }
 
 int swp_constraint_set(swp_engine* e, const swp_constraint* cs, uint32_t n, uint32_t* id_out) {
+    if (e && e->set) return ss::constraint_set(e, cs, n, id_out);
     if (!e || !id_out || (!cs && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
     for (uint32_t i = 0; i < n; ++i) {
@@ -2336,12 +2416,14 @@ int swp_constraint_set(swp_engine* e, const swp_constraint* cs, uint32_t n, uint
 }
 
 int swp_platform_set(swp_engine* e, const swp_platform* ps, uint32_t n, uint32_t* id_out) {
+    if (e && e->set) return ss::platform_set(e, ps, n, id_out);
     if (!e || !id_out || (!ps && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
     return register_set(e->plat_index, e->plat_sets, bytes_of(ps, n), std::vector<swp_platform>(ps, ps + n), id_out);
 }
 
 int swp_plugin_set(swp_engine* e, const uint32_t* required, uint32_t n, uint32_t log_plugin, uint32_t* id_out) {
+    if (e && e->set) return ss::plugin_set(e, required, n, log_plugin, id_out);
     if (!e || !id_out || (!required && n)) return SWP_EINVAL;
     swp_engine::PlugSet ps;
     ps.required.assign(required, required + n);
@@ -2351,6 +2433,7 @@ int swp_plugin_set(swp_engine* e, const uint32_t* required, uint32_t n, uint32_t
 }
 
 int swp_port_set(swp_engine* e, const swp_port* ports, uint32_t n, uint32_t* id_out) {
+    if (e && e->set) return ss::port_set(e, ports, n, id_out);
     if (!e || !id_out || (!ports && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
     // the Explain pass tracks "this port was taken on the node by a LATER commit" in a 32-bit mask per task
@@ -2359,6 +2442,7 @@ int swp_port_set(swp_engine* e, const swp_port* ports, uint32_t n, uint32_t* id_
 }
 
 int swp_spread_set(swp_engine* e, const swp_spread* levels, uint32_t n, uint32_t* id_out) {
+    if (e && e->set) return ss::spread_set(e, levels, n, id_out);
     if (!e || !id_out || (!levels && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
     for (uint32_t i = 0; i < n; ++i)
@@ -2367,6 +2451,7 @@ int swp_spread_set(swp_engine* e, const swp_spread* levels, uint32_t n, uint32_t
 }
 
 int swp_generic_set(swp_engine* e, const swp_generic* items, uint32_t n, uint32_t* id_out) {
+    if (e && e->set) return ss::generic_set(e, items, n, id_out);
     if (!e || !id_out || (!items && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
     if (n > 8) return e->fail(SWP_ERANGE, "a task reserves %u generic kinds (the engine takes 8)", n);
@@ -2385,6 +2470,7 @@ int swp_generic_set(swp_engine* e, const swp_generic* items, uint32_t n, uint32_
 
 // ---- CSI volumes ------------------------------------------------------------------------------------------------------------
 int swp_node_set_csi(swp_engine* e, uint32_t node, const swp_csi* infos, uint32_t n, const swp_seg* segs, uint32_t n_segs) {
+    if (e && e->set) return ss::node_set_csi(e, node, infos, n, segs, n_segs);
     if (!e || (!infos && n) || (!segs && n_segs)) return SWP_EINVAL;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     std::vector<HostNode::Csi> v(n);
@@ -2407,6 +2493,7 @@ int swp_node_set_csi(swp_engine* e, uint32_t node, const swp_csi* infos, uint32_
 }
 
 int swp_volume_upsert(swp_engine* e, uint32_t volume, const swp_volume* v, const uint32_t* topo_off, const swp_seg* segs) {
+    if (e && e->set) return ss::volume_upsert(e, volume, v, topo_off, segs);
     if (!e || !v || (v->n_topologies && (!topo_off || !segs))) return SWP_EINVAL;
     if (volume == 0 || volume >= e->spaces[SWP_SPACE_VOLUME].strs.size()) return e->fail(SWP_EINVAL, "volume id %u was never interned", volume);
     if (v->group >= e->spaces[SWP_SPACE_VOLUME_GROUP].strs.size()) return e->fail(SWP_EINVAL, "volume group id %u was never interned", v->group);
@@ -2427,9 +2514,12 @@ int swp_volume_upsert(swp_engine* e, uint32_t volume, const swp_volume* v, const
 }
 
 int swp_volume_set_usage(swp_engine* e, uint32_t volume, const swp_volume_usage* u) {
+    if (e && e->set) return ss::volume_set_usage(e, volume, u);
     if (!e || !u) return SWP_EINVAL;
     if (volume >= e->volumes.size() || !e->volumes[volume].present) return SWP_ENOTFOUND;
-    if (u->pin < SWP_PIN_MANY && u->pin >= e->nodes.size()) return e->fail(SWP_EINVAL, "volume %u: unknown node %u", volume, u->pin);
+    // (a pin with VOL_PIN_FOREIGN set names a node of ANOTHER shard of the set this engine belongs to: swp_shardset.hpp)
+    if (u->pin < VOL_PIN_FOREIGN && (u->pin >= e->nodes.size() || node_index_released(e, u->pin))) return e->fail(SWP_EINVAL, "volume %u: unknown node %u", volume, u->pin);
+    if (u->pin >= VOL_PIN_FOREIGN && u->pin < SWP_PIN_MANY && e->cfg.shard_count < 2) return e->fail(SWP_EINVAL, "volume %u: unknown node %u", volume, u->pin);
     e->volumes[volume].use = *u;
     e->volumes[volume].use.reserved = 0;
     e->vol_dyn_dirty = true;
@@ -2437,6 +2527,7 @@ int swp_volume_set_usage(swp_engine* e, uint32_t volume, const swp_volume_usage*
 }
 
 int swp_volume_get_usage(swp_engine* e, uint32_t volume, swp_volume_usage* out) {
+    if (e && e->set) return ss::volume_get_usage(e, volume, out);
     if (!e || !out) return SWP_EINVAL;
     if (volume >= e->volumes.size() || !e->volumes[volume].present) return SWP_ENOTFOUND;
     *out = e->volumes[volume].use;
@@ -2444,6 +2535,7 @@ int swp_volume_get_usage(swp_engine* e, uint32_t volume, swp_volume_usage* out) 
 }
 
 int swp_mount_set(swp_engine* e, const swp_mount* mounts, uint32_t n, uint32_t* id_out) {
+    if (e && e->set) return ss::mount_set(e, mounts, n, id_out);
     if (!e || !id_out || (!mounts && n)) return SWP_EINVAL;
     if (n == 0) { *id_out = 0; return SWP_OK; }
     if (n > SWP_MAX_MOUNTS) return e->fail(SWP_ERANGE, "a task has %u cluster mounts (the engine takes %d)", n, SWP_MAX_MOUNTS);
@@ -2465,6 +2557,7 @@ int swp_mount_set(swp_engine* e, const swp_mount* mounts, uint32_t n, uint32_t* 
 }
 
 int swp_choose_volumes(swp_engine* e, uint32_t mount_set, uint32_t node, uint32_t* out, uint32_t* n_out, uint32_t* failed_mount) {
+    if (e && e->set) return ss::choose_volumes(e, mount_set, node, out, n_out, failed_mount);
     if (!e || !out || !n_out) return SWP_EINVAL;
     if (mount_set == 0 || mount_set >= e->mount_sets.size()) return e->fail(SWP_EINVAL, "unknown mount set %u", mount_set);
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
@@ -2496,6 +2589,7 @@ int swp_choose_volumes(swp_engine* e, uint32_t mount_set, uint32_t node, uint32_
 }
 
 int swp_node_set_generic(swp_engine* e, uint32_t node, const swp_generic* counts, uint32_t n) {
+    if (e && e->set) return ss::node_set_generic(e, node, counts, n);
     if (!e || (!counts && n)) return SWP_EINVAL;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     std::vector<std::pair<uint32_t, int64_t>> v;
@@ -2516,6 +2610,7 @@ int swp_node_set_generic(swp_engine* e, uint32_t node, const swp_generic* counts
 }
 
 int swp_node_get_generic(swp_engine* e, uint32_t node, uint32_t kind, int64_t* count_out) {
+    if (e && e->set) return ss::node_get_generic(e, node, kind, count_out);
     if (!e || !count_out) return SWP_EINVAL;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     *count_out = 0;
@@ -2540,6 +2635,7 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
                                 uint32_t* out_fail_hist, uint32_t* out_att) {
     if (!e || (!groups && n_groups) || (!sizes && n_groups)) return SWP_EINVAL;
     if (n_groups == 0) return SWP_OK;
+    if (e->set) return ss::schedule_groups(e, groups, sizes, n_groups, out_node, out_fail_hist, out_att);
     (void)hipSetDevice(e->device);
     uint64_t total = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {
@@ -2794,6 +2890,7 @@ static int download_hist(swp_engine* e, swp_batch* b, uint32_t* out_fail_hist) {
 }
 
 int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_tasks, swp_batch** out) {
+    if (e && e->set) return ss::batch_prepare(e, tasks, n_tasks, nullptr, 0, false, out);
     if (!e || !out || (!tasks && n_tasks)) return SWP_EINVAL;
     *out = nullptr;
     (void)hipSetDevice(e->device);
@@ -2817,6 +2914,7 @@ int swp_batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n_task
 }
 
 int swp_batch_prepare_templates(swp_engine* e, const swp_task_desc* templates, uint32_t n_templates, const uint32_t* template_of_task, uint32_t n_tasks, swp_batch** out) {
+    if (e && e->set) return ss::batch_prepare(e, templates, n_tasks, template_of_task, n_templates, true, out);
     if (!e || !out || (!templates && n_templates) || (!template_of_task && n_tasks) || (n_tasks && !n_templates)) return SWP_EINVAL;
     *out = nullptr;
     (void)hipSetDevice(e->device);
@@ -2832,6 +2930,7 @@ int swp_batch_prepare_templates(swp_engine* e, const swp_task_desc* templates, u
 }
 
 int swp_batch_run(swp_engine* e, swp_batch* b) {
+    if (e && e->set) return ss::batch_run(e, b);
     if (!e || !b) return SWP_EINVAL;
     (void)hipSetDevice(e->device);
     return batch_run(e, b);
@@ -2852,6 +2951,7 @@ static int download_volumes(swp_engine* e, swp_batch* b, bool fold) {
 }
 
 int swp_batch_attachments(swp_engine* e, swp_batch* b, const uint32_t* tasks, uint32_t n, uint32_t* out) {
+    if (e && e->set) return ss::batch_attachments(e, b, tasks, n, out);
     if (!e || !b || (!tasks && n) || (!out && n)) return SWP_EINVAL;
     for (uint32_t i = 0; i < n; ++i) {
         if (tasks[i] >= b->T) return e->fail(SWP_EINVAL, "task %u is not of this batch", tasks[i]);
@@ -2863,6 +2963,7 @@ int swp_batch_attachments(swp_engine* e, swp_batch* b, const uint32_t* tasks, ui
 }
 
 int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* out_fail_hist) {
+    if (e && e->set) return ss::batch_collect(e, b, out_node, out_fail_hist, true);
     if (!e || !b || (!out_node && b->T)) return SWP_EINVAL;
     if (!b->ran) return e->fail(SWP_EINVAL, "swp_batch_fetch before swp_batch_run");
     (void)hipSetDevice(e->device);
@@ -2903,6 +3004,7 @@ int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* ou
 }
 
 int swp_batch_results(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* out_fail_hist) {
+    if (e && e->set) return ss::batch_collect(e, b, out_node, out_fail_hist, false);
     if (!e || !b || (!out_node && b->T)) return SWP_EINVAL;
     if (!b->ran) return e->fail(SWP_EINVAL, "swp_batch_results before swp_batch_run");
     (void)hipSetDevice(e->device);
@@ -2918,6 +3020,7 @@ int swp_batch_results(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* 
 }
 
 void swp_batch_free(swp_engine* e, swp_batch* b) {
+    if ((e && e->set) || (b && b->is_set)) { ss::batch_free(e, b); return; }
     if (e) {
         (void)hipSetDevice(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -2928,6 +3031,7 @@ void swp_batch_free(swp_engine* e, swp_batch* b) {
 // ------------------------------------------------------------------------------------------------------------------
 // node-range shards (include/swp.h): propose / merge / commit over a block of tasks
 int swp_shard_begin(swp_engine* e, swp_batch* b) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set is not a shard: swp_shard_* take the engines of the ranges");
     if (!e || !b) return SWP_EINVAL;
     (void)hipSetDevice(e->device);
     if (e->n_nodes != b->n_nodes_prepared)
@@ -2947,6 +3051,7 @@ int swp_shard_begin(swp_engine* e, swp_batch* b) {
 }
 
 int swp_shard_propose(swp_engine* e, swp_batch* b, uint32_t j0, uint32_t count, swp_proposal* out) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set is not a shard: swp_shard_* take the engines of the ranges");
     if (!e || !b || (!out && count)) return SWP_EINVAL;
     if (!b->shard_open) return e->fail(SWP_EINVAL, "swp_shard_propose before swp_shard_begin");
     if (j0 > b->T || count > b->T - j0) return e->fail(SWP_ERANGE, "tasks [%u, %u) are outside the batch of %u", j0, j0 + count, b->T);
@@ -3073,6 +3178,7 @@ int swp_shard_merge(const swp_proposal* const* proposals, const uint32_t* shard_
 }
 
 int swp_shard_commit(swp_engine* e, swp_batch* b, uint32_t j0, const swp_shard_pick* picks, uint32_t accepted) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set is not a shard: swp_shard_* take the engines of the ranges");
     if (!e || !b || (!picks && accepted)) return SWP_EINVAL;
     if (!b->shard_open) return e->fail(SWP_EINVAL, "swp_shard_commit before swp_shard_begin");
     if (j0 > b->T || accepted > b->T - j0) return e->fail(SWP_ERANGE, "tasks [%u, %u) are outside the batch of %u", j0, j0 + accepted, b->T);
@@ -3140,6 +3246,7 @@ int swp_shard_commit(swp_engine* e, swp_batch* b, uint32_t j0, const swp_shard_p
 }
 
 int swp_shard_end(swp_engine* e, swp_batch* b, int32_t* out_node_local, uint32_t* out_fail_hist) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set is not a shard: swp_shard_* take the engines of the ranges");
     if (!e || !b || (!out_node_local && b->T)) return SWP_EINVAL;
     if (!b->shard_open) return e->fail(SWP_EINVAL, "swp_shard_end before swp_shard_begin");
     (void)hipSetDevice(e->device);
@@ -3173,6 +3280,8 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     const auto t_begin = std::chrono::steady_clock::now();
     if (!engines || !batches || G == 0 || !engines[0] || !batches[0]) return SWP_EINVAL;
     swp_engine* e0 = engines[0];
+    for (uint32_t g = 0; g < G; ++g)
+        if (engines[g] && engines[g]->set) return e0->fail(SWP_EINVAL, "shard %u is a shard set: swp_shard_run takes the engines of the ranges", g);
     if (G > R7_MAXS) return e0->fail(SWP_ERANGE, "%u shards: the device-side rounds take at most %d", G, R7_MAXS);
     const uint32_t T = batches[0]->T;
     if ((!out_shard || !out_node) && T) return SWP_EINVAL;
@@ -3441,6 +3550,7 @@ Rccl* rccl() {
 }  // namespace
 
 int swp_rccl_finalize(swp_engine* e) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set lives in one process: it has no RCCL communicator");
     if (!e) return SWP_EINVAL;
     Rccl* r = rccl();
     if (r && e->rccl_comm) {
@@ -3454,11 +3564,13 @@ int swp_rccl_finalize(swp_engine* e) {
 }
 
 int swp_rccl_available(swp_engine* e) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set lives in one process: it has no RCCL communicator");
     if (!e) return SWP_EINVAL;
     return rccl() ? SWP_OK : e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy)");
 }
 
 int swp_rccl_unique_id(swp_engine* e, uint8_t* id_out) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set lives in one process: it has no RCCL communicator");
     if (!e || !id_out) return SWP_EINVAL;
     Rccl* r = rccl();
     if (!r) return e->fail(SWP_EUNSUPPORTED, "librccl.so cannot be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy)");
@@ -3468,6 +3580,7 @@ int swp_rccl_unique_id(swp_engine* e, uint8_t* id_out) {
 }
 
 int swp_rccl_init(swp_engine* e, const uint8_t* id, uint32_t rank, uint32_t n_ranks) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set lives in one process: it has no RCCL communicator");
     if (!e || !id || n_ranks == 0 || rank >= n_ranks) return SWP_EINVAL;
     if (n_ranks > R7_MAXS) return e->fail(SWP_ERANGE, "%u ranks: the device-side rounds take at most %d", n_ranks, R7_MAXS);
     Rccl* r = rccl();
@@ -3519,6 +3632,7 @@ int swp_shard_verdict(const uint32_t* words, uint32_t n_ranks, uint32_t* who_out
 }
 
 int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes, uint32_t flags, int32_t* out_node_local, uint32_t* out_fail_hist) {
+    if (e && e->set) return e->fail(SWP_EINVAL, "a shard set is not a rank: swp_shard_run_rank takes the engine of ONE range");
     if (!e || !b || !shard_nodes || (!out_node_local && b->T)) return SWP_EINVAL;
     if (!e->rccl_comm) return e->fail(SWP_EINVAL, "swp_shard_run_rank before swp_rccl_init");
     Rccl* r = rccl();
@@ -3662,6 +3776,7 @@ int swp_schedule_batch(swp_engine* e, const swp_task_desc* tasks, uint32_t n_tas
 }
 
 int swp_state_save(swp_engine* e) {
+    if (e && e->set) return ss::state_save(e);
     if (!e) return SWP_EINVAL;
     (void)hipSetDevice(e->device);
     int rc = flush_nodes(e);
@@ -3687,6 +3802,7 @@ int swp_state_save(swp_engine* e) {
 }
 
 int swp_state_restore(swp_engine* e) {
+    if (e && e->set) return ss::state_restore(e);
     if (!e) return SWP_EINVAL;
     if (!e->saved.valid) return e->fail(SWP_EINVAL, "swp_state_restore without swp_state_save");
     (void)hipSetDevice(e->device);
@@ -3708,6 +3824,7 @@ int swp_state_restore(swp_engine* e) {
 }
 
 int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add_or_remove) {
+    if (e && e->set) return ss::commit(e, p, n, add_or_remove);
     if (!e || (!p && n)) return SWP_EINVAL;
     if (n == 0) return SWP_OK;
     (void)hipSetDevice(e->device);
@@ -3736,6 +3853,7 @@ int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add_or_rem
 }
 
 int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int32_t* first_fail) {
+    if (e && e->set) return ss::check_node(e, task, node, first_fail);
     if (!e || !task || !first_fail) return SWP_EINVAL;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     (void)hipSetDevice(e->device);
@@ -3803,6 +3921,7 @@ int swp_check_node(swp_engine* e, const swp_task_desc* task, uint32_t node, int3
 
 int swp_enforce(swp_engine* e, const swp_enforce_node* nodes, uint32_t n_nodes, const swp_enforce_task* tasks, uint32_t n_tasks,
                 uint8_t* out_reject) {
+    if (e && e->set) return ss::enforce(e, nodes, n_nodes, tasks, n_tasks, out_reject);
     if (!e || (!nodes && n_nodes) || (!tasks && n_tasks) || (!out_reject && n_tasks)) return SWP_EINVAL;
     if (n_tasks == 0 || n_nodes == 0) {
         if (n_tasks) std::memset(out_reject, 0, n_tasks);
@@ -3854,6 +3973,7 @@ int swp_enforce(swp_engine* e, const swp_enforce_node* nodes, uint32_t n_nodes, 
 }
 
 int swp_node_matches(swp_engine* e, const uint32_t* constraint_sets, uint32_t n_sets, uint64_t* out_bitmaps, uint32_t n_words) {
+    if (e && e->set) return ss::node_matches(e, constraint_sets, n_sets, out_bitmaps, n_words);
     if (!e || (!constraint_sets && n_sets) || (!out_bitmaps && n_sets)) return SWP_EINVAL;
     if (n_sets == 0) return SWP_OK;
     (void)hipSetDevice(e->device);
@@ -3889,6 +4009,7 @@ int swp_node_matches(swp_engine* e, const uint32_t* constraint_sets, uint32_t n_
 }
 
 int swp_stats(swp_engine* e, swp_stats_t* out) {
+    if (e && e->set) return ss::stats(e, out);
     if (!e || !out) return SWP_EINVAL;
     e->stats.n_nodes = e->n_present;
     e->stats.n_words = n_words_of(e->n_nodes);
@@ -3896,4 +4017,10 @@ int swp_stats(swp_engine* e, swp_stats_t* out) {
     return SWP_OK;
 }
 
+int swp_shardset_create(const swp_config* cfg, const int32_t* devices, uint32_t n_shards, uint32_t nodes_per_shard, swp_engine** out) {
+    return ss::create(cfg, devices, n_shards, nodes_per_shard, out);
+}
+
 }  // extern "C"
+
+#include "swp_shardset.hpp"

@@ -22,6 +22,7 @@ namespace swpdev {
 #define VOL_SHARING_SHIFT 2        // sharing: 0 none, 1 read only, 2 one writer, 3 all
 #define VOL_PIN_NONE 0xFFFFFFFFu
 #define VOL_PIN_MANY 0xFFFFFFFEu
+#define VOL_PIN_FOREIGN 0x80000000u   // | shard << 26 | local index: the one node all usages share belongs to ANOTHER shard of the set (no local node equals it)
 #define VOL_NONE 0xFFFFFFFFu
 #define VOL_MAX_MOUNTS 8
 

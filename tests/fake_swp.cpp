@@ -219,6 +219,7 @@ int swp_create(const swp_config*, swp_engine** out) {
     return SWP_OK;
 }
 void swp_destroy(swp_engine* e) { delete e; }
+int swp_shardset_create(const swp_config*, const int32_t*, uint32_t, uint32_t, swp_engine** out) { if (out) *out = nullptr; return SWP_EUNSUPPORTED; }   // (the double models ONE engine)
 int swp_reset(swp_engine* e, uint32_t) {
     e->nodes.clear();
     e->present_dirty = true;
@@ -254,6 +255,7 @@ int swp_intern_lookup(swp_engine* e, int space, uint32_t id, char* out, size_t c
     return (int)s.size();
 }
 int swp_node_upsert(swp_engine* e, const swp_node_row* row, const swp_kv* nl, uint32_t n_nl, const swp_kv* el, uint32_t n_el, const uint32_t* pl, uint32_t n_pl) {
+    if (row->node >= e->names[SWP_SPACE_NODE_ID].size() || e->free_nodes.count(row->node)) return SWP_EINVAL;   // never interned, or released by swp_node_remove (the engine's rule)
     if (row->node >= e->nodes.size()) e->nodes.resize(row->node + 1);
     FakeNode& nd = e->nodes[row->node];
     nd.present = true;
