@@ -256,7 +256,9 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
             bt.free()
             td = time.perf_counter()
             st = eng.stats()
-            state["rounds_total"] += st["resolve_launches"] if st["last_resolver"] == 7 else 0
+            if st["last_resolver"] == 7:   # (the counter is cumulative: the rounds of THIS batch)
+                state["rounds_total"] += st["resolve_launches"] - state.get("launches_seen", 0)
+            state["launches_seen"] = st["resolve_launches"]
             if timed is not None:
                 timed["swp_batch_prepare"] += tb - ta
                 timed["swp_batch_run"] += tc - tb

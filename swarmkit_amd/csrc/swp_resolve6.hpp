@@ -142,7 +142,14 @@ struct R6Args {
     u64* cmask;              // [n_words] the nodes of the compact index
     u32* crank;              // [n_words] compact position of the word's first such node
     u32* cidx;               // [r6_compact_cap(n_words)] node of a compact position
+    // node-range shards (swp_resolve7.hpp): where this shard publishes the volumes of a task with cluster mounts it placed ([2] slots, by
+    // round parity, right behind its proposals — they travel with them); nullptr: no volumes in the batch
+    struct R7Trail* trail_out;
 };
+struct R7Args;   // swp_resolve7.hpp: what a shard's commit kernel knows of the other shards
+#define R7M_EXC 0x100u   // H_meta of a folded record: list length | the task has an exception-list candidate on some shard | it does not count on its node | it has cluster mounts
+#define R7M_UNC 0x200u
+#define R7M_CSI 0x400u
 
 #define R6_UNROLL 4              // 64-word chunks a propose wave has in flight together ...
 #define R6_SMALL_WORDS 512u      // ... on node sets beyond this many words (32 768 nodes); up to there a wave has ONE chunk: a quarter of the registers, so that
@@ -163,6 +170,14 @@ inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr
 }
 
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
+// the node-range shards' side of the commit kernel (defined in swp_resolve7.hpp; only its R7 instances use them)
+WV_DEV u32 r7_tk_words(const R7Args* m);
+WV_DEV void r7_fold_into(const R7Args* m, u32 i, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh);
+WV_DEV u32 r7_addr(const R7Args* m, u32 shard, u32 node);
+WV_DEV u32 r7_local(const R7Args* m, u32 addr, u32 my, bool* here);
+WV_DEV u32 r7_take_trailers(const R6Args& a, const R7Args* m, u32 my, u32 round);
+WV_DEV void r7_leave_trailer(const R6Args& a, u32 my, u32 round, u32 set, u32 node, const u32* att, u32 n);
+
 WV_DEV u64 r6_wave_min64(u64 v) {
     const u32 hi = (u32)(v >> 32), lo = (u32)v;
     const u32 mh = wv::min_u32(hi);
@@ -673,13 +688,20 @@ WV_DEV u32 r6_first_above(const i64* thr, u32 n, i64 q) {
 // ---- commit: match the block in task order (wave 0), then apply the accepted picks (all threads) ---------------------------
 // (CSI: the instance for batches with cluster mounts — choosing volumes indexes a small array dynamically, which costs the kernel a scratch
 // segment; the ordinary instances have none)
-template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
+// (R7: the instance of the node-range shards, swp_resolve7.hpp — the same kernel on every shard: a thread FOLDS the proposals all shards
+// made for its task into one list in global node order while it stages it, wave 0 matches the block exactly as below — every shard
+// computes the same picks —, and a pick is applied by the shard that owns its node. m7 / my: the other shards' proposals, this shard's number.)
+template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6Args& a, const R7Args* m7 = nullptr, u32 my = 0) {
     const u32 tid = wv::tid(), lane = wv::lane();
     const u32 pos = a.blk->pos, end = a.blk->end;
     if (pos >= end || a.blk->error != ERR_NONE) return;   // a level beyond the planes: the proposals of this round were not written
     const u32 n = min(a.block, end - pos), Wn = a.n_words, n_rr = a.n_dc + a.n_dm;
     // (with a compact index the positions' words come first, the node words behind them: addresses as the lists carry them)
-    const u32 VW = CPT ? (a.blk->csize + 63u) >> 6 : 0u, tkw = CPT ? r6_tk_words(Wn) : Wn;
+    // (R7: the TK row covers the padded half-word space of ALL shards)
+    const u32 VW = CPT ? (a.blk->csize + 63u) >> 6 : 0u;
+    u32 tkw = CPT ? r6_tk_words(Wn) : Wn;
+    if constexpr (R7) tkw = r7_tk_words(m7);
+    const u32 rnd = a.blk->rounds;   // (R7: the same on every shard — the parity of the trailer slots)
     u64* tk = wv::lds();                                         // [tkw] addresses taken by this block so far
     i64* thr = reinterpret_cast<i64*>(tk + tkw);                 // [n_rr] the demand-class thresholds
     u32* pk_node = reinterpret_cast<u32*>(thr + n_rr);           // [block] node, R6_NONE = no suitable node
@@ -690,8 +712,10 @@ template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
     u32* L_hb = sh + 32;                                         // [2 * R6_CAND][block] the block's lists, entry-major: lane i of the matcher reads
     u32* L_cur = L_hb + (size_t)2 * R6_CAND * a.block;           // ... entry k of task i at [k * block + i] (no bank conflicts); [block] a lower bound of every task's cursor: the entries in front of it are dead
     unsigned short* L_hw = reinterpret_cast<unsigned short*>(L_cur + a.block);   // [2 * R6_CAND][block] the half-word indices, 16 bits each (the engine refuses node sets beyond 2^21 nodes)
+    u32* H_level = reinterpret_cast<u32*>(L_hw + (size_t)2 * R6_CAND * a.block);   // R7 only: [block] the folded record's level ...
+    u32* H_meta = H_level + a.block;                                                // ... and its list length | R7M_* flags
     for (u32 j = tid; j < a.block; j += R6_COMMIT_THREADS) L_cur[j] = 0;
-    for (u32 w = tid; w < Wn + VW; w += R6_COMMIT_THREADS) tk[w] = 0;
+    for (u32 w = tid; w < (R7 ? tkw : Wn + VW); w += R6_COMMIT_THREADS) tk[w] = 0;
     for (u32 c = tid; c < n_rr; c += R6_COMMIT_THREADS) thr[c] = a.thr[c];
     if (tid < 16) staged[tid] = 0;
     // Wave v >= 1 applies the picks of the block's group v - 1 (tasks 64 (v - 1) ...) as soon as wave 0 has matched that group, while
@@ -702,12 +726,17 @@ template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
     RTask r{};
     if (mine < n) r = a.rt[pos + mine];
     if (tid == 0) { sh[3] = 0; sh[4] = 0; }
+    if constexpr (R7 && CSI) {
+        if (tid == 0) sh[12] = r7_take_trailers(a, m7, my, rnd);   // the volumes the other shards reserved in the round before: into this shard's table
+    }
     const bool prof = (a.dbg & 16u) != 0;
     const u64 t0 = prof ? wv::clock64() : 0;
     wv::barrier();
     // every thread stages the lists of its task (wave g: the block's group g): the matcher walks them with a cursor (an entry is looked
     // at once) instead of holding all of them in registers. No barrier: a group's flag is published when its lists are in LDS.
-    if (tid < n) {
+    if constexpr (R7) {
+        if (tid < n) r7_fold_into(m7, tid, a.block, L_hw, L_hb, H_level, H_meta, sh);
+    } else if (tid < n) {
         const R6Prop* q = a.prop + tid;
         for (int k = 0; k < 2 * R6_CAND; ++k) {
             L_hw[(size_t)k * a.block + tid] = (unsigned short)q->hw[k];
@@ -729,16 +758,25 @@ template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
             const R6Prop* q = a.prop + j;
             return Head{q->level, q->n_cand, q->exc_hi, q->exc_lo, q->exc_entry, q->flags};
         };
-        Head nxt = head_of(lane < n ? lane : 0);
+        // (R7: the folded heads are in LDS once the group is staged — read behind the wait below; only the block's first task may use its
+        // exception-list candidate, whose record its staging thread left in sh[8..10])
+        auto head7 = [&](u32 j) {
+            const u32 mt = H_meta[j];
+            return Head{H_level[j], mt & 0xFFu, (mt & R7M_EXC) ? 0ull : KEY_NONE, 0ull, 0u, ((mt & R7M_UNC) ? 1u : 0u) | ((mt & R7M_CSI) ? 2u : 0u)};
+        };
+        Head nxt{};
+        if constexpr (!R7) nxt = head_of(lane < n ? lane : 0);
+        if (R7 && CSI && sh[12]) csi_seen = true;   // a reservation arrived from another shard only now: the proposals of tasks with mounts were made without it
         for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
             const u32 i = g0 + lane, glim = min(64u, n - g0);
             const bool have = i < n;
             const u64 tg0 = prof ? wv::clock64() : 0;
             while (wv::lds_poll32(staged + (g0 >> 6)) == 0) wv::spin_pause();   // (long there, but for the first groups of a block)
             const u64 tga = prof ? wv::clock64() : 0;
-            const Head rec = nxt;
+            Head rec = nxt;
+            if constexpr (R7) rec = head7(have ? i : 0u);
             const Head* p = &rec;
-            if (g0 + 64 < n) nxt = head_of(i + 64 < n ? i + 64 : 0);
+            if (!R7 && g0 + 64 < n) nxt = head_of(i + 64 < n ? i + 64 : 0);
             const u32 level = have ? p->level : 0u;
             const u32 nent = (have && level != R6_NONE) ? (p->n_cand & 0x7FFFFFFFu) : 0u;
             const bool plain = nent != 0;
@@ -808,6 +846,10 @@ template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
                     pk_node[0] = (u32)p->exc_lo + 64u * VW;   // (an address, like the matcher's picks)
                     pk_idx[0] = nc;
                     pk_aux[0] = p->exc_entry;
+                    if constexpr (R7) {
+                        pk_node[0] = r7_addr(m7, sh[8], sh[9]);
+                        pk_aux[0] = sh[10];
+                    }
                 }
                 ++nc;
                 acc = 1;
@@ -906,7 +948,9 @@ template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
         if (g0 > 0 && mine < n) {
             // until the matcher reaches this wave's group: move every task's cursor over the entries that are dead by now (taken nodes
             // stay taken: what is dead against an older TK row is dead), so that the matcher seats the group in a step or two
-            const u32 lv = a.prop[mine].level, nent = lv != R6_NONE ? (a.prop[mine].n_cand & 0x7FFFFFFFu) : 0u;
+            u32 lv = 0, nent = 0;
+            if constexpr (R7) { lv = H_level[mine]; nent = lv != R6_NONE ? (H_meta[mine] & 0xFFu) : 0u; }
+            else { lv = a.prop[mine].level; nent = lv != R6_NONE ? (a.prop[mine].n_cand & 0x7FFFFFFFu) : 0u; }
             const u32* tk32 = reinterpret_cast<const u32*>(tk);
             u32 cur = 0;
             while (wv::lds_poll32(sh + 3) + 64u < g0 && wv::lds_poll32(sh + 4) == 0) {   // (stops a group early: the last value must be in LDS when it is read)
@@ -926,10 +970,14 @@ template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
         const u32 t = pos + mine, addr = pk_node[mine];
         u32 nd = addr;
         if (CPT) nd = addr == R6_NONE ? R6_NONE : addr < 64u * VW ? a.cidx[addr] : addr - 64u * VW;   // a compact position, or a node behind them
-        if (nd == R6_NONE) {
+        bool here = true;   // R7: the pick lies in this shard's range
+        if constexpr (R7) {
+            if (addr != R6_NONE) nd = r7_local(m7, addr, my, &here);
+        }
+        if (nd == R6_NONE) {   // (every shard records the unplaceable tasks: each explains them over its own nodes)
             a.inf_task[pk_idx[mine]] = t;
             a.inf_pos[pk_idx[mine]] = pk_aux[mine];
-        } else {
+        } else if (here) {
             const u32 w = nd >> 6, ci = pk_idx[mine], entry = pk_aux[mine];
             const u64 bit = 1ull << (nd & 63);
             // the node row, requested in one go. No two picks of one block share a node: plain read-modify-write of the row; bitmap
@@ -987,6 +1035,9 @@ template <bool CPT, bool CSI> WV_DEV void r6_commit_t(const R6Args& a) {
                     const u32 set = a.csi_set[ck], na = vol_choose(a.vol, set, nd, att, nullptr);
                     if (na) vol_reserve(a.vol, set, nd, att, na);
                     for (u32 q = 0; q < VOL_MAX_MOUNTS; ++q) a.att[(size_t)ck * VOL_MAX_MOUNTS + q] = att[q];
+                    if constexpr (R7) {
+                        if (na) r7_leave_trailer(a, my, rnd, set, nd, att, na);   // the other shards reserve the same volumes at the start of the next round
+                    }
                 }
             }
         }
