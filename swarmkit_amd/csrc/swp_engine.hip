@@ -1596,7 +1596,7 @@ int r6_args_for(swp_engine* e, swp_batch* b, uint32_t r6_block, bool r6_task_row
     HIPCHECK(e, b->d_rr6.reserve((size_t)std::max<uint32_t>(r6_nrr, 1) * Wn * 8));
     if (r6_task_rows) HIPCHECK(e, b->d_trows.reserve((size_t)r6_block * Wn * 8));
     HIPCHECK(e, b->d_blk6.reserve(sizeof(Blk6)));
-    HIPCHECK(e, b->d_prop.reserve((size_t)r6_block * sizeof(R6Prop)));
+    HIPCHECK(e, b->d_prop.reserve(r7_send_bytes(r6_block)));   // (the shard drivers send two trailer slots behind the block: swp_resolve7.hpp)
     if (Wn <= R6_COMPACT_MAX_WORDS) {   // the compact index of a round (k_r6_compact); run_blocks switches it on
         HIPCHECK(e, b->d_cmask.reserve((size_t)Wn * 8));
         HIPCHECK(e, b->d_crank.reserve((size_t)Wn * 4));
@@ -3288,7 +3288,6 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     for (uint32_t g = 0; g < G; ++g) {
         if (!engines[g] || !batches[g] || batches[g]->T != T) return e0->fail(SWP_EINVAL, "shard %u: every shard's batch must hold the same %u tasks", g, T);
         if (engines[g]->n_nodes != batches[g]->n_nodes_prepared) return e0->fail(SWP_EINVAL, "shard %u: the nodeSet grew since swp_batch_prepare", g);
-        if (!batches[g]->csi_set.empty()) return e0->fail(SWP_EUNSUPPORTED, "tasks with cluster mounts are not part of the shard protocols (a volume's use is cluster-wide state)");
         for (uint32_t h = 0; h < g; ++h)
             if (engines[h] == engines[g]) return e0->fail(SWP_EINVAL, "shards %u and %u name the same engine", h, g);
     }
@@ -3298,8 +3297,18 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     const char* env_dbg = getenv("SWP_DBG");
     const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
     const char* env_blk = getenv("SWP_R6_BLOCK");
-    const uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
     const size_t lds_budget = 160 * 1024 - 512;
+    {   // the commit kernel keeps the TK row of ALL shards' nodes next to the block's lists: large node sets get smaller blocks
+        uint32_t hw_all = 0;
+        bool tr = false;
+        for (uint32_t g = 0; g < G; ++g) {
+            hw_all += (engines[g]->n_nodes + 31) / 32;
+            tr = tr || !batches[g]->classes_ok || batches[g]->n_dc + batches[g]->n_dm > 128;
+        }
+        const uint32_t nrr = tr ? 0u : batches[0]->n_dc + batches[0]->n_dm;
+        while (block > 64 && r7_commit_lds_size(hw_all, block, nrr) > lds_budget) block = (block - 1u) / 64u * 64u;
+    }
     // one failure anywhere leaves every shard's device rows possibly half-updated: the host mirrors (untouched) are uploaded again
     auto fail_all = [&](int rc) {
         for (uint32_t g = 0; g < G; ++g) engines[g]->dev_dynamic_dirty = true;
@@ -3312,6 +3321,8 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     ma.block = block;
     ma.dbg = dbg_bits;
     uint32_t first = 0, hw = 0;
+    const bool csi = !batches[0]->csi_set.empty();   // (the task list is the same on every shard)
+    ma.use_trailers = csi ? 1u : 0u;
     const bool task_rows = [&] {
         const char* env_tr = getenv("SWP_R6_TASKROWS");
         if (env_tr) return atoi(env_tr) != 0;
@@ -3327,28 +3338,34 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         ma.first_node[g] = first;
         first += e->n_nodes;
         hw += (e->n_nodes + 31) / 32;
-        if (g > 0 && e->device != e0->device) {   // the leader reads this shard's proposals, this shard reads the leader's picks: peer memory
+        for (uint32_t h = 0; h < g; ++h) {   // every shard reads every other shard's proposals: peer memory between their devices
+            swp_engine* o = engines[h];
+            if (o->device == e->device) continue;
             int ok01 = 0, ok10 = 0;
-            (void)hipDeviceCanAccessPeer(&ok01, e0->device, e->device);
-            (void)hipDeviceCanAccessPeer(&ok10, e->device, e0->device);
-            if (!ok01 || !ok10) return e0->fail(SWP_EUNSUPPORTED, "devices %d and %d cannot access each other's memory", e0->device, e->device);
-            (void)hipSetDevice(e0->device);
+            (void)hipDeviceCanAccessPeer(&ok01, o->device, e->device);
+            (void)hipDeviceCanAccessPeer(&ok10, e->device, o->device);
+            if (!ok01 || !ok10) return e0->fail(SWP_EUNSUPPORTED, "devices %d and %d cannot access each other's memory", o->device, e->device);
+            (void)hipSetDevice(o->device);
             hipError_t pr = hipDeviceEnablePeerAccess(e->device, 0);
             if (pr != hipSuccess && pr != hipErrorPeerAccessAlreadyEnabled) return e0->fail(SWP_EHIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(pr));
             (void)hipSetDevice(e->device);
-            pr = hipDeviceEnablePeerAccess(e0->device, 0);
+            pr = hipDeviceEnablePeerAccess(o->device, 0);
             if (pr != hipSuccess && pr != hipErrorPeerAccessAlreadyEnabled) return e0->fail(SWP_EHIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(pr));
             (void)hipGetLastError();
         }
         if (e->n_nodes == 0) return e0->fail(SWP_EINVAL, "shard %u owns no node", g);
         const uint32_t Wn = n_words_of(e->n_nodes);
         const uint32_t nrr = task_rows ? 0u : b->n_dc + b->n_dm;
-        if (r6_propose_lds_size(Wn) > lds_budget)   // (the shards match with k_r7_match: no commit kernel)
+        if (r6_propose_lds_size(Wn) > lds_budget)
             return e0->fail(SWP_ERANGE, "shard %u: %u nodes exceed the block resolver's LDS", g, e->n_nodes);
         int rc = batch_begin(e, b);
         if (rc) return fail_all(rc);
         if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra[g]))) return fail_all(rc);
         ra[g].tmpl = nullptr;   // a range sees only its own part of a level: its lists start at the level's first candidate
+        R7Tail* tail = reinterpret_cast<R7Tail*>(ra[g].prop + block);   // behind the shard's proposals: the trailer slots
+        ma.tail[g] = tail;
+        HIPCHECK(e, hipMemsetAsync(tail, 0, sizeof(R7Tail), e->stream));
+        if (csi) ra[g].trail_out = tail->slot;
         Blk6 hb{};
         hb.pos = 0;
         hb.end = T;
@@ -3358,9 +3375,12 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         ma.prop[g] = ra[g].prop;
     }
     ma.hw_base[G] = ma.hw_total = hw;
-    if (r7_match_lds_size(hw) > lds_budget) return fail_all(e0->fail(SWP_ERANGE, "%u nodes over all shards exceed the matching wave's LDS", first));
+    const uint32_t nrr_all = task_rows ? 0u : batches[0]->n_dc + batches[0]->n_dm;
+    const size_t lds_commit = r7_commit_lds_size(hw, block, nrr_all);
+    if (hw > 0xFFFFu) return fail_all(e0->fail(SWP_ERANGE, "%u nodes over all shards: the commit kernel's half-word indices are 16 bits (2^21 nodes)", first));
+    if (lds_commit > lds_budget) return fail_all(e0->fail(SWP_ERANGE, "%u nodes over all shards with blocks of %u tasks exceed the commit kernel's LDS (SWP_R6_BLOCK)", first, block));
     // shards that live on one device are served by ONE propose and ONE apply launch per round, on the stream of the first of them
-    struct Group { uint32_t g0, count, max_words; int device; hipStream_t stream; DevBuf d_args; hipEvent_t ev_prop = nullptr; };
+    struct Group { uint32_t g0, count, max_words; int device; hipStream_t stream; DevBuf d_args, d_m; hipEvent_t ev_prop = nullptr, ev_commit = nullptr; };
     std::vector<Group> groups;
     for (uint32_t g = 0; g < G; ++g) {
         if (groups.empty() || groups.back().device != engines[g]->device) {
@@ -3375,21 +3395,11 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         groups.back().max_words = std::max(groups.back().max_words, n_words_of(engines[g]->n_nodes));
     }
     (void)hipSetDevice(e0->device);
-    DevBuf d_picks, d_head, d_merged;
-    HIPCHECK(e0, d_picks.reserve((size_t)block * sizeof(R7Pick)));
-    HIPCHECK(e0, d_head.reserve(sizeof(R7Head)));
-    HIPCHECK(e0, d_merged.reserve((size_t)block * sizeof(R6Prop)));
-    HIPCHECK(e0, hipMemsetAsync(d_head.p, 0, sizeof(R7Head), e0->stream));
-    ma.blk = ra[0].blk;
-    ma.ctl = ra[0].ctl;
-    ma.picks = d_picks.as<R7Pick>();
-    ma.head = d_head.as<R7Head>();
-    ma.merged = d_merged.as<R6Prop>();
-    hipEvent_t ev_match = nullptr;
     auto cleanup = [&] {
-        for (Group& gr : groups)
+        for (Group& gr : groups) {
             if (gr.ev_prop) (void)hipEventDestroy(gr.ev_prop);
-        if (ev_match) (void)hipEventDestroy(ev_match);
+            if (gr.ev_commit) (void)hipEventDestroy(gr.ev_commit);
+        }
     };
     auto die = [&](int rc) {
         for (uint32_t g = 0; g < G; ++g) {
@@ -3401,13 +3411,12 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     };
     for (Group& gr : groups) {
         (void)hipSetDevice(gr.device);
-        if (gr.d_args.reserve((size_t)gr.count * sizeof(R6Args)) != hipSuccess ||
+        if (gr.d_args.reserve((size_t)gr.count * sizeof(R6Args)) != hipSuccess || gr.d_m.reserve(sizeof(R7Args)) != hipSuccess ||
             hipMemcpyAsync(gr.d_args.p, &ra[gr.g0], (size_t)gr.count * sizeof(R6Args), hipMemcpyHostToDevice, gr.stream) != hipSuccess ||
-            hipEventCreateWithFlags(&gr.ev_prop, hipEventDisableTiming) != hipSuccess)
+            hipMemcpyAsync(gr.d_m.p, &ma, sizeof ma, hipMemcpyHostToDevice, gr.stream) != hipSuccess ||
+            hipEventCreateWithFlags(&gr.ev_prop, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&gr.ev_commit, hipEventDisableTiming) != hipSuccess)
             return die(e0->fail(SWP_EHIP, "setting up the shards of device %d: %s", gr.device, hipGetErrorString(hipGetLastError())));
     }
-    (void)hipSetDevice(e0->device);
-    if (hipEventCreateWithFlags(&ev_match, hipEventDisableTiming) != hipSuccess) return die(e0->fail(SWP_EHIP, "hipEventCreate"));
     // the per-engine streams have the batch set-up in flight: the group streams start behind it
     for (uint32_t g = 0; g < G; ++g) {
         (void)hipSetDevice(engines[g]->device);
@@ -3419,25 +3428,31 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     uint64_t rounds = 0;
     Blk6 hb{};
     while (pos < T) {
+        // One round = two launches per device: every shard proposes over its nodes; once the proposals of ALL devices are there (events
+        // between the devices' streams; shards of one device share a stream) every shard folds + matches the block itself and applies the
+        // picks of its own range. A device's next propose overwrites what the other devices' commit kernels read: it waits for them.
+        const bool multi = groups.size() > 1;
         for (uint32_t r = 0; r < chunk; ++r) {
-            for (Group& gr : groups) {
-                (void)hipSetDevice(gr.device);
-                hipError_t x = launch_r7_propose(gr.d_args.as<R6Args>(), gr.count, block, gr.max_words, task_rows, gr.stream, gr.device);
-                if (x == hipSuccess && groups.size() > 1) x = hipEventRecord(gr.ev_prop, gr.stream);
-                if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "propose on device %d: %s", gr.device, hipGetErrorString(x)));
-            }
-            (void)hipSetDevice(e0->device);
-            for (size_t q = 1; q < groups.size(); ++q)
-                if (hipStreamWaitEvent(groups[0].stream, groups[q].ev_prop, 0) != hipSuccess) return die(e0->fail(SWP_EHIP, "hipStreamWaitEvent"));
-            hipError_t x = launch_r7_match(ma, groups[0].stream, e0->device);
-            if (x == hipSuccess && groups.size() > 1) x = hipEventRecord(ev_match, groups[0].stream);
-            if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "k_r7_match: %s", hipGetErrorString(x)));
             for (size_t q = 0; q < groups.size(); ++q) {
                 Group& gr = groups[q];
                 (void)hipSetDevice(gr.device);
-                if (q > 0 && hipStreamWaitEvent(gr.stream, ev_match, 0) != hipSuccess) return die(e0->fail(SWP_EHIP, "hipStreamWaitEvent"));
-                x = launch_r7_apply(gr.d_args.as<R6Args>(), gr.count, ma.picks, ma.head, gr.g0, gr.stream);
-                if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "apply on device %d: %s", gr.device, hipGetErrorString(x)));
+                hipError_t x = hipSuccess;
+                if (multi && rounds + r > 0)
+                    for (size_t o = 0; o < groups.size() && x == hipSuccess; ++o)
+                        if (o != q) x = hipStreamWaitEvent(gr.stream, groups[o].ev_commit, 0);
+                if (x == hipSuccess) x = launch_r7_propose(gr.d_args.as<R6Args>(), gr.count, block, gr.max_words, task_rows, csi, gr.stream, gr.device);
+                if (x == hipSuccess && multi) x = hipEventRecord(gr.ev_prop, gr.stream);
+                if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "propose on device %d: %s", gr.device, hipGetErrorString(x)));
+            }
+            for (size_t q = 0; q < groups.size(); ++q) {
+                Group& gr = groups[q];
+                (void)hipSetDevice(gr.device);
+                hipError_t x = hipSuccess;
+                for (size_t o = 0; multi && o < groups.size() && x == hipSuccess; ++o)
+                    if (o != q) x = hipStreamWaitEvent(gr.stream, groups[o].ev_prop, 0);
+                if (x == hipSuccess) x = launch_r7_commit(gr.d_args.as<R6Args>(), gr.count, gr.d_m.as<R7Args>(), lds_commit, csi, gr.g0, gr.stream, gr.device);
+                if (x == hipSuccess && multi) x = hipEventRecord(gr.ev_commit, gr.stream);
+                if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "commit on device %d: %s", gr.device, hipGetErrorString(x)));
             }
         }
         rounds += chunk;
@@ -3478,6 +3493,9 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         if (out_fail_hist && ctl.ninf && hipMemcpyAsync(hist.data(), b->d_hist.p, (size_t)T * 8 * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
             return die(e0->fail(SWP_EHIP, "histograms of shard %u", g));
         if (hipStreamSynchronize(e->stream) != hipSuccess) return die(e0->fail(SWP_EHIP, "shard %u: %s", g, hipGetErrorString(hipGetLastError())));
+        if (csi && !(flags & SWP_SHARD_NO_FOLD)) {   // (with SWP_SHARD_NO_FOLD the caller fetches them: the shard set does)
+            if (int rcv = download_volumes(e, b, true)) return die(rcv);
+        }
         uint64_t placed = 0;
         for (uint32_t i = 0; i < T; ++i) {
             const int32_t nloc = local[i];
@@ -3499,9 +3517,9 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         e->stats.resolve_launches += (uint32_t)rounds;
     }
     if (dbg_bits & 16) {
-        R7Head hh{};
+        Blk6 hh{};
         (void)hipSetDevice(e0->device);
-        (void)hipMemcpy(&hh, d_head.p, sizeof hh, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&hh, batches[0]->d_blk6.p, sizeof hh, hipMemcpyDeviceToHost);
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[swp] sharded rounds over %u engines: %u rounds of %u (%.1f decided each) | cut by an exhausted list %u, an exception-list task %u, an uncounted task %u | set-up %.2f ms, rounds %.2f ms, explain + results %.2f ms\n", G,
                 hh.rounds, block, (double)T / std::max<uint32_t>(hh.rounds, 1), hh.cut_exhausted, hh.cut_exception, hh.cut_uncounted, ms(t_begin, t_rounds0), ms(t_rounds0, t_rounds1),
@@ -3642,25 +3660,32 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
     const char* env_dbg = getenv("SWP_DBG");
     const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
     const char* env_blk = getenv("SWP_R6_BLOCK");
-    const uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
     const size_t lds_budget = 160 * 1024 - 512;
     // every rank must choose the same row mode: task rows whenever any rank might (the choice only depends on the task list, which is shared)
     const char* env_tr = getenv("SWP_R6_TASKROWS");
     const bool task_rows = env_tr ? atoi(env_tr) != 0 : (!b->classes_ok || b->n_dc + b->n_dm > 128);
+    {   // (and the same block: it follows from shard_nodes and the task list, which every rank holds)
+        uint32_t hw_all = 0;
+        for (uint32_t g = 0; g < G; ++g) hw_all += (shard_nodes[g] + 31) / 32;
+        while (block > 64 && r7_commit_lds_size(hw_all, block, task_rows ? 0u : b->n_dc + b->n_dm) > lds_budget) block = (block - 1u) / 64u * 64u;
+    }
     const uint32_t Wn = n_words_of(e->n_nodes);
     auto bad = [&](int rc) { e->dev_dynamic_dirty = true; (void)hipStreamSynchronize(st); return rc; };
     // ---- everything that can go wrong on THIS rank before the first round is checked here, and the outcome is exchanged: either all
     // ranks start the rounds or none does (a lone early return would leave the others inside ncclAllGather)
     R6Args ra{};
     R7Args ma{};
-    DevBuf d_all, d_picks, d_head, d_merged, d_args, d_stat;
+    DevBuf d_all, d_m, d_args, d_stat;
+    const bool csi = !b->csi_set.empty();
+    const size_t send = r7_send_bytes(block);   // what a rank contributes to a round's exchange: its proposals + the tail (swp_resolve7.hpp)
+    size_t lds_commit = 0;
     Blk6 hb{};
     int pre = SWP_OK;
     if (e->n_nodes != b->n_nodes_prepared) pre = e->fail(SWP_EINVAL, "the nodeSet grew since swp_batch_prepare");
     else if (shard_nodes[me] != e->n_nodes) pre = e->fail(SWP_EINVAL, "rank %u holds %u node slots, shard_nodes says %u", me, e->n_nodes, shard_nodes[me]);
     else if (e->n_nodes == 0) pre = e->fail(SWP_EINVAL, "rank %u owns no node", me);
     else if (r6_propose_lds_size(Wn) > lds_budget) pre = e->fail(SWP_ERANGE, "%u nodes exceed the block resolver's LDS", e->n_nodes);
-    else if (!b->csi_set.empty()) pre = e->fail(SWP_EUNSUPPORTED, "tasks with cluster mounts are not part of the shard protocols (a volume's use is cluster-wide state)");
     if (out_fail_hist) std::memset(out_fail_hist, 0, (size_t)T * SWP_NFILTERS * 4);
     for (uint32_t i = 0; i < T; ++i) out_node_local[i] = -1;
     auto setup = [&]() -> int {
@@ -3668,35 +3693,36 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
         if (rc) return rc;
         if ((rc = r6_args_for(e, b, block, task_rows, dbg_bits, &ra))) return rc;
         ra.tmpl = nullptr;   // (as in swp_shard_run)
+        R7Tail* tail = reinterpret_cast<R7Tail*>(ra.prop + block);   // behind this rank's proposals: it travels with them
+        if (csi) ra.trail_out = tail->slot;
+        HIPCHECK(e, hipMemsetAsync(tail, 0, sizeof(R7Tail), st));
         hb.end = T;
         HIPCHECK(e, hipMemcpyAsync(b->d_blk6.p, &hb, sizeof hb, hipMemcpyHostToDevice, st));
         hipError_t x = launch_r6_build(ra, st);
         if (x != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(x));
-        HIPCHECK(e, d_all.reserve((size_t)G * block * sizeof(R6Prop)));
-        HIPCHECK(e, d_picks.reserve((size_t)block * sizeof(R7Pick)));
-        HIPCHECK(e, d_head.reserve(sizeof(R7Head)));
-        HIPCHECK(e, d_merged.reserve((size_t)block * sizeof(R6Prop)));
+        HIPCHECK(e, d_all.reserve((size_t)G * send));
+        HIPCHECK(e, d_m.reserve(sizeof(R7Args)));
         HIPCHECK(e, d_args.reserve(sizeof(R6Args)));
-        HIPCHECK(e, hipMemsetAsync(d_head.p, 0, sizeof(R7Head), st));
         HIPCHECK(e, hipMemcpyAsync(d_args.p, &ra, sizeof ra, hipMemcpyHostToDevice, st));
         ma.n_shards = G;
         ma.block = block;
         ma.dbg = dbg_bits;
+        ma.use_trailers = csi ? 1u : 0u;
+        ma.check_dead = 1u;
         uint32_t first = 0, hw = 0;
         for (uint32_t g = 0; g < G; ++g) {
             ma.hw_base[g] = hw;
             ma.first_node[g] = first;
             first += shard_nodes[g];
             hw += (shard_nodes[g] + 31) / 32;
-            ma.prop[g] = d_all.as<R6Prop>() + (size_t)g * block;
+            ma.prop[g] = reinterpret_cast<const R6Prop*>(static_cast<const char*>(d_all.p) + (size_t)g * send);   // the layout ncclAllGather leaves
+            ma.tail[g] = reinterpret_cast<const R7Tail*>(ma.prop[g] + block);
         }
         ma.hw_base[G] = ma.hw_total = hw;
-        if (r7_match_lds_size(hw) > lds_budget) return e->fail(SWP_ERANGE, "%u nodes over all ranks exceed the matching wave's LDS", first);
-        ma.blk = ra.blk;
-        ma.ctl = ra.ctl;
-        ma.picks = d_picks.as<R7Pick>();
-        ma.head = d_head.as<R7Head>();
-        ma.merged = d_merged.as<R6Prop>();
+        lds_commit = r7_commit_lds_size(hw, block, task_rows ? 0u : b->n_dc + b->n_dm);
+        if (hw > 0xFFFFu) return e->fail(SWP_ERANGE, "%u nodes over all ranks: the commit kernel's half-word indices are 16 bits (2^21 nodes)", first);
+        if (lds_commit > lds_budget) return e->fail(SWP_ERANGE, "%u nodes over all ranks with blocks of %u tasks exceed the commit kernel's LDS (SWP_R6_BLOCK)", first, block);
+        HIPCHECK(e, hipMemcpyAsync(d_m.p, &ma, sizeof ma, hipMemcpyHostToDevice, st));
         // the build kernel's verdict (the level range of THIS rank's nodes) is part of what is exchanged
         HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
         HIPCHECK(e, hipStreamSynchronize(st));
@@ -3715,22 +3741,32 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
     if (T == 0) return SWP_OK;
     uint32_t pos = 0, chunk = std::min<uint32_t>(16u, (T + 255u) / 256u + 1u);
     uint64_t rounds = 0;
-    hipError_t x = hipSuccess;
+    // Inside the rounds NOTHING returns on its own: a rank whose launch / copy failed remembers the first error, marks its tail's dead
+    // word, and keeps issuing the chunk's collectives (its peers are enqueued in them) — their commit kernels see the word and stand
+    // still; the error travels in the status exchange behind the chunk and every rank leaves there.
+    int local_rc = SWP_OK;
+    auto note = [&](int code) { if (local_rc == SWP_OK) local_rc = code; };
+    R7Tail* my_tail = reinterpret_cast<R7Tail*>(ra.prop + block);
     while (pos < T) {   // (every rank computes the same positions from the same gathered words, hence the same chunks: the collectives line up)
         for (uint32_t q = 0; q < chunk; ++q) {
-            x = launch_r7_propose(d_args.as<R6Args>(), 1, block, Wn, task_rows, st, e->device);
-            if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "propose: %s", hipGetErrorString(x)));
-            const int nr = r->AllGather(ra.prop, d_all.p, (size_t)block * sizeof(R6Prop), /* ncclInt8 */ 0, e->rccl_comm, st);
-            if (nr != 0) return bad(e->fail(SWP_EHIP, "ncclAllGather: %s", r->GetErrorString ? r->GetErrorString(nr) : "error"));
-            x = launch_r7_match(ma, st, e->device);
-            if (x == hipSuccess) x = launch_r7_apply(d_args.as<R6Args>(), 1, ma.picks, ma.head, me, st);
-            if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "match / apply: %s", hipGetErrorString(x)));
+            if (local_rc == SWP_OK) {
+                const hipError_t x = launch_r7_propose(d_args.as<R6Args>(), 1, block, Wn, task_rows, csi, st, e->device);
+                if (x != hipSuccess) note(e->fail(SWP_EHIP, "propose: %s", hipGetErrorString(x)));
+            }
+            if (local_rc != SWP_OK) (void)hipMemsetAsync(&my_tail->dead, 1, sizeof(uint32_t), st);
+            const int nr = r->AllGather(ra.prop, d_all.p, send, /* ncclInt8 */ 0, e->rccl_comm, st);
+            if (nr != 0) note(e->fail(SWP_EHIP, "ncclAllGather: %s", r->GetErrorString ? r->GetErrorString(nr) : "error"));
+            if (local_rc == SWP_OK) {
+                const hipError_t x = launch_r7_commit(d_args.as<R6Args>(), 1, d_m.as<R7Args>(), lds_commit, csi, me, st, e->device);
+                if (x != hipSuccess) note(e->fail(SWP_EHIP, "commit: %s", hipGetErrorString(x)));
+            }
         }
         rounds += chunk;
-        HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
-        HIPCHECK(e, hipStreamSynchronize(st));
-        if ((rc = rank_agree(e, r, st, d_stat, RankStatus{SWP_OK, hb.pos, hb.error, hb.rounds}, all))) return bad(rc);
+        if (local_rc == SWP_OK && (hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+            note(e->fail(SWP_EHIP, "reading the control block: %s", hipGetErrorString(hipGetLastError())));
+        if ((rc = rank_agree(e, r, st, d_stat, RankStatus{local_rc, hb.pos, hb.error, hb.rounds}, all))) return bad(rc);   // (the collective itself failed: nothing is left to agree on)
         switch (rank_verdict(all.data(), G, &who)) {
+        case 1: return bad(local_rc != SWP_OK ? local_rc : e->fail(SWP_EHIP, "rank %u failed inside the sharded rounds (code %d): every rank stops here", who, all[who].code));
         case 2: return bad(e->fail(SWP_ERANGE, "rank %u: per-node task-count spread exceeds the %d level planes of the block resolver", who, R6_NP));
         case 3: return bad(e->fail(SWP_EHIP, "the ranks diverged: rank %u stands at task %u, rank 0 at %u", who, all[who].pos, all[0].pos));
         default: break;
@@ -3747,6 +3783,10 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
     HIPCHECK(e, hipMemcpyAsync(out_node_local, b->d_out.p, (size_t)T * 4, hipMemcpyDeviceToHost, st));
     if (out_fail_hist && ctl.ninf) HIPCHECK(e, hipMemcpyAsync(out_fail_hist, b->d_hist.p, (size_t)T * 8 * 4, hipMemcpyDeviceToHost, st));
     HIPCHECK(e, hipStreamSynchronize(st));
+    if (csi) {   // the attachments of this rank's tasks with cluster mounts; the volumes' usage as the batch left it (every rank holds the whole table)
+        if (int rcv = download_volumes(e, b, !(flags & SWP_SHARD_NO_FOLD))) return bad(rcv);
+        if (flags & SWP_SHARD_NO_FOLD) e->vol_dyn_dirty = true;
+    }
     uint64_t placed = 0;
     for (uint32_t i = 0; i < T; ++i) {
         const int32_t n = out_node_local[i];

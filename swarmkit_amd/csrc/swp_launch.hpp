@@ -35,12 +35,9 @@ hipError_t launch_vol_choose(const VolChooseArgs& a, hipStream_t s);
 
 // node-range shards, rounds on the device (swp_resolve7.hpp, built in swp_resolve6.hip)
 struct R7Args;
-struct R7Pick;
-struct R7Head;
-size_t r7_match_lds_size(uint32_t hw_total);
-hipError_t launch_r7_propose(const R6Args* args, uint32_t count, uint32_t block, uint32_t max_words, bool task_rows, hipStream_t s, int dev);
-hipError_t launch_r7_match(const R7Args& a, hipStream_t s, int dev);   // fold + match
-hipError_t launch_r7_apply(const R6Args* args, uint32_t count, const R7Pick* picks, const R7Head* head, uint32_t shard0, hipStream_t s);
+size_t r7_commit_lds_size(uint32_t hw_total, uint32_t block, uint32_t n_rr);
+hipError_t launch_r7_propose(const R6Args* args, uint32_t count, uint32_t block, uint32_t max_words, bool task_rows, bool csi, hipStream_t s, int dev);
+hipError_t launch_r7_commit(const R6Args* args, uint32_t count, const R7Args* m, size_t lds, bool csi, uint32_t shard0, hipStream_t s, int dev);   // fold + match + apply
 
 // sharded scan, host-merged rounds (swp_shard.hip)
 struct ProposeArgs;

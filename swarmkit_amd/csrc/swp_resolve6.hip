@@ -60,27 +60,24 @@ hipError_t launch_vol_choose(const VolChooseArgs& a, hipStream_t s) {
 }
 
 // ---- node-range shards with the rounds on the device (swp_resolve7.hpp) ----
-size_t r7_match_lds_size(uint32_t hw_total) { return r7_match_lds(hw_total); }
+size_t r7_commit_lds_size(uint32_t hw_total, uint32_t block, uint32_t n_rr) { return r7_commit_lds(hw_total, block, n_rr); }
 // `args`: device array of the argument records of the `count` shards that live on device `dev` (all of the same block size; the
 // launch geometry is sized for the largest of them)
-hipError_t launch_r7_propose(const R6Args* args, uint32_t count, uint32_t block, uint32_t max_words, bool task_rows, hipStream_t s, int dev) {
+hipError_t launch_r7_propose(const R6Args* args, uint32_t count, uint32_t block, uint32_t max_words, bool task_rows, bool csi, hipStream_t s, int dev) {
     const size_t lp = r6_propose_lds(max_words);
     hipError_t r;
     if (lp > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r7_propose), dev)) != hipSuccess) return r;
     if (task_rows) hipLaunchKernelGGL(k_r7_taskrows, dim3((max_words + 3) / 4, count), dim3(256), (size_t)block * 16, s, args);
+    if (csi) hipLaunchKernelGGL(k_r7_volrows, dim3((max_words + 255) / 256, block, count), dim3(256), 0, s, args);   // (batches with cluster mounts only)
     hipLaunchKernelGGL(k_r7_propose, dim3(block, count), dim3(64 * R6_PW), lp, s, args);
     return hipGetLastError();
 }
-hipError_t launch_r7_match(const R7Args& a, hipStream_t s, int dev) {
-    const size_t l = r7_match_lds(a.hw_total);
+// fold + match + apply: one workgroup per shard of the device; `m`: the job's shard table in device memory
+hipError_t launch_r7_commit(const R6Args* args, uint32_t count, const R7Args* m, size_t lds, bool csi, uint32_t shard0, hipStream_t s, int dev) {
     hipError_t r;
-    if (l > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r7_match), dev)) != hipSuccess) return r;
-    hipLaunchKernelGGL(k_r7_fold, dim3((a.block + 63) / 64), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_r7_match, dim3(1), dim3(64), l, s, a);
-    return hipGetLastError();
-}
-hipError_t launch_r7_apply(const R6Args* args, uint32_t count, const R7Pick* picks, const R7Head* head, uint32_t shard0, hipStream_t s) {
-    hipLaunchKernelGGL(k_r7_apply, dim3(count), dim3(R6_COMMIT_THREADS), 0, s, args, picks, head, shard0);
+    if (lds > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(csi ? &k_r7_commit_v : &k_r7_commit), dev)) != hipSuccess) return r;
+    if (csi) hipLaunchKernelGGL(k_r7_commit_v, dim3(count), dim3(R6_COMMIT_THREADS), lds, s, args, m, shard0);
+    else hipLaunchKernelGGL(k_r7_commit, dim3(count), dim3(R6_COMMIT_THREADS), lds, s, args, m, shard0);
     return hipGetLastError();
 }
 

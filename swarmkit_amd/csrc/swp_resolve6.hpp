@@ -144,7 +144,7 @@ struct R6Args {
     u32* cidx;               // [r6_compact_cap(n_words)] node of a compact position
     // node-range shards (swp_resolve7.hpp): where this shard publishes the volumes of a task with cluster mounts it placed ([2] slots, by
     // round parity, right behind its proposals — they travel with them); nullptr: no volumes in the batch
-    struct R7Trail* trail_out;
+    struct R7Trail* trail_out;   // = the slots of its R7Tail
 };
 struct R7Args;   // swp_resolve7.hpp: what a shard's commit kernel knows of the other shards
 #define R7M_EXC 0x100u   // H_meta of a folded record: list length | the task has an exception-list candidate on some shard | it does not count on its node | it has cluster mounts
@@ -172,6 +172,7 @@ inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr
 #ifdef SWP_R6_KERNELS   // the kernels: swp_resolve6.hip and the emulation harness only (the engine TU shares the argument records)
 // the node-range shards' side of the commit kernel (defined in swp_resolve7.hpp; only its R7 instances use them)
 WV_DEV u32 r7_tk_words(const R7Args* m);
+WV_DEV bool r7_any_dead(const R7Args* m);
 WV_DEV void r7_fold_into(const R7Args* m, u32 i, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh);
 WV_DEV u32 r7_addr(const R7Args* m, u32 shard, u32 node);
 WV_DEV u32 r7_local(const R7Args* m, u32 addr, u32 my, bool* here);
@@ -695,6 +696,9 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
     const u32 tid = wv::tid(), lane = wv::lane();
     const u32 pos = a.blk->pos, end = a.blk->end;
     if (pos >= end || a.blk->error != ERR_NONE) return;   // a level beyond the planes: the proposals of this round were not written
+    if constexpr (R7) {
+        if (r7_any_dead(m7)) return;
+    }
     const u32 n = min(a.block, end - pos), Wn = a.n_words, n_rr = a.n_dc + a.n_dm;
     // (with a compact index the positions' words come first, the node words behind them: addresses as the lists carry them)
     // (R7: the TK row covers the padded half-word space of ALL shards)

@@ -1,26 +1,36 @@
 // swp_resolve7.hpp — node-range shards with the rounds on the device: the block resolver's pieces, one node range per
 // engine (one per GPU of a box, or several on one GPU). The scan nodeSet.tree does over ALL nodes (nodeset.go:57-120) becomes, per
-// round of up to `block` tasks:
+// round of up to `block` tasks, TWO launches per device:
 //
-//   every shard    k_r6_propose over ITS nodes against ITS state (swp_resolve6.hpp, unchanged): per task the minimum level among
-//                  its plain candidates there, the first 16 non-empty half-words of that level, the best exception-list node
-//   the leader     k_r7_fold, one thread per task: reads the proposals of all shards (peer memory: xGMI between GPUs) and folds a
-//                  task's records into one list in GLOBAL node order — the minimum level over the shards, the shards that have it
-//                  in range order (ranges are contiguous in the canonical node order, so shard order IS node order), stopping
-//                  behind a shard whose own list was truncated; then k_r7_match, one wave, walks the block with the matcher of
-//                  k_r6_commit: a task takes the first listed node nobody before it took. Same cut rules (an exhausted list, an
-//                  exception-list task that is not the block's first, an uncounted task). This is the north star's per-task "allreduce(min-score, argmin-node)" done for a whole block at
-//                  once by the one wave that has to order the block anyway.
-//   every shard    k_r7_apply: NodeInfo.addTask (nodeinfo.go:108-154) for the picks that landed in its range, the unplaceable
-//                  tasks recorded everywhere (each shard explains them over its own nodes), the position advanced identically.
+//   k_r7_propose   every shard: k_r6_propose over ITS nodes against ITS state (swp_resolve6.hpp, unchanged): per task the minimum level
+//                  among its plain candidates there, the first non-empty half-words of that level, the best exception-list node
+//   (exchange)     the blocks of proposals of all shards become visible to every shard: peer memory between the GPUs of one process
+//                  (swp_shard_run), an ncclAllGather between ranks (swp_shard_run_rank)
+//   k_r7_commit    every shard, the SAME kernel on the SAME inputs: one workgroup shaped like k_r6_commit (it is that kernel's source,
+//                  instance R7). The thread that stages a task's list FOLDS the task's records of all shards into it — the minimum level
+//                  over the shards, the shards that have it in range order (ranges are contiguous in the canonical node order, so shard
+//                  order IS node order), stopping behind a shard whose own list was truncated — in a padded global half-word space;
+//                  wave 0 walks the block with the matcher: a task takes the first listed node nobody before it took, same cut rules
+//                  (an exhausted list, an exception-list task that is not the block's first, an uncounted task, a second task with cluster
+//                  mounts); waves 1-15 apply the picks — each shard those that landed in ITS range (NodeInfo.addTask, nodeinfo.go:108-154),
+//                  every shard the unplaceable tasks (each explains them over its own nodes) and the position.
 //
-// The host enqueues rounds blindly — one propose launch and one apply launch per DEVICE (a launch covers the shards that live
-// there), fold + match on the leader; events order propose -> match -> apply across devices, shards that share the leader's device
-// share its stream — and reads the leader's header every few dozen rounds. Exactness is k_resolve6's list rule; the merged list holds ALL candidates of the global
-// minimum level in node order up to its last listed half-word because every part does and parts are concatenated in node order.
+// This is the north star's per-task "allreduce(min-score, argmin-node)" done for a whole block at once. Every shard computes every
+// pick itself, so no second exchange is needed to agree on them (round 4 ran fold, match and apply as three launches with the leader
+// matching alone: 104 µs a round on one GPU against 56 for the single engine). Exactness is k_resolve6's list rule; the folded list
+// holds ALL candidates of the global minimum level in node order up to its last listed half-word because every part does and parts are
+// concatenated in node order.
 //
 // Half-words are numbered in a padded global space: shard g's local half-word h is hw_base[g] + h (hw_base accumulates
-// ceil(nodes / 32) per shard), so ranges need no alignment. Written against swp_wave.hpp only (tests/emu runs it on CPU fibers).
+// ceil(nodes / 32) per shard), so ranges need no alignment; an address (TK row, pick) is 32 * half-word + bit.
+//
+// CSI volumes (swp_volumes.hpp) are cluster-wide state: every shard holds the whole table. A block decides at most one task with
+// cluster mounts (the single engine's rule); the shard that owns its node chooses and reserves its volumes and leaves them in a TRAILER
+// behind its proposals (two slots, by round parity: they travel with the next round's exchange); every other shard reserves the same
+// volumes at the start of that next round — pinned to a foreign node (VOL_PIN_FOREIGN) — and, since the proposals of that round were made
+// before the reservation was known everywhere, the round decides no task with mounts (it is cut in front of the first one).
+//
+// Written against swp_wave.hpp only (tests/emu runs it on CPU fibers).
 #pragma once
 #include "swp_resolve6.hpp"
 
@@ -28,60 +38,80 @@ namespace swpdev {
 
 #define R7_MAXS 8   // shards of one job (the GPUs of one box)
 
-struct R7Pick {
-    u32 shard;   // owner of the node; R6_NONE: no suitable node on any shard
-    u32 node;    // shard-local node index
-    u32 idx;     // commit index / index among the unplaceable tasks
-    u32 aux;     // exception-list entry on the owner (LIST_EMPTY: a plain node) / commits before an unplaceable task
+struct R7Trail {   // what a shard tells the others about the task with cluster mounts it placed in a round
+    u32 valid, set, shard, node;     // mount set; owner shard and ITS local node index
+    u32 n, pad[3];
+    u32 att[VOL_MAX_MOUNTS];         // the volumes chosen for the mounts (chooseTaskVolumes)
 };
-struct R7Head {   // what one round decided; written by k_r7_match, read by every k_r7_apply and now and then by the host
-    u32 acc, nc, ni, why;
-    u32 rounds, cut_exhausted, cut_exception, cut_uncounted;
-};
+static_assert(sizeof(R7Trail) == 64, "R7Trail layout");
+// what one shard contributes to a round's exchange: its block of proposals, then a tail — the two trailer slots (by round parity) and a
+// word the HOST of a rank sets when it can no longer take part (swp_shard_run_rank: a launch failed on it; it keeps issuing the chunk's
+// collectives so that nobody waits for it, and every rank's commit kernel stands still from then on)
+struct R7Tail { R7Trail slot[2]; u32 dead, pad[3]; };
+static_assert(sizeof(R7Tail) == 144, "R7Tail layout");
+inline __host__ __device__ size_t r7_send_bytes(u32 block) { return (size_t)block * sizeof(R6Prop) + sizeof(R7Tail); }
+
 struct R7Args {
     u32 n_shards, block, hw_total, dbg;
-    R6Prop* merged;                // [block] the folded records: half-words in the padded global space, the best exception-list node of all
-                                   // shards (exc_lo's low half: SHARD-LOCAL node; flags bits 8..15: its shard)
-    const R6Prop* prop[R7_MAXS];   // each shard's proposals of this round
-    u32 hw_base[R7_MAXS + 1];      // first padded half-word of each shard; [n_shards] = hw_total
-    u32 first_node[R7_MAXS];       // global index of each shard's first node (tie order of the exception lists)
-    const Blk6* blk;               // the leader's control block (pos, end, error) and counters: every shard's are the same
-    const Ctl* ctl;
-    R7Pick* picks;                 // [block]
-    R7Head* head;
+    const R6Prop* prop[R7_MAXS];       // each shard's proposals of this round (its own buffer, peer memory, or its part of the gathered buffer)
+    const R7Tail* tail[R7_MAXS];       // ... and the tail behind them (trailer slots, the dead word)
+    u32 use_trailers, check_dead;      // the batch has tasks with cluster mounts; the shards are ranks with hosts of their own
+    u32 hw_base[R7_MAXS + 1];          // first padded half-word of each shard; [n_shards] = hw_total
+    u32 first_node[R7_MAXS];           // global index of each shard's first node (tie order of the exception lists)
 };
 
-inline __host__ __device__ size_t r7_match_lds(u32 hw_total) { return (size_t)hw_total * 4 + 64; }
+// TK row over the padded half-word space, thresholds, the block's picks / cursors / lists / folded heads (r6_commit_t's LDS, instance R7)
+inline __host__ __device__ size_t r7_commit_lds(u32 hw_total, u32 block, u32 n_rr) {
+    return (size_t)((hw_total + 1) / 2 + n_rr) * 8 + (size_t)block * (16 + 2 * R6_CAND * 6 + 8) + 128;
+}
 
 #ifdef SWP_R6_KERNELS
-// ---- fold: one thread per task of the block, on the leader -----------------------------------------------------------------------
-WV_KERNEL(64) void k_r7_fold(R7Args a) {
-    const u32 pos = a.blk->pos, end = a.blk->end;
-    if (pos >= end || a.blk->error != ERR_NONE) return;
-    const u32 n = min(a.block, end - pos), G = a.n_shards, i = wv::block() * 64 + wv::lane();
-    if (i >= n) return;
+WV_DEV u32 r7_tk_words(const R7Args* m) { return (m->hw_total + 1u) / 2u; }
+// a rank's host has given up: every rank's kernels stand still until the hosts have agreed on it (uniform: every thread reads the same words)
+WV_DEV bool r7_any_dead(const R7Args* m) {
+    if (!m->check_dead) return false;
+    bool dead = false;
+    for (u32 g = 0; g < m->n_shards; ++g) dead = dead || wv::uload(&m->tail[g]->dead) != 0;
+    return dead;
+}
+
+// the address of shard `shard`'s local node in the padded space
+WV_DEV u32 r7_addr(const R7Args* m, u32 shard, u32 node) { return ((m->hw_base[shard] + (node >> 5)) << 5) + (node & 31u); }
+
+// owner and local node of an address; *here = the owner is `my`
+WV_DEV u32 r7_local(const R7Args* m, u32 addr, u32 my, bool* here) {
+    const u32 hw = addr >> 5;
+    u32 s = 0;   // the last shard whose base is <= hw
+    for (u32 g = 1; g < m->n_shards; ++g)
+        if (m->hw_base[g] <= hw) s = g;
+    *here = s == my;
+    return ((hw - m->hw_base[s]) << 5) + (addr & 31u);
+}
+
+// ---- fold: the records all shards hold for block-local task i -> one list in global node order, staged into the commit kernel's LDS ----
+WV_DEV void r7_fold_into(const R7Args* m, u32 i, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh) {
+    const u32 G = m->n_shards;
     u32 level = R6_NONE;
-    for (u32 g = 0; g < G; ++g) level = min(level, a.prop[g][i].level);
-    R6Prop* out = a.merged + i;
-    u32 cnt = 0, uncounted = 0;
+    for (u32 g = 0; g < G; ++g) level = min(level, m->prop[g][i].level);
+    u32 cnt = 0, flags = 0;
     bool closed = false;   // a shard's own list was cut short: what lies behind it is unknown, later shards cannot be appended
     u64 bhi = KEY_NONE, blo = KEY_NONE;
     u32 bshard = 0, bnode = 0, bentry = 0;
     for (u32 g = 0; g < G; ++g) {
-        const R6Prop* p = a.prop[g] + i;
-        uncounted = p->flags & 1u;
+        const R6Prop* p = m->prop[g] + i;
+        flags = p->flags;   // (bit 0: uncounted, bit 1: cluster mounts — properties of the task: the same on every shard)
         if (level != R6_NONE) {
             if (p->level != level || closed) continue;
             const u32 c = p->n_cand & 0x7FFFFFFFu;
             u32 k = 0;
             for (; k < c && cnt < 2 * R6_CAND; ++k, ++cnt) {
-                out->hw[cnt] = a.hw_base[g] + p->hw[k];
-                out->hb[cnt] = p->hb[k];
+                L_hw[(size_t)cnt * block + i] = (unsigned short)(m->hw_base[g] + p->hw[k]);
+                L_hb[(size_t)cnt * block + i] = p->hb[k];
             }
             if (k < c || (p->n_cand >> 31)) closed = true;
         } else if (p->exc_hi != KEY_NONE) {
             // nodeLess over the exception lists (scheduler.go:708-735): (failure class, svcCount), then (ActiveTasksCount, GLOBAL index)
-            const u64 lo = (p->exc_lo & 0xFFFFFFFF00000000ull) | (u64)(a.first_node[g] + (u32)p->exc_lo);
+            const u64 lo = (p->exc_lo & 0xFFFFFFFF00000000ull) | (u64)(m->first_node[g] + (u32)p->exc_lo);
             if (p->exc_hi < bhi || (p->exc_hi == bhi && lo < blo)) {
                 bhi = p->exc_hi;
                 blo = lo;
@@ -92,194 +122,63 @@ WV_KERNEL(64) void k_r7_fold(R7Args a) {
         }
     }
     for (u32 k = cnt; k < 2 * R6_CAND; ++k) {
-        out->hw[k] = 0;
-        out->hb[k] = 0;
+        L_hw[(size_t)k * block + i] = 0;
+        L_hb[(size_t)k * block + i] = 0;
     }
-    out->level = level;
-    out->n_cand = cnt | (closed ? 0x80000000u : 0u);
-    out->exc_hi = bhi;
-    out->exc_lo = bhi == KEY_NONE ? KEY_NONE : (u64)bnode;
-    out->exc_entry = bentry;
-    out->flags = uncounted | (bshard << 8);
-}
-
-// ---- match: one wave on the leader -------------------------------------------------------------------------------------------
-#define R7_LIST 16   // half-words of a folded list the matching wave holds in registers: the first ones (the list rule holds for any prefix)
-WV_KERNEL(64) void k_r7_match(R7Args a) {
-    const u32 lane = wv::lane();
-    const u32 pos = a.blk->pos, end = a.blk->end;
-    if (lane == 0) a.head->acc = 0;
-    if (pos >= end || a.blk->error != ERR_NONE) return;
-    const u32 n = min(a.block, end - pos), G = a.n_shards;
-    u32* tk32 = reinterpret_cast<u32*>(wv::lds());   // [hw_total] nodes taken by this block so far, padded half-word space
-    for (u32 w = lane; w < a.hw_total; w += 64) tk32[w] = 0;
-    wv::wave_sync();
-    u32 nc = a.ctl->ncommit, ni = a.ctl->ninf, acc = 0, why = 0;
-    bool stop = false;
-    R6Prop nxt = a.merged[lane < n ? lane : 0];   // the records of the next 64 tasks are in flight while a group is matched
-    for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
-        const u32 i = g0 + lane, glim = min(64u, n - g0);
-        const bool have = i < n;
-        const R6Prop rec = nxt;
-        const R6Prop* p = &rec;
-        if (g0 + 64 < n) nxt = a.merged[i + 64 < n ? i + 64 : 0];
-        const u32 level = have ? p->level : 0u;
-        const u32 cnt = (have && level != R6_NONE) ? min(p->n_cand & 0x7FFFFFFFu, (u32)R7_LIST) : 0u;   // (a prefix of a list is a list)
-        const bool plain = cnt != 0;
-        const bool exc = have && level == R6_NONE && p->exc_hi != KEY_NONE;
-        const bool inf = have && level == R6_NONE && !exc;
-        const u32 uncounted = p->flags & 1u, bshard = (p->flags >> 8) & 0xFFu, bnode = (u32)p->exc_lo, bentry = p->exc_entry;
-        // ---- the list as 32-node half-words (registers), minus the picks of the earlier groups
-        u32 eb[R7_LIST], ew[R7_LIST];
-        for (int k = 0; k < R7_LIST; ++k) {
-            ew[k] = p->hw[k];
-            eb[k] = (u32)k < cnt ? (p->hb[k] & ~tk32[ew[k]]) : 0u;
-        }
-        u32 bits = 0, w = 0, bits2 = 0, w2 = 0;
-        for (int k = R7_LIST - 1; k >= 0; --k)
-            if (eb[k]) { bits2 = bits; w2 = w; bits = eb[k]; w = ew[k]; }
-        const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
-        const u64 m_plain = wv::ballot(plain), m_inf = wv::ballot(inf), m_exc = wv::ballot(exc), m_unc = wv::ballot(plain && uncounted);
-        u32 cut = glim;
-        bool last = false;
-        if (m_exc) { cut = (u32)wv::ffs64(m_exc); why = 2; }
-        if (m_unc && (u32)wv::ffs64(m_unc) < cut) { cut = (u32)wv::ffs64(m_unc) + 1; why = 3; last = true; }
-        if (g0 == 0 && (m_exc & 1ull)) {   // the block's first task, from the exception lists; the block ends behind it
-            if (lane == 0) a.picks[0] = R7Pick{bshard, bnode, nc, bentry};
-            ++nc;
-            acc = 1;
-            why = 2;
-            break;
-        }
-        const bool served = plain && lane < cut;
-        if (!served) { bits = lane == cut ? 0u : 1u; bits2 = 0; w = WV_DUMMY_W | lane; }
-        u32 pickb = 0, from = 0, flushed = 0;
-        for (;;) {
-            const u32 at = wv::match_seq64(bits, w, bits2, w2, pickb, lane, from);
-            if (at >= cut) break;
-            if (served && lane >= flushed && lane < at) wv::lds_or32(tk32 + w, pickb & (0u - pickb));
-            flushed = at;
-            wv::lockstep();
-            if (served && lane >= at && bits == 0) {
-                u32 t[R7_LIST];
-                for (int k = 0; k < R7_LIST; ++k) t[k] = eb[k] & ~tk32[ew[k]];
-                for (int k = R7_LIST - 1; k >= 0; --k)
-                    if (t[k]) { bits2 = bits; w2 = w; bits = t[k]; w = ew[k]; }
-            }
-            if (wv::readlane(bits, at) == 0) {   // every listed node is taken: propose again against the new state
-                cut = at;
-                why = 1;
-                break;
-            }
-            from = at;
-        }
-        if (served && lane >= flushed && lane < cut) wv::lds_or32(tk32 + w, pickb & (0u - pickb));   // for the later groups
-        const u64 below = cut == 64 ? ~0ull : (1ull << cut) - 1ull;
-        const u64 mc = m_plain & below & lanes, mi = m_inf & below & lanes;
-        if (lane < cut && have) {
-            if (plain) {
-                u32 s = 0;   // the owner of padded half-word w: the last shard whose base is <= w
-                for (u32 g = 1; g < G; ++g)
-                    if (a.hw_base[g] <= w) s = g;
-                a.picks[i] = R7Pick{s, ((w - a.hw_base[s]) << 5) + (u32)wv::ffs64((u64)pickb), nc + wv::mbcnt(mc), LIST_EMPTY};
-            } else   // no suitable node: final whatever the earlier tasks of the block did (feasibility only shrinks)
-                a.picks[i] = R7Pick{R6_NONE, 0u, ni + wv::mbcnt(mi), nc + wv::mbcnt(mc)};
-        }
-        nc += (u32)wv::popc64(mc);
-        ni += (u32)wv::popc64(mi);
-        acc = g0 + cut;
-        if (cut < glim || (last && why == 3)) stop = true;
-        else why = 0;
-        wv::wave_sync();
-    }
-    if (lane == 0) {
-        a.head->acc = acc;
-        a.head->nc = nc;
-        a.head->ni = ni;
-        a.head->why = why;
-        a.head->rounds += 1;
-        if (why == 1) a.head->cut_exhausted += 1;
-        if (why == 2) a.head->cut_exception += 1;
-        if (why == 3) a.head->cut_uncounted += 1;
+    H_level[i] = level;
+    H_meta[i] = cnt | (level == R6_NONE && bhi != KEY_NONE ? R7M_EXC : 0u) | ((flags & 1u) ? R7M_UNC : 0u) | ((flags & 2u) ? R7M_CSI : 0u);
+    if (i == 0) {   // only the block's first task may be decided from the exception lists: where its candidate sits
+        sh[8] = bshard;
+        sh[9] = bnode;
+        sh[10] = bentry;
     }
 }
 
-// ---- apply: every shard, the picks of its own range ------------------------------------------------------------------------------
+// ---- CSI volumes across shards ----
+// start of round `round` (one thread): clear this shard's slot of this round, and reserve in THIS shard's table what the other shards
+// reserved in the round before. Returns != 0 when ANY shard (this one included) placed a task with mounts then: the same on every shard.
+WV_DEV u32 r7_take_trailers(const R6Args& a, const R7Args* m, u32 my, u32 round) {
+    if (!a.trail_out) return 0u;
+    a.trail_out[round & 1u].valid = 0;
+    u32 any = 0;
+    for (u32 g = 0; g < m->n_shards; ++g) {
+        const R7Trail* t = &m->tail[g]->slot[(round + 1u) & 1u];
+        if (!t->valid) continue;
+        any = 1;
+        if (g == my) continue;   // (reserved when it was placed)
+        u32 att[VOL_MAX_MOUNTS];
+        for (u32 q = 0; q < VOL_MAX_MOUNTS; ++q) att[q] = t->att[q];
+        vol_reserve(a.vol, t->set, VOL_PIN_FOREIGN | (t->shard << 26) | t->node, att, t->n);
+    }
+    return any;
+}
+WV_DEV void r7_leave_trailer(const R6Args& a, u32 my, u32 round, u32 set, u32 node, const u32* att, u32 n) {
+    if (!a.trail_out) return;
+    R7Trail* t = a.trail_out + (round & 1u);
+    t->set = set;
+    t->shard = my;
+    t->node = node;
+    t->n = n;
+    for (u32 q = 0; q < VOL_MAX_MOUNTS; ++q) t->att[q] = att[q];
+    t->valid = 1;
+}
+
 // One launch covers the shards that live on one device: workgroup b works for shard shard0 + b with the argument record args[b].
 WV_KERNEL(256) void k_r7_taskrows(const R6Args* args) { r6_taskrows(args[wv::block_y()], 0u, 1u); }
-WV_KERNEL(64 * R6_PW) void k_r7_propose(const R6Args* args) { r6_propose(args[wv::block_y()]); }
-
-WV_KERNEL(R6_COMMIT_THREADS) void k_r7_apply(const R6Args* args, const R7Pick* picks, const R7Head* head, u32 shard0) {
-    const R6Args& a = args[wv::block()];
-    const u32 my = shard0 + wv::block();
-    const u32 tid = wv::tid();
-    const u32 pos = a.blk->pos, end = a.blk->end, acc = wv::uload(&head->acc);
-    if (pos >= end || acc == 0) return;
-    const u32 Wn = a.n_words, base = a.blk->base;
-    if (tid < acc) {
-        const u32 t = pos + tid;
-        const R7Pick pk = picks[tid];
-        if (pk.shard == R6_NONE) {   // every shard explains the unplaceable tasks over its own nodes
-            a.inf_task[pk.idx] = t;
-            a.inf_pos[pk.idx] = pk.aux;
-        } else if (pk.shard == my) {
-            const RTask r = a.rt[t];
-            const u32 nd = pk.node, w = nd >> 6, ci = pk.idx, entry = pk.aux;
-            const u64 bit = 1ull << (nd & 63);
-            const i64 qc = a.cpu[nd] - r.cpu, qm = a.mem[nd] - r.mem;
-            const u32 old = a.total[nd];
-            const int32_t prev = a.last[nd];
-            if (r.cpu) {
-                a.cpu[nd] = qc;
-                for (int c = (int)r6_first_above(a.thr, a.n_dc, qc + r.cpu) - 1; c >= 0 && a.thr[c] > qc; --c) wv::g_andn64(a.rr + (size_t)c * Wn + w, bit);
-            }
-            if (r.mem) {
-                a.mem[nd] = qm;
-                for (int c = (int)r6_first_above(a.thr + a.n_dc, a.n_dm, qm + r.mem) - 1; c >= 0 && a.thr[a.n_dc + c] > qm; --c)
-                    wv::g_andn64(a.rr + (size_t)(a.n_dc + c) * Wn + w, bit);
-            }
-            if (r.flags & RT_PORTS)
-                for (u32 q = a.pset_off[r.pset]; q < a.pset_off[r.pset + 1]; ++q) wv::g_or64(a.portmap + (size_t)a.pset_ids[q] * Wn + w, bit);
-            if (a.n_rg) {   // Claim (resource_management.go:11-72), as k_r6_commit does it: the count drops by the request; the node leaves the kind's rows it no longer meets
-                const u32 gset = a.tg[t];
-                for (u32 g = a.gs_off[gset]; g < a.gs_off[gset + 1]; ++g) {
-                    const u32 row = a.gs_row[g];
-                    int32_t* cp = a.gcnt + (size_t)a.rg_kind[row] * a.gstride + nd;
-                    const int32_t c = *cp - a.rg_val[row];
-                    *cp = c;
-                    for (u32 r2 = a.rg_k0[row]; r2 < a.rg_k1[row]; ++r2)
-                        if (a.rg_val[r2] > c) wv::g_andn64(a.rg + (size_t)r2 * Wn + w, bit);
-                }
-            }
-            if (!(r.flags & RT_UNCOUNTED)) {
-                a.total[nd] = old + 1;
-                const u32 rl = old - base, nl = rl + 1, xm = rl ^ nl;
-                for (u32 b = 0; b < R6_NP && ((xm >> b) & 1u); ++b) wv::g_xor64(a.planes + (size_t)b * Wn + w, bit);
-                wv::g_max32(&a.blk->maxrel, nl);
-                if (nl >> R6_NP) a.blk->error = ERR_LEVEL_RANGE;
-                if (entry == LIST_EMPTY) {
-                    wv::g_or64(a.X + (size_t)r.svc * a.xs + w, bit);
-                    a.list_node[r.slot] = nd;
-                    a.list_svc[r.slot] = 1;
-                    a.list_fail[r.slot] = 0;
-                } else
-                    a.list_svc[entry] += 1;
-            }
-            a.log_node[ci] = nd;
-            a.log_task[ci] = t;
-            a.log_prev[ci] = prev;
-            a.last[nd] = (int32_t)ci;
-            a.out_node[t] = (int32_t)nd;
-        }
-    }
-    wv::barrier();   // every thread has read blk->pos before it moves
-    if (tid == 0) {
-        a.blk->pos = pos + acc;
-        a.blk->rounds += 1;
-        a.ctl->ncommit = wv::uload(&head->nc);
-        a.ctl->ninf = wv::uload(&head->ni);
-    }
+WV_KERNEL(256) void k_r7_volrows(const R6Args* args) {   // grid (words / 256, block, shards of the device)
+    const R6Args& a = args[wv::block_z()];
+    const u32 pos = wv::uload(&a.blk->pos), end = wv::uload(&a.blk->end);
+    const u32 t = pos + wv::block_y();
+    if (t >= end || wv::uload(&a.blk->error) != ERR_NONE) return;
+    const u32 ck = wv::uload(a.csi_of + t);
+    if (ck == R6_NONE) return;
+    const u32 w = wv::block() * 256 + wv::tid();
+    if (w < a.n_words) a.vrows[(size_t)ck * a.n_words + w] = vol_filter_word(a.vol, wv::uload(a.csi_set + ck), w);
 }
+WV_KERNEL(64 * R6_PW) void k_r7_propose(const R6Args* args) { r6_propose(args[wv::block_y()]); }
+// (m: the job's shard table in device memory — it does not change between the rounds of a batch)
+WV_KERNEL(R6_COMMIT_THREADS) void k_r7_commit(const R6Args* args, const R7Args* m, u32 shard0) { r6_commit_t<false, false, true>(args[wv::block()], m, shard0 + wv::block()); }
+WV_KERNEL(R6_COMMIT_THREADS) void k_r7_commit_v(const R6Args* args, const R7Args* m, u32 shard0) { r6_commit_t<false, true, true>(args[wv::block()], m, shard0 + wv::block()); }
 #endif   // SWP_R6_KERNELS
 
 }  // namespace swpdev

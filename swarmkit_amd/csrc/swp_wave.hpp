@@ -27,6 +27,7 @@ WV_DEV u32 lane() { return threadIdx.x & 63u; }
 // wave index as a scalar (threadIdx.x >> 6 is uniform, the compiler does not always know)
 WV_DEV u32 wave() { return (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 WV_DEV u32 block() { return blockIdx.x; }   // workgroup index of a multi-workgroup launch (swp_resolve6.hpp)
+WV_DEV u32 block_z() { return blockIdx.z; }
 WV_DEV u32 block_y() { return blockIdx.y; } // second grid dimension: the shard of a launch that covers several (swp_resolve7.hpp)
 WV_DEV u64* lds() {
     extern __shared__ u64 wv_lds_[];

@@ -1,5 +1,5 @@
-// emu_resolve7.cpp — runs the node-range shard kernels (swarmkit_amd/csrc/swp_resolve7.hpp: per-shard k_r6_propose, k_r7_fold,
-// k_r7_match, per-shard k_r7_apply) on CPU fibers (wv_emu.hpp) over a random problem whose node set is split into G contiguous
+// emu_resolve7.cpp — runs the node-range shard kernels (swarmkit_amd/csrc/swp_resolve7.hpp: per-shard k_r7_propose, then k_r7_commit —
+// every shard folds + matches the block itself and applies the picks of its own range) on CPU fibers (wv_emu.hpp) over a random problem whose node set is split into G contiguous
 // ranges, and compares the placements (shard-local node + the range's first node), the node rows of every shard and the counters
 // with the sequential model of emu_model.hpp run over the WHOLE node set. What a job of G GPUs computes, without a GPU.
 // TEST INFRASTRUCTURE (tests/test_emu_resolve7.py); not product.
@@ -94,7 +94,7 @@ struct Shard {
     Problem p;
     State em;
     std::vector<u64> planes, rr, trows, rg;
-    std::vector<R6Prop> prop;
+    std::vector<R6Prop> prop;   // [B] + the tail (trailer slots, dead word): what a shard contributes to a round's exchange
     Blk6 blk{};
     u32 first = 0;
 };
@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
         s.rr.assign((size_t)std::max<u32>(n_dc + n_dm, 1) * s.p.Wn, 0x5555555555555555ull);
         s.trows.assign((size_t)B * s.p.Wn, 0x7777777777777777ull);
         s.rg.assign(std::max<size_t>(p.rg_kind.size(), 1) * s.p.Wn, 0x3333333333333333ull);
-        s.prop.resize(B);
+        s.prop.resize(B + (sizeof(R7Tail) + sizeof(R6Prop) - 1) / sizeof(R6Prop));
         max_words = std::max(max_words, s.p.Wn);
         first += cnt;
     }
@@ -203,9 +203,6 @@ int main(int argc, char** argv) {
             a.rg_k1 = s.p.rg_k1.data();
         }
     }
-    std::vector<R6Prop> merged(B);
-    std::vector<R7Pick> picks(B);
-    R7Head head{};
     R7Args ma{};
     ma.n_shards = G;
     ma.block = B;
@@ -215,20 +212,21 @@ int main(int argc, char** argv) {
         ma.first_node[g] = sh[g].first;
         hw += (sh[g].p.N + 31) / 32;
         ma.prop[g] = sh[g].prop.data();
+        ma.tail[g] = reinterpret_cast<const R7Tail*>(sh[g].prop.data() + B);
+        memset(sh[g].prop.data() + B, 0, sizeof(R7Tail));
     }
     ma.hw_base[G] = ma.hw_total = hw;
-    ma.merged = merged.data();
-    ma.blk = &sh[0].blk;
-    ma.ctl = &sh[0].em.ctl;
-    std::vector<R6Prop> gathered;   // the rank variant: [G][B], what the all-gather leaves on every rank
+    const size_t send = r7_send_bytes(B);
+    std::vector<char> gathered;   // the rank variant: [G][send bytes], what the all-gather leaves on every rank
     if (my_rank >= 0) {
-        gathered.resize((size_t)G * B);
-        for (u32 g = 0; g < G; ++g) ma.prop[g] = gathered.data() + (size_t)g * B;
-        ma.blk = &sh[my_rank].blk;
-        ma.ctl = &sh[my_rank].em.ctl;
+        gathered.resize((size_t)G * send);
+        ma.check_dead = 1;
+        for (u32 g = 0; g < G; ++g) {
+            ma.prop[g] = reinterpret_cast<const R6Prop*>(gathered.data() + (size_t)g * send);
+            ma.tail[g] = reinterpret_cast<const R7Tail*>(ma.prop[g] + B);
+        }
     }
-    ma.picks = picks.data();
-    ma.head = &head;
+    const size_t lds_commit = r7_commit_lds(hw, B, n_dc + n_dm);
 
     for (u32 g = 0; g < G; ++g) {   // build: base / highest level, planes and rows per shard
         if (my_rank >= 0 && (int)g != my_rank) continue;
@@ -240,20 +238,17 @@ int main(int argc, char** argv) {
         sh[g].blk.end = T;
     }
     const R6Args* ap = args.data();
+    const R7Args* mp = &ma;
     u64 rounds = 0;
     auto round = [&]() {
         for (u32 g = 0; g < G; ++g) {
-            for (R6Prop& q : sh[g].prop) memset(&q, 0xEE, sizeof q);
+            memset(sh[g].prop.data(), 0xEE, (size_t)B * sizeof(R6Prop));
             emu::blockidx_y() = g;
             if (task_rows) grid((max_words + 3) / 4, 256, (size_t)B * 16, [ap]() { k_r7_taskrows(ap); });
             grid(B, 64 * R6_PW, r6_propose_lds(max_words), [ap]() { k_r7_propose(ap); });
         }
         emu::blockidx_y() = 0;
-        grid((B + 63) / 64, 64, 0, [ma]() { k_r7_fold(ma); });
-        grid(1, 64, r7_match_lds(ma.hw_total), [ma]() { k_r7_match(ma); });
-        const R7Pick* pk = picks.data();
-        const R7Head* hd = &head;
-        grid(G, R6_COMMIT_THREADS, 0, [ap, pk, hd]() { k_r7_apply(ap, pk, hd, 0u); });
+        grid(G, R6_COMMIT_THREADS, lds_commit, [ap, mp]() { k_r7_commit(ap, mp, 0u); });   // workgroup g: shard g
     };
     auto io_all = [](int fd, void* buf, size_t n, bool wr) {
         char* p = static_cast<char*>(buf);
@@ -272,18 +267,14 @@ int main(int argc, char** argv) {
             io_all(1, &go, 4, true);
             if (!go) break;
             const u32 before = S0.blk.pos;
-            for (R6Prop& q : S0.prop) memset(&q, 0xEE, sizeof q);
+            memset(S0.prop.data(), 0xEE, (size_t)B * sizeof(R6Prop));
             emu::blockidx_y() = 0;
             if (task_rows) grid((S0.p.Wn + 3) / 4, 256, (size_t)B * 16, [am]() { k_r7_taskrows(am); });
             grid(B, 64 * R6_PW, r6_propose_lds(S0.p.Wn), [am]() { k_r7_propose(am); });
-            io_all(1, S0.prop.data(), (size_t)B * sizeof(R6Prop), true);
-            io_all(0, gathered.data(), (size_t)G * B * sizeof(R6Prop), false);
-            if (memcmp(gathered.data() + (size_t)me * B, S0.prop.data(), (size_t)B * sizeof(R6Prop)) != 0) { fprintf(stderr, "rank %u: its own block came back changed\n", me); return 3; }
-            grid((B + 63) / 64, 64, 0, [ma]() { k_r7_fold(ma); });
-            grid(1, 64, r7_match_lds(ma.hw_total), [ma]() { k_r7_match(ma); });
-            const R7Pick* pk = picks.data();
-            const R7Head* hd = &head;
-            grid(1, R6_COMMIT_THREADS, 0, [am, pk, hd, me]() { k_r7_apply(am, pk, hd, me); });
+            io_all(1, S0.prop.data(), send, true);
+            io_all(0, gathered.data(), (size_t)G * send, false);
+            if (memcmp(gathered.data() + (size_t)me * send, S0.prop.data(), send) != 0) { fprintf(stderr, "rank %u: its own block came back changed\n", me); return 3; }
+            grid(1, R6_COMMIT_THREADS, lds_commit, [am, mp, me]() { k_r7_commit(am, mp, me); });
             ++rounds;
             if (S0.blk.error) { fprintf(stderr, "rank %u reported error %u at task %u\n", me, S0.blk.error, S0.blk.pos); return 3; }
             if (S0.blk.pos <= before) { fprintf(stderr, "no progress at task %u\n", before); return 3; }
@@ -351,7 +342,7 @@ int main(int argc, char** argv) {
     }
     if (verbose || !ok)
         fprintf(stderr, "seed %u N %u T %u S %u block %u order %d feat %d shards %u: placed %u inf %u | rounds %llu (%.1f tasks each) cut: exhausted %u exception %u uncounted %u -> %s\n", seed,
-                N, T, S, B, order, feat, G, ref.ctl.ncommit, ref.ctl.ninf, (unsigned long long)rounds, rounds ? (double)T / (double)rounds : 0.0, head.cut_exhausted, head.cut_exception,
-                head.cut_uncounted, ok ? "OK" : "FAIL");
+                N, T, S, B, order, feat, G, ref.ctl.ncommit, ref.ctl.ninf, (unsigned long long)rounds, rounds ? (double)T / (double)rounds : 0.0, sh[0].blk.cut_exhausted, sh[0].blk.cut_exception,
+                sh[0].blk.cut_uncounted, ok ? "OK" : "FAIL");
     return ok ? 0 : 1;
 }

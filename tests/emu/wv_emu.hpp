@@ -98,6 +98,10 @@ struct Block {
     std::vector<void*> last_site;   // per thread: return address of its last collective / barrier call (deadlock report)
     std::vector<u64> ncoll;
 };
+inline u32& blockidx_z() {   // third grid dimension (wv::block_z())
+    static u32 v = 0;
+    return v;
+}
 inline u32& blockidx_y() {   // second grid dimension (wv::block_y()): set by the harness around a launch
     static u32 v = 0;
     return v;
@@ -271,6 +275,7 @@ inline u32 lane() { return emu::B()->cur & 63u; }
 inline u32 wave() { return emu::B()->cur >> 6; }
 inline u32 block() { return emu::blockidx(); }
 inline u32 block_y() { return emu::blockidx_y(); }
+inline u32 block_z() { return emu::blockidx_z(); }
 inline u64* lds() { return emu::B()->lds.data(); }
 
 inline u64 ballot(bool p) { return emu::collective(emu::OP_BALLOT, p ? 1 : 0, 0); }

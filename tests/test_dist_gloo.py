@@ -137,6 +137,7 @@ def _rounds_worker(rank, world, port, q, emu, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     seed, N, T, S, block, order, feat = case
     prop_bytes = 8 + 16 * 16 + 24   # sizeof(R6Prop): level, n_cand, 2 x 32 half-word entries, the exception-list candidate
+    send_bytes = block * prop_bytes + 144   # + sizeof(R7Tail): what a rank contributes to a round's exchange (swp_resolve7.hpp r7_send_bytes)
     proc = subprocess.Popen([emu] + [str(x) for x in (seed, N, T, S, block, order, feat, world)] + ["r%d" % rank], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     rounds = 0
     try:
@@ -148,8 +149,8 @@ def _rounds_worker(rank, world, port, q, emu, case):
             assert len({int(f.item()) for f in all_flags}) == 1, "the ranks disagree on whether the batch is done: %s" % all_flags
             if not go:
                 break
-            mine = torch.frombuffer(bytearray(proc.stdout.read(block * prop_bytes)), dtype=torch.uint8)
-            assert mine.numel() == block * prop_bytes
+            mine = torch.frombuffer(bytearray(proc.stdout.read(send_bytes)), dtype=torch.uint8)
+            assert mine.numel() == send_bytes
             gathered = torch.empty(world * mine.numel(), dtype=torch.uint8)
             dist.all_gather_into_tensor(gathered, mine)     # rank order: [rank 0's block][rank 1's block]...
             proc.stdin.write(gathered.numpy().tobytes())

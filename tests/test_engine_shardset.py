@@ -184,3 +184,19 @@ def test_node_matches_and_enforce_are_split_by_owner():
     ra = swhost.enforce(one, docs, by_node)
     rb = swhost.enforce(many, docs, by_node)
     assert ra == rb and any(ra.values())
+
+
+@pytest.mark.parametrize("case,N,shards", [("volumes_small", 1_500, 2), ("volumes_small", 1_500, 5), ("volumes_mid", 20_000, 4)])
+def test_csi_volumes_over_shards_match_oracle_digests(case, N, shards):
+    """CSI volumes through the node-range shards (VERDICT r4 missing #3; volumes.go:223-316): every shard holds the volume table, the owner
+    of a placed task's node chooses and reserves its volumes (chooseTaskVolumes + reserveTaskVolumes on the device), the other shards
+    learn the reservation from the trailer behind its next proposals — a usage pinned to a node of another range. The script of
+    tests/bigcases.py (tasks with mounts placed, a third of them deleted, new ones placed against what is left) against the digests
+    the oracle produced offline for one sequential scheduler."""
+    want = json.load(open(os.path.join(GOLD, "big_%s.json" % case)))
+    os.environ["SWP_HOST"] = "cxx"
+    sched = swhost.HostScheduler(shards=shards, nodes_per_shard=_cap(N, shards))
+    got = bigcases.CASES[case](sched)
+    assert sched.e.stats()["last_resolver"] == 7
+    assert got["placed"] == want["placed"] and got["released"] == want["released"]
+    assert got["ticks"] == want["ticks"]
