@@ -415,6 +415,10 @@ struct ShardSet {
     uint32_t cap = 0;              // node slots per shard: global index i = shard i / cap, local index i % cap
     Interner nodes;                // SWP_SPACE_NODE_ID of the set (lowest free index first, as every engine's)
     uint32_t hi = 0;               // highest global index handed out so far + 1
+    // The UNION engine (owned, on shard 0's device): one more replica of every replicated table, and — only while a call for task
+    // GROUPS runs — the whole nodeSet by global index, copied from the shards' mirrors (swp_shardset.hpp ss::schedule_groups).
+    swp_engine* uni = nullptr;
+    std::vector<swp_engine*> all;  // sh + uni: who a replicated call goes to
 };
 
 struct swp_engine {
@@ -3297,7 +3301,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     const char* env_dbg = getenv("SWP_DBG");
     const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
     const char* env_blk = getenv("SWP_R6_BLOCK");
-    uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : R6_BLOCK_DEFAULT_CAP));   // (as large as the commit kernel's LDS allows: below)
     const size_t lds_budget = 160 * 1024 - 512;
     {   // the commit kernel keeps the TK row of ALL shards' nodes next to the block's lists: large node sets get smaller blocks
         uint32_t hw_all = 0;
@@ -3660,7 +3664,7 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
     const char* env_dbg = getenv("SWP_DBG");
     const uint32_t dbg_bits = env_dbg ? (uint32_t)atoi(env_dbg) : 0u;
     const char* env_blk = getenv("SWP_R6_BLOCK");
-    uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : 512u));
+    uint32_t block = std::min<uint32_t>(r6_block_max(), std::max<uint32_t>(1u, env_blk ? (uint32_t)atoi(env_blk) : R6_BLOCK_DEFAULT_CAP));   // (as large as the commit kernel's LDS allows: below)
     const size_t lds_budget = 160 * 1024 - 512;
     // every rank must choose the same row mode: task rows whenever any rank might (the choice only depends on the task list, which is shared)
     const char* env_tr = getenv("SWP_R6_TASKROWS");

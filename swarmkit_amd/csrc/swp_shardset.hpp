@@ -42,8 +42,8 @@ inline uint32_t foreign_pin(uint32_t g, uint32_t l) { return VOL_PIN_FOREIGN | (
 #define SS_BROADCAST_ID(e, S, id_out, call)                                                                       \
     do {                                                                                                          \
         uint32_t first_ = 0;                                                                                      \
-        for (size_t q_ = 0; q_ < (S).sh.size(); ++q_) {                                                           \
-            swp_engine* c = (S).sh[q_];                                                                           \
+        for (size_t q_ = 0; q_ < (S).all.size(); ++q_) {                                                          \
+            swp_engine* c = (S).all[q_];                                                                          \
             uint32_t got_ = 0;                                                                                    \
             uint32_t* out_ = &got_;                                                                               \
             const int rc_ = (call);                                                                               \
@@ -80,11 +80,24 @@ int create(const swp_config* cfg, const int32_t* devices, uint32_t n_shards, uin
         }
         S->sh.push_back(child);
     }
+    {   // the union engine: on shard 0's device; it holds no node until a call for task groups fills it
+        swp_config c{};
+        if (cfg) c = *cfg;
+        c.device = S->sh[0]->device;
+        c.shard_rank = c.shard_count = 0;
+        const int rc = swp_create(&c, &S->uni);
+        if (rc) {
+            for (swp_engine* x : S->sh) swp_destroy(x);
+            return rc;
+        }
+        S->all = S->sh;
+        S->all.push_back(S->uni);
+    }
     e->device = S->sh[0]->device;
     e->set = S.release();
     {   // the service the enforcer's pseudo tasks carry (swp_enforce interns it on first use: here every shard has it from the start)
         static const char kDummy[] = "\0swp-enforce";
-        for (swp_engine* c : e->set->sh) {
+        for (swp_engine* c : e->set->all) {
             uint32_t id = 0;
             (void)swp_intern(c, SWP_SPACE_SERVICE, kDummy, sizeof kDummy - 1, &id);
         }
@@ -94,7 +107,7 @@ int create(const swp_config* cfg, const int32_t* devices, uint32_t n_shards, uin
 }
 
 void destroy(swp_engine* e) {
-    for (swp_engine* c : e->set->sh) swp_destroy(c);
+    for (swp_engine* c : e->set->all) swp_destroy(c);
     delete e->set;
     e->set = nullptr;
     delete e;
@@ -102,7 +115,7 @@ void destroy(swp_engine* e) {
 
 int reset(swp_engine* e, uint32_t hint) {
     ShardSet& S = *e->set;
-    for (swp_engine* c : S.sh)
+    for (swp_engine* c : S.all)
         if (int rc = swp_reset(c, hint / (uint32_t)S.sh.size() + 1)) return take_error(e, c, rc);
     S.nodes.init(false);
     S.hi = 0;
@@ -272,7 +285,7 @@ int mount_set(swp_engine* e, const swp_mount* mounts, uint32_t n, uint32_t* id_o
     return SWP_OK;
 }
 int volume_upsert(swp_engine* e, uint32_t volume, const swp_volume* v, const uint32_t* topo_off, const swp_seg* segs) {
-    for (swp_engine* c : e->set->sh)
+    for (swp_engine* c : e->set->all)
         if (int rc = swp_volume_upsert(c, volume, v, topo_off, segs)) return take_error(e, c, rc);
     return SWP_OK;
 }
@@ -436,8 +449,100 @@ void batch_free(swp_engine* e, swp_batch* b) {
     delete b;
 }
 
-int schedule_groups(swp_engine* e, const swp_task_desc*, const uint32_t*, uint32_t, int32_t*, uint32_t*, uint32_t*) {
-    return e->fail(SWP_EUNSUPPORTED, "task groups over a shard set");
+// ---- task groups (scheduleTaskGroup with k > 1, scheduler.go:694-748) over a shard set --------------------------------------------
+// Which of several equal-key nodes a full heap keeps and the order heap-sort pops them in are artefacts of container/heap's array
+// mechanics (nodeset.go:107-120, decision_tree.go:24-52): the reference's answer is the replay of its heap operations over ALL nodes
+// in node order, a serial chain that ONE wave runs (k_groups2) and that is the call's whole cost (162 M of 200 M cycles).
+// What a range could contribute — Process and the nodeLess key of its nodes — is the part that already runs ahead of that chain at no
+// cost. So a call for task groups is not split: the shards' node mirrors are copied into the UNION engine by global index (the
+// canonical order: shard order is node order), k_groups2 runs there exactly as on one engine, and every placement goes back to the
+// owner of its node. Bit-exact by construction; what it costs is the copy (host mirrors: O(nodes) per call, one call per tick).
+void fill_union(ShardSet& S) {
+    swp_engine* U = S.uni;
+    U->nodes.clear();
+    U->nodes.resize(S.hi);
+    U->svc_nodes.clear();
+    U->fail_nodes.clear();
+    U->port_nodes.clear();
+    U->n_present = 0;
+    for (size_t g = 0; g < S.sh.size(); ++g) {
+        const swp_engine* c = S.sh[g];
+        for (uint32_t l = 0; l < c->nodes.size(); ++l) {
+            const HostNode& h = c->nodes[l];
+            if (!h.present) continue;
+            const uint32_t gi = (uint32_t)g * S.cap + l;
+            HostNode& u = U->nodes[gi];
+            u = h;
+            u.row.node = gi;
+            U->n_present++;
+            for (const auto& kv : h.svc) U->svc_nodes[kv.first].v.emplace_back(gi, kv.second);   // (ascending gi: the flat map stays sorted)
+            for (const auto& kv : h.fails) U->fail_nodes[kv.first.first].insert(gi);
+            for (uint64_t k : h.ports) U->port_nodes[k].insert(gi);
+        }
+    }
+    U->n_nodes = S.hi;
+    U->dev_static_dirty = U->dev_dynamic_dirty = true;
+    U->vol_static_dirty = U->vol_dyn_dirty = true;
+    U->saved.valid = false;
+    const swp_engine* c0 = S.sh[0];   // the volumes' usage: every shard holds the same numbers; a pin becomes a global index
+    for (size_t v = 0; v < U->volumes.size() && v < c0->volumes.size(); ++v) {
+        swp_volume_usage use = c0->volumes[v].use;
+        if (use.pin >= VOL_PIN_FOREIGN && use.pin < SWP_PIN_MANY) use.pin = ((use.pin >> 26) & 31u) * S.cap + (use.pin & ((1u << 26) - 1u));
+        U->volumes[v].use = use;
+    }
+}
+
+int schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node, uint32_t* out_hist, uint32_t* out_att) {
+    ShardSet& S = *e->set;
+    swp_engine* U = S.uni;
+    fill_union(S);
+    int rc = out_att ? swp_schedule_groups_volumes(U, groups, sizes, n_groups, out_node, out_hist, out_att) : swp_schedule_groups(U, groups, sizes, n_groups, out_node, out_hist);
+    if (rc) return take_error(e, U, rc);
+    // NodeInfo.addTask for every placement, on the owner of its node (its device rows follow from its mirror at the next call)
+    uint64_t off = 0, placed = 0, total = 0;
+    for (uint32_t q = 0; q < n_groups; ++q) {
+        const swp_task_desc& d = groups[q];
+        for (uint32_t i = 0; i < sizes[q]; ++i) {
+            const int32_t n = out_node[off + i];
+            if (n < 0) continue;
+            uint32_t g = 0, l = 0;
+            if (!locate(S, (uint32_t)n, &g, &l)) return e->fail(SWP_EHIP, "the union engine placed a task on node index %d, which the set does not hold", n);
+            host_apply_placement(S.sh[g], l, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
+            S.sh[g]->dev_dynamic_dirty = true;
+            S.sh[g]->host_dirty_since_save = true;
+            ++placed;
+        }
+        off += sizes[q];
+        total += sizes[q];
+    }
+    if (out_att)   // the volumes' usage as the call left it: to every shard, pinned to its own node or to a foreign one
+        for (size_t v = 0; v < U->volumes.size(); ++v) {
+            if (!U->volumes[v].present) continue;
+            const swp_volume_usage use = U->volumes[v].use;
+            uint32_t g = 0, l = 0;
+            const bool pinned = use.pin < SWP_PIN_MANY && locate(S, use.pin, &g, &l);
+            for (size_t q = 0; q < S.sh.size(); ++q) {
+                if (v >= S.sh[q]->volumes.size()) continue;
+                swp_volume_usage cu = use;
+                if (pinned) cu.pin = q == g ? l : foreign_pin(g, l);
+                else if (use.pin < SWP_PIN_MANY) cu.pin = SWP_PIN_MANY;
+                S.sh[q]->volumes[v].use = cu;
+                S.sh[q]->vol_dyn_dirty = true;
+            }
+        }
+    U->nodes.clear();   // (the union view is rebuilt by the next call: nothing may go stale in it)
+    U->nodes.shrink_to_fit();
+    U->n_nodes = U->n_present = 0;
+    U->svc_nodes.clear();
+    U->fail_nodes.clear();
+    U->port_nodes.clear();
+    U->dev_static_dirty = U->dev_dynamic_dirty = true;
+    e->stats.batches++;
+    e->stats.tasks += total;
+    e->stats.placed += placed;
+    e->stats.infeasible += total - placed;
+    e->stats.last_resolver = U->stats.last_resolver;
+    return SWP_OK;
 }
 
 int state_save(swp_engine* e) {
