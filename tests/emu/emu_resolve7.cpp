@@ -99,21 +99,108 @@ struct Shard {
     u32 first = 0;
 };
 
+// The cluster after a batch, as the NEXT batch finds it (the incremental path between two batches: scheduler.go:254-396, nodeinfo.go:66-154):
+// a tenth of the nodes is drained (they leave `valid` and every static class), the tasks of the first batch that sat on them are gone,
+// and so is every fifth of the other placed tasks — NodeInfo.removeTask: reservations and generic counts back, host ports free, the
+// counts down, the service's exception-list entry shrunk or dropped. As many new tasks of the same services arrive. What the engine's
+// host mirror + swp_batch_prepare derive from the events, derived here from the sequential model's final state.
+static Problem next_problem(const Problem& p, const State& fin) {
+    Problem q = p;
+    q.cpu = fin.cpu; q.mem = fin.mem; q.total = fin.total; q.portmap = fin.portmap; q.gcnt = fin.gcnt;
+    auto drained = [&](u32 n) { return (n * 7u + 3u) % 10u == 0; };
+    for (u32 n = 0; n < p.N; ++n)
+        if (drained(n)) {
+            q.valid[n >> 6] &= ~(1ull << (n & 63));
+            for (u32 c = 0; c < p.n_sc; ++c) q.sc[(size_t)c * p.Wn + (n >> 6)] &= ~(1ull << (n & 63));
+        }
+    // per service: node -> (count, failures), from the final exception lists
+    std::vector<std::map<u32, std::pair<u32, u32>>> cnt(p.S);
+    for (u32 s = 0; s < p.S; ++s)
+        for (u32 e = p.list_off[s]; e < p.list_off[s + 1]; ++e)
+            if (fin.list_node[e] != LIST_EMPTY) cnt[s][fin.list_node[e]] = {fin.list_svc[e], fin.list_fail[e]};
+    std::vector<u32> again;   // the tasks whose replacements form the next batch
+    u32 k = 0;
+    for (u32 j = 0; j < p.T; ++j) {
+        const int32_t n = fin.out[j];
+        if (n < 0) continue;
+        const bool gone = drained((u32)n) || (k++ % 5u == 0);
+        if (!gone) continue;
+        again.push_back(j);
+        const RTask& r = p.rt[j];
+        q.cpu[n] += r.cpu;
+        q.mem[n] += r.mem;
+        if (!p.tg.empty())
+            for (u32 g = p.gs_off[p.tg[j]]; g < p.gs_off[p.tg[j] + 1]; ++g) q.gcnt[(size_t)p.rg_kind[p.gs_row[g]] * p.N + n] += p.rg_val[p.gs_row[g]];
+        if (r.flags & RT_PORTS)
+            for (u32 z = p.pset_off[r.pset]; z < p.pset_off[r.pset + 1]; ++z) q.portmap[(size_t)p.pset_ids[z] * p.Wn + ((u32)n >> 6)] &= ~(1ull << (n & 63));
+        if (!(r.flags & RT_UNCOUNTED)) {
+            q.total[n] -= 1;
+            auto it = cnt[r.svc].find((u32)n);
+            if (it != cnt[r.svc].end() && it->second.first > 0) it->second.first -= 1;
+        }
+    }
+    q.T = (u32)again.size();
+    q.rt.clear();
+    std::vector<u32> ntasks(p.S, 0), rank;
+    for (u32 j : again) {
+        q.rt.push_back(p.rt[j]);
+        q.rt.back().flags &= ~((RT_DCLS_MASK << RT_DC_SHIFT) | (RT_DCLS_MASK << RT_DM_SHIFT));   // (the demand classes are the batch's own)
+        rank.push_back(ntasks[p.rt[j].svc]++);
+    }
+    if (!p.tg.empty()) {
+        q.tg.clear();
+        for (u32 j : again) q.tg.push_back(p.tg[j]);
+    }
+    q.X.assign((size_t)p.S * p.Wn, 0);
+    q.list_node.clear(); q.list_svc.clear(); q.list_fail.clear();
+    q.list_off.assign(p.S + 1, 0);
+    std::vector<u32> init_cnt(p.S, 0);
+    for (u32 s = 0; s < p.S; ++s) {
+        q.list_off[s] = (u32)q.list_node.size();
+        for (const auto& kv : cnt[s]) {
+            if (kv.second.first == 0 && kv.second.second == 0) continue;   // the service left the node
+            q.list_node.push_back(kv.first);
+            q.list_svc.push_back(kv.second.first);
+            q.list_fail.push_back(kv.second.second);
+            q.X[(size_t)s * p.Wn + (kv.first >> 6)] |= 1ull << (kv.first & 63);
+        }
+        init_cnt[s] = (u32)q.list_node.size() - q.list_off[s];
+        for (u32 i = 0; i < ntasks[s]; ++i) { q.list_node.push_back(LIST_EMPTY); q.list_svc.push_back(0); q.list_fail.push_back(0); }
+    }
+    q.list_off[p.S] = (u32)q.list_node.size();
+    for (u32 j = 0; j < q.T; ++j) q.rt[j].slot = q.list_off[q.rt[j].svc] + init_cnt[q.rt[j].svc] + rank[j];
+    return q;
+}
+
+static int run_batch(Problem& p, State& ref, u32 seed, u32 B, int order, int feat, u32 G, bool verbose, bool task_rows, int my_rank);
+
 int main(int argc, char** argv) {
-    if (argc < 9) { fprintf(stderr, "usage: %s seed N T S block order features(0..2) shards [v] [t]\n", argv[0]); return 2; }
+    if (argc < 9) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) shards [v] [t] [r<rank>] [c: a second batch after node and task events]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = std::min(atoi(argv[7]), 3);
     const u32 G = atoi(argv[8]);
-    bool verbose = false, task_rows = false;
+    bool verbose = false, task_rows = false, churn = false;
     int my_rank = -1;   // >= 0: the rank variant
     for (int i = 9; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 't') task_rows = true;
         if (argv[i][0] == 'r') my_rank = atoi(argv[i] + 1);
+        if (argv[i][0] == 'c') churn = true;
     }
     if (my_rank >= (int)atoi(argv[8])) { fprintf(stderr, "rank %d of %s shards\n", my_rank, argv[8]); return 2; }
     if (G < 1 || G > R7_MAXS || G > N) { fprintf(stderr, "1..%d shards, at most one per node\n", R7_MAXS); return 2; }
     Problem p = make_problem(seed, N, T, S, order, feat);
+    State ref;
+    int rc = run_batch(p, ref, seed, B, order, feat, G, verbose, task_rows, my_rank);
+    if (rc || !churn) return rc;
+    // the incremental path: drains, NodeInfo.removeTask, new tasks — then a second sharded batch over the same ranges
+    Problem p2 = next_problem(p, ref);
+    State ref2;
+    return run_batch(p2, ref2, seed, B, order, feat, G, verbose, task_rows, my_rank);
+}
+
+static int run_batch(Problem& p, State& ref, u32 seed, u32 B, int order, int feat, u32 G, bool verbose, bool task_rows, int my_rank) {
+    const u32 N = p.N, T = p.T, S = p.S;
     std::set<i64> sc, sm;
     for (const RTask& r : p.rt)
         if (r.flags & RT_RES) { sc.insert(r.cpu); sm.insert(r.mem); }
@@ -127,7 +214,7 @@ int main(int argc, char** argv) {
         if (r.flags & RT_RES) r.flags |= (ic[r.cpu] << RT_DC_SHIFT) | (im[r.mem] << RT_DM_SHIFT);
     if (task_rows) n_dc = n_dm = 0;
 
-    State ref = initial_state(p);
+    ref = initial_state(p);
     std::vector<u64> F;
     scan_window(p, ref, 0, T, F);
     ref_window(p, ref, 0, T, F);

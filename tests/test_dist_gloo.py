@@ -135,11 +135,14 @@ def _rounds_worker(rank, world, port, q, emu, case):
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    seed, N, T, S, block, order, feat = case
+    seed, N, T, S, block, order, feat = case[:7]
+    churn = len(case) > 7 and case[7] == "c"   # a second batch after node and task events (the emulation's "c" flag)
     prop_bytes = 8 + 16 * 16 + 24   # sizeof(R6Prop): level, n_cand, 2 x 32 half-word entries, the exception-list candidate
     send_bytes = block * prop_bytes + 144   # + sizeof(R7Tail): what a rank contributes to a round's exchange (swp_resolve7.hpp r7_send_bytes)
-    proc = subprocess.Popen([emu] + [str(x) for x in (seed, N, T, S, block, order, feat, world)] + ["r%d" % rank], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    proc = subprocess.Popen([emu] + [str(x) for x in (seed, N, T, S, block, order, feat, world)] + ["r%d" % rank] + (["c"] if churn else []), stdin=subprocess.PIPE,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     rounds = 0
+    batches_left = 2 if churn else 1
     try:
         while True:
             go = int.from_bytes(proc.stdout.read(4), "little")
@@ -148,7 +151,10 @@ def _rounds_worker(rank, world, port, q, emu, case):
             dist.all_gather(all_flags, flags)
             assert len({int(f.item()) for f in all_flags}) == 1, "the ranks disagree on whether the batch is done: %s" % all_flags
             if not go:
-                break
+                batches_left -= 1
+                if batches_left == 0:
+                    break
+                continue   # the rank applies the drains and removals of ITS nodes, then the second sharded batch starts
             mine = torch.frombuffer(bytearray(proc.stdout.read(send_bytes)), dtype=torch.uint8)
             assert mine.numel() == send_bytes
             gathered = torch.empty(world * mine.numel(), dtype=torch.uint8)
@@ -168,8 +174,9 @@ def _rounds_worker(rank, world, port, q, emu, case):
 
 
 # (seed, nodes, tasks, services, block, task order, feature level)
-@pytest.mark.parametrize("world,case", [(2, (2, 700, 900, 30, 64, 0, 1)), (3, (3, 1000, 700, 40, 64, 2, 2)), (3, (7, 500, 600, 40, 32, 0, 3)), (2, (13, 401, 500, 8, 128, 1, 1))],
-                         ids=["2ranks-maxrep", "3ranks-ports-uncounted", "3ranks-generic", "2ranks-service-major"])
+@pytest.mark.parametrize("world,case", [(2, (2, 700, 900, 30, 64, 0, 1)), (3, (3, 1000, 700, 40, 64, 2, 2)), (3, (7, 500, 600, 40, 32, 0, 3)), (2, (13, 401, 500, 8, 128, 1, 1)),
+                                        (2, (3, 1000, 900, 40, 64, 2, 2, "c")), (3, (7, 500, 900, 40, 32, 0, 3, "c"))],
+                         ids=["2ranks-maxrep", "3ranks-ports-uncounted", "3ranks-generic", "2ranks-service-major", "2ranks-churn-node-updates-between-two-batches", "3ranks-churn-generic"])
 def test_device_rounds_protocol_over_gloo(world, case):
     """Every rank's shard ends exactly where the sequential model over the WHOLE node set puts it; the ranks take the same number of
     rounds and agree on the end of the batch in the same round."""
@@ -188,3 +195,5 @@ def test_device_rounds_protocol_over_gloo(world, case):
     for rank, rc, rounds, err in got:
         assert rc == 0 and "-> OK" in err, (rank, rc, err)
         assert rounds == got[0][2] and 0 < rounds < case[2]   # lock-step rounds; an exchange decides more than one task on average
+        if len(case) > 7:   # the incremental path: drains + NodeInfo.removeTask on every rank's own nodes, then a second sharded batch
+            assert err.count("-> OK") == 2, (rank, err)

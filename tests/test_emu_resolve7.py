@@ -43,6 +43,13 @@ CASES = [
     (7, 500, 800, 40, 64, 0, 3, 3, ""),        # feature level 3: generic reservations (HasEnough rows per shard, Claim in k_r7_apply on the owner)
     (8, 885, 1000, 125, 64, 2, 3, 4, ""),
     (10, 1200, 900, 90, 128, 0, 3, 8, "t"),    # ... in task-rows mode
+    # "c": the incremental path — after the batch a tenth of the nodes is drained, the tasks on them and a fifth of
+    # the others are removed (NodeInfo.removeTask: reservations, generic counts, host ports, counts, exception-list entries), as many
+    # new tasks arrive, and a SECOND sharded batch runs over the same ranges against the state the events left
+    (3, 1000, 1200, 40, 64, 2, 2, 3, "c"),
+    (5, 2000, 1500, 150, 128, 0, 1, 8, "c"),
+    (7, 500, 900, 40, 32, 0, 3, 4, "c"),
+    (13, 401, 700, 8, 128, 1, 1, 2, "ct"),
 ]
 
 
@@ -52,3 +59,5 @@ def test_sharded_rounds_source_matches_sequential_model(emu_bin, case):
     r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr
+    if "c" in case[8]:   # both batches
+        assert r.stderr.count("-> OK") == 2, r.stderr[-2000:]
