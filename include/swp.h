@@ -193,7 +193,10 @@ typedef struct {
     uint32_t active;        /* Spec.Availability == ACTIVE (volumes.go:265) */
     uint32_t n_topologies;  /* VolumeInfo.AccessibleTopology: topology t = segs[topo_off[t] .. topo_off[t + 1]) */
 } swp_volume;
-/* addOrUpdateVolume (volumes.go:62-82): `volume` is the SWP_SPACE_VOLUME index. An update keeps the usage. */
+/* addOrUpdateVolume (volumes.go:62-82): `volume` is the SWP_SPACE_VOLUME index. To the letter: for a volume the set holds already the
+ * reference assigns the new object to a COPY of its map entry (:71), so what checkVolume reads — availability, access mode, driver,
+ * topologies — stays what the FIRST call said; the call only adds the volume to the group the new object names (byGroup is never pruned,
+ * :74-78: a volume whose Group changes is a member of both). The usage is kept. */
 int swp_volume_upsert(swp_engine*, uint32_t volume, const swp_volume* v, const uint32_t* topo_off, const swp_seg* segs);
 #define SWP_PIN_NONE 0xFFFFFFFFu   /* nobody uses the volume */
 #define SWP_PIN_MANY 0xFFFFFFFEu   /* its users sit on more than one node */

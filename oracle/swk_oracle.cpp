@@ -964,11 +964,13 @@ void VolumeSet::add_or_update(const VolumePtr& v) {
     if (it == volumes_.end()) {
         Info info;
         info.volume = v;
+        info.store = v;
         info.order = next_order_++;
         volumes_.emplace(v->id, std::move(info));
-    } else {
-        it->second.volume = v;   // only the volume object: the tasks stay
-    }
+    } else it->second.store = v;   // (this harness has no store: the event's object is what store.GetVolume would return from now on)
+    // else: volumes.go:68-72 says `info.volume = v` — on `info`, a COPY of the map's value (vs.volumes is map[string]volumeInfo, structs
+    // by value): the assignment is lost, the set keeps the volume object of the FIRST call, and that is what checkVolume reads from then
+    // on (availability, access mode, driver, accessible topology). Restated as it behaves, not as its comment intends.
     std::vector<std::string>& set = by_group_[v->group];
     if (std::find(set.begin(), set.end(), v->id) == set.end()) set.push_back(v->id);
     by_name_[v->name] = v->id;
@@ -1030,9 +1032,9 @@ std::vector<std::pair<std::string, std::vector<std::string>>> VolumeSet::free_vo
     std::vector<std::pair<std::string, std::vector<std::string>>> out;
     for (auto& kv : volumes_) {
         Info& info = kv.second;
-        if (!info.volume) continue;
+        if (!info.store) continue;
         std::vector<std::string> changed;
-        for (PublishStatus& st : info.volume->publish_status) {
+        for (PublishStatus& st : info.store->publish_status) {
             auto n = info.nodes.find(st.node_id);
             if ((n == info.nodes.end() || n->second == 0) && st.state == VolumePublished) {   // volumes.go:200-203
                 st.state = VolumePendingNodeUnpublish;

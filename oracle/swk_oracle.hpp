@@ -264,7 +264,8 @@ class VolumeSet {
   public:
     struct Usage { std::string node_id; bool read_only = false; };
     struct Info {
-        VolumePtr volume;
+        VolumePtr volume;                          // volumeInfo.volume: the object of the FIRST addOrUpdateVolume (volumes.go:71 updates a copy)
+        VolumePtr store;                           // the latest object: stands for the store's copy, which freeVolumes reads (volumes.go:189)
         std::map<std::string, Usage> tasks;        // task id -> usage
         std::map<std::string, int> nodes;          // node id -> reference count
         uint64_t order = 0;                        // creation ordinal (canonical group order)

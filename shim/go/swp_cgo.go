@@ -6,7 +6,13 @@
 // holding include/swp.h and libswp.so of this repository). It mirrors every nodeSet / NodeInfo mutator into the engine and
 // replaces the two branches of tick() (scheduler.go:456-469) with swp_schedule_groups / swp_schedule_batch; everything
 // else of the reference — event handlers, store commits, noSuitableNode — stays as it is. Tasks the engine declines
-// (CSI cluster volumes, more than 32 host ports, more than 8 generic kinds) keep running through the reference's scheduleTaskGroup.
+// (more than 32 host ports, more than 8 generic kinds or cluster mounts, Named generic reservations) keep running through the
+// reference's scheduleTaskGroup. CSI cluster volumes ARE on the engine: volumeSet keeps its maps, the hooks below mirror them
+// (upsertVolume from addOrUpdateVolume, pushVolumeUsage from reserveVolume / releaseVolume, nodeCSI with every node row), the batch
+// returns the attachments chooseTaskVolumes would have picked and the caller runs its own reserveTaskVolumes on them.
+//
+// A manager on a multi-GPU box holds a shard SET instead of an engine (newSwpShardSet: swp_shardset_create): the same handle type,
+// the same calls — the set routes node calls to the owner of the node's range and runs a batch over all ranges.
 //
 // NOT COMPILED IN THIS REPOSITORY: the build image has no Go toolchain. The same layer, with the same function names and
 // the reference's line numbers, is implemented and tested in C++ (swarmkit_amd/csrc/swp_sched.cpp, include/swp_sched.h);
@@ -51,13 +57,29 @@ type failureBucket struct {
 	version uint64
 }
 
-func newSwpEngine(device int) (*swpEngine, error) {
+// vs: the scheduler's volumeSet (Scheduler.volumes): mountSet resolves a mount's Source through vs.byName
+func newSwpEngine(device int, vs *volumeSet) (*swpEngine, error) {
 	cfg := C.swp_config{device: C.int32_t(device)}
 	var e *C.swp_engine
 	if rc := C.swp_create(&cfg, &e); rc != C.SWP_OK {
 		return nil, fmt.Errorf("swp_create: %s", C.GoString(C.swp_last_error(nil))) // SWP_ENODEVICE: keep the Go path
 	}
-	return &swpEngine{e: e, pushed: map[failureBucket]uint32{}}, nil
+	return &swpEngine{e: e, vs: vs, nodeIdx: map[string]C.uint32_t{}, pushed: map[failureBucket]uint32{}}, nil
+}
+
+// newSwpShardSet: one engine per GPU of the box behind ONE handle (swp_shardset_create, include/swp.h "A shard SET"): node i of the
+// canonical order lives on engine i / nodesPerShard. Everything below is the same for a set and for an engine.
+func newSwpShardSet(devices []int, nodesPerShard int, vs *volumeSet) (*swpEngine, error) {
+	cfg := C.swp_config{device: C.int32_t(devices[0])}
+	devs := make([]C.int32_t, len(devices))
+	for i, d := range devices {
+		devs[i] = C.int32_t(d)
+	}
+	var e *C.swp_engine
+	if rc := C.swp_shardset_create(&cfg, &devs[0], C.uint32_t(len(devs)), C.uint32_t(nodesPerShard), &e); rc != C.SWP_OK {
+		return nil, fmt.Errorf("swp_shardset_create: %s", C.GoString(C.swp_last_error(nil)))
+	}
+	return &swpEngine{e: e, vs: vs, nodeIdx: map[string]C.uint32_t{}, pushed: map[failureBucket]uint32{}}, nil
 }
 
 func (s *swpEngine) close() { C.swp_destroy(s.e) }
@@ -85,6 +107,7 @@ func (s *swpEngine) nodeIndex(id string) C.uint32_t {
 		s.idxNode = append(s.idxNode, "")
 	}
 	s.idxNode[idx] = id
+	s.nodeIdx[id] = idx
 	return idx
 }
 
@@ -195,6 +218,11 @@ func (s *swpEngine) upsert(n NodeInfo) error {
 	for spec := range n.usedHostPorts {
 		C.swp_node_port(s.e, row.node, C.uint32_t(spec.protocol), C.uint32_t(spec.publishedPort), 1)
 	}
+	if n.Description != nil {
+		s.nodeCSI(row.node, n.Description.CSIInfo)
+	} else {
+		s.nodeCSI(row.node, nil)
+	}
 	return s.pushGeneric(row.node, n.AvailableResources.Generic)
 }
 
@@ -267,7 +295,30 @@ func (s *swpEngine) genericSet(rs []*api.GenericResource) (C.uint32_t, bool) {
 	return id, true
 }
 
-func (s *swpEngine) remove(nodeID string) { C.swp_node_remove(s.e, s.intern(C.SWP_SPACE_NODE_ID, nodeID)) } // nodeSet.remove, nodeset.go:46-48
+// remove: nodeSet.remove, nodeset.go:46-48. The index is LOOKED UP, never interned: interning an id the engine does not know would
+// take an index out of the free pool for a node that is not there. The engine hands the index to the next new node: forget it here.
+func (s *swpEngine) remove(nodeID string) {
+	idx, ok := s.nodeIdx[nodeID]
+	if !ok {
+		return
+	}
+	C.swp_node_remove(s.e, idx)
+	delete(s.nodeIdx, nodeID)
+	s.idxNode[idx] = ""
+	for b := range s.pushed { // failure buckets of the index that is free again
+		if b.node == idx {
+			delete(s.pushed, b)
+		}
+	}
+	for id, info := range s.vs.volumes { // a volume in use on that node: none of the set's nodes is that node any more (Scheduler::repinVolumes)
+		for _, usage := range info.tasks {
+			if usage.nodeID == nodeID {
+				s.pushVolumeUsage(id, info)
+				break
+			}
+		}
+	}
+}
 
 // drainBurst: a burst of availability flips (EventUpdateNode) in one call; Engine::node_update_dynamic_many
 func (s *swpEngine) updateDynamic(rows []C.swp_node_dynamic) error {
@@ -509,11 +560,23 @@ func (s *swpEngine) upsertVolume(v *api.Volume) error {
 	if len(segs) > 0 {
 		p = &segs[0]
 	}
-	if rc := C.swp_volume_upsert(s.e, s.intern(C.SWP_SPACE_VOLUME, v.ID), &sv, &off[0], p); rc != C.SWP_OK {
+	idx := s.intern(C.SWP_SPACE_VOLUME, v.ID)
+	for len(s.volumeID) <= int(idx) {
+		s.volumeID = append(s.volumeID, "")
+	}
+	s.volumeID[idx] = v.ID
+	if rc := C.swp_volume_upsert(s.e, idx, &sv, &off[0], p); rc != C.SWP_OK {
 		return s.err("swp_volume_upsert", rc)
 	}
 	return nil
 }
+
+// Where the hooks go in volumes.go (three one-line additions, each behind `if vs.swp != nil`):
+//   addOrUpdateVolume (:62-82)   vs.swp.upsertVolume(v)            — after the maps are updated
+//   reserveVolume     (:156-167) vs.swp.pushVolumeUsage(volumeID, info)
+//   releaseVolume     (:169-178) vs.swp.pushVolumeUsage(volumeID, info)
+// and in scheduler.go: createOrUpdateNode / buildNodeSet call swp.upsert (which carries the node's CSIInfo), the nodeSet's remove
+// calls swp.remove.
 
 // pushVolumeUsage: after every volumeSet.reserveVolume / releaseVolume (volumes.go:156-187) — what checkVolume derives from info.tasks
 func (s *swpEngine) pushVolumeUsage(volumeID string, info volumeInfo) {
@@ -718,12 +781,45 @@ func (sch *Scheduler) scheduleOneOffsSWP(ctx context.Context, tasks []*api.Task,
 	sch.pushFailures(time.Now(), kept)
 	out := make([]C.int32_t, len(descs))
 	hist := make([]C.uint32_t, len(descs)*C.SWP_NFILTERS)
-	if rc := C.swp_schedule_batch(sch.swp.e, &descs[0], C.uint32_t(len(descs)), &out[0], &hist[0]); rc != C.SWP_OK {
-		return tasks // the call was refused as a whole, nothing was applied: the Go scan takes this tick's one-off tasks
+	var mounted []C.uint32_t // the batch's tasks with cluster mounts: their attachments are read back
+	for i := range descs {
+		if descs[i].flags>>C.SWP_TASK_MOUNTS_SHIFT != 0 {
+			mounted = append(mounted, C.uint32_t(i))
+		}
 	}
+	att := make([]C.uint32_t, len(mounted)*C.SWP_MAX_MOUNTS)
+	if len(mounted) == 0 {
+		if rc := C.swp_schedule_batch(sch.swp.e, &descs[0], C.uint32_t(len(descs)), &out[0], &hist[0]); rc != C.SWP_OK {
+			return tasks // the call was refused as a whole, nothing was applied: the Go scan takes this tick's one-off tasks
+		}
+	} else { // the same in three steps: the batch handle is needed for swp_batch_attachments (Scheduler::runOneOffs)
+		var b *C.swp_batch
+		if rc := C.swp_batch_prepare(sch.swp.e, &descs[0], C.uint32_t(len(descs)), &b); rc != C.SWP_OK {
+			return tasks
+		}
+		rc := C.swp_batch_run(sch.swp.e, b)
+		if rc == C.SWP_OK {
+			rc = C.swp_batch_fetch(sch.swp.e, b, &out[0], &hist[0])
+		}
+		if rc == C.SWP_OK {
+			rc = C.swp_batch_attachments(sch.swp.e, b, &mounted[0], C.uint32_t(len(mounted)), &att[0])
+		}
+		C.swp_batch_free(sch.swp.e, b)
+		if rc != C.SWP_OK {
+			return tasks
+		}
+	}
+	m := 0
 	for i, t := range kept {
+		var vols []*api.VolumeAttachment
+		if m < len(mounted) && int(mounted[m]) == i {
+			vols = sch.swp.attachments(t, att[m*C.SWP_MAX_MOUNTS:(m+1)*C.SWP_MAX_MOUNTS])
+			m++
+		}
 		if out[i] >= 0 {
-			sch.assign(ctx, t, sch.swp.idxNode[out[i]], decisions) // newT.NodeID / Status ASSIGNED (scheduler.go:871-879); only NodeInfo.Tasks changes: the engine already did the arithmetic
+			// newT.NodeID / Status ASSIGNED (scheduler.go:871-879), newT.Volumes = vols + reserveTaskVolumes(&newT) (:862-874); only
+			// NodeInfo.Tasks changes: the engine already did the arithmetic
+			sch.assign(ctx, t, sch.swp.idxNode[out[i]], vols, decisions)
 		} else {
 			sch.noSuitableNodeWith(ctx, t, explainFromHist(hist[i*C.SWP_NFILTERS:(i+1)*C.SWP_NFILTERS]), decisions)
 		}
@@ -753,7 +849,19 @@ func (sch *Scheduler) scheduleGroupsSWP(ctx context.Context, groups []map[string
 	sch.pushFailures(time.Now(), all)
 	out := make([]C.int32_t, len(all))
 	hist := make([]C.uint32_t, len(descs)*C.SWP_NFILTERS)
-	if rc := C.swp_schedule_groups(sch.swp.e, &descs[0], &sizes[0], C.uint32_t(len(descs)), &out[0], &hist[0]); rc != C.SWP_OK {
+	anyMounts := false
+	for i := range descs {
+		anyMounts = anyMounts || descs[i].flags>>C.SWP_TASK_MOUNTS_SHIFT != 0
+	}
+	var att []C.uint32_t
+	var rc C.int
+	if anyMounts { // out_att[i * SWP_MAX_MOUNTS + m]: the volume chosen for mount m of the call's i-th task
+		att = make([]C.uint32_t, len(all)*C.SWP_MAX_MOUNTS)
+		rc = C.swp_schedule_groups_volumes(sch.swp.e, &descs[0], &sizes[0], C.uint32_t(len(descs)), &out[0], &hist[0], &att[0])
+	} else {
+		rc = C.swp_schedule_groups(sch.swp.e, &descs[0], &sizes[0], C.uint32_t(len(descs)), &out[0], &hist[0])
+	}
+	if rc != C.SWP_OK {
 		for _, ts := range order { // a group beyond the engine's capacity (SWP_ERANGE): nothing was applied, the Go path takes them
 			tg := map[string]*api.Task{}
 			for _, t := range ts {
@@ -767,7 +875,11 @@ func (sch *Scheduler) scheduleGroupsSWP(ctx context.Context, groups []map[string
 	for g, ts := range order {
 		for _, t := range ts {
 			if out[i] >= 0 {
-				sch.assign(ctx, t, sch.swp.idxNode[out[i]], decisions)
+				var vols []*api.VolumeAttachment
+				if anyMounts {
+					vols = sch.swp.attachments(t, att[i*C.SWP_MAX_MOUNTS:(i+1)*C.SWP_MAX_MOUNTS])
+				}
+				sch.assign(ctx, t, sch.swp.idxNode[out[i]], vols, decisions)
 			} else {
 				sch.noSuitableNodeWith(ctx, t, explainFromHist(hist[g*C.SWP_NFILTERS:(g+1)*C.SWP_NFILTERS]), decisions)
 			}
@@ -787,64 +899,11 @@ func (sch *Scheduler) rollbackSWP(failed []schedulingDecision) {
 }
 
 // sortedByEnqueue, assign and noSuitableNodeWith are three-line wrappers around code that exists in scheduler.go
-// (the task order of a group, the body of scheduleNTasksOnNodes' inner loop :868-897 without the numeric addTask, and
-// noSuitableNode :928-971 with the explanation passed in instead of s.pipeline.Explain()).
+// (the task order of a group, the body of scheduleNTasksOnNodes' inner loop :857-897 without the numeric addTask — newT.Volumes = the
+// attachments passed in, then s.volumes.reserveTaskVolumes(&newT) exactly as :862-874 — and noSuitableNode :928-971 with the
+// explanation passed in instead of s.pipeline.Explain()).
 
-// scheduleOneOffsShardedSWP: the same one-off branch over SEVERAL engines — one per GPU of the box, engine g holding node range g of
-// the canonical order (sch.swps, sch.shardFirst[g] = index of its first node) — with the rounds on the devices: ONE call per tick
-// (swp_shard_run, include/swp.h "node-range shards"; nodeset.go:57-120 is the scan it distributes). A manager that runs one process
-// per GPU calls swp_rccl_unique_id / swp_rccl_init once and swp_shard_run_rank here instead.
-func (sch *Scheduler) scheduleOneOffsShardedSWP(ctx context.Context, tasks []*api.Task, decisions map[string]schedulingDecision) []*api.Task {
-	var rest []*api.Task
-	descs := make([]C.swp_task_desc, 0, len(tasks))
-	kept := make([]*api.Task, 0, len(tasks))
-	for _, t := range tasks {
-		d, ok := sch.swps[0].desc(t) // predicate sets are registered on every engine in the same order: the ids agree
-		if ok && d.flags>>C.SWP_TASK_MOUNTS_SHIFT != 0 {
-			ok = false // cluster mounts: a volume's use is cluster-wide state, swp_shard_* refuses them (SWP_EUNSUPPORTED)
-		}
-		if !ok {
-			rest = append(rest, t)
-			continue
-		}
-		for _, e := range sch.swps[1:] {
-			e.desc(t)
-		}
-		descs = append(descs, d)
-		kept = append(kept, t)
-	}
-	if len(kept) == 0 {
-		return rest
-	}
-	G := len(sch.swps)
-	engines := make([]*C.swp_engine, G)
-	batches := make([]*C.swp_batch, G)
-	for g, e := range sch.swps {
-		engines[g] = e.e
-		if rc := C.swp_batch_prepare(e.e, &descs[0], C.uint32_t(len(descs)), &batches[g]); rc != C.SWP_OK {
-			for h := 0; h < g; h++ { // the batches prepared so far go back
-				C.swp_batch_free(sch.swps[h].e, batches[h])
-			}
-			return append(rest, kept...) // the reference decides this tick
-		}
-	}
-	shard := make([]C.int32_t, len(kept))
-	node := make([]C.int32_t, len(kept))
-	hist := make([]C.uint32_t, len(kept)*C.SWP_NFILTERS)
-	rc := C.swp_shard_run(&engines[0], &batches[0], C.uint32_t(G), 0, &shard[0], &node[0], &hist[0])
-	for g, e := range sch.swps {
-		C.swp_batch_free(e.e, batches[g])
-	}
-	if rc != C.SWP_OK {
-		return append(rest, kept...)
-	}
-	for i, t := range kept {
-		if shard[i] < 0 {
-			sch.noSuitableNodeWith(ctx, t, explainFromHist(hist[i*C.SWP_NFILTERS:(i+1)*C.SWP_NFILTERS]), decisions)
-			continue
-		}
-		e := sch.swps[shard[i]]
-		sch.assign(ctx, t, e.idxNode[node[i]], decisions) // as in scheduleOneOffsSWP: the owning engine already did the arithmetic
-	}
-	return rest
-}
+// Several GPUs: the scheduler holds a shard SET (newSwpShardSet) in sch.swp and the two functions above run unchanged — one-off
+// batches become sharded batches (the rounds on the devices, include/swp.h "node-range shards"; nodeset.go:57-120 is the scan they
+// distribute), task groups run on the set's union engine, tasks with cluster mounts included. A manager that runs one PROCESS per GPU
+// calls swp_rccl_unique_id / swp_rccl_init once and swp_shard_run_rank per batch instead (bench.py --gpus N is that deployment).

@@ -313,6 +313,7 @@ struct HostNode {
 struct HostVolume {   // swp_volume_upsert / swp_volume_set_usage
     bool present = false;
     swp_volume spec{};
+    std::vector<uint32_t> groups;   // byGroup memberships: spec.group first, then every group a later addOrUpdateVolume named (never pruned: volumes.go:74-78)
     std::vector<uint32_t> topo_off{0};
     std::vector<swp_seg> segs;
     swp_volume_usage use{0, 0, SWP_PIN_NONE, 0};
@@ -666,7 +667,8 @@ int flush_volumes(swp_engine* e) {
             if (!hv.present) continue;
             vflags[v] = (hv.spec.active ? VOL_ACTIVE : 0u) | (hv.spec.scope == SWP_VOL_SCOPE_MULTI_NODE ? VOL_MULTI : 0u) | ((hv.spec.sharing & 3u) << VOL_SHARING_SHIFT);
             vdriver[v] = hv.spec.driver;
-            if (hv.spec.group < G) members[hv.spec.group].push_back(v);
+            for (uint32_t gq : hv.groups)
+                if (gq < G) members[gq].push_back(v);
             for (uint32_t t = 0; t < hv.spec.n_topologies; ++t) {
                 for (uint32_t q = hv.topo_off[t]; q < hv.topo_off[t + 1]; ++q) { vseg.push_back(hv.segs[q].key); vseg.push_back(hv.segs[q].value); }
                 topo_off.push_back((uint32_t)vseg.size() / 2);
@@ -2504,8 +2506,20 @@ int swp_volume_upsert(swp_engine* e, uint32_t volume, const swp_volume* v, const
     if (v->scope > 1 || v->sharing > 3) return e->fail(SWP_EINVAL, "volume %u: unknown access mode", volume);
     if (volume >= e->volumes.size()) e->volumes.resize(volume + 1);
     HostVolume& hv = e->volumes[volume];
+    if (hv.present) {
+        // addOrUpdateVolume for a volume the set holds already (volumes.go:62-72): `info.volume = v` assigns to a COPY of the map's value
+        // (vs.volumes is a map of structs), so the volume object checkVolume reads — availability, access mode, driver, accessible
+        // topology — stays the FIRST one for ever; what the call does change is byGroup, which gains the volume under the group the new
+        // object names and is never pruned (:74-78). Restated to the letter.
+        if (std::find(hv.groups.begin(), hv.groups.end(), v->group) == hv.groups.end()) {
+            hv.groups.push_back(v->group);
+            e->vol_static_dirty = true;
+        }
+        return SWP_OK;
+    }
     hv.present = true;
     hv.spec = *v;
+    hv.groups.assign(1, v->group);
     hv.topo_off.assign(1, 0);
     hv.segs.clear();
     for (uint32_t t = 0; t < v->n_topologies; ++t) {

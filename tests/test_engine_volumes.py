@@ -176,6 +176,30 @@ def test_a_volume_that_is_not_created_yet_and_one_that_cannot_be_shared():
     assert b.tick()[0][1] == ""
 
 
+def test_an_update_of_a_known_volume_keeps_its_first_object_and_joins_the_new_group():
+    """addOrUpdateVolume to the letter (volumes.go:62-82; the oracle's test of the same name says why): the engine's swp_volume_upsert keeps
+    the FIRST object of a known volume and only adds it to the new object's group — oracle and engine, call by call."""
+    b = Both()
+    b.create_node({"ID": "n1", "Status": {"State": orc.READY}, "Description": {}})
+    b.set_service("svc")
+    paused = kv.canned_volume(1, group="g1")
+    paused["Spec"]["Availability"] = "PAUSE"
+    b.update_volume(paused)
+    b.update_volume(kv.canned_volume(1, group="g1"))
+    b.create_task(_mount_task("t1", "svc", [kv.cluster_mount("volume1", "/a")]))
+    assert b.tick()[0][3] == "no suitable node (cannot fulfill requested CSI volume mounts on 1 node)"
+    b.update_volume(kv.canned_volume(2, group="g1"))
+    moved = kv.canned_volume(2, group="g2")
+    moved["Spec"]["Availability"] = "PAUSE"
+    moved["Spec"]["Annotations"]["Name"] = "renamed"
+    b.update_volume(moved)
+    for k, src in enumerate(["group:g1", "group:g2", "volume2", "renamed"]):
+        b.create_task(_mount_task("u%d" % k, "svc", [kv.cluster_mount(src, "/m")]))
+    got = {d[0]: (d[1], d[4]) for d in b.tick()}
+    assert all(got["u%d" % k][0] == "n1" and got["u%d" % k][1][0][0] == "volumeID2" for k in range(4)), got
+    b.check_volumes()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
 def test_random_clusters_with_volumes(seed):
     """Nodes with CSI topologies, volumes of every access mode in groups, tasks with one to three cluster mounts (named, grouped, read-only)

@@ -190,3 +190,30 @@ def test_a_volume_reserved_twice_by_one_task_keeps_a_reference():
     o.delete_task(t)
     assert o.volume_info(v["ID"])["Nodes"] == {"n": 1} and o.volume_info(v["ID"])["Tasks"] == {}
     assert o.free_volumes() == []
+
+
+def test_an_update_of_a_known_volume_keeps_its_first_object_and_joins_the_new_group():
+    """volumes.go:62-82 to the letter: vs.volumes is a map of STRUCT values, so `info.volume = v` (:71) assigns to a copy — the volume
+    object checkVolume reads stays the first one the set saw (a PAUSED volume that is updated to ACTIVE stays unusable; an ACTIVE one
+    that is updated to PAUSE stays usable) — while byGroup gains the volume under the new object's group and keeps it under the old one
+    (never pruned, :74-78) and byName gains the new name."""
+    o = orc.Oracle()
+    o.create_node({"ID": "n1", "Status": {"State": orc.READY}, "Description": {}})
+    o.set_service("svc")
+    paused = kv.canned_volume(1, group="g1")
+    paused["Spec"]["Availability"] = "PAUSE"
+    o.update_volume(paused)
+    o.update_volume(kv.canned_volume(1, group="g1"))   # ACTIVE now, says the store — the scheduler's copy never hears of it
+    o.create_task(sc.pending("t1", "svc", Spec={"Container": {"Mounts": [kv.cluster_mount("volume1", "/a")]}}))
+    assert o.tick()[0]["Err"] == "no suitable node (cannot fulfill requested CSI volume mounts on 1 node)"
+    active = kv.canned_volume(2, group="g1")
+    o.update_volume(active)
+    moved = kv.canned_volume(2, group="g2")
+    moved["Spec"]["Availability"] = "PAUSE"
+    moved["Spec"]["Annotations"]["Name"] = "renamed"
+    o.update_volume(moved)
+    # still ACTIVE for checkVolume, a member of g1 AND g2, known as volume2 AND renamed
+    for k, src in enumerate(["group:g1", "group:g2", "volume2", "renamed"]):
+        o.create_task(sc.pending("u%d" % k, "svc", Spec={"Container": {"Mounts": [kv.cluster_mount(src, "/m")]}}))
+    got = {d["ID"]: (d["NodeID"], [v["ID"] for v in d.get("Volumes") or []]) for d in o.tick()}
+    assert {k: got[k] for k in ("u0", "u1", "u2", "u3")} == {k: ("n1", ["volumeID2"]) for k in ("u0", "u1", "u2", "u3")}
