@@ -3541,7 +3541,11 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[swp] sharded rounds over %u engines: %u rounds of %u (%.1f decided each) | cut by an exhausted list %u, an exception-list task %u, an uncounted task %u | set-up %.2f ms, rounds %.2f ms, explain + results %.2f ms\n", G,
                 hh.rounds, block, (double)T / std::max<uint32_t>(hh.rounds, 1), hh.cut_exhausted, hh.cut_exception, hh.cut_uncounted, ms(t_begin, t_rounds0), ms(t_rounds0, t_rounds1),
-                ms(t_rounds1, std::chrono::steady_clock::now()));
+                ms(t_rounds1, std::chrono::steady_clock::now()));        const double rr_ = std::max<uint32_t>(hh.rounds, 1);
+        fprintf(stderr, "[swp] k_r7_commit (shard 0) shader cycles per round: prologue + fold %.0f, matching (wave 0) %.0f (list loads %.0f, walks %.0f), apply %.0f | %.1f matcher stops at an emptied half-word per round\n",
+                hh.cyc[0] * 64.0 / rr_, hh.cyc[1] * 64.0 / rr_, hh.cyc_load * 64.0 / rr_, hh.cyc_walk * 64.0 / rr_, hh.cyc[3] * 64.0 / rr_, hh.reseats / rr_);
+        fprintf(stderr, "[swp] ... of the list loads: waiting for a group's lists %.0f, its head records %.0f, seating %.0f (%.1f steps of the seating loop, stops included) per round\n", hh.cyc_g[0] * 64.0 / rr_,
+                hh.cyc_g[1] * 64.0 / rr_, hh.cyc_g[2] * 64.0 / rr_, hh.cyc_g[3] / rr_);
     }
     cleanup();
     return SWP_OK;

@@ -173,7 +173,7 @@ inline __host__ __device__ size_t r6_commit_lds(u32 n_words, u32 block, u32 n_rr
 // the node-range shards' side of the commit kernel (defined in swp_resolve7.hpp; only its R7 instances use them)
 WV_DEV u32 r7_tk_words(const R7Args* m);
 WV_DEV bool r7_any_dead(const R7Args* m);
-WV_DEV void r7_fold_into(const R7Args* m, u32 i, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh);
+WV_DEV void r7_fold_into(const R7Args* m, u32 i, bool have, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh);
 WV_DEV u32 r7_addr(const R7Args* m, u32 shard, u32 node);
 WV_DEV u32 r7_local(const R7Args* m, u32 addr, u32 my, bool* here);
 WV_DEV u32 r7_take_trailers(const R6Args& a, const R7Args* m, u32 my, u32 round);
@@ -739,7 +739,7 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
     // every thread stages the lists of its task (wave g: the block's group g): the matcher walks them with a cursor (an entry is looked
     // at once) instead of holding all of them in registers. No barrier: a group's flag is published when its lists are in LDS.
     if constexpr (R7) {
-        if (tid < n) r7_fold_into(m7, tid, a.block, L_hw, L_hb, H_level, H_meta, sh);
+        if ((tid & ~63u) < n) r7_fold_into(m7, tid < n ? tid : 0u, tid < n, a.block, L_hw, L_hb, H_level, H_meta, sh);   // (whole waves: it ballots)
     } else if (tid < n) {
         const R6Prop* q = a.prop + tid;
         for (int k = 0; k < 2 * R6_CAND; ++k) {

@@ -89,64 +89,85 @@ WV_DEV u32 r7_local(const R7Args* m, u32 addr, u32 my, bool* here) {
 }
 
 // ---- fold: the records all shards hold for block-local task i -> one list in global node order, staged into the commit kernel's LDS ----
-// Straight-line on purpose (every loop has a constant trip count and is unrolled, a shard's record is chosen by selects): the heads of
-// all shards' records are requested together, then all 2 * R6_CAND entries — a loop over "the entries shard g contributes" would pay one
-// L2 round trip PER ENTRY, and the matching wave folds its own group before it can start (measured: 93 µs a round instead of 58).
-WV_DEV void r7_fold_into(const R7Args* m, u32 i, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh) {
+// The matching wave folds its own group before it can start, so this is on the round's critical path and is written for few
+// instructions with all loads of a step in flight together: the heads of all shards' records at once (one unrolled, predicated batch),
+// then steps in which every lane copies the entries of ITS next contributing shard as one batch of wide loads — usually one step: the
+// first shard that holds the task's minimum level fills its list. (A loop over "the entries shard g contributes" pays an L2 round
+// trip per entry: 93 µs a round; a select tree over all shards per entry pays 2 000 instructions per task: 87 µs; a narrow load per
+// entry: 82 µs; the single engine's commit takes 58.)
+// (called by WHOLE waves — the ballots below — `have`: the lane has a task; i: its block-local index, 0 for a lane without one)
+WV_DEV void r7_fold_into(const R7Args* m, u32 i, bool have, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh) {
     const u32 G = m->n_shards;
     const R6Prop* pp[R7_MAXS];
     u32 lv[R7_MAXS], nc[R7_MAXS], hwb[R7_MAXS];
     WV_UNROLL
-    for (u32 g = 0; g < R7_MAXS; ++g) {
+    for (u32 g = 0; g < R7_MAXS; ++g) {   // the heads of all shards' records: one batch of loads
+        const bool in = g < G && have;
         pp[g] = m->prop[g < G ? g : 0u] + i;
-        lv[g] = g < G ? pp[g]->level : R6_NONE;
-        nc[g] = g < G ? pp[g]->n_cand : 0u;
+        lv[g] = in ? pp[g]->level : R6_NONE;
+        nc[g] = in ? pp[g]->n_cand : 0u;
         hwb[g] = m->hw_base[g < G ? g : 0u];
     }
-    const u32 flags = pp[0]->flags;   // (bit 0: uncounted, bit 1: cluster mounts — properties of the task: the same on every shard)
     u32 level = R6_NONE;
     WV_UNROLL
     for (u32 g = 0; g < R7_MAXS; ++g) level = min(level, lv[g]);
-    // the entries every shard contributes: the shards on the minimum level in range order, until one of them was itself cut short
-    // (what lies behind a truncated list is unknown: later shards cannot be appended)
-    u32 off[R7_MAXS], take[R7_MAXS], cnt = 0;
-    bool closed = false;
-    WV_UNROLL
-    for (u32 g = 0; g < R7_MAXS; ++g) {
-        const bool on = g < G && level != R6_NONE && lv[g] == level && !closed;
-        const u32 c = on ? nc[g] & 0x7FFFFFFFu : 0u;
-        const u32 t = min(c, 2u * R6_CAND - cnt);
-        off[g] = cnt;
-        take[g] = t;
-        cnt += t;
-        if (on && (t < c || (nc[g] >> 31))) closed = true;
-    }
-    WV_UNROLL
-    for (u32 e = 0; e < 2 * R6_CAND; ++e) {
+    const u32 flags = m->prop[0][i].flags;   // (bit 0: uncounted, bit 1: cluster mounts — properties of the task: the same on every shard)
+    // The shards on the minimum level in range order, until one of them was itself cut short (what lies behind a truncated list is
+    // unknown: later shards cannot be appended). Every LANE walks its own shards — a step takes the next shard on the lane's level,
+    // whichever it is — so the wave takes as many steps as its neediest task has contributing shards: one or two.
+    u32 cnt = 0, gnext = 0;
+    bool closed = level == R6_NONE;
+    while (wv::ballot(!closed && cnt < 2u * R6_CAND)) {
         const R6Prop* p = pp[0];
-        u32 k = 0, base = 0;
+        u32 ncs = 0, base = 0, gs = R7_MAXS;
         WV_UNROLL
-        for (u32 g = 0; g < R7_MAXS; ++g) {
-            const bool mine = e >= off[g] && e < off[g] + take[g];
-            p = mine ? pp[g] : p;
-            k = mine ? e - off[g] : k;
-            base = mine ? hwb[g] : base;
+        for (u32 g = R7_MAXS; g-- > 0;) {   // (downwards: the LOWEST shard >= gnext on the level wins the selects)
+            const bool hit = g >= gnext && lv[g] == level;
+            p = hit ? pp[g] : p;
+            ncs = hit ? nc[g] : ncs;
+            base = hit ? hwb[g] : base;
+            gs = hit ? g : gs;
         }
-        const bool have = e < cnt;
-        const u32 hw = have ? p->hw[k] : 0u, hb = have ? p->hb[k] : 0u;
-        L_hw[(size_t)e * block + i] = (unsigned short)(have ? base + hw : 0u);
-        L_hb[(size_t)e * block + i] = hb;
+        const bool on = !closed && cnt < 2u * R6_CAND && gs < R7_MAXS;
+        if (!closed && gs == R7_MAXS) closed = true;   // no shard behind holds the level
+        const u32 c = on ? ncs & 0x7FFFFFFFu : 0u;
+        const u32 t = min(c, 2u * R6_CAND - cnt);
+        if (t != 0) {
+            // the record's two arrays as they lie in memory — unconditional, so that the compiler requests them as wide loads, all in
+            // flight together (a load per entry under its own predicate is 64 narrow requests a lane: measured 25 µs a round) —
+            // and only the entries the list takes go to LDS
+            // (the indices first, then the candidate bits: half the registers of one batch of 64)
+            u32 v[2 * R6_CAND];
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hw[k];
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k)
+                if (k < t) L_hw[(size_t)(cnt + k) * block + i] = (unsigned short)(base + v[k]);
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hb[k];
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k)
+                if (k < t) L_hb[(size_t)(cnt + k) * block + i] = v[k];
+        }
+        cnt += t;
+        if (on && (t < c || (ncs >> 31))) closed = true;
+        gnext = gs + 1u;
     }
+    WV_UNROLL
+    for (u32 e = 0; e < 2 * R6_CAND; ++e)
+        if (have && e >= cnt) {   // (the unused entries of a list are zero: a seating step reads a fixed number of them)
+            L_hw[(size_t)e * block + i] = 0;
+            L_hb[(size_t)e * block + i] = 0;
+        }
     // no plain candidate anywhere: nodeLess over the shards' exception-list candidates (scheduler.go:708-735) — (failure class, svcCount),
     // then (ActiveTasksCount, GLOBAL index)
     u64 bhi = KEY_NONE, blo = KEY_NONE;
     u32 bshard = 0, bnode = 0, bentry = 0;
-    if (level == R6_NONE) {
-        WV_UNROLL
-        for (u32 g = 0; g < R7_MAXS; ++g) {
-            if (g >= G) continue;
-            const u64 hi = pp[g]->exc_hi, lo0 = pp[g]->exc_lo;
-            const u32 en = pp[g]->exc_entry;
+    if (wv::ballot(have && level == R6_NONE)) {
+        for (u32 g = 0; g < G; ++g) {
+            const R6Prop* p = m->prop[g] + i;
+            const u64 hi = (have && level == R6_NONE) ? p->exc_hi : KEY_NONE, lo0 = p->exc_lo;
+            const u32 en = p->exc_entry;
             if (hi == KEY_NONE) continue;
             const u64 lo = (lo0 & 0xFFFFFFFF00000000ull) | (u64)(m->first_node[g] + (u32)lo0);
             if (hi < bhi || (hi == bhi && lo < blo)) {
@@ -158,6 +179,7 @@ WV_DEV void r7_fold_into(const R7Args* m, u32 i, u32 block, unsigned short* L_hw
             }
         }
     }
+    if (!have) return;
     H_level[i] = level;
     H_meta[i] = cnt | (level == R6_NONE && bhi != KEY_NONE ? R7M_EXC : 0u) | ((flags & 1u) ? R7M_UNC : 0u) | ((flags & 2u) ? R7M_CSI : 0u);
     if (i == 0) {   // only the block's first task may be decided from the exception lists: where its candidate sits

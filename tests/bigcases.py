@@ -274,4 +274,7 @@ CASES = {
     "refbench_net_5k_100k": lambda s: run_refbench(s, 5_000, 100_000, True),
     "refbench_100k_100k": lambda s: run_refbench(s, 100_000, 100_000, False),
     "refbench_small": lambda s: run_refbench(s, 100, 3_000, True),
+    # the reference's largest benchmark shape, BenchmarkScheduler100kNodes1MTasks (scheduler_test.go:3355-3357): 1M tasks of ONE service
+    # on 100k nodes — ten tasks a node, the water-filling path (k_waterfill) at its extreme
+    "refbench_100k_1m": lambda s: run_refbench(s, 100_000, 1_000_000, False),
 }
