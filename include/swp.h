@@ -221,7 +221,9 @@ typedef struct {
 int swp_mount_set(swp_engine*, const swp_mount* mounts, uint32_t n, uint32_t* id_out);
 /* isVolumeAvailableOnNode for every mount of the set on one node, in order, each seeing the ones before it (chooseTaskVolumes,
  * volumes.go:101-140): out[i] = the volume index for mount i. Returns SWP_OK with *n_out = the set's size, or *n_out = 0 when a mount
- * finds no volume (the reference's "cannot find volume to satisfy mount"; *failed_mount = its position). Reserves nothing. */
+ * finds no volume (the reference's "cannot find volume to satisfy mount"; *failed_mount = its position; out[] then holds what the mounts
+ * in front of it chose and SWP_NO_VOLUME from the failing one on: the caller's volumeSet counts that prefix, see swp_batch_attachments).
+ * Reserves nothing. */
 int swp_choose_volumes(swp_engine*, uint32_t mount_set, uint32_t node, uint32_t* out /* [SWP_MAX_MOUNTS] */, uint32_t* n_out, uint32_t* failed_mount);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -337,9 +339,12 @@ int swp_batch_fetch(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fa
  * benchmarking: run → results → swp_state_restore → run …) */
 int swp_batch_results(swp_engine*, swp_batch*, int32_t* out_node, uint32_t* out_fail_hist);
 /* The volumes the batch chose for the cluster mounts of `n` of its tasks (chooseTaskVolumes on the node each was placed on,
- * scheduler.go:857-872): out[i * SWP_MAX_MOUNTS + m] = the SWP_SPACE_VOLUME index for mount m of task tasks[i], SWP_NO_VOLUME for
- * every mount of a task that was not placed, has no mounts, or for which a mount found no volume (the reference assigns such a task
- * without attachments). After swp_batch_fetch / swp_batch_results. */
+ * scheduler.go:857-872): out[i * SWP_MAX_MOUNTS + m] = the SWP_SPACE_VOLUME index for mount m of task tasks[i]; SWP_NO_VOLUME for
+ * every mount of a task that was not placed or has no mounts. A task for which mount k found no volume is assigned WITHOUT attachments
+ * (as the reference does) — its row holds the volumes mounts 0 .. k-1 had chosen by then and SWP_NO_VOLUME from k on: a row is a full
+ * set of attachments iff none of the task's mounts reads SWP_NO_VOLUME. (The prefix matters to the caller's books: chooseTaskVolumes
+ * reserves what it picks and releases each volume ONCE, so a volume picked for m mounts of the task leaves m - 1 counts on the node
+ * whether the choice succeeds or not, volumes.go:104-131,162-178.) After swp_batch_fetch / swp_batch_results. */
 int swp_batch_attachments(swp_engine*, swp_batch*, const uint32_t* tasks, uint32_t n, uint32_t* out);
 void swp_batch_free(swp_engine*, swp_batch*);
 /* Device-side snapshot / restore of all mutable node state (cpu, mem, total, per-service counts,

@@ -985,8 +985,9 @@ void VolumeSet::remove(const std::string& id) {
     volumes_.erase(it);
 }
 
-bool VolumeSet::choose_task_volumes(const Task& task, const NodeInfo& node, std::vector<VolumeAttachment>* out, std::string* err) {
+bool VolumeSet::choose_task_volumes(const Task& task, const NodeInfo& node, std::vector<VolumeAttachment>* out, std::string* err, std::vector<VolumeAttachment>* prefix) {
     out->clear();
+    if (prefix) prefix->clear();
     if (!task.has_container) return true;
     bool ok = true;
     for (const Mount& m : task.mounts) {
@@ -1001,7 +1002,10 @@ bool VolumeSet::choose_task_volumes(const Task& task, const NodeInfo& node, std:
         out->push_back(VolumeAttachment{candidate, m.source, m.target});
     }
     for (const VolumeAttachment& va : *out) release(va.id, task.id);   // the deferred release: the caller reserves for good
-    if (!ok) out->clear();   // (the reference returns nil attachments with the error)
+    if (!ok) {
+        if (prefix) *prefix = *out;   // (harness only: what had been chosen in front of the failing mount — the engine double replays it)
+        out->clear();   // (the reference returns nil attachments with the error)
+    }
     return ok;
 }
 
@@ -1450,7 +1454,7 @@ TaskPtr Scheduler::task_fit_node(const TaskPtr& t, const std::string& node_id) {
     {
         std::vector<VolumeAttachment> attachments;
         std::string verr;
-        if (!volumes_.choose_task_volumes(*t, ni, &attachments, &verr)) {
+        if (!volumes_.choose_task_volumes(*t, ni, &attachments, &verr, &new_t->chosen_prefix)) {
             new_t->err = verr;
             all_tasks_[t->id] = new_t;
             return new_t;
@@ -1616,7 +1620,7 @@ int Scheduler::schedule_n_on_nodes(int n, OrderedTasks& group, std::vector<NodeI
         auto new_t = std::make_shared<Task>(*t);
         {   // scheduler.go:857-874: choose the volumes on this node (an error is logged, the task is assigned without them), then reserve
             std::vector<VolumeAttachment> attachments;
-            volumes_.choose_task_volumes(*t, *node, &attachments, nullptr);
+            volumes_.choose_task_volumes(*t, *node, &attachments, nullptr, &new_t->chosen_prefix);
             new_t->volumes = attachments;
         }
         new_t->node_id = node->node->id;

@@ -161,6 +161,7 @@ struct Task {              // the api.Task field subset the path reads
     std::vector<PortConfig> ports;
     GenericList assigned_generic;      // AssignedGenericResources
     std::vector<VolumeAttachment> volumes;   // Volumes (written by the path: scheduler.go:677,872)
+    std::vector<VolumeAttachment> chosen_prefix;   // harness only (not a field of api.Task): what chooseTaskVolumes had picked in front of a mount that found no volume
 };
 using TaskPtr = std::shared_ptr<Task>;
 using NodePtr = std::shared_ptr<Node>;
@@ -273,7 +274,7 @@ class VolumeSet {
     void add_or_update(const VolumePtr& v);        // volumes.go:62-82
     void remove(const std::string& id);            // volumes.go:85-95
     // chooseTaskVolumes, volumes.go:101-140: false + *err = the reference's error string
-    bool choose_task_volumes(const Task& task, const NodeInfo& node, std::vector<VolumeAttachment>* out, std::string* err);
+    bool choose_task_volumes(const Task& task, const NodeInfo& node, std::vector<VolumeAttachment>* out, std::string* err, std::vector<VolumeAttachment>* prefix = nullptr);
     void reserve_task_volumes(const Task& task);   // volumes.go:144-154
     void reserve(const std::string& volume_id, const std::string& task_id, const std::string& node_id, bool read_only);   // :156-167
     void release(const std::string& volume_id, const std::string& task_id);                                              // :169-187

@@ -301,6 +301,14 @@ std::string encode_decisions(const std::vector<Decision>& ds) {
             }
             o += "],";
         }
+        if (!t.chosen_prefix.empty()) {   // harness only: the volumes chooseTaskVolumes had picked before a mount found none (the task has no attachments)
+            o += "\"VolumePrefix\":[";
+            for (size_t q = 0; q < t.chosen_prefix.size(); ++q) {
+                if (q) o += ",";
+                o += "\"" + t.chosen_prefix[q].id + "\"";
+            }
+            o += "],";
+        }
         put_ki(o, "OldState", ds[i].old_task->state, false);
         o += "}";
     }

@@ -1,6 +1,8 @@
 // swp_resolve6.hip — translation unit of the block resolver (k_r6_*, swp_resolve6.hpp) and its launchers.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "swp_launch.hpp"
 #include "swp_wave.hpp"
 #define SWP_R6_KERNELS
@@ -51,7 +53,11 @@ hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int
 // ---- CSI volumes (swp_volumes.hpp) ----
 hipError_t launch_vol_topology(const VolTopoArgs& a, hipStream_t s) {
     if (a.n_vol == 0 || a.n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_vol_topology, dim3((a.n_words * 64 + 255) / 256, a.n_vol), dim3(256), 0, s, a);
+    for (uint32_t v0 = 0; v0 < a.n_vol; v0 += 65535u) {   // (grid.y is a 16-bit quantity)
+        VolTopoArgs c = a;
+        c.vol0 = v0;
+        hipLaunchKernelGGL(k_vol_topology, dim3((a.n_words * 64 + 255) / 256, std::min<uint32_t>(65535u, a.n_vol - v0)), dim3(256), 0, s, c);
+    }
     return hipGetLastError();
 }
 hipError_t launch_vol_choose(const VolChooseArgs& a, hipStream_t s) {

@@ -482,10 +482,25 @@ class Scheduler {
         }
         out = json::dump(updates);
     }
-    // (One thing the reference's counts do that these do not: chooseTaskVolumes reserves every volume it picks for the task and releases
-    // them all on return, volumes.go:118-131 — but a release finds the task only ONCE per volume, so a volume that serves m of ONE task's
-    // mounts keeps m − 1 counts on the node for ever, whether the choice succeeds or not. The engine chooses here and reserves nothing on
-    // the way, so such a volume is unpublished from a node by freeVolumes when its last user is gone; the reference never does — DESIGN §8.)
+    // What chooseTaskVolumes leaves behind in the counts (volumes.go:104-131): it reserves every volume it picks for the task — a count on
+    // the node per CALL (:159) — and releases them all on return, but a release finds the task only ONCE per volume (:169-178), so a
+    // volume that serves m of ONE task's mounts keeps m − 1 counts on the node for ever, whether the choice succeeds or stops at a later
+    // mount. The engine chooses on the device and reserves nothing on the way; the remainder is booked here from what it chose (`att`:
+    // the first n entries, the prefix in front of a failing mount included) so that freeVolumes frees exactly what the reference frees.
+    void bookChooseRemainder(const uint32_t* att, size_t n, const std::string& nid) {
+        for (size_t q = 0; q < n; ++q) {
+            size_t m = 0;
+            bool first = true;
+            for (size_t z = 0; z < n; ++z)
+                if (att[z] == att[q]) {
+                    if (z < q) first = false;
+                    ++m;
+                }
+            if (!first || m < 2 || att[q] >= vol_idx_to_id_.size()) continue;
+            auto it = volumes_.find(vol_idx_to_id_[att[q]]);
+            if (it != volumes_.end()) it->second.nodes[nid] += (int64_t)(m - 1);
+        }
+    }
     // reserveTaskVolumes, volumes.go:144-154
     void reserveTaskVolumes(const Value& t) {
         const Value* vols = t.get("Volumes");
@@ -838,6 +853,7 @@ class Scheduler {
         const swp_task_desc d = taskDesc(t);
         uint32_t att[SWP_MAX_MOUNTS], n_out = 0, failed = 0;
         ck(swp_choose_volumes(e_, d.flags >> SWP_TASK_MOUNTS_SHIFT, ni.idx, att, &n_out, &failed), "swp_choose_volumes");
+        bookChooseRemainder(att, n_out ? n_out : std::min<size_t>(failed, cms.size()), as_str(ni.node.get("ID")));
         if (n_out == 0) {
             Value status = statusCopy(t);
             status.set("Err", Value::str("cannot find volume to satisfy mount with source " + as_str(cms[std::min<size_t>(failed, cms.size() - 1)]->get("Source"))));
@@ -1544,7 +1560,12 @@ class Scheduler {
         // newT.Volumes = attachments; reserveTaskVolumes(&newT) (scheduler.go:862-874): what the engine chose on the node, in mount order; a
         // mount that found no volume leaves the task without attachments (the reference logs the error and assigns it all the same)
         const std::vector<const Value*> cms = clusterMounts(t);
-        if (!cms.empty() && att != nullptr && att[0] != SWP_NO_VOLUME) {
+        size_t n_chosen = 0;   // the mounts chooseTaskVolumes found a volume for, in order (all of them: the task gets its attachments)
+        if (!cms.empty() && att != nullptr) {
+            while (n_chosen < cms.size() && att[n_chosen] != SWP_NO_VOLUME) ++n_chosen;
+            bookChooseRemainder(att, n_chosen, nid);
+        }
+        if (!cms.empty() && n_chosen == cms.size()) {
             Value vols = Value::array();
             for (size_t m = 0; m < cms.size(); ++m) {
                 if (att[m] >= vol_idx_to_id_.size()) fail(SWP_EINVAL, "engine returned an unknown volume index");

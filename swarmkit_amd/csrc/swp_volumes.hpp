@@ -107,7 +107,10 @@ WV_DEV u64 vol_filter_word(const VolView& v, u32 set, u32 w) {
 }
 
 // chooseTaskVolumes (volumes.go:101-140): out[i] = the volume of mount i on `node`, every mount seeing the reservations of the ones
-// before it. Returns the number of mounts, 0 when one of them finds no volume (*failed = its position; out[] is all VOL_NONE then).
+// before it. Returns the number of mounts, 0 when one of them finds no volume (*failed = its position): out[] then still holds what the
+// mounts in front of it chose, VOL_NONE from the failing one on — the reference returns no attachments in that case, but its temporary
+// reservations of that prefix leave a trace in the volumeSet's per-node counts (volumes.go:104-108, 124 with :162-178: a volume that serves
+// m mounts of the task is reserved m times and released once), which the host layer books from this prefix.
 WV_DEV u32 vol_choose(const VolView& v, u32 set, u32 node, u32* out, u32* failed) {
     VolTemp tmp;
     tmp.n = 0;
@@ -117,7 +120,6 @@ WV_DEV u32 vol_choose(const VolView& v, u32 set, u32 node, u32* out, u32* failed
         const VolMount m = v.ms_mount[q0 + i];
         const u32 vol = vol_for_mount(v, m, node, &tmp);
         if (vol == VOL_NONE) {
-            for (u32 k = 0; k < VOL_MAX_MOUNTS; ++k) out[k] = VOL_NONE;
             if (failed) *failed = i;
             return 0;
         }
@@ -154,7 +156,7 @@ struct VolChooseArgs { VolView vol; u32 set, node; u32* out; };   // out[0 .. VO
 
 // the topology bitmaps: T[vol] = {nodes n: IsInTopology(top(n, driver(vol)), accessible(vol))}
 struct VolTopoArgs {
-    u32 n_nodes, n_words, n_vol, pad;
+    u32 n_nodes, n_words, n_vol, vol0;   // vol0: the first volume of this launch (a grid's second dimension ends at 65 535: more volumes, more launches)
     const u32* node_csi_off;   // [n_nodes + 1] a node's CSIInfo entries
     const u32* csi;            // four words an entry: plugin, has_topology, seg_off, n_seg
     const u32* csi_seg;        // two words a pair: (subdomain, segment) of the nodes
@@ -178,7 +180,7 @@ WV_KERNEL(64) void k_vol_choose(VolChooseArgs a) {
 
 // ---- the topology bitmaps: T[vol] = {nodes n: IsInTopology(top(n, driver(vol)), accessible(vol))} ----------------------------
 WV_KERNEL(256) void k_vol_topology(VolTopoArgs a) {
-    const u32 vol = wv::block_y(), n = wv::block() * 256 + wv::tid();
+    const u32 vol = a.vol0 + wv::block_y(), n = wv::block() * 256 + wv::tid();
     bool fits = false;
     if (n < a.n_nodes) {
         // the node's topology for the volume's driver: the first CSIInfo entry of that plugin (volumes.go:272-278)

@@ -158,6 +158,13 @@ struct swp_engine {
         uint32_t pick[SWP_MAX_MOUNTS];
         if (replay_att) {   // the scripted answer's volumes, mount by mount (none: the task is assigned without attachments)
             replay_att = false;
+            if (replay_vols.size() < ms.size()) {   // the scripted choice stopped at a mount without a volume: the prefix it had chosen, as the engine reports it
+                for (size_t m = 0; m < replay_vols.size(); ++m) {
+                    auto it = ids[SWP_SPACE_VOLUME].find(replay_vols[m]);
+                    out[m] = it == ids[SWP_SPACE_VOLUME].end() ? SWP_NO_VOLUME : it->second;
+                }
+                return false;
+            }
             if (replay_vols.size() != ms.size()) return false;
             for (size_t m = 0; m < ms.size(); ++m) {
                 auto it = ids[SWP_SPACE_VOLUME].find(replay_vols[m]);

@@ -25,9 +25,10 @@ class Both:
     def __init__(self, counts=True):
         self.o, self.e = orc.Oracle(), swhost.HostScheduler()
         self.vols = []
-        # counts: compare the volumes' reference counts per node and every freeVolumes batch too. Not in the seeded clusters: there a task's
-        # mounts may resolve to ONE volume twice, and the reference's chooseTaskVolumes then leaks a count (volumes.go:118-131: its deferred
-        # releases find the task only once per volume) which the host layer does not replay (swp_sched.cpp, above reserveTaskVolumes).
+        # counts: compare the volumes' reference counts per node and every freeVolumes batch too — everywhere since round 5: where a task's
+        # mounts resolve to ONE volume twice, the reference's chooseTaskVolumes leaves a count behind (volumes.go:104-131: its deferred
+        # releases find the task only once per volume), and the host layer books the same remainder from the attachments the engine
+        # reports, the prefix in front of a failing mount included (swp_sched.cpp bookChooseRemainder).
         self.counts = counts
 
     def __getattr__(self, name):
@@ -205,7 +206,7 @@ def test_random_clusters_with_volumes(seed):
     """Nodes with CSI topologies, volumes of every access mode in groups, tasks with one to three cluster mounts (named, grouped, read-only)
     next to plain tasks, several ticks with tasks going away in between: every decision, attachment and reservation as the oracle's."""
     rng = random.Random(0xC51 + seed)
-    b = Both(counts=False)
+    b = Both()
     zones = ["z1", "z2", "z3"]
     n_nodes = rng.choice([3, 8, 40, 150])
     for i in range(n_nodes):
@@ -288,7 +289,7 @@ def test_random_task_groups_with_volumes(seed):
     """Services with a spec version (task groups, scheduler.go:442-459) whose specs carry cluster mounts, next to groups without and one-off
     tasks: tree() with the VolumesFilter, the fill loop's re-checks against the volumes as the group's own placements leave them."""
     rng = random.Random(0x6C51 + seed)
-    b = Both(counts=False)
+    b = Both()
     zones = ["z1", "z2"]
     n_nodes = rng.choice([4, 12, 60])
     for i in range(n_nodes):
