@@ -381,7 +381,6 @@ def main():
     ap.add_argument("--tasks", type=int, default=None)
     ap.add_argument("--nodes", type=int, default=None)
     ap.add_argument("--services", type=int, default=None, help="number of services of the synthetic workload (default T/100); 1 = the reference's benchScheduler shape: every task of ONE service")
-    ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--order", default="rr", choices=["rr", "major"], help="task order: round-robin over services (SURVEY 8d) or service-major")
     ap.add_argument("--rounds", type=int, default=20, help="churn rounds (--mode churn; BASELINE configs[4] uses 100)")
     ap.add_argument("--mode", default="one-off", choices=["one-off", "grouped", "enforce", "churn"],
@@ -466,7 +465,7 @@ def main():
         n_shards = world if world > 1 else max(args.shards, 1)
         shard_ranges_ = swshard.shard_ranges(wl.N, n_shards)
         my = rank if world > 1 else 0
-        eng = abi.Engine(device=local_rank, window=args.window, profile=True, shard_rank=my, shard_count=n_shards)
+        eng = abi.Engine(device=local_rank, profile=True, shard_rank=my, shard_count=n_shards)
         sched = host.HostScheduler(engine=eng)
         t0 = time.perf_counter()
         descs = host.load_workload(sched, wl, *shard_ranges_[my])
@@ -475,7 +474,7 @@ def main():
         # replicas: every rank schedules its own cluster of the same shape (seed offset by rank); no data-path collective
         shard_ranges_ = None
         wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, seed=ranks.replica_seed(0x5EED0000), order=args.order, services=args.services)
-        eng = abi.Engine(device=local_rank, window=args.window, profile=True)
+        eng = abi.Engine(device=local_rank, profile=True)
         sched = host.HostScheduler(engine=eng)
         t0 = time.perf_counter()
         descs = host.load_workload(sched, wl)

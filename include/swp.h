@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define SWP_ABI_VERSION 1
+#define SWP_ABI_VERSION 2   /* 2: swp_config lost `window` (unused since round 3), the shard set arrived, swp_volume_upsert restates addOrUpdateVolume to the letter,
+                             * a failed volume choice reports the prefix it had chosen */
 
 enum {
     SWP_OK = 0,
@@ -46,12 +47,11 @@ typedef struct swp_engine swp_engine;
 /* configuration                                                                               */
 typedef struct {
     int32_t  device;        /* HIP device ordinal */
-    uint32_t window;        /* unused since round 3 (the scan mode and its windows are gone); kept for the struct layout, pass 0 */
     uint32_t resolver_threads; /* 0 = auto (256 or 1024 by node count) */
     uint32_t flags;         /* SWP_CFG_* */
     /* node-range shard owned by this engine for the sharded scan; [0,0) = all */
     uint32_t shard_rank, shard_count;
-    uint32_t reserved[2];
+    uint32_t reserved[3];
 } swp_config;
 
 #define SWP_CFG_PROFILE 1u   /* record hipEvent timings per kernel class into swp_stats_t */

@@ -22,8 +22,8 @@ NFILTERS = 8
 
 
 class Config(C.Structure):
-    _fields_ = [("device", C.c_int32), ("window", C.c_uint32), ("resolver_threads", C.c_uint32), ("flags", C.c_uint32),
-                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+    _fields_ = [("device", C.c_int32), ("resolver_threads", C.c_uint32), ("flags", C.c_uint32),
+                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class NodeRow(C.Structure):
@@ -343,13 +343,13 @@ class Batch:
 class Engine:
     """One swp_engine handle. Raises SwpError(SWP_ENODEVICE) when no gfx950 is present: there is no CPU path."""
 
-    def __init__(self, device=0, window=0, resolver_threads=0, profile=False, lib_path=None, shard_rank=0, shard_count=0,
+    def __init__(self, device=0, resolver_threads=0, profile=False, lib_path=None, shard_rank=0, shard_count=0,
                  shards=None, nodes_per_shard=None, devices=None):
         """shards=G, nodes_per_shard=cap: a shard SET (swp_shardset_create) — G engines of this process behind the one handle, on
         `devices` (one ordinal per shard; default: all on `device`). SWP_SHARDSET="G:cap" in the environment turns every engine
         created without shard arguments into such a set (how the whole scenario suite is run over node-range shards)."""
         self.L = load_library(lib_path)
-        cfg = Config(device=device, window=window, resolver_threads=resolver_threads, flags=CFG_PROFILE if profile else 0,
+        cfg = Config(device=device, resolver_threads=resolver_threads, flags=CFG_PROFILE if profile else 0,
                      shard_rank=shard_rank, shard_count=shard_count)
         env = os.environ.get("SWP_SHARDSET")
         if shards is None and env and not shard_count and lib_path is None:

@@ -37,12 +37,13 @@ def test_parity_one_off(name, T, N):
     assert st["placed"] == sum(v is not None for v in op.values())
 
 
-@pytest.mark.parametrize("window", [64, 256, 4096])
-def test_parity_windows(window):
-    """Result must not depend on the scan window (freshness of the feasibility snapshot)."""
+@pytest.mark.parametrize("block", [64, 256, 1024])
+def test_parity_block_sizes(block, monkeypatch):
+    """Result must not depend on how many tasks a round of the block resolver takes (SWP_R6_BLOCK: the freshness of the candidate lists)."""
+    monkeypatch.setenv("SWP_R6_BLOCK", str(block))
     wl = synth.Workload("cfg3", T=3000, N=500)
     op, oe, _ = pu.oracle_run(wl)
-    ep, ee, *_ = pu.engine_run(wl, window=window)
+    ep, ee, *_ = pu.engine_run(wl)
     pu.assert_same(op, oe, ep, ee)
 
 
