@@ -33,11 +33,14 @@ FILTERS = {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filt
            "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}
 
 
-def profile_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/r04_pmc_summary.json, produced by
-    tools/profile_round4.sh on the GPU box) — a separate rocprofv3 --pmc pass cannot run inside the timed bench.
+def profile_traffic(kernel, run=None):
+    """HBM bytes per launch of the dominant kernel(s) from the committed PMC summary (profiles/r05_pmc_summary.json, produced by
+    tools/profile_round5.sh on the GPU box: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, corrected 2*FETCH + WRITE) — a
+    rocprofv3 --pmc pass cannot run inside the timed bench. `kernel`: one kernel name, "k_resolve6" (one ROUND = k_r6_propose* +
+    k_r6_commit*), or a list of kernel names whose per-launch bytes are summed (one round of that mode); `run`: the profiled run
+    whose numbers to take (cfg3 / grouped / churn / shards4), default: whichever run saw the kernel first.
     Returns (bytes or None, provenance string)."""
-    for tag in ("r04", "r03"):   # this round's summary, else the last one that measured the same kernels (its provenance string says which)
+    for tag in ("r05", "r04", "r03"):   # this round's summary, else the last one that measured the same kernels (its provenance string says which)
         path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
         if not os.path.exists(path):
             continue
@@ -46,13 +49,21 @@ def profile_traffic(kernel):
         except Exception:
             continue
         per = doc.get("hbm_bytes_per_launch", {})
+        if run is not None and run in doc.get("runs", {}):
+            per = {k.split("::")[-1].split("<")[0]: v["hbm_bytes_per_launch_corrected"] for k, v in doc["runs"][run].items()}
+        src = "profiles/%s_pmc_summary.json%s (%s)" % (tag, " run " + run if run else "", doc.get("source", "rocprofv3 --pmc"))
+        if isinstance(kernel, (list, tuple)):
+            have = [k for k in kernel if k in per]
+            if have:
+                return sum(per[k] for k in have), " + ".join(have) + " per round, " + src
+            continue
         base = kernel.split("<")[0]
         pk = "k_r6_propose_small" if "k_r6_propose_small" in per else "k_r6_propose"   # (the one-chunk instance is what runs up to 32 768 nodes: the headline)
         if kernel.startswith("k_resolve6") and pk in per and "k_r6_commit" in per:   # per ROUND: one launch of each
-            return per[pk] + per["k_r6_commit"], "profiles/%s_pmc_summary.json, %s + k_r6_commit per round (%s)" % (tag, pk, doc.get("source", ""))
+            return per[pk] + per["k_r6_commit"], "%s + k_r6_commit per round, %s" % (pk, src)
         if base in per:
-            return per[base], "profiles/%s_pmc_summary.json (%s)" % (tag, doc.get("source", "rocprofv3 --pmc"))
-    return None, "no PMC summary for %s under profiles/" % kernel
+            return per[base], src
+    return None, "no PMC summary for %s under profiles/" % (kernel,)
 
 
 def host_cpu():
@@ -186,10 +197,10 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
         launch_ms, achieved, n_launch = t_step * 1e3 / max(rounds, 1), 0.0, rounds * K
         alg_launch = (wl.T / max(rounds, 1)) * wl.N * row_b + (wl.T / max(rounds, 1)) * TASK_B
         achieved = alg_launch / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, "not measured on this path (the PMC passes of profiles/ cover the single-engine kernels)"
-        note = ("a 'launch' is one ROUND of the whole job: every shard's k_r6_propose, the exchange of the proposals, k_r7_fold + k_r7_match, every shard's k_r7_apply; "
+        traffic, traffic_src = profile_traffic(["k_r7_propose", "k_r7_commit"], run="shards4")
+        note = ("a 'launch' is one ROUND of the whole job: every shard's k_r7_propose, the exchange of the proposals, every shard's k_r7_commit (fold + match + apply); "
                 "its time is the step time over the rounds (host gaps included), its bytes are the round's share of the batch's algorithmic bytes over ALL shards")
-        kernels_ms = {"one round (propose + exchange + fold/match + apply), wall": t_step * 1e3 / max(rounds, 1)}
+        kernels_ms = {"one round (k_r7_propose + exchange + k_r7_commit), wall": t_step * 1e3 / max(rounds, 1)}
     result = {
         "metric": f"task placements/sec ({wl.T // 1000}k one-off tasks x {wl.N // 1000}k nodes, " + FILTERS.get(args.workload, args.workload) + ", spread)",
         "value": wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -200,7 +211,7 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
                        control_backend=ranks.backend, block=512 if device_rounds else swshard.BLOCK, rounds_per_step=rounds, tasks_decided_per_round=wl.T / max(rounds, 1)),
         "pair_evals_per_s": wl.T * wl.N / t_step, "placed": placed, "unplaceable": wl.T - placed,
         # (a fraction above 1 is no roofline: the rounds read bitmap rows, not a node row per pair — then the line says so instead)
-        "roofline": {"bound": "hbm", "kernel": "one sharded round (k_r6_propose x shards + k_r7_match + k_r7_apply x shards)" if device_rounds else "k_propose",
+        "roofline": {"bound": "hbm", "kernel": "one sharded round (k_r7_propose + k_r7_commit, one workgroup per shard)" if device_rounds else "k_propose",
                      "achieved": None if achieved > HBM_PEAK_GBS else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": None if achieved > HBM_PEAK_GBS else achieved / HBM_PEAK_GBS, "not_hbm_bound": achieved > HBM_PEAK_GBS, "algorithmic_GBs": achieved,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_launch, "avg_launch_ms": launch_ms,
@@ -339,6 +350,8 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
     row_b = ROW_B.get(args.workload, 48)
     alg = (replaced / R) * wl.N * row_b + (replaced / R) * TASK_B
     n_shards = world if by_rank else (eng.shards or 1)
+    churn_traffic = (profile_traffic(["k_r7_propose", "k_r7_commit"], run="churn_shards4") if n_shards > 1
+                     else profile_traffic(["k_r6_compact", "k_r6_propose_small_c", "k_r6_commit_c"], run="churn"))
     if by_rank:
         par, exch = "node-shard", "one engine per rank over its node range; per round of the resolver an ncclAllGather of the block's proposals (swp_shard_run_rank); drains and swp_commit(remove) on the owner rank"
     elif n_shards > 1:
@@ -355,7 +368,7 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
            "roofline": {"bound": "hbm", "kernel": "the round's re-placement batch (k_r6_propose + k_r6_commit rounds, or the sharded rounds k_r7_*) + explain",
                         "achieved": alg / (dev_ms / R * 1e-3) / 1e9 if dev_ms else 0.0,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / (dev_ms / R * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms else 0.0,
-                        "traffic": profile_traffic("k_resolve6")[0], "traffic_source": "per resolver ROUND, " + profile_traffic("k_resolve6")[1],
+                        "traffic": churn_traffic[0], "traffic_source": "per resolver ROUND, " + churn_traffic[1],
                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dev_ms / R,
                         "note": "device time of the re-placement batch of a round (engine events; over shards: the wall time of the sharded run); the round "
                                 "itself also pays the host side: two bulk node calls, swp_commit(remove) and swp_batch_prepare for ~9k descriptors"}}
@@ -558,7 +571,8 @@ def main():
                    "data": "synthetic", "config": dict(wl.describe(), mode="grouped", groups=int(wl.S)),
                    "pair_evals_per_s": world * wl.S * wl.N / t_step, "placed": int((out >= 0).sum()),
                    "roofline": {"bound": "hbm", "kernel": "k_groups2", "achieved": alg / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": alg / t_step / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                "frac": alg / t_step / 1e9 / HBM_PEAK_GBS, "traffic": profile_traffic("k_groups2", run="grouped")[0],
+                                "traffic_source": profile_traffic("k_groups2", run="grouped")[1], "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_ms": t_step * 1e3,
                                 "note": "one launch = the whole tick (S groups, one workgroup: a machine wave + 15 helper waves); end-to-end step time (no separate kernel events on this path). "
                                         "The tick is bound by the machine wave's instruction issue while it replays container/heap in the reference's exact order (pipelined root replacements, "
