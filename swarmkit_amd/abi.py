@@ -303,6 +303,14 @@ class Batch:
         self.eng._ck(self.eng.L.swp_batch_fetch(self.eng.h, self.h, out.ctypes.data, hist.ctypes.data if want_hist else None))
         return out, hist
 
+    def attachments(self, tasks=None):
+        """swp_batch_attachments: [len(tasks), SWP_MAX_MOUNTS] volume indices (NO_VOLUME beyond a task's mounts), after fetch / results."""
+        tasks = np.arange(self.n, dtype=np.uint32) if tasks is None else np.ascontiguousarray(tasks, dtype=np.uint32)
+        out = np.empty((len(tasks), 8), dtype=np.uint32)
+        self.eng.L.swp_batch_attachments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        self.eng._ck(self.eng.L.swp_batch_attachments(self.eng.h, self.h, tasks.ctypes.data, len(tasks), out.ctypes.data))
+        return out
+
     def results(self, want_hist=True):
         out = np.empty(self.n, dtype=np.int32)
         hist = np.zeros((self.n, NFILTERS), dtype=np.uint32) if want_hist else None
@@ -436,6 +444,13 @@ class Engine:
 
     def node_port(self, node, protocol, port, set_=True):
         self._ck(self.L.swp_node_port(self.h, node, protocol, port, 1 if set_ else 0))
+
+    def volume_get_usage(self, volume):
+        """swp_volume_get_usage: (n_tasks, n_writers, pin). (On a shard set the call also checks that every shard holds the same numbers.)"""
+        u = (C.c_uint32 * 4)()
+        self.L.swp_volume_get_usage.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        self._ck(self.L.swp_volume_get_usage(self.h, volume, u))
+        return u[0], u[1], u[2]
 
     def constraint_set(self, cs):
         arr = (Constraint * max(1, len(cs)))(*cs)

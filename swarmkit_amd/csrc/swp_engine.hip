@@ -3483,6 +3483,17 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         pos = hb.pos;
         chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / pace * 1.05 + 4.0);
     }
+    if (csi) {   // the volumes reserved in the last round: to the shards that did not place that task (every device's rounds are done first)
+        for (Group& gr : groups) {
+            (void)hipSetDevice(gr.device);
+            if (hipStreamSynchronize(gr.stream) != hipSuccess) return die(e0->fail(SWP_EHIP, "device %d: %s", gr.device, hipGetErrorString(hipGetLastError())));
+        }
+        for (Group& gr : groups) {
+            (void)hipSetDevice(gr.device);
+            const hipError_t x = launch_r7_settle(gr.d_args.as<R6Args>(), gr.count, gr.d_m.as<R7Args>(), gr.g0, gr.stream);
+            if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "k_r7_settle on device %d: %s", gr.device, hipGetErrorString(x)));
+        }
+    }
     for (Group& gr : groups) {
         (void)hipSetDevice(gr.device);
         if (hipStreamSynchronize(gr.stream) != hipSuccess) return die(e0->fail(SWP_EHIP, "device %d: %s", gr.device, hipGetErrorString(hipGetLastError())));
@@ -3797,6 +3808,12 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
         const double pace = std::max(1.0, (double)hb.pos / (double)std::max<uint32_t>(hb.rounds, 1));
         pos = hb.pos;
         chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / pace * 1.05 + 4.0);
+    }
+    if (csi) {   // the volumes reserved in the last round: one more exchange (every rank issues it: the batch ended for all of them together), then every rank takes them
+        const int nr = r->AllGather(ra.prop, d_all.p, send, /* ncclInt8 */ 0, e->rccl_comm, st);
+        if (nr != 0) return bad(e->fail(SWP_EHIP, "ncclAllGather (last trailers): %s", r->GetErrorString ? r->GetErrorString(nr) : "error"));
+        const hipError_t x = launch_r7_settle(d_args.as<R6Args>(), 1, d_m.as<R7Args>(), me, st);
+        if (x != hipSuccess) return bad(e->fail(SWP_EHIP, "k_r7_settle: %s", hipGetErrorString(x)));
     }
     Ctl ctl{};
     HIPCHECK(e, hipMemcpyAsync(&ctl, b->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, st));

@@ -38,6 +38,7 @@ struct R7Args;
 size_t r7_commit_lds_size(uint32_t hw_total, uint32_t block, uint32_t n_rr);
 hipError_t launch_r7_propose(const R6Args* args, uint32_t count, uint32_t block, uint32_t max_words, bool task_rows, bool csi, hipStream_t s, int dev);
 hipError_t launch_r7_commit(const R6Args* args, uint32_t count, const R7Args* m, size_t lds, bool csi, uint32_t shard0, hipStream_t s, int dev);   // fold + match + apply
+hipError_t launch_r7_settle(const R6Args* args, uint32_t count, const R7Args* m, uint32_t shard0, hipStream_t s);   // the last round's volume reservations, to every shard
 
 // sharded scan, host-merged rounds (swp_shard.hip)
 struct ProposeArgs;

@@ -88,6 +88,11 @@ hipError_t launch_r7_commit(const R6Args* args, uint32_t count, const R7Args* m,
 }
 
 
+hipError_t launch_r7_settle(const R6Args* args, uint32_t count, const R7Args* m, uint32_t shard0, hipStream_t s) {
+    hipLaunchKernelGGL(k_r7_settle, dim3(count), dim3(64), 0, s, args, m, shard0);
+    return hipGetLastError();
+}
+
 // ---- the scan resolver (swp_scan.hpp): a stretch of tasks one after the other, every task by one workgroup over all nodes ----
 uint32_t scan_max_nodes() { return SCAN_MAXN; }
 template <int NQ, bool LM>

@@ -231,6 +231,13 @@ WV_KERNEL(256) void k_r7_volrows(const R6Args* args) {   // grid (words / 256, b
     if (w < a.n_words) a.vrows[(size_t)ck * a.n_words + w] = vol_filter_word(a.vol, wv::uload(a.csi_set + ck), w);
 }
 WV_KERNEL(64 * R6_PW) void k_r7_propose(const R6Args* args) { r6_propose(args[wv::block_y()]); }
+// Behind the LAST round of a batch with cluster mounts: the reservation a shard made in that round was never taken by the others (a
+// trailer is read at the start of the next round, and there is none): every shard takes what the last round's trailers say, so that all
+// replicas of the volume table end the batch with the same usage numbers. (Between ranks the trailers are exchanged once more first.)
+WV_KERNEL(64) void k_r7_settle(const R6Args* args, const R7Args* m, u32 shard0) {
+    const R6Args& a = args[wv::block()];
+    if (wv::tid() == 0 && a.trail_out) (void)r7_take_trailers(a, m, shard0 + wv::block(), a.blk->rounds);
+}
 // (m: the job's shard table in device memory — it does not change between the rounds of a batch)
 WV_KERNEL(R6_COMMIT_THREADS) void k_r7_commit(const R6Args* args, const R7Args* m, u32 shard0) { r6_commit_t<false, false, true>(args[wv::block()], m, shard0 + wv::block()); }
 WV_KERNEL(R6_COMMIT_THREADS) void k_r7_commit_v(const R6Args* args, const R7Args* m, u32 shard0) { r6_commit_t<false, true, true>(args[wv::block()], m, shard0 + wv::block()); }

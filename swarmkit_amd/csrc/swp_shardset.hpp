@@ -305,9 +305,17 @@ int volume_set_usage(swp_engine* e, uint32_t volume, const swp_volume_usage* u) 
 int volume_get_usage(swp_engine* e, uint32_t volume, swp_volume_usage* out) {
     ShardSet& S = *e->set;
     if (!out) return SWP_EINVAL;
-    if (int rc = swp_volume_get_usage(S.sh[0], volume, out)) return take_error(e, S.sh[0], rc);
-    if (out->pin < VOL_PIN_FOREIGN) out->pin = out->pin;   // shard 0's own node: global index == local index
-    else if (out->pin < SWP_PIN_MANY) out->pin = ((out->pin >> 26) & 31u) * S.cap + (out->pin & ((1u << 26) - 1u));
+    // every shard holds the same numbers (a pin as its own local index or as a foreign one): read from all of them, as GLOBAL node indices
+    for (size_t q = 0; q < S.sh.size(); ++q) {
+        swp_volume_usage u{};
+        if (int rc = swp_volume_get_usage(S.sh[q], volume, &u)) return take_error(e, S.sh[q], rc);
+        if (u.pin < VOL_PIN_FOREIGN) u.pin += (uint32_t)q * S.cap;
+        else if (u.pin < SWP_PIN_MANY) u.pin = ((u.pin >> 26) & 31u) * S.cap + (u.pin & ((1u << 26) - 1u));
+        if (q == 0) *out = u;
+        else if (u.n_tasks != out->n_tasks || u.n_writers != out->n_writers || u.pin != out->pin)
+            return e->fail(SWP_EHIP, "volume %u: shard %zu holds %u users / %u writers / pin %u, shard 0 %u / %u / %u", volume, q, u.n_tasks, u.n_writers, u.pin,
+                           out->n_tasks, out->n_writers, out->pin);
+    }
     return SWP_OK;
 }
 int choose_volumes(swp_engine* e, uint32_t mset, uint32_t node, uint32_t* out, uint32_t* n_out, uint32_t* failed) {

@@ -214,3 +214,47 @@ def test_task_groups_over_shards_match_oracle_digests(case, N, shards):
     got = bigcases.CASES[case](sched)
     assert got["placed"] == want["placed"]
     assert got["ticks"] == want["ticks"]
+
+
+def test_every_replica_of_the_volume_table_ends_a_batch_with_the_same_usage():
+    """The struct ABI without a host layer in between: two batches of tasks with cluster mounts on a shard set, no swp_volume_set_usage
+    between them — "swp_batch_fetch leaves the numbers as the batch made them" (include/swp.h) must hold on EVERY shard, the ones that
+    did not place the last task with mounts included (its reservation reaches them behind the last round: k_r7_settle). Against one engine
+    given the same calls."""
+    os.environ["SWP_HOST"] = "cxx"
+    wl = synth.Workload("cfg4", T=602, N=90, services=12)
+    outs = []
+    for kw in ({}, {"shards": 3, "nodes_per_shard": 30}):
+        s = swhost.HostScheduler(**kw)
+        for i in range(wl.N):
+            d = wl.node_doc(i)
+            seg = {"zone": "z%d" % wl.node_zone[i]}
+            d["Description"]["CSIInfo"] = [{"PluginName": "csi-a", "NodeID": "c%d" % i, "AccessibleTopology": {"Segments": seg}}] if i % 5 else []
+            s.create_node(d)
+        for v in range(240):   # plenty of unshared volumes: every task with a mount takes the next unused one of its group
+            acc = [{"Segments": {"zone": "z%d" % (v % 8)}}] if v % 3 == 0 else []
+            s.update_volume({"ID": "vol%03d" % v,
+                             "Spec": {"Annotations": {"Name": "name%03d" % v}, "Group": "g%d" % (v % 4), "Driver": {"Name": "csi-a"},
+                                      "AccessMode": {"Scope": "SINGLE_NODE", "Sharing": "NONE"}, "Availability": "ACTIVE"},
+                             "VolumeInfo": {"VolumeID": "p%03d" % v, "AccessibleTopology": acc}})
+        for k in range(wl.S):
+            s.set_service(wl.service_id(k))
+
+        def descs(j0, n):
+            out = []
+            for j in range(j0, j0 + n):
+                t = wl.task_doc(j)
+                if j % 3 == 0:
+                    t.setdefault("Spec", {})["Container"] = {"Mounts": [{"Type": "CLUSTER", "Source": "group:g%d" % (j % 4), "Target": "/d"}]}
+                out.append(s.task_desc(t))
+            return np.concatenate(out)
+        res = []
+        for j0 in (0, 301):   # (task 300 has a mount: the first batch ENDS on a reservation)
+            b = s.e.batch_prepare(descs(j0, 301))
+            b.run()
+            out, hist = b.fetch()
+            res.append((out.tolist(), hist.tolist(), b.attachments().tolist(), [s.e.volume_get_usage(s.e.intern(9, "vol%03d" % v)) for v in range(240)]))
+            b.free()
+        outs.append(res)
+    assert outs[0] == outs[1]
+    assert sum(1 for x in outs[0][1][0] if x >= 0) > 0 and any(a[0] != 0xFFFFFFFF for a in outs[0][1][2])
