@@ -274,6 +274,13 @@ inline Value parse(const std::string& text) { return parse(text.data(), text.siz
 
 inline void dump_string(std::string& out, const std::string& s) {
     out.push_back('"');
+    bool plain = true;   // ids, names, messages: nothing to escape — one append
+    for (unsigned char c : s) plain = plain && c >= 0x20 && c != '"' && c != '\\';
+    if (plain) {
+        out += s;
+        out.push_back('"');
+        return;
+    }
     for (unsigned char c : s) {
         switch (c) {
             case '"': out += "\\\""; break;

@@ -275,26 +275,33 @@ struct QItem {
 class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queue at once, so nothing is ever compacted piecemeal)
   public:
     void put(const std::string& id, Value t, uint32_t tmpl = NO_TMPL) {
-        auto it = index_.find(id);
-        if (it != index_.end()) {
-            items_[it->second].second = std::move(t);
-            items_[it->second].tmpl = tmpl;
+        const uint64_t h = hash_id(id);
+        const size_t at = probe(id, h);
+        if (at != NPOS) {
+            items_[slot_[at]].second = std::move(t);
+            items_[slot_[at]].tmpl = tmpl;
             return;
         }
-        index_.emplace(id, items_.size());
+        if ((used_ + 1) * 2 > hash_.size()) grow();
+        insert(h, (uint32_t)items_.size());
         items_.emplace_back(id, std::move(t), tmpl);
         alive_.push_back(1);
         ++live_;
     }
     void erase(const std::string& id) {
-        auto it = index_.find(id);
-        if (it == index_.end()) return;
-        alive_[it->second] = 0;
-        items_[it->second].second = Value();
-        index_.erase(it);
+        const size_t at = probe(id, hash_id(id));
+        if (at == NPOS) return;
+        alive_[slot_[at]] = 0;
+        items_[slot_[at]].second = Value();
+        slot_[at] = GONE;   // (the probe chain stays intact)
         if (--live_ == 0) clear();
     }
-    void clear() { items_.clear(); alive_.clear(); index_.clear(); live_ = 0; }
+    void clear() {
+        items_.clear();
+        alive_.clear();
+        std::fill(hash_.begin(), hash_.end(), 0);
+        used_ = live_ = 0;
+    }
     std::vector<QItem> snapshot() const {
         std::vector<QItem> out;
         out.reserve(live_);
@@ -317,9 +324,49 @@ class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queu
     bool empty() const { return live_ == 0; }
 
   private:
+    // id -> position in items_: open addressing over (hash, position) pairs — no node per entry, so emptying the queue of a 100k-task
+    // tick is one fill instead of 100k frees. hash 0 = a free cell; position GONE = erased (the chain goes on).
+    static constexpr size_t NPOS = ~(size_t)0;
+    static constexpr uint32_t GONE = 0xFFFFFFFFu;
+    static uint64_t hash_id(const std::string& s) {
+        uint64_t h = 0xCBF29CE484222325ull;
+        for (unsigned char c : s) h = (h ^ c) * 0x100000001B3ull;
+        h ^= h >> 29;
+        return h ? h : 1;
+    }
+    size_t probe(const std::string& id, uint64_t h) const {
+        if (hash_.empty()) return NPOS;
+        const size_t mask = hash_.size() - 1;
+        for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
+            if (hash_[i] == 0) return NPOS;
+            if (hash_[i] == h && slot_[i] != GONE && items_[slot_[i]].first == id) return i;
+        }
+    }
+    void insert(uint64_t h, uint32_t pos) {
+        const size_t mask = hash_.size() - 1;
+        size_t i = (size_t)h & mask;
+        while (hash_[i] != 0) i = (i + 1) & mask;
+        hash_[i] = h;
+        slot_[i] = pos;
+        ++used_;
+    }
+    void grow() {
+        std::vector<uint64_t> oh;
+        std::vector<uint32_t> os;
+        oh.swap(hash_);
+        os.swap(slot_);
+        const size_t cap = oh.empty() ? 1024 : oh.size() * 2;
+        hash_.assign(cap, 0);
+        slot_.assign(cap, 0);
+        used_ = 0;
+        for (size_t i = 0; i < oh.size(); ++i)
+            if (oh[i] != 0 && os[i] != GONE) insert(oh[i], os[i]);
+    }
     std::vector<QItem> items_;
     std::vector<char> alive_;
-    std::unordered_map<std::string, size_t> index_;
+    std::vector<uint64_t> hash_;
+    std::vector<uint32_t> slot_;
+    size_t used_ = 0;   // cells taken (erased ones included)
     size_t live_ = 0;
 };
 
@@ -397,13 +444,21 @@ class Decisions {
         buf_ += ",\"NodeID\":";
         json::dump_string(buf_, node);
         buf_ += ",\"State\":";
-        buf_ += std::to_string(state);
+        number(state);
         buf_ += ",\"Message\":";
         json::dump_string(buf_, message);
         buf_ += ",\"Err\":";
         json::dump_string(buf_, err);
         buf_ += ",\"OldState\":";
-        buf_ += std::to_string(old_state);
+        number(old_state);
+    }
+    void number(int64_t v) {
+        char tmp[24];
+        char* p = tmp + sizeof tmp;
+        uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
+        do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) *--p = '-';
+        buf_.append(p, (size_t)(tmp + sizeof tmp - p));
     }
     void field(const char* key, const Value& v) {
         buf_ += ",\"";
@@ -424,11 +479,56 @@ class Decisions {
     size_t n_ = 0;
 };
 
+// NodeInfo.Tasks (map[string]*api.Task, nodeinfo.go:31): a node holds a few dozen tasks — a flat array searched front to back (one
+// allocation, one cache line per probe) until it grows beyond TASKS_FLAT entries, a tree from then on.
+class NodeTasks {
+  public:
+    static constexpr size_t TASKS_FLAT = 48;
+    Value* find(const std::string& id) {
+        if (!tree_.empty()) {
+            auto it = tree_.find(id);
+            return it == tree_.end() ? nullptr : &it->second;
+        }
+        for (auto& kv : flat_)
+            if (kv.first == id) return &kv.second;
+        return nullptr;
+    }
+    void put(const std::string& id, const Value& t) {
+        if (Value* have = find(id)) { *have = t; return; }
+        if (tree_.empty() && flat_.size() < TASKS_FLAT) { flat_.emplace_back(id, t); return; }
+        for (auto& kv : flat_) tree_.emplace(std::move(kv.first), std::move(kv.second));
+        flat_.clear();
+        tree_.emplace(id, t);
+    }
+    bool erase(const std::string& id) {
+        if (!tree_.empty()) return tree_.erase(id) != 0;
+        for (size_t i = 0; i < flat_.size(); ++i)
+            if (flat_[i].first == id) {
+                if (i + 1 != flat_.size()) flat_[i] = std::move(flat_.back());
+                flat_.pop_back();
+                return true;
+            }
+        return false;
+    }
+    // in id order (what ranging over a sorted key list gives: the outputs are deterministic)
+    template <class F> void each_sorted(F f) const {
+        if (!tree_.empty()) { for (const auto& kv : tree_) f(kv.first, kv.second); return; }
+        std::vector<const std::pair<std::string, Value>*> p;
+        for (const auto& kv : flat_) p.push_back(&kv);
+        std::sort(p.begin(), p.end(), [](auto a, auto b) { return a->first < b->first; });
+        for (auto q : p) f(q->first, q->second);
+    }
+
+  private:
+    std::vector<std::pair<std::string, Value>> flat_;
+    std::map<std::string, Value> tree_;
+};
+
 // The non-numeric half of scheduler.NodeInfo (nodeinfo.go:28-44); the numeric half lives in the engine's node row.
 struct NodeInfo {
     Value node;                                           // *api.Node
     uint32_t idx = 0;                                     // engine node index
-    std::map<std::string, Value> Tasks;                   // NodeInfo.Tasks
+    NodeTasks Tasks;                                      // NodeInfo.Tasks
     std::map<FailureKey, std::vector<int64_t>> recentFailures;
     int64_t lastCleanup = 0;
     generic::List availGeneric;                           // AvailableResources.Generic (the engine holds one count per kind of it)
@@ -476,13 +576,13 @@ class Scheduler {
             mem = as_i64(res->get("MemoryBytes"));
             avail = generic::decode(res->get("Generic"));
             if (ni != nullptr) {   // :376-384: subtract the reservations of the tasks already on the node, take their generic resources out
-                for (const auto& kv : ni->Tasks) {
+                ni->Tasks.each_sorted([&](const std::string&, const Value& t) {
                     int64_t c, m;
-                    taskReservations(kv.second, c, m);
+                    taskReservations(t, c, m);
                     cpu -= c;
                     mem -= m;
-                    generic::consume(&avail, generic::decode(kv.second.get("AssignedGenericResources")));
-                }
+                    generic::consume(&avail, generic::decode(t.get("AssignedGenericResources")));
+                });
             }
         }
         const uint32_t idx = intern(SWP_SPACE_NODE_ID, nid);
@@ -539,13 +639,13 @@ class Scheduler {
         swp_node_row row;
         ck(swp_node_get(e_, ni.idx, &row), "swp_node_get");
         Value by_service = Value::object(), tasks = Value::array(), fails = Value::object();
-        for (const auto& kv : ni.Tasks) {
-            const std::string& sid = as_str(kv.second.get("ServiceID"));
+        ni.Tasks.each_sorted([&](const std::string& id, const Value& t) {
+            const std::string& sid = as_str(t.get("ServiceID"));
             uint32_t c = 0;
             ck(swp_node_get_svc_count(e_, ni.idx, intern(SWP_SPACE_SERVICE, sid), &c), "swp_node_get_svc_count");
             if (c) by_service.set(sid, Value::integer(c));
-            tasks.push(Value::str(kv.first));
-        }
+            tasks.push(Value::str(id));
+        });
         for (const auto& kv : ni.recentFailures) fails.set(kv.first.first + "@" + std::to_string(kv.first.second), Value::integer((int64_t)kv.second.size()));
         Value avail = Value::object();
         avail.set("NanoCPUs", Value::integer(row.cpu));
@@ -1649,16 +1749,16 @@ class Scheduler {
     bool addTask(NodeInfo& ni, const Value& t) {
         const std::string& id = task_id(t);
         const int64_t ds = task_state(t.get("DesiredState"));
-        auto old = ni.Tasks.find(id);
-        if (old != ni.Tasks.end()) {
-            const int64_t ods = task_state(old->second.get("DesiredState"));
+        Value* old = ni.Tasks.find(id);
+        if (old != nullptr) {
+            const int64_t ods = task_state(old->get("DesiredState"));
             if (ds <= COMPLETE && ods > COMPLETE) {          // :113-119: the task counts again
-                old->second = t;
+                *old = t;
                 commit(ni, t, true, false, true);
                 return true;
             }
             if (ods <= COMPLETE && ds > COMPLETE) {          // :120-126: the task stops counting
-                old->second = t;
+                *old = t;
                 commit(ni, t, true, false, false);
                 return true;
             }
@@ -1669,7 +1769,7 @@ class Scheduler {
         generic::List assigned;
         generic::claim(&ni.availGeneric, &assigned, generic::decode(at(&t, {"Spec", "Resources", "Reservations", "Generic"})));
         stored.set("AssignedGenericResources", generic::encode(assigned));
-        ni.Tasks[id] = stored;
+        ni.Tasks.put(id, stored);
         auto all = allTasks_.find(id);
         if (all != allTasks_.end()) all->second = stored;   // (the reference writes through the one *api.Task both maps point to)
         commit(ni, t, ds <= COMPLETE, true, true);
@@ -1678,10 +1778,10 @@ class Scheduler {
     }
     // NodeInfo.removeTask, nodeinfo.go:66-104
     bool removeTask(NodeInfo& ni, const Value& t) {
-        auto old = ni.Tasks.find(task_id(t));
-        if (old == ni.Tasks.end()) return false;
-        const bool counted = task_state(old->second.get("DesiredState")) <= COMPLETE;
-        ni.Tasks.erase(old);
+        const Value* old = ni.Tasks.find(task_id(t));
+        if (old == nullptr) return false;
+        const bool counted = task_state(old->get("DesiredState")) <= COMPLETE;
+        ni.Tasks.erase(task_id(t));
         commit(ni, t, counted, true, false);
         // :95-104: the task's AssignedGenericResources go back — unless the node's description lists no generic resources at all
         bool desc_nil = true;
@@ -1818,7 +1918,7 @@ class Scheduler {
         if (!want.empty()) decisions.field("AssignedGenericResources", *newT.get("AssignedGenericResources"));
         if (newT.get("Volumes") != nullptr) decisions.field("Volumes", *newT.get("Volumes"));
         decisions.end();
-        ni_second.Tasks[tid] = newT;
+        ni_second.Tasks.put(tid, newT);
         rememberDecision(tid, t, false);
         allTasks_[tid] = std::move(newT);
     }
