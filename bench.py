@@ -255,11 +255,17 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
     first, cnt = (ranges[rank] if by_rank else (0, wl.N))
     state = {"rounds_total": 0}
 
-    def place(batch_descs, timed=None):
-        """one placement batch over the whole node set -> (global node per task, device ms or None)"""
+    # the descriptors as (templates, template per task) — tasks of one service spec share theirs, which a caller knows (the shim keeps one
+    # per (service, spec version)): the re-placement batches are prepared by swp_batch_prepare_templates, an array lookup per task
+    tmpl, tmpl_of = np.unique(descs, return_inverse=True)
+    tmpl_of = tmpl_of.astype(np.uint32)
+
+    def place(which, timed=None):
+        """one placement batch (the tasks `which` of the workload; None: all) over the whole node set -> (global node per task, device ms or None)"""
+        of = tmpl_of if which is None else tmpl_of[which]
         if not by_rank:
             ta = time.perf_counter()
-            bt = eng.batch_prepare(batch_descs)
+            bt = eng.batch_prepare_templates(tmpl, of)
             tb = time.perf_counter()
             bt.run()
             tc = time.perf_counter()
@@ -271,12 +277,12 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
                 state["rounds_total"] += st["resolve_launches"] - state.get("launches_seen", 0)
             state["launches_seen"] = st["resolve_launches"]
             if timed is not None:
-                timed["swp_batch_prepare"] += tb - ta
+                timed["swp_batch_prepare_templates"] += tb - ta
                 timed["swp_batch_run"] += tc - tb
                 timed["swp_batch_fetch"] += td - tc
             return out.astype(np.int64), st["ms_total"]
         ta = time.perf_counter()
-        bt = eng.batch_prepare(batch_descs)
+        bt = eng.batch_prepare_templates(tmpl, of)
         tb = time.perf_counter()
         drv = swshard.DeviceRankShard(bt, rank, world, ranges, dist, ranks.device, fold=True)   # raises RcclUnavailable on EVERY rank: no silent fallback
         out, _h = drv.run(want_hist=False)
@@ -284,18 +290,18 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
         bt.free()
         state["rounds_total"] += drv.rounds
         if timed is not None:
-            timed["swp_batch_prepare"] += tb - ta
+            timed["swp_batch_prepare_templates"] += tb - ta
             timed["swp_batch_run"] += tc - tb
         return out.astype(np.int64), (tc - tb) * 1e3
 
-    assign, _ms = place(descs)          # task -> global node (or -1)
+    assign, _ms = place(None)           # task -> global node (or -1)
     assign = assign.copy()
     rng = np.random.default_rng(wl.seed)
     prev = np.zeros(0, dtype=np.int64)
     replaced = 0
     dev_ms = 0.0
     t_rounds = []
-    phases = {"node calls (get_many + update_dynamic_many)": 0.0, "swp_commit(remove)": 0.0, "swp_batch_prepare": 0.0, "swp_batch_run": 0.0,
+    phases = {"node calls (get_many + update_dynamic_many)": 0.0, "swp_commit(remove)": 0.0, "swp_batch_prepare_templates": 0.0, "swp_batch_run": 0.0,
               "swp_batch_fetch": 0.0, "the script itself (which tasks sat on the drained nodes, their descriptors)": 0.0}
     is_drained = np.zeros(wl.N + 1, dtype=bool)   # (index -1 = unplaced: the extra last entry)
     state["rounds_total"] = 0
@@ -326,12 +332,11 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
             pl = np.zeros(len(own), dtype=abi.PLACEMENT_DTYPE)
             pl["node"], pl["service"] = assign[own] - first, descs["service"][own]
             pl["cpu"], pl["mem"], pl["counted"] = descs["cpu"][own], descs["mem"][own], 1
-            again = descs[gone]                    # as many new tasks of the same services
-            tc = time.perf_counter()
+            tc = time.perf_counter()               # (as many new tasks of the same services: the same descriptors)
             if len(own):
                 eng.commit(pl, add=False)          # NodeInfo.removeTask for every task on a drained node (on its owner)
             td = time.perf_counter()
-            new_out, ms = place(again, phases)
+            new_out, ms = place(gone, phases)
             tg = time.perf_counter()
             assign[gone] = new_out
             replaced += len(gone)
