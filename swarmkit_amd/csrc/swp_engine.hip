@@ -3055,7 +3055,7 @@ int swp_shard_begin(swp_engine* e, swp_batch* b) {
     if (e->n_nodes != b->n_nodes_prepared)
         return e->fail(SWP_EINVAL, "the nodeSet grew from %u to %u node slots since swp_batch_prepare: prepare the batch again", b->n_nodes_prepared, e->n_nodes);
     if (b->has_generic) return e->fail(SWP_EUNSUPPORTED, "generic reservations are not part of the HOST-merged shard protocol (swp_shard_run / swp_shard_run_rank carry them)");
-    if (!b->csi_set.empty()) return e->fail(SWP_EUNSUPPORTED, "tasks with cluster mounts are not part of the shard protocols (a volume's use is cluster-wide state)");
+    if (!b->csi_set.empty()) return e->fail(SWP_EUNSUPPORTED, "tasks with cluster mounts are not part of the HOST-merged shard protocol (swp_shard_run / swp_shard_run_rank carry them)");
     b->shard_open = true;
     b->shard_ncommit = b->shard_ninf = 0;
     e->stats.ms_propose = e->stats.ms_apply = 0.f;
@@ -3294,6 +3294,15 @@ int swp_shard_end(swp_engine* e, swp_batch* b, int32_t* out_node_local, uint32_t
     return SWP_OK;
 }
 
+// The block follows the pace (as in the single engine's rounds): rounds that are cut after a few dozen tasks — re-placements that all aim at
+// the few emptied nodes — need not propose and stage hundreds of lists on every shard; rounds that fill their block get the next size up.
+// `recent`: tasks decided per round in the last stretch. The argument records carry the block; the proposals' buffer and the tails stay
+// where the LARGEST block put them. Every rank derives the same size from the same agreed numbers.
+static uint32_t r7_next_block(uint32_t cur, uint32_t largest, double recent) {
+    if (recent > 0.4 * cur) return std::min<uint32_t>(largest, cur * 2u);
+    return std::min<uint32_t>(largest, std::max<uint32_t>(128u, ((uint32_t)(2.0 * recent) + 63u) / 64u * 64u));
+}
+
 int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_t G, uint32_t flags, int32_t* out_shard, int32_t* out_node, uint32_t* out_fail_hist) {
     const auto t_begin = std::chrono::steady_clock::now();
     if (!engines || !batches || G == 0 || !engines[0] || !batches[0]) return SWP_EINVAL;
@@ -3444,6 +3453,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
     // rounds: enqueued blindly, the leader's header read every `chunk` rounds (a round past the end is a handful of empty launches)
     uint32_t pos = 0, chunk = std::min<uint32_t>(16u, (T + 255u) / 256u + 1u);
     uint64_t rounds = 0;
+    uint32_t cur_block = block, rounds_seen = 0;
     Blk6 hb{};
     while (pos < T) {
         // One round = two launches per device: every shard proposes over its nodes; once the proposals of ALL devices are there (events
@@ -3458,7 +3468,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
                 if (multi && rounds + r > 0)
                     for (size_t o = 0; o < groups.size() && x == hipSuccess; ++o)
                         if (o != q) x = hipStreamWaitEvent(gr.stream, groups[o].ev_commit, 0);
-                if (x == hipSuccess) x = launch_r7_propose(gr.d_args.as<R6Args>(), gr.count, block, gr.max_words, task_rows, csi, gr.stream, gr.device);
+                if (x == hipSuccess) x = launch_r7_propose(gr.d_args.as<R6Args>(), gr.count, cur_block, gr.max_words, task_rows, csi, gr.stream, gr.device);
                 if (x == hipSuccess && multi) x = hipEventRecord(gr.ev_prop, gr.stream);
                 if (x != hipSuccess) return die(e0->fail(SWP_EHIP, "propose on device %d: %s", gr.device, hipGetErrorString(x)));
             }
@@ -3479,9 +3489,23 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
             return die(e0->fail(SWP_EHIP, "reading the leader's control block: %s", hipGetErrorString(hipGetLastError())));
         if (hb.error != ERR_NONE) return die(e0->fail(SWP_ERANGE, "per-node task-count spread exceeds the %d level planes of the block resolver", R6_NP));
         if (hb.pos <= pos) return die(e0->fail(SWP_EHIP, "sharded rounds made no progress at task %u", pos));
-        const double pace = std::max(1.0, (double)hb.pos / (double)std::max<uint32_t>(hb.rounds, 1));
+        const double recent = (double)(hb.pos - pos) / (double)std::max<uint32_t>(hb.rounds - rounds_seen, 1);
+        rounds_seen = hb.rounds;
         pos = hb.pos;
-        chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / pace * 1.05 + 4.0);
+        chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / std::max(1.0, recent) * 1.05 + 4.0);
+        if (!env_blk && pos < T) {
+            const uint32_t nb = r7_next_block(cur_block, block, recent);
+            if (nb != cur_block) {
+                cur_block = nb;
+                for (uint32_t g = 0; g < G; ++g) ra[g].block = nb;
+                for (Group& gr : groups) {   // (behind the stretch's kernels on the device's stream)
+                    (void)hipSetDevice(gr.device);
+                    if (hipMemcpyAsync(gr.d_args.p, &ra[gr.g0], (size_t)gr.count * sizeof(R6Args), hipMemcpyHostToDevice, gr.stream) != hipSuccess)
+                        return die(e0->fail(SWP_EHIP, "device %d: %s", gr.device, hipGetErrorString(hipGetLastError())));
+                }
+            }
+            if (cur_block < block) chunk = std::min<uint32_t>(chunk, 64u);   // (look again before long while the block is small)
+        }
     }
     if (csi) {   // the volumes reserved in the last round: to the shards that did not place that task (every device's rounds are done first)
         for (Group& gr : groups) {
@@ -3780,10 +3804,11 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
     int local_rc = SWP_OK;
     auto note = [&](int code) { if (local_rc == SWP_OK) local_rc = code; };
     R7Tail* my_tail = reinterpret_cast<R7Tail*>(ra.prop + block);
+    uint32_t cur_block = block, rounds_seen = 0;
     while (pos < T) {   // (every rank computes the same positions from the same gathered words, hence the same chunks: the collectives line up)
         for (uint32_t q = 0; q < chunk; ++q) {
             if (local_rc == SWP_OK) {
-                const hipError_t x = launch_r7_propose(d_args.as<R6Args>(), 1, block, Wn, task_rows, csi, st, e->device);
+                const hipError_t x = launch_r7_propose(d_args.as<R6Args>(), 1, cur_block, Wn, task_rows, csi, st, e->device);
                 if (x != hipSuccess) note(e->fail(SWP_EHIP, "propose: %s", hipGetErrorString(x)));
             }
             if (local_rc != SWP_OK) (void)hipMemsetAsync(&my_tail->dead, 1, sizeof(uint32_t), st);
@@ -3805,9 +3830,20 @@ int swp_shard_run_rank(swp_engine* e, swp_batch* b, const uint32_t* shard_nodes,
         default: break;
         }
         if (hb.pos <= pos) return bad(e->fail(SWP_EHIP, "sharded rounds made no progress at task %u", pos));   // (the same on every rank: the positions agree)
-        const double pace = std::max(1.0, (double)hb.pos / (double)std::max<uint32_t>(hb.rounds, 1));
-        pos = hb.pos;
-        chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / pace * 1.05 + 4.0);
+        // (positions and round counts are the agreed ones — rank 0's words, which every rank's equal: the same pace, chunk and block everywhere)
+        const double recent = (double)(all[0].pos - pos) / (double)std::max<uint32_t>(all[0].rounds - rounds_seen, 1);
+        rounds_seen = all[0].rounds;
+        pos = all[0].pos;
+        chunk = (uint32_t)std::min<double>(4096.0, (double)(T - pos) / std::max(1.0, recent) * 1.05 + 4.0);
+        if (!env_blk && pos < T) {
+            const uint32_t nb = r7_next_block(cur_block, block, recent);
+            if (nb != cur_block) {
+                cur_block = nb;
+                ra.block = nb;
+                if (hipMemcpyAsync(d_args.p, &ra, sizeof ra, hipMemcpyHostToDevice, st) != hipSuccess) note(e->fail(SWP_EHIP, "argument record: %s", hipGetErrorString(hipGetLastError())));
+            }
+            if (cur_block < block) chunk = std::min<uint32_t>(chunk, 64u);
+        }
     }
     if (csi) {   // the volumes reserved in the last round: one more exchange (every rank issues it: the batch ended for all of them together), then every rank takes them
         const int nr = r->AllGather(ra.prop, d_all.p, send, /* ncclInt8 */ 0, e->rccl_comm, st);

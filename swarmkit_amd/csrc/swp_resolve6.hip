@@ -75,7 +75,8 @@ hipError_t launch_r7_propose(const R6Args* args, uint32_t count, uint32_t block,
     if (lp > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_r7_propose), dev)) != hipSuccess) return r;
     if (task_rows) hipLaunchKernelGGL(k_r7_taskrows, dim3((max_words + 3) / 4, count), dim3(256), (size_t)block * 16, s, args);
     if (csi) hipLaunchKernelGGL(k_r7_volrows, dim3((max_words + 255) / 256, block, count), dim3(256), 0, s, args);   // (batches with cluster mounts only)
-    hipLaunchKernelGGL(k_r7_propose, dim3(block, count), dim3(64 * R6_PW), lp, s, args);
+    if (max_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r7_propose_small, dim3(block, count), dim3(64 * R6_PW), lp, s, args);   // (LDS of 8 chunks: never beyond 48 KB)
+    else hipLaunchKernelGGL(k_r7_propose, dim3(block, count), dim3(64 * R6_PW), lp, s, args);
     return hipGetLastError();
 }
 // fold + match + apply: one workgroup per shard of the device; `m`: the job's shard table in device memory

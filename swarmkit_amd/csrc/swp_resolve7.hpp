@@ -70,9 +70,15 @@ WV_DEV u32 r7_tk_words(const R7Args* m) { return (m->hw_total + 1u) / 2u; }
 // a rank's host has given up: every rank's kernels stand still until the hosts have agreed on it (uniform: every thread reads the same words)
 WV_DEV bool r7_any_dead(const R7Args* m) {
     if (!m->check_dead) return false;
-    bool dead = false;
-    for (u32 g = 0; g < m->n_shards; ++g) dead = dead || wv::uload(&m->tail[g]->dead) != 0;
-    return dead;
+    // (no early exit: the words of all shards are requested together — a chain of pointer -> word round trips per shard otherwise)
+    const u32 G = wv::uload(&m->n_shards);
+    const R7Tail* tp[R7_MAXS];
+    WV_UNROLL
+    for (u32 g = 0; g < R7_MAXS; ++g) tp[g] = wv::uload(&m->tail[g < G ? g : 0u]);
+    u32 dead = 0;
+    WV_UNROLL
+    for (u32 g = 0; g < R7_MAXS; ++g) dead |= wv::uload(&tp[g]->dead);
+    return dead != 0;
 }
 
 // the address of shard `shard`'s local node in the padded space
@@ -97,68 +103,112 @@ WV_DEV u32 r7_local(const R7Args* m, u32 addr, u32 my, bool* here) {
 // entry: 82 µs; the single engine's commit takes 58.)
 // (called by WHOLE waves — the ballots below — `have`: the lane has a task; i: its block-local index, 0 for a lane without one)
 WV_DEV void r7_fold_into(const R7Args* m, u32 i, bool have, u32 block, unsigned short* L_hw, u32* L_hb, u32* H_level, u32* H_meta, u32* sh) {
-    const u32 G = m->n_shards;
+    // The shard table is the same for every thread and constant while the kernel runs: scalar loads, all requested together. The heads of
+    // all shards' records are loaded UNCONDITIONALLY (a shard beyond the job's count reads shard 0's record, a lane without a task reads
+    // task 0's: valid addresses) and masked afterwards — a load under its own predicate waits for the one before it: eight pointer -> head
+    // round trips one after the other were 10 µs of every round.
+    const u32 G = wv::uload(&m->n_shards);
     const R6Prop* pp[R7_MAXS];
     u32 lv[R7_MAXS], nc[R7_MAXS], hwb[R7_MAXS];
     WV_UNROLL
-    for (u32 g = 0; g < R7_MAXS; ++g) {   // the heads of all shards' records: one batch of loads
+    for (u32 g = 0; g < R7_MAXS; ++g) {
+        const u32 gg = g < G ? g : 0u;
+        pp[g] = wv::uload(&m->prop[gg]) + i;
+        hwb[g] = wv::uload(&m->hw_base[gg]);
+    }
+    WV_UNROLL
+    for (u32 g = 0; g < R7_MAXS; ++g) {   // one batch of loads
+        lv[g] = pp[g]->level;
+        nc[g] = pp[g]->n_cand;
+    }
+    const u32 flags = pp[0]->flags;   // (bit 0: uncounted, bit 1: cluster mounts — properties of the task: the same on every shard)
+    WV_UNROLL
+    for (u32 g = 0; g < R7_MAXS; ++g) {
         const bool in = g < G && have;
-        pp[g] = m->prop[g < G ? g : 0u] + i;
-        lv[g] = in ? pp[g]->level : R6_NONE;
-        nc[g] = in ? pp[g]->n_cand : 0u;
-        hwb[g] = m->hw_base[g < G ? g : 0u];
+        lv[g] = in ? lv[g] : R6_NONE;
+        nc[g] = in ? nc[g] : 0u;
     }
     u32 level = R6_NONE;
     WV_UNROLL
     for (u32 g = 0; g < R7_MAXS; ++g) level = min(level, lv[g]);
-    const u32 flags = m->prop[0][i].flags;   // (bit 0: uncounted, bit 1: cluster mounts — properties of the task: the same on every shard)
     // The shards on the minimum level in range order, until one of them was itself cut short (what lies behind a truncated list is
     // unknown: later shards cannot be appended). Every LANE walks its own shards — a step takes the next shard on the lane's level,
     // whichever it is — so the wave takes as many steps as its neediest task has contributing shards: one or two.
     u32 cnt = 0, gnext = 0;
     bool closed = level == R6_NONE;
-    while (wv::ballot(!closed && cnt < 2u * R6_CAND)) {
-        const R6Prop* p = pp[0];
-        u32 ncs = 0, base = 0, gs = R7_MAXS;
+    // the lane's next shard on its level: the LOWEST one >= gnext (a downward chain of selects)
+    const R6Prop* p = pp[0];
+    u32 ncs = 0, base = 0, gs = R7_MAXS;
+    auto next_shard = [&] {
+        p = pp[0];
+        ncs = 0;
+        base = 0;
+        gs = R7_MAXS;
         WV_UNROLL
-        for (u32 g = R7_MAXS; g-- > 0;) {   // (downwards: the LOWEST shard >= gnext on the level wins the selects)
+        for (u32 g = R7_MAXS; g-- > 0;) {
             const bool hit = g >= gnext && lv[g] == level;
             p = hit ? pp[g] : p;
             ncs = hit ? nc[g] : ncs;
             base = hit ? hwb[g] : base;
             gs = hit ? g : gs;
         }
-        const bool on = !closed && cnt < 2u * R6_CAND && gs < R7_MAXS;
-        if (!closed && gs == R7_MAXS) closed = true;   // no shard behind holds the level
+    };
+    // The record's two arrays are loaded as they lie in memory — unconditional, so that the compiler requests them as wide loads, all in
+    // flight together (a load per entry under its own predicate is 64 narrow requests a lane: measured 25 µs a round) — the indices first,
+    // then the candidate bits: half the registers of one batch of 64.
+    // The FIRST step is every lane's and fills the whole list: entry k of the lane's first shard, or zero behind its length (the unused
+    // entries of a list are zero: a seating step reads a fixed number of them) — 64 stores without a predicate of their own.
+    next_shard();
+    {
+        const bool on = !closed && gs < R7_MAXS;
+        if (!closed && gs == R7_MAXS) closed = true;   // (cannot happen: some shard holds the minimum)
         const u32 c = on ? ncs & 0x7FFFFFFFu : 0u;
-        const u32 t = min(c, 2u * R6_CAND - cnt);
-        if (t != 0) {
-            // the record's two arrays as they lie in memory — unconditional, so that the compiler requests them as wide loads, all in
-            // flight together (a load per entry under its own predicate is 64 narrow requests a lane: measured 25 µs a round) —
-            // and only the entries the list takes go to LDS
-            // (the indices first, then the candidate bits: half the registers of one batch of 64)
+        const u32 t = min(c, 2u * R6_CAND);
+        if (have) {
             u32 v[2 * R6_CAND];
             WV_UNROLL
             for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hw[k];
             WV_UNROLL
-            for (u32 k = 0; k < 2 * R6_CAND; ++k)
-                if (k < t) L_hw[(size_t)(cnt + k) * block + i] = (unsigned short)(base + v[k]);
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) L_hw[(size_t)k * block + i] = (unsigned short)(k < t ? base + v[k] : 0u);
             WV_UNROLL
             for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hb[k];
             WV_UNROLL
-            for (u32 k = 0; k < 2 * R6_CAND; ++k)
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) L_hb[(size_t)k * block + i] = k < t ? v[k] : 0u;
+        }
+        cnt = t;
+        if (on && (t < c || (ncs >> 31))) closed = true;
+        gnext = gs + 1u;
+    }
+    // ... the steps behind it append: lanes whose list is not full yet and whose shards so far were not cut short — as many steps as the
+    // wave's neediest task has further contributing shards (seldom one)
+    while (wv::ballot(have && !closed && cnt < 2u * R6_CAND)) {
+        next_shard();
+        const bool on = have && !closed && cnt < 2u * R6_CAND && gs < R7_MAXS;
+        if (!closed && gs == R7_MAXS) closed = true;   // no shard behind holds the level
+        const u32 c = on ? ncs & 0x7FFFFFFFu : 0u;
+        const u32 t = min(c, 2u * R6_CAND - cnt);
+        {   // (the whole wave: lanes with nothing to append ride along with t = 0 — the entry loops end where NO lane has one left, a
+            // uniform branch; a store per entry under its own predicate is a skipped branch each: 64 of them cost more than the step's loads)
+            u32 v[2 * R6_CAND];
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hw[k];
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) {
+                if (!wv::ballot(k < t)) break;
+                if (k < t) L_hw[(size_t)(cnt + k) * block + i] = (unsigned short)(base + v[k]);
+            }
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hb[k];
+            WV_UNROLL
+            for (u32 k = 0; k < 2 * R6_CAND; ++k) {
+                if (!wv::ballot(k < t)) break;
                 if (k < t) L_hb[(size_t)(cnt + k) * block + i] = v[k];
+            }
         }
         cnt += t;
         if (on && (t < c || (ncs >> 31))) closed = true;
         gnext = gs + 1u;
     }
-    WV_UNROLL
-    for (u32 e = 0; e < 2 * R6_CAND; ++e)
-        if (have && e >= cnt) {   // (the unused entries of a list are zero: a seating step reads a fixed number of them)
-            L_hw[(size_t)e * block + i] = 0;
-            L_hb[(size_t)e * block + i] = 0;
-        }
     // no plain candidate anywhere: nodeLess over the shards' exception-list candidates (scheduler.go:708-735) — (failure class, svcCount),
     // then (ActiveTasksCount, GLOBAL index)
     u64 bhi = KEY_NONE, blo = KEY_NONE;
@@ -231,6 +281,9 @@ WV_KERNEL(256) void k_r7_volrows(const R6Args* args) {   // grid (words / 256, b
     if (w < a.n_words) a.vrows[(size_t)ck * a.n_words + w] = vol_filter_word(a.vol, wv::uload(a.csi_set + ck), w);
 }
 WV_KERNEL(64 * R6_PW) void k_r7_propose(const R6Args* args) { r6_propose(args[wv::block_y()]); }
+// every range of the device within R6_SMALL_WORDS node words (32 768 nodes): the one-chunk instance — a quarter of the registers, so that the
+// workgroups of all shards' blocks are resident together (as k_r6_propose_small on a single engine)
+WV_KERNEL(64 * R6_PW) void k_r7_propose_small(const R6Args* args) { r6_propose_t<1>(args[wv::block_y()]); }
 // Behind the LAST round of a batch with cluster mounts: the reservation a shard made in that round was never taken by the others (a
 // trailer is read at the start of the next round, and there is none): every shard takes what the last round's trailers say, so that all
 // replicas of the volume table end the batch with the same usage numbers. (Between ranks the trailers are exchanged once more first.)
