@@ -20,7 +20,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 # refbench_100k_1m: the reference's largest benchmark shape, BenchmarkScheduler100kNodes1MTasks (scheduler_test.go:3355-3357) — 1M tasks of ONE
-# service on 100k nodes, ten tasks a node: k_waterfill at its extreme (the oracle's digest took 2.5 h of one core)
+# service on 100k nodes, ten tasks a node: k_waterfill at its extreme (the oracle's digest took 74 min of one core)
 @pytest.mark.parametrize("case", ["cfg4_full", "cfg5_churn_60k", "cfg5_churn", "refbench_100k_1m"])
 def test_baseline_size_script_matches_oracle_digests(case):
     path = os.path.join(GOLD, "big_%s.json" % case)
