@@ -495,7 +495,11 @@ class NodeTasks {
     }
     void put(const std::string& id, const Value& t) {
         if (Value* have = find(id)) { *have = t; return; }
-        if (tree_.empty() && flat_.size() < TASKS_FLAT) { flat_.emplace_back(id, t); return; }
+        if (tree_.empty() && flat_.size() < TASKS_FLAT) {
+            if (flat_.capacity() == 0) flat_.reserve(12);   // (a node's first task: room for the usual dozen at once)
+            flat_.emplace_back(id, t);
+            return;
+        }
         for (auto& kv : flat_) tree_.emplace(std::move(kv.first), std::move(kv.second));
         flat_.clear();
         tree_.emplace(id, t);
