@@ -147,6 +147,7 @@ struct R6Args {
     struct R7Trail* trail_out;   // = the slots of its R7Tail
 };
 struct R7Args;   // swp_resolve7.hpp: what a shard's commit kernel knows of the other shards
+#define R7_FOLDS_IN_FLIGHT 4u   // waves that fold at the same time (the R7 staging below); SWP_DBG bits 8-11 override it for A/B runs (tools/gpu_r5_foldwin.sh)
 #define R7M_EXC 0x100u   // H_meta of a folded record: list length | the task has an exception-list candidate on some shard | it does not count on its node | it has cluster mounts
 #define R7M_UNC 0x200u
 #define R7M_CSI 0x400u
@@ -739,6 +740,14 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
     // every thread stages the lists of its task (wave g: the block's group g): the matcher walks them with a cursor (an entry is looked
     // at once) instead of holding all of them in registers. No barrier: a group's flag is published when its lists are in LDS.
     if constexpr (R7) {
+        // A few folds at a time, in group order: a fold is three dependent batches of uncoalesced loads, and the batches of eleven waves
+        // queue up in the CU's one address path — the matcher's own group (wave 0 stages it) then waits behind all the others': 27.8 k
+        // cycles before the matching starts. Alone a fold takes 11.9 k (latency bound), but then the chain is slower than the matcher
+        // (a group is matched in ≈ 11 k): measured on cfg4 200k x 40k over 4 / 8 shards, window 1: 33.6 / 45.1 ms, 2: 29.8 / 38.1,
+        // 4: 30.1 / 37.2, all at once: 30.9 / 38.4. (Between GPUs a batch takes longer — peer reads — so rather more in flight than fewer.)
+        const u32 fw = ((a.dbg >> 8) & 15u) ? ((a.dbg >> 8) & 15u) : R7_FOLDS_IN_FLIGHT;
+        if (wave_ >= fw)
+            while (wv::lds_poll32(staged + (wave_ - fw)) == 0) wv::spin_pause();
         if ((tid & ~63u) < n) r7_fold_into(m7, tid < n ? tid : 0u, tid < n, a.block, L_hw, L_hb, H_level, H_meta, sh);   // (whole waves: it ballots)
     } else if (tid < n) {
         const R6Prop* q = a.prop + tid;
