@@ -199,7 +199,7 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
         achieved = alg_launch / (launch_ms * 1e-3) / 1e9
         # (the PMC passes of tools/profile_round5.sh ran THIS shape: cfg4 200k x 40k over 4 shards — other shapes carry no traffic figure)
         profiled = args.workload == "cfg4" and wl.T == 200000 and wl.N == 40000 and len(ranges) == 4 and world == 1
-        traffic, traffic_src = profile_traffic(["k_r7_propose", "k_r7_commit"], run="shards4") if profiled else (None, "no PMC pass for this shape (tools/profile_round5.sh profiles cfg4 200k x 40k over 4 shards)")
+        traffic, traffic_src = profile_traffic(["k_r7_propose", "k_r7_propose_small", "k_r7_commit"], run="shards4") if profiled else (None, "no PMC pass for this shape (tools/profile_round5.sh profiles cfg4 200k x 40k over 4 shards)")
         note = ("a 'launch' is one ROUND of the whole job: every shard's k_r7_propose, the exchange of the proposals, every shard's k_r7_commit (fold + match + apply); "
                 "its time is the step time over the rounds (host gaps included), its bytes are the round's share of the batch's algorithmic bytes over ALL shards")
         kernels_ms = {"one round (k_r7_propose + exchange + k_r7_commit), wall": t_step * 1e3 / max(rounds, 1)}
@@ -359,7 +359,7 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
     row_b = ROW_B.get(args.workload, 48)
     alg = (replaced / R) * wl.N * row_b + (replaced / R) * TASK_B
     n_shards = world if by_rank else (eng.shards or 1)
-    churn_traffic = (profile_traffic(["k_r7_propose", "k_r7_commit"], run="churn_shards4") if n_shards > 1
+    churn_traffic = (profile_traffic(["k_r7_propose", "k_r7_propose_small", "k_r7_commit"], run="churn_shards4") if n_shards > 1
                      else profile_traffic(["k_r6_compact", "k_r6_propose_small_c", "k_r6_commit_c"], run="churn"))
     if by_rank:
         par, exch = "node-shard", "one engine per rank over its node range; per round of the resolver an ncclAllGather of the block's proposals (swp_shard_run_rank); drains and swp_commit(remove) on the owner rank"
