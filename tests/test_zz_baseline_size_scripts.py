@@ -53,3 +53,21 @@ def test_cfg4_1m_x_100k_over_8_shards_matches_the_oracle_digest():
     h, placed = tes._digest(wl, sp, se)
     assert placed == want["placed"][0]
     assert h == want["ticks"][0]
+
+
+def test_the_full_churn_script_over_a_shard_set_matches_the_oracle_digests():
+    """BASELINE configs[4] at its stated size — 100 rounds of {drain 10 % of 10 000 nodes, delete their tasks, create as many} on 100 000
+    tasks — over a shard SET of 4 engines (row e2: the incremental path over node-range shards): all 101 tick digests of the oracle's
+    single sequential scheduler."""
+    path = os.path.join(GOLD, "big_cfg5_churn.json")
+    if not os.path.exists(path) or os.environ.get("SWP_TEST_HUGE") == "0":
+        pytest.skip("no digest / SWP_TEST_HUGE=0")
+    want = json.load(open(path))
+    sched = swhost.HostScheduler(shards=4, nodes_per_shard=(want["N"] + 3) // 4)
+    got = bigcases.CASES["cfg5_churn"](sched)
+    assert sched.e.stats()["last_resolver"] == 7
+    assert got["placed"] == want["placed"]
+    bad = [i for i, (a, b) in enumerate(zip(got["ticks"], want["ticks"])) if a != b]
+    assert not bad, "tick digests differ at ticks %s" % bad[:10]
+    for k in ("created", "still_placed", "rounds"):
+        assert got[k] == want[k], k
