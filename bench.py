@@ -33,6 +33,18 @@ FILTERS = {"cfg2": "Resource filter", "cfg3": "Resource+Constraint+Platform filt
            "cfg4": "Resource+Constraint+Platform+HostPort+MaxReplicas+Plugin filters"}
 
 
+def emit_line(text):
+    """The ONE JSON line of the run, as the LAST thing on stdout: whatever native libraries left in the C runtime's stdout buffer (RCCL
+    prints a version banner there when a communicator is created) is flushed first, then the line goes out unbuffered."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    os.write(1, (text + "\n").encode())
+
+
 def profile_traffic(kernel, run=None):
     """HBM bytes per launch of the dominant kernel(s) from the committed PMC summary (profiles/r05_pmc_summary.json, produced by
     tools/profile_round5.sh on the GPU box: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, corrected 2*FETCH + WRITE) — a
@@ -112,6 +124,11 @@ def cpu_baseline(wl, budget_s=12.0):
                       f"(oracle tick() wall time {total_dt:.2f} s, after a {probe}-task warm-in)"}
 
 
+# SWP_BENCH_RANK_PATH=1 (a check, not a measurement mode): a job of ONE rank takes the code paths of a rank of many — DeviceRankShard,
+# swp_shard_run_rank with its ncclAllGather, the churn script by owner rank — so that they can be exercised on a one-GPU box.
+RANK_PATH = os.environ.get("SWP_BENCH_RANK_PATH") == "1"
+
+
 def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
     """Node-range shards: the SAME 100k x 10k (or --workload / --tasks / --nodes) job, the node set split over the
     ranks. Per step: device state restore, then rounds of {k_propose over a block of tasks on every shard, all-gather of the
@@ -139,7 +156,7 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
     state = {"host_merge": bool(args.host_merge) or os.environ.get("SWP_SHARD_EXCHANGE") == "host"}
 
     def make_driver():
-        if world > 1 and not state["host_merge"]:   # rounds on the device, an ncclAllGather of the block's proposals per round (swp_shard_run_rank)
+        if (world > 1 or RANK_PATH) and not state["host_merge"]:   # rounds on the device, an ncclAllGather of the block's proposals per round (swp_shard_run_rank)
             try:
                 return swshard.DeviceRankShard(batches[0], rank, world, ranges, dist, ranks.device, fold=False)
             except swshard.RcclUnavailable as exc:   # raised on EVERY rank (the bootstrap agrees on its outcome): all take the same way out
@@ -233,7 +250,7 @@ def run_sharded(args, ranks, wl, eng, sched, descs, ranges, t_host_prep):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(wl)
     if rank == 0:
-        print(json.dumps(result))
+        emit_line(json.dumps(result))
     for b in batches:
         b.free()
     ranks.close()
@@ -255,7 +272,7 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
     import torch.distributed as dist
     from swarmkit_amd import abi, shard as swshard
     rank, world = ranks.rank, ranks.world
-    by_rank = world > 1
+    by_rank = world > 1 or RANK_PATH
     first, cnt = (ranges[rank] if by_rank else (0, wl.N))
     state = {"rounds_total": 0}
 
@@ -390,7 +407,7 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(wl, budget_s=8.0)
     if rank == 0:
-        print(json.dumps(res))
+        emit_line(json.dumps(res))
     ranks.close()
 
 
@@ -453,7 +470,7 @@ def main():
                 placed = sum(1 for d in dec if d["NodeID"])
             st = s.e.stats()
         t_step = sum(ticks) / max(len(ticks), 1)
-        print(json.dumps({"metric": f"task placements/sec, the reference's benchScheduler shape ({n_tasks // 1000}k tasks of one service x {n_nodes} nodes), end to end through Scheduler.tick()",
+        emit_line(json.dumps({"metric": f"task placements/sec, the reference's benchScheduler shape ({n_tasks // 1000}k tasks of one service x {n_nodes} nodes), end to end through Scheduler.tick()",
                           "value": n_tasks / t_step, "unit": "placements/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
                           "config": {"workload": "refbench", "tasks": n_tasks, "nodes": n_nodes, "services": 1, "path": "k_waterfill" if st["waterfill_tasks"] else "resolver"},
@@ -470,7 +487,7 @@ def main():
         print(f"bench.py: --mode {args.mode} is not run over node-range shards here; use --parallelism replicas (or single)", file=sys.stderr)
         sys.exit(2)
     shard_mode = par == "node-shard"
-    churn_set = shard_mode and args.mode == "churn" and world == 1   # --shards G: ONE handle over G engines on this GPU (swp_shardset_create)
+    churn_set = shard_mode and args.mode == "churn" and world == 1 and not RANK_PATH   # --shards G: ONE handle over G engines on this GPU (swp_shardset_create)
     if churn_set:
         from swarmkit_amd import shard as swshard
         wl = synth.Workload(args.workload, T=args.tasks, N=args.nodes, order=args.order, services=args.services)
@@ -551,7 +568,7 @@ def main():
             dt = time.perf_counter() - t0
             res["cpu_baseline"] = {"value": nt / dt, "unit": "task checks/s", "cores": 1, "kind": "port",
                                    "sample": f"oracle enforce_node on the first {sample} nodes ({nt} tasks, {dt:.2f} s incl. JSON marshalling)"}
-        print(json.dumps(res))
+        emit_line(json.dumps(res))
         ranks.close()
         return
     if args.mode == "grouped":
@@ -608,7 +625,7 @@ def main():
                 model, nproc = host_cpu()
                 res["cpu_baseline"] = {"value": cnt / dt, "unit": "placements/s", "cores": 1, "kind": "port", "cpu_model": model, "nproc": nproc,
                                        "sample": f"the first {n_groups} groups of the same workload ({cnt} tasks) against all {wl.N} nodes, oracle tick() {dt:.2f} s"}
-            print(json.dumps(res))
+            emit_line(json.dumps(res))
         ranks.close()
         return
     if shard_mode:
@@ -755,7 +772,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bounded sample, ~15 s of one host core)
         result["cpu_baseline"] = cpu_baseline(wl)
     if rank == 0:
-        print(json.dumps(result))
+        emit_line(json.dumps(result))
     batch.free()
     ranks.close()
 
