@@ -60,7 +60,16 @@ class Ranks:
     def max_over_ranks(self, x):
         if self.dist is None:
             return float(x)
+        import ctypes
+        import sys
         import torch
+        # (the timing's last collective, in front of rank 0's result line: every rank empties its stdout buffers here — native
+        # libraries' banners included, NCCL_DEBUG=VERSION — so that the line is the last thing the job prints)
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
