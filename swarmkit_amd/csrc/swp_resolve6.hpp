@@ -147,6 +147,8 @@ struct R6Args {
     struct R7Trail* trail_out;   // = the slots of its R7Tail
 };
 struct R7Args;   // swp_resolve7.hpp: what a shard's commit kernel knows of the other shards
+#define R6_STAGES_IN_FLIGHT 2u    // waves that stage their lists at the same time on a single engine (measured, cfg3 / cfg4 1M x 100k: all at once 11.8 / 126.1 ms,
+                                  // 1: 11.6 / 122.7, 2: 11.5 / 122.9, 4: 11.65 / 124.5, 6: 11.7 / 125.6 — the matcher's own group no longer queues behind the others' loads)
 #define R7_FOLDS_IN_FLIGHT 4u   // waves that fold at the same time (the R7 staging below); SWP_DBG bits 8-11 override it for A/B runs (tools/gpu_r5_foldwin.sh)
 #define R7M_EXC 0x100u   // H_meta of a folded record: list length | the task has an exception-list candidate on some shard | it does not count on its node | it has cluster mounts
 #define R7M_UNC 0x200u
@@ -749,11 +751,17 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
         if (wave_ >= fw)
             while (wv::lds_poll32(staged + (wave_ - fw)) == 0) wv::spin_pause();
         if ((tid & ~63u) < n) r7_fold_into(m7, tid < n ? tid : 0u, tid < n, a.block, L_hw, L_hb, H_level, H_meta, sh);   // (whole waves: it ballots)
-    } else if (tid < n) {
-        const R6Prop* q = a.prop + tid;
-        for (int k = 0; k < 2 * R6_CAND; ++k) {
-            L_hw[(size_t)k * a.block + tid] = (unsigned short)q->hw[k];
-            L_hb[(size_t)k * a.block + tid] = q->hb[k];
+    } else {
+        // (in group order, a few at a time — as the folds above: every wave's 64 uncoalesced loads per lane share the CU's one address path)
+        const u32 sw = ((a.dbg >> 8) & 15u) ? ((a.dbg >> 8) & 15u) : R6_STAGES_IN_FLIGHT;
+        if (wave_ >= sw)
+            while (wv::lds_poll32(staged + (wave_ - sw)) == 0) wv::spin_pause();
+        if (tid < n) {
+            const R6Prop* q = a.prop + tid;
+            for (int k = 0; k < 2 * R6_CAND; ++k) {
+                L_hw[(size_t)k * a.block + tid] = (unsigned short)q->hw[k];
+                L_hb[(size_t)k * a.block + tid] = q->hb[k];
+            }
         }
     }
     wv::lockstep();
