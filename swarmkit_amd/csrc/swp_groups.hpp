@@ -138,11 +138,16 @@ inline __host__ __device__ size_t g2_arena_bytes(u32 S, u32 ntn, u32 ngen, u32 d
     return 32 * (size_t)S + 64 * ((size_t)depth + 2) + 8 * (2 * (size_t)ntn + fw) + 4 * ((size_t)S * ngen + 2 * kt + 6 * (size_t)ntn) + 64;
 }
 // mailbox, staging of one chunk of candidates, a few scalars
-#define G2_LDS_FIXED 8192
+#define G2_LDS_FIXED 9216      // (the last KB: the flat mode's scratch, g2_flat_*)
+#define G2_FLAT_OFF 8192
+#define G2_FLAT_MAXK 128u       // heap positions the flat mode's bit mask covers
 #define G2_VISW 8              // node words whose candidate keys are staged through LDS together
 inline __host__ __device__ size_t g2_lds_bytes() { return (size_t)G2_LDS_FIXED + G2_ARENA_LDS; }
 
 #ifdef SWP_G2_KERNELS
+#ifndef G2_STAT
+#define G2_STAT(i, v) ((void)0)   // (tests/emu/emu_groups.cpp counts which admission path a run took)
+#endif
 // nodeLess (scheduler.go:708-735) as ONE integer compare: key = (failures if >= 5 else 0, svcCount, total) packed 8 | 24 | 32 bits
 // (both sides below 5 failures skip the failure compare; a side at >= 5 loses against any side below).
 WV_DEV u64 g2_key(u32 fail, u32 svc, u32 total) {
@@ -463,6 +468,75 @@ WV_DEV void g2_helper(const Groups2Args& a, G2Mail* mb, u32 hid, u32 nh) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// FLAT MODE of a full heap with ONE leaf whose keys take two values (the rule while a tick runs: spread placement keeps every
+// node's task count within one of the others' — "heavy" = the root's key, "light" = the other one).
+// A candidate with the light key replaces the root and sifts down (heap.Fix(0): down(), go stdlib): it moves to the larger child
+// while that child is greater — with two values: to the LEFT child if it is heavy, else to the right one if that is heavy, else it
+// stays. So (1) the path runs through heavy positions only, every element on it moves up one position, the root's leaves the heap,
+// the new element comes to rest at the path's end; light elements never move. (2) The heavy positions form a subtree that contains
+// the root (a max-heap: a heavy child has a heavy parent), the path's end is the node a post-order walk of that subtree (left,
+// right, node) visits first, and removing it leaves a subtree of the same kind: the r-th replacement comes to rest at the r-th node of
+// the heavy subtree in POST-ORDER. (3) While a heavy element is left the root is heavy, so every light candidate is admitted; once
+// all |H| are gone the root is light and light candidates are not less than it any more.
+// Hence, as long as only light candidates come by: they are COUNTED and remembered, nothing is sifted; when |H| of them have come
+// the heap is what it was with candidate r at post-order position r of H — one parallel scatter. If the stream ends (or a candidate
+// with a third key shows up) before all heavy elements are gone, the heavy elements that are left HAVE moved: then the remembered
+// candidates are replayed one after the other by the ordinary down() (g2_flat_flush), and the ordinary code carries on.
+struct G2Flat {
+    bool on;          // wave-uniform, every lane's copy
+    u64 hi, lo;       // the two keys (lo == KEY_NONE: every element is heavy so far, the first candidate below hi names it)
+    u64 m0, m1;       // heavy positions 0..63, 64..127
+    u32 nh, n;        // |H|; candidates remembered so far (n <= nh)
+};
+// heavy positions below position x (x <= 128)
+WV_DEV u32 g2_flat_below(const G2Flat& F, u32 x) {
+    if (x >= 128u) return (u32)wv::popc64(F.m0) + (u32)wv::popc64(F.m1);
+    if (x >= 64u) return (u32)wv::popc64(F.m0) + (x == 64u ? 0u : (u32)wv::popc64(F.m1 & (~0ull >> (128u - x))));
+    return x == 0u ? 0u : (u32)wv::popc64(F.m0 & (~0ull >> (64u - x)));
+}
+// heavy nodes in the subtree of position p (itself included): level j of it is the position range [(p + 1) 2^j - 1, ... + 2^j)
+WV_DEV u32 g2_flat_sub(const G2Flat& F, u32 p, u32 k) {
+    u32 c = 0;
+    for (u32 j = 0;; ++j) {
+        const u32 lo = ((p + 1u) << j) - 1u;
+        if (lo >= k) break;
+        c += g2_flat_below(F, min(lo + (1u << j), 128u)) - g2_flat_below(F, lo);
+    }
+    return c;
+}
+// The remembered candidates enter the heap. cand[r] = node of the r-th one; hs: scratch [G2_FLAT_MAXK].
+WV_DEV void g2_flat_flush(const G2Arena& A, G2Flat& F, u32 k, const u32* cand, u32* hs) {
+    const u32 lane = wv::lane();
+    if (F.n == F.nh) G2_STAT(1, F.n);
+    else G2_STAT(2, F.n);
+    if (F.n == F.nh && F.n != 0) {
+        // every heavy element was replaced: candidate r sits at the r-th heavy position in post-order
+        for (u32 p = lane; p < k; p += 64u) hs[p] = g2_flat_sub(F, p, k);
+        wv::wave_sync();
+        for (u32 p = lane; p < k; p += 64u) {
+            const bool heavy = ((p < 64u ? F.m0 >> p : F.m1 >> (p - 64u)) & 1ull) != 0;
+            if (!heavy) continue;
+            u32 r = hs[p] - 1u;   // its heavy descendants come first ...
+            for (u32 c = p; c > 0u; c = (c - 1u) >> 1)
+                if ((c & 1u) == 0u) r += hs[c - 1u];   // ... and the subtrees that hang to the LEFT of the way from the root to it
+            G2Ent he;
+            he.key = F.lo; he.node = cand[r]; he.tix = G2_NONE;
+            A.HE[p] = he;
+        }
+    } else if (F.n != 0) {
+        // heavy elements are left and have moved: the ordinary replay, one candidate after the other (rare)
+        if (lane == 0)
+            for (u32 r = 0; r < F.n; ++r) {
+                G2Ent he;
+                he.key = F.lo; he.node = cand[r]; he.tix = G2_NONE;
+                (void)g2_down_val(A, 0u, 0, (int)k, he);
+            }
+    }
+    wv::wave_sync();
+    F.on = false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // the machine: wave 0
 // ---------------------------------------------------------------------------------------------------------------------------
 struct G2Post {   // wave 0's view of the ring
@@ -545,6 +619,10 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         bool p_act = false;
         u64 p_key = 0;
         u32 p_node = 0, p_hole = 0, p_since = 2, p_slots = 0;
+        G2Flat F{false, 0, 0, 0, 0, 0, 0};   // the flat mode (above): tried once, when the one heap has just become full
+        bool flat_tried = false;
+        u32* f_cand = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + G2_FLAT_OFF);   // [G2_FLAT_MAXK] the remembered candidates' nodes
+        u32* f_hs = f_cand + G2_FLAT_MAXK;                                                            // [G2_FLAT_MAXK] scratch of the flush
         const u64* minb = a.minbuf + (size_t)b * Wn;
         const u64* ckb = a.ckeybuf + (size_t)b * N;
         u64* vis = reinterpret_cast<u64*>(reinterpret_cast<unsigned char*>(mb) + 2048);                       // [G2_VISW][64] candidate keys
@@ -577,6 +655,48 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                             if (!single) rl[q] = leaf_of[n];
                         }
                     }
+                }
+                // Flat mode (above) with nothing but the two keys in the whole batch: the light candidates of all its words are counted
+                // and remembered straight from the registers, word after word in node order — no staging, no per-word pass.
+                bool batch_done = false;
+                if (single && F.on && F.lo != KEY_NONE) {
+                    bool third = false;
+                    WV_UNROLL
+                    for (int q = 0; q < G2_VISW; ++q) third = third || (r[q] != KEY_NONE && r[q] != F.lo && r[q] < F.hi);
+                    if (wv::ballot(third) == 0) {
+                        u64 t = sm;
+                        WV_UNROLL
+                        for (int q = 0; q < G2_VISW; ++q) {
+                            if (t == 0) break;
+                            const u32 c = (u32)wv::ffs64(t);
+                            t &= t - 1ull;
+                            const bool isl = r[q] == F.lo;
+                            const u32 idx = F.n + wv::mbcnt(wv::ballot(isl));
+                            const bool acc = isl && idx < F.nh;   // (admitted while a heavy element is left: the root is heavy until then)
+                            if (acc) f_cand[idx] = (w0 + c) * 64u + lane;
+                            const u64 ab = wv::ballot(acc);
+                            if (ab) {
+                                const u32 hib = (u32)(ab >> 32), lob = (u32)ab;
+                                const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);
+                                lastp = (w0 + c) * 64u + top + 1u;   // the last Process that returned true inside tree()
+                                F.n += (u32)wv::popc64(ab);
+                                if (a.dbg & 16u) gt[12] += (u32)wv::popc64(ab);
+                            }
+                            if (a.dbg & 16u) gt[10] += 1;
+                            G2_STAT(5, 1);
+                        }
+                        wv::wave_sync();
+                        root0 = F.n < F.nh ? F.hi : F.lo;
+                        if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
+                            g2_flat_flush(A, F, k, f_cand, f_hs);
+                            root0 = A.HE[0].key;
+                        }
+                        batch_done = true;
+                    }
+                }
+                if (batch_done) {
+                    if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;
+                    continue;
                 }
                 WV_UNROLL
                 for (int q = 0; q < G2_VISW; ++q) {
@@ -643,6 +763,54 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     }
                 }
                 if (first == ne) continue;
+                if (single && len0 >= k && !flat_tried && k <= G2_FLAT_MAXK) {
+                    // the heap has just become full (nothing is in flight yet): do its keys take two values?
+                    flat_tried = true;
+                    const u64 k0 = lane < k ? A.HE[lane].key : 0ull, k1 = lane + 64u < k ? A.HE[lane + 64u].key : 0ull;
+                    F.hi = wv::readlane64(k0, 0);
+                    F.m0 = wv::ballot(lane < k && k0 == F.hi);
+                    F.m1 = wv::ballot(lane + 64u < k && k1 == F.hi);
+                    const u64 o0 = (lane < k && k0 != F.hi) ? k0 : KEY_NONE, o1 = (lane + 64u < k && k1 != F.hi) ? k1 : KEY_NONE;
+                    F.lo = g2_wave_min64(o0 < o1 ? o0 : o1);
+                    F.on = wv::ballot((lane < k && k0 != F.hi && k0 != F.lo) || (lane + 64u < k && k1 != F.hi && k1 != F.lo)) == 0;
+                    F.nh = (u32)wv::popc64(F.m0) + (u32)wv::popc64(F.m1);
+                    F.n = 0;
+                    if (F.on) G2_STAT(0, 1);
+                }
+                if (F.on) {
+                    // the word's remaining candidates in lane order (= node order: the compaction keeps it)
+                    const bool mineC = cand && myj >= first;
+                    if (F.lo == KEY_NONE) {   // every element is heavy: the first candidate below the root names the light key
+                        const u64 b0 = wv::ballot(mineC && key < F.hi);
+                        if (b0) F.lo = wv::readlane64(key, (u32)wv::ffs64(b0));
+                    }
+                    const bool is_lo = mineC && F.lo != KEY_NONE && key == F.lo;
+                    const u32 before = wv::mbcnt(wv::ballot(is_lo));          // light candidates in front of this lane
+                    const bool root_heavy = F.n + before < F.nh;              // ... all admitted while a heavy element was left
+                    const bool foreign = mineC && key != F.lo && key < (root_heavy ? F.hi : F.lo);   // admitted, with a third key
+                    const u64 fb = wv::ballot(foreign);
+                    const u32 fl = fb ? (u32)wv::ffs64(fb) : 64u;
+                    const bool acc = is_lo && root_heavy && lane < fl;
+                    const u64 ab = wv::ballot(acc);
+                    if (acc) f_cand[F.n + before] = n;
+                    if (ab) {
+                        u32 hib = (u32)(ab >> 32), lob = (u32)ab;
+                        const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);   // the last admitted lane
+                        lastp = wv::readlane(n, top) + 1u;       // the last Process that returned true inside tree()
+                        F.n += (u32)wv::popc64(ab);
+                        if (a.dbg & 16u) gt[12] += (u32)wv::popc64(ab);
+                    }
+                    wv::wave_sync();
+                    root0 = F.n < F.nh ? F.hi : F.lo;
+                    if (fb == 0 && F.n < F.nh) continue;
+                    // all heavy elements are gone, or a candidate with a third key is admitted: the remembered ones enter the heap and the
+                    // ordinary code carries on — with that candidate, if there is one
+                    if (fb) G2_STAT(3, 1);
+                    g2_flat_flush(A, F, k, f_cand, f_hs);
+                    root0 = A.HE[0].key;
+                    if (fb == 0) continue;
+                    first = (u32)wv::popc64(bal & ((1ull << fl) - 1ull));   // (fl < 64 here)
+                }
                 if (single && len0 >= k) {
                     // ---- the heap is full: every remaining candidate either replaces the root (heap.Fix(0), a sift from the top) or is not
                     // less than it. A sift only ever touches deeper levels as it goes, so the next replacement may start two steps behind
@@ -684,6 +852,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                                 p_since = 0;
                                 lastp = en + 1u;       // the last Process that returned true inside tree()
                                 ci = f + 1u;
+                                G2_STAT(4, 1);
                                 if (a.dbg & 16u) gt[12] += 1;
                             }
                         }
@@ -752,6 +921,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
               }
             }
         }
+        if (F.on) g2_flat_flush(A, F, k, f_cand, f_hs);   // the stream ended in flat mode
         while (wv::ballot(p_act)) {   // the replacements still in flight run to their ends
             const u32 j1 = 2u * p_hole + 1u;
             const bool has = p_act && j1 < k;
@@ -1165,7 +1335,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
     G2Mail* mb = reinterpret_cast<G2Mail*>(l);
     G2Stage* sg = reinterpret_cast<G2Stage*>(l + 512);
-    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 12 <= G2_LDS_FIXED, "fixed LDS layout");
+    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 12 <= G2_FLAT_OFF && G2_FLAT_OFF + 8 * G2_FLAT_MAXK <= G2_LDS_FIXED, "fixed LDS layout");
     const u32 wave = wv::wave(), lane = wv::lane(), nh = wv::nthreads() / 64u - 1u;
     if (wv::tid() == 0) { mb->posted = 0; mb->done = 0; mb->quit = 0; }
     wv::barrier();

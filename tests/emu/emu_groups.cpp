@@ -9,6 +9,11 @@
 // Built twice by the test: as is, and with -DG2_ARENA_LDS=3072 so that most groups take the global-memory instance of the machine.
 #include "wv_emu.hpp"
 
+// which of the machine's admission paths a run took (the kernel's G2_STAT hook; the product compiles it away): [0] heaps that went into
+// flat mode, [1] candidates that entered by the post-order scatter, [2] ... by the one-by-one replay of a flush, [3] flushes forced by a
+// candidate with a third key, [4] root replacements of the ordinary pipelined code, [5] node words whose candidates were taken by a whole batch in flat mode
+static unsigned long long g2_stat[8];
+#define G2_STAT(i, v) do { if (wv::lane() == 0) g2_stat[i] += (unsigned long long)(v); } while (0)
 #define SWP_G2_KERNELS
 #include "../../swarmkit_amd/csrc/swp_groups.hpp"
 
@@ -503,8 +508,11 @@ int main(int argc, char** argv) {
         left_groups += any;
         lds_groups += g2_arena_bytes(p.groups[g].n_slots, tree_off[p.groups[g].tree + 1] - tree_off[p.groups[g].tree], p.groups[g].n_gen, max_depth, p.groups[g].k) <= G2_ARENA_LDS;
     }
-    if (verbose || bad)
+    if (verbose || bad) {
+        fprintf(stderr, "admission paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu words taken by whole batches in flat mode\n",
+                g2_stat[0], g2_stat[1], g2_stat[2], g2_stat[3], g2_stat[4], g2_stat[5]);
         fprintf(stderr, "emu_groups seed %u N %u groups %zu (LDS arena: %u) trees %zu: %u of %zu tasks placed, %u groups with an explanation -> %s\n", seed, N,
                 p.groups.size(), lds_groups, p.trees.size(), placed, out.size(), left_groups, bad ? "FAILED" : "OK");
+    }
     return bad ? 1 : 0;
 }
