@@ -50,6 +50,14 @@ CASES = [
     (32, 70, 40, 30, 3, 3, 256),       # barely more than one node word, many small groups
     (33, 64, 25, 200, 2, 2, 128),      # exactly one node word
     (41, 1500, 30, 5, 4, 3, 256),      # groups of a handful of tasks
+    # one leaf, heaps of up to 128: the FLAT MODE of a heap whose keys take two values — light candidates counted and
+    # scattered by post-order rank, flushes replayed one by one when the stream ends first, a third key forcing the ordinary code
+    (5, 300, 12, 120, 1, 0, 256),
+    (7, 2000, 20, 100, 1, 0, 256),
+    (101, 500, 10, 128, 1, 1, 256),
+    (102, 200, 16, 100, 1, 2, 128),
+    (103, 1000, 8, 128, 1, 3, 1024),
+    (104, 3000, 12, 90, 1, 0, 256),
 ]
 
 
@@ -60,9 +68,27 @@ def test_group_kernel_source_matches_sequential_model(emu_lds, case):
     assert "-> OK" in r.stderr
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[0] in (11, 14, 21, 23, 31, 32)], ids=lambda c: "seed%d-N%d-g%d-k%d-t%d-f%d-w%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6] // 64))
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in (11, 14, 21, 23, 31, 32, 5, 7, 101)], ids=lambda c: "seed%d-N%d-g%d-k%d-t%d-f%d-w%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6] // 64))
 def test_global_memory_instance(emu_global, case):
     """The same machine with its working set in global memory (groups whose heaps exceed the LDS arena)."""
     r = subprocess.run([emu_global] + [str(x) for x in case] + ["v"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr
+
+
+def test_the_flat_mode_and_its_ways_out_are_taken(emu_lds):
+    """The cases above are only worth something if the admission really takes the paths they are there for: the kernel's G2_STAT hook
+    (compiled away in the product) counts them."""
+    import re
+
+    def paths(case):
+        r = subprocess.run([emu_lds] + [str(x) for x in case] + ["v"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "-> OK" in r.stderr, r.stderr[-2000:]
+        m = re.search(r"admission paths: (\d+) heaps in flat mode, (\d+) candidates by the post-order scatter, (\d+) by a flush's replay, (\d+) flushes forced by a third key, "
+                      r"(\d+) pipelined root replacements, (\d+) words taken by whole batches", r.stderr)
+        assert m, r.stderr[-500:]
+        return [int(x) for x in m.groups()]
+    flat, scatter, replay, third, piped, batch_words = paths((5, 300, 12, 120, 1, 0, 256))
+    assert flat >= 5 and scatter >= 100 and replay >= 10
+    flat, scatter, replay, third, piped, batch_words = paths((7, 2000, 20, 100, 1, 0, 256))
+    assert flat >= 5 and third >= 1 and piped >= 100 and batch_words >= 8
