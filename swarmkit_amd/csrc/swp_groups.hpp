@@ -619,6 +619,8 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         bool p_act = false;
         u64 p_key = 0;
         u32 p_node = 0, p_hole = 0, p_since = 2, p_slots = 0;
+        bool u_valid = true;   // one leaf, still filling: every element so far has the same key u_key (nothing ever moved) — then a batch of words
+        u64 u_key = KEY_NONE;  // whose candidates all have that key too is ONE append (below)
         G2Flat F{false, 0, 0, 0, 0, 0, 0};   // the flat mode (above): tried once, when the one heap has just become full
         bool flat_tried = false;
         u32* f_cand = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + G2_FLAT_OFF);   // [G2_FLAT_MAXK] the remembered candidates' nodes
@@ -637,6 +639,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
               // The candidate keys of the next G2_VISW words to visit go through LDS: their loads are all in flight together, so the
               // replay below never waits for global memory.
               u64 sm = 0;
+              u32 vq0 = 0;   // words at the front of the batch that were taken whole
               {
                 u64 r[G2_VISW];
                 u32 rl[G2_VISW];
@@ -659,7 +662,55 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 // Flat mode (above) with nothing but the two keys in the whole batch: the light candidates of all its words are counted
                 // and remembered straight from the registers, word after word in node order — no staging, no per-word pass.
                 bool batch_done = false;
-                if (single && F.on && F.lo != KEY_NONE) {
+                // The heap is still filling and every element has the same key (heap.Push moves nothing: the new element is never above
+                // its parent): words whose candidates all have that key, and fit, are appended whole, straight from the registers.
+                if (single && len0 < k && u_valid) {
+                    u64 uk = len0 == 0 ? KEY_NONE : u_key;
+                    if (uk == KEY_NONE) {   // an empty heap: its first element names the key
+                        WV_UNROLL
+                        for (int q = 0; q < G2_VISW; ++q) {
+                            const u64 bq = wv::ballot(r[q] != KEY_NONE);
+                            if (uk == KEY_NONE && bq) uk = wv::readlane64(r[q], (u32)wv::ffs64(bq));
+                        }
+                    }
+                    bool odd = false;
+                    WV_UNROLL
+                    for (int q = 0; q < G2_VISW; ++q) odd = odd || (r[q] != KEY_NONE && r[q] != uk);
+                    if (uk != KEY_NONE && wv::ballot(odd) == 0) {
+                        u64 t = sm;
+                        WV_UNROLL
+                        for (int q = 0; q < G2_VISW; ++q) {
+                            if (t == 0) break;
+                            const u32 c = (u32)wv::ffs64(t);
+                            const bool have = r[q] != KEY_NONE;
+                            const u64 bq = wv::ballot(have);
+                            const u32 cnt = (u32)wv::popc64(bq);
+                            if (len0 + cnt > k) break;   // this word fills the heap beyond its size: the per-word pass takes over here
+                            t &= t - 1ull;
+                            ++vq0;
+                            if (have) {
+                                G2Ent he;
+                                he.key = uk; he.node = (w0 + c) * 64u + lane; he.tix = G2_NONE;
+                                A.HE[len0 + wv::mbcnt(bq)] = he;
+                            }
+                            if (bq) {
+                                const u32 hib = (u32)(bq >> 32), lob = (u32)bq;
+                                const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);
+                                lastp = (w0 + c) * 64u + top + 1u;
+                                if (len0 == 0) root0 = uk;
+                                len0 += cnt;
+                                if (a.dbg & 16u) { gt[11] += cnt; gt[14] += cnt; }
+                            }
+                            if (a.dbg & 16u) gt[10] += 1;
+                            G2_STAT(6, 1);
+                        }
+                        wv::wave_sync();
+                        u_key = uk;
+                        sm = t;
+                        if (sm == 0) batch_done = true;
+                    }
+                }
+                if (!batch_done && single && F.on && F.lo != KEY_NONE) {
                     bool third = false;
                     WV_UNROLL
                     for (int q = 0; q < G2_VISW; ++q) third = third || (r[q] != KEY_NONE && r[q] != F.lo && r[q] < F.hi);
@@ -705,7 +756,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 }
                 if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;   // (mostly: waiting for the loads)
               }
-              u32 vq = 0;
+              u32 vq = vq0;
               while (sm) {
                 const u32 c = (u32)wv::ffs64(sm);
                 sm &= sm - 1ull;
@@ -754,7 +805,8 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                             he.key = key; he.node = n; he.tix = G2_NONE;
                             A.HE[len0 + myj] = he;
                         }
-                        if (len0 == 0) root0 = sg->ent[0].key;
+                        if (len0 == 0) { root0 = sg->ent[0].key; u_key = root0; }
+                        if (wv::ballot(cand && myj < np && key != u_key)) u_valid = false;
                         lastp = sg->ent[np - 1u].node + 1u;
                         len0 += np;
                         first = np;
@@ -860,6 +912,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     if (a.dbg & 16u) gt[13] += wv::clock64() - ta_;
                     continue;
                 }
+                u_valid = false;   // (lane 0 replays pushes that move something: the heap is no longer known to hold one key)
                 if (lane == 0) {
                     const u64 ta_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
                     if (single) { c_lf = 0; hbase = 0; hlen = (int)len0; hroot = root0; }

@@ -5,13 +5,13 @@
 // (nodeLess on the three fields instead of the packed key, swap-based sifts, a recursive tree walk with a std::set as noRoom, the
 // Explain counters by the actual call sequence). TEST INFRASTRUCTURE (tests/test_emu_groups.py); not product.
 //
-//   emu_groups <seed> <N> <groups> <kmax> <trees> <features 0..3> <threads> [v]
+//   emu_groups <seed> <N> <groups> <kmax> <trees> <features 0..3> <threads> [v] [u]   (u: every node starts with the same task count)
 // Built twice by the test: as is, and with -DG2_ARENA_LDS=3072 so that most groups take the global-memory instance of the machine.
 #include "wv_emu.hpp"
 
 // which of the machine's admission paths a run took (the kernel's G2_STAT hook; the product compiles it away): [0] heaps that went into
 // flat mode, [1] candidates that entered by the post-order scatter, [2] ... by the one-by-one replay of a flush, [3] flushes forced by a
-// candidate with a third key, [4] root replacements of the ordinary pipelined code, [5] node words whose candidates were taken by a whole batch in flat mode
+// candidate with a third key, [4] root replacements of the ordinary pipelined code, [5] node words whose candidates were taken by a whole batch in flat mode, [6] node words appended whole while a heap of one key was filling
 static unsigned long long g2_stat[8];
 #define G2_STAT(i, v) do { if (wv::lane() == 0) g2_stat[i] += (unsigned long long)(v); } while (0)
 #define SWP_G2_KERNELS
@@ -95,6 +95,7 @@ static Tree make_tree(Rng& r, u32 N, const std::vector<u64>& valid, u32 levels, 
     return t;
 }
 
+static bool g_level_start = false;   // 'u': every node starts with the same task count (a tick on a balanced cluster: heaps of one key, then of two)
 static Problem make_problem(u32 seed, u32 N, u32 n_groups, u32 kmax, u32 n_trees, int feat) {
     Rng r{0xC0FFEE00ull + seed};
     Problem p;
@@ -116,7 +117,7 @@ static Problem make_problem(u32 seed, u32 N, u32 n_groups, u32 kmax, u32 n_trees
     p.plug = bits(p.n_plug, 85);
     State& s = p.st0;
     s.cpu.resize(N); s.mem.resize(N); s.total.resize(N);
-    const u32 spread = 1 + r.below(4);
+    const u32 spread = g_level_start ? 1u : 1 + r.below(4);
     for (u32 n = 0; n < N; ++n) {
         s.cpu[n] = (i64)(1 + r.below(16)) * 1000;
         s.mem[n] = (i64)(1 + r.below(16)) * 1000;
@@ -398,8 +399,10 @@ int main(int argc, char** argv) {
     const int feat = atoi(argv[6]);
     const u32 threads = atoi(argv[7]);
     bool verbose = false;
-    for (int i = 8; i < argc; ++i)
+    for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
+        if (argv[i][0] == 'u') g_level_start = true;
+    }
     Problem p = make_problem(seed, N, n_groups, kmax, n_trees, feat);
     Model m(p);
     m.run();
@@ -509,8 +512,8 @@ int main(int argc, char** argv) {
         lds_groups += g2_arena_bytes(p.groups[g].n_slots, tree_off[p.groups[g].tree + 1] - tree_off[p.groups[g].tree], p.groups[g].n_gen, max_depth, p.groups[g].k) <= G2_ARENA_LDS;
     }
     if (verbose || bad) {
-        fprintf(stderr, "admission paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu words taken by whole batches in flat mode\n",
-                g2_stat[0], g2_stat[1], g2_stat[2], g2_stat[3], g2_stat[4], g2_stat[5]);
+        fprintf(stderr, "admission paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu words taken by whole batches in flat mode, %llu words appended whole while a heap of one key filled\n",
+                g2_stat[0], g2_stat[1], g2_stat[2], g2_stat[3], g2_stat[4], g2_stat[5], g2_stat[6]);
         fprintf(stderr, "emu_groups seed %u N %u groups %zu (LDS arena: %u) trees %zu: %u of %zu tasks placed, %u groups with an explanation -> %s\n", seed, N,
                 p.groups.size(), lds_groups, p.trees.size(), placed, out.size(), left_groups, bad ? "FAILED" : "OK");
     }

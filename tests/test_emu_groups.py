@@ -59,6 +59,9 @@ CASES = [
     (103, 1000, 8, 128, 1, 3, 1024),
     (104, 3000, 12, 90, 1, 0, 256),
 ]
+# ... the same shapes on a LEVEL cluster (every node starts with the same task count: option u): a tick's first heaps hold one key and
+# are appended whole batches at a time, the later ones two
+LEVEL = [(1, 3000, 40, 100, 1, 0, 256), (2, 2000, 30, 128, 1, 1, 256), (3, 1500, 30, 64, 1, 2, 128), (4, 4000, 25, 120, 1, 3, 1024)]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d-N%d-g%d-k%d-t%d-f%d-w%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6] // 64))
@@ -92,3 +95,13 @@ def test_the_flat_mode_and_its_ways_out_are_taken(emu_lds):
     assert flat >= 5 and scatter >= 100 and replay >= 10
     flat, scatter, replay, third, piped, batch_words = paths((7, 2000, 20, 100, 1, 0, 256))
     assert flat >= 5 and third >= 1 and piped >= 100 and batch_words >= 8
+
+
+@pytest.mark.parametrize("case", LEVEL, ids=lambda c: "level-seed%d-N%d-g%d-k%d-f%d" % (c[0], c[1], c[2], c[3], c[5]))
+@pytest.mark.parametrize("arena", ["lds", "global"])
+def test_a_tick_on_a_level_cluster(emu_lds, emu_global, case, arena):
+    import re
+    r = subprocess.run([emu_lds if arena == "lds" else emu_global] + [str(x) for x in case] + ["v", "u"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "-> OK" in r.stderr, r.stderr[-2000:]
+    m = re.search(r"(\d+) candidates by the post-order scatter.* (\d+) words appended whole", r.stderr)
+    assert m and int(m.group(1)) > 100 and int(m.group(2)) >= 1, r.stderr[-600:]
