@@ -601,8 +601,8 @@ def main():
                                 "traffic_source": profile_traffic("k_groups2", run="grouped")[1], "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_ms": t_step * 1e3,
                                 "note": "one launch = the whole tick (S groups, one workgroup: a machine wave + 15 helper waves); end-to-end step time (no separate kernel events on this path). "
-                                        "The tick is bound by the machine wave's instruction issue while it replays container/heap in the reference's exact order (pipelined root replacements, "
-                                        "parallel appends / rotation / fill where the keys allow), not by bytes: the fraction says how far from a streaming scan that is"}}
+                                        "The tick is bound by the machine wave's instruction issue while it replays container/heap in the reference's exact order (a two-key heap admits light candidates by counting them and scatters them by post-order rank, "
+                                        "pipelined root replacements otherwise, parallel appends / rotation / fill where the keys allow), not by bytes: the fraction says how far from a streaming scan that is"}}
             if world == 1 and not args.no_cpu_baseline:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import orc
