@@ -409,12 +409,14 @@ int swp_shard_end(swp_engine*, swp_batch*, int32_t* out_node_local, uint32_t* ou
 
 /* The same job with the ROUNDS ON THE DEVICE, for the deployment a Go manager is: ONE process, n engines — one per GPU of the box
  * (peer access over xGMI), or several on one GPU — engines[g] owning node range g of the canonical order, batches[g] prepared on
- * engines[g] from the SAME task list. Per round every shard proposes for a block of tasks over its own nodes (the block resolver's
- * propose kernel, 16 non-empty half-words per task), the leader (shard 0) folds the records of all shards into one list per task in
- * global node order and walks the block with its matching wave — the per-task "allreduce(min-score, argmin-node)" of the node-range
- * split, done for the whole block by the one wave that has to order it — and every shard applies the picks of its range. No host
- * work inside a round: the call enqueues rounds on the engines' streams (events order them across engines) and reads the leader's
- * counters every few dozen rounds. At most 8 shards; generic reservations are not part of it yet (SWP_EUNSUPPORTED).
+ * engines[g] from the SAME task list. Per round — two kernel launches per device — every shard proposes for a block of tasks over its
+ * own nodes (the block resolver's propose kernel: up to 32 non-empty half-words per task), and every shard then folds the records of
+ * ALL shards into one list per task in global node order, walks the block with its matching wave — the per-task "allreduce(min-score,
+ * argmin-node)" of the node-range split, done for the whole block by the wave that has to order it; every shard derives the same
+ * picks from the same bytes, so no pick travels — and applies the picks that landed in its own range. No host work inside a round: the
+ * call enqueues rounds on the engines' streams (events order them across devices) and reads a header every few dozen rounds. At most 8
+ * shards. Generic reservations and cluster mounts are carried (a placed task's volumes travel behind its owner's next proposals; the
+ * volume table is replicated on every shard).
  *   out_shard[i]    owner of task i's node, -1 = no suitable node
  *   out_node[i]     shard-LOCAL node index on that engine
  *   out_fail_hist   [n_tasks][SWP_NFILTERS], summed over the shards; may be NULL
@@ -425,7 +427,9 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
 
 /* The rank variant: ONE engine per process / GPU, the ranks of a job connected by RCCL over xGMI (librccl.so is loaded on first use;
  * the engine links nothing of it). The rounds are the same kernels — every rank proposes over its own node range, an
- * ncclAllGather on the engine's stream hands every rank the proposals of all of them (block x 288 bytes per rank and round), and
+ * ncclAllGather on the engine's stream hands every rank the proposals of all of them (block x 288 + 144 bytes per rank and round: the
+ * proposals, the trailer slots of a placed task's volumes and the rank's `dead` word — a rank whose launch failed keeps issuing the
+ * stretch's collectives with that word set, every rank's kernels stand still, and all ranks leave at the next status exchange), and
  * EVERY rank folds + matches the block (the same deterministic wave everywhere: no second collective to agree on the picks) and
  * applies the picks of its own range. Bootstrap as usual with RCCL: rank 0 fills an id (swp_rccl_unique_id), the application
  * hands it to the other ranks over whatever it has (the Go manager's raft / gRPC; bench.py: torch.distributed), every rank calls

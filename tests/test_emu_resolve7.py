@@ -1,5 +1,5 @@
-"""The node-range shard kernels with the rounds on the device (swarmkit_amd/csrc/swp_resolve7.hpp: k_r6_propose per shard, k_r7_fold,
-k_r7_match, k_r7_apply per shard) on CPU fibers: a random problem's node set is split into 2 ... 8 contiguous ranges, every range gets
+"""The node-range shard kernels with the rounds on the device (swarmkit_amd/csrc/swp_resolve7.hpp: k_r7_propose per shard, then k_r7_commit per shard —
+fold + match + apply in one kernel since round 5) on CPU fibers: a random problem's node set is split into 2 ... 8 contiguous ranges, every range gets
 its own state (bitmap rows re-packed from bit 0, exception lists with the entries of its own nodes), and the SOURCE of the kernels
 decides the batch round by round exactly as swp_shard_run / swp_shard_run_rank enqueue them. Placements (shard + local node), every
 shard's node rows, host ports, service rows, counters and the list of unplaceable tasks must equal the sequential model over the WHOLE
@@ -40,7 +40,7 @@ CASES = [
     (21, 2000, 1050, 150, 1024, 0, 0, 3, ""),  # the largest block
     (7, 1500, 1200, 60, 64, 0, 1, 4, "t"),     # task-rows mode
     (9, 37, 150, 12, 32, 2, 2, 8, ""),         # shards of four or five nodes
-    (7, 500, 800, 40, 64, 0, 3, 3, ""),        # feature level 3: generic reservations (HasEnough rows per shard, Claim in k_r7_apply on the owner)
+    (7, 500, 800, 40, 64, 0, 3, 3, ""),        # feature level 3: generic reservations (HasEnough rows per shard, Claim in the owner's apply step)
     (8, 885, 1000, 125, 64, 2, 3, 4, ""),
     (10, 1200, 900, 90, 128, 0, 3, 8, "t"),    # ... in task-rows mode
     # "c": the incremental path — after the batch a tenth of the nodes is drained, the tasks on them and a fifth of

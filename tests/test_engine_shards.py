@@ -141,7 +141,7 @@ class GenericWorkload(synth.Workload):
 @pytest.mark.parametrize("shards", [2, 4])
 def test_shards_with_generic_reservations(shards):
     """Generic reservations through the sharded rounds (round 3 refused them): HasEnough as rows of every shard's propose, Claim in
-    k_r7_apply on the owner — against the oracle and against the single engine."""
+    the owner's apply step of k_r7_commit — against the oracle and against the single engine."""
     wl = GenericWorkload("cfg3", T=3000, N=500)
     op, oe, _ = pu.oracle_run(wl)
     sp, se, _ = pu.sharded_run(wl, shards, mode="device")
