@@ -799,18 +799,22 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                             moves = pk < key;   // Less(j, i)
                         }
                     }
-                    if (wv::ballot(moves) == 0) {
-                        if (cand && myj < np) {
+                    // (the pushes in FRONT of the first one that moves move nothing either — their parents are in the heap or among
+                    // themselves — so they are appended in parallel all the same; lane 0 replays the rest)
+                    const u64 mvb = wv::ballot(moves);
+                    const u32 npp = mvb ? wv::readlane(myj, (u32)wv::ffs64(mvb)) : np;
+                    if (npp != 0) {
+                        if (cand && myj < npp) {
                             G2Ent he;
                             he.key = key; he.node = n; he.tix = G2_NONE;
                             A.HE[len0 + myj] = he;
                         }
                         if (len0 == 0) { root0 = sg->ent[0].key; u_key = root0; }
-                        if (wv::ballot(cand && myj < np && key != u_key)) u_valid = false;
-                        lastp = sg->ent[np - 1u].node + 1u;
-                        len0 += np;
-                        first = np;
-                        if (a.dbg & 16u) gt[14] += np;
+                        if (wv::ballot(cand && myj < npp && key != u_key)) u_valid = false;
+                        lastp = sg->ent[npp - 1u].node + 1u;
+                        len0 += npp;
+                        first = npp;
+                        if (a.dbg & 16u) gt[14] += npp;
                         wv::wave_sync();
                     }
                 }
