@@ -3382,7 +3382,6 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
         }
         if (e->n_nodes == 0) return e0->fail(SWP_EINVAL, "shard %u owns no node", g);
         const uint32_t Wn = n_words_of(e->n_nodes);
-        const uint32_t nrr = task_rows ? 0u : b->n_dc + b->n_dm;
         if (r6_propose_lds_size(Wn) > lds_budget)
             return e0->fail(SWP_ERANGE, "shard %u: %u nodes exceed the block resolver's LDS", g, e->n_nodes);
         int rc = batch_begin(e, b);

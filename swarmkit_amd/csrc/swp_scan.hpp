@@ -69,7 +69,7 @@ WV_KERNEL(256) void k_scan_lists(ScanArgs s) {
 template <int SCAN_NQ, bool SCAN_LM>
 WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
     const R6Args& a = s.a;
-    const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave(), N = a.n_nodes, Wn = a.n_words;
+    const u32 tid = wv::tid(), lane = wv::lane(), N = a.n_nodes, Wn = a.n_words;
     unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
     i64* cpu = reinterpret_cast<i64*>(l);
     i64* mem = cpu + N;
