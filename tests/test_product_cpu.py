@@ -42,6 +42,17 @@ def test_no_cpu_fallback():
     assert "ERR %d" % abi.SWP_ENODEVICE in out, out
 
 
+def test_a_shard_set_has_no_cpu_fallback_either():
+    """swp_shardset_create (G engines behind one handle) without a gfx950 device: the same loud failure, no handle."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\nfrom swarmkit_amd import abi\n"
+            "try:\n    abi.Engine(shards=3, nodes_per_shard=16)\n    print('CREATED')\nexcept abi.SwpError as e:\n    print('ERR', e.code)\n") % ROOT
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
+    assert "ERR %d" % abi.SWP_ENODEVICE in out, out
+
+
 def test_product_does_not_import_the_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "swarmkit_amd")):
         for f in files:
