@@ -232,28 +232,41 @@ static bool parse_ip(const std::string& s, uint8_t out[16], bool* is_v4) {
 // Pipeline.Explain (pipeline.go:84-103): entries sorted by failure count, descending, stable for ≤ 12 elements
 // (insertion sort inside sort.Sort), zero counts skipped; each filter's Explain(nodes) text (filter.go).
 static std::string explain(const uint32_t* hist) {
-    static const char* one[SWP_NFILTERS] = {"1 node not available for new tasks", "insufficient resources on 1 node", "missing plugin on 1 node",
-                                            "scheduling constraints not satisfied on 1 node", "unsupported platform on 1 node",
-                                            "host-mode port already in use on 1 node", "max replicas per node limit exceed",
-                                            "cannot fulfill requested CSI volume mounts on 1 node"};
-    static const char* many[SWP_NFILTERS] = {"%u nodes not available for new tasks", "insufficient resources on %u nodes", "missing plugin on %u nodes",
-                                             "scheduling constraints not satisfied on %u nodes", "unsupported platform on %u nodes",
-                                             "host-mode port already in use on %u nodes", "max replicas per node limit exceed",
-                                             "cannot fulfill requested CSI volume mounts on %u nodes"};
+    // (text, then whether a count goes in front of it / in its middle — "%u nodes …" and "… on %u nodes")
+    struct Reason { const char* one; const char* head; const char* tail; };
+    static const Reason reasons[SWP_NFILTERS] = {
+        {"1 node not available for new tasks", "", " nodes not available for new tasks"},
+        {"insufficient resources on 1 node", "insufficient resources on ", " nodes"},
+        {"missing plugin on 1 node", "missing plugin on ", " nodes"},
+        {"scheduling constraints not satisfied on 1 node", "scheduling constraints not satisfied on ", " nodes"},
+        {"unsupported platform on 1 node", "unsupported platform on ", " nodes"},
+        {"host-mode port already in use on 1 node", "host-mode port already in use on ", " nodes"},
+        {"max replicas per node limit exceed", nullptr, nullptr},
+        {"cannot fulfill requested CSI volume mounts on 1 node", "cannot fulfill requested CSI volume mounts on ", " nodes"}};
+    // most failures first, pipeline order among equals (pipeline.go:86-98: sort.Sort over eight entries is Go's insertion sort, equals keep
+    // their order): an insertion sort here too
     int order[SWP_NFILTERS];
-    for (int i = 0; i < SWP_NFILTERS; ++i) order[i] = i;
-    std::stable_sort(order, order + SWP_NFILTERS, [&](int a, int b) { return hist[a] > hist[b]; });
+    for (int i = 0; i < SWP_NFILTERS; ++i) {
+        int k = i;
+        while (k > 0 && hist[order[k - 1]] < hist[i]) { order[k] = order[k - 1]; --k; }
+        order[k] = i;
+    }
     std::string out;
+    out.reserve(128);
     for (int k = 0; k < SWP_NFILTERS; ++k) {
         const int i = order[k];
         const uint32_t n = hist[i];
         if (n == 0) continue;
         if (!out.empty()) out += "; ";
-        if (n == 1) out += one[i];
+        if (n == 1 || reasons[i].head == nullptr) out += reasons[i].one;
         else {
-            char buf[96];
-            std::snprintf(buf, sizeof buf, many[i], n);
-            out += buf;
+            char tmp[12];
+            char* q = tmp + sizeof tmp;
+            uint32_t u = n;
+            do { *--q = (char)('0' + u % 10); u /= 10; } while (u);
+            out += reasons[i].head;
+            out.append(q, (size_t)(tmp + sizeof tmp - q));
+            out += reasons[i].tail;
         }
     }
     return out;
@@ -270,6 +283,144 @@ struct QItem {
     uint32_t tmpl = NO_TMPL;
     QItem() = default;
     QItem(std::string id, Value t, uint32_t tm = NO_TMPL) : first(std::move(id)), second(std::move(t)), tmpl(tm) {}
+};
+
+// One hash of a task id serves every table a decision touches (allTasks, the decision log, NodeInfo.Tasks).
+static inline uint64_t id_hash(const std::string& s) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (unsigned char c : s) h = (h ^ c) * 0x100000001B3ull;
+    h ^= h >> 29;
+    return h ? h : 1;
+}
+
+// id -> V for the maps a tick goes through task by task (Scheduler.allTasks, the decisions of the last tick): entries in ONE vector in
+// insertion order, found through an open-addressing table of (hash, position) pairs. Against std::unordered_map / std::map this is no
+// node per entry (a 100k-task tick: 100k allocations less per map, and dropping the decisions of the previous tick is one fill), one
+// probe sequence over 12 bytes per cell instead of a chain walk, and entries that were created together lie together.
+// find() returns a pointer (end() is nullptr) that stays valid until the next put / operator[] / erase.
+template <class V> class IdTable {
+  public:
+    struct Entry { std::string first; V second; };
+    Entry* end() const { return nullptr; }
+    Entry* find(const std::string& id) { return find(id, id_hash(id)); }
+    Entry* find(const std::string& id, uint64_t h) {
+        const size_t at = probe(id, h);
+        return at == NPOS ? nullptr : &items_[slot_[at]];
+    }
+    const Entry* find(const std::string& id) const { return const_cast<IdTable*>(this)->find(id); }
+    V& operator[](const std::string& id) { return at(id, id_hash(id)); }
+    V& at(const std::string& id, uint64_t h) {   // the entry of id, made if absent
+        const size_t c = probe(id, h);
+        if (c != NPOS) return items_[slot_[c]].second;
+        if ((used_ + 1) * 2 > hash_.size()) grow(live_ + 1);
+        insert(h, (uint32_t)items_.size());
+        items_.push_back(Entry{id, V()});
+        alive_.push_back(1);
+        ++live_;
+        return items_.back().second;
+    }
+    bool erase(const std::string& id) {
+        const size_t c = probe(id, id_hash(id));
+        if (c == NPOS) return false;
+        alive_[slot_[c]] = 0;
+        items_[slot_[c]] = Entry();
+        slot_[c] = GONE;   // (the probe chain stays intact)
+        if (--live_ == 0) clear();
+        else if (items_.size() - live_ > 1024 && items_.size() > 2 * live_) grow(live_);   // mostly holes: close them
+        return true;
+    }
+    template <class P> void erase_if(P pred) {
+        size_t hit = 0;
+        for (size_t i = 0; i < items_.size(); ++i) hit += alive_[i] && pred(items_[i].second) ? 1 : 0;
+        if (hit == 0) return;
+        if (hit == live_) { clear(); return; }
+        for (size_t i = 0; i < items_.size(); ++i)
+            if (alive_[i] && pred(items_[i].second)) {
+                alive_[i] = 0;
+                items_[i] = Entry();
+                --live_;
+            }
+        grow(live_);   // rebuilds the index from the entries that are left
+    }
+    void clear() {
+        items_.clear();
+        alive_.clear();
+        std::fill(hash_.begin(), hash_.end(), 0);
+        used_ = live_ = 0;
+    }
+    size_t size() const { return live_; }
+    bool empty() const { return live_ == 0; }
+    // What a look-up of h will read, asked for ahead of time (a tick knows the ids it is going to book): 1 = the table cell, 2 = the
+    // entry the cell names (once the cell is there).
+    void prefetch(uint64_t h, int stage) const {
+        if (hash_.empty()) return;
+        const size_t i = (size_t)h & (hash_.size() - 1);
+        if (stage == 1) {
+            __builtin_prefetch(&hash_[i]);
+            __builtin_prefetch(&slot_[i]);
+        } else if (hash_[i] == h && slot_[i] < items_.size()) __builtin_prefetch(&items_[slot_[i]]);
+    }
+    void reserve(size_t n) {   // room for n entries without a move of the entries or a rebuild of the table on the way
+        if (hash_.size() < 2 * n) grow(n);
+        items_.reserve(n);
+        alive_.reserve(n);
+    }
+    // the entries in ascending id order (what ranging over a std::map gave: deterministic outputs)
+    std::vector<const Entry*> sorted() const {
+        std::vector<const Entry*> out;
+        out.reserve(live_);
+        bool ordered = true;
+        for (size_t i = 0; i < items_.size(); ++i)
+            if (alive_[i]) {
+                ordered = ordered && (out.empty() || out.back()->first < items_[i].first);
+                out.push_back(&items_[i]);
+            }
+        if (!ordered) std::sort(out.begin(), out.end(), [](const Entry* a, const Entry* b) { return a->first < b->first; });
+        return out;
+    }
+
+  private:
+    static constexpr size_t NPOS = ~(size_t)0;
+    static constexpr uint32_t GONE = 0xFFFFFFFFu;
+    size_t probe(const std::string& id, uint64_t h) const {
+        if (hash_.empty()) return NPOS;
+        const size_t mask = hash_.size() - 1;
+        for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
+            if (hash_[i] == 0) return NPOS;
+            if (hash_[i] == h && slot_[i] != GONE && items_[slot_[i]].first == id) return i;
+        }
+    }
+    void insert(uint64_t h, uint32_t pos) {
+        const size_t mask = hash_.size() - 1;
+        size_t i = (size_t)h & mask;
+        while (hash_[i] != 0) i = (i + 1) & mask;
+        hash_[i] = h;
+        slot_[i] = pos;
+        ++used_;
+    }
+    // a table for at least `want` entries, the holes of items_ closed
+    void grow(size_t want) {
+        if (items_.size() != live_) {
+            std::vector<Entry> kept;
+            kept.reserve(std::max(live_, want));
+            for (size_t i = 0; i < items_.size(); ++i)
+                if (alive_[i]) kept.push_back(std::move(items_[i]));
+            items_.swap(kept);
+            alive_.assign(items_.size(), 1);
+        }
+        size_t cap = 1024;
+        while (cap < 4 * want) cap *= 2;
+        hash_.assign(cap, 0);
+        slot_.assign(cap, 0);
+        used_ = 0;
+        for (size_t i = 0; i < items_.size(); ++i) insert(id_hash(items_[i].first), (uint32_t)i);
+    }
+    std::vector<Entry> items_;
+    std::vector<char> alive_;
+    std::vector<uint64_t> hash_;
+    std::vector<uint32_t> slot_;
+    size_t used_ = 0;   // cells taken (erased ones included)
+    size_t live_ = 0;
 };
 
 class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queue at once, so nothing is ever compacted piecemeal)
@@ -328,12 +479,7 @@ class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queu
     // tick is one fill instead of 100k frees. hash 0 = a free cell; position GONE = erased (the chain goes on).
     static constexpr size_t NPOS = ~(size_t)0;
     static constexpr uint32_t GONE = 0xFFFFFFFFu;
-    static uint64_t hash_id(const std::string& s) {
-        uint64_t h = 0xCBF29CE484222325ull;
-        for (unsigned char c : s) h = (h ^ c) * 0x100000001B3ull;
-        h ^= h >> 29;
-        return h ? h : 1;
-    }
+    static uint64_t hash_id(const std::string& s) { return id_hash(s); }
     size_t probe(const std::string& id, uint64_t h) const {
         if (hash_.empty()) return NPOS;
         const size_t mask = hash_.size() - 1;
@@ -428,15 +574,42 @@ using FailureKey = std::pair<std::string, int64_t>;   // versionedService: (Serv
 class Decisions {
   public:
     Decisions() { buf_.reserve(1 << 16); buf_.push_back('['); }
+    void expect(size_t n) {   // a line of an assigned task is 150 bytes with ids of 10 characters: room for n of them at once
+        buf_.reserve(n * 192 + 64);
+        ids_.reserve(n);
+    }
     // {"ID","ServiceID","NodeID","State","Message","Err","OldState"} from (decision.old, decision.new); err: instead of new's Status.Err
     void begin(const Value& old, const Value& neu, const std::string* err = nullptr) {
         const Value* st = neu.get("Status");
         begin(task_id(neu), as_str(neu.get("ServiceID")), as_str(neu.get("NodeID")), task_state(st ? st->get("State") : nullptr), as_str(st ? st->get("Message") : nullptr),
-              err ? *err : as_str(st ? st->get("Err") : nullptr), task_state(at(&old, {"Status", "State"})));
+              err ? *err : as_str(st ? st->get("Err") : nullptr), task_state(at(&old, "Status", "State")));
     }
     void begin(const std::string& id, const std::string& service, const std::string& node, int64_t state, const std::string& message, const std::string& err, int64_t old_state) {
         if (n_++) buf_.push_back(',');
         ids_.push_back(id);
+        // The usual line — ids, a fixed message, no character to escape — is written through a pointer into room made once: seven members
+        // were fourteen appends with a capacity check each.
+        if (plain(id) && plain(service) && plain(node) && plain(message) && plain(err)) {
+            const size_t at = buf_.size();
+            buf_.resize(at + 128 + id.size() + service.size() + node.size() + message.size() + err.size());
+            char* p = &buf_[at];
+            p = lit(p, "{\"ID\":\"");
+            p = raw(p, id);
+            p = lit(p, "\",\"ServiceID\":\"");
+            p = raw(p, service);
+            p = lit(p, "\",\"NodeID\":\"");
+            p = raw(p, node);
+            p = lit(p, "\",\"State\":");
+            p = num(p, state);
+            p = lit(p, ",\"Message\":\"");
+            p = raw(p, message);
+            p = lit(p, "\",\"Err\":\"");
+            p = raw(p, err);
+            p = lit(p, "\",\"OldState\":");
+            p = num(p, old_state);
+            buf_.resize((size_t)(p - buf_.data()));
+            return;
+        }
         buf_ += "{\"ID\":";
         json::dump_string(buf_, id);
         buf_ += ",\"ServiceID\":";
@@ -451,6 +624,23 @@ class Decisions {
         json::dump_string(buf_, err);
         buf_ += ",\"OldState\":";
         number(old_state);
+    }
+    static bool plain(const std::string& s) {   // nothing json::dump_string would escape
+        bool ok = true;
+        for (unsigned char c : s) ok = ok && c >= 0x20 && c != '"' && c != '\\';
+        return ok;
+    }
+    template <size_t N> static char* lit(char* p, const char (&text)[N]) { std::memcpy(p, text, N - 1); return p + (N - 1); }
+    static char* raw(char* p, const std::string& s) { std::memcpy(p, s.data(), s.size()); return p + s.size(); }
+    static char* num(char* p, int64_t v) {   // at most 20 characters
+        char tmp[24];
+        char* q = tmp + sizeof tmp;
+        uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
+        do { *--q = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) *--q = '-';
+        const size_t n = (size_t)(tmp + sizeof tmp - q);
+        std::memcpy(p, q, n);
+        return p + n;
     }
     void number(int64_t v) {
         char tmp[24];
@@ -484,35 +674,46 @@ class Decisions {
 class NodeTasks {
   public:
     static constexpr size_t TASKS_FLAT = 48;
-    Value* find(const std::string& id) {
+    Value* find(const std::string& id) { return find(id, id_hash(id)); }
+    Value* find(const std::string& id, uint64_t h) {
         if (!tree_.empty()) {
             auto it = tree_.find(id);
             return it == tree_.end() ? nullptr : &it->second;
         }
-        for (auto& kv : flat_)
-            if (kv.first == id) return &kv.second;
+        // (the hashes lie together: a probe of a dozen tasks reads one cache line, and an entry only where the hash fits)
+        for (size_t i = 0; i < hash_.size(); ++i)
+            if (hash_[i] == (uint32_t)h && flat_[i].first == id) return &flat_[i].second;
         return nullptr;
     }
-    void put(const std::string& id, const Value& t) {
-        if (Value* have = find(id)) { *have = t; return; }
+    void put(const std::string& id, const Value& t) { put(id, id_hash(id), t); }
+    void put(const std::string& id, uint64_t h, const Value& t) {
+        if (Value* have = find(id, h)) { *have = t; return; }
         if (tree_.empty() && flat_.size() < TASKS_FLAT) {
-            if (flat_.capacity() == 0) flat_.reserve(12);   // (a node's first task: room for the usual dozen at once)
+            if (flat_.capacity() == 0) { flat_.reserve(12); hash_.reserve(12); }   // (a node's first task: room for the usual dozen at once)
             flat_.emplace_back(id, t);
+            hash_.push_back((uint32_t)h);
             return;
         }
         for (auto& kv : flat_) tree_.emplace(std::move(kv.first), std::move(kv.second));
         flat_.clear();
+        hash_.clear();
         tree_.emplace(id, t);
     }
     bool erase(const std::string& id) {
         if (!tree_.empty()) return tree_.erase(id) != 0;
+        const uint32_t h = (uint32_t)id_hash(id);
         for (size_t i = 0; i < flat_.size(); ++i)
-            if (flat_[i].first == id) {
-                if (i + 1 != flat_.size()) flat_[i] = std::move(flat_.back());
+            if (hash_[i] == h && flat_[i].first == id) {
+                if (i + 1 != flat_.size()) { flat_[i] = std::move(flat_.back()); hash_[i] = hash_.back(); }
                 flat_.pop_back();
+                hash_.pop_back();
                 return true;
             }
         return false;
+    }
+    void prefetch() const {   // what put() of a new task reads and writes
+        __builtin_prefetch(hash_.data());
+        __builtin_prefetch(flat_.data() + flat_.size(), 1);
     }
     // in id order (what ranging over a sorted key list gives: the outputs are deterministic)
     template <class F> void each_sorted(F f) const {
@@ -525,6 +726,7 @@ class NodeTasks {
 
   private:
     std::vector<std::pair<std::string, Value>> flat_;
+    std::vector<uint32_t> hash_;   // id_hash of flat_[i].first, low half
     std::map<std::string, Value> tree_;
 };
 
@@ -572,7 +774,7 @@ class Scheduler {
         const std::string& nid = task_id(n);
         auto it = nodes_.find(nid);
         NodeInfo* ni = it == nodes_.end() ? nullptr : &it->second;
-        const Value* res = at(&n, {"Description", "Resources"});
+        const Value* res = at(&n, "Description", "Resources");
         int64_t cpu = 0, mem = 0;
         generic::List avail;
         if (res != nullptr) {
@@ -670,7 +872,7 @@ class Scheduler {
     // EventUpdateVolume (scheduler.go:200-213) and the volumes of the store at start (:70-81): addOrUpdateVolume (volumes.go:62-82) once
     // the plugin has created the volume. The engine gets what checkVolume reads; the maps behind its usage numbers stay here.
     void updateVolume(const Value& v) {
-        const std::string& plugin_id = as_str(at(&v, {"VolumeInfo", "VolumeID"}));
+        const std::string& plugin_id = as_str(at(&v, "VolumeInfo", "VolumeID"));
         if (v.get("VolumeInfo") == nullptr || plugin_id.empty()) return;
         const std::string& vid = task_id(v);
         auto it = volumes_.find(vid);
@@ -684,14 +886,14 @@ class Scheduler {
         it->second.doc = v;
         swp_volume sv;
         std::memset(&sv, 0, sizeof sv);
-        sv.group = intern(SWP_SPACE_VOLUME_GROUP, as_str(at(&v, {"Spec", "Group"})));
-        sv.driver = intern(SWP_SPACE_CSI, as_str(at(&v, {"Spec", "Driver", "Name"})));
-        sv.scope = (uint32_t)enum_value(at(&v, {"Spec", "AccessMode", "Scope"}), {{"SINGLE_NODE", 0}, {"MULTI_NODE", 1}});
-        sv.sharing = (uint32_t)enum_value(at(&v, {"Spec", "AccessMode", "Sharing"}), {{"NONE", 0}, {"READ_ONLY", 1}, {"ONE_WRITER", 2}, {"ALL", 3}});
-        sv.active = enum_value(at(&v, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) == 0 ? 1u : 0u;
+        sv.group = intern(SWP_SPACE_VOLUME_GROUP, as_str(at(&v, "Spec", "Group")));
+        sv.driver = intern(SWP_SPACE_CSI, as_str(at(&v, "Spec", "Driver", "Name")));
+        sv.scope = (uint32_t)enum_value(at(&v, "Spec", "AccessMode", "Scope"), {{"SINGLE_NODE", 0}, {"MULTI_NODE", 1}});
+        sv.sharing = (uint32_t)enum_value(at(&v, "Spec", "AccessMode", "Sharing"), {{"NONE", 0}, {"READ_ONLY", 1}, {"ONE_WRITER", 2}, {"ALL", 3}});
+        sv.active = enum_value(at(&v, "Spec", "Availability"), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) == 0 ? 1u : 0u;
         std::vector<uint32_t> topo_off(1, 0);
         std::vector<swp_seg> segs;
-        if (const Value* at_ = at(&v, {"VolumeInfo", "AccessibleTopology"}))
+        if (const Value* at_ = at(&v, "VolumeInfo", "AccessibleTopology"))
             if (at_->is_arr())
                 for (const Value& top : *at_->a) {
                     if (const Value* sg = top.get("Segments"))
@@ -702,7 +904,7 @@ class Scheduler {
         sv.n_topologies = (uint32_t)topo_off.size() - 1;
         static const swp_seg no_seg = {0, 0};
         ck(swp_volume_upsert(e_, it->second.idx, &sv, topo_off.data(), segs.empty() ? &no_seg : segs.data()), "swp_volume_upsert");
-        volByName_[as_str(at(&v, {"Spec", "Annotations", "Name"}))] = vid;
+        volByName_[as_str(at(&v, "Spec", "Annotations", "Name"))] = vid;
         ++tmplGen_;   // (a mount's Source may resolve differently from now on)
     }
     // volumeSet.reserveVolume / releaseVolume (volumes.go:156-187) + the usage numbers the engine judges by
@@ -772,7 +974,7 @@ class Scheduler {
     // reserveTaskVolumes, volumes.go:144-154
     void reserveTaskVolumes(const Value& t) {
         const Value* vols = t.get("Volumes");
-        const Value* mounts = at(&t, {"Spec", "Container", "Mounts"});
+        const Value* mounts = at(&t, "Spec", "Container", "Mounts");
         if (vols == nullptr || !vols->is_arr() || mounts == nullptr || !mounts->is_arr()) return;
         for (const Value& va : *vols->a)
             for (const Value& m : *mounts->a)
@@ -821,7 +1023,7 @@ class Scheduler {
     // the reference), a request of 0 (selectNodeResources would claim every named value, resource_management.go:52-66), a kind
     // listed twice — stays on the Go path.
     static generic::List genericReservations(const Value& t) {
-        generic::List r = generic::decode(at(&t, {"Spec", "Resources", "Reservations", "Generic"}));
+        generic::List r = generic::decode(at(&t, "Spec", "Resources", "Reservations", "Generic"));
         if (r.size() > 8) unsupported("more than 8 generic reservations in one task stay on the Go path");
         std::set<std::string> kinds;
         for (const generic::Res& g : r) {
@@ -835,7 +1037,7 @@ class Scheduler {
     // leaves them to the Go scheduler's own path — so that a tick never meets one half-way through a batch.
     static void requireSupported(const Value& t) {
         (void)genericReservations(t);   // refuses what swp_generic_set would refuse
-        if (const Value* ports = at(&t, {"Endpoint", "Ports"}))
+        if (const Value* ports = at(&t, "Endpoint", "Ports"))
             if (ports->is_arr()) {
                 size_t host_ports = 0;
                 for (const Value& p : *ports->a)
@@ -848,7 +1050,7 @@ class Scheduler {
     static bool isCluster(const Value& m) { return enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) == MOUNT_CLUSTER; }
     static std::vector<const Value*> clusterMounts(const Value& t) {
         std::vector<const Value*> out;
-        const Value* mounts = at(&t, {"Spec", "Container", "Mounts"});
+        const Value* mounts = at(&t, "Spec", "Container", "Mounts");
         if (mounts != nullptr && mounts->is_arr())
             for (const Value& m : *mounts->a)
                 if (isCluster(m)) out.push_back(&m);
@@ -856,7 +1058,7 @@ class Scheduler {
     }
     // createTask, scheduler.go:254-283
     bool createTask(const Value& t) {
-        const int64_t st = task_state(at(&t, {"Status", "State"}));
+        const int64_t st = task_state(at(&t, "Status", "State"));
         if (st < PENDING || st > RUNNING) return false;
         requireSupported(t);
         const std::string& id = task_id(t);
@@ -877,7 +1079,7 @@ class Scheduler {
     // setupTasksList, scheduler.go:68-126: a task found in the store at start-up. One rule differs from the createTask
     // event: a task still PENDING whose desired state is already past COMPLETED is ignored (:93-101).
     bool setupTask(const Value& t) {
-        const int64_t st = task_state(at(&t, {"Status", "State"}));
+        const int64_t st = task_state(at(&t, "Status", "State"));
         if (st == PENDING && task_state(t.get("DesiredState")) > COMPLETE) return false;
         const bool r = createTask(t);
         // :115-116: the volumes in use by a task that sits on its node already (NOT what the createTask event does)
@@ -886,7 +1088,7 @@ class Scheduler {
     }
     // updateTask, scheduler.go:283-348
     bool updateTask(const Value& t) {
-        const int64_t st = task_state(at(&t, {"Status", "State"}));
+        const int64_t st = task_state(at(&t, "Status", "State"));
         if (st < PENDING) return false;
         const std::string& id = task_id(t);
         auto old_it = allTasks_.find(id);
@@ -894,7 +1096,7 @@ class Scheduler {
         if (st > RUNNING) {
             if (!has_old) return false;
             const Value old = old_it->second;
-            if (st != task_state(at(&old, {"Status", "State"})) && (st == FAILED || st == REJECTED)) {
+            if (st != task_state(at(&old, "Status", "State")) && (st == FAILED || st == REJECTED)) {
                 if (preassignedTasks_.count(id) == 0) {   // preassigned tasks do not count against the node, :303-310
                     auto n = nodes_.find(as_str(t.get("NodeID")));
                     if (n != nodes_.end()) taskFailed(n->second, t);
@@ -952,6 +1154,8 @@ class Scheduler {
         int64_t version = 0;
         swp_task_desc desc{};
         uint64_t gen = ~0ull;     // tmplGen_ the descriptor was computed at (a mount's Source resolves through byName NOW, volumes.go:252)
+        bool wants_generic = false;   // Spec.Resources.Reservations.Generic is there: place() decides WHICH resources the task holds
+        bool has_mounts = false;      // Spec.Container.Mounts is there: place() looks for the cluster mounts' attachments
     };
     std::vector<Template> templates_;
     std::unordered_map<uint64_t, std::vector<uint32_t>> tmplIndex_;
@@ -975,6 +1179,8 @@ class Scheduler {
         tm.service = sid;
         tm.has_version = sv != nullptr;
         tm.version = as_i64(sv != nullptr ? sv->get("Index") : nullptr);
+        tm.wants_generic = at(spec, "Resources", "Reservations", "Generic") != nullptr;
+        tm.has_mounts = at(spec, "Container", "Mounts") != nullptr;
         templates_.push_back(std::move(tm));
         cands.push_back((uint32_t)templates_.size() - 1);
         return (uint32_t)templates_.size() - 1;
@@ -995,7 +1201,7 @@ class Scheduler {
         swp_task_desc d;
         std::memset(&d, 0, sizeof d);
         d.service = intern(SWP_SPACE_SERVICE, as_str(t.get("ServiceID")));
-        if (const Value* res = at(&t, {"Spec", "Resources", "Reservations"})) {   // ResourceFilter.SetTask, filter.go:61-74
+        if (const Value* res = at(&t, "Spec", "Resources", "Reservations")) {   // ResourceFilter.SetTask, filter.go:61-74
             d.cpu = as_i64(res->get("NanoCPUs"));
             d.mem = as_i64(res->get("MemoryBytes"));
             const bool any_generic = res->get("Generic") != nullptr && res->get("Generic")->is_arr() && res->get("Generic")->size() > 0;
@@ -1005,7 +1211,7 @@ class Scheduler {
             if (!items.empty()) ck(swp_generic_set(e_, items.data(), (uint32_t)items.size(), &d.generic_set), "swp_generic_set");
         }
         if (task_state(t.get("DesiredState")) > COMPLETE) d.flags |= 0x2u;   // SWP_TASK_UNCOUNTED: nodeinfo.go:148
-        if (const Value* pl = at(&t, {"Spec", "Placement"})) {
+        if (const Value* pl = at(&t, "Spec", "Placement")) {
             d.constraint_set = constraintSet(pl->get("Constraints"));          // ConstraintFilter.SetTask, filter.go:218-232
             if (const Value* plats = pl->get("Platforms")) {                    // PlatformFilter.SetTask, filter.go:253-263
                 if (plats->is_arr() && plats->size() > 0) {
@@ -1030,7 +1236,7 @@ class Scheduler {
         }
         // PluginFilter.SetTask, filter.go:119-131 (+ Check :133-177 decides what counts as a requirement)
         std::vector<std::string> vol;
-        if (const Value* mounts = at(&t, {"Spec", "Container", "Mounts"})) {
+        if (const Value* mounts = at(&t, "Spec", "Container", "Mounts")) {
             if (mounts->is_arr()) {
                 {   // VolumesFilter.SetTask, filter.go:392-422: the cluster mounts as a mount set (a name resolves through byName NOW, volumes.go:252)
                     std::vector<swp_mount> ms;
@@ -1061,7 +1267,7 @@ class Scheduler {
                 }
                 for (const Value& m : *mounts->a) {
                     if (enum_value(m.get("Type"), {{"BIND", 0}, {"VOLUME", 1}, {"TMPFS", 2}, {"NPIPE", 3}, {"CLUSTER", 4}}, -1) != MOUNT_VOLUME) continue;
-                    const Value* dc = at(&m, {"VolumeOptions", "DriverConfig"});
+                    const Value* dc = at(&m, "VolumeOptions", "DriverConfig");
                     if (dc == nullptr) continue;
                     const Value* name = dc->get("Name");
                     if (name == nullptr || !name->is_str() || name->s.empty() || name->s == "local") continue;
@@ -1071,13 +1277,13 @@ class Scheduler {
         }
         const Value* nets = t.get("Networks");
         const bool has_nets = truthy(nets) && nets->is_arr();
-        const Value* logd = at(&t, {"Spec", "LogDriver"});
+        const Value* logd = at(&t, "Spec", "LogDriver");
         if (has_nets || logd != nullptr || !vol.empty()) {
             std::vector<uint32_t> req;
             for (const std::string& v : vol) req.push_back(intern(SWP_SPACE_PLUGIN, std::string("Volume") + '\0' + v));
             if (has_nets)
                 for (const Value& na : *nets->a) {
-                    const std::string& name = as_str(at(&na, {"Network", "DriverState", "Name"}));
+                    const std::string& name = as_str(at(&na, "Network", "DriverState", "Name"));
                     if (!name.empty()) req.push_back(intern(SWP_SPACE_PLUGIN, std::string("Network") + '\0' + name));
                 }
             uint32_t log = 0;
@@ -1088,7 +1294,7 @@ class Scheduler {
             if (!req.empty() || log != 0) ck(swp_plugin_set(e_, req.empty() ? &log : req.data(), (uint32_t)req.size(), log, &d.plugin_set), "swp_plugin_set");
         }
         d.port_set = portSet(t);                                                 // HostPortFilter.SetTask, filter.go:322-333
-        d.spec_version = (uint64_t)as_i64(at(&t, {"SpecVersion", "Index"}));
+        d.spec_version = (uint64_t)as_i64(at(&t, "SpecVersion", "Index"));
         return d;
     }
     // Placement.Constraints → predicate set id; 0 = filter disabled (empty list, or constraint.Parse failed: filter.go:223-229)
@@ -1109,8 +1315,7 @@ class Scheduler {
     // processPreassignedTasks + taskFitNode, scheduler.go:398-426, 646-690
     std::string processPreassignedTasks() {
         Decisions decisions;
-        for (auto it = lastDecisions_.begin(); it != lastDecisions_.end();)
-            it = it->second.preassigned ? lastDecisions_.erase(it) : std::next(it);
+        lastDecisions_.erase_if([](const PendingDecision& d) { return d.preassigned; });
         for (auto& kv : pendingPreassignedTasks_.snapshot()) {
             const std::string& tid = kv.first;
             const Value& t = kv.second;
@@ -1156,7 +1361,7 @@ class Scheduler {
             decisions.begin(t, newT);
             const Value* ag = newT.get("AssignedGenericResources");
             if (ag && ag->is_arr() && ag->size() > 0) decisions.field("AssignedGenericResources", *ag);
-            if (newT.get("Volumes") != nullptr && task_state(at(&newT, {"Status", "State"})) == ASSIGNED) decisions.field("Volumes", *newT.get("Volumes"));
+            if (newT.get("Volumes") != nullptr && task_state(at(&newT, "Status", "State")) == ASSIGNED) decisions.field("Volumes", *newT.get("Volumes"));
             decisions.end();
         }
         return decisions.finish();
@@ -1198,9 +1403,10 @@ class Scheduler {
         prof_.start();
         std::vector<Item> queue = unassignedTasks_.take_all();   // (only tasks without a NodeID are ever queued: createTask / updateTask / enqueue)
         Decisions decisions;
-        for (auto it = lastDecisions_.begin(); it != lastDecisions_.end();)   // the previous tick's decisions are final now
-            it = it->second.preassigned ? std::next(it) : lastDecisions_.erase(it);
+        lastDecisions_.erase_if([](const PendingDecision& d) { return !d.preassigned; });   // the previous tick's decisions are final now
         if (queue.empty()) return decisions.finish();
+        decisions.expect(queue.size());
+        lastDecisions_.reserve(lastDecisions_.size() + queue.size());
         std::set<std::string> sids;
         {
             std::vector<char> seen(templates_.size() + queue.size(), 0);   // (a task re-queued without a template gets one here)
@@ -1245,6 +1451,7 @@ class Scheduler {
         std::vector<std::vector<Item>> groups;
         std::map<FailureKey, size_t> group_of;
         std::vector<Item> one_off;
+        one_off.reserve(queue.size());
         for (Item& it : queue) {
             const Template& tm = templates_[it.tmpl];
             if (tm.has_version) {   // :442-459: tasks with a spec version are grouped
@@ -1262,6 +1469,8 @@ class Scheduler {
         // one-off tasks (:460-466): a task with spread preferences is a group of one and keeps its place in the order
         std::vector<Item> run;
         std::vector<swp_task_desc> run_descs;   // Pipeline.SetTask once per task
+        run.reserve(one_off.size());
+        run_descs.reserve(one_off.size());
         for (Item& it : one_off) {
             swp_task_desc d;
             try {
@@ -1294,14 +1503,14 @@ class Scheduler {
         auto it = lastDecisions_.find(tid);
         if (it == lastDecisions_.end()) return false;
         const PendingDecision pd = it->second;
-        lastDecisions_.erase(it);
+        lastDecisions_.erase(tid);
         auto cur = allTasks_.find(tid);
         if (cur != allTasks_.end()) {
             const Value newT = cur->second;
             releaseTaskVolumes(newT);   // scheduler.go:480-483 and :422-424 (a preassigned task's attachments were never reserved: releasing them finds nothing)
             auto n = nodes_.find(as_str(newT.get("NodeID")));
             if (n != nodes_.end() && !truthy(pd.old.get("NodeID")) ) removeTask(n->second, newT);                 // tick: the node was chosen by this decision
-            else if (n != nodes_.end() && pd.preassigned && task_state(at(&newT, {"Status", "State"})) == ASSIGNED) removeTask(n->second, newT);
+            else if (n != nodes_.end() && pd.preassigned && task_state(at(&newT, "Status", "State")) == ASSIGNED) removeTask(n->second, newT);
         }
         allTasks_[tid] = pd.old;
         if (pd.preassigned) pendingPreassignedTasks_.put(tid, pd.old);
@@ -1314,7 +1523,8 @@ class Scheduler {
         if (max_changes == 0) max_changes = 200;   // MaxChangesPerTransaction, manager/state/store/memory.go:47
         std::map<uint32_t, std::vector<std::string>> by_node;   // engine node index -> task ids (map order: ascending id)
         Value unassigned = Value::array();
-        for (const auto& kv : lastDecisions_) {
+        for (const auto* dp : lastDecisions_.sorted()) {
+            const auto& kv = *dp;
             auto cur = allTasks_.find(kv.first);
             const std::string nid = cur != allTasks_.end() ? as_str(cur->second.get("NodeID")) : std::string();
             auto n = nid.empty() ? nodes_.end() : nodes_.find(nid);
@@ -1350,7 +1560,8 @@ class Scheduler {
         // them; the caller repeats the "already published?" look at its store's copy inside its transaction, as :591-606 does.
         Value vol_failed = Value::array(), publish = Value::array();
         std::vector<std::pair<std::string, std::vector<std::string>>> pub;   // volume -> nodes, in commit order
-        for (const auto& kv : lastDecisions_) {
+        for (const auto* dp : lastDecisions_.sorted()) {
+            const auto& kv = *dp;
             auto cur = allTasks_.find(kv.first);
             if (cur == allTasks_.end()) continue;
             const Value* vols = cur->second.get("Volumes");
@@ -1359,7 +1570,7 @@ class Scheduler {
             bool ok = true;
             for (const Value& va : *vols->a) {
                 auto v = volumes_.find(as_str(va.get("ID")));
-                if (v == volumes_.end() || enum_value(at(&v->second.doc, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) != 0) ok = false;
+                if (v == volumes_.end() || enum_value(at(&v->second.doc, "Spec", "Availability"), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) != 0) ok = false;
             }
             if (!ok) {
                 vol_failed.push(Value::str(kv.first));
@@ -1394,7 +1605,8 @@ class Scheduler {
     }
     uint32_t rejectNode(const std::string& nid) {
         std::vector<std::string> ids;
-        for (const auto& kv : lastDecisions_) {
+        for (const auto* dp : lastDecisions_.sorted()) {
+            const auto& kv = *dp;
             auto cur = allTasks_.find(kv.first);
             if (cur != allTasks_.end() && as_str(cur->second.get("NodeID")) == nid) ids.push_back(kv.first);
         }
@@ -1417,14 +1629,14 @@ class Scheduler {
         Value out = Value::object();
         if (node_docs == nullptr || !node_docs->is_arr()) return out;
         for (const Value& nd : *node_docs->a) {
-            if (enum_value(at(&nd, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) != AVAILABILITY_ACTIVE) continue;   // :70-72
+            if (enum_value(at(&nd, "Spec", "Availability"), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}}) != AVAILABILITY_ACTIVE) continue;   // :70-72
             const std::string& nid = task_id(nd);
             std::vector<const Value*> tasks;
-            if (const Value* lst = tbn != nullptr ? tbn->get(nid.c_str()) : nullptr)
+            if (const Value* lst = tbn != nullptr ? tbn->get_key(nid) : nullptr)
                 if (lst->is_arr())
                     for (const Value& t : *lst->a) tasks.push_back(&t);
             std::stable_sort(tasks.begin(), tasks.end(), [](const Value* a, const Value* b) { return task_id(*a) < task_id(*b); });
-            const Value* res = at(&nd, {"Description", "Resources"});
+            const Value* res = at(&nd, "Description", "Resources");
             // The generic half (constraint_enforcer.go:186-200) is walked on the host AFTER the device call (below): the device's verdicts
             // — constraints, then memory and cpu accounted task by task — do not depend on it.
             bool generic = false;
@@ -1446,20 +1658,20 @@ class Scheduler {
             if (ni == nodes_.end()) fail(SWP_ENOTFOUND, "enforce: node " + nid + " is not in the nodeSet");
             const uint32_t first = (uint32_t)trec.size();
             for (const Value* t : tasks) {
-                const Value* svc = services != nullptr ? services->get(as_str(t->get("ServiceID")).c_str()) : nullptr;
+                const Value* svc = services != nullptr ? services->get_key(as_str(t->get("ServiceID"))) : nullptr;
                 // :152-168: the CURRENT service spec decides; the task's own placement only when the service is gone
-                const Value* pl = svc != nullptr ? at(svc, {"Spec", "Task", "Placement"}) : at(t, {"Spec", "Placement"});
+                const Value* pl = svc != nullptr ? at(svc, "Spec", "Task", "Placement") : at(t, "Spec", "Placement");
                 swp_enforce_task r;
                 std::memset(&r, 0, sizeof r);
                 r.constraint_set = constraintSet(pl != nullptr ? pl->get("Constraints") : nullptr);
-                const Value* rsv = at(t, {"Spec", "Resources", "Reservations"});
+                const Value* rsv = at(t, "Spec", "Resources", "Reservations");
                 if (rsv != nullptr) {
                     r.cpu = as_i64(rsv->get("NanoCPUs"));
                     r.mem = as_i64(rsv->get("MemoryBytes"));
                     r.flags = SWP_ENF_RESERVATIONS;
                 }
                 r.desired_state = (uint32_t)task_state(t->get("DesiredState"));
-                r.state = (uint32_t)task_state(at(t, {"Status", "State"}));
+                r.state = (uint32_t)task_state(at(t, "Status", "State"));
                 trec.push_back(r);
                 owners.emplace_back(nid, task_id(*t));
             }
@@ -1513,8 +1725,8 @@ class Scheduler {
     OrderedTasks pendingPreassignedTasks_;                                 // Scheduler.pendingPreassignedTasks
     // the `old` half of every decision of the last tick / processPreassignedTasks (schedulingDecision.old, scheduler.go:53-56),
     // kept until the next one so that the caller can roll a decision back when its store commit failed (rejectDecision)
-    struct PendingDecision { Value old; bool preassigned; };
-    std::map<std::string, PendingDecision> lastDecisions_;
+    struct PendingDecision { Value old; bool preassigned = false; };
+    IdTable<PendingDecision> lastDecisions_;
     std::string engine_detail_;   // "<strerror>: <engine message>" of the last failed engine call
     // failure counts pushed to the engine: (node index, service, spec version) -> count, so that a bucket the clean-up
     // erased (nodeinfo.go:163-183) is reset there too
@@ -1537,7 +1749,7 @@ class Scheduler {
         }
         ck(swp_volume_set_usage(e_, r.idx, &u), "swp_volume_set_usage");
     }
-    std::unordered_map<std::string, Value> allTasks_;                      // Scheduler.allTasks
+    IdTable<Value> allTasks_;                                              // Scheduler.allTasks
 
     void ck(int rc, const char* what) {
         if (rc == SWP_OK) return;
@@ -1628,8 +1840,8 @@ class Scheduler {
         row.mem = mem;
         row.total = total;
         uint32_t flags = 0;
-        const int64_t st = enum_value(at(&doc, {"Status", "State"}), {{"UNKNOWN", 0}, {"DOWN", 1}, {"READY", 2}, {"DISCONNECTED", 3}});
-        const int64_t av = enum_value(at(&doc, {"Spec", "Availability"}), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}});
+        const int64_t st = enum_value(at(&doc, "Status", "State"), {{"UNKNOWN", 0}, {"DOWN", 1}, {"READY", 2}, {"DISCONNECTED", 3}});
+        const int64_t av = enum_value(at(&doc, "Spec", "Availability"), {{"ACTIVE", 0}, {"PAUSE", 1}, {"DRAIN", 2}});
         if (st == NODE_STATE_READY && av == AVAILABILITY_ACTIVE) flags |= SWP_NODE_READY;   // ReadyFilter, filter.go:41-44
         if (enum_value(doc.get("Role"), {{"WORKER", 0}, {"MANAGER", 1}}) == 1) flags |= SWP_NODE_MANAGER;
         row.id_fold = folded(doc.get("ID"));
@@ -1640,7 +1852,7 @@ class Scheduler {
             for (const json::Member& m : *labels->o)
                 out.push_back({intern(SWP_SPACE_LABEL_KEY, m.first), folded(&m.second), intern(SWP_SPACE_RAW, as_str(&m.second))});
         };
-        if (const Value* labels = at(&doc, {"Spec", "Annotations", "Labels"})) {
+        if (const Value* labels = at(&doc, "Spec", "Annotations", "Labels")) {
             flags |= SWP_NODE_HAS_LABELS;
             kvs(labels, lab);
         }
@@ -1673,10 +1885,10 @@ class Scheduler {
             }
         }
         bool v4 = false;
-        if (parse_ip(as_str(at(&doc, {"Status", "Addr"})), row.ip, &v4)) flags |= SWP_NODE_IP_VALID | (v4 ? SWP_NODE_IP_V4 : 0u);
+        if (parse_ip(as_str(at(&doc, "Status", "Addr")), row.ip, &v4)) flags |= SWP_NODE_IP_VALID | (v4 ? SWP_NODE_IP_V4 : 0u);
         else std::memset(row.ip, 0, sizeof row.ip);
         row.flags = flags;
-        row.version = (uint64_t)as_i64(at(&doc, {"Meta", "Version", "Index"}));
+        row.version = (uint64_t)as_i64(at(&doc, "Meta", "Version", "Index"));
         static const swp_kv no_kv = {0, 0, 0};
         static const uint32_t no_plugin = 0;
         ck(swp_node_upsert(e_, &row, lab.empty() ? &no_kv : lab.data(), (uint32_t)lab.size(), elab.empty() ? &no_kv : elab.data(), (uint32_t)elab.size(),
@@ -1685,7 +1897,7 @@ class Scheduler {
         // Description.CSIInfo: the node's topology per CSI plugin (volumes.go:272-278)
         std::vector<swp_csi> infos;
         std::vector<swp_seg> segs;
-        if (const Value* cs = at(&doc, {"Description", "CSIInfo"}))
+        if (const Value* cs = at(&doc, "Description", "CSIInfo"))
             if (cs->is_arr())
                 for (const Value& c : *cs->a) {
                     swp_csi ci;
@@ -1708,13 +1920,13 @@ class Scheduler {
 
     // taskReservations, nodeinfo.go:156-161
     static void taskReservations(const Value& t, int64_t& cpu, int64_t& mem) {
-        const Value* r = at(&t, {"Spec", "Resources", "Reservations"});
+        const Value* r = at(&t, "Spec", "Resources", "Reservations");
         cpu = r != nullptr ? as_i64(r->get("NanoCPUs")) : 0;
         mem = r != nullptr ? as_i64(r->get("MemoryBytes")) : 0;
     }
     // host-mode published ports of the task (filter.go:322-333, nodeinfo.go:78-84,139-145) → port-set id, 0 = none
     uint32_t portSet(const Value& t) {
-        const Value* ports = at(&t, {"Endpoint", "Ports"});
+        const Value* ports = at(&t, "Endpoint", "Ports");
         if (ports == nullptr || !ports->is_arr()) return 0;
         std::vector<swp_port> ps;
         for (const Value& p : *ports->a) {
@@ -1771,7 +1983,7 @@ class Scheduler {
         // :128-137: a fresh AssignedGenericResources, then Claim against the node's available list
         Value stored = t.shallow_copy();
         generic::List assigned;
-        generic::claim(&ni.availGeneric, &assigned, generic::decode(at(&t, {"Spec", "Resources", "Reservations", "Generic"})));
+        generic::claim(&ni.availGeneric, &assigned, generic::decode(at(&t, "Spec", "Resources", "Reservations", "Generic")));
         stored.set("AssignedGenericResources", generic::encode(assigned));
         ni.Tasks.put(id, stored);
         auto all = allTasks_.find(id);
@@ -1789,7 +2001,7 @@ class Scheduler {
         commit(ni, t, counted, true, false);
         // :95-104: the task's AssignedGenericResources go back — unless the node's description lists no generic resources at all
         bool desc_nil = true;
-        const generic::List node_res = generic::decode(at(&ni.node, {"Description", "Resources", "Generic"}), &desc_nil);
+        const generic::List node_res = generic::decode(at(&ni.node, "Description", "Resources", "Generic"), &desc_nil);
         if (!desc_nil) {
             generic::reclaim(&ni.availGeneric, generic::decode(t.get("AssignedGenericResources")), node_res);
             pushGeneric(ni);
@@ -1807,7 +2019,7 @@ class Scheduler {
             }
             ni.lastCleanup = now_;
         }
-        FailureKey k{as_str(t.get("ServiceID")), as_i64(at(&t, {"SpecVersion", "Index"}))};
+        FailureKey k{as_str(t.get("ServiceID")), as_i64(at(&t, "SpecVersion", "Index"))};
         std::vector<int64_t>& lst = ni.recentFailures[k];
         size_t expired = 0;
         for (int64_t ts : lst) {
@@ -1855,9 +2067,28 @@ class Scheduler {
         const Value* s = t.get("Status");
         return (s != nullptr && s->is_obj()) ? s->shallow_copy() : Value::object();
     }
+    // The decisions of a device call are booked task by task, and every one of them lands in memory nothing has touched since the
+    // task's event (its entry in allTasks, its node's task list): the answer is known for the WHOLE call, so the lines a task will
+    // need are asked for a few tasks ahead — stage 1: the table cells and the NodeInfo, stage 2: what those point to.
+    static constexpr size_t PREFETCH_FAR = 12, PREFETCH_NEAR = 6;
+    void prefetchBooking(const Item& item, int32_t n, int stage) const {
+        const uint64_t h = id_hash(item.first);
+        allTasks_.prefetch(h, stage);
+        lastDecisions_.prefetch(h, stage);
+        if (n < 0 || (size_t)n >= node_by_idx_.size() || node_by_idx_[(size_t)n] == nullptr) return;
+        const NodeInfo* ni = node_by_idx_[(size_t)n];
+        if (stage == 1) {
+            __builtin_prefetch(&ni->Tasks);
+            __builtin_prefetch(idx_to_id_.data() + n);
+        } else ni->Tasks.prefetch();
+    }
     // scheduleNTasksOnNodes' bookkeeping for one placed task (scheduler.go:868-897); the numeric addTask already
     // happened on the device
-    void place(const std::string& tid, const Value& t, int32_t n, Decisions& decisions, const uint32_t* att = nullptr) {
+    void place(const Item& item, int32_t n, Decisions& decisions, const uint32_t* att = nullptr) {
+        const std::string& tid = item.first;
+        const Value& t = item.second;
+        const Template& tm = templates_[item.tmpl];   // (what follows reads of the Spec is the same for every task of the template)
+        const uint64_t tid_hash = id_hash(tid);
         if ((size_t)n >= idx_to_id_.size()) fail(SWP_EINVAL, "engine returned an unknown node index");
         const std::string& nid = idx_to_id_[(size_t)n];
         // (every assigned task's Status is the same two fields: ONE shared sub-document — sub-documents are immutable once built, a
@@ -1877,10 +2108,10 @@ class Scheduler {
         newT.o->reserve(t.o->size() + 2);
         const Value *v_service = nullptr, *v_status = nullptr, *v_spec = nullptr;
         for (const json::Member& m : *t.o) {
-            if (m.first == "NodeID") continue;
-            if (m.first == "Status") { v_status = &m.second; continue; }
-            if (m.first == "ServiceID") v_service = &m.second;
-            else if (m.first == "Spec") v_spec = &m.second;
+            if (Value::key_is(m.first, "NodeID")) continue;
+            if (Value::key_is(m.first, "Status")) { v_status = &m.second; continue; }
+            if (Value::key_is(m.first, "ServiceID")) v_service = &m.second;
+            else if (Value::key_is(m.first, "Spec")) v_spec = &m.second;
             newT.o->push_back(m);
         }
         newT.o->emplace_back("NodeID", Value::str(nid));
@@ -1889,7 +2120,7 @@ class Scheduler {
         if (nip == nullptr) fail(SWP_EINVAL, "engine placed a task on a node the nodeSet does not hold");
         NodeInfo& ni_second = *nip;
         // nodeInfo.addTask(&newT) (:886-888): the counts moved on the device already; WHICH resources the task holds is decided here
-        const generic::List want = generic::decode(at(v_spec, {"Resources", "Reservations", "Generic"}));
+        const generic::List want = tm.wants_generic ? generic::decode(at(v_spec, "Resources", "Reservations", "Generic")) : generic::List();
         if (!want.empty()) {
             generic::List assigned;
             generic::claim(&ni_second.availGeneric, &assigned, want);
@@ -1899,7 +2130,7 @@ class Scheduler {
         }
         // newT.Volumes = attachments; reserveTaskVolumes(&newT) (scheduler.go:862-874): what the engine chose on the node, in mount order; a
         // mount that found no volume leaves the task without attachments (the reference logs the error and assigns it all the same)
-        const std::vector<const Value*> cms = at(v_spec, {"Container", "Mounts"}) != nullptr ? clusterMounts(t) : std::vector<const Value*>();
+        const std::vector<const Value*> cms = tm.has_mounts ? clusterMounts(t) : std::vector<const Value*>();
         size_t n_chosen = 0;   // the mounts chooseTaskVolumes found a volume for, in order (all of them: the task gets its attachments)
         if (!cms.empty() && att != nullptr) {
             while (n_chosen < cms.size() && att[n_chosen] != SWP_NO_VOLUME) ++n_chosen;
@@ -1922,41 +2153,70 @@ class Scheduler {
         if (!want.empty()) decisions.field("AssignedGenericResources", *newT.get("AssignedGenericResources"));
         if (newT.get("Volumes") != nullptr) decisions.field("Volumes", *newT.get("Volumes"));
         decisions.end();
-        ni_second.Tasks.put(tid, newT);
-        rememberDecision(tid, t, false);
-        allTasks_[tid] = std::move(newT);
+        ni_second.Tasks.put(tid, tid_hash, newT);
+        lastDecisions_.at(tid, tid_hash) = PendingDecision{t, false};
+        allTasks_.at(tid, tid_hash) = std::move(newT);
     }
     // lastDecisions_[tid] = {old, preassigned}; a tick decides its tasks in id order more often than not: try the end of the map first
     void rememberDecision(const std::string& tid, const Value& old, bool preassigned) {
-        if (lastDecisions_.empty() || lastDecisions_.rbegin()->first < tid) lastDecisions_.emplace_hint(lastDecisions_.end(), tid, PendingDecision{old, preassigned});
-        else lastDecisions_[tid] = PendingDecision{old, preassigned};
+        lastDecisions_[tid] = PendingDecision{old, preassigned};
     }
     // noSuitableNode, scheduler.go:928-971
-    void noSuitableNode(const std::string& tid, const Value& t, const uint32_t* hist, Decisions& decisions) {
+    void noSuitableNode(const Item& item, const uint32_t* hist, Decisions& decisions) {
+        const std::string& tid = item.first;
+        const Value& t = item.second;
+        const uint64_t tid_hash = id_hash(tid);
         auto svc = services_.find(as_str(t.get("ServiceID")));
         if (svc == services_.end()) return;   // :935-939: the service is gone, the task is dropped
         Value newT = t.shallow_copy();
-        const Value* tv = at(&t, {"SpecVersion", "Index"});
+        const Value* tv = at(&t, "SpecVersion", "Index");
         if (svc->second.has_value() && tv != nullptr && *svc->second > (uint64_t)as_i64(tv)) {
             // :940-953: a task of an old revision that is meant to shut down anyway is moved to SHUTDOWN instead of retried
-            if (task_state(at(&t, {"Status", "State"})) == PENDING && task_state(t.get("DesiredState")) >= SHUTDOWN) {
+            if (task_state(at(&t, "Status", "State")) == PENDING && task_state(t.get("DesiredState")) >= SHUTDOWN) {
                 Value status = statusCopy(t);
                 status.set("State", Value::integer(SHUTDOWN));
                 status.set("Err", Value::str(""));
                 newT.set("Status", status);
             }
         } else {
-            const std::string ex = explain(hist);
-            Value status = statusCopy(t);
-            status.set("Err", Value::str(ex.empty() ? "no suitable node" : "no suitable node (" + ex + ")"));
-            newT.set("Status", status);
-            unassignedTasks_.put(tid, newT);   // enqueue again, :968
+            // The tasks of a batch that find no node do so for a handful of reasons and from the same status: the new Status is ONE shared
+            // sub-document per (old status, histogram) — sub-documents are immutable once built — kept in a small direct-mapped memo.
+            const Value* old_status = t.get("Status");
+            uint64_t hh = 0xCBF29CE484222325ull;
+            for (int k = 0; k < SWP_NFILTERS; ++k) hh = hash_mix(hh, hist[k]);
+            NsnMemo& memo = nsn_[(hh >> 20) % (sizeof nsn_ / sizeof nsn_[0])];
+            if (!(memo.valid && std::memcmp(memo.hist, hist, sizeof memo.hist) == 0 && equal_value(old_status, memo.old.is_null() ? nullptr : &memo.old))) {
+                const std::string ex = explain(hist);
+                std::string err;
+                err.reserve(ex.size() + 20);
+                err += "no suitable node";
+                if (!ex.empty()) { err += " ("; err += ex; err += ')'; }
+                // the old Status with Err replaced (or added behind the other members): one vector of the right size
+                Value status = Value::object();
+                bool had_err = false;
+                if (old_status != nullptr && old_status->is_obj()) {
+                    status.o->reserve(old_status->o->size() + 1);
+                    for (const json::Member& m : *old_status->o) {
+                        if (Value::key_is(m.first, "Err")) { status.o->emplace_back(m.first, Value::str(std::move(err))); had_err = true; }
+                        else status.o->push_back(m);
+                    }
+                }
+                if (!had_err) status.o->emplace_back("Err", Value::str(std::move(err)));
+                memo.status = std::move(status);
+                memo.old = old_status != nullptr ? *old_status : Value();
+                std::memcpy(memo.hist, hist, sizeof memo.hist);
+                memo.valid = true;
+            }
+            newT.set("Status", memo.status);
+            unassignedTasks_.put(tid, newT, item.tmpl);   // enqueue again, :968 (its template is what it was: nothing SetTask reads changed)
         }
         decisions.begin(t, newT);
         decisions.end();
-        rememberDecision(tid, t, false);
-        allTasks_[tid] = std::move(newT);
+        lastDecisions_.at(tid, tid_hash) = PendingDecision{t, false};
+        allTasks_.at(tid, tid_hash) = std::move(newT);
     }
+    struct NsnMemo { Value status, old; uint32_t hist[SWP_NFILTERS]; bool valid = false; };   // noSuitableNode: a new Status, and what it was made from
+    NsnMemo nsn_[64];
     // A device call failed for these tasks (a predicate set the engine refuses, a device error): nothing of the call was applied, so the tasks go back on the queue — the Go shim routes a deferred task to the
     // reference's own scheduleTaskGroup — and the tick carries on with the rest. One decision line per task says why.
     void defer(const std::string& tid, const Value& t, const Fail& f, Decisions& decisions) {
@@ -1978,7 +2238,7 @@ class Scheduler {
         for (size_t i = from; i < to; ++i) {
             const Value& t0 = groups[i][0].second;
             const std::string& sid = as_str(t0.get("ServiceID"));
-            const int64_t ver = as_i64(at(&t0, {"SpecVersion", "Index"}));
+            const int64_t ver = as_i64(at(&t0, "SpecVersion", "Index"));
             auto ins = seen.emplace(sid, ver);
             if (!ins.second && ins.first->second != ver) { cut = i; break; }
         }
@@ -2031,8 +2291,10 @@ class Scheduler {
         for (size_t g = from; g < to; ++g) {
             for (size_t i = 0; i < groups[g].size(); ++i) {
                 const int32_t n = out[off + i];
-                if (n >= 0) place(groups[g][i].first, groups[g][i].second, n, decisions, any_mounts ? &att[(off + i) * SWP_MAX_MOUNTS] : nullptr);
-                else noSuitableNode(groups[g][i].first, groups[g][i].second, &hist[(g - from) * SWP_NFILTERS], decisions);
+                if (i + PREFETCH_FAR < groups[g].size()) prefetchBooking(groups[g][i + PREFETCH_FAR], out[off + i + PREFETCH_FAR], 1);
+                if (i + PREFETCH_NEAR < groups[g].size()) prefetchBooking(groups[g][i + PREFETCH_NEAR], out[off + i + PREFETCH_NEAR], 2);
+                if (n >= 0) place(groups[g][i], n, decisions, any_mounts ? &att[(off + i) * SWP_MAX_MOUNTS] : nullptr);
+                else noSuitableNode(groups[g][i], &hist[(g - from) * SWP_NFILTERS], decisions);
             }
             off += groups[g].size();
         }
@@ -2067,8 +2329,10 @@ class Scheduler {
         for (size_t i = 0; i < run.size(); ++i) {
             const uint32_t* a = nullptr;
             if (wm < with_mounts.size() && with_mounts[wm] == i) a = &att[wm++ * SWP_MAX_MOUNTS];
-            if (out[i] >= 0) place(run[i].first, run[i].second, out[i], decisions, a);
-            else noSuitableNode(run[i].first, run[i].second, &hist[i * SWP_NFILTERS], decisions);
+            if (i + PREFETCH_FAR < run.size()) prefetchBooking(run[i + PREFETCH_FAR], out[i + PREFETCH_FAR], 1);
+            if (i + PREFETCH_NEAR < run.size()) prefetchBooking(run[i + PREFETCH_NEAR], out[i + PREFETCH_NEAR], 2);
+            if (out[i] >= 0) place(run[i], out[i], decisions, a);
+            else noSuitableNode(run[i], &hist[i * SWP_NFILTERS], decisions);
         }
         pushTouched();
         prof_.lap(5);
