@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <initializer_list>
+#include <iterator>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -121,6 +122,8 @@ class Parser {
   public:
     Parser(const char* p, size_t n) : p_(p), e_(p + n) {}
     Value parse_document() {
+        members_.clear();   // (left behind by a parse that failed half-way)
+        elements_.clear();
         Value v = value(0);
         ws();
         if (p_ != e_) fail("trailing characters");
@@ -130,6 +133,12 @@ class Parser {
   private:
     const char* p_;
     const char* e_;
+    // the members / elements of the objects and arrays that are still open, innermost last; per thread, so that the room they have
+    // grown to serves the next document (an event is one small document: two allocations less per event)
+    struct Scratch { std::vector<Member> members; std::vector<Value> elements; };
+    static Scratch& scratch() { static thread_local Scratch s; return s; }
+    std::vector<Member>& members_ = scratch().members;   // (bound once per parser: a thread_local is a function call per access)
+    std::vector<Value>& elements_ = scratch().elements;
     [[noreturn]] void fail(const char* what) { throw ParseError(std::string("json: ") + what); }
     void ws() {
         while (p_ != e_ && (*p_ == ' ' || *p_ == '\t' || *p_ == '\n' || *p_ == '\r')) ++p_;
@@ -167,8 +176,14 @@ class Parser {
         return v;
     }
     std::string string() {
-        std::string out;
         ++p_;   // opening quote
+        // a name, an id, a label: nothing escaped — found by one scan, copied by one assignment
+        const char* q = p_;
+        while (q != e_ && *q != '"' && *q != '\\') ++q;
+        if (q == e_) fail("unterminated string");
+        std::string out(p_, q);
+        p_ = q;
+        if (*p_ == '"') { ++p_; return out; }
         for (;;) {
             if (p_ == e_) fail("unterminated string");
             char c = *p_++;
@@ -209,6 +224,20 @@ class Parser {
             if (*p_ == '.' || *p_ == 'e' || *p_ == 'E') real = true;
             ++p_;
         }
+        if (!real && p_ - s >= 1 && p_ - s <= 18 && *s != '+') {   // the usual case: an integer of at most 17 digits — no overflow to look for
+            const char* q = s;
+            const bool neg = *q == '-';
+            if (neg) ++q;
+            if (q != p_) {
+                int64_t v = 0;
+                bool digits = true;
+                for (; q != p_; ++q) {
+                    digits = digits && *q >= '0' && *q <= '9';
+                    v = v * 10 + (*q - '0');
+                }
+                if (digits) return Value::integer(neg ? -v : v);
+            }
+        }
         std::string t(s, p_);
         if (t.empty() || t == "-") fail("bad number");
         if (!real) {
@@ -230,9 +259,12 @@ class Parser {
         char c = *p_;
         if (c == '{') {
             ++p_;
-            Value v = Value::object();
             ws();
-            if (p_ != e_ && *p_ == '}') { ++p_; return v; }
+            if (p_ != e_ && *p_ == '}') { ++p_; return Value::object(); }
+            // The members are gathered on the parser's own stack (nested objects use the part above) and moved into a vector of exactly
+            // their number when the object closes: a document's member vectors were grown one by one before (four allocations and seven
+            // moved members for an object of five).
+            const size_t base = members_.size();
             for (;;) {
                 ws();
                 if (p_ == e_ || *p_ != '"') fail("expected a member name");
@@ -241,25 +273,39 @@ class Parser {
                 if (p_ == e_ || *p_ != ':') fail("expected ':'");
                 ++p_;
                 Value m = value(depth + 1);
-                v.set(k, std::move(m));   // a repeated key keeps its first position, last value (Python dict)
+                size_t dup = base;   // a repeated key keeps its first position, last value (Python dict)
+                while (dup < members_.size() && members_[dup].first != k) ++dup;
+                if (dup < members_.size()) members_[dup].second = std::move(m);
+                else members_.emplace_back(std::move(k), std::move(m));
                 ws();
                 if (p_ != e_ && *p_ == ',') { ++p_; continue; }
-                if (p_ != e_ && *p_ == '}') { ++p_; return v; }
+                if (p_ != e_ && *p_ == '}') { ++p_; break; }
                 fail("expected ',' or '}'");
             }
+            Value v;
+            v.kind = Value::Obj;
+            v.o = std::make_shared<std::vector<Member>>(std::make_move_iterator(members_.begin() + (std::ptrdiff_t)base), std::make_move_iterator(members_.end()));
+            members_.resize(base);
+            return v;
         }
         if (c == '[') {
             ++p_;
-            Value v = Value::array();
             ws();
-            if (p_ != e_ && *p_ == ']') { ++p_; return v; }
+            if (p_ != e_ && *p_ == ']') { ++p_; return Value::array(); }
+            const size_t base = elements_.size();
             for (;;) {
-                v.push(value(depth + 1));
+                Value x = value(depth + 1);
+                elements_.push_back(std::move(x));
                 ws();
                 if (p_ != e_ && *p_ == ',') { ++p_; continue; }
-                if (p_ != e_ && *p_ == ']') { ++p_; return v; }
+                if (p_ != e_ && *p_ == ']') { ++p_; break; }
                 fail("expected ',' or ']'");
             }
+            Value v;
+            v.kind = Value::Arr;
+            v.a = std::make_shared<std::vector<Value>>(std::make_move_iterator(elements_.begin() + (std::ptrdiff_t)base), std::make_move_iterator(elements_.end()));
+            elements_.resize(base);
+            return v;
         }
         if (c == '"') return Value::str(string());
         if (lit("true")) return Value::boolean(true);

@@ -14,7 +14,11 @@ DEPS = SRCS + [os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_json.hpp"), os.pa
 def build():
     # SWP_FAKE_SANITIZE=1: the same library under AddressSanitizer + UBSan (tests/test_sanitized_host_cpu.py runs the host-layer tests
     # against it in a child process that preloads the sanitizer runtimes)
+    # SWP_FAKE_O3=1: the host layer at the product's optimisation level (csrc/Makefile: -O3) — what tools/host_layer_bench.py times; the tests
+    # take -O1 (a third of the compile time)
     san = os.environ.get("SWP_FAKE_SANITIZE") == "1"
+    if os.environ.get("SWP_FAKE_O3") == "1" and not san:
+        return _build(OUT.replace(".so", "_O3.so"), ["-O3"])
     out = OUT.replace(".so", "_san.so") if san else OUT
     return _build(out, ["-O0", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if san else [])   # (-O0: a fifth of the compile time)
 

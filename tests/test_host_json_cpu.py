@@ -1,0 +1,203 @@
+"""CPU: the host layer's own containers (csrc/swp_json.hpp, the IdTable of csrc/swp_sched.cpp) from the outside — raw JSON text through the
+C boundary (the Python wrapper would re-serialise it), and the task maps under create / delete churn that closes the holes of the table.
+The engine behind the scheduler is the scripted double (tests/fake_swp.cpp)."""
+import ctypes as C
+import random
+
+import pytest
+
+import fakelib
+from swarmkit_amd import abi, sched as swsched
+
+
+@pytest.fixture()
+def s():
+    return swsched.Scheduler(engine=abi.Engine(lib_path=fakelib.build()))
+
+
+def raw_desc(s, text):
+    b = text.encode() if isinstance(text, str) else text
+    d = abi.TaskDesc()
+    rc = s.L.swp_sched_task_desc(s.h, b, len(b), C.byref(d))
+    return rc, d
+
+
+def task_text(cpu="1", mem="2", extra=""):
+    return '{"ID":"t","ServiceID":"s","DesiredState":512,"Status":{"State":64},"Spec":{"Resources":{"Reservations":{"NanoCPUs":%s,"MemoryBytes":%s%s}}}}' % (cpu, mem, extra)
+
+
+# ------------------------------------------------------------------------------------------------ numbers
+@pytest.mark.parametrize("text,want", [
+    ("0", 0), ("7", 7), ("-5", -5), ("250000000", 250000000), ("12345678901234567", 12345678901234567), ("-12345678901234567", -12345678901234567),
+    ("123456789012345678", 123456789012345678),                      # 18 characters: still the short path
+    ("1234567890123456789", 1234567890123456789),                    # 19 digits: strtoll
+    ("9223372036854775807", 2**63 - 1), ("-9223372036854775808", -2**63),
+    ("1e3", 1000), ("1.5", 1), ("2.5E2", 250), ("-0", 0),
+])
+def test_integers_and_reals_reach_the_descriptor(s, text, want):
+    rc, d = raw_desc(s, task_text(cpu=text))
+    assert rc == 0, s.L.swp_sched_last_error(s.h)
+    assert d.cpu == want and d.mem == 2
+
+
+def test_a_uint64_above_int64_keeps_its_bit_pattern(s):
+    # MaxReplicas is a uint64 (api/specs.proto): 2^64 - 1 must not become a float
+    t = '{"ID":"t","ServiceID":"s","DesiredState":512,"Status":{"State":64},"Spec":{"Placement":{"MaxReplicas":18446744073709551615}}}'
+    rc, d = raw_desc(s, t)
+    assert rc == 0 and d.max_replicas == 2**64 - 1
+
+
+@pytest.mark.parametrize("bad", ["-", "--1", "+1", "1-2x", ".", "-e"])
+def test_malformed_numbers_are_refused_or_read_as_a_real(s, bad):
+    # "-" is refused; the others go to strtod like before (whatever it makes of them): the scheduler answers, it does not crash
+    rc, _ = raw_desc(s, task_text(cpu=bad))
+    assert rc in (0, abi.SWP_EINVAL)
+    if bad == "-":
+        assert rc == abi.SWP_EINVAL
+
+
+# ------------------------------------------------------------------------------------------------ objects
+def test_a_repeated_member_keeps_its_last_value(s):
+    rc, d = raw_desc(s, task_text(cpu="1", mem="2", extra=',"NanoCPUs":5'))
+    assert rc == 0 and d.cpu == 5 and d.mem == 2
+    # ... on every level, and a repeated sub-document replaces the earlier one as a whole
+    t = '{"ID":"t","ServiceID":"s","Status":{"State":64},"Spec":{"Resources":{"Reservations":{"NanoCPUs":1}}},"Spec":{"Resources":{"Reservations":{"MemoryBytes":9}}}}'
+    rc, d = raw_desc(s, t)
+    assert rc == 0 and d.cpu == 0 and d.mem == 9
+
+
+def test_whitespace_and_empty_containers(s):
+    t = ' {\n "ID" : "t" ,\t"ServiceID":"s","Status":{ },"Networks":[ ],"Spec":{"Resources":{"Reservations":{ "NanoCPUs" : 3 }},"Placement":{"Constraints":[]}}}\r\n'
+    rc, d = raw_desc(s, t)
+    assert rc == 0 and d.cpu == 3 and d.constraint_set == 0
+
+
+@pytest.mark.parametrize("bad", ['{"ID":"t"', '{"ID":"t"}}', '{"ID":"t",}', '{"ID" "t"}', '{"ID":"t\\x"}', '{"ID":"t\\u12"}', '{"ID":"t', '[1,2', '{"a":[1,2,}', 'nul', '',
+                                 '{"ID":"t"} x', '{ID:1}'])
+def test_malformed_documents_are_refused_and_leave_the_parser_usable(s, bad):
+    rc, _ = raw_desc(s, bad)
+    assert rc == abi.SWP_EINVAL
+    assert b"json" in s.L.swp_sched_last_error(s.h)
+    # the members gathered before the failure are gone: the next document is read on its own
+    rc, d = raw_desc(s, task_text(cpu="11", mem="12"))
+    assert rc == 0 and d.cpu == 11 and d.mem == 12
+
+
+def test_nesting_is_bounded(s):
+    ok = '{"ID":"t","x":' + "[" * 60 + "]" * 60 + "}"
+    assert raw_desc(s, ok)[0] == 0
+    assert raw_desc(s, '{"ID":"t","x":' + "[" * 70 + "]" * 70 + "}")[0] == abi.SWP_EINVAL
+    assert raw_desc(s, '{"ID":"t","x":' + '{"a":' * 70 + "1" + "}" * 70 + "}")[0] == abi.SWP_EINVAL
+
+
+# ------------------------------------------------------------------------------------------------ strings
+BS = chr(92)   # (escapes are put together here so that no tool on the way to this file reads them)
+ESCAPED_IDS = [
+    ("plain", "plain"),
+    (BS + "u0041" + BS + "u00e9", "A" + chr(0xE9)),                 # \u escapes, one of them two UTF-8 bytes
+    (BS + "ud83d" + BS + "ude00", chr(0x1F600)),                    # a surrogate pair
+    (BS + "ud83dx", chr(0xD83D) + "x"),                             # a lone surrogate is kept as it stands (three bytes), like Go's decoder would not — never crashes
+    ("x" + BS + "/y" + BS + "n" + BS + "t" + BS + "b" + BS + "f" + BS + "r", "x/y\n\t\b\f\r"),
+    (chr(0xE9) + chr(0x4E2D), chr(0xE9) + chr(0x4E2D)),             # raw UTF-8 passes through
+]
+
+
+@pytest.mark.parametrize("raw,value", ESCAPED_IDS[:3] + ESCAPED_IDS[4:])
+def test_string_escapes_survive_parse_and_dump(s, raw, value):
+    """A task id written with escapes comes back, in the decision line, as the same string."""
+    s.create_node(node_doc(0))
+    s.set_service("svc")
+    text = ('{"ID":"%s","ServiceID":"svc","DesiredState":512,"Status":{"State":64},"Spec":{}}' % raw).encode()
+    flag = C.c_int(0)
+    assert s.L.swp_sched_create_task(s.h, text, len(text), C.byref(flag)) == 0 and flag.value == 1
+    out = s.tick()
+    assert [d["ID"] for d in out] == [value]
+    assert s.node_info("n000")["Tasks"] == [value]
+
+
+def test_escaped_quotes_and_backslashes_are_written_back_escaped(s):
+    # a node id with a quote, a backslash and a control character: the decision line must be valid JSON that names it again
+    nid = 'n"1\\x\ty'
+    s.create_node({"ID": nid, "Status": {"State": 2}, "Spec": {"Availability": 0}, "Description": {"Resources": {"NanoCPUs": 10**10, "MemoryBytes": 2**34}}})
+    s.set_service("svc")
+    s.create_task({"ID": "t\"1", "ServiceID": "svc", "DesiredState": 512, "Status": {"State": 64}, "Spec": {}})
+    out = s.tick()   # json.loads inside: invalid text would raise
+    assert [(d["ID"], d["NodeID"]) for d in out] == [('t"1', nid)]
+    assert s.node_info(nid)["Tasks"] == ['t"1']
+
+
+# ------------------------------------------------------------------------------------------------ the task maps under churn
+def node_doc(i):
+    return {"ID": "n%03d" % i, "Status": {"State": 2}, "Spec": {"Availability": 0}, "Description": {"Resources": {"NanoCPUs": 10**13, "MemoryBytes": 2**50}}}
+
+
+def running(tid, nid):
+    return {"ID": tid, "ServiceID": "svc", "NodeID": nid, "DesiredState": 512, "Status": {"State": 512}, "Spec": {"Resources": {"Reservations": {"NanoCPUs": 1000}}}}
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_all_tasks_survives_the_closing_of_its_holes(s, seed):
+    """4 000 tasks known to the scheduler, most of them deleted again in random order (the table closes its holes when more than half of it —
+    and more than 1 024 entries — are gone), new ones created in between: afterwards the scheduler knows exactly the survivors."""
+    rng = random.Random(seed)
+    nodes = ["n%03d" % i for i in range(20)]
+    for i in range(20):
+        s.create_node(node_doc(i))
+    s.set_service("svc")
+    alive = {}
+    for j in range(4000):
+        tid, nid = "t%05d" % j, rng.choice(nodes)
+        s.create_task(running(tid, nid))
+        alive[tid] = nid
+    order = list(alive)
+    rng.shuffle(order)
+    for k, tid in enumerate(order[:3400]):
+        assert s.delete_task(running(tid, alive.pop(tid))) is True
+        if k % 400 == 0:   # a newcomer in the middle of the deletions
+            tid2, nid2 = "u%05d" % k, rng.choice(nodes)
+            s.create_task(running(tid2, nid2))
+            alive[tid2] = nid2
+    # deleting a task a second time finds nothing on its node
+    gone = order[0]
+    assert s.delete_task(running(gone, nodes[0])) is False
+    by_node = {n: sorted(t for t, x in alive.items() if x == n) for n in nodes}
+    for n in nodes:
+        info = s.node_info(n)
+        assert info["Tasks"] == by_node[n]
+        assert info["ActiveTasksCount"] == len(by_node[n])
+    # updateTask of a task that failed: true exactly for the tasks allTasks still holds (scheduler.go:283-300)
+    for tid in order[:50]:
+        t = running(tid, nodes[0])
+        t["Status"] = {"State": 640}
+        assert s.update_task(t) is False
+    for tid in sorted(alive)[:50]:
+        t = running(tid, alive[tid])
+        t["Status"] = {"State": 640}
+        assert s.update_task(t) is True
+
+
+def test_decisions_of_the_last_tick_are_found_after_many_ticks(s):
+    """The decision log is emptied by every tick (one fill, not an erase per entry) and filled again: reject_decision finds exactly the last
+    tick's tasks, and the commit plan lists them in id order whatever order they were decided in."""
+    for i in range(4):
+        s.create_node(node_doc(i))
+    s.set_service("svc")
+    final = None
+    for r in range(6):
+        ids = ["r%d-%03d" % (r, k) for k in range(300)]
+        random.Random(r).shuffle(ids)
+        for tid in ids:
+            s.create_task({"ID": tid, "ServiceID": "svc", "DesiredState": 512, "Status": {"State": 64}, "Spec": {}})
+        out = s.tick()
+        decided = sorted(d["ID"] for d in out if d["NodeID"])
+        plan = s.commit_plan()
+        listed = [t for n in plan["Nodes"] for t in n["Tasks"]]
+        assert sorted(listed) == decided
+        for n in plan["Nodes"]:
+            assert n["Tasks"] == sorted(n["Tasks"])
+        if final is not None:
+            assert s.reject_decision(final) is False   # a decision of the tick before is final
+        final = decided[1] if len(decided) > 1 else None
+        if decided:
+            assert s.reject_decision(decided[0]) is True
+            assert s.reject_decision(decided[0]) is False

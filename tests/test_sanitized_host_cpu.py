@@ -1,6 +1,7 @@
 """CPU: the C++ host layer (csrc/swp_sched.cpp, product source) under AddressSanitizer + UndefinedBehaviorSanitizer: the event scripts of
 tests/test_sched_volumes_cpu.py (volume bookkeeping, placements with attachments, freeVolumes) and a few twin scripts of
-tests/test_sched_cpu.py run in a child process over a sanitized build of the scripted engine double + host layer. A finding aborts the
+tests/test_sched_cpu.py, and the container tests of tests/test_host_json_cpu.py (malformed documents, the task table closing its holes,
+the decision log over many ticks) run in a child process over a sanitized build of the scripted engine double + host layer. A finding aborts the
 child; its report is the assertion message."""
 import os
 import subprocess
@@ -23,5 +24,6 @@ def test_host_layer_event_scripts_under_the_sanitizers():
     env = dict(os.environ, SWP_FAKE_SANITIZE="1", LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", SWP_TWIN_SEEDS="3", PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(HERE, "test_sched_volumes_cpu.py"),
-                        os.path.join(HERE, "test_sched_cpu.py"), "-k", "volume or attachments or books or start or twin or refused or survives"], capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(HERE))
+                        os.path.join(HERE, "test_sched_cpu.py"), os.path.join(HERE, "test_host_json_cpu.py"),
+                        "-k", "volume or attachments or books or start or twin or refused or survives or decisions or escape or nesting or repeated"], capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
