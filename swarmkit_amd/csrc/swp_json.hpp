@@ -26,9 +26,11 @@ using Member = std::pair<std::string, Value>;
 struct Value {
     enum Kind : uint8_t { Null, Bool, Int, Real, Str, Arr, Obj };
     Kind kind = Null;
-    bool b = false;
-    int64_t i = 0;
-    double d = 0.0;
+    union {   // the scalar of a Bool / Int / Real (read only under its kind): one word, not three — a member is 104 bytes instead of 120
+        bool b;
+        int64_t i = 0;
+        double d;
+    };
     std::string s;
     std::shared_ptr<std::vector<Value>> a;
     std::shared_ptr<std::vector<Member>> o;

@@ -1450,18 +1450,19 @@ class Scheduler {
         using Item = QItem;
         std::vector<std::vector<Item>> groups;
         std::map<FailureKey, size_t> group_of;
+        std::vector<size_t> group_of_tmpl(templates_.size(), ~(size_t)0);   // (the key is looked up once per template, not once per task)
         std::vector<Item> one_off;
         one_off.reserve(queue.size());
         for (Item& it : queue) {
             const Template& tm = templates_[it.tmpl];
             if (tm.has_version) {   // :442-459: tasks with a spec version are grouped
-                FailureKey k{tm.service, tm.version};
-                auto g = group_of.find(k);
-                if (g == group_of.end()) {
-                    group_of[k] = groups.size();
-                    groups.emplace_back();
-                    groups.back().push_back(std::move(it));
-                } else groups[g->second].push_back(std::move(it));
+                size_t& g = group_of_tmpl[it.tmpl];
+                if (g == ~(size_t)0) {
+                    auto ins = group_of.emplace(FailureKey{tm.service, tm.version}, groups.size());
+                    if (ins.second) groups.emplace_back();
+                    g = ins.first->second;
+                }
+                groups[g].push_back(std::move(it));
             } else one_off.push_back(std::move(it));
         }
         prof_.lap(2);
@@ -2273,12 +2274,14 @@ class Scheduler {
         }
         std::vector<int32_t> out(total, -1);
         std::vector<uint32_t> hist(descs.size() * SWP_NFILTERS, 0);
+        prof_.lap(3);
         bool any_mounts = false;
         for (const swp_task_desc& d : descs) any_mounts = any_mounts || (d.flags >> SWP_TASK_MOUNTS_SHIFT) != 0;
         std::vector<uint32_t> att(any_mounts ? total * SWP_MAX_MOUNTS : 0, SWP_NO_VOLUME);
         try {
             if (any_mounts) ck(swp_schedule_groups_volumes(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data(), att.data()), "swp_schedule_groups");
             else ck(swp_schedule_groups(e_, descs.data(), sizes.data(), (uint32_t)descs.size(), out.data(), hist.data()), "swp_schedule_groups");
+            prof_.lap(4);
         } catch (const Fail& f) {
             if (to - from > 1) {   // find the group(s) the engine cannot take: run them one by one
                 for (size_t g = from; g < to; ++g) runGroups(groups, g, g + 1, decisions);
@@ -2299,6 +2302,7 @@ class Scheduler {
             off += groups[g].size();
         }
         pushTouched();   // groups with generic reservations: the nodes' available lists after place()'s Claim
+        prof_.lap(5);
     }
     void runOneOffs(const std::vector<Item>& run, const std::vector<swp_task_desc>& descs, Decisions& decisions) {
         if (run.empty()) return;
