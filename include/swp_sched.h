@@ -59,6 +59,11 @@ int swp_sched_set_service(swp_sched*, const char* service_id, size_t len, int ha
 int swp_sched_delete_service(swp_sched*, const char* service_id, size_t len);
 /* Test clock: time.Now() of taskFailed / countRecentFailures (nodeinfo.go:177-221) advances by `ns`. */
 int swp_sched_advance(swp_sched*, int64_t ns);
+/* What the scheduler holds, for monitoring (no counterpart in the reference: len() of its maps): out[0] = tasks in allTasks
+ * (scheduler.go:40), out[1] = tasks waiting in unassignedTasks (:37), out[2] = decisions of the last tick / processPreassignedTasks that
+ * can still be rejected, out[3] = task templates (one per service revision with queued tasks; swept by tick once there are more than
+ * 1 024 and most are out of use). */
+int swp_sched_counts(swp_sched*, uint64_t out[4]);
 
 /* Task event handlers. task_json = api.Task. *tick_needed = the handler's bool result (scheduler.go:178-190:
  * a true result sets tickRequired). */

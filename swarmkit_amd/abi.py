@@ -113,7 +113,7 @@ EXPORTS = [
     "swp_shard_begin", "swp_shard_propose", "swp_shard_merge", "swp_shard_commit", "swp_shard_end", "swp_shard_run", "swp_rccl_available", "swp_rccl_unique_id", "swp_rccl_init", "swp_rccl_finalize", "swp_shard_run_rank", "swp_shard_verdict",
     # include/swp_sched.h — the host layer above the engine
     "swp_sched_create", "swp_sched_destroy", "swp_sched_last_error", "swp_sched_create_or_update_node", "swp_sched_delete_node", "swp_sched_node_info",
-    "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
+    "swp_sched_set_service", "swp_sched_delete_service", "swp_sched_advance", "swp_sched_counts", "swp_sched_create_task", "swp_sched_setup_task", "swp_sched_update_task",
     "swp_sched_delete_task", "swp_sched_tick", "swp_sched_process_preassigned", "swp_sched_reject_decision", "swp_sched_commit_plan", "swp_sched_reject_decisions", "swp_sched_reject_node", "swp_sched_task_desc", "swp_sched_constraint_set", "swp_sched_enforce", "swp_sched_update_volume", "swp_sched_volume_info", "swp_sched_free_volumes",
     "swp_constraint_parse", "swp_key_equal_fold", "swp_explain", "swp_parse_ip",
 ]
@@ -227,6 +227,7 @@ def load_library(path=None):
         "swp_sched_set_service": ([vp, cp, sz, C.c_int, u64], C.c_int),
         "swp_sched_delete_service": ([vp, cp, sz], C.c_int),
         "swp_sched_advance": ([vp, i64], C.c_int),
+        "swp_sched_counts": ([vp, C.POINTER(C.c_uint64)], C.c_int),
         "swp_sched_create_task": ([vp, cp, sz, P(C.c_int)], C.c_int),
         "swp_sched_setup_task": ([vp, cp, sz, P(C.c_int)], C.c_int),
         "swp_sched_update_task": ([vp, cp, sz, P(C.c_int)], C.c_int),

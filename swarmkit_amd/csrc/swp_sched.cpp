@@ -473,6 +473,7 @@ class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queu
         return out;
     }
     bool empty() const { return live_ == 0; }
+    size_t size() const { return live_; }
 
   private:
     // id -> position in items_: open addressing over (hash, position) pairs — no node per entry, so emptying the queue of a 100k-task
@@ -1160,14 +1161,17 @@ class Scheduler {
     std::vector<Template> templates_;
     std::unordered_map<uint64_t, std::vector<uint32_t>> tmplIndex_;
     uint64_t tmplGen_ = 0;
+    static uint64_t templateHash(const Value& t) {
+        const Value *spec = t.get("Spec"), *nets = t.get("Networks"), *endp = t.get("Endpoint"), *sv = t.get("SpecVersion");
+        uint64_t h = hash_bytes(0xCBF29CE484222325ull, as_str(t.get("ServiceID")));
+        h = hash_mix(h, task_state(t.get("DesiredState")) > COMPLETE ? 1 : 0);
+        return hash_value(hash_value(hash_value(hash_value(h, sv), spec), nets), endp);
+    }
     uint32_t templateOf(const Value& t) {
         const Value *spec = t.get("Spec"), *nets = t.get("Networks"), *endp = t.get("Endpoint"), *sv = t.get("SpecVersion");
         const std::string& sid = as_str(t.get("ServiceID"));
         const bool uncounted = task_state(t.get("DesiredState")) > COMPLETE;
-        uint64_t h = hash_bytes(0xCBF29CE484222325ull, sid);
-        h = hash_mix(h, uncounted ? 1 : 0);
-        h = hash_value(hash_value(hash_value(hash_value(h, sv), spec), nets), endp);
-        std::vector<uint32_t>& cands = tmplIndex_[h];
+        std::vector<uint32_t>& cands = tmplIndex_[templateHash(t)];
         for (uint32_t id : cands) {
             const Value& x = templates_[id].exemplar;
             if (as_str(x.get("ServiceID")) == sid && (task_state(x.get("DesiredState")) > COMPLETE) == uncounted && equal_value(x.get("SpecVersion"), sv) &&
@@ -1184,6 +1188,27 @@ class Scheduler {
         templates_.push_back(std::move(tm));
         cands.push_back((uint32_t)templates_.size() - 1);
         return (uint32_t)templates_.size() - 1;
+    }
+    // Templates are only ever referred to by QUEUED tasks (QItem::tmpl), and a tick holds the whole queue in its hands: when most of
+    // the templates belong to service revisions nothing in the queue is of any more, the ones in use move to the front and the rest
+    // — their exemplar documents, their descriptors — go (a scheduler that lives for months sees revisions come and never sees them
+    // leave otherwise). A revision that comes back is recognised afresh from its next event.
+    static constexpr size_t TEMPLATES_KEPT = 1024;   // below this many nothing is swept
+    void sweepTemplates(std::vector<QItem>& queue, size_t in_use) {
+        if (templates_.size() <= TEMPLATES_KEPT || templates_.size() <= 4 * in_use) return;
+        std::vector<uint32_t> remap(templates_.size(), NO_TMPL);
+        std::vector<Template> kept;
+        kept.reserve(in_use);
+        for (QItem& it : queue) {
+            if (remap[it.tmpl] == NO_TMPL) {
+                remap[it.tmpl] = (uint32_t)kept.size();
+                kept.push_back(std::move(templates_[it.tmpl]));
+            }
+            it.tmpl = remap[it.tmpl];
+        }
+        templates_.swap(kept);
+        tmplIndex_.clear();
+        for (size_t i = 0; i < templates_.size(); ++i) tmplIndex_[templateHash(templates_[i].exemplar)].push_back((uint32_t)i);
     }
     // the template's descriptor (Pipeline.SetTask once per template and volume generation); throws what taskDesc throws
     const swp_task_desc& descOf(uint32_t tmpl) {
@@ -1410,13 +1435,16 @@ class Scheduler {
         std::set<std::string> sids;
         {
             std::vector<char> seen(templates_.size() + queue.size(), 0);   // (a task re-queued without a template gets one here)
+            size_t in_use = 0;
             for (Item& it : queue) {
                 if (it.tmpl == NO_TMPL) it.tmpl = templateOf(it.second);
                 if (it.tmpl >= seen.size()) seen.resize(it.tmpl + 1, 0);
                 if (seen[it.tmpl]) continue;
                 seen[it.tmpl] = 1;
+                ++in_use;
                 sids.insert(templates_[it.tmpl].service);
             }
+            sweepTemplates(queue, in_use);
         }
         prof_.lap(0);
         try {
@@ -1614,6 +1642,14 @@ class Scheduler {
         uint32_t n = 0;
         for (const std::string& tid : ids) n += rejectDecision(tid) ? 1u : 0u;
         return n;
+    }
+
+    // what the scheduler holds (swp_sched_counts)
+    void counts(uint64_t out[4]) const {
+        out[0] = allTasks_.size();
+        out[1] = unassignedTasks_.size();
+        out[2] = lastDecisions_.size();
+        out[3] = templates_.size();
     }
 
     // ---------------------------------------------------------------------------------------------- constraint enforcer
@@ -2466,6 +2502,13 @@ int swp_sched_delete_service(swp_sched* s, const char* service_id, size_t len) {
     return guarded(s, [&](swp::Scheduler& impl) {
         if (service_id == nullptr) return (int)SWP_EINVAL;
         impl.deleteService(std::string(service_id, len));
+        return (int)SWP_OK;
+    });
+}
+int swp_sched_counts(swp_sched* s, uint64_t out[4]) {
+    return guarded(s, [&](swp::Scheduler& impl) {
+        if (out == nullptr) return (int)SWP_EINVAL;
+        impl.counts(out);
         return (int)SWP_OK;
     });
 }

@@ -113,6 +113,12 @@ class Scheduler:
     def advance(self, seconds):
         self._ck(self.L.swp_sched_advance(self.h, int(seconds * self.SECOND)))
 
+    def counts(self):
+        """What the scheduler holds: tasks, queued tasks, rejectable decisions, task templates (swp_sched_counts)."""
+        out = (C.c_uint64 * 4)()
+        self._ck(self.L.swp_sched_counts(self.h, out))
+        return {"tasks": out[0], "queued": out[1], "decisions": out[2], "templates": out[3]}
+
     # ---- task events ----
     def create_task(self, t):
         return self._doc_call(self.L.swp_sched_create_task, t)

@@ -201,3 +201,41 @@ def test_decisions_of_the_last_tick_are_found_after_many_ticks(s):
         if decided:
             assert s.reject_decision(decided[0]) is True
             assert s.reject_decision(decided[0]) is False
+
+
+# ------------------------------------------------------------------------------------------------ task templates come and go
+def spec_task(tid, k):
+    # (every k is a service revision of its own: the reservation differs)
+    return {"ID": tid, "ServiceID": "svc", "DesiredState": 512, "Status": {"State": 64}, "Spec": {"Resources": {"Reservations": {"NanoCPUs": 1000 + k}}}}
+
+
+def test_templates_of_revisions_nothing_is_queued_of_are_swept(s):
+    """One template per service revision with queued tasks (swp_sched_counts): once there are more than 1 024 and most of them belong to
+    revisions the queue holds nothing of, a tick keeps the ones in use — and the tasks it re-queues (no suitable node) are still
+    scheduled with THEIR spec afterwards."""
+    for i in range(8):
+        s.create_node(node_doc(i))
+    s.set_service("svc")
+    for k in range(1500):
+        s.create_task(spec_task("a%04d" % k, k))
+    assert s.counts() == {"tasks": 1500, "queued": 1500, "decisions": 0, "templates": 1500}
+    out = s.tick()
+    waiting = sorted(d["ID"] for d in out if not d["NodeID"])
+    assert 100 < len(waiting) < 600            # the double leaves one task in five without a node: they are queued again
+    c = s.counts()
+    assert c["templates"] == 1500 and c["queued"] == len(waiting) and c["decisions"] == 1500
+    for k in range(10):
+        s.create_task(spec_task("b%04d" % k, 5000 + k))
+    assert s.counts()["templates"] == 1510
+    out = s.tick()
+    assert sorted(d["ID"] for d in out) == sorted(waiting + ["b%04d" % k for k in range(10)])
+    assert s.counts()["templates"] == len(waiting) + 10   # swept: what this tick's queue was of
+    # a task keeps the descriptor of ITS revision through the sweep: the double logs the cpu it was asked for
+    log = "\n".join(fakelib.take_log(s.e))
+    for tid in waiting[:20]:
+        assert "cpu=%d " % (1000 + int(tid[1:])) in log
+    # a revision that was swept is recognised again from its next event
+    before = s.counts()["templates"]
+    s.create_task(spec_task("c0000", 7))
+    assert s.counts()["templates"] == before + (0 if "a0007" in waiting else 1)   # (kept if a0007 was in the second tick's queue)
+    assert [d["ID"] for d in s.tick() if d["ID"] == "c0000"] == ["c0000"]
