@@ -8,7 +8,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "_build", "libswpfake.so")
 SRCS = [os.path.join(ROOT, "tests", "fake_swp.cpp"), os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_sched.cpp")]
-DEPS = SRCS + [os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_json.hpp"), os.path.join(ROOT, "include", "swp.h"), os.path.join(ROOT, "include", "swp_sched.h")]
+DEPS = SRCS + [os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_json.hpp"), os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_tables.hpp"), os.path.join(ROOT, "swarmkit_amd", "csrc", "swp_generic.hpp"), os.path.join(ROOT, "include", "swp.h"), os.path.join(ROOT, "include", "swp_sched.h")]
 
 
 def build():

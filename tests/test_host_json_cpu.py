@@ -1,4 +1,4 @@
-"""CPU: the host layer's own containers (csrc/swp_json.hpp, the IdTable of csrc/swp_sched.cpp) from the outside — raw JSON text through the
+"""CPU: the host layer's own containers (csrc/swp_json.hpp, the IdTable of csrc/swp_tables.hpp) from the outside — raw JSON text through the
 C boundary (the Python wrapper would re-serialise it), and the task maps under create / delete churn that closes the holes of the table.
 The engine behind the scheduler is the scripted double (tests/fake_swp.cpp)."""
 import ctypes as C
