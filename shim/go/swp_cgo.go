@@ -38,6 +38,7 @@ import (
 	"unsafe"
 
 	"github.com/moby/swarmkit/v2/api"
+	"github.com/moby/swarmkit/v2/api/genericresource"
 	"github.com/moby/swarmkit/v2/manager/constraint"
 )
 
