@@ -3,7 +3,7 @@
 // read from files. Development tool; not part of the product or of any test.
 //   python tools/host_layer_bench.py --dump /tmp/hl        (nodes.jsonl, services.txt, tasks.jsonl)
 //   g++ -std=c++17 -O2 -g -pg -Iinclude -o /tmp/hl/prof tools/host_layer_prof.cpp tests/fake_swp.cpp swarmkit_amd/csrc/swp_sched.cpp
-//   /tmp/hl/prof /tmp/hl [repetitions] [all|events|tick] && gprof /tmp/hl/prof gmon.out | head -40
+//   /tmp/hl/prof /tmp/hl [repetitions] [all|nodes|events|tick] && gprof /tmp/hl/prof gmon.out | head -40
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,7 +28,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 int main(int argc, char** argv) {
     const std::string dir = argc > 1 ? argv[1] : "/tmp/hl";
     const int reps = argc > 2 ? std::atoi(argv[2]) : 1;
-    const std::string phase = argc > 3 ? argv[3] : "all";   // what gprof samples: all | events | tick
+    const std::string phase = argc > 3 ? argv[3] : "all";   // what gprof samples: all | nodes | events | tick
     moncontrol(phase == "all");
     const auto nodes = lines(dir + "/nodes.jsonl"), services = lines(dir + "/services.txt"), tasks = lines(dir + "/tasks.jsonl");
     for (int r = 0; r < reps; ++r) {
@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
         if (swp_create(&cfg, &e) != SWP_OK) { std::fprintf(stderr, "swp_create: %s\n", swp_last_error(nullptr)); return 1; }
         swp_sched* s = nullptr;
         if (swp_sched_create(e, &s) != SWP_OK) { std::fprintf(stderr, "swp_sched_create: %s\n", swp_sched_last_error(nullptr)); return 1; }
+        moncontrol(phase == "all" || phase == "nodes");
         double t0 = now();
         for (const auto& n : nodes)
             if (swp_sched_create_or_update_node(s, n.data(), n.size()) != SWP_OK) { std::fprintf(stderr, "node: %s\n", swp_sched_last_error(s)); return 1; }
