@@ -463,6 +463,7 @@ WV_DEV void g2_helper(const Groups2Args& a, G2Mail* mb, u32 hid, u32 nh) {
                 }
             }
         }
+        wv::lockstep();   // every lane of the wave is through the command before lane 0 says so (the device runs them together: this is for the CPU fibers)
         if (lane == 0) wv::lds_add_release32(&mb->done, 1u);
     }
 }

@@ -89,6 +89,19 @@ struct Block {
     std::vector<WaveSync> waves;
     int bar_arrived = 0;
     std::deque<u32> runq;
+    // EMU_SCHED_SEED=<n>: the runnable fibers are kept per WAVE and the next wave to run is drawn at random — but only at the points where
+    // a wave is of one mind: when one of its collectives completes (every lane is at the same instruction), or when none of its lanes can
+    // go on (they wait for another wave). In between, the wave drawn last runs all the lanes it has runnable, in their order: on the
+    // device the lanes of a wave execute an instruction together, so another wave can never see the stores of lane 0's stretch without
+    // those of lane 1's — the stretch between two collectives is the unit of interleaving here. At such a point the same wave is kept
+    // with a probability drawn per launch (from "waves alternate" to "one wave runs as far as it can"). The default order — one queue,
+    // first in first out — is ONE timing among the ones the device can produce; the hand-shakes between waves that never meet at a
+    // barrier must hold under all of them.
+    std::vector<std::deque<u32>> wq;
+    u64 rng = 0;
+    u32 sticky_wave = ~0u, stick_pct = 0;
+    bool decide = true;   // the next dequeue is a point where another wave may be drawn
+    size_t queued = 0;
     std::vector<u32> pollers;   // fibers parked in a polling loop (spin_pause) until the next lds_publish32
     std::vector<u64> lds;
     std::function<void()> body;
@@ -114,6 +127,48 @@ inline Block*& B() {
     static Block* b = nullptr;
     return b;
 }
+inline u64 sched_seed() {
+    static const u64 s = getenv("EMU_SCHED_SEED") ? strtoull(getenv("EMU_SCHED_SEED"), nullptr, 10) : 0;
+    return s;
+}
+inline u64& launch_counter() {
+    static u64 n = 0;
+    return n;
+}
+inline u64 next_rand(Block* b) {   // xorshift64*
+    b->rng ^= b->rng >> 12;
+    b->rng ^= b->rng << 25;
+    b->rng ^= b->rng >> 27;
+    return b->rng * 0x2545F4914F6CDD1Dull;
+}
+inline void enqueue(Block* b, u32 t) {
+    if (sched_seed() == 0) { b->runq.push_back(t); return; }
+    b->wq[t >> 6].push_back(t);
+    b->queued++;
+}
+inline bool nothing_runnable(Block* b) { return sched_seed() == 0 ? b->runq.empty() : b->queued == 0; }
+inline u32 dequeue(Block* b) {
+    if (sched_seed() == 0) {
+        const u32 t = b->runq.front();
+        b->runq.pop_front();
+        return t;
+    }
+    u32 w = b->sticky_wave;
+    if (b->decide || w >= b->wq.size() || b->wq[w].empty()) {
+        if (w >= b->wq.size() || b->wq[w].empty() || next_rand(b) % 100 >= b->stick_pct) {
+            u32 cand[64], n = 0;
+            for (u32 k = 0; k < b->wq.size(); ++k)
+                if (!b->wq[k].empty()) cand[n++] = k;
+            w = cand[next_rand(b) % n];
+            b->sticky_wave = w;
+        }
+        b->decide = false;
+    }
+    const u32 t = b->wq[w].front();
+    b->wq[w].pop_front();
+    b->queued--;
+    return t;
+}
 
 inline void yield_until_publish() {   // a polling loop: parked until some fiber publishes a flag (wake_pollers), then it polls again
     Block* b = B();
@@ -123,7 +178,7 @@ inline void yield_until_publish() {   // a polling loop: parked until some fiber
 }
 inline void wake_pollers() {
     Block* b = B();
-    for (u32 t : b->pollers) b->runq.push_back(t);
+    for (u32 t : b->pollers) enqueue(b, t);
     b->pollers.clear();
 }
 inline void yield_blocked() {   // park the current fiber; somebody else re-queues it
@@ -151,6 +206,13 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
     blk.ncoll.assign(nthreads, 0);
     blk.lds.assign((lds_bytes + 7) / 8 + 8, 0xCDCDCDCDCDCDCDCDull);   // LDS is NOT zero-initialised on the device either
     blk.body = body;
+    if (sched_seed() != 0) {
+        blk.wq.resize(blk.waves.size());
+        blk.rng = (sched_seed() * 0x9E3779B97F4A7C15ull) ^ (++launch_counter() * 0xD1B54A32D192ED03ull) ^ 1;
+        static const u32 pcts[6] = {0, 50, 90, 99, 100, 97};
+        blk.stick_pct = pcts[next_rand(&blk) % 6];
+        if (getenv("EMU_SCHED_STICK")) blk.stick_pct = (u32)atoi(getenv("EMU_SCHED_STICK"));   // (a fixed regime, for narrowing a failure down)
+    }
     const size_t STK = 256 * 1024;
     // one stack area for the process, kept between launches: a run makes thousands of launches, and fresh mappings would be
     // paged in (zeroed) again every time
@@ -173,11 +235,11 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
         *--sp = (void*)fiber_main;
         for (int r = 0; r < 6; ++r) *--sp = nullptr;
         f.ctx.sp = sp;
-        blk.runq.push_back(t);
+        enqueue(&blk, t);
     }
     u32 alive = nthreads;
     while (alive) {
-        if (blk.runq.empty()) {
+        if (nothing_runnable(&blk)) {
             fprintf(stderr, "emu: DEADLOCK — %u threads alive, none runnable\n", alive);
             for (size_t w = 0; w < blk.waves.size(); ++w)
                 fprintf(stderr, "  wave %zu: %d lanes waiting in op %d\n", w, blk.waves[w].arrived, blk.waves[w].op);
@@ -187,8 +249,7 @@ inline void launch(u32 nthreads, size_t lds_bytes, std::function<void()> body) {
                     fprintf(stderr, "  thread %u: %llu collectives, last at %p\n", t, (unsigned long long)blk.ncoll[t], blk.last_site[t]);
             abort();
         }
-        blk.cur = blk.runq.front();
-        blk.runq.pop_front();
+        blk.cur = dequeue(&blk);
         emu_switch(&blk.sched, &blk.fib[blk.cur].ctx);
         if (blk.fib[blk.cur].done) --alive;
     }
@@ -240,8 +301,16 @@ __attribute__((noinline)) inline u64 collective(int op, u64 v, u64 aux) {
     }
     ws.arrived = 0;
     ws.op = OP_NONE;
+    if (sched_seed() != 0) {   // the wave is of one mind here: another wave may get the next turn (this lane still goes first when its wave does)
+        enqueue(b, t);
+        for (u32 l = 0; l < lanes; ++l)
+            if (wave * 64 + l != t) enqueue(b, wave * 64 + l);
+        b->decide = true;
+        yield_blocked();
+        return ws.result[lane];
+    }
     for (u32 l = 0; l < lanes; ++l)
-        if (wave * 64 + l != t) b->runq.push_back(wave * 64 + l);
+        if (wave * 64 + l != t) enqueue(b, wave * 64 + l);
     return ws.result[lane];
 }
 
@@ -260,7 +329,12 @@ __attribute__((noinline)) inline void block_barrier() {
     }
     b->bar_arrived = 0;
     for (u32 t = 0; t < b->nthreads; ++t)
-        if (t != b->cur) b->runq.push_back(t);
+        if (t != b->cur) enqueue(b, t);
+    if (sched_seed() != 0) {
+        enqueue(b, b->cur);
+        b->decide = true;
+        yield_blocked();
+    }
 }
 }  // namespace emu
 

@@ -105,3 +105,15 @@ def test_a_tick_on_a_level_cluster(emu_lds, emu_global, case, arena):
     assert r.returncode == 0 and "-> OK" in r.stderr, r.stderr[-2000:]
     m = re.search(r"(\d+) candidates by the post-order scatter.* (\d+) words appended whole", r.stderr)
     assert m and int(m.group(1)) > 100 and int(m.group(2)) >= 1, r.stderr[-600:]
+
+
+@pytest.mark.parametrize("sched", [51, 52])
+@pytest.mark.parametrize("case", [CASES[0], CASES[4], CASES[7], CASES[9], CASES[12], CASES[14], LEVEL[1] + ("u",)],
+                         ids=lambda c: "seed%d-N%d-g%d-k%d-t%d-f%d-w%d" % (c[0], c[1], c[2], c[3], c[4], c[5], c[6] // 64))
+def test_under_random_wave_schedules(emu_lds, case, sched):
+    """The machine wave and its helper waves (candidate batches ahead of the heap replay, the flat mode's counting, the filling phase) under
+    wave orders the first-in-first-out run never produces (EMU_SCHED_SEED, tests/emu/wv_emu.hpp): the helpers far ahead, far behind,
+    one at a time."""
+    r = subprocess.run([emu_lds] + [str(x) for x in case[:7]] + ["v"] + list(case[7:]), capture_output=True, text=True, timeout=900, env=dict(os.environ, EMU_SCHED_SEED=str(sched)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr

@@ -51,3 +51,14 @@ def test_round_resolver_source_matches_sequential_model(emu_bin, case):
         pytest.skip("this problem has more distinct reservations than the round resolver has LDS rows for (the engine gives such a batch to the block resolver)")
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr
+
+
+@pytest.mark.parametrize("sched", [41, 42])
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5], CASES[8], CASES[-1]], ids=lambda c: "s%d_n%d_t%d_o%d_f%d" % (c[0], c[1], c[2], c[5], c[6]))
+def test_under_random_wave_schedules(emu_bin, case, sched):
+    """... under wave orders the first-in-first-out run never produces (EMU_SCHED_SEED, tests/emu/wv_emu.hpp)."""
+    r = subprocess.run([emu_bin] + [str(x) for x in case] + ["v"], capture_output=True, text=True, timeout=600, env=dict(os.environ, EMU_SCHED_SEED=str(sched)))
+    if r.returncode == 77:
+        pytest.skip("more distinct reservations than the round resolver has LDS rows for")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr

@@ -98,3 +98,19 @@ def test_compact_index(emu_bin, case, lvl):
     r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr
+
+
+SCHED = [(1, 300, 1000, 20, 64, 0, 0, ""), (4, 5000, 2000, 300, 256, 0, 2, "s"), (12, 5924, 1856, 377, 128, 0, 0, "s"), (8, 885, 1500, 125, 64, 2, 3, ""),
+         (4, 5000, 1200, 300, 128, 0, 2, "st"), (52, 6000, 3000, 12, 256, 1, 2, ""), (21, 4500, 1500, 200, 1024, 0, 1, "")]
+
+
+@pytest.mark.parametrize("sched", [11, 12])
+@pytest.mark.parametrize("case", SCHED, ids=lambda c: "seed%d-N%d-B%d-f%d%s" % (c[0], c[1], c[4], c[6], c[7]))
+def test_under_random_wave_schedules(emu_bin, case, sched):
+    """The fibers above run first in, first out: ONE timing. EMU_SCHED_SEED draws which runnable wave goes next and how long it keeps going
+    (tests/emu/wv_emu.hpp) — the staging window, the list hand-over to the matcher and the apply waves behind it must decide the same
+    under every order the device could produce."""
+    args = [str(x) for x in case[:7]] + ["v"] + list(case[7])
+    r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, EMU_SCHED_SEED=str(sched)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr

@@ -61,3 +61,18 @@ def test_sharded_rounds_source_matches_sequential_model(emu_bin, case):
     assert "-> OK" in r.stderr
     if "c" in case[8]:   # both batches
         assert r.stderr.count("-> OK") == 2, r.stderr[-2000:]
+
+
+SCHED = [(1, 300, 400, 20, 64, 0, 0, 3, ""), (4, 1500, 500, 80, 128, 0, 2, 8, ""), (12, 5924, 1856, 377, 128, 0, 0, 3, ""), (10, 1200, 900, 90, 128, 0, 3, 8, "t"),
+         (5, 2000, 1500, 150, 128, 0, 1, 8, "c"), (13, 401, 700, 8, 128, 1, 1, 2, "ct")]
+
+
+@pytest.mark.parametrize("sched", [21, 22])
+@pytest.mark.parametrize("case", SCHED, ids=lambda c: "seed%d-N%d-B%d-f%d-G%d%s" % (c[0], c[1], c[4], c[6], c[7], c[8]))
+def test_under_random_wave_schedules(emu_bin, case, sched):
+    """The fold window (four folds in flight), the matcher and the apply waves under wave orders the default first-in-first-out run never
+    produces (EMU_SCHED_SEED, tests/emu/wv_emu.hpp)."""
+    args = [str(x) for x in case[:8]] + ["v"] + list(case[8])
+    r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, EMU_SCHED_SEED=str(sched)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("-> OK") == (2 if "c" in case[8] else 1), r.stderr[-2000:]

@@ -51,3 +51,13 @@ def test_scan_resolver_source_matches_sequential_model(emu_bin, case):
     r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "-> OK" in r.stderr
+
+
+@pytest.mark.parametrize("sched", [31, 32])
+@pytest.mark.parametrize("case", [CASES[1], CASES[4], CASES[5], CASES[8], CASES[-2]], ids=lambda c: "seed%d-N%d-T%d-f%d%s" % (c[0], c[1], c[2], c[6], c[7]))
+def test_under_random_wave_schedules(emu_bin, case, sched):
+    """... under wave orders the first-in-first-out run never produces (EMU_SCHED_SEED, tests/emu/wv_emu.hpp)."""
+    args = [str(x) for x in case[:7]] + ["v"] + list(case[7])
+    r = subprocess.run([emu_bin] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, EMU_SCHED_SEED=str(sched)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "-> OK" in r.stderr
