@@ -164,6 +164,29 @@ class Parser {
             out.push_back((char)(0x80 | (cp & 0x3F)));
         }
     }
+    // well-formed UTF-8 (RFC 3629 byte ranges: no overlong forms, no surrogates, nothing beyond U+10FFFF)
+    static bool utf8_ok(const std::string& s) {
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(s.data());
+        const unsigned char* e = p + s.size();
+        while (p != e) {
+            const unsigned char c = *p++;
+            if (c < 0x80) continue;
+            int n;
+            if (c >= 0xC2 && c <= 0xDF) n = 1;
+            else if (c >= 0xE0 && c <= 0xEF) n = 2;
+            else if (c >= 0xF0 && c <= 0xF4) n = 3;
+            else return false;
+            if (e - p < n) return false;
+            if (c == 0xE0 && p[0] < 0xA0) return false;                    // overlong
+            if (c == 0xED && p[0] > 0x9F) return false;                    // U+D800..DFFF
+            if (c == 0xF0 && p[0] < 0x90) return false;
+            if (c == 0xF4 && p[0] > 0x8F) return false;                    // beyond U+10FFFF
+            for (int k = 0; k < n; ++k)
+                if ((p[k] & 0xC0) != 0x80) return false;
+            p += n;
+        }
+        return true;
+    }
     uint32_t hex4() {
         if (e_ - p_ < 4) fail("short \\u escape");
         uint32_t v = 0;
@@ -181,15 +204,23 @@ class Parser {
         ++p_;   // opening quote
         // a name, an id, a label: nothing escaped — found by one scan, copied by one assignment
         const char* q = p_;
-        while (q != e_ && *q != '"' && *q != '\\') ++q;
+        unsigned char high = 0;
+        while (q != e_ && *q != '"' && *q != '\\') high |= (unsigned char)*q++;
         if (q == e_) fail("unterminated string");
         std::string out(p_, q);
         p_ = q;
-        if (*p_ == '"') { ++p_; return out; }
+        if (*p_ == '"') {
+            ++p_;
+            if ((high & 0x80u) && !utf8_ok(out)) fail("a string that is not UTF-8");   // (what goes in comes out again: the decisions must stay JSON)
+            return out;
+        }
         for (;;) {
             if (p_ == e_) fail("unterminated string");
             char c = *p_++;
-            if (c == '"') return out;
+            if (c == '"') {
+                if (!utf8_ok(out)) fail("a string that is not UTF-8");
+                return out;
+            }
             if (c != '\\') { out.push_back(c); continue; }
             if (p_ == e_) fail("unterminated escape");
             char x = *p_++;
@@ -211,6 +242,7 @@ class Parser {
                         if (lo >= 0xDC00 && lo < 0xE000) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
                         else p_ = save;
                     }
+                    if (cp >= 0xD800 && cp < 0xE000) cp = 0xFFFD;   // half of a surrogate pair on its own: U+FFFD, as Go's encoding/json decodes it
                     utf8(out, cp);
                     break;
                 }

@@ -69,6 +69,8 @@ static int64_t enum_value(const Value* v, std::initializer_list<std::pair<const 
     }
     return as_i64(v, def);
 }
+// a - b as Go computes it on int64: two's complement, wrapping
+static inline int64_t wrap_sub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 static int64_t task_state(const Value* v) {
     return enum_value(v, {{"NEW", 0}, {"PENDING", 64}, {"ASSIGNED", 192}, {"ACCEPTED", 256}, {"PREPARING", 320}, {"READY", 384}, {"STARTING", 448},
                           {"RUNNING", 512}, {"COMPLETE", 576}, {"SHUTDOWN", 640}, {"FAILED", 704}, {"REJECTED", 768}, {"REMOVE", 800}, {"ORPHANED", 832}}, 0, true);
@@ -481,8 +483,8 @@ class Scheduler {
                 ni->Tasks.each_sorted([&](const std::string&, const Value& t) {
                     int64_t c, m;
                     taskReservations(t, c, m);
-                    cpu -= c;
-                    mem -= m;
+                    cpu = wrap_sub(cpu, c);   // (Go's int64 wraps; documents at the boundary may say anything)
+                    mem = wrap_sub(mem, m);
                     generic::consume(&avail, generic::decode(t.get("AssignedGenericResources")));
                 });
             }

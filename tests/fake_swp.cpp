@@ -106,8 +106,9 @@ struct swp_engine {
     }
     void apply(uint32_t n, uint32_t service, int64_t cpu, int64_t mem, bool counted, bool add) {
         FakeNode& nd = nodes[n];
-        nd.row.cpu += add ? -cpu : cpu;
-        nd.row.mem += add ? -mem : mem;
+        // (two's-complement wrap-around like Go's int64: a reservation of INT64_MIN must not be undefined behaviour in a test double)
+        nd.row.cpu = (int64_t)((uint64_t)nd.row.cpu + (add ? 0 - (uint64_t)cpu : (uint64_t)cpu));
+        nd.row.mem = (int64_t)((uint64_t)nd.row.mem + (add ? 0 - (uint64_t)mem : (uint64_t)mem));
         if (counted) {
             nd.row.total += add ? 1u : (uint32_t)-1;
             nd.svc[service] += add ? 1u : (uint32_t)-1;

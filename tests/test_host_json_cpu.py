@@ -96,13 +96,13 @@ ESCAPED_IDS = [
     ("plain", "plain"),
     (BS + "u0041" + BS + "u00e9", "A" + chr(0xE9)),                 # \u escapes, one of them two UTF-8 bytes
     (BS + "ud83d" + BS + "ude00", chr(0x1F600)),                    # a surrogate pair
-    (BS + "ud83dx", chr(0xD83D) + "x"),                             # a lone surrogate is kept as it stands (three bytes), like Go's decoder would not — never crashes
+    (BS + "ud83dx", chr(0xFFFD) + "x"),                             # half a surrogate pair on its own: U+FFFD, as Go's encoding/json decodes it
     ("x" + BS + "/y" + BS + "n" + BS + "t" + BS + "b" + BS + "f" + BS + "r", "x/y\n\t\b\f\r"),
     (chr(0xE9) + chr(0x4E2D), chr(0xE9) + chr(0x4E2D)),             # raw UTF-8 passes through
 ]
 
 
-@pytest.mark.parametrize("raw,value", ESCAPED_IDS[:3] + ESCAPED_IDS[4:])
+@pytest.mark.parametrize("raw,value", ESCAPED_IDS)
 def test_string_escapes_survive_parse_and_dump(s, raw, value):
     """A task id written with escapes comes back, in the decision line, as the same string."""
     s.create_node(node_doc(0))
@@ -113,6 +113,16 @@ def test_string_escapes_survive_parse_and_dump(s, raw, value):
     out = s.tick()
     assert [d["ID"] for d in out] == [value]
     assert s.node_info("n000")["Tasks"] == [value]
+
+
+@pytest.mark.parametrize("raw", [b"\xac", b"a\xc3", b"\xc0\xaf", b"\xe0\x80\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xf8\x88\x80\x80\x80", b"\x80x"])
+def test_strings_that_are_not_utf8_are_refused(s, raw):
+    """What goes in comes out again in the decisions: a string that is not UTF-8 (a stray byte, a cut sequence, an overlong form, a
+    surrogate, something beyond U+10FFFF) is refused at the boundary instead of making the output something that is not JSON."""
+    text = b'{"ID":"' + raw + b'","ServiceID":"svc","DesiredState":512,"Status":{"State":64},"Spec":{}}'
+    flag = C.c_int(0)
+    assert s.L.swp_sched_create_task(s.h, text, len(text), C.byref(flag)) == abi.SWP_EINVAL
+    assert b"UTF-8" in s.L.swp_sched_last_error(s.h)
 
 
 def test_escaped_quotes_and_backslashes_are_written_back_escaped(s):
