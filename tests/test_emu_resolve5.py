@@ -53,7 +53,7 @@ def test_round_resolver_source_matches_sequential_model(emu_bin, case):
     assert "-> OK" in r.stderr
 
 
-@pytest.mark.parametrize("sched", [41, 42])
+@pytest.mark.parametrize("sched", [41])
 @pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5], CASES[8], CASES[-1]], ids=lambda c: "s%d_n%d_t%d_o%d_f%d" % (c[0], c[1], c[2], c[5], c[6]))
 def test_under_random_wave_schedules(emu_bin, case, sched):
     """... under wave orders the first-in-first-out run never produces (EMU_SCHED_SEED, tests/emu/wv_emu.hpp)."""

@@ -100,12 +100,12 @@ def test_compact_index(emu_bin, case, lvl):
     assert "-> OK" in r.stderr
 
 
-SCHED = [(1, 300, 1000, 20, 64, 0, 0, ""), (4, 5000, 2000, 300, 256, 0, 2, "s"), (12, 5924, 1856, 377, 128, 0, 0, "s"), (8, 885, 1500, 125, 64, 2, 3, ""),
-         (4, 5000, 1200, 300, 128, 0, 2, "st"), (52, 6000, 3000, 12, 256, 1, 2, ""), (21, 4500, 1500, 200, 1024, 0, 1, "")]
+# (case, schedule): tools/emu_fuzz.py --sched draws as many more as it is given time for
+SCHED = [((1, 300, 600, 20, 64, 0, 0, ""), 11), ((12, 5924, 1856, 377, 128, 0, 0, "s"), 12), ((8, 885, 1500, 125, 64, 2, 3, ""), 11), ((4, 5000, 1200, 300, 128, 0, 2, "st"), 12),
+         ((52, 6000, 3000, 12, 256, 1, 2, ""), 11), ((21, 4500, 1500, 200, 1024, 0, 1, ""), 12), ((13, 901, 1200, 8, 64, 1, 1, "n"), 13)]
 
 
-@pytest.mark.parametrize("sched", [11, 12])
-@pytest.mark.parametrize("case", SCHED, ids=lambda c: "seed%d-N%d-B%d-f%d%s" % (c[0], c[1], c[4], c[6], c[7]))
+@pytest.mark.parametrize("case,sched", SCHED, ids=lambda c: "seed%d-N%d-B%d-f%d%s" % (c[0], c[1], c[4], c[6], c[7]) if isinstance(c, tuple) else "sched%d" % c)
 def test_under_random_wave_schedules(emu_bin, case, sched):
     """The fibers above run first in, first out: ONE timing. EMU_SCHED_SEED draws which runnable wave goes next and how long it keeps going
     (tests/emu/wv_emu.hpp) — the staging window, the list hand-over to the matcher and the apply waves behind it must decide the same

@@ -63,12 +63,11 @@ def test_sharded_rounds_source_matches_sequential_model(emu_bin, case):
         assert r.stderr.count("-> OK") == 2, r.stderr[-2000:]
 
 
-SCHED = [(1, 300, 400, 20, 64, 0, 0, 3, ""), (4, 1500, 500, 80, 128, 0, 2, 8, ""), (12, 5924, 1856, 377, 128, 0, 0, 3, ""), (10, 1200, 900, 90, 128, 0, 3, 8, "t"),
-         (5, 2000, 1500, 150, 128, 0, 1, 8, "c"), (13, 401, 700, 8, 128, 1, 1, 2, "ct")]
+SCHED = [((1, 300, 400, 20, 64, 0, 0, 3, ""), 21), ((4, 1500, 500, 80, 128, 0, 2, 8, ""), 22), ((12, 5924, 1856, 377, 128, 0, 0, 3, ""), 21), ((10, 1200, 500, 90, 128, 0, 3, 8, "t"), 22),
+         ((7, 500, 900, 40, 32, 0, 3, 4, "c"), 21), ((13, 401, 700, 8, 128, 1, 1, 2, "ct"), 22)]
 
 
-@pytest.mark.parametrize("sched", [21, 22])
-@pytest.mark.parametrize("case", SCHED, ids=lambda c: "seed%d-N%d-B%d-f%d-G%d%s" % (c[0], c[1], c[4], c[6], c[7], c[8]))
+@pytest.mark.parametrize("case,sched", SCHED, ids=lambda c: "seed%d-N%d-B%d-f%d-G%d%s" % (c[0], c[1], c[4], c[6], c[7], c[8]) if isinstance(c, tuple) else "sched%d" % c)
 def test_under_random_wave_schedules(emu_bin, case, sched):
     """The fold window (four folds in flight), the matcher and the apply waves under wave orders the default first-in-first-out run never
     produces (EMU_SCHED_SEED, tests/emu/wv_emu.hpp)."""
