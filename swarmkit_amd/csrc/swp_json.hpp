@@ -92,7 +92,11 @@ inline int64_t as_i64(const Value* v, int64_t def = 0) {
     if (v == nullptr) return def;
     switch (v->kind) {
         case Value::Int: return v->i;
-        case Value::Real: return (int64_t)v->d;
+        case Value::Real:   // (a real beyond int64 saturates: the conversion itself would be undefined)
+            if (!(v->d == v->d)) return def;
+            if (v->d >= 9223372036854775807.0) return INT64_MAX;
+            if (v->d <= -9223372036854775808.0) return INT64_MIN;
+            return (int64_t)v->d;
         case Value::Bool: return v->b ? 1 : 0;
         default: return def;
     }

@@ -20,7 +20,7 @@ def build():
     if os.environ.get("SWP_FAKE_O3") == "1" and not san:
         return _build(OUT.replace(".so", "_O3.so"), ["-O3"])
     out = OUT.replace(".so", "_san.so") if san else OUT
-    return _build(out, ["-O0", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if san else [])   # (-O0: a fifth of the compile time)
+    return _build(out, ["-O0", "-fsanitize=address,undefined,float-cast-overflow", "-fno-omit-frame-pointer"] if san else [])   # (-O0: a fifth of the compile time)
 
 
 def _build(OUT, extra):

@@ -33,6 +33,7 @@ def task_text(cpu="1", mem="2", extra=""):
     ("1234567890123456789", 1234567890123456789),                    # 19 digits: strtoll
     ("9223372036854775807", 2**63 - 1), ("-9223372036854775808", -2**63),
     ("1e3", 1000), ("1.5", 1), ("2.5E2", 250), ("-0", 0),
+    ("1e308", 2**63 - 1), ("-1e308", -2**63), ("9.3e18", 2**63 - 1),   # a real beyond int64 saturates (the conversion itself would be undefined)
 ])
 def test_integers_and_reals_reach_the_descriptor(s, text, want):
     rc, d = raw_desc(s, task_text(cpu=text))
