@@ -18,7 +18,8 @@
  * again in the decisions), nesting beyond 64 levels — is SWP_EINVAL with the reason in swp_sched_last_error; a member of the wrong type
  * reads as absent (a nil pointer in the Go structs); a repeated member keeps its last value; half a surrogate pair written as an escape
  * decodes to U+FFFD as in Go's encoding/json; an integer beyond int64 keeps its uint64 bit pattern (MaxReplicas), a real beyond int64
- * saturates; int64 arithmetic on reservations wraps as Go's does. tools/host_fuzz.py throws such documents at every entry point
+ * saturates; int64 arithmetic on reservations wraps as Go's does. Read although RFC 8259 would not: a control character inside a string
+ * (written back escaped) and leading zeros of a number. tools/host_fuzz.py throws such documents at every entry point
  * under the sanitizers (tests/test_sanitized_host_cpu.py).
  * Paths below are under /root/reference/manager/scheduler/ unless stated otherwise.
  */
