@@ -75,9 +75,12 @@ def draw(rng, which):
     raise ValueError(which)
 
 
-def run(binary, args, sched=0):
+def run(binary, args, sched=0, lvl=None):
     cmd = [binary] + [str(a) for a in args]
     env = dict(os.environ)
+    if lvl is not None:   # the start of the problem's task counts (tests/emu/emu_model.hpp): 4 hundreds of levels, 5 a tenth of the nodes emptied
+        env["EMU_LVL_MODE"] = str(lvl)
+        cmd = ["env", "EMU_LVL_MODE=%d" % lvl] + cmd
     if sched:   # a random order among the runnable waves (tests/emu/wv_emu.hpp) instead of first in, first out
         env["EMU_SCHED_SEED"] = str(sched)
         cmd = ["env", "EMU_SCHED_SEED=%d" % sched] + cmd
@@ -111,7 +114,9 @@ def main():
         while time.time() < deadline or pending:
             while time.time() < deadline and len(pending) < a.jobs:
                 which = rng.choice(list(bins))
-                pending.add(ex.submit(run, bins[which], draw(rng, which), rng.randrange(1, 1 << 30) if a.sched else 0))
+                # (the round resolver answers "hundreds of levels" with ERR_LEVEL_RANGE and the engine goes on with the block resolver: not drawn for it)
+                lvl = rng.choice([4, 5]) if (which in ("resolve6", "resolve7", "scan") and rng.random() < 0.2) else (5 if which == "resolve5" and rng.random() < 0.1 else None)
+                pending.add(ex.submit(run, bins[which], draw(rng, which), rng.randrange(1, 1 << 30) if a.sched else 0, lvl))
             fin, pending = cf.wait(pending, return_when=cf.FIRST_COMPLETED)
             for f in fin:
                 ok, cmd, tail, dt = f.result()
