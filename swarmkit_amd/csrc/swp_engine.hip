@@ -14,6 +14,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <map>
+#include <tuple>
 #include <queue>
 #include <mutex>
 #include <numeric>
@@ -2734,6 +2735,8 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
         max_depth = std::max<uint32_t>(max_depth, (uint32_t)levels.size());
     }
     std::vector<GroupRec2> recs(n_groups);
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> scls_ids;   // static classes: the distinct (plugin, constraint, platform) class triples
+    std::vector<uint32_t> scls_def;
     uint32_t off = 0, att_rows = 0;   // att_rows: tasks of the groups with cluster mounts
     size_t arena_bytes = 64;
     for (uint32_t g = 0; g < n_groups; ++g) {
@@ -2743,6 +2746,15 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
         q.cpu = r.cpu; q.mem = r.mem; q.flags = r.flags; q.k = sizes[g]; q.svc = r.svc; q.out_off = off; q.pset = r.pset;
         q.cls_con = r.cls_con; q.cls_plat = r.cls_plat; q.cls_plug = r.cls_plug; q.maxrep = r.maxrep;
         q.tree = tree_local[groups[g].spread_set];
+        {
+            auto key = std::make_tuple(q.cls_plug, q.cls_con, q.cls_plat);
+            auto it = scls_ids.find(key);
+            if (it == scls_ids.end()) {
+                it = scls_ids.emplace(key, (uint32_t)scls_ids.size()).first;
+                scls_def.push_back(q.cls_plug); scls_def.push_back(q.cls_con); scls_def.push_back(q.cls_plat);
+            }
+            q.scls = it->second;
+        }
         q.dep_prev = g > 0 && b.rt[g - 1].svc == r.svc;
         q.mset = groups[g].flags >> SWP_TASK_MOUNTS_SHIFT;
         if (q.mset) {   // its VolumesFilter depends on the volumes every earlier group took: nothing of it is prepared ahead
@@ -2764,7 +2776,7 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
         if (ab > G2_ARENA_LDS) arena_bytes = std::max(arena_bytes, ab);   // this group's working set lives in global memory
         off += sizes[g];
     }
-    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_tnn, d_leaf, d_ff, d_key, d_ckey, d_min, d_dense, d_tsum, d_xroot, d_xadm, d_arena, d_lcnt, d_out, d_hist;
+    DevBuf d_recs, d_tree_off, d_par, d_first, d_next, d_nch, d_tnn, d_leaf, d_ff, d_key, d_dense, d_tsum, d_xroot, d_xadm, d_arena, d_lcnt, d_out, d_hist;
     if ((rc = upload(e, d_recs, recs))) return rc;
     if ((rc = upload(e, d_tree_off, tree_off))) return rc;
     if ((rc = upload(e, d_par, tn_parent))) return rc;
@@ -2776,8 +2788,16 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
     if ((rc = upload(e, d_lcnt, b.list_cnt0))) return rc;
     HIPCHECK(e, d_ff.reserve((size_t)2 * N));
     HIPCHECK(e, d_key.reserve((size_t)2 * N * 8));
-    HIPCHECK(e, d_ckey.reserve((size_t)2 * N * 8));
-    HIPCHECK(e, d_min.reserve((size_t)2 * Wn * 8));
+    DevBuf d_ccand, d_cpos, d_cmin, d_scdef, d_slist, d_scnt;   // static class lists and a group's candidate list (swp_groups.hpp)
+    const uint32_t n_scls = (uint32_t)scls_ids.size();
+    if ((uint64_t)n_scls * N * 4 > (64ull << 30))
+        return e->fail(SWP_ERANGE, "%u distinct (plugin, constraint, platform) classes over %u nodes: the static class lists would take more than 64 GiB", n_scls, N);
+    HIPCHECK(e, d_ccand.reserve((size_t)2 * N * sizeof(G2Cand)));
+    HIPCHECK(e, d_cpos.reserve((size_t)2 * N * 4));
+    HIPCHECK(e, d_cmin.reserve((size_t)2 * Wn * 8));
+    if ((rc = upload(e, d_scdef, scls_def))) return rc;
+    HIPCHECK(e, d_slist.reserve((size_t)n_scls * N * 4));
+    HIPCHECK(e, d_scnt.reserve((size_t)n_scls * 4));
     HIPCHECK(e, d_dense.reserve((size_t)6 * N * 4));
     HIPCHECK(e, d_tsum.reserve((size_t)2 * max_ntn * 8));
     HIPCHECK(e, d_xroot.reserve((size_t)max_ntn * 8));
@@ -2814,7 +2834,9 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
     ga.list_off = b.d_list_off.as<uint32_t>(); ga.list_cnt = d_lcnt.as<uint32_t>();
     ga.tree_off = d_tree_off.as<uint32_t>(); ga.tn_parent = d_par.as<uint32_t>(); ga.tn_first = d_first.as<uint32_t>();
     ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.tn_nodes = d_tnn.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
-    ga.ffbuf = d_ff.as<unsigned char>(); ga.keybuf = d_key.as<u64>(); ga.minbuf = d_min.as<u64>(); ga.ckeybuf = d_ckey.as<u64>();
+    ga.ffbuf = d_ff.as<unsigned char>(); ga.keybuf = d_key.as<u64>();
+    ga.ccand = d_ccand.as<G2Cand>(); ga.cpos = d_cpos.as<uint32_t>(); ga.cmin = d_cmin.as<u64>();
+    ga.n_scls = n_scls; ga.scls_def = d_scdef.as<uint32_t>(); ga.slist = d_slist.as<uint32_t>(); ga.scnt = d_scnt.as<uint32_t>();
     ga.svc_dense = d_dense.as<uint32_t>(); ga.fail_dense = d_dense.as<uint32_t>() + (size_t)2 * N; ga.lpos_dense = d_dense.as<uint32_t>() + (size_t)4 * N;
     ga.tsumbuf = d_tsum.as<long long>(); ga.xroot = d_xroot.as<u64>(); ga.xadm = d_xadm.as<int32_t>(); ga.arena = d_arena.as<unsigned char>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();
@@ -2838,6 +2860,8 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
         (void)hipMemcpy(&c2, b.d_ctl.p, sizeof c2, hipMemcpyDeviceToHost);
         fprintf(stderr, "[swp] k_groups2 %.3f ms for %u groups | shader cycles: wait-prep %llu reset %llu admit %llu load %llu walk %llu explain %llu writeback %llu patch %llu | in walk: ordered %llu fill %llu | admission: words %llu candidates %llu heap ops %llu replay cycles %llu parallel pushes %llu load-wait cycles %llu\n", ms, n_groups,
                 c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5], c2.cyc[6], c2.cyc[7], c2.m_cyc[0], c2.m_cyc[1], c2.l_cyc[0], c2.l_cyc[1], c2.l_cyc[2], c2.l_cyc[3], c2.l_cyc[4], c2.l_cyc[5]);
+        fprintf(stderr, "[swp] k_groups2 admission, cycles by part: records %llu, whole chunks while filling %llu, flat counting %llu, flushes %llu, staging %llu, per-chunk pass %llu, replay + pipelined %llu, minima scan %llu\n",
+                c2.wave_cyc[0], c2.wave_cyc[1], c2.wave_cyc[2], c2.wave_cyc[3], c2.wave_cyc[4], c2.wave_cyc[5], c2.wave_cyc[6], c2.wave_cyc[7]);
         (void)hipEventDestroy(gev0); (void)hipEventDestroy(gev1);
     }
     Ctl ctl{};

@@ -9,7 +9,7 @@
 
 namespace swpdev {
 
-// one workgroup for the whole tick: the machine wave + 15 helper waves (swp_groups.hpp)
+// k_g2_static: a wave per static class; then one workgroup for the whole tick: the machine wave + 15 helper waves (swp_groups.hpp)
 hipError_t launch_groups2(const Groups2Args& a, hipStream_t s, int dev) {
     hipError_t r = ensure_big_lds(reinterpret_cast<const void*>(&k_groups2), dev);
     if (r != hipSuccess) return r;
@@ -18,6 +18,9 @@ hipError_t launch_groups2(const Groups2Args& a, hipStream_t s, int dev) {
         const unsigned v = (unsigned)atoi(t);
         if (v >= 128 && v <= G2_THREADS && v % 64 == 0) threads = v;
     }
+    // the static class lists first (one wave per class, all over the chip), then the tick
+    hipLaunchKernelGGL(k_g2_static, dim3(a.n_scls), dim3(64), 0, s, a);
+    if ((r = hipGetLastError()) != hipSuccess) return r;
     hipLaunchKernelGGL(k_groups2, dim3(1), dim3(threads), g2_lds_bytes(), s, a);
     return hipGetLastError();
 }

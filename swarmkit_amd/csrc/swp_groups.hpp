@@ -49,7 +49,16 @@ namespace swpdev {
 
 enum { G2_OP_SCATTER = 1, G2_OP_EVAL = 2, G2_OP_EXPLAIN = 3, G2_OP_UNSCATTER = 4, G2_OP_QUIT = 5 };
 
-struct GroupRec2 {   // one per group, 144 B
+// One entry of a group's candidate list (Groups2Args.ccand): a node of the group's static class list with its nodeLess key and spread
+// leaf — all the admission scan reads (one 16-byte load per candidate, 64 candidates per "chunk" instead of the handful a node word holds)
+struct alignas(16) G2Cand {
+    u64 key;     // KEY_NONE: the node dropped out since the list was built (a hole)
+    u32 node;
+    u32 leaf;
+};
+static_assert(sizeof(G2Cand) == 16, "G2Cand layout");
+
+struct GroupRec2 {   // one per group, 152 B
     i64 cpu, mem;
     u64 maxrep;
     u32 flags;          // RT_*
@@ -66,8 +75,10 @@ struct GroupRec2 {   // one per group, 144 B
     int32_t gval[G2_MAXGEN];
     u32 mset;           // mount set of the group's tasks (swp_volumes.hpp), 0: no cluster mounts
     u32 att_off;        // first row of the group's tasks in Groups2Args.att
+    u32 scls;           // static class of the group: its (cls_plug, cls_con, cls_plat) among the call's distinct ones (Groups2Args.slist)
+    u32 pad1;
 };
-static_assert(sizeof(GroupRec2) == 144, "GroupRec2 layout");
+static_assert(sizeof(GroupRec2) == 152, "GroupRec2 layout");
 
 struct Groups2Args {
     u32 n_nodes, n_words, n_groups, gstride;
@@ -103,8 +114,18 @@ struct Groups2Args {
     // scratch, all double-buffered by group parity
     unsigned char* ffbuf;    // [2][n_nodes] first failing filter of Pipeline.Process, G2_FF_PASS, G2_FF_ABSENT
     u64* keybuf;             // [2][n_nodes] nodeLess key at tree() time
-    u64* ckeybuf;            // [2][n_nodes] the key again for a node that passes every filter, KEY_NONE otherwise: all the admission scan reads
-    u64* minbuf;             // [2][n_words] the lowest key among the word's nodes that pass every filter (KEY_NONE: none passes)
+    // Static class lists (round 6). ReadyFilter, PluginFilter, ConstraintFilter and PlatformFilter do not change while a tick runs, and
+    // groups share them (cfg3: 63 distinct (plugin, constraint, platform) classes among 1 000 groups): k_g2_static lists, once per call
+    // and per class, the nodes that pass all four IN NODE ORDER — a chip-wide pass, one wave per class. A group is then evaluated over
+    // its class's list only (a tenth of the nodes on cfg3), and that evaluation IS the group's compact candidate list: entry i =
+    // {nodeLess key, node slist[i], spread leaf}, KEY_NONE for a node that fails Resource / HostPort / MaxReplicas / Volumes (a hole).
+    u32 n_scls, pad2;
+    const u32* scls_def;     // [n_scls][3] cls_plug, cls_con, cls_plat
+    u32* slist;              // [n_scls][n_nodes] the class's nodes in node order
+    u32* scnt;               // [n_scls] how many
+    G2Cand* ccand;           // [2][n_nodes] the group's candidates: what the admission scan reads, 64 to a chunk
+    u32* cpos;               // [2][n_nodes] a listed node's place (the patch after a write-back finds its entry there)
+    u64* cmin;               // [2][n_words] per chunk: the lowest key among its candidates (KEY_NONE: none)
     u32* svc_dense;          // [2][n_nodes] the group's service: ActiveTasksCountByService per node (zero outside the list)
     u32* fail_dense;         // [2][n_nodes] recent failures (only values >= maxFailures are listed)
     u32* lpos_dense;         // [2][n_nodes] list entry of the node + 1, 0: not listed
@@ -141,7 +162,7 @@ inline __host__ __device__ size_t g2_arena_bytes(u32 S, u32 ntn, u32 ngen, u32 d
 #define G2_LDS_FIXED 9216      // (the last KB: the flat mode's scratch, g2_flat_*)
 #define G2_FLAT_OFF 8192
 #define G2_FLAT_MAXK 128u       // heap positions the flat mode's bit mask covers
-#define G2_VISW 8              // node words whose candidate keys are staged through LDS together
+#define G2_VISW 4              // chunks of 64 candidates whose records are staged through LDS together
 inline __host__ __device__ size_t g2_lds_bytes() { return (size_t)G2_LDS_FIXED + G2_ARENA_LDS; }
 
 #ifdef SWP_G2_KERNELS
@@ -326,38 +347,82 @@ WV_DEV bool g2_res_ok(const Groups2Args& a, const GroupRec2& G, const GroupRec2*
     return true;
 }
 
-// Pipeline.Process on node n for group G (pipeline.go:56-68: the FIRST failing filter in checklist order) and the node's key
-// (returns the key of a node that passes, KEY_NONE otherwise)
-WV_DEV u64 g2_eval_node(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n) {
+// Pipeline.Process on node n for group G (pipeline.go:56-68: the FIRST failing filter in checklist order: Ready, Resource, Plugin,
+// Constraint, Platform, HostPort, MaxReplicas, Volumes — scheduler.go:60-66) and the node's nodeLess key. Returns the first failing
+// filter (G2_FF_PASS, G2_FF_ABSENT); `listed`: the node is on the group's static class list (present and passing Ready, Plugin,
+// Constraint, Platform). LISTED: the caller took n FROM that list, so those five are not looked at again.
+template <bool LISTED>
+WV_DEV u32 g2_process(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n, u64& key, bool& listed) {
     const u32 N = a.n_nodes, Wn = a.n_words, w = n >> 6;
     const u64 bit = 1ull << (n & 63);
-    u32 ff = G2_FF_PASS;
-    u64 key = 0;
-    if (!(a.valid[w] & bit)) ff = G2_FF_ABSENT;
-    else {
-        const u32 sv = a.svc_dense[(size_t)b * N + n], fl = a.fail_dense[(size_t)b * N + n];
-        if (!(a.ready[w] & bit)) ff = 0;
-        else if ((G.flags & RT_RES) && !g2_res_ok(a, G, Gm, n)) ff = 1;
-        else if (G.cls_plug && !(a.plug[(size_t)G.cls_plug * Wn + w] & bit)) ff = 2;
-        else if (G.cls_con && !(a.con[(size_t)G.cls_con * Wn + w] & bit)) ff = 3;
-        else if (G.cls_plat && !(a.plat[(size_t)G.cls_plat * Wn + w] & bit)) ff = 4;
-        else {
-            bool busy = false;
-            if (G.flags & RT_PORTS)
-                for (u32 q = a.pset_off[G.pset]; q < a.pset_off[G.pset + 1]; ++q)
-                    if (a.portmap[(size_t)a.pset_ids[q] * Wn + w] & bit) busy = true;
-            if (busy) ff = 5;
-            else if ((G.flags & RT_MAXREP) && !((u64)sv < G.maxrep)) ff = 6;
-            else if (G.mset && !((vol_filter_word(a.vol, G.mset, w) >> (n & 63u)) & 1ull)) ff = 7;   // VolumesFilter, the pipeline's last entry
-        }
-        if (!g2_key_ok(fl, sv)) a.ctl->error = ERR_GROUP_RANGE;
-        key = g2_key(fl, sv, a.total[n]);
+    key = 0;
+    listed = LISTED;
+    if (!LISTED && !(a.valid[w] & bit)) return G2_FF_ABSENT;
+    const u32 sv = a.svc_dense[(size_t)b * N + n], fl = a.fail_dense[(size_t)b * N + n];
+    bool ready = true;
+    u32 sff = G2_FF_PASS;   // the first failing one of Plugin / Constraint / Platform
+    if (!LISTED) {
+        ready = (a.ready[w] & bit) != 0;
+        if (G.cls_plug && !(a.plug[(size_t)G.cls_plug * Wn + w] & bit)) sff = 2;
+        else if (G.cls_con && !(a.con[(size_t)G.cls_con * Wn + w] & bit)) sff = 3;
+        else if (G.cls_plat && !(a.plat[(size_t)G.cls_plat * Wn + w] & bit)) sff = 4;
+        listed = ready && sff == G2_FF_PASS;
     }
+    u32 ff = G2_FF_PASS;
+    if (!ready) ff = 0;
+    else if ((G.flags & RT_RES) && !g2_res_ok(a, G, Gm, n)) ff = 1;
+    else if (sff != G2_FF_PASS) ff = sff;
+    else {
+        bool busy = false;
+        if (G.flags & RT_PORTS)
+            for (u32 q = a.pset_off[G.pset]; q < a.pset_off[G.pset + 1]; ++q)
+                if (a.portmap[(size_t)a.pset_ids[q] * Wn + w] & bit) busy = true;
+        if (busy) ff = 5;
+        else if ((G.flags & RT_MAXREP) && !((u64)sv < G.maxrep)) ff = 6;
+        else if (G.mset && !((vol_filter_word(a.vol, G.mset, w) >> (n & 63u)) & 1ull)) ff = 7;   // VolumesFilter, the pipeline's last entry
+    }
+    if (!g2_key_ok(fl, sv)) a.ctl->error = ERR_GROUP_RANGE;
+    key = g2_key(fl, sv, a.total[n]);
+    return ff;
+}
+// A node that got a task since the next group was evaluated is evaluated again: its Explain record, and — if it is on that group's
+// static class list — its candidate entry (keys only grow, nodes only drop out: the chunk minima stay lower bounds).
+WV_DEV void g2_patch_node(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n) {
+    const u32 N = a.n_nodes;
+    const u32 cp = a.cpos[(size_t)b * N + n];   // (meaningless unless listed; requested with the rest)
+    u64 key;
+    bool listed;
+    const u32 ff = g2_process<false>(a, G, Gm, b, n, key, listed);
     a.ffbuf[(size_t)b * N + n] = (unsigned char)ff;
     a.keybuf[(size_t)b * N + n] = key;
-    const u64 ck = ff == G2_FF_PASS ? key : KEY_NONE;
-    a.ckeybuf[(size_t)b * N + n] = ck;
-    return ck;
+    if (listed) a.ccand[(size_t)b * N + cp].key = ff == G2_FF_PASS ? key : KEY_NONE;
+}
+// The static class lists (Groups2Args.slist): ONE WAVE per class (k_g2_static: a grid of n_scls workgroups of 64), lanes over the node words.
+WV_DEV void g2_static_list(const Groups2Args& a, u32 c) {
+    const u32 lane = wv::lane(), N = a.n_nodes, Wn = a.n_words;
+    const u32 cpl = a.scls_def[3u * c], cco = a.scls_def[3u * c + 1u], cpa = a.scls_def[3u * c + 2u];
+    u32* out = a.slist + (size_t)c * N;
+    u32 run = 0;
+    for (u32 w0 = 0; w0 < Wn; w0 += 64u) {
+        const u32 w = w0 + lane;
+        u64 m = 0;
+        if (w < Wn) {
+            m = a.valid[w] & a.ready[w];
+            if (cpl) m &= a.plug[(size_t)cpl * Wn + w];
+            if (cco) m &= a.con[(size_t)cco * Wn + w];
+            if (cpa) m &= a.plat[(size_t)cpa * Wn + w];
+            if (w == Wn - 1u && (N & 63u)) m &= (1ull << (N & 63u)) - 1ull;
+        }
+        const u32 cnt = (u32)wv::popc64(m);
+        const u32 incl = wv::scan_incl_u32(cnt);
+        u32 pos = run + incl - cnt;
+        while (m) {
+            out[pos++] = w * 64u + (u32)wv::ffs64(m);
+            m &= m - 1ull;
+        }
+        run += wv::readlane(incl, 63);
+    }
+    if (lane == 0) a.scnt[c] = run;
 }
 WV_DEV u64 g2_wave_min64(u64 v) {
     const u32 hi = (u32)(v >> 32), lo = (u32)v;
@@ -434,12 +499,30 @@ WV_DEV void g2_helper(const Groups2Args& a, G2Mail* mb, u32 hid, u32 nh) {
                     for (u32 t = leaf_of[n]; t != G2_NONE; t = a.tn_parent[tbase + t]) wv::g_add64(&a.tsumbuf[(size_t)b * a.max_ntn + t], (i64)sv);
             }
         } else if (op == G2_OP_EVAL) {
-            // + the word's lowest passing key: what lets the machine skip 64 nodes at a time. (Keys only grow and nodes only drop out
-            // while the tick runs, so a minimum taken early stays a lower bound: the patch after a write-back need not touch it.)
-            for (u32 w = hid; w < Wn; w += nh) {
-                const u32 n = w * 64u + lane;
-                const u64 mk = g2_wave_min64(n < N ? g2_eval_node(a, G, Gm, b, n) : KEY_NONE);
-                if (lane == 0) a.minbuf[(size_t)b * Wn + w] = mk;
+            // The group's candidates: its static class's nodes, a chunk of 64 per wave and turn, + the chunk's lowest key: what lets the
+            // machine skip 64 candidates at a time. (Keys only grow and nodes only drop out while the tick runs, so a minimum taken
+            // early stays a lower bound: the patch after a write-back need not touch it.)
+            const u32 M = a.scnt[G.scls];
+            const u32* sl = a.slist + (size_t)G.scls * N;
+            const u32* leaf_of = a.leaf_of_node + (size_t)G.tree * N;
+            for (u32 c = hid; c * 64u < M; c += nh) {
+                const u32 i = c * 64u + lane;
+                u64 ck = KEY_NONE;
+                if (i < M) {
+                    const u32 n = sl[i];
+                    u64 key;
+                    bool listed;
+                    const u32 ff = g2_process<true>(a, G, Gm, b, n, key, listed);
+                    a.ffbuf[(size_t)b * N + n] = (unsigned char)ff;
+                    a.keybuf[(size_t)b * N + n] = key;
+                    if (ff == G2_FF_PASS) ck = key;
+                    G2Cand ce;
+                    ce.key = ck; ce.node = n; ce.leaf = leaf_of[n];
+                    a.ccand[(size_t)b * N + i] = ce;
+                    a.cpos[(size_t)b * N + n] = i;
+                }
+                const u64 mk = g2_wave_min64(ck);
+                if (lane == 0) a.cmin[(size_t)b * Wn + c] = mk;
             }
         } else if (op == G2_OP_EXPLAIN) {
             // Every passing Process zeroes the counters (pipeline.go:64-66), so only the calls AFTER the last passing one count. Inside
@@ -449,12 +532,18 @@ WV_DEV void g2_helper(const Groups2Args& a, G2Mail* mb, u32 hid, u32 nh) {
             const u32* leaf_of = a.leaf_of_node + (size_t)G.tree * N;
             for (u32 w = hid; w < Wn; w += nh) {
                 const u32 n = w * 64u + lane;
+                // (a node on the group's static class list has its record from EVAL / the patch; any other node is evaluated here — its
+                // rows have not moved since tree(): a group only ever touches listed nodes, and this command is through before the NEXT
+                // group's write-back)
                 u32 f = 0xFFu;
                 if (n < N && n >= lastp) {
-                    const u32 ffn = a.ffbuf[(size_t)b * N + n];
+                    u64 key;
+                    bool listed;
+                    u32 ffn = g2_process<false>(a, G, Gm, b, n, key, listed);
+                    if (listed) { ffn = a.ffbuf[(size_t)b * N + n]; key = a.keybuf[(size_t)b * N + n]; }
                     if (ffn < 8u) {
                         const u32 lf = leaf_of[n];
-                        if (a.xadm[lf] < (int32_t)k || a.keybuf[(size_t)b * N + n] < a.xroot[lf]) f = ffn;
+                        if (a.xadm[lf] < (int32_t)k || key < a.xroot[lf]) f = ffn;
                     }
                 }
                 for (u32 q = 0; q < 8; ++q) {
@@ -562,7 +651,6 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                      u32& eval_next) {
     const u32 lane = wv::lane(), N = a.n_nodes, Wn = a.n_words, b = gi & 1u, k = G.k;
     const u32 tbase = a.tree_off[G.tree], ntn = a.tree_off[G.tree + 1] - tbase;
-    const u32* leaf_of = a.leaf_of_node + (size_t)G.tree * N;
     const bool single = ntn == 1;
     const GroupRec2* Gm = a.g + gi;
     const u32 NG = GEN ? G.n_gen : 0u;   // generic kinds the group reserves
@@ -626,13 +714,18 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         bool flat_tried = false;
         u32* f_cand = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + G2_FLAT_OFF);   // [G2_FLAT_MAXK] the remembered candidates' nodes
         u32* f_hs = f_cand + G2_FLAT_MAXK;                                                            // [G2_FLAT_MAXK] scratch of the flush
-        const u64* minb = a.minbuf + (size_t)b * Wn;
-        const u64* ckb = a.ckeybuf + (size_t)b * N;
+        // The scan runs over the group's candidate list (the helpers' EVAL command over the static class list): chunk c = entries
+        // [64 c, 64 c + 64) in node order, `minb[c]` a lower bound of the chunk's keys. A lane's candidate is a record {key, node, leaf};
+        // a hole (a listed node that fails a dynamic filter, or dropped out since) carries KEY_NONE.
+        const u32 M = a.scnt[G.scls], Cn = (M + 63u) / 64u;
+        const u64* minb = a.cmin + (size_t)b * Wn;
+        const G2Cand* ccb = a.ccand + (size_t)b * N;
         u64* vis = reinterpret_cast<u64*>(reinterpret_cast<unsigned char*>(mb) + 2048);                       // [G2_VISW][64] candidate keys
-        u32* visl = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + 2048 + G2_VISW * 64 * 8);   // [G2_VISW][64] leaves
-        for (u32 w0 = 0; w0 < Wn; w0 += 64) {
-            // 64 node words at a time: which of them can hold a candidate at all? (a superset: the root only drops from here on)
-            const u64 mk = w0 + lane < Wn ? minb[w0 + lane] : KEY_NONE;
+        u32* visn = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + 2048 + G2_VISW * 64 * 8);   // [G2_VISW][64] nodes
+        u32* visl = visn + G2_VISW * 64;                                                                       // [G2_VISW][64] leaves
+        for (u32 w0 = 0; w0 < Cn; w0 += 64) {
+            // 64 chunks at a time: which of them can hold a candidate at all? (a superset: the root only drops from here on)
+            const u64 mk = w0 + lane < Cn ? minb[w0 + lane] : KEY_NONE;
             bool visit = mk != KEY_NONE;
             if (visit && single) visit = len0 < k || mk < root0;
             u64 vm = wv::ballot(visit);
@@ -643,20 +736,23 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
               u32 vq0 = 0;   // words at the front of the batch that were taken whole
               {
                 u64 r[G2_VISW];
-                u32 rl[G2_VISW];
+                u32 rn[G2_VISW], rl[G2_VISW];
                 const u64 tw_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
                 WV_UNROLL
                 for (int q = 0; q < G2_VISW; ++q) {
                     r[q] = KEY_NONE;
+                    rn[q] = 0;
                     rl[q] = 0;
                     if (vm) {
                         const u32 c = (u32)wv::ffs64(vm);
                         vm &= vm - 1ull;
                         sm |= 1ull << c;
-                        const u32 n = (w0 + c) * 64u + lane;
-                        if (n < N) {
-                            r[q] = ckb[n];
-                            if (!single) rl[q] = leaf_of[n];
+                        const u32 ci_ = (w0 + c) * 64u + lane;
+                        if (ci_ < M) {
+                            const G2Cand ce = ccb[ci_];
+                            r[q] = ce.key;
+                            rn[q] = ce.node;
+                            rl[q] = ce.leaf;
                         }
                     }
                 }
@@ -674,30 +770,27 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                             if (uk == KEY_NONE && bq) uk = wv::readlane64(r[q], (u32)wv::ffs64(bq));
                         }
                     }
-                    bool odd = false;
-                    WV_UNROLL
-                    for (int q = 0; q < G2_VISW; ++q) odd = odd || (r[q] != KEY_NONE && r[q] != uk);
-                    if (uk != KEY_NONE && wv::ballot(odd) == 0) {
+                    if (uk != KEY_NONE) {
                         u64 t = sm;
                         WV_UNROLL
                         for (int q = 0; q < G2_VISW; ++q) {
                             if (t == 0) break;
-                            const u32 c = (u32)wv::ffs64(t);
+                            if (wv::ballot(r[q] != KEY_NONE && r[q] != uk)) break;   // a candidate with another key: the per-chunk pass takes over here
                             const bool have = r[q] != KEY_NONE;
                             const u64 bq = wv::ballot(have);
                             const u32 cnt = (u32)wv::popc64(bq);
-                            if (len0 + cnt > k) break;   // this word fills the heap beyond its size: the per-word pass takes over here
+                            if (len0 + cnt > k) break;   // this chunk fills the heap beyond its size: the per-chunk pass takes over here
                             t &= t - 1ull;
                             ++vq0;
                             if (have) {
                                 G2Ent he;
-                                he.key = uk; he.node = (w0 + c) * 64u + lane; he.tix = G2_NONE;
+                                he.key = uk; he.node = rn[q]; he.tix = G2_NONE;
                                 A.HE[len0 + wv::mbcnt(bq)] = he;
                             }
                             if (bq) {
                                 const u32 hib = (u32)(bq >> 32), lob = (u32)bq;
                                 const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);
-                                lastp = (w0 + c) * 64u + top + 1u;
+                                lastp = wv::readlane(rn[q], top) + 1u;
                                 if (len0 == 0) root0 = uk;
                                 len0 += cnt;
                                 if (a.dbg & 16u) { gt[11] += cnt; gt[14] += cnt; }
@@ -712,39 +805,37 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     }
                 }
                 if (!batch_done && single && F.on && F.lo != KEY_NONE) {
-                    bool third = false;
+                    u64 t = sm;
                     WV_UNROLL
-                    for (int q = 0; q < G2_VISW; ++q) third = third || (r[q] != KEY_NONE && r[q] != F.lo && r[q] < F.hi);
-                    if (wv::ballot(third) == 0) {
-                        u64 t = sm;
-                        WV_UNROLL
-                        for (int q = 0; q < G2_VISW; ++q) {
-                            if (t == 0) break;
-                            const u32 c = (u32)wv::ffs64(t);
-                            t &= t - 1ull;
-                            const bool isl = r[q] == F.lo;
-                            const u32 idx = F.n + wv::mbcnt(wv::ballot(isl));
-                            const bool acc = isl && idx < F.nh;   // (admitted while a heavy element is left: the root is heavy until then)
-                            if (acc) f_cand[idx] = (w0 + c) * 64u + lane;
-                            const u64 ab = wv::ballot(acc);
-                            if (ab) {
-                                const u32 hib = (u32)(ab >> 32), lob = (u32)ab;
-                                const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);
-                                lastp = (w0 + c) * 64u + top + 1u;   // the last Process that returned true inside tree()
-                                F.n += (u32)wv::popc64(ab);
-                                if (a.dbg & 16u) gt[12] += (u32)wv::popc64(ab);
-                            }
-                            if (a.dbg & 16u) gt[10] += 1;
-                            G2_STAT(5, 1);
+                    for (int q = 0; q < G2_VISW; ++q) {
+                        if (q < (int)vq0) continue;
+                        if (t == 0) break;
+                        if (wv::ballot(r[q] != KEY_NONE && r[q] != F.lo && r[q] < F.hi)) break;   // a third key: the per-chunk pass takes over here
+                        t &= t - 1ull;
+                        ++vq0;
+                        const bool isl = r[q] == F.lo;
+                        const u32 idx = F.n + wv::mbcnt(wv::ballot(isl));
+                        const bool acc = isl && idx < F.nh;   // (admitted while a heavy element is left: the root is heavy until then)
+                        if (acc) f_cand[idx] = rn[q];
+                        const u64 ab = wv::ballot(acc);
+                        if (ab) {
+                            const u32 hib = (u32)(ab >> 32), lob = (u32)ab;
+                            const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);
+                            lastp = wv::readlane(rn[q], top) + 1u;   // the last Process that returned true inside tree()
+                            F.n += (u32)wv::popc64(ab);
+                            if (a.dbg & 16u) gt[12] += (u32)wv::popc64(ab);
                         }
-                        wv::wave_sync();
-                        root0 = F.n < F.nh ? F.hi : F.lo;
-                        if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
-                            g2_flat_flush(A, F, k, f_cand, f_hs);
-                            root0 = A.HE[0].key;
-                        }
-                        batch_done = true;
+                        if (a.dbg & 16u) gt[10] += 1;
+                        G2_STAT(5, 1);
                     }
+                    wv::wave_sync();
+                    root0 = F.n < F.nh ? F.hi : F.lo;
+                    if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
+                        g2_flat_flush(A, F, k, f_cand, f_hs);
+                        root0 = A.HE[0].key;
+                    }
+                    sm = t;
+                    if (sm == 0) batch_done = true;
                 }
                 if (batch_done) {
                     if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;
@@ -753,6 +844,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 WV_UNROLL
                 for (int q = 0; q < G2_VISW; ++q) {
                     vis[q * 64 + (int)lane] = r[q];
+                    visn[q * 64 + (int)lane] = rn[q];
                     if (!single) visl[q * 64 + (int)lane] = rl[q];
                 }
                 if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;   // (mostly: waiting for the loads)
@@ -762,9 +854,9 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 const u32 c = (u32)wv::ffs64(sm);
                 sm &= sm - 1ull;
                 const u64 key = vis[vq * 64u + lane];   // (a lane reads back what it wrote itself)
+                const u32 n = visn[vq * 64u + lane];
                 u32 leaf = single ? 0u : visl[vq * 64u + lane];
                 ++vq;
-                const u32 n = (w0 + c) * 64u + lane;
                 const u64 mkc = single ? wv::readlane64(mk, c) : 0ull;
                 if (single && !(len0 < k || mkc < root0)) continue;   // the root dropped below the word's minimum since the batch was looked at
                 bool cand = key != KEY_NONE;
@@ -1379,7 +1471,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             eval_next = P.n;
         } else {
             if (!g2_wait_ge(&mb->done, eval_next * nh, mb)) return false;
-            for (u32 i = lane; i < nt; i += 64) g2_eval_node(a, Gn, a.g + gi + 1, bn, A.tnode[i]);
+            for (u32 i = lane; i < nt; i += 64) g2_patch_node(a, Gn, a.g + gi + 1, bn, A.tnode[i]);
             wv::wait_vm();
         }
     }
@@ -1389,11 +1481,16 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
 #undef G2_TICK
 }
 
+// the static class lists of a call: a grid of n_scls workgroups of ONE wave each, in front of k_groups2 on the same stream
+WV_KERNEL(64) void k_g2_static(Groups2Args a) {
+    if (wv::block() < a.n_scls) g2_static_list(a, wv::block());
+}
+
 WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
     G2Mail* mb = reinterpret_cast<G2Mail*>(l);
     G2Stage* sg = reinterpret_cast<G2Stage*>(l + 512);
-    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 12 <= G2_FLAT_OFF && G2_FLAT_OFF + 8 * G2_FLAT_MAXK <= G2_LDS_FIXED, "fixed LDS layout");
+    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 16 <= G2_FLAT_OFF && G2_FLAT_OFF + 8 * G2_FLAT_MAXK <= G2_LDS_FIXED, "fixed LDS layout");
     const u32 wave = wv::wave(), lane = wv::lane(), nh = wv::nthreads() / 64u - 1u;
     if (wv::tid() == 0) { mb->posted = 0; mb->done = 0; mb->quit = 0; }
     wv::barrier();

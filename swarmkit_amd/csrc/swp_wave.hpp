@@ -60,6 +60,18 @@ WV_DEV u32 min_u32(u32 v) {
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// inclusive prefix sum over the 64 lanes (lane l returns v[0] + ... + v[l]): four DPP row shifts inside the rows of 16, then the three
+// row totals by readlane (k_groups2's helpers: the offsets of the node words in a group's compact candidate list)
+WV_DEV u32 scan_incl_u32(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1 (a lane without a source adds `old` = 0)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    const u32 r0 = (u32)__builtin_amdgcn_readlane((int)v, 15), r1 = (u32)__builtin_amdgcn_readlane((int)v, 31), r2 = (u32)__builtin_amdgcn_readlane((int)v, 47);
+    const u32 l = threadIdx.x & 63u;
+    return v + (l >= 16u ? r0 : 0u) + (l >= 32u ? r1 : 0u) + (l >= 48u ? r2 : 0u);
+}
+
 // workgroup barrier that orders LDS only: outstanding global loads / fire-and-forget atomics stay in flight
 WV_DEV void barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // the wave's LDS operations issued so far are done before any lane goes on: what one lane wrote (or or-ed) is what another
@@ -98,6 +110,7 @@ WV_DEV void spin_pause() { __builtin_amdgcn_s_sleep(8); }   // ~0.2 µs off the 
 WV_DEV void g_add64(i64* p, i64 v) { __hip_atomic_fetch_add(reinterpret_cast<u64*>(p), (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void g_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void g_or64(u64* p, u64 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void g_min64(u64* p, u64 v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void g_xor64(u64* p, u64 v) { __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV_DEV void g_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV_DEV void g_max32(u32* p, u32 v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -19,6 +19,7 @@ static unsigned long long g2_stat[8];
 
 #include <map>
 #include <set>
+#include <tuple>
 
 using namespace swpdev;
 
@@ -445,8 +446,27 @@ int main(int argc, char** argv) {
         total_out += g.k;
     }
     std::vector<unsigned char> ffbuf((size_t)2 * N, 0xEE), arena(arena_bytes + 64, 0xCD);
-    std::vector<u64> keybuf((size_t)2 * N, 0xEEEEEEEEEEEEEEEEull), xroot(max_ntn, 0), minbuf((size_t)2 * Wn, 0x1111), ckeybuf((size_t)2 * N, 0x2222);
+    std::vector<u64> keybuf((size_t)2 * N, 0xEEEEEEEEEEEEEEEEull), xroot(max_ntn, 0);
     std::vector<u32> svc_dense((size_t)2 * N, 0), fail_dense((size_t)2 * N, 0), lpos_dense((size_t)2 * N, 0);
+    std::vector<G2Cand> ccand((size_t)2 * N, G2Cand{0x3333, 0xEEEEEEEEu, 0xEEEEEEEEu});
+    std::vector<u32> cpos((size_t)2 * N, 0xEEEEEEEEu);
+    std::vector<u64> cmin((size_t)2 * Wn, 0x6666);
+    // static classes: the distinct (plugin, constraint, platform) class triples of the groups, as the engine's host side names them
+    std::vector<u32> scls_def;
+    {
+        std::map<std::tuple<u32, u32, u32>, u32> ids;
+        for (GroupRec2& g : p.groups) {
+            auto key = std::make_tuple(g.cls_plug, g.cls_con, g.cls_plat);
+            auto it = ids.find(key);
+            if (it == ids.end()) {
+                it = ids.emplace(key, (u32)ids.size()).first;
+                scls_def.push_back(g.cls_plug); scls_def.push_back(g.cls_con); scls_def.push_back(g.cls_plat);
+            }
+            g.scls = it->second;
+        }
+    }
+    const u32 n_scls = (u32)scls_def.size() / 3;
+    std::vector<u32> slist((size_t)n_scls * N, 0xEEEEEEEEu), scnt(n_scls, 0x7777);
     std::vector<i64> tsumbuf((size_t)2 * max_ntn, 0x7777);
     std::vector<int32_t> xadm(max_ntn, 0), out(total_out, -7);
     std::vector<u32> hist(p.groups.size() * 8, 0);
@@ -462,10 +482,27 @@ int main(int argc, char** argv) {
     a.list_node = list_node.data(); a.list_svc = list_svc.data(); a.list_fail = list_fail.data(); a.list_off = list_off.data(); a.list_cnt = list_cnt.data();
     a.tree_off = tree_off.data(); a.tn_parent = tn_parent.data(); a.tn_first = tn_first.data(); a.tn_next = tn_next.data();
     a.tn_nchild = tn_nchild.data(); a.tn_nodes = tn_nodes.data(); a.leaf_of_node = leaf_of.data();
-    a.ffbuf = ffbuf.data(); a.keybuf = keybuf.data(); a.minbuf = minbuf.data(); a.ckeybuf = ckeybuf.data(); a.svc_dense = svc_dense.data(); a.fail_dense = fail_dense.data(); a.lpos_dense = lpos_dense.data();
+    a.ffbuf = ffbuf.data(); a.keybuf = keybuf.data(); a.ccand = ccand.data(); a.cpos = cpos.data(); a.cmin = cmin.data();
+    a.n_scls = n_scls; a.scls_def = scls_def.data(); a.slist = slist.data(); a.scnt = scnt.data(); a.svc_dense = svc_dense.data(); a.fail_dense = fail_dense.data(); a.lpos_dense = lpos_dense.data();
     a.tsumbuf = tsumbuf.data(); a.xroot = xroot.data(); a.xadm = xadm.data(); a.arena = arena.data();
     a.out_node = out.data(); a.hist = hist.data(); a.ctl = &ctl;
 
+    for (u32 c = 0; c < n_scls; ++c) {   // k_g2_static: one workgroup of one wave per class
+        emu::blockidx() = c;
+        emu::launch(64, 0, [&] { k_g2_static(a); });
+    }
+    emu::blockidx() = 0;
+    for (u32 c = 0; c < n_scls; ++c) {   // ... against the definition: the nodes that pass Ready / Plugin / Constraint / Platform, in node order
+        std::vector<u32> want;
+        for (u32 n = 0; n < N; ++n)
+            if (bit(p.valid, 0, Wn, n) && bit(p.ready, 0, Wn, n) && (!scls_def[3 * c] || bit(p.plug, scls_def[3 * c], Wn, n)) &&
+                (!scls_def[3 * c + 1] || bit(p.con, scls_def[3 * c + 1], Wn, n)) && (!scls_def[3 * c + 2] || bit(p.plat, scls_def[3 * c + 2], Wn, n)))
+                want.push_back(n);
+        if (scnt[c] != want.size() || !std::equal(want.begin(), want.end(), slist.begin() + (size_t)c * N)) {
+            fprintf(stderr, "static class list %u differs from its definition (%u entries, want %zu)\n", c, scnt[c], want.size());
+            return 1;
+        }
+    }
     emu::launch(threads, g2_lds_bytes(), [&] { k_groups2(a); });
 
     // ---- compare ----

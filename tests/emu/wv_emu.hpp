@@ -41,7 +41,7 @@ namespace emu {
 using swpdev::u32;
 using swpdev::u64;
 
-enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_READFIRST, OP_MIN, OP_SYNC, OP_BARRIER };
+enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_READFIRST, OP_MIN, OP_SYNC, OP_BARRIER, OP_SCAN };
 
 // Minimal x86-64 System V context switch (callee-saved registers + stack pointer). glibc's swapcontext makes a
 // sigprocmask system call per switch, and a run makes tens of millions of switches.
@@ -296,6 +296,11 @@ __attribute__((noinline)) inline u64 collective(int op, u64 v, u64 aux) {
         for (u32 l = 0; l < lanes; ++l) ws.result[l] = m;
         break;
     }
+    case OP_SCAN: {
+        u64 run = 0;
+        for (u32 l = 0; l < lanes; ++l) { run += ws.vals[l]; ws.result[l] = run; }
+        break;
+    }
     default:
         break;
     }
@@ -359,6 +364,7 @@ inline u64 readlane64(u64 v, u32 l) { return emu::collective(emu::OP_READLANE, v
 inline u32 writelane(u32 v, u32 s, u32 l) { return lane() == l ? s : v; }
 inline u32 mbcnt(u64 mask) { return (u32)__builtin_popcountll(mask & ((1ull << lane()) - 1ull)); }
 inline u32 min_u32(u32 v) { return (u32)emu::collective(emu::OP_MIN, v, 0); }
+inline u32 scan_incl_u32(u32 v) { return (u32)emu::collective(emu::OP_SCAN, v, 0); }
 inline void barrier() { emu::block_barrier(); }
 inline void wave_sync() { (void)emu::collective(emu::OP_SYNC, 0, 0); }
 inline void lockstep() { (void)emu::collective(emu::OP_SYNC, 1, 1); }
@@ -380,6 +386,7 @@ inline void lds_add_release32(u32* p, u32 v) { *reinterpret_cast<volatile u32*>(
 inline void g_add64(i64* p, i64 v) { *p += v; }
 inline void g_add32(u32* p, u32 v) { *p += v; }
 inline void g_or64(u64* p, u64 v) { *p |= v; }
+inline void g_min64(u64* p, u64 v) { if (v < *p) *p = v; }
 inline void g_xor64(u64* p, u64 v) { *p ^= v; }
 inline void g_andn64(u64* p, u64 v) { *p &= ~v; }
 inline void g_max32(u32* p, u32 v) { if (v > *p) *p = v; }

@@ -58,6 +58,10 @@ CASES = [
     (102, 200, 16, 100, 1, 2, 128),
     (103, 1000, 8, 128, 1, 3, 1024),
     (104, 3000, 12, 90, 1, 0, 256),
+    # compact candidate lists (round 6) beyond 64 chunks of 64 candidates: the machine's chunk pre-filter goes round more than once
+    (9, 20000, 6, 100, 1, 0, 256),
+    (10, 9000, 10, 128, 3, 1, 1024),
+    (12, 12000, 8, 70, 1, 2, 512),
 ]
 # ... the same shapes on a LEVEL cluster (every node starts with the same task count: option u): a tick's first heaps hold one key and
 # are appended whole batches at a time, the later ones two
@@ -104,7 +108,8 @@ def test_a_tick_on_a_level_cluster(emu_lds, emu_global, case, arena):
     r = subprocess.run([emu_lds if arena == "lds" else emu_global] + [str(x) for x in case] + ["v", "u"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "-> OK" in r.stderr, r.stderr[-2000:]
     m = re.search(r"(\d+) candidates by the post-order scatter.* (\d+) words appended whole", r.stderr)
-    assert m and int(m.group(1)) > 100 and int(m.group(2)) >= 1, r.stderr[-600:]
+    # (a chunk of the compact candidate list holds 64 candidates: a heap of fewer never takes one whole)
+    assert m and int(m.group(1)) > 100 and (int(m.group(2)) >= 1 or case[3] <= 64), r.stderr[-600:]
 
 
 @pytest.mark.parametrize("sched", [51])

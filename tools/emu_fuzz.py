@@ -67,8 +67,8 @@ def draw(rng, which):
         opts = "".join(o for o in "mg" if rng.random() < 0.4)
         return [seed, n, t, s, rng.choice([32, 64, 128, 256]), rng.randrange(3), rng.randrange(4)] + ([opts] if opts else [])
     if which in ("groups", "groups_small"):
-        n = pick_n(rng, rng.choice([600, 3000]))
-        groups = rng.randrange(1, 40)
+        n = pick_n(rng, rng.choice([600, 3000, 3000, 20000]))   # (20000: compact candidate lists beyond 64 chunks of 64)
+        groups = rng.randrange(1, 40 if n < 5000 else 12)
         kmax = rng.choice([1, 5, 30, 64, 100, 128, 129, 300, 900])
         trees = rng.choice([1, 1, 2, 3, 4, 6])
         return [seed, n, groups, kmax, trees, rng.randrange(4), rng.choice([128, 256, 512, 1024])] + (["u"] if rng.random() < 0.3 else [])
