@@ -647,7 +647,7 @@ WV_DEV void g2_post(G2Mail* mb, G2Post& P, u32 op, u32 gi) {
 // dep_prev); on return it always is.
 // GEN: the group reserves generic resources (the instance without them carries none of that code)
 template <bool L, bool GEN>
-WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned char* arena_base, const GroupRec2& G, u32 gi, u64* gt, G2Post& P, u32 nh,
+WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned char* arena_base, const GroupRec2& G, u32 gi, u64* gt, u64* gx, G2Post& P, u32 nh,
                      u32& eval_next) {
     const u32 lane = wv::lane(), N = a.n_nodes, Wn = a.n_words, b = gi & 1u, k = G.k;
     const u32 tbase = a.tree_off[G.tree], ntn = a.tree_off[G.tree + 1] - tbase;
@@ -658,6 +658,11 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
     g2_carve(A, arena_base, G.n_slots, ntn, G.n_gen, a.max_depth, k);
     u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
 #define G2_TICK(q) do { if (a.dbg & 16u) { const u64 n_ = wv::clock64(); gt[q] += n_ - tk; tk = n_; } } while (0)
+    // (the admission's own partition: every mark charges the time since the last one to a bucket — [0] waiting for a batch's records,
+    // [1] whole chunks appended while a heap of one key fills, [2] flat mode's counting, [3] its flushes, [4] staging, [5] the per-chunk
+    // pass, [6] lane 0's replay and the pipelined replacements, [7] the scan over the chunk minima)
+    u64 tx = 0;
+#define G2_X(q) do { if (a.dbg & 16u) { const u64 n_ = wv::clock64(); gx[q] += n_ - tx; tx = n_; } } while (0)
 
     // ---------- per-group reset: tree-node arrays, leaf heap offsets (a leaf's heap holds at most min(k, its nodes)) ----------
     {
@@ -723,12 +728,14 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         u64* vis = reinterpret_cast<u64*>(reinterpret_cast<unsigned char*>(mb) + 2048);                       // [G2_VISW][64] candidate keys
         u32* visn = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + 2048 + G2_VISW * 64 * 8);   // [G2_VISW][64] nodes
         u32* visl = visn + G2_VISW * 64;                                                                       // [G2_VISW][64] leaves
+        if (a.dbg & 16u) tx = wv::clock64();
         for (u32 w0 = 0; w0 < Cn; w0 += 64) {
             // 64 chunks at a time: which of them can hold a candidate at all? (a superset: the root only drops from here on)
             const u64 mk = w0 + lane < Cn ? minb[w0 + lane] : KEY_NONE;
             bool visit = mk != KEY_NONE;
             if (visit && single) visit = len0 < k || mk < root0;
             u64 vm = wv::ballot(visit);
+            G2_X(7);
             while (vm) {
               // The candidate keys of the next G2_VISW words to visit go through LDS: their loads are all in flight together, so the
               // replay below never waits for global memory.
@@ -756,6 +763,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                         }
                     }
                 }
+                if (a.dbg & 16u) { wv::wait_vm(); G2_X(0); }
                 // Flat mode (above) with nothing but the two keys in the whole batch: the light candidates of all its words are counted
                 // and remembered straight from the registers, word after word in node order — no staging, no per-word pass.
                 bool batch_done = false;
@@ -803,6 +811,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                         sm = t;
                         if (sm == 0) batch_done = true;
                     }
+                    G2_X(1);
                 }
                 if (!batch_done && single && F.on && F.lo != KEY_NONE) {
                     u64 t = sm;
@@ -830,9 +839,11 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     }
                     wv::wave_sync();
                     root0 = F.n < F.nh ? F.hi : F.lo;
+                    G2_X(2);
                     if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
                         g2_flat_flush(A, F, k, f_cand, f_hs);
                         root0 = A.HE[0].key;
+                        G2_X(3);
                     }
                     sm = t;
                     if (sm == 0) batch_done = true;
@@ -848,9 +859,11 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     if (!single) visl[q * 64 + (int)lane] = rl[q];
                 }
                 if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;   // (mostly: waiting for the loads)
+                G2_X(4);
               }
               u32 vq = vq0;
               while (sm) {
+                G2_X(5);
                 const u32 c = (u32)wv::ffs64(sm);
                 sm &= sm - 1ull;
                 const u64 key = vis[vq * 64u + lane];   // (a lane reads back what it wrote itself)
@@ -955,7 +968,9 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     // all heavy elements are gone, or a candidate with a third key is admitted: the remembered ones enter the heap and the
                     // ordinary code carries on — with that candidate, if there is one
                     if (fb) G2_STAT(3, 1);
+                    G2_X(5);
                     g2_flat_flush(A, F, k, f_cand, f_hs);
+                    G2_X(3);
                     root0 = A.HE[0].key;
                     if (fb == 0) continue;
                     first = (u32)wv::popc64(bal & ((1ull << fl) - 1ull));   // (fl < 64 here)
@@ -967,6 +982,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     // (it reads level 1, which the one before it finished with a step ago). Lanes hold the operations in flight; every
                     // tick all of them take one step. Same comparisons, same writes, same final array as one after the other.
                     const u64 ta_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                    G2_X(5);
                     const G2Ent mine = sg->ent[lane < ne ? lane : 0u];   // lane j looks after candidate j of the word
                     u32 ci = first;
                     while (ci < ne) {
@@ -1007,9 +1023,11 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                         }
                     }
                     if (a.dbg & 16u) gt[13] += wv::clock64() - ta_;
+                    G2_X(6);
                     continue;
                 }
-                u_valid = false;   // (lane 0 replays pushes that move something: the heap is no longer known to hold one key)
+                u_valid = false;
+                G2_X(5);   // (lane 0 replays pushes that move something: the heap is no longer known to hold one key)
                 if (lane == 0) {
                     const u64 ta_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
                     if (single) { c_lf = 0; hbase = 0; hlen = (int)len0; hroot = root0; }
@@ -1063,6 +1081,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     if (a.dbg & 16u) gt[13] += wv::clock64() - ta_;
                     if (!single && c_lf != G2_NONE) A.h_len[c_lf] = hlen;   // the other lanes' pre-filter reads the lengths of all leaves
                 }
+                G2_X(6);
                 lastp = wv::readfirstlane(lastp);
                 if (single) {   // ... and lane 0's registers when there is one leaf
                     len0 = wv::readfirstlane((u32)hlen);
@@ -1071,7 +1090,8 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
               }
             }
         }
-        if (F.on) g2_flat_flush(A, F, k, f_cand, f_hs);   // the stream ended in flat mode
+        G2_X(5);
+        if (F.on) { g2_flat_flush(A, F, k, f_cand, f_hs); G2_X(3); }   // the stream ended in flat mode
         while (wv::ballot(p_act)) {   // the replacements still in flight run to their ends
             const u32 j1 = 2u * p_hole + 1u;
             const bool has = p_act && j1 < k;
@@ -1479,6 +1499,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
     G2_TICK(7);
     return true;
 #undef G2_TICK
+#undef G2_X
 }
 
 // the static class lists of a call: a grid of n_scls workgroups of ONE wave each, in front of k_groups2 on the same stream
@@ -1501,6 +1522,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     }
     wv::setprio<3>();   // the machine's instructions go first on its SIMD: the helper waves it shares it with only fill the gaps
     u64 gt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 gx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
     G2Post P{0};
     {   // the first group is prepared with nothing to overlap
@@ -1532,9 +1554,9 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         }
         const u32 ntn = a.tree_off[G.tree + 1] - a.tree_off[G.tree];
         const bool in_lds = g2_arena_bytes(G.n_slots, ntn, G.n_gen, a.max_depth, G.k) <= G2_ARENA_LDS;
-        if (in_lds && !G.n_gen) ok = g2_group<true, false>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, P, nh, eval_next);
-        else if (in_lds) ok = g2_group<true, true>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, P, nh, eval_next);
-        else ok = g2_group<false, true>(a, mb, sg, a.arena, G, gi, gt, P, nh, eval_next);
+        if (in_lds && !G.n_gen) ok = g2_group<true, false>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, gx, P, nh, eval_next);
+        else if (in_lds) ok = g2_group<true, true>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, gx, P, nh, eval_next);
+        else ok = g2_group<false, true>(a, mb, sg, a.arena, G, gi, gt, gx, P, nh, eval_next);
         eval_cur = eval_next;
         if (a.dbg & 16u) tk = wv::clock64();
     }
@@ -1547,7 +1569,8 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         for (int q = 0; q < 8; ++q) a.ctl->cyc[q] = gt[q];
         a.ctl->m_cyc[0] = gt[8];   // inside the walk: orderedNodes ...
         a.ctl->m_cyc[1] = gt[9];   // ... and the fill loops
-        for (int q = 0; q < 6; ++q) a.ctl->l_cyc[q] = gt[10 + q];   // admission: words visited, candidates staged, heap operations, cycles inside lane 0's replay
+        for (int q = 0; q < 6; ++q) a.ctl->l_cyc[q] = gt[10 + q];
+        for (int q = 0; q < 8; ++q) a.ctl->wave_cyc[q] = gx[q];   // admission: words visited, candidates staged, heap operations, cycles inside lane 0's replay
     }
 }
 
