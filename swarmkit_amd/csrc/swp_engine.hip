@@ -2823,7 +2823,7 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
     Groups2Args ga{};
     ga.n_nodes = N; ga.n_words = Wn; ga.n_groups = n_groups; ga.gstride = e->ncap; ga.max_ntn = max_ntn; ga.max_depth = max_depth;
     const bool gdbg = getenv("SWP_DBG") && (atoi(getenv("SWP_DBG")) & 16);
-    ga.dbg = gdbg ? 16u : 0u;
+    ga.dbg = gdbg ? (16u | ((uint32_t)atoi(getenv("SWP_DBG")) & 64u)) : 0u;
     ga.g = d_recs.as<GroupRec2>();
     ga.valid = e->d_valid.as<u64>(); ga.ready = e->d_ready.as<u64>();
     ga.con = b.d_con.as<u64>(); ga.plat = b.d_plat.as<u64>(); ga.plug = b.d_plug.as<u64>();
@@ -2862,6 +2862,8 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
                 c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5], c2.cyc[6], c2.cyc[7], c2.m_cyc[0], c2.m_cyc[1], c2.l_cyc[0], c2.l_cyc[1], c2.l_cyc[2], c2.l_cyc[3], c2.l_cyc[4], c2.l_cyc[5]);
         fprintf(stderr, "[swp] k_groups2 admission, cycles by part: records %llu, whole chunks while filling %llu, flat counting %llu, flushes %llu, staging %llu, per-chunk pass %llu, replay + pipelined %llu, minima scan %llu\n",
                 c2.wave_cyc[0], c2.wave_cyc[1], c2.wave_cyc[2], c2.wave_cyc[3], c2.wave_cyc[4], c2.wave_cyc[5], c2.wave_cyc[6], c2.wave_cyc[7]);
+        fprintf(stderr, "[swp] k_groups2 latency probe (cycles, helpers idle): clock %llu, cold line %llu, same line %llu, another line %llu, LDS round trip %llu\n", c2.wave_cyc[8], c2.wave_cyc[9], c2.wave_cyc[10], c2.wave_cyc[11], c2.wave_cyc[12]);
+        if (c2.wave_cyc[15]) fprintf(stderr, "[swp] k_groups2 flush twice in a row (SWP_DBG bit 64): first %llu, second %llu cycles over %llu flushes\n", c2.wave_cyc[13], c2.wave_cyc[14], c2.wave_cyc[15]);
         (void)hipEventDestroy(gev0); (void)hipEventDestroy(gev1);
     }
     Ctl ctl{};

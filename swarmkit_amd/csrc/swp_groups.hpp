@@ -162,6 +162,7 @@ inline __host__ __device__ size_t g2_arena_bytes(u32 S, u32 ntn, u32 ngen, u32 d
 #define G2_LDS_FIXED 9216      // (the last KB: the flat mode's scratch, g2_flat_*)
 #define G2_FLAT_OFF 8192
 #define G2_FLAT_MAXK 128u       // heap positions the flat mode's bit mask covers
+#define G2_PRE_OFF 6144         // [G2_FLAT_MAXK][2] u64: the positions that come before position p in a post-order walk of the heap's tree (g2_pre_table)
 #define G2_VISW 4              // chunks of 64 candidates whose records are staged through LDS together
 inline __host__ __device__ size_t g2_lds_bytes() { return (size_t)G2_LDS_FIXED + G2_ARENA_LDS; }
 
@@ -578,40 +579,46 @@ struct G2Flat {
     u64 m0, m1;       // heavy positions 0..63, 64..127
     u32 nh, n;        // |H|; candidates remembered so far (n <= nh)
 };
-// heavy positions below position x (x <= 128)
-WV_DEV u32 g2_flat_below(const G2Flat& F, u32 x) {
-    if (x >= 128u) return (u32)wv::popc64(F.m0) + (u32)wv::popc64(F.m1);
-    if (x >= 64u) return (u32)wv::popc64(F.m0) + (x == 64u ? 0u : (u32)wv::popc64(F.m1 & (~0ull >> (128u - x))));
-    return x == 0u ? 0u : (u32)wv::popc64(F.m0 & (~0ull >> (64u - x)));
+// Position q comes before position p in a post-order walk (left, right, node) of the binary tree of heap positions: q is a descendant
+// of p, or q's subtree hangs to the left of the way from the root to p. (1-based indices: the ancestor of x at depth d is x >> (depth(x) - d).)
+WV_DEV bool g2_post_before(u32 q, u32 p) {
+    const u32 x = q + 1u, y = p + 1u;
+    const u32 dx = 31u - (u32)wv::clz32(x), dy = 31u - (u32)wv::clz32(y);
+    if (dx >= dy) return x != y && (x >> (dx - dy)) <= y;   // (x's ancestor at p's depth is p itself, or lies to its left)
+    return x < (y >> (dy - dx));                             // (p's ancestor at q's depth: q itself comes AFTER its descendant p)
 }
-// heavy nodes in the subtree of position p (itself included): level j of it is the position range [(p + 1) 2^j - 1, ... + 2^j)
-WV_DEV u32 g2_flat_sub(const G2Flat& F, u32 p, u32 k) {
-    u32 c = 0;
-    for (u32 j = 0;; ++j) {
-        const u32 lo = ((p + 1u) << j) - 1u;
-        if (lo >= k) break;
-        c += g2_flat_below(F, min(lo + (1u << j), 128u)) - g2_flat_below(F, lo);
+// pre[p] = {positions 0..63, positions 64..127} that come before p: the table the flat mode's scatter counts in (built once per launch)
+WV_DEV void g2_pre_table(u64* pre) {
+    const u32 lane = wv::lane();
+    for (u32 p = lane; p < G2_FLAT_MAXK; p += 64u) {
+        u64 lo = 0, hi = 0;
+        for (u32 q = 0; q < 64u; ++q) {
+            if (g2_post_before(q, p)) lo |= 1ull << q;
+            if (g2_post_before(q + 64u, p)) hi |= 1ull << q;
+        }
+        pre[2u * p] = lo;
+        pre[2u * p + 1u] = hi;
     }
-    return c;
+    wv::wave_sync();
 }
-// The remembered candidates enter the heap. cand[r] = node of the r-th one; hs: scratch [G2_FLAT_MAXK].
-WV_DEV void g2_flat_flush(const G2Arena& A, G2Flat& F, u32 k, const u32* cand, u32* hs) {
+// The remembered candidates enter the heap. cand[r] = node of the r-th one; pre: g2_pre_table.
+WV_DEV void g2_flat_flush(const G2Arena& A, G2Flat& F, u32 k, const u32* cand, const u64* pre) {
     const u32 lane = wv::lane();
     if (F.n == F.nh) G2_STAT(1, F.n);
     else G2_STAT(2, F.n);
     if (F.n == F.nh && F.n != 0) {
-        // every heavy element was replaced: candidate r sits at the r-th heavy position in post-order
-        for (u32 p = lane; p < k; p += 64u) hs[p] = g2_flat_sub(F, p, k);
-        wv::wave_sync();
-        for (u32 p = lane; p < k; p += 64u) {
-            const bool heavy = ((p < 64u ? F.m0 >> p : F.m1 >> (p - 64u)) & 1ull) != 0;
-            if (!heavy) continue;
-            u32 r = hs[p] - 1u;   // its heavy descendants come first ...
-            for (u32 c = p; c > 0u; c = (c - 1u) >> 1)
-                if ((c & 1u) == 0u) r += hs[c - 1u];   // ... and the subtrees that hang to the LEFT of the way from the root to it
-            G2Ent he;
-            he.key = F.lo; he.node = cand[r]; he.tix = G2_NONE;
-            A.HE[p] = he;
+        // every heavy element was replaced: candidate r sits at the r-th heavy position in post-order — r = the heavy positions that
+        // come before it (two and-popcounts against the table; a lane per position)
+        WV_UNROLL
+        for (u32 h = 0; h < 2u; ++h) {
+            const u32 p = lane + 64u * h;
+            const bool heavy = p < k && (((h ? F.m1 : F.m0) >> lane) & 1ull) != 0;
+            if (heavy) {
+                const u32 r = (u32)wv::popc64(F.m0 & pre[2u * p]) + (u32)wv::popc64(F.m1 & pre[2u * p + 1u]);
+                G2Ent he;
+                he.key = F.lo; he.node = cand[r]; he.tix = G2_NONE;
+                A.HE[p] = he;
+            }
         }
     } else if (F.n != 0) {
         // heavy elements are left and have moved: the ordinary replay, one candidate after the other (rare)
@@ -675,17 +682,9 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 A.h_len[i] = 0; A.h_cnt[i] = 0; A.h_adm[i] = 0; A.noroom[i] = 0; A.h_vis[i] = 0;
                 if (a.tn_nchild[tbase + i] == 0) cap = min(k, a.tn_nodes[tbase + i]);
             }
-            // exclusive prefix over the wave (ntn is small: lanes add through LDS)
-            sg->scan[lane] = cap;
-            wv::wave_sync();
-            u32 before = 0;
-            for (u32 q = 0; q < lane; ++q) before += sg->scan[q];
-            u32 tot = 0;
-            if (lane == 63) tot = before + cap;
-            tot = wv::readlane(tot, 63);
-            if (i < ntn) A.h_off[i] = run + before;
-            run += tot;
-            wv::wave_sync();
+            const u32 incl = wv::scan_incl_u32(cap);   // exclusive prefix over the wave
+            if (i < ntn) A.h_off[i] = run + incl - cap;
+            run += wv::readlane(incl, 63);
         }
         if (run != G.n_slots) {   // the host's slot count and the tree disagree: refuse rather than overrun the arena
             if (lane == 0) a.ctl->error = ERR_GROUP_RANGE;
@@ -718,7 +717,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         G2Flat F{false, 0, 0, 0, 0, 0, 0};   // the flat mode (above): tried once, when the one heap has just become full
         bool flat_tried = false;
         u32* f_cand = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + G2_FLAT_OFF);   // [G2_FLAT_MAXK] the remembered candidates' nodes
-        u32* f_hs = f_cand + G2_FLAT_MAXK;                                                            // [G2_FLAT_MAXK] scratch of the flush
+        const u64* f_pre = reinterpret_cast<const u64*>(reinterpret_cast<unsigned char*>(mb) + G2_PRE_OFF);   // the post-order table (k_groups2 builds it)
         // The scan runs over the group's candidate list (the helpers' EVAL command over the static class list): chunk c = entries
         // [64 c, 64 c + 64) in node order, `minb[c]` a lower bound of the chunk's keys. A lane's candidate is a record {key, node, leaf};
         // a hole (a listed node that fails a dynamic filter, or dropped out since) carries KEY_NONE.
@@ -841,7 +840,21 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     root0 = F.n < F.nh ? F.hi : F.lo;
                     G2_X(2);
                     if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
-                        g2_flat_flush(A, F, k, f_cand, f_hs);
+                        if (a.dbg & 64u) {   // experiment: the same flush twice in a row (is the first one slow because its code is not cached?)
+                            G2Flat F2 = F;
+                            const u64 e0 = wv::clock64();
+                            g2_flat_flush(A, F2, k, f_cand, f_pre);
+                            const u64 e1 = wv::clock64();
+                            F2 = F;
+                            g2_flat_flush(A, F2, k, f_cand, f_pre);
+                            const u64 e2 = wv::clock64();
+                            gx[7] += 0;
+                            gt[0] += 0;
+                            a.ctl->wave_cyc[13] += e1 - e0;
+                            a.ctl->wave_cyc[14] += e2 - e1;
+                            a.ctl->wave_cyc[15] += 1;
+                        }
+                        g2_flat_flush(A, F, k, f_cand, f_pre);
                         root0 = A.HE[0].key;
                         G2_X(3);
                     }
@@ -969,7 +982,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     // ordinary code carries on — with that candidate, if there is one
                     if (fb) G2_STAT(3, 1);
                     G2_X(5);
-                    g2_flat_flush(A, F, k, f_cand, f_hs);
+                    g2_flat_flush(A, F, k, f_cand, f_pre);
                     G2_X(3);
                     root0 = A.HE[0].key;
                     if (fb == 0) continue;
@@ -1091,7 +1104,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             }
         }
         G2_X(5);
-        if (F.on) { g2_flat_flush(A, F, k, f_cand, f_hs); G2_X(3); }   // the stream ended in flat mode
+        if (F.on) { g2_flat_flush(A, F, k, f_cand, f_pre); G2_X(3); }   // the stream ended in flat mode
         while (wv::ballot(p_act)) {   // the replacements still in flight run to their ends
             const u32 j1 = 2u * p_hole + 1u;
             const bool has = p_act && j1 < k;
@@ -1511,7 +1524,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
     G2Mail* mb = reinterpret_cast<G2Mail*>(l);
     G2Stage* sg = reinterpret_cast<G2Stage*>(l + 512);
-    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 16 <= G2_FLAT_OFF && G2_FLAT_OFF + 8 * G2_FLAT_MAXK <= G2_LDS_FIXED, "fixed LDS layout");
+    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 16 <= G2_PRE_OFF && G2_PRE_OFF + 16 * G2_FLAT_MAXK <= G2_FLAT_OFF && G2_FLAT_OFF + 8 * G2_FLAT_MAXK <= G2_LDS_FIXED, "fixed LDS layout");
     const u32 wave = wv::wave(), lane = wv::lane(), nh = wv::nthreads() / 64u - 1u;
     if (wv::tid() == 0) { mb->posted = 0; mb->done = 0; mb->quit = 0; }
     wv::barrier();
@@ -1520,11 +1533,33 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         g2_helper(a, mb, wave - 1u, nh);
         return;
     }
+    g2_pre_table(reinterpret_cast<u64*>(l + G2_PRE_OFF));
     wv::setprio<3>();   // the machine's instructions go first on its SIMD: the helper waves it shares it with only fill the gaps
     u64 gt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 gx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
     G2Post P{0};
+    if (a.dbg & 16u) {   // latency probe (helpers idle): clock overhead, a cold line, the same line again (L1), its neighbour (L2 or further), an LDS round trip
+        const u64 c0 = wv::clock64();
+        const u64 c1 = wv::clock64();
+        u64 v = a.ccand[lane].key;
+        wv::wait_vm();
+        const u64 c2 = wv::clock64();
+        v += a.ccand[lane].key + (v & 1ull);
+        wv::wait_vm();
+        const u64 c3 = wv::clock64();
+        v += a.ccand[(size_t)a.n_nodes + lane + (v & 1ull)].key;
+        wv::wait_vm();
+        const u64 c4 = wv::clock64();
+        mb->sh[15] = (u32)v;
+        wv::wave_sync();
+        const u32 lv = mb->sh[15];
+        wv::wave_sync();
+        const u64 c5 = wv::clock64();
+        if (lane == 0) {
+            a.ctl->wave_cyc[8] = c1 - c0; a.ctl->wave_cyc[9] = c2 - c1; a.ctl->wave_cyc[10] = c3 - c2; a.ctl->wave_cyc[11] = c4 - c3; a.ctl->wave_cyc[12] = c5 - c4 + (lv & 0u);
+        }
+    }
     {   // the first group is prepared with nothing to overlap
         const GroupRec2 G0 = a.g[0];
         const u32 ntn0 = a.tree_off[G0.tree + 1] - a.tree_off[G0.tree];
