@@ -908,32 +908,64 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 // word); if it holds for every push of the word, the pushes are one parallel append.
                 u32 first = 0;
                 if (single && len0 < k) {
-                    const u32 np = min(ne, k - len0);
-                    bool moves = false;
-                    if (cand && myj < np) {
-                        const u32 pos = len0 + myj;
-                        if (pos > 0) {
-                            const u32 pp = (pos - 1u) >> 1;
-                            const u64 pk = pp < len0 ? A.HE[pp].key : sg->ent[pp - len0].key;
-                            moves = pk < key;   // Less(j, i)
+                    // Candidates [first, ne) are pushed while the heap has room. Every lane checks its own candidate against its parent
+                    // (in the heap already, or an earlier candidate of this stretch): the pushes in FRONT of the first one that moves
+                    // move nothing — one parallel append. The one that moves is then sifted up BY THE WAVE: lane d holds the ancestor at
+                    // depth d of the new position; the ancestors that are less than the new element are the lowest ones on the path (a
+                    // max-heap: keys do not grow downwards), each of them goes one step down, the new element takes the place of the
+                    // topmost — the same comparisons and the same final array as container/heap's up(), one LDS round trip instead of
+                    // one per level. Then the parallel check again, from the next candidate on.
+                    for (;;) {
+                        const u32 np = min(ne - first, k - len0);
+                        if (np == 0) break;
+                        bool moves = false;
+                        const bool mine = cand && myj >= first && myj < first + np;
+                        if (mine) {
+                            const u32 pos = len0 + (myj - first);
+                            if (pos > 0) {
+                                const u32 pp = (pos - 1u) >> 1;
+                                const u64 pk = pp < len0 ? A.HE[pp].key : sg->ent[first + (pp - len0)].key;
+                                moves = pk < key;   // Less(j, i)
+                            }
                         }
-                    }
-                    // (the pushes in FRONT of the first one that moves move nothing either — their parents are in the heap or among
-                    // themselves — so they are appended in parallel all the same; lane 0 replays the rest)
-                    const u64 mvb = wv::ballot(moves);
-                    const u32 npp = mvb ? wv::readlane(myj, (u32)wv::ffs64(mvb)) : np;
-                    if (npp != 0) {
-                        if (cand && myj < npp) {
+                        const u64 mvb = wv::ballot(moves);
+                        const u32 npp = mvb ? wv::readlane(myj, (u32)wv::ffs64(mvb)) - first : np;
+                        if (npp != 0) {
+                            if (mine && myj < first + npp) {
+                                G2Ent he;
+                                he.key = key; he.node = n; he.tix = G2_NONE;
+                                A.HE[len0 + (myj - first)] = he;
+                            }
+                            if (len0 == 0) { root0 = sg->ent[first].key; u_key = root0; }
+                            if (wv::ballot(mine && myj < first + npp && key != u_key)) u_valid = false;
+                            lastp = sg->ent[first + npp - 1u].node + 1u;
+                            len0 += npp;
+                            first += npp;
+                            if (a.dbg & 16u) gt[14] += npp;
+                            wv::wave_sync();
+                        }
+                        if (npp == np) break;
+                        // candidate `first` goes to position len0 and moves up
+                        const G2Ent e = sg->ent[first];
+                        const u32 j1 = len0 + 1u, dj = 31u - (u32)wv::clz32(j1);   // (1-based index; its ancestor at depth d is j1 >> (dj - d))
+                        const bool anc = lane < dj;
+                        const G2Ent ae = A.HE[anc ? (j1 >> (dj - lane)) - 1u : 0u];
+                        const bool less = anc && ae.key < e.key;
+                        const u32 mv = (u32)wv::popc64(wv::ballot(less));
+                        wv::lockstep();   // every lane has read its ancestor before any lane overwrites one
+                        if (less) A.HE[(j1 >> (dj - lane - 1u)) - 1u] = ae;
+                        if (lane == 0) {
                             G2Ent he;
-                            he.key = key; he.node = n; he.tix = G2_NONE;
-                            A.HE[len0 + myj] = he;
+                            he.key = e.key; he.node = e.node; he.tix = G2_NONE;
+                            A.HE[(j1 >> mv) - 1u] = he;
                         }
-                        if (len0 == 0) { root0 = sg->ent[0].key; u_key = root0; }
-                        if (wv::ballot(cand && myj < npp && key != u_key)) u_valid = false;
-                        lastp = sg->ent[npp - 1u].node + 1u;
-                        len0 += npp;
-                        first = npp;
-                        if (a.dbg & 16u) gt[14] += npp;
+                        if (mv == dj) root0 = e.key;
+                        u_valid = false;
+                        lastp = e.node + 1u;
+                        len0 += 1u;
+                        first += 1u;
+                        if (a.dbg & 16u) gt[12] += 1;
+                        G2_STAT(7, 1);
                         wv::wave_sync();
                     }
                 }

@@ -549,8 +549,8 @@ int main(int argc, char** argv) {
         lds_groups += g2_arena_bytes(p.groups[g].n_slots, tree_off[p.groups[g].tree + 1] - tree_off[p.groups[g].tree], p.groups[g].n_gen, max_depth, p.groups[g].k) <= G2_ARENA_LDS;
     }
     if (verbose || bad) {
-        fprintf(stderr, "admission paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu words taken by whole batches in flat mode, %llu words appended whole while a heap of one key filled\n",
-                g2_stat[0], g2_stat[1], g2_stat[2], g2_stat[3], g2_stat[4], g2_stat[5], g2_stat[6]);
+        fprintf(stderr, "admission paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu words taken by whole batches in flat mode, %llu words appended whole while a heap of one key filled, %llu pushes sifted up by the wave\n",
+                g2_stat[0], g2_stat[1], g2_stat[2], g2_stat[3], g2_stat[4], g2_stat[5], g2_stat[6], g2_stat[7]);
         fprintf(stderr, "emu_groups seed %u N %u groups %zu (LDS arena: %u) trees %zu: %u of %zu tasks placed, %u groups with an explanation -> %s\n", seed, N,
                 p.groups.size(), lds_groups, p.trees.size(), placed, out.size(), left_groups, bad ? "FAILED" : "OK");
     }

@@ -98,7 +98,10 @@ def test_the_flat_mode_and_its_ways_out_are_taken(emu_lds):
     flat, scatter, replay, third, piped, batch_words = paths((5, 300, 12, 120, 1, 0, 256))
     assert flat >= 5 and scatter >= 100 and replay >= 10
     flat, scatter, replay, third, piped, batch_words = paths((7, 2000, 20, 100, 1, 0, 256))
-    assert flat >= 5 and third >= 1 and piped >= 100 and batch_words >= 8
+    assert flat >= 5 and third >= 1 and piped >= 100
+    # (chunks of the candidate list hold 64 candidates where a node word held a handful: a chunk without a third key needs a calmer cluster)
+    flat, scatter, replay, third, piped, batch_words = paths((104, 3000, 12, 90, 1, 0, 256))
+    assert flat >= 5 and batch_words >= 8
 
 
 @pytest.mark.parametrize("case", LEVEL, ids=lambda c: "level-seed%d-N%d-g%d-k%d-f%d" % (c[0], c[1], c[2], c[3], c[5]))
