@@ -736,6 +736,9 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             u64 vm = wv::ballot(visit);
             G2_X(7);
             while (vm) {
+              // (the root may have dropped since the 64 chunks were looked at: the ones it rules out by now are not even loaded)
+              if (single) vm &= wv::ballot(len0 < k || mk < root0);
+              if (vm == 0) break;
               // The candidate keys of the next G2_VISW words to visit go through LDS: their loads are all in flight together, so the
               // replay below never waits for global memory.
               u64 sm = 0;
@@ -762,7 +765,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                         }
                     }
                 }
-                if (a.dbg & 16u) { wv::wait_vm(); G2_X(0); }
+                if (a.dbg & 16u) { wv::wait_vm(); G2_X(0); gx[8] += wv::clock64() - tw_; gx[9] += 1; }
                 // Flat mode (above) with nothing but the two keys in the whole batch: the light candidates of all its words are counted
                 // and remembered straight from the registers, word after word in node order — no staging, no per-word pass.
                 bool batch_done = false;
@@ -840,20 +843,6 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     root0 = F.n < F.nh ? F.hi : F.lo;
                     G2_X(2);
                     if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
-                        if (a.dbg & 64u) {   // experiment: the same flush twice in a row (is the first one slow because its code is not cached?)
-                            G2Flat F2 = F;
-                            const u64 e0 = wv::clock64();
-                            g2_flat_flush(A, F2, k, f_cand, f_pre);
-                            const u64 e1 = wv::clock64();
-                            F2 = F;
-                            g2_flat_flush(A, F2, k, f_cand, f_pre);
-                            const u64 e2 = wv::clock64();
-                            gx[7] += 0;
-                            gt[0] += 0;
-                            a.ctl->wave_cyc[13] += e1 - e0;
-                            a.ctl->wave_cyc[14] += e2 - e1;
-                            a.ctl->wave_cyc[15] += 1;
-                        }
                         g2_flat_flush(A, F, k, f_cand, f_pre);
                         root0 = A.HE[0].key;
                         G2_X(3);
@@ -1133,9 +1122,10 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     root0 = ((u64)wv::readfirstlane((u32)(hroot >> 32)) << 32) | wv::readfirstlane((u32)hroot);
                 } else wv::wave_sync();
               }
+              G2_X(5);
             }
         }
-        G2_X(5);
+        G2_X(7);
         if (F.on) { g2_flat_flush(A, F, k, f_cand, f_pre); G2_X(3); }   // the stream ended in flat mode
         while (wv::ballot(p_act)) {   // the replacements still in flight run to their ends
             const u32 j1 = 2u * p_hole + 1u;
@@ -1568,7 +1558,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     g2_pre_table(reinterpret_cast<u64*>(l + G2_PRE_OFF));
     wv::setprio<3>();   // the machine's instructions go first on its SIMD: the helper waves it shares it with only fill the gaps
     u64 gt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    u64 gx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 gx[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
     G2Post P{0};
     if (a.dbg & 16u) {   // latency probe (helpers idle): clock overhead, a cold line, the same line again (L1), its neighbour (L2 or further), an LDS round trip
@@ -1637,7 +1627,9 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         a.ctl->m_cyc[0] = gt[8];   // inside the walk: orderedNodes ...
         a.ctl->m_cyc[1] = gt[9];   // ... and the fill loops
         for (int q = 0; q < 6; ++q) a.ctl->l_cyc[q] = gt[10 + q];
-        for (int q = 0; q < 8; ++q) a.ctl->wave_cyc[q] = gx[q];   // admission: words visited, candidates staged, heap operations, cycles inside lane 0's replay
+        for (int q = 0; q < 8; ++q) a.ctl->wave_cyc[q] = gx[q];
+        a.ctl->wave_cyc[13] = gx[8];
+        a.ctl->wave_cyc[14] = gx[9];   // admission: words visited, candidates staged, heap operations, cycles inside lane 0's replay
     }
 }
 
