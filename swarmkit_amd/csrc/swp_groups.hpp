@@ -159,10 +159,11 @@ inline __host__ __device__ size_t g2_arena_bytes(u32 S, u32 ntn, u32 ngen, u32 d
     return 32 * (size_t)S + 64 * ((size_t)depth + 2) + 8 * (2 * (size_t)ntn + fw) + 4 * ((size_t)S * ngen + 2 * kt + 6 * (size_t)ntn) + 64;
 }
 // mailbox, staging of one chunk of candidates, a few scalars
-#define G2_LDS_FIXED 9216      // (the last KB: the flat mode's scratch, g2_flat_*)
+#define G2_LDS_FIXED 11264     // (the flat mode's scratch and tables: g2_flat_*, g2_pre_table)
 #define G2_FLAT_OFF 8192
 #define G2_FLAT_MAXK 128u       // heap positions the flat mode's bit mask covers
 #define G2_PRE_OFF 6144         // [G2_FLAT_MAXK][2] u64: the positions that come before position p in a post-order walk of the heap's tree (g2_pre_table)
+#define G2_LEFT_OFF 9216        // [G2_FLAT_MAXK][2] u64: ... those of them that are not descendants of p
 #define G2_VISW 4              // chunks of 64 candidates whose records are staged through LDS together
 inline __host__ __device__ size_t g2_lds_bytes() { return (size_t)G2_LDS_FIXED + G2_ARENA_LDS; }
 
@@ -588,46 +589,89 @@ WV_DEV bool g2_post_before(u32 q, u32 p) {
     return x < (y >> (dy - dx));                             // (p's ancestor at q's depth: q itself comes AFTER its descendant p)
 }
 // pre[p] = {positions 0..63, positions 64..127} that come before p: the table the flat mode's scatter counts in (built once per launch)
-WV_DEV void g2_pre_table(u64* pre) {
+WV_DEV bool g2_is_desc(u32 q, u32 p) {   // q lies in the subtree below p
+    const u32 x = q + 1u, y = p + 1u;
+    const u32 dx = 31u - (u32)wv::clz32(x), dy = 31u - (u32)wv::clz32(y);
+    return dx > dy && (x >> (dx - dy)) == y;
+}
+WV_DEV void g2_pre_table(u64* pre, u64* left) {
     const u32 lane = wv::lane();
     for (u32 p = lane; p < G2_FLAT_MAXK; p += 64u) {
-        u64 lo = 0, hi = 0;
+        u64 lo = 0, hi = 0, llo = 0, lhi = 0;
         for (u32 q = 0; q < 64u; ++q) {
-            if (g2_post_before(q, p)) lo |= 1ull << q;
-            if (g2_post_before(q + 64u, p)) hi |= 1ull << q;
+            if (g2_post_before(q, p)) { lo |= 1ull << q; if (!g2_is_desc(q, p)) llo |= 1ull << q; }
+            if (g2_post_before(q + 64u, p)) { hi |= 1ull << q; if (!g2_is_desc(q + 64u, p)) lhi |= 1ull << q; }
         }
         pre[2u * p] = lo;
         pre[2u * p + 1u] = hi;
+        left[2u * p] = llo;
+        left[2u * p + 1u] = lhi;
     }
     wv::wave_sync();
 }
-// The remembered candidates enter the heap. cand[r] = node of the r-th one; pre: g2_pre_table.
-WV_DEV void g2_flat_flush(const G2Arena& A, G2Flat& F, u32 k, const u32* cand, const u64* pre) {
+// The heap's keys as the flat mode sees them: hi = the root's key, the heavy positions, lo = the LARGEST key below hi (KEY_NONE: every
+// element is heavy). Candidates with the key lo are counted (the argument above only needs that no light ELEMENT exceeds a light
+// CANDIDATE: the sift then still stops where the heavy children end, and lighter elements further down are never looked at).
+WV_DEV void g2_flat_init(const G2Arena& A, G2Flat& F, u32 k) {
+    const u32 lane = wv::lane();
+    const u64 k0 = lane < k ? A.HE[lane].key : 0ull, k1 = lane + 64u < k ? A.HE[lane + 64u].key : 0ull;
+    F.hi = wv::readlane64(k0, 0);
+    F.m0 = wv::ballot(lane < k && k0 == F.hi);
+    F.m1 = wv::ballot(lane + 64u < k && k1 == F.hi);
+    // (the largest key below hi = the least of the complements)
+    const u64 o0 = (lane < k && k0 != F.hi) ? ~k0 : KEY_NONE, o1 = (lane + 64u < k && k1 != F.hi) ? ~k1 : KEY_NONE;
+    const u64 mn = g2_wave_min64(o0 < o1 ? o0 : o1);
+    F.lo = mn == KEY_NONE ? KEY_NONE : ~mn;
+    F.nh = (u32)wv::popc64(F.m0) + (u32)wv::popc64(F.m1);
+    F.n = 0;
+    F.on = true;
+    G2_STAT(0, 1);
+}
+// The remembered candidates enter the heap. cand[r] = node of the r-th one; pre / left: g2_pre_table.
+// After r replacements candidate j < r sits at the j-th heavy position in post-order (light elements never move), and a heavy element
+// that started at position p has moved up once per replacement from the first one that came to rest inside p's subtree on — the way
+// from the root to a landing place passes every ancestor of it, and the post-order successor of a landing place inside a subtree lies
+// inside the parent's subtree: once an element is on the move, every further replacement moves it, until it leaves at the root. The
+// first landing inside p's subtree is number b(p) = the heavy positions in front of p that are not its descendants. So the element
+// from p is min(r - b(p), ...) steps up, or gone after depth(p) + 1 moves: every lane moves its own element, no replay.
+WV_DEV void g2_flat_flush(const G2Arena& A, G2Flat& F, u32 k, const u32* cand, const u64* pre, const u64* left) {
     const u32 lane = wv::lane();
     if (F.n == F.nh) G2_STAT(1, F.n);
     else G2_STAT(2, F.n);
-    if (F.n == F.nh && F.n != 0) {
-        // every heavy element was replaced: candidate r sits at the r-th heavy position in post-order — r = the heavy positions that
-        // come before it (two and-popcounts against the table; a lane per position)
+    if (F.n != 0) {
+        const u32 r = F.n;
+        G2Ent old[2];
+        u32 rp[2], mv[2];
+        bool heavy[2];
         WV_UNROLL
         for (u32 h = 0; h < 2u; ++h) {
             const u32 p = lane + 64u * h;
-            const bool heavy = p < k && (((h ? F.m1 : F.m0) >> lane) & 1ull) != 0;
-            if (heavy) {
-                const u32 r = (u32)wv::popc64(F.m0 & pre[2u * p]) + (u32)wv::popc64(F.m1 & pre[2u * p + 1u]);
-                G2Ent he;
-                he.key = F.lo; he.node = cand[r]; he.tix = G2_NONE;
-                A.HE[p] = he;
+            heavy[h] = p < k && (((h ? F.m1 : F.m0) >> lane) & 1ull) != 0;
+            rp[h] = 0; mv[h] = 0;
+            old[h] = A.HE[heavy[h] ? p : 0u];
+            if (heavy[h]) {
+                rp[h] = (u32)wv::popc64(F.m0 & pre[2u * p]) + (u32)wv::popc64(F.m1 & pre[2u * p + 1u]);
+                const u32 bp = (u32)wv::popc64(F.m0 & left[2u * p]) + (u32)wv::popc64(F.m1 & left[2u * p + 1u]);
+                mv[h] = r > bp ? r - bp : 0u;
             }
         }
-    } else if (F.n != 0) {
-        // heavy elements are left and have moved: the ordinary replay, one candidate after the other (rare)
-        if (lane == 0)
-            for (u32 r = 0; r < F.n; ++r) {
+        wv::lockstep();   // every lane holds its old elements before any position is rewritten
+        WV_UNROLL
+        for (u32 h = 0; h < 2u; ++h) {
+            const u32 p = lane + 64u * h;
+            if (!heavy[h]) continue;
+            if (rp[h] < r) {
                 G2Ent he;
-                he.key = F.lo; he.node = cand[r]; he.tix = G2_NONE;
-                (void)g2_down_val(A, 0u, 0, (int)k, he);
+                he.key = F.lo; he.node = cand[rp[h]]; he.tix = G2_NONE;
+                A.HE[p] = he;
             }
+            const u32 dp = 31u - (u32)wv::clz32(p + 1u);
+            if (mv[h] != 0 && mv[h] <= dp) {
+                G2Ent he;   // (field by field: a record handed on as a whole lives in scratch memory)
+                he.key = old[h].key; he.node = old[h].node; he.tix = old[h].tix;
+                A.HE[((p + 1u) >> mv[h]) - 1u] = he;
+            }
+        }
     }
     wv::wave_sync();
     F.on = false;
@@ -715,9 +759,10 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         bool u_valid = true;   // one leaf, still filling: every element so far has the same key u_key (nothing ever moved) — then a batch of words
         u64 u_key = KEY_NONE;  // whose candidates all have that key too is ONE append (below)
         G2Flat F{false, 0, 0, 0, 0, 0, 0};   // the flat mode (above): tried once, when the one heap has just become full
-        bool flat_tried = false;
+        u32 flat_fail = 0;   // flat sessions that a foreign candidate ended before they had admitted anything: after two the group gives up on them
         u32* f_cand = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + G2_FLAT_OFF);   // [G2_FLAT_MAXK] the remembered candidates' nodes
-        const u64* f_pre = reinterpret_cast<const u64*>(reinterpret_cast<unsigned char*>(mb) + G2_PRE_OFF);   // the post-order table (k_groups2 builds it)
+        const u64* f_pre = reinterpret_cast<const u64*>(reinterpret_cast<unsigned char*>(mb) + G2_PRE_OFF);   // the post-order tables (k_groups2 builds them)
+        const u64* f_left = reinterpret_cast<const u64*>(reinterpret_cast<unsigned char*>(mb) + G2_LEFT_OFF);
         // The scan runs over the group's candidate list (the helpers' EVAL command over the static class list): chunk c = entries
         // [64 c, 64 c + 64) in node order, `minb[c]` a lower bound of the chunk's keys. A lane's candidate is a record {key, node, leaf};
         // a hole (a listed node that fails a dynamic filter, or dropped out since) carries KEY_NONE.
@@ -815,6 +860,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     }
                     G2_X(1);
                 }
+                if (!batch_done && single && !F.on && len0 >= k && k <= G2_FLAT_MAXK && flat_fail < 2u && p_slots == 0u) g2_flat_init(A, F, k);
                 if (!batch_done && single && F.on && F.lo != KEY_NONE) {
                     u64 t = sm;
                     WV_UNROLL
@@ -843,7 +889,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     root0 = F.n < F.nh ? F.hi : F.lo;
                     G2_X(2);
                     if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
-                        g2_flat_flush(A, F, k, f_cand, f_pre);
+                        g2_flat_flush(A, F, k, f_cand, f_pre, f_left);
                         root0 = A.HE[0].key;
                         G2_X(3);
                     }
@@ -959,22 +1005,14 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     }
                 }
                 if (first == ne) continue;
-                if (single && len0 >= k && !flat_tried && k <= G2_FLAT_MAXK) {
-                    // the heap has just become full (nothing is in flight yet): do its keys take two values?
-                    flat_tried = true;
-                    const u64 k0 = lane < k ? A.HE[lane].key : 0ull, k1 = lane + 64u < k ? A.HE[lane + 64u].key : 0ull;
-                    F.hi = wv::readlane64(k0, 0);
-                    F.m0 = wv::ballot(lane < k && k0 == F.hi);
-                    F.m1 = wv::ballot(lane + 64u < k && k1 == F.hi);
-                    const u64 o0 = (lane < k && k0 != F.hi) ? k0 : KEY_NONE, o1 = (lane + 64u < k && k1 != F.hi) ? k1 : KEY_NONE;
-                    F.lo = g2_wave_min64(o0 < o1 ? o0 : o1);
-                    F.on = wv::ballot((lane < k && k0 != F.hi && k0 != F.lo) || (lane + 64u < k && k1 != F.hi && k1 != F.lo)) == 0;
-                    F.nh = (u32)wv::popc64(F.m0) + (u32)wv::popc64(F.m1);
-                    F.n = 0;
-                    if (F.on) G2_STAT(0, 1);
-                }
-                if (F.on) {
-                    // the word's remaining candidates in lane order (= node order: the compaction keeps it)
+                // ---- the heap is full, one leaf, k <= 128: FLAT sessions over the chunk's remaining candidates (see G2Flat). A session ends when
+                // all heavy elements are replaced (nothing else of the chunk can enter then: the root is light), or in front of a FOREIGN
+                // candidate — admitted, with a key other than the light one: the session's candidates enter the heap (g2_flat_flush: closed
+                // form, whether or not heavy elements are left), lane 0 replaces the root by that ONE candidate the ordinary way, and the
+                // next session starts from the heap as it is then.
+                while (first < ne && single && len0 >= k && k <= G2_FLAT_MAXK && flat_fail < 2u && p_slots == 0u) {
+                    if (!F.on) g2_flat_init(A, F, k);
+                    // the chunk's remaining candidates in lane order (= node order: the compaction keeps it)
                     const bool mineC = cand && myj >= first;
                     if (F.lo == KEY_NONE) {   // every element is heavy: the first candidate below the root names the light key
                         const u64 b0 = wv::ballot(mineC && key < F.hi);
@@ -983,7 +1021,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     const bool is_lo = mineC && F.lo != KEY_NONE && key == F.lo;
                     const u32 before = wv::mbcnt(wv::ballot(is_lo));          // light candidates in front of this lane
                     const bool root_heavy = F.n + before < F.nh;              // ... all admitted while a heavy element was left
-                    const bool foreign = mineC && key != F.lo && key < (root_heavy ? F.hi : F.lo);   // admitted, with a third key
+                    const bool foreign = mineC && key != F.lo && key < (root_heavy ? F.hi : F.lo);   // admitted, with another key
                     const u64 fb = wv::ballot(foreign);
                     const u32 fl = fb ? (u32)wv::ffs64(fb) : 64u;
                     const bool acc = is_lo && root_heavy && lane < fl;
@@ -998,17 +1036,31 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     }
                     wv::wave_sync();
                     root0 = F.n < F.nh ? F.hi : F.lo;
-                    if (fb == 0 && F.n < F.nh) continue;
-                    // all heavy elements are gone, or a candidate with a third key is admitted: the remembered ones enter the heap and the
-                    // ordinary code carries on — with that candidate, if there is one
+                    if (fb == 0 && F.n < F.nh) { first = ne; break; }   // the chunk is through, the session goes on
                     if (fb) G2_STAT(3, 1);
+                    if (fb && F.n == 0) ++flat_fail;
                     G2_X(5);
-                    g2_flat_flush(A, F, k, f_cand, f_pre);
+                    g2_flat_flush(A, F, k, f_cand, f_pre, f_left);
                     G2_X(3);
-                    root0 = A.HE[0].key;
-                    if (fb == 0) continue;
+                    if (fb == 0) { root0 = A.HE[0].key; first = ne; break; }   // every heavy element is replaced: the root is light, nothing else of the chunk enters
+                    // the foreign candidate: heap.Fix(0) with it at the root (it is less than the root: that is what made it foreign)
                     first = (u32)wv::popc64(bal & ((1ull << fl) - 1ull));   // (fl < 64 here)
+                    u64 nroot = 0;
+                    if (lane == 0) {
+                        const G2Ent fe = sg->ent[first];
+                        G2Ent he;
+                        he.key = fe.key; he.node = fe.node; he.tix = G2_NONE;
+                        nroot = g2_down_val(A, 0u, 0, (int)k, he).top.key;
+                    }
+                    root0 = ((u64)wv::readfirstlane((u32)(nroot >> 32)) << 32) | wv::readfirstlane((u32)nroot);
+                    lastp = sg->ent[first].node + 1u;
+                    first += 1u;
+                    if (a.dbg & 16u) gt[12] += 1;
+                    G2_STAT(4, 1);
+                    wv::wave_sync();
+                    G2_X(6);
                 }
+                if (first == ne) continue;
                 if (single && len0 >= k) {
                     // ---- the heap is full: every remaining candidate either replaces the root (heap.Fix(0), a sift from the top) or is not
                     // less than it. A sift only ever touches deeper levels as it goes, so the next replacement may start two steps behind
@@ -1126,7 +1178,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             }
         }
         G2_X(7);
-        if (F.on) { g2_flat_flush(A, F, k, f_cand, f_pre); G2_X(3); }   // the stream ended in flat mode
+        if (F.on) { g2_flat_flush(A, F, k, f_cand, f_pre, f_left); G2_X(3); }   // the stream ended in flat mode
         while (wv::ballot(p_act)) {   // the replacements still in flight run to their ends
             const u32 j1 = 2u * p_hole + 1u;
             const bool has = p_act && j1 < k;
@@ -1546,7 +1598,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
     G2Mail* mb = reinterpret_cast<G2Mail*>(l);
     G2Stage* sg = reinterpret_cast<G2Stage*>(l + 512);
-    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 16 <= G2_PRE_OFF && G2_PRE_OFF + 16 * G2_FLAT_MAXK <= G2_FLAT_OFF && G2_FLAT_OFF + 8 * G2_FLAT_MAXK <= G2_LDS_FIXED, "fixed LDS layout");
+    static_assert(sizeof(G2Mail) <= 512 && 512 + sizeof(G2Stage) <= 2048 && 2048 + G2_VISW * 64 * 16 <= G2_PRE_OFF && G2_PRE_OFF + 16 * G2_FLAT_MAXK <= G2_FLAT_OFF && G2_FLAT_OFF + 8 * G2_FLAT_MAXK <= G2_LEFT_OFF && G2_LEFT_OFF + 16 * G2_FLAT_MAXK <= G2_LDS_FIXED, "fixed LDS layout");
     const u32 wave = wv::wave(), lane = wv::lane(), nh = wv::nthreads() / 64u - 1u;
     if (wv::tid() == 0) { mb->posted = 0; mb->done = 0; mb->quit = 0; }
     wv::barrier();
@@ -1555,7 +1607,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         g2_helper(a, mb, wave - 1u, nh);
         return;
     }
-    g2_pre_table(reinterpret_cast<u64*>(l + G2_PRE_OFF));
+    g2_pre_table(reinterpret_cast<u64*>(l + G2_PRE_OFF), reinterpret_cast<u64*>(l + G2_LEFT_OFF));
     wv::setprio<3>();   // the machine's instructions go first on its SIMD: the helper waves it shares it with only fill the gaps
     u64 gt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 gx[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
