@@ -342,37 +342,46 @@ WV_DEV void g2_pop_all(const G2Arena& A, u32 base, int len) {
 
 // (a group's record is copied to registers field by field; its two small arrays are only ever read through the record in
 // memory — `Gm` — because an array indexed by a loop counter would drag the whole copy into scratch memory)
-WV_DEV bool g2_res_ok(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 n) {   // ResourceFilter.Check, filter.go:76-95
-    if (!(G.cpu <= a.cpu[n] && G.mem <= a.mem[n])) return false;
-    for (u32 q = 0; q < G.n_gen; ++q)
-        if (a.gcnt[(size_t)Gm->gkind[q] * a.gstride + n] < Gm->gval[q]) return false;   // HasEnough, validate.go:24-52
-    return true;
-}
 
 // Pipeline.Process on node n for group G (pipeline.go:56-68: the FIRST failing filter in checklist order: Ready, Resource, Plugin,
 // Constraint, Platform, HostPort, MaxReplicas, Volumes — scheduler.go:60-66) and the node's nodeLess key. Returns the first failing
 // filter (G2_FF_PASS, G2_FF_ABSENT); `listed`: the node is on the group's static class list (present and passing Ready, Plugin,
 // Constraint, Platform). LISTED: the caller took n FROM that list, so those five are not looked at again.
-template <bool LISTED>
-WV_DEV u32 g2_process(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n, u64& key, bool& listed) {
+// OVR: the node's residuals and task count are handed in (the write-back has them in registers: g2_group's fused pass).
+// Every input is REQUESTED before any of them is looked at — one memory round trip, not one per filter of the chain (class 0 = "no
+// such filter" has a row like any other: it is loaded and not looked at).
+template <bool LISTED, bool OVR = false>
+WV_DEV u32 g2_process(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n, u64& key, bool& listed, i64 ocpu = 0, i64 omem = 0,
+                      u32 ototal = 0) {
     const u32 N = a.n_nodes, Wn = a.n_words, w = n >> 6;
     const u64 bit = 1ull << (n & 63);
+    const u64 vw = LISTED ? ~0ull : a.valid[w], rw = LISTED ? ~0ull : a.ready[w];
+    const u64 pw = LISTED ? ~0ull : a.plug[(size_t)G.cls_plug * Wn + w];
+    const u64 cw = LISTED ? ~0ull : a.con[(size_t)G.cls_con * Wn + w];
+    const u64 tw = LISTED ? ~0ull : a.plat[(size_t)G.cls_plat * Wn + w];
+    const u32 sv = a.svc_dense[(size_t)b * N + n], fl = a.fail_dense[(size_t)b * N + n];
+    const i64 c = OVR ? ocpu : a.cpu[n], m = OVR ? omem : a.mem[n];
+    const u32 tot = OVR ? ototal : a.total[n];
     key = 0;
     listed = LISTED;
-    if (!LISTED && !(a.valid[w] & bit)) return G2_FF_ABSENT;
-    const u32 sv = a.svc_dense[(size_t)b * N + n], fl = a.fail_dense[(size_t)b * N + n];
-    bool ready = true;
+    if (!LISTED && !(vw & bit)) return G2_FF_ABSENT;
+    const bool ready = LISTED || (rw & bit) != 0;
     u32 sff = G2_FF_PASS;   // the first failing one of Plugin / Constraint / Platform
     if (!LISTED) {
-        ready = (a.ready[w] & bit) != 0;
-        if (G.cls_plug && !(a.plug[(size_t)G.cls_plug * Wn + w] & bit)) sff = 2;
-        else if (G.cls_con && !(a.con[(size_t)G.cls_con * Wn + w] & bit)) sff = 3;
-        else if (G.cls_plat && !(a.plat[(size_t)G.cls_plat * Wn + w] & bit)) sff = 4;
+        if (G.cls_plug && !(pw & bit)) sff = 2;
+        else if (G.cls_con && !(cw & bit)) sff = 3;
+        else if (G.cls_plat && !(tw & bit)) sff = 4;
         listed = ready && sff == G2_FF_PASS;
+    }
+    bool res = true;   // ResourceFilter.Check, filter.go:76-95
+    if (G.flags & RT_RES) {
+        res = G.cpu <= c && G.mem <= m;
+        for (u32 q = 0; q < G.n_gen; ++q)
+            if (a.gcnt[(size_t)Gm->gkind[q] * a.gstride + n] < Gm->gval[q]) res = false;   // HasEnough, validate.go:24-52
     }
     u32 ff = G2_FF_PASS;
     if (!ready) ff = 0;
-    else if ((G.flags & RT_RES) && !g2_res_ok(a, G, Gm, n)) ff = 1;
+    else if (!res) ff = 1;
     else if (sff != G2_FF_PASS) ff = sff;
     else {
         bool busy = false;
@@ -384,7 +393,7 @@ WV_DEV u32 g2_process(const Groups2Args& a, const GroupRec2& G, const GroupRec2*
         else if (G.mset && !((vol_filter_word(a.vol, G.mset, w) >> (n & 63u)) & 1ull)) ff = 7;   // VolumesFilter, the pipeline's last entry
     }
     if (!g2_key_ok(fl, sv)) a.ctl->error = ERR_GROUP_RANGE;
-    key = g2_key(fl, sv, a.total[n]);
+    key = g2_key(fl, sv, tot);
     return ff;
 }
 // A node that got a task since the next group was evaluated is evaluated again: its Explain record, and — if it is on that group's
@@ -693,13 +702,29 @@ WV_DEV void g2_post(G2Mail* mb, G2Post& P, u32 op, u32 gi) {
     if (wv::lane() == 0) wv::lds_publish32(&mb->posted, P.n);
 }
 
+// A group's Explain command is not waited for where it is posted: the helpers count while the machine writes the group back and admits
+// the next one. It is taken before the NEXT group's Explain section — which may overwrite xroot / xadm / cntx, and which comes in front
+// of that group's write-back (the command evaluates unlisted nodes from their rows: only ITS OWN group's write-back leaves those alone).
+struct G2Pend {
+    u32 on, gi, cmd;
+};
+WV_DEV bool g2_take_explain(const Groups2Args& a, G2Mail* mb, G2Pend& X, u32 nh) {
+    if (!X.on) return true;
+    if (!g2_wait_ge(&mb->done, X.cmd * nh, mb)) return false;
+    const u32 lane = wv::lane();
+    if (lane < 8) a.hist[(size_t)X.gi * 8 + lane] += mb->cntx[lane];
+    wv::wave_sync();
+    X.on = 0;
+    return true;
+}
+
 // One group, state in the arena A (LDS instance: L == true). Returns false when the launch must end (error / hang).
 // gi + 1 < n_groups: `eval_next` is the ring position behind the next group's EVAL command if it was posted ahead (0: it was not,
 // dep_prev); on return it always is.
 // GEN: the group reserves generic resources (the instance without them carries none of that code)
 template <bool L, bool GEN>
 WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned char* arena_base, const GroupRec2& G, u32 gi, u64* gt, u64* gx, G2Post& P, u32 nh,
-                     u32& eval_next) {
+                     u32& eval_next, G2Pend& X) {
     const u32 lane = wv::lane(), N = a.n_nodes, Wn = a.n_words, b = gi & 1u, k = G.k;
     const u32 tbase = a.tree_off[G.tree], ntn = a.tree_off[G.tree + 1] - tbase;
     const bool single = ntn == 1;
@@ -1507,28 +1532,83 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
     G2_TICK(4);
 
     // ---------- Explain counters for a group with leftovers (pipeline.go:56-68 call sequence: tree()'s calls, then the fill phase's) ----------
+    if (!g2_take_explain(a, mb, X, nh)) return false;   // (the group before)
     if (mb->sh[SH_LEFT] > 0) {
         const u32 fpass = mb->sh[SH_FPASS];
+        if (lane < 8) {   // the fill phase's share now, tree()'s share when the helpers have counted it (g2_take_explain)
+            u32 v = 0;
+            if (lane == 1) v = mb->sh[SH_C1];
+            if (lane == 5) v = mb->sh[SH_C5];
+            if (lane == 6) v = mb->sh[SH_C6];
+            if (lane == 7) v = mb->sh[SH_C7];
+            a.hist[(size_t)gi * 8 + lane] = v;
+        }
         if (!fpass) {   // no Process passed after tree(): the failing calls inside tree() behind its last passing one count, too
             for (u32 i = lane; i < ntn; i += 64) { a.xroot[i] = A.rootkey[i]; a.xadm[i] = A.h_adm[i]; }
             if (lane < 8) mb->cntx[lane] = 0;
             if (lane == 0) { mb->x_lastp = mb->sh[SH_LASTP]; mb->x_k = k; }
+            wv::wait_vm();
             g2_post(mb, P, G2_OP_EXPLAIN, gi);
-            if (!g2_wait_ge(&mb->done, P.n * nh, mb)) return false;
-        }
-        if (lane < 8) {
-            u32 v = fpass ? 0u : mb->cntx[lane];
-            if (lane == 1) v += mb->sh[SH_C1];
-            if (lane == 5) v += mb->sh[SH_C5];
-            if (lane == 6) v += mb->sh[SH_C6];
-            if (lane == 7) v += mb->sh[SH_C7];
-            a.hist[(size_t)gi * 8 + lane] = v;
+            X.on = 1; X.gi = gi; X.cmd = P.n;
         }
     }
     G2_TICK(5);
 
     // ---------- write-back of the nodes that got a task: node rows, host ports, generic counts, the service's (node, count) list ----------
     const u32 nt = mb->sh[SH_NTOUCH];
+    // The usual case — the next group was evaluated ahead, this one takes neither host ports nor generic resources — does the write-back
+    // and the next group's patch in ONE pass over the touched nodes: the node's row, its place in the service's list and everything the
+    // next group's Process reads are requested together (one memory round trip), the patch is evaluated on the new residuals from
+    // registers, then everything is stored.
+    const bool fuse = gi + 1 < a.n_groups && eval_next != 0 && !(G.flags & RT_PORTS) && NG == 0;
+    if (fuse) {
+        const GroupRec2* Gnm = a.g + gi + 1;
+        const GroupRec2 Gn = *Gnm;
+        const u32 bn = (gi + 1) & 1u;
+        const bool counted = !(G.flags & RT_UNCOUNTED);
+        const u32 lbase = a.list_off[G.svc];
+        u32 lcnt = a.list_cnt[G.svc];
+        if (!g2_wait_ge(&mb->done, eval_next * nh, mb)) return false;
+        for (u32 i0 = 0; i0 < nt; i0 += 64) {
+            const u32 i = i0 + lane;
+            const bool act = i < nt;
+            const u32 n = act ? A.tnode[i] : 0u, pl = act ? A.tcount[i] : 0u;
+            const i64 oc = a.cpu[n], om = a.mem[n];
+            const u32 ot = a.total[n];
+            const u32 e1 = a.lpos_dense[(size_t)b * N + n], osv = a.svc_dense[(size_t)b * N + n];
+            const u32 cp = a.cpos[(size_t)bn * N + n];
+            const i64 nc = oc - (i64)pl * G.cpu, nm = om - (i64)pl * G.mem;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
+            const u32 ntot = ot + (counted ? pl : 0u);
+            u64 key;
+            bool listed;
+            const u32 ff = g2_process<false, true>(a, Gn, Gnm, bn, n, key, listed, nc, nm, ntot);
+            const bool app = act && counted && e1 == 0u;
+            if (act) {
+                a.cpu[n] = nc;
+                a.mem[n] = nm;
+                if (counted) {
+                    a.total[n] = ntot;
+                    if (e1) a.list_svc[e1 - 1u] = osv + pl;   // (the dense column IS the list entry's count since the scatter)
+                }
+                a.ffbuf[(size_t)bn * N + n] = (unsigned char)ff;
+                a.keybuf[(size_t)bn * N + n] = key;
+                if (listed) a.ccand[(size_t)bn * N + cp].key = ff == G2_FF_PASS ? key : KEY_NONE;
+            }
+            const u64 bal = wv::ballot(app);
+            if (app) {
+                const u32 e = lbase + lcnt + wv::mbcnt(bal);
+                a.list_node[e] = n; a.list_svc[e] = pl; a.list_fail[e] = 0;
+            }
+            lcnt += (u32)wv::popc64(bal);
+        }
+        if (lane == 0) a.list_cnt[G.svc] = lcnt;
+        wv::wait_vm();
+        g2_post(mb, P, G2_OP_UNSCATTER, gi);
+        G2_TICK(6);
+        wv::lockstep();
+        G2_TICK(7);
+        return true;
+    }
     {
         const bool counted = !(G.flags & RT_UNCOUNTED);
         const u32 lbase = a.list_off[G.svc];
@@ -1644,6 +1724,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     }
     u32 eval_cur = P.n;
     bool ok = true;
+    G2Pend X{0, 0, 0};
     for (u32 gi = 0; gi < a.n_groups && ok; ++gi) {
         if (!g2_wait_ge(&mb->done, eval_cur * nh, mb)) { ok = false; break; }
         if (wv::g_fresh32(&a.ctl->error) != ERR_NONE) { ok = false; break; }
@@ -1663,12 +1744,13 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         }
         const u32 ntn = a.tree_off[G.tree + 1] - a.tree_off[G.tree];
         const bool in_lds = g2_arena_bytes(G.n_slots, ntn, G.n_gen, a.max_depth, G.k) <= G2_ARENA_LDS;
-        if (in_lds && !G.n_gen) ok = g2_group<true, false>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, gx, P, nh, eval_next);
-        else if (in_lds) ok = g2_group<true, true>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, gx, P, nh, eval_next);
-        else ok = g2_group<false, true>(a, mb, sg, a.arena, G, gi, gt, gx, P, nh, eval_next);
+        if (in_lds && !G.n_gen) ok = g2_group<true, false>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, gx, P, nh, eval_next, X);
+        else if (in_lds) ok = g2_group<true, true>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, gx, P, nh, eval_next, X);
+        else ok = g2_group<false, true>(a, mb, sg, a.arena, G, gi, gt, gx, P, nh, eval_next, X);
         eval_cur = eval_next;
         if (a.dbg & 16u) tk = wv::clock64();
     }
+    if (ok) ok = g2_take_explain(a, mb, X, nh);   // the last group's
     if (!ok && lane == 0) {
         if (wv::lds_poll32(&mb->quit) && wv::g_fresh32(&a.ctl->error) == ERR_NONE) a.ctl->error = ERR_GROUP_HANG;
         wv::lds_publish32(&mb->quit, 1u);   // helpers leave their wait loops
