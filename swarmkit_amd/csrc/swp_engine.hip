@@ -2862,7 +2862,7 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
                 c2.cyc[0], c2.cyc[1], c2.cyc[2], c2.cyc[3], c2.cyc[4], c2.cyc[5], c2.cyc[6], c2.cyc[7], c2.m_cyc[0], c2.m_cyc[1], c2.l_cyc[0], c2.l_cyc[1], c2.l_cyc[2], c2.l_cyc[3], c2.l_cyc[4], c2.l_cyc[5]);
         fprintf(stderr, "[swp] k_groups2 admission, cycles by part: records %llu, whole chunks while filling %llu, flat counting %llu, flushes %llu, staging %llu, per-chunk pass %llu, replay + pipelined %llu, minima scan %llu\n",
                 c2.wave_cyc[0], c2.wave_cyc[1], c2.wave_cyc[2], c2.wave_cyc[3], c2.wave_cyc[4], c2.wave_cyc[5], c2.wave_cyc[6], c2.wave_cyc[7]);
-        fprintf(stderr, "[swp] k_groups2 latency probe (cycles, helpers idle): clock %llu, cold line %llu, same line %llu, another line %llu, LDS round trip %llu\n", c2.wave_cyc[8], c2.wave_cyc[9], c2.wave_cyc[10], c2.wave_cyc[11], c2.wave_cyc[12]);
+        fprintf(stderr, "[swp] k_groups2 sort section, cycles: equal-keys check %llu, rotation / lane 0's pops %llu, residual loads %llu\n", c2.wave_cyc[8], c2.wave_cyc[9], c2.wave_cyc[10]);
         fprintf(stderr, "[swp] k_groups2 batches of candidate records: %llu, %llu cycles from the first load to the last answer\n", c2.wave_cyc[14], c2.wave_cyc[13]);
         (void)hipEventDestroy(gev0); (void)hipEventDestroy(gev1);
     }

@@ -6,7 +6,7 @@
 #include "swp_wave.hpp"
 #ifdef SWP_G2_STATS   // experiments only (make EXTRA=-DSWP_G2_STATS): which admission path the machine took, counted on the device
 #include <stdio.h>
-namespace swpdev { __device__ unsigned long long g2_stat_dev[8]; }
+namespace swpdev { __device__ unsigned long long g2_stat_dev[12]; }
 #define G2_STAT(i, v) do { if (wv::lane() == 0) atomicAdd(&swpdev::g2_stat_dev[i], (unsigned long long)(v)); } while (0)
 #endif
 #define SWP_G2_KERNELS
@@ -29,12 +29,13 @@ hipError_t launch_groups2(const Groups2Args& a, hipStream_t s, int dev) {
     hipLaunchKernelGGL(k_groups2, dim3(1), dim3(threads), g2_lds_bytes(), s, a);
 #ifdef SWP_G2_STATS
     {
-        unsigned long long h[8] = {0}, z[8] = {0};
+        unsigned long long h[12] = {0}, z[12] = {0};
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g2_stat_dev), sizeof h);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g2_stat_dev), z, sizeof z);
         fprintf(stderr, "[swp] k_groups2 paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu chunks taken whole in flat mode, %llu chunks appended whole while filling, %llu pushes sifted up by the wave\n",
                 h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        fprintf(stderr, "[swp] k_groups2 sort: %llu heaps popped by lane 0, %llu elements in them, %llu of them with the root's key\n", h[9], h[11], h[10]);
     }
 #endif
     return hipGetLastError();

@@ -1249,6 +1249,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             }
         }
         wv::wave_sync();
+        if (a.dbg & 16u) tx = wv::clock64();
         if (single) {
             // One leaf. When every key in the heap is the same, no pop moves anything but the two elements it swaps, and the heap-sort
             // comes out as a rotation by one — new[j] = old[(j + 1) % len] — which all lanes do together; otherwise lane 0 pops.
@@ -1256,19 +1257,79 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             const u64 k0 = len ? A.HE[0].key : 0ull;
             bool differs = false;
             for (u32 pos = lane; pos < len; pos += 64) differs |= A.HE[pos].key != k0;
-            if (wv::ballot(differs) == 0) {
-                if (len >= 2) {
+            bool same_ = wv::ballot(differs) == 0;
+            G2_X(10);
+            u32 rl_ = len;   // the heap's front [0, rl_) still to be sorted when the keys in it are all the same
+            if (!same_ && len <= G2_FLAT_MAXK) {
+                // TWO keys (the root's: "heavy", and one other): heap-sort by the WAVE. While a heavy element is left the root is heavy. A pop
+                // takes the last element x: if x is heavy it stays at the root (no child is greater); if it is light it sifts down — to the
+                // left child if that is heavy, else to the right one if that is heavy, else it stays: it comes to rest at the heavy position
+                // a post-order walk visits first, and the heavy elements on its way move up one place (the flat mode's argument, G2Flat).
+                // Either way one heavy position goes: the path is known from the MASK of heavy positions alone, and the moves of one pop are
+                // one LDS round trip for the lanes along the path. When the front that is left holds one key, the rotation finishes it.
+                const u64 kk0 = lane < len ? A.HE[lane].key : k0, kk1 = lane + 64u < len ? A.HE[lane + 64u].key : k0;
+                const u64 o0 = kk0 != k0 ? kk0 : KEY_NONE, o1 = kk1 != k0 ? kk1 : KEY_NONE;
+                const u64 lo_ = g2_wave_min64(o0 < o1 ? o0 : o1);
+                if (wv::ballot((kk0 != k0 && kk0 != lo_) || (kk1 != k0 && kk1 != lo_)) == 0) {
+                    const u64* pre_ = reinterpret_cast<const u64*>(reinterpret_cast<unsigned char*>(mb) + G2_PRE_OFF);
+                    u64 s0 = wv::ballot(lane < len && kk0 == k0), s1 = wv::ballot(lane + 64u < len && kk1 == k0);
+                    u32 m = len - 1u;
+                    for (;;) {
+                        const u32 hcnt = (u32)wv::popc64(s0) + (u32)wv::popc64(s1);
+                        if (hcnt == 0u || hcnt == m + 1u) break;   // one key in [0, m]
+                        const bool last_heavy = ((m < 64u ? s0 >> m : s1 >> (m - 64u)) & 1ull) != 0;
+                        u32 src = 0, dst = 0;
+                        bool act = false;
+                        u32 q = m;   // the heavy position that goes
+                        if (last_heavy) {   // x stays at the root, the root goes to m
+                            if (lane == 0) { act = true; src = m; dst = 0; }
+                        } else {
+                            const bool f0 = ((s0 >> lane) & 1ull) && (s0 & pre_[2u * lane]) == 0 && (s1 & pre_[2u * lane + 1u]) == 0;
+                            const bool f1 = ((s1 >> lane) & 1ull) && (s0 & pre_[2u * (lane + 64u)]) == 0 && (s1 & pre_[2u * (lane + 64u) + 1u]) == 0;
+                            const u64 b0 = wv::ballot(f0), b1 = wv::ballot(f1);
+                            q = b0 ? (u32)wv::ffs64(b0) : 64u + (u32)wv::ffs64(b1);
+                            const u32 dq = 31u - (u32)wv::clz32(q + 1u);
+                            if (lane <= dq) {   // lane d: the path's position at depth d takes the element one level down (the last one takes x)
+                                act = true;
+                                dst = ((q + 1u) >> (dq - lane)) - 1u;
+                                src = lane < dq ? ((q + 1u) >> (dq - lane - 1u)) - 1u : m;
+                            }
+                        }
+                        if (lane == 63u) { act = true; src = 0; dst = m; }   // the popped root
+                        const G2Ent e = A.HE[act ? src : 0u];
+                        wv::lockstep();   // every lane holds its element before any position is rewritten
+                        if (act) {
+                            G2Ent he;
+                            he.key = e.key; he.node = e.node; he.tix = e.tix;
+                            A.HE[dst] = he;
+                        }
+                        wv::wave_sync();
+                        if (q < 64u) s0 &= ~(1ull << q);
+                        else s1 &= ~(1ull << (q - 64u));
+                        m -= 1u;
+                        G2_STAT(8, 1);
+                    }
+                    rl_ = m + 1u;
+                    same_ = true;
+                }
+            }
+            if (same_) {
+                if (rl_ >= 2) {
                     const G2Ent head = A.HE[0];
-                    for (u32 j0 = 0; j0 < len; j0 += 64) {
+                    for (u32 j0 = 0; j0 < rl_; j0 += 64) {
                         const u32 j = j0 + lane;
-                        const G2Ent nx = A.HE[j + 1 < len ? j + 1 : 0u];
-                        const G2Ent v = g2_pick(j + 1 < len, nx, head);   // (field by field: a record selected as a whole lives in scratch memory)
+                        const G2Ent nx = A.HE[j + 1 < rl_ ? j + 1 : 0u];
+                        const G2Ent v = g2_pick(j + 1 < rl_, nx, head);   // (field by field: a record selected as a whole lives in scratch memory)
                         wv::lockstep();   // every lane has read its element before any lane overwrites one
-                        if (j < len) A.HE[j] = v;
+                        if (j < rl_) A.HE[j] = v;
                     }
                 }
-            } else if (lane == 0) g2_pop_all(A, 0u, (int)len);
+            } else {
+                G2_STAT(9, 1);
+                if (lane == 0) g2_pop_all(A, 0u, (int)len);
+            }
             wv::wave_sync();
+            G2_X(11);
         }
         if (single) {   // one leaf: all lanes load its positions
             const u32 len = (u32)A.h_cnt[0];
@@ -1280,6 +1341,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 for (u32 z = 0; z < NG; ++z) A.gen[(size_t)pos * NG + z] = a.gcnt[(size_t)Gm->gkind[z] * a.gstride + n];
             }
             wv::wave_sync();
+            G2_X(12);
         }
     }
     G2_TICK(3);
@@ -1690,30 +1752,9 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     g2_pre_table(reinterpret_cast<u64*>(l + G2_PRE_OFF), reinterpret_cast<u64*>(l + G2_LEFT_OFF));
     wv::setprio<3>();   // the machine's instructions go first on its SIMD: the helper waves it shares it with only fill the gaps
     u64 gt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    u64 gx[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 gx[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
     G2Post P{0};
-    if (a.dbg & 16u) {   // latency probe (helpers idle): clock overhead, a cold line, the same line again (L1), its neighbour (L2 or further), an LDS round trip
-        const u64 c0 = wv::clock64();
-        const u64 c1 = wv::clock64();
-        u64 v = a.ccand[lane].key;
-        wv::wait_vm();
-        const u64 c2 = wv::clock64();
-        v += a.ccand[lane].key + (v & 1ull);
-        wv::wait_vm();
-        const u64 c3 = wv::clock64();
-        v += a.ccand[(size_t)a.n_nodes + lane + (v & 1ull)].key;
-        wv::wait_vm();
-        const u64 c4 = wv::clock64();
-        mb->sh[15] = (u32)v;
-        wv::wave_sync();
-        const u32 lv = mb->sh[15];
-        wv::wave_sync();
-        const u64 c5 = wv::clock64();
-        if (lane == 0) {
-            a.ctl->wave_cyc[8] = c1 - c0; a.ctl->wave_cyc[9] = c2 - c1; a.ctl->wave_cyc[10] = c3 - c2; a.ctl->wave_cyc[11] = c4 - c3; a.ctl->wave_cyc[12] = c5 - c4 + (lv & 0u);
-        }
-    }
     {   // the first group is prepared with nothing to overlap
         const GroupRec2 G0 = a.g[0];
         const u32 ntn0 = a.tree_off[G0.tree + 1] - a.tree_off[G0.tree];
@@ -1763,7 +1804,8 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         for (int q = 0; q < 6; ++q) a.ctl->l_cyc[q] = gt[10 + q];
         for (int q = 0; q < 8; ++q) a.ctl->wave_cyc[q] = gx[q];
         a.ctl->wave_cyc[13] = gx[8];
-        a.ctl->wave_cyc[14] = gx[9];   // admission: words visited, candidates staged, heap operations, cycles inside lane 0's replay
+        a.ctl->wave_cyc[14] = gx[9];
+        for (int q = 0; q < 4; ++q) a.ctl->wave_cyc[8 + q] = gx[10 + q];   // admission: words visited, candidates staged, heap operations, cycles inside lane 0's replay
     }
 }
 

@@ -12,7 +12,7 @@
 // which of the machine's admission paths a run took (the kernel's G2_STAT hook; the product compiles it away): [0] heaps that went into
 // flat mode, [1] candidates that entered by the post-order scatter, [2] ... by the one-by-one replay of a flush, [3] flushes forced by a
 // candidate with a third key, [4] root replacements of the ordinary pipelined code, [5] node words whose candidates were taken by a whole batch in flat mode, [6] node words appended whole while a heap of one key was filling
-static unsigned long long g2_stat[8];
+static unsigned long long g2_stat[12];
 #define G2_STAT(i, v) do { if (wv::lane() == 0) g2_stat[i] += (unsigned long long)(v); } while (0)
 #define SWP_G2_KERNELS
 #include "../../swarmkit_amd/csrc/swp_groups.hpp"
@@ -549,8 +549,8 @@ int main(int argc, char** argv) {
         lds_groups += g2_arena_bytes(p.groups[g].n_slots, tree_off[p.groups[g].tree + 1] - tree_off[p.groups[g].tree], p.groups[g].n_gen, max_depth, p.groups[g].k) <= G2_ARENA_LDS;
     }
     if (verbose || bad) {
-        fprintf(stderr, "admission paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu words taken by whole batches in flat mode, %llu words appended whole while a heap of one key filled, %llu pushes sifted up by the wave\n",
-                g2_stat[0], g2_stat[1], g2_stat[2], g2_stat[3], g2_stat[4], g2_stat[5], g2_stat[6], g2_stat[7]);
+        fprintf(stderr, "admission paths: %llu heaps in flat mode, %llu candidates by the post-order scatter, %llu by a flush's replay, %llu flushes forced by a third key, %llu pipelined root replacements, %llu words taken by whole batches in flat mode, %llu words appended whole while a heap of one key filled, %llu pushes sifted up by the wave, %llu pops of two-key heaps by the wave, %llu heaps popped by lane 0\n",
+                g2_stat[0], g2_stat[1], g2_stat[2], g2_stat[3], g2_stat[4], g2_stat[5], g2_stat[6], g2_stat[7], g2_stat[8], g2_stat[9]);
         fprintf(stderr, "emu_groups seed %u N %u groups %zu (LDS arena: %u) trees %zu: %u of %zu tasks placed, %u groups with an explanation -> %s\n", seed, N,
                 p.groups.size(), lds_groups, p.trees.size(), placed, out.size(), left_groups, bad ? "FAILED" : "OK");
     }
