@@ -435,6 +435,10 @@ WV_DEV void g2_static_list(const Groups2Args& a, u32 c) {
     }
     if (lane == 0) a.scnt[c] = run;
 }
+WV_DEV u32 g2_fls64(u64 v) {   // index of the highest set bit (v != 0)
+    const u32 hi = (u32)(v >> 32);
+    return hi ? 63u - (u32)wv::clz32(hi) : 31u - (u32)wv::clz32((u32)v);
+}
 WV_DEV u64 g2_wave_min64(u64 v) {
     const u32 hi = (u32)(v >> 32), lo = (u32)v;
     const u32 mh = wv::min_u32(hi);
@@ -1272,42 +1276,74 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 const u64 lo_ = g2_wave_min64(o0 < o1 ? o0 : o1);
                 if (wv::ballot((kk0 != k0 && kk0 != lo_) || (kk1 != k0 && kk1 != lo_)) == 0) {
                     const u64* pre_ = reinterpret_cast<const u64*>(reinterpret_cast<unsigned char*>(mb) + G2_PRE_OFF);
+                    const u64* left_ = reinterpret_cast<const u64*>(reinterpret_cast<unsigned char*>(mb) + G2_LEFT_OFF);
                     u64 s0 = wv::ballot(lane < len && kk0 == k0), s1 = wv::ballot(lane + 64u < len && kk1 == k0);
                     u32 m = len - 1u;
                     for (;;) {
                         const u32 hcnt = (u32)wv::popc64(s0) + (u32)wv::popc64(s1);
                         if (hcnt == 0u || hcnt == m + 1u) break;   // one key in [0, m]
                         const bool last_heavy = ((m < 64u ? s0 >> m : s1 >> (m - 64u)) & 1ull) != 0;
-                        u32 src = 0, dst = 0;
-                        bool act = false;
-                        u32 q = m;   // the heavy position that goes
-                        if (last_heavy) {   // x stays at the root, the root goes to m
-                            if (lane == 0) { act = true; src = m; dst = 0; }
-                        } else {
-                            const bool f0 = ((s0 >> lane) & 1ull) && (s0 & pre_[2u * lane]) == 0 && (s1 & pre_[2u * lane + 1u]) == 0;
-                            const bool f1 = ((s1 >> lane) & 1ull) && (s0 & pre_[2u * (lane + 64u)]) == 0 && (s1 & pre_[2u * (lane + 64u) + 1u]) == 0;
-                            const u64 b0 = wv::ballot(f0), b1 = wv::ballot(f1);
-                            q = b0 ? (u32)wv::ffs64(b0) : 64u + (u32)wv::ffs64(b1);
-                            const u32 dq = 31u - (u32)wv::clz32(q + 1u);
-                            if (lane <= dq) {   // lane d: the path's position at depth d takes the element one level down (the last one takes x)
-                                act = true;
-                                dst = ((q + 1u) >> (dq - lane)) - 1u;
-                                src = lane < dq ? ((q + 1u) >> (dq - lane - 1u)) - 1u : m;
+                        if (last_heavy) {   // x stays at the root, the root goes to m: positions 0 and m change places
+                            const bool act = lane == 0u || lane == 63u;
+                            const G2Ent e = A.HE[lane == 0u ? m : 0u];
+                            wv::lockstep();
+                            if (act) {
+                                G2Ent he;
+                                he.key = e.key; he.node = e.node; he.tix = e.tix;
+                                A.HE[lane == 0u ? 0u : m] = he;
+                            }
+                            wv::wave_sync();
+                            if (m < 64u) s0 &= ~(1ull << m);
+                            else s1 &= ~(1ull << (m - 64u));
+                            m -= 1u;
+                            G2_STAT(8, 1);
+                            continue;
+                        }
+                        // A RUN of light pops: the positions m, m - 1, ... down to the highest heavy one are light, so the next t pops (t <= the
+                        // heavy elements left) each take a light x — t root replacements in a row with the "candidates" HE[m], HE[m - 1], ...:
+                        // g2_flat_flush's closed form (x_j comes to rest at the j-th heavy position in post-order; the element from heavy
+                        // position p moves up once per pop from pop b(p) on), and the element that leaves at the root in pop j — the one
+                        // with b(p) + depth(p) == j — is what the pop puts at position m - j.
+                        const u32 hb = s1 ? 64u + g2_fls64(s1) : g2_fls64(s0);   // the highest heavy position (below m: m is light)
+                        const u32 t = min(m - hb, hcnt);
+                        G2Ent old[2], xin[2];
+                        u32 rp[2], mv[2], bp[2];
+                        bool hv[2];
+                        WV_UNROLL
+                        for (u32 h = 0; h < 2u; ++h) {
+                            const u32 p = lane + 64u * h;
+                            hv[h] = (((h ? s1 : s0) >> lane) & 1ull) != 0;
+                            rp[h] = 0; mv[h] = 0; bp[h] = 0;
+                            if (hv[h]) {
+                                rp[h] = (u32)wv::popc64(s0 & pre_[2u * p]) + (u32)wv::popc64(s1 & pre_[2u * p + 1u]);
+                                bp[h] = (u32)wv::popc64(s0 & left_[2u * p]) + (u32)wv::popc64(s1 & left_[2u * p + 1u]);
+                                mv[h] = t > bp[h] ? t - bp[h] : 0u;
+                            }
+                            old[h] = A.HE[hv[h] ? p : 0u];
+                            xin[h] = A.HE[hv[h] && rp[h] < t ? m - rp[h] : 0u];
+                        }
+                        wv::lockstep();   // every lane holds what it needs before any position is rewritten
+                        WV_UNROLL
+                        for (u32 h = 0; h < 2u; ++h) {
+                            const u32 p = lane + 64u * h;
+                            if (!hv[h]) continue;
+                            if (rp[h] < t) {
+                                G2Ent he;
+                                he.key = xin[h].key; he.node = xin[h].node; he.tix = xin[h].tix;
+                                A.HE[p] = he;
+                            }
+                            if (mv[h] != 0) {
+                                const u32 dp = 31u - (u32)wv::clz32(p + 1u);
+                                G2Ent he;
+                                he.key = old[h].key; he.node = old[h].node; he.tix = old[h].tix;
+                                A.HE[mv[h] <= dp ? ((p + 1u) >> mv[h]) - 1u : m - (bp[h] + dp)] = he;
                             }
                         }
-                        if (lane == 63u) { act = true; src = 0; dst = m; }   // the popped root
-                        const G2Ent e = A.HE[act ? src : 0u];
-                        wv::lockstep();   // every lane holds its element before any position is rewritten
-                        if (act) {
-                            G2Ent he;
-                            he.key = e.key; he.node = e.node; he.tix = e.tix;
-                            A.HE[dst] = he;
-                        }
                         wv::wave_sync();
-                        if (q < 64u) s0 &= ~(1ull << q);
-                        else s1 &= ~(1ull << (q - 64u));
-                        m -= 1u;
-                        G2_STAT(8, 1);
+                        s0 = wv::ballot(hv[0] && rp[0] >= t);
+                        s1 = wv::ballot(hv[1] && rp[1] >= t);
+                        m -= t;
+                        G2_STAT(8, t);
                     }
                     rl_ = m + 1u;
                     same_ = true;
