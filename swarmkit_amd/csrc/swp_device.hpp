@@ -742,6 +742,21 @@ __global__ void k_units(u32 n, const i64* __restrict__ cpu, const i64* __restric
     q[2 * i + 1] = (int32_t)fd(mem[i], um);
 }
 
+// k_scatter_rows — the rows swp_node_update_dynamic changed (flush_nodes): flags word, residuals, task count of each
+struct DevRow {
+    u32 node, flags, total, pad;
+    i64 cpu, mem;
+};
+static_assert(sizeof(DevRow) == 32, "DevRow layout");
+__global__ void k_scatter_rows(u32 n, const DevRow* __restrict__ r, u32* flags, i64* cpu, i64* mem, u32* total) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevRow x = r[i];
+    flags[x.node] = x.flags;
+    cpu[x.node] = x.cpu;
+    mem[x.node] = x.mem;
+    total[x.node] = x.total;
+}
 struct DevPlacement { u32 node; u32 counted; i64 cpu, mem; };
 
 __global__ void k_commit(u32 n, const DevPlacement* __restrict__ p, int add, i64* cpu, i64* mem, u32* total) {

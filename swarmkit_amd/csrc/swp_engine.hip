@@ -471,6 +471,15 @@ struct swp_engine {
     uint32_t dev_gkinds = 0;
     bool dev_static_dirty = true;    // flags/os/arch/attr/ip/plugins need a re-upload
     bool dev_dynamic_dirty = true;   // cpu/mem/total need a re-upload
+    // Rows that swp_node_update_dynamic changed since the last flush (a drain flips one flag word, a correction moves one node's
+    // residuals): flush_nodes scatters exactly those — one pinned block, one copy, k_scatter_rows — instead of rebuilding and uploading
+    // every array, as long as they are few and nothing else is pending. `dev_flags_dirty`: some flag word changed, so a fallback to the
+    // whole-array path must carry the flags along (they are not one of the "dynamic" arrays).
+    std::vector<uint32_t> dirty_rows;
+    bool dev_flags_dirty = false;
+    PinBuf rows_stage;
+    DevBuf d_rows;
+    hipEvent_t rows_ev = nullptr;    // the last scatter's copy has read rows_stage
     uint32_t dev_cols = 0;
 
     // saved host state for swp_state_restore
@@ -604,8 +613,47 @@ int flush_nodes(swp_engine* e) {
         HIPCHECK(e, hipStreamSynchronize(e->stream));   // host vectors die at scope exit
         e->dev_cols = e->n_cols;
         e->dev_static_dirty = false;
+        e->dev_flags_dirty = false;
+    }
+    if (!e->dev_dynamic_dirty && !e->dirty_rows.empty()) {
+        if (e->dirty_rows.size() * 4 > (size_t)N) e->dev_dynamic_dirty = true;   // most of the node set: the whole arrays are cheaper
+        else {
+            const size_t R = e->dirty_rows.size();
+            if (e->rows_ev) HIPCHECK(e, hipEventSynchronize(e->rows_ev));   // (the block is free again: long since, as a rule)
+            else HIPCHECK(e, hipEventCreateWithFlags(&e->rows_ev, hipEventDisableTiming));
+            HIPCHECK(e, e->rows_stage.reserve(R * sizeof(DevRow)));
+            DevRow* rows = static_cast<DevRow*>(e->rows_stage.p);
+            for (size_t i = 0; i < R; ++i) {   // (a node listed twice carries its latest row twice)
+                const uint32_t n = e->dirty_rows[i];
+                const HostNode& h = e->nodes[n];
+                DevRow& r = rows[i];
+                r.node = n; r.pad = 0;
+                r.flags = h.present ? ((h.row.flags & 0x7FFFFFFFu) | DEV_VALID) : 0u;
+                r.total = h.present ? h.row.total : 0u;
+                r.cpu = h.present ? h.row.cpu : 0;
+                r.mem = h.present ? h.row.mem : 0;
+            }
+            HIPCHECK(e, e->d_rows.reserve(R * sizeof(DevRow)));   // (stream order: the last scatter's kernel is through before this copy lands)
+            HIPCHECK(e, hipMemcpyAsync(e->d_rows.p, rows, R * sizeof(DevRow), hipMemcpyHostToDevice, e->stream));
+            HIPCHECK(e, hipEventRecord(e->rows_ev, e->stream));
+            hipLaunchKernelGGL(k_scatter_rows, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, e->stream, (uint32_t)R, e->d_rows.as<DevRow>(), e->d_flags.as<uint32_t>(),
+                               e->d_cpu.as<long long>(), e->d_mem.as<long long>(), e->d_total.as<uint32_t>());
+            HIPCHECK(e, hipGetLastError());
+            e->dirty_rows.clear();
+            e->dev_flags_dirty = false;
+        }
+    }
+    if (e->dev_flags_dirty) {   // a flag word changed and the rows go up as whole arrays: the flags with them
+        std::vector<uint32_t> flags(cap, 0);
+        for (uint32_t n = 0; n < N; ++n)
+            if (e->nodes[n].present) flags[n] = (e->nodes[n].row.flags & 0x7FFFFFFFu) | DEV_VALID;
+        int rc;
+        if ((rc = upload(e, e->d_flags, flags))) return rc;
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        e->dev_flags_dirty = false;
     }
     if (e->dev_dynamic_dirty) {
+        e->dirty_rows.clear();
         std::vector<int64_t> cpu(cap, 0), mem(cap, 0);
         std::vector<uint32_t> total(cap, 0);
         for (uint32_t n = 0; n < N; ++n) {
@@ -2226,6 +2274,7 @@ void swp_destroy(swp_engine* e) {
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->rows_ev) (void)hipEventDestroy(e->rows_ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     const int dev = e->device;
     delete e;
@@ -2290,12 +2339,13 @@ int swp_node_update_dynamic(swp_engine* e, uint32_t node, uint32_t flags, int64_
     e->host_dirty_since_save = true;
     if (node >= e->nodes.size() || !e->nodes[node].present) return SWP_ENOTFOUND;
     HostNode& h = e->nodes[node];
-    if (h.row.flags != flags) e->dev_static_dirty = true;
+    const bool moved = h.row.flags != flags || h.row.cpu != cpu || h.row.mem != mem || h.row.total != total;
+    if (h.row.flags != flags) e->dev_flags_dirty = true;   // (the flags word alone: no other static array, no volume topology, depends on it)
     h.row.flags = flags;
     h.row.cpu = cpu;
     h.row.mem = mem;
     h.row.total = total;
-    e->dev_dynamic_dirty = true;
+    if (moved && !e->dev_dynamic_dirty) e->dirty_rows.push_back(node);   // (a pending whole-array upload carries the row anyway)
     return SWP_OK;
 }
 
@@ -3958,8 +4008,10 @@ int swp_state_restore(swp_engine* e) {
         e->svc_nodes = e->saved.svc_nodes_;
         e->port_nodes = e->saved.port_nodes_;
         e->host_dirty_since_save = false;
+        e->dev_flags_dirty = true;   // (flag words may have moved since the save: the mirror has the saved ones again, the device follows)
     }
     e->dev_dynamic_dirty = false;
+    e->dirty_rows.clear();           // (rows changed since the save: both sides hold the saved ones again)
     return SWP_OK;
 }
 

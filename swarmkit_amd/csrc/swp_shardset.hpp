@@ -516,7 +516,8 @@ int schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* 
             uint32_t g = 0, l = 0;
             if (!locate(S, (uint32_t)n, &g, &l)) return e->fail(SWP_EHIP, "the union engine placed a task on node index %d, which the set does not hold", n);
             host_apply_placement(S.sh[g], l, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
-            S.sh[g]->dev_dynamic_dirty = true;
+            if (d.generic_set) S.sh[g]->dev_dynamic_dirty = true;   // (generic counts are whole rows of their own)
+            else if (!S.sh[g]->dev_dynamic_dirty) S.sh[g]->dirty_rows.push_back(l);   // the owner's device row follows by scatter (flush_nodes)
             S.sh[g]->host_dirty_since_save = true;
             ++placed;
         }

@@ -169,7 +169,8 @@ template <class V> class IdTable {
     size_t live_ = 0;
 };
 
-class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queue at once, so nothing is ever compacted piecemeal)
+class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queue at once; a queue that is never taken whole — the preassigned
+                       // tasks, where one task that never fits keeps it alive — closes its holes once they outnumber the entries: compact())
   public:
     void put(const std::string& id, Value t, uint32_t tmpl = NO_TMPL) {
         const uint64_t h = hash_id(id);
@@ -192,6 +193,7 @@ class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queu
         items_[slot_[at]].second = Value();
         slot_[at] = GONE;   // (the probe chain stays intact)
         if (--live_ == 0) clear();
+        else if (items_.size() - live_ > 1024 && items_.size() > 2 * live_) compact();
     }
     void clear() {
         items_.clear();
@@ -199,6 +201,22 @@ class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queu
         std::fill(hash_.begin(), hash_.end(), 0);
         used_ = live_ = 0;
     }
+    // the live entries in their order, the erased ones dropped; the index rebuilt for what is left (sized from live_, not doubled)
+    void compact() {
+        std::vector<QItem> kept;
+        kept.reserve(live_);
+        for (size_t i = 0; i < items_.size(); ++i)
+            if (alive_[i]) kept.push_back(std::move(items_[i]));
+        items_.swap(kept);
+        alive_.assign(items_.size(), 1);
+        size_t cap = 1024;
+        while (cap < 4 * items_.size()) cap *= 2;
+        hash_.assign(cap, 0);
+        slot_.assign(cap, 0);
+        used_ = 0;
+        for (size_t i = 0; i < items_.size(); ++i) insert(hash_id(items_[i].first), (uint32_t)i);
+    }
+    size_t slots() const { return items_.size(); }   // entries held, erased ones included (tests)
     std::vector<QItem> snapshot() const {
         std::vector<QItem> out;
         out.reserve(live_);
@@ -244,6 +262,7 @@ class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queu
         ++used_;
     }
     void grow() {
+        if (items_.size() - live_ > 1024 && items_.size() > 2 * live_) { compact(); if ((used_ + 1) * 2 <= hash_.size()) return; }   // (cells of erased entries: not a reason to double)
         std::vector<uint64_t> oh;
         std::vector<uint32_t> os;
         oh.swap(hash_);

@@ -126,6 +126,31 @@ int main(int argc, char** argv) {
             CHECK(q.size() == order.size());
         }
     }
+    // ---- OrderedTasks that is never taken whole (the preassigned queue: ONE task that never fits keeps it alive): the erased entries
+    // of everything that came and went must not pile up (300k put / erase pairs next to one live entry held 49 MB) ----
+    {
+        OrderedTasks q;
+        q.put("stays", Value::integer(-1));
+        std::vector<std::string> live{"stays"};
+        size_t worst = 0;
+        for (long i = 0; i < 300000; ++i) {
+            const std::string id = "t" + std::to_string(i);
+            q.put(id, Value::integer(i));
+            if (i % 1000 == 999) live.push_back(id);   // a few more stay for good
+            else q.erase(id);
+            worst = std::max(worst, q.slots());
+            if (i % 50000 == 0) {
+                auto snap = q.snapshot();
+                CHECK(snap.size() == live.size());
+                for (size_t k = 0; k < snap.size() && k < live.size(); ++k) CHECK(snap[k].first == live[k]);
+            }
+        }
+        CHECK(q.size() == live.size());
+        CHECK(worst <= 2 * live.size() + 1100);   // holes never outnumber the entries by more than the compaction's slack
+        auto all = q.take_all();
+        CHECK(all.size() == live.size());
+        for (size_t k = 0; k < all.size() && k < live.size(); ++k) CHECK(all[k].first == live[k]);
+    }
     // ---- NodeTasks: flat while small, a tree beyond 48 entries; sorted iteration ----
     {
         for (int round = 0; round < 200; ++round) {
