@@ -209,3 +209,96 @@ class RankShard:
             self.dist.all_reduce(t)
             h = t.cpu().numpy().astype(np.uint32)
         return _finish(shard, node, self.firsts, [h])
+
+
+class RankUnionGroups:
+    """Task GROUPS in a job of ranks (SURVEY §8e "grouped top-k"; scheduler.go:449-461: replicated services ARE
+    groups, nodeset.go:107-120: a bounded heap per spread leaf over ALL nodes).
+
+    `scheduleTaskGroup` with k > 1 replays container/heap over the whole node set in node order — one sequential machine
+    (csrc/swp_groups.hpp); it is not sharded. A job of ranks therefore places a group on ONE rank: rank 0 keeps a UNION engine that holds
+    every node of the job by its global index (the caller sends it every node event, as a single engine would get them) and is kept in
+    step with what the ranks decide:
+
+      note_batch(descs, out)       after a sharded one-off batch (DeviceRankShard.run / RankShard.run): `out` — the same array on every
+                                   rank — enters the union as swp_commit(add);
+      commit(placements, add)      placements decided outside the engine / tasks going away, by GLOBAL node index: the owner applies its
+                                   share to its own engine, rank 0 the whole list to the union;
+      schedule_groups(groups, n)   rank 0 runs swp_schedule_groups on the union (k_groups2, which writes the placements back there
+                                   itself); out + Explain histograms travel to all ranks in ONE broadcast; every owner books the tasks
+                                   that landed in its range with swp_commit(add).
+
+    Bit-exact by construction: the union IS a single engine over the same state. The price is capacity: task groups are bound by what ONE
+    GPU holds (≈ 650k nodes); the §8e merge — every shard offering its k best per leaf, the replay consuming G streams in node order — was
+    not built, because the replay's admission order depends on every candidate's key AT ITS TURN (a root replacement changes what the next
+    node is compared with), so the shards' offers would have to be re-cut after every admitted node. Groups with generic reservations or
+    cluster mounts are refused here (swp_commit carries neither): they run on a shard SET in one process (swp_shardset_create).
+
+    `union` is an abi.Engine on rank 0 and None elsewhere; `local` this rank's engine (its node range, local indices); `firsts[g]` the
+    first global index of rank g's range, `counts[g]` its length. dist: torch.distributed (nccl == RCCL, or gloo on CPU test doubles)."""
+
+    def __init__(self, local, union, rank, world, firsts, counts, dist, device):
+        if (rank == 0) != (union is not None):
+            raise ValueError("the union engine lives on rank 0, and only there")
+        self.local, self.union, self.rank, self.world = local, union, rank, world
+        self.firsts, self.counts, self.dist, self.device = [int(f) for f in firsts], [int(c) for c in counts], dist, device
+
+    def _mine(self, nodes):
+        lo = self.firsts[self.rank]
+        return (nodes >= lo) & (nodes < lo + self.counts[self.rank])
+
+    @staticmethod
+    def _placements(nodes, descs):
+        pl = np.zeros(len(nodes), dtype=abi.PLACEMENT_DTYPE)
+        pl["node"], pl["service"], pl["cpu"], pl["mem"] = nodes, descs["service"], descs["cpu"], descs["mem"]
+        pl["port_set"], pl["counted"] = descs["port_set"], (descs["flags"] & 0x2) == 0   # (SWP_TASK_UNCOUNTED: not in ActiveTasksCount)
+        return pl
+
+    def commit(self, nodes_global, descs, add=True):
+        """NodeInfo.addTask / removeTask (nodeinfo.go:66-154) for tasks decided elsewhere: the owner's engine and the union follow."""
+        nodes_global = np.asarray(nodes_global, dtype=np.int64)
+        descs = np.asarray(descs, dtype=abi.TASK_DTYPE)
+        if self.union is not None and len(nodes_global):
+            self.union.commit(self._placements(nodes_global, descs), add)
+        m = self._mine(nodes_global)
+        if m.any():
+            self.local.commit(self._placements(nodes_global[m] - self.firsts[self.rank], descs[m]), add)
+
+    def note_batch(self, descs, out_global):
+        """A sharded one-off batch has run (every rank holds the same `out_global`; the owners applied their picks in the rounds)."""
+        if self.union is None:
+            return
+        out_global = np.asarray(out_global, dtype=np.int64)
+        ok = out_global >= 0
+        if ok.any():
+            self.union.commit(self._placements(out_global[ok], np.asarray(descs, dtype=abi.TASK_DTYPE)[ok]), True)
+
+    def schedule_groups(self, groups, sizes):
+        """-> (out int64[sum sizes] global node per task or -1, hist uint32[n_groups, 8]) on EVERY rank."""
+        groups = np.ascontiguousarray(groups, dtype=abi.TASK_DTYPE)
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        if (groups["generic_set"] != 0).any() or ((groups["flags"] >> 8) != 0).any():
+            raise ValueError("task groups with generic reservations or cluster mounts are not placed over ranks (use a shard set)")
+        total, G = int(sizes.sum()), len(groups)
+        box = np.full(total + G * abi.NFILTERS + 1, -1, dtype=np.int64)
+        if self.union is not None:
+            try:
+                out, hist = self.union.schedule_groups(groups, sizes)
+                box[:total], box[total:total + G * abi.NFILTERS], box[-1] = out, hist.reshape(-1), 0
+            except Exception as exc:   # the broadcast still happens: it carries the failure to every rank
+                self._err = exc
+                box[-1] = 1
+        if self.world > 1:
+            import torch
+            t = torch.from_numpy(box).to(self.device)
+            self.dist.broadcast(t, src=0)
+            box = t.cpu().numpy()
+        if box[-1] != 0:
+            raise RuntimeError("rank 0 could not place the groups on the union engine: %s" % (getattr(self, "_err", "see rank 0"),))
+        out = box[:total].copy()
+        hist = box[total:total + G * abi.NFILTERS].astype(np.uint32).reshape(G, abi.NFILTERS)
+        per_task = np.repeat(np.arange(G), sizes)
+        m = (out >= 0) & self._mine(out)
+        if m.any():
+            self.local.commit(self._placements(out[m] - self.firsts[self.rank], groups[per_task[m]]), True)
+        return out, hist
