@@ -481,10 +481,14 @@ def main():
     par = args.parallelism
     if par == "auto":
         par = "node-shard" if (world > 1 or args.shards > 1) else "single"
-    if par == "node-shard" and args.mode not in ("one-off", "churn"):
-        # (task groups and the enforcer's sweep over node ranges go through a shard SET in one process — tests/test_engine_shardset.py;
-        # this harness measures them on one engine. Refuse rather than measure N independent replicas under a sharded label.)
+    if par == "node-shard" and args.mode not in ("one-off", "churn", "grouped"):
+        # (the enforcer's sweep over node ranges goes through a shard SET in one process — tests/test_engine_shardset.py;
+        # this harness measures it on one engine. Refuse rather than measure N independent replicas under a sharded label.)
         print(f"bench.py: --mode {args.mode} is not run over node-range shards here; use --parallelism replicas (or single)", file=sys.stderr)
+        sys.exit(2)
+    if par == "node-shard" and args.mode == "grouped" and not (world > 1 or RANK_PATH):
+        print("bench.py: --mode grouped is not run over node-range shards of ONE rank here: a shard SET places groups on its union engine (tests/test_engine_shardset.py); "
+              "this harness runs the RANK path (--gpus N, or SWP_BENCH_RANK_PATH=1)", file=sys.stderr)
         sys.exit(2)
     shard_mode = par == "node-shard"
     churn_set = shard_mode and args.mode == "churn" and world == 1 and not RANK_PATH   # --shards G: ONE handle over G engines on this GPU (swp_shardset_create)
@@ -577,32 +581,52 @@ def main():
         import numpy as np
         per_service = descs[:wl.S] if wl.order == "rr" else descs[::max(wl.T // wl.S, 1)][:wl.S]
         sizes = np.bincount(np.array([wl.task_service(j) for j in range(wl.T)]), minlength=wl.S).astype(np.uint32)
+        by_rank = shard_mode and (world > 1 or RANK_PATH)
+        union = None
+        if by_rank:
+            # Task groups in a job of ranks (swarmkit_amd.shard.RankUnionGroups): every rank's engine holds ITS node range; rank 0 also keeps
+            # the UNION engine (every node, global indices), places the groups there with k_groups2, ONE broadcast carries the placements,
+            # every owner books its share. Groups are capacity-bound by one GPU; what the ranks add is that the one-off batches around a
+            # grouped tick stay sharded.
+            from swarmkit_amd import shard as swshard
+            if rank == 0:
+                union = abi.Engine(device=local_rank, profile=True)
+                descs_u = host.load_workload(host.HostScheduler(engine=union), wl)
+                assert np.array_equal(descs_u, descs), "the union engine and the rank's engine name services and predicate sets differently"
+                union.state_save()
+            my = rank if world > 1 else 0
+            ru = swshard.RankUnionGroups(eng, union, my, world if world > 1 else 1, [r[0] for r in shard_ranges_], [r[1] for r in shard_ranges_], ranks.dist, ranks.device)
         eng.state_save()
-        for _ in range(args.warmup):
+
+        def one_tick():
             eng.state_restore()
-            eng.schedule_groups(per_service, sizes)
+            if union is not None:
+                union.state_restore()
+            return ru.schedule_groups(per_service, sizes) if by_rank else eng.schedule_groups(per_service, sizes)
+        for _ in range(args.warmup):
+            one_tick()
         torch.cuda.synchronize(); ranks.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            eng.state_restore()
-            out, _h = eng.schedule_groups(per_service, sizes)
+            out, _h = one_tick()
         torch.cuda.synchronize(); ranks.barrier()
         t_step = ranks.max_over_ranks(time.perf_counter() - t0) / max(args.steps, 1)
         if rank == 0:
             row_b = ROW_B.get(args.workload, 48)
             alg = wl.S * wl.N * row_b + wl.T * TASK_B          # pairs = S x N in grouped mode
             res = {"metric": "task placements/sec, grouped mode (S groups of T/S tasks, end to end through swp_schedule_groups)",
-                   "value": world * wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
-                   "data": "synthetic", "config": dict(wl.describe(), mode="grouped", groups=int(wl.S)),
-                   "pair_evals_per_s": world * wl.S * wl.N / t_step, "placed": int((out >= 0).sum()),
+                   "value": (1 if by_rank else world) * wl.T / t_step, "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong" if by_rank else "weak", "vs_baseline": None, "dtype": "int64",
+                   "data": "synthetic", "config": dict(wl.describe(), mode="grouped", groups=int(wl.S),
+                                                         parallelism=("ranks: the groups on rank 0's union engine, one broadcast, owners book their share" if by_rank else par)),
+                   "pair_evals_per_s": (1 if by_rank else world) * wl.S * wl.N / t_step, "placed": int((out >= 0).sum()),
                    "roofline": {"bound": "hbm", "kernel": "k_groups2", "achieved": alg / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": alg / t_step / 1e9 / HBM_PEAK_GBS, "traffic": profile_traffic("k_groups2", run="grouped")[0],
                                 "traffic_source": profile_traffic("k_groups2", run="grouped")[1], "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_ms": t_step * 1e3,
                                 "note": "one launch = the whole tick (S groups, one workgroup: a machine wave + 15 helper waves); end-to-end step time (no separate kernel events on this path). "
-                                        "The tick is bound by the machine wave's instruction issue while it replays container/heap in the reference's exact order (a two-key heap admits light candidates by counting them and scatters them by post-order rank, "
-                                        "pipelined root replacements otherwise, parallel appends / rotation / fill where the keys allow), not by bytes: the fraction says how far from a streaming scan that is"}}
+                                        "The tick is bound by the machine wave's instruction issue while it replays container/heap in the reference's exact order (candidates from the group's static class list, 64 to a chunk; a full heap admits the candidates with its second key by counting them and scatters them by post-order rank, "
+                                        "a push that moves is sifted up by the wave, two-key heaps are sorted by the wave; parallel appends / rotation / fill where the keys allow), not by bytes: the fraction says how far from a streaming scan that is"}}
             if world == 1 and not args.no_cpu_baseline:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import orc

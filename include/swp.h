@@ -448,6 +448,13 @@ int swp_shard_run_rank(swp_engine*, swp_batch*, const uint32_t* shard_nodes, uin
  * the same verdict from the same words: 0 go on, 1 a rank could not take part (*who_out names it), 2 a rank's kernels reported an
  * error, 3 the positions differ (the ranks diverged). Exposed for the host layer's tests; words = n_ranks x 4 uint32. */
 int swp_shard_verdict(const uint32_t* words, uint32_t n_ranks, uint32_t* who_out);
+/* TASK GROUPS over node-range shards (scheduler.go:449-461: replicated services ARE groups; nodeset.go:107-120) are capacity-bound by
+ * ONE GPU: swp_schedule_groups replays container/heap over all nodes in node order — one sequential machine (csrc/swp_groups.hpp) — so a
+ * shard set runs a group call on a union engine of its own, and a job of ranks keeps that union on rank 0 (swarmkit_amd/shard.py
+ * RankUnionGroups: every sharded batch's result enters it with swp_commit, the groups' placements travel to the owners in one broadcast,
+ * every owner books its share with swp_commit). SURVEY 8e's merge of k candidates per shard was not built: which node the heap admits
+ * next depends on every earlier admission (a root replacement changes what the next node is compared with), so the shards' offers would
+ * have to be cut again after every admitted node. */
 
 /* A shard SET: the same node-range split behind ONE engine handle — what a Go manager on a multi-GPU box holds instead of an engine.
  * swp_shardset_create makes n_shards engines (devices[g]: the HIP device of shard g; NULL: all on cfg->device) and returns a handle that

@@ -94,3 +94,77 @@ class ModelShard:
 
     def shard_end(self, want_hist=True):
         return self.local, (np.zeros((self.p.T, abi.NFILTERS), dtype=np.uint32) if want_hist else None)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The same toy cluster with PERSISTENT state, for scripts of several calls (one-off batch, grouped tick, one-off batch): what
+# swarmkit_amd.shard.RankUnionGroups needs of an engine — commit, schedule_groups — and a factory of batches for RankShard.
+class ToyEngine:
+    def __init__(self, prob, rank, first, count):
+        sl = slice(first, first + count)
+        self.p, self.rank, self.first, self.count = prob, rank, first, count
+        self.total, self.cpu = prob.total0[sl].copy(), prob.cpu0[sl].copy()
+        self.cnt = np.zeros((prob.S, count), dtype=np.int64)
+
+    def descs(self, task_ids):
+        d = np.zeros(len(task_ids), dtype=abi.TASK_DTYPE)
+        d["service"] = self.p.task_svc[task_ids]
+        d["cpu"] = self.p.svc_need[d["service"]]
+        return d
+
+    def batch(self, task_ids):
+        return _ToyBatch(self, np.asarray(task_ids))
+
+    def commit(self, placements, add=True):   # NodeInfo.addTask / removeTask
+        sign = 1 if add else -1
+        for pl in placements:
+            n, s = int(pl["node"]), int(pl["service"])
+            self.total[n] += sign * int(pl["counted"])
+            self.cpu[n] -= sign * int(pl["cpu"])
+            self.cnt[s][n] += sign
+
+    def place_one(self, s):
+        """the reference's choice for one task of service s over this engine's nodes: least (svcCount, total, index) among the feasible"""
+        sl = slice(self.first, self.first + self.count)
+        ok = self.p.mask[self.p.svc_class[s]][sl] & (self.cpu >= self.p.svc_need[s])
+        if not ok.any():
+            return -1
+        idx = np.nonzero(ok)[0]
+        n = int(idx[np.lexsort((idx, self.total[idx], self.cnt[s][idx]))[0]])
+        self.total[n] += 1
+        self.cpu[n] -= self.p.svc_need[s]
+        self.cnt[s][n] += 1
+        return n
+
+    def schedule_groups(self, groups, sizes):   # (a stand-in for k_groups2: the toy rule task by task; what matters here is who learns what)
+        out = [self.place_one(int(g["service"])) for g, k in zip(groups, sizes) for _ in range(int(k))]
+        return np.asarray(out, dtype=np.int32), np.zeros((len(groups), abi.NFILTERS), dtype=np.uint32)
+
+
+class _ToyBatch(ModelShard):
+    """ModelShard over a ToyEngine's live state and a subset of the problem's tasks."""
+
+    def __init__(self, eng, task_ids):
+        self.e, self.ids = eng, task_ids
+        self.p, self.rank, self.first, self.count, self.n = eng.p, eng.rank, eng.first, eng.count, len(task_ids)
+
+    def shard_begin(self):
+        self.total, self.cpu, self.cnt = self.e.total, self.e.cpu, self.e.cnt   # (views: the batch's picks stay in the engine)
+        self.local = np.full(self.n, -1, dtype=np.int32)
+        self._svc = self.p.task_svc
+        self.p = _TaskView(self.p, self.ids)
+
+    def shard_end(self, want_hist=True):
+        return self.local, (np.zeros((self.n, abi.NFILTERS), dtype=np.uint32) if want_hist else None)
+
+
+class _TaskView:
+    """a ToyProblem whose task list is a subset (ModelShard indexes tasks by position in the batch)"""
+
+    def __init__(self, prob, ids):
+        self._p = prob
+        self.task_svc = prob.task_svc[ids]
+        self.T = len(ids)
+
+    def __getattr__(self, k):
+        return getattr(self._p, k)

@@ -197,3 +197,91 @@ def test_device_rounds_protocol_over_gloo(world, case):
         assert rounds == got[0][2] and 0 < rounds < case[2]   # lock-step rounds; an exchange decides more than one task on average
         if len(case) > 7:   # the incremental path: drains + NodeInfo.removeTask on every rank's own nodes, then a second sharded batch
             assert err.count("-> OK") == 2, (rank, err)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Task GROUPS in a job of ranks (swarmkit_amd.shard.RankUnionGroups): rank 0's union engine places the groups, one
+# broadcast carries the placements, every owner books its share — BETWEEN two sharded one-off batches, whose results the union has to
+# learn (note_batch), and with tasks going away in between (commit(remove) by global index). Engines: the persistent toy cluster of
+# tests/shard_model.py; the exchange of the one-off batches is the real RankShard protocol with the real swp_shard_merge.
+def _groups_worker(rank, world, port, q, seed):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    import shard_model
+    from swarmkit_amd import abi, shard as swshard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = shard_model.ToyProblem(seed, n_nodes=97, n_tasks=600, n_services=12)
+    ranges = swshard.shard_ranges(prob.N, world)
+    firsts, counts = [r[0] for r in ranges], [r[1] for r in ranges]
+    local = shard_model.ToyEngine(prob, rank, *ranges[rank])
+    union = shard_model.ToyEngine(prob, 0, 0, prob.N) if rank == 0 else None
+    ru = swshard.RankUnionGroups(local, union, rank, world, firsts, counts, dist, "cpu")
+    A, B = np.arange(0, 300), np.arange(300, 600)
+    drv = swshard.RankShard(local.batch(A), rank, world, firsts, dist, "cpu", block=64)
+    out_a, _ = drv.run(want_hist=False)
+    ru.note_batch(local.descs(A), out_a)
+    gone = np.nonzero(out_a >= 0)[0][::7]                       # every seventh placed task goes away (a drain's removeTask)
+    ru.commit(out_a[gone], local.descs(A[gone]), add=False)
+    groups = np.zeros(6, dtype=abi.TASK_DTYPE)
+    groups["service"] = np.arange(6)
+    groups["cpu"] = prob.svc_need[np.arange(6)]
+    out_g, hist = ru.schedule_groups(groups, np.full(6, 7, dtype=np.uint32))
+    drv = swshard.RankShard(local.batch(B), rank, world, firsts, dist, "cpu", block=64)
+    out_b, _ = drv.run(want_hist=False)
+    ru.note_batch(local.descs(B), out_b)
+    state = (local.total.tolist(), local.cpu.tolist(), local.cnt.sum(axis=0).tolist())
+    ustate = (union.total.tolist(), union.cpu.tolist()) if union is not None else None
+    q.put((rank, out_a.tolist(), out_g.tolist(), out_b.tolist(), state, ustate, hist.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_task_groups_between_two_sharded_batches_over_gloo(world):
+    """Every rank ends with the placements and the node rows of ONE engine running the same script; rank 0's union holds them all."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shard_model
+    from swarmkit_amd import abi, shard as swshard
+    seed = 4321 + world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_groups_worker, args=(rk, world, port, q, seed)) for rk in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the same script on one engine over the whole node set
+    prob = shard_model.ToyProblem(seed, n_nodes=97, n_tasks=600, n_services=12)
+    ref = shard_model.ToyEngine(prob, 0, 0, prob.N)
+    A, B = np.arange(0, 300), np.arange(300, 600)
+    want_a = np.array([ref.place_one(int(s)) for s in prob.task_svc[A]])
+    gone = np.nonzero(want_a >= 0)[0][::7]
+    pl = np.zeros(len(gone), dtype=abi.PLACEMENT_DTYPE)
+    pl["node"], pl["service"], pl["cpu"], pl["counted"] = want_a[gone], prob.task_svc[A[gone]], prob.svc_need[prob.task_svc[A[gone]]], 1
+    ref.commit(pl, add=False)
+    groups = np.zeros(6, dtype=abi.TASK_DTYPE)
+    groups["service"] = np.arange(6)
+    groups["cpu"] = prob.svc_need[np.arange(6)]
+    want_g, _ = ref.schedule_groups(groups, np.full(6, 7, dtype=np.uint32))
+    want_b = np.array([ref.place_one(int(s)) for s in prob.task_svc[B]])
+    ranges = swshard.shard_ranges(prob.N, world)
+    assert (want_g >= 0).sum() > 20 and (want_b >= 0).sum() > 100
+    for rank, out_a, out_g, out_b, state, ustate, hshape in got:
+        assert np.array_equal(np.asarray(out_a), want_a), rank
+        assert np.array_equal(np.asarray(out_g), want_g), rank      # every rank holds the groups' placements (one broadcast)
+        assert np.array_equal(np.asarray(out_b), want_b), rank      # ... and the batch behind them saw what they took
+        first, cnt = ranges[rank]
+        assert state[0] == ref.total[first:first + cnt].tolist() and state[1] == ref.cpu[first:first + cnt].tolist(), rank
+        assert state[2] == ref.cnt.sum(axis=0)[first:first + cnt].tolist(), rank
+        assert tuple(hshape) == (6, abi.NFILTERS)
+        if rank == 0:
+            assert ustate[0] == ref.total.tolist() and ustate[1] == ref.cpu.tolist()

@@ -165,3 +165,62 @@ def test_cfg4_200k_x_40k_over_8_shards_matches_the_oracle_digest():
     h, placed = _digest(wl, sp, se)
     assert placed == want["placed"][0]
     assert h == want["ticks"][0]
+
+
+@pytest.mark.gpu
+def test_rank_path_places_task_groups_between_two_sharded_batches():
+    """VERDICT r5 row e3 on one GPU: a job of ONE rank through the rank code paths (swp_shard_run_rank + swarmkit_amd.shard.RankUnionGroups:
+    the union engine, note_batch, the owners' commits) runs {one-off batch, tasks going away, grouped tick, one-off batch} and ends where a
+    single engine running the same script ends — placements, Explain histograms of the groups, node rows."""
+    from swarmkit_amd import abi, host, synth
+    from swarmkit_amd import shard as swshard
+    wl = synth.Workload("cfg3", T=6000, N=1500)
+
+    def build(**kw):
+        e = abi.Engine(**kw)
+        return e, host.load_workload(host.HostScheduler(engine=e), wl)
+    single, descs = build()
+    local, descs_l = build(shard_rank=0, shard_count=1)
+    union, descs_u = build()
+    assert np.array_equal(descs, descs_l) and np.array_equal(descs, descs_u)
+    A, B = np.arange(0, 2500), np.arange(3500, 6000)
+    G = np.arange(2500, 3500)                       # the tasks in between go as groups: one per service, in service order
+    svc = np.array([wl.task_service(int(j)) for j in G])
+    order = np.argsort(svc, kind="stable")
+    g_first = order[np.concatenate([[True], svc[order][1:] != svc[order][:-1]])]
+    groups, sizes = descs[G][g_first], np.bincount(svc)[np.unique(svc)].astype(np.uint32)
+    ru = swshard.RankUnionGroups(local, union, 0, 1, [0], [wl.N], None, None)
+
+    def placements(nodes, d):
+        pl = np.zeros(len(nodes), dtype=abi.PLACEMENT_DTYPE)
+        pl["node"], pl["service"], pl["cpu"], pl["mem"], pl["port_set"], pl["counted"] = nodes, d["service"], d["cpu"], d["mem"], d["port_set"], 1
+        return pl
+    # one engine
+    out_a, _ = single.schedule_batch(descs[A], want_hist=False)
+    gone = np.nonzero(out_a >= 0)[0][::5]
+    single.commit(placements(out_a[gone], descs[A][gone]), add=False)
+    out_g, hist_g = single.schedule_groups(groups, sizes)
+    out_b, _ = single.schedule_batch(descs[B], want_hist=False)
+    # the rank path
+    bt = local.batch_prepare(descs[A])
+    drv = swshard.DeviceRankShard(bt, 0, 1, [(0, wl.N)], None, None)   # (opens the RCCL communicator of the one-rank job)
+    la, _ = drv.run(want_hist=False)
+    bt.free()
+    assert np.array_equal(la, out_a)
+    ru.note_batch(descs[A], la)
+    ru.commit(la[gone], descs[A][gone], add=False)
+    rg, rh = ru.schedule_groups(groups, sizes)
+    assert np.array_equal(rg, out_g) and np.array_equal(rh, hist_g)
+    bt = local.batch_prepare(descs[B])
+    lb, _ = swshard.DeviceRankShard(bt, 0, 1, [(0, wl.N)], None, None).run(want_hist=False)
+    bt.free()
+    local.rccl_finalize()
+    assert np.array_equal(lb, out_b)
+    ru.note_batch(descs[B], lb)
+    assert (out_g >= 0).sum() > 500 and (out_b >= 0).sum() > 1500
+    nodes = np.arange(wl.N, dtype=np.uint32)
+    want = single.node_get_many(nodes)
+    for e in (local, union):
+        got = e.node_get_many(nodes)
+        for f in ("cpu", "mem", "total"):
+            assert np.array_equal(got[f], want[f]), f
