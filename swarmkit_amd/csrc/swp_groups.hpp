@@ -168,6 +168,14 @@ inline __host__ __device__ size_t g2_arena_bytes(u32 S, u32 ntn, u32 ngen, u32 d
 inline __host__ __device__ size_t g2_lds_bytes() { return (size_t)G2_LDS_FIXED + G2_ARENA_LDS; }
 
 #ifdef SWP_G2_KERNELS
+// The machine's section timers (SWP_DBG=16) are compiled in only with -DSWP_G2_PROF (make prof: swarmkit_amd/lib/libswp_prof.so): their
+// thirty 64-bit counters live in scalar registers, and a kernel whose scalar registers are long spilled pays for each of them with a
+// lane of a vector register — 25 VGPRs went to scratch memory in the product before they were taken out (tools/check_kernels.py).
+#ifdef SWP_G2_PROF
+#define G2_PROF_ON(a) (((a).dbg & 16u) != 0)
+#else
+#define G2_PROF_ON(a) false
+#endif
 #ifndef G2_STAT
 #define G2_STAT(i, v) ((void)0)   // (tests/emu/emu_groups.cpp counts which admission path a run took)
 #endif
@@ -736,13 +744,13 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
     const u32 NG = GEN ? G.n_gen : 0u;   // generic kinds the group reserves
     G2Arena A;
     g2_carve(A, arena_base, G.n_slots, ntn, G.n_gen, a.max_depth, k);
-    u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
-#define G2_TICK(q) do { if (a.dbg & 16u) { const u64 n_ = wv::clock64(); gt[q] += n_ - tk; tk = n_; } } while (0)
+    u64 tk = G2_PROF_ON(a) ? wv::clock64() : 0ull;
+#define G2_TICK(q) do { if (G2_PROF_ON(a)) { const u64 n_ = wv::clock64(); gt[q] += n_ - tk; tk = n_; } } while (0)
     // (the admission's own partition: every mark charges the time since the last one to a bucket — [0] waiting for a batch's records,
     // [1] whole chunks appended while a heap of one key fills, [2] flat mode's counting, [3] its flushes, [4] staging, [5] the per-chunk
     // pass, [6] lane 0's replay and the pipelined replacements, [7] the scan over the chunk minima)
     u64 tx = 0;
-#define G2_X(q) do { if (a.dbg & 16u) { const u64 n_ = wv::clock64(); gx[q] += n_ - tx; tx = n_; } } while (0)
+#define G2_X(q) do { if (G2_PROF_ON(a)) { const u64 n_ = wv::clock64(); gx[q] += n_ - tx; tx = n_; } } while (0)
 
     // ---------- per-group reset: tree-node arrays, leaf heap offsets (a leaf's heap holds at most min(k, its nodes)) ----------
     {
@@ -801,7 +809,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         u64* vis = reinterpret_cast<u64*>(reinterpret_cast<unsigned char*>(mb) + 2048);                       // [G2_VISW][64] candidate keys
         u32* visn = reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(mb) + 2048 + G2_VISW * 64 * 8);   // [G2_VISW][64] nodes
         u32* visl = visn + G2_VISW * 64;                                                                       // [G2_VISW][64] leaves
-        if (a.dbg & 16u) tx = wv::clock64();
+        if (G2_PROF_ON(a)) tx = wv::clock64();
         for (u32 w0 = 0; w0 < Cn; w0 += 64) {
             // 64 chunks at a time: which of them can hold a candidate at all? (a superset: the root only drops from here on)
             const u64 mk = w0 + lane < Cn ? minb[w0 + lane] : KEY_NONE;
@@ -820,7 +828,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
               {
                 u64 r[G2_VISW];
                 u32 rn[G2_VISW], rl[G2_VISW];
-                const u64 tw_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                const u64 tw_ = G2_PROF_ON(a) ? wv::clock64() : 0ull;
                 WV_UNROLL
                 for (int q = 0; q < G2_VISW; ++q) {
                     r[q] = KEY_NONE;
@@ -839,7 +847,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                         }
                     }
                 }
-                if (a.dbg & 16u) { wv::wait_vm(); G2_X(0); gx[8] += wv::clock64() - tw_; gx[9] += 1; }
+                if (G2_PROF_ON(a)) { wv::wait_vm(); G2_X(0); gx[8] += wv::clock64() - tw_; gx[9] += 1; }
                 // Flat mode (above) with nothing but the two keys in the whole batch: the light candidates of all its words are counted
                 // and remembered straight from the registers, word after word in node order — no staging, no per-word pass.
                 bool batch_done = false;
@@ -877,9 +885,9 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                                 lastp = wv::readlane(rn[q], top) + 1u;
                                 if (len0 == 0) root0 = uk;
                                 len0 += cnt;
-                                if (a.dbg & 16u) { gt[11] += cnt; gt[14] += cnt; }
+                                if (G2_PROF_ON(a)) { gt[11] += cnt; gt[14] += cnt; }
                             }
-                            if (a.dbg & 16u) gt[10] += 1;
+                            if (G2_PROF_ON(a)) gt[10] += 1;
                             G2_STAT(6, 1);
                         }
                         wv::wave_sync();
@@ -909,9 +917,9 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                             const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);
                             lastp = wv::readlane(rn[q], top) + 1u;   // the last Process that returned true inside tree()
                             F.n += (u32)wv::popc64(ab);
-                            if (a.dbg & 16u) gt[12] += (u32)wv::popc64(ab);
+                            if (G2_PROF_ON(a)) gt[12] += (u32)wv::popc64(ab);
                         }
-                        if (a.dbg & 16u) gt[10] += 1;
+                        if (G2_PROF_ON(a)) gt[10] += 1;
                         G2_STAT(5, 1);
                     }
                     wv::wave_sync();
@@ -926,7 +934,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     if (sm == 0) batch_done = true;
                 }
                 if (batch_done) {
-                    if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;
+                    if (G2_PROF_ON(a)) gt[15] += wv::clock64() - tw_;
                     continue;
                 }
                 WV_UNROLL
@@ -935,7 +943,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     visn[q * 64 + (int)lane] = rn[q];
                     if (!single) visl[q * 64 + (int)lane] = rl[q];
                 }
-                if (a.dbg & 16u) gt[15] += wv::clock64() - tw_;   // (mostly: waiting for the loads)
+                if (G2_PROF_ON(a)) gt[15] += wv::clock64() - tw_;   // (mostly: waiting for the loads)
                 G2_X(4);
               }
               u32 vq = vq0;
@@ -966,7 +974,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     sg->ent[myj] = se;
                 }
                 wv::wave_sync();
-                if (a.dbg & 16u) { gt[10] += 1; gt[11] += ne; }
+                if (G2_PROF_ON(a)) { gt[10] += 1; gt[11] += ne; }
                 // heap.Push moves nothing when the new element is not above its parent — with equal keys all around, the usual case.
                 // All lanes check that for their candidate at once (the parent is in the heap already or an earlier candidate of this
                 // word); if it holds for every push of the word, the pushes are one parallel append.
@@ -1005,7 +1013,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                             lastp = sg->ent[first + npp - 1u].node + 1u;
                             len0 += npp;
                             first += npp;
-                            if (a.dbg & 16u) gt[14] += npp;
+                            if (G2_PROF_ON(a)) gt[14] += npp;
                             wv::wave_sync();
                         }
                         if (npp == np) break;
@@ -1028,7 +1036,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                         lastp = e.node + 1u;
                         len0 += 1u;
                         first += 1u;
-                        if (a.dbg & 16u) gt[12] += 1;
+                        if (G2_PROF_ON(a)) gt[12] += 1;
                         G2_STAT(7, 1);
                         wv::wave_sync();
                     }
@@ -1061,7 +1069,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                         const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);   // the last admitted lane
                         lastp = wv::readlane(n, top) + 1u;       // the last Process that returned true inside tree()
                         F.n += (u32)wv::popc64(ab);
-                        if (a.dbg & 16u) gt[12] += (u32)wv::popc64(ab);
+                        if (G2_PROF_ON(a)) gt[12] += (u32)wv::popc64(ab);
                     }
                     wv::wave_sync();
                     root0 = F.n < F.nh ? F.hi : F.lo;
@@ -1084,7 +1092,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     root0 = ((u64)wv::readfirstlane((u32)(nroot >> 32)) << 32) | wv::readfirstlane((u32)nroot);
                     lastp = sg->ent[first].node + 1u;
                     first += 1u;
-                    if (a.dbg & 16u) gt[12] += 1;
+                    if (G2_PROF_ON(a)) gt[12] += 1;
                     G2_STAT(4, 1);
                     wv::wave_sync();
                     G2_X(6);
@@ -1096,7 +1104,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                     // the previous one: the operation that started 2j steps ago works on level 2j while the new one works on level 0
                     // (it reads level 1, which the one before it finished with a step ago). Lanes hold the operations in flight; every
                     // tick all of them take one step. Same comparisons, same writes, same final array as one after the other.
-                    const u64 ta_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                    const u64 ta_ = G2_PROF_ON(a) ? wv::clock64() : 0ull;
                     G2_X(5);
                     const G2Ent mine = sg->ent[lane < ne ? lane : 0u];   // lane j looks after candidate j of the word
                     u32 ci = first;
@@ -1133,18 +1141,18 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                                 lastp = en + 1u;       // the last Process that returned true inside tree()
                                 ci = f + 1u;
                                 G2_STAT(4, 1);
-                                if (a.dbg & 16u) gt[12] += 1;
+                                if (G2_PROF_ON(a)) gt[12] += 1;
                             }
                         }
                     }
-                    if (a.dbg & 16u) gt[13] += wv::clock64() - ta_;
+                    if (G2_PROF_ON(a)) gt[13] += wv::clock64() - ta_;
                     G2_X(6);
                     continue;
                 }
                 u_valid = false;
                 G2_X(5);   // (lane 0 replays pushes that move something: the heap is no longer known to hold one key)
                 if (lane == 0) {
-                    const u64 ta_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                    const u64 ta_ = G2_PROF_ON(a) ? wv::clock64() : 0ull;
                     if (single) { c_lf = 0; hbase = 0; hlen = (int)len0; hroot = root0; }
                     G2Ent cur = sg->ent[first];
                     for (u32 i = first; i < ne; ++i) {
@@ -1191,9 +1199,9 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                             } else hroot = g2_down_val(A, hbase, 0, hlen, he).top.key;
                         } else continue;
                         lastp = e.node + 1;            // the last Process that returned true inside tree()
-                        if (a.dbg & 16u) gt[12] += 1;
+                        if (G2_PROF_ON(a)) gt[12] += 1;
                     }
-                    if (a.dbg & 16u) gt[13] += wv::clock64() - ta_;
+                    if (G2_PROF_ON(a)) gt[13] += wv::clock64() - ta_;
                     if (!single && c_lf != G2_NONE) A.h_len[c_lf] = hlen;   // the other lanes' pre-filter reads the lengths of all leaves
                 }
                 G2_X(6);
@@ -1253,7 +1261,7 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             }
         }
         wv::wave_sync();
-        if (a.dbg & 16u) tx = wv::clock64();
+        if (G2_PROF_ON(a)) tx = wv::clock64();
         if (single) {
             // One leaf. When every key in the heap is the same, no pop moves anything but the two elements it swaps, and the heap-sort
             // comes out as a rotation by one — new[j] = old[(j + 1) % len] — which all lanes do together; otherwise lane 0 pops.
@@ -1556,11 +1564,11 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             const u32 nch = a.tn_nchild[tbase + f.tn];
             if (f.phase == 0) {
                 if (nch == 0) {   // leaf
-                    const u64 t0_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                    const u64 t0_ = G2_PROF_ON(a) ? wv::clock64() : 0ull;
                     const int cnt = ordered(f.tn);
-                    const u64 t1_ = (a.dbg & 16u) ? wv::clock64() : 0ull;
+                    const u64 t1_ = G2_PROF_ON(a) ? wv::clock64() : 0ull;
                     ret = cnt == 0 ? 0 : fill(f.n, A.h_off[f.tn], cnt);
-                    if (a.dbg & 16u) { gt[8] += t1_ - t0_; gt[9] += wv::clock64() - t1_; }
+                    if (G2_PROF_ON(a)) { gt[8] += t1_ - t0_; gt[9] += wv::clock64() - t1_; }
                     --sp;
                     continue;
                 }
@@ -1789,7 +1797,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     wv::setprio<3>();   // the machine's instructions go first on its SIMD: the helper waves it shares it with only fill the gaps
     u64 gt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 gx[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    u64 tk = (a.dbg & 16u) ? wv::clock64() : 0ull;
+    u64 tk = G2_PROF_ON(a) ? wv::clock64() : 0ull;
     G2Post P{0};
     {   // the first group is prepared with nothing to overlap
         const GroupRec2 G0 = a.g[0];
@@ -1805,7 +1813,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
     for (u32 gi = 0; gi < a.n_groups && ok; ++gi) {
         if (!g2_wait_ge(&mb->done, eval_cur * nh, mb)) { ok = false; break; }
         if (wv::g_fresh32(&a.ctl->error) != ERR_NONE) { ok = false; break; }
-        if (a.dbg & 16u) { const u64 n_ = wv::clock64(); gt[0] += n_ - tk; tk = n_; }
+        if (G2_PROF_ON(a)) { const u64 n_ = wv::clock64(); gt[0] += n_ - tk; tk = n_; }
         const GroupRec2 G = a.g[gi];
         u32 eval_next = 0;
         if (gi + 1 < a.n_groups) {
@@ -1825,7 +1833,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         else if (in_lds) ok = g2_group<true, true>(a, mb, sg, l + G2_LDS_FIXED, G, gi, gt, gx, P, nh, eval_next, X);
         else ok = g2_group<false, true>(a, mb, sg, a.arena, G, gi, gt, gx, P, nh, eval_next, X);
         eval_cur = eval_next;
-        if (a.dbg & 16u) tk = wv::clock64();
+        if (G2_PROF_ON(a)) tk = wv::clock64();
     }
     if (ok) ok = g2_take_explain(a, mb, X, nh);   // the last group's
     if (!ok && lane == 0) {
@@ -1833,7 +1841,7 @@ WV_KERNEL(G2_THREADS) void k_groups2(Groups2Args a) {
         wv::lds_publish32(&mb->quit, 1u);   // helpers leave their wait loops
     }
     g2_post(mb, P, G2_OP_QUIT, 0);
-    if (lane == 0 && (a.dbg & 16u)) {
+    if (lane == 0 && G2_PROF_ON(a)) {
         for (int q = 0; q < 8; ++q) a.ctl->cyc[q] = gt[q];
         a.ctl->m_cyc[0] = gt[8];   // inside the walk: orderedNodes ...
         a.ctl->m_cyc[1] = gt[9];   // ... and the fill loops
