@@ -355,35 +355,46 @@ WV_DEV void g2_pop_all(const G2Arena& A, u32 base, int len) {
 // Constraint, Platform, HostPort, MaxReplicas, Volumes — scheduler.go:60-66) and the node's nodeLess key. Returns the first failing
 // filter (G2_FF_PASS, G2_FF_ABSENT); `listed`: the node is on the group's static class list (present and passing Ready, Plugin,
 // Constraint, Platform). LISTED: the caller took n FROM that list, so those five are not looked at again.
-// OVR: the node's residuals and task count are handed in (the write-back has them in registers: g2_group's fused pass).
-// Every input is REQUESTED before any of them is looked at — one memory round trip, not one per filter of the chain (class 0 = "no
-// such filter" has a row like any other: it is loaded and not looked at).
-template <bool LISTED, bool OVR = false>
-WV_DEV u32 g2_process(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n, u64& key, bool& listed, i64 ocpu = 0, i64 omem = 0,
-                      u32 ototal = 0) {
+// Every input is REQUESTED before any of them is looked at — one memory round trip, not one per filter of the chain (class 0 = "no such
+// filter" has a row like any other: it is loaded and not looked at): g2_load_in asks, g2_decide answers. OVR: the node's residuals and
+// task count are not loaded — the caller fills them in (the write-back has the new ones in registers: g2_group's fused pass).
+struct G2In {
+    u64 vw, rw, pw, cw, tw;
+    u32 sv, fl, tot;
+    i64 c, m;
+};
+template <bool LISTED, bool OVR>
+WV_DEV void g2_load_in(const Groups2Args& a, const GroupRec2& G, u32 b, u32 n, G2In& in) {
     const u32 N = a.n_nodes, Wn = a.n_words, w = n >> 6;
+    in.vw = LISTED ? ~0ull : a.valid[w];
+    in.rw = LISTED ? ~0ull : a.ready[w];
+    in.pw = LISTED ? ~0ull : a.plug[(size_t)G.cls_plug * Wn + w];
+    in.cw = LISTED ? ~0ull : a.con[(size_t)G.cls_con * Wn + w];
+    in.tw = LISTED ? ~0ull : a.plat[(size_t)G.cls_plat * Wn + w];
+    in.sv = a.svc_dense[(size_t)b * N + n];
+    in.fl = a.fail_dense[(size_t)b * N + n];
+    in.c = OVR ? 0 : a.cpu[n];
+    in.m = OVR ? 0 : a.mem[n];
+    in.tot = OVR ? 0u : a.total[n];
+}
+template <bool LISTED>
+WV_DEV u32 g2_decide(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 n, const G2In& in, u64& key, bool& listed) {
+    const u32 Wn = a.n_words, w = n >> 6;
     const u64 bit = 1ull << (n & 63);
-    const u64 vw = LISTED ? ~0ull : a.valid[w], rw = LISTED ? ~0ull : a.ready[w];
-    const u64 pw = LISTED ? ~0ull : a.plug[(size_t)G.cls_plug * Wn + w];
-    const u64 cw = LISTED ? ~0ull : a.con[(size_t)G.cls_con * Wn + w];
-    const u64 tw = LISTED ? ~0ull : a.plat[(size_t)G.cls_plat * Wn + w];
-    const u32 sv = a.svc_dense[(size_t)b * N + n], fl = a.fail_dense[(size_t)b * N + n];
-    const i64 c = OVR ? ocpu : a.cpu[n], m = OVR ? omem : a.mem[n];
-    const u32 tot = OVR ? ototal : a.total[n];
     key = 0;
     listed = LISTED;
-    if (!LISTED && !(vw & bit)) return G2_FF_ABSENT;
-    const bool ready = LISTED || (rw & bit) != 0;
+    if (!LISTED && !(in.vw & bit)) return G2_FF_ABSENT;
+    const bool ready = LISTED || (in.rw & bit) != 0;
     u32 sff = G2_FF_PASS;   // the first failing one of Plugin / Constraint / Platform
     if (!LISTED) {
-        if (G.cls_plug && !(pw & bit)) sff = 2;
-        else if (G.cls_con && !(cw & bit)) sff = 3;
-        else if (G.cls_plat && !(tw & bit)) sff = 4;
+        if (G.cls_plug && !(in.pw & bit)) sff = 2;
+        else if (G.cls_con && !(in.cw & bit)) sff = 3;
+        else if (G.cls_plat && !(in.tw & bit)) sff = 4;
         listed = ready && sff == G2_FF_PASS;
     }
     bool res = true;   // ResourceFilter.Check, filter.go:76-95
     if (G.flags & RT_RES) {
-        res = G.cpu <= c && G.mem <= m;
+        res = G.cpu <= in.c && G.mem <= in.m;
         for (u32 q = 0; q < G.n_gen; ++q)
             if (a.gcnt[(size_t)Gm->gkind[q] * a.gstride + n] < Gm->gval[q]) res = false;   // HasEnough, validate.go:24-52
     }
@@ -397,12 +408,18 @@ WV_DEV u32 g2_process(const Groups2Args& a, const GroupRec2& G, const GroupRec2*
             for (u32 q = a.pset_off[G.pset]; q < a.pset_off[G.pset + 1]; ++q)
                 if (a.portmap[(size_t)a.pset_ids[q] * Wn + w] & bit) busy = true;
         if (busy) ff = 5;
-        else if ((G.flags & RT_MAXREP) && !((u64)sv < G.maxrep)) ff = 6;
+        else if ((G.flags & RT_MAXREP) && !((u64)in.sv < G.maxrep)) ff = 6;
         else if (G.mset && !((vol_filter_word(a.vol, G.mset, w) >> (n & 63u)) & 1ull)) ff = 7;   // VolumesFilter, the pipeline's last entry
     }
-    if (!g2_key_ok(fl, sv)) a.ctl->error = ERR_GROUP_RANGE;
-    key = g2_key(fl, sv, tot);
+    if (!g2_key_ok(in.fl, in.sv)) a.ctl->error = ERR_GROUP_RANGE;
+    key = g2_key(in.fl, in.sv, in.tot);
     return ff;
+}
+template <bool LISTED>
+WV_DEV u32 g2_process(const Groups2Args& a, const GroupRec2& G, const GroupRec2* Gm, u32 b, u32 n, u64& key, bool& listed) {
+    G2In in;
+    g2_load_in<LISTED, false>(a, G, b, n, in);
+    return g2_decide<LISTED>(a, G, Gm, n, in, key, listed);
 }
 // A node that got a task since the next group was evaluated is evaluated again: its Explain record, and — if it is on that group's
 // static class list — its candidate entry (keys only grow, nodes only drop out: the chunk minima stay lower bounds).
@@ -957,6 +974,33 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
                 ++vq;
                 const u64 mkc = single ? wv::readlane64(mk, c) : 0ull;
                 if (single && !(len0 < k || mkc < root0)) continue;   // the root dropped below the word's minimum since the batch was looked at
+                if (single && F.on && F.lo != KEY_NONE && !wv::ballot(key != KEY_NONE && key != F.lo && key < F.hi)) {
+                    // a flat session is open and the chunk holds no foreign candidate: its light candidates are counted as the batch path
+                    // counts them (no compaction, no staging of the chunk's candidates)
+                    const bool isl = key == F.lo;
+                    const u32 idx = F.n + wv::mbcnt(wv::ballot(isl));
+                    const bool acc = isl && idx < F.nh;   // (admitted while a heavy element is left: the root is heavy until then)
+                    if (acc) f_cand[idx] = n;
+                    const u64 ab = wv::ballot(acc);
+                    if (ab) {
+                        const u32 hib = (u32)(ab >> 32), lob = (u32)ab;
+                        const u32 top = hib ? 63u - (u32)wv::clz32(hib) : 31u - (u32)wv::clz32(lob);
+                        lastp = wv::readlane(n, top) + 1u;   // the last Process that returned true inside tree()
+                        F.n += (u32)wv::popc64(ab);
+                        if (G2_PROF_ON(a)) gt[12] += (u32)wv::popc64(ab);
+                    }
+                    if (G2_PROF_ON(a)) gt[10] += 1;
+                    G2_STAT(5, 1);
+                    wv::wave_sync();
+                    root0 = F.n < F.nh ? F.hi : F.lo;
+                    if (F.n == F.nh) {   // all heavy elements are gone: the remembered candidates enter the heap
+                        G2_X(2);
+                        g2_flat_flush(A, F, k, f_cand, f_pre, f_left);
+                        root0 = A.HE[0].key;
+                        G2_X(3);
+                    }
+                    continue;
+                }
                 bool cand = key != KEY_NONE;
                 if (cand) {
                     if (single) cand = len0 < k || key < root0;
@@ -1675,37 +1719,52 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         const u32 lbase = a.list_off[G.svc];
         u32 lcnt = a.list_cnt[G.svc];
         if (!g2_wait_ge(&mb->done, eval_next * nh, mb)) return false;
-        for (u32 i0 = 0; i0 < nt; i0 += 64) {
-            const u32 i = i0 + lane;
-            const bool act = i < nt;
-            const u32 n = act ? A.tnode[i] : 0u, pl = act ? A.tcount[i] : 0u;
-            const i64 oc = a.cpu[n], om = a.mem[n];
-            const u32 ot = a.total[n];
-            const u32 e1 = a.lpos_dense[(size_t)b * N + n], osv = a.svc_dense[(size_t)b * N + n];
-            const u32 cp = a.cpos[(size_t)bn * N + n];
-            const i64 nc = oc - (i64)pl * G.cpu, nm = om - (i64)pl * G.mem;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
-            const u32 ntot = ot + (counted ? pl : 0u);
-            u64 key;
-            bool listed;
-            const u32 ff = g2_process<false, true>(a, Gn, Gnm, bn, n, key, listed, nc, nm, ntot);
-            const bool app = act && counted && e1 == 0u;
-            if (act) {
-                a.cpu[n] = nc;
-                a.mem[n] = nm;
-                if (counted) {
-                    a.total[n] = ntot;
-                    if (e1) a.list_svc[e1 - 1u] = osv + pl;   // (the dense column IS the list entry's count since the scatter)
+        for (u32 i0 = 0; i0 < nt; i0 += 128) {   // two nodes a lane and turn: everything both of them need is in flight together
+            G2In in[2];
+            u32 n[2], pl[2], ot[2], e1[2], osv[2], cp[2];
+            i64 oc[2], om[2];
+            bool act[2];
+            WV_UNROLL
+            for (u32 h = 0; h < 2u; ++h) {
+                const u32 i = i0 + 64u * h + lane;
+                act[h] = i < nt;
+                n[h] = act[h] ? A.tnode[i] : 0u;
+                pl[h] = act[h] ? A.tcount[i] : 0u;
+            }
+            WV_UNROLL
+            for (u32 h = 0; h < 2u; ++h) {
+                oc[h] = a.cpu[n[h]]; om[h] = a.mem[n[h]]; ot[h] = a.total[n[h]];
+                e1[h] = a.lpos_dense[(size_t)b * N + n[h]]; osv[h] = a.svc_dense[(size_t)b * N + n[h]];
+                cp[h] = a.cpos[(size_t)bn * N + n[h]];
+                g2_load_in<false, true>(a, Gn, bn, n[h], in[h]);
+            }
+            WV_UNROLL
+            for (u32 h = 0; h < 2u; ++h) {
+                const i64 nc = oc[h] - (i64)pl[h] * G.cpu, nm = om[h] - (i64)pl[h] * G.mem;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
+                const u32 ntot = ot[h] + (counted ? pl[h] : 0u);
+                in[h].c = nc; in[h].m = nm; in[h].tot = ntot;
+                u64 key;
+                bool listed;
+                const u32 ff = g2_decide<false>(a, Gn, Gnm, n[h], in[h], key, listed);
+                const bool app = act[h] && counted && e1[h] == 0u;
+                if (act[h]) {
+                    a.cpu[n[h]] = nc;
+                    a.mem[n[h]] = nm;
+                    if (counted) {
+                        a.total[n[h]] = ntot;
+                        if (e1[h]) a.list_svc[e1[h] - 1u] = osv[h] + pl[h];   // (the dense column IS the list entry's count since the scatter)
+                    }
+                    a.ffbuf[(size_t)bn * N + n[h]] = (unsigned char)ff;
+                    a.keybuf[(size_t)bn * N + n[h]] = key;
+                    if (listed) a.ccand[(size_t)bn * N + cp[h]].key = ff == G2_FF_PASS ? key : KEY_NONE;
                 }
-                a.ffbuf[(size_t)bn * N + n] = (unsigned char)ff;
-                a.keybuf[(size_t)bn * N + n] = key;
-                if (listed) a.ccand[(size_t)bn * N + cp].key = ff == G2_FF_PASS ? key : KEY_NONE;
+                const u64 bal = wv::ballot(app);
+                if (app) {
+                    const u32 e = lbase + lcnt + wv::mbcnt(bal);
+                    a.list_node[e] = n[h]; a.list_svc[e] = pl[h]; a.list_fail[e] = 0;
+                }
+                lcnt += (u32)wv::popc64(bal);
             }
-            const u64 bal = wv::ballot(app);
-            if (app) {
-                const u32 e = lbase + lcnt + wv::mbcnt(bal);
-                a.list_node[e] = n; a.list_svc[e] = pl; a.list_fail[e] = 0;
-            }
-            lcnt += (u32)wv::popc64(bal);
         }
         if (lane == 0) a.list_cnt[G.svc] = lcnt;
         wv::wait_vm();

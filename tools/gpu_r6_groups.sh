@@ -16,4 +16,4 @@ grep -n "passed\|failed\|error" "$OUT/tests.log" | tail -3
 timeout 300 python bench.py --no-cpu-baseline --steps 3 --warmup 1 --mode grouped > "$OUT/grouped.json" 2> "$OUT/grouped.err"
 python -c "
 import json; d=json.load(open('$OUT/grouped.json')); print('grouped: ms_per_step %.2f value %.0f' % (d['ms_per_step'], d['value']))"
-SWP_DBG=16 timeout 200 python bench.py --no-cpu-baseline --steps 1 --warmup 1 --mode grouped 2>&1 >/dev/null | grep "\[swp\]" | tail -4 | cut -c1-700 | tee "$OUT/grouped_dbg.txt"
+SWP_LIB_PATH=$ROOT/swarmkit_amd/lib/libswp_prof.so SWP_DBG=16 timeout 200 python bench.py --no-cpu-baseline --steps 1 --warmup 1 --mode grouped 2>&1 >/dev/null | grep "\[swp\]" | tail -4 | cut -c1-700 | tee "$OUT/grouped_dbg.txt"
