@@ -2848,6 +2848,8 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
     if ((rc = upload(e, d_scdef, scls_def))) return rc;
     HIPCHECK(e, d_slist.reserve((size_t)n_scls * N * 4));
     HIPCHECK(e, d_scnt.reserve((size_t)n_scls * 4));
+    DevBuf d_sbits;
+    HIPCHECK(e, d_sbits.reserve((size_t)n_scls * Wn * 8));
     HIPCHECK(e, d_dense.reserve((size_t)6 * N * 4));
     HIPCHECK(e, d_tsum.reserve((size_t)2 * max_ntn * 8));
     HIPCHECK(e, d_xroot.reserve((size_t)max_ntn * 8));
@@ -2886,7 +2888,7 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
     ga.tn_next = d_next.as<uint32_t>(); ga.tn_nchild = d_nch.as<uint32_t>(); ga.tn_nodes = d_tnn.as<uint32_t>(); ga.leaf_of_node = d_leaf.as<uint32_t>();
     ga.ffbuf = d_ff.as<unsigned char>(); ga.keybuf = d_key.as<u64>();
     ga.ccand = d_ccand.as<G2Cand>(); ga.cpos = d_cpos.as<uint32_t>(); ga.cmin = d_cmin.as<u64>();
-    ga.n_scls = n_scls; ga.scls_def = d_scdef.as<uint32_t>(); ga.slist = d_slist.as<uint32_t>(); ga.scnt = d_scnt.as<uint32_t>();
+    ga.n_scls = n_scls; ga.scls_def = d_scdef.as<uint32_t>(); ga.slist = d_slist.as<uint32_t>(); ga.scnt = d_scnt.as<uint32_t>(); ga.sbits = d_sbits.as<u64>();
     ga.svc_dense = d_dense.as<uint32_t>(); ga.fail_dense = d_dense.as<uint32_t>() + (size_t)2 * N; ga.lpos_dense = d_dense.as<uint32_t>() + (size_t)4 * N;
     ga.tsumbuf = d_tsum.as<long long>(); ga.xroot = d_xroot.as<u64>(); ga.xadm = d_xadm.as<int32_t>(); ga.arena = d_arena.as<unsigned char>();
     ga.out_node = d_out.as<int32_t>(); ga.hist = d_hist.as<uint32_t>(); ga.ctl = b.d_ctl.as<Ctl>();

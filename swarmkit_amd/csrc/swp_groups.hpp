@@ -123,6 +123,7 @@ struct Groups2Args {
     const u32* scls_def;     // [n_scls][3] cls_plug, cls_con, cls_plat
     u32* slist;              // [n_scls][n_nodes] the class's nodes in node order
     u32* scnt;               // [n_scls] how many
+    u64* sbits;              // [n_scls][n_words] the same as a bitmap (the patch after a write-back asks ONE word whether a node is listed)
     G2Cand* ccand;           // [2][n_nodes] the group's candidates: what the admission scan reads, 64 to a chunk
     u32* cpos;               // [2][n_nodes] a listed node's place (the patch after a write-back finds its entry there)
     u64* cmin;               // [2][n_words] per chunk: the lowest key among its candidates (KEY_NONE: none)
@@ -363,14 +364,16 @@ struct G2In {
     u32 sv, fl, tot;
     i64 c, m;
 };
-template <bool LISTED, bool OVR>
+// CLS: the five static words are not asked for one by one — only the class bitmap's word, in `vw` (g2_decide_patch: a node that is
+// not listed needs no verdict of its own: nothing reads its record before the Explain command evaluates it itself).
+template <bool LISTED, bool OVR, bool CLS = false>
 WV_DEV void g2_load_in(const Groups2Args& a, const GroupRec2& G, u32 b, u32 n, G2In& in) {
     const u32 N = a.n_nodes, Wn = a.n_words, w = n >> 6;
-    in.vw = LISTED ? ~0ull : a.valid[w];
-    in.rw = LISTED ? ~0ull : a.ready[w];
-    in.pw = LISTED ? ~0ull : a.plug[(size_t)G.cls_plug * Wn + w];
-    in.cw = LISTED ? ~0ull : a.con[(size_t)G.cls_con * Wn + w];
-    in.tw = LISTED ? ~0ull : a.plat[(size_t)G.cls_plat * Wn + w];
+    in.vw = LISTED ? ~0ull : CLS ? a.sbits[(size_t)G.scls * Wn + w] : a.valid[w];
+    in.rw = (LISTED || CLS) ? ~0ull : a.ready[w];
+    in.pw = (LISTED || CLS) ? ~0ull : a.plug[(size_t)G.cls_plug * Wn + w];
+    in.cw = (LISTED || CLS) ? ~0ull : a.con[(size_t)G.cls_con * Wn + w];
+    in.tw = (LISTED || CLS) ? ~0ull : a.plat[(size_t)G.cls_plat * Wn + w];
     in.sv = a.svc_dense[(size_t)b * N + n];
     in.fl = a.fail_dense[(size_t)b * N + n];
     in.c = OVR ? 0 : a.cpu[n];
@@ -428,10 +431,14 @@ WV_DEV void g2_patch_node(const Groups2Args& a, const GroupRec2& G, const GroupR
     const u32 cp = a.cpos[(size_t)b * N + n];   // (meaningless unless listed; requested with the rest)
     u64 key;
     bool listed;
-    const u32 ff = g2_process<false>(a, G, Gm, b, n, key, listed);
+    G2In in;
+    g2_load_in<false, false, true>(a, G, b, n, in);
+    listed = ((in.vw >> (n & 63u)) & 1ull) != 0;
+    if (!listed) return;   // (its Explain record is not read: the command evaluates unlisted nodes itself)
+    const u32 ff = g2_decide<true>(a, G, Gm, n, in, key, listed);
     a.ffbuf[(size_t)b * N + n] = (unsigned char)ff;
     a.keybuf[(size_t)b * N + n] = key;
-    if (listed) a.ccand[(size_t)b * N + cp].key = ff == G2_FF_PASS ? key : KEY_NONE;
+    a.ccand[(size_t)b * N + cp].key = ff == G2_FF_PASS ? key : KEY_NONE;
 }
 // The static class lists (Groups2Args.slist): ONE WAVE per class (k_g2_static: a grid of n_scls workgroups of 64), lanes over the node words.
 WV_DEV void g2_static_list(const Groups2Args& a, u32 c) {
@@ -449,6 +456,7 @@ WV_DEV void g2_static_list(const Groups2Args& a, u32 c) {
             if (cpa) m &= a.plat[(size_t)cpa * Wn + w];
             if (w == Wn - 1u && (N & 63u)) m &= (1ull << (N & 63u)) - 1ull;
         }
+        if (w < Wn) a.sbits[(size_t)c * Wn + w] = m;
         const u32 cnt = (u32)wv::popc64(m);
         const u32 incl = wv::scan_incl_u32(cnt);
         u32 pos = run + incl - cnt;
@@ -1719,52 +1727,45 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
         const u32 lbase = a.list_off[G.svc];
         u32 lcnt = a.list_cnt[G.svc];
         if (!g2_wait_ge(&mb->done, eval_next * nh, mb)) return false;
-        for (u32 i0 = 0; i0 < nt; i0 += 128) {   // two nodes a lane and turn: everything both of them need is in flight together
-            G2In in[2];
-            u32 n[2], pl[2], ot[2], e1[2], osv[2], cp[2];
-            i64 oc[2], om[2];
-            bool act[2];
-            WV_UNROLL
-            for (u32 h = 0; h < 2u; ++h) {
-                const u32 i = i0 + 64u * h + lane;
-                act[h] = i < nt;
-                n[h] = act[h] ? A.tnode[i] : 0u;
-                pl[h] = act[h] ? A.tcount[i] : 0u;
-            }
-            WV_UNROLL
-            for (u32 h = 0; h < 2u; ++h) {
-                oc[h] = a.cpu[n[h]]; om[h] = a.mem[n[h]]; ot[h] = a.total[n[h]];
-                e1[h] = a.lpos_dense[(size_t)b * N + n[h]]; osv[h] = a.svc_dense[(size_t)b * N + n[h]];
-                cp[h] = a.cpos[(size_t)bn * N + n[h]];
-                g2_load_in<false, true>(a, Gn, bn, n[h], in[h]);
-            }
-            WV_UNROLL
-            for (u32 h = 0; h < 2u; ++h) {
-                const i64 nc = oc[h] - (i64)pl[h] * G.cpu, nm = om[h] - (i64)pl[h] * G.mem;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
-                const u32 ntot = ot[h] + (counted ? pl[h] : 0u);
-                in[h].c = nc; in[h].m = nm; in[h].tot = ntot;
-                u64 key;
-                bool listed;
-                const u32 ff = g2_decide<false>(a, Gn, Gnm, n[h], in[h], key, listed);
-                const bool app = act[h] && counted && e1[h] == 0u;
-                if (act[h]) {
-                    a.cpu[n[h]] = nc;
-                    a.mem[n[h]] = nm;
-                    if (counted) {
-                        a.total[n[h]] = ntot;
-                        if (e1[h]) a.list_svc[e1[h] - 1u] = osv[h] + pl[h];   // (the dense column IS the list entry's count since the scatter)
-                    }
-                    a.ffbuf[(size_t)bn * N + n[h]] = (unsigned char)ff;
-                    a.keybuf[(size_t)bn * N + n[h]] = key;
-                    if (listed) a.ccand[(size_t)bn * N + cp[h]].key = ff == G2_FF_PASS ? key : KEY_NONE;
+        for (u32 i0 = 0; i0 < nt; i0 += 64) {
+            // (two nodes a lane and turn — the inputs of both in flight together — was tried: 32 vector registers went to scratch memory
+            // elsewhere in the kernel and the tick got no faster)
+            const u32 i = i0 + lane;
+            const bool act = i < nt;
+            const u32 n = act ? A.tnode[i] : 0u, pl = act ? A.tcount[i] : 0u;
+            const i64 oc = a.cpu[n], om = a.mem[n];
+            const u32 ot = a.total[n];
+            const u32 e1 = a.lpos_dense[(size_t)b * N + n], osv = a.svc_dense[(size_t)b * N + n];
+            const u32 cp = a.cpos[(size_t)bn * N + n];
+            G2In in;
+            g2_load_in<false, true, true>(a, Gn, bn, n, in);
+            const i64 nc = oc - (i64)pl * G.cpu, nm = om - (i64)pl * G.mem;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
+            const u32 ntot = ot + (counted ? pl : 0u);
+            in.c = nc; in.m = nm; in.tot = ntot;
+            u64 key;
+            bool as_listed;
+            const bool listed = ((in.vw >> (n & 63u)) & 1ull) != 0;   // (on the next group's static class list: only then is there a record to renew)
+            const u32 ff = g2_decide<true>(a, Gn, Gnm, n, in, key, as_listed);
+            const bool app = act && counted && e1 == 0u;
+            if (act) {
+                a.cpu[n] = nc;
+                a.mem[n] = nm;
+                if (counted) {
+                    a.total[n] = ntot;
+                    if (e1) a.list_svc[e1 - 1u] = osv + pl;   // (the dense column IS the list entry's count since the scatter)
                 }
-                const u64 bal = wv::ballot(app);
-                if (app) {
-                    const u32 e = lbase + lcnt + wv::mbcnt(bal);
-                    a.list_node[e] = n[h]; a.list_svc[e] = pl[h]; a.list_fail[e] = 0;
+                if (listed) {
+                    a.ffbuf[(size_t)bn * N + n] = (unsigned char)ff;
+                    a.keybuf[(size_t)bn * N + n] = key;
+                    a.ccand[(size_t)bn * N + cp].key = ff == G2_FF_PASS ? key : KEY_NONE;
                 }
-                lcnt += (u32)wv::popc64(bal);
             }
+            const u64 bal = wv::ballot(app);
+            if (app) {
+                const u32 e = lbase + lcnt + wv::mbcnt(bal);
+                a.list_node[e] = n; a.list_svc[e] = pl; a.list_fail[e] = 0;
+            }
+            lcnt += (u32)wv::popc64(bal);
         }
         if (lane == 0) a.list_cnt[G.svc] = lcnt;
         wv::wait_vm();

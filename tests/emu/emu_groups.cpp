@@ -467,6 +467,7 @@ int main(int argc, char** argv) {
     }
     const u32 n_scls = (u32)scls_def.size() / 3;
     std::vector<u32> slist((size_t)n_scls * N, 0xEEEEEEEEu), scnt(n_scls, 0x7777);
+    std::vector<u64> sbits((size_t)n_scls * Wn, 0x8888);
     std::vector<i64> tsumbuf((size_t)2 * max_ntn, 0x7777);
     std::vector<int32_t> xadm(max_ntn, 0), out(total_out, -7);
     std::vector<u32> hist(p.groups.size() * 8, 0);
@@ -483,7 +484,7 @@ int main(int argc, char** argv) {
     a.tree_off = tree_off.data(); a.tn_parent = tn_parent.data(); a.tn_first = tn_first.data(); a.tn_next = tn_next.data();
     a.tn_nchild = tn_nchild.data(); a.tn_nodes = tn_nodes.data(); a.leaf_of_node = leaf_of.data();
     a.ffbuf = ffbuf.data(); a.keybuf = keybuf.data(); a.ccand = ccand.data(); a.cpos = cpos.data(); a.cmin = cmin.data();
-    a.n_scls = n_scls; a.scls_def = scls_def.data(); a.slist = slist.data(); a.scnt = scnt.data(); a.svc_dense = svc_dense.data(); a.fail_dense = fail_dense.data(); a.lpos_dense = lpos_dense.data();
+    a.n_scls = n_scls; a.scls_def = scls_def.data(); a.slist = slist.data(); a.scnt = scnt.data(); a.sbits = sbits.data(); a.svc_dense = svc_dense.data(); a.fail_dense = fail_dense.data(); a.lpos_dense = lpos_dense.data();
     a.tsumbuf = tsumbuf.data(); a.xroot = xroot.data(); a.xadm = xadm.data(); a.arena = arena.data();
     a.out_node = out.data(); a.hist = hist.data(); a.ctl = &ctl;
 
