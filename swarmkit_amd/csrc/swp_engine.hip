@@ -1875,7 +1875,11 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 HIPCHECK(e, b->d_emat.reserve((size_t)b->n_svc * N * 4));
                 sa.hmat = b->d_hmat.as<uint32_t>();
                 sa.emat = b->d_emat.as<uint32_t>();
-                r = launch_scan(sa, st, e->device);
+                sa.n_sc = b->n_sc;
+                bool node_local = ra.n_rg == 0 && ra.csi_of == nullptr;   // (k_scanb: every input of a task in LDS, every effect on ONE node)
+                for (uint32_t j = pos; j < upto && node_local; ++j)
+                    if (b->rt[j].flags & RT_PORTS) node_local = false;
+                r = launch_scan(sa, st, e->device, node_local);
                 if (r == hipSuccess) r = launch_r6_build(ra, st);   // the rounds go on from the rows as the scan left them
                 if (r != hipSuccess) return e->fail(SWP_EHIP, "k_scan launch: %s", hipGetErrorString(r));
                 scanned += upto - pos;

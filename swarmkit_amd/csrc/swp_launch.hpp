@@ -49,7 +49,7 @@ hipError_t launch_shard_apply(const ShardApplyArgs& a, hipStream_t s);
 // the scan resolver (swp_scan.hpp, built in swp_resolve6.hip)
 struct ScanArgs;
 uint32_t scan_max_nodes();
-hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev);
+hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev, bool node_local);
 
 // task groups (swp_groups.hip)
 struct Groups2Args;

@@ -112,9 +112,26 @@ static hipError_t launch_scan_nq(const ScanArgs& s, size_t lds, hipStream_t st, 
     }
 }
 bool scan_matrices_in_lds(uint32_t n_nodes, uint32_t n_svc) { return scan_lds_lm(n_nodes, n_svc) <= (size_t)160 * 1024 - 512; }
-hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev) {
+template <int NQ>
+static hipError_t launch_scanb_as(const ScanArgs& s, size_t lds, hipStream_t st, int dev) {
+    hipError_t r;
+    if (lds > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_scanb<NQ>), dev)) != hipSuccess) return r;
+    hipLaunchKernelGGL((k_scanb<NQ>), dim3(1), dim3(SCAN_THREADS), lds, st, s);
+    return hipGetLastError();
+}
+// node_local: no task of the stretch reserves generic resources, publishes host ports or mounts cluster volumes (the caller looked) —
+// then, when everything a task reads fits in LDS, SCAN_B tasks share a barrier (k_scanb)
+hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev, bool node_local) {
     hipLaunchKernelGGL(k_scan_fill, dim3(1024), dim3(256), 0, st, s);
     hipLaunchKernelGGL(k_scan_lists, dim3(64, s.n_svc), dim3(256), 0, st, s);
+    if (node_local && !getenv("SWP_SCAN_UNBATCHED") && scan_lds_b(s.a.n_nodes, s.n_svc, s.n_sc) <= (size_t)160 * 1024 - 512) {
+        const size_t lds = scan_lds_b(s.a.n_nodes, s.n_svc, s.n_sc);
+        switch (scan_nq(s.a.n_nodes)) {
+            case 1: return launch_scanb_as<1>(s, lds, st, dev);
+            case 2: return launch_scanb_as<2>(s, lds, st, dev);
+            default: return launch_scanb_as<4>(s, lds, st, dev);
+        }
+    }
     // the (service, node) matrices in LDS when they fit next to the node rows: a task's turn then waits for no global load
     if (scan_matrices_in_lds(s.a.n_nodes, s.n_svc)) return launch_scan_nq<true>(s, scan_lds_lm(s.a.n_nodes, s.n_svc), st, dev);
     return launch_scan_nq<false>(s, scan_lds(s.a.n_nodes), st, dev);

@@ -34,7 +34,7 @@ inline __host__ __device__ u32 scan_nq(u32 n_nodes) {   // nodes per thread of t
 struct ScanArgs {
     R6Args a;          // the block resolver's argument record: node rows, static class rows, lists, host ports, generic sets, logs
     u32 j0, j1;        // the stretch: tasks [j0, j1)
-    u32 n_svc, pad;
+    u32 n_svc, n_sc;   // services of the batch; static class rows (k_scanb keeps them in LDS)
     u32* hmat;         // [n_svc][n_nodes] (failures >= 5 ? failures : 0) << 24 | ActiveTasksCountByService
     u32* emat;         // [n_svc][n_nodes] list entry of (service, node), LIST_EMPTY: none
 };
@@ -42,6 +42,19 @@ struct ScanArgs {
 inline __host__ __device__ size_t scan_lds(u32 n_nodes) { return (size_t)n_nodes * 24 + 16 * 16 + 64 + 2 * SCAN_RTQ * 64; }
 // ... plus the two (service, node) matrices when they fit next to it (SCAN_LM instances): a task then reads nothing but its static-class words from global memory
 inline __host__ __device__ size_t scan_lds_lm(u32 n_nodes, u32 n_svc) { return ((scan_lds(n_nodes) + 15) & ~(size_t)15) + (size_t)2 * n_svc * n_nodes * 4; }
+
+// The BATCHED instance (k_scanb, round 6): SCAN_B tasks share one barrier. Every thread evaluates its nodes for the next SCAN_B tasks
+// against the state as it is NOW; the workgroup's SCAN_B argmins meet in SCAN_B words; behind the one barrier everybody accepts the longest
+// prefix of tasks whose picks are pairwise different. That is exact: a placement changes ONE node — its residuals, task counts, the
+// service's count there — and only for the worse, so the argmin of task j + 1 taken before task j was placed is its argmin afterwards
+// too unless both are the same node (then task j + 1 and everything behind it is evaluated again in the next batch). No task of the
+// stretch may reserve generic resources, publish host ports or mount cluster volumes (their inputs live in global memory, and a
+// volume's state is not node-local): the launcher checks, and everything a task reads — node rows, the (service, node) matrices, the
+// static class rows — is in LDS.
+#define SCAN_B 4
+inline __host__ __device__ size_t scan_lds_b(u32 n_nodes, u32 n_svc, u32 n_sc) {
+    return ((scan_lds_lm(n_nodes, n_svc) + 15) & ~(size_t)15) + (size_t)n_sc * ((n_nodes + 63) / 64) * 8 + 3 * SCAN_B * 8;
+}
 
 #ifdef SWP_SCAN_KERNELS
 // hmat / emat from the per-service lists: grid (entries of the longest list / 256, services)
@@ -235,6 +248,146 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
         }
         // (no second barrier: a node's row is read and written by its owner only, the records of a chunk are staged behind a barrier of their own)
     }
+    for (u32 n = tid; n < N; n += SCAN_THREADS) { a.cpu[n] = cpu[n]; a.mem[n] = mem[n]; a.total[n] = tot[n]; a.last[n] = lastc[n]; }
+    if (tid == 0) {
+        a.ctl->ncommit = nc;
+        a.ctl->ninf = ni;
+        a.blk->pos = s.j1;
+    }
+}
+template <int SCAN_NQ>
+WV_KERNEL(SCAN_THREADS) void k_scanb(ScanArgs s) {
+    const R6Args& a = s.a;
+    const u32 tid = wv::tid(), lane = wv::lane(), N = a.n_nodes, Wn = a.n_words;
+    unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
+    i64* cpu = reinterpret_cast<i64*>(l);
+    i64* mem = cpu + N;
+    u32* tot = reinterpret_cast<u32*>(mem + N);
+    int32_t* lastc = reinterpret_cast<int32_t*>(tot + N);
+    u32* rtq = reinterpret_cast<u32*>(l + (((size_t)N * 24 + 15) & ~(size_t)15)) + 2 * 16 + 16;   // (where k_scan keeps its records: behind red_k[16], red_n[16])
+    u32* hm = reinterpret_cast<u32*>(l + ((scan_lds(N) + 15) & ~(size_t)15));
+    u32* em = hm + (size_t)s.n_svc * N;
+    u64* scl = reinterpret_cast<u64*>(l + ((scan_lds_lm(N, s.n_svc) + 15) & ~(size_t)15));       // [n_sc][Wn] the static class rows
+    u64* red = scl + (size_t)s.n_sc * Wn;                                                            // [3][SCAN_B] the argmins, three sets in rotation
+    if (a.blk->error != ERR_NONE) return;
+    for (u32 n = tid; n < N; n += SCAN_THREADS) { cpu[n] = a.cpu[n]; mem[n] = a.mem[n]; tot[n] = a.total[n]; lastc[n] = a.last[n]; }
+    for (u32 x = tid; x < s.n_svc * N; x += SCAN_THREADS) { hm[x] = s.hmat[x]; em[x] = s.emat[x]; }
+    for (u32 x = tid; x < s.n_sc * Wn; x += SCAN_THREADS) scl[x] = a.sc[x];
+    if (tid < 3 * SCAN_B) red[tid] = KEY_NONE;
+    u32 nc = a.ctl->ncommit, ni = a.ctl->ninf;
+    const u32* rt32 = reinterpret_cast<const u32*>(a.rt);
+    const u32 cdw = SCAN_RTQ * 16u;   // dwords of a chunk of task records
+    auto chunk_load = [&](u32 c) -> u32 {
+        const u32 t0 = s.j0 + c * SCAN_RTQ;
+        return (tid < cdw && t0 + tid / 16u < s.j1) ? rt32[(size_t)t0 * 16u + tid] : 0u;
+    };
+    if (tid < cdw) rtq[tid] = chunk_load(0);
+    u32 next_dw = chunk_load(1);
+    u32 slot = 0;
+    wv::barrier();
+    for (u32 t = s.j0; t < s.j1;) {
+        const u32 i = t - s.j0;
+        if (i != 0 && i % SCAN_RTQ == 0) {   // the batch opens a chunk of records: it is in this thread's register since the chunk before
+            const u32 c = i / SCAN_RTQ;
+            if (tid < cdw) rtq[(c & 1u) * cdw + tid] = next_dw;   // (that half was last read a chunk ago: barriers lie in between)
+            next_dw = chunk_load(c + 1);
+            wv::barrier();
+        }
+        const u32 nb = min(min((u32)SCAN_B, s.j1 - t), SCAN_RTQ - i % SCAN_RTQ);   // (a batch stays inside one chunk)
+        RTask r[SCAN_B];
+        u64 bk[SCAN_B];
+        WV_UNROLL
+        for (int b = 0; b < SCAN_B; ++b) {
+            bk[b] = KEY_NONE;
+            const u32 ib = i + ((u32)b < nb ? (u32)b : 0u);
+            r[b] = *reinterpret_cast<const RTask*>(rtq + ((ib / SCAN_RTQ) & 1u) * cdw + (ib % SCAN_RTQ) * 16u);
+        }
+        // ---- every thread: the best of its own nodes, for each of the batch's tasks
+        WV_UNROLL
+        for (int b = 0; b < SCAN_B; ++b) {
+            if ((u32)b >= nb) continue;
+            WV_UNROLL
+            for (int q = 0; q < SCAN_NQ; ++q) {
+                const u32 n = tid + (u32)q * SCAN_THREADS;
+                if (n >= N) continue;
+                if (!((scl[(size_t)r[b].sc * Wn + (n >> 6)] >> (n & 63)) & 1ull)) continue;   // valid & ready & constraints & platform & plugins
+                const u32 hi = hm[(size_t)r[b].svc * N + n];
+                if ((r[b].flags & RT_RES) && !(r[b].cpu <= cpu[n] && r[b].mem <= mem[n])) continue;
+                if ((r[b].flags & RT_MAXREP) && !((u64)(hi & 0xFFFFFFu) < r[b].maxrep)) continue;
+                const u32 tn = tot[n];
+                if (tn >> 20) a.blk->error = ERR_LEVEL_RANGE;
+                const u64 key = ((u64)hi << 32) | ((u64)tn << 12) | n;
+                if (key < bk[b]) bk[b] = key;
+            }
+        }
+        WV_UNROLL
+        for (int b = 0; b < SCAN_B; ++b) {
+            const u64 wk = r6_wave_min64(bk[b]);
+            if (lane == 0 && wk != KEY_NONE) wv::lds_min64(red + slot * SCAN_B + b, wk);
+        }
+        wv::barrier();
+        u64 gk[SCAN_B];
+        WV_UNROLL
+        for (int b = 0; b < SCAN_B; ++b) gk[b] = wv::lds_read64(red + slot * SCAN_B + b);
+        if (tid < SCAN_B) red[(slot == 0 ? 2u : slot - 1u) * SCAN_B + tid] = KEY_NONE;   // (the set of the batch before: everybody is past reading it)
+        slot = slot == 2 ? 0 : slot + 1;
+        // ---- the longest prefix of tasks whose picks differ (the same on every thread: the same words)
+        u32 na = 0;
+        u32 gn[SCAN_B];
+        WV_UNROLL
+        for (int b = 0; b < SCAN_B; ++b) {
+            gn[b] = gk[b] == KEY_NONE ? R6_NONE : (u32)gk[b] & 0xFFFu;
+            bool clash = (u32)b >= nb || na != (u32)b;   // (behind a task that was not accepted nothing is)
+            WV_UNROLL
+            for (int c = 0; c < b; ++c) clash = clash || (gn[b] != R6_NONE && gn[c] == gn[b]);
+            if (!clash) na = (u32)b + 1u;
+        }
+        // ---- the owners apply (NodeInfo.addTask); everybody counts
+        WV_UNROLL
+        for (int b = 0; b < SCAN_B; ++b) {
+            if ((u32)b >= na) continue;
+            const u32 tb = t + (u32)b;
+            if (gn[b] == R6_NONE) {
+                if (tid == 0) {
+                    a.inf_task[ni] = tb;
+                    a.inf_pos[ni] = nc;
+                    a.out_node[tb] = -1;
+                }
+                ++ni;
+                continue;
+            }
+            if ((gn[b] & (SCAN_THREADS - 1u)) == tid) {
+                const u32 nd = gn[b], w = nd >> 6;
+                const u64 bit = 1ull << (nd & 63);
+                if (r[b].cpu) cpu[nd] -= r[b].cpu;
+                if (r[b].mem) mem[nd] -= r[b].mem;
+                if (!(r[b].flags & RT_UNCOUNTED)) {
+                    tot[nd] += 1;
+                    u32 hi = hm[(size_t)r[b].svc * N + nd] + 1u;
+                    u32 entry = em[(size_t)r[b].svc * N + nd];
+                    if ((hi & 0xFFFFFFu) == 0) a.blk->error = ERR_GROUP_RANGE;
+                    hm[(size_t)r[b].svc * N + nd] = hi;
+                    if (entry == LIST_EMPTY) {
+                        wv::g_or64(a.X + (size_t)r[b].svc * a.xs + w, bit);
+                        a.list_node[r[b].slot] = nd;
+                        a.list_svc[r[b].slot] = 1;
+                        a.list_fail[r[b].slot] = 0;
+                        em[(size_t)r[b].svc * N + nd] = r[b].slot;
+                    } else
+                        a.list_svc[entry] = hi & 0xFFFFFFu;
+                }
+                const int32_t prev = lastc[nd];
+                a.log_node[nc] = nd;
+                a.log_task[nc] = tb;
+                a.log_prev[nc] = prev;
+                lastc[nd] = (int32_t)nc;
+                a.out_node[tb] = (int32_t)nd;
+            }
+            ++nc;
+        }
+        t += na;
+    }
+    wv::barrier();
     for (u32 n = tid; n < N; n += SCAN_THREADS) { a.cpu[n] = cpu[n]; a.mem[n] = mem[n]; a.total[n] = tot[n]; a.last[n] = lastc[n]; }
     if (tid == 0) {
         a.ctl->ncommit = nc;

@@ -26,10 +26,12 @@ int main(int argc, char** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
-    bool verbose = false, split = false, task_rows = false, mixed = false, no_lm = false;
+    bool verbose = false, split = false, task_rows = false, mixed = false, no_lm = false, no_batch = false;
+    unsigned batched_launches = 0;
     for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 'm') mixed = true;
+        if (argv[i][0] == 'u') no_batch = true;   // the one-task-a-barrier instances even where the batched one (k_scanb) would be launched
         if (argv[i][0] == 'g') no_lm = true;   // the (service, node) matrices stay in global memory even if they would fit in LDS
     }
     if (N > SCAN_MAXN) { fprintf(stderr, "the scan resolver takes %d nodes\n", SCAN_MAXN); return 2; }
@@ -155,6 +157,23 @@ int main(int argc, char** argv) {
             grid(64, 256, 0, [s]() { k_scan_lists(s); });
         }
         emu::blockidx_y() = 0;
+        s.n_sc = p.n_sc;
+        // the launcher's rule for the BATCHED instance (k_scanb): no generic reservations, no host ports in the stretch, everything in LDS
+        bool node_local = a.n_rg == 0 && !no_lm && !no_batch;
+        for (u32 j = j0; j < j1 && node_local; ++j)
+            if (a.rt[j].flags & RT_PORTS) node_local = false;
+        if (node_local && scan_lds_b(N, s.n_svc, s.n_sc) <= (size_t)160 * 1024 - 512) {
+            const size_t ldsb = scan_lds_b(N, s.n_svc, s.n_sc);
+            switch (scan_nq(N)) {
+                case 1: grid(1, SCAN_THREADS, ldsb, [s]() { k_scanb<1>(s); }); break;
+                case 2: grid(1, SCAN_THREADS, ldsb, [s]() { k_scanb<2>(s); }); break;
+                default: grid(1, SCAN_THREADS, ldsb, [s]() { k_scanb<4>(s); }); break;
+            }
+            ++rounds;
+            ++batched_launches;
+            if (blk.error) { fprintf(stderr, "k_scanb reported error %u\n", blk.error); return false; }
+            return blk.pos == j1;
+        }
         const bool lm = scan_lds_lm(N, s.n_svc) <= (size_t)160 * 1024 - 512 && !no_lm;   // the launcher's rule: the matrices in LDS when they fit
         const size_t lds = lm ? scan_lds_lm(N, s.n_svc) : scan_lds(N);
         switch (scan_nq(N) * 2 + (lm ? 1 : 0)) {   // the instance the launcher picks for this node count
@@ -194,6 +213,7 @@ int main(int argc, char** argv) {
         if (maxrel < hi) { fprintf(stderr, "maxrel %u below the highest level %u\n", maxrel, hi); ok = false; }
     }
     if (verbose || !ok)
+        fprintf(stderr, "batched scan launches (k_scanb): %u\n", batched_launches);
         fprintf(stderr, "seed %u N %u T %u S %u block %u order %d feat %d split %d: placed %u inf %u | rounds %llu (%.1f tasks each) cut: exhausted %u exception %u uncounted %u | classes %u+%u -> %s\n",
                 seed, N, T, S, B, order, feat, (int)split, em.ctl.ncommit, em.ctl.ninf, (unsigned long long)rounds, rounds ? (double)T / (double)rounds : 0.0, blk.cut_exhausted,
                 blk.cut_exception, blk.cut_uncounted, n_dc, n_dm, ok ? "OK" : "FAIL");

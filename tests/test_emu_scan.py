@@ -42,6 +42,14 @@ CASES = [
     (3, 1000, 2500, 40, 64, 2, 2, "mg"),
     (7, 500, 1200, 40, 128, 0, 3, "mg"),
     (13, 65, 800, 3, 32, 2, 2, "g"),
+    # the BATCHED instance (k_scanb, round 6: four tasks share a barrier; every input in LDS, so few services): one / two / four nodes a
+    # thread, between two stretches of the block resolver, and "u": the same problem through the one-task-a-barrier instance
+    (21, 1000, 3000, 10, 64, 0, 1, ""),
+    (21, 1000, 3000, 10, 64, 0, 1, "u"),
+    (22, 2000, 2000, 5, 64, 0, 1, "m"),
+    (23, 2500, 1500, 3, 64, 1, 1, ""),
+    (24, 1000, 3000, 10, 64, 2, 0, "m"),
+    (25, 64, 2000, 4, 32, 0, 1, ""),
 ]
 
 
@@ -54,7 +62,7 @@ def test_scan_resolver_source_matches_sequential_model(emu_bin, case):
 
 
 @pytest.mark.parametrize("sched", [31])
-@pytest.mark.parametrize("case", [CASES[1], CASES[4], CASES[5], CASES[8], CASES[-2]], ids=lambda c: "seed%d-N%d-T%d-f%d%s" % (c[0], c[1], c[2], c[6], c[7]))
+@pytest.mark.parametrize("case", [CASES[1], CASES[4], CASES[5], CASES[8], CASES[14], CASES[15], CASES[17], CASES[19]], ids=lambda c: "seed%d-N%d-T%d-f%d%s" % (c[0], c[1], c[2], c[6], c[7]))
 def test_under_random_wave_schedules(emu_bin, case, sched):
     """... under wave orders the first-in-first-out run never produces (EMU_SCHED_SEED, tests/emu/wv_emu.hpp)."""
     args = [str(x) for x in case[:7]] + ["v"] + list(case[7])

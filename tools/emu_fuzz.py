@@ -64,6 +64,9 @@ def draw(rng, which):
         n = pick_n(rng, 4096)
         t = rng.randrange(1, 2000)
         s = rng.randrange(1, max(min(t, 60), 2))
+        if rng.random() < 0.4:   # few services: everything a task reads fits in LDS, the BATCHED instance (k_scanb) runs
+            s = rng.randrange(1, 12)
+            n = min(n, 2600)
         opts = "".join(o for o in "mg" if rng.random() < 0.4)
         return [seed, n, t, s, rng.choice([32, 64, 128, 256]), rng.randrange(3), rng.randrange(4)] + ([opts] if opts else [])
     if which in ("groups", "groups_small"):
