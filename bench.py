@@ -46,13 +46,13 @@ def emit_line(text):
 
 
 def profile_traffic(kernel, run=None):
-    """HBM bytes per launch of the dominant kernel(s) from the committed PMC summary (profiles/r05_pmc_summary.json, produced by
-    tools/profile_round5.sh on the GPU box: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, corrected 2*FETCH + WRITE) — a
+    """HBM bytes per launch of the dominant kernel(s) from the committed PMC summary (profiles/r06_pmc_summary.json, produced by
+    tools/profile_round6.sh on the GPU box: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, corrected 2*FETCH + WRITE) — a
     rocprofv3 --pmc pass cannot run inside the timed bench. `kernel`: one kernel name, "k_resolve6" (one ROUND = k_r6_propose* +
     k_r6_commit*), or a list of kernel names whose per-launch bytes are summed (one round of that mode); `run`: the profiled run
     whose numbers to take (cfg3 / grouped / churn / shards4), default: whichever run saw the kernel first.
     Returns (bytes or None, provenance string)."""
-    for tag in ("r05", "r04", "r03"):   # this round's summary, else the last one that measured the same kernels (its provenance string says which)
+    for tag in ("r06", "r05", "r04", "r03"):   # this round's summary, else the last one that measured the same kernels (its provenance string says which)
         path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
         if not os.path.exists(path):
             continue
@@ -621,10 +621,10 @@ def main():
                                                          parallelism=("ranks: the groups on rank 0's union engine, one broadcast, owners book their share" if by_rank else par)),
                    "pair_evals_per_s": (1 if by_rank else world) * wl.S * wl.N / t_step, "placed": int((out >= 0).sum()),
                    "roofline": {"bound": "hbm", "kernel": "k_groups2", "achieved": alg / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": alg / t_step / 1e9 / HBM_PEAK_GBS, "traffic": profile_traffic("k_groups2", run="grouped")[0],
-                                "traffic_source": profile_traffic("k_groups2", run="grouped")[1], "algorithmic_bytes_per_launch": alg,
+                                "frac": alg / t_step / 1e9 / HBM_PEAK_GBS, "traffic": profile_traffic(["k_g2_static", "k_groups2"], run="grouped")[0],
+                                "traffic_source": profile_traffic(["k_g2_static", "k_groups2"], run="grouped")[1], "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_ms": t_step * 1e3,
-                                "note": "one launch = the whole tick (S groups, one workgroup: a machine wave + 15 helper waves); end-to-end step time (no separate kernel events on this path). "
+                                "note": "one launch = the whole tick (k_g2_static: a wave per static class over the chip, then k_groups2: S groups, one workgroup: a machine wave + 15 helper waves); end-to-end step time (no separate kernel events on this path). "
                                         "The tick is bound by the machine wave's instruction issue while it replays container/heap in the reference's exact order (candidates from the group's static class list, 64 to a chunk; a full heap admits the candidates with its second key by counting them and scatters them by post-order rank, "
                                         "a push that moves is sifted up by the wave, two-key heaps are sorted by the wave; parallel appends / rotation / fill where the keys allow), not by bytes: the fraction says how far from a streaming scan that is"}}
             if world == 1 and not args.no_cpu_baseline:

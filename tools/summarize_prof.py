@@ -52,7 +52,7 @@ def main():
     summary = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 0 [--shards 4]; "
                        "KB per launch as reported; corrected = 2*FETCH + WRITE (gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, "
                        "MI355X_MICROARCH.md HBM section)",
-               "source": "tools/profile_round5.sh %s at commit %s" % (tag, commit or "?"),
+               "source": "tools/profile_round.sh %s at commit %s" % (tag, commit or "?"),
                "hbm_bytes_per_launch": per_launch, "runs": runs}
     json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(per_launch))
