@@ -427,7 +427,7 @@ int swp_shard_run(swp_engine* const* engines, swp_batch* const* batches, uint32_
 
 /* The rank variant: ONE engine per process / GPU, the ranks of a job connected by RCCL over xGMI (librccl.so is loaded on first use;
  * the engine links nothing of it). The rounds are the same kernels — every rank proposes over its own node range, an
- * ncclAllGather on the engine's stream hands every rank the proposals of all of them (block x 288 + 144 bytes per rank and round: the
+ * ncclAllGather on the engine's stream hands every rank the proposals of all of them (block x 224 + 144 bytes per rank and round: the
  * proposals, the trailer slots of a placed task's volumes and the rank's `dead` word — a rank whose launch failed keeps issuing the
  * stretch's collectives with that word set, every rank's kernels stand still, and all ranks leave at the next status exchange), and
  * EVERY rank folds + matches the block (the same deterministic wave everywhere: no second collective to agree on the picks) and

@@ -67,12 +67,13 @@ static_assert(sizeof(Blk6) == 104, "Blk6 layout");
 
 struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidates, as 32-node half-words
     u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); half-words listed | bit 31: there are more
-    u32 hw[2 * R6_CAND];     // half-word index (node = 32 * hw + bit), ascending: the first 2 * R6_CAND NON-EMPTY half-words of the level
+    unsigned short hw[2 * R6_CAND];   // half-word index (node = 32 * hw + bit), ascending: the first 2 * R6_CAND NON-EMPTY half-words of the level — 16 bits
+                                      // (round 6: node sets end at 2^21 nodes): a record is 224 bytes instead of 288, to write, to stage, to fold and to all-gather
     u32 hb[2 * R6_CAND];     // the level's survivors inside each
     u64 exc_hi, exc_lo;      // best node of the service's exception list by nodeLess' key, KEY_NONE: none
     u32 exc_entry, flags;    // flags bit 0: the task does not count on its node; bit 1: it has cluster mounts
 };
-static_assert(sizeof(R6Prop) == 8 + 16 * R6_CAND + 24, "R6Prop layout");
+static_assert(sizeof(R6Prop) == 8 + 12 * R6_CAND + 24, "R6Prop layout");
 static_assert(2 * R6_CAND <= 64, "one lane per list entry");
 
 struct R6Args {
@@ -596,11 +597,11 @@ template <int UN, bool CPT = false> WV_DEV void r6_propose_t(const R6Args& a) {
             }
             const u32 at_lo = cnt + wv::mbcnt(b_lo) + wv::mbcnt(b_hi), at_hi = at_lo + (lo != 0 ? 1u : 0u);
             if (lo && at_lo < 2 * R6_CAND) {
-                out->hw[at_lo] = hw_off + 2 * (k * 64 + lane);
+                out->hw[at_lo] = (unsigned short)(hw_off + 2 * (k * 64 + lane));
                 out->hb[at_lo] = lo;
             }
             if (hi && at_hi < 2 * R6_CAND) {
-                out->hw[at_hi] = hw_off + 2 * (k * 64 + lane) + 1;
+                out->hw[at_hi] = (unsigned short)(hw_off + 2 * (k * 64 + lane) + 1);
                 out->hb[at_hi] = hi;
             }
             const u32 total = cnt + (u32)wv::popc64(b_lo) + (u32)wv::popc64(b_hi);
@@ -645,7 +646,7 @@ template <int UN, bool CPT = false> WV_DEV void r6_propose_t(const R6Args& a) {
     const u32 gentry = who ? wv::readlane(be, (u32)wv::ffs64(who)) : 0u;
     if (level != R6_NONE && cnt == 0) {   // every candidate of the level lies among the twins' share: the level's last half-word, all taken by then (a cut)
         if (lane == 0) {
-            out->hw[0] = last_hw;
+            out->hw[0] = (unsigned short)last_hw;
             out->hb[0] = last_hb;
         }
         cnt = 1;
@@ -758,10 +759,13 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             while (wv::lds_poll32(staged + (wave_ - sw)) == 0) wv::spin_pause();
         if (tid < n) {
             const R6Prop* q = a.prop + tid;
-            for (int k = 0; k < 2 * R6_CAND; ++k) {
-                L_hw[(size_t)k * a.block + tid] = (unsigned short)q->hw[k];
-                L_hb[(size_t)k * a.block + tid] = q->hb[k];
+            const u32* qh = reinterpret_cast<const u32*>(q->hw);   // (two indices a dword)
+            for (int k = 0; k < R6_CAND; ++k) {
+                const u32 v = qh[k];
+                L_hw[(size_t)(2 * k) * a.block + tid] = (unsigned short)(v & 0xFFFFu);
+                L_hw[(size_t)(2 * k + 1) * a.block + tid] = (unsigned short)(v >> 16);
             }
+            for (int k = 0; k < 2 * R6_CAND; ++k) L_hb[(size_t)k * a.block + tid] = q->hb[k];
         }
     }
     wv::lockstep();

@@ -166,8 +166,14 @@ WV_DEV void r7_fold_into(const R7Args* m, u32 i, bool have, u32 block, unsigned 
         const u32 t = min(c, 2u * R6_CAND);
         if (have) {
             u32 v[2 * R6_CAND];
-            WV_UNROLL
-            for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hw[k];
+            {
+                const u32* ph = reinterpret_cast<const u32*>(p->hw);   // (two 16-bit indices a dword: half the loads)
+                u32 pk[R6_CAND];
+                WV_UNROLL
+                for (u32 k = 0; k < R6_CAND; ++k) pk[k] = ph[k];
+                WV_UNROLL
+                for (u32 k = 0; k < R6_CAND; ++k) { v[2 * k] = pk[k] & 0xFFFFu; v[2 * k + 1] = pk[k] >> 16; }
+            }
             WV_UNROLL
             for (u32 k = 0; k < 2 * R6_CAND; ++k) L_hw[(size_t)k * block + i] = (unsigned short)(k < t ? base + v[k] : 0u);
             WV_UNROLL
@@ -190,8 +196,14 @@ WV_DEV void r7_fold_into(const R7Args* m, u32 i, bool have, u32 block, unsigned 
         {   // (the whole wave: lanes with nothing to append ride along with t = 0 — the entry loops end where NO lane has one left, a
             // uniform branch; a store per entry under its own predicate is a skipped branch each: 64 of them cost more than the step's loads)
             u32 v[2 * R6_CAND];
-            WV_UNROLL
-            for (u32 k = 0; k < 2 * R6_CAND; ++k) v[k] = p->hw[k];
+            {
+                const u32* ph = reinterpret_cast<const u32*>(p->hw);
+                u32 pk[R6_CAND];
+                WV_UNROLL
+                for (u32 k = 0; k < R6_CAND; ++k) pk[k] = ph[k];
+                WV_UNROLL
+                for (u32 k = 0; k < R6_CAND; ++k) { v[2 * k] = pk[k] & 0xFFFFu; v[2 * k + 1] = pk[k] >> 16; }
+            }
             WV_UNROLL
             for (u32 k = 0; k < 2 * R6_CAND; ++k) {
                 if (!wv::ballot(k < t)) break;

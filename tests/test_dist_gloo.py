@@ -137,7 +137,7 @@ def _rounds_worker(rank, world, port, q, emu, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     seed, N, T, S, block, order, feat = case[:7]
     churn = len(case) > 7 and case[7] == "c"   # a second batch after node and task events (the emulation's "c" flag)
-    prop_bytes = 8 + 16 * 16 + 24   # sizeof(R6Prop): level, n_cand, 2 x 32 half-word entries, the exception-list candidate
+    prop_bytes = 8 + 12 * 16 + 24   # sizeof(R6Prop): level, n_cand, 32 half-word indices (16 bits) + 32 candidate words, the exception-list candidate
     send_bytes = block * prop_bytes + 144   # + sizeof(R7Tail): what a rank contributes to a round's exchange (swp_resolve7.hpp r7_send_bytes)
     proc = subprocess.Popen([emu] + [str(x) for x in (seed, N, T, S, block, order, feat, world)] + ["r%d" % rank] + (["c"] if churn else []), stdin=subprocess.PIPE,
                             stdout=subprocess.PIPE, stderr=subprocess.PIPE)
