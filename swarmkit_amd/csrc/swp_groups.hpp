@@ -778,7 +778,19 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
 #define G2_X(q) do { if (G2_PROF_ON(a)) { const u64 n_ = wv::clock64(); gx[q] += n_ - tx; tx = n_; } } while (0)
 
     // ---------- per-group reset: tree-node arrays, leaf heap offsets (a leaf's heap holds at most min(k, its nodes)) ----------
-    {
+    if (single) {
+        // a tree of one node: its heap takes all the group's slots (the host counted min(k, nodes of the leaf)); decisionTree.tasks is
+        // only read by the walk over a tree with levels — nothing to fetch from global memory here
+        if (lane == 0) {
+            A.tsum[0] = 0;
+            A.h_len[0] = 0; A.h_cnt[0] = 0; A.h_adm[0] = 0; A.noroom[0] = 0; A.h_vis[0] = 0;
+            A.h_off[0] = 0;
+            mb->sh[SH_ERR] = 0; mb->sh[SH_LASTP] = 0;
+        }
+        const u32 kt = k < G.n_slots ? k : G.n_slots;
+        for (u32 i = lane; i < kt; i += 64) A.tcount[i] = 0;
+        wv::wave_sync();
+    } else {
         u32 run = 0;
         for (u32 i0 = 0; i0 < ntn; i0 += 64) {
             const u32 i = i0 + lane;
@@ -1733,14 +1745,19 @@ WV_DEV bool g2_group(const Groups2Args& a, G2Mail* mb, G2Stage* sg, unsigned cha
             const u32 i = i0 + lane;
             const bool act = i < nt;
             const u32 n = act ? A.tnode[i] : 0u, pl = act ? A.tcount[i] : 0u;
-            const i64 oc = a.cpu[n], om = a.mem[n];
-            const u32 ot = a.total[n];
+            // (after the all-lanes fill task j sits at heap position j: the node's new residuals and task count are in the arena already —
+            // three gathers less)
+            i64 oc = 0, om = 0;
+            u32 ot = 0;
+            if (!filled) { oc = a.cpu[n]; om = a.mem[n]; ot = a.total[n]; }
+            const G2Res fr = A.PS[filled && act ? i : 0u];
+            const u64 fkey = A.HE[filled && act ? i : 0u].key;
             const u32 e1 = a.lpos_dense[(size_t)b * N + n], osv = a.svc_dense[(size_t)b * N + n];
             const u32 cp = a.cpos[(size_t)bn * N + n];
             G2In in;
             g2_load_in<false, true, true>(a, Gn, bn, n, in);
-            const i64 nc = oc - (i64)pl * G.cpu, nm = om - (i64)pl * G.mem;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
-            const u32 ntot = ot + (counted ? pl : 0u);
+            const i64 nc = filled ? fr.cpu : oc - (i64)pl * G.cpu, nm = filled ? fr.mem : om - (i64)pl * G.mem;   // NodeInfo.addTask's arithmetic for the node's `pl` new tasks (nodeinfo.go:128-153)
+            const u32 ntot = filled ? (u32)fkey : ot + (counted ? pl : 0u);
             in.c = nc; in.m = nm; in.tot = ntot;
             u64 key;
             bool as_listed;
