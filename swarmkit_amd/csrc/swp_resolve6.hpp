@@ -795,6 +795,7 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
         for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
             const u32 i = g0 + lane, glim = min(64u, n - g0);
             const bool have = i < n;
+            const u32 tmid = (!R7 && a.tmpl != nullptr && have) ? a.tmpl[pos + i] : 0u;   // the task's descriptor id (a RUN of identical tasks: below); requested ahead of the wait
             const u64 tg0 = prof ? wv::clock64() : 0;
             while (wv::lds_poll32(staged + (g0 >> 6)) == 0) wv::spin_pause();   // (long there, but for the first groups of a block)
             const u64 tga = prof ? wv::clock64() : 0;
@@ -846,8 +847,59 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
                     cur += adv;
                 }
             };
+            // ---- A group that is ONE RUN of identical tasks (service-major batches: a service's tasks follow each other) needs no walk.
+            // Identical tasks have the same candidates in the same order, and each takes the first one nobody took: task j of the run
+            // takes the (j + 1)-th candidate that is still free when the group starts — of lane 0's list, which starts in front of all
+            // the others' (a twin's list starts a twin's share further on: k_r6_propose; the candidates in front of lane 0's are taken
+            // by then). Lane h looks at entry h of that list behind its cursor and counts what the TK row leaves of it; a prefix sum
+            // places the half-words on the lanes' ranks (a marker at every half-word's first rank, summed up: the half-word a rank
+            // falls into); every lane picks its bit. If the list holds fewer free candidates than the group has tasks, the ordinary
+            // seating and walk take over (they cut the block where the list is exhausted).
+            bool fastrun = false;
+            u32 fr_w = 0, fr_b = 0;
+            if constexpr (!R7) {
+                if (a.tmpl != nullptr && glim >= 8u && g0 + 64u <= a.block) {   // (the scratch below: 64 pick slots from g0 on)
+                    const bool simple = plain && !(p->flags & 3u);
+                    const u32 t0 = wv::readlane(tmid, 0);
+                    if (wv::ballot(have && (!simple || tmid != t0)) == 0) {
+                        const u32 cur0 = wv::readlane(cur, 0), nent0 = wv::readlane(nent, 0);
+                        const u32 k = cur0 + lane;
+                        const bool hv = lane < 32u && k < nent0;
+                        const u32 hwv = hv ? L_hw[(size_t)k * a.block + g0] : 0u;
+                        const u32 hbv = hv ? L_hb[(size_t)k * a.block + g0] : 0u;
+                        const u32 av = hv ? hbv & ~tk32[hwv] : 0u;
+                        const u32 cnt = (u32)wv::popc64((u64)av);
+                        const u32 incl = wv::scan_incl_u32(cnt), excl = incl - cnt;
+                        if (wv::readlane(incl, 63) >= glim) {
+                            const u32 ord = wv::mbcnt(wv::ballot(cnt != 0));
+                            pk_node[g0 + lane] = 0;   // (scratch: this group's pick slots are written further down, read by its applying wave behind the publish)
+                            wv::wave_sync();
+                            if (cnt != 0) {
+                                if (excl < 64u) pk_node[g0 + excl] = 1;
+                                pk_idx[g0 + ord] = hwv;
+                                pk_idx[g0 + 32u + ord] = av;
+                                pk_aux[g0 + ord] = excl;
+                            }
+                            wv::wave_sync();
+                            const u32 upto = wv::scan_incl_u32(pk_node[g0 + lane]);   // half-words that begin at or in front of this rank
+                            const u32 oo = lane < glim ? upto - 1u : 0u;
+                            const u32 mav = pk_idx[g0 + 32u + oo], rk = lane < glim ? lane - pk_aux[g0 + oo] : 0u;
+                            fr_w = pk_idx[g0 + oo];
+                            u32 bsel = mav;
+                            for (u32 t = 0; t < 32u; ++t) {
+                                const bool more_ = lane < glim && t < rk;
+                                if (!wv::ballot(more_)) break;
+                                if (more_) bsel &= bsel - 1u;
+                            }
+                            fr_b = bsel & (0u - bsel);
+                            wv::wave_sync();
+                            fastrun = true;
+                        }
+                    }
+                }
+            }
             const u64 tgb = prof ? wv::clock64() : 0;
-            seat(plain, 1u);   // (a second optional step costs more than the stops it saves)
+            if (!fastrun) seat(plain, 1u);   // (a second optional step costs more than the stops it saves)
             const u64 tgc = prof ? wv::clock64() : 0;
             if (prof) { cy_g0 += tga - tg0; cy_g1 += tgb - tga; cy_g2 += tgc - tgb; }
             const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
@@ -888,7 +940,8 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             u32 pickb = 0, from = 0;
             u32 flushed = 0;   // picks of lanes < flushed are in the TK row
             const u64 tg1 = prof ? wv::clock64() : 0;
-            for (;;) {
+            if (fastrun) { w = fr_w; pickb = fr_b; }   // (the run's picks are known: no walk)
+            else for (;;) {
                 const u32 at = wv::match_seq64(bits, w, bits2, w2, pickb, lane, from);
                 if (at >= cut) break;
                 ++reseats;
