@@ -855,51 +855,62 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             // places the half-words on the lanes' ranks (a marker at every half-word's first rank, summed up: the half-word a rank
             // falls into); every lane picks its bit. If the list holds fewer free candidates than the group has tasks, the ordinary
             // seating and walk take over (they cut the block where the list is exhausted).
-            bool fastrun = false;
+            // (A group usually holds the end of one service's run and the start of the next: up to four runs in front of the group's first
+            // task that is not plain-and-counted are taken this way, one after the other — a run's picks are in the TK row before the
+            // next run counts; the lanes behind them are seated and walked as ever, from there.)
+            u32 fdone = 0;   // lanes [0, fdone) have their picks from the run path
             u32 fr_w = 0, fr_b = 0;
             if constexpr (!R7) {
-                if (a.tmpl != nullptr && glim >= 8u && g0 + 64u <= a.block) {   // (the scratch below: 64 pick slots from g0 on)
-                    const bool simple = plain && !(p->flags & 3u);
-                    const u32 t0 = wv::readlane(tmid, 0);
-                    if (wv::ballot(have && (!simple || tmid != t0)) == 0) {
-                        const u32 cur0 = wv::readlane(cur, 0), nent0 = wv::readlane(nent, 0);
+                if (a.tmpl != nullptr && g0 + 64u <= a.block) {   // (the scratch below: 64 pick slots from g0 on)
+                    const bool simple = have && plain && !(p->flags & 3u);
+                    const u64 ns = ~wv::ballot(simple);
+                    const u32 nsimple = min(glim, ns ? (u32)wv::ffs64(ns) : 64u);
+                    for (u32 it = 0; it < 4u && fdone + 8u <= nsimple; ++it) {
+                        const u32 ra = fdone, t_ra = wv::readlane(tmid, ra);
+                        const u64 df = wv::ballot(lane >= ra && lane < nsimple && tmid != t_ra);
+                        const u32 rb = df ? (u32)wv::ffs64(df) : nsimple, rl = rb - ra;
+                        if (rl < 8u) break;   // (a short run: the walk is as good)
+                        const u32 cur0 = wv::readlane(cur, ra), nent0 = wv::readlane(nent, ra);
                         const u32 k = cur0 + lane;
                         const bool hv = lane < 32u && k < nent0;
-                        const u32 hwv = hv ? L_hw[(size_t)k * a.block + g0] : 0u;
-                        const u32 hbv = hv ? L_hb[(size_t)k * a.block + g0] : 0u;
+                        const u32 hwv = hv ? L_hw[(size_t)k * a.block + g0 + ra] : 0u;
+                        const u32 hbv = hv ? L_hb[(size_t)k * a.block + g0 + ra] : 0u;
                         const u32 av = hv ? hbv & ~tk32[hwv] : 0u;
                         const u32 cnt = (u32)wv::popc64((u64)av);
                         const u32 incl = wv::scan_incl_u32(cnt), excl = incl - cnt;
-                        if (wv::readlane(incl, 63) >= glim) {
-                            const u32 ord = wv::mbcnt(wv::ballot(cnt != 0));
-                            pk_node[g0 + lane] = 0;   // (scratch: this group's pick slots are written further down, read by its applying wave behind the publish)
-                            wv::wave_sync();
-                            if (cnt != 0) {
-                                if (excl < 64u) pk_node[g0 + excl] = 1;
-                                pk_idx[g0 + ord] = hwv;
-                                pk_idx[g0 + 32u + ord] = av;
-                                pk_aux[g0 + ord] = excl;
-                            }
-                            wv::wave_sync();
-                            const u32 upto = wv::scan_incl_u32(pk_node[g0 + lane]);   // half-words that begin at or in front of this rank
-                            const u32 oo = lane < glim ? upto - 1u : 0u;
-                            const u32 mav = pk_idx[g0 + 32u + oo], rk = lane < glim ? lane - pk_aux[g0 + oo] : 0u;
-                            fr_w = pk_idx[g0 + oo];
-                            u32 bsel = mav;
-                            for (u32 t = 0; t < 32u; ++t) {
-                                const bool more_ = lane < glim && t < rk;
-                                if (!wv::ballot(more_)) break;
-                                if (more_) bsel &= bsel - 1u;
-                            }
-                            fr_b = bsel & (0u - bsel);
-                            wv::wave_sync();
-                            fastrun = true;
+                        if (wv::readlane(incl, 63) < rl) break;   // the list holds too few free candidates: seating and walk cut the block where it ends
+                        const u32 ord = wv::mbcnt(wv::ballot(cnt != 0));
+                        pk_node[g0 + lane] = 0;   // (scratch: this group's pick slots are written further down, read by its applying wave behind the publish)
+                        wv::wave_sync();
+                        if (cnt != 0) {
+                            if (ra + excl < 64u) pk_node[g0 + ra + excl] = 1;   // a marker at the lane whose rank is the half-word's first
+                            pk_idx[g0 + ord] = hwv;
+                            pk_idx[g0 + 32u + ord] = av;
+                            pk_aux[g0 + ord] = excl;
                         }
+                        wv::wave_sync();
+                        const u32 upto = wv::scan_incl_u32(pk_node[g0 + lane]);   // half-words that begin at or in front of this lane's rank
+                        const bool inr = lane >= ra && lane < rb;
+                        const u32 oo = inr ? upto - 1u : 0u;
+                        const u32 mav = pk_idx[g0 + 32u + oo], mhw = pk_idx[g0 + oo], rk = inr ? (lane - ra) - pk_aux[g0 + oo] : 0u;
+                        u32 bsel = mav;
+                        for (u32 t = 0; t < 32u; ++t) {
+                            const bool more_ = inr && t < rk;
+                            if (!wv::ballot(more_)) break;
+                            if (more_) bsel &= bsel - 1u;
+                        }
+                        if (inr) {
+                            fr_w = mhw;
+                            fr_b = bsel & (0u - bsel);
+                            wv::lds_or32(tk32 + fr_w, fr_b);   // (the next run, the seating and the later groups meet it there)
+                        }
+                        wv::wave_sync();
+                        fdone = rb;
                     }
                 }
             }
             const u64 tgb = prof ? wv::clock64() : 0;
-            if (!fastrun) seat(plain, 1u);   // (a second optional step costs more than the stops it saves)
+            if (fdone < glim) seat(plain && lane >= fdone, 1u);   // (a second optional step costs more than the stops it saves)
             const u64 tgc = prof ? wv::clock64() : 0;
             if (prof) { cy_g0 += tga - tg0; cy_g1 += tgb - tga; cy_g2 += tgc - tgb; }
             const u64 lanes = glim == 64 ? ~0ull : (1ull << glim) - 1ull;
@@ -937,11 +948,11 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             // carry a dummy, and the lane at the cut (if the cut is inside the group) stops it with empty bits
             const bool served = plain && lane < cut;
             if (!served) { bits = lane == cut ? 0u : 1u; bits2 = 0; w = WV_DUMMY_W | lane; }
-            u32 pickb = 0, from = 0;
-            u32 flushed = 0;   // picks of lanes < flushed are in the TK row
+            u32 pickb = 0, from = fdone;
+            u32 flushed = fdone;   // picks of lanes < flushed are in the TK row
             const u64 tg1 = prof ? wv::clock64() : 0;
-            if (fastrun) { w = fr_w; pickb = fr_b; }   // (the run's picks are known: no walk)
-            else for (;;) {
+            if (lane < fdone) { w = fr_w; pickb = fr_b; }   // (the runs' picks are known: the walk starts behind them)
+            if (fdone < cut) for (;;) {
                 const u32 at = wv::match_seq64(bits, w, bits2, w2, pickb, lane, from);
                 if (at >= cut) break;
                 ++reseats;
