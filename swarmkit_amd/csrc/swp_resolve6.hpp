@@ -855,8 +855,8 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             // places the half-words on the lanes' ranks (a marker at every half-word's first rank, summed up: the half-word a rank
             // falls into); every lane picks its bit. If the list holds fewer free candidates than the group has tasks, the ordinary
             // seating and walk take over (they cut the block where the list is exhausted).
-            // (A group usually holds the end of one service's run and the start of the next: up to four runs in front of the group's first
-            // task that is not plain-and-counted are taken this way, one after the other — a run's picks are in the TK row before the
+            // (A group usually holds the end of one service's run and the start of the next: up to eight runs — or stretches of a run that
+            // one list's free candidates cover — in front of the group's first task that is not plain-and-counted are taken this way, one after the other — a run's picks are in the TK row before the
             // next run counts; the lanes behind them are seated and walked as ever, from there.)
             u32 fdone = 0;   // lanes [0, fdone) have their picks from the run path
             u32 fr_w = 0, fr_b = 0;
@@ -865,10 +865,10 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
                     const bool simple = have && plain && !(p->flags & 3u);
                     const u64 ns = ~wv::ballot(simple);
                     const u32 nsimple = min(glim, ns ? (u32)wv::ffs64(ns) : 64u);
-                    for (u32 it = 0; it < 4u && fdone + 8u <= nsimple; ++it) {
+                    for (u32 it = 0; it < 8u && fdone + 8u <= nsimple; ++it) {
                         const u32 ra = fdone, t_ra = wv::readlane(tmid, ra);
                         const u64 df = wv::ballot(lane >= ra && lane < nsimple && tmid != t_ra);
-                        const u32 rb = df ? (u32)wv::ffs64(df) : nsimple, rl = rb - ra;
+                        u32 rb = df ? (u32)wv::ffs64(df) : nsimple, rl = rb - ra;
                         if (rl < 8u) break;   // (a short run: the walk is as good)
                         const u32 cur0 = wv::readlane(cur, ra), nent0 = wv::readlane(nent, ra);
                         const u32 k = cur0 + lane;
@@ -878,7 +878,12 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
                         const u32 av = hv ? hbv & ~tk32[hwv] : 0u;
                         const u32 cnt = (u32)wv::popc64((u64)av);
                         const u32 incl = wv::scan_incl_u32(cnt), excl = incl - cnt;
-                        if (wv::readlane(incl, 63) < rl) break;   // the list holds too few free candidates: seating and walk cut the block where it ends
+                        const u32 free_ = wv::readlane(incl, 63);
+                        if (free_ < rl) {   // lane ra's list holds fewer free candidates than the run has tasks: it serves as many, the next turn
+                            if (free_ < 8u) break;   // goes on with the list of the first lane behind them (it starts further into the level)
+                            rl = free_;
+                            rb = ra + rl;
+                        }
                         const u32 ord = wv::mbcnt(wv::ballot(cnt != 0));
                         pk_node[g0 + lane] = 0;   // (scratch: this group's pick slots are written further down, read by its applying wave behind the publish)
                         wv::wave_sync();
