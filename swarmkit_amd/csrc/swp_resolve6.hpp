@@ -789,8 +789,12 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             const u32 mt = H_meta[j];
             return Head{H_level[j], mt & 0xFFu, (mt & R7M_EXC) ? 0ull : KEY_NONE, 0ull, 0u, ((mt & R7M_UNC) ? 1u : 0u) | ((mt & R7M_CSI) ? 2u : 0u)};
         };
-        Head nxt{};
-        if constexpr (!R7) nxt = head_of(lane < n ? lane : 0);
+        Head nxt{}, nx2{};   // the heads of the next group and of the one behind it (a group that is one run of identical tasks is through
+                              // before a load issued at its start has answered: two groups ahead since round 6)
+        if constexpr (!R7) {
+            nxt = head_of(lane < n ? lane : 0);
+            nx2 = head_of(64u + lane < n ? 64u + lane : 0);
+        }
         if (R7 && CSI && sh[12]) csi_seen = true;   // a reservation arrived from another shard only now: the proposals of tasks with mounts were made without it
         for (u32 g0 = 0; g0 < n && !stop; g0 += 64) {
             const u32 i = g0 + lane, glim = min(64u, n - g0);
@@ -802,7 +806,10 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             Head rec = nxt;
             if constexpr (R7) rec = head7(have ? i : 0u);
             const Head* p = &rec;
-            if (!R7 && g0 + 64 < n) nxt = head_of(i + 64 < n ? i + 64 : 0);
+            if constexpr (!R7) {
+                nxt = nx2;
+                if (g0 + 128 < n) nx2 = head_of(i + 128 < n ? i + 128 : 0);
+            }
             const u32 level = have ? p->level : 0u;
             const u32 nent = (have && level != R6_NONE) ? (p->n_cand & 0x7FFFFFFFu) : 0u;
             const bool plain = nent != 0;
