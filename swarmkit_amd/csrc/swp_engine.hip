@@ -1823,6 +1823,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(r));
         uint32_t pos = start, chunk = std::min<uint32_t>(16u, (end - start + 255u) / 256u + 1u);   // a short stretch does not pay for empty rounds
         uint32_t rounds_seen = 0, scan_len = 2048, scanned = 0;
+        bool after_scan = false;   // the rounds since the last scan stretch: four of them say whether the tasks still have no plain candidates
         // The compact index (swp_resolve6.hpp, R6Args.compact): one more small launch per round, worth it when the level the tasks aim at is a
         // sparse set of nodes (re-placements after a drain): the matcher then stops at an emptied half-word every few tasks and the rounds are
         // cut by exhausted lists after a fraction of their block. Switched on by that symptom (a stop per <= 12 decided tasks; ordinary
@@ -1864,7 +1865,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                     else if (cpt && used >= 4 && cr == 0) cpt = false;
                 }
             }
-            if (scan_ok && used >= 8 && recent < 8.0 && end - pos >= 64) {
+            if (scan_ok && used >= (after_scan ? 4u : 8u) && recent < 8.0 && end - pos >= 64) {
                 const uint32_t upto = std::min<uint64_t>(end, (uint64_t)pos + scan_len);
                 ScanArgs sa{};
                 sa.a = ra;
@@ -1885,9 +1886,11 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 scanned += upto - pos;
                 pos = upto;
                 scan_len = std::min<uint32_t>(scan_len * 2, 1u << 20);   // still no plain candidates afterwards: the next stretch is twice as long
-                chunk = 16;
+                chunk = 4;   // (round 6: sixteen rounds of ~40 us between two stretches were a sixth of the dense batch)
+                after_scan = true;
                 continue;
             }
+            after_scan = false;
             // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
             const double pace = std::max(1.0, recent);
             chunk = (uint32_t)std::min<double>(4096.0, (double)(end - pos) / pace * 1.05 + 4.0);
@@ -1900,7 +1903,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 chunk = std::min<uint32_t>(chunk, ra.block < r6_block ? 64u : 4096u);   // (look again before long while the block is small)
             }
         }
-        if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u)\n", scanned, start, end);
+        if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u), %u of them without a look (an identical task had found no node)\n", scanned, start, end, hb.scan_skipped);
         if ((dbg_bits & 16) && hb.crounds) fprintf(stderr, "[swp] %u of the %u rounds with a compact index | of the cuts at an exhausted list: %u full lists, %u lists in compact positions, %u lists of one entry\n", hb.crounds, hb.rounds, hb.dbg_cut[0], hb.dbg_cut[1], hb.dbg_cut[2]);
         e->r6_compact_hint = cpt && cpt_paid;
         r6_rounds += hb.rounds;

@@ -62,8 +62,9 @@ struct Blk6 {   // control block, global memory
     u32 csize, clevel;     // compact index of this round (k_r6_compact): its nodes (0: none, every list in plain half-words), their level above the base
     u32 crounds;           // rounds that had one
     u32 dbg_cut[3];        // dbg: of the cuts at an exhausted list, those whose list was full (more candidates on the level), in compact positions, one entry long
+    u32 scan_skipped;      // k_scanb: tasks answered "no node" without a look (an identical task found none earlier in the stretch)
 };
-static_assert(sizeof(Blk6) == 104, "Blk6 layout");
+static_assert(sizeof(Blk6) == 108, "Blk6 layout");
 
 struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidates, as 32-node half-words
     u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); half-words listed | bit 31: there are more

@@ -51,9 +51,22 @@ inline __host__ __device__ size_t scan_lds_lm(u32 n_nodes, u32 n_svc) { return (
 // stretch may reserve generic resources, publish host ports or mount cluster volumes (their inputs live in global memory, and a
 // volume's state is not node-local): the launcher checks, and everything a task reads — node rows, the (service, node) matrices, the
 // static class rows — is in LDS.
+//
+// Tasks nobody needs to look at. Inside a batch nothing is ever given back: a (task, node) pair that fails a filter fails it for the rest
+// of the tick. So once a task found NO node, every later task with the same descriptor (R6Args.tmpl: the same service, class
+// row, reservations, replica limit) finds none either — a saturated cluster answers its whole backlog that way. The stretch is walked in
+// WINDOWS of SCAN_W tasks: a thread per task asks a small table of such descriptors (exact ids, one per cell: a cell taken by another
+// descriptor just means no short cut), the tasks that are left form the window's queue — a bit mask, every thread holds it — and only they
+// are evaluated, SCAN_B at a time. A skipped task changes nothing, so the others' order among themselves is all that matters; what the
+// sequence of ALL tasks fixes — a task's place in the list of unplaceable tasks, the number of commits in front of it (Explain's
+// moment) — is written at the window's end from the mask of placed tasks: place = unplaced tasks in front, commits = placed ones in front.
 #define SCAN_B 4
+#define SCAN_W 256          // tasks of a window: their records (16 KB) and descriptor ids in LDS, the next window's in registers
+#define SCAN_DT 1024        // cells of the table of descriptors found unplaceable
+inline __host__ __device__ u32 scan_dt_cell(u32 tm) { return (tm * 2654435761u) >> 22; }
 inline __host__ __device__ size_t scan_lds_b(u32 n_nodes, u32 n_svc, u32 n_sc) {
-    return ((scan_lds_lm(n_nodes, n_svc) + 15) & ~(size_t)15) + (size_t)n_sc * ((n_nodes + 63) / 64) * 8 + 3 * SCAN_B * 8;
+    return (((size_t)n_nodes * 24 + 15) & ~(size_t)15) + (size_t)2 * n_svc * n_nodes * 4 + (size_t)n_sc * ((n_nodes + 63) / 64) * 8 + 3 * SCAN_B * 8 +
+           (SCAN_W / 64) * 8 + 16 + (size_t)SCAN_W * 64 + SCAN_W * 4 + SCAN_DT * 4;
 }
 
 #ifdef SWP_SCAN_KERNELS
@@ -264,129 +277,178 @@ WV_KERNEL(SCAN_THREADS) void k_scanb(ScanArgs s) {
     i64* mem = cpu + N;
     u32* tot = reinterpret_cast<u32*>(mem + N);
     int32_t* lastc = reinterpret_cast<int32_t*>(tot + N);
-    u32* rtq = reinterpret_cast<u32*>(l + (((size_t)N * 24 + 15) & ~(size_t)15)) + 2 * 16 + 16;   // (where k_scan keeps its records: behind red_k[16], red_n[16])
-    u32* hm = reinterpret_cast<u32*>(l + ((scan_lds(N) + 15) & ~(size_t)15));
+    u32* hm = reinterpret_cast<u32*>(l + (((size_t)N * 24 + 15) & ~(size_t)15));
     u32* em = hm + (size_t)s.n_svc * N;
-    u64* scl = reinterpret_cast<u64*>(l + ((scan_lds_lm(N, s.n_svc) + 15) & ~(size_t)15));       // [n_sc][Wn] the static class rows
+    u64* scl = reinterpret_cast<u64*>(em + (size_t)s.n_svc * N);                                   // [n_sc][Wn] the static class rows
     u64* red = scl + (size_t)s.n_sc * Wn;                                                            // [3][SCAN_B] the argmins, three sets in rotation
+    u64* wlive = red + 3 * SCAN_B;                                                                   // [SCAN_W / 64] the window's queue: tasks to be looked at
+    u32* wrec = reinterpret_cast<u32*>(l + ((reinterpret_cast<unsigned char*>(wlive + SCAN_W / 64) - l + 15) & ~(size_t)15));   // [SCAN_W][16] the window's task records
+    u32* wtm = wrec + SCAN_W * 16;                                                                   // [SCAN_W] ... and descriptor ids
+    u32* dtab = wtm + SCAN_W;                                                                        // [SCAN_DT] descriptors found unplaceable (id + 1; 0: free)
     if (a.blk->error != ERR_NONE) return;
     for (u32 n = tid; n < N; n += SCAN_THREADS) { cpu[n] = a.cpu[n]; mem[n] = a.mem[n]; tot[n] = a.total[n]; lastc[n] = a.last[n]; }
     for (u32 x = tid; x < s.n_svc * N; x += SCAN_THREADS) { hm[x] = s.hmat[x]; em[x] = s.emat[x]; }
     for (u32 x = tid; x < s.n_sc * Wn; x += SCAN_THREADS) scl[x] = a.sc[x];
+    for (u32 x = tid; x < SCAN_DT; x += SCAN_THREADS) dtab[x] = 0;
     if (tid < 3 * SCAN_B) red[tid] = KEY_NONE;
     u32 nc = a.ctl->ncommit, ni = a.ctl->ninf;
     const u32* rt32 = reinterpret_cast<const u32*>(a.rt);
-    const u32 cdw = SCAN_RTQ * 16u;   // dwords of a chunk of task records
-    auto chunk_load = [&](u32 c) -> u32 {
-        const u32 t0 = s.j0 + c * SCAN_RTQ;
-        return (tid < cdw && t0 + tid / 16u < s.j1) ? rt32[(size_t)t0 * 16u + tid] : 0u;
+    // a window's records are 16 KB: sixteen bytes a thread, requested a window ahead (each is read once: a miss all the way to HBM)
+    u32 nr[4], ntm;
+    auto window_load = [&](u32 base) {
+        const bool have = base < s.j1 && base + tid / 4u < s.j1;
+        WV_UNROLL
+        for (int k = 0; k < 4; ++k) nr[k] = have ? rt32[(size_t)base * 16u + tid * 4u + (u32)k] : 0u;
+        ntm = (tid < SCAN_W && base < s.j1 && base + tid < s.j1) ? (a.tmpl ? a.tmpl[base + tid] : base + tid) : 0u;
     };
-    if (tid < cdw) rtq[tid] = chunk_load(0);
-    u32 next_dw = chunk_load(1);
-    u32 slot = 0;
-    wv::barrier();
-    for (u32 t = s.j0; t < s.j1;) {
-        const u32 i = t - s.j0;
-        if (i != 0 && i % SCAN_RTQ == 0) {   // the batch opens a chunk of records: it is in this thread's register since the chunk before
-            const u32 c = i / SCAN_RTQ;
-            if (tid < cdw) rtq[(c & 1u) * cdw + tid] = next_dw;   // (that half was last read a chunk ago: barriers lie in between)
-            next_dw = chunk_load(c + 1);
-            wv::barrier();
-        }
-        const u32 nb = min(min((u32)SCAN_B, s.j1 - t), SCAN_RTQ - i % SCAN_RTQ);   // (a batch stays inside one chunk)
-        RTask r[SCAN_B];
-        u64 bk[SCAN_B];
+    window_load(s.j0);
+    u32 slot = 0, skipped = 0;
+    for (u32 base = s.j0; base < s.j1; base += SCAN_W) {
+        const u32 wn = min((u32)SCAN_W, s.j1 - base);
+        wv::barrier();   // everybody is past the window before (its records, its ids), and what it added to the table is in
         WV_UNROLL
-        for (int b = 0; b < SCAN_B; ++b) {
-            bk[b] = KEY_NONE;
-            const u32 ib = i + ((u32)b < nb ? (u32)b : 0u);
-            r[b] = *reinterpret_cast<const RTask*>(rtq + ((ib / SCAN_RTQ) & 1u) * cdw + (ib % SCAN_RTQ) * 16u);
-        }
-        // ---- every thread: the best of its own nodes, for each of the batch's tasks
-        WV_UNROLL
-        for (int b = 0; b < SCAN_B; ++b) {
-            if ((u32)b >= nb) continue;
-            WV_UNROLL
-            for (int q = 0; q < SCAN_NQ; ++q) {
-                const u32 n = tid + (u32)q * SCAN_THREADS;
-                if (n >= N) continue;
-                if (!((scl[(size_t)r[b].sc * Wn + (n >> 6)] >> (n & 63)) & 1ull)) continue;   // valid & ready & constraints & platform & plugins
-                const u32 hi = hm[(size_t)r[b].svc * N + n];
-                if ((r[b].flags & RT_RES) && !(r[b].cpu <= cpu[n] && r[b].mem <= mem[n])) continue;
-                if ((r[b].flags & RT_MAXREP) && !((u64)(hi & 0xFFFFFFu) < r[b].maxrep)) continue;
-                const u32 tn = tot[n];
-                if (tn >> 20) a.blk->error = ERR_LEVEL_RANGE;
-                const u64 key = ((u64)hi << 32) | ((u64)tn << 12) | n;
-                if (key < bk[b]) bk[b] = key;
-            }
-        }
-        WV_UNROLL
-        for (int b = 0; b < SCAN_B; ++b) {
-            const u64 wk = r6_wave_min64(bk[b]);
-            if (lane == 0 && wk != KEY_NONE) wv::lds_min64(red + slot * SCAN_B + b, wk);
-        }
+        for (int k = 0; k < 4; ++k) wrec[tid * 4u + (u32)k] = nr[k];
+        const u32 tm = ntm;
+        if (tid < SCAN_W) wtm[tid] = tm;
+        window_load(base + SCAN_W);
+        const u64 lb = wv::ballot(tid < wn && dtab[scan_dt_cell(tm)] != tm + 1u);
+        if (tid < SCAN_W && lane == 0) wlive[tid >> 6] = lb;
         wv::barrier();
-        u64 gk[SCAN_B];
+        const u32 nc0 = nc;
+        u64 placed[SCAN_W / 64], looked[SCAN_W / 64];
         WV_UNROLL
-        for (int b = 0; b < SCAN_B; ++b) gk[b] = wv::lds_read64(red + slot * SCAN_B + b);
-        if (tid < SCAN_B) red[(slot == 0 ? 2u : slot - 1u) * SCAN_B + tid] = KEY_NONE;   // (the set of the batch before: everybody is past reading it)
-        slot = slot == 2 ? 0 : slot + 1;
-        // ---- the longest prefix of tasks whose picks differ (the same on every thread: the same words)
-        u32 na = 0;
-        u32 gn[SCAN_B];
-        WV_UNROLL
-        for (int b = 0; b < SCAN_B; ++b) {
-            gn[b] = gk[b] == KEY_NONE ? R6_NONE : (u32)gk[b] & 0xFFFu;
-            bool clash = (u32)b >= nb || na != (u32)b;   // (behind a task that was not accepted nothing is)
-            WV_UNROLL
-            for (int c = 0; c < b; ++c) clash = clash || (gn[b] != R6_NONE && gn[c] == gn[b]);
-            if (!clash) na = (u32)b + 1u;
-        }
-        // ---- the owners apply (NodeInfo.addTask); everybody counts
-        WV_UNROLL
-        for (int b = 0; b < SCAN_B; ++b) {
-            if ((u32)b >= na) continue;
-            const u32 tb = t + (u32)b;
-            if (gn[b] == R6_NONE) {
-                if (tid == 0) {
-                    a.inf_task[ni] = tb;
-                    a.inf_pos[ni] = nc;
-                    a.out_node[tb] = -1;
+        for (int cw = 0; cw < SCAN_W / 64; ++cw) {
+            const u64 lv = wv::lds_read64(wlive + cw);
+            u64 cur = ((u64)wv::readfirstlane((u32)(lv >> 32)) << 32) | wv::readfirstlane((u32)lv);   // (the same on every thread: the loop below is a scalar one)
+            u64 pl = 0;
+            looked[cw] = cur;
+            while (cur) {
+                // ---- the batch: the next SCAN_B tasks of the queue (a batch stays inside one word of it)
+                u32 ib[SCAN_B];
+                u32 nb = 0;
+                {
+                    u64 c2 = cur;
+                    WV_UNROLL
+                    for (int b = 0; b < SCAN_B; ++b) {
+                        ib[b] = c2 ? (u32)cw * 64u + (u32)wv::ffs64(c2) : ib[0];
+                        if (c2) ++nb;
+                        c2 &= c2 - 1ull;
+                    }
                 }
-                ++ni;
-                continue;
-            }
-            if ((gn[b] & (SCAN_THREADS - 1u)) == tid) {
-                const u32 nd = gn[b], w = nd >> 6;
-                const u64 bit = 1ull << (nd & 63);
-                if (r[b].cpu) cpu[nd] -= r[b].cpu;
-                if (r[b].mem) mem[nd] -= r[b].mem;
-                if (!(r[b].flags & RT_UNCOUNTED)) {
-                    tot[nd] += 1;
-                    u32 hi = hm[(size_t)r[b].svc * N + nd] + 1u;
-                    u32 entry = em[(size_t)r[b].svc * N + nd];
-                    if ((hi & 0xFFFFFFu) == 0) a.blk->error = ERR_GROUP_RANGE;
-                    hm[(size_t)r[b].svc * N + nd] = hi;
-                    if (entry == LIST_EMPTY) {
-                        wv::g_or64(a.X + (size_t)r[b].svc * a.xs + w, bit);
-                        a.list_node[r[b].slot] = nd;
-                        a.list_svc[r[b].slot] = 1;
-                        a.list_fail[r[b].slot] = 0;
-                        em[(size_t)r[b].svc * N + nd] = r[b].slot;
-                    } else
-                        a.list_svc[entry] = hi & 0xFFFFFFu;
+                RTask r[SCAN_B];
+                u64 bk[SCAN_B];
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    bk[b] = KEY_NONE;
+                    r[b] = *reinterpret_cast<const RTask*>(wrec + ib[b] * 16u);
                 }
-                const int32_t prev = lastc[nd];
-                a.log_node[nc] = nd;
-                a.log_task[nc] = tb;
-                a.log_prev[nc] = prev;
-                lastc[nd] = (int32_t)nc;
-                a.out_node[tb] = (int32_t)nd;
+                // ---- every thread: the best of its own nodes, for each of the batch's tasks
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    if ((u32)b >= nb) continue;
+                    WV_UNROLL
+                    for (int q = 0; q < SCAN_NQ; ++q) {
+                        const u32 n = tid + (u32)q * SCAN_THREADS;
+                        if (n >= N) continue;
+                        if (!((scl[(size_t)r[b].sc * Wn + (n >> 6)] >> (n & 63)) & 1ull)) continue;   // valid & ready & constraints & platform & plugins
+                        const u32 hi = hm[(size_t)r[b].svc * N + n];
+                        if ((r[b].flags & RT_RES) && !(r[b].cpu <= cpu[n] && r[b].mem <= mem[n])) continue;
+                        if ((r[b].flags & RT_MAXREP) && !((u64)(hi & 0xFFFFFFu) < r[b].maxrep)) continue;
+                        const u32 tn = tot[n];
+                        if (tn >> 20) a.blk->error = ERR_LEVEL_RANGE;
+                        const u64 key = ((u64)hi << 32) | ((u64)tn << 12) | n;
+                        if (key < bk[b]) bk[b] = key;
+                    }
+                }
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    const u64 wk = r6_wave_min64(bk[b]);
+                    if (lane == 0 && wk != KEY_NONE) wv::lds_min64(red + slot * SCAN_B + b, wk);
+                }
+                wv::barrier();
+                u64 gk[SCAN_B];
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) gk[b] = wv::lds_read64(red + slot * SCAN_B + b);
+                if (tid < SCAN_B) red[(slot == 0 ? 2u : slot - 1u) * SCAN_B + tid] = KEY_NONE;   // (the set of the batch before: everybody is past reading it)
+                slot = slot == 2 ? 0 : slot + 1;
+                // ---- the longest prefix of tasks whose picks differ (the same on every thread: the same words)
+                u32 na = 0;
+                u32 gn[SCAN_B];
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    gn[b] = gk[b] == KEY_NONE ? R6_NONE : (u32)gk[b] & 0xFFFu;
+                    bool clash = (u32)b >= nb || na != (u32)b;   // (behind a task that was not accepted nothing is)
+                    WV_UNROLL
+                    for (int c = 0; c < b; ++c) clash = clash || (gn[b] != R6_NONE && gn[c] == gn[b]);
+                    if (!clash) na = (u32)b + 1u;
+                }
+                // ---- the owners apply (NodeInfo.addTask); everybody counts
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    if ((u32)b >= na) continue;
+                    cur &= cur - 1ull;   // the task leaves the queue
+                    const u32 tb = base + ib[b];
+                    if (gn[b] == R6_NONE) {   // no node: nor for any later task with this descriptor (its place among the unplaceable ones: the window's end)
+                        if (tid == 0) {
+                            const u32 dm = wtm[ib[b]], cell = scan_dt_cell(dm);
+                            if (dtab[cell] == 0) dtab[cell] = dm + 1u;
+                        }
+                        continue;
+                    }
+                    pl |= 1ull << (ib[b] & 63u);
+                    if ((gn[b] & (SCAN_THREADS - 1u)) == tid) {
+                        const u32 nd = gn[b], w = nd >> 6;
+                        const u64 bit = 1ull << (nd & 63);
+                        if (r[b].cpu) cpu[nd] -= r[b].cpu;
+                        if (r[b].mem) mem[nd] -= r[b].mem;
+                        if (!(r[b].flags & RT_UNCOUNTED)) {
+                            tot[nd] += 1;
+                            u32 hi = hm[(size_t)r[b].svc * N + nd] + 1u;
+                            u32 entry = em[(size_t)r[b].svc * N + nd];
+                            if ((hi & 0xFFFFFFu) == 0) a.blk->error = ERR_GROUP_RANGE;
+                            hm[(size_t)r[b].svc * N + nd] = hi;
+                            if (entry == LIST_EMPTY) {
+                                wv::g_or64(a.X + (size_t)r[b].svc * a.xs + w, bit);
+                                a.list_node[r[b].slot] = nd;
+                                a.list_svc[r[b].slot] = 1;
+                                a.list_fail[r[b].slot] = 0;
+                                em[(size_t)r[b].svc * N + nd] = r[b].slot;
+                            } else
+                                a.list_svc[entry] = hi & 0xFFFFFFu;
+                        }
+                        const int32_t prev = lastc[nd];
+                        a.log_node[nc] = nd;
+                        a.log_task[nc] = tb;
+                        a.log_prev[nc] = prev;
+                        lastc[nd] = (int32_t)nc;
+                        a.out_node[tb] = (int32_t)nd;
+                    }
+                    ++nc;
+                }
             }
-            ++nc;
+            placed[cw] = pl;
         }
-        t += na;
+        // ---- the window's unplaceable tasks, looked at or not: a thread per task
+        u32 un_before = 0, un_all = 0;   // unplaced tasks of the words in front of this thread's; of the window
+        u64 un_mine = 0;
+        WV_UNROLL
+        for (int cw = 0; cw < SCAN_W / 64; ++cw) {
+            const u32 left = wn > (u32)cw * 64u ? wn - (u32)cw * 64u : 0u;
+            const u64 un = ~placed[cw] & (left >= 64u ? ~0ull : (1ull << left) - 1ull);
+            if ((tid >> 6) == (u32)cw) { un_before = un_all; un_mine = un; }
+            un_all += (u32)wv::popc64(un);
+        }
+        if (tid < wn && ((un_mine >> lane) & 1ull)) {
+            const u32 rank = un_before + (u32)wv::popc64(un_mine & ((1ull << lane) - 1ull));
+            a.inf_task[ni + rank] = base + tid;
+            a.inf_pos[ni + rank] = nc0 + (tid - rank);   // (the commits in front of it: the window's placed tasks in front of it)
+            a.out_node[base + tid] = -1;
+        }
+        ni += un_all;
+        WV_UNROLL
+        for (int cw = 0; cw < SCAN_W / 64; ++cw) skipped += min(wn > (u32)cw * 64u ? wn - (u32)cw * 64u : 0u, 64u) - (u32)wv::popc64(looked[cw]);
     }
+    if (tid == 0) a.blk->scan_skipped += skipped;
     wv::barrier();
     for (u32 n = tid; n < N; n += SCAN_THREADS) { a.cpu[n] = cpu[n]; a.mem[n] = mem[n]; a.total[n] = tot[n]; a.last[n] = lastc[n]; }
     if (tid == 0) {

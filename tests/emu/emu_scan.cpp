@@ -26,13 +26,14 @@ int main(int argc, char** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
-    bool verbose = false, split = false, task_rows = false, mixed = false, no_lm = false, no_batch = false;
+    bool verbose = false, split = false, task_rows = false, mixed = false, no_lm = false, no_batch = false, no_tmpl = false;
     unsigned batched_launches = 0;
     for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 'm') mixed = true;
         if (argv[i][0] == 'u') no_batch = true;   // the one-task-a-barrier instances even where the batched one (k_scanb) would be launched
         if (argv[i][0] == 'g') no_lm = true;   // the (service, node) matrices stay in global memory even if they would fit in LDS
+        if (argv[i][0] == 'n') no_tmpl = true; // R6Args.tmpl == nullptr (what the shard drivers pass): k_scanb then never skips a task
     }
     if (N > SCAN_MAXN) { fprintf(stderr, "the scan resolver takes %d nodes\n", SCAN_MAXN); return 2; }
     Problem p = make_problem(seed, N, T, S, order, feat);
@@ -110,6 +111,18 @@ int main(int argc, char** argv) {
         a.rg_k0 = p.rg_k0.data();
         a.rg_k1 = p.rg_k1.data();
     }
+
+    // identical tasks: the first task with the same record (but for its list slot) and generic set — what the engine's batch preparation
+    // derives from the descriptors (k_scanb: a task whose twin found no node earlier in the stretch is not looked at)
+    std::vector<u32> tmpl(T);
+    {
+        std::map<std::tuple<u32, u32, u32, i64, i64, u32, u64, u32>, u32> first;
+        for (u32 j = 0; j < T; ++j) {
+            const RTask& r = p.rt[j];
+            tmpl[j] = first.emplace(std::make_tuple(r.svc, r.sc, r.flags, r.cpu, r.mem, r.pset, r.maxrep, p.tg.empty() ? 0u : p.tg[j]), j).first->second;
+        }
+    }
+    a.tmpl = no_tmpl ? nullptr : tmpl.data();
 
     u64 rounds = 0;
     auto build = [&]() {
@@ -213,7 +226,7 @@ int main(int argc, char** argv) {
         if (maxrel < hi) { fprintf(stderr, "maxrel %u below the highest level %u\n", maxrel, hi); ok = false; }
     }
     if (verbose || !ok)
-        fprintf(stderr, "batched scan launches (k_scanb): %u\n", batched_launches);
+        fprintf(stderr, "batched scan launches (k_scanb): %u, tasks it answered without a look: %u\n", batched_launches, blk.scan_skipped);
         fprintf(stderr, "seed %u N %u T %u S %u block %u order %d feat %d split %d: placed %u inf %u | rounds %llu (%.1f tasks each) cut: exhausted %u exception %u uncounted %u | classes %u+%u -> %s\n",
                 seed, N, T, S, B, order, feat, (int)split, em.ctl.ncommit, em.ctl.ninf, (unsigned long long)rounds, rounds ? (double)T / (double)rounds : 0.0, blk.cut_exhausted,
                 blk.cut_exception, blk.cut_uncounted, n_dc, n_dm, ok ? "OK" : "FAIL");
