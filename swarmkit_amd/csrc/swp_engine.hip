@@ -1903,7 +1903,16 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 chunk = std::min<uint32_t>(chunk, ra.block < r6_block ? 64u : 4096u);   // (look again before long while the block is small)
             }
         }
-        if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u), %u of them without a look (an identical task had found no node)\n", scanned, start, end, hb.scan_skipped);
+        if ((dbg_bits & 16) && scanned) fprintf(stderr, "[swp] k_scan decided %u tasks of [%u, %u), %u of them without a look (an identical task had found no node), the others %.2f to a barrier\n", scanned, start, end, hb.scan_skipped, (double)(scanned - hb.scan_skipped) / std::max(1u, hb.scan_batches));
+#ifdef SWP_SCAN_PROF
+        if ((dbg_bits & 16) && scanned) {
+            Ctl pc{};
+            (void)hipMemcpy(&pc, b->d_ctl.p, sizeof pc, hipMemcpyDeviceToHost);
+            const double nb_ = std::max(1u, hb.scan_batches);
+            fprintf(stderr, "[swp] k_scanb cycles per batch (wave 0; %u batches): read + evaluate %.0f, reduce + atomic %.0f, barrier %.0f, accept %.0f, apply %.0f, window work %.0f\n", hb.scan_batches,
+                    pc.cyc[0] / nb_, pc.cyc[1] / nb_, pc.cyc[2] / nb_, pc.cyc[3] / nb_, pc.cyc[4] / nb_, pc.cyc[5] / nb_);
+        }
+#endif
         if ((dbg_bits & 16) && hb.crounds) fprintf(stderr, "[swp] %u of the %u rounds with a compact index | of the cuts at an exhausted list: %u full lists, %u lists in compact positions, %u lists of one entry\n", hb.crounds, hb.rounds, hb.dbg_cut[0], hb.dbg_cut[1], hb.dbg_cut[2]);
         e->r6_compact_hint = cpt && cpt_paid;
         r6_rounds += hb.rounds;

@@ -116,7 +116,7 @@ template <int NQ>
 static hipError_t launch_scanb_as(const ScanArgs& s, size_t lds, hipStream_t st, int dev) {
     hipError_t r;
     if (lds > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(&k_scanb<NQ>), dev)) != hipSuccess) return r;
-    hipLaunchKernelGGL((k_scanb<NQ>), dim3(1), dim3(SCAN_THREADS), lds, st, s);
+    hipLaunchKernelGGL((k_scanb<NQ>), dim3(1), dim3(SCANB_THREADS), lds, st, s);
     return hipGetLastError();
 }
 // node_local: no task of the stretch reserves generic resources, publishes host ports or mounts cluster volumes (the caller looked) —
@@ -126,10 +126,12 @@ hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev, bool node_loc
     hipLaunchKernelGGL(k_scan_lists, dim3(64, s.n_svc), dim3(256), 0, st, s);
     if (node_local && !getenv("SWP_SCAN_UNBATCHED") && scan_lds_b(s.a.n_nodes, s.n_svc, s.n_sc) <= (size_t)160 * 1024 - 512) {
         const size_t lds = scan_lds_b(s.a.n_nodes, s.n_svc, s.n_sc);
-        switch (scan_nq(s.a.n_nodes)) {
+        switch (scanb_nq(s.a.n_nodes)) {
             case 1: return launch_scanb_as<1>(s, lds, st, dev);
             case 2: return launch_scanb_as<2>(s, lds, st, dev);
-            default: return launch_scanb_as<4>(s, lds, st, dev);
+            case 4: return launch_scanb_as<4>(s, lds, st, dev);
+            case 8: return launch_scanb_as<8>(s, lds, st, dev);
+            default: return launch_scanb_as<16>(s, lds, st, dev);
         }
     }
     // the (service, node) matrices in LDS when they fit next to the node rows: a task's turn then waits for no global load

@@ -63,8 +63,9 @@ struct Blk6 {   // control block, global memory
     u32 crounds;           // rounds that had one
     u32 dbg_cut[3];        // dbg: of the cuts at an exhausted list, those whose list was full (more candidates on the level), in compact positions, one entry long
     u32 scan_skipped;      // k_scanb: tasks answered "no node" without a look (an identical task found none earlier in the stretch)
+    u32 scan_batches;      // k_scanb: barriers it took for the tasks it did look at
 };
-static_assert(sizeof(Blk6) == 108, "Blk6 layout");
+static_assert(sizeof(Blk6) == 112, "Blk6 layout");
 
 struct R6Prop {   // one task's proposal: the shard protocol's record (include/swp.h swp_proposal) with more candidates, as 32-node half-words
     u32 level, n_cand;       // minimum level among the plain candidates (R6_NONE: there is none); half-words listed | bit 31: there are more

@@ -63,6 +63,19 @@ inline __host__ __device__ size_t scan_lds_lm(u32 n_nodes, u32 n_svc) { return (
 #define SCAN_B 4
 #define SCAN_W 256          // tasks of a window: their records (16 KB) and descriptor ids in LDS, the next window's in registers
 #define SCAN_DT 1024        // cells of the table of descriptors found unplaceable
+// Threads of k_scanb. A SIMD issues one wave instruction every four cycles whoever it belongs to, and a wave on its own gets one out every
+// ~5: ONE wave per SIMD nearly fills it. Sixteen waves (a node per thread at 1 000 nodes) made every wave repeat the batch's bookkeeping
+// — ~450 instructions a wave and batch, four waves to a SIMD: 3.1 us a batch; four waves with four nodes a thread do the same evaluations
+// and the bookkeeping once per SIMD.
+#ifndef SCANB_THREADS
+#define SCANB_THREADS 256
+#endif
+static_assert(SCANB_THREADS >= SCAN_W && SCANB_THREADS % 64 == 0 && (SCAN_W * 4) % SCANB_THREADS == 0, "a thread per task of a window");
+inline __host__ __device__ u32 scanb_nq(u32 n_nodes) {   // nodes per thread of the instance for this node count: a power of two up to SCAN_MAXN / SCANB_THREADS
+    u32 q = 1;
+    while (q * SCANB_THREADS < n_nodes) q *= 2;
+    return q;
+}
 inline __host__ __device__ u32 scan_dt_cell(u32 tm) { return (tm * 2654435761u) >> 22; }
 inline __host__ __device__ size_t scan_lds_b(u32 n_nodes, u32 n_svc, u32 n_sc) {
     return (((size_t)n_nodes * 24 + 15) & ~(size_t)15) + (size_t)2 * n_svc * n_nodes * 4 + (size_t)n_sc * ((n_nodes + 63) / 64) * 8 + 3 * SCAN_B * 8 +
@@ -269,7 +282,7 @@ WV_KERNEL(SCAN_THREADS) void k_scan(ScanArgs s) {
     }
 }
 template <int SCAN_NQ>
-WV_KERNEL(SCAN_THREADS) void k_scanb(ScanArgs s) {
+WV_KERNEL(SCANB_THREADS) void k_scanb(ScanArgs s) {
     const R6Args& a = s.a;
     const u32 tid = wv::tid(), lane = wv::lane(), N = a.n_nodes, Wn = a.n_words;
     unsigned char* l = reinterpret_cast<unsigned char*>(wv::lds());
@@ -286,28 +299,52 @@ WV_KERNEL(SCAN_THREADS) void k_scanb(ScanArgs s) {
     u32* wtm = wrec + SCAN_W * 16;                                                                   // [SCAN_W] ... and descriptor ids
     u32* dtab = wtm + SCAN_W;                                                                        // [SCAN_DT] descriptors found unplaceable (id + 1; 0: free)
     if (a.blk->error != ERR_NONE) return;
-    for (u32 n = tid; n < N; n += SCAN_THREADS) { cpu[n] = a.cpu[n]; mem[n] = a.mem[n]; tot[n] = a.total[n]; lastc[n] = a.last[n]; }
-    for (u32 x = tid; x < s.n_svc * N; x += SCAN_THREADS) { hm[x] = s.hmat[x]; em[x] = s.emat[x]; }
-    for (u32 x = tid; x < s.n_sc * Wn; x += SCAN_THREADS) scl[x] = a.sc[x];
-    for (u32 x = tid; x < SCAN_DT; x += SCAN_THREADS) dtab[x] = 0;
+    for (u32 n = tid; n < N; n += SCANB_THREADS) { cpu[n] = a.cpu[n]; mem[n] = a.mem[n]; tot[n] = a.total[n]; lastc[n] = a.last[n]; }
+    for (u32 x = tid; x < s.n_svc * N; x += SCANB_THREADS) { hm[x] = s.hmat[x]; em[x] = s.emat[x]; }
+    for (u32 x = tid; x < s.n_sc * Wn; x += SCANB_THREADS) scl[x] = a.sc[x];
+    for (u32 x = tid; x < SCAN_DT; x += SCANB_THREADS) dtab[x] = 0;
     if (tid < 3 * SCAN_B) red[tid] = KEY_NONE;
     u32 nc = a.ctl->ncommit, ni = a.ctl->ninf;
     const u32* rt32 = reinterpret_cast<const u32*>(a.rt);
-    // a window's records are 16 KB: sixteen bytes a thread, requested a window ahead (each is read once: a miss all the way to HBM)
-    u32 nr[4], ntm;
+    // a window's records are 16 KB: SCAN_WX times sixteen bytes a thread, requested a window ahead (each is read once: a miss all the way to HBM)
+    constexpr int SCAN_WX = SCAN_W * 4 / SCANB_THREADS;
+    u32 nr[SCAN_WX][4], ntm;
     auto window_load = [&](u32 base) {
-        const bool have = base < s.j1 && base + tid / 4u < s.j1;
         WV_UNROLL
-        for (int k = 0; k < 4; ++k) nr[k] = have ? rt32[(size_t)base * 16u + tid * 4u + (u32)k] : 0u;
+        for (int x = 0; x < SCAN_WX; ++x) {
+            const u32 v = tid + (u32)x * SCANB_THREADS;   // the window's v-th sixteen bytes
+            const bool have = base < s.j1 && base + v / 4u < s.j1;
+            WV_UNROLL
+            for (int k = 0; k < 4; ++k) nr[x][k] = have ? rt32[(size_t)base * 16u + v * 4u + (u32)k] : 0u;
+        }
         ntm = (tid < SCAN_W && base < s.j1 && base + tid < s.j1) ? (a.tmpl ? a.tmpl[base + tid] : base + tid) : 0u;
     };
     window_load(s.j0);
-    u32 slot = 0, skipped = 0;
+    // this thread's nodes (a node beyond the last one tests no class bit: it is never a candidate)
+    u32 nn[SCAN_NQ], cbit[SCAN_NQ];
+    WV_UNROLL
+    for (int q = 0; q < SCAN_NQ; ++q) {
+        const u32 n = tid + (u32)q * SCANB_THREADS;
+        nn[q] = min(n, N - 1u);
+        cbit[q] = n < N ? 1u << (n & 31u) : 0u;
+    }
+    const u32* scl32 = reinterpret_cast<const u32*>(scl);
+    u32 slot = 0, skipped = 0, batches = 0, over = 0;
+#ifdef SWP_SCAN_PROF   // section timers (make EXTRA=-DSWP_SCAN_PROF; SWP_DBG=16 prints them): cycles of wave 0 per batch
+    u64 pc[6] = {0, 0, 0, 0, 0, 0}, pt = wv::clock64();
+#define SCAN_TICK(q) do { const u64 n_ = wv::clock64(); pc[q] += n_ - pt; pt = n_; } while (0)
+#else
+#define SCAN_TICK(q) do { } while (0)
+#endif
+    bool any_none = false;
     for (u32 base = s.j0; base < s.j1; base += SCAN_W) {
         const u32 wn = min((u32)SCAN_W, s.j1 - base);
         wv::barrier();   // everybody is past the window before (its records, its ids), and what it added to the table is in
         WV_UNROLL
-        for (int k = 0; k < 4; ++k) wrec[tid * 4u + (u32)k] = nr[k];
+        for (int x = 0; x < SCAN_WX; ++x) {
+            WV_UNROLL
+            for (int k = 0; k < 4; ++k) wrec[(tid + (u32)x * SCANB_THREADS) * 4u + (u32)k] = nr[x][k];
+        }
         const u32 tm = ntm;
         if (tid < SCAN_W) wtm[tid] = tm;
         window_load(base + SCAN_W);
@@ -323,108 +360,180 @@ WV_KERNEL(SCAN_THREADS) void k_scanb(ScanArgs s) {
             u64 pl = 0;
             looked[cw] = cur;
             while (cur) {
-                // ---- the batch: the next SCAN_B tasks of the queue (a batch stays inside one word of it)
+                SCAN_TICK(5);
+                // ---- the batch: the next SCAN_B tasks of the queue (a batch stays inside one word of it). Everything that is the same on
+                // every thread — the queue, the picks, the counters — is kept in scalar registers (readfirstlane where a value came through
+                // LDS): the loop's bookkeeping then runs on the scalar unit, and its branches are scalar ones.
                 u32 ib[SCAN_B];
                 u32 nb = 0;
                 {
                     u64 c2 = cur;
                     WV_UNROLL
                     for (int b = 0; b < SCAN_B; ++b) {
-                        ib[b] = c2 ? (u32)cw * 64u + (u32)wv::ffs64(c2) : ib[0];
+                        ib[b] = c2 ? (u32)cw * 64u + (u32)wv::ffs64(c2) : ib[0];   // (a batch that is short evaluates its first task again: nobody reads the result)
                         if (c2) ++nb;
                         c2 &= c2 - 1ull;
                     }
                 }
-                RTask r[SCAN_B];
+                // the records' fields and this thread's node rows: one batch of LDS reads
+                i64 rcpu[SCAN_B], rmem[SCAN_B];
+                u32 rfl[SCAN_B], rsc[SCAN_B], rsvc[SCAN_B], rslot[SCAN_B];
+                u64 rmax[SCAN_B];
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    const RTask* rp = reinterpret_cast<const RTask*>(wrec + ib[b] * 16u);
+                    rcpu[b] = rp->cpu;
+                    rmem[b] = rp->mem;
+                    rfl[b] = rp->flags;
+                    rsc[b] = rp->sc;
+                    rsvc[b] = rp->svc;
+                    rslot[b] = rp->slot;
+                    rmax[b] = rp->maxrep;
+                }
+                i64 ncpu[SCAN_NQ], nmem[SCAN_NQ];
+                u32 ntl[SCAN_NQ];
+                WV_UNROLL
+                for (int q = 0; q < SCAN_NQ; ++q) {
+                    ncpu[q] = cpu[nn[q]];
+                    nmem[q] = mem[nn[q]];
+                    const u32 tn = tot[nn[q]];
+                    over |= tn >> 20;   // (a million tasks on one node: beyond the 20 bits the packed key has for the count; reported at the end)
+                    ntl[q] = (tn << 12) | nn[q];
+                }
+                // what a flag switches off is switched off in the task's numbers (the same on every lane): no ResourceFilter = reservations
+                // nothing can undercut, no replica limit = one no count reaches (a count has 24 bits: the limit is cut to 32)
+                i64 ecpu[SCAN_B], emem[SCAN_B];
+                u32 emax[SCAN_B], scoff[SCAN_B], svoff[SCAN_B];
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    const u32 fl = wv::readfirstlane(rfl[b]);
+                    ecpu[b] = (fl & RT_RES) ? rcpu[b] : INT64_MIN;
+                    emem[b] = (fl & RT_RES) ? rmem[b] : INT64_MIN;
+                    emax[b] = (fl & RT_MAXREP) ? (rmax[b] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)rmax[b]) : 0xFFFFFFFFu;
+                    scoff[b] = wv::readfirstlane(rsc[b]) * Wn * 2u;
+                    svoff[b] = wv::readfirstlane(rsvc[b]) * N;
+                }
+                // ---- every thread: the best of its own nodes, for each of the batch's tasks. First every word the evaluations read — a task's
+                // class word (32 nodes of it) and the service's key half per node — requested together: one wait, not one per word
+                u32 cwv[SCAN_B][SCAN_NQ], hiv[SCAN_B][SCAN_NQ];
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) {
+                    WV_UNROLL
+                    for (int q = 0; q < SCAN_NQ; ++q) {
+                        cwv[b][q] = scl32[scoff[b] + (nn[q] >> 5)];   // valid & ready & constraints & platform & plugins
+                        hiv[b][q] = hm[svoff[b] + nn[q]];
+                    }
+                }
+                // ... then straight-line code, no branch
                 u64 bk[SCAN_B];
                 WV_UNROLL
                 for (int b = 0; b < SCAN_B; ++b) {
                     bk[b] = KEY_NONE;
-                    r[b] = *reinterpret_cast<const RTask*>(wrec + ib[b] * 16u);
-                }
-                // ---- every thread: the best of its own nodes, for each of the batch's tasks
-                WV_UNROLL
-                for (int b = 0; b < SCAN_B; ++b) {
-                    if ((u32)b >= nb) continue;
                     WV_UNROLL
                     for (int q = 0; q < SCAN_NQ; ++q) {
-                        const u32 n = tid + (u32)q * SCAN_THREADS;
-                        if (n >= N) continue;
-                        if (!((scl[(size_t)r[b].sc * Wn + (n >> 6)] >> (n & 63)) & 1ull)) continue;   // valid & ready & constraints & platform & plugins
-                        const u32 hi = hm[(size_t)r[b].svc * N + n];
-                        if ((r[b].flags & RT_RES) && !(r[b].cpu <= cpu[n] && r[b].mem <= mem[n])) continue;
-                        if ((r[b].flags & RT_MAXREP) && !((u64)(hi & 0xFFFFFFu) < r[b].maxrep)) continue;
-                        const u32 tn = tot[n];
-                        if (tn >> 20) a.blk->error = ERR_LEVEL_RANGE;
-                        const u64 key = ((u64)hi << 32) | ((u64)tn << 12) | n;
-                        if (key < bk[b]) bk[b] = key;
+                        const bool ok = ((cwv[b][q] & cbit[q]) != 0) & (ecpu[b] <= ncpu[q]) & (emem[b] <= nmem[q]) & ((hiv[b][q] & 0xFFFFFFu) < emax[b]);
+                        const u64 key = ((u64)hiv[b][q] << 32) | ntl[q];
+                        bk[b] = (ok & (key < bk[b])) ? key : bk[b];
                     }
                 }
+                SCAN_TICK(0);
+                // the waves' least keys: the four upper halves together, then the lower halves of the lanes that hold the least upper one
+                u32 kh[SCAN_B], kl[SCAN_B];
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) kh[b] = (u32)(bk[b] >> 32);
+                static_assert(SCAN_B == 4, "wv::min4_u32 takes four values");
+                u32 mh0 = kh[0], mh1 = kh[1], mh2 = kh[2], mh3 = kh[3];
+                wv::min4_u32(mh0, mh1, mh2, mh3);
+                const u32 mh[SCAN_B] = {mh0, mh1, mh2, mh3};
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) kl[b] = kh[b] == mh[b] ? (u32)bk[b] : 0xFFFFFFFFu;
+                wv::min4_u32(kl[0], kl[1], kl[2], kl[3]);
+                if (lane == 0) {
+                    WV_UNROLL
+                    for (int b = 0; b < SCAN_B; ++b) wv::lds_min64(red + slot * SCAN_B + b, ((u64)mh[b] << 32) | kl[b]);
+                }
+                SCAN_TICK(1);
+                wv::barrier();
+                SCAN_TICK(2);
+                u32 gn[SCAN_B];
+                bool none[SCAN_B];
                 WV_UNROLL
                 for (int b = 0; b < SCAN_B; ++b) {
-                    const u64 wk = r6_wave_min64(bk[b]);
-                    if (lane == 0 && wk != KEY_NONE) wv::lds_min64(red + slot * SCAN_B + b, wk);
+                    const u64 g = wv::lds_read64(red + slot * SCAN_B + b);
+                    const u32 glo = wv::readfirstlane((u32)g), ghi = wv::readfirstlane((u32)(g >> 32));
+                    none[b] = (glo & ghi) == 0xFFFFFFFFu;
+                    gn[b] = glo & 0xFFFu;
                 }
-                wv::barrier();
-                u64 gk[SCAN_B];
-                WV_UNROLL
-                for (int b = 0; b < SCAN_B; ++b) gk[b] = wv::lds_read64(red + slot * SCAN_B + b);
                 if (tid < SCAN_B) red[(slot == 0 ? 2u : slot - 1u) * SCAN_B + tid] = KEY_NONE;   // (the set of the batch before: everybody is past reading it)
                 slot = slot == 2 ? 0 : slot + 1;
-                // ---- the longest prefix of tasks whose picks differ (the same on every thread: the same words)
-                u32 na = 0;
-                u32 gn[SCAN_B];
+                // ---- the longest prefix of tasks whose picks differ (the same on every thread: the same words) — selects, no branch
+                bool acc[SCAN_B], mine[SCAN_B];
+                u32 ncb[SCAN_B];
+                u32 any_mine = 0;
                 WV_UNROLL
                 for (int b = 0; b < SCAN_B; ++b) {
-                    gn[b] = gk[b] == KEY_NONE ? R6_NONE : (u32)gk[b] & 0xFFFu;
-                    bool clash = (u32)b >= nb || na != (u32)b;   // (behind a task that was not accepted nothing is)
+                    bool clash = (u32)b >= nb;
+                    if (b) clash = clash | !acc[b - 1];   // (behind a task that was not accepted nothing is)
                     WV_UNROLL
-                    for (int c = 0; c < b; ++c) clash = clash || (gn[b] != R6_NONE && gn[c] == gn[b]);
-                    if (!clash) na = (u32)b + 1u;
+                    for (int c = 0; c < b; ++c) clash = clash | (!none[b] & !none[c] & (gn[c] == gn[b]));
+                    acc[b] = !clash;
+                    const bool put = acc[b] & !none[b];
+                    cur = acc[b] ? cur & (cur - 1ull) : cur;   // the task leaves the queue
+                    pl |= put ? 1ull << (ib[b] & 63u) : 0ull;
+                    ncb[b] = nc;
+                    nc += put ? 1u : 0u;
+                    any_none = any_none | (acc[b] & none[b]);
+                    mine[b] = put & ((gn[b] & (SCANB_THREADS - 1u)) == tid);
                 }
-                // ---- the owners apply (NodeInfo.addTask); everybody counts
-                WV_UNROLL
-                for (int b = 0; b < SCAN_B; ++b) {
-                    if ((u32)b >= na) continue;
-                    cur &= cur - 1ull;   // the task leaves the queue
-                    const u32 tb = base + ib[b];
-                    if (gn[b] == R6_NONE) {   // no node: nor for any later task with this descriptor (its place among the unplaceable ones: the window's end)
-                        if (tid == 0) {
-                            const u32 dm = wtm[ib[b]], cell = scan_dt_cell(dm);
-                            if (dtab[cell] == 0) dtab[cell] = dm + 1u;
-                        }
-                        continue;
+                ++batches;
+                SCAN_TICK(3);
+                // no node: nor for any later task with this descriptor (its place among the unplaceable ones: the window's end)
+                if (any_none) {
+                    any_none = false;
+                    if (tid == 0) {
+                        WV_UNROLL
+                        for (int b = 0; b < SCAN_B; ++b)
+                            if (acc[b] && none[b]) {
+                                const u32 dm = wtm[ib[b]], cell = scan_dt_cell(dm);
+                                if (dtab[cell] == 0) dtab[cell] = dm + 1u;
+                            }
                     }
-                    pl |= 1ull << (ib[b] & 63u);
-                    if ((gn[b] & (SCAN_THREADS - 1u)) == tid) {
-                        const u32 nd = gn[b], w = nd >> 6;
+                }
+                // ---- the owners apply (NodeInfo.addTask)
+                WV_UNROLL
+                for (int b = 0; b < SCAN_B; ++b) any_mine |= mine[b] ? 1u : 0u;
+                if (any_mine) {
+                    WV_UNROLL
+                    for (int b = 0; b < SCAN_B; ++b) {
+                        if (!mine[b]) continue;
+                        const u32 nd = gn[b], w = nd >> 6, tb = base + ib[b];
                         const u64 bit = 1ull << (nd & 63);
-                        if (r[b].cpu) cpu[nd] -= r[b].cpu;
-                        if (r[b].mem) mem[nd] -= r[b].mem;
-                        if (!(r[b].flags & RT_UNCOUNTED)) {
+                        cpu[nd] -= rcpu[b];
+                        mem[nd] -= rmem[b];
+                        if (!(rfl[b] & RT_UNCOUNTED)) {
                             tot[nd] += 1;
-                            u32 hi = hm[(size_t)r[b].svc * N + nd] + 1u;
-                            u32 entry = em[(size_t)r[b].svc * N + nd];
+                            u32 hi = hm[(size_t)rsvc[b] * N + nd] + 1u;
+                            u32 entry = em[(size_t)rsvc[b] * N + nd];
                             if ((hi & 0xFFFFFFu) == 0) a.blk->error = ERR_GROUP_RANGE;
-                            hm[(size_t)r[b].svc * N + nd] = hi;
+                            hm[(size_t)rsvc[b] * N + nd] = hi;
                             if (entry == LIST_EMPTY) {
-                                wv::g_or64(a.X + (size_t)r[b].svc * a.xs + w, bit);
-                                a.list_node[r[b].slot] = nd;
-                                a.list_svc[r[b].slot] = 1;
-                                a.list_fail[r[b].slot] = 0;
-                                em[(size_t)r[b].svc * N + nd] = r[b].slot;
+                                wv::g_or64(a.X + (size_t)rsvc[b] * a.xs + w, bit);
+                                a.list_node[rslot[b]] = nd;
+                                a.list_svc[rslot[b]] = 1;
+                                a.list_fail[rslot[b]] = 0;
+                                em[(size_t)rsvc[b] * N + nd] = rslot[b];
                             } else
                                 a.list_svc[entry] = hi & 0xFFFFFFu;
                         }
                         const int32_t prev = lastc[nd];
-                        a.log_node[nc] = nd;
-                        a.log_task[nc] = tb;
-                        a.log_prev[nc] = prev;
-                        lastc[nd] = (int32_t)nc;
+                        a.log_node[ncb[b]] = nd;
+                        a.log_task[ncb[b]] = tb;
+                        a.log_prev[ncb[b]] = prev;
+                        lastc[nd] = (int32_t)ncb[b];
                         a.out_node[tb] = (int32_t)nd;
                     }
-                    ++nc;
                 }
+                SCAN_TICK(4);
             }
             placed[cw] = pl;
         }
@@ -448,9 +557,16 @@ WV_KERNEL(SCAN_THREADS) void k_scanb(ScanArgs s) {
         WV_UNROLL
         for (int cw = 0; cw < SCAN_W / 64; ++cw) skipped += min(wn > (u32)cw * 64u ? wn - (u32)cw * 64u : 0u, 64u) - (u32)wv::popc64(looked[cw]);
     }
-    if (tid == 0) a.blk->scan_skipped += skipped;
+    if (tid == 0) {
+        a.blk->scan_skipped += skipped;
+        a.blk->scan_batches += batches;
+#ifdef SWP_SCAN_PROF
+        for (int q = 0; q < 6; ++q) a.ctl->cyc[q] += pc[q];
+#endif
+    }
+    if (over) a.blk->error = ERR_LEVEL_RANGE;
     wv::barrier();
-    for (u32 n = tid; n < N; n += SCAN_THREADS) { a.cpu[n] = cpu[n]; a.mem[n] = mem[n]; a.total[n] = tot[n]; a.last[n] = lastc[n]; }
+    for (u32 n = tid; n < N; n += SCANB_THREADS) { a.cpu[n] = cpu[n]; a.mem[n] = mem[n]; a.total[n] = tot[n]; a.last[n] = lastc[n]; }
     if (tid == 0) {
         a.ctl->ncommit = nc;
         a.ctl->ninf = ni;

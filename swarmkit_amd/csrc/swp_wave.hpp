@@ -60,6 +60,23 @@ WV_DEV u32 min_u32(u32 v) {
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// the wave's minimum of FOUR values at once; every lane gets the four minima. Four independent DPP chains, interleaved: one fused
+// instruction per step and value (dst = min(dst, its DPP source); a lane without a source is left alone), and no chain ever waits for the
+// VALU-write -> DPP-read hazard because three other instructions lie in between. (The compiler's own code for dpp_ + min is a mov, a
+// mov_dpp, a min and a nop per step: k_scanb's eight reductions a batch were 200 of its instructions.)
+WV_DEV void min4_u32(u32& a, u32& b, u32& c, u32& d) {
+#define WV_M4(ctrl)                                                                                                                     \
+    "v_min_u32_dpp %0, %0, %0 " ctrl "\n\tv_min_u32_dpp %1, %1, %1 " ctrl "\n\tv_min_u32_dpp %2, %2, %2 " ctrl "\n\tv_min_u32_dpp %3, %3, %3 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t" WV_M4("row_shr:1 row_mask:0xf bank_mask:0xf") WV_M4("row_shr:2 row_mask:0xf bank_mask:0xf") WV_M4("row_shr:4 row_mask:0xf bank_mask:0xf")
+                     WV_M4("row_shr:8 row_mask:0xf bank_mask:0xf") WV_M4("row_bcast:15 row_mask:0xa bank_mask:0xf") WV_M4("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef WV_M4
+    a = (u32)__builtin_amdgcn_readlane((int)a, 63);
+    b = (u32)__builtin_amdgcn_readlane((int)b, 63);
+    c = (u32)__builtin_amdgcn_readlane((int)c, 63);
+    d = (u32)__builtin_amdgcn_readlane((int)d, 63);
+}
+
 // inclusive prefix sum over the 64 lanes (lane l returns v[0] + ... + v[l]): four DPP row shifts inside the rows of 16, then the three
 // row totals by readlane (k_groups2's helpers: the offsets of the node words in a group's compact candidate list)
 WV_DEV u32 scan_incl_u32(u32 v) {
@@ -89,7 +106,12 @@ WV_DEV void lds_xor64(u64* p, u64 v) { __hip_atomic_fetch_xor(p, v, __ATOMIC_REL
 WV_DEV void lds_or32(u32* p, u32 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_andn64(u64* p, u64 v) { __hip_atomic_fetch_and(p, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV void lds_min64(u64* p, u64 v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-WV_DEV u64 lds_read64(const u64* p) { return *reinterpret_cast<const volatile u64*>(p); }   // (behind a barrier: not to be merged with an earlier read)
+// a read behind a barrier, not to be merged with an earlier one: the compiler fence does that — a `volatile` access would lose the
+// pointer's address space and come out as a FLAT load with a wait of its own (found in k_scanb: four of them in a row, ~2 000 cycles a batch)
+WV_DEV u64 lds_read64(const u64* p) {
+    asm volatile("" ::: "memory");
+    return *p;
+}
 WV_DEV void lds_add32(u32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ---- flags between waves of one workgroup that do NOT meet at a barrier (k_r6_commit: the matching wave runs on while the others apply) ----

@@ -177,10 +177,12 @@ int main(int argc, char** argv) {
             if (a.rt[j].flags & RT_PORTS) node_local = false;
         if (node_local && scan_lds_b(N, s.n_svc, s.n_sc) <= (size_t)160 * 1024 - 512) {
             const size_t ldsb = scan_lds_b(N, s.n_svc, s.n_sc);
-            switch (scan_nq(N)) {
-                case 1: grid(1, SCAN_THREADS, ldsb, [s]() { k_scanb<1>(s); }); break;
-                case 2: grid(1, SCAN_THREADS, ldsb, [s]() { k_scanb<2>(s); }); break;
-                default: grid(1, SCAN_THREADS, ldsb, [s]() { k_scanb<4>(s); }); break;
+            switch (scanb_nq(N)) {
+                case 1: grid(1, SCANB_THREADS, ldsb, [s]() { k_scanb<1>(s); }); break;
+                case 2: grid(1, SCANB_THREADS, ldsb, [s]() { k_scanb<2>(s); }); break;
+                case 4: grid(1, SCANB_THREADS, ldsb, [s]() { k_scanb<4>(s); }); break;
+                case 8: grid(1, SCANB_THREADS, ldsb, [s]() { k_scanb<8>(s); }); break;
+                default: grid(1, SCANB_THREADS, ldsb, [s]() { k_scanb<16>(s); }); break;
             }
             ++rounds;
             ++batched_launches;

@@ -364,6 +364,7 @@ inline u64 readlane64(u64 v, u32 l) { return emu::collective(emu::OP_READLANE, v
 inline u32 writelane(u32 v, u32 s, u32 l) { return lane() == l ? s : v; }
 inline u32 mbcnt(u64 mask) { return (u32)__builtin_popcountll(mask & ((1ull << lane()) - 1ull)); }
 inline u32 min_u32(u32 v) { return (u32)emu::collective(emu::OP_MIN, v, 0); }
+inline void min4_u32(u32& a, u32& b, u32& c, u32& d) { a = min_u32(a); b = min_u32(b); c = min_u32(c); d = min_u32(d); }
 inline u32 scan_incl_u32(u32 v) { return (u32)emu::collective(emu::OP_SCAN, v, 0); }
 inline void barrier() { emu::block_barrier(); }
 inline void wave_sync() { (void)emu::collective(emu::OP_SYNC, 0, 0); }
