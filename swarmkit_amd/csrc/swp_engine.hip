@@ -1822,7 +1822,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         hipError_t r = launch_r6_build(ra, st);
         if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 build launch: %s", hipGetErrorString(r));
         uint32_t pos = start, chunk = std::min<uint32_t>(16u, (end - start + 255u) / 256u + 1u);   // a short stretch does not pay for empty rounds
-        uint32_t rounds_seen = 0, scan_len = 2048, scanned = 0;
+        uint32_t rounds_seen = 0, scan_len = 2048, scanned = 0, skipped_seen = 0;
         bool after_scan = false;   // the rounds since the last scan stretch: four of them say whether the tasks still have no plain candidates
         // The compact index (swp_resolve6.hpp, R6Args.compact): one more small launch per round, worth it when the level the tasks aim at is a
         // sparse set of nodes (re-placements after a drain): the matcher then stops at an emptied half-word every few tasks and the rounds are
@@ -1837,6 +1837,10 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         bool cpt_paid = false;   // the last chunk that ran with the index had rounds that used it
         const char* env_scan = getenv("SWP_SCAN");   // 0: never hand a stretch to the scan resolver (tests, A/B runs)
         const bool scan_ok = N <= scan_max_nodes() && !(env_scan && atoi(env_scan) == 0) && b->csi_set.empty();   // (the scan resolver knows no volumes)
+        // The batched instance of the scan (k_scanb) decides ~4 tasks a barrier and answers an unplaceable task's twins without a look: where
+        // it can run, a stretch goes to it after four poor rounds and two probing rounds follow it; the one-task-a-barrier instance
+        // (~1 us a task) has to be worth more: eight poor rounds, four probes
+        const bool scan_fast = scan_ok && ra.n_rg == 0 && ra.csi_of == nullptr && scan_batched_fits(N, b->n_svc, b->n_sc);
         while (pos < end) {
             ra.compact = cpt ? 1u : 0u;
             r = launch_r6_rounds(ra, chunk, st, e->device);
@@ -1865,7 +1869,8 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                     else if (cpt && used >= 4 && cr == 0) cpt = false;
                 }
             }
-            if (scan_ok && used >= (after_scan ? 4u : 8u) && recent < 8.0 && end - pos >= 64) {
+            if (scan_ok && used >= (scan_fast ? (after_scan ? 2u : 4u) : (after_scan ? 4u : 8u)) && recent < 8.0 && end - pos >= 64) {
+              scan_again:
                 const uint32_t upto = std::min<uint64_t>(end, (uint64_t)pos + scan_len);
                 ScanArgs sa{};
                 sa.a = ra;
@@ -1884,17 +1889,29 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 if (r == hipSuccess) r = launch_r6_build(ra, st);   // the rounds go on from the rows as the scan left them
                 if (r != hipSuccess) return e->fail(SWP_EHIP, "k_scan launch: %s", hipGetErrorString(r));
                 scanned += upto - pos;
-                pos = upto;
                 scan_len = std::min<uint32_t>(scan_len * 2, 1u << 20);   // still no plain candidates afterwards: the next stretch is twice as long
-                chunk = 4;   // (round 6: sixteen rounds of ~40 us between two stretches were a sixth of the dense batch)
+                chunk = scan_fast ? 2 : 4;   // (round 6: sixteen rounds of ~40 us between two stretches were a sixth of the dense batch)
                 after_scan = true;
+                if (node_local && scan_fast && (upto < end || (dbg_bits & 16))) {
+                    // Most of the stretch was answered without a look (k_scanb: identical tasks had found no node — a saturated cluster's
+                    // backlog): the kernel does that at a hundred tasks a microsecond, a round of the block resolver at ten. On with it.
+                    HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));
+                    HIPCHECK(e, hipStreamSynchronize(st));
+                    const uint32_t sk = hb.scan_skipped - skipped_seen;
+                    skipped_seen = hb.scan_skipped;
+                    if (upto < end && 2 * (uint64_t)sk >= upto - pos) {
+                        pos = upto;
+                        goto scan_again;
+                    }
+                }
+                pos = upto;
                 continue;
             }
             after_scan = false;
             // as many rounds as the rest needs at the pace so far, and a few more: a round past the end costs two empty launches
             const double pace = std::max(1.0, recent);
             chunk = (uint32_t)std::min<double>(4096.0, (double)(end - pos) / pace * 1.05 + 4.0);
-            if (scan_ok) chunk = std::min<uint32_t>(chunk, recent < 16.0 ? 16u : recent < 64.0 ? 48u : 256u);   // (look again soon: rounds that hit such a stretch decide one task each)
+            if (scan_ok) chunk = std::min<uint32_t>(chunk, scan_fast ? (recent < 16.0 ? 8u : recent < 64.0 ? 16u : 256u) : (recent < 16.0 ? 16u : recent < 64.0 ? 48u : 256u));   // (look again soon: rounds that hit such a stretch decide one task each)
             // the block follows the pace: rounds that are cut after a few dozen tasks (re-placements that all aim at the few emptied nodes)
             // need not propose and stage hundreds of lists each; rounds that fill their block get the next size up
             if (!env_blk) {

@@ -49,6 +49,7 @@ hipError_t launch_shard_apply(const ShardApplyArgs& a, hipStream_t s);
 // the scan resolver (swp_scan.hpp, built in swp_resolve6.hip)
 struct ScanArgs;
 uint32_t scan_max_nodes();
+bool scan_batched_fits(uint32_t n_nodes, uint32_t n_svc, uint32_t n_sc);   // k_scanb (several tasks a barrier, identical unplaceable tasks skipped) can take such a batch: everything it reads fits in LDS
 hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev, bool node_local);
 
 // task groups (swp_groups.hip)

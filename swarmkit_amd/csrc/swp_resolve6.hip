@@ -111,6 +111,7 @@ static hipError_t launch_scan_nq(const ScanArgs& s, size_t lds, hipStream_t st, 
         default: return launch_scan_as<4, LM>(s, lds, st, dev);
     }
 }
+bool scan_batched_fits(uint32_t n_nodes, uint32_t n_svc, uint32_t n_sc) { return !getenv("SWP_SCAN_UNBATCHED") && scan_lds_b(n_nodes, n_svc, n_sc) <= (size_t)160 * 1024 - 512; }
 bool scan_matrices_in_lds(uint32_t n_nodes, uint32_t n_svc) { return scan_lds_lm(n_nodes, n_svc) <= (size_t)160 * 1024 - 512; }
 template <int NQ>
 static hipError_t launch_scanb_as(const ScanArgs& s, size_t lds, hipStream_t st, int dev) {
@@ -124,7 +125,7 @@ static hipError_t launch_scanb_as(const ScanArgs& s, size_t lds, hipStream_t st,
 hipError_t launch_scan(const ScanArgs& s, hipStream_t st, int dev, bool node_local) {
     hipLaunchKernelGGL(k_scan_fill, dim3(1024), dim3(256), 0, st, s);
     hipLaunchKernelGGL(k_scan_lists, dim3(64, s.n_svc), dim3(256), 0, st, s);
-    if (node_local && !getenv("SWP_SCAN_UNBATCHED") && scan_lds_b(s.a.n_nodes, s.n_svc, s.n_sc) <= (size_t)160 * 1024 - 512) {
+    if (node_local && scan_batched_fits(s.a.n_nodes, s.n_svc, s.n_sc)) {
         const size_t lds = scan_lds_b(s.a.n_nodes, s.n_svc, s.n_sc);
         switch (scanb_nq(s.a.n_nodes)) {
             case 1: return launch_scanb_as<1>(s, lds, st, dev);
