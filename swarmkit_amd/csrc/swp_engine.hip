@@ -93,6 +93,46 @@ inline DevPool& dev_pool() {
     return *p;
 }
 
+// SWP_HOST_PROF=1: wall time of the host-side sections of the calls a churn round makes, summed per section, printed when an engine is
+// destroyed (tools: where a round's host milliseconds go; nothing is measured without the variable)
+struct HostProf {
+    bool on = getenv("SWP_HOST_PROF") != nullptr;
+    std::mutex mu;
+    std::map<std::string, std::pair<double, uint64_t>> acc;
+    std::map<std::string, double> longest;
+    void add(const char* name, double ms) {
+        std::lock_guard<std::mutex> g(mu);
+        auto& a = acc[name];
+        a.first += ms;
+        a.second += 1;
+        double& l = longest[name];
+        if (ms > l) l = ms;
+    }
+    void print() {
+        if (!on) return;
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& kv : acc)   // (the longest call apart: a script's first batch places every task, its rounds a tenth of them)
+            fprintf(stderr, "[swp host] %-44s %9.3f ms over %7llu calls | longest %8.3f ms, the others %8.2f us each\n", kv.first.c_str(), kv.second.first, (unsigned long long)kv.second.second,
+                    longest[kv.first], kv.second.second > 1 ? 1e3 * (kv.second.first - longest[kv.first]) / (kv.second.second - 1) : 0.0);
+        acc.clear();
+        longest.clear();
+    }
+};
+static HostProf& host_prof() { static HostProf p; return p; }
+struct HostSpan {
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostSpan(const char* n) : name(host_prof().on ? n : nullptr) { if (name) t0 = std::chrono::steady_clock::now(); }
+    void next(const char* n) {
+        if (!name) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        host_prof().add(name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        name = n;
+        t0 = t1;
+    }
+    ~HostSpan() { next(nullptr); }
+};
+
 struct DevBuf {   // owns one device allocation: movable, not copyable
     void* p = nullptr;
     size_t cap = 0;
@@ -311,6 +351,29 @@ struct HostNode {
     std::vector<Csi> csi;                                         // Description.CSIInfo (swp_node_set_csi)
 };
 
+// service -> (node -> count): the engine's index of where a service runs (the exception lists of a batch are read off it). Service ids are
+// interned, so small: a vector by id — a placement's update is then an index, and the loops that book thousands of placements can
+// prefetch it (an unordered_map was a dependent miss per placement); ids beyond the dense range (a caller's own numbering) live in a map
+struct SvcNodes {
+    static constexpr uint32_t DENSE_MAX = 1u << 20;
+    std::vector<FlatMap32> dense;
+    std::unordered_map<uint32_t, FlatMap32> sparse;
+    FlatMap32& operator[](uint32_t s) {
+        if (s >= DENSE_MAX) return sparse[s];
+        if (s >= dense.size()) dense.resize(std::max<size_t>((size_t)s + 1, std::min<size_t>(dense.size() * 2, DENSE_MAX)));
+        return dense[s];
+    }
+    const FlatMap32* find(uint32_t s) const {
+        if (s < dense.size()) return &dense[s];
+        if (s < DENSE_MAX) return nullptr;
+        auto it = sparse.find(s);
+        return it == sparse.end() ? nullptr : &it->second;
+    }
+    void clear() { dense.clear(); sparse.clear(); }
+    void prefetch(uint32_t s) const { if (s < dense.size()) __builtin_prefetch(&dense[s]); }
+    void prefetch_entries(uint32_t s) const { if (s < dense.size() && !dense[s].v.empty()) __builtin_prefetch(dense[s].v.data()); }
+};
+
 struct HostVolume {   // swp_volume_upsert / swp_volume_set_usage
     bool present = false;
     swp_volume spec{};
@@ -435,7 +498,7 @@ struct swp_engine {
     std::vector<HostNode> nodes;
     uint32_t n_nodes = 0;   // highest node index in use + 1
     uint32_t n_present = 0;
-    std::unordered_map<uint32_t, FlatMap32> svc_nodes;   // service -> node -> count (>0), nodes ascending
+    SvcNodes svc_nodes;                                    // service -> node -> count (>0), nodes ascending
     std::unordered_map<uint32_t, std::unordered_set<uint32_t>> fail_nodes;            // service -> nodes with failure records
     std::unordered_map<uint64_t, std::unordered_set<uint32_t>> port_nodes;            // (proto,port) -> nodes
 
@@ -825,6 +888,7 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
         const uint32_t* ix;
         const swp_task_desc& operator[](uint32_t i) const { return ix ? d[ix[i]] : d[i]; }
     } tasks{descs, tmpl_idx};
+    HostSpan sp("build_batch: descriptors -> records");
     if (tmpl_idx)
         for (uint32_t i = 0; i < T; ++i)
             if (tmpl_idx[i] >= n_tmpl) return e->fail(SWP_EINVAL, "task %u names template %u of %u", i, tmpl_idx[i], n_tmpl);
@@ -1037,6 +1101,7 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
     for (uint32_t i = 0; i < T; ++i)   // every other task of a descriptor gets the record of the first one (its list slot follows below)
         if (tmpl_of[i] != i) b->rt[i] = b->rt[tmpl_of[i]];
     mark("records copied to the tasks");
+    sp.next("build_batch: generic sets, explain groups, runs");
     // generic reservations: the distinct (kind, value) pairs become rows sorted by (kind, value); a task's set names its rows
     b->has_generic = false;
     b->tg.clear();
@@ -1167,6 +1232,7 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
             b->csi_task.push_back(i);
         }
     mark("runs");
+    sp.next("build_batch: exception lists");
     // per-service exception lists: nodes with svcCount>0 or ≥ maxFailures recent failures
     b->list_off.assign(b->n_svc + 1, 0);
     b->list_cnt0.clear();
@@ -1184,16 +1250,18 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
             b->list_svc0.push_back(cnt);
             b->list_fail0.push_back(fails);
         };
-        auto sn = e->svc_nodes.find(g);
+        const FlatMap32* sn = e->svc_nodes.find(g);
         auto fn = e->fail_nodes.find(g);
         if (fn == e->fail_nodes.end() || fn->second.empty()) {   // the common case: the service's nodes, already in node order
-            if (sn != e->svc_nodes.end())
-                for (const auto& kv : sn->second)
-                    if (kv.second > 0 && e->nodes[kv.first].present) emit(kv.first, kv.second, 0u);
+            // (svc_nodes names present nodes only — swp_node_remove takes a node out of every service's entry — so the node records,
+            // a miss each, are not looked at: 90 000 entries per churn round)
+            if (sn)
+                for (const auto& kv : *sn)
+                    if (kv.second > 0) emit(kv.first, kv.second, 0u);
         } else {
             std::map<uint32_t, std::pair<uint32_t, uint32_t>> ent;   // node -> (svc, fail), node-ordered
-            if (sn != e->svc_nodes.end())
-                for (const auto& kv : sn->second)
+            if (sn)
+                for (const auto& kv : *sn)
                     if (kv.second > 0 && e->nodes[kv.first].present) ent[kv.first].first = kv.second;
             for (uint32_t n : fn->second) {
                 if (!e->nodes[n].present) continue;
@@ -1215,6 +1283,7 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
     for (uint32_t i = 0; i < T; ++i) b->rt[i].slot = b->list_off[b->rt[i].svc] + init_cnt[b->rt[i].svc] + task_rank[i];
 
     mark("exception lists + slots");
+    sp.next("build_batch: ports, class tables");
     // host ports
     b->pset_off.assign(1, 0);
     for (uint32_t gs : pset_ids_global) {
@@ -2299,6 +2368,7 @@ int swp_create(const swp_config* cfg, swp_engine** out) {
 
 void swp_destroy(swp_engine* e) {
     if (!e) return;
+    host_prof().print();
     if (e->set) { ss::destroy(e); return; }
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -3047,11 +3117,14 @@ int swp_batch_prepare_templates(swp_engine* e, const swp_task_desc* templates, u
     if (!e || !out || (!templates && n_templates) || (!template_of_task && n_tasks) || (n_tasks && !n_templates)) return SWP_EINVAL;
     *out = nullptr;
     (void)hipSetDevice(e->device);
+    HostSpan sp("prepare_templates: flush_nodes");
     int rc = flush_nodes(e);
     if (rc) return rc;
+    sp.next("prepare_templates: build_batch");
     auto b = std::make_unique<swp_batch>();
     if ((rc = build_batch(e, templates, n_tasks, b.get(), nullptr, template_of_task, n_templates))) return rc;
     if (e->dev_static_dirty && (rc = flush_nodes(e))) return rc;
+    sp.next("prepare_templates: upload_batch");
     if (n_tasks && e->n_nodes && (rc = upload_batch(e, b.get()))) return rc;
     b->n_nodes_prepared = e->n_nodes;
     *out = b.release();
@@ -3108,14 +3181,26 @@ int swp_batch_fetch(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* ou
         b->ran = false;
         return SWP_OK;
     }
+    HostSpan sp("fetch: D2H + wait");
     HIPCHECK(e, hipMemcpyAsync(out_node, b->d_out.p, (size_t)T * 4, hipMemcpyDeviceToHost, e->stream));
     if (out_fail_hist) {
         if (int rch = download_hist(e, b, out_fail_hist)) return rch;
     }
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     if (int rcv = download_volumes(e, b, true)) return rcv;
+    sp.next("fetch: placements into the node mirror");
     uint64_t placed = 0;
     for (uint32_t i = 0; i < T; ++i) {
+        if (i + 16 < T && out_node[i + 16] >= 0 && (uint32_t)out_node[i + 16] < e->nodes.size()) {   // (as in swp_commit)
+            __builtin_prefetch(&e->nodes[out_node[i + 16]].row);
+            __builtin_prefetch(&e->nodes[out_node[i + 16]].svc);
+            e->svc_nodes.prefetch(b->desc(i + 16).service);
+        }
+        if (i + 8 < T && out_node[i + 8] >= 0 && (uint32_t)out_node[i + 8] < e->nodes.size()) {
+            const FlatMap32& hs = e->nodes[out_node[i + 8]].svc;
+            if (!hs.v.empty()) __builtin_prefetch(hs.v.data());
+            e->svc_nodes.prefetch_entries(b->desc(i + 8).service);
+        }
         int32_t n = out_node[i];
         if (n < 0) continue;
         if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return e->fail(SWP_EHIP, "device returned an invalid node index %d for task %u", n, i);
@@ -3150,6 +3235,7 @@ int swp_batch_results(swp_engine* e, swp_batch* b, int32_t* out_node, uint32_t* 
 
 void swp_batch_free(swp_engine* e, swp_batch* b) {
     if ((e && e->set) || (b && b->is_set)) { ss::batch_free(e, b); return; }
+    HostSpan sp("batch_free");
     if (e) {
         (void)hipSetDevice(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -4059,16 +4145,29 @@ int swp_commit(swp_engine* e, const swp_placement* p, uint32_t n, int add_or_rem
         if (p[i].node >= e->nodes.size() || !e->nodes[p[i].node].present) return SWP_ENOTFOUND;
         if (p[i].port_set >= e->port_sets.size()) return SWP_EINVAL;
     }
+    HostSpan sp("commit: flush_nodes");
     int rc = flush_nodes(e);   // device rows must be current before the residual kernel touches them
     if (rc) return rc;
+    sp.next("commit: node mirror");
     std::vector<DevPlacement> dp(n);
     for (uint32_t i = 0; i < n; ++i) {
+        if (i + 16 < n) {   // the records a later placement will touch, on their way while this one is booked
+            __builtin_prefetch(&e->nodes[p[i + 16].node].row);
+            __builtin_prefetch(&e->nodes[p[i + 16].node].svc);
+            e->svc_nodes.prefetch(p[i + 16].service);
+        }
+        if (i + 8 < n) {
+            const FlatMap32& hs = e->nodes[p[i + 8].node].svc;
+            if (!hs.v.empty()) __builtin_prefetch(hs.v.data());
+            e->svc_nodes.prefetch_entries(p[i + 8].service);
+        }
         dp[i].node = p[i].node;
         dp[i].counted = p[i].counted;
         dp[i].cpu = p[i].cpu;
         dp[i].mem = p[i].mem;
         host_apply_placement(e, p[i].node, p[i].service, p[i].cpu, p[i].mem, p[i].port_set, p[i].counted != 0, add_or_remove != 0);
     }
+    sp.next("commit: upload + k_commit + wait");
     DevBuf d;
     HIPCHECK(e, d.reserve((size_t)n * sizeof(DevPlacement)));
     HIPCHECK(e, hipMemcpyAsync(d.p, dp.data(), (size_t)n * sizeof(DevPlacement), hipMemcpyHostToDevice, e->stream));
