@@ -26,6 +26,33 @@ def test_abi_roundtrip():
     assert e.node_get(n1) is None
 
 
+def test_service_counts_of_a_service_id_beyond_the_dense_index():
+    """The engine's service -> nodes index is a vector by service id up to 2^20 ids and a map beyond (swp_engine.hip SvcNodes): counts set,
+    changed by swp_commit and dropped with the node behave the same on both sides of that border."""
+    e = abi.Engine()
+    e.reset(4)
+    nodes = [e.intern(abi.SPACE_NODE_ID, "n%d" % i) for i in range(3)]
+    for n in nodes:
+        e.node_upsert(abi.NodeRow(node=n, flags=abi.NODE_READY, cpu=100, mem=100, total=0))
+    for svc in (5, (1 << 20) - 1, 1 << 20, 3_000_000_000):
+        e.node_set_svc_count(nodes[0], svc, 7)
+        e.node_set_svc_count(nodes[2], svc, 1)
+        assert [e.node_get_svc_count(n, svc) for n in nodes] == [7, 0, 1]
+        pl = np.zeros(2, dtype=abi.PLACEMENT_DTYPE)
+        pl["node"], pl["service"], pl["cpu"], pl["mem"], pl["counted"] = [nodes[1], nodes[2]], svc, 1, 1, 1
+        e.commit(pl, add=True)
+        assert [e.node_get_svc_count(n, svc) for n in nodes] == [7, 1, 2]
+        e.commit(pl, add=False)
+        assert [e.node_get_svc_count(n, svc) for n in nodes] == [7, 0, 1]
+        e.node_set_svc_count(nodes[2], svc, 0)
+        assert e.node_get_svc_count(nodes[2], svc) == 0
+    e.node_remove(nodes[0])
+    n0 = e.intern(abi.SPACE_NODE_ID, "again")   # the lowest free index: the removed node's
+    assert n0 == nodes[0]
+    e.node_upsert(abi.NodeRow(node=n0, flags=abi.NODE_READY, cpu=100, mem=100, total=0))
+    assert [e.node_get_svc_count(n0, svc) for svc in (5, 1 << 20, 3_000_000_000)] == [0, 0, 0]
+
+
 @pytest.mark.parametrize("name,T,N", [("cfg2", 2000, 300), ("cfg2", 10_000, 1_000), ("cfg3", 6000, 1000), ("cfg4", 6000, 1500)])
 def test_parity_one_off(name, T, N):
     wl = synth.Workload(name, T=T, N=N)

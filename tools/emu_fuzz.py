@@ -67,6 +67,11 @@ def draw(rng, which):
         if rng.random() < 0.4:   # few services: everything a task reads fits in LDS, the BATCHED instance (k_scanb) runs
             s = rng.randrange(1, 12)
             n = min(n, 2600)
+            if rng.random() < 0.5:   # ... and a backlog several times what the cluster takes: its windows skip the twins of a task that found no node
+                t = rng.randrange(1000, 6000)
+                n = min(n, rng.choice([40, 300, 1100]))
+            opts = "".join(o for o in "mn" if rng.random() < 0.3)
+            return [seed, n, t, s, rng.choice([32, 64, 128, 256]), rng.randrange(3), rng.randrange(2)] + ([opts] if opts else [])
         opts = "".join(o for o in "mg" if rng.random() < 0.4)
         return [seed, n, t, s, rng.choice([32, 64, 128, 256]), rng.randrange(3), rng.randrange(4)] + ([opts] if opts else [])
     if which in ("groups", "groups_small"):
