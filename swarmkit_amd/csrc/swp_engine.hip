@@ -557,7 +557,7 @@ struct swp_engine {
     void* rccl_comm = nullptr;
     uint32_t rccl_rank = 0, rccl_ranks = 0;
 
-    bool r6_compact_hint = false;   // the last batch's rounds ended with a compact index (re-placements after a drain): the next one starts with it
+    bool r6_compact_hint = false;   // the last batch's rounds used a compact index (re-placements after a drain): the next one starts with it
     swp_stats_t stats{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;   // per-launch kernel timing (SWP_CFG_PROFILE)
@@ -1902,6 +1902,10 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         const char* env_cpt = getenv("SWP_R6_COMPACT");
         const bool cpt_ok = Wn <= R6_COMPACT_MAX_WORDS && r6_commit_lds_size(Wn, r6_block, r6_nrr, true) <= lds_budget && b->csi_set.empty() && !(env_cpt && atoi(env_cpt) == 0);   // (no smaller blocks for it)
         bool cpt = cpt_ok && ((env_cpt && atoi(env_cpt) != 0) || e->r6_compact_hint);
+        bool cpt_ever = false;          // some chunk of this batch had rounds with an index
+        // (round 6: a churn round's batch ENDS on tasks that aim at a level every node has — no index — and the hint used to say "the last
+        // chunk had one": every batch then began with sixteen rounds without it. Starting with the previous batch's small BLOCK as well was
+        // measured and lost: device 3.39 -> 3.62 ms a round, same box, three runs each.)
         uint32_t exh_seen = 0, crounds_seen = 0, stops_seen = 0;
         bool cpt_paid = false;   // the last chunk that ran with the index had rounds that used it
         const char* env_scan = getenv("SWP_SCAN");   // 0: never hand a stretch to the scan resolver (tests, A/B runs)
@@ -1933,6 +1937,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 crounds_seen = hb.crounds;
                 stops_seen = hb.reseats;
                 if (cpt) cpt_paid = cr != 0;
+                if (cpt && cr) cpt_ever = true;
                 if (cpt_ok && !(env_cpt && atoi(env_cpt) != 0)) {
                     if (!cpt && used >= 4 && 2 * exh >= used && recent < 0.4 * ra.block && (double)stops * 12.0 >= recent * used) cpt = true;
                     else if (cpt && used >= 4 && cr == 0) cpt = false;
@@ -2000,7 +2005,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         }
 #endif
         if ((dbg_bits & 16) && hb.crounds) fprintf(stderr, "[swp] %u of the %u rounds with a compact index | of the cuts at an exhausted list: %u full lists, %u lists in compact positions, %u lists of one entry\n", hb.crounds, hb.rounds, hb.dbg_cut[0], hb.dbg_cut[1], hb.dbg_cut[2]);
-        e->r6_compact_hint = cpt && cpt_paid;
+        e->r6_compact_hint = cpt_ever;
         r6_rounds += hb.rounds;
         if (prof) HIPCHECK(e, hipEventRecord(e->ev_pool[4 * wi + 3], st));
         ++wi;
