@@ -1907,7 +1907,6 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         // chunk had one": every batch then began with sixteen rounds without it. Starting with the previous batch's small BLOCK as well was
         // measured and lost: device 3.39 -> 3.62 ms a round, same box, three runs each.)
         uint32_t exh_seen = 0, crounds_seen = 0, stops_seen = 0;
-        bool cpt_paid = false;   // the last chunk that ran with the index had rounds that used it
         const char* env_scan = getenv("SWP_SCAN");   // 0: never hand a stretch to the scan resolver (tests, A/B runs)
         const bool scan_ok = N <= scan_max_nodes() && !(env_scan && atoi(env_scan) == 0) && b->csi_set.empty();   // (the scan resolver knows no volumes)
         // The batched instance of the scan (k_scanb) decides ~4 tasks a barrier and answers an unplaceable task's twins without a look: where
@@ -1936,7 +1935,6 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 exh_seen = hb.cut_exhausted;
                 crounds_seen = hb.crounds;
                 stops_seen = hb.reseats;
-                if (cpt) cpt_paid = cr != 0;
                 if (cpt && cr) cpt_ever = true;
                 if (cpt_ok && !(env_cpt && atoi(env_cpt) != 0)) {
                     if (!cpt && used >= 4 && 2 * exh >= used && recent < 0.4 * ra.block && (double)stops * 12.0 >= recent * used) cpt = true;
