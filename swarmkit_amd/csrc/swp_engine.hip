@@ -137,15 +137,23 @@ struct DevBuf {   // owns one device allocation: movable, not copyable
     void* p = nullptr;
     size_t cap = 0;
     int dev = -1;
+    bool view = false;   // p lies inside another DevBuf's allocation (a batch's upload arena): nothing of its own to give back
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), dev(o.dev) { o.p = nullptr; o.cap = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), dev(o.dev), view(o.view) { o.p = nullptr; o.cap = 0; o.view = false; }
     ~DevBuf() { release(); }
     void release() {
-        if (p && !dev_pool().give(dev, cap, p)) (void)hipFree(p);
+        if (p && !view && !dev_pool().give(dev, cap, p)) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        view = false;
+    }
+    void point_into(void* q, size_t bytes) {   // (what was here before goes back first)
+        release();
+        p = q;
+        cap = bytes;
+        view = true;
     }
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap && p) return hipSuccess;
@@ -435,6 +443,8 @@ struct swp_batch {
     DevBuf d_csi_of, d_csi_set, d_vrows, d_att;
     std::vector<uint32_t> h_att;   // [csi tasks][SWP_MAX_MOUNTS] after fetch / results
 
+    DevBuf d_up;    // the upload arena: every small table of the batch in ONE allocation, filled by ONE copy from h_up (upload_batch)
+    PinBuf h_up;
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_hmat, d_emat;   // the scan resolver's (service, node) matrices, allocated when a stretch first goes to it
     DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
@@ -1354,41 +1364,62 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     const uint32_t T = b->T;
     int rc;
     if ((rc = upload(e, b->d_rt, b->rt))) return rc;
-    if ((rc = upload(e, b->d_tmpl, b->tmpl))) return rc;
+    // Every other table goes up through ONE pinned block and ONE copy into ONE device allocation (round 6: two dozen copies from pageable
+    // vectors, 10-20 us each whatever their size, were a sixth of a churn round's preparation); the DevBufs become views into the arena.
+    struct Up { DevBuf* d; const void* src; size_t bytes, room, off; };
+    std::vector<Up> ups;
+    auto stage = [&](DevBuf& d, const auto& v) -> int {
+        typedef typename std::decay<decltype(v)>::type::value_type V;
+        ups.push_back(Up{&d, v.data(), v.size() * sizeof(V), std::max<size_t>(v.size(), 1) * sizeof(V), 0});
+        return SWP_OK;
+    };
+    if ((rc = stage(b->d_tmpl, b->tmpl))) return rc;
     if (!b->csi_set.empty()) {
-        if ((rc = upload(e, b->d_csi_of, b->csi_of))) return rc;
-        if ((rc = upload(e, b->d_csi_set, b->csi_set))) return rc;
+        if ((rc = stage(b->d_csi_of, b->csi_of))) return rc;
+        if ((rc = stage(b->d_csi_set, b->csi_set))) return rc;
         HIPCHECK(e, b->d_vrows.reserve(b->csi_set.size() * (size_t)std::max<uint32_t>(Wn, 1) * 8));
         HIPCHECK(e, b->d_att.reserve(b->csi_set.size() * (size_t)SWP_MAX_MOUNTS * 4));
     }
-    if ((rc = upload(e, b->d_thr, b->thr))) return rc;
-    if ((rc = upload(e, b->d_thr64, b->thr64))) return rc;
+    if ((rc = stage(b->d_thr, b->thr))) return rc;
+    if ((rc = stage(b->d_thr64, b->thr64))) return rc;
     if (b->has_generic) {
-        if ((rc = upload(e, b->d_tg, b->tg))) return rc;
-        if ((rc = upload(e, b->d_gs_off, b->gs_off))) return rc;
-        if ((rc = upload(e, b->d_gs_row, b->gs_row))) return rc;
-        if ((rc = upload(e, b->d_rg_kind, b->rg_kind))) return rc;
-        if ((rc = upload(e, b->d_rg_k0, b->rg_k0))) return rc;
-        if ((rc = upload(e, b->d_rg_k1, b->rg_k1))) return rc;
-        if ((rc = upload(e, b->d_rg_val, b->rg_val))) return rc;
+        if ((rc = stage(b->d_tg, b->tg))) return rc;
+        if ((rc = stage(b->d_gs_off, b->gs_off))) return rc;
+        if ((rc = stage(b->d_gs_row, b->gs_row))) return rc;
+        if ((rc = stage(b->d_rg_kind, b->rg_kind))) return rc;
+        if ((rc = stage(b->d_rg_k0, b->rg_k0))) return rc;
+        if ((rc = stage(b->d_rg_k1, b->rg_k1))) return rc;
+        if ((rc = stage(b->d_rg_val, b->rg_val))) return rc;
     }
-    if ((rc = upload(e, b->d_list_node0, b->list_node0))) return rc;
-    if ((rc = upload(e, b->d_list_svc0, b->list_svc0))) return rc;
-    if ((rc = upload(e, b->d_list_fail0, b->list_fail0))) return rc;
-    if ((rc = upload(e, b->d_list_off, b->list_off))) return rc;
-    if ((rc = upload(e, b->d_xrow, b->xrow))) return rc;
-    if ((rc = upload(e, b->d_xnode, b->xnode))) return rc;
-    if ((rc = upload(e, b->d_prow, b->prow))) return rc;
-    if ((rc = upload(e, b->d_pnode, b->pnode))) return rc;
-    if ((rc = upload(e, b->d_pset_off, b->pset_off))) return rc;
-    if ((rc = upload(e, b->d_pset_ids, b->pset_ids))) return rc;
-    if ((rc = upload(e, b->d_con_off, b->con_off))) return rc;
-    if ((rc = upload(e, b->d_cons, b->cons))) return rc;
-    if ((rc = upload(e, b->d_plat_off, b->plat_off))) return rc;
-    if ((rc = upload(e, b->d_plats, b->plats))) return rc;
-    if ((rc = upload(e, b->d_plug_off, b->plug_off))) return rc;
-    if ((rc = upload(e, b->d_plug_req, b->plug_req))) return rc;
-    if ((rc = upload(e, b->d_triples, b->triples))) return rc;
+    if ((rc = stage(b->d_list_node0, b->list_node0))) return rc;
+    if ((rc = stage(b->d_list_svc0, b->list_svc0))) return rc;
+    if ((rc = stage(b->d_list_fail0, b->list_fail0))) return rc;
+    if ((rc = stage(b->d_list_off, b->list_off))) return rc;
+    if ((rc = stage(b->d_xrow, b->xrow))) return rc;
+    if ((rc = stage(b->d_xnode, b->xnode))) return rc;
+    if ((rc = stage(b->d_prow, b->prow))) return rc;
+    if ((rc = stage(b->d_pnode, b->pnode))) return rc;
+    if ((rc = stage(b->d_pset_off, b->pset_off))) return rc;
+    if ((rc = stage(b->d_pset_ids, b->pset_ids))) return rc;
+    if ((rc = stage(b->d_con_off, b->con_off))) return rc;
+    if ((rc = stage(b->d_cons, b->cons))) return rc;
+    if ((rc = stage(b->d_plat_off, b->plat_off))) return rc;
+    if ((rc = stage(b->d_plats, b->plats))) return rc;
+    if ((rc = stage(b->d_plug_off, b->plug_off))) return rc;
+    if ((rc = stage(b->d_plug_req, b->plug_req))) return rc;
+    if ((rc = stage(b->d_triples, b->triples))) return rc;
+    {
+        size_t total = 0;
+        for (Up& u : ups) { u.off = total; total += (u.room + 255) & ~(size_t)255; }
+        if (b->h_up.p) HIPCHECK(e, hipStreamSynchronize(e->stream));   // (a batch uploaded again: the first copy may still be reading the block)
+        HIPCHECK(e, b->d_up.reserve(std::max<size_t>(total, 256)));
+        HIPCHECK(e, b->h_up.reserve(std::max<size_t>(total, 256)));
+        for (Up& u : ups) {
+            if (u.bytes) std::memcpy(static_cast<char*>(b->h_up.p) + u.off, u.src, u.bytes);
+            u.d->point_into(static_cast<char*>(b->d_up.p) + u.off, (u.room + 255) & ~(size_t)255);
+        }
+        if (total) HIPCHECK(e, hipMemcpyAsync(b->d_up.p, b->h_up.p, total, hipMemcpyHostToDevice, e->stream));
+    }
     size_t L = std::max<size_t>(b->list_node0.size(), 1);
     HIPCHECK(e, b->d_list_node.reserve(L * 4));
     HIPCHECK(e, b->d_list_svc.reserve(L * 4));
