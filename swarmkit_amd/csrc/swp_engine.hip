@@ -2857,11 +2857,13 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
         for (uint64_t i = 0; i < total; ++i) out_node[i] = -1;
         return SWP_OK;
     }
+    HostSpan sp("groups: build_batch + upload");
     swp_batch b;
     if ((rc = build_batch(e, groups, n_groups, &b, sizes))) return rc;
     if ((rc = flush_nodes(e))) return rc;
     if ((rc = upload_batch(e, &b))) return rc;
     hipStream_t st = e->stream;
+    sp.next("groups: trees, records, class lists, buffers");
 
     // decision-tree topology per spread set: branch creation order = node index order (nodeset.go:57-101)
     std::map<uint32_t, uint32_t> tree_local;   // spread set -> local tree
@@ -3039,6 +3041,7 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
         ga.vol = vol_view(e);
         ga.att = d_gatt.as<uint32_t>();
     }
+    sp.next("groups: k_groups2 + download");
     HIPCHECK(e, launch_groups2(ga, st, e->device));
     if (gdbg) {
         (void)hipEventRecord(gev1, st);
@@ -3080,6 +3083,7 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
                 if (recs[g].mset)
                     std::memcpy(out_att + (size_t)recs[g].out_off * SWP_MAX_MOUNTS, h.data() + (size_t)recs[g].att_off * SWP_MAX_MOUNTS, (size_t)sizes[g] * SWP_MAX_MOUNTS * 4);
     }
+    sp.next("groups: placements into the node mirror");
     return groups_apply_to_host(e, groups, sizes, n_groups, total, out_node);
 }
 
@@ -3087,16 +3091,55 @@ static int schedule_groups_impl(swp_engine* e, const swp_task_desc* groups, cons
 static int groups_apply_to_host(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, uint64_t total, const int32_t* out_node) {
     uint64_t placed = 0;
     uint32_t off = 0;
+    std::vector<FlatMap32::Ent> upd, merged;
     for (uint32_t g = 0; g < n_groups; ++g) {
         const swp_task_desc& d = groups[g];
-        for (uint32_t i = 0; i < sizes[g]; ++i) {
-            int32_t n = out_node[off + i];
-            if (n < 0) continue;
-            if ((uint32_t)n >= e->nodes.size() || !e->nodes[n].present) return e->fail(SWP_EHIP, "device returned an invalid node index %d", n);
-            host_apply_placement(e, (uint32_t)n, d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
+        const int32_t* on = out_node + off;
+        const uint32_t k = sizes[g];
+        off += k;
+        for (uint32_t i = 0; i < k; ++i)
+            if (on[i] >= 0 && ((uint32_t)on[i] >= e->nodes.size() || !e->nodes[on[i]].present)) return e->fail(SWP_EHIP, "device returned an invalid node index %d", on[i]);
+        if (d.port_set || d.generic_set || (d.flags & 0x2u)) {   // the general path, placement by placement
+            for (uint32_t i = 0; i < k; ++i)
+                if (on[i] >= 0) {
+                    host_apply_placement(e, (uint32_t)on[i], d.service, d.cpu, d.mem, d.port_set, !(d.flags & 0x2u), true, d.generic_set);
+                    ++placed;
+                }
+            continue;
+        }
+        // A group's placements are k tasks of ONE service: the node records are requested together, and the service's entry of the
+        // service -> nodes index takes them in one merge instead of k insertions into a sorted vector (round 6: 100 000 placements a
+        // tick were 2.5 ms of bookkeeping after a 23 ms kernel)
+        for (uint32_t i = 0; i < k; ++i)
+            if (on[i] >= 0) {
+                __builtin_prefetch(&e->nodes[on[i]].row);
+                __builtin_prefetch(&e->nodes[on[i]].svc);
+            }
+        upd.clear();
+        for (uint32_t i = 0; i < k; ++i) {
+            if (on[i] < 0) continue;
+            HostNode& h = e->nodes[on[i]];
+            h.row.cpu -= d.cpu;
+            h.row.mem -= d.mem;
+            h.row.total += 1;
+            upd.emplace_back((uint32_t)on[i], ++h.svc[d.service]);
             ++placed;
         }
-        off += sizes[g];
+        if (upd.empty()) continue;
+        e->host_dirty_since_save = true;
+        std::sort(upd.begin(), upd.end());   // (a node that took several tasks of the group: its highest count is its last)
+        FlatMap32& m = e->svc_nodes[d.service];
+        merged.clear();
+        merged.reserve(m.v.size() + upd.size());
+        size_t a = 0;
+        for (size_t u = 0; u < upd.size(); ++u) {
+            if (u + 1 < upd.size() && upd[u + 1].first == upd[u].first) continue;
+            while (a < m.v.size() && m.v[a].first < upd[u].first) merged.push_back(m.v[a++]);
+            if (a < m.v.size() && m.v[a].first == upd[u].first) ++a;
+            merged.push_back(upd[u]);
+        }
+        while (a < m.v.size()) merged.push_back(m.v[a++]);
+        m.v.swap(merged);
     }
     e->stats.batches++;
     e->stats.tasks += total;
