@@ -194,6 +194,17 @@ __global__ void k_scatter_bits(u32 n_entries, const u32* __restrict__ row, const
     atomicOr(&bm[(size_t)row[i] * n_words + (n >> 6)], 1ull << (n & 63));
 }
 
+// X[s] = the nodes of service s's exception list (the entries the batch starts with; a task's reserved slot is LIST_EMPTY): read off
+// the lists themselves — grid (entries of the longest list / 256 at most 64, services) — instead of a second (row, node) copy of them
+__global__ void k_scatter_lists(const u32* __restrict__ list_off, const u32* __restrict__ list_node, u32 n_words, u64* __restrict__ X) {
+    const u32 s = blockIdx.y;
+    const u32 e1 = list_off[s + 1];
+    for (u32 e = list_off[s] + blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += gridDim.x * blockDim.x) {
+        const u32 n = list_node[e];
+        if (n != LIST_EMPTY) atomicOr(&X[(size_t)s * n_words + (n >> 6)], 1ull << (n & 63));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_explain — per-filter first-failure histogram for every task that found no node, evaluated
 // against the node state AT THE MOMENT that task was tried (Pipeline.Process counters,

@@ -406,7 +406,7 @@ struct swp_batch {
     std::vector<uint32_t> list_off;        // [n_svc+1]
     std::vector<uint32_t> list_node0, list_svc0, list_fail0;   // pristine lists
     std::vector<uint32_t> list_cnt0;                            // [n_svc] entries in use at the front of a service's range
-    std::vector<uint32_t> xrow, xnode;     // scatter sources for X
+    uint32_t n_list0 = 0, max_list = 0;    // entries the exception lists start with (all services); the longest list's length, free slots included
     std::vector<uint32_t> prow, pnode;     // scatter sources for portmap
     std::vector<uint64_t> port_keys;       // batch-local port -> (proto,port)
     std::vector<uint32_t> pset_off, pset_ids;
@@ -447,7 +447,7 @@ struct swp_batch {
     PinBuf h_up;
     DevBuf d_rt, d_out, d_hist, d_X, d_list_node, d_list_svc, d_list_fail, d_list_node0, d_list_svc0, d_list_fail0, d_list_off;
     DevBuf d_hmat, d_emat;   // the scan resolver's (service, node) matrices, allocated when a stretch first goes to it
-    DevBuf d_xrow, d_xnode, d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
+    DevBuf d_prow, d_pnode, d_portmap, d_pset_off, d_pset_ids;
     DevBuf d_con_off, d_cons, d_plat_off, d_plats, d_plug_off, d_plug_req, d_triples;
     DevBuf d_con, d_plat, d_plug, d_sc, d_log_node, d_log_task, d_log_prev, d_last, d_inf_task, d_inf_pos, d_ctl;
     DevBuf d_seg_off, d_seg_len, d_ent_ci, d_ent_scpu, d_ent_smem, d_seg_alloc;   // explain pass: per-node commit segments
@@ -1254,8 +1254,6 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
         uint32_t g = b->svc_global[s];
         b->list_off[s] = (uint32_t)b->list_node0.size();
         auto emit = [&](uint32_t node, uint32_t cnt, uint32_t fails) {
-            b->xrow.push_back(s);
-            b->xnode.push_back(node);
             b->list_node0.push_back(node);
             b->list_svc0.push_back(cnt);
             b->list_fail0.push_back(fails);
@@ -1290,6 +1288,11 @@ int build_batch(swp_engine* e, const swp_task_desc* descs, uint32_t T, swp_batch
         b->list_fail0.insert(b->list_fail0.end(), svc_ntasks[s], 0u);
     }
     b->list_off[b->n_svc] = (uint32_t)b->list_node0.size();
+    b->n_list0 = b->max_list = 0;
+    for (uint32_t s = 0; s < b->n_svc; ++s) {
+        b->n_list0 += init_cnt[s];
+        b->max_list = std::max(b->max_list, b->list_off[s + 1] - b->list_off[s]);
+    }
     for (uint32_t i = 0; i < T; ++i) b->rt[i].slot = b->list_off[b->rt[i].svc] + init_cnt[b->rt[i].svc] + task_rank[i];
 
     mark("exception lists + slots");
@@ -1395,8 +1398,6 @@ int upload_batch(swp_engine* e, swp_batch* b) {
     if ((rc = stage(b->d_list_svc0, b->list_svc0))) return rc;
     if ((rc = stage(b->d_list_fail0, b->list_fail0))) return rc;
     if ((rc = stage(b->d_list_off, b->list_off))) return rc;
-    if ((rc = stage(b->d_xrow, b->xrow))) return rc;
-    if ((rc = stage(b->d_xnode, b->xnode))) return rc;
     if ((rc = stage(b->d_prow, b->prow))) return rc;
     if ((rc = stage(b->d_pnode, b->pnode))) return rc;
     if ((rc = stage(b->d_pset_off, b->pset_off))) return rc;
@@ -1733,9 +1734,9 @@ int batch_begin(swp_engine* e, swp_batch* b) {
         HIPCHECK(e, hipMemsetAsync(b->d_att.p, 0xFF, b->csi_set.size() * (size_t)SWP_MAX_MOUNTS * 4, st));
         HIPCHECK(e, hipMemsetAsync(b->d_vrows.p, 0, b->csi_set.size() * (size_t)Wn * 8, st));
     }
-    if (!b->xrow.empty())
-        hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b->xrow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b->xrow.size(),
-                           b->d_xrow.as<uint32_t>(), b->d_xnode.as<uint32_t>(), Wn, b->d_X.as<u64>());
+    if (b->n_list0 && b->n_svc)   // X rows from the lists as they start (d_list_node0: the batch's own copy, whatever the rounds did to d_list_node)
+        hipLaunchKernelGGL(k_scatter_lists, dim3(std::min<uint32_t>(64u, (b->max_list + 255u) / 256u), b->n_svc), dim3(256), 0, st, b->d_list_off.as<uint32_t>(),
+                           b->d_list_node0.as<uint32_t>(), Wn, b->d_X.as<u64>());
     if (!b->prow.empty())
         hipLaunchKernelGGL(k_scatter_bits, dim3(((uint32_t)b->prow.size() + 255) / 256), dim3(256), 0, st, (uint32_t)b->prow.size(),
                            b->d_prow.as<uint32_t>(), b->d_pnode.as<uint32_t>(), Wn, b->d_portmap.as<u64>());
