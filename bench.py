@@ -676,9 +676,11 @@ def main():
     ms_resolve = ms_explain = ms_classes = ms_dev = 0.0
     launches0 = eng.stats()["resolve_launches"]
     t0 = time.perf_counter()
+    ms_scan = 0.0
     for _ in range(args.steps):
         out, _ = step()
         st = eng.stats()
+        ms_scan += st["ms_scan"]
         ms_resolve += st["ms_resolve"]
         ms_explain += st["ms_explain"]
         ms_classes += st["ms_classes"]
@@ -745,6 +747,14 @@ def main():
         windows = max((launches1 - launches0) / 2.0 / K, 1.0)
     res_launch_ms = ms_resolve / K / windows
     alg_bytes_launch = alg_bytes_step / windows
+    # A batch whose tasks have no plain candidates (a saturated small cluster) is mostly decided by the scan resolver (k_scanb / k_scan:
+    # DESIGN 5b): it is then the dominant kernel, a "launch" is one stretch of tasks, its bytes the stretch's (task, node) pairs
+    scan_dominant = kernel.startswith("k_resolve6") and ms_scan > 0.5 * ms_resolve and st["scan_launches"] > 0
+    if scan_dominant:
+        kernel = "k_scanb / k_scan (the scan resolver: one 'launch' = one STRETCH of tasks without plain candidates, k_scan_fill + k_scan_lists + the scan kernel)"
+        windows = float(st["scan_launches"])
+        res_launch_ms = ms_scan / K / windows
+        alg_bytes_launch = (st["scan_tasks"] * wl.N * row_b + st["scan_tasks"] * TASK_B) / windows
     achieved = alg_bytes_launch / (res_launch_ms * 1e-3) / 1e9 if res_launch_ms > 0 else 0.0
     # (the PMC passes ran the headline shape — cfg3 100k x 10k, round-robin order; a line of another shape carries no traffic figure)
     profiled = args.workload == "cfg3" and wl.T == 100000 and wl.N == 10000 and getattr(wl, "order", "rr") == "rr" and wl.S == 1000
@@ -780,15 +790,20 @@ def main():
                      "frac": ((measured_gbs / HBM_PEAK_GBS) if (not_hbm and measured_gbs is not None) else (None if not_hbm else roof_frac)),
                      "not_hbm_bound": not_hbm, "algorithmic_GBs": achieved,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows, "tasks_per_launch": wl.T / windows,
-                     "note": ("per ROUND of the block resolver (launches_per_step rounds, tasks_per_launch decided each): algorithmic bytes = the round's "
+                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": res_launch_ms, "launches_per_step": windows, "tasks_per_launch": (st["scan_tasks"] if scan_dominant else wl.T) / windows,
+                     "note": ("per STRETCH of the scan resolver (scan_tasks of the batch's tasks in scan_launches stretches; the rest by rounds of the block resolver): "
+                              "algorithmic bytes = the stretch's (task, node) pairs x node-row bytes (SURVEY 8d). Everything a task reads is in LDS (node rows, the "
+                              "(service, node) matrices, the class rows), so real HBM traffic is the task records and the logs; the kernel is bound by the "
+                              "instruction issue of one workgroup (four waves, ~7 800 cycles per batch of four tasks: DESIGN 5b), and a task whose identical twin "
+                              "found no node is answered without a look" if scan_dominant else
+                              "per ROUND of the block resolver (launches_per_step rounds, tasks_per_launch decided each): algorithmic bytes = the round's "
                               "(task, node) pairs x node-row bytes (SURVEY 8d); traffic = PMC bytes of one k_r6_propose + one k_r6_commit. The resolver reads "
                               "bitmap ROWS (one bit per pair and filter, L2-resident) instead of a node row per pair, so real traffic is a small fraction "
                               "of the algorithmic figure; a round is bound by one wave's instruction issue in k_r6_commit (resolver.cycles_per_task), "
                               "not by HBM" if kernel.startswith("k_resolve6") else
                               "algorithmic bytes = pairs x node-row bytes (SURVEY 8d); the resolver decides from bitmaps held in LDS, so its real HBM "
                               "traffic is far below that (see traffic): the kernel is bound by one workgroup's instruction issue, not by HBM")},
-        "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_resolve": ms_resolve / K, "k_explain": ms_explain / K, "device_total": ms_dev / K},
+        "kernels_ms_per_step": {"classes+init": ms_classes / K, "k_resolve": ms_resolve / K, "of which scan stretches": ms_scan / K, "k_explain": ms_explain / K, "device_total": ms_dev / K},
         # what really bounds the resolver: the instruction issue of ONE wavefront (the matcher's dependent chain), not bytes
         "issue_bound": {"matcher_instr_per_task": 13, "issue_cycles_per_instr": 5.0, "floor_cycles_per_task": 65.0, "cycles_per_task": cycles_per_task,
                         "note": "the serial chain of the batch is wv::match_seq64 on ONE wave: 13 instructions per task (tools/check_matcher_asm.sh), a lone wave issues one "

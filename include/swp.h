@@ -533,7 +533,8 @@ typedef struct {
     float    ms_propose, ms_apply;          /* Σ k_propose / k_shard_apply launch durations */
     uint32_t propose_launches, propose_tasks;   /* launches and Σ tasks proposed (a task cut off a block is proposed again) */
     uint32_t waterfill_tasks;   /* tasks placed as runs of identical tasks (k_waterfill), since swp_create */
-    uint32_t reserved2;
+    uint32_t scan_tasks;        /* last batch: tasks the scan resolver decided (k_scan / k_scanb: stretches without plain candidates); scan_launches
+                                   counts those stretches and ms_scan their time (SWP_CFG_PROFILE) */
 } swp_stats_t;
 
 int swp_create(const swp_config*, swp_engine** out);

@@ -73,7 +73,7 @@ class Stats(C.Structure):
                 ("ms_classes", C.c_float), ("ms_scan", C.c_float), ("ms_resolve", C.c_float), ("ms_explain", C.c_float), ("ms_total", C.c_float),
                 ("scan_launches", C.c_uint32), ("resolve_launches", C.c_uint32), ("last_resolver", C.c_uint32),
                 ("ms_propose", C.c_float), ("ms_apply", C.c_float), ("propose_launches", C.c_uint32), ("propose_tasks", C.c_uint32),
-                ("waterfill_tasks", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("waterfill_tasks", C.c_uint32), ("scan_tasks", C.c_uint32)]
 
 
 # numpy views of the POD structs, for bulk construction

@@ -567,6 +567,8 @@ struct swp_engine {
     void* rccl_comm = nullptr;
     uint32_t rccl_rank = 0, rccl_ranks = 0;
 
+    std::vector<hipEvent_t> ev_scan;   // SWP_CFG_PROFILE: a pair per stretch the scan resolver took (run_blocks); ev_scan_used of them in this batch
+    uint32_t ev_scan_used = 0, scan_tasks_batch = 0, scan_stretches_batch = 0;
     bool r6_compact_hint = false;   // the last batch's rounds used a compact index (re-placements after a drain): the next one starts with it
     swp_stats_t stats{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1845,6 +1847,8 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
     const bool prof = (e->cfg.flags & SWP_CFG_PROFILE) != 0;
     hipStream_t st = e->stream;
     if (prof) HIPCHECK(e, hipEventRecord(e->ev[0], st));
+    e->ev_scan_used = 0;
+    e->scan_tasks_batch = e->scan_stretches_batch = 0;
 
     int rc = batch_begin(e, b);
     if (rc) return rc;
@@ -1989,7 +1993,21 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
                 bool node_local = ra.n_rg == 0 && ra.csi_of == nullptr;   // (k_scanb: every input of a task in LDS, every effect on ONE node)
                 for (uint32_t j = pos; j < upto && node_local; ++j)
                     if (b->rt[j].flags & RT_PORTS) node_local = false;
+                if (prof) {
+                    while (e->ev_scan.size() < (size_t)e->ev_scan_used + 2) {
+                        hipEvent_t x;
+                        HIPCHECK(e, hipEventCreate(&x));
+                        e->ev_scan.push_back(x);
+                    }
+                    HIPCHECK(e, hipEventRecord(e->ev_scan[e->ev_scan_used], st));
+                }
                 r = launch_scan(sa, st, e->device, node_local);
+                if (prof) {
+                    HIPCHECK(e, hipEventRecord(e->ev_scan[e->ev_scan_used + 1], st));
+                    e->ev_scan_used += 2;
+                }
+                e->scan_tasks_batch += upto - pos;
+                e->scan_stretches_batch += 1;
                 if (r == hipSuccess) r = launch_r6_build(ra, st);   // the rounds go on from the rows as the scan left them
                 if (r != hipSuccess) return e->fail(SWP_EHIP, "k_scan launch: %s", hipGetErrorString(r));
                 scanned += upto - pos;
@@ -2184,6 +2202,11 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
             scan_sum += x;
             res_sum += y;
         }
+        for (uint32_t q = 0; q + 1 < e->ev_scan_used; q += 2) {   // the stretches the scan resolver took (k_scan_fill + k_scan_lists + k_scan / k_scanb each)
+            float x = 0;
+            (void)hipEventElapsedTime(&x, e->ev_scan[q], e->ev_scan[q + 1]);
+            scan_sum += x;
+        }
         e->stats.ms_classes = a;
         e->stats.ms_scan = scan_sum;      // Σ over windows of k_scan launch durations
         e->stats.ms_resolve = b->segs.empty() ? res_sum : c;   // Σ of the resolver launches; with runs of identical tasks in the batch: the whole phase (k_waterfill launches + the stretches between them)
@@ -2218,6 +2241,8 @@ fprintf(stderr, "[swp] k_resolve5 lister wave 1 per round (cycles): prologue %.0
                 ctl.cyc[0], ctl.cyc[1], ctl.cyc[2], ctl.cyc[3], ctl.cyc[4], ctl.cyc[5], ctl.ncommit, ctl.ninf, ctl.generic_tasks);
     if ((dbg_bits & 16) && ctl.cyc[7])
         fprintf(stderr, "[swp] shader clock: %llu cycles / %llu x10ns => %.0f MHz\n", ctl.cyc[6], ctl.cyc[7], (double)ctl.cyc[6] / ((double)ctl.cyc[7] * 0.01));
+    e->stats.scan_launches = e->scan_stretches_batch;
+    e->stats.scan_tasks = e->scan_tasks_batch;
     e->stats.last_windows = wi;   // resolver launches of this batch (1 in k_resolve5's exact mode: no scan windows)
     e->stats.last_static_classes = b->n_sc;
     e->stats.resolve_launches += variant == 6 ? (uint32_t)(2 * r6_rounds) : wi;   // k_resolve6: a propose and a commit launch per round
@@ -2490,6 +2515,7 @@ void swp_destroy(swp_engine* e) {
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_scan) (void)hipEventDestroy(ev);
     if (e->rows_ev) (void)hipEventDestroy(e->rows_ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     const int dev = e->device;
