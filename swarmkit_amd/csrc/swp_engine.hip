@@ -494,6 +494,7 @@ struct ShardSet {
     // GROUPS runs — the whole nodeSet by global index, copied from the shards' mirrors (swp_shardset.hpp ss::schedule_groups).
     swp_engine* uni = nullptr;
     std::vector<swp_engine*> all;  // sh + uni: who a replicated call goes to
+    bool broken = false;           // a shard holds a node id under another index than the set's (ss::intern): refused until swp_reset
 };
 
 struct swp_engine {

@@ -127,7 +127,15 @@ struct ParseError : std::runtime_error {
 class Parser {
   public:
     Parser(const char* p, size_t n) : p_(p), e_(p + n) {}
+    // NOT re-entrant on one thread: every Parser of a thread shares the scratch stacks below, so a parse started while another one is
+    // under way on the same thread (nothing does that: a document is parsed in one go, no callbacks) would clear the outer one's open
+    // members. The flag turns such a use into an error instead of a corrupted document.
     Value parse_document() {
+        struct Busy {
+            bool& b;
+            explicit Busy(bool& x) : b(x) { if (b) throw ParseError("json: nested parse on one thread"); b = true; }
+            ~Busy() { b = false; }
+        } busy(scratch().busy);
         members_.clear();   // (left behind by a parse that failed half-way)
         elements_.clear();
         Value v = value(0);
@@ -141,7 +149,7 @@ class Parser {
     const char* e_;
     // the members / elements of the objects and arrays that are still open, innermost last; per thread, so that the room they have
     // grown to serves the next document (an event is one small document: two allocations less per event)
-    struct Scratch { std::vector<Member> members; std::vector<Value> elements; };
+    struct Scratch { std::vector<Member> members; std::vector<Value> elements; bool busy = false; };
     static Scratch& scratch() { static thread_local Scratch s; return s; }
     std::vector<Member>& members_ = scratch().members;   // (bound once per parser: a thread_local is a function call per access)
     std::vector<Value>& elements_ = scratch().elements;
@@ -168,28 +176,49 @@ class Parser {
             out.push_back((char)(0x80 | (cp & 0x3F)));
         }
     }
-    // well-formed UTF-8 (RFC 3629 byte ranges: no overlong forms, no surrogates, nothing beyond U+10FFFF)
+    // length of the well-formed UTF-8 sequence at p (RFC 3629 byte ranges: no overlong forms, no surrogates, nothing beyond U+10FFFF); 0: none
+    static size_t utf8_seq(const unsigned char* p, const unsigned char* e) {
+        const unsigned char c = *p;
+        if (c < 0x80) return 1;
+        size_t n;
+        if (c >= 0xC2 && c <= 0xDF) n = 1;
+        else if (c >= 0xE0 && c <= 0xEF) n = 2;
+        else if (c >= 0xF0 && c <= 0xF4) n = 3;
+        else return 0;
+        if ((size_t)(e - p) < n + 1) return 0;
+        if (c == 0xE0 && p[1] < 0xA0) return 0;                    // overlong
+        if (c == 0xED && p[1] > 0x9F) return 0;                    // U+D800..DFFF
+        if (c == 0xF0 && p[1] < 0x90) return 0;
+        if (c == 0xF4 && p[1] > 0x8F) return 0;                    // beyond U+10FFFF
+        for (size_t k = 1; k <= n; ++k)
+            if ((p[k] & 0xC0) != 0x80) return 0;
+        return n + 1;
+    }
     static bool utf8_ok(const std::string& s) {
         const unsigned char* p = reinterpret_cast<const unsigned char*>(s.data());
         const unsigned char* e = p + s.size();
         while (p != e) {
-            const unsigned char c = *p++;
-            if (c < 0x80) continue;
-            int n;
-            if (c >= 0xC2 && c <= 0xDF) n = 1;
-            else if (c >= 0xE0 && c <= 0xEF) n = 2;
-            else if (c >= 0xF0 && c <= 0xF4) n = 3;
-            else return false;
-            if (e - p < n) return false;
-            if (c == 0xE0 && p[0] < 0xA0) return false;                    // overlong
-            if (c == 0xED && p[0] > 0x9F) return false;                    // U+D800..DFFF
-            if (c == 0xF0 && p[0] < 0x90) return false;
-            if (c == 0xF4 && p[0] > 0x8F) return false;                    // beyond U+10FFFF
-            for (int k = 0; k < n; ++k)
-                if ((p[k] & 0xC0) != 0x80) return false;
+            const size_t n = utf8_seq(p, e);
+            if (n == 0) return false;
             p += n;
         }
         return true;
+    }
+    // A string that is not UTF-8 is coerced the way Go's encoding/json does it (decode.go, unquote: utf8.DecodeRune — an ill-formed
+    // sequence is ONE byte long and reads as U+FFFD), so that an event written by something other than Go's marshaller is scheduled, not
+    // lost, and what goes out in the decisions is JSON again. (Until round 6 such a document was refused: ADVICE r5.)
+    static void utf8_coerce(std::string& s) {
+        if (utf8_ok(s)) return;
+        std::string out;
+        out.reserve(s.size() + 8);
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(s.data());
+        const unsigned char* e = p + s.size();
+        while (p != e) {
+            const size_t n = utf8_seq(p, e);
+            if (n == 0) { out.append("\xEF\xBF\xBD"); ++p; }
+            else { out.append(reinterpret_cast<const char*>(p), n); p += n; }
+        }
+        s.swap(out);
     }
     uint32_t hex4() {
         if (e_ - p_ < 4) fail("short \\u escape");
@@ -215,14 +244,14 @@ class Parser {
         p_ = q;
         if (*p_ == '"') {
             ++p_;
-            if ((high & 0x80u) && !utf8_ok(out)) fail("a string that is not UTF-8");   // (what goes in comes out again: the decisions must stay JSON)
+            if (high & 0x80u) utf8_coerce(out);   // (what goes in comes out again: the decisions must stay JSON)
             return out;
         }
         for (;;) {
             if (p_ == e_) fail("unterminated string");
             char c = *p_++;
             if (c == '"') {
-                if (!utf8_ok(out)) fail("a string that is not UTF-8");
+                utf8_coerce(out);
                 return out;
             }
             if (c != '\\') { out.push_back(c); continue; }

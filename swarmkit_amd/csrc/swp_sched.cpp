@@ -832,6 +832,7 @@ class Scheduler {
     bool deleteTask(const Value& t) {
         const std::string id = task_id(t);
         allTasks_.erase(id);
+        if (unassignedTasks_.find(id)) deletedWhileQueued_.push_back(id);   // (the queue keeps it, as the reference's does: tick's catch-all path below)
         preassignedTasks_.erase(id);
         pendingPreassignedTasks_.erase(id);
         releaseTaskVolumes(t);   // :355-358
@@ -908,6 +909,10 @@ class Scheduler {
         for (size_t i = 0; i < templates_.size(); ++i) tmplIndex_[templateHash(templates_[i].exemplar)].push_back((uint32_t)i);
     }
     // the template's descriptor (Pipeline.SetTask once per template and volume generation); throws what taskDesc throws
+    // INVARIANT: a cached descriptor carries engine-side set ids (constraint, platform, plugin, port, generic, spread, mount sets) and
+    // interned ids; they stay valid because this scheduler's engine is reset ONCE, in the constructor, and sets are never collected.
+    // Whatever invalidates them later — an swp_reset of the engine, a shard set rebuilt under the same scheduler — must bump tmplGen_
+    // (as updateVolume does for mounts), or every tick afterwards schedules with stale ids and nothing says so.
     const swp_task_desc& descOf(uint32_t tmpl) {
         Template& tm = templates_[tmpl];
         if (tm.gen != tmplGen_) {
@@ -1156,6 +1161,16 @@ class Scheduler {
         // the node rows already.
         std::vector<std::string> ids;
         for (const Item& it : queue) ids.push_back(it.first);
+        // (a task deleted while it was queued is scheduled all the same — deleteTask leaves the queue alone, scheduler.go:350-366 — but it is
+        // not in allTasks_, where the handler below finds the others' documents once scheduleQueue has moved the queue's away: its queued
+        // document is kept aside. Rare: nothing is copied unless a deletion met a queued task since the last tick.)
+        std::map<std::string, Value> orphans;
+        if (!deletedWhileQueued_.empty()) {
+            const std::set<std::string> gone(deletedWhileQueued_.begin(), deletedWhileQueued_.end());
+            deletedWhileQueued_.clear();
+            for (const Item& it : queue)
+                if (gone.count(it.first) && allTasks_.find(it.first) == allTasks_.end()) orphans.emplace(it.first, it.second);
+        }
         try {
             scheduleQueue(queue, decisions);
         } catch (const Fail& f) {
@@ -1164,6 +1179,10 @@ class Scheduler {
                 if (have.count(id)) continue;
                 auto t = allTasks_.find(id);
                 if (t != allTasks_.end()) defer(id, t->second, f, decisions);
+                else {
+                    auto o = orphans.find(id);
+                    if (o != orphans.end()) defer(id, o->second, f, decisions);
+                }
             }
         }
         std::string out = decisions.finish();
@@ -1456,6 +1475,7 @@ class Scheduler {
     std::vector<NodeInfo*> node_by_idx_;                                   // engine node index -> its NodeInfo (place(): no look-up by id)
     std::unordered_map<std::string, std::optional<uint64_t>> services_;   // store.GetService: existence + SpecVersion
     OrderedTasks unassignedTasks_;                                         // Scheduler.unassignedTasks
+    std::vector<std::string> deletedWhileQueued_;                           // ids deleteTask met in the queue since the last tick (tick's catch-all path)
     OrderedTasks pendingPreassignedTasks_;                                 // Scheduler.pendingPreassignedTasks
     // the `old` half of every decision of the last tick / processPreassignedTasks (schedulingDecision.old, scheduler.go:53-56),
     // kept until the next one so that the caller can roll a decision back when its store commit failed (rejectDecision)
@@ -1836,6 +1856,7 @@ class Scheduler {
         static const std::string assigned_message = "scheduler assigned task to node", no_err;
         // newT = the task with NodeID and Status set: ONE pass over the document's members, one allocation; what the decision line and the
         // checks below need of the document is picked up on the way
+        if (t.kind != Value::Obj || !t.o) fail(SWP_EINVAL, "a queued task document is not a JSON object");   // (create_task / update_task only queue objects: a guard, not a path)
         Value newT;
         newT.kind = Value::Obj;
         newT.o = std::make_shared<std::vector<json::Member>>();

@@ -27,6 +27,7 @@ inline int take_error(swp_engine* e, swp_engine* child, int rc) {
     if (rc != SWP_OK) e->last_error = child->last_error;
     return rc;
 }
+inline int broken_error(swp_engine* e) { return e->fail(SWP_EINVAL, "the shard set and a shard disagree about a node index (an id interned on a shard directly): swp_reset the set"); }
 inline bool locate(const ShardSet& S, uint32_t gi, uint32_t* g, uint32_t* l) {
     if (gi >= S.nodes.strs.size() || (gi < S.nodes.freed.size() && S.nodes.freed[gi])) return false;
     *g = gi / S.cap;
@@ -119,6 +120,7 @@ int reset(swp_engine* e, uint32_t hint) {
         if (int rc = swp_reset(c, hint / (uint32_t)S.sh.size() + 1)) return take_error(e, c, rc);
     S.nodes.init(false);
     S.hi = 0;
+    S.broken = false;
     return SWP_OK;
 }
 
@@ -135,6 +137,7 @@ int intern(swp_engine* e, int space, const char* utf8, size_t len, uint32_t* id_
         *id_out = it->second;
         return SWP_OK;
     }
+    if (S.broken) return broken_error(e);
     const uint32_t gi = S.nodes.get(s);
     const uint32_t g = gi / S.cap, l = gi % S.cap;
     if (g >= S.sh.size()) {
@@ -146,7 +149,10 @@ int intern(swp_engine* e, int space, const char* utf8, size_t len, uint32_t* id_
     if (rc || got != l) {
         S.nodes.release(gi);
         if (rc) return take_error(e, S.sh[g], rc);
-        return e->fail(SWP_EINVAL, "shard %u gave node '%s' local index %u, the set expects %u (node ids must be interned through the set only)", g, s.c_str(), got, l);
+        // the id stays interned on the shard under another index than the set's arithmetic gives it: from here on set and shard would
+        // disagree about every later node of the range — the set refuses node ids, batches, groups and commits until swp_reset
+        S.broken = true;
+        return e->fail(SWP_EINVAL, "shard %u gave node '%s' local index %u, the set expects %u (node ids must be interned through the set only); the set is unusable until swp_reset", g, s.c_str(), got, l);
     }
     S.hi = std::max(S.hi, gi + 1);
     *id_out = gi;
@@ -329,6 +335,7 @@ int batch_prepare(swp_engine* e, const swp_task_desc* tasks, uint32_t n, const u
     ShardSet& S = *e->set;
     if (!out || (!tasks && n)) return SWP_EINVAL;
     *out = nullptr;
+    if (S.broken) return broken_error(e);
     auto b = std::make_unique<swp_batch>();
     b->T = n;
     b->is_set = true;
@@ -352,9 +359,9 @@ int batch_run(swp_engine* e, swp_batch* b) {
     b->set_shard.assign(T, -1);
     b->set_node.assign(T, -1);
     b->set_hist.assign((size_t)T * SWP_NFILTERS, 0);
-    b->ran = true;
+    b->ran = false;   // (true behind a run that succeeded: a fetch after a failed run is an error, not a batch of "no suitable node")
     b->set_single = -1;
-    if (T == 0) return SWP_OK;
+    if (T == 0) { b->ran = true; return SWP_OK; }
     std::vector<swp_engine*> eng;
     std::vector<swp_batch*> bat;
     std::vector<uint32_t> who;
@@ -365,16 +372,18 @@ int batch_run(swp_engine* e, swp_batch* b) {
             who.push_back((uint32_t)g);
         }
     const auto t0 = std::chrono::steady_clock::now();
-    if (eng.empty()) return SWP_OK;   // an empty nodeSet: every task is "no suitable node" with an empty explanation
+    if (eng.empty()) { b->ran = true; return SWP_OK; }   // an empty nodeSet: every task is "no suitable node" with an empty explanation
     if (eng.size() == 1) {            // one range holds every node: that engine's own batch path (results are taken at fetch time)
         b->set_single = (int32_t)who[0];
         const int rc = take_error(e, eng[0], swp_batch_run(eng[0], bat[0]));
         e->stats.last_resolver = eng[0]->stats.last_resolver;
+        b->ran = rc == SWP_OK;
         return rc;
     }
     std::vector<int32_t> shard(T), node(T);
     const int rc = swp_shard_run(eng.data(), bat.data(), (uint32_t)eng.size(), SWP_SHARD_NO_FOLD, shard.data(), node.data(), b->set_hist.data());
-    if (rc) return take_error(e, eng[0], rc);
+    if (rc) return take_error(e, eng[0], rc);   // (swp_shard_run leaves its message — whichever shard failed — on the first engine it was given)
+    b->ran = true;
     for (uint32_t i = 0; i < T; ++i)
         if (shard[i] >= 0) {
             b->set_shard[i] = (int32_t)who[(size_t)shard[i]];
@@ -502,6 +511,7 @@ void fill_union(ShardSet& S) {
 
 int schedule_groups(swp_engine* e, const swp_task_desc* groups, const uint32_t* sizes, uint32_t n_groups, int32_t* out_node, uint32_t* out_hist, uint32_t* out_att) {
     ShardSet& S = *e->set;
+    if (S.broken) return broken_error(e);
     swp_engine* U = S.uni;
     fill_union(S);
     int rc = out_att ? swp_schedule_groups_volumes(U, groups, sizes, n_groups, out_node, out_hist, out_att) : swp_schedule_groups(U, groups, sizes, n_groups, out_node, out_hist);
@@ -569,6 +579,7 @@ int state_restore(swp_engine* e) {
 int commit(swp_engine* e, const swp_placement* p, uint32_t n, int add) {
     ShardSet& S = *e->set;
     if (!p && n) return SWP_EINVAL;
+    if (S.broken) return broken_error(e);
     std::vector<std::vector<swp_placement>> per(S.sh.size());
     for (uint32_t i = 0; i < n; ++i) {
         uint32_t g = 0, l = 0;

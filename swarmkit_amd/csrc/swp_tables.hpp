@@ -186,6 +186,10 @@ class OrderedTasks {   // (a vector with tombstones: a tick takes the whole queu
         alive_.push_back(1);
         ++live_;
     }
+    const Value* find(const std::string& id) const {   // the queued document, nullptr: the id is not queued
+        const size_t at = probe(id, hash_id(id));
+        return at == NPOS ? nullptr : &items_[slot_[at]].second;
+    }
     void erase(const std::string& id) {
         const size_t at = probe(id, hash_id(id));
         if (at == NPOS) return;

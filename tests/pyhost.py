@@ -863,9 +863,9 @@ class PyHostScheduler:
             self._schedule_queue(queue, decisions)
         except (abi.SwpError, abi.Unsupported) as err:
             have = {d["ID"] for d in decisions}
-            for tid, _ in queue:
-                if tid not in have and tid in self.all_tasks:
-                    self._defer(tid, self.all_tasks[tid], err, decisions)
+            for tid, t in queue:   # (a task deleted while it was queued is not in all_tasks: its queued document goes back, as the normal path would have scheduled it)
+                if tid not in have:
+                    self._defer(tid, self.all_tasks.get(tid, t), err, decisions)
         return decisions
 
     def _schedule_queue(self, queue, decisions):

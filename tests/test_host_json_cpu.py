@@ -116,14 +116,41 @@ def test_string_escapes_survive_parse_and_dump(s, raw, value):
     assert s.node_info("n000")["Tasks"] == [value]
 
 
-@pytest.mark.parametrize("raw", [b"\xac", b"a\xc3", b"\xc0\xaf", b"\xe0\x80\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xf8\x88\x80\x80\x80", b"\x80x"])
-def test_strings_that_are_not_utf8_are_refused(s, raw):
+def _go_coerce(raw):
+    """Go's encoding/json on a string that is not UTF-8 (decode.go, unquote): utf8.DecodeRune — an ill-formed sequence is ONE byte long
+    and reads as U+FFFD."""
+    out, i = [], 0
+    while i < len(raw):
+        for n in (1, 2, 3, 4):
+            try:
+                out.append(raw[i:i + n].decode("utf-8"))
+                if len(out[-1]) == 1:
+                    i += n
+                    break
+                out.pop()
+            except UnicodeDecodeError:
+                pass
+        else:
+            out.append(chr(0xFFFD))
+            i += 1
+    return "".join(out)
+
+
+@pytest.mark.parametrize("raw", [b"\xac", b"a\xc3", b"\xc0\xaf", b"\xe0\x80\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xf8\x88\x80\x80\x80", b"\x80x", b"k\xe2\x82", b"\xe2\x82\xacok\xff"])
+def test_strings_that_are_not_utf8_are_coerced_as_go_does(s, raw):
     """What goes in comes out again in the decisions: a string that is not UTF-8 (a stray byte, a cut sequence, an overlong form, a
-    surrogate, something beyond U+10FFFF) is refused at the boundary instead of making the output something that is not JSON."""
+    surrogate, something beyond U+10FFFF) reads as Go's encoding/json reads it — U+FFFD for every ill-formed byte — so the event is
+    scheduled and the output stays JSON (until round 6 the document was refused: ADVICE r5)."""
+    s.create_node({"ID": "n000", "Status": {"State": 2}, "Spec": {"Availability": 0}, "Description": {"Resources": {"NanoCPUs": 10**10, "MemoryBytes": 2**34}}})
+    s.set_service("svc")
     text = b'{"ID":"' + raw + b'","ServiceID":"svc","DesiredState":512,"Status":{"State":64},"Spec":{}}'
     flag = C.c_int(0)
-    assert s.L.swp_sched_create_task(s.h, text, len(text), C.byref(flag)) == abi.SWP_EINVAL
-    assert b"UTF-8" in s.L.swp_sched_last_error(s.h)
+    assert s.L.swp_sched_create_task(s.h, text, len(text), C.byref(flag)) == 0 and flag.value == 1
+    want = _go_coerce(raw)
+    assert chr(0xFFFD) in want
+    out = s.tick()   # json.loads inside: text that is not JSON would raise
+    assert [d["ID"] for d in out] == [want]
+    assert s.node_info("n000")["Tasks"] == [want]
 
 
 def test_escaped_quotes_and_backslashes_are_written_back_escaped(s):

@@ -25,7 +25,7 @@ def test_host_layer_event_scripts_under_the_sanitizers():
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", SWP_TWIN_SEEDS="3", PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(HERE, "test_sched_volumes_cpu.py"),
                         os.path.join(HERE, "test_sched_cpu.py"), os.path.join(HERE, "test_host_json_cpu.py"),
-                        "-k", "volume or attachments or books or start or twin or refused or survives or decisions or escape or nesting or repeated"], capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(HERE))
+                        "-k", "volume or attachments or books or start or twin or refused or coerced or survives or decisions or escape or nesting or repeated"], capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
 
 
