@@ -166,7 +166,13 @@ typedef struct {
     uint32_t reserved;
     int64_t  value;      /* a node's count / a task's Discrete reservation; 1 <= value < 2^31 */
 } swp_generic;           /* 16 bytes */
-/* replaces the node's counts (n == 0: the node offers nothing). A kind listed twice: SWP_EINVAL. */
+/* replaces the node's counts (n == 0: the node offers nothing). A kind listed twice: SWP_EINVAL.
+ * ONE count per kind stands for the node's list only while the list holds the kind ONCE as a Discrete entry or as Named entries with
+ * distinct values. Reclaim + sanitize (resource_management.go:75-153) can leave a kind behind twice — a node's description changed
+ * under a running task that then went away —, and for such a list HasEnough (first entry) and ConsumeNodeResources (every entry) no
+ * longer amount to "count -= request": the count is right for the next request, not for a second one inside the same batch. The caller
+ * keeps tasks that reserve such a kind on its own path until the list is regular again (shim/go/swp_cgo.go irregularKinds, csrc/
+ * swp_generic.hpp irregular_kinds; swp_sched.cpp hands the whole tick back: every line Deferred). */
 int swp_node_set_generic(swp_engine*, uint32_t node, const swp_generic* counts, uint32_t n);
 int swp_node_get_generic(swp_engine*, uint32_t node, uint32_t kind, int64_t* count_out);
 

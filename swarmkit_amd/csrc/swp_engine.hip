@@ -1939,6 +1939,9 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         const char* env_cpt = getenv("SWP_R6_COMPACT");
         const bool cpt_ok = Wn <= R6_COMPACT_MAX_WORDS && r6_commit_lds_size(Wn, r6_block, r6_nrr, true) <= lds_budget && b->csi_set.empty() && !(env_cpt && atoi(env_cpt) == 0);   // (no smaller blocks for it)
         bool cpt = cpt_ok && ((env_cpt && atoi(env_cpt) != 0) || e->r6_compact_hint);
+        // (the index of the NEXT round built at the end of k_r6_commit_c instead of by a launch of its own: SWP_R6_COMPACT_FUSED=0 for A/B runs)
+        const char* env_cf = getenv("SWP_R6_COMPACT_FUSED");
+        const bool cpt_fused = !(env_cf && atoi(env_cf) == 0);
         bool cpt_ever = false;          // some chunk of this batch had rounds with an index
         // (round 6: a churn round's batch ENDS on tasks that aim at a level every node has — no index — and the hint used to say "the last
         // chunk had one": every batch then began with sixteen rounds without it. Starting with the previous batch's small BLOCK as well was
@@ -1951,7 +1954,7 @@ int batch_run_impl(swp_engine* e, swp_batch* b) {
         // (~1 us a task) has to be worth more: eight poor rounds, four probes
         const bool scan_fast = scan_ok && ra.n_rg == 0 && ra.csi_of == nullptr && scan_batched_fits(N, b->n_svc, b->n_sc);
         while (pos < end) {
-            ra.compact = cpt ? 1u : 0u;
+            ra.compact = cpt ? (cpt_fused ? 2u : 1u) : 0u;
             r = launch_r6_rounds(ra, chunk, st, e->device);
             if (r != hipSuccess) return e->fail(SWP_EHIP, "k_r6 round launch: %s", hipGetErrorString(r));
             HIPCHECK(e, hipMemcpyAsync(&hb, b->d_blk6.p, sizeof hb, hipMemcpyDeviceToHost, st));

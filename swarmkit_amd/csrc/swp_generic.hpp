@@ -11,6 +11,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -220,6 +221,29 @@ inline std::map<std::string, int64_t> counts(const List& avail) {
         const int64_t c = seen_named_first[kv.first] ? kv.second : first_discrete[kv.first];
         if (c > 0) out[kv.first] = c;
     }
+    return out;
+}
+
+// The kinds of a list that ONE count cannot stand for: (a) more than one entry of the kind and not all of them Named, (b) a Named
+// value listed twice. Reclaim + sanitize (resource_management.go:75-153) leave such lists behind when a node's description changed
+// under a running task and that task goes away — a second Discrete entry next to the first (the kind changed its type), or a task's
+// named values appended next to the same values of the fresh description. HasEnough (validate.go:24-52) reads the FIRST entry (or counts
+// the entries) while ConsumeNodeResources (helpers.go:87-111) subtracts a claim from EVERY Discrete entry of the kind and removes EVERY
+// entry with a claimed name: the list's answer to a second request on the same node is not "count - request" any more. counts() is
+// exact for ONE request; a device call that may place several tasks on the node is not: the host layer keeps a tick with tasks that
+// reserve such a kind on the Go path (swp_sched.cpp refuseIrregularGeneric).
+inline std::set<std::string> irregular_kinds(const List& avail) {
+    std::map<std::string, std::pair<int, int>> n;   // kind -> (entries, Discrete entries)
+    std::set<std::pair<std::string, std::string>> names;
+    std::set<std::string> out;
+    for (const Res& r : avail) {
+        auto& c = n[r.kind];
+        c.first += 1;
+        c.second += r.named ? 0 : 1;
+        if (r.named && !names.insert({r.kind, r.sval}).second) out.insert(r.kind);
+    }
+    for (const auto& kv : n)
+        if (kv.second.first > 1 && kv.second.second > 0) out.insert(kv.first);
     return out;
 }
 

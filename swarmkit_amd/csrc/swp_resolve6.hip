@@ -32,14 +32,20 @@ hipError_t launch_r6_rounds(const R6Args& a, uint32_t rounds, hipStream_t s, int
     hipError_t r;
     if (lp > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(cpt ? &k_r6_propose_c : &k_r6_propose), dev)) != hipSuccess) return r;
     if (lc > 48 * 1024 && (r = ensure_big_lds(reinterpret_cast<const void*>(cpt ? &k_r6_commit_c : a.csi_of ? &k_r6_commit_v : &k_r6_commit), dev)) != hipSuccess) return r;
+    // compact == 2: k_r6_commit_c builds the next round's index at its end; a launch of k_r6_compact only in front of the chunk's first round
+    // (the state may have moved since the last commit: a scan stretch, a rebuild). Task-rows mode builds the rows the index pass reads
+    // at the START of a round: there the index keeps its own launch.
+    const bool fused = cpt && a.compact == 2 && !a.task_rows;
+    R6Args ac = a;
+    if (cpt && !fused) ac.compact = 1;
     for (uint32_t i = 0; i < rounds; ++i) {
         if (a.task_rows) hipLaunchKernelGGL(k_r6_taskrows, dim3((a.n_words + 3) / 4, (a.block + 63) / 64), dim3(256), (size_t)a.block * 16, s, a);
         if (a.csi_of) hipLaunchKernelGGL(k_r6_volrows, dim3((a.n_words + 255) / 256, a.block), dim3(256), 0, s, a);   // (batches with cluster mounts only)
         if (cpt) {   // rounds with a compact index of the level their first task aims at (run_blocks decides when)
-            hipLaunchKernelGGL(k_r6_compact, dim3(1), dim3(1024), 256, s, a);
-            if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small_c, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
-            else hipLaunchKernelGGL(k_r6_propose_c, dim3(a.block), dim3(64 * R6_PW), lp, s, a);
-            hipLaunchKernelGGL(k_r6_commit_c, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, a);
+            if (!fused || i == 0) hipLaunchKernelGGL(k_r6_compact, dim3(1), dim3(1024), 256, s, ac);
+            if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small_c, dim3(a.block), dim3(64 * R6_PW), lp, s, ac);
+            else hipLaunchKernelGGL(k_r6_propose_c, dim3(a.block), dim3(64 * R6_PW), lp, s, ac);
+            hipLaunchKernelGGL(k_r6_commit_c, dim3(1), dim3(R6_COMMIT_THREADS), lc, s, ac);
             continue;
         }
         if (a.n_words <= R6_SMALL_WORDS) hipLaunchKernelGGL(k_r6_propose_small, dim3(a.block), dim3(64 * R6_PW), lp, s, a);   // (LDS of 8 chunks: never beyond 48 KB)

@@ -139,7 +139,8 @@ struct R6Args {
     // compact positions; a task whose minimum level is that one lists half-words of POSITIONS (dense: 32 candidates each), every other task plain half-words behind
     // them (+ 2 * ceil(csize / 64)). One level per list, so a list lives in one of the two address ranges; a node has one address per round,
     // so strikes meet; numbering in node order keeps every list in node order. The applying threads translate a picked address back.
-    u32 compact;             // != 0: the rounds launch k_r6_compact and the kernels honour Blk6.csize
+    u32 compact;             // != 0: the rounds launch k_r6_compact and the kernels honour Blk6.csize; 2: k_r6_commit_c builds the NEXT round's index itself
+                             // at its end (launch_r6_rounds: one k_r6_compact in front of a chunk's first round only)
     const u64* cbase;        // [n_words] the nodes an index is drawn from: READY && valid — every static class row is a subset, so every task's
                              // candidates are (a drained node keeps its place in `valid` and its level, which is usually the lowest)
     u64* cmask;              // [n_words] the nodes of the compact index
@@ -307,13 +308,15 @@ WV_KERNEL(256) void k_r6_volrows(R6Args a) {
 // lowest level among the ready nodes, where nodes that nobody can use (no room, the wrong platform) sit for ever. The index holds ALL
 // ready nodes on that level (their running count is a word's first position, crank; the nodes themselves go to cidx). More than a
 // quarter of the node set on it, or no plain candidate: no index this round.
-WV_KERNEL(1024) void k_r6_compact(R6Args a) {
+// (FUSED: the same pass at the END of k_r6_commit_c, for the round that follows — R6Args.compact == 2: the launch, its ramp and its drain
+// are a fifth of a churn round. The rows it reads were changed by this workgroup's atomics a moment ago, so every load of a row that
+// moves goes past the vector L1 (g_fresh*), and Blk6.maxrel — which the kernel's scalar loads may have cached with the control block —
+// is read the same way. `t`: the first task of the coming round; `red`: 32 words of LDS nobody else uses any more.)
+template <bool FUSED> WV_DEV void r6_compact_body(const R6Args& a, u32 t, u32* red) {
     const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave();
-    const u32 t = wv::uload(&a.blk->pos);
-    if (t >= wv::uload(&a.blk->end) || wv::uload(&a.blk->error) != ERR_NONE) return;
-    u32* red = reinterpret_cast<u32*>(wv::lds());   // [16] a wave's minimum, [16] a wave's count
     const u32 Wn = a.n_words;
-    const int nb = 32 - wv::clz32(wv::uload(&a.blk->maxrel));
+    auto ld = [](const u64* q) { return FUSED ? wv::g_fresh64(q) : *q; };
+    const int nb = 32 - wv::clz32(FUSED ? wv::readfirstlane(wv::g_fresh32(&a.blk->maxrel)) : wv::uload(&a.blk->maxrel));
     const RTask* rt = a.rt + t;
     const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc), scid = wv::uload(&rt->sc), pset = wv::uload(&rt->pset);
     const u64* scrow = a.sc + (size_t)scid * Wn;
@@ -335,14 +338,14 @@ WV_KERNEL(1024) void k_r6_compact(R6Args a) {
     const u64* vrow = ck != R6_NONE ? a.vrows + (size_t)ck * Wn : nullptr;
     u32 best = R6_NONE;
     for (u32 w = tid; w < Wn; w += 1024) {
-        u64 m = scrow[w] & ~xrow[w];
-        if (res) m &= rc[w] & rm[w];
-        for (u32 g = g0; g < g1; ++g) m &= a.rg[(size_t)wv::uload(a.gs_row + g) * Wn + w];
+        u64 m = scrow[w] & ~ld(xrow + w);
+        if (res) m &= ld(rc + w) & ld(rm + w);
+        for (u32 g = g0; g < g1; ++g) m &= ld(a.rg + (size_t)wv::uload(a.gs_row + g) * Wn + w);
         if (vrow) m &= vrow[w];
-        for (u32 p = p0; p < p1; ++p) m &= ~a.portmap[(size_t)wv::uload(a.pset_ids + p) * Wn + w];
+        for (u32 p = p0; p < p1; ++p) m &= ~ld(a.portmap + (size_t)wv::uload(a.pset_ids + p) * Wn + w);
         u32 rel = 0;
         for (int b = nb - 1; b >= 0; --b) {
-            const u64 c = m & ~a.planes[(size_t)b * Wn + w];
+            const u64 c = m & ~ld(a.planes + (size_t)b * Wn + w);
             if (c) m = c;
             else if (m) rel |= 1u << b;
         }
@@ -358,7 +361,7 @@ WV_KERNEL(1024) void k_r6_compact(R6Args a) {
         const u32 w = w0 + tid;
         u64 c = (w < Wn && gl != R6_NONE) ? a.cbase[w] : 0ull;   // the ready nodes whose level IS gl
         for (int b = 0; b < nb && c; ++b) {
-            const u64 pl = a.planes[(size_t)b * Wn + w];
+            const u64 pl = ld(a.planes + (size_t)b * Wn + w);
             c &= ((gl >> b) & 1u) ? pl : ~pl;
         }
         const u32 pc = (u32)wv::popc64(c);
@@ -387,8 +390,8 @@ WV_KERNEL(1024) void k_r6_compact(R6Args a) {
     const bool on = running != 0 && running <= r6_compact_cap(Wn);
     if (on)
         for (u32 w = tid; w < Wn; w += 1024) {
-            u64 c = a.cmask[w];
-            u32 at = a.crank[w];
+            u64 c = FUSED ? wv::g_fresh64(a.cmask + w) : a.cmask[w];
+            u32 at = FUSED ? wv::g_fresh32(a.crank + w) : a.crank[w];
             while (c) {
                 a.cidx[at++] = w * 64u + (u32)wv::ffs64(c);
                 c &= c - 1ull;
@@ -397,8 +400,12 @@ WV_KERNEL(1024) void k_r6_compact(R6Args a) {
     if (tid == 0) {
         a.blk->csize = on ? running : 0u;
         a.blk->clevel = gl;
-        if (on) a.blk->crounds += 1;
     }
+}
+WV_KERNEL(1024) void k_r6_compact(R6Args a) {
+    const u32 t = wv::uload(&a.blk->pos);
+    if (t >= wv::uload(&a.blk->end) || wv::uload(&a.blk->error) != ERR_NONE) return;
+    r6_compact_body<false>(a, t, reinterpret_cast<u32*>(wv::lds()));   // [16] a wave's minimum, [16] a wave's count
 }
 
 // ---- propose: one workgroup of R6_PW waves per task of the block -----------------------------------------------------------
@@ -1025,6 +1032,7 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
             wv::lds_publish32(sh + 3, acc);   // (the first task from its exception list leaves the loop before the publish above)
             wv::lds_publish32(sh + 4, 1u);
             a.blk->rounds += 1;
+            if (CPT && VW) a.blk->crounds += 1;   // a round with a compact index
             if (why == 1) a.blk->cut_exhausted += 1;
             if (why == 2) a.blk->cut_exception += 1;
             if (why == 3) a.blk->cut_uncounted += 1;
@@ -1146,6 +1154,16 @@ template <bool CPT, bool CSI, bool R7 = false> WV_DEV void r6_commit_t(const R6A
         }
     }
     if (prof && wave_ == 1 && lane == 0) a.blk->cyc[3] += (u32)((wv::clock64() - t2) >> 6);   // the first group's applying wave: waiting for it + applying
+    if constexpr (CPT && !R7) {
+        if (a.compact == 2u) {   // the next round's compact index, here instead of in a launch of its own (r6_compact_body)
+            wv::wait_vm();       // this wave's atomics on the rows have arrived ...
+            wv::barrier();       // ... and every other wave's; nobody reads the TK row any more (the body's 32 words lie on it)
+            const u32 np = pos + sh[0];
+            const bool go = np < end && wv::readfirstlane(wv::g_fresh32(&a.blk->error)) == ERR_NONE;
+            wv::barrier();       // (sh[0] is read before the body's first barrier lets anybody write LDS)
+            if (go) r6_compact_body<true>(a, np, reinterpret_cast<u32*>(wv::lds()));
+        }
+    }
 }
 WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit(R6Args a) { r6_commit_t<false, false>(a); }
 WV_KERNEL(R6_COMMIT_THREADS) void k_r6_commit_c(R6Args a) { r6_commit_t<true, false>(a); }   // ... with a compact index (launched behind k_r6_compact only)

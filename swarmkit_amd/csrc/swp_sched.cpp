@@ -528,6 +528,7 @@ class Scheduler {
         if (it == nodes_.end()) return;
         const uint32_t idx = it->second.idx;
         nodes_.erase(it);
+        irregularGeneric_.erase(nid);
         repinVolumes(nid);   // (before the index is free again: no usage number may name it)
         ck(swp_node_remove(e_, idx), "swp_node_remove");
         // the engine hands the index to the next node that is new to it: nothing here may remember it as this node's
@@ -1150,6 +1151,7 @@ class Scheduler {
         }
         prof_.lap(0);
         try {
+            refuseIrregularGeneric(queue);
             pushFailures(sids);
             prof_.lap(1);
         } catch (const Fail& f) {   // nothing was scheduled: the whole queue stays queued
@@ -1475,6 +1477,7 @@ class Scheduler {
     std::vector<NodeInfo*> node_by_idx_;                                   // engine node index -> its NodeInfo (place(): no look-up by id)
     std::unordered_map<std::string, std::optional<uint64_t>> services_;   // store.GetService: existence + SpecVersion
     OrderedTasks unassignedTasks_;                                         // Scheduler.unassignedTasks
+    std::map<std::string, std::set<std::string>> irregularGeneric_;          // node id -> generic kinds its available list holds more than once, not all Named (pushGeneric)
     std::vector<std::string> deletedWhileQueued_;                           // ids deleteTask met in the queue since the last tick (tick's catch-all path)
     OrderedTasks pendingPreassignedTasks_;                                 // Scheduler.pendingPreassignedTasks
     // the `old` half of every decision of the last tick / processPreassignedTasks (schedulingDecision.old, scheduler.go:53-56),
@@ -1702,6 +1705,28 @@ class Scheduler {
             items.push_back({intern(SWP_SPACE_GENERIC_KIND, kv.first), 0u, kv.second});
         }
         ck(swp_node_set_generic(e_, ni.idx, items.data(), (uint32_t)items.size()), "swp_node_set_generic");
+        // (a list one count per kind cannot stand for — swp_generic.hpp irregular_kinds: tick() looks at this before it schedules)
+        const std::string& nid = as_str(ni.node.get("ID"));
+        std::set<std::string> irr = generic::irregular_kinds(ni.availGeneric);
+        if (irr.empty()) irregularGeneric_.erase(nid);
+        else irregularGeneric_[nid] = std::move(irr);
+    }
+    // A node lists a generic kind in a way the engine's one count per kind cannot stand for, and a queued task reserves that kind: the
+    // engine's arithmetic inside a device call (count -= request) would not be the reference's for a second task on that node. Such a
+    // tick stays on the Go path as a whole — a task left out would change the others' answers. Throws; tick() defers the queue.
+    void refuseIrregularGeneric(const std::vector<QItem>& queue) {
+        if (irregularGeneric_.empty()) return;
+        std::vector<char> seen(templates_.size(), 0);
+        for (const QItem& it : queue) {
+            if (it.tmpl >= templates_.size() || seen[it.tmpl]) continue;
+            seen[it.tmpl] = 1;
+            const Template& tm = templates_[it.tmpl];
+            if (!tm.wants_generic) continue;
+            for (const generic::Res& r : generic::decode(at(&tm.exemplar, "Spec", "Resources", "Reservations", "Generic")))
+                for (const auto& kv : irregularGeneric_)
+                    if (kv.second.count(r.kind))
+                        fail(SWP_EUNSUPPORTED, ("node " + kv.first + " lists the generic kind '" + r.kind + "' more than once (its type changed under a running task): a tick with tasks that reserve it stays on the Go path").c_str());
+        }
     }
     void commit(const NodeInfo& ni, const Value& t, bool counted, bool with_resources, bool add) {
         swp_placement p;

@@ -26,12 +26,13 @@ int main(int argc, char** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s seed N T S block order features(0..3) [v] [s]\n", argv[0]); return 2; }
     const u32 seed = atoi(argv[1]), N = atoi(argv[2]), T = atoi(argv[3]), S = atoi(argv[4]), B = atoi(argv[5]);
     const int order = atoi(argv[6]), feat = atoi(argv[7]);
-    bool verbose = false, split = false, task_rows = false, twins = true, compact = false;
+    bool verbose = false, split = false, task_rows = false, twins = true, compact = false, fused = false;
     for (int i = 8; i < argc; ++i) {
         if (argv[i][0] == 'v') verbose = true;
         if (argv[i][0] == 's') split = true;
         if (argv[i][0] == 't') task_rows = true;   // rows per task of the block, rebuilt every round, instead of demand-class rows
         if (argv[i][0] == 'c') compact = true;     // a compact index of the lowest level's nodes in front of every round (k_r6_compact)
+        if (argv[i][0] == 'f') compact = fused = true;   // ... built at the END of k_r6_commit_c for the next round (R6Args.compact == 2); k_r6_compact itself only in front of every fifth round (a chunk's first)
         if (argv[i][0] == 'n') twins = false;      // lists start at the level's first candidate (R6Args.tmpl == nullptr: what the shard drivers run)
     }
     Problem p = make_problem(seed, N, T, S, order, feat);
@@ -123,7 +124,7 @@ int main(int argc, char** argv) {
     a.tmpl = twins ? tmpl.data() : nullptr;
     std::vector<u64> cmask(p.Wn, 0xDDDDDDDDDDDDDDDDull);
     std::vector<u32> crank(p.Wn, 0xDDDDDDDDu), cidx(r6_compact_cap(p.Wn), 0xDDDDDDDDu);
-    a.compact = compact ? 1u : 0u;
+    a.compact = compact ? (fused && !task_rows ? 2u : 1u) : 0u;
     a.cbase = p.valid.data();   // (the harness has no drained nodes: every valid node is ready)
     a.cmask = cmask.data();
     a.crank = crank.data();
@@ -150,7 +151,7 @@ int main(int argc, char** argv) {
                 }
             emu::blockidx_y() = 0;
             if (compact) {
-                grid(1, 1024, 256, [a]() { k_r6_compact(a); });
+                if (a.compact != 2u || rounds % 5 == 0 || blk.pos == j0) grid(1, 1024, 256, [a]() { k_r6_compact(a); });
                 // the index against its definition: the ready nodes on ONE level, in node order, no more than a quarter of the node set;
                 // whether that level is the first task's is checked by the outcome (a wrong level only makes the index useless)
                 std::vector<u32> want;

@@ -152,6 +152,21 @@ def reclaim(avail, assigned, node_res):
     return sanitize(node_res, avail)
 
 
+def irregular_kinds(avail):
+    """The kinds ONE count cannot stand for (csrc/swp_generic.hpp irregular_kinds): more than one entry of the kind and not all of them
+    Named, or a Named value listed twice — what Reclaim + sanitize leave behind when a node's description changed under a running task."""
+    n, names, out = {}, set(), set()
+    for named, kind, val in avail:
+        c = n.setdefault(kind, [0, 0])
+        c[0] += 1
+        c[1] += 0 if named else 1
+        if named:
+            if (kind, val) in names:
+                out.add(kind)
+            names.add((kind, val))
+    return out | {k for k, c in n.items() if c[0] > 1 and c[1] > 0}
+
+
 def counts(avail):
     """kind -> what HasEnough (validate.go:24-52) compares a request with: the first entry of the kind decides — Discrete: its
     value, Named: how many entries the kind has. Kinds whose count is <= 0 are left out. Sorted by kind."""

@@ -125,6 +125,7 @@ class PyHostScheduler:
         self.pending_preassigned = {}
         self.last_decisions = {}   # task id -> (old task, preassigned?) of the last tick / process_preassigned (reject_decision)
         self.pushed_failures = {}  # (node index, service, spec version) -> count the engine holds
+        self.irregular_generic = {}  # node id -> generic kinds its available list holds more than once, not all Named (_push_generic)
         self.last_error = ""
         self.preassigned = set()
         self.all_tasks = {}
@@ -234,6 +235,24 @@ class PyHostScheduler:
                 raise Unsupported("a generic resource count of 2^31 or more stays on the Go path")
             items.append((self.e.intern(abi.SPACE_GENERIC_KIND, kind), c))
         self.e.node_set_generic(ent["idx"], items)
+        irr = gres.irregular_kinds(ent["generic"])   # (a list one count per kind cannot stand for: tick() looks at this before it schedules)
+        nid = ent["doc"].get("ID", "")
+        if irr:
+            self.irregular_generic[nid] = irr
+        else:
+            self.irregular_generic.pop(nid, None)
+
+    def _refuse_irregular_generic(self, queue):
+        """csrc/swp_sched.cpp refuseIrregularGeneric: a queued task reserves a kind some node lists more than once — the whole tick stays
+        on the Go path."""
+        if not self.irregular_generic:
+            return
+        for _, t in queue:
+            r, _ = gres.decode(_get(t, "Spec", "Resources", "Reservations", "Generic"))
+            for _, kind, _ in r:
+                for nid in sorted(self.irregular_generic):
+                    if kind in self.irregular_generic[nid]:
+                        raise abi.Unsupported("node %s lists the generic kind '%s' more than once (its type changed under a running task): a tick with tasks that reserve it stays on the Go path" % (nid, kind))
 
     @staticmethod
     def _generic_reservations(t):
@@ -257,6 +276,7 @@ class PyHostScheduler:
     def delete_node(self, nid):
         """nodeSet.remove, nodeset.go:46-48."""
         ent = self.nodes.pop(nid, None)
+        self.irregular_generic.pop(nid, None)
         if ent is not None:
             self.e.node_remove(ent["idx"])
             # the engine hands the index to the next node that is new to it: nothing here may remember it as this node's
@@ -852,6 +872,7 @@ class PyHostScheduler:
         if not queue:
             return decisions
         try:
+            self._refuse_irregular_generic(queue)
             self._push_failures({t.get("ServiceID", "") for _, t in queue})
         except (abi.SwpError, abi.Unsupported) as err:   # nothing was scheduled: the whole queue stays queued
             for tid, t in queue:

@@ -86,6 +86,16 @@ COMPACT = [
     ((50, 10000, 3000, 20, 512, 1, 0, "c"), "5"),     # twins: the offset counts compact positions
     ((3, 1000, 2500, 40, 64, 2, 2, "c"), None),       # whatever level mode the seed draws
     ((21, 4500, 600, 200, 1024, 0, 1, "c"), None),    # the largest block
+    # "f": the next round's index built at the END of k_r6_commit_c (R6Args.compact == 2); k_r6_compact itself only in front of every fifth round
+    ((12, 5924, 1856, 377, 512, 0, 0, "f"), "5"),
+    ((79, 66000, 1500, 200, 512, 0, 0, "f"), "3"),
+    ((2, 700, 1500, 30, 64, 0, 1, "tf"), "5"),        # task-rows mode: the index keeps its own launch
+    ((4, 5000, 1000, 300, 256, 0, 2, "sf"), "3"),
+    ((8, 885, 1500, 125, 64, 2, 3, "f"), "5"),
+    ((50, 10000, 3000, 20, 512, 1, 0, "f"), "5"),
+    ((3, 1000, 2500, 40, 64, 2, 2, "f"), None),
+    ((21, 4500, 600, 200, 1024, 0, 1, "f"), None),
+    ((7, 63, 400, 9, 32, 0, 0, "f"), "5"),            # one node word: the body's 32 words of LDS are wider than the TK row
 ]
 
 

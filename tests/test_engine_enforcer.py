@@ -80,7 +80,7 @@ CONS = ["node.labels.zone==a", "node.labels.zone!=b", "node.role==manager", "nod
         "bogus expr", "node.labels.zone==a"]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_FIRST", "0")), int(os.environ.get("SWP_FUZZ_FIRST", "0")) + int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
 def test_random_clusters(seed):
     rng = random.Random(0xE4F0 + seed)
     nodes = []

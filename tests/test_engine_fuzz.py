@@ -81,7 +81,7 @@ def service_spec(rng):
     return t
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "64"))))   # SWP_FUZZ_SEEDS=1000 for a soak
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_FIRST", "0")), int(os.environ.get("SWP_FUZZ_FIRST", "0")) + int(os.environ.get("SWP_FUZZ_SEEDS", "64"))))   # SWP_FUZZ_SEEDS=1000 for a soak
 def test_random_event_scripts(seed):
     rng = random.Random(0xC0FFEE + seed)
     rng.choice([0, 0, 7, 64, 300])   # (the scan window of rounds 1-2: the draw stays so that the seeds keep their scripts)

@@ -48,7 +48,7 @@ def service_spec(rng):
     return {"Spec": spec}
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_FIRST", "0")), int(os.environ.get("SWP_FUZZ_FIRST", "0")) + int(os.environ.get("SWP_FUZZ_SEEDS", "24"))))
 def test_generic_event_scripts(seed):
     rng = random.Random(0x6E0E + seed)
     o, e = orc.Oracle(), swhost.HostScheduler()
@@ -78,6 +78,13 @@ def test_generic_event_scripts(seed):
         de_raw = e.tick()
         do = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in o.tick())
         de = sorted((d["ID"], d["NodeID"], d["Err"], d["State"]) for d in de_raw)
+        if any(d.get("Deferred") and "more than once" in d["Err"] for d in de_raw):
+            # A kind changed its type on a node under a running task and that task went away: sanitize left the kind in the node's list
+            # twice, which one count per kind cannot stand for (csrc/swp_generic.hpp irregular_kinds). The host layer hands such a tick
+            # to the Go path as a whole — every line Deferred, nothing placed — instead of answering something else than the reference
+            # (round 6's 20 000-seed soak: 9 of 5 800 seeds reach this; until then the engine placed one task too few or too many).
+            assert all(d.get("Deferred") and d["NodeID"] == "" for d in de_raw), seed
+            pytest.skip("seed %d reaches a node list the engine hands to the Go path (a generic kind listed twice)" % seed)
         assert do == de, (seed, [(a, b) for a, b in zip(do, de) if a != b][:5])
         for d in de_raw:
             if d["NodeID"] and d["State"] >= orc.ASSIGNED:

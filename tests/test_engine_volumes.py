@@ -201,7 +201,7 @@ def test_an_update_of_a_known_volume_keeps_its_first_object_and_joins_the_new_gr
     b.check_volumes()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_FIRST", "0")), int(os.environ.get("SWP_FUZZ_FIRST", "0")) + int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
 def test_random_clusters_with_volumes(seed):
     """Nodes with CSI topologies, volumes of every access mode in groups, tasks with one to three cluster mounts (named, grouped, read-only)
     next to plain tasks, several ticks with tasks going away in between: every decision, attachment and reservation as the oracle's."""
@@ -284,7 +284,7 @@ def test_a_group_whose_tasks_share_a_volume_that_cannot_leave_its_node():
     assert {x[3] for x in d if not x[1]} == {"no suitable node (cannot fulfill requested CSI volume mounts on 3 nodes)"}
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_FIRST", "0")), int(os.environ.get("SWP_FUZZ_FIRST", "0")) + int(os.environ.get("SWP_FUZZ_SEEDS", "12"))))
 def test_random_task_groups_with_volumes(seed):
     """Services with a spec version (task groups, scheduler.go:442-459) whose specs carry cluster mounts, next to groups without and one-off
     tasks: tree() with the VolumesFilter, the fill loop's re-checks against the volumes as the group's own placements leave them."""

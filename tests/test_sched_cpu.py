@@ -498,3 +498,45 @@ def test_commit_plan_groups_by_node_and_a_stale_node_is_rolled_back_once():
         assert set(stale["Tasks"]) <= d2
         logs.append((plan, log))
     assert logs[0] == logs[1]
+
+
+def test_a_generic_kind_listed_twice_keeps_the_tick_on_the_go_path():
+    """A node's generic kind changes its type (Named -> Discrete) under a running task that holds a named value; when that task goes
+    away, Reclaim + sanitize (resource_management.go:75-153) leave the kind in the node's available list TWICE. HasEnough reads the first
+    entry, a claim is subtracted from every entry: one count per kind cannot stand for that list inside a device call, so a tick with a
+    task that reserves the kind is handed back whole (every line Deferred, nothing placed) — and ticks go on as before once the list is
+    regular again. (Found by the 20 000-seed soak of round 6.)"""
+    GIB = 1 << 30
+    logs = []
+    for s in _both_hosts():
+        def node(gen):
+            return {"ID": "n0", "Status": {"State": 2}, "Spec": {"Availability": 0},
+                    "Description": {"Resources": {"NanoCPUs": 16 * 10**9, "MemoryBytes": 64 * GIB, "Generic": gen}}}
+        s.create_node(node([{"Named": {"Kind": "ssd", "Value": "ssd0"}}]))
+        for sid in ("want-ssd", "plain"):
+            s.set_service(sid)
+        spec = {"Spec": {"Resources": {"Reservations": {"Generic": [{"Discrete": {"Kind": "ssd", "Value": 1}}]}}}}
+        # a task that holds the named value runs on the node
+        s.create_task(dict(_task("held", "want-ssd", NodeID="n0", AssignedGenericResources=[{"Named": {"Kind": "ssd", "Value": "ssd0"}}]), Status={"State": 512}, **spec))
+        s.update_node(node([{"Discrete": {"Kind": "ssd", "Value": 2}}]))   # the kind changes its type: the named assignment is ignored (helpers.go remove())
+        s.create_task(dict(_task("a", "want-ssd"), **spec))
+        d1 = s.tick()
+        assert [(d["ID"], d["NodeID"], bool(d.get("Deferred"))) for d in d1] == [("a", "n0", False)]
+        placed_a = [d for d in d1 if d["ID"] == "a"][0]
+        s.delete_task(dict(_task("held", "want-ssd", NodeID="n0", AssignedGenericResources=[{"Named": {"Kind": "ssd", "Value": "ssd0"}}]), Status={"State": 512}, **spec))
+        gen = s.node_info("n0")["AvailableResources"]["Generic"]
+        assert [g["Discrete"]["Kind"] for g in gen if "Discrete" in g].count("ssd") == 2, gen   # the list the reference ends up with
+        s.create_task(dict(_task("b", "want-ssd"), **spec))
+        s.create_task(_task("p", "plain"))
+        d2 = s.tick()
+        by = {d["ID"]: d for d in d2}
+        assert set(by) == {"b", "p"} and all(d.get("Deferred") and d["NodeID"] == "" for d in d2), d2
+        assert "more than once" in by["b"]["Err"] and "ssd" in by["b"]["Err"]
+        d3 = s.tick()                                                   # still so: the tasks stay queued, nothing is lost
+        assert {d["ID"] for d in d3} == {"b", "p"} and all(d.get("Deferred") for d in d3)
+        s.update_node(node([{"Discrete": {"Kind": "ssd", "Value": 2}}]))   # createOrUpdateNode rebuilds the list from the description: regular again
+        s.create_task(dict(_task("c", "want-ssd"), **spec))
+        d4 = s.tick()
+        assert {d["ID"] for d in d4} == {"b", "p", "c"} and not any(d.get("Deferred") for d in d4), d4
+        logs.append((d1, d2, d3, d4, fakelib.take_log(s.e), placed_a["NodeID"]))
+    assert logs[0] == logs[1]   # the twins agree call by call

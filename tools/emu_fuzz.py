@@ -45,7 +45,7 @@ def draw(rng, which):
         n = pick_n(rng, rng.choice([2000, 8000, 70000]))
         t = rng.randrange(1, 2500 if n < 20000 else 500)
         s = rng.randrange(1, max(min(t, 400), 2))
-        opts = "".join(o for o in "stcn" if rng.random() < 0.25)
+        opts = "".join(o for o in "stcnf" if rng.random() < 0.25)
         return [seed, n, t, s, rng.choice([1, 8, 32, 64, 128, 256, 512, 1024]), rng.randrange(3), rng.randrange(4)] + ([opts] if opts else [])
     if which == "resolve7":
         n = pick_n(rng, rng.choice([1500, 6000]))
