@@ -316,9 +316,10 @@ template <bool FUSED> WV_DEV void r6_compact_body(const R6Args& a, u32 t, u32* r
     const u32 tid = wv::tid(), lane = wv::lane(), wave = wv::wave();
     const u32 Wn = a.n_words;
     auto ld = [](const u64* q) { return FUSED ? wv::g_fresh64(q) : *q; };
-    const int nb = 32 - wv::clz32(FUSED ? wv::readfirstlane(wv::g_fresh32(&a.blk->maxrel)) : wv::uload(&a.blk->maxrel));
+    const u32 maxrel_v = FUSED ? wv::g_fresh32(&a.blk->maxrel) : 0u;   // (requested with the task's record, not in front of it)
     const RTask* rt = a.rt + t;
     const u32 flags = wv::uload(&rt->flags), svc = wv::uload(&rt->svc), scid = wv::uload(&rt->sc), pset = wv::uload(&rt->pset);
+    const int nb = 32 - wv::clz32(FUSED ? wv::readfirstlane(maxrel_v) : wv::uload(&a.blk->maxrel));
     const u64* scrow = a.sc + (size_t)scid * Wn;
     const u64* xrow = a.X + (size_t)svc * a.xs;
     const bool res = (flags & RT_RES) != 0;
@@ -356,7 +357,8 @@ template <bool FUSED> WV_DEV void r6_compact_body(const R6Args& a, u32 t, u32* r
     wv::barrier();
     u32 gl = R6_NONE;
     for (u32 v = 0; v < 16; ++v) gl = min(gl, red[v]);
-    u32 running = 0;
+    u32 running = 0, at0 = 0;
+    u64 c0 = 0;   // this thread's first word: its nodes of the level and their first position
     for (u32 w0 = 0; w0 < Wn; w0 += 1024) {
         const u32 w = w0 + tid;
         u64 c = (w < Wn && gl != R6_NONE) ? a.cbase[w] : 0ull;   // the ready nodes whose level IS gl
@@ -382,16 +384,17 @@ template <bool FUSED> WV_DEV void r6_compact_body(const R6Args& a, u32 t, u32* r
             all += x;
         }
         if (w < Wn) {
-            a.cmask[w] = c;   // (read back below by the thread that wrote it)
+            a.cmask[w] = c;   // (the words beyond a thread's first are read back below by the thread that wrote them)
             a.crank[w] = running + off + ex;
         }
+        if (w0 == 0) { c0 = c; at0 = off + ex; }
         running += all;
     }
     const bool on = running != 0 && running <= r6_compact_cap(Wn);
     if (on)
         for (u32 w = tid; w < Wn; w += 1024) {
-            u64 c = FUSED ? wv::g_fresh64(a.cmask + w) : a.cmask[w];
-            u32 at = FUSED ? wv::g_fresh32(a.crank + w) : a.crank[w];
+            u64 c = w == tid ? c0 : FUSED ? wv::g_fresh64(a.cmask + w) : a.cmask[w];   // (a thread's first word: from its registers, no round trip)
+            u32 at = w == tid ? at0 : FUSED ? wv::g_fresh32(a.crank + w) : a.crank[w];
             while (c) {
                 a.cidx[at++] = w * 64u + (u32)wv::ffs64(c);
                 c &= c - 1ull;
