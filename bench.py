@@ -377,7 +377,7 @@ def run_churn(args, ranks, wl, eng, descs, ranges):
     alg = (replaced / R) * wl.N * row_b + (replaced / R) * TASK_B
     n_shards = world if by_rank else (eng.shards or 1)
     churn_traffic = (profile_traffic(["k_r7_propose", "k_r7_propose_small", "k_r7_commit"], run="churn_shards4") if n_shards > 1
-                     else profile_traffic(["k_r6_compact", "k_r6_propose_small_c", "k_r6_commit_c"], run="churn"))
+                     else profile_traffic(["k_r6_propose_small_c", "k_r6_commit_c"], run="churn"))   # (the compact index of the next round is built at the end of k_r6_commit_c since round 6: its bytes are that kernel's)
     if by_rank:
         par, exch = "node-shard", "one engine per rank over its node range; per round of the resolver an ncclAllGather of the block's proposals (swp_shard_run_rank); drains and swp_commit(remove) on the owner rank"
     elif n_shards > 1:

@@ -48,6 +48,7 @@ bj churn --mode churn
 bj churn_shards4 --mode churn --shards 4 --no-cpu-baseline
 bj dense --tasks 100000 --nodes 1000 --services 10
 bj cfg1_10svc --no-cpu-baseline --tasks 1000 --nodes 10 --services 10
+bj cfg2 --workload cfg2
 bj cfg3_major --no-cpu-baseline --order major
 bj cfg4_1M_100k --no-cpu-baseline --workload cfg4
 bj cfg4_200k_40k --no-cpu-baseline --workload cfg4 --tasks 200000 --nodes 40000
@@ -55,7 +56,7 @@ bj cfg4_200k_40k_shards4 --no-cpu-baseline --workload cfg4 --tasks 200000 --node
 bj cfg4_200k_40k_shards8 --no-cpu-baseline --workload cfg4 --tasks 200000 --nodes 40000 --shards 8
 bj cfg3_200k_100k --no-cpu-baseline --tasks 200000 --nodes 100000
 SWP_BENCH_RANK_PATH=1 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode grouped --parallelism node-shard > "$OUT/${TAG}_bench_grouped_rankpath.json" 2> "$OUT/bench_grouped_rankpath.err"
-for f in cfg3 grouped grouped_rankpath churn churn_shards4 dense cfg1_10svc cfg3_major cfg4_1M_100k cfg4_200k_40k cfg4_200k_40k_shards4 cfg4_200k_40k_shards8 cfg3_200k_100k; do
+for f in cfg3 grouped grouped_rankpath churn churn_shards4 dense cfg1_10svc cfg2 cfg3_major cfg4_1M_100k cfg4_200k_40k cfg4_200k_40k_shards4 cfg4_200k_40k_shards8 cfg3_200k_100k; do
 python - <<PY
 import json
 try:
