@@ -48,9 +48,14 @@ def service_spec(rng):
     return {"Spec": spec}
 
 
+# with_groups: some of the services carry a SpecVersion — their tasks are task GROUPS (scheduler.go:449-461): k_groups2 claims the generic
+# reservations in the kernel (its own copy of Claim's arithmetic), next to one-off services in the same ticks. Drawn from a generator of its
+# own, so the scripts of the plain variant are the ones they always were.
+@pytest.mark.parametrize("with_groups", [False, True], ids=["oneoff", "groups"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SWP_FUZZ_FIRST", "0")), int(os.environ.get("SWP_FUZZ_FIRST", "0")) + int(os.environ.get("SWP_FUZZ_SEEDS", "24"))))
-def test_generic_event_scripts(seed):
+def test_generic_event_scripts(seed, with_groups):
     rng = random.Random(0x6E0E + seed)
+    grng = random.Random(0x9A0B + seed)
     o, e = orc.Oracle(), swhost.HostScheduler()
     both = (o, e)
     n_nodes = rng.choice([1, 5, 40, 130, 700])
@@ -61,6 +66,7 @@ def test_generic_event_scripts(seed):
             s.create_node(d)
     n_svc = rng.randrange(1, 10)
     specs = [service_spec(rng) for _ in range(n_svc)]
+    grouped = [with_groups and grng.random() < 0.5 for _ in range(n_svc)]
     for k in range(n_svc):
         for s in both:
             s.set_service("svc%02d" % k)
@@ -96,6 +102,8 @@ def test_generic_event_scripts(seed):
             k = rng.randrange(n_svc)
             for _ in range(rng.choice([1, 3, 10, 40, 120])):
                 t = {"ID": "t%06d" % tid, "ServiceID": "svc%02d" % k, "DesiredState": orc.RUNNING, "Status": {"State": orc.PENDING}}
+                if grouped[k]:
+                    t["SpecVersion"] = {"Index": 1}
                 t.update(specs[k])
                 docs[t["ID"]] = t
                 for s in both:
