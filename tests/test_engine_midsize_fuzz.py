@@ -26,12 +26,24 @@ def draw(seed):
     order = rng.choice(["rr", "rr", "major"])
     uncounted = rng.choice([0, 0, 0, 3, 17])
     shards = rng.choice([0, 0, 2, 5])
-    return name, T, N, services, order, rng.randrange(1 << 30), uncounted, shards
+    wseed = rng.randrange(1 << 30)
+    # engine knobs (drawn last: the shapes of the seeds stay what they were): the compact index forced on from the first round — with the
+    # next round's index built at the end of k_r6_commit_c —, other block sizes
+    knobs = {}
+    if rng.random() < 0.35:
+        knobs["SWP_R6_COMPACT"] = "1"
+        if rng.random() < 0.3:
+            knobs["SWP_R6_COMPACT_FUSED"] = "0"
+    if rng.random() < 0.3:
+        knobs["SWP_R6_BLOCK"] = str(rng.choice([1, 64, 192, 448, 1024]))
+    return name, T, N, services, order, wseed, uncounted, shards, knobs
 
 
 @pytest.mark.parametrize("seed", range(FIRST, FIRST + int(os.environ.get("SWP_FUZZ_SEEDS", "16"))))
 def test_random_midsize_batches(seed, monkeypatch):
-    name, T, N, services, order, wseed, uncounted, shards = draw(seed)
+    name, T, N, services, order, wseed, uncounted, shards, knobs = draw(seed)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     if shards:
         monkeypatch.setenv("SWP_SHARDSET", "%d:%d" % (shards, (N + shards - 1) // shards + 3))
     wl = synth.Workload(name, T=T, N=N, seed=wseed, services=services, order=order)
@@ -51,8 +63,10 @@ def draw_script(seed):
     per = rng.choice([1, 3, 8, 12])
     T0 = max(1, min(N * per, 30_000_000 // N))
     services = rng.choice([None, rng.randrange(1, 12), rng.randrange(12, 200)])
-    return dict(name=name, N=N, T0=T0, services=services, grouped=rng.random() < 0.4, rounds=rng.randrange(2, 6), wseed=rng.randrange(1 << 30),
-                shards=rng.choice([0, 0, 0, 3]), rseed=rng.randrange(1 << 30))
+    p = dict(name=name, N=N, T0=T0, services=services, grouped=rng.random() < 0.4, rounds=rng.randrange(2, 6), wseed=rng.randrange(1 << 30),
+             shards=rng.choice([0, 0, 0, 3]), rseed=rng.randrange(1 << 30))
+    p["knobs"] = {"SWP_R6_COMPACT": "1"} if rng.random() < 0.35 else {}   # (drawn last, as above)
+    return p
 
 
 def run_script(s, p):
@@ -125,6 +139,8 @@ def test_random_midsize_event_scripts(seed, monkeypatch):
     from swarmkit_amd import host as swhost
     p = draw_script(seed)
     want = run_script(orc.Oracle(), p)
+    for k, v in p["knobs"].items():
+        monkeypatch.setenv(k, v)
     if p["shards"]:
         monkeypatch.setenv("SWP_SHARDSET", "%d:%d" % (p["shards"], (p["N"] + p["shards"] - 1) // p["shards"] + 3))
     got = run_script(swhost.HostScheduler(), p)
